@@ -1,0 +1,303 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by IMPORTING THE REFERENCE.
+
+Run once in the build container (where /root/reference exists):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+The reference (chenzpstar/Multi-Modal-Image-Fusion, torch-CPU, fp32) is executed on
+closed-form inputs / parameters (oracle.fusion_oracle.closed_form_*), so the committed
+fixtures hold only the reference's OUTPUTS; tests rebuild the inputs from the same
+formulas.  Nothing here is imported at test time and the reference never travels to the
+GPU box.  Fixture map:
+
+  f1_loss_known_answer.json  core/loss.py:388-423 recipe (seed 0, rand(2,1,256,256) x3)
+  f2_loss_grads.npz          loss values + d/dimgf on closed-form images (incl. clamp / tie cases)
+  f3_conv.npz                ConvLayer fwd + (dx, dW, db) per (Cin, Cout, k)
+  f4_blocks.npz              DenseBlock / ConvBlock / RFN / NestDecoder / fusion fns fwd + bwd
+  f5_models.npz              PFNetv1, PFNetv2, DenseFuse, NestFuse, RFNNest forward + grad digests
+  f5_manifest.json           state_dict key/shape manifests
+  f6_traj.npz                3-step train trajectories (train.py:61-75 semantics)
+"""
+import json
+import os
+import sys
+
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("MMIF_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)       # reference's `core` package
+sys.path.insert(1, ROOT)      # oracle.* (closed-form helpers only)
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+import core.block as rblock      # noqa: E402  (reference)
+import core.fusion as rfusion    # noqa: E402
+import core.loss as rloss        # noqa: E402
+import core.model as rmodel      # noqa: E402
+from oracle.fusion_oracle import closed_form_image, closed_form_param, closed_form_signed  # noqa: E402
+
+assert os.path.realpath(rblock.__file__).startswith(os.path.realpath(REF)), rblock.__file__
+torch.set_num_threads(8)
+T = torch.from_numpy
+
+
+def load_closed_form(module, seed=0):
+    sd = module.state_dict()
+    new = {}
+    for i, (k, v) in enumerate(sd.items()):
+        new[k] = T(closed_form_param(i, k, tuple(v.shape), seed))
+    module.load_state_dict(new)
+    return module
+
+
+def digest(a):
+    """Compact pin of a tensor: sum, abs-sum, first 16 and 16 strided samples."""
+    f = np.asarray(a, dtype=np.float32).reshape(-1)
+    n = f.size
+    idx = (np.arange(16) * max(1, n // 16)) % n
+    return np.concatenate(([f.astype(np.float64).sum(), np.abs(f.astype(np.float64)).sum()],
+                           f[:16] if n >= 16 else np.pad(f, (0, 16 - n)), f[idx])).astype(np.float64)
+
+
+# ---------------------------------------------------------------- F1
+def make_f1():
+    torch.manual_seed(0)
+    x1 = torch.rand(2, 1, 256, 256)
+    x2 = torch.rand(2, 1, 256, 256)
+    y = torch.rand(2, 1, 256, 256)
+    out = {}
+    out["ssim"] = rloss.SSIMLoss("ssim", weight=1.0)(x1, x2, y).item()
+    out["pixel_avg"] = rloss.PixelLoss("l1", weight=0.01)(x1, x2, y).item()
+    out["grad_avg"] = rloss.GradLoss("l1", weight=0.1)(x1, x2, y).item()
+    out["tv"] = rloss.TVLoss("l1", weight=1.0)(y - x1).item()
+    out["pixel_max"] = rloss.PixelLoss("l1", weight=0.01)(x1, x2, y, mode="max").item()
+    out["grad_max"] = rloss.GradLoss("l1", weight=0.1)(x1, x2, y, mode="max").item()
+    out["total_max"] = out["ssim"] + out["pixel_max"] + out["grad_max"]
+    out["ssim_per_sample_x1_y"] = rloss.SSIM(11, 1.0, False)(x1, y)["ssim"].tolist()
+    out["window_1d"] = rloss._gaussian_kernel(11, 1.5).tolist()
+    out["window_2d_sum"] = float(rloss.create_window(11).double().sum())
+    # first 8 values of each random image so the test can confirm it regenerated the same inputs
+    out["x1_head"] = x1.reshape(-1)[:8].tolist()
+    out["y_head"] = y.reshape(-1)[:8].tolist()
+    json.dump(out, open(os.path.join(HERE, "f1_loss_known_answer.json"), "w"), indent=1)
+
+
+# ---------------------------------------------------------------- F2
+def loss_case(img1, img2, imgf):
+    res = {}
+    i1, i2 = T(img1), T(img2)
+    f = T(imgf).clone().requires_grad_(True)
+    l1 = rloss.SSIMLoss("ssim", weight=1.0)(i1, i2, f)
+    l2 = rloss.PixelLoss("l1", weight=0.01)(i1, i2, f, mode="max")
+    l3 = rloss.GradLoss("l1", weight=0.1)(i1, i2, f, mode="max")
+    for name, l in (("ssim", l1), ("pixel", l2), ("grad", l3)):
+        g, = torch.autograd.grad(l, f, retain_graph=True)
+        res["l_" + name] = np.float64(l.item())
+        res["g_" + name] = g.numpy()
+    g, = torch.autograd.grad(l1 + l2 + l3, f)
+    res["g_total"] = g.numpy()
+    res["l_pixel_avg"] = np.float64(rloss.PixelLoss("l1", weight=0.01)(i1, i2, f.detach(), mode="avg").item())
+    res["l_grad_avg"] = np.float64(rloss.GradLoss("l1", weight=0.1)(i1, i2, f.detach(), mode="avg").item())
+    return res
+
+
+def f2_inputs(case):
+    if case == "a":
+        s = (2, 1, 32, 32)
+        return closed_form_image(s, 0.1), closed_form_image(s, 1.3), closed_form_image(s, 2.2)
+    if case == "b":
+        s = (1, 1, 64, 48)
+        return closed_form_image(s, 0.7), closed_form_image(s, 0.2), closed_form_image(s, 1.9)
+    if case == "c":  # constant fused image: sigma_f^2 = 0 -> clamp branch of calc_ssim
+        s = (1, 1, 24, 24)
+        return closed_form_image(s, 0.4), closed_form_image(s, 1.1), np.full(s, 0.375, np.float32)
+    if case == "d":  # img1 == img2: ties in torch.max
+        s = (2, 1, 20, 28)
+        a = closed_form_image(s, 0.9)
+        return a, a.copy(), closed_form_image(s, 2.9)
+    raise KeyError(case)
+
+
+def make_f2():
+    out = {}
+    for case in "abcd":
+        for k, v in loss_case(*f2_inputs(case)).items():
+            out[f"{case}_{k}"] = v
+    np.savez_compressed(os.path.join(HERE, "f2_loss_grads.npz"), **out)
+
+
+# ---------------------------------------------------------------- F3
+F3_CASES = [  # (name, Cin, Cout, k, relu, N, H, W)
+    ("c1_16", 1, 16, 3, True, 2, 12, 20),
+    ("c16_16", 16, 16, 3, True, 2, 12, 20),
+    ("c48_16", 48, 16, 3, True, 2, 12, 20),
+    ("c128_64", 128, 64, 3, True, 2, 12, 20),
+    ("c16_1_lin", 16, 1, 3, False, 2, 12, 20),
+    ("c8_64_k1", 8, 64, 1, True, 2, 12, 20),
+    ("c88_64_k1", 88, 64, 1, True, 2, 12, 20),
+    ("c16_16_thin_h", 16, 16, 3, True, 1, 2, 9),     # 2-row image: every row reflects
+    ("c16_16_thin_w", 16, 16, 3, True, 1, 9, 2),
+    ("c32_16_odd", 32, 16, 3, True, 1, 37, 53),      # ragged vs. any power-of-two tile
+]
+
+
+def make_f3():
+    out = {}
+    for name, cin, cout, k, relu, N, H, W in F3_CASES:
+        layer = rblock.ConvLayer(cin, cout, ksize=k, act=nn.ReLU if relu else None)
+        load_closed_form(layer, seed=3)
+        x = T(closed_form_signed((N, cin, H, W), 0.5, 1.0)).requires_grad_(True)
+        gy = T(closed_form_signed((N, cout, H, W), 1.5, 1.0))
+        y = layer(x)
+        y.backward(gy)
+        out[name + "_y"] = y.detach().numpy()
+        out[name + "_dx"] = x.grad.numpy()
+        out[name + "_dw"] = layer.layers[0].weight.grad.numpy()
+        out[name + "_db"] = layer.layers[0].bias.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, "f3_conv.npz"), **out)
+
+
+# ---------------------------------------------------------------- F4
+def run_module(mod, inputs, gout_phase):
+    xs = [T(a).requires_grad_(True) for a in inputs]
+    y = mod(*xs)
+    gy = T(closed_form_signed(tuple(y.shape), gout_phase, 1.0))
+    y.backward(gy)
+    res = {"y": y.detach().numpy()}
+    for i, x in enumerate(xs):
+        res[f"dx{i}"] = x.grad.numpy()
+    for k, p in mod.named_parameters():
+        res["dp_" + k] = digest(p.grad.numpy())
+    return res
+
+
+def make_f4():
+    out = {}
+
+    def put(prefix, res):
+        for k, v in res.items():
+            out[f"{prefix}__{k}"] = v
+
+    m = load_closed_form(rblock.DenseBlock(16, 16), 4)
+    put("dense", run_module(m, [closed_form_signed((2, 16, 10, 14), 0.3)], 0.8))
+    m = load_closed_form(rblock.ConvBlock(16, 64), 5)
+    put("convblock", run_module(m, [closed_form_signed((1, 16, 9, 11), 0.4)], 0.9))
+    m = load_closed_form(rblock.RFN(16), 6)
+    put("rfn", run_module(m, [closed_form_signed((1, 16, 8, 10), 0.6), closed_form_signed((1, 16, 8, 10), 1.6)], 1.0))
+
+    # NestDecoder with odd sizes so Upsample._pad (core/block.py:981-991) is exercised
+    ch = [8, 16, 24, 32]
+    dec = load_closed_form(rblock.NestDecoder(rblock.ConvBlock, ch, "nearest"), 7)
+    sizes = [(37, 53), (18, 26), (9, 13), (4, 6)]
+    feats = [T(closed_form_signed((1, c, h, w), 0.2 * i + 0.1)).requires_grad_(True) for i, (c, (h, w)) in enumerate(zip(ch, sizes))]
+    y = dec(feats)
+    y.backward(T(closed_form_signed(tuple(y.shape), 1.1)))
+    out["nestdec__y"] = y.detach().numpy()
+    for i, f in enumerate(feats):
+        out[f"nestdec__dx{i}"] = f.grad.numpy()
+    for k, p in dec.named_parameters():
+        out["nestdec__dp_" + k] = digest(p.grad.numpy())
+
+    # maxpool + nearest upsample on their own
+    x = T(closed_form_signed((1, 8, 10, 14), 0.77)).requires_grad_(True)
+    y = nn.MaxPool2d(2, 2)(x)
+    y.backward(T(closed_form_signed(tuple(y.shape), 0.31)))
+    out["maxpool__y"], out["maxpool__dx"] = y.detach().numpy(), x.grad.numpy()
+    x = T(closed_form_signed((1, 8, 4, 6), 0.57)).requires_grad_(True)
+    y = rblock.Upsample("nearest", 2)(x, (1, 8, 9, 13))
+    y.backward(T(closed_form_signed(tuple(y.shape), 0.41)))
+    out["upsample__y"], out["upsample__dx"] = y.detach().numpy(), x.grad.numpy()
+
+    # fusion functions
+    s = (2, 16, 6, 10)
+    a, b = closed_form_signed(s, 0.15), closed_form_signed(s, 1.25)
+    gy = closed_form_signed(s, 2.35)
+    for mode in ("sum", "mean", "max"):
+        ta, tb = T(a).requires_grad_(True), T(b).requires_grad_(True)
+        y = rfusion.element_fusion(ta, tb, mode)
+        y.backward(T(gy))
+        out[f"elem_{mode}__y"], out[f"elem_{mode}__da"], out[f"elem_{mode}__db"] = y.detach().numpy(), ta.grad.numpy(), tb.grad.numpy()
+    for mode in ("sa", "ca", "sca"):
+        ta, tb = T(a).requires_grad_(True), T(b).requires_grad_(True)
+        y = rfusion.attention_fusion(ta, tb, mode)
+        y.backward(T(gy))
+        out[f"attn_{mode}__y"], out[f"attn_{mode}__da"], out[f"attn_{mode}__db"] = y.detach().numpy(), ta.grad.numpy(), tb.grad.numpy()
+    # all-zero features: the clamp(min=1e-7) branch of weighted_fusion (core/fusion.py:33)
+    z = np.zeros(s, np.float32)
+    ta, tb = T(z).requires_grad_(True), T(z.copy()).requires_grad_(True)
+    y = rfusion.attention_fusion(ta, tb, "sca")
+    y.backward(T(gy))
+    out["attn_zero__y"], out["attn_zero__da"], out["attn_zero__db"] = y.detach().numpy(), ta.grad.numpy(), tb.grad.numpy()
+    # post-ReLU style features (non-negative, many exact zeros) as NestFuse produces
+    ar, br = np.maximum(a, 0), np.maximum(b, 0)
+    ta, tb = T(ar).requires_grad_(True), T(br).requires_grad_(True)
+    y = rfusion.attention_fusion(ta, tb, "sca")
+    y.backward(T(gy))
+    out["attn_relu__y"], out["attn_relu__da"], out["attn_relu__db"] = y.detach().numpy(), ta.grad.numpy(), tb.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, "f4_blocks.npz"), **out)
+
+
+# ---------------------------------------------------------------- F5
+F5_CASES = [("PFNetv1", (2, 1, 32, 32)), ("PFNetv2", (2, 1, 32, 32)), ("DenseFuse", (2, 1, 32, 32)),
+            ("NestFuse", (1, 1, 32, 32)), ("RFNNest", (1, 1, 32, 32)), ("PFNetv1", (1, 1, 37, 53))]
+
+
+def make_f5():
+    out, manifest = {}, {}
+    for name, shape in F5_CASES:
+        tag = f"{name}_{shape[0]}x{shape[2]}x{shape[3]}"
+        model = load_closed_form(getattr(rmodel, name)(), seed=1)
+        manifest[name] = [[k, list(v.shape)] for k, v in model.state_dict().items()]
+        i1, i2 = T(closed_form_image(shape, 0.3)), T(closed_form_image(shape, 1.7))
+        y = model(i1, i2)
+        gy = T(closed_form_signed(shape, 0.9, 1.0))
+        y.backward(gy)
+        out[tag + "__y"] = y.detach().numpy()
+        for k, p in model.named_parameters():
+            out[f"{tag}__dp_{k}"] = digest(p.grad.numpy())
+        if name == "DenseFuse":  # auto-encoder mode, core/model.py:43-51
+            out[tag + "__y_ae"] = model(i1).detach().numpy()
+    np.savez_compressed(os.path.join(HERE, "f5_models.npz"), **out)
+    json.dump(manifest, open(os.path.join(HERE, "f5_manifest.json"), "w"), indent=0)
+
+
+# ---------------------------------------------------------------- F6
+def make_f6():
+    out = {}
+    for name in ("PFNetv1", "DenseFuse"):
+        model = load_closed_form(getattr(rmodel, name)(), seed=2)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4, betas=(0.9, 0.999))
+        l_ssim = rloss.SSIMLoss("ssim", weight=1.0)
+        l_pix = rloss.PixelLoss("l1", weight=0.01)
+        l_grad = rloss.GradLoss("l1", weight=0.1)
+        shape = (4, 1, 64, 64)
+        rows = []
+        for step in range(3):
+            i1 = T(closed_form_image(shape, 0.21 + step))
+            i2 = T(closed_form_image(shape, 1.43 + step))
+            opt.zero_grad(set_to_none=True)
+            f = model(i1, i2)
+            a, b, c = l_ssim(i1, i2, f), l_pix(i1, i2, f, mode="max"), l_grad(i1, i2, f, mode="max")
+            tot = a + b + c
+            tot.backward()
+            norm = nn.utils.clip_grad_norm_(model.parameters(), max_norm=5)
+            opt.step()
+            rows.append([a.item(), b.item(), c.item(), tot.item(), float(norm)])
+            if step == 0:
+                out[name + "__imgf0"] = f.detach().numpy()
+        out[name + "__rows"] = np.array(rows, dtype=np.float64)
+        for k, p in model.state_dict().items():
+            out[f"{name}__w_{k}"] = digest(p.numpy())
+    np.savez_compressed(os.path.join(HERE, "f6_traj.npz"), **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6"]
+    for w in which:
+        globals()["make_" + w]()
+        print("wrote", w)

@@ -1,0 +1,281 @@
+"""Pin the CPU oracle (oracle/fusion_oracle.py) to the reference's own outputs.
+
+The fixtures under tests/golden/ were produced by importing the reference
+(tests/golden/make_golden.py); inputs/parameters are closed-form and rebuilt here.
+Tolerances: fp32 oracle vs fp32 reference (different summation order) -> 2e-5 relative to the
+tensor's max-abs; the fp64 oracle run tightens logic errors vs rounding.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import fusion_oracle as O
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def close(a, b, rtol=2e-5, what=""):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = max(np.abs(b).max(), 1e-12)
+    err = np.abs(a - b).max() / scale
+    assert err <= rtol, f"{what}: max err {err:.3e} (scale {scale:.3e})"
+
+
+def digest(a):
+    f = np.asarray(a, dtype=np.float32).reshape(-1)
+    n = f.size
+    idx = (np.arange(16) * max(1, n // 16)) % n
+    return np.concatenate(([f.astype(np.float64).sum(), np.abs(f.astype(np.float64)).sum()],
+                           f[:16] if n >= 16 else np.pad(f, (0, 16 - n)), f[idx])).astype(np.float64)
+
+
+def close_digest(arr, dg, rtol=5e-5, what=""):
+    mine = digest(arr)
+    scale = max(np.abs(np.asarray(arr)).max(), 1e-12)
+    n = np.asarray(arr).size
+    # sums accumulate rounding over n elements
+    assert abs(mine[0] - dg[0]) <= rtol * scale * max(1.0, np.sqrt(n)) * 4, (what, "sum", mine[0], dg[0])
+    assert abs(mine[1] - dg[1]) <= rtol * max(dg[1], scale), (what, "abs-sum", mine[1], dg[1])
+    assert np.abs(mine[2:] - dg[2:]).max() <= rtol * scale, (what, "samples", np.abs(mine[2:] - dg[2:]).max(), scale)
+
+
+# ------------------------------------------------------------------ F1
+def test_f1_known_answer_losses():
+    import torch
+    ref = json.load(open(os.path.join(G, "f1_loss_known_answer.json")))
+    torch.manual_seed(0)
+    x1 = torch.rand(2, 1, 256, 256).numpy()
+    x2 = torch.rand(2, 1, 256, 256).numpy()
+    y = torch.rand(2, 1, 256, 256).numpy()
+    np.testing.assert_allclose(x1.reshape(-1)[:8], ref["x1_head"], rtol=0, atol=0)
+    np.testing.assert_allclose(y.reshape(-1)[:8], ref["y_head"], rtol=0, atol=0)
+    np.testing.assert_allclose(O.gaussian_window_1d(), ref["window_1d"], rtol=0, atol=0)
+    assert abs(float(O.create_window().astype(np.float64).sum()) - ref["window_2d_sum"]) < 1e-7
+    l, _ = O.ssim_loss(x1, x2, y, 1.0, need_grad=False)
+    assert abs(l - ref["ssim"]) < 2e-6
+    # the values printed by core/loss.py:419-423 (4 decimals) and SURVEY section 4
+    assert abs(l - 0.9944541454) < 2e-6
+    l, _ = O.pixel_loss(x1, x2, y, 0.01, "avg", False)
+    assert abs(l - ref["pixel_avg"]) < 1e-8
+    l, _ = O.grad_loss(x1, x2, y, 0.1, "avg", False)
+    assert abs(l - ref["grad_avg"]) < 5e-7
+    lp, _ = O.pixel_loss(x1, x2, y, 0.01, "max", False)
+    assert abs(lp - ref["pixel_max"]) < 1e-8
+    lg, _ = O.grad_loss(x1, x2, y, 0.1, "max", False)
+    assert abs(lg - ref["grad_max"]) < 5e-7
+    (a, b, c, tot), _ = O.fusion_losses(x1, x2, y, need_grad=False)
+    assert abs(tot - ref["total_max"]) < 3e-6
+    s, _ = O.ssim_terms(x1, y, O.create_window())
+    np.testing.assert_allclose(s, ref["ssim_per_sample_x1_y"], atol=2e-7)
+
+
+# ------------------------------------------------------------------ F2
+def f2_inputs(case):
+    if case == "a":
+        s = (2, 1, 32, 32)
+        return O.closed_form_image(s, 0.1), O.closed_form_image(s, 1.3), O.closed_form_image(s, 2.2)
+    if case == "b":
+        s = (1, 1, 64, 48)
+        return O.closed_form_image(s, 0.7), O.closed_form_image(s, 0.2), O.closed_form_image(s, 1.9)
+    if case == "c":
+        s = (1, 1, 24, 24)
+        return O.closed_form_image(s, 0.4), O.closed_form_image(s, 1.1), np.full(s, 0.375, np.float32)
+    if case == "d":
+        s = (2, 1, 20, 28)
+        a = O.closed_form_image(s, 0.9)
+        return a, a.copy(), O.closed_form_image(s, 2.9)
+    raise KeyError(case)
+
+
+@pytest.mark.parametrize("case", list("abcd"))
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_f2_loss_values_and_grads(case, dt):
+    ref = np.load(os.path.join(G, "f2_loss_grads.npz"))
+    i1, i2, f = (a.astype(dt) for a in f2_inputs(case))
+    l1, g1 = O.ssim_loss(i1, i2, f, 1.0)
+    l2, g2 = O.pixel_loss(i1, i2, f, 0.01, "max")
+    l3, g3 = O.grad_loss(i1, i2, f, 0.1, "max")
+    assert abs(l1 - ref[f"{case}_l_ssim"]) < 3e-6
+    assert abs(l2 - ref[f"{case}_l_pixel"]) < 1e-7
+    assert abs(l3 - ref[f"{case}_l_grad"]) < 1e-6
+    # case c: constant f makes the reference's own fp32 SSIM gradient ill-conditioned (sigma_f^2
+    # is pure rounding noise around the clamp); compare it loosely there.
+    rt = 5e-3 if case == "c" else (2e-4 if dt == np.float32 else 2e-4)
+    close(g1, ref[f"{case}_g_ssim"], rt, "g_ssim")
+    close(g2, ref[f"{case}_g_pixel"], 1e-6, "g_pixel")
+    close(g3, ref[f"{case}_g_grad"], 1e-6, "g_grad")
+    close(g1 + g2 + g3, ref[f"{case}_g_total"], rt, "g_total")
+    la, _ = O.pixel_loss(i1, i2, f, 0.01, "avg", False)
+    lb, _ = O.grad_loss(i1, i2, f, 0.1, "avg", False)
+    assert abs(la - ref[f"{case}_l_pixel_avg"]) < 1e-7
+    assert abs(lb - ref[f"{case}_l_grad_avg"]) < 1e-6
+
+
+# ------------------------------------------------------------------ F3
+F3_CASES = [
+    ("c1_16", 1, 16, 3, True, 2, 12, 20), ("c16_16", 16, 16, 3, True, 2, 12, 20),
+    ("c48_16", 48, 16, 3, True, 2, 12, 20), ("c128_64", 128, 64, 3, True, 2, 12, 20),
+    ("c16_1_lin", 16, 1, 3, False, 2, 12, 20), ("c8_64_k1", 8, 64, 1, True, 2, 12, 20),
+    ("c88_64_k1", 88, 64, 1, True, 2, 12, 20), ("c16_16_thin_h", 16, 16, 3, True, 1, 2, 9),
+    ("c16_16_thin_w", 16, 16, 3, True, 1, 9, 2), ("c32_16_odd", 32, 16, 3, True, 1, 37, 53),
+]
+
+
+def f3_tensors(case):
+    name, cin, cout, k, relu, N, H, W = case
+    w = O.closed_form_param(0, "layers.0.weight", (cout, cin, k, k), 3)
+    b = O.closed_form_param(1, "layers.0.bias", (cout,), 3)
+    x = O.closed_form_signed((N, cin, H, W), 0.5, 1.0)
+    gy = O.closed_form_signed((N, cout, H, W), 1.5, 1.0)
+    return x, w, b, gy
+
+
+@pytest.mark.parametrize("case", F3_CASES, ids=[c[0] for c in F3_CASES])
+def test_f3_conv_layer(case):
+    ref = np.load(os.path.join(G, "f3_conv.npz"))
+    name, relu = case[0], case[4]
+    x, w, b, gy = f3_tensors(case)
+    y = O.conv2d_reflect_fwd(x, w, b, relu)
+    close(y, ref[name + "_y"], 2e-5, "y")
+    gx, gw, gb = O.conv2d_reflect_bwd(x, w, y, gy, relu)
+    close(gx, ref[name + "_dx"], 2e-5, "dx")
+    close(gw, ref[name + "_dw"], 2e-5, "dw")
+    close(gb, ref[name + "_db"], 2e-5, "db")
+
+
+# ------------------------------------------------------------------ F4
+def _params(mod, seed):
+    return O.OrderedDict((k, O.closed_form_param(i, k, s, seed)) for i, (k, s) in enumerate(mod.param_shapes().items()))
+
+
+def _check_dp(ref, prefix, Gd, strip=""):
+    keys = [k for k in ref.files if k.startswith(prefix + "__dp_")]
+    assert keys
+    for k in keys:
+        name = k[len(prefix) + 5:]
+        close_digest(Gd[strip + name], ref[k], 5e-5, name)
+
+
+def test_f4_dense_block():
+    ref = np.load(os.path.join(G, "f4_blocks.npz"))
+    m = O.DenseBlock("", 16, 16)
+    # reference keys are 'layers.i.layers.0.weight'; oracle prefix '' gives '.layers.i...'
+    P = O.OrderedDict((k, O.closed_form_param(i, k, s, 4)) for i, (k, s) in enumerate(m.param_shapes().items()))
+    x = O.closed_form_signed((2, 16, 10, 14), 0.3)
+    y = m.forward(P, x)
+    close(y, ref["dense__y"], 2e-5, "y")
+    Gd = {}
+    gx = m.backward(P, Gd, O.closed_form_signed(y.shape, 0.8))
+    close(gx, ref["dense__dx0"], 2e-5, "dx")
+    _check_dp(ref, "dense", Gd, strip=".")
+
+
+def test_f4_convblock_and_rfn():
+    ref = np.load(os.path.join(G, "f4_blocks.npz"))
+    m = O.ConvBlock("", 16, 64)
+    P = _params(m, 5)
+    x = O.closed_form_signed((1, 16, 9, 11), 0.4)
+    y = m.forward(P, x)
+    close(y, ref["convblock__y"], 2e-5)
+    Gd = {}
+    close(m.backward(P, Gd, O.closed_form_signed(y.shape, 0.9)), ref["convblock__dx0"], 2e-5)
+    _check_dp(ref, "convblock", Gd, strip=".")
+
+    m = O.RFN("", 16)
+    P = _params(m, 6)
+    x1, x2 = O.closed_form_signed((1, 16, 8, 10), 0.6), O.closed_form_signed((1, 16, 8, 10), 1.6)
+    y = m.forward(P, x1, x2)
+    close(y, ref["rfn__y"], 2e-5)
+    Gd = {}
+    g1, g2 = m.backward(P, Gd, O.closed_form_signed(y.shape, 1.0))
+    close(g1, ref["rfn__dx0"], 2e-5)
+    close(g2, ref["rfn__dx1"], 2e-5)
+    _check_dp(ref, "rfn", Gd, strip=".")
+
+
+def test_f4_pool_upsample():
+    ref = np.load(os.path.join(G, "f4_blocks.npz"))
+    x = O.closed_form_signed((1, 8, 10, 14), 0.77)
+    y, idx = O.maxpool2x2_fwd(x)
+    close(y, ref["maxpool__y"], 0)
+    close(O.maxpool2x2_bwd(O.closed_form_signed(y.shape, 0.31), idx, x.shape), ref["maxpool__dx"], 0)
+    x = O.closed_form_signed((1, 8, 4, 6), 0.57)
+    y = O.upsample_nearest2x_fwd(x, (9, 13))
+    close(y, ref["upsample__y"], 0)
+    close(O.upsample_nearest2x_bwd(O.closed_form_signed(y.shape, 0.41), x.shape), ref["upsample__dx"], 1e-6)
+
+
+def test_f4_fusion_functions():
+    ref = np.load(os.path.join(G, "f4_blocks.npz"))
+    s = (2, 16, 6, 10)
+    a, b, gy = O.closed_form_signed(s, 0.15), O.closed_form_signed(s, 1.25), O.closed_form_signed(s, 2.35)
+    for mode in ("sum", "mean", "max"):
+        close(O.element_fusion(a, b, mode), ref[f"elem_{mode}__y"], 1e-6)
+        da, db = O.element_fusion_bwd(a, b, gy, mode)
+        close(da, ref[f"elem_{mode}__da"], 1e-6)
+        close(db, ref[f"elem_{mode}__db"], 1e-6)
+    for mode in ("sa", "ca", "sca"):
+        close(O.attention_fusion(a, b, mode), ref[f"attn_{mode}__y"], 2e-5, mode)
+        da, db = O.attention_fusion_bwd(a, b, gy, mode)
+        close(da, ref[f"attn_{mode}__da"], 5e-5, mode)
+        close(db, ref[f"attn_{mode}__db"], 5e-5, mode)
+    z = np.zeros(s, np.float32)
+    close(O.attention_fusion(z, z, "sca"), ref["attn_zero__y"], 0)
+    da, db = O.attention_fusion_bwd(z, z, gy, "sca")
+    close(da, ref["attn_zero__da"], 1e-6)
+    close(db, ref["attn_zero__db"], 1e-6)
+    ar, br = np.maximum(a, 0), np.maximum(b, 0)
+    close(O.attention_fusion(ar, br, "sca"), ref["attn_relu__y"], 2e-5)
+    da, db = O.attention_fusion_bwd(ar, br, gy, "sca")
+    close(da, ref["attn_relu__da"], 5e-5)
+    close(db, ref["attn_relu__db"], 5e-5)
+    with pytest.raises(ValueError):
+        O.element_fusion(a, b, "nope")
+    with pytest.raises(ValueError):
+        O.attention_fusion(a, b, "nope")
+
+
+# ------------------------------------------------------------------ F5
+F5_CASES = [("PFNetv1", (2, 1, 32, 32)), ("PFNetv2", (2, 1, 32, 32)), ("DenseFuse", (2, 1, 32, 32)),
+            ("NestFuse", (1, 1, 32, 32)), ("RFNNest", (1, 1, 32, 32)), ("PFNetv1", (1, 1, 37, 53))]
+
+
+@pytest.mark.parametrize("name,shape", F5_CASES, ids=[f"{n}-{s[2]}x{s[3]}" for n, s in F5_CASES])
+def test_f5_models(name, shape):
+    ref = np.load(os.path.join(G, "f5_models.npz"))
+    man = json.load(open(os.path.join(G, "f5_manifest.json")))
+    tag = f"{name}_{shape[0]}x{shape[2]}x{shape[3]}"
+    m = O.MODELS[name]()
+    assert [[k, list(s)] for k, s in m.param_shapes().items()] == man[name]
+    P = m.init_params(seed=1)
+    i1, i2 = O.closed_form_image(shape, 0.3), O.closed_form_image(shape, 1.7)
+    y = m.forward(P, i1, i2)
+    close(y, ref[tag + "__y"], 5e-5, "y")
+    Gd = m.backward(P, O.closed_form_signed(shape, 0.9, 1.0))
+    for k in P:
+        close_digest(Gd[k], ref[f"{tag}__dp_{k}"], 1e-4, k)
+    if name == "DenseFuse":
+        close(m.forward(P, i1), ref[tag + "__y_ae"], 5e-5, "auto-encoder")
+
+
+# ------------------------------------------------------------------ F6
+@pytest.mark.parametrize("name", ["PFNetv1", "DenseFuse"])
+def test_f6_train_trajectory(name):
+    ref = np.load(os.path.join(G, "f6_traj.npz"))
+    m = O.MODELS[name]()
+    P = m.init_params(seed=2)
+    st = O.AdamState(P)
+    shape = (4, 1, 64, 64)
+    rows = ref[name + "__rows"]
+    for step in range(3):
+        i1, i2 = O.closed_form_image(shape, 0.21 + step), O.closed_form_image(shape, 1.43 + step)
+        r = O.train_step(m, P, st, i1, i2)
+        if step == 0:
+            close(r["imgf"], ref[name + "__imgf0"], 5e-5, "imgf")
+        got = list(r["losses"]) + [r["grad_norm"]]
+        np.testing.assert_allclose(got, rows[step], rtol=2e-4, atol=2e-6, err_msg=f"step {step}")
+    for k in P:
+        close_digest(P[k], ref[f"{name}__w_{k}"], 2e-5, k)
