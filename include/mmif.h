@@ -1,0 +1,161 @@
+/*
+ * mmif.h -- C ABI of the MI355X (gfx950) image-fusion hot-path library (libmmif_hip.so).
+ *
+ * The reference (chenzpstar/Multi-Modal-Image-Fusion) has no FFI of its own: its hot path is
+ * Python calling torch ops.  This header is the boundary a maintainer would bind (ctypes stub in
+ * INTEGRATION.md) to replace those torch calls.  Every entry point below cites the reference
+ * call site it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers owned by the caller; nothing here allocates or frees;
+ *   - every function enqueues work on `stream` (a hipStream_t passed as void*) and returns
+ *     immediately: 0 on success, a negative MMIF_E* code on error (message: mmif_last_error());
+ *   - no function throws, synchronises the device, or touches the host copy of any tensor, so
+ *     all of them are legal inside hipStreamBeginCapture/EndCapture (hipGraph);
+ *   - reductions are two-stage and deterministic (no floating-point atomics).
+ *
+ * Feature-map layout ("blocked NHWC", mmif_tensor): [n][cb_total][hs][ws][8] where one granule
+ * = 8 consecutive channels of one pixel (16 B in bf16, 32 B in fp32), hs = h + 2*halo,
+ * ws = w + 2*halo.  A view selects channel blocks [cb_off, cb_off+cb): torch.cat(dim=1)
+ * (core/fusion.py:38-39) becomes "producers write adjacent channel blocks of one allocation".
+ * Activations use halo = 0 (reflect padding is applied by index arithmetic while loading).
+ * Gradients w.r.t. activations use halo = 1 ("padded-domain" gradients): a dgrad kernel writes
+ * the gradient of the reflect-PADDED input; whoever reads it folds the halo back onto the
+ * interior while loading (the adjoint of reflect padding), see DESIGN.md.
+ * Single-channel images ([B,1,H,W] in the reference) are plain contiguous fp32 [n][h][w].
+ */
+#ifndef MMIF_H
+#define MMIF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMIF_F32 0
+#define MMIF_BF16 1
+
+#define MMIF_IMPL_AUTO 0 /* bf16 -> MFMA kernels, fp32 -> VALU kernels */
+#define MMIF_IMPL_VALU 1 /* LDS-tiled fp32-accumulate VALU kernels (any dtype) */
+#define MMIF_IMPL_MFMA 2 /* v_mfma_f32_16x16x32_bf16 kernels (bf16 storage only) */
+
+#define MMIF_OK 0
+#define MMIF_EINVAL (-1)   /* bad argument / unsupported shape */
+#define MMIF_ELAUNCH (-2)  /* HIP launch error */
+#define MMIF_EWORKSPACE (-3) /* workspace too small */
+
+typedef struct mmif_tensor {
+    void* data;       /* base of the allocation (NOT offset to the view) */
+    int32_t dtype;    /* MMIF_F32 | MMIF_BF16 */
+    int32_t n, h, w;  /* logical extent, halo excluded */
+    int32_t halo;     /* 0 (activations) or 1 (padded-domain gradients) */
+    int32_t cb_total; /* channel blocks (of 8 channels) in the allocation */
+    int32_t cb_off;   /* first channel block of the view */
+    int32_t cb;       /* channel blocks in the view */
+} mmif_tensor;
+
+const char* mmif_version(void);
+const char* mmif_last_error(void);
+
+/* ---- layout helpers (boundary between the reference's NCHW fp32 tensors and the engine) ---- */
+/* NCHW fp32 [n][c][h][w] -> view (channels >= c inside the view are zero-filled). */
+int mmif_nchw_to_blocked(const float* src, int32_t c, const mmif_tensor* dst, void* stream);
+/* view -> NCHW fp32 [n][c][h][w]; for halo=1 views the interior is exported with the halo folded
+ * (i.e. the true gradient w.r.t. the unpadded tensor). */
+int mmif_blocked_to_nchw(const mmif_tensor* src, float* dst, int32_t c, void* stream);
+/* fill a view (all of hs x ws) with zeros */
+int mmif_zero(const mmif_tensor* t, void* stream);
+
+/* Pack fp32 master weights [cout][cin][k][k] (nn.Conv2d layout, core/block.py:56-66) into the
+ * MFMA operand images: fwd  [k*k][cin/8 ][cout16][8] and dgrad [k*k][cout16/8][cin16][8]
+ * (flipped taps, transposed), bf16, cout16/cin16 = rounded up to 16, zero padded. */
+size_t mmif_packed_weight_bytes(int32_t cout, int32_t cin, int32_t ksize);
+int mmif_pack_weights(const float* w, int32_t cout, int32_t cin, int32_t ksize, void* packed_fwd,
+                      void* packed_dgrad, void* stream);
+
+/* ---- ConvLayer: reflect-pad(k/2) conv + bias + ReLU, stride 1, k in {1,3}
+ *      replaces core/block.py:98-99 (nn.Conv2d(padding_mode='reflect') + nn.ReLU(inplace)) ---- */
+/* y = act(bias + corr(reflect_pad(x), w)).  w: fp32 master weights; w_packed: mmif_pack_weights'
+ * fwd image (may be NULL for MMIF_IMPL_VALU). */
+int mmif_conv2d_reflect_fwd(const mmif_tensor* x, const float* w, const void* w_packed, const float* bias,
+                            const mmif_tensor* y, int32_t cin, int32_t cout, int32_t ksize, int32_t relu,
+                            int32_t impl, void* stream);
+/* gx(+)= full-correlation(fold(gy), w^T) on the padded domain [h+2p][w+2p].
+ * gy: gradient w.r.t. the conv's (post-activation) output, halo 0 or 1, ALREADY masked by the
+ *     layer's own ReLU.  gx: halo = 1 view.
+ * mask_bits / accum_bits: bit i refers to channel block i of the gx view:
+ *   accum: gx = gx_old + new (another consumer of x already wrote its contribution);
+ *   mask : multiply by [x > 0] (x = this conv's forward input = previous layer's ReLU output),
+ *          applied after accumulation; x may be NULL when mask_bits == 0.
+ * replaces autograd's convolution_backward(input) + reflection_pad2d_backward + threshold_backward. */
+int mmif_conv2d_reflect_dgrad(const mmif_tensor* gy, const float* w, const void* w_packed_t, const mmif_tensor* x,
+                              const mmif_tensor* gx, int32_t cin, int32_t cout, int32_t ksize, uint64_t mask_bits,
+                              uint64_t accum_bits, int32_t impl, void* stream);
+/* dw[cout][cin][k][k] (=|+=) sum_p fold(gy)[p] * reflect_pad(x)[p+tap]; db[cout] (=|+=) sum_p fold(gy)[p].
+ * replaces convolution_backward(weight, bias). */
+size_t mmif_conv2d_wgrad_workspace(int32_t cin, int32_t cout, int32_t ksize);
+int mmif_conv2d_reflect_wgrad(const mmif_tensor* x, const mmif_tensor* gy, float* dw, float* db, int32_t cin,
+                              int32_t cout, int32_t ksize, int32_t accumulate, void* workspace,
+                              size_t workspace_bytes, int32_t impl, void* stream);
+
+/* ---- image-side layers: Cin == 1 (first encoder conv, core/model.py:73,77,118,169,326) and
+ *      Cout == 1 (last decoder conv, core/model.py:86,131,179,344).  Images are fp32 [n][h][w]. */
+int mmif_conv2d_image_in_fwd(const float* img, const float* w, const float* bias, const mmif_tensor* y,
+                             int32_t cout, int32_t ksize, int32_t relu, void* stream);
+int mmif_conv2d_image_in_wgrad(const float* img, const mmif_tensor* gy, float* dw, float* db, int32_t cout,
+                               int32_t ksize, int32_t accumulate, void* workspace, size_t workspace_bytes,
+                               void* stream);
+int mmif_conv2d_image_out_fwd(const mmif_tensor* x, const float* w, const float* bias, float* img, int32_t cin,
+                              int32_t ksize, int32_t relu, void* stream);
+/* gimg: dL/d(output image) [n][h][w]; y_img: the layer's output when it has a ReLU (else NULL). */
+int mmif_conv2d_image_out_dgrad(const float* gimg, const float* y_img, const float* w, const mmif_tensor* x,
+                                const mmif_tensor* gx, int32_t cin, int32_t ksize, uint64_t mask_bits,
+                                uint64_t accum_bits, void* stream);
+int mmif_conv2d_image_out_wgrad(const mmif_tensor* x, const float* gimg, const float* y_img, float* dw, float* db,
+                                int32_t cin, int32_t ksize, int32_t accumulate, void* workspace,
+                                size_t workspace_bytes, void* stream);
+size_t mmif_conv2d_image_wgrad_workspace(int32_t c, int32_t ksize);
+
+/* ---- fusion functions (core/fusion.py) ---- */
+#define MMIF_FUSE_SUM 0
+#define MMIF_FUSE_MEAN 1
+#define MMIF_FUSE_MAX 2
+/* element_fusion core/fusion.py:21-29; a, b, out: halo-0 views of equal shape */
+int mmif_fuse_elem_fwd(const mmif_tensor* a, const mmif_tensor* b, const mmif_tensor* out, int32_t mode,
+                       void* stream);
+/* g: halo 0 or 1 (folded on load); ga/gb: halo-0 views.  mask_a/mask_b: multiply by [a>0]/[b>0]
+ * (when a, b are ReLU outputs whose only consumer is this fusion). */
+int mmif_fuse_elem_bwd(const mmif_tensor* a, const mmif_tensor* b, const mmif_tensor* g, const mmif_tensor* ga,
+                       const mmif_tensor* gb, int32_t mode, int32_t relu_mask, void* stream);
+
+/* ---- losses (core/loss.py); images fp32 [n][h][w] ---- */
+size_t mmif_loss_workspace(int32_t n, int32_t h, int32_t w);
+/* SSIMLoss(mode='ssim') core/loss.py:252-257,284 = weight*(1 - (mean SSIM(img1,f)+mean SSIM(img2,f))/2),
+ * 11x11 Gaussian window sigma 1.5, valid correlation, data_range given.
+ * loss_out: device float[1]; grad_out (may be NULL): dloss/df [n][h][w]. */
+int mmif_ssim_loss(const float* img1, const float* img2, const float* imgf, int32_t n, int32_t h, int32_t w,
+                   float weight, float data_range, float* loss_out, float* grad_out, void* workspace,
+                   size_t workspace_bytes, void* stream);
+/* PixelLoss core/loss.py:287-304 (NormLoss 'l1'|'l2' :361-385); mode 0 = 'avg', 1 = 'max'. */
+int mmif_pixel_loss(const float* img1, const float* img2, const float* imgf, int32_t n, int32_t h, int32_t w,
+                    float weight, int32_t mode_max, int32_t l2, float* loss_out, float* grad_out, void* workspace,
+                    size_t workspace_bytes, void* stream);
+/* GradLoss core/loss.py:307-344: Sobel |gx|+|gy| on the reflect-padded image. */
+int mmif_grad_loss(const float* img1, const float* img2, const float* imgf, int32_t n, int32_t h, int32_t w,
+                   float weight, int32_t mode_max, int32_t l2, float* loss_out, float* grad_out, void* workspace,
+                   size_t workspace_bytes, void* stream);
+
+/* ---- optimiser (train.py:72-75,319): clip_grad_norm_(max_norm) + Adam on flat fp32 buffers ---- */
+size_t mmif_clip_adam_workspace(int64_t numel);
+/* grad_scale multiplies the gradients first (1/world after a SUM all-reduce).  max_norm <= 0
+ * disables clipping.  norm_out (device float[1], may be NULL) receives the pre-clip global L2 norm. */
+int mmif_clip_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t numel,
+                        float lr, float beta1, float beta2, float eps, int32_t step, float max_norm,
+                        float grad_scale, float* norm_out, void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMIF_H */

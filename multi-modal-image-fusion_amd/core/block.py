@@ -1,0 +1,261 @@
+# -*- coding: utf-8 -*-
+"""Network blocks -- API mirror of the reference's core/block.py for the hot-path blocks
+(ConvLayer :26-118, DenseBlock :137-151, ConvBlock :708-722, RFN :737-759, NestDecoder :836-867,
+Upsample/Downsample :941-991), executed by hand-written HIP kernels.
+
+Called standalone (NCHW tensors in / out) every block converts at its boundary; inside the models
+(core/model.py) the whole network runs on blocked-NHWC buffers without these conversions.
+"""
+import torch
+import torch.nn as nn
+
+from mmif import _lib
+from mmif import engine as E
+from mmif import tensor as T
+from mmif.tensor import BT
+
+from .fusion import concat_fusion
+
+__all__ = ['ConvLayer', 'DenseBlock', 'ConvBlock', 'RFN', 'NestDecoder', 'Downsample', 'Upsample']
+
+
+class _ConvLayerFn(torch.autograd.Function):
+    """One ConvLayer on NCHW boundary tensors: reflect-pad conv + bias + ReLU through the C ABI."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        T.require_device(x, "ConvLayer input")
+        cout, cin, k, _ = weight.shape
+        dtype, impl = E.compute_dtype(), E.conv_impl()
+        n, _, h, w = x.shape
+        dev = x.device
+        wd, bd = weight.detach(), bias.detach() if bias is not None else None
+        packed = None
+        if dtype == torch.bfloat16 and impl != _lib.IMPL_VALU and cin > 1 and cout > 1:
+            packed = T.PackedWeights(cout, cin, k, dev)
+            packed.pack(wd)
+        if cin == 1:
+            xin = x.detach().contiguous().float()
+            yb = BT.alloc(n, cout, h, w, dtype, dev)
+            T.image_in_fwd(xin, wd, bd, yb, cout, k, relu)
+            y = yb.to_nchw(cout)
+            ctx.saved = ("in", xin, yb)
+        elif cout == 1:
+            xb = BT.from_nchw(x.detach(), dtype)
+            y = torch.empty((n, 1, h, w), dtype=torch.float32, device=dev)
+            T.image_out_fwd(xb, wd, bd, y, cin, k, relu)
+            ctx.saved = ("out", xb, y if relu else None)
+        else:
+            xb = BT.from_nchw(x.detach(), dtype)
+            yb = BT.alloc(n, cout, h, w, dtype, dev)
+            T.conv_fwd(xb, wd, bd, yb, cin, cout, k, relu, packed, impl)
+            y = yb.to_nchw(cout)
+            ctx.saved = ("mid", xb, yb)
+        ctx.meta = (cin, cout, k, relu, dtype, impl, packed, wd)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        cin, cout, k, relu, dtype, impl, packed, wd = ctx.meta
+        kind, a, b = ctx.saved
+        gy = gy.contiguous().float()
+        n, _, h, w = gy.shape
+        dev = gy.device
+        dw = torch.empty_like(wd)
+        db = torch.empty(cout, dtype=torch.float32, device=dev)
+        gx = None
+        if kind == "out":
+            xb, yimg = a, b
+            ws = torch.empty(T.image_wgrad_workspace_bytes(cin, k) // 4 + 1, dtype=torch.float32, device=dev)
+            T.image_out_wgrad(xb, gy, yimg, dw, db, cin, k, ws)
+            if ctx.needs_input_grad[0]:
+                gxb = BT.alloc(n, cin, h, w, dtype, dev, halo=1)
+                T.image_out_dgrad(gy, yimg, wd, None, gxb, cin, k, 0, 0)
+                gx = gxb.to_nchw(cin)
+        else:
+            gb = BT.from_nchw(gy, dtype)
+            yb = b
+            if relu:  # g * [y > 0]
+                gm = BT.alloc(n, cout, h, w, dtype, dev)
+                scratch = BT.alloc(n, cout, h, w, dtype, dev)
+                T.fuse_elem_bwd(yb, yb, gb, gm, scratch, _lib.FUSE_SUM, True)
+                gb = gm
+            if kind == "in":
+                ws = torch.empty(T.image_wgrad_workspace_bytes(cout, k) // 4 + 1, dtype=torch.float32, device=dev)
+                T.image_in_wgrad(a, gb, dw, db, cout, k, ws)
+                if ctx.needs_input_grad[0]:
+                    raise NotImplementedError("mmif: gradient w.r.t. a single-channel input image is not provided")
+            else:
+                xb = a
+                ws = torch.empty(T.wgrad_workspace_bytes(cin, cout, k) // 4 + 1, dtype=torch.float32, device=dev)
+                T.conv_wgrad(xb, gb, dw, db, cin, cout, k, ws, False, impl)
+                if ctx.needs_input_grad[0]:
+                    gxb = BT.alloc(n, cin, h, w, dtype, dev, halo=1)
+                    T.conv_dgrad(gb, wd, None, gxb, cin, cout, k, 0, 0, packed, impl)
+                    gx = gxb.to_nchw(cin)
+        return gx, dw, (db if ctx.has_bias else None), None
+
+
+class ConvLayer(nn.Module):
+    """reference core/block.py:26-118 -- same constructor signature, same sub-module layout
+    (`layers.0` = the nn.Conv2d that owns weight/bias, so state_dict keys are identical), same
+    initialisation (kaiming-normal for ReLU-family acts, zero bias, torch default otherwise)."""
+
+    def __init__(self, in_ch, out_ch, ksize=3, stride=1, padding=None, dilation=1, groups=1, bias=None, norm=None,
+                 pre_norm=None, layer=nn.Conv2d, act=nn.ReLU, padding_mode='reflect'):
+        super(ConvLayer, self).__init__()
+        if padding is None:
+            padding = ksize // 2
+        if bias is None:
+            bias = (norm is not nn.BatchNorm2d) or (pre_norm is not nn.BatchNorm2d)
+        mods = []
+        if pre_norm is not None:
+            mods.append(pre_norm(out_ch, out_ch) if pre_norm is nn.GroupNorm else pre_norm(out_ch))
+        if layer is nn.Conv2d:
+            mods.append(nn.Conv2d(in_ch, out_ch, ksize, stride, padding, dilation, groups, bias=bias, padding_mode=padding_mode))
+        elif layer is nn.ConvTranspose2d:
+            mods.append(nn.ConvTranspose2d(in_ch, out_ch, ksize, stride, padding, output_padding=1, bias=bias, padding_mode='zeros'))
+        if norm is not None:
+            mods.append(norm(out_ch, out_ch) if norm is nn.GroupNorm else norm(out_ch))
+        if act is not None:
+            if act in (nn.ReLU, nn.ReLU6, nn.Hardswish):
+                mods.append(act(inplace=True))
+            elif act is nn.LeakyReLU:
+                mods.append(act(0.2, inplace=True))
+            else:
+                mods.append(act())
+        self.layers = nn.Sequential(*mods)
+        self.norm, self.pre_norm, self.act = norm, pre_norm, act
+        # the HIP kernels cover exactly what the hot-path models use
+        self._hip = (layer is nn.Conv2d and norm is None and pre_norm is None and act in (nn.ReLU, None) and stride == 1
+                     and dilation == 1 and groups == 1 and ksize in (1, 3) and padding == ksize // 2
+                     and (padding_mode == 'reflect' or ksize == 1) and bias)
+        self._init_weights()
+
+    def forward(self, x):
+        if self._hip:
+            conv = self.layers[0]
+            return _ConvLayerFn.apply(x, conv.weight, conv.bias, self.act is not None)
+        # argument combinations outside the hot path (norm layers, strides, other activations ...)
+        # are not re-implemented: they run as the stock torch modules they are
+        return self.layers(x)
+
+    def _init_weights(self):
+        for m in self.modules():
+            if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+                if self.act in (nn.ReLU, nn.ReLU6, nn.Hardswish, nn.SiLU, nn.GELU):
+                    nn.init.kaiming_normal_(m.weight)
+                elif self.act is nn.LeakyReLU:
+                    nn.init.kaiming_normal_(m.weight, a=0.2)
+                elif self.act is nn.Tanh:
+                    nn.init.xavier_normal_(m.weight, gain=nn.init.calculate_gain('tanh'))
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+            elif isinstance(m, (nn.BatchNorm2d, nn.GroupNorm)):
+                nn.init.ones_(m.weight)
+                nn.init.zeros_(m.bias)
+
+
+class DenseBlock(nn.Module):
+    """reference core/block.py:137-151"""
+
+    def __init__(self, in_ch, out_ch, num_convs=3):
+        super(DenseBlock, self).__init__()
+        self.in_ch, self.out_ch = in_ch, out_ch
+        self.layers = nn.ModuleList([ConvLayer(in_ch + i * out_ch, out_ch) for i in range(num_convs)])
+
+    def forward(self, x):
+        for layer in self.layers:
+            x = concat_fusion((x, layer(x)))
+        return x
+
+
+class ConvBlock(nn.Module):
+    """reference core/block.py:708-722"""
+
+    def __init__(self, in_ch, out_ch, ksize1=3, ksize2=1):
+        super(ConvBlock, self).__init__()
+        self.in_ch, self.out_ch = in_ch, out_ch
+        hid_ch = in_ch // 2
+        self.layers = nn.Sequential(ConvLayer(in_ch, hid_ch, ksize=ksize1), ConvLayer(hid_ch, out_ch, ksize=ksize2))
+
+    def forward(self, x):
+        return self.layers(x)
+
+
+class RFN(nn.Module):
+    """reference core/block.py:737-759"""
+
+    def __init__(self, num_ch):
+        super(RFN, self).__init__()
+        self.res = ConvLayer(num_ch * 2, num_ch)
+        self.conv1 = ConvLayer(num_ch, num_ch)
+        self.conv2 = ConvLayer(num_ch, num_ch)
+        self.layers = nn.Sequential(ConvLayer(num_ch * 2, num_ch, ksize=1), ConvLayer(num_ch, num_ch), ConvLayer(num_ch, num_ch))
+
+    def forward(self, x1, x2):
+        f_res = self.res(concat_fusion((x1, x2)))
+        f_out = self.layers(concat_fusion((self.conv1(x1), self.conv2(x2))))
+        return f_out + f_res
+
+
+class _Resample(nn.Module):
+    """shape-matching tail shared by Upsample / Downsample (reference core/block.py:953-961,981-991)"""
+
+    @staticmethod
+    def _pad(feat, shape):
+        pad_h, pad_w = shape[-2] - feat.shape[-2], shape[-1] - feat.shape[-1]
+        top, left = pad_h // 2, pad_w // 2
+        return nn.ReflectionPad2d((left, pad_w - left, top, pad_h - top))(feat)
+
+    def forward(self, feat, shape):
+        out = self.op(feat)
+        if out.shape != shape:
+            out = self._pad(out, shape)
+        return out
+
+
+class Downsample(_Resample):
+    """reference core/block.py:941-962"""
+
+    def __init__(self, kernel_size=2, stride=2):
+        super(Downsample, self).__init__()
+        self.down = nn.MaxPool2d(kernel_size, stride)
+        self.op = self.down
+
+
+class Upsample(_Resample):
+    """reference core/block.py:965-991"""
+
+    def __init__(self, mode, scale_factor=2):
+        super(Upsample, self).__init__()
+        if mode == 'nearest':
+            self.up = nn.Upsample(scale_factor=scale_factor, mode=mode)
+        else:
+            self.up = nn.Upsample(scale_factor=scale_factor, mode=mode, align_corners=True)
+        self.op = self.up
+
+
+class NestDecoder(nn.Module):
+    """reference core/block.py:836-867 (UNet++ nested decoder)"""
+
+    def __init__(self, block, num_ch, up_mode='bilinear'):
+        super(NestDecoder, self).__init__()
+        c = num_ch
+        self.DB1_1 = block(c[0] + c[1], c[0])
+        self.DB2_1 = block(c[1] + c[2], c[1])
+        self.DB3_1 = block(c[2] + c[3], c[2])
+        self.DB1_2 = block(c[0] * 2 + c[1], c[0])
+        self.DB2_2 = block(c[1] * 2 + c[2], c[1])
+        self.DB1_3 = block(c[0] * 3 + c[1], c[0])
+        self.up = Upsample(up_mode, 2)
+
+    def forward(self, feats):
+        f, up = feats, self.up
+        x1_1 = self.DB1_1(concat_fusion((f[0], up(f[1], f[0].shape))))
+        x2_1 = self.DB2_1(concat_fusion((f[1], up(f[2], f[1].shape))))
+        x3_1 = self.DB3_1(concat_fusion((f[2], up(f[3], f[2].shape))))
+        x1_2 = self.DB1_2(concat_fusion((f[0], x1_1, up(x2_1, x1_1.shape))))
+        x2_2 = self.DB2_2(concat_fusion((f[1], x2_1, up(x3_1, x2_1.shape))))
+        return self.DB1_3(concat_fusion((f[0], x1_1, x1_2, up(x2_2, x1_2.shape))))

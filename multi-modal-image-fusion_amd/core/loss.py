@@ -1,0 +1,146 @@
+# -*- coding: utf-8 -*-
+"""Fusion losses -- API mirror of the reference's core/loss.py (SSIM :163-185, SSIMLoss :240-284,
+PixelLoss :287-304, GradLoss :307-344, NormLoss :361-385) on the fused HIP loss kernels: each call
+computes the loss AND d(loss)/d(imgf) in one pass; backward() only scales that gradient.
+All loss arithmetic is fp32 regardless of the feature-map dtype.
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from mmif import tensor as T
+from mmif._lib import check, lib
+
+__all__ = ['SSIM', 'SSIMLoss', 'PixelLoss', 'GradLoss', 'NormLoss']
+
+eps = 1e-7
+
+
+def _prep(img1, img2, imgf):
+    T.require_device(imgf, "loss input")
+    if imgf.dim() != 4 or imgf.shape[1] != 1:
+        raise ValueError(f"fusion losses take single-channel images [B,1,H,W]; got {tuple(imgf.shape)}")
+    if img1.shape != imgf.shape or img2.shape != imgf.shape:
+        raise ValueError("img1, img2 and imgf must have the same shape")
+    return img1.detach().contiguous().float(), img2.detach().contiguous().float(), imgf.detach().contiguous().float()
+
+
+_ws_cache = {}
+
+
+def _workspace(n, h, w, device):
+    key = (n, h, w, device)
+    ws = _ws_cache.get(key)
+    if ws is None:
+        ws = torch.empty(lib.mmif_loss_workspace(n, h, w) // 4 + 1, dtype=torch.float32, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+class _LossFn(torch.autograd.Function):
+    """kind: 0 ssim, 1 pixel, 2 grad.  Returns a 0-dim loss; saves dloss/dimgf computed in the same launch."""
+
+    @staticmethod
+    def forward(ctx, imgf, img1, img2, kind, weight, a, b):
+        i1, i2, f = _prep(img1, img2, imgf)
+        n, _, h, w = f.shape
+        need = imgf.requires_grad and torch.is_grad_enabled()
+        out = torch.empty(1, dtype=torch.float32, device=f.device)
+        grad = torch.empty_like(f) if need else None
+        ws = _workspace(n, h, w, f.device)
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        nbytes = ws.numel() * 4
+        if kind == 0:
+            check(lib.mmif_ssim_loss(p(i1), p(i2), p(f), n, h, w, weight, a, p(out), p(grad), p(ws), nbytes, T.stream_ptr()), "ssim_loss")
+        elif kind == 1:
+            check(lib.mmif_pixel_loss(p(i1), p(i2), p(f), n, h, w, weight, int(a), int(b), p(out), p(grad), p(ws), nbytes, T.stream_ptr()), "pixel_loss")
+        else:
+            check(lib.mmif_grad_loss(p(i1), p(i2), p(f), n, h, w, weight, int(a), int(b), p(out), p(grad), p(ws), nbytes, T.stream_ptr()), "grad_loss")
+        ctx.grad = grad
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.grad is None:
+            return (None,) * 7
+        return ctx.grad * g, None, None, None, None, None, None
+
+
+class SSIM(nn.Module):
+    """Structural similarity (reference core/loss.py:163-185): returns {'ssim': per-sample mean}."""
+
+    def __init__(self, win_size=11, data_range=1.0, use_padding=False, size_average=True):
+        super(SSIM, self).__init__()
+        if win_size != 11 or use_padding or not size_average:
+            raise NotImplementedError("the HIP SSIM kernel implements the training configuration: 11x11 window, no padding, per-sample mean")
+        self.win_size, self.data_range, self.use_padding, self.size_average = win_size, data_range, use_padding, size_average
+
+    def forward(self, img1, img2):
+        # per-sample means: run the batch-1 kernel per sample slice (evaluation-side API, not the training path)
+        vals = []
+        for i in range(img1.shape[0]):
+            l = _LossFn.apply(img2[i:i + 1], img1[i:i + 1], img1[i:i + 1], 0, 1.0, float(self.data_range), 0)
+            vals.append(1.0 - l)  # loss = 1 - (S(x,f)+S(x,f))/2 = 1 - S
+        return {'ssim': torch.stack(vals)}
+
+
+class SSIMLoss(nn.Module):
+    def __init__(self, mode='ssim', data_range=1.0, use_padding=False, weight=1.0):
+        super(SSIMLoss, self).__init__()
+        self.mode, self.data_range, self.use_padding, self.weight = mode, data_range, use_padding, weight
+
+    def forward(self, img1, img2, imgf):
+        if self.mode == 'ssim':
+            if self.use_padding:
+                raise NotImplementedError("use_padding=True is outside the accelerated hot path")
+            return _LossFn.apply(imgf, img1, img2, 0, float(self.weight), float(self.data_range), 0)
+        if self.mode in ('w-ssim', 'ms-ssim', 'msw-ssim'):
+            raise NotImplementedError(f"SSIMLoss mode '{self.mode}' is outside the accelerated hot path (train.py uses 'ssim')")
+        raise ValueError("only supported ['ssim', 'w-ssim', 'ms-ssim', 'msw-ssim'] mode")
+
+
+def _norm_code(mode):
+    if mode == 'l1':
+        return 0
+    if mode == 'l2':
+        return 1
+    raise ValueError("only supported ['l1', 'l2'] mode")
+
+
+class NormLoss(nn.Module):
+    """reference core/loss.py:361-385: weight * mean|x| or weight * mean x^2"""
+
+    def __init__(self, mode='l1', weight=1.0):
+        super(NormLoss, self).__init__()
+        self.mode, self.weight = mode, weight
+
+    def forward(self, x):
+        _norm_code(self.mode)
+        return self.weight * (torch.abs(x).mean() if self.mode == 'l1' else torch.pow(x, 2).mean())
+
+
+class PixelLoss(nn.Module):
+    def __init__(self, mode='l1', weight=1.0):
+        super(PixelLoss, self).__init__()
+        self.mode, self.weight = mode, weight
+        self.loss_fn = NormLoss(mode, weight)
+
+    def forward(self, img1, img2, imgf, mode='avg'):
+        if mode not in ('avg', 'max'):
+            return None  # the reference has no else branch (core/loss.py:294-304)
+        return _LossFn.apply(imgf, img1, img2, 1, float(self.weight), mode == 'max', _norm_code(self.mode))
+
+
+class GradLoss(nn.Module):
+    def __init__(self, mode='l1', weight=1.0):
+        super(GradLoss, self).__init__()
+        self.mode, self.weight = mode, weight
+        self.loss_fn = NormLoss(mode, weight)
+        self.register_buffer('x_sobel', torch.FloatTensor([[-1, 0, 1], [-2, 0, 2], [-1, 0, 1]]).reshape(1, 1, 3, 3))
+        self.register_buffer('y_sobel', torch.FloatTensor([[-1, -2, -1], [0, 0, 0], [1, 2, 1]]).reshape(1, 1, 3, 3))
+
+    def forward(self, img1, img2, imgf, mode='avg'):
+        if mode not in ('avg', 'max'):
+            return None  # as the reference (core/loss.py:335-344)
+        return _LossFn.apply(imgf, img1, img2, 2, float(self.weight), mode == 'max', _norm_code(self.mode))

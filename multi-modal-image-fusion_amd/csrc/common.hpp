@@ -1,0 +1,171 @@
+// Shared device/host helpers for the gfx950 image-fusion kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/mmif.h"
+
+namespace mmif {
+
+constexpr int CBS = 8;  // channels per block (one granule = 8 channels of one pixel)
+
+// ---------------------------------------------------------------- error plumbing
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+#define MMIF_REQUIRE(cond, ...)          \
+    do {                                 \
+        if (!(cond)) {                   \
+            mmif::set_error(__VA_ARGS__); \
+            return MMIF_EINVAL;          \
+        }                                \
+    } while (0)
+
+// ---------------------------------------------------------------- bf16 <-> f32 (round to nearest even)
+typedef uint16_t bf16_t;
+
+__host__ __device__ inline float bf16_to_f32(bf16_t v) {
+    union { uint32_t u; float f; } c;
+    c.u = ((uint32_t)v) << 16;
+    return c.f;
+}
+__host__ __device__ inline bf16_t f32_to_bf16(float f) {
+    union { uint32_t u; float f; } c;
+    c.f = f;
+    uint32_t u = c.u;
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+// ---------------------------------------------------------------- granule load/store (8 channels)
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static constexpr int dtype = MMIF_F32;
+    static constexpr int gran_bytes = 32;
+    __device__ static inline void load(const void* p, float (&v)[8]) {
+        const float4* q = reinterpret_cast<const float4*>(p);
+        float4 a = q[0], b = q[1];
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+    __device__ static inline void store(void* p, const float (&v)[8]) {
+        float4* q = reinterpret_cast<float4*>(p);
+        q[0] = make_float4(v[0], v[1], v[2], v[3]);
+        q[1] = make_float4(v[4], v[5], v[6], v[7]);
+    }
+    __device__ static inline float quant(float f) { return f; }
+};
+template <> struct Elem<bf16_t> {
+    static constexpr int dtype = MMIF_BF16;
+    static constexpr int gran_bytes = 16;
+    __device__ static inline void load(const void* p, float (&v)[8]) {
+        uint4 a = *reinterpret_cast<const uint4*>(p);
+        uint32_t w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = __uint_as_float(w[i] << 16);
+            v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+        }
+    }
+    __device__ static inline void store(void* p, const float (&v)[8]) {
+        uint32_t w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f32_to_bf16(v[2 * i]) | ((uint32_t)f32_to_bf16(v[2 * i + 1]) << 16);
+        *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    __device__ static inline float quant(float f) { return bf16_to_f32(f32_to_bf16(f)); }
+};
+
+// ---------------------------------------------------------------- device-side tensor view
+struct TV {
+    char* base;            // allocation base
+    int n, h, w, halo;     // logical extent
+    int hs, ws;            // stored extent (h + 2*halo, w + 2*halo)
+    int cb_total, cb_off, cb;
+    long long plane;       // granules per channel-block plane = hs*ws
+    long long img;         // granules per image = cb_total*plane
+
+    // granule index of (n, view-channel-block c, stored row ys, stored col xs)
+    __host__ __device__ inline long long gidx(int in, int c, int ys, int xs) const {
+        return (long long)in * img + (long long)(cb_off + c) * plane + (long long)ys * ws + xs;
+    }
+};
+
+inline TV make_tv(const mmif_tensor* t) {
+    TV v;
+    v.base = (char*)t->data;
+    v.n = t->n; v.h = t->h; v.w = t->w; v.halo = t->halo;
+    v.hs = t->h + 2 * t->halo; v.ws = t->w + 2 * t->halo;
+    v.cb_total = t->cb_total; v.cb_off = t->cb_off; v.cb = t->cb;
+    v.plane = (long long)v.hs * v.ws;
+    v.img = (long long)v.cb_total * v.plane;
+    return v;
+}
+
+int validate_tensor(const mmif_tensor* t, const char* name);
+
+// reflect index R(t, L) of F.pad(mode='reflect') (edge pixel not repeated); L >= 2 for |offset| 1
+__host__ __device__ inline int reflect_idx(int t, int L) {
+    if (t < 0) t = -t;
+    if (t >= L) t = 2 * (L - 1) - t;
+    return t;
+}
+
+// Load one granule of an ACTIVATION (halo 0) at logical (y, x) with reflect padding; coordinates
+// may lie up to one pixel outside.  Result in fp32.
+template <typename T>
+__device__ inline void load_act_reflect(const TV& t, int in, int c, int y, int x, float (&v)[8]) {
+    y = min(max(reflect_idx(y, t.h), 0), t.h - 1);  // clamp only matters for tile overhang lanes
+    x = min(max(reflect_idx(x, t.w), 0), t.w - 1);
+    Elem<T>::load(t.base + t.gidx(in, c, y, x) * Elem<T>::gran_bytes, v);
+}
+
+// Load one granule of a GRADIENT at logical (y, x): zero outside [0,h)x[0,w); for halo-1
+// (padded-domain) tensors the halo is folded onto rows/cols 1 and h-2 / w-2 while loading
+// (adjoint of reflect padding by 1).
+template <typename T>
+__device__ inline void load_grad_fold(const TV& t, int in, int c, int y, int x, float (&v)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = 0.f;
+    if (y < 0 || y >= t.h || x < 0 || x >= t.w) return;
+    if (t.halo == 0) {
+        Elem<T>::load(t.base + t.gidx(in, c, y, x) * Elem<T>::gran_bytes, v);
+        return;
+    }
+    // candidate sources: the interior pixel plus the mirrored halo rows / cols (-1 = absent)
+    const int ya = y + 1, yb = (y == 1) ? 0 : -1, yc = (y == t.h - 2) ? t.h + 1 : -1;
+    const int xa = x + 1, xb = (x == 1) ? 0 : -1, xc = (x == t.w - 2) ? t.w + 1 : -1;
+    auto add = [&](int ys, int xs) {
+        if (ys < 0 || xs < 0) return;
+        float u[8];
+        Elem<T>::load(t.base + t.gidx(in, c, ys, xs) * Elem<T>::gran_bytes, u);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] += u[i];
+    };
+    add(ya, xa); add(ya, xb); add(ya, xc);
+    add(yb, xa); add(yb, xb); add(yb, xc);
+    add(yc, xa); add(yc, xb); add(yc, xc);
+}
+
+// block-wide sum of one float per thread (blockDim.x multiple of 64, <= 1024); result valid in
+// thread 0.  Deterministic for a fixed block size.
+__device__ inline float block_sum(float v, float* smem /* >= 16 floats */) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) smem[wave] = v;
+    __syncthreads();
+    float r = 0.f;
+    if (threadIdx.x == 0) {
+        const int nw = (blockDim.x + 63) >> 6;
+        for (int i = 0; i < nw; ++i) r += smem[i];
+    }
+    return r;
+}
+
+inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace mmif

@@ -1,0 +1,107 @@
+// C-ABI entry points of the generic ConvLayer kernels: argument validation + dispatch between the
+// VALU (fp32 parity) and MFMA (bf16 throughput) implementations.
+#include "common.hpp"
+
+namespace mmif {
+// conv_valu.hip
+int conv_valu(bool dgrad, int dtype, int ks, const TV& tin, const TV& tout, const TV& tmask, const float* w,
+              const float* bias, int cin, int cout, int relu, uint64_t mask_bits, uint64_t accum_bits, hipStream_t st);
+size_t wgrad_valu_workspace(int cin, int cout, int ks);
+int wgrad_valu(int dtype, int ks, const TV& tx, const TV& tg, float* dw, float* db, int cin, int cout, int accumulate,
+               float* ws, hipStream_t st);
+// conv_mfma.hip
+bool conv_mfma_supported(bool dgrad, int ks, int cin, int cout);
+int conv_mfma(bool dgrad, int ks, const TV& tin, const TV& tout, const TV& tmask, const void* w_packed, const float* bias,
+              int cin, int cout, int relu, uint64_t mask_bits, uint64_t accum_bits, hipStream_t st);
+bool wgrad_mfma_supported(int ks, int cin, int cout);
+size_t wgrad_mfma_workspace(int cin, int cout, int ks);
+int wgrad_mfma(int ks, const TV& tx, const TV& tg, float* dw, float* db, int cin, int cout, int accumulate, float* ws,
+               hipStream_t st);
+}  // namespace mmif
+
+using namespace mmif;
+
+static int pick_impl(int impl, int dtype, bool mfma_ok, const char* what) {
+    if (impl == MMIF_IMPL_AUTO) return (dtype == MMIF_BF16 && mfma_ok) ? MMIF_IMPL_MFMA : MMIF_IMPL_VALU;
+    if (impl == MMIF_IMPL_MFMA && (dtype != MMIF_BF16 || !mfma_ok)) {
+        set_error("%s: MFMA implementation unavailable for this dtype/shape", what);
+        return -1;
+    }
+    if (impl != MMIF_IMPL_VALU && impl != MMIF_IMPL_MFMA) {
+        set_error("%s: bad impl %d", what, impl);
+        return -1;
+    }
+    return impl;
+}
+
+extern "C" int mmif_conv2d_reflect_fwd(const mmif_tensor* x, const float* w, const void* w_packed, const float* bias,
+                                       const mmif_tensor* y, int32_t cin, int32_t cout, int32_t ksize, int32_t relu,
+                                       int32_t impl, void* stream) {
+    if (int rc = validate_tensor(x, "x")) return rc;
+    if (int rc = validate_tensor(y, "y")) return rc;
+    MMIF_REQUIRE(ksize == 1 || ksize == 3, "conv2d_reflect_fwd: ksize must be 1 or 3 (got %d)", ksize);
+    MMIF_REQUIRE(x->halo == 0 && y->halo == 0, "conv2d_reflect_fwd: activations must have halo 0");
+    MMIF_REQUIRE(x->dtype == y->dtype && x->n == y->n && x->h == y->h && x->w == y->w, "conv2d_reflect_fwd: x/y mismatch");
+    MMIF_REQUIRE(cin > 0 && cin % 8 == 0 && cin == x->cb * 8, "conv2d_reflect_fwd: cin=%d must equal 8*x.cb=%d", cin, x->cb * 8);
+    MMIF_REQUIRE(cout > 0 && (cout + 7) / 8 == y->cb, "conv2d_reflect_fwd: cout=%d does not match y.cb=%d", cout, y->cb);
+    MMIF_REQUIRE(ksize == 1 || (x->h >= 2 && x->w >= 2), "reflect padding needs h,w >= 2");
+    const int im = pick_impl(impl, x->dtype, conv_mfma_supported(false, ksize, cin, cout) && w_packed != nullptr, "conv2d_reflect_fwd");
+    if (im < 0) return MMIF_EINVAL;
+    TV tx = make_tv(x), ty = make_tv(y);
+    if (im == MMIF_IMPL_MFMA) return conv_mfma(false, ksize, tx, ty, ty, w_packed, bias, cin, cout, relu, 0, 0, (hipStream_t)stream);
+    MMIF_REQUIRE(w != nullptr, "conv2d_reflect_fwd: VALU path needs the fp32 master weights");
+    return conv_valu(false, x->dtype, ksize, tx, ty, ty, w, bias, cin, cout, relu, 0, 0, (hipStream_t)stream);
+}
+
+extern "C" int mmif_conv2d_reflect_dgrad(const mmif_tensor* gy, const float* w, const void* w_packed_t, const mmif_tensor* x,
+                                         const mmif_tensor* gx, int32_t cin, int32_t cout, int32_t ksize, uint64_t mask_bits,
+                                         uint64_t accum_bits, int32_t impl, void* stream) {
+    if (int rc = validate_tensor(gy, "gy")) return rc;
+    if (int rc = validate_tensor(gx, "gx")) return rc;
+    MMIF_REQUIRE(ksize == 1 || ksize == 3, "conv2d_reflect_dgrad: ksize must be 1 or 3 (got %d)", ksize);
+    MMIF_REQUIRE(gx->halo >= ksize / 2, "conv2d_reflect_dgrad: gx needs halo >= ksize/2");
+    MMIF_REQUIRE(gy->dtype == gx->dtype && gy->n == gx->n && gy->h == gx->h && gy->w == gx->w, "conv2d_reflect_dgrad: gy/gx mismatch");
+    MMIF_REQUIRE(cin > 0 && cin % 8 == 0 && cin == gx->cb * 8, "conv2d_reflect_dgrad: cin=%d must equal 8*gx.cb=%d", cin, gx->cb * 8);
+    MMIF_REQUIRE(cout > 0 && (cout + 7) / 8 == gy->cb, "conv2d_reflect_dgrad: cout=%d does not match gy.cb=%d", cout, gy->cb);
+    TV tg = make_tv(gy), tgx = make_tv(gx), tm = tgx;
+    if (mask_bits) {
+        MMIF_REQUIRE(x != nullptr, "conv2d_reflect_dgrad: mask_bits set but x is NULL");
+        if (int rc = validate_tensor(x, "x")) return rc;
+        MMIF_REQUIRE(x->halo == 0 && x->dtype == gx->dtype && x->n == gx->n && x->h == gx->h && x->w == gx->w && x->cb == gx->cb,
+                     "conv2d_reflect_dgrad: x does not match gx");
+        tm = make_tv(x);
+    }
+    const int im = pick_impl(impl, gy->dtype, conv_mfma_supported(true, ksize, cin, cout) && w_packed_t != nullptr, "conv2d_reflect_dgrad");
+    if (im < 0) return MMIF_EINVAL;
+    if (im == MMIF_IMPL_MFMA) return conv_mfma(true, ksize, tg, tgx, tm, w_packed_t, nullptr, cin, cout, 0, mask_bits, accum_bits, (hipStream_t)stream);
+    MMIF_REQUIRE(w != nullptr, "conv2d_reflect_dgrad: VALU path needs the fp32 master weights");
+    return conv_valu(true, gy->dtype, ksize, tg, tgx, tm, w, nullptr, cin, cout, 0, mask_bits, accum_bits, (hipStream_t)stream);
+}
+
+extern "C" size_t mmif_conv2d_wgrad_workspace(int32_t cin, int32_t cout, int32_t ksize) {
+    size_t a = wgrad_valu_workspace(cin, cout, ksize);
+    size_t b = wgrad_mfma_workspace(cin, cout, ksize);
+    return a > b ? a : b;
+}
+
+extern "C" int mmif_conv2d_reflect_wgrad(const mmif_tensor* x, const mmif_tensor* gy, float* dw, float* db, int32_t cin,
+                                         int32_t cout, int32_t ksize, int32_t accumulate, void* workspace,
+                                         size_t workspace_bytes, int32_t impl, void* stream) {
+    if (int rc = validate_tensor(x, "x")) return rc;
+    if (int rc = validate_tensor(gy, "gy")) return rc;
+    MMIF_REQUIRE(ksize == 1 || ksize == 3, "conv2d_reflect_wgrad: ksize must be 1 or 3 (got %d)", ksize);
+    MMIF_REQUIRE(x->halo == 0, "conv2d_reflect_wgrad: x must be an activation (halo 0)");
+    MMIF_REQUIRE(x->dtype == gy->dtype && x->n == gy->n && x->h == gy->h && x->w == gy->w, "conv2d_reflect_wgrad: x/gy mismatch");
+    MMIF_REQUIRE(cin > 0 && cin % 8 == 0 && cin == x->cb * 8, "conv2d_reflect_wgrad: cin=%d must equal 8*x.cb=%d", cin, x->cb * 8);
+    MMIF_REQUIRE(cout > 0 && (cout + 7) / 8 == gy->cb, "conv2d_reflect_wgrad: cout=%d does not match gy.cb=%d", cout, gy->cb);
+    MMIF_REQUIRE(dw != nullptr, "conv2d_reflect_wgrad: dw is NULL");
+    if (workspace_bytes < mmif_conv2d_wgrad_workspace(cin, cout, ksize)) {
+        set_error("conv2d_reflect_wgrad: workspace too small (%zu < %zu)", workspace_bytes, mmif_conv2d_wgrad_workspace(cin, cout, ksize));
+        return MMIF_EWORKSPACE;
+    }
+    const int im = pick_impl(impl, x->dtype, wgrad_mfma_supported(ksize, cin, cout), "conv2d_reflect_wgrad");
+    if (im < 0) return MMIF_EINVAL;
+    TV tx = make_tv(x), tg = make_tv(gy);
+    if (im == MMIF_IMPL_MFMA) return wgrad_mfma(ksize, tx, tg, dw, db, cin, cout, accumulate, (float*)workspace, (hipStream_t)stream);
+    return wgrad_valu(x->dtype, ksize, tx, tg, dw, db, cin, cout, accumulate, (float*)workspace, (hipStream_t)stream);
+}

@@ -1,0 +1,398 @@
+// Image-side convolution layers: Cin == 1 (first encoder conv) and Cout == 1 (last decoder conv).
+// Reference: ConvLayer(1,16) core/model.py:73,77,118,169 / ConvLayer(1,16,ksize=1) :326 and
+// ConvLayer(16,1,act=None) :86,131,179 / ConvLayer(64,1,ksize=1) :344.  Images are fp32 [n][h][w].
+// These layers are HBM-bound (K = 9 or M = 1): plain VALU kernels, fp32 math, T only on the
+// feature-map side.
+#include "common.hpp"
+
+namespace mmif {
+
+constexpr int ITILE = 16;
+
+__device__ inline float img_reflect(const float* img, int h, int w, int y, int x) {
+    y = min(max(reflect_idx(y, h), 0), h - 1);
+    x = min(max(reflect_idx(x, w), 0), w - 1);
+    return img[(long long)y * w + x];
+}
+
+// ---------------------------------------------------------------- Cin == 1 forward
+template <typename T, int KS>
+__global__ __launch_bounds__(256) void image_in_fwd_kernel(const float* __restrict__ img, TV ty, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, int cout, int relu, int tiles_x) {
+    constexpr int KK = KS * KS, P = KS / 2;
+    extern __shared__ float sm[];  // [cout*KK] weights, [cout] bias
+    float* wsm = sm;
+    float* bsm = sm + cout * KK;
+    for (int e = threadIdx.x; e < cout * KK; e += 256) wsm[e] = w[e];
+    for (int e = threadIdx.x; e < cout; e += 256) bsm[e] = bias ? bias[e] : 0.f;
+    __syncthreads();
+    const int tx = threadIdx.x & 15, tyy = threadIdx.x >> 4;
+    const int x = (blockIdx.x % tiles_x) * ITILE + tx, y = (blockIdx.x / tiles_x) * ITILE + tyy;
+    const int in_ = blockIdx.y;
+    if (y >= ty.h || x >= ty.w) return;
+    const float* im = img + (long long)in_ * ty.h * ty.w;
+    float nb[KK];
+#pragma unroll
+    for (int t = 0; t < KK; ++t) nb[t] = img_reflect(im, ty.h, ty.w, y + t / KS - P, x + t % KS - P);
+    for (int b = 0; b < ty.cb; ++b) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int o = b * 8 + i;
+            float r = 0.f;
+            if (o < cout) {
+                r = bsm[o];
+#pragma unroll
+                for (int t = 0; t < KK; ++t) r = fmaf(nb[t], wsm[o * KK + t], r);
+                if (relu) r = fmaxf(r, 0.f);
+            }
+            v[i] = r;
+        }
+        Elem<T>::store(ty.base + ty.gidx(in_, b, y, x) * Elem<T>::gran_bytes, v);
+    }
+}
+
+// ---------------------------------------------------------------- Cin == 1 wgrad
+// partial layout per (block g, og): [16 o][KK] then [16] bias sums
+template <typename T, int KS>
+__global__ __launch_bounds__(256) void image_in_wgrad_kernel(const float* __restrict__ img, TV tg, float* __restrict__ partial,
+                                                             int cout, int tiles_x, int tpi, int total) {
+    constexpr int KK = KS * KS, P = KS / 2, IT = ITILE + KS - 1;
+    __shared__ float gsm[16][ITILE * ITILE + 1];
+    __shared__ float ism[IT][IT + 1];
+    const int tid = threadIdx.x, og = blockIdx.y;
+    const int o = tid / KK, tap = tid % KK;      // valid for tid < 16*KK
+    const bool wthread = tid < 16 * KK;
+    const bool bthread = tid >= 16 * KK && tid < 16 * KK + 16;
+    const int bo = tid - 16 * KK;
+    float acc = 0.f;
+    for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
+        const int in_ = tile / tpi, tt = tile % tpi;
+        const int y0 = (tt / tiles_x) * ITILE, x0 = (tt % tiles_x) * ITILE;
+        const float* im = img + (long long)in_ * tg.h * tg.w;
+        __syncthreads();
+        for (int e = tid; e < IT * IT; e += 256) ism[e / IT][e % IT] = img_reflect(im, tg.h, tg.w, y0 + e / IT - P, x0 + e % IT - P);
+        for (int e = tid; e < ITILE * ITILE * 2; e += 256) {
+            const int b = e / (ITILE * ITILE), p = e % (ITILE * ITILE);
+            float v[8];
+            const int gcb = og * 2 + b;
+            if (gcb < tg.cb) load_grad_fold<T>(tg, in_, gcb, y0 + p / ITILE, x0 + p % ITILE, v);
+            else {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) v[c] = 0.f;
+            }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) gsm[b * 8 + c][p] = v[c];
+        }
+        __syncthreads();
+        if (wthread) {
+            const int u = tap / KS, v = tap % KS;
+            for (int p = 0; p < ITILE * ITILE; ++p) acc = fmaf(gsm[o][p], ism[p / ITILE + u][p % ITILE + v], acc);
+        } else if (bthread) {
+            for (int p = 0; p < ITILE * ITILE; ++p) acc += gsm[bo][p];
+        }
+    }
+    float* dst = partial + ((long long)blockIdx.x * gridDim.y + og) * (16 * KK + 16);
+    if (wthread) dst[tid] = acc;
+    else if (bthread) dst[tid] = acc;
+}
+
+template <int KS>
+__global__ void image_in_wgrad_reduce(const float* __restrict__ partial, float* __restrict__ dw, float* __restrict__ db,
+                                      int cout, int G, int n_og, int accumulate) {
+    constexpr int KK = KS * KS, PER = 16 * KK + 16;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < cout * KK) {
+        const int o = idx / KK, tap = idx % KK, og = o / 16, oo = o % 16;
+        float s = 0.f;
+        for (int g = 0; g < G; ++g) s += partial[((long long)g * n_og + og) * PER + oo * KK + tap];
+        dw[idx] = accumulate ? dw[idx] + s : s;
+    } else if (idx < cout * KK + cout && db) {
+        const int o = idx - cout * KK, og = o / 16, oo = o % 16;
+        float s = 0.f;
+        for (int g = 0; g < G; ++g) s += partial[((long long)g * n_og + og) * PER + 16 * KK + oo];
+        db[o] = accumulate ? db[o] + s : s;
+    }
+}
+
+// ---------------------------------------------------------------- Cout == 1 forward
+template <typename T, int KS>
+__global__ __launch_bounds__(256) void image_out_fwd_kernel(TV tx, const float* __restrict__ w, const float* __restrict__ bias,
+                                                            float* __restrict__ img, int cin, int relu, int tiles_x) {
+    constexpr int KK = KS * KS, P = KS / 2;
+    extern __shared__ float wsm[];  // [cin][KK]
+    for (int e = threadIdx.x; e < cin * KK; e += 256) wsm[e] = w[e];
+    __syncthreads();
+    const int txx = threadIdx.x & 15, tyy = threadIdx.x >> 4;
+    const int x = (blockIdx.x % tiles_x) * ITILE + txx, y = (blockIdx.x / tiles_x) * ITILE + tyy;
+    const int in_ = blockIdx.y;
+    if (y >= tx.h || x >= tx.w) return;
+    float r = bias ? bias[0] : 0.f;
+    for (int b = 0; b < tx.cb; ++b) {
+#pragma unroll
+        for (int t = 0; t < KK; ++t) {
+            float v[8];
+            load_act_reflect<T>(tx, in_, b, y + t / KS - P, x + t % KS - P, v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (b * 8 + i < cin) r = fmaf(v[i], wsm[(b * 8 + i) * KK + t], r);
+        }
+    }
+    if (relu) r = fmaxf(r, 0.f);
+    img[((long long)in_ * tx.h + y) * tx.w + x] = r;
+}
+
+// ---------------------------------------------------------------- Cout == 1 dgrad
+// gx[y][x][c] (+)= sum_{u,v} W[0][c][k-1-u][k-1-v] * g0(y+u-p, x+v-p) over the stored domain of gx.
+template <typename T, int KS>
+__global__ __launch_bounds__(256) void image_out_dgrad_kernel(const float* __restrict__ gimg, const float* __restrict__ yimg,
+                                                              const float* __restrict__ w, TV tmask, TV tgx, int cin,
+                                                              unsigned long long mask_bits, unsigned long long accum_bits,
+                                                              int tiles_x) {
+    constexpr int KK = KS * KS, P = KS / 2;
+    extern __shared__ float wsm[];  // [cin][KK]
+    for (int e = threadIdx.x; e < cin * KK; e += 256) wsm[e] = w[e];
+    __syncthreads();
+    const int txx = threadIdx.x & 15, tyy = threadIdx.x >> 4;
+    const int xs = (blockIdx.x % tiles_x) * ITILE + txx, ys = (blockIdx.x / tiles_x) * ITILE + tyy;
+    const int in_ = blockIdx.y;
+    if (ys >= tgx.hs || xs >= tgx.ws) return;
+    const int y = ys - tgx.halo, x = xs - tgx.halo;
+    const int H = tgx.h, W = tgx.w;
+    float g[KK];
+#pragma unroll
+    for (int t = 0; t < KK; ++t) {
+        const int yy = y + t / KS - P, xx = x + t % KS - P;
+        float v = 0.f;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+            const long long i = ((long long)in_ * H + yy) * W + xx;
+            v = gimg[i];
+            if (yimg != nullptr && !(yimg[i] > 0.f)) v = 0.f;
+        }
+        g[t] = v;
+    }
+    for (int b = 0; b < tgx.cb; ++b) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float r = 0.f;
+            const int c = b * 8 + i;
+            if (c < cin) {
+#pragma unroll
+                for (int t = 0; t < KK; ++t) r = fmaf(g[t], wsm[c * KK + (KK - 1 - t)], r);
+            }
+            v[i] = r;
+        }
+        char* dst = tgx.base + tgx.gidx(in_, b, ys, xs) * Elem<T>::gran_bytes;
+        if ((accum_bits >> b) & 1ull) {
+            float old[8];
+            Elem<T>::load(dst, old);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] += old[i];
+        }
+        if ((mask_bits >> b) & 1ull) {
+            float xm[8];
+            load_act_reflect<T>(tmask, in_, b, y, x, xm);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = xm[i] > 0.f ? v[i] : 0.f;
+        }
+        Elem<T>::store(dst, v);
+    }
+}
+
+// ---------------------------------------------------------------- Cout == 1 wgrad
+// partial per (block g, channel group cg of 16): [16 c][KK] then [1] bias (cg == 0 only)
+template <typename T, int KS>
+__global__ __launch_bounds__(256) void image_out_wgrad_kernel(TV tx, const float* __restrict__ gimg, const float* __restrict__ yimg,
+                                                              float* __restrict__ partial, int tiles_x, int tpi, int total) {
+    constexpr int KK = KS * KS, P = KS / 2, IT = ITILE + KS - 1;
+    __shared__ float xsm[16][IT][IT + 1];
+    __shared__ float gsm[ITILE * ITILE];
+    const int tid = threadIdx.x, cg = blockIdx.y;
+    const int c = tid / KK, tap = tid % KK;
+    const bool wthread = tid < 16 * KK;
+    const bool bthread = tid == 16 * KK;
+    float acc = 0.f;
+    for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
+        const int in_ = tile / tpi, tt = tile % tpi;
+        const int y0 = (tt / tiles_x) * ITILE, x0 = (tt % tiles_x) * ITILE;
+        __syncthreads();
+        for (int e = tid; e < IT * IT * 2; e += 256) {
+            const int b = e / (IT * IT), p = e % (IT * IT);
+            float v[8];
+            const int xcb = cg * 2 + b;
+            if (xcb < tx.cb) load_act_reflect<T>(tx, in_, xcb, y0 + p / IT - P, x0 + p % IT - P, v);
+            else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) xsm[b * 8 + i][p / IT][p % IT] = v[i];
+        }
+        for (int e = tid; e < ITILE * ITILE; e += 256) {
+            const int yy = y0 + e / ITILE, xx = x0 + e % ITILE;
+            float v = 0.f;
+            if (yy < tx.h && xx < tx.w) {
+                const long long i = ((long long)in_ * tx.h + yy) * tx.w + xx;
+                v = gimg[i];
+                if (yimg != nullptr && !(yimg[i] > 0.f)) v = 0.f;
+            }
+            gsm[e] = v;
+        }
+        __syncthreads();
+        if (wthread) {
+            const int u = tap / KS, v = tap % KS;
+            for (int p = 0; p < ITILE * ITILE; ++p) acc = fmaf(gsm[p], xsm[c][p / ITILE + u][p % ITILE + v], acc);
+        } else if (bthread) {
+            for (int p = 0; p < ITILE * ITILE; ++p) acc += gsm[p];
+        }
+    }
+    float* dst = partial + ((long long)blockIdx.x * gridDim.y + cg) * (16 * KK + 1);
+    if (wthread || bthread) dst[tid] = acc;
+}
+
+template <int KS>
+__global__ void image_out_wgrad_reduce(const float* __restrict__ partial, float* __restrict__ dw, float* __restrict__ db,
+                                       int cin, int G, int n_cg, int accumulate) {
+    constexpr int KK = KS * KS, PER = 16 * KK + 1;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < cin * KK) {
+        const int c = idx / KK, tap = idx % KK, cg = c / 16, cc = c % 16;
+        float s = 0.f;
+        for (int g = 0; g < G; ++g) s += partial[((long long)g * n_cg + cg) * PER + cc * KK + tap];
+        dw[idx] = accumulate ? dw[idx] + s : s;
+    } else if (idx == cin * KK && db) {
+        float s = 0.f;
+        for (int g = 0; g < G; ++g) s += partial[((long long)g * n_cg + 0) * PER + 16 * KK];
+        db[0] = accumulate ? db[0] + s : s;
+    }
+}
+
+constexpr int IMG_G = 256;
+
+}  // namespace mmif
+
+using namespace mmif;
+
+#define DISPATCH_T_KS(dtype, ks, CALL)                 \
+    do {                                               \
+        if ((dtype) == MMIF_F32) {                     \
+            if ((ks) == 3) { CALL(float, 3); } else { CALL(float, 1); } \
+        } else {                                       \
+            if ((ks) == 3) { CALL(bf16_t, 3); } else { CALL(bf16_t, 1); } \
+        }                                              \
+    } while (0)
+
+extern "C" size_t mmif_conv2d_image_wgrad_workspace(int32_t c, int32_t ksize) {
+    return (size_t)IMG_G * cdiv(c, 16) * (16 * ksize * ksize + 16) * sizeof(float);
+}
+
+extern "C" int mmif_conv2d_image_in_fwd(const float* img, const float* w, const float* bias, const mmif_tensor* y,
+                                        int32_t cout, int32_t ksize, int32_t relu, void* stream) {
+    if (int rc = validate_tensor(y, "y")) return rc;
+    MMIF_REQUIRE(ksize == 1 || ksize == 3, "image_in_fwd: ksize must be 1 or 3");
+    MMIF_REQUIRE(y->halo == 0 && cout <= y->cb * 8 && cout > 0, "image_in_fwd: bad output view");
+    MMIF_REQUIRE(ksize == 1 || (y->h >= 2 && y->w >= 2), "reflect padding needs h,w >= 2");
+    TV ty = make_tv(y);
+    const int tiles_x = cdiv(ty.w, ITILE), tiles_y = cdiv(ty.h, ITILE);
+    const size_t shm = (size_t)(cout * ksize * ksize + cout) * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+#define CALL(T, KS) hipLaunchKernelGGL((image_in_fwd_kernel<T, KS>), dim3(tiles_x * tiles_y, ty.n), dim3(256), shm, st, img, ty, w, bias, cout, relu, tiles_x)
+    DISPATCH_T_KS(y->dtype, ksize, CALL);
+#undef CALL
+    return check_launch("image_in_fwd");
+}
+
+extern "C" int mmif_conv2d_image_in_wgrad(const float* img, const mmif_tensor* gy, float* dw, float* db, int32_t cout,
+                                          int32_t ksize, int32_t accumulate, void* workspace, size_t workspace_bytes,
+                                          void* stream) {
+    if (int rc = validate_tensor(gy, "gy")) return rc;
+    MMIF_REQUIRE(ksize == 1 || ksize == 3, "image_in_wgrad: ksize must be 1 or 3");
+    if (workspace_bytes < mmif_conv2d_image_wgrad_workspace(cout, ksize)) {
+        set_error("image_in_wgrad: workspace too small");
+        return MMIF_EWORKSPACE;
+    }
+    TV tg = make_tv(gy);
+    const int tiles_x = cdiv(tg.w, ITILE), tiles_y = cdiv(tg.h, ITILE);
+    const int tpi = tiles_x * tiles_y, total = tpi * tg.n;
+    const int G = total < IMG_G ? total : IMG_G;
+    const int n_og = cdiv(cout, 16);
+    hipStream_t st = (hipStream_t)stream;
+    float* ws = (float*)workspace;
+#define CALL(T, KS) hipLaunchKernelGGL((image_in_wgrad_kernel<T, KS>), dim3(G, n_og), dim3(256), 0, st, img, tg, ws, cout, tiles_x, tpi, total)
+    DISPATCH_T_KS(gy->dtype, ksize, CALL);
+#undef CALL
+    if (int rc = check_launch("image_in_wgrad")) return rc;
+    const int n = cout * ksize * ksize + cout;
+    if (ksize == 3) hipLaunchKernelGGL((image_in_wgrad_reduce<3>), dim3(cdiv(n, 256)), dim3(256), 0, st, ws, dw, db, cout, G, n_og, accumulate);
+    else hipLaunchKernelGGL((image_in_wgrad_reduce<1>), dim3(cdiv(n, 256)), dim3(256), 0, st, ws, dw, db, cout, G, n_og, accumulate);
+    return check_launch("image_in_wgrad_reduce");
+}
+
+extern "C" int mmif_conv2d_image_out_fwd(const mmif_tensor* x, const float* w, const float* bias, float* img, int32_t cin,
+                                         int32_t ksize, int32_t relu, void* stream) {
+    if (int rc = validate_tensor(x, "x")) return rc;
+    MMIF_REQUIRE(ksize == 1 || ksize == 3, "image_out_fwd: ksize must be 1 or 3");
+    MMIF_REQUIRE(x->halo == 0 && cin <= x->cb * 8 && cin > 0, "image_out_fwd: bad input view");
+    MMIF_REQUIRE(ksize == 1 || (x->h >= 2 && x->w >= 2), "reflect padding needs h,w >= 2");
+    TV tx = make_tv(x);
+    const int tiles_x = cdiv(tx.w, ITILE), tiles_y = cdiv(tx.h, ITILE);
+    const size_t shm = (size_t)cin * ksize * ksize * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+#define CALL(T, KS) hipLaunchKernelGGL((image_out_fwd_kernel<T, KS>), dim3(tiles_x * tiles_y, tx.n), dim3(256), shm, st, tx, w, bias, img, cin, relu, tiles_x)
+    DISPATCH_T_KS(x->dtype, ksize, CALL);
+#undef CALL
+    return check_launch("image_out_fwd");
+}
+
+extern "C" int mmif_conv2d_image_out_dgrad(const float* gimg, const float* y_img, const float* w, const mmif_tensor* x,
+                                           const mmif_tensor* gx, int32_t cin, int32_t ksize, uint64_t mask_bits,
+                                           uint64_t accum_bits, void* stream) {
+    if (int rc = validate_tensor(gx, "gx")) return rc;
+    MMIF_REQUIRE(ksize == 1 || ksize == 3, "image_out_dgrad: ksize must be 1 or 3");
+    MMIF_REQUIRE(gx->halo >= ksize / 2, "image_out_dgrad: gx needs halo >= ksize/2");
+    MMIF_REQUIRE(cin <= gx->cb * 8, "image_out_dgrad: gx view too small");
+    TV tgx = make_tv(gx);
+    TV tm = tgx;
+    if (mask_bits) {
+        MMIF_REQUIRE(x != nullptr, "image_out_dgrad: mask_bits set but x is NULL");
+        if (int rc = validate_tensor(x, "x")) return rc;
+        MMIF_REQUIRE(x->halo == 0 && x->dtype == gx->dtype && x->h == gx->h && x->w == gx->w && x->n == gx->n && x->cb >= gx->cb,
+                     "image_out_dgrad: x / gx mismatch");
+        tm = make_tv(x);
+    }
+    const int tiles_x = cdiv(tgx.ws, ITILE), tiles_y = cdiv(tgx.hs, ITILE);
+    const size_t shm = (size_t)cin * ksize * ksize * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+#define CALL(T, KS) hipLaunchKernelGGL((image_out_dgrad_kernel<T, KS>), dim3(tiles_x * tiles_y, tgx.n), dim3(256), shm, st, gimg, y_img, w, tm, tgx, cin, (unsigned long long)mask_bits, (unsigned long long)accum_bits, tiles_x)
+    DISPATCH_T_KS(gx->dtype, ksize, CALL);
+#undef CALL
+    return check_launch("image_out_dgrad");
+}
+
+extern "C" int mmif_conv2d_image_out_wgrad(const mmif_tensor* x, const float* gimg, const float* y_img, float* dw, float* db,
+                                           int32_t cin, int32_t ksize, int32_t accumulate, void* workspace,
+                                           size_t workspace_bytes, void* stream) {
+    if (int rc = validate_tensor(x, "x")) return rc;
+    MMIF_REQUIRE(ksize == 1 || ksize == 3, "image_out_wgrad: ksize must be 1 or 3");
+    MMIF_REQUIRE(x->halo == 0, "image_out_wgrad: x must be an activation (halo 0)");
+    if (workspace_bytes < mmif_conv2d_image_wgrad_workspace(cin, ksize)) {
+        set_error("image_out_wgrad: workspace too small");
+        return MMIF_EWORKSPACE;
+    }
+    TV tx = make_tv(x);
+    const int tiles_x = cdiv(tx.w, ITILE), tiles_y = cdiv(tx.h, ITILE);
+    const int tpi = tiles_x * tiles_y, total = tpi * tx.n;
+    const int G = total < IMG_G ? total : IMG_G;
+    const int n_cg = cdiv(cin, 16);
+    hipStream_t st = (hipStream_t)stream;
+    float* ws = (float*)workspace;
+#define CALL(T, KS) hipLaunchKernelGGL((image_out_wgrad_kernel<T, KS>), dim3(G, n_cg), dim3(256), 0, st, tx, gimg, y_img, ws, tiles_x, tpi, total)
+    DISPATCH_T_KS(x->dtype, ksize, CALL);
+#undef CALL
+    if (int rc = check_launch("image_out_wgrad")) return rc;
+    const int n = cin * ksize * ksize + 1;
+    if (ksize == 3) hipLaunchKernelGGL((image_out_wgrad_reduce<3>), dim3(cdiv(n, 256)), dim3(256), 0, st, ws, dw, db, cin, G, n_cg, accumulate);
+    else hipLaunchKernelGGL((image_out_wgrad_reduce<1>), dim3(cdiv(n, 256)), dim3(256), 0, st, ws, dw, db, cin, G, n_cg, accumulate);
+    return check_launch("image_out_wgrad_reduce");
+}

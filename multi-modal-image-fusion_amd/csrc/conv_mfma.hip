@@ -1,0 +1,576 @@
+// bf16 MFMA convolution kernels for gfx950 (v_mfma_f32_16x16x32_bf16, fp32 accumulate).
+//
+// Implicit GEMM, one formulation for forward and dgrad (see conv_valu.hip for the maths):
+//     D[oc][pixel] = sum_{tap, ic} Wk[tap][ic][oc] * IN(pixel + tap - p)[ic]
+//   M = output channels (A operand = packed weights), N = 16 consecutive pixels of one row
+//   (B operand = input tile), K = (tap, 8-channel block) "k-groups": lane group g = lane>>4 of a
+//   k-step handles k-group 4*step+g, i.e. ONE 16-byte granule per lane per operand.
+// Data layout: HBM tensors are blocked NHWC ([n][C/8][H][W][8]); the LDS tiles keep the same
+//   granule structure ([channel block][tile row][tile col][8 ch], plane stride = 0 mod 256 B), so
+//   staging is a pure 16-byte-granule copy with reflect / zero-fill / halo-fold applied to the
+//   SOURCE index only, and every ds_read_b128 operand fetch is bank-conflict free (a lane group's
+//   two k-groups read complementary pixel sets of planes that alias the same banks).
+// Block = 4 waves, output tile 16x16 pixels x (MF*16) channels; wave w owns rows 4w..4w+3.
+// K is consumed in chunks of 4 channel blocks (32 channels x k*k taps): per chunk the input halo
+//   tile (18x18 granules per block) and the packed weight slab are staged to LDS, then
+//   nsteps = ceil(k*k*ncb/4) MFMA k-steps run out of LDS.  Two blocks per CU overlap each
+//   other's staging and MFMA phases.
+//
+// wgrad (dW = sum_pixels g (x) xpad) has K = pixels: both operands are "k-major" in the blocked
+// layout, so fragments are fetched with the gfx950 LDS transpose read ds_read_b64_tr_b16
+// (4 pixels x 16 channels per 16-lane group -> per lane 4 consecutive pixels of one channel).
+#include "common.hpp"
+
+namespace mmif {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+#define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+
+constexpr int MT = 16;        // output tile edge
+constexpr int CHUNK_CB = 4;   // channel blocks per K chunk
+
+__host__ __device__ constexpr int plane_granules(int ks) { return ks == 3 ? 336 : 256; }  // bytes = 0 mod 256
+
+static inline int pick_mf(int n_out) {
+    const int fr = (n_out + 15) / 16;
+    return fr <= 4 ? fr : 4;
+}
+static inline int n_mblocks(int n_out) {
+    const int fr = (n_out + 15) / 16, mf = pick_mf(n_out);
+    return (fr + mf - 1) / mf;
+}
+// packed image: for each chunk, nkg_pad(chunk) k-group planes of [M16p][8] bf16, M16p = n_mblocks*MF*16
+static size_t packed_bytes(int n_out, int n_in, int ks) {
+    const int ncb = (n_in + 7) / 8, kk = ks * ks;
+    const size_t m16p = (size_t)n_mblocks(n_out) * pick_mf(n_out) * 16;
+    size_t kg = 0;
+    for (int c0 = 0; c0 < ncb; c0 += CHUNK_CB) {
+        const int n = ncb - c0 < CHUNK_CB ? ncb - c0 : CHUNK_CB;
+        kg += (size_t)((kk * n + 3) / 4) * 4;
+    }
+    return kg * m16p * 16;
+}
+
+// ------------------------------------------------------------------ weight packing
+// dgrad == 0: out channel = o, in channel = c, Wk[u][v] = W[o][c][u][v]
+// dgrad == 1: out channel = c, in channel = o, Wk[u][v] = W[o][c][k-1-u][k-1-v]
+__global__ void pack_weights_kernel(const float* __restrict__ w, int cout, int cin, int ks, int dgrad, int mf,
+                                    int m16p, bf16_t* __restrict__ dst, long long total) {
+    const int kk = ks * ks;
+    const int n_out = dgrad ? cin : cout, n_in = dgrad ? cout : cin;
+    const int ncb = (n_in + 7) / 8;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int e = idx & 7;
+        const long long row = idx >> 3;             // (global k-group plane, oc row)
+        const int oc = (int)(row % m16p);
+        long long kgp = row / m16p;                 // padded k-group index over all chunks
+        // locate the chunk
+        int c0 = 0, n = 0, kg = 0;
+        for (c0 = 0; c0 < ncb; c0 += CHUNK_CB) {
+            n = ncb - c0 < CHUNK_CB ? ncb - c0 : CHUNK_CB;
+            const int pad = ((kk * n + 3) / 4) * 4;
+            if (kgp < pad) { kg = (int)kgp; break; }
+            kgp -= pad;
+        }
+        float val = 0.f;
+        if (kg < kk * n) {
+            const int tap = kg / n, cb = kg % n;
+            const int u = tap / ks, v = tap % ks;
+            const int ic = (c0 + cb) * 8 + e;
+            if (oc < n_out && ic < n_in) {
+                if (dgrad) val = w[(((long long)ic * cin + oc) * ks + (ks - 1 - u)) * ks + (ks - 1 - v)];
+                else val = w[(((long long)oc * cin + ic) * ks + u) * ks + v];
+            }
+        }
+        dst[idx] = f32_to_bf16(val);
+    }
+    (void)mf;
+}
+
+// ------------------------------------------------------------------ granule loaders (bf16, raw uint4)
+__device__ inline uint4 ld_gran(const TV& t, int in_, int c, int ys, int xs) {
+    return *reinterpret_cast<const uint4*>(t.base + t.gidx(in_, c, ys, xs) * 16);
+}
+__device__ inline uint4 load_in_reflect(const TV& t, int in_, int c, int y, int x) {
+    y = min(max(reflect_idx(y, t.h), 0), t.h - 1);
+    x = min(max(reflect_idx(x, t.w), 0), t.w - 1);
+    return ld_gran(t, in_, c, y, x);
+}
+__device__ inline uint4 load_in_gradfold(const TV& t, int in_, int c, int y, int x) {
+    if (y < 0 || y >= t.h || x < 0 || x >= t.w) return make_uint4(0, 0, 0, 0);
+    if (t.halo == 0) return ld_gran(t, in_, c, y, x);
+    const bool by = (y == 1) || (y == t.h - 2), bx = (x == 1) || (x == t.w - 2);
+    if (!by && !bx) return ld_gran(t, in_, c, y + 1, x + 1);
+    float v[8];
+    load_grad_fold<bf16_t>(t, in_, c, y, x, v);  // fp32 fold, rounded once
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f32_to_bf16(v[2 * i]) | ((uint32_t)f32_to_bf16(v[2 * i + 1]) << 16);
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// ------------------------------------------------------------------ forward / dgrad kernel
+template <int KS, int MF, bool DGRAD>
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(TV tin, TV tout, TV tmask, const uint4* __restrict__ wpk,
+                                                            const float* __restrict__ bias, int n_out, int m16p,
+                                                            int relu, unsigned long long mask_bits,
+                                                            unsigned long long accum_bits, int tiles_x) {
+    constexpr int KK = KS * KS, P = KS / 2;
+    constexpr int TP = MT + KS - 1;             // input tile edge (18 / 16)
+    constexpr int PL = plane_granules(KS);      // granules per LDS plane
+    constexpr int MAXKG = KK * CHUNK_CB;        // 36 / 4
+    constexpr int MAXKGP = (MAXKG + 3) / 4 * 4;
+    constexpr int NIN = (CHUNK_CB * TP * TP + 255) / 256;   // staged input granules per thread per chunk
+    constexpr int NW = (MAXKGP * MF * 16 + 255) / 256;      // staged weight granules per thread per chunk
+    __shared__ __attribute__((aligned(16))) uint4 s_in[CHUNK_CB * PL];
+    __shared__ __attribute__((aligned(16))) uint4 s_w[MAXKGP * MF * 16];
+    __shared__ int2 s_tab[MAXKGP];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int tile_x = blockIdx.x % tiles_x, tile_y = blockIdx.x / tiles_x;
+    const int in_ = blockIdx.y, mb = blockIdx.z;
+    const int iy0 = tile_y * MT - tout.halo - P, ix0 = tile_x * MT - tout.halo - P;  // logical origin of the input tile
+
+    // ---- per-thread staging descriptors (chunk independent) ----
+    // input element i of this thread: chunk-local channel block icb[i], LDS slot ilds[i], and either a
+    // plane-relative granule offset (imode 1), a zero (imode 0) or a halo-fold slow path (imode 2)
+    int idesc[NIN], ioff[NIN];  // idesc = LDS slot | chunk-local channel block << 16 | mode << 20
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
+        const int e = tid + 256 * i;
+        const int cb = e / (TP * TP), p = e % (TP * TP);
+        const int py = p / TP, px = p % TP;
+        int mode;  // cb >= CHUNK_CB for the tail elements of the last iteration
+        int y = iy0 + py, x = ix0 + px;
+        if (!DGRAD) {
+            y = min(max(reflect_idx(y, tin.h), 0), tin.h - 1);
+            x = min(max(reflect_idx(x, tin.w), 0), tin.w - 1);
+            mode = 1;
+            ioff[i] = y * tin.ws + x;
+        } else {
+            const bool inside = y >= 0 && y < tin.h && x >= 0 && x < tin.w;
+            const bool border = tin.halo && ((y == 1) || (y == tin.h - 2) || (x == 1) || (x == tin.w - 2));
+            mode = !inside ? 0 : (border ? 2 : 1);
+            ioff[i] = (y + tin.halo) * tin.ws + x + tin.halo;
+        }
+        idesc[i] = (cb * PL + p) | (cb << 16) | (mode << 20);
+    }
+    const char* in_img = tin.base + ((long long)in_ * tin.img + (long long)tin.cb_off * tin.plane) * 16;
+    // does this block's input tile contain a fold row/col (1 or h-2 / w-2) of a halo-1 gradient?
+    const bool fold_tile = DGRAD && tin.halo &&
+                           ((iy0 <= 1 && 1 < iy0 + TP) || (iy0 <= tin.h - 2 && tin.h - 2 < iy0 + TP) ||
+                            (ix0 <= 1 && 1 < ix0 + TP) || (ix0 <= tin.w - 2 && tin.w - 2 < ix0 + TP));
+
+    f32x4 acc[MF][4];
+#pragma unroll
+    for (int m = 0; m < MF; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int ncb_tot = tin.cb;
+    const char* in_lane = reinterpret_cast<const char*>(s_in) + ((wave * 4) * TP + j) * 16;
+    const char* w_lane = reinterpret_cast<const char*>(s_w) + j * 16;
+
+    uint4 rin[NIN], rw[NW];
+    auto prefetch = [&](int c0, long long wchunk_off) {
+        const int ncb = min(CHUNK_CB, ncb_tot - c0);
+        const int nkgp = (KK * ncb + 3) / 4 * 4;
+#pragma unroll
+        for (int i = 0; i < NIN; ++i) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            const int cb = (idesc[i] >> 16) & 15, mode = idesc[i] >> 20;
+            if (cb < ncb) {
+                if (mode >= 1) v = *reinterpret_cast<const uint4*>(in_img + ((long long)(c0 + cb) * tin.plane + ioff[i]) * 16);
+            }
+            rin[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int e = tid + 256 * i;
+            const int kg = e / (MF * 16), r = e % (MF * 16);
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (kg < nkgp) v = wpk[wchunk_off + (long long)kg * m16p + mb * MF * 16 + r];
+            rw[i] = v;
+        }
+    };
+
+    long long wchunk_off = 0;  // granule offset of the current chunk in the packed weights
+    prefetch(0, 0);
+    for (int c0 = 0; c0 < ncb_tot; c0 += CHUNK_CB) {
+        const int ncb = min(CHUNK_CB, ncb_tot - c0);
+        const int nkg = KK * ncb, nkgp = (nkg + 3) / 4 * 4;
+        __syncthreads();  // previous chunk's MFMAs are done with the LDS tiles
+#pragma unroll
+        for (int i = 0; i < NIN; ++i)
+            if (((idesc[i] >> 16) & 15) < ncb) s_in[idesc[i] & 0xffff] = rin[i];
+        if (DGRAD && fold_tile) {
+            // rare (border tiles of a padded-domain gradient): pixels on row/col 1 or h-2/w-2 get the
+            // mirrored halo folded in; deliberately NOT unrolled (keeps the hot path's registers free)
+#pragma unroll 1
+            for (int e = tid; e < ncb * TP * TP; e += 256) {
+                const int cb = e / (TP * TP), p = e % (TP * TP);
+                const int y = iy0 + p / TP, x = ix0 + p % TP;
+                const bool inside = y >= 0 && y < tin.h && x >= 0 && x < tin.w;
+                if (inside && ((y == 1) || (y == tin.h - 2) || (x == 1) || (x == tin.w - 2)))
+                    s_in[cb * PL + p] = load_in_gradfold(tin, in_, c0 + cb, y, x);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int e = tid + 256 * i;
+            if (e < nkgp * MF * 16) s_w[e] = rw[i];
+        }
+        // k-group offset table: .x = byte offset into s_in, .y = byte offset into s_w
+        if (tid < nkgp) {
+            int tap = 0, cb = 0;
+            if (tid < nkg) { tap = tid / ncb; cb = tid % ncb; }
+            s_tab[tid] = make_int2((cb * PL + (tap / KS) * TP + (tap % KS)) * 16, tid * MF * 256);
+        }
+        __syncthreads();
+        wchunk_off += (long long)nkgp * m16p;
+        if (c0 + CHUNK_CB < ncb_tot) prefetch(c0 + CHUNK_CB, wchunk_off);  // in flight during the MFMAs below
+        const int nsteps = nkgp >> 2;
+        int2 off = s_tab[g];
+        for (int s = 0; s < nsteps; ++s) {
+            const int2 nxt = s_tab[min(4 * (s + 1), nkgp - 4) + g];
+            bf16x8 b[4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) b[n] = *reinterpret_cast<const bf16x8*>(in_lane + off.x + n * TP * 16);
+#pragma unroll
+            for (int m = 0; m < MF; ++m) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(w_lane + off.y + m * 256);
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[n], acc[m][n], 0, 0, 0);
+            }
+            off = nxt;
+        }
+    }
+
+    // ---- epilogue: lane (g, j) holds oc = 16*m + 4*g + r (r = 0..3) of pixel (row 4*wave + n, col j) ----
+    const int oxs = tile_x * MT + j;
+    if (oxs >= tout.ws) return;
+#pragma unroll
+    for (int m = 0; m < MF; ++m) {
+        const int ocb = (mb * MF + m) * 2 + (g >> 1);  // channel block inside the out view
+        if (ocb >= tout.cb) continue;
+        const int oc0 = ocb * 8 + (g & 1) * 4;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (!DGRAD && bias != nullptr) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bv[r] = (oc0 + r < n_out) ? bias[oc0 + r] : 0.f;
+        }
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int oys = tile_y * MT + wave * 4 + n;
+            if (oys >= tout.hs) continue;
+            float v[4] = {acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]};
+            char* dst = tout.base + tout.gidx(in_, ocb, oys, oxs) * 16 + (g & 1) * 8;
+            if (!DGRAD) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float t = v[r] + bv[r];
+                    if (relu) t = fmaxf(t, 0.f);
+                    v[r] = (oc0 + r < n_out) ? t : 0.f;
+                }
+            } else {
+                if ((accum_bits >> ocb) & 1ull) {
+                    const uint2 o = *reinterpret_cast<const uint2*>(dst);
+                    v[0] += __uint_as_float(o.x << 16);
+                    v[1] += __uint_as_float(o.x & 0xffff0000u);
+                    v[2] += __uint_as_float(o.y << 16);
+                    v[3] += __uint_as_float(o.y & 0xffff0000u);
+                }
+                if ((mask_bits >> ocb) & 1ull) {
+                    const int y = min(max(reflect_idx(oys - tout.halo, tmask.h), 0), tmask.h - 1);
+                    const int x = min(max(reflect_idx(oxs - tout.halo, tmask.w), 0), tmask.w - 1);
+                    const uint2 xm = *reinterpret_cast<const uint2*>(tmask.base + tmask.gidx(in_, ocb, y, x) * 16 + (g & 1) * 8);
+                    // bf16 > 0  <=>  sign bit clear and magnitude non-zero
+                    const uint32_t q[4] = {xm.x & 0xffffu, xm.x >> 16, xm.y & 0xffffu, xm.y >> 16};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (!((q[r] & 0x8000u) == 0 && (q[r] & 0x7fffu) != 0)) v[r] = 0.f;
+                }
+            }
+            uint2 o;
+            o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+            o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+            *reinterpret_cast<uint2*>(dst) = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ wgrad kernel (K = pixels)
+// block: (pixel-tile group, input-channel group of 16, output-channel group of MFW*16); wave w
+// consumes k-steps 2w, 2w+1 of each 16x16 tile (k-step = 2 tile rows = 32 pixels):
+//   lane group g of a k-step: tile row 2s + (g>>1), cols 8*(g&1) .. +7
+// A = g^T (oc x pixels), B = shifted x (pixels x (tap, ic)); acc[m][tap] 16x16 blocks.
+constexpr int WG_XPL = 324;   // x-tile plane stride in granules  (5184 B = 64 mod 256)
+constexpr int WG_GPL = 260;   // g-tile plane stride in granules  (4160 B = 64 mod 256)
+
+template <int KS, int MFW>
+__global__ __launch_bounds__(256) void wgrad_mfma_kernel(TV tx, TV tg, float* __restrict__ partial, int tiles_x,
+                                                         int tpi, int total) {
+    constexpr int KK = KS * KS, P = KS / 2, TP = MT + KS - 1;
+    constexpr int XPL = KS == 3 ? WG_XPL : WG_GPL;
+    constexpr int PER = MFW * 16 * 16 * KK + MFW * 16;  // floats per block partial
+    constexpr int TILE_BYTES = (2 * XPL + MFW * 2 * WG_GPL) * 16;
+    constexpr int RED_BYTES = MFW * 16 * 16 * KK * 4 + MFW * 16 * 4;
+    constexpr int SM_BYTES = TILE_BYTES > RED_BYTES ? TILE_BYTES : RED_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[SM_BYTES];
+    uint4* s_x = reinterpret_cast<uint4*>(smem);
+    uint4* s_g = s_x + 2 * XPL;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sl = lane & 15, g = lane >> 4;
+    const int icg = blockIdx.y, ocg = blockIdx.z;
+    const int xcb0 = icg * 2, gcb0 = ocg * MFW * 2;
+
+    f32x4 acc[MFW][KK];
+    f32x4 accb[MFW];
+#pragma unroll
+    for (int m = 0; m < MFW; ++m) {
+        accb[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < KK; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    // constant all-ones bf16 operand for the bias-gradient column sums
+    const uint4 ones_u = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_u);
+
+    // per-lane transpose-read addressing: in-group lane sl supplies row (sl>>2) = pixel, chunk (sl&3)
+    const int tr_row = sl >> 2, tr_c = sl & 3;
+    const int lane_plane = tr_c >> 1, lane_byte = (tr_c & 1) * 8;
+
+    constexpr int NX = (2 * TP * TP + 255) / 256;      // x granules per thread per tile
+    constexpr int NG = MFW * 2;                         // g granules per thread per tile (256 px per plane)
+    uint4 rx[NX], rg[NG];
+    auto prefetch = [&](int tile) {
+        const int in_ = tile / tpi, tt = tile % tpi;
+        const int y0 = (tt / tiles_x) * MT, x0 = (tt % tiles_x) * MT;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int e = tid + 256 * i;
+            const int cb = e / (TP * TP), p = e % (TP * TP);
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (cb < 2 && xcb0 + cb < tx.cb) v = load_in_reflect(tx, in_, xcb0 + cb, y0 + p / TP - P, x0 + p % TP - P);
+            rx[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (gcb0 + i < tg.cb) v = load_in_gradfold(tg, in_, gcb0 + i, y0 + tid / MT, x0 + tid % MT);
+            rg[i] = v;
+        }
+    };
+    if ((int)blockIdx.x < total) prefetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int e = tid + 256 * i;
+            const int cb = e / (TP * TP), p = e % (TP * TP);
+            if (cb < 2) s_x[cb * XPL + p] = rx[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NG; ++i) s_g[i * WG_GPL + tid] = rg[i];
+        __syncthreads();
+        if (tile + (int)gridDim.x < total) prefetch(tile + gridDim.x);  // in flight during the MFMAs below
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+            const int s = wave * 2 + ss;
+            const int row = 2 * s + (g >> 1), col0 = 8 * (g & 1);
+            // A fragments: g^T, M-frag m = planes 2m, 2m+1
+            bf16x8 a[MFW];
+#pragma unroll
+            for (int m = 0; m < MFW; ++m) {
+                const char* base = reinterpret_cast<const char*>(s_g) +
+                                   (((2 * m + lane_plane) * WG_GPL) + row * MT + col0 + tr_row) * 16 + lane_byte;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, base));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, base + 4 * 16));
+                typedef __attribute__((ext_vector_type(8))) short s16x8;
+                const s16x8 c = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                a[m] = __builtin_bit_cast(bf16x8, c);
+            }
+            if (icg == 0) {
+#pragma unroll
+                for (int m = 0; m < MFW; ++m) accb[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], ones, accb[m], 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < KK; ++t) {
+                const int u = t / KS, v = t % KS;
+                const char* base = reinterpret_cast<const char*>(s_x) +
+                                   ((lane_plane * XPL) + (row + u) * TP + col0 + v + tr_row) * 16 + lane_byte;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, base));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, base + 4 * 16));
+                typedef __attribute__((ext_vector_type(8))) short s16x8;
+                const s16x8 c = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                const bf16x8 b = __builtin_bit_cast(bf16x8, c);
+#pragma unroll
+                for (int m = 0; m < MFW; ++m) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], b, acc[m][t], 0, 0, 0);
+            }
+        }
+    }
+    // ---- combine the 4 waves (K split) through LDS, then write the block partial ----
+    // lane (g, sl) reg r holds (oc = 16m + 4g + r, ic = sl) for tap t; bias sums: column sl (all equal)
+    float* red = reinterpret_cast<float*>(smem);  // [MFW*16 oc][16 ic][KK] + [MFW*16]
+    for (int w = 0; w < 4; ++w) {
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int m = 0; m < MFW; ++m) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int oc = 16 * m + 4 * g + r;
+#pragma unroll
+                    for (int t = 0; t < KK; ++t) {
+                        float* p = &red[(oc * 16 + sl) * KK + t];
+                        *p = (w == 0 ? 0.f : *p) + acc[m][t][r];
+                    }
+                    if (sl == 0) {
+                        float* p = &red[MFW * 16 * 16 * KK + oc];
+                        *p = (w == 0 ? 0.f : *p) + accb[m][r];
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    float* dst = partial + (((long long)blockIdx.x * gridDim.y + icg) * gridDim.z + ocg) * PER;
+    for (int e = tid; e < PER; e += 256) dst[e] = red[e];
+}
+
+template <int KS, int MFW>
+__global__ void wgrad_mfma_reduce(const float* __restrict__ partial, float* __restrict__ dw, float* __restrict__ db,
+                                  int cin, int cout, int G, int n_icg, int n_ocg, int accumulate) {
+    constexpr int KK = KS * KS;
+    constexpr int PER = MFW * 16 * 16 * KK + MFW * 16;
+    const int total_w = cout * cin * KK;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < total_w) {
+        const int tap = idx % KK, c = (idx / KK) % cin, o = idx / (KK * cin);
+        const int icg = c / 16, ic = c % 16, ocg = o / (MFW * 16), oc = o % (MFW * 16);
+        float s = 0.f;
+        for (int gi = 0; gi < G; ++gi) s += partial[(((long long)gi * n_icg + icg) * n_ocg + ocg) * PER + (oc * 16 + ic) * KK + tap];
+        dw[idx] = accumulate ? dw[idx] + s : s;
+    } else if (idx < total_w + cout && db != nullptr) {
+        const int o = idx - total_w;
+        const int ocg = o / (MFW * 16), oc = o % (MFW * 16);
+        float s = 0.f;
+        for (int gi = 0; gi < G; ++gi) s += partial[(((long long)gi * n_icg + 0) * n_ocg + ocg) * PER + MFW * 16 * 16 * KK + oc];
+        db[o] = accumulate ? db[o] + s : s;
+    }
+}
+
+// ------------------------------------------------------------------ host side
+bool conv_mfma_supported(bool dgrad, int ks, int cin, int cout) {
+    (void)dgrad;
+    return (ks == 1 || ks == 3) && cin % 8 == 0 && cin >= 8 && cout >= 8;
+}
+
+template <int KS, int MF>
+static int launch_conv_mfma(bool dgrad, const TV& tin, const TV& tout, const TV& tmask, const void* wpk, const float* bias,
+                            int n_out, int relu, uint64_t mask_bits, uint64_t accum_bits, hipStream_t st) {
+    const int tiles_x = cdiv(tout.ws, MT), tiles_y = cdiv(tout.hs, MT);
+    const int nmb = n_mblocks(n_out);
+    const int m16p = nmb * MF * 16;
+    dim3 grid(tiles_x * tiles_y, tout.n, nmb);
+    if (dgrad)
+        hipLaunchKernelGGL((conv_mfma_kernel<KS, MF, true>), grid, dim3(256), 0, st, tin, tout, tmask, (const uint4*)wpk, bias,
+                           n_out, m16p, relu, (unsigned long long)mask_bits, (unsigned long long)accum_bits, tiles_x);
+    else
+        hipLaunchKernelGGL((conv_mfma_kernel<KS, MF, false>), grid, dim3(256), 0, st, tin, tout, tmask, (const uint4*)wpk, bias,
+                           n_out, m16p, relu, (unsigned long long)mask_bits, (unsigned long long)accum_bits, tiles_x);
+    return check_launch(dgrad ? "conv_mfma dgrad" : "conv_mfma fwd");
+}
+
+int conv_mfma(bool dgrad, int ks, const TV& tin, const TV& tout, const TV& tmask, const void* w_packed, const float* bias,
+              int cin, int cout, int relu, uint64_t mask_bits, uint64_t accum_bits, hipStream_t st) {
+    const int n_out = dgrad ? cin : cout;
+    const int mf = pick_mf(n_out);
+#define GO(KS_, MF_) return launch_conv_mfma<KS_, MF_>(dgrad, tin, tout, tmask, w_packed, bias, n_out, relu, mask_bits, accum_bits, st)
+    if (ks == 3) {
+        switch (mf) { case 1: GO(3, 1); case 2: GO(3, 2); case 3: GO(3, 3); default: GO(3, 4); }
+    } else {
+        switch (mf) { case 1: GO(1, 1); case 2: GO(1, 2); case 3: GO(1, 3); default: GO(1, 4); }
+    }
+#undef GO
+}
+
+static inline int pick_mfw(int cout) { return cout <= 16 ? 1 : (cout <= 32 ? 2 : 4); }
+constexpr int WG_MAX_G = 1024;
+
+static int wgrad_G(int cin, int cout) {
+    const int nb = cdiv(cin, 16) * cdiv(cout, pick_mfw(cout) * 16);
+    int G = 1024 / nb;
+    if (G < 32) G = 32;
+    if (G > WG_MAX_G) G = WG_MAX_G;
+    return G;
+}
+
+bool wgrad_mfma_supported(int ks, int cin, int cout) { return (ks == 1 || ks == 3) && cin % 8 == 0 && cin >= 8 && cout >= 8; }
+
+size_t wgrad_mfma_workspace(int cin, int cout, int ks) {
+    const int mfw = pick_mfw(cout);
+    const size_t per = (size_t)mfw * 16 * 16 * ks * ks + mfw * 16;
+    return (size_t)wgrad_G(cin, cout) * cdiv(cin, 16) * cdiv(cout, mfw * 16) * per * sizeof(float);
+}
+
+template <int KS, int MFW>
+static int launch_wgrad_mfma(const TV& tx, const TV& tg, float* dw, float* db, int cin, int cout, int accumulate, float* ws,
+                             hipStream_t st) {
+    const int tiles_x = cdiv(tx.w, MT), tiles_y = cdiv(tx.h, MT);
+    const int tpi = tiles_x * tiles_y, total = tpi * tx.n;
+    int G = wgrad_G(cin, cout);
+    if (G > total) G = total;
+    const int n_icg = cdiv(cin, 16), n_ocg = cdiv(cout, MFW * 16);
+    hipLaunchKernelGGL((wgrad_mfma_kernel<KS, MFW>), dim3(G, n_icg, n_ocg), dim3(256), 0, st, tx, tg, ws, tiles_x, tpi, total);
+    if (int rc = check_launch("wgrad_mfma")) return rc;
+    const int n = cout * cin * KS * KS + cout;
+    hipLaunchKernelGGL((wgrad_mfma_reduce<KS, MFW>), dim3(cdiv(n, 256)), dim3(256), 0, st, ws, dw, db, cin, cout, G, n_icg, n_ocg,
+                       accumulate);
+    return check_launch("wgrad_mfma_reduce");
+}
+
+int wgrad_mfma(int ks, const TV& tx, const TV& tg, float* dw, float* db, int cin, int cout, int accumulate, float* ws,
+               hipStream_t st) {
+    const int mfw = pick_mfw(cout);
+#define GO(KS_, M_) return launch_wgrad_mfma<KS_, M_>(tx, tg, dw, db, cin, cout, accumulate, ws, st)
+    if (ks == 3) {
+        switch (mfw) { case 1: GO(3, 1); case 2: GO(3, 2); default: GO(3, 4); }
+    } else {
+        switch (mfw) { case 1: GO(1, 1); case 2: GO(1, 2); default: GO(1, 4); }
+    }
+#undef GO
+}
+
+}  // namespace mmif
+
+using namespace mmif;
+
+extern "C" size_t mmif_packed_weight_bytes(int32_t cout, int32_t cin, int32_t ksize) {
+    const size_t a = packed_bytes(cout, cin, ksize), b = packed_bytes(cin, cout, ksize);
+    return a > b ? a : b;
+}
+
+extern "C" int mmif_pack_weights(const float* w, int32_t cout, int32_t cin, int32_t ksize, void* packed_fwd, void* packed_dgrad,
+                                 void* stream) {
+    MMIF_REQUIRE(ksize == 1 || ksize == 3, "pack_weights: ksize must be 1 or 3");
+    MMIF_REQUIRE(w != nullptr && cout > 0 && cin > 0, "pack_weights: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    for (int d = 0; d < 2; ++d) {
+        void* dst = d ? packed_dgrad : packed_fwd;
+        if (dst == nullptr) continue;
+        const int n_out = d ? cin : cout, n_in = d ? cout : cin;
+        const long long total = (long long)(packed_bytes(n_out, n_in, ksize) / 2);
+        const int mf = pick_mf(n_out), m16p = n_mblocks(n_out) * mf * 16;
+        int nb = (int)((total + 255) / 256);
+        if (nb > 2048) nb = 2048;
+        hipLaunchKernelGGL(pack_weights_kernel, dim3(nb), dim3(256), 0, st, w, cout, cin, ksize, d, mf, m16p, (bf16_t*)dst, total);
+        if (int rc = check_launch("pack_weights")) return rc;
+    }
+    return MMIF_OK;
+}

@@ -1,0 +1,404 @@
+// Fusion losses on fp32 images [n][h][w]: SSIM (11x11 Gaussian, valid), max/avg pixel L1/L2,
+// Sobel-gradient L1/L2 -- each computes the loss value AND its gradient w.r.t. the fused image
+// in the same call (reference: core/loss.py:52-110,240-344,361-385; maths in DESIGN.md / SURVEY A.4-A.5).
+// All reductions: per-block partial (wave shuffles + LDS) -> fixed-order second stage; no float atomics.
+#include <math.h>
+
+#include "common.hpp"
+
+namespace mmif {
+
+struct Win11 {
+    float t[11];
+};
+
+constexpr int LT = 16;            // tile edge
+constexpr int WIN = 11;
+constexpr int LIN = LT + WIN - 1; // 26
+
+// ------------------------------------------------------------------ SSIM, pass 1
+// per map pixel: S(x1,f) + S(x2,f) (block partial) and the adjoint inputs
+//   mA = Ap1 + Ap2, mB = Bp1 + Bp2, mC1 = Cp1, mC2 = Cp2   
+__global__ __launch_bounds__(256) void ssim_stats_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
+                                                         const float* __restrict__ f, int H, int W, Win11 win, float C1,
+                                                         float C2, float* __restrict__ maps /* [4][n][Hm][Wm] or null */,
+                                                         float* __restrict__ partial, int tiles_x) {
+    __shared__ float in[3][LIN][LIN + 1];
+    __shared__ float hb[8][LIN][LT + 1];
+    __shared__ float red[16];
+    const int Hm = H - WIN + 1, Wm = W - WIN + 1;
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int mx0 = (blockIdx.x % tiles_x) * LT, my0 = (blockIdx.x / tiles_x) * LT;
+    const int in_ = blockIdx.y;
+    const long long ibase = (long long)in_ * H * W;
+    for (int e = tid; e < LIN * LIN; e += 256) {
+        const int py = e / LIN, px = e % LIN;
+        const int y = my0 + py, x = mx0 + px;
+        const bool ok = (y < H) && (x < W);
+        const long long i = ibase + (long long)y * W + x;
+        in[0][py][px] = ok ? x1[i] : 0.f;
+        in[1][py][px] = ok ? x2[i] : 0.f;
+        in[2][py][px] = ok ? f[i] : 0.f;
+    }
+    __syncthreads();
+    // horizontal 11-tap pass: 26 rows x 16 cols x 8 quantities
+    for (int e = tid; e < LIN * LT; e += 256) {
+        const int py = e / LT, px = e % LT;
+        float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < WIN; ++k) {
+            const float a = in[0][py][px + k], b = in[1][py][px + k], c = in[2][py][px + k], wk = win.t[k];
+            s[0] = fmaf(wk, a, s[0]);
+            s[1] = fmaf(wk, b, s[1]);
+            s[2] = fmaf(wk, c, s[2]);
+            s[3] = fmaf(wk, a * a, s[3]);
+            s[4] = fmaf(wk, b * b, s[4]);
+            s[5] = fmaf(wk, c * c, s[5]);
+            s[6] = fmaf(wk, a * c, s[6]);
+            s[7] = fmaf(wk, b * c, s[7]);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) hb[q][py][px] = s[q];
+    }
+    __syncthreads();
+    float m[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < WIN; ++k) {
+        const float wk = win.t[k];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) m[q] = fmaf(wk, hb[q][ty + k][tx], m[q]);
+    }
+    const int my = my0 + ty, mx = mx0 + tx;
+    const bool valid = (my < Hm) && (mx < Wm);
+    float ssum = 0.f;
+    if (valid) {
+        const float mu1 = m[0], mu2 = m[1], muf = m[2];
+        const float sf_raw = m[5] - muf * muf;
+        const float sf = fmaxf(sf_raw, 0.f);
+        const float kf = sf_raw > 0.f ? 1.f : 0.f;
+        float A = 0.f, B = 0.f, Cs[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const float mux = s == 0 ? mu1 : mu2;
+            const float ex2 = s == 0 ? m[3] : m[4];
+            const float exf = s == 0 ? m[6] : m[7];
+            const float sx = fmaxf(ex2 - mux * mux, 0.f);
+            const float sxf = exf - mux * muf;
+            const float m1 = 2.f * mux * muf + C1, m2 = mux * mux + muf * muf + C1;
+            const float v1 = 2.f * sxf + C2, v2 = sx + sf + C2;
+            const float inv = 1.f / (m2 * v2);
+            const float S = m1 * v1 * inv;
+            ssum += S;
+            const float Bp = -(S / v2) * kf;
+            const float Cp = 2.f * m1 * inv;
+            const float Ap = 2.f * mux * v1 * inv - 2.f * muf * S / m2 - 2.f * mux * m1 * inv - 2.f * muf * Bp;
+            A += Ap;
+            B += Bp;
+            Cs[s] = Cp;
+        }
+        if (maps != nullptr) {
+            const long long msz = (long long)gridDim.y * Hm * Wm;
+            const long long mi = ((long long)in_ * Hm + my) * Wm + mx;
+            maps[mi] = A;
+            maps[msz + mi] = B;
+            maps[2 * msz + mi] = Cs[0];
+            maps[3 * msz + mi] = Cs[1];
+        }
+    }
+    const float bs = block_sum(ssum, red);
+    if (tid == 0) partial[(long long)in_ * gridDim.x + blockIdx.x] = bs;
+}
+
+// ------------------------------------------------------------------ SSIM, pass 2 (adjoint correlation)
+// grad[y][x] = scale * ( (G^T*mA) + 2 f (G^T*mB) + x1 (G^T*mC1) + x2 (G^T*mC2) ),
+// (G^T*M)[y][x] = sum_{u,v} G[u][v] M[y-u][x-v], M zero outside the map.
+__global__ __launch_bounds__(256) void ssim_grad_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
+                                                        const float* __restrict__ f, int H, int W, Win11 win,
+                                                        const float* __restrict__ maps, float scale,
+                                                        float* __restrict__ grad, int tiles_x) {
+    __shared__ float in[4][LIN][LIN + 1];
+    __shared__ float hb[4][LIN][LT + 1];
+    const int Hm = H - WIN + 1, Wm = W - WIN + 1;
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int x0 = (blockIdx.x % tiles_x) * LT, y0 = (blockIdx.x / tiles_x) * LT;
+    const int in_ = blockIdx.y;
+    const long long msz = (long long)gridDim.y * Hm * Wm;
+    // map tile origin: (y0 - 10, x0 - 10)
+    for (int e = tid; e < LIN * LIN; e += 256) {
+        const int py = e / LIN, px = e % LIN;
+        const int my = y0 - (WIN - 1) + py, mx = x0 - (WIN - 1) + px;
+        const bool ok = my >= 0 && my < Hm && mx >= 0 && mx < Wm;
+        const long long mi = ((long long)in_ * Hm + my) * Wm + mx;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) in[q][py][px] = ok ? maps[q * msz + mi] : 0.f;
+    }
+    __syncthreads();
+    // out[x] = sum_v G[v] M[x - v]  -> with tile offset: M index px = tx + (WIN-1) - v
+    for (int e = tid; e < LIN * LT; e += 256) {
+        const int py = e / LT, px = e % LT;
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < WIN; ++k) {
+            const float wk = win.t[k];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s[q] = fmaf(wk, in[q][py][px + (WIN - 1) - k], s[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) hb[q][py][px] = s[q];
+    }
+    __syncthreads();
+    float m[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < WIN; ++k) {
+        const float wk = win.t[k];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) m[q] = fmaf(wk, hb[q][ty + (WIN - 1) - k][tx], m[q]);
+    }
+    const int y = y0 + ty, x = x0 + tx;
+    if (y < H && x < W) {
+        const long long i = ((long long)in_ * H + y) * W + x;
+        grad[i] = scale * (m[0] + 2.f * f[i] * m[1] + x1[i] * m[2] + x2[i] * m[3]);
+    }
+}
+
+// loss = weight * (1 - 0.5 * sum / (n * nmap))
+__global__ void ssim_finish_kernel(const float* __restrict__ partial, int np, float weight, float inv_count,
+                                   float* __restrict__ loss) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < np; i += blockDim.x) s += partial[i];
+    const float t = block_sum(s, red);
+    if (threadIdx.x == 0) loss[0] = weight * (1.f - 0.5f * t * inv_count);
+}
+
+// ------------------------------------------------------------------ pixel loss
+// mode_max: d = f - max(x1,x2);  avg: 0.5*(|f-x1| + |f-x2|)      (core/loss.py:294-304)
+__global__ __launch_bounds__(256) void pixel_loss_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
+                                                         const float* __restrict__ f, long long total, float gscale,
+                                                         int mode_max, int l2, float* __restrict__ grad,
+                                                         float* __restrict__ partial) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const float a = x1[i], b = x2[i], c = f[i];
+        float g;
+        if (mode_max) {
+            const float d = c - fmaxf(a, b);
+            s += l2 ? d * d : fabsf(d);
+            g = l2 ? 2.f * d : (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+        } else {
+            const float d1 = c - a, d2 = c - b;
+            s += 0.5f * (l2 ? d1 * d1 + d2 * d2 : fabsf(d1) + fabsf(d2));
+            g = 0.5f * (l2 ? 2.f * (d1 + d2)
+                           : ((d1 > 0.f ? 1.f : (d1 < 0.f ? -1.f : 0.f)) + (d2 > 0.f ? 1.f : (d2 < 0.f ? -1.f : 0.f))));
+        }
+        if (grad) grad[i] = gscale * g;
+    }
+    const float t = block_sum(s, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+__global__ void scale_finish_kernel(const float* __restrict__ partial, int np, float scale, float* __restrict__ loss) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < np; i += blockDim.x) s += partial[i];
+    const float t = block_sum(s, red);
+    if (threadIdx.x == 0) loss[0] = scale * t;
+}
+
+// ------------------------------------------------------------------ Sobel gradient loss
+constexpr int GH = 3;                 // image halo in LDS
+constexpr int GIN = LT + 2 * GH;      // 22
+constexpr int DH = 2;                 // D-map halo in LDS
+constexpr int GD = LT + 2 * DH;       // 20
+
+__device__ inline float sgnf(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
+
+__global__ __launch_bounds__(256) void grad_loss_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
+                                                        const float* __restrict__ f, int H, int W, float gscale,
+                                                        int mode_max, int l2, float* __restrict__ grad,
+                                                        float* __restrict__ partial, int tiles_x) {
+    __shared__ float in[3][GIN][GIN + 1];
+    __shared__ float dx[GD][GD + 1], dy[GD][GD + 1];
+    __shared__ float red[16];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int x0 = (blockIdx.x % tiles_x) * LT, y0 = (blockIdx.x / tiles_x) * LT;
+    const int in_ = blockIdx.y;
+    const long long ibase = (long long)in_ * H * W;
+    for (int e = tid; e < GIN * GIN; e += 256) {
+        const int py = e / GIN, px = e % GIN;
+        const int y = min(max(reflect_idx(y0 - GH + py, H), 0), H - 1);
+        const int x = min(max(reflect_idx(x0 - GH + px, W), 0), W - 1);
+        const long long i = ibase + (long long)y * W + x;
+        in[0][py][px] = x1[i];
+        in[1][py][px] = x2[i];
+        in[2][py][px] = f[i];
+    }
+    __syncthreads();
+    float lsum = 0.f;
+    for (int e = tid; e < GD * GD; e += 256) {
+        const int py = e / GD, px = e % GD;
+        const int y = y0 - DH + py, x = x0 - DH + px;  // logical position of this D element
+        float vx = 0.f, vy = 0.f;
+        if (y >= 0 && y < H && x >= 0 && x < W) {
+            float mag[3], sx = 0.f, sy = 0.f;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                // 3x3 neighbourhood centred at LDS (py + GH - DH, px + GH - DH)
+                const int cy = py + GH - DH, cx = px + GH - DH;
+                const float a00 = in[q][cy - 1][cx - 1], a01 = in[q][cy - 1][cx], a02 = in[q][cy - 1][cx + 1];
+                const float a10 = in[q][cy][cx - 1], a12 = in[q][cy][cx + 1];
+                const float a20 = in[q][cy + 1][cx - 1], a21 = in[q][cy + 1][cx], a22 = in[q][cy + 1][cx + 1];
+                const float gx = (a02 - a00) + 2.f * (a12 - a10) + (a22 - a20);
+                const float gy = (a20 - a00) + 2.f * (a21 - a01) + (a22 - a02);
+                mag[q] = fabsf(gx) + fabsf(gy);
+                if (q == 2) { sx = sgnf(gx); sy = sgnf(gy); }
+            }
+            float s, l;
+            if (mode_max) {
+                const float d = mag[2] - fmaxf(mag[0], mag[1]);
+                l = l2 ? d * d : fabsf(d);
+                s = l2 ? 2.f * d : sgnf(d);
+            } else {
+                const float d1 = mag[2] - mag[0], d2 = mag[2] - mag[1];
+                l = 0.5f * (l2 ? d1 * d1 + d2 * d2 : fabsf(d1) + fabsf(d2));
+                s = 0.5f * (l2 ? 2.f * (d1 + d2) : sgnf(d1) + sgnf(d2));
+            }
+            vx = s * sx;
+            vy = s * sy;
+            // count the loss once: only positions of this block's own 16x16 tile
+            if (py >= DH && py < DH + LT && px >= DH && px < DH + LT) lsum += l;
+        }
+        dx[py][px] = vx;
+        dy[py][px] = vy;
+    }
+    __syncthreads();
+    const int y = y0 + ty, x = x0 + tx;
+    if (grad != nullptr && y < H && x < W) {
+        // T(q): adjoint of the Sobel correlation on the reflect-padded domain, D zero outside the image
+        auto D = [&](int qy, int qx, bool isx) -> float {
+            if (qy < 0 || qy >= H || qx < 0 || qx >= W) return 0.f;
+            const int ly = qy - y0 + DH, lx = qx - x0 + DH;
+            return isx ? dx[ly][lx] : dy[ly][lx];
+        };
+        auto Tq = [&](int qy, int qx) -> float {
+            // gx[p] = sum Kx[u][v] pad[p+u-1][p+v-1]  =>  T[q] = sum Kx[u][v] Dx[q-u+1][q-v+1] (+ Ky, Dy)
+            float t = 0.f;
+            // Kx = [[-1,0,1],[-2,0,2],[-1,0,1]]
+            t += -1.f * D(qy + 1, qx + 1, true) + 1.f * D(qy + 1, qx - 1, true);
+            t += -2.f * D(qy, qx + 1, true) + 2.f * D(qy, qx - 1, true);
+            t += -1.f * D(qy - 1, qx + 1, true) + 1.f * D(qy - 1, qx - 1, true);
+            // Ky = [[-1,-2,-1],[0,0,0],[1,2,1]]
+            t += -1.f * D(qy + 1, qx + 1, false) - 2.f * D(qy + 1, qx, false) - 1.f * D(qy + 1, qx - 1, false);
+            t += 1.f * D(qy - 1, qx + 1, false) + 2.f * D(qy - 1, qx, false) + 1.f * D(qy - 1, qx - 1, false);
+            return t;
+        };
+        int ys[3], xs[3], ny = 1, nx = 1;
+        ys[0] = y;
+        xs[0] = x;
+        if (y == 1) ys[ny++] = -1;
+        if (y == H - 2) ys[ny++] = H;
+        if (x == 1) xs[nx++] = -1;
+        if (x == W - 2) xs[nx++] = W;
+        float g = 0.f;
+        for (int a = 0; a < ny; ++a)
+            for (int b = 0; b < nx; ++b) g += Tq(ys[a], xs[b]);
+        grad[ibase + (long long)y * W + x] = gscale * g;
+    }
+    const float t = block_sum(lsum, red);
+    if (tid == 0) partial[(long long)in_ * gridDim.x + blockIdx.x] = t;
+}
+
+void gaussian_window(Win11& w) {
+    // core/loss.py:24-30: taps in double -> float32, divided by their float32 sum (== correctly
+    // rounded sum for these 11 values; pinned bit-for-bit by tests/golden/f1)
+    float g[WIN];
+    double sum = 0.0;
+    for (int i = 0; i < WIN; ++i) {
+        g[i] = (float)exp(-(double)((i - WIN / 2) * (i - WIN / 2)) / (2.0 * 1.5 * 1.5));
+        sum += (double)g[i];
+    }
+    const float fs = (float)sum;
+    for (int i = 0; i < WIN; ++i) w.t[i] = g[i] / fs;
+}
+
+}  // namespace mmif
+
+using namespace mmif;
+
+extern "C" size_t mmif_loss_workspace(int32_t n, int32_t h, int32_t w) {
+    const size_t tiles = (size_t)cdiv(h, LT) * cdiv(w, LT) * n;
+    const size_t maps = (size_t)4 * n * (h > 10 ? h - 10 : 0) * (w > 10 ? w - 10 : 0);
+    return (tiles + 4096 + maps) * sizeof(float);
+}
+
+extern "C" int mmif_ssim_loss(const float* img1, const float* img2, const float* imgf, int32_t n, int32_t h, int32_t w,
+                              float weight, float data_range, float* loss_out, float* grad_out, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+    MMIF_REQUIRE(h >= WIN && w >= WIN, "ssim_loss: image smaller than the 11x11 window (%dx%d)", h, w);
+    if (workspace_bytes < mmif_loss_workspace(n, h, w)) {
+        set_error("ssim_loss: workspace too small");
+        return MMIF_EWORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    Win11 win;
+    gaussian_window(win);
+    const float C1 = (0.01f * data_range) * (0.01f * data_range), C2 = (0.03f * data_range) * (0.03f * data_range);
+    const int Hm = h - WIN + 1, Wm = w - WIN + 1;
+    const int tmx = cdiv(Wm, LT), tmy = cdiv(Hm, LT);
+    float* partial = (float*)workspace;
+    const int np = tmx * tmy * n;
+    float* maps = grad_out ? partial + (((size_t)np + 63) / 64) * 64 : nullptr;
+    hipLaunchKernelGGL(ssim_stats_kernel, dim3(tmx * tmy, n), dim3(256), 0, st, img1, img2, imgf, h, w, win, C1, C2, maps,
+                       partial, tmx);
+    if (int rc = check_launch("ssim_stats")) return rc;
+    hipLaunchKernelGGL(ssim_finish_kernel, dim3(1), dim3(256), 0, st, partial, np, weight, 1.f / ((float)n * Hm * Wm),
+                       loss_out);
+    if (int rc = check_launch("ssim_finish")) return rc;
+    if (grad_out) {
+        const int tx = cdiv(w, LT), ty = cdiv(h, LT);
+        const float scale = -weight * 0.5f / ((float)n * Hm * Wm);
+        hipLaunchKernelGGL(ssim_grad_kernel, dim3(tx * ty, n), dim3(256), 0, st, img1, img2, imgf, h, w, win, maps, scale,
+                           grad_out, tx);
+        if (int rc = check_launch("ssim_grad")) return rc;
+    }
+    return MMIF_OK;
+}
+
+extern "C" int mmif_pixel_loss(const float* img1, const float* img2, const float* imgf, int32_t n, int32_t h, int32_t w,
+                               float weight, int32_t mode_max, int32_t l2, float* loss_out, float* grad_out,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+    if (workspace_bytes < mmif_loss_workspace(n, h, w)) {
+        set_error("pixel_loss: workspace too small");
+        return MMIF_EWORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const long long total = (long long)n * h * w;
+    int nb = cdiv(total, 256);
+    if (nb > 2048) nb = 2048;
+    float* partial = (float*)workspace;
+    hipLaunchKernelGGL(pixel_loss_kernel, dim3(nb), dim3(256), 0, st, img1, img2, imgf, total, weight / (float)total, mode_max,
+                       l2, grad_out, partial);
+    if (int rc = check_launch("pixel_loss")) return rc;
+    hipLaunchKernelGGL(scale_finish_kernel, dim3(1), dim3(256), 0, st, partial, nb, weight / (float)total, loss_out);
+    return check_launch("pixel_finish");
+}
+
+extern "C" int mmif_grad_loss(const float* img1, const float* img2, const float* imgf, int32_t n, int32_t h, int32_t w,
+                              float weight, int32_t mode_max, int32_t l2, float* loss_out, float* grad_out,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+    MMIF_REQUIRE(h >= 2 && w >= 2, "grad_loss: reflect padding needs h,w >= 2");
+    if (workspace_bytes < mmif_loss_workspace(n, h, w)) {
+        set_error("grad_loss: workspace too small");
+        return MMIF_EWORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int tx = cdiv(w, LT), ty = cdiv(h, LT);
+    const long long total = (long long)n * h * w;
+    float* partial = (float*)workspace;
+    hipLaunchKernelGGL(grad_loss_kernel, dim3(tx * ty, n), dim3(256), 0, st, img1, img2, imgf, h, w, weight / (float)total,
+                       mode_max, l2, grad_out, partial, tx);
+    if (int rc = check_launch("grad_loss")) return rc;
+    hipLaunchKernelGGL(scale_finish_kernel, dim3(1), dim3(256), 0, st, partial, tx * ty * n, weight / (float)total, loss_out);
+    return check_launch("grad_finish");
+}

@@ -1,0 +1,81 @@
+"""ctypes binding of libmmif_hip.so (C ABI declared in include/mmif.h).
+
+The library is the product: if it is missing or fails to load, importing this module raises --
+there is no CPU or torch fallback for the hot path."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libmmif_hip.so")
+
+F32, BF16 = 0, 1
+IMPL_AUTO, IMPL_VALU, IMPL_MFMA = 0, 1, 2
+FUSE_SUM, FUSE_MEAN, FUSE_MAX = 0, 1, 2
+
+
+class MmifTensor(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("dtype", C.c_int32), ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32),
+                ("halo", C.c_int32), ("cb_total", C.c_int32), ("cb_off", C.c_int32), ("cb", C.c_int32)]
+
+
+class MmifError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.isfile(LIB_PATH):
+        raise ImportError(
+            f"mmif: {LIB_PATH} not found -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C multi-modal-image-fusion_amd/csrc`).  The HIP library is required; there is no fallback.")
+    return C.CDLL(LIB_PATH)
+
+
+lib = _load()
+
+_TP = C.POINTER(MmifTensor)
+_vp, _i32, _u64, _f32, _sz, _i64 = C.c_void_p, C.c_int32, C.c_uint64, C.c_float, C.c_size_t, C.c_int64
+
+# name -> (restype, argtypes); mirrors include/mmif.h one for one
+SIGNATURES = {
+    "mmif_version": (C.c_char_p, []),
+    "mmif_last_error": (C.c_char_p, []),
+    "mmif_nchw_to_blocked": (_i32, [_vp, _i32, _TP, _vp]),
+    "mmif_blocked_to_nchw": (_i32, [_TP, _vp, _i32, _vp]),
+    "mmif_zero": (_i32, [_TP, _vp]),
+    "mmif_packed_weight_bytes": (_sz, [_i32, _i32, _i32]),
+    "mmif_pack_weights": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "mmif_conv2d_reflect_fwd": (_i32, [_TP, _vp, _vp, _vp, _TP, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "mmif_conv2d_reflect_dgrad": (_i32, [_TP, _vp, _vp, _TP, _TP, _i32, _i32, _i32, _u64, _u64, _i32, _vp]),
+    "mmif_conv2d_wgrad_workspace": (_sz, [_i32, _i32, _i32]),
+    "mmif_conv2d_reflect_wgrad": (_i32, [_TP, _TP, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _sz, _i32, _vp]),
+    "mmif_conv2d_image_in_fwd": (_i32, [_vp, _vp, _vp, _TP, _i32, _i32, _i32, _vp]),
+    "mmif_conv2d_image_in_wgrad": (_i32, [_vp, _TP, _vp, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),
+    "mmif_conv2d_image_out_fwd": (_i32, [_TP, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "mmif_conv2d_image_out_dgrad": (_i32, [_vp, _vp, _vp, _TP, _TP, _i32, _i32, _u64, _u64, _vp]),
+    "mmif_conv2d_image_out_wgrad": (_i32, [_TP, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),
+    "mmif_conv2d_image_wgrad_workspace": (_sz, [_i32, _i32]),
+    "mmif_fuse_elem_fwd": (_i32, [_TP, _TP, _TP, _i32, _vp]),
+    "mmif_fuse_elem_bwd": (_i32, [_TP, _TP, _TP, _TP, _TP, _i32, _i32, _vp]),
+    "mmif_loss_workspace": (_sz, [_i32, _i32, _i32]),
+    "mmif_ssim_loss": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _sz, _vp]),
+    "mmif_pixel_loss": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "mmif_grad_loss": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "mmif_clip_adam_workspace": (_sz, [_i64]),
+    "mmif_clip_adam_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i32, _f32, _f32, _vp, _vp, _sz, _vp]),
+    "mmif_probe_tr16": (_i32, [_vp, _vp, _vp]),
+    "mmif_probe_mfma": (_i32, [_vp, _vp, _vp, _vp]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)  # AttributeError here = header / library mismatch: fail loudly
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise MmifError(f"{what or 'mmif'} failed (code {rc}): {lib.mmif_last_error().decode()}")
+
+
+def version():
+    return lib.mmif_version().decode()

@@ -1,0 +1,428 @@
+"""Whole-model execution engine: runs the encoder / fusion / decoder forward and backward of the
+fusion nets (reference core/model.py) as a fixed sequence of HIP kernel launches on blocked-NHWC
+buffers, with torch.cat replaced by channel-block views of one allocation (zero-copy concat).
+
+Gradient convention (DESIGN.md "padded-domain gradients"): a dgrad kernel writes the gradient of
+the reflect-PADDED input ([h+2][w+2], halo = 1); consumers fold the halo on load.  The ReLU mask of a
+producer layer is applied by the LAST kernel that contributes to that tensor's gradient
+(mask_bits), accumulation of several consumers' contributions by accum_bits.
+"""
+import os
+import threading
+
+import torch
+
+from . import _lib
+from . import tensor as T
+from .tensor import BT, PackedWeights
+
+_cfg = threading.local()
+
+# base data_ptr -> flat gradient buffer (lets mmif.optim find the buffer behind a parameter's .grad view)
+FLAT_BUFFERS = {}
+# bumped by every fused optimiser step: the packed bf16 weight images must be rebuilt
+WEIGHTS_EPOCH = [0]
+GRAD_TAIL = 8  # scalar slots after the gradients (loss values ride along in the gradient all-reduce)
+
+
+def compute_dtype():
+    """Storage dtype of feature maps: torch.float32 (parity path, VALU kernels) or torch.bfloat16
+    (throughput path, MFMA kernels).  Default from $MMIF_DTYPE, else float32."""
+    d = getattr(_cfg, "dtype", None)
+    if d is None:
+        d = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16}.get(os.environ.get("MMIF_DTYPE", "fp32").lower(), torch.float32)
+        _cfg.dtype = d
+    return d
+
+
+def set_compute_dtype(dtype):
+    if isinstance(dtype, str):
+        dtype = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32, "float32": torch.float32}[dtype.lower()]
+    assert dtype in (torch.float32, torch.bfloat16)
+    _cfg.dtype = dtype
+
+
+def conv_impl():
+    """MMIF_IMPL_AUTO unless $MMIF_CONV_IMPL = valu | mfma (cross-checking the two kernel families)."""
+    return {"valu": _lib.IMPL_VALU, "mfma": _lib.IMPL_MFMA}.get(os.environ.get("MMIF_CONV_IMPL", "auto").lower(), _lib.IMPL_AUTO)
+
+
+def bits(*blocks):
+    m = 0
+    for b in blocks:
+        m |= 1 << b
+    return m
+
+
+def all_bits(n):
+    return (1 << n) - 1
+
+
+class ConvSpec:
+    """One ConvLayer as the engine sees it: fp32 master weight/bias (nn.Parameter), geometry, the
+    packed bf16 operand images and where its gradients go."""
+
+    def __init__(self, name, conv, relu):
+        self.name = name
+        self.conv = conv  # nn.Conv2d holding .weight / .bias
+        self.cout, self.cin, self.k = conv.weight.shape[0], conv.weight.shape[1], conv.weight.shape[2]
+        self.relu = relu
+        self.packed = None
+        self.packed_version = None
+        self.dw = None  # views into the flat gradient buffer, set per backward
+        self.db = None
+
+    @property
+    def w(self):
+        return self.conv.weight
+
+    @property
+    def b(self):
+        return self.conv.bias
+
+    def ensure_packed(self, version):
+        if self.cin == 1 or self.cout == 1:
+            return
+        w = self.conv.weight
+        key = (version, WEIGHTS_EPOCH[0], w._version, w.data_ptr())
+        if self.packed is None or self.packed.fwd.device != w.device:
+            self.packed = PackedWeights(self.cout, self.cin, self.k, w.device)
+            self.packed_version = None
+        if self.packed_version != key:
+            self.packed.pack(w.detach())
+            self.packed_version = key
+
+
+class Lease:
+    """Per-call activation / gradient buffers; reused across iterations through the engine's pool."""
+
+    def __init__(self):
+        self.bufs = {}
+        self.key = None
+        self.imgs = None
+        self.out = None
+        self.busy = False
+
+
+class ModelEngine:
+    """Base: buffer pool, flat parameter / gradient storage, autograd glue."""
+
+    def __init__(self, module, specs):
+        self.module = module
+        self.specs = specs  # ordered list of ConvSpec (any order; grads are matched by parameter)
+        self.pool = {}
+        self.weights_version = 0
+        self.flat_grads = [None, None]
+        self.flat_idx = 0
+        self._ws = None
+        self._params = None
+
+    # ---- parameters -------------------------------------------------------------------------
+    def params(self):
+        if self._params is None:
+            self._params = list(self.module.parameters())
+        return self._params
+
+    def bump_weights(self):
+        self.weights_version += 1
+
+    def _grad_buffer(self, device):
+        """A flat fp32 gradient buffer that no live .grad aliases (two are rotated)."""
+        ps = self.params()
+        total = sum(p.numel() for p in ps)
+        live = {p.grad.data_ptr() for p in ps if p.grad is not None}
+        for i in (self.flat_idx, 1 - self.flat_idx):
+            buf = self.flat_grads[i]
+            if buf is None or buf.device != device or buf.numel() != total + GRAD_TAIL:
+                if buf is not None:
+                    FLAT_BUFFERS.pop(buf.data_ptr(), None)
+                buf = torch.zeros(total + GRAD_TAIL, dtype=torch.float32, device=device)
+                FLAT_BUFFERS[buf.data_ptr()] = buf
+                self.flat_grads[i] = buf
+            lo, hi = buf.data_ptr(), buf.data_ptr() + buf.numel() * 4
+            if not any(lo <= a < hi for a in live):
+                self.flat_idx = 1 - i
+                return buf
+        return torch.zeros(total + GRAD_TAIL, dtype=torch.float32, device=device)  # both aliased: fresh allocation
+
+    def _assign_grad_views(self, device):
+        flat = self._grad_buffer(device)
+        views, off = {}, 0
+        for p in self.params():
+            views[id(p)] = flat[off:off + p.numel()].view(p.shape)
+            off += p.numel()
+        for s in self.specs:
+            s.dw = views[id(s.conv.weight)]
+            s.db = views[id(s.conv.bias)]
+        # hand autograd FRESH view objects (sole owners), so AccumulateGrad can adopt them as .grad without a copy
+        return flat, [views[id(p)].view(p.shape) for p in self.params()]
+
+    def workspace(self, device):
+        need = 0
+        for s in self.specs:
+            if s.cin == 1 or s.cout == 1:
+                need = max(need, T.image_wgrad_workspace_bytes(max(s.cin, s.cout), s.k))
+            else:
+                need = max(need, T.wgrad_workspace_bytes(s.cin, s.cout, s.k))
+        if self._ws is None or self._ws.device != device or self._ws.numel() * 4 < need:
+            self._ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=device)
+        return self._ws
+
+    # ---- buffers ----------------------------------------------------------------------------
+    def lease(self, key, device):
+        lst = self.pool.setdefault(key, [])
+        for l in lst:
+            if not l.busy:
+                l.busy = True
+                return l
+        l = Lease()
+        l.key = key
+        l.busy = True
+        lst.append(l)
+        return l
+
+    @staticmethod
+    def buf(lease, name, n, c, h, w, dtype, device, halo=0):
+        b = lease.bufs.get(name)
+        if b is None:
+            b = BT.alloc(n, c, h, w, dtype, device, halo)
+            lease.bufs[name] = b
+        return b
+
+    # ---- entry point ------------------------------------------------------------------------
+    def run(self, img1, img2=None):
+        T.require_device(img1, "img1")
+        if img2 is not None:
+            T.require_device(img2, "img2")
+        ps = self.params()
+        need_grad = torch.is_grad_enabled() and (any(p.requires_grad for p in ps) or img1.requires_grad)
+        if need_grad:
+            return _EngineFn.apply(self, img1, img2, *ps)
+        with torch.no_grad():
+            out, lease = self.forward(img1, img2)
+            lease.busy = False
+            return out
+
+    def prepare(self, imgs):
+        dtype = compute_dtype()
+        impl = conv_impl()
+        use_mfma = dtype == torch.bfloat16 and impl != _lib.IMPL_VALU
+        if use_mfma:
+            for s in self.specs:
+                s.ensure_packed(self.weights_version)
+        imgs = [None if i is None else i.detach().contiguous().float() for i in imgs]
+        n, c, h, w = imgs[0].shape
+        if c != 1:
+            raise ValueError(f"fusion nets take single-channel images [B,1,H,W]; got {tuple(imgs[0].shape)}")
+        for i in imgs[1:]:
+            if i is not None and i.shape != imgs[0].shape:
+                raise ValueError("img1 and img2 must have the same shape")
+        return imgs, n, h, w, dtype, impl
+
+    # conv helpers operating on ConvSpecs ------------------------------------------------------
+    @staticmethod
+    def c_fwd(s, x, y, impl):
+        T.conv_fwd(x, s.w.detach(), s.b.detach(), y, s.cin, s.cout, s.k, s.relu, s.packed, impl, s.name + ":fwd")
+
+    @staticmethod
+    def c_dgrad(s, gy, x, gx, mask_bits, accum_bits, impl):
+        T.conv_dgrad(gy, s.w.detach(), x, gx, s.cin, s.cout, s.k, mask_bits, accum_bits, s.packed, impl, s.name + ":dgrad")
+
+    @staticmethod
+    def c_wgrad(s, x, gy, ws, impl):
+        T.conv_wgrad(x, gy, s.dw, s.db, s.cin, s.cout, s.k, ws, False, impl, s.name + ":wgrad")
+
+    def forward(self, img1, img2):
+        raise NotImplementedError
+
+    def backward(self, lease, gout):
+        raise NotImplementedError
+
+
+class _EngineFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, engine, img1, img2, *params):
+        out, lease = engine.forward(img1, img2)
+        ctx.engine, ctx.lease = engine, lease
+        ctx.n_params = len(params)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lease = ctx.lease
+        if lease is None:
+            raise RuntimeError("mmif: backward called twice on the same forward (buffers were recycled)")
+        grads = ctx.engine.backward(lease, gout.contiguous().float())
+        lease.busy = False
+        ctx.lease = None
+        return (None, None, None) + tuple(grads)
+
+
+# =============================================================================================
+class DenseEncoderMixin:
+    """Conv(1->16) + DenseBlock(16,16) into an 8-block (64 ch) slice of a feature buffer
+    (reference core/model.py:73-80 + core/block.py:137-151)."""
+
+    @staticmethod
+    def enc_fwd(specs, img, F, base, impl):
+        first, c0, c1, c2 = specs
+        T.image_in_fwd(img, first.w.detach(), first.b.detach(), F.view(base, 2), first.cout, first.k, first.relu)
+        ModelEngine.c_fwd(c0, F.view(base, 2), F.view(base + 2, 2), impl)
+        ModelEngine.c_fwd(c1, F.view(base, 4), F.view(base + 4, 2), impl)
+        ModelEngine.c_fwd(c2, F.view(base, 6), F.view(base + 6, 2), impl)
+
+    @staticmethod
+    def enc_bwd(specs, img, F, GF, fbase, gbase, ws, impl, accumulate_w=False):
+        """GF[gbase:gbase+8] holds dL/d(encoder output) (padded domain), top 2 blocks already masked."""
+        first, c0, c1, c2 = specs
+        for s, nin in ((c2, 6), (c1, 4), (c0, 2)):
+            g = GF.view(gbase + nin, 2)
+            x = F.view(fbase, nin)
+            T.conv_wgrad(x, g, s.dw, s.db, s.cin, s.cout, s.k, ws, accumulate_w, impl, s.name + ":wgrad")
+            # accumulate into the lower blocks; this conv is the LAST contributor of its top 2 input blocks
+            ModelEngine.c_dgrad(s, g, x, GF.view(gbase, nin), bits(nin - 2, nin - 1), all_bits(nin), impl)
+        T.image_in_wgrad(img, GF.view(gbase, 2), first.dw, first.db, first.cout, first.k, ws, accumulate_w)
+
+
+class PFNetv1Engine(ModelEngine, DenseEncoderMixin):
+    """reference core/model.py:69-111."""
+
+    def __init__(self, module):
+        m = module
+        def cs(name, layer):
+            return ConvSpec(name, layer.layers[0], layer.act is not None)
+        self.enc = []
+        for e, seq in enumerate((m.encode1, m.encode2)):
+            self.enc.append([cs(f"encode{e + 1}.0", seq[0])] + [cs(f"encode{e + 1}.1.{i}", l) for i, l in enumerate(seq[1].layers)])
+        self.dec = [cs(f"decode.{i}", l) for i, l in enumerate(m.decode)]
+        super().__init__(module, self.enc[0] + self.enc[1] + self.dec)
+
+    def forward(self, img1, img2):
+        (img1, img2), n, h, w, dtype, impl = self.prepare((img1, img2))
+        dev = img1.device
+        L = self.lease((n, h, w, dtype), dev)
+        L.imgs = (img1, img2)
+        F = self.buf(L, "F", n, 128, h, w, dtype, dev)
+        self.enc_fwd(self.enc[0], img1, F, 0, impl)
+        self.enc_fwd(self.enc[1], img2, F, 8, impl)
+        x = F
+        for i, s in enumerate(self.dec[:-1]):
+            y = self.buf(L, f"D{i}", n, s.cout, h, w, dtype, dev)
+            self.c_fwd(s, x, y, impl)
+            x = y
+        last = self.dec[-1]
+        out = torch.empty((n, 1, h, w), dtype=torch.float32, device=dev)
+        T.image_out_fwd(x, last.w.detach(), last.b.detach(), out, last.cin, last.k, last.relu)
+        L.out = out if last.relu else None
+        return out, L
+
+    def backward(self, L, gout):
+        n, h, w, dtype = L.key
+        dev = gout.device
+        impl = conv_impl()
+        flat, grads = self._assign_grad_views(dev)
+        ws = self.workspace(dev)
+        img1, img2 = L.imgs
+        F = L.bufs["F"]
+        acts = [F] + [L.bufs[f"D{i}"] for i in range(len(self.dec) - 1)]
+        last = self.dec[-1]
+        x = acts[-1]
+        T.image_out_wgrad(x, gout, L.out, last.dw, last.db, last.cin, last.k, ws)
+        g = self.buf(L, f"G{len(acts) - 1}", n, last.cin, h, w, dtype, dev, halo=1)
+        T.image_out_dgrad(gout, L.out, last.w.detach(), x, g, last.cin, last.k, all_bits(g.cb), 0)
+        for i in range(len(self.dec) - 2, -1, -1):
+            s, x = self.dec[i], acts[i]
+            self.c_wgrad(s, x, g, ws, impl)
+            gx = self.buf(L, f"G{i}", n, s.cin, h, w, dtype, dev, halo=1)
+            if i > 0:
+                self.c_dgrad(s, g, x, gx, all_bits(gx.cb), 0, impl)
+            else:
+                # gradient w.r.t. the concatenated encoder features: only each encoder's last
+                # DenseBlock output (blocks 6,7 / 14,15) has no further contributor
+                self.c_dgrad(s, g, x, gx, bits(6, 7, 14, 15), 0, impl)
+            g = gx
+        self.enc_bwd(self.enc[0], img1, F, g, 0, 0, ws, impl)
+        self.enc_bwd(self.enc[1], img2, F, g, 8, 8, ws, impl)
+        return grads
+
+
+class DenseFuseEngine(ModelEngine, DenseEncoderMixin):
+    """reference core/model.py:165-186 (+ _FusionModel :27-63): shared encoder run on both images,
+    element 'sum' fusion, 4-conv decoder.  Also the auto-encoder mode forward(img1)."""
+
+    fusion_mode = _lib.FUSE_SUM
+
+    def __init__(self, module):
+        m = module
+        def cs(name, layer):
+            return ConvSpec(name, layer.layers[0], layer.act is not None)
+        self.enc = [cs("encode.0", m.encode[0])] + [cs(f"encode.1.{i}", l) for i, l in enumerate(m.encode[1].layers)]
+        self.dec = [cs(f"decode.{i}", l) for i, l in enumerate(m.decode)]
+        super().__init__(module, self.enc + self.dec)
+
+    def forward(self, img1, img2):
+        (img1, img2), n, h, w, dtype, impl = self.prepare((img1, img2))
+        dev = img1.device
+        single = img2 is None
+        L = self.lease((n, h, w, dtype, single), dev)
+        L.imgs = (img1, img2)
+        F = self.buf(L, "F", n, 64 if single else 128, h, w, dtype, dev)
+        self.enc_fwd(self.enc, img1, F, 0, impl)
+        if single:
+            x = F
+        else:
+            self.enc_fwd(self.enc, img2, F, 8, impl)
+            x = self.buf(L, "S", n, 64, h, w, dtype, dev)
+            T.fuse_elem_fwd(F.view(0, 8), F.view(8, 8), x, self.fusion_mode)
+        for i, s in enumerate(self.dec[:-1]):
+            y = self.buf(L, f"D{i}", n, s.cout, h, w, dtype, dev)
+            self.c_fwd(s, x, y, impl)
+            x = y
+        last = self.dec[-1]
+        out = torch.empty((n, 1, h, w), dtype=torch.float32, device=dev)
+        T.image_out_fwd(x, last.w.detach(), last.b.detach(), out, last.cin, last.k, last.relu)
+        L.out = out if last.relu else None
+        return out, L
+
+    def backward(self, L, gout):
+        n, h, w, dtype, single = L.key
+        dev = gout.device
+        impl = conv_impl()
+        flat, grads = self._assign_grad_views(dev)
+        ws = self.workspace(dev)
+        img1, img2 = L.imgs
+        F = L.bufs["F"]
+        first_in = F if single else L.bufs["S"]
+        acts = [first_in] + [L.bufs[f"D{i}"] for i in range(len(self.dec) - 1)]
+        last = self.dec[-1]
+        x = acts[-1]
+        T.image_out_wgrad(x, gout, L.out, last.dw, last.db, last.cin, last.k, ws)
+        g = self.buf(L, f"G{len(acts) - 1}", n, last.cin, h, w, dtype, dev, halo=1)
+        T.image_out_dgrad(gout, L.out, last.w.detach(), x, g, last.cin, last.k, all_bits(g.cb), 0)
+        for i in range(len(self.dec) - 2, -1, -1):
+            s, x = self.dec[i], acts[i]
+            self.c_wgrad(s, x, g, ws, impl)
+            gx = self.buf(L, f"G{i}", n, s.cin, h, w, dtype, dev, halo=1)
+            if i > 0:
+                self.c_dgrad(s, g, x, gx, all_bits(gx.cb), 0, impl)
+            elif single:
+                self.c_dgrad(s, g, x, gx, bits(6, 7), 0, impl)
+            else:
+                self.c_dgrad(s, g, x, gx, 0, 0, impl)  # x = f1 + f2 is not a ReLU output
+            g = gx
+        if single:
+            self.enc_bwd(self.enc, img1, F, g, 0, 0, ws, impl)
+            return grads
+        # fusion backward: d(f1+f2) -> each encoder's own gradient buffer (they diverge below);
+        # ReLU mask only on the DenseBlock's last conv output (blocks 6,7), the rest are masked by
+        # their last contributor inside enc_bwd
+        GF = self.buf(L, "GF", n, 128, h, w, dtype, dev, halo=1)
+        self.fusion_bwd(F, g, GF)
+        self.enc_bwd(self.enc, img1, F, GF, 0, 0, ws, impl, accumulate_w=False)
+        self.enc_bwd(self.enc, img2, F, GF, 8, 8, ws, impl, accumulate_w=True)
+        return grads
+
+    def fusion_bwd(self, F, g, GF):
+        # blocks 0..5: plain copy scaled by the fusion derivative; blocks 6,7: also ReLU-masked
+        T.fuse_elem_bwd(F.view(0, 6), F.view(8, 6), g.view(0, 6), GF.view(0, 6), GF.view(8, 6), self.fusion_mode, False)
+        T.fuse_elem_bwd(F.view(6, 2), F.view(14, 2), g.view(6, 2), GF.view(6, 2), GF.view(14, 2), self.fusion_mode, True)

@@ -1,0 +1,117 @@
+"""Fused clip_grad_norm_ + Adam (+ data-parallel gradient all-reduce) on flat fp32 buffers.
+
+Replaces train.py:72-75 (`nn.utils.clip_grad_norm_(max_norm=5)`; `optim.Adam(lr, betas).step()`) and,
+when torch.distributed is initialised, DDP's bucketed gradient all-reduce plus the four
+`reduce_value` scalar all-reduces of train.py:92-96 -- as ONE RCCL all-reduce of
+[flat gradients | loss scalars] followed by ONE fused kernel sequence (mmif_clip_adam_step).
+"""
+import ctypes as C
+
+import torch
+import torch.distributed as dist
+
+from . import engine as E
+from ._lib import check, lib
+from .tensor import stream_ptr
+
+N_TAIL = 8  # scalar slots appended to the flat gradient buffer (losses ride along in the all-reduce)
+
+
+class FusedClipAdam(torch.optim.Optimizer):
+    """Adam(lr, betas, eps, weight_decay=0) with optional global-norm clipping, bias-corrected exactly as
+    torch.optim.Adam; parameters are re-pointed to one flat fp32 buffer on first use."""
+
+    def __init__(self, params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, max_norm=None):
+        defaults = dict(lr=lr, betas=betas, eps=eps, max_norm=max_norm)
+        super().__init__(params, defaults)
+        if len(self.param_groups) != 1:
+            raise ValueError("FusedClipAdam supports a single parameter group")
+        self._flat_p = self._m = self._v = self._ws = self._stage = None
+        self._steps = 0
+        self.grad_norm = None  # device float[1]: pre-clip global L2 norm of the last step
+        self.reduced_scalars = None
+
+    def _params(self):
+        return [p for p in self.param_groups[0]["params"] if p.requires_grad]
+
+    def _flatten_params(self, ps):
+        dev = ps[0].device
+        total = sum(p.numel() for p in ps)
+        ok = self._flat_p is not None and self._flat_p.device == dev and self._flat_p.numel() == total
+        if ok:
+            off = 0
+            for p in ps:
+                if p.data_ptr() != self._flat_p.data_ptr() + 4 * off:
+                    ok = False
+                    break
+                off += p.numel()
+        if ok:
+            return
+        flat = torch.empty(total, dtype=torch.float32, device=dev)
+        off = 0
+        for p in ps:
+            n = p.numel()
+            flat[off:off + n].copy_(p.data.reshape(-1))
+            p.data = flat[off:off + n].view(p.shape)
+            off += n
+        old_m, old_v = self._m, self._v
+        self._flat_p = flat
+        self._m = torch.zeros_like(flat) if old_m is None or old_m.numel() != total else old_m.to(dev)
+        self._v = torch.zeros_like(flat) if old_v is None or old_v.numel() != total else old_v.to(dev)
+        self._ws = torch.empty(lib.mmif_clip_adam_workspace(total) // 4 + 1, dtype=torch.float32, device=dev)
+        self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
+
+    def _flat_grads(self, ps):
+        """The engine's flat gradient buffer when every .grad is a view of it (zero-copy), else a staging copy."""
+        total = sum(p.numel() for p in ps)
+        g0 = ps[0].grad
+        if g0 is None:
+            raise RuntimeError("FusedClipAdam.step(): parameter without gradient")
+        flat = E.FLAT_BUFFERS.get(g0.data_ptr())
+        if flat is not None and flat.numel() == total + N_TAIL:
+            off, ok = 0, True
+            for p in ps:
+                if p.grad is None or p.grad.data_ptr() != flat.data_ptr() + 4 * off or not p.grad.is_contiguous():
+                    ok = False
+                    break
+                off += p.numel()
+            if ok:
+                return flat
+        if self._stage is None or self._stage.numel() != total + N_TAIL or self._stage.device != ps[0].device:
+            self._stage = torch.empty(total + N_TAIL, dtype=torch.float32, device=ps[0].device)
+        off = 0
+        for p in ps:
+            n = p.numel()
+            if p.grad is None:
+                raise RuntimeError("FusedClipAdam.step(): parameter without gradient")
+            self._stage[off:off + n].copy_(p.grad.reshape(-1))
+            off += n
+        return self._stage
+
+    @torch.no_grad()
+    def step(self, closure=None, scalars=None):
+        """scalars: optional list of up to 8 0-dim device tensors (loss values) that are summed across
+        ranks in the same all-reduce as the gradients; their rank-mean is left in `reduced_scalars`."""
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        ps = self._params()
+        self._flatten_params(ps)
+        flat_g = self._flat_grads(ps)
+        total = self._flat_p.numel()
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        if scalars:
+            flat_g[total:total + len(scalars)] = torch.stack([s.detach().float().reshape(()) for s in scalars])
+        if world > 1:
+            dist.all_reduce(flat_g)  # ONE collective: gradients + loss scalars (SUM); mean taken below
+        if scalars:
+            self.reduced_scalars = flat_g[total:total + len(scalars)] / world
+        g = self.param_groups[0]
+        self._steps += 1
+        p = lambda t: C.c_void_p(t.data_ptr())
+        check(lib.mmif_clip_adam_step(p(self._flat_p), p(flat_g), p(self._m), p(self._v), total, g["lr"], g["betas"][0],
+                                      g["betas"][1], g["eps"], self._steps, float(g["max_norm"] or 0.0), 1.0 / world,
+                                      p(self.grad_norm), p(self._ws), self._ws.numel() * 4, stream_ptr()), "clip_adam_step")
+        E.WEIGHTS_EPOCH[0] += 1  # packed bf16 weight images are stale now
+        return loss

@@ -1,0 +1,175 @@
+"""Blocked-NHWC device tensors and thin wrappers over the C ABI (one Python call = one kernel launch
+sequence on the current HIP stream)."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import BF16, F32, MmifTensor, check, lib
+
+_TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16}
+_CODE = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def require_device(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(f"mmif: {what} must live on the GPU (got a {t.device} tensor); the HIP engine has no CPU path")
+
+
+class BT:
+    """A view [cb_off, cb_off+cb) of a blocked allocation [n][cb_total][h+2*halo][w+2*halo][8]."""
+    __slots__ = ("buf", "n", "h", "w", "halo", "cb_total", "cb_off", "cb", "code", "_d")
+
+    def __init__(self, buf, n, h, w, halo, cb_total, cb_off, cb, code):
+        self.buf, self.n, self.h, self.w, self.halo = buf, n, h, w, halo
+        self.cb_total, self.cb_off, self.cb, self.code = cb_total, cb_off, cb, code
+        self._d = MmifTensor(buf.data_ptr(), code, n, h, w, halo, cb_total, cb_off, cb)
+
+    @staticmethod
+    def alloc(n, c, h, w, dtype, device, halo=0, zero=False):
+        cb = (c + 7) // 8
+        shape = (n, cb, h + 2 * halo, w + 2 * halo, 8)
+        buf = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=device)
+        return BT(buf, n, h, w, halo, cb, 0, cb, _CODE[dtype])
+
+    def view(self, cb_off, cb):
+        assert 0 <= cb_off and cb_off + cb <= self.cb, (cb_off, cb, self.cb)
+        return BT(self.buf, self.n, self.h, self.w, self.halo, self.cb_total, self.cb_off + cb_off, cb, self.code)
+
+    @property
+    def d(self):
+        return C.byref(self._d)
+
+    @property
+    def channels(self):
+        return self.cb * 8
+
+    @property
+    def dtype(self):
+        return _TORCH_DTYPE[self.code]
+
+    # ---- boundary conversions (reference tensors are NCHW fp32) ----
+    @staticmethod
+    def from_nchw(x, dtype, halo=0):
+        require_device(x, "input")
+        x = x.contiguous().float()
+        n, c, h, w = x.shape
+        t = BT.alloc(n, c, h, w, dtype, x.device, halo, zero=halo > 0)
+        check(lib.mmif_nchw_to_blocked(_ptr(x), c, t.d, stream_ptr()), "nchw_to_blocked")
+        return t
+
+    def to_nchw(self, c=None):
+        c = self.channels if c is None else c
+        out = torch.empty((self.n, c, self.h, self.w), dtype=torch.float32, device=self.buf.device)
+        check(lib.mmif_blocked_to_nchw(self.d, _ptr(out), c, stream_ptr()), "blocked_to_nchw")
+        return out
+
+    def zero_(self):
+        check(lib.mmif_zero(self.d, stream_ptr()), "zero")
+        return self
+
+
+class PackedWeights:
+    """bf16 MFMA operand images of one conv layer's weights (forward + dgrad)."""
+    __slots__ = ("fwd", "dgrad", "cout", "cin", "k")
+
+    def __init__(self, cout, cin, k, device):
+        nbytes = lib.mmif_packed_weight_bytes(cout, cin, k)
+        self.fwd = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self.dgrad = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self.cout, self.cin, self.k = cout, cin, k
+
+    def pack(self, w):
+        check(lib.mmif_pack_weights(_ptr(w), self.cout, self.cin, self.k, _ptr(self.fwd), _ptr(self.dgrad), stream_ptr()),
+              "pack_weights")
+
+
+# ------------------------------------------------------------------ per-op HIP-event timing (bench.py roofline)
+PROFILE_TAGS = set()     # op tags ("<layer>:fwd|dgrad|wgrad") to time
+PROFILE_EVENTS = {}      # tag -> [(start_event, end_event), ...] recorded on the launch stream
+
+
+class _timed:
+    __slots__ = ("tag", "e0")
+
+    def __init__(self, tag):
+        self.tag = tag if (tag is not None and tag in PROFILE_TAGS) else None
+
+    def __enter__(self):
+        if self.tag is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *a):
+        if self.tag is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            PROFILE_EVENTS.setdefault(self.tag, []).append((self.e0, e1))
+
+
+# ------------------------------------------------------------------ op wrappers
+def conv_fwd(x, w, bias, y, cin, cout, k, relu, packed=None, impl=_lib.IMPL_AUTO, tag=None):
+    with _timed(tag):
+        check(lib.mmif_conv2d_reflect_fwd(x.d, _ptr(w), _ptr(packed.fwd) if packed is not None else None, _ptr(bias), y.d,
+                                          cin, cout, k, int(relu), impl, stream_ptr()), "conv2d_reflect_fwd")
+
+
+def conv_dgrad(gy, w, x, gx, cin, cout, k, mask_bits=0, accum_bits=0, packed=None, impl=_lib.IMPL_AUTO, tag=None):
+    with _timed(tag):
+        check(lib.mmif_conv2d_reflect_dgrad(gy.d, _ptr(w), _ptr(packed.dgrad) if packed is not None else None,
+                                            x.d if x is not None else None, gx.d, cin, cout, k, mask_bits, accum_bits, impl,
+                                            stream_ptr()), "conv2d_reflect_dgrad")
+
+
+def conv_wgrad(x, gy, dw, db, cin, cout, k, ws, accumulate=False, impl=_lib.IMPL_AUTO, tag=None):
+    with _timed(tag):
+        check(lib.mmif_conv2d_reflect_wgrad(x.d, gy.d, _ptr(dw), _ptr(db), cin, cout, k, int(accumulate), _ptr(ws),
+                                            ws.numel() * ws.element_size(), impl, stream_ptr()), "conv2d_reflect_wgrad")
+
+
+def image_in_fwd(img, w, bias, y, cout, k, relu):
+    check(lib.mmif_conv2d_image_in_fwd(_ptr(img), _ptr(w), _ptr(bias), y.d, cout, k, int(relu), stream_ptr()), "image_in_fwd")
+
+
+def image_in_wgrad(img, gy, dw, db, cout, k, ws, accumulate=False):
+    check(lib.mmif_conv2d_image_in_wgrad(_ptr(img), gy.d, _ptr(dw), _ptr(db), cout, k, int(accumulate), _ptr(ws),
+                                         ws.numel() * ws.element_size(), stream_ptr()), "image_in_wgrad")
+
+
+def image_out_fwd(x, w, bias, img, cin, k, relu):
+    check(lib.mmif_conv2d_image_out_fwd(x.d, _ptr(w), _ptr(bias), _ptr(img), cin, k, int(relu), stream_ptr()), "image_out_fwd")
+
+
+def image_out_dgrad(gimg, yimg, w, x, gx, cin, k, mask_bits=0, accum_bits=0):
+    check(lib.mmif_conv2d_image_out_dgrad(_ptr(gimg), _ptr(yimg), _ptr(w), x.d if x is not None else None, gx.d, cin, k,
+                                          mask_bits, accum_bits, stream_ptr()), "image_out_dgrad")
+
+
+def image_out_wgrad(x, gimg, yimg, dw, db, cin, k, ws, accumulate=False):
+    check(lib.mmif_conv2d_image_out_wgrad(x.d, _ptr(gimg), _ptr(yimg), _ptr(dw), _ptr(db), cin, k, int(accumulate), _ptr(ws),
+                                          ws.numel() * ws.element_size(), stream_ptr()), "image_out_wgrad")
+
+
+def fuse_elem_fwd(a, b, out, mode):
+    check(lib.mmif_fuse_elem_fwd(a.d, b.d, out.d, mode, stream_ptr()), "fuse_elem_fwd")
+
+
+def fuse_elem_bwd(a, b, g, ga, gb, mode, relu_mask):
+    check(lib.mmif_fuse_elem_bwd(a.d if a is not None else None, b.d if b is not None else None, g.d, ga.d, gb.d, mode,
+                                 int(relu_mask), stream_ptr()), "fuse_elem_bwd")
+
+
+def wgrad_workspace_bytes(cin, cout, k):
+    return lib.mmif_conv2d_wgrad_workspace(cin, cout, k)
+
+
+def image_wgrad_workspace_bytes(c, k):
+    return lib.mmif_conv2d_image_wgrad_workspace(c, k)

@@ -1,0 +1,71 @@
+"""Fusion-loss kernels (SSIM / pixel / Sobel-gradient: value and d/dimgf in one launch) against the
+reference's known answers (core/loss.py:388-423 recipe) and autograd gradients (golden F1 / F2)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fusion_oracle as O
+from gpu_util import G, close, tg
+from test_oracle_golden import f2_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def _losses():
+    from core.loss import GradLoss, PixelLoss, SSIMLoss
+    return SSIMLoss('ssim', weight=1.0), PixelLoss('l1', weight=0.01), GradLoss('l1', weight=0.1).to("cuda:0")
+
+
+def test_known_answer_losses():
+    ref = json.load(open(os.path.join(G, "f1_loss_known_answer.json")))
+    torch.manual_seed(0)
+    x1 = torch.rand(2, 1, 256, 256).to("cuda:0")
+    x2 = torch.rand(2, 1, 256, 256).to("cuda:0")
+    y = torch.rand(2, 1, 256, 256).to("cuda:0")
+    l1, l2, l3 = _losses()
+    a = l1(x1, x2, y).item()
+    assert abs(a - ref["ssim"]) < 5e-6 and abs(a - 0.9944541454) < 5e-6
+    assert abs(l2(x1, x2, y).item() - ref["pixel_avg"]) < 1e-7
+    assert abs(l3(x1, x2, y).item() - ref["grad_avg"]) < 1e-6
+    b = l2(x1, x2, y, mode='max').item()
+    c = l3(x1, x2, y, mode='max').item()
+    assert abs(b - ref["pixel_max"]) < 1e-7 and abs(c - ref["grad_max"]) < 1e-6
+    assert abs((a + b + c) - ref["total_max"]) < 6e-6
+    from core.loss import SSIM
+    s = SSIM(11, 1.0, False)(x1, y)['ssim'].cpu().numpy()
+    np.testing.assert_allclose(s, ref["ssim_per_sample_x1_y"], atol=5e-7)
+    assert l2(x1, x2, y, mode='nope') is None and l3(x1, x2, y, mode='nope') is None
+
+
+@pytest.mark.parametrize("case", list("abcd"))
+def test_loss_grads_vs_reference_autograd(case):
+    ref = np.load(os.path.join(G, "f2_loss_grads.npz"))
+    i1, i2, f = f2_inputs(case)
+    l1, l2, l3 = _losses()
+    t1, t2 = tg(i1), tg(i2)
+    tf = tg(f).requires_grad_(True)
+    a, b, c = l1(t1, t2, tf), l2(t1, t2, tf, mode='max'), l3(t1, t2, tf, mode='max')
+    assert abs(a.item() - ref[f"{case}_l_ssim"]) < 5e-6
+    assert abs(b.item() - ref[f"{case}_l_pixel"]) < 1e-7
+    assert abs(c.item() - ref[f"{case}_l_grad"]) < 1e-6
+    rt = 5e-3 if case == "c" else 3e-4  # case c: sigma_f^2 == 0, the reference's own fp32 gradient is ill-conditioned
+    for l, key, tol in ((a, "g_ssim", rt), (b, "g_pixel", 1e-5), (c, "g_grad", 1e-5)):
+        g, = torch.autograd.grad(l, tf, retain_graph=True)
+        close(g.cpu().numpy(), ref[f"{case}_{key}"], tol, key)
+    g, = torch.autograd.grad(a + b + c, tf)
+    close(g.cpu().numpy(), ref[f"{case}_g_total"], rt, "g_total")
+    assert abs(l2(t1, t2, tf, mode='avg').item() - ref[f"{case}_l_pixel_avg"]) < 1e-7
+    assert abs(l3(t1, t2, tf, mode='avg').item() - ref[f"{case}_l_grad_avg"]) < 1e-6
+
+
+def test_loss_errors():
+    from core.loss import NormLoss, SSIMLoss
+    with pytest.raises(ValueError):
+        SSIMLoss('nope')(torch.zeros(1, 1, 16, 16, device="cuda:0"), torch.zeros(1, 1, 16, 16, device="cuda:0"), torch.zeros(1, 1, 16, 16, device="cuda:0"))
+    with pytest.raises(ValueError):
+        NormLoss('l3')(torch.zeros(4, device="cuda:0"))
+    with pytest.raises(RuntimeError):
+        SSIMLoss()(torch.zeros(1, 1, 16, 16), torch.zeros(1, 1, 16, 16), torch.zeros(1, 1, 16, 16))  # CPU tensors: no silent fallback

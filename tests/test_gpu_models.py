@@ -1,0 +1,136 @@
+"""End-to-end parity of the model engines (forward, backward, optimiser step) with the golden
+fixtures generated from the reference (F5 forward + gradient digests, F6 3-step trajectories)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fusion_oracle as O
+from gpu_util import G, close, close_digest, dtype_ctx, load_closed_form, rel_err, tg
+
+pytestmark = pytest.mark.gpu
+
+CASES = [("PFNetv1", (2, 1, 32, 32)), ("DenseFuse", (2, 1, 32, 32)), ("PFNetv1", (1, 1, 37, 53))]
+
+
+def _model(name, seed):
+    import core.model as M
+    return load_closed_form(getattr(M, name)(), seed).to("cuda:0")
+
+
+@pytest.mark.parametrize("name,shape", CASES, ids=[f"{n}-{s[2]}x{s[3]}" for n, s in CASES])
+def test_model_fp32_vs_golden(name, shape):
+    ref = np.load(os.path.join(G, "f5_models.npz"))
+    man = json.load(open(os.path.join(G, "f5_manifest.json")))
+    tag = f"{name}_{shape[0]}x{shape[2]}x{shape[3]}"
+    with dtype_ctx("fp32"):
+        m = _model(name, 1)
+        assert [[k, list(v.shape)] for k, v in m.state_dict().items()] == man[name]
+        i1, i2 = tg(O.closed_form_image(shape, 0.3)), tg(O.closed_form_image(shape, 1.7))
+        y = m(i1, i2)
+        y.backward(tg(O.closed_form_signed(shape, 0.9, 1.0)))
+        torch.cuda.synchronize()
+        close(y.detach().cpu().numpy(), ref[tag + "__y"], 1e-4, "imgf")        # bar: 1e-3
+        for k, p in m.named_parameters():
+            close_digest(p.grad.cpu().numpy(), ref[f"{tag}__dp_{k}"], 2e-4, k)
+        if name == "DenseFuse":
+            with torch.no_grad():
+                close(m(i1).cpu().numpy(), ref[tag + "__y_ae"], 1e-4, "auto-encoder")
+
+
+@pytest.mark.parametrize("impl", ["valu", "mfma"])
+@pytest.mark.parametrize("name,shape", CASES, ids=[f"{n}-{s[2]}x{s[3]}" for n, s in CASES])
+def test_model_bf16_close_to_fp32(name, shape, impl):
+    """bf16 feature maps through ~10 layers cannot meet 1e-3; the documented bar for the bf16 path
+    is 3e-2 of max|.| on the fused image and 6e-2 on parameter gradients (it is an input-rounding
+    effect: test_gpu_conv pins each kernel to one output rounding)."""
+    ref = np.load(os.path.join(G, "f5_models.npz"))
+    tag = f"{name}_{shape[0]}x{shape[2]}x{shape[3]}"
+    m_or = O.MODELS[name]()
+    P = m_or.init_params(seed=1)
+    i1n, i2n, gn = O.closed_form_image(shape, 0.3), O.closed_form_image(shape, 1.7), O.closed_form_signed(shape, 0.9, 1.0)
+    y_or = m_or.forward(P, i1n, i2n)
+    G_or = m_or.backward(P, gn)
+    with dtype_ctx("bf16", impl):
+        m = _model(name, 1)
+        y = m(tg(i1n), tg(i2n))
+        y.backward(tg(gn))
+        torch.cuda.synchronize()
+        close(y.detach().cpu().numpy(), y_or, 3e-2, "imgf")
+        for k, p in m.named_parameters():
+            close(p.grad.cpu().numpy(), G_or[k], 6e-2, k)
+
+
+def test_mfma_and_valu_kernels_agree_bf16():
+    """Same bf16 operands through the two independent kernel families."""
+    shape = (2, 1, 48, 40)
+    i1n, i2n, gn = O.closed_form_image(shape, 0.3), O.closed_form_image(shape, 1.7), O.closed_form_signed(shape, 0.9, 1.0)
+    res = {}
+    for impl in ("valu", "mfma"):
+        with dtype_ctx("bf16", impl):
+            m = _model("PFNetv1", 1)
+            y = m(tg(i1n), tg(i2n))
+            y.backward(tg(gn))
+            torch.cuda.synchronize()
+            res[impl] = (y.detach().cpu().numpy(), {k: p.grad.cpu().numpy() for k, p in m.named_parameters()})
+    close(res["mfma"][0], res["valu"][0], 1e-2, "imgf")
+    for k in res["valu"][1]:
+        close(res["mfma"][1][k], res["valu"][1][k], 3e-2, k)
+
+
+@pytest.mark.parametrize("name", ["PFNetv1", "DenseFuse"])
+def test_train_trajectory_fp32(name):
+    """train.py:61-75 semantics for 3 steps: losses, pre-clip gradient norm, updated weights."""
+    from core.loss import GradLoss, PixelLoss, SSIMLoss
+    from mmif.optim import FusedClipAdam
+    ref = np.load(os.path.join(G, "f6_traj.npz"))
+    rows = ref[name + "__rows"]
+    with dtype_ctx("fp32"):
+        m = _model(name, 2)
+        opt = FusedClipAdam(m.parameters(), lr=1e-4, betas=(0.9, 0.999), max_norm=5.0)
+        l_ssim, l_pix, l_grad = SSIMLoss('ssim', weight=1.0), PixelLoss('l1', weight=0.01), GradLoss('l1', weight=0.1).to("cuda:0")
+        shape = (4, 1, 64, 64)
+        for step in range(3):
+            i1, i2 = tg(O.closed_form_image(shape, 0.21 + step)), tg(O.closed_form_image(shape, 1.43 + step))
+            opt.zero_grad(set_to_none=True)
+            f = m(i1, i2)
+            a, b, c = l_ssim(i1, i2, f), l_pix(i1, i2, f, mode='max'), l_grad(i1, i2, f, mode='max')
+            tot = a + b + c
+            tot.backward()
+            opt.step()
+            torch.cuda.synchronize()
+            if step == 0:
+                close(f.detach().cpu().numpy(), ref[name + "__imgf0"], 1e-4, "imgf")
+            got = [a.item(), b.item(), c.item(), tot.item(), opt.grad_norm.item()]
+            np.testing.assert_allclose(got, rows[step], rtol=5e-4, atol=5e-6, err_msg=f"step {step}")
+        for k, p in m.state_dict().items():
+            close_digest(p.cpu().numpy(), ref[f"{name}__w_{k}"], 5e-5, k)
+
+
+def test_torch_optimizer_and_grad_accumulation_semantics():
+    """The engine's gradients behave like ordinary autograd gradients: usable by torch.optim.Adam +
+    clip_grad_norm_ (reference train.py:72-75 verbatim), and accumulate over two backward passes."""
+    with dtype_ctx("fp32"):
+        m = _model("DenseFuse", 2)
+        shape = (2, 1, 32, 32)
+        i1, i2 = tg(O.closed_form_image(shape, 0.21)), tg(O.closed_form_image(shape, 1.43))
+        g = tg(O.closed_form_signed(shape, 0.5))
+        m(i1, i2).backward(g)
+        once = {k: p.grad.clone() for k, p in m.named_parameters()}
+        m(i1, i2).backward(g)
+        for k, p in m.named_parameters():
+            assert rel_err(p.grad.cpu().numpy(), 2 * once[k].cpu().numpy()) < 1e-6, k
+        opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+        before = {k: p.detach().clone() for k, p in m.named_parameters()}
+        torch.nn.utils.clip_grad_norm_(m.parameters(), max_norm=5)
+        opt.step()
+        assert any((p.detach() != before[k]).any().item() for k, p in m.named_parameters())
+
+
+def test_cpu_tensors_fail_loudly():
+    import core.model as M
+    m = M.PFNetv1()
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 1, 16, 16), torch.zeros(1, 1, 16, 16))
