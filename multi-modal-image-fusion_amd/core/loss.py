@@ -45,7 +45,7 @@ class _LossFn(torch.autograd.Function):
     def forward(ctx, imgf, img1, img2, kind, weight, a, b):
         i1, i2, f = _prep(img1, img2, imgf)
         n, _, h, w = f.shape
-        need = imgf.requires_grad and torch.is_grad_enabled()
+        need = ctx.needs_input_grad[0]
         out = torch.empty(1, dtype=torch.float32, device=f.device)
         grad = torch.empty_like(f) if need else None
         ws = _workspace(n, h, w, f.device)

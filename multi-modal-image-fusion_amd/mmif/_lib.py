@@ -5,6 +5,10 @@ there is no CPU or torch fallback for the hot path."""
 import ctypes as C
 import os
 
+import torch  # noqa: F401  MUST precede the CDLL below: the process-wide HIP runtime has to be the one torch
+#                            ships (libamdhip64 in torch/lib); loading ours first leaves two runtimes that do not
+#                            share devices ("no ROCm-capable device is detected" on the first launch)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "libmmif_hip.so")
 
