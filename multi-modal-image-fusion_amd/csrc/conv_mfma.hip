@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(TV tin, TV tout, TV t
             const bool inside = y >= 0 && y < tin.h && x >= 0 && x < tin.w;
             const bool border = tin.halo && ((y == 1) || (y == tin.h - 2) || (x == 1) || (x == tin.w - 2));
             mode = !inside ? 0 : (border ? 2 : 1);
-            ioff[i] = (y + tin.halo) * tin.ws + x + tin.halo;
+            ioff[i] = (min(max(y, 0), tin.h - 1) + tin.halo) * tin.ws + min(max(x, 0), tin.w - 1) + tin.halo;  // always a valid address
         }
         idesc[i] = (cb * PL + p) | (cb << 16) | (mode << 20);
     }
@@ -181,12 +181,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(TV tin, TV tout, TV t
         const int nkgp = (KK * ncb + 3) / 4 * 4;
 #pragma unroll
         for (int i = 0; i < NIN; ++i) {
-            uint4 v = make_uint4(0, 0, 0, 0);
+            // unconditional load from a clamped (always valid) address, zero by select: no branch, no serialisation
             const int cb = (idesc[i] >> 16) & 15, mode = idesc[i] >> 20;
-            if (cb < ncb) {
-                if (mode >= 1) v = *reinterpret_cast<const uint4*>(in_img + ((long long)(c0 + cb) * tin.plane + ioff[i]) * 16);
-            }
-            rin[i] = v;
+            const uint4 v = *reinterpret_cast<const uint4*>(in_img + ((long long)(c0 + min(cb, ncb - 1)) * tin.plane + ioff[i]) * 16);
+            rin[i] = (cb < ncb && mode >= 1) ? v : make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
@@ -304,35 +302,47 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(TV tin, TV tout, TV t
 }
 
 // ------------------------------------------------------------------ wgrad kernel (K = pixels)
-// block: (pixel-tile group, input-channel group of 16, output-channel group of MFW*16); wave w
-// consumes k-steps 2w, 2w+1 of each 16x16 tile (k-step = 2 tile rows = 32 pixels):
-//   lane group g of a k-step: tile row 2s + (g>>1), cols 8*(g&1) .. +7
-// A = g^T (oc x pixels), B = shifted x (pixels x (tap, ic)); acc[m][tap] 16x16 blocks.
+// block: (pixel-tile group gi, input-channel group of 16, output-channel group of MFW*16).
+// k-step = 2 tile rows = 32 pixels; lane group g of a k-step: tile row 2s + (g>>1), cols 8*(g&1)..+7.
+// The 4 waves split K (KSPLIT halves/quarters of the tile's 8 k-steps) x M (MW = MFW*KSPLIT/4 M-frags
+// each): A = g^T (oc x pixels), B = shifted x (pixels x (tap, ic)); acc[m][tap] are 16x16 blocks.
 constexpr int WG_XPL = 324;   // x-tile plane stride in granules  (5184 B = 64 mod 256)
 constexpr int WG_GPL = 260;   // g-tile plane stride in granules  (4160 B = 64 mod 256)
 
-template <int KS, int MFW>
+template <int KS, int MFW, int KSPLIT>
 __global__ __launch_bounds__(256) void wgrad_mfma_kernel(TV tx, TV tg, float* __restrict__ partial, int tiles_x,
-                                                         int tpi, int total) {
+                                                         int tpi, int total, int G, int n_icg, int n_ocg) {
     constexpr int KK = KS * KS, P = KS / 2, TP = MT + KS - 1;
     constexpr int XPL = KS == 3 ? WG_XPL : WG_GPL;
-    constexpr int PER = MFW * 16 * 16 * KK + MFW * 16;  // floats per block partial
+    constexpr int MGROUPS = 4 / KSPLIT;                  // wave groups along M
+    constexpr int MW = MFW / MGROUPS;                    // M-frags per wave
+    constexpr int KSTEPS = 8 / KSPLIT;                   // k-steps per wave per tile
+    constexpr int PER = MFW * 16 * 16 * KK + MFW * 16;   // floats per block partial
     constexpr int TILE_BYTES = (2 * XPL + MFW * 2 * WG_GPL) * 16;
-    constexpr int RED_BYTES = MFW * 16 * 16 * KK * 4 + MFW * 16 * 4;
+    constexpr int RED_BYTES = PER * 4;
     constexpr int SM_BYTES = TILE_BYTES > RED_BYTES ? TILE_BYTES : RED_BYTES;
+    static_assert(MFW % MGROUPS == 0, "bad wave split");
     __shared__ __attribute__((aligned(16))) char smem[SM_BYTES];
     uint4* s_x = reinterpret_cast<uint4*>(smem);
     uint4* s_g = s_x + 2 * XPL;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int sl = lane & 15, g = lane >> 4;
-    const int icg = blockIdx.y, ocg = blockIdx.z;
+    const int km = wave % KSPLIT, mm = wave / KSPLIT;
+    // XCD-aware block order: the n_icg*n_ocg blocks that walk the SAME tiles are adjacent in dispatch order
+    // and land on the same XCD (block b runs on XCD b % 8), so the shared g / x tiles are L2 hits
+    const int npairs = n_icg * n_ocg;
+    const int b = blockIdx.x;
+    int gi, pair;
+    if ((G & 7) == 0) { pair = (b >> 3) % npairs; gi = ((b >> 3) / npairs) * 8 + (b & 7); }
+    else { pair = b % npairs; gi = b / npairs; }
+    const int icg = pair % n_icg, ocg = pair / n_icg;
     const int xcb0 = icg * 2, gcb0 = ocg * MFW * 2;
 
-    f32x4 acc[MFW][KK];
-    f32x4 accb[MFW];
+    f32x4 acc[MW][KK];
+    f32x4 accb[MW];
 #pragma unroll
-    for (int m = 0; m < MFW; ++m) {
+    for (int m = 0; m < MW; ++m) {
         accb[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < KK; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -346,28 +356,32 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(TV tx, TV tg, float* __
     const int lane_plane = tr_c >> 1, lane_byte = (tr_c & 1) * 8;
 
     constexpr int NX = (2 * TP * TP + 255) / 256;      // x granules per thread per tile
-    constexpr int NG = MFW * 2;                         // g granules per thread per tile (256 px per plane)
+    constexpr int NG = MFW * 2;                         // g granules per thread per tile (one per plane)
     uint4 rx[NX], rg[NG];
+    // all prefetch loads are unconditional (clamped addresses, zero by select): nothing serialises them
     auto prefetch = [&](int tile) {
         const int in_ = tile / tpi, tt = tile % tpi;
         const int y0 = (tt / tiles_x) * MT, x0 = (tt % tiles_x) * MT;
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            const int e = tid + 256 * i;
+            const int e = min(tid + 256 * i, 2 * TP * TP - 1);
             const int cb = e / (TP * TP), p = e % (TP * TP);
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (cb < 2 && xcb0 + cb < tx.cb) v = load_in_reflect(tx, in_, xcb0 + cb, y0 + p / TP - P, x0 + p % TP - P);
-            rx[i] = v;
+            const int y = min(max(reflect_idx(y0 + p / TP - P, tx.h), 0), tx.h - 1);
+            const int x = min(max(reflect_idx(x0 + p % TP - P, tx.w), 0), tx.w - 1);
+            const uint4 v = ld_gran(tx, in_, min(xcb0 + cb, tx.cb - 1), y, x);
+            rx[i] = (xcb0 + cb < tx.cb) ? v : make_uint4(0, 0, 0, 0);
         }
+        const int gy = y0 + tid / MT, gx = x0 + tid % MT;
+        const bool inside = gy < tg.h && gx < tg.w;
+        const int cy = min(gy, tg.h - 1) + tg.halo, cx = min(gx, tg.w - 1) + tg.halo;
 #pragma unroll
         for (int i = 0; i < NG; ++i) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (gcb0 + i < tg.cb) v = load_in_gradfold(tg, in_, gcb0 + i, y0 + tid / MT, x0 + tid % MT);
-            rg[i] = v;
+            const uint4 v = ld_gran(tg, in_, min(gcb0 + i, tg.cb - 1), cy, cx);
+            rg[i] = (inside && gcb0 + i < tg.cb) ? v : make_uint4(0, 0, 0, 0);
         }
     };
-    if ((int)blockIdx.x < total) prefetch(blockIdx.x);
-    for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
+    if (gi < total) prefetch(gi);
+    for (int tile = gi; tile < total; tile += G) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
@@ -377,27 +391,42 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(TV tx, TV tg, float* __
         }
 #pragma unroll
         for (int i = 0; i < NG; ++i) s_g[i * WG_GPL + tid] = rg[i];
+        if (tg.halo) {
+            // rare: tiles containing row/col 1 or h-2 / w-2 of a padded-domain gradient fold the halo in
+            const int in_ = tile / tpi, tt = tile % tpi;
+            const int y0 = (tt / tiles_x) * MT, x0 = (tt % tiles_x) * MT;
+            const bool fold_tile = (y0 <= 1 && 1 < y0 + MT) || (y0 <= tg.h - 2 && tg.h - 2 < y0 + MT) ||
+                                   (x0 <= 1 && 1 < x0 + MT) || (x0 <= tg.w - 2 && tg.w - 2 < x0 + MT);
+            if (fold_tile) {
+                const int gy = y0 + tid / MT, gx = x0 + tid % MT;
+                if (gy < tg.h && gx < tg.w && (gy == 1 || gy == tg.h - 2 || gx == 1 || gx == tg.w - 2)) {
+#pragma unroll 1
+                    for (int i = 0; i < NG; ++i)
+                        if (gcb0 + i < tg.cb) s_g[i * WG_GPL + tid] = load_in_gradfold(tg, in_, gcb0 + i, gy, gx);
+                }
+            }
+        }
         __syncthreads();
-        if (tile + (int)gridDim.x < total) prefetch(tile + gridDim.x);  // in flight during the MFMAs below
+        if (tile + G < total) prefetch(tile + G);  // in flight during the MFMAs below
 #pragma unroll
-        for (int ss = 0; ss < 2; ++ss) {
-            const int s = wave * 2 + ss;
+        for (int ss = 0; ss < KSTEPS; ++ss) {
+            const int s = km * KSTEPS + ss;
             const int row = 2 * s + (g >> 1), col0 = 8 * (g & 1);
+            typedef __attribute__((ext_vector_type(8))) short s16x8;
             // A fragments: g^T, M-frag m = planes 2m, 2m+1
-            bf16x8 a[MFW];
+            bf16x8 a[MW];
 #pragma unroll
-            for (int m = 0; m < MFW; ++m) {
+            for (int m = 0; m < MW; ++m) {
                 const char* base = reinterpret_cast<const char*>(s_g) +
-                                   (((2 * m + lane_plane) * WG_GPL) + row * MT + col0 + tr_row) * 16 + lane_byte;
+                                   (((2 * (mm * MW + m) + lane_plane) * WG_GPL) + row * MT + col0 + tr_row) * 16 + lane_byte;
                 const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, base));
                 const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, base + 4 * 16));
-                typedef __attribute__((ext_vector_type(8))) short s16x8;
                 const s16x8 c = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                 a[m] = __builtin_bit_cast(bf16x8, c);
             }
             if (icg == 0) {
 #pragma unroll
-                for (int m = 0; m < MFW; ++m) accb[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], ones, accb[m], 0, 0, 0);
+                for (int m = 0; m < MW; ++m) accb[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], ones, accb[m], 0, 0, 0);
             }
 #pragma unroll
             for (int t = 0; t < KK; ++t) {
@@ -406,62 +435,74 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(TV tx, TV tg, float* __
                                    ((lane_plane * XPL) + (row + u) * TP + col0 + v + tr_row) * 16 + lane_byte;
                 const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, base));
                 const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, base + 4 * 16));
-                typedef __attribute__((ext_vector_type(8))) short s16x8;
                 const s16x8 c = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                const bf16x8 b = __builtin_bit_cast(bf16x8, c);
+                const bf16x8 bb = __builtin_bit_cast(bf16x8, c);
 #pragma unroll
-                for (int m = 0; m < MFW; ++m) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], b, acc[m][t], 0, 0, 0);
+                for (int m = 0; m < MW; ++m) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], bb, acc[m][t], 0, 0, 0);
             }
         }
     }
-    // ---- combine the 4 waves (K split) through LDS, then write the block partial ----
-    // lane (g, sl) reg r holds (oc = 16m + 4g + r, ic = sl) for tap t; bias sums: column sl (all equal)
+    // ---- combine the KSPLIT K-slices through LDS, then write the block partial ----
+    // lane (g, sl) reg r holds (oc = 16*frag + 4g + r, ic = sl) for tap t; bias sums: any column (all equal)
     float* red = reinterpret_cast<float*>(smem);  // [MFW*16 oc][16 ic][KK] + [MFW*16]
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < KSPLIT; ++w) {
         __syncthreads();
-        if (wave == w) {
+        if (km == w) {
 #pragma unroll
-            for (int m = 0; m < MFW; ++m) {
+            for (int m = 0; m < MW; ++m) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int oc = 16 * m + 4 * g + r;
+                    const int oc = 16 * (mm * MW + m) + 4 * g + r;
 #pragma unroll
                     for (int t = 0; t < KK; ++t) {
-                        float* p = &red[(oc * 16 + sl) * KK + t];
-                        *p = (w == 0 ? 0.f : *p) + acc[m][t][r];
+                        float* pp = &red[(oc * 16 + sl) * KK + t];
+                        *pp = (w == 0 ? 0.f : *pp) + acc[m][t][r];
                     }
                     if (sl == 0) {
-                        float* p = &red[MFW * 16 * 16 * KK + oc];
-                        *p = (w == 0 ? 0.f : *p) + accb[m][r];
+                        float* pp = &red[MFW * 16 * 16 * KK + oc];
+                        *pp = (w == 0 ? 0.f : *pp) + accb[m][r];
                     }
                 }
             }
         }
     }
     __syncthreads();
-    float* dst = partial + (((long long)blockIdx.x * gridDim.y + icg) * gridDim.z + ocg) * PER;
+    float* dst = partial + (((long long)gi * n_icg + icg) * n_ocg + ocg) * PER;
     for (int e = tid; e < PER; e += 256) dst[e] = red[e];
 }
 
+// 64 outputs x 4 G-slices per block: coalesced across outputs, 4-way parallel over G, fixed order
 template <int KS, int MFW>
-__global__ void wgrad_mfma_reduce(const float* __restrict__ partial, float* __restrict__ dw, float* __restrict__ db,
-                                  int cin, int cout, int G, int n_icg, int n_ocg, int accumulate) {
+__global__ __launch_bounds__(256) void wgrad_mfma_reduce(const float* __restrict__ partial, float* __restrict__ dw,
+                                                         float* __restrict__ db, int cin, int cout, int G, int n_icg,
+                                                         int n_ocg, int accumulate) {
     constexpr int KK = KS * KS;
     constexpr int PER = MFW * 16 * 16 * KK + MFW * 16;
+    __shared__ float red[4][64];
     const int total_w = cout * cin * KK;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int o_local = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + o_local;
+    long long off = -1;
     if (idx < total_w) {
         const int tap = idx % KK, c = (idx / KK) % cin, o = idx / (KK * cin);
         const int icg = c / 16, ic = c % 16, ocg = o / (MFW * 16), oc = o % (MFW * 16);
-        float s = 0.f;
-        for (int gi = 0; gi < G; ++gi) s += partial[(((long long)gi * n_icg + icg) * n_ocg + ocg) * PER + (oc * 16 + ic) * KK + tap];
-        dw[idx] = accumulate ? dw[idx] + s : s;
-    } else if (idx < total_w + cout && db != nullptr) {
+        off = ((long long)icg * n_ocg + ocg) * PER + (oc * 16 + ic) * KK + tap;
+    } else if (idx < total_w + cout) {
         const int o = idx - total_w;
         const int ocg = o / (MFW * 16), oc = o % (MFW * 16);
-        float s = 0.f;
-        for (int gi = 0; gi < G; ++gi) s += partial[(((long long)gi * n_icg + 0) * n_ocg + ocg) * PER + MFW * 16 * 16 * KK + oc];
-        db[o] = accumulate ? db[o] + s : s;
+        off = ((long long)0 * n_ocg + ocg) * PER + MFW * 16 * 16 * KK + oc;
+    }
+    float s = 0.f;
+    if (off >= 0) {
+        const long long stride = (long long)n_icg * n_ocg * PER;
+        for (int gi = slice; gi < G; gi += 4) s += partial[gi * stride + off];
+    }
+    red[slice][o_local] = s;
+    __syncthreads();
+    if (slice == 0 && off >= 0) {
+        const float t = (red[0][o_local] + red[1][o_local]) + (red[2][o_local] + red[3][o_local]);
+        if (idx < total_w) dw[idx] = accumulate ? dw[idx] + t : t;
+        else if (db != nullptr) db[idx - total_w] = accumulate ? db[idx - total_w] + t : t;
     }
 }
 
@@ -501,14 +542,13 @@ int conv_mfma(bool dgrad, int ks, const TV& tin, const TV& tout, const TV& tmask
 }
 
 static inline int pick_mfw(int cout) { return cout <= 16 ? 1 : (cout <= 32 ? 2 : 4); }
-constexpr int WG_MAX_G = 1024;
 
 static int wgrad_G(int cin, int cout) {
     const int nb = cdiv(cin, 16) * cdiv(cout, pick_mfw(cout) * 16);
     int G = 1024 / nb;
-    if (G < 32) G = 32;
-    if (G > WG_MAX_G) G = WG_MAX_G;
-    return G;
+    if (G < 64) G = 64;
+    if (G > 512) G = 512;
+    return (G + 7) / 8 * 8;
 }
 
 bool wgrad_mfma_supported(int ks, int cin, int cout) { return (ks == 1 || ks == 3) && cin % 8 == 0 && cin >= 8 && cout >= 8; }
@@ -519,18 +559,19 @@ size_t wgrad_mfma_workspace(int cin, int cout, int ks) {
     return (size_t)wgrad_G(cin, cout) * cdiv(cin, 16) * cdiv(cout, mfw * 16) * per * sizeof(float);
 }
 
-template <int KS, int MFW>
+template <int KS, int MFW, int KSPLIT>
 static int launch_wgrad_mfma(const TV& tx, const TV& tg, float* dw, float* db, int cin, int cout, int accumulate, float* ws,
                              hipStream_t st) {
     const int tiles_x = cdiv(tx.w, MT), tiles_y = cdiv(tx.h, MT);
     const int tpi = tiles_x * tiles_y, total = tpi * tx.n;
     int G = wgrad_G(cin, cout);
-    if (G > total) G = total;
+    if (G > total) G = total;  // (no longer a multiple of 8: the kernel falls back to the plain block order)
     const int n_icg = cdiv(cin, 16), n_ocg = cdiv(cout, MFW * 16);
-    hipLaunchKernelGGL((wgrad_mfma_kernel<KS, MFW>), dim3(G, n_icg, n_ocg), dim3(256), 0, st, tx, tg, ws, tiles_x, tpi, total);
+    hipLaunchKernelGGL((wgrad_mfma_kernel<KS, MFW, KSPLIT>), dim3(G * n_icg * n_ocg), dim3(256), 0, st, tx, tg, ws, tiles_x, tpi,
+                       total, G, n_icg, n_ocg);
     if (int rc = check_launch("wgrad_mfma")) return rc;
     const int n = cout * cin * KS * KS + cout;
-    hipLaunchKernelGGL((wgrad_mfma_reduce<KS, MFW>), dim3(cdiv(n, 256)), dim3(256), 0, st, ws, dw, db, cin, cout, G, n_icg, n_ocg,
+    hipLaunchKernelGGL((wgrad_mfma_reduce<KS, MFW>), dim3(cdiv(n, 64)), dim3(256), 0, st, ws, dw, db, cin, cout, G, n_icg, n_ocg,
                        accumulate);
     return check_launch("wgrad_mfma_reduce");
 }
@@ -538,11 +579,11 @@ static int launch_wgrad_mfma(const TV& tx, const TV& tg, float* dw, float* db, i
 int wgrad_mfma(int ks, const TV& tx, const TV& tg, float* dw, float* db, int cin, int cout, int accumulate, float* ws,
                hipStream_t st) {
     const int mfw = pick_mfw(cout);
-#define GO(KS_, M_) return launch_wgrad_mfma<KS_, M_>(tx, tg, dw, db, cin, cout, accumulate, ws, st)
+#define GO(KS_, M_, K_) return launch_wgrad_mfma<KS_, M_, K_>(tx, tg, dw, db, cin, cout, accumulate, ws, st)
     if (ks == 3) {
-        switch (mfw) { case 1: GO(3, 1); case 2: GO(3, 2); default: GO(3, 4); }
+        switch (mfw) { case 1: GO(3, 1, 4); case 2: GO(3, 2, 2); default: GO(3, 4, 2); }
     } else {
-        switch (mfw) { case 1: GO(1, 1); case 2: GO(1, 2); default: GO(1, 4); }
+        switch (mfw) { case 1: GO(1, 1, 4); case 2: GO(1, 2, 2); default: GO(1, 4, 2); }
     }
 #undef GO
 }
