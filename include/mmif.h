@@ -54,7 +54,10 @@ typedef struct mmif_tensor {
     int32_t cb_total; /* channel blocks (of 8 channels) in the allocation */
     int32_t cb_off;   /* first channel block of the view */
     int32_t cb;       /* channel blocks in the view */
+    int32_t flags;    /* MMIF_T_FOLDED: halo already folded onto the interior and zeroed (mmif_fold_halo) */
 } mmif_tensor;
+
+#define MMIF_T_FOLDED 1
 
 const char* mmif_version(void);
 const char* mmif_last_error(void);
@@ -67,6 +70,11 @@ int mmif_nchw_to_blocked(const float* src, int32_t c, const mmif_tensor* dst, vo
 int mmif_blocked_to_nchw(const mmif_tensor* src, float* dst, int32_t c, void* stream);
 /* fill a view (all of hs x ws) with zeros */
 int mmif_zero(const mmif_tensor* t, void* stream);
+/* halo-1 (padded-domain) gradient view: add the halo onto rows/cols 1 and h-2 / w-2 (adjoint of reflect
+ * padding; replaces autograd's reflection_pad2d_backward) and zero the halo, in place.  Afterwards the
+ * interior IS the gradient w.r.t. the unpadded tensor; readers given MMIF_T_FOLDED skip their fold-on-load.
+ * Linear, so it may run after every contribution of an accumulated gradient. */
+int mmif_fold_halo(const mmif_tensor* t, void* stream);
 
 /* Pack fp32 master weights [cout][cin][k][k] (nn.Conv2d layout, core/block.py:56-66) into the
  * MFMA operand images: fwd  [k*k][cin/8 ][cout16][8] and dgrad [k*k][cout16/8][cin16][8]

@@ -84,6 +84,7 @@ struct TV {
     int n, h, w, halo;     // logical extent
     int hs, ws;            // stored extent (h + 2*halo, w + 2*halo)
     int cb_total, cb_off, cb;
+    int folded;            // halo already folded + zeroed
     long long plane;       // granules per channel-block plane = hs*ws
     long long img;         // granules per image = cb_total*plane
 
@@ -99,6 +100,7 @@ inline TV make_tv(const mmif_tensor* t) {
     v.n = t->n; v.h = t->h; v.w = t->w; v.halo = t->halo;
     v.hs = t->h + 2 * t->halo; v.ws = t->w + 2 * t->halo;
     v.cb_total = t->cb_total; v.cb_off = t->cb_off; v.cb = t->cb;
+    v.folded = (t->flags & MMIF_T_FOLDED) ? 1 : 0;
     v.plane = (long long)v.hs * v.ws;
     v.img = (long long)v.cb_total * v.plane;
     return v;
@@ -130,8 +132,8 @@ __device__ inline void load_grad_fold(const TV& t, int in, int c, int y, int x, 
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = 0.f;
     if (y < 0 || y >= t.h || x < 0 || x >= t.w) return;
-    if (t.halo == 0) {
-        Elem<T>::load(t.base + t.gidx(in, c, y, x) * Elem<T>::gran_bytes, v);
+    if (t.halo == 0 || t.folded) {
+        Elem<T>::load(t.base + t.gidx(in, c, y + t.halo, x + t.halo) * Elem<T>::gran_bytes, v);
         return;
     }
     // candidate sources: the interior pixel plus the mirrored halo rows / cols (-1 = absent)

@@ -101,7 +101,7 @@ __device__ inline uint4 load_in_reflect(const TV& t, int in_, int c, int y, int 
 }
 __device__ inline uint4 load_in_gradfold(const TV& t, int in_, int c, int y, int x) {
     if (y < 0 || y >= t.h || x < 0 || x >= t.w) return make_uint4(0, 0, 0, 0);
-    if (t.halo == 0) return ld_gran(t, in_, c, y, x);
+    if (t.halo == 0 || t.folded) return ld_gran(t, in_, c, y + t.halo, x + t.halo);
     const bool by = (y == 1) || (y == t.h - 2), bx = (x == 1) || (x == t.w - 2);
     if (!by && !bx) return ld_gran(t, in_, c, y + 1, x + 1);
     float v[8];
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(TV tin, TV tout, TV t
             ioff[i] = y * tin.ws + x;
         } else {
             const bool inside = y >= 0 && y < tin.h && x >= 0 && x < tin.w;
-            const bool border = tin.halo && ((y == 1) || (y == tin.h - 2) || (x == 1) || (x == tin.w - 2));
+            const bool border = tin.halo && !tin.folded && ((y == 1) || (y == tin.h - 2) || (x == 1) || (x == tin.w - 2));
             mode = !inside ? 0 : (border ? 2 : 1);
             ioff[i] = (min(max(y, 0), tin.h - 1) + tin.halo) * tin.ws + min(max(x, 0), tin.w - 1) + tin.halo;  // always a valid address
         }
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(TV tin, TV tout, TV t
     }
     const char* in_img = tin.base + ((long long)in_ * tin.img + (long long)tin.cb_off * tin.plane) * 16;
     // does this block's input tile contain a fold row/col (1 or h-2 / w-2) of a halo-1 gradient?
-    const bool fold_tile = DGRAD && tin.halo &&
+    const bool fold_tile = DGRAD && tin.halo && !tin.folded &&
                            ((iy0 <= 1 && 1 < iy0 + TP) || (iy0 <= tin.h - 2 && tin.h - 2 < iy0 + TP) ||
                             (ix0 <= 1 && 1 < ix0 + TP) || (ix0 <= tin.w - 2 && tin.w - 2 < ix0 + TP));
 
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(TV tx, TV tg, float* __
         }
 #pragma unroll
         for (int i = 0; i < NG; ++i) s_g[i * WG_GPL + tid] = rg[i];
-        if (tg.halo) {
+        if (tg.halo && !tg.folded) {
             // rare: tiles containing row/col 1 or h-2 / w-2 of a padded-domain gradient fold the halo in
             const int in_ = tile / tpi, tt = tile % tpi;
             const int y0 = (tt / tiles_x) * MT, x0 = (tt % tiles_x) * MT;

@@ -91,6 +91,42 @@ __global__ void zero_kernel(TV t) {
     }
 }
 
+// fold targets of one (n, channel block): rows 1 and h-2 (all x), then cols 1 and w-2 (remaining y)
+template <typename T>
+__global__ void fold_targets_kernel(TV t) {
+    const int per = 2 * t.w + 2 * t.h;
+    const long long total = (long long)t.n * t.cb * per;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int j = i % per, c = (i / per) % t.cb, n = i / ((long long)per * t.cb);
+        int y, x;
+        bool dup = false;
+        if (j < t.w) { y = 1; x = j; }
+        else if (j < 2 * t.w) { y = t.h - 2; x = j - t.w; dup = (t.h - 2 == 1); }
+        else if (j < 2 * t.w + t.h) { y = j - 2 * t.w; x = 1; dup = (y == 1 || y == t.h - 2); }
+        else { y = j - 2 * t.w - t.h; x = t.w - 2; dup = (y == 1 || y == t.h - 2) || (t.w - 2 == 1); }
+        if (dup || y < 0 || y >= t.h || x < 0 || x >= t.w) continue;
+        float v[8];
+        load_grad_fold<T>(t, n, c, y, x, v);   // reads this pixel's interior + halo sources only: no hazard between targets
+        Elem<T>::store(t.base + t.gidx(n, c, y + 1, x + 1) * Elem<T>::gran_bytes, v);
+    }
+}
+
+template <typename T>
+__global__ void zero_halo_kernel(TV t) {
+    const int per = 2 * t.ws + 2 * t.hs;
+    const long long total = (long long)t.n * t.cb * per;
+    const float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int j = i % per, c = (i / per) % t.cb, n = i / ((long long)per * t.cb);
+        int ys, xs;
+        if (j < t.ws) { ys = 0; xs = j; }
+        else if (j < 2 * t.ws) { ys = t.hs - 1; xs = j - t.ws; }
+        else if (j < 2 * t.ws + t.hs) { ys = j - 2 * t.ws; xs = 0; }
+        else { ys = j - 2 * t.ws - t.hs; xs = t.ws - 1; }
+        Elem<T>::store(t.base + t.gidx(n, c, ys, xs) * Elem<T>::gran_bytes, z);
+    }
+}
+
 // ---------------------------------------------------------------- element fusion (core/fusion.py:21-29)
 template <typename T>
 __global__ void fuse_elem_fwd_kernel(TV a, TV b, TV o, int mode) {
@@ -225,6 +261,23 @@ extern "C" int mmif_zero(const mmif_tensor* t, void* stream) {
     if (t->dtype == MMIF_F32) hipLaunchKernelGGL(zero_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, v);
     else hipLaunchKernelGGL(zero_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, v);
     return check_launch("zero");
+}
+
+extern "C" int mmif_fold_halo(const mmif_tensor* t, void* stream) {
+    if (int rc = validate_tensor(t, "t")) return rc;
+    MMIF_REQUIRE(t->halo == 1, "fold_halo: tensor has no halo");
+    MMIF_REQUIRE(t->h >= 2 && t->w >= 2, "fold_halo: reflect padding needs h,w >= 2");
+    mmif_tensor u = *t;
+    u.flags &= ~MMIF_T_FOLDED;  // the fold itself must read the halo
+    TV v = make_tv(&u);
+    const long long n1 = (long long)v.n * v.cb * (2 * v.w + 2 * v.h), n2 = (long long)v.n * v.cb * (2 * v.ws + 2 * v.hs);
+    hipStream_t st = (hipStream_t)stream;
+    if (t->dtype == MMIF_F32) hipLaunchKernelGGL(fold_targets_kernel<float>, dim3(grid_for(n1)), dim3(256), 0, st, v);
+    else hipLaunchKernelGGL(fold_targets_kernel<bf16_t>, dim3(grid_for(n1)), dim3(256), 0, st, v);
+    if (int rc = check_launch("fold_targets")) return rc;
+    if (t->dtype == MMIF_F32) hipLaunchKernelGGL(zero_halo_kernel<float>, dim3(grid_for(n2)), dim3(256), 0, st, v);
+    else hipLaunchKernelGGL(zero_halo_kernel<bf16_t>, dim3(grid_for(n2)), dim3(256), 0, st, v);
+    return check_launch("zero_halo");
 }
 
 static int same_shape(const mmif_tensor* a, const mmif_tensor* b) {

@@ -15,11 +15,12 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "libmmif_hip.so")
 F32, BF16 = 0, 1
 IMPL_AUTO, IMPL_VALU, IMPL_MFMA = 0, 1, 2
 FUSE_SUM, FUSE_MEAN, FUSE_MAX = 0, 1, 2
+T_FOLDED = 1
 
 
 class MmifTensor(C.Structure):
     _fields_ = [("data", C.c_void_p), ("dtype", C.c_int32), ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32),
-                ("halo", C.c_int32), ("cb_total", C.c_int32), ("cb_off", C.c_int32), ("cb", C.c_int32)]
+                ("halo", C.c_int32), ("cb_total", C.c_int32), ("cb_off", C.c_int32), ("cb", C.c_int32), ("flags", C.c_int32)]
 
 
 class MmifError(RuntimeError):
@@ -46,6 +47,7 @@ SIGNATURES = {
     "mmif_nchw_to_blocked": (_i32, [_vp, _i32, _TP, _vp]),
     "mmif_blocked_to_nchw": (_i32, [_TP, _vp, _i32, _vp]),
     "mmif_zero": (_i32, [_TP, _vp]),
+    "mmif_fold_halo": (_i32, [_TP, _vp]),
     "mmif_packed_weight_bytes": (_sz, [_i32, _i32, _i32]),
     "mmif_pack_weights": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "mmif_conv2d_reflect_fwd": (_i32, [_TP, _vp, _vp, _vp, _TP, _i32, _i32, _i32, _i32, _i32, _vp]),

@@ -3,9 +3,10 @@ fusion nets (reference core/model.py) as a fixed sequence of HIP kernel launches
 buffers, with torch.cat replaced by channel-block views of one allocation (zero-copy concat).
 
 Gradient convention (DESIGN.md "padded-domain gradients"): a dgrad kernel writes the gradient of
-the reflect-PADDED input ([h+2][w+2], halo = 1); consumers fold the halo on load.  The ReLU mask of a
-producer layer is applied by the LAST kernel that contributes to that tensor's gradient
-(mask_bits), accumulation of several consumers' contributions by accum_bits.
+the reflect-PADDED input ([h+2][w+2], halo = 1); a tiny fold kernel (mmif_fold_halo) then adds the
+halo onto the interior (adjoint of reflect padding) and zeroes it, so readers see an ordinary
+gradient.  The ReLU mask of a producer layer is applied by the LAST kernel that contributes to that
+tensor's gradient (mask_bits), accumulation of several consumers' contributions by accum_bits.
 """
 import os
 import threading
@@ -226,7 +227,9 @@ class ModelEngine:
 
     @staticmethod
     def c_dgrad(s, gy, x, gx, mask_bits, accum_bits, impl):
+        """dgrad into the padded-domain view gx, then fold its halo; returns the folded view."""
         T.conv_dgrad(gy, s.w.detach(), x, gx, s.cin, s.cout, s.k, mask_bits, accum_bits, s.packed, impl, s.name + ":dgrad")
+        return gx.fold_halo_() if s.k > 1 else gx.as_folded()
 
     @staticmethod
     def c_wgrad(s, x, gy, ws, impl):
@@ -275,6 +278,7 @@ class DenseEncoderMixin:
     def enc_bwd(specs, img, F, GF, fbase, gbase, ws, impl, accumulate_w=False):
         """GF[gbase:gbase+8] holds dL/d(encoder output) (padded domain), top 2 blocks already masked."""
         first, c0, c1, c2 = specs
+        GF = GF.as_folded()   # every contribution so far has been folded; each dgrad below re-folds what it adds
         for s, nin in ((c2, 6), (c1, 4), (c0, 2)):
             g = GF.view(gbase + nin, 2)
             x = F.view(fbase, nin)
@@ -330,17 +334,17 @@ class PFNetv1Engine(ModelEngine, DenseEncoderMixin):
         T.image_out_wgrad(x, gout, L.out, last.dw, last.db, last.cin, last.k, ws)
         g = self.buf(L, f"G{len(acts) - 1}", n, last.cin, h, w, dtype, dev, halo=1)
         T.image_out_dgrad(gout, L.out, last.w.detach(), x, g, last.cin, last.k, all_bits(g.cb), 0)
+        g = g.fold_halo_() if last.k > 1 else g.as_folded()
         for i in range(len(self.dec) - 2, -1, -1):
             s, x = self.dec[i], acts[i]
             self.c_wgrad(s, x, g, ws, impl)
             gx = self.buf(L, f"G{i}", n, s.cin, h, w, dtype, dev, halo=1)
             if i > 0:
-                self.c_dgrad(s, g, x, gx, all_bits(gx.cb), 0, impl)
+                g = self.c_dgrad(s, g, x, gx, all_bits(gx.cb), 0, impl)
             else:
                 # gradient w.r.t. the concatenated encoder features: only each encoder's last
                 # DenseBlock output (blocks 6,7 / 14,15) has no further contributor
-                self.c_dgrad(s, g, x, gx, bits(6, 7, 14, 15), 0, impl)
-            g = gx
+                g = self.c_dgrad(s, g, x, gx, bits(6, 7, 14, 15), 0, impl)
         self.enc_bwd(self.enc[0], img1, F, g, 0, 0, ws, impl)
         self.enc_bwd(self.enc[1], img2, F, g, 8, 8, ws, impl)
         return grads
@@ -399,17 +403,17 @@ class DenseFuseEngine(ModelEngine, DenseEncoderMixin):
         T.image_out_wgrad(x, gout, L.out, last.dw, last.db, last.cin, last.k, ws)
         g = self.buf(L, f"G{len(acts) - 1}", n, last.cin, h, w, dtype, dev, halo=1)
         T.image_out_dgrad(gout, L.out, last.w.detach(), x, g, last.cin, last.k, all_bits(g.cb), 0)
+        g = g.fold_halo_() if last.k > 1 else g.as_folded()
         for i in range(len(self.dec) - 2, -1, -1):
             s, x = self.dec[i], acts[i]
             self.c_wgrad(s, x, g, ws, impl)
             gx = self.buf(L, f"G{i}", n, s.cin, h, w, dtype, dev, halo=1)
             if i > 0:
-                self.c_dgrad(s, g, x, gx, all_bits(gx.cb), 0, impl)
+                g = self.c_dgrad(s, g, x, gx, all_bits(gx.cb), 0, impl)
             elif single:
-                self.c_dgrad(s, g, x, gx, bits(6, 7), 0, impl)
+                g = self.c_dgrad(s, g, x, gx, bits(6, 7), 0, impl)
             else:
-                self.c_dgrad(s, g, x, gx, 0, 0, impl)  # x = f1 + f2 is not a ReLU output
-            g = gx
+                g = self.c_dgrad(s, g, x, gx, 0, 0, impl)  # x = f1 + f2 is not a ReLU output
         if single:
             self.enc_bwd(self.enc, img1, F, g, 0, 0, ws, impl)
             return grads

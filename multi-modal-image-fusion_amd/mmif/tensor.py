@@ -26,12 +26,12 @@ def require_device(t, what):
 
 class BT:
     """A view [cb_off, cb_off+cb) of a blocked allocation [n][cb_total][h+2*halo][w+2*halo][8]."""
-    __slots__ = ("buf", "n", "h", "w", "halo", "cb_total", "cb_off", "cb", "code", "_d")
+    __slots__ = ("buf", "n", "h", "w", "halo", "cb_total", "cb_off", "cb", "code", "flags", "_d")
 
-    def __init__(self, buf, n, h, w, halo, cb_total, cb_off, cb, code):
+    def __init__(self, buf, n, h, w, halo, cb_total, cb_off, cb, code, flags=0):
         self.buf, self.n, self.h, self.w, self.halo = buf, n, h, w, halo
-        self.cb_total, self.cb_off, self.cb, self.code = cb_total, cb_off, cb, code
-        self._d = MmifTensor(buf.data_ptr(), code, n, h, w, halo, cb_total, cb_off, cb)
+        self.cb_total, self.cb_off, self.cb, self.code, self.flags = cb_total, cb_off, cb, code, flags
+        self._d = MmifTensor(buf.data_ptr(), code, n, h, w, halo, cb_total, cb_off, cb, flags)
 
     @staticmethod
     def alloc(n, c, h, w, dtype, device, halo=0, zero=False):
@@ -42,7 +42,15 @@ class BT:
 
     def view(self, cb_off, cb):
         assert 0 <= cb_off and cb_off + cb <= self.cb, (cb_off, cb, self.cb)
-        return BT(self.buf, self.n, self.h, self.w, self.halo, self.cb_total, self.cb_off + cb_off, cb, self.code)
+        return BT(self.buf, self.n, self.h, self.w, self.halo, self.cb_total, self.cb_off + cb_off, cb, self.code, self.flags)
+
+    def as_folded(self):
+        """Same view, flagged 'halo already folded + zeroed' (after fold_halo): readers skip fold-on-load."""
+        return BT(self.buf, self.n, self.h, self.w, self.halo, self.cb_total, self.cb_off, self.cb, self.code, _lib.T_FOLDED)
+
+    def fold_halo_(self):
+        check(lib.mmif_fold_halo(self.d, stream_ptr()), "fold_halo")
+        return self.as_folded()
 
     @property
     def d(self):
