@@ -53,65 +53,111 @@ __global__ __launch_bounds__(256) void image_in_fwd_kernel(const float* __restri
 }
 
 // ---------------------------------------------------------------- Cin == 1 wgrad
-// partial layout per (block g, og): [16 o][KK] then [16] bias sums
+// dw[o][tap] = sum_p g[p][o] * img[R(p+tap-P)], db[o] = sum_p g[p][o] for one group of 16 output channels.
+// One pixel per thread per iteration (grid-stride), 16*KK + 16 accumulators in registers, wave-shuffle
+// + LDS block reduction at the end; partial layout per (block, og): [16 o][KK] then [16] bias sums.
 template <typename T, int KS>
 __global__ __launch_bounds__(256) void image_in_wgrad_kernel(const float* __restrict__ img, TV tg, float* __restrict__ partial,
-                                                             int cout, int tiles_x, int tpi, int total) {
-    constexpr int KK = KS * KS, P = KS / 2, IT = ITILE + KS - 1;
-    __shared__ float gsm[16][ITILE * ITILE + 1];
-    __shared__ float ism[IT][IT + 1];
+                                                             int cout, long long npix) {
+    constexpr int KK = KS * KS, P = KS / 2, PER = 16 * KK + 16;
+    __shared__ float red[4][PER];
     const int tid = threadIdx.x, og = blockIdx.y;
-    const int o = tid / KK, tap = tid % KK;      // valid for tid < 16*KK
-    const bool wthread = tid < 16 * KK;
-    const bool bthread = tid >= 16 * KK && tid < 16 * KK + 16;
-    const int bo = tid - 16 * KK;
-    float acc = 0.f;
-    for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
-        const int in_ = tile / tpi, tt = tile % tpi;
-        const int y0 = (tt / tiles_x) * ITILE, x0 = (tt % tiles_x) * ITILE;
-        const float* im = img + (long long)in_ * tg.h * tg.w;
-        __syncthreads();
-        for (int e = tid; e < IT * IT; e += 256) ism[e / IT][e % IT] = img_reflect(im, tg.h, tg.w, y0 + e / IT - P, x0 + e % IT - P);
-        for (int e = tid; e < ITILE * ITILE * 2; e += 256) {
-            const int b = e / (ITILE * ITILE), p = e % (ITILE * ITILE);
+    float acc[16][KK], accb[16];
+#pragma unroll
+    for (int o = 0; o < 16; ++o) {
+        accb[o] = 0.f;
+#pragma unroll
+        for (int t = 0; t < KK; ++t) acc[o][t] = 0.f;
+    }
+    const int hw = tg.h * tg.w;
+    for (long long pix = (long long)blockIdx.x * 256 + tid; pix < npix; pix += (long long)gridDim.x * 256) {
+        const int in_ = (int)(pix / hw), r = (int)(pix % hw);
+        const int y = r / tg.w, x = r % tg.w;
+        float gv[16];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
             float v[8];
             const int gcb = og * 2 + b;
-            if (gcb < tg.cb) load_grad_fold<T>(tg, in_, gcb, y0 + p / ITILE, x0 + p % ITILE, v);
+            if (gcb < tg.cb) load_grad_fold<T>(tg, in_, gcb, y, x, v);
             else {
 #pragma unroll
                 for (int c = 0; c < 8; ++c) v[c] = 0.f;
             }
 #pragma unroll
-            for (int c = 0; c < 8; ++c) gsm[b * 8 + c][p] = v[c];
+            for (int c = 0; c < 8; ++c) gv[b * 8 + c] = v[c];
         }
-        __syncthreads();
-        if (wthread) {
-            const int u = tap / KS, v = tap % KS;
-            for (int p = 0; p < ITILE * ITILE; ++p) acc = fmaf(gsm[o][p], ism[p / ITILE + u][p % ITILE + v], acc);
-        } else if (bthread) {
-            for (int p = 0; p < ITILE * ITILE; ++p) acc += gsm[bo][p];
+        const float* im = img + (long long)in_ * hw;
+        float iv[KK];
+#pragma unroll
+        for (int t = 0; t < KK; ++t) iv[t] = img_reflect(im, tg.h, tg.w, y + t / KS - P, x + t % KS - P);
+#pragma unroll
+        for (int o = 0; o < 16; ++o) {
+            accb[o] += gv[o];
+#pragma unroll
+            for (int t = 0; t < KK; ++t) acc[o][t] = fmaf(gv[o], iv[t], acc[o][t]);
         }
     }
-    float* dst = partial + ((long long)blockIdx.x * gridDim.y + og) * (16 * KK + 16);
-    if (wthread) dst[tid] = acc;
-    else if (bthread) dst[tid] = acc;
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int o = 0; o < 16; ++o) {
+#pragma unroll
+        for (int t = 0; t < KK; ++t) {
+            float v = acc[o][t];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if (lane == 0) red[wave][o * KK + t] = v;
+        }
+        float v = accb[o];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) red[wave][16 * KK + o] = v;
+    }
+    __syncthreads();
+    float* dst = partial + ((long long)blockIdx.x * gridDim.y + og) * PER;
+    for (int e = tid; e < PER; e += 256) dst[e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+}
+
+// fixed-order reduction over the G block partials: 64 outputs x 4 G-slices per block, 4 load chains per thread
+__device__ inline float sliced_sum(const float* __restrict__ partial, long long off, long long stride, int G, int slice,
+                                   float (*red)[64], int o_local, bool valid) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (valid) {
+        int g = slice;
+        for (; g + 12 < G; g += 16) {
+            s0 += partial[g * stride + off];
+            s1 += partial[(g + 4) * stride + off];
+            s2 += partial[(g + 8) * stride + off];
+            s3 += partial[(g + 12) * stride + off];
+        }
+        for (; g < G; g += 4) s0 += partial[g * stride + off];
+    }
+    red[slice][o_local] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    return (red[0][o_local] + red[1][o_local]) + (red[2][o_local] + red[3][o_local]);
 }
 
 template <int KS>
-__global__ void image_in_wgrad_reduce(const float* __restrict__ partial, float* __restrict__ dw, float* __restrict__ db,
-                                      int cout, int G, int n_og, int accumulate) {
+__global__ __launch_bounds__(256) void image_in_wgrad_reduce(const float* __restrict__ partial, float* __restrict__ dw,
+                                                             float* __restrict__ db, int cout, int G, int n_og, int accumulate) {
     constexpr int KK = KS * KS, PER = 16 * KK + 16;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float red[4][64];
+    const int o_local = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + o_local;
+    long long off = 0;
+    bool valid = false;
     if (idx < cout * KK) {
-        const int o = idx / KK, tap = idx % KK, og = o / 16, oo = o % 16;
-        float s = 0.f;
-        for (int g = 0; g < G; ++g) s += partial[((long long)g * n_og + og) * PER + oo * KK + tap];
-        dw[idx] = accumulate ? dw[idx] + s : s;
-    } else if (idx < cout * KK + cout && db) {
-        const int o = idx - cout * KK, og = o / 16, oo = o % 16;
-        float s = 0.f;
-        for (int g = 0; g < G; ++g) s += partial[((long long)g * n_og + og) * PER + 16 * KK + oo];
-        db[o] = accumulate ? db[o] + s : s;
+        const int o = idx / KK, tap = idx % KK;
+        off = (long long)(o / 16) * PER + (o % 16) * KK + tap;
+        valid = true;
+    } else if (idx < cout * KK + cout) {
+        const int o = idx - cout * KK;
+        off = (long long)(o / 16) * PER + 16 * KK + (o % 16);
+        valid = true;
+    }
+    const float t = sliced_sum(partial, off, (long long)n_og * PER, G, slice, red, o_local, valid);
+    if (slice == 0 && valid) {
+        if (idx < cout * KK) dw[idx] = accumulate ? dw[idx] + t : t;
+        else if (db) db[idx - cout * KK] = accumulate ? db[idx - cout * KK] + t : t;
     }
 }
 
@@ -201,74 +247,87 @@ __global__ __launch_bounds__(256) void image_out_dgrad_kernel(const float* __res
 }
 
 // ---------------------------------------------------------------- Cout == 1 wgrad
-// partial per (block g, channel group cg of 16): [16 c][KK] then [1] bias (cg == 0 only)
+// dw[0][c][tap] = sum_p g[p] * x[R(p+tap-P)][c], db = sum_p g[p] for one group of 16 input channels.
+// Same scheme as image_in_wgrad: one pixel per thread per iteration, 16*KK + 1 register accumulators;
+// partial per (block, cg): [16 c][KK] then [1] bias.
 template <typename T, int KS>
 __global__ __launch_bounds__(256) void image_out_wgrad_kernel(TV tx, const float* __restrict__ gimg, const float* __restrict__ yimg,
-                                                              float* __restrict__ partial, int tiles_x, int tpi, int total) {
-    constexpr int KK = KS * KS, P = KS / 2, IT = ITILE + KS - 1;
-    __shared__ float xsm[16][IT][IT + 1];
-    __shared__ float gsm[ITILE * ITILE];
+                                                              float* __restrict__ partial, long long npix) {
+    constexpr int KK = KS * KS, P = KS / 2, PER = 16 * KK + 1;
+    __shared__ float red[4][PER];
     const int tid = threadIdx.x, cg = blockIdx.y;
-    const int c = tid / KK, tap = tid % KK;
-    const bool wthread = tid < 16 * KK;
-    const bool bthread = tid == 16 * KK;
-    float acc = 0.f;
-    for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
-        const int in_ = tile / tpi, tt = tile % tpi;
-        const int y0 = (tt / tiles_x) * ITILE, x0 = (tt % tiles_x) * ITILE;
-        __syncthreads();
-        for (int e = tid; e < IT * IT * 2; e += 256) {
-            const int b = e / (IT * IT), p = e % (IT * IT);
-            float v[8];
-            const int xcb = cg * 2 + b;
-            if (xcb < tx.cb) load_act_reflect<T>(tx, in_, xcb, y0 + p / IT - P, x0 + p % IT - P, v);
-            else {
+    float acc[16][KK], accb = 0.f;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = 0.f;
-            }
+    for (int c = 0; c < 16; ++c)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) xsm[b * 8 + i][p / IT][p % IT] = v[i];
-        }
-        for (int e = tid; e < ITILE * ITILE; e += 256) {
-            const int yy = y0 + e / ITILE, xx = x0 + e % ITILE;
-            float v = 0.f;
-            if (yy < tx.h && xx < tx.w) {
-                const long long i = ((long long)in_ * tx.h + yy) * tx.w + xx;
-                v = gimg[i];
-                if (yimg != nullptr && !(yimg[i] > 0.f)) v = 0.f;
+        for (int t = 0; t < KK; ++t) acc[c][t] = 0.f;
+    const int hw = tx.h * tx.w;
+    for (long long pix = (long long)blockIdx.x * 256 + tid; pix < npix; pix += (long long)gridDim.x * 256) {
+        const int in_ = (int)(pix / hw), r = (int)(pix % hw);
+        const int y = r / tx.w, x = r % tx.w;
+        float g = gimg[pix];
+        if (yimg != nullptr && !(yimg[pix] > 0.f)) g = 0.f;
+        accb += g;
+#pragma unroll
+        for (int t = 0; t < KK; ++t) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int xcb = cg * 2 + b;
+                if (xcb < tx.cb) {
+                    float v[8];
+                    load_act_reflect<T>(tx, in_, xcb, y + t / KS - P, x + t % KS - P, v);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) acc[b * 8 + c][t] = fmaf(g, v[c], acc[b * 8 + c][t]);
+                }
             }
-            gsm[e] = v;
-        }
-        __syncthreads();
-        if (wthread) {
-            const int u = tap / KS, v = tap % KS;
-            for (int p = 0; p < ITILE * ITILE; ++p) acc = fmaf(gsm[p], xsm[c][p / ITILE + u][p % ITILE + v], acc);
-        } else if (bthread) {
-            for (int p = 0; p < ITILE * ITILE; ++p) acc += gsm[p];
         }
     }
-    float* dst = partial + ((long long)blockIdx.x * gridDim.y + cg) * (16 * KK + 1);
-    if (wthread || bthread) dst[tid] = acc;
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+#pragma unroll
+        for (int t = 0; t < KK; ++t) {
+            float v = acc[c][t];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if (lane == 0) red[wave][c * KK + t] = v;
+        }
+    {
+        float v = accb;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) red[wave][16 * KK] = v;
+    }
+    __syncthreads();
+    float* dst = partial + ((long long)blockIdx.x * gridDim.y + cg) * PER;
+    for (int e = tid; e < PER; e += 256) dst[e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
 }
 
 template <int KS>
-__global__ void image_out_wgrad_reduce(const float* __restrict__ partial, float* __restrict__ dw, float* __restrict__ db,
-                                       int cin, int G, int n_cg, int accumulate) {
+__global__ __launch_bounds__(256) void image_out_wgrad_reduce(const float* __restrict__ partial, float* __restrict__ dw,
+                                                              float* __restrict__ db, int cin, int G, int n_cg, int accumulate) {
     constexpr int KK = KS * KS, PER = 16 * KK + 1;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float red[4][64];
+    const int o_local = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + o_local;
+    long long off = 0;
+    bool valid = false;
     if (idx < cin * KK) {
-        const int c = idx / KK, tap = idx % KK, cg = c / 16, cc = c % 16;
-        float s = 0.f;
-        for (int g = 0; g < G; ++g) s += partial[((long long)g * n_cg + cg) * PER + cc * KK + tap];
-        dw[idx] = accumulate ? dw[idx] + s : s;
-    } else if (idx == cin * KK && db) {
-        float s = 0.f;
-        for (int g = 0; g < G; ++g) s += partial[((long long)g * n_cg + 0) * PER + 16 * KK];
-        db[0] = accumulate ? db[0] + s : s;
+        const int c = idx / KK, tap = idx % KK;
+        off = (long long)(c / 16) * PER + (c % 16) * KK + tap;
+        valid = true;
+    } else if (idx == cin * KK) {
+        off = 16 * KK;  // bias sum lives in channel group 0
+        valid = true;
+    }
+    const float t = sliced_sum(partial, off, (long long)n_cg * PER, G, slice, red, o_local, valid);
+    if (slice == 0 && valid) {
+        if (idx < cin * KK) dw[idx] = accumulate ? dw[idx] + t : t;
+        else if (db) db[0] = accumulate ? db[0] + t : t;
     }
 }
 
-constexpr int IMG_G = 256;
+constexpr int IMG_G = 512;
 
 }  // namespace mmif
 
@@ -313,19 +372,18 @@ extern "C" int mmif_conv2d_image_in_wgrad(const float* img, const mmif_tensor* g
         return MMIF_EWORKSPACE;
     }
     TV tg = make_tv(gy);
-    const int tiles_x = cdiv(tg.w, ITILE), tiles_y = cdiv(tg.h, ITILE);
-    const int tpi = tiles_x * tiles_y, total = tpi * tg.n;
-    const int G = total < IMG_G ? total : IMG_G;
+    const long long npix = (long long)tg.n * tg.h * tg.w;
+    const int G = (int)(cdiv(npix, 256) < IMG_G ? cdiv(npix, 256) : IMG_G);
     const int n_og = cdiv(cout, 16);
     hipStream_t st = (hipStream_t)stream;
     float* ws = (float*)workspace;
-#define CALL(T, KS) hipLaunchKernelGGL((image_in_wgrad_kernel<T, KS>), dim3(G, n_og), dim3(256), 0, st, img, tg, ws, cout, tiles_x, tpi, total)
+#define CALL(T, KS) hipLaunchKernelGGL((image_in_wgrad_kernel<T, KS>), dim3(G, n_og), dim3(256), 0, st, img, tg, ws, cout, npix)
     DISPATCH_T_KS(gy->dtype, ksize, CALL);
 #undef CALL
     if (int rc = check_launch("image_in_wgrad")) return rc;
     const int n = cout * ksize * ksize + cout;
-    if (ksize == 3) hipLaunchKernelGGL((image_in_wgrad_reduce<3>), dim3(cdiv(n, 256)), dim3(256), 0, st, ws, dw, db, cout, G, n_og, accumulate);
-    else hipLaunchKernelGGL((image_in_wgrad_reduce<1>), dim3(cdiv(n, 256)), dim3(256), 0, st, ws, dw, db, cout, G, n_og, accumulate);
+    if (ksize == 3) hipLaunchKernelGGL((image_in_wgrad_reduce<3>), dim3(cdiv(n, 64)), dim3(256), 0, st, ws, dw, db, cout, G, n_og, accumulate);
+    else hipLaunchKernelGGL((image_in_wgrad_reduce<1>), dim3(cdiv(n, 64)), dim3(256), 0, st, ws, dw, db, cout, G, n_og, accumulate);
     return check_launch("image_in_wgrad_reduce");
 }
 
@@ -381,18 +439,17 @@ extern "C" int mmif_conv2d_image_out_wgrad(const mmif_tensor* x, const float* gi
         return MMIF_EWORKSPACE;
     }
     TV tx = make_tv(x);
-    const int tiles_x = cdiv(tx.w, ITILE), tiles_y = cdiv(tx.h, ITILE);
-    const int tpi = tiles_x * tiles_y, total = tpi * tx.n;
-    const int G = total < IMG_G ? total : IMG_G;
+    const long long npix = (long long)tx.n * tx.h * tx.w;
+    const int G = (int)(cdiv(npix, 256) < IMG_G ? cdiv(npix, 256) : IMG_G);
     const int n_cg = cdiv(cin, 16);
     hipStream_t st = (hipStream_t)stream;
     float* ws = (float*)workspace;
-#define CALL(T, KS) hipLaunchKernelGGL((image_out_wgrad_kernel<T, KS>), dim3(G, n_cg), dim3(256), 0, st, tx, gimg, y_img, ws, tiles_x, tpi, total)
+#define CALL(T, KS) hipLaunchKernelGGL((image_out_wgrad_kernel<T, KS>), dim3(G, n_cg), dim3(256), 0, st, tx, gimg, y_img, ws, npix)
     DISPATCH_T_KS(x->dtype, ksize, CALL);
 #undef CALL
     if (int rc = check_launch("image_out_wgrad")) return rc;
     const int n = cin * ksize * ksize + 1;
-    if (ksize == 3) hipLaunchKernelGGL((image_out_wgrad_reduce<3>), dim3(cdiv(n, 256)), dim3(256), 0, st, ws, dw, db, cin, G, n_cg, accumulate);
-    else hipLaunchKernelGGL((image_out_wgrad_reduce<1>), dim3(cdiv(n, 256)), dim3(256), 0, st, ws, dw, db, cin, G, n_cg, accumulate);
+    if (ksize == 3) hipLaunchKernelGGL((image_out_wgrad_reduce<3>), dim3(cdiv(n, 64)), dim3(256), 0, st, ws, dw, db, cin, G, n_cg, accumulate);
+    else hipLaunchKernelGGL((image_out_wgrad_reduce<1>), dim3(cdiv(n, 64)), dim3(256), 0, st, ws, dw, db, cin, G, n_cg, accumulate);
     return check_launch("image_out_wgrad_reduce");
 }

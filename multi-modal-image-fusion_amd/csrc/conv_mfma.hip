@@ -495,7 +495,16 @@ __global__ __launch_bounds__(256) void wgrad_mfma_reduce(const float* __restrict
     float s = 0.f;
     if (off >= 0) {
         const long long stride = (long long)n_icg * n_ocg * PER;
-        for (int gi = slice; gi < G; gi += 4) s += partial[gi * stride + off];
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;   // 4 independent chains keep 4+ loads in flight
+        int gi = slice;
+        for (; gi + 12 < G; gi += 16) {
+            s0 += partial[gi * stride + off];
+            s1 += partial[(gi + 4) * stride + off];
+            s2 += partial[(gi + 8) * stride + off];
+            s3 += partial[(gi + 12) * stride + off];
+        }
+        for (; gi < G; gi += 4) s0 += partial[gi * stride + off];
+        s = (s0 + s1) + (s2 + s3);
     }
     red[slice][o_local] = s;
     __syncthreads();
