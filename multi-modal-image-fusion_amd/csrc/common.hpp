@@ -40,6 +40,15 @@ __host__ __device__ inline bf16_t f32_to_bf16(float f) {
     return (bf16_t)(u >> 16);
 }
 
+// device fast path: v_cvt_pk_bf16_f32 (round to nearest even), two values per instruction
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ inline uint32_t pack_bf16x2(float lo, float hi) {
+    const f32x2_t v = {lo, hi};
+    const bf16x2_t r = __builtin_convertvector(v, bf16x2_t);
+    return __builtin_bit_cast(uint32_t, r);
+}
+
 // ---------------------------------------------------------------- granule load/store (8 channels)
 template <typename T> struct Elem;
 template <> struct Elem<float> {
@@ -70,12 +79,10 @@ template <> struct Elem<bf16_t> {
         }
     }
     __device__ static inline void store(void* p, const float (&v)[8]) {
-        uint32_t w[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f32_to_bf16(v[2 * i]) | ((uint32_t)f32_to_bf16(v[2 * i + 1]) << 16);
-        *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+        *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+                                                  pack_bf16x2(v[6], v[7]));
     }
-    __device__ static inline float quant(float f) { return bf16_to_f32(f32_to_bf16(f)); }
+    __device__ static inline float quant(float f) { return __uint_as_float(pack_bf16x2(f, 0.f) << 16); }
 };
 
 // ---------------------------------------------------------------- device-side tensor view

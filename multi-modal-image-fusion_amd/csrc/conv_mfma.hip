@@ -106,10 +106,7 @@ __device__ inline uint4 load_in_gradfold(const TV& t, int in_, int c, int y, int
     if (!by && !bx) return ld_gran(t, in_, c, y + 1, x + 1);
     float v[8];
     load_grad_fold<bf16_t>(t, in_, c, y, x, v);  // fp32 fold, rounded once
-    uint32_t w[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f32_to_bf16(v[2 * i]) | ((uint32_t)f32_to_bf16(v[2 * i + 1]) << 16);
-    return make_uint4(w[0], w[1], w[2], w[3]);
+    return make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
 }
 
 // ------------------------------------------------------------------ forward / dgrad kernel
@@ -138,7 +135,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(TV tin, TV tout, TV t
     // ---- per-thread staging descriptors (chunk independent) ----
     // input element i of this thread: chunk-local channel block icb[i], LDS slot ilds[i], and either a
     // plane-relative granule offset (imode 1), a zero (imode 0) or a halo-fold slow path (imode 2)
-    int idesc[NIN], ioff[NIN];  // idesc = LDS slot | chunk-local channel block << 16 | mode << 20
+    // idesc = LDS slot | chunk-local channel block << 16 | mode << 20; ioff = byte offset from the chunk's first plane
+    // (always a valid address); ioff0 = the same pixel in the chunk's plane 0 (used for the ragged last chunk)
+    int idesc[NIN];
+    unsigned ioff[NIN], ioff0[NIN];
 #pragma unroll
     for (int i = 0; i < NIN; ++i) {
         const int e = tid + 256 * i;
@@ -150,14 +150,15 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(TV tin, TV tout, TV t
             y = min(max(reflect_idx(y, tin.h), 0), tin.h - 1);
             x = min(max(reflect_idx(x, tin.w), 0), tin.w - 1);
             mode = 1;
-            ioff[i] = y * tin.ws + x;
+            ioff0[i] = (unsigned)(y * tin.ws + x) * 16u;
         } else {
             const bool inside = y >= 0 && y < tin.h && x >= 0 && x < tin.w;
             const bool border = tin.halo && !tin.folded && ((y == 1) || (y == tin.h - 2) || (x == 1) || (x == tin.w - 2));
             mode = !inside ? 0 : (border ? 2 : 1);
-            ioff[i] = (min(max(y, 0), tin.h - 1) + tin.halo) * tin.ws + min(max(x, 0), tin.w - 1) + tin.halo;  // always a valid address
+            ioff0[i] = (unsigned)((min(max(y, 0), tin.h - 1) + tin.halo) * tin.ws + min(max(x, 0), tin.w - 1) + tin.halo) * 16u;
         }
         idesc[i] = (cb * PL + p) | (cb << 16) | (mode << 20);
+        ioff[i] = ioff0[i] + (unsigned)min(cb, CHUNK_CB - 1) * (unsigned)(tin.plane * 16);
     }
     const char* in_img = tin.base + ((long long)in_ * tin.img + (long long)tin.cb_off * tin.plane) * 16;
     // does this block's input tile contain a fold row/col (1 or h-2 / w-2) of a halo-1 gradient?
@@ -175,6 +176,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(TV tin, TV tout, TV t
     const char* in_lane = reinterpret_cast<const char*>(s_in) + ((wave * 4) * TP + j) * 16;
     const char* w_lane = reinterpret_cast<const char*>(s_w) + j * 16;
 
+    unsigned woff[NW];  // byte offset of this thread's weight granule i inside a chunk's packed slab
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const int e = tid + 256 * i;
+        woff[i] = (unsigned)((e / (MF * 16)) * m16p + mb * MF * 16 + e % (MF * 16)) * 16u;
+    }
     uint4 rin[NIN], rw[NW];
     auto prefetch = [&](int c0, long long wchunk_off) {
         const int ncb = min(CHUNK_CB, ncb_tot - c0);
@@ -183,15 +190,17 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(TV tin, TV tout, TV t
         for (int i = 0; i < NIN; ++i) {
             // unconditional load from a clamped (always valid) address, zero by select: no branch, no serialisation
             const int cb = (idesc[i] >> 16) & 15, mode = idesc[i] >> 20;
-            const uint4 v = *reinterpret_cast<const uint4*>(in_img + ((long long)(c0 + min(cb, ncb - 1)) * tin.plane + ioff[i]) * 16);
+            const char* chunk = in_img + (long long)c0 * tin.plane * 16;          // wave-uniform base (SGPR pair)
+            const uint4 v = *reinterpret_cast<const uint4*>(chunk + (cb < ncb ? ioff[i] : ioff0[i]));   // + 32-bit lane offset
             rin[i] = (cb < ncb && mode >= 1) ? v : make_uint4(0, 0, 0, 0);
         }
+        const char* wchunk = reinterpret_cast<const char*>(wpk + wchunk_off);   // wave-uniform base
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
             const int e = tid + 256 * i;
-            const int kg = e / (MF * 16), r = e % (MF * 16);
+            const int kg = e / (MF * 16);
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (kg < nkgp) v = wpk[wchunk_off + (long long)kg * m16p + mb * MF * 16 + r];
+            if (kg < nkgp) v = *reinterpret_cast<const uint4*>(wchunk + woff[i]);
             rw[i] = v;
         }
     };
@@ -251,6 +260,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(TV tin, TV tout, TV t
     // ---- epilogue: lane (g, j) holds oc = 16*m + 4*g + r (r = 0..3) of pixel (row 4*wave + n, col j) ----
     const int oxs = tile_x * MT + j;
     if (oxs >= tout.ws) return;
+    const int oys0 = tile_y * MT + wave * 4;
+    const unsigned row_bytes = (unsigned)tout.ws * 16u;
+    const unsigned pix_off = (unsigned)(oys0 * tout.ws + oxs) * 16u + (g & 1) * 8u;   // inside one plane
+    unsigned mpix_off = 0;
+    if (DGRAD) {
+        const int x = min(max(reflect_idx(oxs - tout.halo, tmask.w), 0), tmask.w - 1);
+        mpix_off = (unsigned)x * 16u + (g & 1) * 8u;
+    }
 #pragma unroll
     for (int m = 0; m < MF; ++m) {
         const int ocb = (mb * MF + m) * 2 + (g >> 1);  // channel block inside the out view
@@ -261,12 +278,15 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(TV tin, TV tout, TV t
 #pragma unroll
             for (int r = 0; r < 4; ++r) bv[r] = (oc0 + r < n_out) ? bias[oc0 + r] : 0.f;
         }
+        char* oplane = tout.base + ((long long)in_ * tout.img + (long long)(tout.cb_off + ocb) * tout.plane) * 16 + pix_off;
+        const char* mplane = DGRAD ? tmask.base + ((long long)in_ * tmask.img + (long long)(tmask.cb_off + ocb) * tmask.plane) * 16 + mpix_off : nullptr;
+        const bool do_acc = DGRAD && ((accum_bits >> ocb) & 1ull);
+        const bool do_mask = DGRAD && ((mask_bits >> ocb) & 1ull);
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
-            const int oys = tile_y * MT + wave * 4 + n;
-            if (oys >= tout.hs) continue;
+            if (oys0 + n >= tout.hs) continue;
             float v[4] = {acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]};
-            char* dst = tout.base + tout.gidx(in_, ocb, oys, oxs) * 16 + (g & 1) * 8;
+            char* dst = oplane + n * row_bytes;
             if (!DGRAD) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -275,28 +295,24 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(TV tin, TV tout, TV t
                     v[r] = (oc0 + r < n_out) ? t : 0.f;
                 }
             } else {
-                if ((accum_bits >> ocb) & 1ull) {
+                if (do_acc) {
                     const uint2 o = *reinterpret_cast<const uint2*>(dst);
                     v[0] += __uint_as_float(o.x << 16);
                     v[1] += __uint_as_float(o.x & 0xffff0000u);
                     v[2] += __uint_as_float(o.y << 16);
                     v[3] += __uint_as_float(o.y & 0xffff0000u);
                 }
-                if ((mask_bits >> ocb) & 1ull) {
-                    const int y = min(max(reflect_idx(oys - tout.halo, tmask.h), 0), tmask.h - 1);
-                    const int x = min(max(reflect_idx(oxs - tout.halo, tmask.w), 0), tmask.w - 1);
-                    const uint2 xm = *reinterpret_cast<const uint2*>(tmask.base + tmask.gidx(in_, ocb, y, x) * 16 + (g & 1) * 8);
-                    // bf16 > 0  <=>  sign bit clear and magnitude non-zero
+                if (do_mask) {
+                    const int y = min(max(reflect_idx(oys0 + n - tout.halo, tmask.h), 0), tmask.h - 1);
+                    const uint2 xm = *reinterpret_cast<const uint2*>(mplane + (unsigned)(y * tmask.ws) * 16u);
+                    // bf16 > 0  <=>  sign bit clear and magnitude non-zero (activations are never NaN)
                     const uint32_t q[4] = {xm.x & 0xffffu, xm.x >> 16, xm.y & 0xffffu, xm.y >> 16};
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         if (!((q[r] & 0x8000u) == 0 && (q[r] & 0x7fffu) != 0)) v[r] = 0.f;
                 }
             }
-            uint2 o;
-            o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-            o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-            *reinterpret_cast<uint2*>(dst) = o;
+            *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
         }
     }
 }
