@@ -12,7 +12,7 @@ from mmif import engine as E
 from .block import *
 from .fusion import *
 
-__all__ = ['PFNetv1', 'DenseFuse']
+__all__ = ['PFNetv1', 'PFNetv2', 'DenseFuse', 'NestFuse', 'RFNNest']
 
 
 class _FusionModel(nn.Module):
@@ -73,6 +73,24 @@ class PFNetv1(nn.Module):
         return self._engine.run(img1, img2)
 
 
+class PFNetv2(_FusionModel):
+    '''Polarization Image Fusion with Self-Learned Fusion Strategy (reference core/model.py:114-141).
+    The reference's 64-iteration per-channel Python loop over the shared `fuse` stack (192 tiny conv
+    launches per forward) is one batched call on [B*64, 2, H, W] -- same weights, same result.
+    Runs layer by layer through the HIP ConvLayer (no fused engine yet).'''
+
+    def __init__(self):
+        super(PFNetv2, self).__init__()
+        self.encode = nn.Sequential(ConvLayer(1, 16), DenseBlock(16, 16))
+        self.fuse = nn.Sequential(ConvLayer(2, 2), ConvLayer(2, 2), ConvLayer(2, 1, act=None))
+        self.decode = nn.Sequential(ConvLayer(64, 64), ConvLayer(64, 32), ConvLayer(32, 16), ConvLayer(16, 1, act=None))
+
+    def fusion(self, feat1, feat2):
+        b, c, h, w = feat1.shape
+        pairs = torch.stack((feat1, feat2), dim=2).reshape(b * c, 2, h, w)
+        return self.fuse(pairs).reshape(b, c, h, w) + feat1 + feat2
+
+
 class DenseFuse(_FusionModel):
     '''DenseFuse: A Fusion Approach to Infrared and Visible Images (reference core/model.py:165-186)'''
 
@@ -90,3 +108,52 @@ class DenseFuse(_FusionModel):
 
     def _make_engine(self):
         return E.DenseFuseEngine(self)
+
+
+class NestFuse(_FusionModel):
+    '''NestFuse (reference core/model.py:319-363): 1x1 conv_in, four ConvBlock levels with 2x2 max-pool,
+    spatial/channel attention fusion per level, UNet++ NestDecoder, 1x1 conv_out.  Every ConvLayer runs on
+    the HIP kernels (k = 1 and 3); pooling / up-sampling / attention are tensor-level glue for now.'''
+
+    def __init__(self, down_mode='maxpool', up_mode='nearest'):
+        super(NestFuse, self).__init__()
+        num_ch = [64, 112, 160, 208]
+        self.conv_in = ConvLayer(1, 16, ksize=1)
+        self.CB1_0 = ConvBlock(16, num_ch[0])
+        self.CB2_0 = ConvBlock(num_ch[0], num_ch[1])
+        self.CB3_0 = ConvBlock(num_ch[1], num_ch[2])
+        self.CB4_0 = ConvBlock(num_ch[2], num_ch[3])
+        if down_mode == 'maxpool':
+            self.down1, self.down2, self.down3 = nn.MaxPool2d(2, 2), nn.MaxPool2d(2, 2), nn.MaxPool2d(2, 2)
+        elif down_mode == 'stride':
+            self.down1 = ConvLayer(num_ch[0], num_ch[0], stride=2)
+            self.down2 = ConvLayer(num_ch[1], num_ch[1], stride=2)
+            self.down3 = ConvLayer(num_ch[2], num_ch[2], stride=2)
+        self.decode = NestDecoder(ConvBlock, num_ch, up_mode)
+        self.conv_out = ConvLayer(num_ch[0], 1, ksize=1)
+
+    def encoder(self, img):
+        x1_0 = self.CB1_0(self.conv_in(img))
+        x2_0 = self.CB2_0(self.down1(x1_0))
+        x3_0 = self.CB3_0(self.down2(x2_0))
+        x4_0 = self.CB4_0(self.down3(x3_0))
+        return x1_0, x2_0, x3_0, x4_0
+
+    def fusion(self, feats1, feats2, mode='sca'):
+        return tuple(attention_fusion(a, b, mode) for a, b in zip(feats1, feats2))
+
+    def decoder(self, feats):
+        return self.conv_out(self.decode(feats))
+
+
+class RFNNest(NestFuse):
+    '''RFN-Nest (reference core/model.py:366-384): NestFuse with a learnable RFN per pyramid level.'''
+
+    def __init__(self, down_mode='maxpool', up_mode='nearest'):
+        super(RFNNest, self).__init__(down_mode, up_mode)
+        num_ch = [64, 112, 160, 208]
+        self.RFN1, self.RFN2, self.RFN3, self.RFN4 = RFN(num_ch[0]), RFN(num_ch[1]), RFN(num_ch[2]), RFN(num_ch[3])
+
+    def fusion(self, feats1, feats2):
+        return (self.RFN1(feats1[0], feats2[0]), self.RFN2(feats1[1], feats2[1]), self.RFN3(feats1[2], feats2[2]),
+                self.RFN4(feats1[3], feats2[3]))

@@ -42,7 +42,7 @@ extern "C" int mmif_conv2d_reflect_fwd(const mmif_tensor* x, const float* w, con
     MMIF_REQUIRE(ksize == 1 || ksize == 3, "conv2d_reflect_fwd: ksize must be 1 or 3 (got %d)", ksize);
     MMIF_REQUIRE(x->halo == 0 && y->halo == 0, "conv2d_reflect_fwd: activations must have halo 0");
     MMIF_REQUIRE(x->dtype == y->dtype && x->n == y->n && x->h == y->h && x->w == y->w, "conv2d_reflect_fwd: x/y mismatch");
-    MMIF_REQUIRE(cin > 0 && cin % 8 == 0 && cin == x->cb * 8, "conv2d_reflect_fwd: cin=%d must equal 8*x.cb=%d", cin, x->cb * 8);
+    MMIF_REQUIRE(cin > 0 && (cin + 7) / 8 == x->cb, "conv2d_reflect_fwd: cin=%d does not match x.cb=%d", cin, x->cb);
     MMIF_REQUIRE(cout > 0 && (cout + 7) / 8 == y->cb, "conv2d_reflect_fwd: cout=%d does not match y.cb=%d", cout, y->cb);
     MMIF_REQUIRE(ksize == 1 || (x->h >= 2 && x->w >= 2), "reflect padding needs h,w >= 2");
     const int im = pick_impl(impl, x->dtype, conv_mfma_supported(false, ksize, cin, cout) && w_packed != nullptr, "conv2d_reflect_fwd");
@@ -61,7 +61,7 @@ extern "C" int mmif_conv2d_reflect_dgrad(const mmif_tensor* gy, const float* w, 
     MMIF_REQUIRE(ksize == 1 || ksize == 3, "conv2d_reflect_dgrad: ksize must be 1 or 3 (got %d)", ksize);
     MMIF_REQUIRE(gx->halo >= ksize / 2, "conv2d_reflect_dgrad: gx needs halo >= ksize/2");
     MMIF_REQUIRE(gy->dtype == gx->dtype && gy->n == gx->n && gy->h == gx->h && gy->w == gx->w, "conv2d_reflect_dgrad: gy/gx mismatch");
-    MMIF_REQUIRE(cin > 0 && cin % 8 == 0 && cin == gx->cb * 8, "conv2d_reflect_dgrad: cin=%d must equal 8*gx.cb=%d", cin, gx->cb * 8);
+    MMIF_REQUIRE(cin > 0 && (cin + 7) / 8 == gx->cb, "conv2d_reflect_dgrad: cin=%d does not match gx.cb=%d", cin, gx->cb);
     MMIF_REQUIRE(cout > 0 && (cout + 7) / 8 == gy->cb, "conv2d_reflect_dgrad: cout=%d does not match gy.cb=%d", cout, gy->cb);
     TV tg = make_tv(gy), tgx = make_tv(gx), tm = tgx;
     if (mask_bits) {
@@ -92,7 +92,7 @@ extern "C" int mmif_conv2d_reflect_wgrad(const mmif_tensor* x, const mmif_tensor
     MMIF_REQUIRE(ksize == 1 || ksize == 3, "conv2d_reflect_wgrad: ksize must be 1 or 3 (got %d)", ksize);
     MMIF_REQUIRE(x->halo == 0, "conv2d_reflect_wgrad: x must be an activation (halo 0)");
     MMIF_REQUIRE(x->dtype == gy->dtype && x->n == gy->n && x->h == gy->h && x->w == gy->w, "conv2d_reflect_wgrad: x/gy mismatch");
-    MMIF_REQUIRE(cin > 0 && cin % 8 == 0 && cin == x->cb * 8, "conv2d_reflect_wgrad: cin=%d must equal 8*x.cb=%d", cin, x->cb * 8);
+    MMIF_REQUIRE(cin > 0 && (cin + 7) / 8 == x->cb, "conv2d_reflect_wgrad: cin=%d does not match x.cb=%d", cin, x->cb);
     MMIF_REQUIRE(cout > 0 && (cout + 7) / 8 == gy->cb, "conv2d_reflect_wgrad: cout=%d does not match gy.cb=%d", cout, gy->cb);
     MMIF_REQUIRE(dw != nullptr, "conv2d_reflect_wgrad: dw is NULL");
     if (workspace_bytes < mmif_conv2d_wgrad_workspace(cin, cout, ksize)) {

@@ -534,7 +534,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_reduce(const float* __restrict
 // ------------------------------------------------------------------ host side
 bool conv_mfma_supported(bool dgrad, int ks, int cin, int cout) {
     (void)dgrad;
-    return (ks == 1 || ks == 3) && cin % 8 == 0 && cin >= 8 && cout >= 8;
+    return (ks == 1 || ks == 3) && cin >= 1 && cout >= 1;
 }
 
 template <int KS, int MF>
@@ -576,7 +576,7 @@ static int wgrad_G(int cin, int cout) {
     return (G + 7) / 8 * 8;
 }
 
-bool wgrad_mfma_supported(int ks, int cin, int cout) { return (ks == 1 || ks == 3) && cin % 8 == 0 && cin >= 8 && cout >= 8; }
+bool wgrad_mfma_supported(int ks, int cin, int cout) { return (ks == 1 || ks == 3) && cin >= 1 && cout >= 1; }
 
 size_t wgrad_mfma_workspace(int cin, int cout, int ks) {
     const int mfw = pick_mfw(cout);

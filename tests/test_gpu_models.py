@@ -136,3 +136,40 @@ def test_cpu_tensors_fail_loudly():
     m = M.PFNetv1()
     with pytest.raises(RuntimeError):
         m(torch.zeros(1, 1, 16, 16), torch.zeros(1, 1, 16, 16))
+
+
+LAYERWISE = [("PFNetv2", (2, 1, 32, 32)), ("NestFuse", (1, 1, 32, 32)), ("RFNNest", (1, 1, 32, 32))]
+
+
+@pytest.mark.parametrize("name,shape", LAYERWISE, ids=[n for n, _ in LAYERWISE])
+def test_layerwise_models_fp32_vs_golden(name, shape):
+    """PFNetv2 / NestFuse / RFN-Nest: every ConvLayer (k=1 and k=3, channel counts 2..384) through the HIP
+    kernels, glued layer by layer; forward + parameter-gradient digests vs the reference (golden F5)."""
+    ref = np.load(os.path.join(G, "f5_models.npz"))
+    man = json.load(open(os.path.join(G, "f5_manifest.json")))
+    tag = f"{name}_{shape[0]}x{shape[2]}x{shape[3]}"
+    with dtype_ctx("fp32"):
+        m = _model(name, 1)
+        assert [[k, list(v.shape)] for k, v in m.state_dict().items()] == man[name]
+        i1, i2 = tg(O.closed_form_image(shape, 0.3)), tg(O.closed_form_image(shape, 1.7))
+        y = m(i1, i2)
+        y.backward(tg(O.closed_form_signed(shape, 0.9, 1.0)))
+        torch.cuda.synchronize()
+        close(y.detach().cpu().numpy(), ref[tag + "__y"], 2e-4, "imgf")
+        for k, p in m.named_parameters():
+            close_digest(p.grad.cpu().numpy(), ref[f"{tag}__dp_{k}"], 5e-4, k)
+
+
+def test_nestfuse_bf16_mfma_runs_close():
+    """bf16 / MFMA kernels on NestFuse's odd channel counts (8, 56, 88, 120, 136, 152, 184 ...) and 1x1 convs."""
+    shape = (1, 1, 32, 32)
+    om = O.NestFuse()
+    P = om.init_params(seed=1)
+    i1n, i2n = O.closed_form_image(shape, 0.3), O.closed_form_image(shape, 1.7)
+    y_or = om.forward(P, i1n, i2n)
+    with dtype_ctx("bf16", "mfma"):
+        m = _model("NestFuse", 1)
+        with torch.no_grad():
+            y = m(tg(i1n), tg(i2n))
+        torch.cuda.synchronize()
+        close(y.cpu().numpy(), y_or, 5e-2, "imgf")
