@@ -153,6 +153,14 @@ def main():
                         "achieved": ach / 1e12, "peak": PEAK_MFMA_BF16 / 1e12 if args.dtype == "bf16" else 157.3,
                         "unit": "TFLOP/s", "frac": ach / (PEAK_MFMA_BF16 if args.dtype == "bf16" else 157.3e12),
                         "avg_launch_ms": ms, "launches": len(evs), "traffic": None}
+                # HBM bytes per launch of this kernel from the TCC PMC passes of the same command (separate
+                # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 correction applied; profiles/r01_traffic.json)
+                tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+                if os.path.isfile(tpath) and B == 32 and S == 256 and args.dtype == "bf16":
+                    tj = json.load(open(tpath)).get(args.roofline_tag)
+                    if tj:
+                        roof["traffic"] = tj["hbm_bytes_per_launch"]
+                        roof["algorithmic_bytes"] = tj["algorithmic_bytes_per_launch"]
         out = {
             "metric": "image-pairs/sec at 256x256, PFNet train step", "value": value, "unit": "image-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
