@@ -114,7 +114,8 @@ template <int KS, int MF, bool DGRAD>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(TV tin, TV tout, TV tmask, const uint4* __restrict__ wpk,
                                                             const float* __restrict__ bias, int n_out, int m16p,
                                                             int relu, unsigned long long mask_bits,
-                                                            unsigned long long accum_bits, int tiles_x) {
+                                                            unsigned long long accum_bits, int tiles_x, int tiles_y,
+                                                            int nmb) {
     constexpr int KK = KS * KS, P = KS / 2;
     constexpr int TP = MT + KS - 1;             // input tile edge (18 / 16)
     constexpr int PL = plane_granules(KS);      // granules per LDS plane
@@ -128,8 +129,16 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(TV tin, TV tout, TV t
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, g = lane >> 4;
-    const int tile_x = blockIdx.x % tiles_x, tile_y = blockIdx.x / tiles_x;
-    const int in_ = blockIdx.y, mb = blockIdx.z;
+    // XCD-aware block order (block b runs on XCD b % 8; speed only, any placement is correct): every XCD walks
+    // a CONTIGUOUS band of (image, tile row, tile col) with a tile's M-blocks back to back, so the second
+    // M-block's input tile and the halos shared with neighbouring tiles are hits in that XCD's L2.
+    const int nb = gridDim.x, b = blockIdx.x;
+    const int q8 = nb >> 3, r8 = nb & 7, xcd = b & 7;
+    const int lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
+    const int mb = lin % nmb, tl = lin / nmb;
+    const int tpi = tiles_x * tiles_y;
+    const int in_ = tl / tpi, trem = tl % tpi;
+    const int tile_x = trem % tiles_x, tile_y = trem / tiles_x;
     const int iy0 = tile_y * MT - tout.halo - P, ix0 = tile_x * MT - tout.halo - P;  // logical origin of the input tile
 
     // ---- per-thread staging descriptors (chunk independent) ----
@@ -543,13 +552,13 @@ static int launch_conv_mfma(bool dgrad, const TV& tin, const TV& tout, const TV&
     const int tiles_x = cdiv(tout.ws, MT), tiles_y = cdiv(tout.hs, MT);
     const int nmb = n_mblocks(n_out);
     const int m16p = nmb * MF * 16;
-    dim3 grid(tiles_x * tiles_y, tout.n, nmb);
+    dim3 grid(tiles_x * tiles_y * tout.n * nmb);
     if (dgrad)
         hipLaunchKernelGGL((conv_mfma_kernel<KS, MF, true>), grid, dim3(256), 0, st, tin, tout, tmask, (const uint4*)wpk, bias,
-                           n_out, m16p, relu, (unsigned long long)mask_bits, (unsigned long long)accum_bits, tiles_x);
+                           n_out, m16p, relu, (unsigned long long)mask_bits, (unsigned long long)accum_bits, tiles_x, tiles_y, nmb);
     else
         hipLaunchKernelGGL((conv_mfma_kernel<KS, MF, false>), grid, dim3(256), 0, st, tin, tout, tmask, (const uint4*)wpk, bias,
-                           n_out, m16p, relu, (unsigned long long)mask_bits, (unsigned long long)accum_bits, tiles_x);
+                           n_out, m16p, relu, (unsigned long long)mask_bits, (unsigned long long)accum_bits, tiles_x, tiles_y, nmb);
     return check_launch(dgrad ? "conv_mfma dgrad" : "conv_mfma fwd");
 }
 
