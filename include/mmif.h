@@ -163,6 +163,10 @@ int mmif_clip_adam_step(float* params, const float* grads, float* exp_avg, float
                         float lr, float beta1, float beta2, float eps, int32_t step, float max_norm,
                         float grad_scale, float* norm_out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- diagnostics: device buffer long long[1024][64]; when non-NULL the MFMA conv kernel stamps s_memtime per
+ * phase for its first 1024 blocks (tools/trace_conv.py).  NULL (default) disables it. */
+void mmif_debug_set_trace(void* device_buf);
+
 #ifdef __cplusplus
 }
 #endif

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(TV tin, TV tout, TV t
                                                             const float* __restrict__ bias, int n_out, int m16p,
                                                             int relu, unsigned long long mask_bits,
                                                             unsigned long long accum_bits, int tiles_x, int tiles_y,
-                                                            int nmb) {
+                                                            int nmb, long long* __restrict__ trace) {
     constexpr int KK = KS * KS, P = KS / 2;
     constexpr int TP = MT + KS - 1;             // input tile edge (18 / 16)
     constexpr int PL = plane_granules(KS);      // granules per LDS plane
@@ -126,12 +126,18 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(TV tin, TV tout, TV t
     __shared__ __attribute__((aligned(16))) uint4 s_in[CHUNK_CB * PL];
     __shared__ __attribute__((aligned(16))) uint4 s_w[MAXKGP * MF * 16];
     __shared__ int2 s_tab[MAXKGP];
+    __shared__ __attribute__((aligned(16))) float s_bias[MF * 16];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, g = lane >> 4;
     // XCD-aware block order (block b runs on XCD b % 8; speed only, any placement is correct): every XCD walks
     // a CONTIGUOUS band of (image, tile row, tile col) with a tile's M-blocks back to back, so the second
     // M-block's input tile and the halos shared with neighbouring tiles are hits in that XCD's L2.
+    // optional phase trace (diagnostics, tools/trace_conv.py): wave 0 of the first 1024 blocks stamps s_memtime
+    int tr_n = 0;
+    long long* tr = (trace != nullptr && blockIdx.x < 1024 && threadIdx.x == 0) ? trace + (long long)blockIdx.x * 64 : nullptr;
+#define TRACE_STAMP() do { if (tr != nullptr && tr_n < 64) tr[tr_n++] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+    TRACE_STAMP();
     const int nb = gridDim.x, b = blockIdx.x;
     const int q8 = nb >> 3, r8 = nb & 7, xcd = b & 7;
     const int lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
@@ -147,7 +153,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(TV tin, TV tout, TV t
     // idesc = LDS slot | chunk-local channel block << 16 | mode << 20; ioff = byte offset from the chunk's first plane
     // (always a valid address); ioff0 = the same pixel in the chunk's plane 0 (used for the ragged last chunk)
     int idesc[NIN];
-    unsigned ioff[NIN], ioff0[NIN];
+    unsigned ioff[NIN];
 #pragma unroll
     for (int i = 0; i < NIN; ++i) {
         const int e = tid + 256 * i;
@@ -159,15 +165,15 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(TV tin, TV tout, TV t
             y = min(max(reflect_idx(y, tin.h), 0), tin.h - 1);
             x = min(max(reflect_idx(x, tin.w), 0), tin.w - 1);
             mode = 1;
-            ioff0[i] = (unsigned)(y * tin.ws + x) * 16u;
+            ioff[i] = (unsigned)(y * tin.ws + x) * 16u;
         } else {
             const bool inside = y >= 0 && y < tin.h && x >= 0 && x < tin.w;
             const bool border = tin.halo && !tin.folded && ((y == 1) || (y == tin.h - 2) || (x == 1) || (x == tin.w - 2));
             mode = !inside ? 0 : (border ? 2 : 1);
-            ioff0[i] = (unsigned)((min(max(y, 0), tin.h - 1) + tin.halo) * tin.ws + min(max(x, 0), tin.w - 1) + tin.halo) * 16u;
+            ioff[i] = (unsigned)((min(max(y, 0), tin.h - 1) + tin.halo) * tin.ws + min(max(x, 0), tin.w - 1) + tin.halo) * 16u;
         }
         idesc[i] = (cb * PL + p) | (cb << 16) | (mode << 20);
-        ioff[i] = ioff0[i] + (unsigned)min(cb, CHUNK_CB - 1) * (unsigned)(tin.plane * 16);
+        ioff[i] += (unsigned)min(cb, CHUNK_CB - 1) * (unsigned)(tin.plane * 16);
     }
     const char* in_img = tin.base + ((long long)in_ * tin.img + (long long)tin.cb_off * tin.plane) * 16;
     // does this block's input tile contain a fold row/col (1 or h-2 / w-2) of a halo-1 gradient?
@@ -185,46 +191,62 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(TV tin, TV tout, TV t
     const char* in_lane = reinterpret_cast<const char*>(s_in) + ((wave * 4) * TP + j) * 16;
     const char* w_lane = reinterpret_cast<const char*>(s_w) + j * 16;
 
-    unsigned woff[NW];  // byte offset of this thread's weight granule i inside a chunk's packed slab
+    // byte offset of this thread's weight granule i inside a chunk's packed slab: granule i is (256 / (MF*16)) k-group
+    // planes below granule 0 whenever MF*16 divides 256, so ONE lane offset + a scalar stride serves all of them
+    constexpr bool WREG = (256 % (MF * 16)) == 0;
+    constexpr int NWO = WREG ? 1 : NW;
+    unsigned woff[NWO];
 #pragma unroll
-    for (int i = 0; i < NW; ++i) {
+    for (int i = 0; i < NWO; ++i) {
         const int e = tid + 256 * i;
         woff[i] = (unsigned)((e / (MF * 16)) * m16p + mb * MF * 16 + e % (MF * 16)) * 16u;
     }
+    const unsigned wstride = (unsigned)(256 / (MF * 16)) * (unsigned)m16p * 16u;   // uniform
     uint4 rin[NIN], rw[NW];
-    auto prefetch = [&](int c0, long long wchunk_off) {
+    // one staged load (compile-time index i after unrolling): input granule i < NIN, else weight granule i - NIN.
+    // Unconditional loads from clamped (always valid) addresses, zero by select: nothing serialises them.
+    auto issue_load = [&](int i, int c0, long long wchunk_off) {
         const int ncb = min(CHUNK_CB, ncb_tot - c0);
-        const int nkgp = (KK * ncb + 3) / 4 * 4;
-#pragma unroll
-        for (int i = 0; i < NIN; ++i) {
-            // unconditional load from a clamped (always valid) address, zero by select: no branch, no serialisation
+        if (i < NIN) {
             const int cb = (idesc[i] >> 16) & 15, mode = idesc[i] >> 20;
             const char* chunk = in_img + (long long)c0 * tin.plane * 16;          // wave-uniform base (SGPR pair)
-            const uint4 v = *reinterpret_cast<const uint4*>(chunk + (cb < ncb ? ioff[i] : ioff0[i]));   // + 32-bit lane offset
+            const uint4 v = *reinterpret_cast<const uint4*>(chunk + (cb < ncb ? ioff[i] : ioff[0]));   // + 32-bit lane offset (element 0 is always in plane 0)
             rin[i] = (cb < ncb && mode >= 1) ? v : make_uint4(0, 0, 0, 0);
-        }
-        const char* wchunk = reinterpret_cast<const char*>(wpk + wchunk_off);   // wave-uniform base
-#pragma unroll
-        for (int i = 0; i < NW; ++i) {
-            const int e = tid + 256 * i;
-            const int kg = e / (MF * 16);
+        } else if (i < NIN + NW) {
+            const int nkgp = (KK * ncb + 3) / 4 * 4;
+            const char* wchunk = reinterpret_cast<const char*>(wpk + wchunk_off);   // wave-uniform base
+            const int e = tid + 256 * (i - NIN);
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (kg < nkgp) v = *reinterpret_cast<const uint4*>(wchunk + woff[i]);
-            rw[i] = v;
+            if (e / (MF * 16) < nkgp) {
+                if (WREG) v = *reinterpret_cast<const uint4*>(wchunk + (long long)(i - NIN) * wstride + woff[0]);
+                else v = *reinterpret_cast<const uint4*>(wchunk + woff[WREG ? 0 : i - NIN]);
+            }
+            rw[i - NIN] = v;
         }
     };
+    auto prefetch = [&](int c0, long long wchunk_off) {
+#pragma unroll
+        for (int i = 0; i < NIN + NW; ++i) issue_load(i, c0, wchunk_off);
+    };
+    if (!DGRAD && tid < MF * 16) {   // bias of this block's channels -> LDS (read back in the epilogue)
+        const int oc = mb * MF * 16 + tid;
+        s_bias[tid] = (bias != nullptr && oc < n_out) ? bias[oc] : 0.f;
+    }
 
     long long wchunk_off = 0;  // granule offset of the current chunk in the packed weights
+    TRACE_STAMP();   // [1] prologue done
     prefetch(0, 0);
+    TRACE_STAMP();   // [2] first prefetch issued
     for (int c0 = 0; c0 < ncb_tot; c0 += CHUNK_CB) {
         const int ncb = min(CHUNK_CB, ncb_tot - c0);
         const int nkg = KK * ncb, nkgp = (nkg + 3) / 4 * 4;
         __syncthreads();  // previous chunk's MFMAs are done with the LDS tiles
+        TRACE_STAMP();    // chunk: after barrier A
 #pragma unroll
         for (int i = 0; i < NIN; ++i)
             if (((idesc[i] >> 16) & 15) < ncb) s_in[idesc[i] & 0xffff] = rin[i];
         if (DGRAD && fold_tile) {
-            // rare (border tiles of a padded-domain gradient): pixels on row/col 1 or h-2/w-2 get the
+            // rare (border tiles of an UNFOLDED padded-domain gradient): pixels on row/col 1 or h-2/w-2 get the
             // mirrored halo folded in; deliberately NOT unrolled (keeps the hot path's registers free)
 #pragma unroll 1
             for (int e = tid; e < ncb * TP * TP; e += 256) {
@@ -246,84 +268,113 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(TV tin, TV tout, TV t
             if (tid < nkg) { tap = tid / ncb; cb = tid % ncb; }
             s_tab[tid] = make_int2((cb * PL + (tap / KS) * TP + (tap % KS)) * 16, tid * MF * 256);
         }
+        TRACE_STAMP();    // chunk: LDS stores issued (includes the wait for the prefetched data)
         __syncthreads();
+        TRACE_STAMP();    // chunk: after barrier B
         wchunk_off += (long long)nkgp * m16p;
-        if (c0 + CHUNK_CB < ncb_tot) prefetch(c0 + CHUNK_CB, wchunk_off);  // in flight during the MFMAs below
+        const bool have_next = c0 + CHUNK_CB < ncb_tot;
         const int nsteps = nkgp >> 2;
+        // table-driven k-groups; the next chunk's global loads are issued up front and land during the MFMAs.
+        // (Interleaving them into a fully unrolled k-loop was tried: the vector-memory issue cost is per instruction,
+        // ~110 cycles each, and the unrolled body spilled 120+ VGPRs -- no gain.)
+        if (have_next) prefetch(c0 + CHUNK_CB, wchunk_off);
         int2 off = s_tab[g];
+        int2 nxt = s_tab[min(4, nkgp - 4) + g];
+        bf16x8 b[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) b[n] = *reinterpret_cast<const bf16x8*>(in_lane + off.x + n * TP * 16);
         for (int s = 0; s < nsteps; ++s) {
-            const int2 nxt = s_tab[min(4 * (s + 1), nkgp - 4) + g];
-            bf16x8 b[4];
+            const int2 nxt2 = s_tab[min(4 * (s + 2), nkgp - 4) + g];
+            bf16x8 a[MF], bn[4];
 #pragma unroll
-            for (int n = 0; n < 4; ++n) b[n] = *reinterpret_cast<const bf16x8*>(in_lane + off.x + n * TP * 16);
+            for (int m = 0; m < MF; ++m) a[m] = *reinterpret_cast<const bf16x8*>(w_lane + off.y + m * 256);
 #pragma unroll
-            for (int m = 0; m < MF; ++m) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(w_lane + off.y + m * 256);
+            for (int n = 0; n < 4; ++n) bn[n] = *reinterpret_cast<const bf16x8*>(in_lane + nxt.x + n * TP * 16);
 #pragma unroll
-                for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[n], acc[m][n], 0, 0, 0);
-            }
+            for (int m = 0; m < MF; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], b[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) b[n] = bn[n];
             off = nxt;
+            nxt = nxt2;
         }
+        TRACE_STAMP();    // chunk: k-loop done
     }
 
-    // ---- epilogue: lane (g, j) holds oc = 16*m + 4*g + r (r = 0..3) of pixel (row 4*wave + n, col j) ----
+    // ---- epilogue.  After the MFMAs lane (g, j) holds oc = 16*m + 4*g + r (r = 0..3) of pixels (row 4*wave + n, col j).
+    // v_permlane16_swap pairs rows n, n+1: lanes with even g end up with all 8 channels of row n, odd g with all
+    // 8 channels of row n+1, so every lane issues ONE 16-byte store per row pair (the 8-byte version was store-issue
+    // bound: 16 stores ~ 10k cycles per block).
     const int oxs = tile_x * MT + j;
     if (oxs >= tout.ws) return;
-    const int oys0 = tile_y * MT + wave * 4;
+    const int oys0 = tile_y * MT + wave * 4 + (g & 1);
     const unsigned row_bytes = (unsigned)tout.ws * 16u;
-    const unsigned pix_off = (unsigned)(oys0 * tout.ws + oxs) * 16u + (g & 1) * 8u;   // inside one plane
+    const unsigned pix_off = (unsigned)(oys0 * tout.ws + oxs) * 16u;   // inside one plane
     unsigned mpix_off = 0;
-    if (DGRAD) {
-        const int x = min(max(reflect_idx(oxs - tout.halo, tmask.w), 0), tmask.w - 1);
-        mpix_off = (unsigned)x * 16u + (g & 1) * 8u;
-    }
+    if (DGRAD) mpix_off = (unsigned)min(max(reflect_idx(oxs - tout.halo, tmask.w), 0), tmask.w - 1) * 16u;
 #pragma unroll
     for (int m = 0; m < MF; ++m) {
         const int ocb = (mb * MF + m) * 2 + (g >> 1);  // channel block inside the out view
-        if (ocb >= tout.cb) continue;
-        const int oc0 = ocb * 8 + (g & 1) * 4;
-        float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (!DGRAD && bias != nullptr) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) bv[r] = (oc0 + r < n_out) ? bias[oc0 + r] : 0.f;
+        const bool blk_ok = ocb < tout.cb;
+        float bv[8];
+        if (!DGRAD) {
+            const float4 b0 = *reinterpret_cast<const float4*>(&s_bias[m * 16 + (g >> 1) * 8]);
+            const float4 b1 = *reinterpret_cast<const float4*>(&s_bias[m * 16 + (g >> 1) * 8 + 4]);
+            bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
         }
-        char* oplane = tout.base + ((long long)in_ * tout.img + (long long)(tout.cb_off + ocb) * tout.plane) * 16 + pix_off;
-        const char* mplane = DGRAD ? tmask.base + ((long long)in_ * tmask.img + (long long)(tmask.cb_off + ocb) * tmask.plane) * 16 + mpix_off : nullptr;
+        char* oplane = tout.base + ((long long)in_ * tout.img + (long long)(tout.cb_off + min(ocb, tout.cb - 1)) * tout.plane) * 16 + pix_off;
+        const char* mplane = DGRAD ? tmask.base + ((long long)in_ * tmask.img + (long long)(tmask.cb_off + min(ocb, tmask.cb - 1)) * tmask.plane) * 16 + mpix_off : nullptr;
         const bool do_acc = DGRAD && ((accum_bits >> ocb) & 1ull);
         const bool do_mask = DGRAD && ((mask_bits >> ocb) & 1ull);
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            if (oys0 + n >= tout.hs) continue;
-            float v[4] = {acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]};
-            char* dst = oplane + n * row_bytes;
+        for (int p2 = 0; p2 < 2; ++p2) {
+            float c[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[m][2 * p2][r]), __float_as_uint(acc[m][2 * p2 + 1][r]), false, false);
+                c[r] = __uint_as_float(sw[0]);
+                c[4 + r] = __uint_as_float(sw[1]);
+            }
+            const int oys = oys0 + 2 * p2;
+            if (!blk_ok || oys >= tout.hs) continue;
+            char* dst = oplane + (2 * p2) * row_bytes;
             if (!DGRAD) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float t = v[r] + bv[r];
-                    if (relu) t = fmaxf(t, 0.f);
-                    v[r] = (oc0 + r < n_out) ? t : 0.f;
+                for (int i = 0; i < 8; ++i) {
+                    const float t = c[i] + bv[i];
+                    c[i] = relu ? fmaxf(t, 0.f) : t;
                 }
             } else {
                 if (do_acc) {
-                    const uint2 o = *reinterpret_cast<const uint2*>(dst);
-                    v[0] += __uint_as_float(o.x << 16);
-                    v[1] += __uint_as_float(o.x & 0xffff0000u);
-                    v[2] += __uint_as_float(o.y << 16);
-                    v[3] += __uint_as_float(o.y & 0xffff0000u);
+                    const uint4 o = *reinterpret_cast<const uint4*>(dst);
+                    const uint32_t ow[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        c[2 * i] += __uint_as_float(ow[i] << 16);
+                        c[2 * i + 1] += __uint_as_float(ow[i] & 0xffff0000u);
+                    }
                 }
                 if (do_mask) {
-                    const int y = min(max(reflect_idx(oys0 + n - tout.halo, tmask.h), 0), tmask.h - 1);
-                    const uint2 xm = *reinterpret_cast<const uint2*>(mplane + (unsigned)(y * tmask.ws) * 16u);
+                    const int y = min(max(reflect_idx(oys - tout.halo, tmask.h), 0), tmask.h - 1);
+                    const uint4 xm = *reinterpret_cast<const uint4*>(mplane + (unsigned)(y * tmask.ws) * 16u);
+                    const uint32_t xw[4] = {xm.x, xm.y, xm.z, xm.w};
                     // bf16 > 0  <=>  sign bit clear and magnitude non-zero (activations are never NaN)
-                    const uint32_t q[4] = {xm.x & 0xffffu, xm.x >> 16, xm.y & 0xffffu, xm.y >> 16};
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (!((q[r] & 0x8000u) == 0 && (q[r] & 0x7fffu) != 0)) v[r] = 0.f;
+                    for (int i = 0; i < 4; ++i) {
+                        const uint32_t lo = xw[i] & 0xffffu, hi = xw[i] >> 16;
+                        if (!((lo & 0x8000u) == 0 && (lo & 0x7fffu) != 0)) c[2 * i] = 0.f;
+                        if (!((hi & 0x8000u) == 0 && (hi & 0x7fffu) != 0)) c[2 * i + 1] = 0.f;
+                    }
                 }
             }
-            *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+            *reinterpret_cast<uint4*>(dst) = make_uint4(pack_bf16x2(c[0], c[1]), pack_bf16x2(c[2], c[3]), pack_bf16x2(c[4], c[5]),
+                                                         pack_bf16x2(c[6], c[7]));
         }
     }
+    TRACE_STAMP();        // epilogue stores issued
+    if (tr != nullptr) tr[63] = tr_n;
+#undef TRACE_STAMP
 }
 
 // ------------------------------------------------------------------ wgrad kernel (K = pixels)
@@ -541,6 +592,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_reduce(const float* __restrict
 }
 
 // ------------------------------------------------------------------ host side
+static long long* g_trace = nullptr;  // device buffer [1024][64] for the optional phase trace
 bool conv_mfma_supported(bool dgrad, int ks, int cin, int cout) {
     (void)dgrad;
     return (ks == 1 || ks == 3) && cin >= 1 && cout >= 1;
@@ -555,10 +607,10 @@ static int launch_conv_mfma(bool dgrad, const TV& tin, const TV& tout, const TV&
     dim3 grid(tiles_x * tiles_y * tout.n * nmb);
     if (dgrad)
         hipLaunchKernelGGL((conv_mfma_kernel<KS, MF, true>), grid, dim3(256), 0, st, tin, tout, tmask, (const uint4*)wpk, bias,
-                           n_out, m16p, relu, (unsigned long long)mask_bits, (unsigned long long)accum_bits, tiles_x, tiles_y, nmb);
+                           n_out, m16p, relu, (unsigned long long)mask_bits, (unsigned long long)accum_bits, tiles_x, tiles_y, nmb, g_trace);
     else
         hipLaunchKernelGGL((conv_mfma_kernel<KS, MF, false>), grid, dim3(256), 0, st, tin, tout, tmask, (const uint4*)wpk, bias,
-                           n_out, m16p, relu, (unsigned long long)mask_bits, (unsigned long long)accum_bits, tiles_x, tiles_y, nmb);
+                           n_out, m16p, relu, (unsigned long long)mask_bits, (unsigned long long)accum_bits, tiles_x, tiles_y, nmb, g_trace);
     return check_launch(dgrad ? "conv_mfma dgrad" : "conv_mfma fwd");
 }
 
@@ -625,6 +677,8 @@ int wgrad_mfma(int ks, const TV& tx, const TV& tg, float* dw, float* db, int cin
 }  // namespace mmif
 
 using namespace mmif;
+
+extern "C" void mmif_debug_set_trace(void* device_buf) { mmif::g_trace = (long long*)device_buf; }
 
 extern "C" size_t mmif_packed_weight_bytes(int32_t cout, int32_t cin, int32_t ksize) {
     const size_t a = packed_bytes(cout, cin, ksize), b = packed_bytes(cin, cout, ksize);
