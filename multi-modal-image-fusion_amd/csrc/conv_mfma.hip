@@ -327,6 +327,24 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(TV tin, TV tout, TV t
         const char* mplane = DGRAD ? tmask.base + ((long long)in_ * tmask.img + (long long)(tmask.cb_off + min(ocb, tmask.cb - 1)) * tmask.plane) * 16 + mpix_off : nullptr;
         const bool do_acc = DGRAD && ((accum_bits >> ocb) & 1ull);
         const bool do_mask = DGRAD && ((mask_bits >> ocb) & 1ull);
+        // dgrad: fetch the old gradient / the ReLU-mask activations of BOTH row pairs first (the stores below may
+        // alias them as far as the compiler can tell, which would serialise load -> store -> load)
+        uint4 oldv[2], xmv[2];
+        if (DGRAD) {
+#pragma unroll
+            for (int p2 = 0; p2 < 2; ++p2) {
+                oldv[p2] = make_uint4(0, 0, 0, 0);
+                xmv[p2] = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+                const int oys = oys0 + 2 * p2;
+                if (blk_ok && oys < tout.hs) {
+                    if (do_acc) oldv[p2] = *reinterpret_cast<const uint4*>(oplane + (2 * p2) * row_bytes);
+                    if (do_mask) {
+                        const int y = min(max(reflect_idx(oys - tout.halo, tmask.h), 0), tmask.h - 1);
+                        xmv[p2] = *reinterpret_cast<const uint4*>(mplane + (unsigned)(y * tmask.ws) * 16u);
+                    }
+                }
+            }
+        }
 #pragma unroll
         for (int p2 = 0; p2 < 2; ++p2) {
             float c[8];
@@ -346,26 +364,16 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(TV tin, TV tout, TV t
                     c[i] = relu ? fmaxf(t, 0.f) : t;
                 }
             } else {
-                if (do_acc) {
-                    const uint4 o = *reinterpret_cast<const uint4*>(dst);
-                    const uint32_t ow[4] = {o.x, o.y, o.z, o.w};
+                const uint32_t ow[4] = {oldv[p2].x, oldv[p2].y, oldv[p2].z, oldv[p2].w};
+                const uint32_t xw[4] = {xmv[p2].x, xmv[p2].y, xmv[p2].z, xmv[p2].w};
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        c[2 * i] += __uint_as_float(ow[i] << 16);
-                        c[2 * i + 1] += __uint_as_float(ow[i] & 0xffff0000u);
-                    }
-                }
-                if (do_mask) {
-                    const int y = min(max(reflect_idx(oys - tout.halo, tmask.h), 0), tmask.h - 1);
-                    const uint4 xm = *reinterpret_cast<const uint4*>(mplane + (unsigned)(y * tmask.ws) * 16u);
-                    const uint32_t xw[4] = {xm.x, xm.y, xm.z, xm.w};
-                    // bf16 > 0  <=>  sign bit clear and magnitude non-zero (activations are never NaN)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const uint32_t lo = xw[i] & 0xffffu, hi = xw[i] >> 16;
-                        if (!((lo & 0x8000u) == 0 && (lo & 0x7fffu) != 0)) c[2 * i] = 0.f;
-                        if (!((hi & 0x8000u) == 0 && (hi & 0x7fffu) != 0)) c[2 * i + 1] = 0.f;
-                    }
+                for (int i = 0; i < 4; ++i) {
+                    c[2 * i] += __uint_as_float(ow[i] << 16);          // zeros when not accumulating
+                    c[2 * i + 1] += __uint_as_float(ow[i] & 0xffff0000u);
+                    // bf16 > 0  <=>  sign bit clear and magnitude non-zero (activations are never NaN); 1.0 when unmasked
+                    const uint32_t lo = xw[i] & 0xffffu, hi = xw[i] >> 16;
+                    if (!((lo & 0x8000u) == 0 && (lo & 0x7fffu) != 0)) c[2 * i] = 0.f;
+                    if (!((hi & 0x8000u) == 0 && (hi & 0x7fffu) != 0)) c[2 * i + 1] = 0.f;
                 }
             }
             *reinterpret_cast<uint4*>(dst) = make_uint4(pack_bf16x2(c[0], c[1]), pack_bf16x2(c[2], c[3]), pack_bf16x2(c[4], c[5]),
