@@ -138,6 +138,24 @@ int mmif_fuse_elem_fwd(const mmif_tensor* a, const mmif_tensor* b, const mmif_te
 int mmif_fuse_elem_bwd(const mmif_tensor* a, const mmif_tensor* b, const mmif_tensor* g, const mmif_tensor* ga,
                        const mmif_tensor* gb, int32_t mode, int32_t relu_mask, void* stream);
 
+/* attention_fusion core/fusion.py:42-59 with spatial 'l1' (:89-90) / channel 'avg' (:123-124) pooling, softmax=False;
+ * mode 0 'sa', 1 'ca', 2 'sca'.  a, b, out: halo-0 views.  bwd: g halo 0/1; ga/gb gradient views (interior written,
+ * optionally accumulated); gradients flow through the pooled weights as in the reference. */
+size_t mmif_fuse_attn_workspace(int32_t n, int32_t c);
+int mmif_fuse_attn_fwd(const mmif_tensor* a, const mmif_tensor* b, const mmif_tensor* out, int32_t mode, void* workspace,
+                       size_t workspace_bytes, void* stream);
+int mmif_fuse_attn_bwd(const mmif_tensor* a, const mmif_tensor* b, const mmif_tensor* g, const mmif_tensor* ga,
+                       const mmif_tensor* gb, int32_t mode, int32_t accumulate, void* workspace, size_t workspace_bytes,
+                       void* stream);
+
+/* ---- NestFuse glue: nn.MaxPool2d(2,2) (core/model.py:332-335), nn.Upsample(x2,'nearest') + ReflectionPad2d to the
+ *      skip's shape (core/block.py:965-991), threshold_backward of a ReLU output ---- */
+int mmif_maxpool2x2_fwd(const mmif_tensor* x, const mmif_tensor* y, void* stream);
+int mmif_maxpool2x2_bwd(const mmif_tensor* x, const mmif_tensor* g, const mmif_tensor* gx, int32_t accumulate, void* stream);
+int mmif_upsample2x_fwd(const mmif_tensor* x, const mmif_tensor* y, void* stream);
+int mmif_upsample2x_bwd(const mmif_tensor* g, const mmif_tensor* gx, int32_t accumulate, void* stream);
+int mmif_relu_mask(const mmif_tensor* x, const mmif_tensor* g, void* stream); /* g *= [x > 0], in place */
+
 /* ---- losses (core/loss.py); images fp32 [n][h][w] ---- */
 size_t mmif_loss_workspace(int32_t n, int32_t h, int32_t w);
 /* SSIMLoss(mode='ssim') core/loss.py:252-257,284 = weight*(1 - (mean SSIM(img1,f)+mean SSIM(img2,f))/2),

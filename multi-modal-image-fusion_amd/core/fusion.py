@@ -3,8 +3,9 @@
 
 element_fusion runs on the HIP element-fusion kernels (mmif_fuse_elem_{fwd,bwd}); inside the models
 concat_fusion is zero-copy (channel-block views) and DenseFuse's 'sum' runs on blocked buffers.
-The attention / pooling functions below are tensor-level compositions kept for API completeness
-(NestFuse-family path, SURVEY section 8 row a3/a5 -- HIP kernels for them are the next widening step).
+attention_fusion 'sa' / 'ca' / 'sca' with the reference's default pooling (spatial 'l1', channel 'avg') runs on
+the HIP attention kernels (mmif_fuse_attn_{fwd,bwd}); the remaining pooling modes are tensor-level compositions
+kept for API completeness.
 """
 import torch
 
@@ -38,6 +39,30 @@ class _ElemFusionFn(torch.autograd.Function):
         ga = BT.alloc(ab.n, c, ab.h, ab.w, ab.dtype, g.device)
         gbb = BT.alloc(ab.n, c, ab.h, ab.w, ab.dtype, g.device)
         T.fuse_elem_bwd(ab, bb, gb, ga, gbb, mode, False)
+        return ga.to_nchw(c), gbb.to_nchw(c), None
+
+
+class _AttnFusionFn(torch.autograd.Function):
+    """attention_fusion('sa'|'ca'|'sca') with spatial 'l1' / channel 'avg' pooling on the HIP kernels."""
+
+    @staticmethod
+    def forward(ctx, a, b, mode):
+        dtype = E.compute_dtype()
+        ab, bb = BT.from_nchw(a.detach(), dtype), BT.from_nchw(b.detach(), dtype)
+        c = a.shape[1]
+        ob = BT.alloc(ab.n, c, ab.h, ab.w, dtype, a.device)
+        ws = T.attn_workspace(ab.n, c, a.device)
+        T.attn_fwd(ab, bb, ob, mode, ws)
+        ctx.saved = (ab, bb, mode, c, ws)
+        return ob.to_nchw(c)
+
+    @staticmethod
+    def backward(ctx, g):
+        ab, bb, mode, c, ws = ctx.saved
+        gb = BT.from_nchw(g.contiguous(), ab.dtype)
+        ga = BT.alloc(ab.n, c, ab.h, ab.w, ab.dtype, g.device)
+        gbb = BT.alloc(ab.n, c, ab.h, ab.w, ab.dtype, g.device)
+        T.attn_bwd(ab, bb, gb, ga, gbb, mode, False, ws)
         return ga.to_nchw(c), gbb.to_nchw(c), None
 
 
@@ -102,6 +127,9 @@ def channel_fusion(tensor1, tensor2, mode='avg', softmax=True):
 def attention_fusion(tensor1, tensor2, mode='sca', spatial_mode='l1', channel_mode='avg'):
     if mode not in ('sa', 'ca', 'sca', 'wavg'):
         raise ValueError("only supported ['sa', 'ca', 'sca', 'wavg'] mode")
+    if (tensor1.is_cuda and mode in T.ATTN_MODES and spatial_mode == 'l1' and channel_mode == 'avg' and tensor1.dim() == 4
+            and tensor1.shape == tensor2.shape):
+        return _AttnFusionFn.apply(tensor1, tensor2, T.ATTN_MODES[mode])
     f_spatial = spatial_fusion(tensor1, tensor2, spatial_mode, softmax=False)
     f_channel = channel_fusion(tensor1, tensor2, channel_mode, softmax=False)
     if mode == 'sa':

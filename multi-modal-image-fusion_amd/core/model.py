@@ -23,6 +23,7 @@ class _FusionModel(nn.Module):
         self.encode = nn.Sequential()
         self.decode = nn.Sequential()
         self._engine = None
+        self._engine_single = True   # engine also serves the auto-encoder call forward(img1)
 
     def encoder(self, img):
         return self.encode(img)
@@ -39,7 +40,7 @@ class _FusionModel(nn.Module):
     def forward(self, img1, img2=None):
         if self._engine is None:
             self._engine = self._make_engine()
-        if self._engine is not None:
+        if self._engine is not None and (img2 is not None or self._engine_single):
             return self._engine.run(img1, img2)
         if img2 is None:
             return self.decoder(self.encoder(img1))
@@ -141,6 +142,14 @@ class NestFuse(_FusionModel):
 
     def fusion(self, feats1, feats2, mode='sca'):
         return tuple(attention_fusion(a, b, mode) for a, b in zip(feats1, feats2))
+
+    def _make_engine(self):
+        # fused engine for the reference's default configuration; other down/up modes run block by block
+        self._engine_single = False
+        if isinstance(self.down1, nn.MaxPool2d) and isinstance(self.decode.up.up, nn.Upsample) and self.decode.up.up.mode == 'nearest':
+            from mmif.nest_engine import NestEngine
+            return NestEngine(self, rfn=hasattr(self, 'RFN1'))
+        return None
 
     def decoder(self, feats):
         return self.conv_out(self.decode(feats))

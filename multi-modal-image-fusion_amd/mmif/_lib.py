@@ -62,6 +62,14 @@ SIGNATURES = {
     "mmif_conv2d_image_wgrad_workspace": (_sz, [_i32, _i32]),
     "mmif_fuse_elem_fwd": (_i32, [_TP, _TP, _TP, _i32, _vp]),
     "mmif_fuse_elem_bwd": (_i32, [_TP, _TP, _TP, _TP, _TP, _i32, _i32, _vp]),
+    "mmif_fuse_attn_workspace": (_sz, [_i32, _i32]),
+    "mmif_fuse_attn_fwd": (_i32, [_TP, _TP, _TP, _i32, _vp, _sz, _vp]),
+    "mmif_fuse_attn_bwd": (_i32, [_TP, _TP, _TP, _TP, _TP, _i32, _i32, _vp, _sz, _vp]),
+    "mmif_maxpool2x2_fwd": (_i32, [_TP, _TP, _vp]),
+    "mmif_maxpool2x2_bwd": (_i32, [_TP, _TP, _TP, _i32, _vp]),
+    "mmif_upsample2x_fwd": (_i32, [_TP, _TP, _vp]),
+    "mmif_upsample2x_bwd": (_i32, [_TP, _TP, _i32, _vp]),
+    "mmif_relu_mask": (_i32, [_TP, _TP, _vp]),
     "mmif_loss_workspace": (_sz, [_i32, _i32, _i32]),
     "mmif_ssim_loss": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _sz, _vp]),
     "mmif_pixel_loss": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),

@@ -61,37 +61,76 @@ def all_bits(n):
 
 class ConvSpec:
     """One ConvLayer as the engine sees it: fp32 master weight/bias (nn.Parameter), geometry, the
-    packed bf16 operand images and where its gradients go."""
+    packed bf16 operand images and where its gradients go.
 
-    def __init__(self, name, conv, relu):
+    split = Cf > 0: the layer's reference input is cat(feats[Cf], up[Cu]) but the engine's buffer holds
+    [up | feats] (NestDecoder rows, so every concat is a contiguous PREFIX of one allocation): the kernels
+    see the input-channel-permuted weights `wperm`, and dW is permuted back into the parameter's order."""
+
+    def __init__(self, name, conv, relu, split=0):
         self.name = name
         self.conv = conv  # nn.Conv2d holding .weight / .bias
         self.cout, self.cin, self.k = conv.weight.shape[0], conv.weight.shape[1], conv.weight.shape[2]
         self.relu = relu
+        self.split = split
+        self.wperm = None
+        self.dw_tmp = None
         self.packed = None
         self.packed_version = None
+        self.perm_version = None
         self.dw = None  # views into the flat gradient buffer, set per backward
         self.db = None
 
     @property
     def w(self):
-        return self.conv.weight
+        return self.wperm if self.split else self.conv.weight
 
     @property
     def b(self):
         return self.conv.bias
 
-    def ensure_packed(self, version):
-        if self.cin == 1 or self.cout == 1:
-            return
+    def _key(self, version):
         w = self.conv.weight
-        key = (version, WEIGHTS_EPOCH[0], w._version, w.data_ptr())
-        if self.packed is None or self.packed.fwd.device != w.device:
-            self.packed = PackedWeights(self.cout, self.cin, self.k, w.device)
-            self.packed_version = None
-        if self.packed_version != key:
-            self.packed.pack(w.detach())
-            self.packed_version = key
+        return (version, WEIGHTS_EPOCH[0], w._version, w.data_ptr())
+
+    def refresh(self, version, pack):
+        """Bring the derived weight images (channel permutation, bf16 MFMA packing) up to date."""
+        key = self._key(version)
+        if self.split and self.perm_version != key:
+            w = self.conv.weight.detach()
+            self.wperm = torch.cat((w[:, self.split:], w[:, :self.split]), dim=1).contiguous()
+            self.perm_version = key
+        if pack and self.cin > 1 and self.cout > 1:
+            w = self.conv.weight
+            if self.packed is None or self.packed.fwd.device != w.device:
+                self.packed = PackedWeights(self.cout, self.cin, self.k, w.device)
+                self.packed_version = None
+            if self.packed_version != key:
+                self.packed.pack(self.w.detach())
+                self.packed_version = key
+
+    def ensure_packed(self, version):
+        self.refresh(version, True)
+
+    def grad_target(self):
+        """Where the wgrad kernel writes dW: the parameter's gradient view, or a scratch in buffer order."""
+        if not self.split:
+            return self.dw
+        if self.dw_tmp is None or self.dw_tmp.device != self.dw.device:
+            self.dw_tmp = torch.empty_like(self.dw)
+        return self.dw_tmp
+
+    def finish_grad(self, accumulate):
+        if not self.split:
+            return
+        cu = self.cin - self.split   # buffer order [up(cu) | feats(split)] -> parameter order [feats | up]
+        t = self.dw_tmp
+        if accumulate:
+            self.dw[:, :self.split] += t[:, cu:]
+            self.dw[:, self.split:] += t[:, :cu]
+        else:
+            self.dw[:, :self.split] = t[:, cu:]
+            self.dw[:, self.split:] = t[:, :cu]
 
 
 class Lease:
@@ -208,9 +247,8 @@ class ModelEngine:
         dtype = compute_dtype()
         impl = conv_impl()
         use_mfma = dtype == torch.bfloat16 and impl != _lib.IMPL_VALU
-        if use_mfma:
-            for s in self.specs:
-                s.ensure_packed(self.weights_version)
+        for s in self.specs:
+            s.refresh(self.weights_version, use_mfma)
         imgs = [None if i is None else i.detach().contiguous().float() for i in imgs]
         n, c, h, w = imgs[0].shape
         if c != 1:
@@ -232,8 +270,13 @@ class ModelEngine:
         return gx.fold_halo_() if s.k > 1 else gx.as_folded()
 
     @staticmethod
-    def c_wgrad(s, x, gy, ws, impl):
-        T.conv_wgrad(x, gy, s.dw, s.db, s.cin, s.cout, s.k, ws, False, impl, s.name + ":wgrad")
+    def c_wgrad(s, x, gy, ws, impl, accumulate=False):
+        if s.split:
+            T.conv_wgrad(x, gy, s.grad_target(), s.db, s.cin, s.cout, s.k, ws, False, impl, s.name + ":wgrad")
+            # db went straight to the parameter's view (accumulate unsupported for permuted layers: used once per step)
+            s.finish_grad(accumulate)
+        else:
+            T.conv_wgrad(x, gy, s.dw, s.db, s.cin, s.cout, s.k, ws, accumulate, impl, s.name + ":wgrad")
 
     def forward(self, img1, img2):
         raise NotImplementedError

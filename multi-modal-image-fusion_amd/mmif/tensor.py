@@ -181,3 +181,38 @@ def wgrad_workspace_bytes(cin, cout, k):
 
 def image_wgrad_workspace_bytes(c, k):
     return lib.mmif_conv2d_image_wgrad_workspace(c, k)
+
+
+def maxpool_fwd(x, y):
+    check(lib.mmif_maxpool2x2_fwd(x.d, y.d, stream_ptr()), "maxpool2x2_fwd")
+
+
+def maxpool_bwd(x, g, gx, accumulate):
+    check(lib.mmif_maxpool2x2_bwd(x.d, g.d, gx.d, int(accumulate), stream_ptr()), "maxpool2x2_bwd")
+
+
+def upsample_fwd(x, y):
+    check(lib.mmif_upsample2x_fwd(x.d, y.d, stream_ptr()), "upsample2x_fwd")
+
+
+def upsample_bwd(g, gx, accumulate):
+    check(lib.mmif_upsample2x_bwd(g.d, gx.d, int(accumulate), stream_ptr()), "upsample2x_bwd")
+
+
+def relu_mask_(x, g):
+    check(lib.mmif_relu_mask(x.d, g.d, stream_ptr()), "relu_mask")
+
+
+ATTN_MODES = {"sa": 0, "ca": 1, "sca": 2}
+
+
+def attn_workspace(n, c, device):
+    return torch.empty(lib.mmif_fuse_attn_workspace(n, c) // 4 + 1, dtype=torch.float32, device=device)
+
+
+def attn_fwd(a, b, out, mode, ws):
+    check(lib.mmif_fuse_attn_fwd(a.d, b.d, out.d, mode, _ptr(ws), ws.numel() * 4, stream_ptr()), "fuse_attn_fwd")
+
+
+def attn_bwd(a, b, g, ga, gb, mode, accumulate, ws):
+    check(lib.mmif_fuse_attn_bwd(a.d, b.d, g.d, ga.d, gb.d, mode, int(accumulate), _ptr(ws), ws.numel() * 4, stream_ptr()), "fuse_attn_bwd")

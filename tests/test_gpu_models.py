@@ -173,3 +173,54 @@ def test_nestfuse_bf16_mfma_runs_close():
             y = m(tg(i1n), tg(i2n))
         torch.cuda.synchronize()
         close(y.cpu().numpy(), y_or, 5e-2, "imgf")
+
+
+@pytest.mark.parametrize("name", ["NestFuse", "RFNNest"])
+def test_nest_engine_odd_size_vs_oracle(name):
+    """Odd pyramid sizes (36x44 -> 18x22 -> 9x11 -> 4x5): the up-sampled 8x10 map is reflect-padded to 9x11
+    (core/block.py:981-991); fused engine (HIP pool / upsample / attention / RFN adds) vs the CPU oracle."""
+    shape = (2, 1, 36, 44)
+    om = O.MODELS[name]()
+    P = om.init_params(seed=3)
+    i1n, i2n, gn = O.closed_form_image(shape, 0.3), O.closed_form_image(shape, 1.7), O.closed_form_signed(shape, 0.9, 1.0)
+    y_or = om.forward(P, i1n, i2n)
+    G_or = om.backward(P, gn)
+    with dtype_ctx("fp32"):
+        m = _model(name, 3)
+        assert m._make_engine() is not None
+        y = m(tg(i1n), tg(i2n))
+        y.backward(tg(gn))
+        torch.cuda.synchronize()
+        close(y.detach().cpu().numpy(), y_or, 2e-4, "imgf")
+        for k, p in m.named_parameters():
+            close(p.grad.cpu().numpy(), G_or[k], 1e-3, k)
+
+
+def test_fusion_functions_hip_vs_golden():
+    """core.fusion attention_fusion / element_fusion on the HIP kernels vs the reference (golden F4)."""
+    import core.fusion as F
+    ref = np.load(os.path.join(G, "f4_blocks.npz"))
+    s = (2, 16, 6, 10)
+    a, b, gy = O.closed_form_signed(s, 0.15), O.closed_form_signed(s, 1.25), O.closed_form_signed(s, 2.35)
+    with dtype_ctx("fp32"):
+        for mode in ("sa", "ca", "sca"):
+            for tagn, (aa, bb) in (("attn_" + mode, (a, b)),) + ((("attn_relu", (np.maximum(a, 0), np.maximum(b, 0))),) if mode == "sca" else ()):
+                ta, tb = tg(aa).requires_grad_(True), tg(bb).requires_grad_(True)
+                y = F.attention_fusion(ta, tb, mode)
+                y.backward(tg(gy))
+                close(y.detach().cpu().numpy(), ref[tagn + "__y"], 1e-4, tagn)
+                close(ta.grad.cpu().numpy(), ref[tagn + "__da"], 2e-4, tagn + " da")
+                close(tb.grad.cpu().numpy(), ref[tagn + "__db"], 2e-4, tagn + " db")
+        z = tg(np.zeros(s, np.float32))
+        ta, tb = z.clone().requires_grad_(True), z.clone().requires_grad_(True)
+        y = F.attention_fusion(ta, tb, "sca")
+        y.backward(tg(gy))
+        assert float(y.abs().max()) == 0.0
+        close(ta.grad.cpu().numpy(), ref["attn_zero__da"], 1e-5, "zero da")
+        for mode in ("sum", "mean", "max"):
+            ta, tb = tg(a).requires_grad_(True), tg(b).requires_grad_(True)
+            y = F.element_fusion(ta, tb, mode)
+            y.backward(tg(gy))
+            close(y.detach().cpu().numpy(), ref[f"elem_{mode}__y"], 1e-6)
+            close(ta.grad.cpu().numpy(), ref[f"elem_{mode}__da"], 1e-6)
+            close(tb.grad.cpu().numpy(), ref[f"elem_{mode}__db"], 1e-6)
