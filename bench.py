@@ -29,7 +29,7 @@ for _p in (ROOT, os.path.join(ROOT, "multi-modal-image-fusion_amd")):
 import torch
 import torch.distributed as dist
 
-MODEL_FLOPS_TRAIN = {"PFNetv1": 107.04e9}  # per pair @256x256
+MODEL_FLOPS_TRAIN = {"PFNetv1": 107.04e9, "PFNetv2": 36.82e9, "DenseFuse": 34.56e9}  # per pair @256x256
 MODEL_BYTES_TRAIN_BF16 = {"PFNetv1": 366.1e6}
 PEAK_MFMA_BF16 = 2.5e15   # dense, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM = 8.0e12
@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=32, help="image pairs per GPU")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--model", default="PFNetv1", choices=["PFNetv1", "DenseFuse"])
+    ap.add_argument("--model", default="PFNetv1", choices=["PFNetv1", "PFNetv2", "DenseFuse", "NestFuse", "RFNNest"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=2, help="image pairs in the CPU-oracle sample")
     ap.add_argument("--roofline-tag", default="decode.0:fwd", help="engine op timed with HIP events for `roofline`")
