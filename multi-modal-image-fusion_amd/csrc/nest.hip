@@ -106,12 +106,14 @@ __global__ void upsample_bwd_kernel(TV g, TV gx, int accumulate) {
     GRID_STRIDE(i, total) {
         const int xi = i % gx.w, yi = (i / gx.w) % gx.h, c = (i / ((long long)gx.w * gx.h)) % gx.cb, n = i / ((long long)gx.w * gx.h * gx.cb);
         float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        // candidate y rows: the 2 direct rows plus reflected pad rows (pads are at most a few pixels)
-        for (int yy = 0; yy < g.h; ++yy) {
-            if (!((yy - top >= 2 * yi && yy - top <= 2 * yi + 1) || yy < top || yy >= top + H2)) continue;
+        // candidates: the 2 direct rows / cols plus the (few) reflected pad rows / cols that mirror onto them
+        const int bot = g.h - top - H2, right = g.w - left - W2;
+        const int ny = 2 + top + bot, nx = 2 + left + right;
+        for (int a = 0; a < ny; ++a) {
+            const int yy = a < 2 ? top + 2 * yi + a : (a < 2 + top ? a - 2 : top + H2 + (a - 2 - top));
             if (up_src(yy, top, H2) != yi) continue;
-            for (int xx = 0; xx < g.w; ++xx) {
-                if (!((xx - left >= 2 * xi && xx - left <= 2 * xi + 1) || xx < left || xx >= left + W2)) continue;
+            for (int b = 0; b < nx; ++b) {
+                const int xx = b < 2 ? left + 2 * xi + b : (b < 2 + left ? b - 2 : left + W2 + (b - 2 - left));
                 if (up_src(xx, left, W2) != xi) continue;
                 float gv[8];
                 load_grad_fold<T>(g, n, c, yy, xx, gv);
@@ -147,14 +149,16 @@ __global__ void relu_mask_kernel(TV x, TV g) {
 // ------------------------------------------------------------------ attention fusion (core/fusion.py:32-124)
 // per-(n, channel) plane sums: out[(n*C + ch)*NV + v]; mode 0: v0 = sum a, v1 = sum b (channel 'avg' pooling * HW);
 // mode 1: v0 = sum g*(a-b)  (gradient w.r.t. the channel weight).  One block per (n, channel block).
+constexpr int PS_SLICES = 32;
+
 template <typename T, int MODE>
-__global__ __launch_bounds__(256) void plane_sums_kernel(TV a, TV b, TV g, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void plane_sums_kernel(TV a, TV b, TV g, float* __restrict__ partial) {
     __shared__ float red[16];
-    const int c = blockIdx.x % a.cb, n = blockIdx.x / a.cb;
+    const int c = blockIdx.x % a.cb, n = blockIdx.x / a.cb, sl = blockIdx.y;
     float s0[8], s1[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) s0[k] = s1[k] = 0.f;
-    for (int p = threadIdx.x; p < a.h * a.w; p += 256) {
+    for (int p = sl * 256 + threadIdx.x; p < a.h * a.w; p += 256 * PS_SLICES) {
         const int y = p / a.w, x = p % a.w;
         float va[8], vb[8];
         ld<T>(a, n, c, y, x, va);
@@ -171,15 +175,25 @@ __global__ __launch_bounds__(256) void plane_sums_kernel(TV a, TV b, TV g, float
     }
     constexpr int NV = MODE == 0 ? 2 : 1;
     const int C = a.cb * 8;
+    float* dst = partial + ((long long)sl * a.n * C + (long long)n * C + c * 8) * NV;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const float t0 = block_sum(s0[k], red);
-        if (threadIdx.x == 0) out[((long long)n * C + c * 8 + k) * NV + 0] = t0;
+        if (threadIdx.x == 0) dst[k * NV + 0] = t0;
         if (MODE == 0) {
             const float t1 = block_sum(s1[k], red);
-            if (threadIdx.x == 0) out[((long long)n * C + c * 8 + k) * NV + 1] = t1;
+            if (threadIdx.x == 0) dst[k * NV + 1] = t1;
         }
     }
+}
+
+// out[i] = sum over the PS_SLICES partial planes (fixed order)
+__global__ void plane_sums_finish(const float* __restrict__ partial, float* __restrict__ out, int count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    float s = 0.f;
+    for (int sl = 0; sl < PS_SLICES; ++sl) s += partial[(long long)sl * count + i];
+    out[i] = s;
 }
 
 // mode bits: 1 = spatial branch, 2 = channel branch; both -> 'sca' = mean of the two
@@ -355,7 +369,9 @@ extern "C" int mmif_relu_mask(const mmif_tensor* x, const mmif_tensor* g, void* 
 
 static int attn_mode(int32_t mode) { return mode == 0 ? 1 : (mode == 1 ? 2 : (mode == 2 ? 3 : -1)); }  // sa, ca, sca
 
-extern "C" size_t mmif_fuse_attn_workspace(int32_t n, int32_t c) { return (size_t)n * ((c + 7) / 8 * 8) * 3 * sizeof(float); }
+extern "C" size_t mmif_fuse_attn_workspace(int32_t n, int32_t c) {
+    return (size_t)n * ((c + 7) / 8 * 8) * (3 + 2 * PS_SLICES) * sizeof(float);  // sums + per-slice partials
+}
 
 extern "C" int mmif_fuse_attn_fwd(const mmif_tensor* a, const mmif_tensor* b, const mmif_tensor* out, int32_t mode,
                                   void* workspace, size_t workspace_bytes, void* stream) {
@@ -377,8 +393,11 @@ extern "C" int mmif_fuse_attn_fwd(const mmif_tensor* a, const mmif_tensor* b, co
     TV ta = make_tv(a), tb = make_tv(b), to = make_tv(out);
     float* csum = (float*)workspace;
     if (m & 2) {
-        if (a->dtype == MMIF_F32) hipLaunchKernelGGL((plane_sums_kernel<float, 0>), dim3(ta.n * ta.cb), dim3(256), 0, st, ta, tb, ta, csum);
-        else hipLaunchKernelGGL((plane_sums_kernel<bf16_t, 0>), dim3(ta.n * ta.cb), dim3(256), 0, st, ta, tb, ta, csum);
+        const int cnt = a->n * a->cb * 8;
+        float* part = csum + (size_t)cnt * 3;
+        if (a->dtype == MMIF_F32) hipLaunchKernelGGL((plane_sums_kernel<float, 0>), dim3(ta.n * ta.cb, PS_SLICES), dim3(256), 0, st, ta, tb, ta, part);
+        else hipLaunchKernelGGL((plane_sums_kernel<bf16_t, 0>), dim3(ta.n * ta.cb, PS_SLICES), dim3(256), 0, st, ta, tb, ta, part);
+        hipLaunchKernelGGL(plane_sums_finish, dim3((cnt * 2 + 255) / 256), dim3(256), 0, st, part, csum, cnt * 2);
         if (int rc = check_launch("attn plane sums")) return rc;
     }
     LAUNCH_T(a->dtype, attn_fwd_kernel, grid_for((long long)to.n * to.h * to.w), ta, tb, to, csum, m);
@@ -409,13 +428,15 @@ extern "C" int mmif_fuse_attn_bwd(const mmif_tensor* a, const mmif_tensor* b, co
     float* csum = (float*)workspace;
     float* gsum = csum + (size_t)a->n * a->cb * 8 * 2;
     if (m & 2) {
-        if (a->dtype == MMIF_F32) {
-            hipLaunchKernelGGL((plane_sums_kernel<float, 0>), dim3(ta.n * ta.cb), dim3(256), 0, st, ta, tb, ta, csum);
-            hipLaunchKernelGGL((plane_sums_kernel<float, 1>), dim3(ta.n * ta.cb), dim3(256), 0, st, ta, tb, tg, gsum);
-        } else {
-            hipLaunchKernelGGL((plane_sums_kernel<bf16_t, 0>), dim3(ta.n * ta.cb), dim3(256), 0, st, ta, tb, ta, csum);
-            hipLaunchKernelGGL((plane_sums_kernel<bf16_t, 1>), dim3(ta.n * ta.cb), dim3(256), 0, st, ta, tb, tg, gsum);
-        }
+        const int cnt = a->n * a->cb * 8;
+        float* part = csum + (size_t)cnt * 3;
+        const dim3 grid(ta.n * ta.cb, PS_SLICES);
+        if (a->dtype == MMIF_F32) hipLaunchKernelGGL((plane_sums_kernel<float, 0>), grid, dim3(256), 0, st, ta, tb, ta, part);
+        else hipLaunchKernelGGL((plane_sums_kernel<bf16_t, 0>), grid, dim3(256), 0, st, ta, tb, ta, part);
+        hipLaunchKernelGGL(plane_sums_finish, dim3((cnt * 2 + 255) / 256), dim3(256), 0, st, part, csum, cnt * 2);
+        if (a->dtype == MMIF_F32) hipLaunchKernelGGL((plane_sums_kernel<float, 1>), grid, dim3(256), 0, st, ta, tb, tg, part);
+        else hipLaunchKernelGGL((plane_sums_kernel<bf16_t, 1>), grid, dim3(256), 0, st, ta, tb, tg, part);
+        hipLaunchKernelGGL(plane_sums_finish, dim3((cnt + 255) / 256), dim3(256), 0, st, part, gsum, cnt);
         if (int rc = check_launch("attn plane sums (bwd)")) return rc;
     }
     LAUNCH_T(a->dtype, attn_bwd_kernel, grid_for((long long)ta.n * ta.h * ta.w), ta, tb, tg, tga, tgb, csum, gsum, m, accumulate);
