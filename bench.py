@@ -41,7 +41,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="image pairs per GPU")
-    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--size", type=int, default=256, help="image height (and width unless --width)")
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--mode", default="train", choices=["train", "infer"],
+                    help="infer = forward only under no_grad (test.py path; BASELINE config 5: --mode infer --batch 1 --size 1024 --width 1224)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--model", default="PFNetv1", choices=["PFNetv1", "PFNetv2", "DenseFuse", "NestFuse", "RFNNest"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -102,11 +105,18 @@ def main():
     l_ssim, l_pix, l_grad = SSIMLoss('ssim', weight=1.0), PixelLoss('l1', weight=0.01), GradLoss('l1', weight=0.1).to(dev)
 
     B, S = args.batch, args.size
+    Wd = args.width or S
     gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
-    img1 = torch.rand(B, 1, S, S, generator=gen).to(dev)  # synthetic IR / visible pairs in [0,1)
-    img2 = torch.rand(B, 1, S, S, generator=gen).to(dev)
+    img1 = torch.rand(B, 1, S, Wd, generator=gen).to(dev)  # synthetic IR / visible pairs in [0,1)
+    img2 = torch.rand(B, 1, S, Wd, generator=gen).to(dev)
+
+    def infer_step():
+        with torch.no_grad():
+            return model(img1, img2).mean()
 
     def step():
+        if args.mode == "infer":
+            return infer_step()
         opt.zero_grad(set_to_none=True)
         f = model(img1, img2)
         a, b, c = l_ssim(img1, img2, f), l_pix(img1, img2, f, mode='max'), l_grad(img1, img2, f, mode='max')
@@ -147,7 +157,7 @@ def main():
             spec = [s for s in model._engine.specs if args.roofline_tag.startswith(s.name + ":")]
             if spec:
                 s = spec[0]
-                flops = 2.0 * B * S * S * s.cin * s.cout * s.k * s.k
+                flops = 2.0 * B * S * Wd * s.cin * s.cout * s.k * s.k
                 ach = flops / (ms * 1e-3)
                 roof = {"bound": "mfma", "kernel": f"conv_mfma {s.cin}->{s.cout} k{s.k} ({args.roofline_tag})",
                         "achieved": ach / 1e12, "peak": PEAK_MFMA_BF16 / 1e12 if args.dtype == "bf16" else 157.3,
@@ -156,24 +166,24 @@ def main():
                 # HBM bytes per launch of this kernel from the TCC PMC passes of the same command (separate
                 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 correction applied; profiles/r01_traffic.json)
                 tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-                if os.path.isfile(tpath) and B == 32 and S == 256 and args.dtype == "bf16":
+                if os.path.isfile(tpath) and B == 32 and S == 256 and Wd == 256 and args.dtype == "bf16" and args.mode == "train":
                     tj = json.load(open(tpath)).get(args.roofline_tag)
                     if tj:
                         roof["traffic"] = tj["hbm_bytes_per_launch"]
                         roof["algorithmic_bytes"] = tj["algorithmic_bytes_per_launch"]
         out = {
-            "metric": "image-pairs/sec at 256x256, PFNet train step", "value": value, "unit": "image-pairs/s",
+            "metric": "image-pairs/sec at 256x256, PFNet train step" if args.mode == "train" else f"image-pairs/sec at {Wd}x{S}, {args.model} inference", "value": value, "unit": "image-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"{args.model} train step (fwd + SSIM/pixel/grad losses + bwd + clip + Adam), {S}x{S} synthetic IR/visible pairs, "
+            "config": {"workload": (f"{args.model} train step (fwd + SSIM/pixel/grad losses + bwd + clip + Adam)" if args.mode == "train" else f"{args.model} forward (no_grad, test.py path)") + f", {Wd}x{S} synthetic IR/visible pairs, "
                                    f"batch {B} per GPU, {args.dtype} feature maps / fp32 accumulate, random-init weights (seed 0)",
                        "global_batch": B * world, "parallelism": f"dp{world}" if world > 1 else "single",
-                       "step_model_tflops": MODEL_FLOPS_TRAIN.get(args.model, 0) * value / 1e12 if S == 256 else None},
+                       "step_model_tflops": MODEL_FLOPS_TRAIN.get(args.model, 0) * value / 1e12 if (S == 256 and Wd == 256 and args.mode == "train") else None},
             "final_loss": loss,
             "roofline": roof,
             "cpu_baseline": None,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.mode == "train" and Wd == S:
             out["cpu_baseline"] = cpu_baseline(args.model, S, args.cpu_sample)
         print(json.dumps(out))
     if world > 1:

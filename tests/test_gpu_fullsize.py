@@ -1,0 +1,97 @@
+"""BASELINE.json's full-size configurations, checked through size-independent properties (the CPU
+oracle cannot run them in seconds):
+
+  config 5  full-res 1224(W) x 1024(H) inference: a window of the full-res fused image must equal the
+            fused image of the (receptive-field padded) crop -- i.e. tiling / block order / XCD mapping
+            leave no trace -- and the crop itself is held to the oracle.
+  config 2/3  B=32 256x256 train step: the gradient of the batch-mean loss equals the mean of the
+            gradients of its sub-batches (linearity; "checksum of checksums" over the batch).
+  config 4  NestFuse 512x512: samples of a batch do not interact (no cross-sample coupling on the path,
+            SURVEY 8e) although channel attention pools over whole planes.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fusion_oracle as O
+from gpu_util import close, dtype_ctx, load_closed_form, tg
+
+pytestmark = pytest.mark.gpu
+
+RF = 8  # PFNetv1: 4 encoder + 4 decoder 3x3 convs -> receptive-field radius 8
+
+
+def _model(name, seed=1):
+    import core.model as M
+    return load_closed_form(getattr(M, name)(), seed).to("cuda:0")
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_fullres_inference_window_equals_crop(dtype):
+    H, W = 1024, 1224
+    g = torch.Generator().manual_seed(5)
+    i1, i2 = torch.rand(1, 1, H, W, generator=g).cuda(), torch.rand(1, 1, H, W, generator=g).cuda()
+    with dtype_ctx(dtype), torch.no_grad():
+        m = _model("PFNetv1")
+        full = m(i1, i2)
+        assert full.shape == (1, 1, H, W) and bool(torch.isfinite(full).all())
+        # interior window at an unaligned offset, the last (ragged: 1224 = 76*16 + 8) columns, and the corners
+        for (y0, x0, h, w) in [(301, 517, 64, 64), (H - 48, W - 56, 48, 56), (0, 0, 40, 40), (511, W - 40, 33, 40)]:
+            ya, xa = max(y0 - 2 * RF, 0), max(x0 - 2 * RF, 0)
+            yb, xb = min(y0 + h + 2 * RF, H), min(x0 + w + 2 * RF, W)
+            crop = m(i1[:, :, ya:yb, xa:xb].contiguous(), i2[:, :, ya:yb, xa:xb].contiguous())
+            a = full[:, :, y0:y0 + h, x0:x0 + w]
+            b = crop[:, :, y0 - ya:y0 - ya + h, x0 - xa:x0 - xa + w]
+            assert torch.equal(a, b), f"window {(y0, x0, h, w)}: max diff {float((a - b).abs().max()):.3e}"
+        # and the crop is right: oracle on a 56x72 corner crop
+        c1, c2 = i1[:, :, :56, W - 72:].contiguous(), i2[:, :, :56, W - 72:].contiguous()
+        y = m(c1, c2).cpu().numpy()
+    mo = O.MODELS["PFNetv1"]()
+    y_or = mo.forward(mo.init_params(seed=1), c1.cpu().numpy(), c2.cpu().numpy())
+    close(y, y_or, 1e-4 if dtype == "fp32" else 3e-2, "crop vs oracle")
+
+
+def _loss_grads(m, i1, i2):
+    from core.loss import GradLoss, PixelLoss, SSIMLoss
+    l1, l2, l3 = SSIMLoss('ssim', weight=1.0), PixelLoss('l1', weight=0.01), GradLoss('l1', weight=0.1).to("cuda:0")
+    for p in m.parameters():
+        p.grad = None
+    f = m(i1, i2)
+    tot = l1(i1, i2, f) + l2(i1, i2, f, mode='max') + l3(i1, i2, f, mode='max')
+    tot.backward()
+    return float(tot.detach()), {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+
+
+@pytest.mark.parametrize("name,dtype,tol", [("PFNetv1", "fp32", 1e-4), ("PFNetv1", "bf16", 2e-3), ("DenseFuse", "bf16", 2e-3)])
+def test_full_batch_gradient_is_mean_of_subbatch_gradients(name, dtype, tol):
+    """B=32 256x256 (configs 2 and 3 per GPU).  Every loss is a batch mean, so grad(B=32) = mean of the four
+    B=8 gradients.  bf16: activations are identical per sample either way; only the fp32 wgrad summation
+    order over the batch differs."""
+    B, S = 32, 256
+    g = torch.Generator().manual_seed(7)
+    i1, i2 = torch.rand(B, 1, S, S, generator=g).cuda(), torch.rand(B, 1, S, S, generator=g).cuda()
+    with dtype_ctx(dtype):
+        m = _model(name)
+        tot, full = _loss_grads(m, i1, i2)
+        acc, tots = None, []
+        for c in range(4):
+            t, gr = _loss_grads(m, i1[8 * c:8 * c + 8].contiguous(), i2[8 * c:8 * c + 8].contiguous())
+            tots.append(t)
+            acc = gr if acc is None else {k: acc[k] + v for k, v in gr.items()}
+    assert abs(tot - np.mean(tots)) <= 1e-5 * abs(tot)
+    for k in full:
+        close(full[k].cpu().numpy(), (acc[k] / 4).cpu().numpy(), tol, k)
+
+
+@pytest.mark.parametrize("name", ["NestFuse", "RFNNest"])
+def test_nest_512_samples_do_not_interact(name):
+    S = 512
+    g = torch.Generator().manual_seed(9)
+    i1, i2 = torch.rand(2, 1, S, S, generator=g).cuda(), torch.rand(2, 1, S, S, generator=g).cuda()
+    with dtype_ctx("bf16"), torch.no_grad():
+        m = _model(name)
+        both = m(i1, i2)
+        assert bool(torch.isfinite(both).all())
+        for b in range(2):
+            one = m(i1[b:b + 1].contiguous(), i2[b:b + 1].contiguous())
+            assert torch.equal(both[b:b + 1], one), f"sample {b}: max diff {float((both[b:b + 1] - one).abs().max()):.3e}"
