@@ -148,6 +148,28 @@ int mmif_fuse_attn_bwd(const mmif_tensor* a, const mmif_tensor* b, const mmif_te
                        const mmif_tensor* gb, int32_t mode, int32_t accumulate, void* workspace, size_t workspace_bytes,
                        void* stream);
 
+/* ---- PFNetv2's self-learned fusion (core/model.py:120-124,134-141): the conv stack ConvLayer(2,2) -> ConvLayer(2,2) ->
+ *      ConvLayer(2,1,act=None) applied to every channel pair (feat1[:,i], feat2[:,i]) with SHARED weights.  One "pair conv"
+ *      launch replaces the 64 per-channel nn.Conv2d calls of one layer of that Python loop: every channel c of the two
+ *      operand views a, b is an independent 2-channel image,
+ *          oa[c] = act(bias[0] + corr(reflect_pad(a[c]), w[0][0]) + corr(reflect_pad(b[c]), w[0][1]))   (ob: w[1], nout = 2)
+ *      w: fp32 [nout][2][3][3] (nn.Conv2d layout), bias fp32 [nout] or NULL.  res1/res2 (both or neither): added to oa
+ *      (the "+ feat1 + feat2" of core/model.py:141). ---- */
+int mmif_pairconv_fwd(const mmif_tensor* a, const mmif_tensor* b, const float* w, const float* bias, int32_t nout,
+                      const mmif_tensor* oa, const mmif_tensor* ob, int32_t relu, const mmif_tensor* res1,
+                      const mmif_tensor* res2, void* stream);
+/* gxa/gxb (halo-1 views): padded-domain gradient w.r.t. a, b from ga (and gb when nout = 2; already masked by the layer's
+ * own ReLU); `add` (optional, halo 0/1): gradient of a residual path, added to both; mask_bits: channel blocks multiplied
+ * by [xa > 0] / [xb > 0].  The caller folds the halo afterwards (mmif_fold_halo). */
+int mmif_pairconv_dgrad(const mmif_tensor* ga, const mmif_tensor* gb, const float* w, int32_t nout, const mmif_tensor* xa,
+                        const mmif_tensor* xb, const mmif_tensor* gxa, const mmif_tensor* gxb, uint64_t mask_bits,
+                        const mmif_tensor* add, void* stream);
+/* dw[nout][2][3][3] (=|+=), db[nout] (=|+=): summed over batch, channels and pixels (deterministic two-stage). */
+size_t mmif_pairconv_wgrad_workspace(void);
+int mmif_pairconv_wgrad(const mmif_tensor* xa, const mmif_tensor* xb, const mmif_tensor* ga, const mmif_tensor* gb,
+                        int32_t nout, float* dw, float* db, int32_t accumulate, void* workspace, size_t workspace_bytes,
+                        void* stream);
+
 /* ---- NestFuse glue: nn.MaxPool2d(2,2) (core/model.py:332-335), nn.Upsample(x2,'nearest') + ReflectionPad2d to the
  *      skip's shape (core/block.py:965-991), threshold_backward of a ReLU output ---- */
 int mmif_maxpool2x2_fwd(const mmif_tensor* x, const mmif_tensor* y, void* stream);

@@ -78,7 +78,8 @@ class PFNetv2(_FusionModel):
     '''Polarization Image Fusion with Self-Learned Fusion Strategy (reference core/model.py:114-141).
     The reference's 64-iteration per-channel Python loop over the shared `fuse` stack (192 tiny conv
     launches per forward) is one batched call on [B*64, 2, H, W] -- same weights, same result.
-    Runs layer by layer through the HIP ConvLayer (no fused engine yet).'''
+    forward() runs on mmif.engine.PFNetv2Engine (one pair-conv launch per fuse layer, csrc/pair.hip); the
+    stand-alone fusion() below keeps the block-level API on plain tensors.'''
 
     def __init__(self):
         super(PFNetv2, self).__init__()
@@ -90,6 +91,9 @@ class PFNetv2(_FusionModel):
         b, c, h, w = feat1.shape
         pairs = torch.stack((feat1, feat2), dim=2).reshape(b * c, 2, h, w)
         return self.fuse(pairs).reshape(b, c, h, w) + feat1 + feat2
+
+    def _make_engine(self):
+        return E.PFNetv2Engine(self)
 
 
 class DenseFuse(_FusionModel):

@@ -73,6 +73,7 @@ class ConvSpec:
         self.cout, self.cin, self.k = conv.weight.shape[0], conv.weight.shape[1], conv.weight.shape[2]
         self.relu = relu
         self.split = split
+        self.pair = False   # PFNetv2 fuse layer: runs on the pair-conv kernels (fp32 weights, nothing to pack)
         self.wperm = None
         self.dw_tmp = None
         self.packed = None
@@ -100,7 +101,7 @@ class ConvSpec:
             w = self.conv.weight.detach()
             self.wperm = torch.cat((w[:, self.split:], w[:, :self.split]), dim=1).contiguous()
             self.perm_version = key
-        if pack and self.cin > 1 and self.cout > 1:
+        if pack and self.cin > 1 and self.cout > 1 and not self.pair:
             w = self.conv.weight
             if self.packed is None or self.packed.fwd.device != w.device:
                 self.packed = PackedWeights(self.cout, self.cin, self.k, w.device)
@@ -200,7 +201,9 @@ class ModelEngine:
     def workspace(self, device):
         need = 0
         for s in self.specs:
-            if s.cin == 1 or s.cout == 1:
+            if s.pair:
+                need = max(need, T.pairconv_wgrad_workspace_bytes())
+            elif s.cin == 1 or s.cout == 1:
                 need = max(need, T.image_wgrad_workspace_bytes(max(s.cin, s.cout), s.k))
             else:
                 need = max(need, T.wgrad_workspace_bytes(s.cin, s.cout, s.k))
@@ -420,7 +423,7 @@ class DenseFuseEngine(ModelEngine, DenseEncoderMixin):
         else:
             self.enc_fwd(self.enc, img2, F, 8, impl)
             x = self.buf(L, "S", n, 64, h, w, dtype, dev)
-            T.fuse_elem_fwd(F.view(0, 8), F.view(8, 8), x, self.fusion_mode)
+            self.fusion_fwd(L, F, x)
         for i, s in enumerate(self.dec[:-1]):
             y = self.buf(L, f"D{i}", n, s.cout, h, w, dtype, dev)
             self.c_fwd(s, x, y, impl)
@@ -464,12 +467,62 @@ class DenseFuseEngine(ModelEngine, DenseEncoderMixin):
         # ReLU mask only on the DenseBlock's last conv output (blocks 6,7), the rest are masked by
         # their last contributor inside enc_bwd
         GF = self.buf(L, "GF", n, 128, h, w, dtype, dev, halo=1)
-        self.fusion_bwd(F, g, GF)
+        self.fusion_bwd(L, F, g, GF, ws)
         self.enc_bwd(self.enc, img1, F, GF, 0, 0, ws, impl, accumulate_w=False)
         self.enc_bwd(self.enc, img2, F, GF, 8, 8, ws, impl, accumulate_w=True)
         return grads
 
-    def fusion_bwd(self, F, g, GF):
+    def fusion_fwd(self, L, F, out):
+        T.fuse_elem_fwd(F.view(0, 8), F.view(8, 8), out, self.fusion_mode)
+
+    def fusion_bwd(self, L, F, g, GF, ws):
         # blocks 0..5: plain copy scaled by the fusion derivative; blocks 6,7: also ReLU-masked
         T.fuse_elem_bwd(F.view(0, 6), F.view(8, 6), g.view(0, 6), GF.view(0, 6), GF.view(8, 6), self.fusion_mode, False)
         T.fuse_elem_bwd(F.view(6, 2), F.view(14, 2), g.view(6, 2), GF.view(6, 2), GF.view(14, 2), self.fusion_mode, True)
+
+
+class PFNetv2Engine(DenseFuseEngine):
+    """reference core/model.py:114-141: DenseFuse's encoder / decoder around the self-learned fusion -- the shared
+    conv stack fuse = (2->2, 2->2, 2->1) applied to every channel pair (feat1[:, i], feat2[:, i]) plus feat1 + feat2.
+    Each fuse layer is ONE pair-conv launch over the blocked feature buffers (csrc/pair.hip) instead of the
+    reference's 64-iteration Python loop; the intermediates H1, H2 are 2 x 64-channel buffers [a-half | b-half]."""
+
+    def __init__(self, module):
+        super().__init__(module)
+        self.fuse = [ConvSpec(f"fuse.{i}", l.layers[0], l.act is not None) for i, l in enumerate(module.fuse)]
+        for s in self.fuse:
+            assert (s.cin, s.k) == (2, 3) and s.cout in (1, 2), "PFNetv2.fuse layers are 3x3 convs on channel pairs"
+            s.pair = True
+        self.specs = self.enc + self.fuse + self.dec
+
+    def fusion_fwd(self, L, F, out):
+        n, h, w, dtype = L.key[:4]
+        dev = F.buf.device
+        f0, f1, f2 = self.fuse
+        H1 = self.buf(L, "H1", n, 128, h, w, dtype, dev)
+        H2 = self.buf(L, "H2", n, 128, h, w, dtype, dev)
+        a, b = F.view(0, 8), F.view(8, 8)
+        T.pairconv_fwd(a, b, f0.w.detach(), f0.b.detach(), 2, H1.view(0, 8), H1.view(8, 8), f0.relu)
+        T.pairconv_fwd(H1.view(0, 8), H1.view(8, 8), f1.w.detach(), f1.b.detach(), 2, H2.view(0, 8), H2.view(8, 8), f1.relu)
+        T.pairconv_fwd(H2.view(0, 8), H2.view(8, 8), f2.w.detach(), f2.b.detach(), 1, out, None, f2.relu, a, b)
+
+    def fusion_bwd(self, L, F, g, GF, ws):
+        n, h, w, dtype = L.key[:4]
+        dev = F.buf.device
+        f0, f1, f2 = self.fuse
+        H1, H2 = L.bufs["H1"], L.bufs["H2"]
+        GH1 = self.buf(L, "GH1", n, 128, h, w, dtype, dev, halo=1)
+        GH2 = self.buf(L, "GH2", n, 128, h, w, dtype, dev, halo=1)
+        a, b = F.view(0, 8), F.view(8, 8)
+        h1a, h1b, h2a, h2b = H1.view(0, 8), H1.view(8, 8), H2.view(0, 8), H2.view(8, 8)
+        # fuse.2 (2 -> 1, no activation): g is dL/d(fused features), not masked
+        T.pairconv_wgrad(h2a, h2b, g, None, 1, f2.dw, f2.db, ws)
+        T.pairconv_dgrad(g, None, f2.w.detach(), 1, h2a, h2b, GH2.view(0, 8), GH2.view(8, 8), all_bits(8))
+        g2 = GH2.fold_halo_()
+        T.pairconv_wgrad(h1a, h1b, g2.view(0, 8), g2.view(8, 8), 2, f1.dw, f1.db, ws)
+        T.pairconv_dgrad(g2.view(0, 8), g2.view(8, 8), f1.w.detach(), 2, h1a, h1b, GH1.view(0, 8), GH1.view(8, 8), all_bits(8))
+        g1 = GH1.fold_halo_()
+        T.pairconv_wgrad(a, b, g1.view(0, 8), g1.view(8, 8), 2, f0.dw, f0.db, ws)
+        # + g: the residual "+ feat1 + feat2"; ReLU mask only where the gradient is complete (DenseBlock's last conv output)
+        T.pairconv_dgrad(g1.view(0, 8), g1.view(8, 8), f0.w.detach(), 2, a, b, GF.view(0, 8), GF.view(8, 8), bits(6, 7), add=g)
+        GF.fold_halo_()

@@ -216,3 +216,24 @@ def attn_fwd(a, b, out, mode, ws):
 
 def attn_bwd(a, b, g, ga, gb, mode, accumulate, ws):
     check(lib.mmif_fuse_attn_bwd(a.d, b.d, g.d, ga.d, gb.d, mode, int(accumulate), _ptr(ws), ws.numel() * 4, stream_ptr()), "fuse_attn_bwd")
+
+
+def _d(t):
+    return t.d if t is not None else None
+
+
+def pairconv_fwd(a, b, w, bias, nout, oa, ob, relu, res1=None, res2=None):
+    check(lib.mmif_pairconv_fwd(a.d, b.d, _ptr(w), _ptr(bias), nout, oa.d, _d(ob), int(relu), _d(res1), _d(res2), stream_ptr()), "pairconv_fwd")
+
+
+def pairconv_dgrad(ga, gb, w, nout, xa, xb, gxa, gxb, mask_bits=0, add=None):
+    check(lib.mmif_pairconv_dgrad(ga.d, _d(gb), _ptr(w), nout, _d(xa), _d(xb), gxa.d, gxb.d, mask_bits, _d(add), stream_ptr()), "pairconv_dgrad")
+
+
+def pairconv_wgrad_workspace_bytes():
+    return lib.mmif_pairconv_wgrad_workspace()
+
+
+def pairconv_wgrad(xa, xb, ga, gb, nout, dw, db, ws, accumulate=False):
+    check(lib.mmif_pairconv_wgrad(xa.d, xb.d, ga.d, _d(gb), nout, _ptr(dw), _ptr(db), int(accumulate), _ptr(ws), ws.numel() * ws.element_size(),
+                                  stream_ptr()), "pairconv_wgrad")

@@ -160,6 +160,41 @@ def test_layerwise_models_fp32_vs_golden(name, shape):
             close_digest(p.grad.cpu().numpy(), ref[f"{tag}__dp_{k}"], 5e-4, k)
 
 
+@pytest.mark.parametrize("dtype,ytol,gtol", [("fp32", 2e-4, 1e-3), ("bf16", 3e-2, 0.5)])
+def test_pfnetv2_engine_ragged_vs_oracle_and_layerwise(dtype, ytol, gtol):
+    """PFNetv2Engine (pair-conv kernels for the self-learned fusion, csrc/pair.hip) on a ragged 37x53 batch:
+    forward + every parameter gradient vs the CPU oracle, and vs the layer-by-layer path (batched
+    [B*64, 2, H, W] ConvLayers) that the block-level API model.fusion() still offers."""
+    shape = (2, 1, 37, 53)
+    om = O.MODELS["PFNetv2"]()
+    P = om.init_params(seed=2)
+    i1n, i2n, gn = O.closed_form_image(shape, 0.3), O.closed_form_image(shape, 1.7), O.closed_form_signed(shape, 0.9, 1.0)
+    y_or = om.forward(P, i1n, i2n)
+    G_or = om.backward(P, gn)
+    with dtype_ctx(dtype):
+        m = _model("PFNetv2", 2)
+        from mmif.engine import PFNetv2Engine
+        assert isinstance(m._make_engine(), PFNetv2Engine)
+        y = m(tg(i1n), tg(i2n))
+        y.backward(tg(gn))
+        torch.cuda.synchronize()
+        close(y.detach().cpu().numpy(), y_or, ytol, "imgf")
+        g_eng = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+        for k, g in g_eng.items():
+            close(g.cpu().numpy(), G_or[k], gtol, k)
+        if dtype == "fp32":
+            for p in m.parameters():
+                p.grad = None
+            i1, i2 = tg(i1n), tg(i2n)
+            y2 = m.decoder(m.fusion(m.encoder(i1), m.encoder(i2)))
+            y2.backward(tg(gn))
+            close(y2.detach().cpu().numpy(), y.detach().cpu().numpy(), 1e-5, "layer-wise imgf")
+            for k, p in m.named_parameters():
+                close(p.grad.cpu().numpy(), g_eng[k].cpu().numpy(), 2e-4, "layer-wise " + k)
+            with torch.no_grad():   # auto-encoder mode forward(img1) (core/model.py:43-51)
+                close(m(i1).cpu().numpy(), om.forward(P, i1n, None), 2e-4, "auto-encoder")
+
+
 def test_nestfuse_bf16_mfma_runs_close():
     """bf16 / MFMA kernels on NestFuse's odd channel counts (8, 56, 88, 120, 136, 152, 184 ...) and 1x1 convs."""
     shape = (1, 1, 32, 32)
