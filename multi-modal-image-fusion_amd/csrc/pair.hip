@@ -13,154 +13,283 @@
 
 namespace mmif {
 
-#define PAIR_GRID_STRIDE(i, total) \
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (total); i += (long long)gridDim.x * blockDim.x)
+// ---- LDS tile: 16x16 pixels of ONE channel block plus a 1-pixel ring, both operands, raw storage granules split
+// into 16-byte quads (bf16: 1 quad, fp32: 2 quads in separate planes so ds_read_b128 stays conflict free)
+constexpr int PT = 16, PTP = 18, PLN = PTP * PTP;
+template <typename T> struct Quads;
+template <> struct Quads<bf16_t> { static constexpr int NQ = 1; };
+template <> struct Quads<float> { static constexpr int NQ = 2; };
 
-static int pair_grid(long long total) {
-    long long b = (total + 255) / 256;
-    if (b > 16384) b = 16384;
-    if (b < 1) b = 1;
-    return (int)b;
+// REFLECT: activation (halo 0), reflect padding by index.  !REFLECT: gradient (halo 0, or halo 1 already folded), zero
+// outside the image.  (y0, x0) = logical coordinates of tile pixel (0, 0); LDS slot (i, j) holds logical (y0-1+i, x0-1+j).
+template <typename T, bool REFLECT>
+__device__ inline void stage_tile(const TV& t, int n, int c, int y0, int x0, uint4* __restrict__ s) {
+    constexpr int NQ = Quads<T>::NQ;
+    for (int e = threadIdx.x; e < PLN; e += 256) {
+        int y = y0 - 1 + e / PTP, x = x0 - 1 + e % PTP;
+        bool ok = true;
+        if (REFLECT) {
+            y = reflect_idx(y, t.h);
+            x = reflect_idx(x, t.w);
+        } else {
+            ok = y >= 0 && y < t.h && x >= 0 && x < t.w;
+        }
+        y = min(max(y, 0), t.h - 1);
+        x = min(max(x, 0), t.w - 1);
+        const uint4* p = reinterpret_cast<const uint4*>(t.base + t.gidx(n, c, y + t.halo, x + t.halo) * Elem<T>::gran_bytes);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const uint4 v = p[q];
+            s[q * PLN + e] = ok ? v : make_uint4(0, 0, 0, 0);
+        }
+    }
+}
+
+// granule -> 4 packed fp32 pairs (channels 2i, 2i+1): the arithmetic below is v_pk_fma_f32 (2 lanes-values per
+// instruction); these kernels are VALU-bound, not HBM-bound, once the taps come from LDS
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ inline f32x2 splat(float v) { return (f32x2){v, v}; }
+__device__ inline f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// two-phase variant for persistent kernels: fetch a tile into registers (in flight while the previous tile is being
+// consumed), then drop it into LDS
+constexpr int PSL = (PLN + 255) / 256;   // staged granules per thread (2)
+template <typename T>
+__device__ inline void fetch_tile_reflect(const TV& t, int n, int c, int y0, int x0, uint4 (&r)[PSL][Quads<T>::NQ]) {
+#pragma unroll
+    for (int i = 0; i < PSL; ++i) {
+        const int e = min((int)threadIdx.x + 256 * i, PLN - 1);
+        const int y = min(max(reflect_idx(y0 - 1 + e / PTP, t.h), 0), t.h - 1);
+        const int x = min(max(reflect_idx(x0 - 1 + e % PTP, t.w), 0), t.w - 1);
+        const uint4* p = reinterpret_cast<const uint4*>(t.base + t.gidx(n, c, y, x) * Elem<T>::gran_bytes);
+#pragma unroll
+        for (int q = 0; q < Quads<T>::NQ; ++q) r[i][q] = p[q];
+    }
+}
+template <typename T>
+__device__ inline void drop_tile(const uint4 (&r)[PSL][Quads<T>::NQ], uint4* __restrict__ s) {
+#pragma unroll
+    for (int i = 0; i < PSL; ++i) {
+        const int e = threadIdx.x + 256 * i;
+        if (e < PLN) {
+#pragma unroll
+            for (int q = 0; q < Quads<T>::NQ; ++q) s[q * PLN + e] = r[i][q];
+        }
+    }
+}
+
+template <typename T>
+__device__ inline void tile_read(const uint4* __restrict__ s, int idx, f32x2 (&v)[4]) {
+    if (Quads<T>::NQ == 1) {
+        const uint4 a = s[idx];
+        const uint32_t w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = (f32x2){__uint_as_float(w[i] << 16), __uint_as_float(w[i] & 0xffff0000u)};
+    } else {
+        const uint4 a = s[idx], b = s[PLN + idx];
+        v[0] = (f32x2){__uint_as_float(a.x), __uint_as_float(a.y)};
+        v[1] = (f32x2){__uint_as_float(a.z), __uint_as_float(a.w)};
+        v[2] = (f32x2){__uint_as_float(b.x), __uint_as_float(b.y)};
+        v[3] = (f32x2){__uint_as_float(b.z), __uint_as_float(b.w)};
+    }
+}
+template <typename T>
+__device__ inline void load_pairs(const float (&u)[8], f32x2 (&v)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (f32x2){u[2 * i], u[2 * i + 1]};
+}
+__device__ inline void unpack_pairs(const f32x2 (&v)[4], float (&u)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { u[2 * i] = v[i].x; u[2 * i + 1] = v[i].y; }
+}
+
+struct TileId { int n, c, y0, x0; };
+// 32-bit arithmetic on purpose: 64-bit divisions of the (wave-uniform) tile index cost ~900 scalar instructions per block
+__device__ inline TileId tile_of(unsigned tile, int tiles_x, int tiles_y, int cb) {
+    TileId t;
+    const unsigned tx = (unsigned)tiles_x, tyy = (unsigned)tiles_y, ucb = (unsigned)cb;
+    unsigned r = tile / tx;
+    t.x0 = (int)(tile - r * tx) * PT;
+    unsigned r2 = r / tyy;
+    t.y0 = (int)(r - r2 * tyy) * PT;
+    const unsigned r3 = r2 / ucb;
+    t.c = (int)(r2 - r3 * ucb);
+    t.n = (int)r3;
+    return t;
 }
 
 template <typename T, int NOUT>
-__global__ __launch_bounds__(256) void pairconv_fwd_kernel(TV a, TV b, const float* __restrict__ w, const float* __restrict__ bias,
-                                                            TV oa, TV ob, int relu, TV r1, TV r2, int has_res) {
-    const long long total = (long long)a.n * a.cb * a.h * a.w;
-    PAIR_GRID_STRIDE(i, total) {
-        const int x = i % a.w, y = (i / a.w) % a.h, c = (i / ((long long)a.w * a.h)) % a.cb, n = i / ((long long)a.w * a.h * a.cb);
-        float acc[NOUT][8];
+__global__ __launch_bounds__(256, 4) void pairconv_fwd_kernel(TV a, TV b, const float* __restrict__ w, const float* __restrict__ bias,
+                                                            TV oa, TV ob, int relu, TV r1, TV r2, int has_res, int tiles_x, int tiles_y) {
+    constexpr int NQ = Quads<T>::NQ;
+    __shared__ __attribute__((aligned(16))) uint4 s_a[NQ * PLN], s_b[NQ * PLN];
+    const TileId ti = tile_of(blockIdx.x, tiles_x, tiles_y, a.cb);
+    stage_tile<T, true>(a, ti.n, ti.c, ti.y0, ti.x0, s_a);
+    stage_tile<T, true>(b, ti.n, ti.c, ti.y0, ti.x0, s_b);
+    __syncthreads();
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int y = ti.y0 + ty, x = ti.x0 + tx, n = ti.n, c = ti.c;
+    if (y >= a.h || x >= a.w) return;
+    f32x2 acc[NOUT][4];
 #pragma unroll
-        for (int o = 0; o < NOUT; ++o) {
-            const float bo = bias ? bias[o] : 0.f;
+    for (int o = 0; o < NOUT; ++o) {
+        const float bo = bias ? bias[o] : 0.f;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) acc[o][k] = bo;
-        }
+        for (int k = 0; k < 4; ++k) acc[o][k] = splat(bo);
+    }
+    // a real loop over tap rows: fully unrolled, the compiler runs output 0's whole chain first and keeps all 18 unpacked
+    // granules alive for output 1 (160 VGPRs / spills)
+#pragma unroll 1
+    for (int u = 0; u < 3; ++u) {
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            float va[8], vb[8];
-            load_act_reflect<T>(a, n, c, y + t / 3 - 1, x + t % 3 - 1, va);
-            load_act_reflect<T>(b, n, c, y + t / 3 - 1, x + t % 3 - 1, vb);
+        for (int v = 0; v < 3; ++v) {
+            f32x2 va[4], vb[4];
+            const int idx = (ty + u) * PTP + tx + v;
+            tile_read<T>(s_a, idx, va);
+            tile_read<T>(s_b, idx, vb);
 #pragma unroll
             for (int o = 0; o < NOUT; ++o) {
-                const float wa = w[(o * 2 + 0) * 9 + t], wb = w[(o * 2 + 1) * 9 + t];
+                const f32x2 wa = splat(w[(o * 2 + 0) * 9 + u * 3 + v]), wb = splat(w[(o * 2 + 1) * 9 + u * 3 + v]);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) acc[o][k] = fmaf(wb, vb[k], fmaf(wa, va[k], acc[o][k]));
+                for (int k = 0; k < 4; ++k) acc[o][k] = pk_fma(wb, vb[k], pk_fma(wa, va[k], acc[o][k]));
             }
         }
+    }
+    float out[NOUT][8];
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+        unpack_pairs(acc[o], out[o]);
         if (relu) {
 #pragma unroll
-            for (int o = 0; o < NOUT; ++o)
-#pragma unroll
-                for (int k = 0; k < 8; ++k) acc[o][k] = fmaxf(acc[o][k], 0.f);
+            for (int k = 0; k < 8; ++k) out[o][k] = fmaxf(out[o][k], 0.f);
         }
-        if (has_res) {  // + feat1 + feat2 (core/model.py:141), added to output 0
-            float u[8], v[8];
-            Elem<T>::load(r1.base + r1.gidx(n, c, y, x) * Elem<T>::gran_bytes, u);
-            Elem<T>::load(r2.base + r2.gidx(n, c, y, x) * Elem<T>::gran_bytes, v);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) acc[0][k] = (acc[0][k] + u[k]) + v[k];
-        }
-        Elem<T>::store(oa.base + oa.gidx(n, c, y, x) * Elem<T>::gran_bytes, acc[0]);
-        if (NOUT == 2) Elem<T>::store(ob.base + ob.gidx(n, c, y, x) * Elem<T>::gran_bytes, acc[NOUT - 1]);
     }
+    if (has_res) {  // + feat1 + feat2 (core/model.py:141), added to output 0
+        float u[8], v[8];
+        Elem<T>::load(r1.base + r1.gidx(n, c, y, x) * Elem<T>::gran_bytes, u);
+        Elem<T>::load(r2.base + r2.gidx(n, c, y, x) * Elem<T>::gran_bytes, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) out[0][k] = (out[0][k] + u[k]) + v[k];
+    }
+    Elem<T>::store(oa.base + oa.gidx(n, c, y, x) * Elem<T>::gran_bytes, out[0]);
+    if (NOUT == 2) Elem<T>::store(ob.base + ob.gidx(n, c, y, x) * Elem<T>::gran_bytes, out[NOUT - 1]);
 }
 
 // gxa/gxb (halo 1): padded-domain gradient w.r.t. the operands A, B:
 //   gx_c[p] = sum_o sum_tap w[o][c][tap] * g_o[p - tap + 1]   (g zero outside the image), p in [-1, h] x [-1, w]
 //   (+ add[p]: the residual path's gradient, same for A and B)   then  * [x_c(R(p)) > 0] for the masked channel blocks.
+// Tiles cover the STORED domain [h+2][w+2] of gx; g must be halo 0 or already folded.
 template <typename T, int NOUT>
 __global__ __launch_bounds__(256) void pairconv_dgrad_kernel(TV ga, TV gb, const float* __restrict__ w, TV xa, TV xb, TV gxa, TV gxb,
-                                                              unsigned long long mask_bits, TV add, int has_add) {
-    const long long total = (long long)gxa.n * gxa.cb * gxa.hs * gxa.ws;
-    PAIR_GRID_STRIDE(i, total) {
-        const int xs = i % gxa.ws, ys = (i / gxa.ws) % gxa.hs, c = (i / ((long long)gxa.ws * gxa.hs)) % gxa.cb,
-                  n = i / ((long long)gxa.ws * gxa.hs * gxa.cb);
-        const int py = ys - gxa.halo, px = xs - gxa.halo;
-        float da[8], db[8];
+                                                              unsigned long long mask_bits, TV add, int has_add, int tiles_x, int tiles_y) {
+    constexpr int NQ = Quads<T>::NQ;
+    __shared__ __attribute__((aligned(16))) uint4 s_a[NQ * PLN], s_b[NOUT == 2 ? NQ * PLN : 1];
+    const TileId ti = tile_of(blockIdx.x, tiles_x, tiles_y, gxa.cb);
+    // stored (ys, xs) <-> logical p = (ys - 1, xs - 1)
+    stage_tile<T, false>(ga, ti.n, ti.c, ti.y0 - 1, ti.x0 - 1, s_a);
+    if (NOUT == 2) stage_tile<T, false>(gb, ti.n, ti.c, ti.y0 - 1, ti.x0 - 1, s_b);
+    __syncthreads();
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int ys = ti.y0 + ty, xs = ti.x0 + tx, n = ti.n, c = ti.c;
+    if (ys >= gxa.hs || xs >= gxa.ws) return;
+    const int py = ys - 1, px = xs - 1;
+    f32x2 pa[4], pb[4];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) da[k] = db[k] = 0.f;
+    for (int k = 0; k < 4; ++k) pa[k] = pb[k] = splat(0.f);
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int qy = py - (t / 3) + 1, qx = px - (t % 3) + 1;
-            float g0[8], g1[8];
-            load_grad_fold<T>(ga, n, c, qy, qx, g0);
-            if (NOUT == 2) load_grad_fold<T>(gb, n, c, qy, qx, g1);
+    for (int t = 0; t < 9; ++t) {
+        const int idx = (ty + 2 - t / 3) * PTP + tx + 2 - t % 3;   // g at p - tap + 1
+        f32x2 g0[4], g1[4];
+        tile_read<T>(s_a, idx, g0);
+        if (NOUT == 2) tile_read<T>(s_b, idx, g1);
+        const f32x2 w00 = splat(w[(0 * 2 + 0) * 9 + t]), w01 = splat(w[(0 * 2 + 1) * 9 + t]);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                da[k] = fmaf(w[(0 * 2 + 0) * 9 + t], g0[k], da[k]);
-                db[k] = fmaf(w[(0 * 2 + 1) * 9 + t], g0[k], db[k]);
-                if (NOUT == 2) {
-                    da[k] = fmaf(w[(1 * 2 + 0) * 9 + t], g1[k], da[k]);
-                    db[k] = fmaf(w[(1 * 2 + 1) * 9 + t], g1[k], db[k]);
-                }
+        for (int k = 0; k < 4; ++k) {
+            pa[k] = pk_fma(w00, g0[k], pa[k]);
+            pb[k] = pk_fma(w01, g0[k], pb[k]);
+        }
+        if (NOUT == 2) {
+            const f32x2 w10 = splat(w[(1 * 2 + 0) * 9 + t]), w11 = splat(w[(1 * 2 + 1) * 9 + t]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                pa[k] = pk_fma(w10, g1[k], pa[k]);
+                pb[k] = pk_fma(w11, g1[k], pb[k]);
             }
         }
-        if (has_add) {
-            float r[8];
-            load_grad_fold<T>(add, n, c, py, px, r);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { da[k] += r[k]; db[k] += r[k]; }
-        }
-        if ((mask_bits >> c) & 1ull) {
-            float va[8], vb[8];
-            load_act_reflect<T>(xa, n, c, py, px, va);
-            load_act_reflect<T>(xb, n, c, py, px, vb);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                da[k] = va[k] > 0.f ? da[k] : 0.f;
-                db[k] = vb[k] > 0.f ? db[k] : 0.f;
-            }
-        }
-        Elem<T>::store(gxa.base + gxa.gidx(n, c, ys, xs) * Elem<T>::gran_bytes, da);
-        Elem<T>::store(gxb.base + gxb.gidx(n, c, ys, xs) * Elem<T>::gran_bytes, db);
     }
+    float da[8], db[8];
+    unpack_pairs(pa, da);
+    unpack_pairs(pb, db);
+    if (has_add) {
+        float r[8];
+        load_grad_fold<T>(add, n, c, py, px, r);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { da[k] += r[k]; db[k] += r[k]; }
+    }
+    if ((mask_bits >> c) & 1ull) {
+        float va[8], vb[8];
+        load_act_reflect<T>(xa, n, c, py, px, va);
+        load_act_reflect<T>(xb, n, c, py, px, vb);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            da[k] = va[k] > 0.f ? da[k] : 0.f;
+            db[k] = vb[k] > 0.f ? db[k] : 0.f;
+        }
+    }
+    Elem<T>::store(gxa.base + gxa.gidx(n, c, ys, xs) * Elem<T>::gran_bytes, da);
+    Elem<T>::store(gxb.base + gxb.gidx(n, c, ys, xs) * Elem<T>::gran_bytes, db);
 }
 
 // dw[o][c][tap] = sum over (n, channel, p) of g_o[p] * reflect_pad(x_c)[p + tap - 1];  db[o] = sum g_o.
-// Persistent blocks, NOUT*19 register accumulators per thread, block reduction -> partial[block][NOUT*19].
+// Persistent blocks walking tiles, NOUT*19 register accumulators per thread, block reduction -> partial[block][NOUT*19].
 constexpr int PAIR_WG_BLOCKS = 2048;
 
 template <typename T, int NOUT>
-__global__ __launch_bounds__(256) void pairconv_wgrad_kernel(TV xa, TV xb, TV ga, TV gb, float* __restrict__ partial) {
+__global__ __launch_bounds__(256, 4) void pairconv_wgrad_kernel(TV xa, TV xb, TV ga, TV gb, float* __restrict__ partial, int tiles_x,
+                                                                 int tiles_y, unsigned ntiles) {
     constexpr int PER = NOUT * 19;
+    constexpr int NQ = Quads<T>::NQ;
+    __shared__ __attribute__((aligned(16))) uint4 s_a[NQ * PLN], s_b[NQ * PLN];
     __shared__ float red[4][PER];
-    float acc[NOUT][2][9], accb[NOUT];
+    // packed accumulators: lane-pair sums stay separate until the end (no horizontal add per tap)
+    f32x2 acc[NOUT][2][9], accb[NOUT];
 #pragma unroll
     for (int o = 0; o < NOUT; ++o) {
-        accb[o] = 0.f;
+        accb[o] = splat(0.f);
 #pragma unroll
-        for (int t = 0; t < 9; ++t) acc[o][0][t] = acc[o][1][t] = 0.f;
+        for (int t = 0; t < 9; ++t) acc[o][0][t] = acc[o][1][t] = splat(0.f);
     }
-    const long long total = (long long)xa.n * xa.cb * xa.h * xa.w;
-    PAIR_GRID_STRIDE(i, total) {
-        const int x = i % xa.w, y = (i / xa.w) % xa.h, c = (i / ((long long)xa.w * xa.h)) % xa.cb, n = i / ((long long)xa.w * xa.h * xa.cb);
-        float g[NOUT][8];
-        load_grad_fold<T>(ga, n, c, y, x, g[0]);
-        if (NOUT == 2) load_grad_fold<T>(gb, n, c, y, x, g[NOUT - 1]);
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const TileId ti = tile_of(tile, tiles_x, tiles_y, xa.cb);
+        __syncthreads();
+        stage_tile<T, true>(xa, ti.n, ti.c, ti.y0, ti.x0, s_a);
+        stage_tile<T, true>(xb, ti.n, ti.c, ti.y0, ti.x0, s_b);
+        __syncthreads();
+        const int y = ti.y0 + ty, x = ti.x0 + tx;
+        if (y >= xa.h || x >= xa.w) continue;
+        float gf[NOUT][8];
+        load_grad_fold<T>(ga, ti.n, ti.c, y, x, gf[0]);
+        if (NOUT == 2) load_grad_fold<T>(gb, ti.n, ti.c, y, x, gf[NOUT - 1]);
+        f32x2 g[NOUT][4];
 #pragma unroll
         for (int o = 0; o < NOUT; ++o) {
-            float s = 0.f;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) s += g[o][k];
-            accb[o] += s;
+            load_pairs<T>(gf[o], g[o]);
+            accb[o] += (g[o][0] + g[o][1]) + (g[o][2] + g[o][3]);
         }
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            float va[8], vb[8];
-            load_act_reflect<T>(xa, n, c, y + t / 3 - 1, x + t % 3 - 1, va);
-            load_act_reflect<T>(xb, n, c, y + t / 3 - 1, x + t % 3 - 1, vb);
+            f32x2 va[4], vb[4];
+            const int idx = (ty + t / 3) * PTP + tx + t % 3;
+            tile_read<T>(s_a, idx, va);
+            tile_read<T>(s_b, idx, vb);
 #pragma unroll
-            for (int o = 0; o < NOUT; ++o) {
-                float sa = 0.f, sb = 0.f;
+            for (int o = 0; o < NOUT; ++o)
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    sa = fmaf(g[o][k], va[k], sa);
-                    sb = fmaf(g[o][k], vb[k], sb);
+                for (int k = 0; k < 4; ++k) {
+                    acc[o][0][t] = pk_fma(g[o][k], va[k], acc[o][0][t]);
+                    acc[o][1][t] = pk_fma(g[o][k], vb[k], acc[o][1][t]);
                 }
-                acc[o][0][t] += sa;
-                acc[o][1][t] += sb;
-            }
         }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -170,12 +299,12 @@ __global__ __launch_bounds__(256) void pairconv_wgrad_kernel(TV xa, TV xb, TV ga
         for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
-                float v = acc[o][cc][t];
+                float v = acc[o][cc][t].x + acc[o][cc][t].y;
 #pragma unroll
                 for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
                 if (lane == 0) red[wave][(o * 2 + cc) * 9 + t] = v;
             }
-        float v = accb[o];
+        float v = accb[o].x + accb[o].y;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
         if (lane == 0) red[wave][NOUT * 18 + o] = v;
@@ -245,8 +374,10 @@ extern "C" int mmif_pairconv_fwd(const mmif_tensor* a, const mmif_tensor* b, con
     hipStream_t st = (hipStream_t)stream;
     TV ta = make_tv(a), tb = make_tv(b), toa = make_tv(oa), tob = make_tv(nout == 2 ? ob : oa);
     TV t1 = make_tv(has_res ? res1 : a), t2 = make_tv(has_res ? res2 : a);
-    const long long total = (long long)ta.n * ta.cb * ta.h * ta.w;
-    PAIR_LAUNCH(a->dtype, nout, pairconv_fwd_kernel, pair_grid(total), ta, tb, w, bias, toa, tob, relu, t1, t2, has_res ? 1 : 0);
+    const int tiles_x = cdiv(ta.w, PT), tiles_y = cdiv(ta.h, PT);
+    const long long ntiles = (long long)ta.n * ta.cb * tiles_x * tiles_y;
+    MMIF_REQUIRE(ntiles < (1ll << 31), "pairconv_fwd: too many tiles");
+    PAIR_LAUNCH(a->dtype, nout, pairconv_fwd_kernel, (unsigned)ntiles, ta, tb, w, bias, toa, tob, relu, t1, t2, has_res ? 1 : 0, tiles_x, tiles_y);
     return check_launch("pairconv_fwd");
 }
 
@@ -259,6 +390,8 @@ extern "C" int mmif_pairconv_dgrad(const mmif_tensor* ga, const mmif_tensor* gb,
     MMIF_REQUIRE(nout == 1 || nout == 2, "pairconv_dgrad: nout must be 1 or 2 (got %d)", nout);
     MMIF_REQUIRE(w != nullptr, "pairconv_dgrad: w is NULL");
     MMIF_REQUIRE(same_shape(ga, gxa) && same_shape(ga, gxb) && gxa->halo == 1 && gxb->halo == 1, "pairconv_dgrad: gx must be halo-1 views of g's shape");
+    MMIF_REQUIRE(ga->halo == 0 || (ga->flags & MMIF_T_FOLDED), "pairconv_dgrad: a halo-1 gradient must be folded first (mmif_fold_halo)");
+    if (nout == 2 && gb) MMIF_REQUIRE(gb->halo == 0 || (gb->flags & MMIF_T_FOLDED), "pairconv_dgrad: a halo-1 gradient must be folded first (mmif_fold_halo)");
     if (nout == 2) {
         MMIF_REQUIRE(gb != nullptr, "pairconv_dgrad: gb is NULL with nout = 2");
         if (int rc = validate_tensor(gb, "gb")) return rc;
@@ -277,9 +410,11 @@ extern "C" int mmif_pairconv_dgrad(const mmif_tensor* ga, const mmif_tensor* gb,
     hipStream_t st = (hipStream_t)stream;
     TV tga = make_tv(ga), tgb = make_tv(nout == 2 ? gb : ga), txa = make_tv(mask_bits ? xa : ga), txb = make_tv(mask_bits ? xb : ga);
     TV tgxa = make_tv(gxa), tgxb = make_tv(gxb), tadd = make_tv(add ? add : ga);
-    const long long total = (long long)tgxa.n * tgxa.cb * tgxa.hs * tgxa.ws;
-    PAIR_LAUNCH(ga->dtype, nout, pairconv_dgrad_kernel, pair_grid(total), tga, tgb, w, txa, txb, tgxa, tgxb, (unsigned long long)mask_bits, tadd,
-                add ? 1 : 0);
+    const int tiles_x = cdiv(tgxa.ws, PT), tiles_y = cdiv(tgxa.hs, PT);
+    const long long ntiles = (long long)tgxa.n * tgxa.cb * tiles_x * tiles_y;
+    MMIF_REQUIRE(ntiles < (1ll << 31), "pairconv_dgrad: too many tiles");
+    PAIR_LAUNCH(ga->dtype, nout, pairconv_dgrad_kernel, (unsigned)ntiles, tga, tgb, w, txa, txb, tgxa, tgxb, (unsigned long long)mask_bits, tadd,
+                add ? 1 : 0, tiles_x, tiles_y);
     return check_launch("pairconv_dgrad");
 }
 
@@ -304,11 +439,12 @@ extern "C" int mmif_pairconv_wgrad(const mmif_tensor* xa, const mmif_tensor* xb,
     }
     hipStream_t st = (hipStream_t)stream;
     TV txa = make_tv(xa), txb = make_tv(xb), tga = make_tv(ga), tgb = make_tv(nout == 2 ? gb : ga);
-    const long long total = (long long)txa.n * txa.cb * txa.h * txa.w;
-    int G = pair_grid(total);
-    if (G > PAIR_WG_BLOCKS) G = PAIR_WG_BLOCKS;
+    const int tiles_x = cdiv(txa.w, PT), tiles_y = cdiv(txa.h, PT);
+    const long long ntiles = (long long)txa.n * txa.cb * tiles_x * tiles_y;
+    const int G = (int)(ntiles < PAIR_WG_BLOCKS ? ntiles : PAIR_WG_BLOCKS);
     float* partial = (float*)workspace;
-    PAIR_LAUNCH(xa->dtype, nout, pairconv_wgrad_kernel, G, txa, txb, tga, tgb, partial);
+    MMIF_REQUIRE(ntiles < (1ll << 31), "pairconv_wgrad: too many tiles");
+    PAIR_LAUNCH(xa->dtype, nout, pairconv_wgrad_kernel, G, txa, txb, tga, tgb, partial, tiles_x, tiles_y, (unsigned)ntiles);
     hipLaunchKernelGGL(pairconv_wgrad_reduce, dim3(1), dim3(256), 0, st, partial, G, nout * 19, nout, dw, db, accumulate);
     return check_launch("pairconv_wgrad");
 }
