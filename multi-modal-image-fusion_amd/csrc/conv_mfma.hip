@@ -20,6 +20,7 @@
 // layout, so fragments are fetched with the gfx950 LDS transpose read ds_read_b64_tr_b16
 // (4 pixels x 16 channels per 16-lane group -> per lane 4 consecutive pixels of one channel).
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace mmif {
 
@@ -107,6 +108,88 @@ __device__ inline uint4 load_in_gradfold(const TV& t, int in_, int c, int y, int
     float v[8];
     load_grad_fold<bf16_t>(t, in_, c, y, x, v);  // fp32 fold, rounded once
     return make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+}
+
+// ------------------------------------------------------------------ shared epilogue
+// After the MFMAs lane (g, j) holds oc = 16*m + 4*g + r (r = 0..3) of pixels (row 4*wave + n, col j).
+// v_permlane16_swap pairs rows n, n+1: lanes with even g end up with all 8 channels of row n, odd g with all
+// 8 channels of row n+1, so every lane issues ONE 16-byte store per row pair (the 8-byte version was store-issue
+// bound: 16 stores ~ 10k cycles per block).  oxs / oys0: stored column / first stored row (of the lane's row pair 0).
+template <int MF, bool DGRAD>
+__device__ inline void conv_epilogue(const f32x4 (&acc)[MF][4], const TV& tout, const TV& tmask, const float* s_bias, int mb, int in_,
+                                     int oxs, int oys0, int g, int relu, unsigned long long mask_bits, unsigned long long accum_bits) {
+    if (oxs >= tout.ws) return;
+    const unsigned row_bytes = (unsigned)tout.ws * 16u;
+    const unsigned pix_off = (unsigned)(oys0 * tout.ws + oxs) * 16u;   // inside one plane
+    unsigned mpix_off = 0;
+    if (DGRAD) mpix_off = (unsigned)min(max(reflect_idx(oxs - tout.halo, tmask.w), 0), tmask.w - 1) * 16u;
+#pragma unroll
+    for (int m = 0; m < MF; ++m) {
+        const int ocb = (mb * MF + m) * 2 + (g >> 1);  // channel block inside the out view
+        const bool blk_ok = ocb < tout.cb;
+        float bv[8];
+        if (!DGRAD) {
+            const float4 b0 = *reinterpret_cast<const float4*>(&s_bias[m * 16 + (g >> 1) * 8]);
+            const float4 b1 = *reinterpret_cast<const float4*>(&s_bias[m * 16 + (g >> 1) * 8 + 4]);
+            bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+        }
+        char* oplane = tout.base + ((long long)in_ * tout.img + (long long)(tout.cb_off + min(ocb, tout.cb - 1)) * tout.plane) * 16 + pix_off;
+        const char* mplane = DGRAD ? tmask.base + ((long long)in_ * tmask.img + (long long)(tmask.cb_off + min(ocb, tmask.cb - 1)) * tmask.plane) * 16 + mpix_off : nullptr;
+        const bool do_acc = DGRAD && ((accum_bits >> ocb) & 1ull);
+        const bool do_mask = DGRAD && ((mask_bits >> ocb) & 1ull);
+        // dgrad: fetch the old gradient / the ReLU-mask activations of BOTH row pairs first (the stores below may
+        // alias them as far as the compiler can tell, which would serialise load -> store -> load)
+        uint4 oldv[2], xmv[2];
+        if (DGRAD) {
+#pragma unroll
+            for (int p2 = 0; p2 < 2; ++p2) {
+                oldv[p2] = make_uint4(0, 0, 0, 0);
+                xmv[p2] = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+                const int oys = oys0 + 2 * p2;
+                if (blk_ok && oys < tout.hs) {
+                    if (do_acc) oldv[p2] = *reinterpret_cast<const uint4*>(oplane + (2 * p2) * row_bytes);
+                    if (do_mask) {
+                        const int y = min(max(reflect_idx(oys - tout.halo, tmask.h), 0), tmask.h - 1);
+                        xmv[p2] = *reinterpret_cast<const uint4*>(mplane + (unsigned)(y * tmask.ws) * 16u);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int p2 = 0; p2 < 2; ++p2) {
+            float c[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[m][2 * p2][r]), __float_as_uint(acc[m][2 * p2 + 1][r]), false, false);
+                c[r] = __uint_as_float(sw[0]);
+                c[4 + r] = __uint_as_float(sw[1]);
+            }
+            const int oys = oys0 + 2 * p2;
+            if (!blk_ok || oys >= tout.hs) continue;
+            char* dst = oplane + (2 * p2) * row_bytes;
+            if (!DGRAD) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float t = c[i] + bv[i];
+                    c[i] = relu ? fmaxf(t, 0.f) : t;
+                }
+            } else {
+                const uint32_t ow[4] = {oldv[p2].x, oldv[p2].y, oldv[p2].z, oldv[p2].w};
+                const uint32_t xw[4] = {xmv[p2].x, xmv[p2].y, xmv[p2].z, xmv[p2].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    c[2 * i] += __uint_as_float(ow[i] << 16);          // zeros when not accumulating
+                    c[2 * i + 1] += __uint_as_float(ow[i] & 0xffff0000u);
+                    // bf16 > 0  <=>  sign bit clear and magnitude non-zero (activations are never NaN); 1.0 when unmasked
+                    const uint32_t lo = xw[i] & 0xffffu, hi = xw[i] >> 16;
+                    if (!((lo & 0x8000u) == 0 && (lo & 0x7fffu) != 0)) c[2 * i] = 0.f;
+                    if (!((hi & 0x8000u) == 0 && (hi & 0x7fffu) != 0)) c[2 * i + 1] = 0.f;
+                }
+            }
+            *reinterpret_cast<uint4*>(dst) = make_uint4(pack_bf16x2(c[0], c[1]), pack_bf16x2(c[2], c[3]), pack_bf16x2(c[4], c[5]),
+                                                         pack_bf16x2(c[6], c[7]));
+        }
+    }
 }
 
 // ------------------------------------------------------------------ forward / dgrad kernel
@@ -302,87 +385,315 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(TV tin, TV tout, TV t
         TRACE_STAMP();    // chunk: k-loop done
     }
 
-    // ---- epilogue.  After the MFMAs lane (g, j) holds oc = 16*m + 4*g + r (r = 0..3) of pixels (row 4*wave + n, col j).
-    // v_permlane16_swap pairs rows n, n+1: lanes with even g end up with all 8 channels of row n, odd g with all
-    // 8 channels of row n+1, so every lane issues ONE 16-byte store per row pair (the 8-byte version was store-issue
-    // bound: 16 stores ~ 10k cycles per block).
-    const int oxs = tile_x * MT + j;
-    if (oxs >= tout.ws) return;
-    const int oys0 = tile_y * MT + wave * 4 + (g & 1);
-    const unsigned row_bytes = (unsigned)tout.ws * 16u;
-    const unsigned pix_off = (unsigned)(oys0 * tout.ws + oxs) * 16u;   // inside one plane
-    unsigned mpix_off = 0;
-    if (DGRAD) mpix_off = (unsigned)min(max(reflect_idx(oxs - tout.halo, tmask.w), 0), tmask.w - 1) * 16u;
-#pragma unroll
-    for (int m = 0; m < MF; ++m) {
-        const int ocb = (mb * MF + m) * 2 + (g >> 1);  // channel block inside the out view
-        const bool blk_ok = ocb < tout.cb;
-        float bv[8];
-        if (!DGRAD) {
-            const float4 b0 = *reinterpret_cast<const float4*>(&s_bias[m * 16 + (g >> 1) * 8]);
-            const float4 b1 = *reinterpret_cast<const float4*>(&s_bias[m * 16 + (g >> 1) * 8 + 4]);
-            bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
-        }
-        char* oplane = tout.base + ((long long)in_ * tout.img + (long long)(tout.cb_off + min(ocb, tout.cb - 1)) * tout.plane) * 16 + pix_off;
-        const char* mplane = DGRAD ? tmask.base + ((long long)in_ * tmask.img + (long long)(tmask.cb_off + min(ocb, tmask.cb - 1)) * tmask.plane) * 16 + mpix_off : nullptr;
-        const bool do_acc = DGRAD && ((accum_bits >> ocb) & 1ull);
-        const bool do_mask = DGRAD && ((mask_bits >> ocb) & 1ull);
-        // dgrad: fetch the old gradient / the ReLU-mask activations of BOTH row pairs first (the stores below may
-        // alias them as far as the compiler can tell, which would serialise load -> store -> load)
-        uint4 oldv[2], xmv[2];
-        if (DGRAD) {
-#pragma unroll
-            for (int p2 = 0; p2 < 2; ++p2) {
-                oldv[p2] = make_uint4(0, 0, 0, 0);
-                xmv[p2] = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
-                const int oys = oys0 + 2 * p2;
-                if (blk_ok && oys < tout.hs) {
-                    if (do_acc) oldv[p2] = *reinterpret_cast<const uint4*>(oplane + (2 * p2) * row_bytes);
-                    if (do_mask) {
-                        const int y = min(max(reflect_idx(oys - tout.halo, tmask.h), 0), tmask.h - 1);
-                        xmv[p2] = *reinterpret_cast<const uint4*>(mplane + (unsigned)(y * tmask.ws) * 16u);
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int p2 = 0; p2 < 2; ++p2) {
-            float c[8];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[m][2 * p2][r]), __float_as_uint(acc[m][2 * p2 + 1][r]), false, false);
-                c[r] = __uint_as_float(sw[0]);
-                c[4 + r] = __uint_as_float(sw[1]);
-            }
-            const int oys = oys0 + 2 * p2;
-            if (!blk_ok || oys >= tout.hs) continue;
-            char* dst = oplane + (2 * p2) * row_bytes;
-            if (!DGRAD) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const float t = c[i] + bv[i];
-                    c[i] = relu ? fmaxf(t, 0.f) : t;
-                }
-            } else {
-                const uint32_t ow[4] = {oldv[p2].x, oldv[p2].y, oldv[p2].z, oldv[p2].w};
-                const uint32_t xw[4] = {xmv[p2].x, xmv[p2].y, xmv[p2].z, xmv[p2].w};
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    c[2 * i] += __uint_as_float(ow[i] << 16);          // zeros when not accumulating
-                    c[2 * i + 1] += __uint_as_float(ow[i] & 0xffff0000u);
-                    // bf16 > 0  <=>  sign bit clear and magnitude non-zero (activations are never NaN); 1.0 when unmasked
-                    const uint32_t lo = xw[i] & 0xffffu, hi = xw[i] >> 16;
-                    if (!((lo & 0x8000u) == 0 && (lo & 0x7fffu) != 0)) c[2 * i] = 0.f;
-                    if (!((hi & 0x8000u) == 0 && (hi & 0x7fffu) != 0)) c[2 * i + 1] = 0.f;
-                }
-            }
-            *reinterpret_cast<uint4*>(dst) = make_uint4(pack_bf16x2(c[0], c[1]), pack_bf16x2(c[2], c[3]), pack_bf16x2(c[4], c[5]),
-                                                         pack_bf16x2(c[6], c[7]));
-        }
-    }
+    conv_epilogue<MF, DGRAD>(acc, tout, tmask, s_bias, mb, in_, tile_x * MT + j, tile_y * MT + wave * 4 + (g & 1), g, relu, mask_bits,
+                             accum_bits);
     TRACE_STAMP();        // epilogue stores issued
     if (tr != nullptr) tr[63] = tr_n;
 #undef TRACE_STAMP
+}
+
+// ------------------------------------------------------------------ DMA-staged forward / dgrad kernel (3x3, 64-channel M-blocks)
+// Same implicit GEMM, restructured around the two things the phase trace of the kernel above showed:
+//   * staging through registers costs a vector-memory issue + an LDS-store phase per chunk and 60 VGPRs, and the packed
+//     weight slab (64% of the staged bytes) is re-staged for every 256 pixels;
+//   * two barriers per chunk, with the LDS tiles single-buffered.
+// Here a block is 8 waves on a 32x16-pixel tile (the weight slab serves 512 pixels), operands go global -> LDS directly
+// (global_load_lds_dwordx4: lane l of a wave writes base + 16*l, tests/test_gpu_probe.py), the LDS tiles are double
+// buffered (2 x 75 KB, one block per CU) and there is ONE barrier per chunk: the DMAs of chunk q+1 are issued right after
+// the barrier that opens chunk q and have the whole k-loop to land.  Blocks are persistent: each walks its list of
+// (tile, M-block) items (XCD-contiguous bands, as above), so the first chunk of the next tile is in flight during the last
+// chunk of the current one, and a tile's epilogue (stores) runs after the NEXT chunk's DMAs are issued.
+// Requires the input gradient of a dgrad to be a FOLDED halo-1 tensor (mmif_fold_halo): its zeroed halo ring is the zero fill.
+constexpr int DT_ROWS = 32;                          // output tile rows (8 waves x 4)
+constexpr int DTP_Y = DT_ROWS + 2, DTP_X = MT + 2;   // 34 x 18 input tile
+constexpr int DPL = 624;                             // granules per LDS plane (612 used); 9984 B = 0 mod 256
+constexpr int DIN_PIECES = CHUNK_CB * DPL / 64;      // 39 DMA pieces (64 granules = 1 KiB each)
+constexpr int DW_PIECES = 36;                        // one k-group plane of the 64-row M-block per piece
+constexpr int D_PIECES = DIN_PIECES + DW_PIECES;
+constexpr int D_ITERS = (D_PIECES + 7) / 8;          // pieces per wave
+constexpr int D_IN_ITERS = (DIN_PIECES + 7) / 8;     // 5
+constexpr int DBUF_BYTES = CHUNK_CB * DPL * 16 + DW_PIECES * 64 * 16;   // 76800
+static_assert(CHUNK_CB * DPL % 64 == 0, "input planes must be whole DMA pieces");
+
+#define MMIF_GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define MMIF_LPTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+struct DItem { int mb, in_, tile_y, tile_x; };
+
+template <bool DGRAD, int ABL = 0>
+__global__ __launch_bounds__(512, 2) void conv_dma_kernel(TV tin, TV tout, TV tmask, const uint4* __restrict__ wpk,
+                                                           const float* __restrict__ bias, int n_out, int m16p, int relu,
+                                                           unsigned long long mask_bits, unsigned long long accum_bits,
+                                                           int tiles_x, int tiles_y, int nmb, long long* __restrict__ trace, int abl) {
+    constexpr int MF = 4;
+    int tr_n = 0;
+    // diagnostics (tools/trace_dma.py): lane 0 of every wave of the first 128 blocks stamps s_memtime per phase
+    long long* tr = (trace != nullptr && blockIdx.x < 128 && (threadIdx.x & 63) == 0) ? trace + ((long long)blockIdx.x * 8 + (threadIdx.x >> 6)) * 64 : nullptr;
+#define DTRACE() do { if (tr != nullptr && tr_n < 62) tr[tr_n++] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+    DTRACE();
+    __shared__ __attribute__((aligned(16))) char s_buf[2 * DBUF_BYTES];
+    __shared__ int2 s_tab[2][DW_PIECES];
+    __shared__ __attribute__((aligned(16))) float s_bias[3][MF * 16];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: piece indices, LDS bases and M0 stay in SGPRs
+    const int j = lane & 15, g = lane >> 4;
+    const int tpi = tiles_x * tiles_y;
+    const int nitems = tpi * tout.n * nmb;
+    // this block's items: first + i * stride, i < count (XCD x = blockIdx % 8 owns a contiguous band of items)
+    int first, stride, count;
+    {
+        const int G = gridDim.x, b = blockIdx.x;
+        if ((G & 7) == 0) {
+            const int xcd = b & 7, slot = b >> 3, nsl = G >> 3;
+            const int q8 = nitems >> 3, r8 = nitems & 7;
+            const int band0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+            const int blen = q8 + (xcd < r8 ? 1 : 0);
+            first = band0 + slot;
+            stride = nsl;
+            count = blen > slot ? (blen - slot + nsl - 1) / nsl : 0;
+        } else {
+            first = b;
+            stride = G;
+            count = b < nitems ? (nitems - b + G - 1) / G : 0;
+        }
+    }
+    if (count == 0) return;
+    auto decode = [&](int lin) {
+        DItem it;
+        it.mb = lin % nmb;
+        const int tl = lin / nmb;
+        it.in_ = tl / tpi;
+        const int trem = tl - it.in_ * tpi;
+        it.tile_y = trem / tiles_x;
+        it.tile_x = trem - it.tile_y * tiles_x;
+        return it;
+    };
+
+    const int ncb_tot = tin.cb;
+    const int nch = (ncb_tot + CHUNK_CB - 1) / CHUNK_CB;
+    const int ncb_last = ncb_tot - (nch - 1) * CHUNK_CB;
+    // k-group tables: [0] full chunk (4 channel blocks), [1] the ragged last chunk; .x = byte offset into the input tile,
+    // .y = byte offset into the weight slab
+    if (tid < 2 * DW_PIECES) {
+        const int which = tid / DW_PIECES, kg = tid % DW_PIECES;
+        const int ncb = which ? ncb_last : CHUNK_CB;
+        int tap = 0, cb = 0;
+        if (kg < 9 * ncb) { tap = kg / ncb; cb = kg % ncb; }
+        s_tab[which][kg] = make_int2((cb * DPL + (tap / 3) * DTP_X + (tap % 3)) * 16, kg * MF * 256);
+    }
+
+    // ---- DMA descriptors of the item being staged: per input piece of this wave a 32-bit byte offset from the chunk's
+    // first plane, its chunk-local channel block and a validity bit
+    unsigned d_off[D_IN_ITERS];
+    unsigned d_cb = 0;   // chunk-local channel block of each piece, 2 bits per piece
+    unsigned d_geo[D_IN_ITERS];    // item independent: tile row << 8 | tile col of the granule this lane stages
+#pragma unroll
+    for (int i = 0; i < D_IN_ITERS; ++i) {
+        const int slot = (wave + 8 * i) * 64 + lane;
+        const int cb = min(slot / DPL, CHUNK_CB - 1);
+        const int p = min(slot - cb * DPL, DTP_Y * DTP_X - 1);
+        d_geo[i] = (unsigned)((p / DTP_X) << 8 | (p % DTP_X));
+        d_cb |= (unsigned)cb << (2 * i);
+    }
+    // Source of every staged granule is a plain address (no zero-select on the issue path):
+    //   fwd   reflect padding by index;
+    //   dgrad out-of-image taps read the gradient's halo ring, which a FOLDED halo-1 tensor keeps at zero (mmif_fold_halo;
+    //         include/mmif.h MMIF_T_FOLDED) -- stored coordinates are clamped into [0, hs) x [0, ws);
+    //   channel blocks past the end of a ragged last chunk re-read the last valid plane (their packed weights are zero).
+    auto make_desc = [&](const DItem& itm) {
+        const int iy0 = itm.tile_y * DT_ROWS - tout.halo - 1, ix0 = itm.tile_x * MT - tout.halo - 1;
+#pragma unroll
+        for (int i = 0; i < D_IN_ITERS; ++i) {
+            int y = iy0 + (int)(d_geo[i] >> 8), x = ix0 + (int)(d_geo[i] & 255u);
+            if (!DGRAD) {
+                y = min(max(reflect_idx(y, tin.h), 0), tin.h - 1);
+                x = min(max(reflect_idx(x, tin.w), 0), tin.w - 1);
+            } else {
+                y = min(max(y + 1, 0), tin.hs - 1);
+                x = min(max(x + 1, 0), tin.ws - 1);
+            }
+            d_off[i] = (unsigned)(y * tin.ws + x) * 16u;
+        }
+    };
+    const unsigned plane_bytes = (unsigned)(tin.plane * 16);
+    // staging state of the chunk whose DMAs are being issued (set by begin_dma, consumed piece by piece)
+    int dn_ncb = 0, dn_nkgp = 0;
+    char *dn_in = nullptr, *dn_w = nullptr;
+    const char *dn_src_in = nullptr, *dn_src_w = nullptr;
+    auto begin_dma = [&](const DItem& itm, int c, int buf) {
+        dn_ncb = min(CHUNK_CB, ncb_tot - c * CHUNK_CB);
+        dn_nkgp = (9 * dn_ncb + 3) / 4 * 4;
+        dn_in = s_buf + buf * DBUF_BYTES;
+        dn_w = dn_in + CHUNK_CB * DPL * 16;
+        dn_src_in = tin.base + ((long long)itm.in_ * tin.img + (long long)(tin.cb_off + c * CHUNK_CB) * tin.plane) * 16;
+        dn_src_w = reinterpret_cast<const char*>(wpk) + ((long long)c * DW_PIECES * m16p + itm.mb * MF * 16 + lane) * 16;
+    };
+    auto issue_piece = [&](int i) {   // i: compile-time after unrolling; piece P = wave + 8 i is wave-uniform (scalar)
+        const int P = wave + 8 * i;
+        if (i < D_IN_ITERS && P < DIN_PIECES) {
+            const unsigned cbc = min((d_cb >> (2 * (i < D_IN_ITERS ? i : 0))) & 3u, (unsigned)(dn_ncb - 1));
+            const unsigned off = d_off[i < D_IN_ITERS ? i : 0] + cbc * plane_bytes;
+            __builtin_amdgcn_global_load_lds(MMIF_GPTR(dn_src_in + off), MMIF_LPTR(dn_in + P * 1024), 16, 0, 0);
+        } else if (P >= DIN_PIECES && P < D_PIECES) {
+            const int kg = P - DIN_PIECES;
+            if (kg < dn_nkgp)
+                __builtin_amdgcn_global_load_lds(MMIF_GPTR(dn_src_w + (long long)kg * m16p * 16), MMIF_LPTR(dn_w + kg * 1024), 16, 0, 0);
+        }
+    };
+    auto issue_dma = [&](const DItem& itm, int c, int buf) {
+        begin_dma(itm, c, buf);
+#pragma unroll
+        for (int i = 0; i < D_ITERS; ++i) issue_piece(i);
+    };
+    auto load_bias = [&](const DItem& itm, int slot) {
+        if (!DGRAD && tid < MF * 16) {
+            const int oc = itm.mb * MF * 16 + tid;
+            s_bias[slot][tid] = (bias != nullptr && oc < n_out) ? bias[oc] : 0.f;
+        }
+    };
+
+    f32x4 acc[MF][4];
+    DItem cur = decode(first), nxt = cur, pend = cur;
+    bool have_pend = false, dma_pending = false, skip_wait = false;
+    int pend_slot = 0;
+    make_desc(cur);
+    load_bias(cur, 0);
+    issue_dma(cur, 0, 0);
+    int c = 0, item_i = 0;
+    const int total_q = count * nch;
+    for (int q = 0; q < total_q; ++q) {
+        const int buf = q & 1;
+        DTRACE();   // chunk top
+        if (!skip_wait) __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's pieces of chunk q have landed
+        skip_wait = false;
+        DTRACE();   // own DMAs landed
+        __builtin_amdgcn_s_barrier();         // ... everyone's have, and nobody still reads the other buffer
+        DTRACE();   // barrier passed
+        if (q + 1 < total_q) {
+            int cn = c + 1;
+            if (cn == nch) {
+                cn = 0;
+                nxt = decode(first + (item_i + 1) * stride);
+                make_desc(nxt);
+                load_bias(nxt, (item_i + 1) % 3);
+            }
+            begin_dma(cn == 0 ? nxt : cur, cn, buf ^ 1);
+            dma_pending = !(abl & 1);   // (ablation 1: timing without any staging traffic; results are garbage)
+        }
+        const int ncb = min(CHUNK_CB, ncb_tot - c * CHUNK_CB);
+        if (dma_pending && ncb != CHUNK_CB) {   // ragged chunk: generic k-loop below, stage the next chunk up front
+#pragma unroll
+            for (int i = 0; i < D_ITERS; ++i) issue_piece(i);
+            dma_pending = false;
+        }
+        DTRACE();   // next chunk's DMAs issued (ragged chunks only; else they ride inside the k-loop)
+        if (have_pend) {   // previous tile's outputs: the stores overlap this chunk's MFMAs
+            conv_epilogue<MF, DGRAD>(acc, tout, tmask, s_bias[pend_slot], pend.mb, pend.in_, pend.tile_x * MT + j,
+                                     pend.tile_y * DT_ROWS + wave * 4 + (g & 1), g, relu, mask_bits, accum_bits);
+            have_pend = false;
+        }
+        DTRACE();   // pending epilogue done
+        if (c == 0) {
+#pragma unroll
+            for (int m = 0; m < MF; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        const char* in_lane = s_buf + buf * DBUF_BYTES + ((wave * 4) * DTP_X + j) * 16;
+        const char* w_lane = s_buf + buf * DBUF_BYTES + CHUNK_CB * DPL * 16 + j * 16;
+        if (ncb == CHUNK_CB) {
+            // ---- full chunk: k-step s = tap s over channel blocks g = 0..3; fully unrolled (immediate LDS offsets), one
+            // DMA piece of the next chunk issued per k-step so the vector-memory path never sees a burst
+            const char* in_g = in_lane + g * (DPL * 16);
+            const char* w_g = w_lane + g * (MF * 256);
+            // operands of k-step s+1 are fetched while the MFMAs of k-step s run (explicit double buffer, order pinned with
+            // sched_group_barrier: the 8 LDS reads ride on the first 8 MFMAs) -- left to itself the scheduler reads and consumes inside one
+            // k-step and every s_waitcnt exposes the LDS latency to a wave pair that has nothing else to issue
+            bf16x8 a[2][MF], b[2][4];
+            auto fetch = [&](int s2, int slot) {   // in the order the MFMAs consume them: a0, b0..b3, a1..a3
+                a[slot][0] = *reinterpret_cast<const bf16x8*>(w_g + s2 * 4 * MF * 256);
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    b[slot][n] = *reinterpret_cast<const bf16x8*>(in_g + ((s2 / 3) * DTP_X + (s2 % 3)) * 16 + n * DTP_X * 16);
+#pragma unroll
+                for (int m = 1; m < MF; ++m) a[slot][m] = *reinterpret_cast<const bf16x8*>(w_g + s2 * 4 * MF * 256 + m * 256);
+            };
+            fetch(0, 0);
+#pragma unroll
+            for (int s2 = 0; s2 < 9; ++s2) {
+                if (dma_pending && s2 < 5) {   // 2 pieces per k-step, all issued by step 4: steps 5..8 cover their landing
+                    issue_piece(2 * s2);
+                    issue_piece(2 * s2 + 1);
+                }
+                if (s2 + 1 < 9 && !(ABL & 2)) fetch(s2 + 1, (s2 + 1) & 1);
+#pragma unroll
+                for (int m = 0; m < MF; ++m)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[(ABL & 2) ? 0 : (s2 & 1)][m], b[(ABL & 2) ? 0 : (s2 & 1)][n], acc[m][n], 0, 0, 0);
+                if (s2 + 1 < 9) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);       // the other 8 MFMAs cover the last reads' latency
+                }
+            }
+            dma_pending = false;
+        } else {
+            const int nkgp = (9 * ncb + 3) / 4 * 4, nsteps = nkgp >> 2;
+            const int2* tab = s_tab[1];
+            int2 off = tab[g];
+            int2 nx = tab[min(4, nkgp - 4) + g];
+            bf16x8 b[4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) b[n] = *reinterpret_cast<const bf16x8*>(in_lane + off.x + n * DTP_X * 16);
+            for (int s2 = 0; s2 < nsteps; ++s2) {
+                const int2 nx2 = tab[min(4 * (s2 + 2), nkgp - 4) + g];
+                bf16x8 a[MF], bn[4];
+#pragma unroll
+                for (int m = 0; m < MF; ++m) a[m] = *reinterpret_cast<const bf16x8*>(w_lane + off.y + m * 256);
+#pragma unroll
+                for (int n = 0; n < 4; ++n) bn[n] = *reinterpret_cast<const bf16x8*>(in_lane + nx.x + n * DTP_X * 16);
+#pragma unroll
+                for (int m = 0; m < MF; ++m)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], b[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+                for (int n = 0; n < 4; ++n) b[n] = bn[n];
+                off = nx;
+                nx = nx2;
+            }
+        }
+        if (++c == nch) {
+            c = 0;
+            // Waves 0..3 are the older wave of their SIMD and win the MFMA arbitration: they leave the k-loop first, so they
+            // store their outputs now, under the partner's remaining MFMAs; waves 4..7 store after the next barrier, under
+            // the partner's next k-loop.  (All eight storing at the same point left the MFMA pipe idle for the whole epilogue.)
+            if (wave < 4) {
+                // the next chunk's pieces were issued in k-steps 0..4: waiting for them HERE (instead of at the chunk top)
+                // keeps the stores below out of that wait -- they get the whole next chunk to drain
+                __builtin_amdgcn_s_waitcnt(0x0f70);
+                skip_wait = true;
+                conv_epilogue<MF, DGRAD>(acc, tout, tmask, s_bias[item_i % 3], cur.mb, cur.in_, cur.tile_x * MT + j,
+                                         cur.tile_y * DT_ROWS + wave * 4 + (g & 1), g, relu, mask_bits, accum_bits);
+            } else {
+                pend = cur;
+                pend_slot = item_i % 3;
+                have_pend = true;
+            }
+            cur = nxt;
+            ++item_i;
+        }
+    }
+    DTRACE();
+    if (tr != nullptr) tr[63] = tr_n;
+#undef DTRACE
+    if (have_pend)
+        conv_epilogue<MF, DGRAD>(acc, tout, tmask, s_bias[pend_slot], pend.mb, pend.in_, pend.tile_x * MT + j,
+                                 pend.tile_y * DT_ROWS + wave * 4 + (g & 1), g, relu, mask_bits, accum_bits);
 }
 
 // ------------------------------------------------------------------ wgrad kernel (K = pixels)
@@ -622,10 +933,51 @@ static int launch_conv_mfma(bool dgrad, const TV& tin, const TV& tout, const TV&
     return check_launch(dgrad ? "conv_mfma dgrad" : "conv_mfma fwd");
 }
 
+static int g_dma_mode = -1;   // $MMIF_CONV_DMA: 1 (default) = DMA-staged kernel where it applies, 0 = never
+static int g_num_cus = 0;
+static int g_abl = 0;            // $MMIF_CONV_ABLATE (diagnostics): bit 0 = no staging DMAs after the first chunk
+
+static int launch_conv_dma(bool dgrad, const TV& tin, const TV& tout, const TV& tmask, const void* wpk, const float* bias, int n_out,
+                           int relu, uint64_t mask_bits, uint64_t accum_bits, hipStream_t st) {
+    const int tiles_x = cdiv(tout.ws, MT), tiles_y = cdiv(tout.hs, DT_ROWS);
+    const int nmb = n_mblocks(n_out);
+    const int m16p = nmb * 4 * 16;
+    const long long nitems = (long long)tiles_x * tiles_y * tout.n * nmb;
+    if (g_num_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_num_cus = prop.multiProcessorCount;
+        if (g_num_cus <= 0) g_num_cus = 256;
+    }
+    int G = g_num_cus / 8 * 8;   // one persistent block per CU (150 KB of LDS each)
+    if (G < 8) G = 8;
+    if (nitems < G) G = (int)nitems;
+    if (!dgrad && (g_abl & 2))
+        hipLaunchKernelGGL((conv_dma_kernel<false, 2>), dim3(G), dim3(512), 0, st, tin, tout, tmask, (const uint4*)wpk, bias, n_out, m16p, relu,
+                           (unsigned long long)mask_bits, (unsigned long long)accum_bits, tiles_x, tiles_y, nmb, g_trace, g_abl);
+    else if (dgrad)
+        hipLaunchKernelGGL((conv_dma_kernel<true>), dim3(G), dim3(512), 0, st, tin, tout, tmask, (const uint4*)wpk, bias, n_out, m16p, relu,
+                           (unsigned long long)mask_bits, (unsigned long long)accum_bits, tiles_x, tiles_y, nmb, g_trace, g_abl);
+    else
+        hipLaunchKernelGGL((conv_dma_kernel<false>), dim3(G), dim3(512), 0, st, tin, tout, tmask, (const uint4*)wpk, bias, n_out, m16p, relu,
+                           (unsigned long long)mask_bits, (unsigned long long)accum_bits, tiles_x, tiles_y, nmb, g_trace, g_abl);
+    return check_launch(dgrad ? "conv_dma dgrad" : "conv_dma fwd");
+}
+
 int conv_mfma(bool dgrad, int ks, const TV& tin, const TV& tout, const TV& tmask, const void* w_packed, const float* bias,
               int cin, int cout, int relu, uint64_t mask_bits, uint64_t accum_bits, hipStream_t st) {
     const int n_out = dgrad ? cin : cout;
     const int mf = pick_mf(n_out);
+    if (g_dma_mode < 0) {
+        const char* e = getenv("MMIF_CONV_DMA");
+        g_dma_mode = (e != nullptr && e[0] == '0') ? 0 : 1;
+        const char* a = getenv("MMIF_CONV_ABLATE");
+        g_abl = a != nullptr ? atoi(a) : 0;
+    }
+    // the DMA-staged kernel: 3x3, 64-row M-blocks, input gradient already folded, tensors within 32-bit plane offsets
+    if (g_dma_mode == 1 && ks == 3 && mf == 4 && (!dgrad || (tin.halo == 1 && tin.folded)) &&
+        tin.plane * 16 * CHUNK_CB < (1ll << 31))
+        return launch_conv_dma(dgrad, tin, tout, tmask, w_packed, bias, n_out, relu, mask_bits, accum_bits, st);
 #define GO(KS_, MF_) return launch_conv_mfma<KS_, MF_>(dgrad, tin, tout, tmask, w_packed, bias, n_out, relu, mask_bits, accum_bits, st)
     if (ks == 3) {
         switch (mf) { case 1: GO(3, 1); case 2: GO(3, 2); case 3: GO(3, 3); default: GO(3, 4); }

@@ -36,8 +36,29 @@ __global__ void probe_mfma_kernel(const bf16_t* __restrict__ A, const bf16_t* __
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ua), __builtin_bit_cast(bf16x8, ub), acc, 0, 0, 0);
     for (int r = 0; r < 4; ++r) out[(4 * g + r) * 16 + ij] = acc[r];
 }
+
+// LDS-DMA (global_load_lds_dwordx4): 4 waves; wave w, lane l fetches the 16-byte granule src[idx[64w + l]] straight into LDS
+// at (wave-uniform base given for wave w) + 16*l -- the ASSUMED destination mapping.  out = the LDS image, so the test sees
+// where every lane's granule landed.  The base of wave w is lds + 64*slot[w] granules (slot: any permutation of 0..3).
+__global__ void probe_dma_kernel(const uint4* __restrict__ src, const int* __restrict__ idx, const int* __restrict__ slot,
+                                 uint4* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) uint4 lds[256];
+    const int wave = threadIdx.x >> 6;
+    lds[threadIdx.x] = make_uint4(0xdeadbeefu, 0, 0, 0);
+    __syncthreads();
+    const int base = __builtin_amdgcn_readfirstlane(slot[wave]) * 64;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + idx[threadIdx.x]),
+                                     (__attribute__((address_space(3))) void*)(lds + base), 16, 0, 0);
+    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's DMA has landed
+    __syncthreads();
+    out[threadIdx.x] = lds[threadIdx.x];
+}
 }  // namespace mmif
 
+extern "C" int mmif_probe_dma(const void* src, const int* idx, const int* slot, void* out, void* stream) {
+    hipLaunchKernelGGL(mmif::probe_dma_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const uint4*)src, idx, slot, (uint4*)out);
+    return mmif::check_launch("probe_dma");
+}
 extern "C" int mmif_probe_tr16(const int* perm, short* out, void* stream) {
     hipLaunchKernelGGL(mmif::probe_tr16_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, perm, out);
     return mmif::check_launch("probe_tr16");

@@ -83,6 +83,7 @@ SIGNATURES = {
     "mmif_debug_set_trace": (None, [_vp]),
     "mmif_probe_tr16": (_i32, [_vp, _vp, _vp]),
     "mmif_probe_mfma": (_i32, [_vp, _vp, _vp, _vp]),
+    "mmif_probe_dma": (_i32, [_vp, _vp, _vp, _vp, _vp]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

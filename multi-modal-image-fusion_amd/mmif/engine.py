@@ -228,7 +228,9 @@ class ModelEngine:
     def buf(lease, name, n, c, h, w, dtype, device, halo=0):
         b = lease.bufs.get(name)
         if b is None:
-            b = BT.alloc(n, c, h, w, dtype, device, halo)
+            # gradient (halo-1) buffers start zeroed: writers either cover the whole padded domain and then fold + zero the
+            # halo (mmif_fold_halo) or touch the interior only, so 'folded => halo ring is zero' holds for every reader
+            b = BT.alloc(n, c, h, w, dtype, device, halo, zero=halo > 0)
             lease.bufs[name] = b
         return b
 

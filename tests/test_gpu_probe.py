@@ -46,3 +46,24 @@ def test_mfma_16x16x32_bf16_layout():
     got = out.cpu().numpy()
     np.save(os.path.join(_out_dir(), "probe_mfma.npy"), got)
     assert np.array_equal(got, A @ B), "v_mfma_f32_16x16x32_bf16 operand / result lane mapping differs from the assumed one"
+
+
+def test_lds_dma_lane_mapping():
+    """global_load_lds_dwordx4: lane l of a wave writes its (arbitrary) source granule to LDS at the wave-uniform
+    base + 16*l -- the destination rule the DMA-staged conv kernel relies on."""
+    from mmif._lib import check, lib
+    rng = np.random.default_rng(1)
+    src = torch.arange(4096 * 4, dtype=torch.int32, device="cuda:0").reshape(4096, 4)   # granule g = [4g, 4g+1, 4g+2, 4g+3]
+    idx_np = rng.permutation(4096)[:256].astype(np.int32)
+    slot_np = np.array([2, 0, 3, 1], dtype=np.int32)
+    idx, slot = torch.from_numpy(idx_np).cuda(), torch.from_numpy(slot_np).cuda()
+    out = torch.zeros(256, 4, dtype=torch.int32, device="cuda:0")
+    check(lib.mmif_probe_dma(C.c_void_p(src.data_ptr()), C.c_void_p(idx.data_ptr()), C.c_void_p(slot.data_ptr()),
+                             C.c_void_p(out.data_ptr()), None))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    want = np.zeros((256, 4), dtype=np.int64)
+    for w in range(4):
+        for l in range(64):
+            want[slot_np[w] * 64 + l] = 4 * idx_np[64 * w + l] + np.arange(4)
+    assert np.array_equal(got, want), f"LDS-DMA destination mapping differs:\n{got[:8]}\n{want[:8]}"
