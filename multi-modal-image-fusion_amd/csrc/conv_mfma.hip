@@ -397,7 +397,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(TV tin, TV tout, TV t
 //   * staging through registers costs a vector-memory issue + an LDS-store phase per chunk and 60 VGPRs, and the packed
 //     weight slab (64% of the staged bytes) is re-staged for every 256 pixels;
 //   * two barriers per chunk, with the LDS tiles single-buffered.
-// Here a block is 8 waves on a 32x16-pixel tile (the weight slab serves 512 pixels), operands go global -> LDS directly
+// Here a block is 8 MFMA (consumer) waves on a 32x16-pixel tile (the weight slab serves 512 pixels) plus 4 loader waves,
+// one per SIMD, that only issue the staging traffic; operands go global -> LDS directly
 // (global_load_lds_dwordx4: lane l of a wave writes base + 16*l, tests/test_gpu_probe.py), the LDS tiles are double
 // buffered (2 x 75 KB, one block per CU) and there is ONE barrier per chunk: the DMAs of chunk q+1 are issued right after
 // the barrier that opens chunk q and have the whole k-loop to land.  Blocks are persistent: each walks its list of
@@ -410,8 +411,6 @@ constexpr int DPL = 624;                             // granules per LDS plane (
 constexpr int DIN_PIECES = CHUNK_CB * DPL / 64;      // 39 DMA pieces (64 granules = 1 KiB each)
 constexpr int DW_PIECES = 36;                        // one k-group plane of the 64-row M-block per piece
 constexpr int D_PIECES = DIN_PIECES + DW_PIECES;
-constexpr int D_ITERS = (D_PIECES + 7) / 8;          // pieces per wave
-constexpr int D_IN_ITERS = (DIN_PIECES + 7) / 8;     // 5
 constexpr int DBUF_BYTES = CHUNK_CB * DPL * 16 + DW_PIECES * 64 * 16;   // 76800
 static_assert(CHUNK_CB * DPL % 64 == 0, "input planes must be whole DMA pieces");
 
@@ -420,24 +419,30 @@ static_assert(CHUNK_CB * DPL % 64 == 0, "input planes must be whole DMA pieces")
 
 struct DItem { int mb, in_, tile_y, tile_x; };
 
-template <bool DGRAD, int ABL = 0>
-__global__ __launch_bounds__(512, 2) void conv_dma_kernel(TV tin, TV tout, TV tmask, const uint4* __restrict__ wpk,
-                                                           const float* __restrict__ bias, int n_out, int m16p, int relu,
-                                                           unsigned long long mask_bits, unsigned long long accum_bits,
-                                                           int tiles_x, int tiles_y, int nmb, long long* __restrict__ trace, int abl) {
+constexpr int D_CONS = 8;                                          // consumer waves (MFMA): wave w owns tile rows 4w..4w+3
+constexpr int D_LOAD = 4;                                          // loader waves (LDS-DMA issue only), one per SIMD
+constexpr int DL_ITERS = (D_PIECES + D_LOAD - 1) / D_LOAD;         // 19 pieces per loader wave per chunk
+constexpr int DL_IN_ITERS = (DIN_PIECES + D_LOAD - 1) / D_LOAD;    // 10 of them may be input pieces
+
+template <bool DGRAD>
+__global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void conv_dma_kernel(TV tin, TV tout, TV tmask, const uint4* __restrict__ wpk,
+                                                                              const float* __restrict__ bias, int n_out, int m16p, int relu,
+                                                                              unsigned long long mask_bits, unsigned long long accum_bits,
+                                                                              int tiles_x, int tiles_y, int nmb, long long* __restrict__ trace,
+                                                                              int abl) {
     constexpr int MF = 4;
-    int tr_n = 0;
-    // diagnostics (tools/trace_dma.py): lane 0 of every wave of the first 128 blocks stamps s_memtime per phase
-    long long* tr = (trace != nullptr && blockIdx.x < 128 && (threadIdx.x & 63) == 0) ? trace + ((long long)blockIdx.x * 8 + (threadIdx.x >> 6)) * 64 : nullptr;
-#define DTRACE() do { if (tr != nullptr && tr_n < 62) tr[tr_n++] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
-    DTRACE();
     __shared__ __attribute__((aligned(16))) char s_buf[2 * DBUF_BYTES];
     __shared__ int2 s_tab[2][DW_PIECES];
     __shared__ __attribute__((aligned(16))) float s_bias[3][MF * 16];
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: piece indices, LDS bases and M0 stay in SGPRs
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: roles, piece indices, LDS bases and M0 stay in SGPRs
     const int j = lane & 15, g = lane >> 4;
+    // diagnostics (tools/trace_dma.py): lane 0 of every consumer wave of the first 128 blocks stamps s_memtime per phase
+    int tr_n = 0;
+    long long* tr = (trace != nullptr && blockIdx.x < 128 && lane == 0 && wave < D_CONS) ? trace + ((long long)blockIdx.x * 8 + wave) * 64 : nullptr;
+#define DTRACE() do { if (tr != nullptr && tr_n < 62) tr[tr_n++] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+    DTRACE();
     const int tpi = tiles_x * tiles_y;
     const int nitems = tpi * tout.n * nmb;
     // this block's items: first + i * stride, i < count (XCD x = blockIdx % 8 owns a contiguous band of items)
@@ -469,126 +474,115 @@ __global__ __launch_bounds__(512, 2) void conv_dma_kernel(TV tin, TV tout, TV tm
         it.tile_x = trem - it.tile_y * tiles_x;
         return it;
     };
-
     const int ncb_tot = tin.cb;
     const int nch = (ncb_tot + CHUNK_CB - 1) / CHUNK_CB;
     const int ncb_last = ncb_tot - (nch - 1) * CHUNK_CB;
-    // k-group tables: [0] full chunk (4 channel blocks), [1] the ragged last chunk; .x = byte offset into the input tile,
-    // .y = byte offset into the weight slab
-    if (tid < 2 * DW_PIECES) {
-        const int which = tid / DW_PIECES, kg = tid % DW_PIECES;
-        const int ncb = which ? ncb_last : CHUNK_CB;
-        int tap = 0, cb = 0;
-        if (kg < 9 * ncb) { tap = kg / ncb; cb = kg % ncb; }
-        s_tab[which][kg] = make_int2((cb * DPL + (tap / 3) * DTP_X + (tap % 3)) * 16, kg * MF * 256);
-    }
-
-    // ---- DMA descriptors of the item being staged: per input piece of this wave a 32-bit byte offset from the chunk's
-    // first plane, its chunk-local channel block and a validity bit
-    unsigned d_off[D_IN_ITERS];
-    unsigned d_cb = 0;   // chunk-local channel block of each piece, 2 bits per piece
-    unsigned d_geo[D_IN_ITERS];    // item independent: tile row << 8 | tile col of the granule this lane stages
-#pragma unroll
-    for (int i = 0; i < D_IN_ITERS; ++i) {
-        const int slot = (wave + 8 * i) * 64 + lane;
-        const int cb = min(slot / DPL, CHUNK_CB - 1);
-        const int p = min(slot - cb * DPL, DTP_Y * DTP_X - 1);
-        d_geo[i] = (unsigned)((p / DTP_X) << 8 | (p % DTP_X));
-        d_cb |= (unsigned)cb << (2 * i);
-    }
-    // Source of every staged granule is a plain address (no zero-select on the issue path):
-    //   fwd   reflect padding by index;
-    //   dgrad out-of-image taps read the gradient's halo ring, which a FOLDED halo-1 tensor keeps at zero (mmif_fold_halo;
-    //         include/mmif.h MMIF_T_FOLDED) -- stored coordinates are clamped into [0, hs) x [0, ws);
-    //   channel blocks past the end of a ragged last chunk re-read the last valid plane (their packed weights are zero).
-    auto make_desc = [&](const DItem& itm) {
-        const int iy0 = itm.tile_y * DT_ROWS - tout.halo - 1, ix0 = itm.tile_x * MT - tout.halo - 1;
-#pragma unroll
-        for (int i = 0; i < D_IN_ITERS; ++i) {
-            int y = iy0 + (int)(d_geo[i] >> 8), x = ix0 + (int)(d_geo[i] & 255u);
-            if (!DGRAD) {
-                y = min(max(reflect_idx(y, tin.h), 0), tin.h - 1);
-                x = min(max(reflect_idx(x, tin.w), 0), tin.w - 1);
-            } else {
-                y = min(max(y + 1, 0), tin.hs - 1);
-                x = min(max(x + 1, 0), tin.ws - 1);
-            }
-            d_off[i] = (unsigned)(y * tin.ws + x) * 16u;
-        }
-    };
-    const unsigned plane_bytes = (unsigned)(tin.plane * 16);
-    // staging state of the chunk whose DMAs are being issued (set by begin_dma, consumed piece by piece)
-    int dn_ncb = 0, dn_nkgp = 0;
-    char *dn_in = nullptr, *dn_w = nullptr;
-    const char *dn_src_in = nullptr, *dn_src_w = nullptr;
-    auto begin_dma = [&](const DItem& itm, int c, int buf) {
-        dn_ncb = min(CHUNK_CB, ncb_tot - c * CHUNK_CB);
-        dn_nkgp = (9 * dn_ncb + 3) / 4 * 4;
-        dn_in = s_buf + buf * DBUF_BYTES;
-        dn_w = dn_in + CHUNK_CB * DPL * 16;
-        dn_src_in = tin.base + ((long long)itm.in_ * tin.img + (long long)(tin.cb_off + c * CHUNK_CB) * tin.plane) * 16;
-        dn_src_w = reinterpret_cast<const char*>(wpk) + ((long long)c * DW_PIECES * m16p + itm.mb * MF * 16 + lane) * 16;
-    };
-    auto issue_piece = [&](int i) {   // i: compile-time after unrolling; piece P = wave + 8 i is wave-uniform (scalar)
-        const int P = wave + 8 * i;
-        if (i < D_IN_ITERS && P < DIN_PIECES) {
-            const unsigned cbc = min((d_cb >> (2 * (i < D_IN_ITERS ? i : 0))) & 3u, (unsigned)(dn_ncb - 1));
-            const unsigned off = d_off[i < D_IN_ITERS ? i : 0] + cbc * plane_bytes;
-            __builtin_amdgcn_global_load_lds(MMIF_GPTR(dn_src_in + off), MMIF_LPTR(dn_in + P * 1024), 16, 0, 0);
-        } else if (P >= DIN_PIECES && P < D_PIECES) {
-            const int kg = P - DIN_PIECES;
-            if (kg < dn_nkgp)
-                __builtin_amdgcn_global_load_lds(MMIF_GPTR(dn_src_w + (long long)kg * m16p * 16), MMIF_LPTR(dn_w + kg * 1024), 16, 0, 0);
-        }
-    };
-    auto issue_dma = [&](const DItem& itm, int c, int buf) {
-        begin_dma(itm, c, buf);
-#pragma unroll
-        for (int i = 0; i < D_ITERS; ++i) issue_piece(i);
-    };
-    auto load_bias = [&](const DItem& itm, int slot) {
-        if (!DGRAD && tid < MF * 16) {
-            const int oc = itm.mb * MF * 16 + tid;
-            s_bias[slot][tid] = (bias != nullptr && oc < n_out) ? bias[oc] : 0.f;
-        }
-    };
-
-    f32x4 acc[MF][4];
-    DItem cur = decode(first), nxt = cur, pend = cur;
-    bool have_pend = false, dma_pending = false, skip_wait = false;
-    int pend_slot = 0;
-    make_desc(cur);
-    load_bias(cur, 0);
-    issue_dma(cur, 0, 0);
-    int c = 0, item_i = 0;
     const int total_q = count * nch;
+    // k-group table of the ragged last chunk: .x = byte offset into the input tile, .y = byte offset into the weight slab
+    if (tid < DW_PIECES) {
+        const int kg = tid;
+        int tap = 0, cb = 0;
+        if (kg < 9 * ncb_last) { tap = kg / ncb_last; cb = kg % ncb_last; }
+        s_tab[1][kg] = make_int2((cb * DPL + (tap / 3) * DTP_X + (tap % 3)) * 16, kg * MF * 256);
+    }
+
+    if (wave >= D_CONS) {
+        // =============================== loader waves: stage chunk q+1 while the consumers run chunk q ===============================
+        // Source of every staged granule is a plain address (nothing is selected on the issue path):
+        //   fwd   reflect padding by index;
+        //   dgrad out-of-image taps read the gradient's halo ring, which a FOLDED halo-1 tensor keeps at zero (mmif_fold_halo;
+        //         include/mmif.h MMIF_T_FOLDED) -- stored coordinates are clamped into [0, hs) x [0, ws);
+        //   channel blocks past the end of a ragged last chunk re-read the last valid plane (their packed weights are zero).
+        const int lw = wave - D_CONS;
+        unsigned d_off[DL_IN_ITERS];     // per input piece: byte offset of this lane's pixel inside a plane (per item)
+        unsigned d_geo[DL_IN_ITERS];     // item independent: tile row << 8 | tile col
+        unsigned d_cb = 0;               // chunk-local channel block of each piece, 2 bits per piece
+#pragma unroll
+        for (int i = 0; i < DL_IN_ITERS; ++i) {
+            const int slot = (lw + D_LOAD * i) * 64 + lane;
+            const int cb = min(slot / DPL, CHUNK_CB - 1);
+            const int p = min(slot - cb * DPL, DTP_Y * DTP_X - 1);
+            d_geo[i] = (unsigned)((p / DTP_X) << 8 | (p % DTP_X));
+            d_cb |= (unsigned)cb << (2 * i);
+        }
+        auto make_desc = [&](const DItem& itm) {
+            const int iy0 = itm.tile_y * DT_ROWS - tout.halo - 1, ix0 = itm.tile_x * MT - tout.halo - 1;
+#pragma unroll
+            for (int i = 0; i < DL_IN_ITERS; ++i) {
+                int y = iy0 + (int)(d_geo[i] >> 8), x = ix0 + (int)(d_geo[i] & 255u);
+                if (!DGRAD) {
+                    y = min(max(reflect_idx(y, tin.h), 0), tin.h - 1);
+                    x = min(max(reflect_idx(x, tin.w), 0), tin.w - 1);
+                } else {
+                    y = min(max(y + 1, 0), tin.hs - 1);
+                    x = min(max(x + 1, 0), tin.ws - 1);
+                }
+                d_off[i] = (unsigned)(y * tin.ws + x) * 16u;
+            }
+        };
+        const unsigned plane_bytes = (unsigned)(tin.plane * 16);
+        auto issue_dma = [&](const DItem& itm, int c, int buf) {
+            const int ncb = min(CHUNK_CB, ncb_tot - c * CHUNK_CB);
+            const int nkgp = (9 * ncb + 3) / 4 * 4;
+            char* dst_in = s_buf + buf * DBUF_BYTES;
+            char* dst_w = dst_in + CHUNK_CB * DPL * 16;
+            const char* src_in = tin.base + ((long long)itm.in_ * tin.img + (long long)(tin.cb_off + c * CHUNK_CB) * tin.plane) * 16;
+            const char* src_w = reinterpret_cast<const char*>(wpk) + ((long long)c * DW_PIECES * m16p + itm.mb * MF * 16 + lane) * 16;
+#pragma unroll
+            for (int i = 0; i < DL_ITERS; ++i) {
+                const int P = lw + D_LOAD * i;   // wave-uniform piece index
+                if (i < DL_IN_ITERS && P < DIN_PIECES) {
+                    const unsigned cbc = min((d_cb >> (2 * (i < DL_IN_ITERS ? i : 0))) & 3u, (unsigned)(ncb - 1));
+                    const unsigned off = d_off[i < DL_IN_ITERS ? i : 0] + cbc * plane_bytes;
+                    __builtin_amdgcn_global_load_lds(MMIF_GPTR(src_in + off), MMIF_LPTR(dst_in + P * 1024), 16, 0, 0);
+                } else if (P >= DIN_PIECES && P < D_PIECES) {
+                    const int kg = P - DIN_PIECES;
+                    if (kg < nkgp)
+                        __builtin_amdgcn_global_load_lds(MMIF_GPTR(src_w + (long long)kg * m16p * 16), MMIF_LPTR(dst_w + kg * 1024), 16, 0, 0);
+                }
+            }
+        };
+        auto load_bias = [&](const DItem& itm, int slot) {
+            const int t = tid - D_CONS * 64;
+            if (!DGRAD && t < MF * 16) {
+                const int oc = itm.mb * MF * 16 + t;
+                s_bias[slot][t] = (bias != nullptr && oc < n_out) ? bias[oc] : 0.f;
+            }
+        };
+        DItem cur = decode(first);
+        make_desc(cur);
+        load_bias(cur, 0);
+        issue_dma(cur, 0, 0);
+        int c = 0, item_i = 0;
+        for (int q = 0; q < total_q; ++q) {
+            __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's pieces of chunk q have landed
+            __builtin_amdgcn_s_barrier();         // consumers: chunk q is readable; loaders: the other buffer is free
+            if (++c == nch) {
+                c = 0;
+                ++item_i;
+                if (q + 1 < total_q) {
+                    cur = decode(first + item_i * stride);
+                    make_desc(cur);
+                    load_bias(cur, item_i % 3);
+                }
+            }
+            if (q + 1 < total_q && !(abl & 1)) issue_dma(cur, c, (q & 1) ^ 1);
+        }
+        return;
+    }
+
+    // =============================== consumer waves ===============================
+    f32x4 acc[MF][4];
+    DItem cur = decode(first), pend = cur;
+    bool have_pend = false;
+    int pend_slot = 0;
+    int c = 0, item_i = 0;
     for (int q = 0; q < total_q; ++q) {
         const int buf = q & 1;
         DTRACE();   // chunk top
-        if (!skip_wait) __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's pieces of chunk q have landed
-        skip_wait = false;
-        DTRACE();   // own DMAs landed
-        __builtin_amdgcn_s_barrier();         // ... everyone's have, and nobody still reads the other buffer
+        __builtin_amdgcn_s_barrier();
         DTRACE();   // barrier passed
-        if (q + 1 < total_q) {
-            int cn = c + 1;
-            if (cn == nch) {
-                cn = 0;
-                nxt = decode(first + (item_i + 1) * stride);
-                make_desc(nxt);
-                load_bias(nxt, (item_i + 1) % 3);
-            }
-            begin_dma(cn == 0 ? nxt : cur, cn, buf ^ 1);
-            dma_pending = !(abl & 1);   // (ablation 1: timing without any staging traffic; results are garbage)
-        }
-        const int ncb = min(CHUNK_CB, ncb_tot - c * CHUNK_CB);
-        if (dma_pending && ncb != CHUNK_CB) {   // ragged chunk: generic k-loop below, stage the next chunk up front
-#pragma unroll
-            for (int i = 0; i < D_ITERS; ++i) issue_piece(i);
-            dma_pending = false;
-        }
-        DTRACE();   // next chunk's DMAs issued (ragged chunks only; else they ride inside the k-loop)
-        if (have_pend) {   // previous tile's outputs: the stores overlap this chunk's MFMAs
+        if (have_pend) {   // waves 4..7: previous tile's outputs, stored under the partner wave's MFMAs (see below)
             conv_epilogue<MF, DGRAD>(acc, tout, tmask, s_bias[pend_slot], pend.mb, pend.in_, pend.tile_x * MT + j,
                                      pend.tile_y * DT_ROWS + wave * 4 + (g & 1), g, relu, mask_bits, accum_bits);
             have_pend = false;
@@ -600,16 +594,15 @@ __global__ __launch_bounds__(512, 2) void conv_dma_kernel(TV tin, TV tout, TV tm
 #pragma unroll
                 for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
+        const int ncb = min(CHUNK_CB, ncb_tot - c * CHUNK_CB);
         const char* in_lane = s_buf + buf * DBUF_BYTES + ((wave * 4) * DTP_X + j) * 16;
         const char* w_lane = s_buf + buf * DBUF_BYTES + CHUNK_CB * DPL * 16 + j * 16;
         if (ncb == CHUNK_CB) {
-            // ---- full chunk: k-step s = tap s over channel blocks g = 0..3; fully unrolled (immediate LDS offsets), one
-            // DMA piece of the next chunk issued per k-step so the vector-memory path never sees a burst
+            // ---- full chunk: k-step s = tap s over channel blocks g = 0..3; fully unrolled (immediate LDS offsets).
+            // Operands of k-step s+1 are fetched while the MFMAs of k-step s run (explicit double buffer, order pinned with
+            // sched_group_barrier: the 8 LDS reads ride on the first 8 MFMAs, the other 8 cover the last reads' latency)
             const char* in_g = in_lane + g * (DPL * 16);
             const char* w_g = w_lane + g * (MF * 256);
-            // operands of k-step s+1 are fetched while the MFMAs of k-step s run (explicit double buffer, order pinned with
-            // sched_group_barrier: the 8 LDS reads ride on the first 8 MFMAs) -- left to itself the scheduler reads and consumes inside one
-            // k-step and every s_waitcnt exposes the LDS latency to a wave pair that has nothing else to issue
             bf16x8 a[2][MF], b[2][4];
             auto fetch = [&](int s2, int slot) {   // in the order the MFMAs consume them: a0, b0..b3, a1..a3
                 a[slot][0] = *reinterpret_cast<const bf16x8*>(w_g + s2 * 4 * MF * 256);
@@ -622,26 +615,21 @@ __global__ __launch_bounds__(512, 2) void conv_dma_kernel(TV tin, TV tout, TV tm
             fetch(0, 0);
 #pragma unroll
             for (int s2 = 0; s2 < 9; ++s2) {
-                if (dma_pending && s2 < 5) {   // 2 pieces per k-step, all issued by step 4: steps 5..8 cover their landing
-                    issue_piece(2 * s2);
-                    issue_piece(2 * s2 + 1);
-                }
-                if (s2 + 1 < 9 && !(ABL & 2)) fetch(s2 + 1, (s2 + 1) & 1);
+                if (s2 + 1 < 9) fetch(s2 + 1, (s2 + 1) & 1);
 #pragma unroll
                 for (int m = 0; m < MF; ++m)
 #pragma unroll
                     for (int n = 0; n < 4; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[(ABL & 2) ? 0 : (s2 & 1)][m], b[(ABL & 2) ? 0 : (s2 & 1)][n], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s2 & 1][m], b[s2 & 1][n], acc[m][n], 0, 0, 0);
                 if (s2 + 1 < 9) {
 #pragma unroll
                     for (int r = 0; r < 8; ++r) {
                         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
                     }
-                    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);       // the other 8 MFMAs cover the last reads' latency
+                    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
                 }
             }
-            dma_pending = false;
         } else {
             const int nkgp = (9 * ncb + 3) / 4 * 4, nsteps = nkgp >> 2;
             const int2* tab = s_tab[1];
@@ -667,16 +655,13 @@ __global__ __launch_bounds__(512, 2) void conv_dma_kernel(TV tin, TV tout, TV tm
                 nx = nx2;
             }
         }
+        DTRACE();   // k-loop done
         if (++c == nch) {
             c = 0;
-            // Waves 0..3 are the older wave of their SIMD and win the MFMA arbitration: they leave the k-loop first, so they
-            // store their outputs now, under the partner's remaining MFMAs; waves 4..7 store after the next barrier, under
-            // the partner's next k-loop.  (All eight storing at the same point left the MFMA pipe idle for the whole epilogue.)
+            // Waves 0..3 are the older wave of their SIMD and win the MFMA arbitration: they leave the k-loop first and store
+            // their outputs now, under the partner's remaining MFMAs; waves 4..7 store after the next barrier, under the
+            // partner's next k-loop.  (All eight storing at the same point leaves the MFMA pipe idle for a whole epilogue.)
             if (wave < 4) {
-                // the next chunk's pieces were issued in k-steps 0..4: waiting for them HERE (instead of at the chunk top)
-                // keeps the stores below out of that wait -- they get the whole next chunk to drain
-                __builtin_amdgcn_s_waitcnt(0x0f70);
-                skip_wait = true;
                 conv_epilogue<MF, DGRAD>(acc, tout, tmask, s_bias[item_i % 3], cur.mb, cur.in_, cur.tile_x * MT + j,
                                          cur.tile_y * DT_ROWS + wave * 4 + (g & 1), g, relu, mask_bits, accum_bits);
             } else {
@@ -684,11 +669,11 @@ __global__ __launch_bounds__(512, 2) void conv_dma_kernel(TV tin, TV tout, TV tm
                 pend_slot = item_i % 3;
                 have_pend = true;
             }
-            cur = nxt;
             ++item_i;
+            if (q + 1 < total_q) cur = decode(first + item_i * stride);
         }
+        DTRACE();   // tile epilogue (waves 0..3) done
     }
-    DTRACE();
     if (tr != nullptr) tr[63] = tr_n;
 #undef DTRACE
     if (have_pend)
@@ -952,14 +937,11 @@ static int launch_conv_dma(bool dgrad, const TV& tin, const TV& tout, const TV& 
     int G = g_num_cus / 8 * 8;   // one persistent block per CU (150 KB of LDS each)
     if (G < 8) G = 8;
     if (nitems < G) G = (int)nitems;
-    if (!dgrad && (g_abl & 2))
-        hipLaunchKernelGGL((conv_dma_kernel<false, 2>), dim3(G), dim3(512), 0, st, tin, tout, tmask, (const uint4*)wpk, bias, n_out, m16p, relu,
-                           (unsigned long long)mask_bits, (unsigned long long)accum_bits, tiles_x, tiles_y, nmb, g_trace, g_abl);
-    else if (dgrad)
-        hipLaunchKernelGGL((conv_dma_kernel<true>), dim3(G), dim3(512), 0, st, tin, tout, tmask, (const uint4*)wpk, bias, n_out, m16p, relu,
+    if (dgrad)
+        hipLaunchKernelGGL((conv_dma_kernel<true>), dim3(G), dim3((D_CONS + D_LOAD) * 64), 0, st, tin, tout, tmask, (const uint4*)wpk, bias, n_out, m16p, relu,
                            (unsigned long long)mask_bits, (unsigned long long)accum_bits, tiles_x, tiles_y, nmb, g_trace, g_abl);
     else
-        hipLaunchKernelGGL((conv_dma_kernel<false>), dim3(G), dim3(512), 0, st, tin, tout, tmask, (const uint4*)wpk, bias, n_out, m16p, relu,
+        hipLaunchKernelGGL((conv_dma_kernel<false>), dim3(G), dim3((D_CONS + D_LOAD) * 64), 0, st, tin, tout, tmask, (const uint4*)wpk, bias, n_out, m16p, relu,
                            (unsigned long long)mask_bits, (unsigned long long)accum_bits, tiles_x, tiles_y, nmb, g_trace, g_abl);
     return check_launch(dgrad ? "conv_dma dgrad" : "conv_dma fwd");
 }

@@ -19,22 +19,18 @@ tr = torch.zeros(1024, 64, dtype=torch.int64, device=dev)
 lib.mmif_debug_set_trace(C.c_void_p(tr.data_ptr()))
 T.conv_fwd(x, w, b, y, cin, cout, 3, True, pk, IMPL_MFMA)
 torch.cuda.synchronize(); lib.mmif_debug_set_trace(None)
-t = tr.cpu().numpy().reshape(128, 8, 64)
+t = tr.cpu().numpy().reshape(128, 8, 64).astype(np.float64)
 n = int(t[0, 0, 63])
-# per-wave view: when does each wave reach the end of its k-loop relative to wave 0 of its block (chunk 1..3)
-ends = t[:, :, [1 + 5 * q + 5 for q in range(1, 4)]].astype(np.float64)      # stamp "next top" of chunks 1..3
-tops = t[:, :, [1 + 5 * q + 2 for q in range(1, 4)]].astype(np.float64)      # barrier passed
-print("k-loop+epilogue span per wave (barrier passed -> next chunk top), median over blocks/chunks:")
-print("  ", np.median((ends - tops), axis=(0, 2)).round(0))
-print("arrival at the next barrier relative to the block's first arrival, median:")
-rel = ends - ends.min(axis=1, keepdims=True)
-print("  ", np.median(rel, axis=(0, 2)).round(0))
-t = t[:, 0, :]
-d = np.diff(t[:, :n], axis=1).astype(np.float64)
-names = ["prologue (desc + first DMA issue)"]
-per = ["wait own DMAs (vmcnt 0)", "barrier", "issue next DMAs", "pending epilogue", "k-loop"]
-i = 0
-while len(names) < d.shape[1]:
-    names.append(f"q{i // 5} {per[i % 5]}"); i += 1
-print(f"conv_dma {cin}->{cout} B={B} {S}x{S}: {n} stamps, median / mean cycles over 128 blocks (wave 0)")
-for i, nm in enumerate(names[:d.shape[1]]): print(f"  {nm:36s} {np.median(d[:, i]):9.0f} {d[:, i].mean():9.0f}")
+nq = (n - 1) // 5
+# stamps: [0] kernel start; chunk q: 1+5q chunk top, 2+5q barrier passed, 3+5q pending epilogue done, 4+5q k-loop done, 5+5q tile epilogue done
+names = ["wait at barrier", "pending epilogue (waves 4-7)", "k-loop", "tile epilogue (waves 0-3)", "loop overhead"]
+print(f"conv_dma {cin}->{cout} B={B} {S}x{S}: {n} stamps/wave; median cycles over 128 blocks, chunks 1..{nq - 1}; one column per consumer wave")
+for k, nm in enumerate(names):
+    lo = [1 + 5 * q + k for q in range(1, nq - 1)]
+    hi = [2 + 5 * q + k for q in range(1, nq - 1)]
+    d = t[:, :, hi] - t[:, :, lo]
+    print(f"  {nm:30s}", np.median(d, axis=(0, 2)).round(0))
+tops = t[:, :, [1 + 5 * q for q in range(1, nq)]]
+print("  chunk period (top -> top)     ", np.median(np.diff(tops, axis=2), axis=(0, 2)).round(0))
+arr = t[:, :, [1 + 5 * q for q in range(2, nq)]]
+print("  arrival at barrier vs first   ", np.median(arr - arr.min(axis=1, keepdims=True), axis=(0, 2)).round(0))
