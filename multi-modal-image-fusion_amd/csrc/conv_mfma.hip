@@ -121,8 +121,34 @@ __device__ inline void conv_epilogue(const f32x4 (&acc)[MF][4], const TV& tout, 
     if (oxs >= tout.ws) return;
     const unsigned row_bytes = (unsigned)tout.ws * 16u;
     const unsigned pix_off = (unsigned)(oys0 * tout.ws + oxs) * 16u;   // inside one plane
-    unsigned mpix_off = 0;
-    if (DGRAD) mpix_off = (unsigned)min(max(reflect_idx(oxs - tout.halo, tmask.w), 0), tmask.w - 1) * 16u;
+    // dgrad: fetch the old gradient / the ReLU-mask activations of ALL the lane's outputs first -- one memory round trip for
+    // the whole epilogue instead of one per 16-channel fragment (and the stores below may alias them as far as the compiler
+    // can tell, which would serialise load -> store -> load)
+    uint4 oldv[DGRAD ? MF : 1][2], xmv[DGRAD ? MF : 1][2];
+    if (DGRAD) {
+        const unsigned mpix_off = (unsigned)min(max(reflect_idx(oxs - tout.halo, tmask.w), 0), tmask.w - 1) * 16u;
+#pragma unroll
+        for (int m = 0; m < MF; ++m) {
+            const int ocb = (mb * MF + m) * 2 + (g >> 1);
+            const bool blk_ok = ocb < tout.cb;
+            const char* oplane = tout.base + ((long long)in_ * tout.img + (long long)(tout.cb_off + min(ocb, tout.cb - 1)) * tout.plane) * 16 + pix_off;
+            const char* mplane = tmask.base + ((long long)in_ * tmask.img + (long long)(tmask.cb_off + min(ocb, tmask.cb - 1)) * tmask.plane) * 16 + mpix_off;
+            const bool do_acc = (accum_bits >> ocb) & 1ull, do_mask = (mask_bits >> ocb) & 1ull;
+#pragma unroll
+            for (int p2 = 0; p2 < 2; ++p2) {
+                oldv[m][p2] = make_uint4(0, 0, 0, 0);
+                xmv[m][p2] = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);   // 1.0: mask passes
+                const int oys = oys0 + 2 * p2;
+                if (blk_ok && oys < tout.hs) {
+                    if (do_acc) oldv[m][p2] = *reinterpret_cast<const uint4*>(oplane + (2 * p2) * row_bytes);
+                    if (do_mask) {
+                        const int y = min(max(reflect_idx(oys - tout.halo, tmask.h), 0), tmask.h - 1);
+                        xmv[m][p2] = *reinterpret_cast<const uint4*>(mplane + (unsigned)(y * tmask.ws) * 16u);
+                    }
+                }
+            }
+        }
+    }
 #pragma unroll
     for (int m = 0; m < MF; ++m) {
         const int ocb = (mb * MF + m) * 2 + (g >> 1);  // channel block inside the out view
@@ -134,27 +160,6 @@ __device__ inline void conv_epilogue(const f32x4 (&acc)[MF][4], const TV& tout, 
             bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
         }
         char* oplane = tout.base + ((long long)in_ * tout.img + (long long)(tout.cb_off + min(ocb, tout.cb - 1)) * tout.plane) * 16 + pix_off;
-        const char* mplane = DGRAD ? tmask.base + ((long long)in_ * tmask.img + (long long)(tmask.cb_off + min(ocb, tmask.cb - 1)) * tmask.plane) * 16 + mpix_off : nullptr;
-        const bool do_acc = DGRAD && ((accum_bits >> ocb) & 1ull);
-        const bool do_mask = DGRAD && ((mask_bits >> ocb) & 1ull);
-        // dgrad: fetch the old gradient / the ReLU-mask activations of BOTH row pairs first (the stores below may
-        // alias them as far as the compiler can tell, which would serialise load -> store -> load)
-        uint4 oldv[2], xmv[2];
-        if (DGRAD) {
-#pragma unroll
-            for (int p2 = 0; p2 < 2; ++p2) {
-                oldv[p2] = make_uint4(0, 0, 0, 0);
-                xmv[p2] = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
-                const int oys = oys0 + 2 * p2;
-                if (blk_ok && oys < tout.hs) {
-                    if (do_acc) oldv[p2] = *reinterpret_cast<const uint4*>(oplane + (2 * p2) * row_bytes);
-                    if (do_mask) {
-                        const int y = min(max(reflect_idx(oys - tout.halo, tmask.h), 0), tmask.h - 1);
-                        xmv[p2] = *reinterpret_cast<const uint4*>(mplane + (unsigned)(y * tmask.ws) * 16u);
-                    }
-                }
-            }
-        }
 #pragma unroll
         for (int p2 = 0; p2 < 2; ++p2) {
             float c[8];
@@ -166,7 +171,6 @@ __device__ inline void conv_epilogue(const f32x4 (&acc)[MF][4], const TV& tout, 
             }
             const int oys = oys0 + 2 * p2;
             if (!blk_ok || oys >= tout.hs) continue;
-            char* dst = oplane + (2 * p2) * row_bytes;
             if (!DGRAD) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
@@ -174,8 +178,8 @@ __device__ inline void conv_epilogue(const f32x4 (&acc)[MF][4], const TV& tout, 
                     c[i] = relu ? fmaxf(t, 0.f) : t;
                 }
             } else {
-                const uint32_t ow[4] = {oldv[p2].x, oldv[p2].y, oldv[p2].z, oldv[p2].w};
-                const uint32_t xw[4] = {xmv[p2].x, xmv[p2].y, xmv[p2].z, xmv[p2].w};
+                const uint32_t ow[4] = {oldv[m][p2].x, oldv[m][p2].y, oldv[m][p2].z, oldv[m][p2].w};
+                const uint32_t xw[4] = {xmv[m][p2].x, xmv[m][p2].y, xmv[m][p2].z, xmv[m][p2].w};
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     c[2 * i] += __uint_as_float(ow[i] << 16);          // zeros when not accumulating
@@ -186,8 +190,8 @@ __device__ inline void conv_epilogue(const f32x4 (&acc)[MF][4], const TV& tout, 
                     if (!((hi & 0x8000u) == 0 && (hi & 0x7fffu) != 0)) c[2 * i + 1] = 0.f;
                 }
             }
-            *reinterpret_cast<uint4*>(dst) = make_uint4(pack_bf16x2(c[0], c[1]), pack_bf16x2(c[2], c[3]), pack_bf16x2(c[4], c[5]),
-                                                         pack_bf16x2(c[6], c[7]));
+            *reinterpret_cast<uint4*>(oplane + (2 * p2) * row_bytes) =
+                make_uint4(pack_bf16x2(c[0], c[1]), pack_bf16x2(c[2], c[3]), pack_bf16x2(c[4], c[5]), pack_bf16x2(c[6], c[7]));
         }
     }
 }
@@ -597,7 +601,11 @@ __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void conv_dma_kernel(TV 
         const int ncb = min(CHUNK_CB, ncb_tot - c * CHUNK_CB);
         const char* in_lane = s_buf + buf * DBUF_BYTES + ((wave * 4) * DTP_X + j) * 16;
         const char* w_lane = s_buf + buf * DBUF_BYTES + CHUNK_CB * DPL * 16 + j * 16;
-        if (ncb == CHUNK_CB) {
+        // a wave whose 4 rows lie below the output (ragged last tile row; 258 = 8*32 + 2 for the padded domain of a 256-row
+        // dgrad) has nothing to compute: it leaves the MFMA pipe to its SIMD partner and just keeps the barrier count
+        const bool rows_live = !DGRAD || cur.tile_y * DT_ROWS + wave * 4 < tout.hs;
+        if (!rows_live) {
+        } else if (ncb == CHUNK_CB) {
             // ---- full chunk: k-step s = tap s over channel blocks g = 0..3; fully unrolled (immediate LDS offsets).
             // Operands of k-step s+1 are fetched while the MFMAs of k-step s run (explicit double buffer, order pinned with
             // sched_group_barrier: the 8 LDS reads ride on the first 8 MFMAs, the other 8 cover the last reads' latency)

@@ -10,7 +10,8 @@ import torch  # noqa: F401  MUST precede the CDLL below: the process-wide HIP ru
 #                            share devices ("no ROCm-capable device is detected" on the first launch)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libmmif_hip.so")
+# $MMIF_LIB: load another build of the library (A/B timing of kernel variants inside one GPU session)
+LIB_PATH = os.environ.get("MMIF_LIB") or os.path.join(os.path.dirname(_HERE), "libmmif_hip.so")
 
 F32, BF16 = 0, 1
 IMPL_AUTO, IMPL_VALU, IMPL_MFMA = 0, 1, 2
