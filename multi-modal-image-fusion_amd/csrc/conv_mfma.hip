@@ -903,6 +903,185 @@ __global__ __launch_bounds__(256) void wgrad_mfma_reduce(const float* __restrict
     }
 }
 
+// ------------------------------------------------------------------ DMA-staged wgrad (3x3, 64 input x 64 output channels per block)
+// Same maths and the same transpose-read fragments as wgrad_mfma_kernel, restructured like conv_dma_kernel: the register-staged
+// kernel above re-stages the 64-channel g tile for every 16 input channels (135 staged bytes per MFMA); here a block owns a
+// 64 x 64 channel pair, so one x tile (8 planes) + one g tile (8 planes) = 74 KB feed 8 consumer waves x 8 k-steps x 18 MFMAs
+// (32 bytes per MFMA).  4 loader waves stage tile t+1 by LDS-DMA while the consumers run tile t (double-buffered, one barrier
+// per tile); consumer wave w accumulates dW[out 32*(w>>2) .. +32][in 16*(w&3) .. +16][9 taps] over all of the block's tiles in
+// registers (no K split, so no cross-wave reduction) and writes one partial per block at the end.
+// Requires cin % 64 == 0, cout % 64 == 0 and a FOLDED halo-1 gradient (its zero halo ring pads ragged tiles).
+constexpr int WD_XG = 8 * WG_XPL;                          // x-tile granules (8 planes of 18x18)
+constexpr int WD_GG = 8 * WG_GPL;                          // g-tile granules (8 planes of 16x16, stride 260)
+constexpr int WD_XPIECES = (WD_XG + 63) / 64;              // 41
+constexpr int WD_GPIECES = (WD_GG + 63) / 64;              // 33
+constexpr int WD_PIECES = WD_XPIECES + WD_GPIECES;         // 74
+constexpr int WD_BUF_BYTES = WD_PIECES * 1024;             // 75776
+constexpr int WDL_ITERS = (WD_PIECES + D_LOAD - 1) / D_LOAD;   // 19 pieces per loader wave per tile
+constexpr int WD_PER = 64 * 64 * 9 + 64;                   // floats per block partial: dW[64 oc][64 ic][9], db[64]
+
+__global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void wgrad_dma_kernel(TV tx, TV tg, float* __restrict__ partial, int tiles_x,
+                                                                               int tpi, int total, int G, int n_icg, int n_ocg) {
+    constexpr int TP = MT + 2;
+    __shared__ __attribute__((aligned(16))) char s_buf[2 * WD_BUF_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int npairs = n_icg * n_ocg;
+    const int b = blockIdx.x;
+    int gi, pair;
+    if ((G & 7) == 0) { pair = (b >> 3) % npairs; gi = ((b >> 3) / npairs) * 8 + (b & 7); }   // blocks sharing tiles: same XCD
+    else { pair = b % npairs; gi = b / npairs; }
+    const int icg = pair % n_icg, ocg = pair / n_icg;
+    const int ntile = gi < total ? (total - gi + G - 1) / G : 0;
+
+    if (wave >= D_CONS) {
+        // ---------------- loader waves ----------------
+        const int lw = wave - D_CONS;
+        unsigned geo[WDL_ITERS];   // item independent: plane << 16 | tile row << 8 | tile col of the granule this lane stages
+#pragma unroll
+        for (int i = 0; i < WDL_ITERS; ++i) {
+            const int P = lw + D_LOAD * i;
+            if (P < WD_XPIECES) {
+                const int slot = min(P * 64 + lane, WD_XG - 1);
+                const int pl = slot / WG_XPL, p = min(slot - pl * WG_XPL, TP * TP - 1);
+                geo[i] = (unsigned)(pl << 16 | (p / TP) << 8 | (p % TP));
+            } else {
+                const int slot = min((P - WD_XPIECES) * 64 + lane, WD_GG - 1);
+                const int pl = slot / WG_GPL, p = min(slot - pl * WG_GPL, MT * MT - 1);
+                geo[i] = (unsigned)(pl << 16 | (p / MT) << 8 | (p % MT));
+            }
+        }
+        const unsigned xplane = (unsigned)(tx.plane * 16), gplane = (unsigned)(tg.plane * 16);
+        auto issue = [&](int tile, int buf) {
+            const int in_ = tile / tpi, tt = tile - in_ * tpi;
+            const int y0 = (tt / tiles_x) * MT, x0 = (tt % tiles_x) * MT;
+            const char* src_x = tx.base + ((long long)in_ * tx.img + (long long)(tx.cb_off + icg * 8) * tx.plane) * 16;
+            const char* src_g = tg.base + ((long long)in_ * tg.img + (long long)(tg.cb_off + ocg * 8) * tg.plane) * 16;
+            char* dst = s_buf + buf * WD_BUF_BYTES;
+#pragma unroll
+            for (int i = 0; i < WDL_ITERS; ++i) {
+                const int P = lw + D_LOAD * i;   // wave uniform
+                const int pl = (int)(geo[i] >> 16), py = (int)((geo[i] >> 8) & 255u), px = (int)(geo[i] & 255u);
+                if (P < WD_XPIECES) {
+                    const int y = min(max(reflect_idx(y0 + py - 1, tx.h), 0), tx.h - 1);
+                    const int x = min(max(reflect_idx(x0 + px - 1, tx.w), 0), tx.w - 1);
+                    const unsigned off = (unsigned)(y * tx.ws + x) * 16u + (unsigned)pl * xplane;
+                    __builtin_amdgcn_global_load_lds(MMIF_GPTR(src_x + off), MMIF_LPTR(dst + P * 1024), 16, 0, 0);
+                } else if (P < WD_PIECES) {
+                    // pixels of a ragged tile that lie outside the image read the zeroed halo ring (stored row h+1 / col w+1)
+                    const int y = min(y0 + py, tg.h) + 1, x = min(x0 + px, tg.w) + 1;
+                    const unsigned off = (unsigned)(y * tg.ws + x) * 16u + (unsigned)pl * gplane;
+                    __builtin_amdgcn_global_load_lds(MMIF_GPTR(src_g + off), MMIF_LPTR(dst + P * 1024), 16, 0, 0);
+                }
+            }
+        };
+        if (ntile > 0) issue(gi, 0);
+        for (int k = 0; k < ntile; ++k) {
+            __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's pieces of tile k have landed
+            __builtin_amdgcn_s_barrier();
+            if (k + 1 < ntile) issue(gi + (k + 1) * G, (k & 1) ^ 1);
+        }
+        return;
+    }
+
+    // ---------------- consumer waves ----------------
+    const int sl = lane & 15, g = lane >> 4;
+    const int icf = wave & 3, mp = wave >> 2;   // input-channel fragment (16 ch), output-channel half (2 fragments of 16)
+    f32x4 acc[2][9], accb[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        accb[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const uint4 ones_u = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_u);
+    // per-lane transpose-read addressing (see wgrad_mfma_kernel): in-group lane sl supplies pixel row (sl>>2), chunk (sl&3)
+    const int tr_row = sl >> 2, tr_c = sl & 3;
+    const int lane_plane = tr_c >> 1, lane_byte = (tr_c & 1) * 8;
+    for (int k = 0; k < ntile; ++k) {
+        __builtin_amdgcn_s_barrier();
+        const char* s_x = s_buf + (k & 1) * WD_BUF_BYTES;
+        const char* s_g = s_x + WD_XPIECES * 1024;
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) {
+            const int row = 2 * s2 + (g >> 1), col0 = 8 * (g & 1);
+            bf16x8 a[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const char* base = s_g + (((2 * (mp * 2 + m) + lane_plane) * WG_GPL) + row * MT + col0 + tr_row) * 16 + lane_byte;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, base));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, base + 4 * 16));
+                a[m] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+            if (icf == 0) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) accb[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], ones, accb[m], 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int u = t / 3, v = t % 3;
+                const char* base = s_x + (((2 * icf + lane_plane) * WG_XPL) + (row + u) * TP + col0 + v + tr_row) * 16 + lane_byte;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, base));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, base + 4 * 16));
+                const bf16x8 bb = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                for (int m = 0; m < 2; ++m) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], bb, acc[m][t], 0, 0, 0);
+            }
+        }
+    }
+    // lane (g, sl) reg r of fragment m holds (oc = 16*(2*mp + m) + 4g + r, ic = 16*icf + sl) for tap t; bias sums: column sl == 0
+    float* dst = partial + ((long long)gi * npairs + pair) * WD_PER;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int oc = 16 * (2 * mp + m) + 4 * g + r, ic = 16 * icf + sl;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) dst[(oc * 64 + ic) * 9 + t] = acc[m][t][r];
+            if (icf == 0 && sl == 0) dst[64 * 64 * 9 + oc] = accb[m][r];
+        }
+}
+
+// dw / db = fixed-order sum of the G block partials of each (icg, ocg) pair
+__global__ __launch_bounds__(256) void wgrad_dma_reduce(const float* __restrict__ partial, float* __restrict__ dw, float* __restrict__ db,
+                                                        int cin, int cout, int G, int n_icg, int n_ocg, int accumulate) {
+    __shared__ float red[4][64];
+    const int total_w = cout * cin * 9;
+    const int o_local = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + o_local;
+    const int npairs = n_icg * n_ocg;
+    long long off = -1;
+    if (idx < total_w) {
+        const int tap = idx % 9, c = (idx / 9) % cin, o = idx / (9 * cin);
+        off = (long long)((c / 64) + n_icg * (o / 64)) * WD_PER + ((o % 64) * 64 + (c % 64)) * 9 + tap;
+    } else if (idx < total_w + cout) {
+        const int o = idx - total_w;
+        off = (long long)(0 + n_icg * (o / 64)) * WD_PER + 64 * 64 * 9 + (o % 64);
+    }
+    float s = 0.f;
+    if (off >= 0) {
+        const long long stride = (long long)npairs * WD_PER;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int gi = slice;
+        for (; gi + 12 < G; gi += 16) {
+            s0 += partial[gi * stride + off];
+            s1 += partial[(gi + 4) * stride + off];
+            s2 += partial[(gi + 8) * stride + off];
+            s3 += partial[(gi + 12) * stride + off];
+        }
+        for (; gi < G; gi += 4) s0 += partial[gi * stride + off];
+        s = (s0 + s1) + (s2 + s3);
+    }
+    red[slice][o_local] = s;
+    __syncthreads();
+    if (slice == 0 && off >= 0) {
+        const float t = (red[0][o_local] + red[1][o_local]) + (red[2][o_local] + red[3][o_local]);
+        if (idx < total_w) dw[idx] = accumulate ? dw[idx] + t : t;
+        else if (db != nullptr) db[idx - total_w] = accumulate ? db[idx - total_w] + t : t;
+    }
+}
+
 // ------------------------------------------------------------------ host side
 static long long* g_trace = nullptr;  // device buffer [1024][64] for the optional phase trace
 bool conv_mfma_supported(bool dgrad, int ks, int cin, int cout) {
@@ -989,10 +1168,36 @@ static int wgrad_G(int cin, int cout) {
 
 bool wgrad_mfma_supported(int ks, int cin, int cout) { return (ks == 1 || ks == 3) && cin >= 1 && cout >= 1; }
 
+static bool wgrad_dma_shape(int ks, int cin, int cout) { return ks == 3 && cin % 64 == 0 && cout % 64 == 0; }
+static int wgrad_dma_G(int cin, int cout) {   // tile groups per (icg, ocg) pair: one persistent block per CU in total
+    const int npairs = (cin / 64) * (cout / 64);
+    int G = 256 / npairs / 8 * 8;
+    return G < 8 ? 8 : G;
+}
+
 size_t wgrad_mfma_workspace(int cin, int cout, int ks) {
     const int mfw = pick_mfw(cout);
     const size_t per = (size_t)mfw * 16 * 16 * ks * ks + mfw * 16;
-    return (size_t)wgrad_G(cin, cout) * cdiv(cin, 16) * cdiv(cout, mfw * 16) * per * sizeof(float);
+    size_t a = (size_t)wgrad_G(cin, cout) * cdiv(cin, 16) * cdiv(cout, mfw * 16) * per * sizeof(float);
+    if (wgrad_dma_shape(ks, cin, cout)) {
+        const size_t b = (size_t)wgrad_dma_G(cin, cout) * (cin / 64) * (cout / 64) * WD_PER * sizeof(float);
+        if (b > a) a = b;
+    }
+    return a;
+}
+
+static int launch_wgrad_dma(const TV& tx, const TV& tg, float* dw, float* db, int cin, int cout, int accumulate, float* ws, hipStream_t st) {
+    const int tiles_x = cdiv(tx.w, MT), tiles_y = cdiv(tx.h, MT);
+    const int tpi = tiles_x * tiles_y, total = tpi * tx.n;
+    const int n_icg = cin / 64, n_ocg = cout / 64;
+    int G = wgrad_dma_G(cin, cout);
+    if (G > total) G = total;   // every tile group owns at least one tile (the reduce sums all G partials)
+    hipLaunchKernelGGL(wgrad_dma_kernel, dim3(G * n_icg * n_ocg), dim3((D_CONS + D_LOAD) * 64), 0, st, tx, tg, ws, tiles_x, tpi, total, G,
+                       n_icg, n_ocg);
+    if (int rc = check_launch("wgrad_dma")) return rc;
+    const int n = cout * cin * 9 + cout;
+    hipLaunchKernelGGL(wgrad_dma_reduce, dim3(cdiv(n, 64)), dim3(256), 0, st, ws, dw, db, cin, cout, G, n_icg, n_ocg, accumulate);
+    return check_launch("wgrad_dma_reduce");
 }
 
 template <int KS, int MFW, int KSPLIT>
@@ -1015,6 +1220,13 @@ static int launch_wgrad_mfma(const TV& tx, const TV& tg, float* dw, float* db, i
 int wgrad_mfma(int ks, const TV& tx, const TV& tg, float* dw, float* db, int cin, int cout, int accumulate, float* ws,
                hipStream_t st) {
     const int mfw = pick_mfw(cout);
+    if (g_dma_mode < 0) {
+        const char* e = getenv("MMIF_CONV_DMA");
+        g_dma_mode = (e != nullptr && e[0] == '0') ? 0 : 1;
+    }
+    if (g_dma_mode == 1 && wgrad_dma_shape(ks, cin, cout) && tg.halo == 1 && tg.folded && tx.plane * 16 * 8 < (1ll << 31) &&
+        tg.plane * 16 * 8 < (1ll << 31))
+        return launch_wgrad_dma(tx, tg, dw, db, cin, cout, accumulate, ws, st);
 #define GO(KS_, M_, K_) return launch_wgrad_mfma<KS_, M_, K_>(tx, tg, dw, db, cin, cout, accumulate, ws, st)
     if (ks == 3) {
         switch (mfw) { case 1: GO(3, 1, 4); case 2: GO(3, 2, 2); default: GO(3, 4, 2); }
