@@ -159,7 +159,8 @@ def main():
                 s = spec[0]
                 flops = 2.0 * B * S * Wd * s.cin * s.cout * s.k * s.k
                 ach = flops / (ms * 1e-3)
-                roof = {"bound": "mfma", "kernel": f"conv_mfma {s.cin}->{s.cout} k{s.k} ({args.roofline_tag})",
+                dma = os.environ.get("MMIF_CONV_DMA", "1") != "0" and s.k == 3 and s.cout >= 49 and args.dtype == "bf16"
+                roof = {"bound": "mfma", "kernel": f"{'conv_dma_kernel' if dma else 'conv_mfma_kernel'} {s.cin}->{s.cout} k{s.k} ({args.roofline_tag})",
                         "achieved": ach / 1e12, "peak": PEAK_MFMA_BF16 / 1e12 if args.dtype == "bf16" else 157.3,
                         "unit": "TFLOP/s", "frac": ach / (PEAK_MFMA_BF16 if args.dtype == "bf16" else 157.3e12),
                         "avg_launch_ms": ms, "launches": len(evs), "traffic": None}
