@@ -195,6 +195,13 @@ int mmif_grad_loss(const float* img1, const float* img2, const float* imgf, int3
                    float weight, int32_t mode_max, int32_t l2, float* loss_out, float* grad_out, void* workspace,
                    size_t workspace_bytes, void* stream);
 
+/* ---- data feed (the step before the hot path).  out[b] = transform(norm(bank[idx[b]]), mode[b]) as fp32 [batch][P][P]:
+ *      FusionPatches.__getitem__ data/patches.py:61-74 with norm data/transform.py:15-29 (norm_mode 0: /255.0, 1: 'min-max',
+ *      2: 'z-score') and the 8 dihedral variants of transform data/transform.py:38-66 (mode 0..7; NULL = no augmentation), plus
+ *      the DataLoader's collate + H2D copy.  bank: uint8 [n_patches][P][P] resident in HBM; idx / mode: int32 [batch], device. */
+int mmif_patch_feed(const uint8_t* bank, int64_t n_patches, int32_t patch, const int32_t* idx, const int32_t* mode, int32_t batch,
+                    int32_t norm_mode, float* out, void* stream);
+
 /* ---- optimiser (train.py:72-75,319): clip_grad_norm_(max_norm) + Adam on flat fp32 buffers ---- */
 size_t mmif_clip_adam_workspace(int64_t numel);
 /* grad_scale multiplies the gradients first (1/world after a SUM all-reduce).  max_norm <= 0

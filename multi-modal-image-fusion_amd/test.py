@@ -12,13 +12,12 @@ sys.path.insert(0, BASE_DIR)
 import torch
 
 from common import *
-from core.loss import SSIM
+from core.metric import calc_ssim
 from core.model import *
 from mmif import engine as E
 
 
 def test_model(model, pairs, save_dir=None):
-    ssim_fn = SSIM(11, 1.0, False)
     times, ssims = [], []
     for idx, (img1, img2) in enumerate(pairs):
         img1, img2 = img1.to(device), img2.to(device)
@@ -29,7 +28,8 @@ def test_model(model, pairs, save_dir=None):
         torch.cuda.synchronize(device)
         if idx > 0:
             times.append(time.time() - t0)
-        s = 0.5 * (ssim_fn(img1, imgf)['ssim'].mean().item() + ssim_fn(img2, imgf)['ssim'].mean().item())
+        with torch.no_grad():   # reference test.py:49-52
+            s = ((calc_ssim(img1, imgf, data_range=1.0) + calc_ssim(img2, imgf, data_range=1.0)) * 0.5).item()
         ssims.append(s)
         if save_dir is not None:
             try:
@@ -46,7 +46,7 @@ if __name__ == '__main__':
     assert torch.cuda.is_available(), 'the HIP engine needs a GPU'
     device = torch.device('cuda', 0)
     E.set_compute_dtype(args.dtype)
-    model = {'PFNetv1': PFNetv1, 'DenseFuse': DenseFuse}[args.model]().to(device)
+    model = {'PFNetv1': PFNetv1, 'PFNetv2': PFNetv2, 'DenseFuse': DenseFuse, 'NestFuse': NestFuse, 'RFNNest': RFNNest}[args.model]().to(device)
     if args.ckpt is not None:
         ckpt = os.path.join(BASE_DIR, '..', 'checkpoints', args.ckpt, 'epoch_best.pth')
         assert os.path.isfile(ckpt), f'{ckpt} is not a file'

@@ -83,25 +83,43 @@ def train_model(model, data_loader, loss_fn1, loss_fn2, loss_fn3, epoch, mode='t
 
 
 def make_loaders():
+    per_rank = batch_size // world_size
+    set_name = None if args.data in ['tno'] else 'train'     # reference train.py:181-184
+    if args.use_patches:
+        # patch training: the uint8 patch bank lives in HBM, batches (norm + dihedral augmentation) are produced on the
+        # device (mmif.feed / csrc/feed.hip) -- no DataLoader workers, collate, pin_memory or H2D copies
+        from mmif.feed import DevicePatchFeed
+        if args.synthetic > 0:
+            g = torch.Generator().manual_seed(0)
+            def bank(n):
+                return torch.randint(0, 256, (n, 64, 64), generator=g, dtype=torch.uint8)
+            nv = max(batch_size, args.synthetic // 8)
+            tr = DevicePatchFeed(bank(args.synthetic), bank(args.synthetic), per_rank, device, transform=True, seed=0, rank=rank,
+                                 world_size=world_size, drop_last=True)
+            va = DevicePatchFeed(bank(nv), bank(nv), per_rank, device, shuffle=False, rank=rank, world_size=world_size)
+        else:
+            from data.patches import FusionPatches
+            data_dir = os.path.join(BASE_DIR, '..', 'datasets', args.data)
+            assert os.path.isdir(data_dir), f'{data_dir} is not a dir (use --synthetic N to train without a dataset)'
+            tr = FusionPatches(data_dir, set_name=set_name, set_type='train', transform=True).device_feed(
+                per_rank, device, shuffle=True, rank=rank, world_size=world_size, drop_last=True)
+            va = FusionPatches(data_dir, set_name=set_name, set_type='valid').device_feed(
+                per_rank, device, shuffle=False, rank=rank, world_size=world_size)
+        return tr, va, tr   # the feed is its own (distributed) sampler: set_epoch()
     if args.synthetic > 0:
         g = torch.Generator().manual_seed(0)
-        size = 64 if args.use_patches else 256
         def ds(n):
-            return TensorDataset(torch.rand(n, 1, size, size, generator=g), torch.rand(n, 1, size, size, generator=g))
+            return TensorDataset(torch.rand(n, 1, 256, 256, generator=g), torch.rand(n, 1, 256, 256, generator=g))
         train_set, valid_set = ds(args.synthetic), ds(max(batch_size, args.synthetic // 8))
     else:
-        # the reference's own datasets (cv2 / patchify based, data/patches.py, data/dataset.py) plug in unchanged
+        # whole-image training: the reference's own FusionDataset (cv2 / torchvision based, data/dataset.py) plugs in unchanged
         data_dir = os.path.join(BASE_DIR, '..', 'datasets', args.data)
         assert os.path.isdir(data_dir), f'{data_dir} is not a dir (use --synthetic N to train without a dataset)'
-        if args.use_patches:
-            from data.patches import FusionPatches as Data
-        else:
-            from data.dataset import FusionDataset as Data
-        train_set = Data(data_dir, 'train', transform=True)
-        valid_set = Data(data_dir, 'valid')
+        from data.dataset import FusionDataset as Data
+        train_set = Data(data_dir, set_name=set_name, set_type='train', transform=True, fix_size=True)
+        valid_set = Data(data_dir, set_name=set_name, set_type='valid', fix_size=True)
     tr_sampler = DistributedSampler(train_set) if is_distributed else None
     va_sampler = DistributedSampler(valid_set, shuffle=False) if is_distributed else None
-    per_rank = batch_size // world_size
     tr = DataLoader(train_set, batch_size=per_rank, shuffle=tr_sampler is None, sampler=tr_sampler, num_workers=4, pin_memory=True, drop_last=True)
     va = DataLoader(valid_set, batch_size=per_rank, shuffle=False, sampler=va_sampler, num_workers=4, pin_memory=True)
     return tr, va, tr_sampler
@@ -130,7 +148,7 @@ if __name__ == '__main__':
     logger, log_dir = make_logger(os.path.join(BASE_DIR, '..', 'checkpoints')) if local_rank == 0 else (None, None)
     train_loader, valid_loader, train_sampler = make_loaders()
 
-    model = {'PFNetv1': PFNetv1, 'DenseFuse': DenseFuse}[args.model]().to(device)
+    model = {'PFNetv1': PFNetv1, 'PFNetv2': PFNetv2, 'DenseFuse': DenseFuse, 'NestFuse': NestFuse, 'RFNNest': RFNNest}[args.model]().to(device)
     if is_distributed:
         broadcast_parameters(model, 0)  # replaces the reference's init_weights.pth + DDP constructor broadcast
 

@@ -18,6 +18,8 @@ GPU box.  Fixture map:
   f5_models.npz              PFNetv1, PFNetv2, DenseFuse, NestFuse, RFNNest forward + grad digests
   f5_manifest.json           state_dict key/shape manifests
   f6_traj.npz                3-step train trajectories (train.py:61-75 semantics)
+  f8_feed.npz                data/transform.py norm (3 modes) + transform (8 modes) on an integer-valued 6x6 / 5x5 patch
+  f7_metric_ssim.json        core/metric.py:316-364 calc_ssim (the SSIM that test.py:49-52 reports) on closed-form images
 """
 import json
 import os
@@ -296,8 +298,46 @@ def make_f6():
     np.savez_compressed(os.path.join(HERE, "f6_traj.npz"), **out)
 
 
+def make_f7():
+    """core/metric.py calc_ssim as test.py uses it (data_range=1.0) and with its default data_range=255."""
+    import core.metric as rmetric
+    out = {}
+    for tag, shape, scale, kw in (("unit_2x40x52", (2, 1, 40, 52), 1.0, dict(data_range=1.0)),
+                                  ("unit_1x64x64", (1, 1, 64, 64), 1.0, dict(data_range=1.0)),
+                                  ("u8range_1x64x64", (1, 1, 64, 64), 255.0, dict())):
+        a = T(closed_form_image(shape, 0.37) * scale)
+        b = T(closed_form_image(shape, 1.91) * scale)
+        with torch.no_grad():
+            s_ab = rmetric.calc_ssim(a, b, **kw)
+            s_aa = rmetric.calc_ssim(a, a, **kw)
+            s_full, cs_full = rmetric.calc_ssim(a, b, full=True, **kw)
+        out[tag] = {"shape": list(shape), "scale": scale, "kwargs": kw, "ssim": float(s_ab), "ssim_self": float(s_aa),
+                    "ssim_full": float(s_full), "cs_full": float(cs_full)}
+    json.dump(out, open(os.path.join(HERE, "f7_metric_ssim.json"), "w"), indent=1)
+
+
+def feed_patch(P, seed):
+    """Closed-form uint8 patch without symmetries."""
+    y, x = np.mgrid[0:P, 0:P]
+    return ((y * 37 + x * 11 + (y * x) * 5 + seed * 13) % 256).astype(np.uint8)
+
+
+def make_f8():
+    """data/transform.py as FusionPatches.__getitem__ applies it (data/patches.py:61-74): norm, then transform."""
+    sys.path.insert(0, os.path.join(REF, "data"))
+    import transform as rtf   # the reference's data/transform.py (data/ has no __init__-free import path of its own)
+    out = {}
+    for P in (5, 6):
+        patch = feed_patch(P, P).astype(np.float32)
+        for nm, tag in ((None, "none"), ("min-max", "minmax"), ("z-score", "zscore")):
+            n = rtf.norm(patch.copy(), mode=nm)
+            for mode in range(8):
+                out[f"P{P}_{tag}_m{mode}"] = np.ascontiguousarray(rtf.transform(n, mode=mode)).astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, "f8_feed.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6"]
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8"]
     for w in which:
         globals()["make_" + w]()
         print("wrote", w)

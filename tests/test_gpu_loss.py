@@ -69,3 +69,22 @@ def test_loss_errors():
         NormLoss('l3')(torch.zeros(4, device="cuda:0"))
     with pytest.raises(RuntimeError):
         SSIMLoss()(torch.zeros(1, 1, 16, 16), torch.zeros(1, 1, 16, 16), torch.zeros(1, 1, 16, 16))  # CPU tensors: no silent fallback
+
+
+def test_metric_calc_ssim_vs_golden():
+    """core.metric.calc_ssim (test.py:49-52) on the fused HIP loss kernel vs the reference's values (golden F7)."""
+    import json
+    from core.metric import calc_ssim
+    ref = json.load(open(os.path.join(G, "f7_metric_ssim.json")))
+    for tag, r in ref.items():
+        shape = tuple(r["shape"])
+        a = tg(O.closed_form_image(shape, 0.37) * np.float32(r["scale"]))
+        b = tg(O.closed_form_image(shape, 1.91) * np.float32(r["scale"]))
+        s = calc_ssim(a, b, **r["kwargs"])
+        assert s.dim() == 0
+        assert abs(float(s) - r["ssim"]) <= 1e-4, (tag, float(s), r["ssim"])
+        assert abs(float(calc_ssim(a, a, **r["kwargs"])) - r["ssim_self"]) <= 1e-5
+    with pytest.raises(NotImplementedError):
+        calc_ssim(a, b, full=True)
+    with pytest.raises(RuntimeError):
+        calc_ssim(a.repeat(1, 3, 1, 1), b.repeat(1, 3, 1, 1))

@@ -279,3 +279,17 @@ def test_f6_train_trajectory(name):
         np.testing.assert_allclose(got, rows[step], rtol=2e-4, atol=2e-6, err_msg=f"step {step}")
     for k in P:
         close_digest(P[k], ref[f"{name}__w_{k}"], 2e-5, k)
+
+
+def test_f7_metric_calc_ssim():
+    """core/metric.py calc_ssim (test.py's per-image SSIM) -- oracle vs the reference's values."""
+    ref = json.load(open(os.path.join(G, "f7_metric_ssim.json")))
+    for tag, r in ref.items():
+        shape = tuple(r["shape"])
+        a = O.closed_form_image(shape, 0.37) * np.float32(r["scale"])
+        b = O.closed_form_image(shape, 1.91) * np.float32(r["scale"])
+        dr = r["kwargs"].get("data_range", 255.0)
+        s, cs = O.metric_calc_ssim(a, b, dr, full=True)
+        assert abs(float(s) - r["ssim"]) <= 2e-5, (tag, float(s), r["ssim"])
+        assert abs(float(cs) - r["cs_full"]) <= 2e-5, (tag, float(cs), r["cs_full"])
+        assert abs(float(O.metric_calc_ssim(a, a, dr)) - r["ssim_self"]) <= 1e-6
