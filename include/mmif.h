@@ -213,6 +213,9 @@ int mmif_clip_adam_step(float* params, const float* grads, float* exp_avg, float
 /* ---- diagnostics: device buffer long long[1024][64]; when non-NULL the MFMA conv kernel stamps s_memtime per
  * phase for its first 1024 blocks (tools/trace_conv.py).  NULL (default) disables it. */
 void mmif_debug_set_trace(void* device_buf);
+/* kernel-generation switch for cross-checks: 1 (default, also $MMIF_CONV_DMA) = DMA-staged conv / wgrad kernels where they apply,
+ * 0 = the register-staged kernels everywhere. */
+void mmif_debug_set_conv_dma(int32_t mode);
 
 #ifdef __cplusplus
 }

@@ -910,7 +910,8 @@ __global__ __launch_bounds__(256) void wgrad_mfma_reduce(const float* __restrict
 // (32 bytes per MFMA).  4 loader waves stage tile t+1 by LDS-DMA while the consumers run tile t (double-buffered, one barrier
 // per tile); consumer wave w accumulates dW[out 32*(w>>2) .. +32][in 16*(w&3) .. +16][9 taps] over all of the block's tiles in
 // registers (no K split, so no cross-wave reduction) and writes one partial per block at the end.
-// Requires cin % 64 == 0, cout % 64 == 0 and a FOLDED halo-1 gradient (its zero halo ring pads ragged tiles).
+// Channel counts that are not multiples of 64 run with a ragged last group (used when >= 60 % of the 64 x 64 pairs is real work);
+// requires a FOLDED halo-1 gradient (its zero halo ring pads ragged tiles).
 constexpr int WD_XG = 8 * WG_XPL;                          // x-tile granules (8 planes of 18x18)
 constexpr int WD_GG = 8 * WG_GPL;                          // g-tile granules (8 planes of 16x16, stride 260)
 constexpr int WD_XPIECES = (WD_XG + 63) / 64;              // 41
@@ -957,6 +958,8 @@ __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void wgrad_dma_kernel(TV
             const int y0 = (tt / tiles_x) * MT, x0 = (tt % tiles_x) * MT;
             const char* src_x = tx.base + ((long long)in_ * tx.img + (long long)(tx.cb_off + icg * 8) * tx.plane) * 16;
             const char* src_g = tg.base + ((long long)in_ * tg.img + (long long)(tg.cb_off + ocg * 8) * tg.plane) * 16;
+            // ragged last channel group: planes past the tensor re-read its last plane (those dW rows/cols are never reduced)
+            const int xpl_max = min(8, tx.cb - icg * 8) - 1, gpl_max = min(8, tg.cb - ocg * 8) - 1;
             char* dst = s_buf + buf * WD_BUF_BYTES;
 #pragma unroll
             for (int i = 0; i < WDL_ITERS; ++i) {
@@ -965,12 +968,12 @@ __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void wgrad_dma_kernel(TV
                 if (P < WD_XPIECES) {
                     const int y = min(max(reflect_idx(y0 + py - 1, tx.h), 0), tx.h - 1);
                     const int x = min(max(reflect_idx(x0 + px - 1, tx.w), 0), tx.w - 1);
-                    const unsigned off = (unsigned)(y * tx.ws + x) * 16u + (unsigned)pl * xplane;
+                    const unsigned off = (unsigned)(y * tx.ws + x) * 16u + (unsigned)min(pl, xpl_max) * xplane;
                     __builtin_amdgcn_global_load_lds(MMIF_GPTR(src_x + off), MMIF_LPTR(dst + P * 1024), 16, 0, 0);
                 } else if (P < WD_PIECES) {
                     // pixels of a ragged tile that lie outside the image read the zeroed halo ring (stored row h+1 / col w+1)
                     const int y = min(y0 + py, tg.h) + 1, x = min(x0 + px, tg.w) + 1;
-                    const unsigned off = (unsigned)(y * tg.ws + x) * 16u + (unsigned)pl * gplane;
+                    const unsigned off = (unsigned)(y * tg.ws + x) * 16u + (unsigned)min(pl, gpl_max) * gplane;
                     __builtin_amdgcn_global_load_lds(MMIF_GPTR(src_g + off), MMIF_LPTR(dst + P * 1024), 16, 0, 0);
                 }
             }
@@ -1168,11 +1171,15 @@ static int wgrad_G(int cin, int cout) {
 
 bool wgrad_mfma_supported(int ks, int cin, int cout) { return (ks == 1 || ks == 3) && cin >= 1 && cout >= 1; }
 
-static bool wgrad_dma_shape(int ks, int cin, int cout) { return ks == 3 && cin % 64 == 0 && cout % 64 == 0; }
-static int wgrad_dma_G(int cin, int cout) {   // tile groups per (icg, ocg) pair: one persistent block per CU in total
-    const int npairs = (cin / 64) * (cout / 64);
-    int G = 256 / npairs / 8 * 8;
-    return G < 8 ? 8 : G;
+static bool wgrad_dma_shape(int ks, int cin, int cout) {
+    const long long padded = (long long)cdiv(cin, 64) * 64 * cdiv(cout, 64) * 64;
+    return ks == 3 && cin % 8 == 0 && cout % 8 == 0 && (long long)cin * cout * 10 >= padded * 6;
+}
+static int wgrad_dma_G(int cin, int cout) {   // tile groups per (icg, ocg) pair: about one persistent block per CU in total
+    const int npairs = cdiv(cin, 64) * cdiv(cout, 64);
+    int G = 256 / npairs;
+    if (G >= 8) G = G / 8 * 8;   // multiples of 8 keep the blocks that share tiles on one XCD
+    return G < 1 ? 1 : G;
 }
 
 size_t wgrad_mfma_workspace(int cin, int cout, int ks) {
@@ -1180,7 +1187,7 @@ size_t wgrad_mfma_workspace(int cin, int cout, int ks) {
     const size_t per = (size_t)mfw * 16 * 16 * ks * ks + mfw * 16;
     size_t a = (size_t)wgrad_G(cin, cout) * cdiv(cin, 16) * cdiv(cout, mfw * 16) * per * sizeof(float);
     if (wgrad_dma_shape(ks, cin, cout)) {
-        const size_t b = (size_t)wgrad_dma_G(cin, cout) * (cin / 64) * (cout / 64) * WD_PER * sizeof(float);
+        const size_t b = (size_t)wgrad_dma_G(cin, cout) * cdiv(cin, 64) * cdiv(cout, 64) * WD_PER * sizeof(float);
         if (b > a) a = b;
     }
     return a;
@@ -1189,7 +1196,7 @@ size_t wgrad_mfma_workspace(int cin, int cout, int ks) {
 static int launch_wgrad_dma(const TV& tx, const TV& tg, float* dw, float* db, int cin, int cout, int accumulate, float* ws, hipStream_t st) {
     const int tiles_x = cdiv(tx.w, MT), tiles_y = cdiv(tx.h, MT);
     const int tpi = tiles_x * tiles_y, total = tpi * tx.n;
-    const int n_icg = cin / 64, n_ocg = cout / 64;
+    const int n_icg = cdiv(cin, 64), n_ocg = cdiv(cout, 64);
     int G = wgrad_dma_G(cin, cout);
     if (G > total) G = total;   // every tile group owns at least one tile (the reduce sums all G partials)
     hipLaunchKernelGGL(wgrad_dma_kernel, dim3(G * n_icg * n_ocg), dim3((D_CONS + D_LOAD) * 64), 0, st, tx, tg, ws, tiles_x, tpi, total, G,
@@ -1241,6 +1248,8 @@ int wgrad_mfma(int ks, const TV& tx, const TV& tg, float* dw, float* db, int cin
 using namespace mmif;
 
 extern "C" void mmif_debug_set_trace(void* device_buf) { mmif::g_trace = (long long*)device_buf; }
+// 1 (default; also $MMIF_CONV_DMA) = use the DMA-staged kernels where they apply, 0 = register-staged kernels only
+extern "C" void mmif_debug_set_conv_dma(int32_t mode) { mmif::g_dma_mode = mode ? 1 : 0; }
 
 extern "C" size_t mmif_packed_weight_bytes(int32_t cout, int32_t cin, int32_t ksize) {
     const size_t a = packed_bytes(cout, cin, ksize), b = packed_bytes(cin, cout, ksize);

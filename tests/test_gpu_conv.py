@@ -64,3 +64,45 @@ def test_conv_bf16_vs_oracle_on_rounded_operands(case, impl):
     close(db, gb_ref, 2e-3, "db")
     if dx is not None:
         close(dx, gx_ref, 1.2e-2, "dx")   # dgrad output is stored in bf16 (padded domain) and folded in fp32
+
+
+DMA_SHAPES = [(128, 128, 2, 37, 53), (176, 112, 1, 64, 48), (72, 64, 2, 33, 40), (64, 184, 1, 40, 72), (96, 96, 3, 16, 16)]
+
+
+@pytest.mark.parametrize("cin,cout,n,h,w", DMA_SHAPES, ids=[f"{a}-{b}-{n}x{h}x{w}" for a, b, n, h, w in DMA_SHAPES])
+def test_dma_staged_kernels_equal_register_staged(cin, cout, n, h, w):
+    """The two kernel generations (conv_dma / wgrad_dma vs conv_mfma / wgrad_mfma) on identical bf16 operands: ragged
+    tiles, ragged K chunks (cin % 32 != 0), ragged 64-channel groups, partial mask / accumulate bit sets.  fwd and dgrad
+    use the same MFMA order -> bit identical; wgrad sums tiles in a different order -> 2e-5."""
+    from mmif import tensor as T
+    from mmif._lib import IMPL_MFMA, lib
+    dev = "cuda:0"
+    torch.manual_seed(cin * 7 + cout)
+    x = T.BT.alloc(n, cin, h, w, torch.bfloat16, dev); x.buf.normal_()
+    gy = T.BT.alloc(n, cout, h, w, torch.bfloat16, dev, halo=1, zero=True); gy.buf[:, :, 1:-1, 1:-1].normal_()
+    gy = gy.as_folded()
+    wt = torch.randn(cout, cin, 3, 3, device=dev) * 0.05
+    b = torch.randn(cout, device=dev)
+    pk = T.PackedWeights(cout, cin, 3, dev); pk.pack(wt)
+    ws = torch.empty(T.wgrad_workspace_bytes(cin, cout, 3) // 4 + 1, dtype=torch.float32, device=dev)
+    mask = 0x5a5a5a5a5a5a & ((1 << x.cb) - 1)
+    acc_bits = 0x333333333333 & ((1 << x.cb) - 1)
+    res = {}
+    try:
+        for mode in (0, 1):
+            lib.mmif_debug_set_conv_dma(mode)
+            y = T.BT.alloc(n, cout, h, w, torch.bfloat16, dev)
+            gx = T.BT.alloc(n, cin, h, w, torch.bfloat16, dev, halo=1, zero=True)
+            gx.buf.fill_(0.25)
+            dw, db = torch.zeros_like(wt), torch.zeros_like(b)
+            T.conv_fwd(x, wt, b, y, cin, cout, 3, True, pk, IMPL_MFMA)
+            T.conv_dgrad(gy, wt, x, gx, cin, cout, 3, mask, acc_bits, pk, IMPL_MFMA)
+            T.conv_wgrad(x, gy, dw, db, cin, cout, 3, ws, False, IMPL_MFMA)
+            torch.cuda.synchronize()
+            res[mode] = (y.buf.clone(), gx.buf.clone(), dw, db)
+    finally:
+        lib.mmif_debug_set_conv_dma(1)
+    assert torch.equal(res[0][0], res[1][0]), "fwd differs"
+    assert torch.equal(res[0][1], res[1][1]), "dgrad differs"
+    close(res[1][2].cpu().numpy(), res[0][2].cpu().numpy(), 2e-5, "dw")
+    close(res[1][3].cpu().numpy(), res[0][3].cpu().numpy(), 2e-5, "db")
