@@ -186,6 +186,17 @@ size_t mmif_loss_workspace(int32_t n, int32_t h, int32_t w);
 int mmif_ssim_loss(const float* img1, const float* img2, const float* imgf, int32_t n, int32_t h, int32_t w,
                    float weight, float data_range, float* loss_out, float* grad_out, void* workspace,
                    size_t workspace_bytes, void* stream);
+/* The other SSIMLoss modes core/loss.py:259-277: mode 1 'w-ssim' (per-sample sigma weights), 2 'ms-ssim' (5-level
+ * avg-pool pyramid, :113-160; images >= 161x161), 3 'msw-ssim' (windows 11/9/7/5/3, per-pixel sigma weights, :211-237).
+ * Same contract as mmif_ssim_loss (mode 0 'ssim' stays there); any other mode -> MMIF_EINVAL with the reference's message. */
+size_t mmif_ssim_loss_mode_workspace(int32_t n, int32_t h, int32_t w, int32_t mode);
+int mmif_ssim_loss_mode(const float* img1, const float* img2, const float* imgf, int32_t n, int32_t h, int32_t w, float weight,
+                        float data_range, int32_t mode, float* loss_out, float* grad_out, void* workspace, size_t workspace_bytes,
+                        void* stream);
+/* TVLoss core/loss.py:347-358 = NormLoss(l1|l2)(x[1:] - x[:-1]) + NormLoss(x[:, 1:] - x[:, :-1]) over n images [h][w]. */
+size_t mmif_tv_loss_workspace(void);
+int mmif_tv_loss(const float* x, int32_t n, int32_t h, int32_t w, float weight, int32_t l2, float* loss_out, float* grad_out,
+                 void* workspace, size_t workspace_bytes, void* stream);
 /* PixelLoss core/loss.py:287-304 (NormLoss 'l1'|'l2' :361-385); mode 0 = 'avg', 1 = 'max'. */
 int mmif_pixel_loss(const float* img1, const float* img2, const float* imgf, int32_t n, int32_t h, int32_t w,
                     float weight, int32_t mode_max, int32_t l2, float* loss_out, float* grad_out, void* workspace,

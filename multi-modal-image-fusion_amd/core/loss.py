@@ -12,7 +12,7 @@ import torch.nn as nn
 from mmif import tensor as T
 from mmif._lib import check, lib
 
-__all__ = ['SSIM', 'SSIMLoss', 'PixelLoss', 'GradLoss', 'NormLoss']
+__all__ = ['SSIM', 'SSIMLoss', 'PixelLoss', 'GradLoss', 'TVLoss', 'NormLoss']
 
 eps = 1e-7
 
@@ -67,6 +67,59 @@ class _LossFn(torch.autograd.Function):
         return ctx.grad * g, None, None, None, None, None, None
 
 
+_SSIM_MODES = {'w-ssim': 1, 'ms-ssim': 2, 'msw-ssim': 3}
+
+
+class _ModeLossFn(torch.autograd.Function):
+    """SSIMLoss 'w-ssim' | 'ms-ssim' | 'msw-ssim' (reference core/loss.py:259-277) on csrc/loss_modes.hip."""
+
+    @staticmethod
+    def forward(ctx, imgf, img1, img2, mode, weight, data_range):
+        i1, i2, f = _prep(img1, img2, imgf)
+        n, _, h, w = f.shape
+        need = ctx.needs_input_grad[0]
+        out = torch.empty(1, dtype=torch.float32, device=f.device)
+        grad = torch.empty_like(f) if need else None
+        nbytes = lib.mmif_ssim_loss_mode_workspace(n, h, w, mode)
+        ws = torch.empty(nbytes // 4 + 1, dtype=torch.float32, device=f.device)
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        check(lib.mmif_ssim_loss_mode(p(i1), p(i2), p(f), n, h, w, weight, data_range, mode, p(out), p(grad), p(ws), ws.numel() * 4,
+                                      T.stream_ptr()), "ssim_loss_mode")
+        ctx.grad = grad
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.grad is None:
+            return (None,) * 6
+        return ctx.grad * g, None, None, None, None, None
+
+
+class _TVFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, l2, weight):
+        T.require_device(x, "TVLoss input")
+        if x.dim() < 2:
+            raise ValueError("TVLoss needs at least 2 dimensions")
+        xf = x.detach().contiguous().float()
+        h, w = xf.shape[-2:]
+        n = xf.numel() // (h * w)
+        need = ctx.needs_input_grad[0]
+        out = torch.empty(1, dtype=torch.float32, device=xf.device)
+        grad = torch.empty_like(xf) if need else None
+        ws = torch.empty(lib.mmif_tv_loss_workspace() // 4 + 1, dtype=torch.float32, device=xf.device)
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        check(lib.mmif_tv_loss(p(xf), n, h, w, weight, int(l2), p(out), p(grad), p(ws), ws.numel() * 4, T.stream_ptr()), "tv_loss")
+        ctx.grad = grad
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.grad is None:
+            return None, None, None
+        return ctx.grad * g, None, None
+
+
 class SSIM(nn.Module):
     """Structural similarity (reference core/loss.py:163-185): returns {'ssim': per-sample mean}."""
 
@@ -95,8 +148,10 @@ class SSIMLoss(nn.Module):
             if self.use_padding:
                 raise NotImplementedError("use_padding=True is outside the accelerated hot path")
             return _LossFn.apply(imgf, img1, img2, 0, float(self.weight), float(self.data_range), 0)
-        if self.mode in ('w-ssim', 'ms-ssim', 'msw-ssim'):
-            raise NotImplementedError(f"SSIMLoss mode '{self.mode}' is outside the accelerated hot path (train.py uses 'ssim')")
+        if self.mode in _SSIM_MODES:
+            if self.use_padding:
+                raise NotImplementedError("use_padding=True is outside the accelerated path")
+            return _ModeLossFn.apply(imgf, img1, img2, _SSIM_MODES[self.mode], float(self.weight), float(self.data_range))
         raise ValueError("only supported ['ssim', 'w-ssim', 'ms-ssim', 'msw-ssim'] mode")
 
 
@@ -118,6 +173,18 @@ class NormLoss(nn.Module):
     def forward(self, x):
         _norm_code(self.mode)
         return self.weight * (torch.abs(x).mean() if self.mode == 'l1' else torch.pow(x, 2).mean())
+
+
+class TVLoss(nn.Module):
+    """reference core/loss.py:347-358: NormLoss(mode, weight) of the vertical plus of the horizontal first differences."""
+
+    def __init__(self, mode='l1', weight=1.0):
+        super(TVLoss, self).__init__()
+        self.mode, self.weight = mode, weight
+        self.loss_fn = NormLoss(mode, weight)
+
+    def forward(self, x):
+        return _TVFn.apply(x, _norm_code(self.mode), float(self.weight))
 
 
 class PixelLoss(nn.Module):

@@ -77,6 +77,10 @@ SIGNATURES = {
     "mmif_relu_mask": (_i32, [_TP, _TP, _vp]),
     "mmif_loss_workspace": (_sz, [_i32, _i32, _i32]),
     "mmif_ssim_loss": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _sz, _vp]),
+    "mmif_ssim_loss_mode_workspace": (_sz, [_i32, _i32, _i32, _i32]),
+    "mmif_ssim_loss_mode": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _f32, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "mmif_tv_loss_workspace": (_sz, []),
+    "mmif_tv_loss": (_i32, [_vp, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp, _sz, _vp]),
     "mmif_pixel_loss": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     "mmif_grad_loss": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     "mmif_patch_feed": (_i32, [_vp, _i64, _i32, _vp, _vp, _i32, _i32, _vp, _vp]),

@@ -19,6 +19,7 @@ GPU box.  Fixture map:
   f5_manifest.json           state_dict key/shape manifests
   f6_traj.npz                3-step train trajectories (train.py:61-75 semantics)
   f8_feed.npz                data/transform.py norm (3 modes) + transform (8 modes) on an integer-valued 6x6 / 5x5 patch
+  f9_ssim_modes.npz          SSIMLoss 'w-ssim' | 'ms-ssim' | 'msw-ssim' (core/loss.py:259-277) and TVLoss (:347-358): value + d/dimgf
   f7_metric_ssim.json        core/metric.py:316-364 calc_ssim (the SSIM that test.py:49-52 reports) on closed-form images
 """
 import json
@@ -336,8 +337,42 @@ def make_f8():
     np.savez_compressed(os.path.join(HERE, "f8_feed.npz"), **out)
 
 
+def make_f9():
+    """The SSIMLoss modes beyond 'ssim' and TVLoss, on closed-form images (value + gradient w.r.t. the fused image)."""
+    out = {}
+    def run(tag, fn, shape, phases=(0.3, 1.7, 2.9)):
+        i1, i2 = T(closed_form_image(shape, phases[0])), T(closed_form_image(shape, phases[1]))
+        f = T(closed_form_image(shape, phases[2])).requires_grad_(True)
+        loss = fn(i1, i2, f)
+        loss.backward()
+        out[tag + "__loss"] = np.float64(loss.item())
+        out[tag + "__grad"] = f.grad.numpy()
+    for mode, shapes in (("w-ssim", [(2, 1, 40, 52), (3, 1, 33, 47)]), ("msw-ssim", [(2, 1, 40, 52), (1, 1, 33, 47)]),
+                         ("ms-ssim", [(1, 1, 192, 208), (2, 1, 193, 211)])):
+        for shape in shapes:
+            fn = rloss.SSIMLoss(mode, weight=0.7)
+            run(f"{mode}_{shape[0]}x{shape[2]}x{shape[3]}", fn, shape)
+    # flat source image: sigma clamps (1e-4) and the gamma denominators
+    for mode in ("w-ssim", "msw-ssim"):
+        shape = (2, 1, 24, 24)
+        i1 = T(np.full(shape, 0.4, np.float32)); i2 = T(closed_form_image(shape, 1.1))
+        f = T(closed_form_image(shape, 2.2)).requires_grad_(True)
+        loss = rloss.SSIMLoss(mode)(i1, i2, f)
+        loss.backward()
+        out[f"{mode}_flat__loss"] = np.float64(loss.item())
+        out[f"{mode}_flat__grad"] = f.grad.numpy()
+    for mode in ("l1", "l2"):
+        shape = (2, 1, 21, 34)
+        x = T(closed_form_image(shape, 0.77)).requires_grad_(True)
+        loss = rloss.TVLoss(mode, weight=0.3)(x)
+        loss.backward()
+        out[f"tv_{mode}__loss"] = np.float64(loss.item())
+        out[f"tv_{mode}__grad"] = x.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, "f9_ssim_modes.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8"]
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9"]
     for w in which:
         globals()["make_" + w]()
         print("wrote", w)

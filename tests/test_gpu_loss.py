@@ -88,3 +88,58 @@ def test_metric_calc_ssim_vs_golden():
         calc_ssim(a, b, full=True)
     with pytest.raises(RuntimeError):
         calc_ssim(a.repeat(1, 3, 1, 1), b.repeat(1, 3, 1, 1))
+
+
+F9_SSIM = [("w-ssim", (2, 1, 40, 52)), ("w-ssim", (3, 1, 33, 47)), ("msw-ssim", (2, 1, 40, 52)), ("msw-ssim", (1, 1, 33, 47)),
+           ("ms-ssim", (1, 1, 192, 208)), ("ms-ssim", (2, 1, 193, 211))]
+
+
+@pytest.mark.parametrize("mode,shape", F9_SSIM, ids=[f"{m}-{s[0]}x{s[2]}x{s[3]}" for m, s in F9_SSIM])
+def test_ssim_modes_vs_golden(mode, shape):
+    """SSIMLoss 'w-ssim' / 'ms-ssim' / 'msw-ssim' on csrc/loss_modes.hip: value + d/dimgf vs the reference's autograd (golden F9)."""
+    from core.loss import SSIMLoss
+    ref = np.load(os.path.join(G, "f9_ssim_modes.npz"))
+    tag = f"{mode}_{shape[0]}x{shape[2]}x{shape[3]}"
+    i1, i2 = tg(O.closed_form_image(shape, 0.3)), tg(O.closed_form_image(shape, 1.7))
+    f = tg(O.closed_form_image(shape, 2.9)).requires_grad_(True)
+    loss = SSIMLoss(mode, weight=0.7)(i1, i2, f)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(ref[tag + "__loss"])) <= 5e-5
+    close(f.grad.cpu().numpy(), ref[tag + "__grad"], 5e-4, tag)
+    with torch.no_grad():   # value-only call (no gradient buffers)
+        assert abs(float(SSIMLoss(mode, weight=0.7)(i1, i2, f)) - float(ref[tag + "__loss"])) <= 5e-5
+
+
+@pytest.mark.parametrize("mode", ["w-ssim", "msw-ssim"])
+def test_ssim_modes_flat_source_clamps(mode):
+    from core.loss import SSIMLoss
+    ref = np.load(os.path.join(G, "f9_ssim_modes.npz"))
+    shape = (2, 1, 24, 24)
+    i1, i2 = tg(np.full(shape, 0.4, np.float32)), tg(O.closed_form_image(shape, 1.1))
+    f = tg(O.closed_form_image(shape, 2.2)).requires_grad_(True)
+    loss = SSIMLoss(mode)(i1, i2, f)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(ref[f"{mode}_flat__loss"])) <= 5e-5
+    close(f.grad.cpu().numpy(), ref[f"{mode}_flat__grad"], 5e-4, mode)
+
+
+@pytest.mark.parametrize("mode", ["l1", "l2"])
+def test_tv_loss_vs_golden(mode):
+    from core.loss import TVLoss
+    ref = np.load(os.path.join(G, "f9_ssim_modes.npz"))
+    x = tg(O.closed_form_image((2, 1, 21, 34), 0.77)).requires_grad_(True)
+    loss = TVLoss(mode, weight=0.3)(x)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(ref[f"tv_{mode}__loss"])) <= 1e-6
+    close(x.grad.cpu().numpy(), ref[f"tv_{mode}__grad"], 1e-5, mode)
+
+
+def test_ssim_mode_errors():
+    from core.loss import SSIMLoss, TVLoss
+    z = tg(np.zeros((1, 1, 32, 32), np.float32))
+    with pytest.raises(ValueError, match="only supported"):
+        SSIMLoss("psnr")(z, z, z)
+    with pytest.raises(ValueError, match="only supported"):
+        TVLoss("l3")(z)
+    with pytest.raises(Exception, match="161x161"):
+        SSIMLoss("ms-ssim")(z, z, z)

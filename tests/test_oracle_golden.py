@@ -293,3 +293,37 @@ def test_f7_metric_calc_ssim():
         assert abs(float(s) - r["ssim"]) <= 2e-5, (tag, float(s), r["ssim"])
         assert abs(float(cs) - r["cs_full"]) <= 2e-5, (tag, float(cs), r["cs_full"])
         assert abs(float(O.metric_calc_ssim(a, a, dr)) - r["ssim_self"]) <= 1e-6
+
+
+F9_SSIM = [("w-ssim", (2, 1, 40, 52)), ("w-ssim", (3, 1, 33, 47)), ("msw-ssim", (2, 1, 40, 52)), ("msw-ssim", (1, 1, 33, 47)),
+           ("ms-ssim", (1, 1, 192, 208)), ("ms-ssim", (2, 1, 193, 211))]
+
+
+@pytest.mark.parametrize("mode,shape", F9_SSIM, ids=[f"{m}-{s[0]}x{s[2]}x{s[3]}" for m, s in F9_SSIM])
+def test_f9_ssim_modes(mode, shape):
+    """SSIMLoss 'w-ssim' / 'ms-ssim' / 'msw-ssim' (weight 0.7): oracle value + explicit gradient vs the reference's autograd."""
+    ref = np.load(os.path.join(G, "f9_ssim_modes.npz"))
+    tag = f"{mode}_{shape[0]}x{shape[2]}x{shape[3]}"
+    i1, i2, f = O.closed_form_image(shape, 0.3), O.closed_form_image(shape, 1.7), O.closed_form_image(shape, 2.9)
+    loss, grad = O.ssim_mode_loss(i1, i2, f, mode, weight=0.7)
+    assert abs(float(loss) - float(ref[tag + "__loss"])) <= 2e-5, (float(loss), float(ref[tag + "__loss"]))
+    close(grad, ref[tag + "__grad"], 2e-4, tag)
+
+
+@pytest.mark.parametrize("mode", ["w-ssim", "msw-ssim"])
+def test_f9_flat_source_clamps(mode):
+    ref = np.load(os.path.join(G, "f9_ssim_modes.npz"))
+    shape = (2, 1, 24, 24)
+    i1, i2, f = np.full(shape, 0.4, np.float32), O.closed_form_image(shape, 1.1), O.closed_form_image(shape, 2.2)
+    loss, grad = O.ssim_mode_loss(i1, i2, f, mode)
+    assert abs(float(loss) - float(ref[f"{mode}_flat__loss"])) <= 2e-5
+    close(grad, ref[f"{mode}_flat__grad"], 2e-4, mode)
+
+
+@pytest.mark.parametrize("mode", ["l1", "l2"])
+def test_f9_tv_loss(mode):
+    ref = np.load(os.path.join(G, "f9_ssim_modes.npz"))
+    x = O.closed_form_image((2, 1, 21, 34), 0.77)
+    loss, grad = O.tv_loss(x, mode, weight=0.3)
+    assert abs(float(loss) - float(ref[f"tv_{mode}__loss"])) <= 1e-6
+    close(grad, ref[f"tv_{mode}__grad"], 1e-5, mode)
