@@ -197,8 +197,9 @@ __device__ inline void conv_epilogue(const f32x4 (&acc)[MF][4], const TV& tout, 
 }
 
 // ------------------------------------------------------------------ forward / dgrad kernel
+// (min waves per SIMD: the Cout <= 16 instantiations are HBM-bound and want bytes in flight, i.e. occupancy: 128 VGPRs -> 4 blocks/CU)
 template <int KS, int MF, bool DGRAD>
-__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(TV tin, TV tout, TV tmask, const uint4* __restrict__ wpk,
+__global__ __launch_bounds__(256, MF == 1 ? 4 : 2) void conv_mfma_kernel(TV tin, TV tout, TV tmask, const uint4* __restrict__ wpk,
                                                             const float* __restrict__ bias, int n_out, int m16p,
                                                             int relu, unsigned long long mask_bits,
                                                             unsigned long long accum_bits, int tiles_x, int tiles_y,
