@@ -17,8 +17,12 @@ pk = T.PackedWeights(cout, cin, 3, dev); pk.pack(w)
 for _ in range(3): T.conv_fwd(x, w, b, y, cin, cout, 3, True, pk, IMPL_MFMA)
 tr = torch.zeros(1024, 64, dtype=torch.int64, device=dev)
 lib.mmif_debug_set_trace(C.c_void_p(tr.data_ptr()))
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
 T.conv_fwd(x, w, b, y, cin, cout, 3, True, pk, IMPL_MFMA)
+e1.record()
 torch.cuda.synchronize(); lib.mmif_debug_set_trace(None)
+traced_ms = e0.elapsed_time(e1)
 t = tr.cpu().numpy().reshape(128, 8, 64).astype(np.float64)
 n = int(t[0, 0, 63])
 nq = (n - 1) // 5
@@ -33,4 +37,7 @@ for k, nm in enumerate(names):
 tops = t[:, :, [1 + 5 * q for q in range(1, nq)]]
 print("  chunk period (top -> top)     ", np.median(np.diff(tops, axis=2), axis=(0, 2)).round(0))
 arr = t[:, :, [1 + 5 * q for q in range(2, nq)]]
+span = (t[:, 0, n - 1] - t[:, 0, 0])
+print(f"  traced launch: {traced_ms:.3f} ms; first-to-last stamp of wave 0: median {np.median(span):.0f} ticks -> {np.median(span) / (traced_ms * 1e3):.0f} ticks/us "
+      f"(s_memtime is a constant-rate counter if this is ~100, the shader clock in MHz otherwise; stamps cover {nq} of the block's chunks)")
 print("  arrival at barrier vs first   ", np.median(arr - arr.min(axis=1, keepdims=True), axis=(0, 2)).round(0))

@@ -7,11 +7,22 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 // MODE 0: admin first in all waves; 1: admin first in waves 0-3, last in waves 4-7; 2: like 0 but setprio(1) on MFMAs of waves 4-7
-template <int MODE>
+template <int MODE, bool RANDOM>
 __global__ __launch_bounds__(512, 2) void k(float* out, int iters, int admin, long long* cyc) {
-    const uint4 ua = make_uint4(0x3f803f80u + threadIdx.x, 0x3f813f80u, 0x3f803f82u, 0x3f833f80u);
     bf16x8 a[4], b[4];
-    for (int i = 0; i < 4; ++i) { a[i] = __builtin_bit_cast(bf16x8, ua); b[i] = __builtin_bit_cast(bf16x8, ua); }
+    for (int i = 0; i < 4; ++i) {
+        uint4 ua, ub;
+        if (RANDOM) {   // pseudo-random bf16 values in (-2, 2): full mantissa + sign toggling, like real activations / weights
+            unsigned h = (threadIdx.x * 2654435761u) ^ (blockIdx.x * 40503u) ^ (i * 0x9e3779b9u);
+            auto nxt = [&]() { h = h * 1664525u + 1013904223u; return ((h >> 9) & 0x807f807fu) | 0x3f003f00u | ((h >> 3) & 0x00800080u); };
+            ua = make_uint4(nxt(), nxt(), nxt(), nxt());
+            ub = make_uint4(nxt(), nxt(), nxt(), nxt());
+        } else {
+            ua = ub = make_uint4(0x3f803f80u + threadIdx.x, 0x3f813f80u, 0x3f803f82u, 0x3f833f80u);
+        }
+        a[i] = __builtin_bit_cast(bf16x8, ua);
+        b[i] = __builtin_bit_cast(bf16x8, ub);
+    }
     f32x4 acc[4][4];
     for (int m = 0; m < 4; ++m) for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0, 0, 0, 0};
     float v = threadIdx.x * 0.001f;
@@ -37,15 +48,15 @@ __global__ __launch_bounds__(512, 2) void k(float* out, int iters, int admin, lo
     if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
 }
 
-template <int MODE>
+template <int MODE, bool RANDOM = false>
 void run(const char* name, int admin) {
     float* out; long long* cyc;
     hipMalloc(&out, 256 * 512 * sizeof(float)); hipMalloc(&cyc, 8);
-    const int iters = 2000, grid = 256;
+    const int iters = 4000, grid = 256;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    k<MODE><<<grid, 512>>>(out, 10, admin, cyc);
+    k<MODE, RANDOM><<<grid, 512>>>(out, 10, admin, cyc);
     hipEventRecord(e0);
-    k<MODE><<<grid, 512>>>(out, iters, admin, cyc);
+    k<MODE, RANDOM><<<grid, 512>>>(out, iters, admin, cyc);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
@@ -55,6 +66,11 @@ void run(const char* name, int admin) {
 }
 
 int main() {
+    // operand data: near-constant vs pseudo-random (the clock the chip sustains depends on it)
+    run<0, false>("pure MFMA, near-constant operands", 0);
+    run<0, true>("pure MFMA, pseudo-random operands", 0);
+    run<0, false>("pure MFMA, near-constant operands", 0);
+    run<0, true>("pure MFMA, pseudo-random operands", 0);
     for (int admin : {0, 50, 100, 200}) {
         run<0>("admin first in all waves", admin);
         run<1>("admin first (w0-3) / last (w4-7)", admin);
