@@ -92,8 +92,11 @@ __global__ void zero_kernel(TV t) {
 }
 
 // fold targets of one (n, channel block): rows 1 and h-2 (all x), then cols 1 and w-2 (remaining y)
+// zero_src: also zero the halo granules this target folded in.  Every halo pixel mirrors onto exactly ONE interior pixel
+// (reflect_idx is a function) and every target is handled by one thread, so there is no hazard and no second launch; only
+// valid for h, w >= 4 (below that the two fold rows / cols coincide and the host keeps the separate zero_halo pass).
 template <typename T>
-__global__ void fold_targets_kernel(TV t) {
+__global__ void fold_targets_kernel(TV t, int zero_src) {
     const int per = 2 * t.w + 2 * t.h;
     const long long total = (long long)t.n * t.cb * per;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -108,6 +111,17 @@ __global__ void fold_targets_kernel(TV t) {
         float v[8];
         load_grad_fold<T>(t, n, c, y, x, v);   // reads this pixel's interior + halo sources only: no hazard between targets
         Elem<T>::store(t.base + t.gidx(n, c, y + 1, x + 1) * Elem<T>::gran_bytes, v);
+        if (zero_src) {
+            const float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            // stored coordinates of the mirrored halo rows / cols (as in load_grad_fold), -1 = none
+            const int ys[3] = {y + 1, (y == 1) ? 0 : -1, (y == t.h - 2) ? t.h + 1 : -1};
+            const int xs[3] = {x + 1, (x == 1) ? 0 : -1, (x == t.w - 2) ? t.w + 1 : -1};
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b)
+                    if ((a | b) != 0 && ys[a] >= 0 && xs[b] >= 0) Elem<T>::store(t.base + t.gidx(n, c, ys[a], xs[b]) * Elem<T>::gran_bytes, z);
+        }
     }
 }
 
@@ -272,9 +286,11 @@ extern "C" int mmif_fold_halo(const mmif_tensor* t, void* stream) {
     TV v = make_tv(&u);
     const long long n1 = (long long)v.n * v.cb * (2 * v.w + 2 * v.h), n2 = (long long)v.n * v.cb * (2 * v.ws + 2 * v.hs);
     hipStream_t st = (hipStream_t)stream;
-    if (t->dtype == MMIF_F32) hipLaunchKernelGGL(fold_targets_kernel<float>, dim3(grid_for(n1)), dim3(256), 0, st, v);
-    else hipLaunchKernelGGL(fold_targets_kernel<bf16_t>, dim3(grid_for(n1)), dim3(256), 0, st, v);
+    const int fused = (v.h >= 4 && v.w >= 4) ? 1 : 0;
+    if (t->dtype == MMIF_F32) hipLaunchKernelGGL(fold_targets_kernel<float>, dim3(grid_for(n1)), dim3(256), 0, st, v, fused);
+    else hipLaunchKernelGGL(fold_targets_kernel<bf16_t>, dim3(grid_for(n1)), dim3(256), 0, st, v, fused);
     if (int rc = check_launch("fold_targets")) return rc;
+    if (fused) return MMIF_OK;
     if (t->dtype == MMIF_F32) hipLaunchKernelGGL(zero_halo_kernel<float>, dim3(grid_for(n2)), dim3(256), 0, st, v);
     else hipLaunchKernelGGL(zero_halo_kernel<bf16_t>, dim3(grid_for(n2)), dim3(256), 0, st, v);
     return check_launch("zero_halo");

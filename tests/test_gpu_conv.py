@@ -106,3 +106,32 @@ def test_dma_staged_kernels_equal_register_staged(cin, cout, n, h, w):
     assert torch.equal(res[0][1], res[1][1]), "dgrad differs"
     close(res[1][2].cpu().numpy(), res[0][2].cpu().numpy(), 2e-5, "dw")
     close(res[1][3].cpu().numpy(), res[0][3].cpu().numpy(), 2e-5, "db")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("n,c,h,w", [(2, 16, 9, 12), (1, 24, 4, 4), (1, 8, 3, 5), (2, 8, 2, 2)])
+def test_fold_halo_is_reflect_pad_adjoint_and_zeroes_halo(dtype, n, c, h, w):
+    """mmif_fold_halo on a padded-domain gradient: interior = adjoint of F.pad(mode='reflect', 1) applied to the stored
+    [h+2][w+2] map, halo ring = 0 afterwards (the DMA-staged dgrad reads that ring as its zero fill)."""
+    from mmif import tensor as T
+    torch.manual_seed(h * 31 + w)
+    g = T.BT.alloc(n, c, h, w, dtype, "cuda:0", halo=1)
+    g.buf.normal_()
+    full = g.buf.float().cpu().numpy().copy()            # [n][cb][h+2][w+2][8]
+    want = full[:, :, 1:-1, 1:-1].copy()
+    def R(t, L):
+        t = -t if t < 0 else t
+        return 2 * (L - 1) - t if t >= L else t
+    for ys in range(h + 2):
+        for xs in range(w + 2):
+            if 1 <= ys <= h and 1 <= xs <= w:
+                continue
+            want[:, :, R(ys - 1, h), R(xs - 1, w)] += full[:, :, ys, xs]
+    folded = g.fold_halo_()
+    torch.cuda.synchronize()
+    got = folded.buf.float().cpu().numpy()
+    tol = 1e-6 if dtype == torch.float32 else 2e-2
+    assert np.abs(got[:, :, 1:-1, 1:-1] - want).max() <= tol * max(1.0, np.abs(want).max())
+    ring = got.copy()
+    ring[:, :, 1:-1, 1:-1] = 0
+    assert np.abs(ring).max() == 0.0, "halo ring must be zero after the fold"
