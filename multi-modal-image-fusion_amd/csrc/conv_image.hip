@@ -53,68 +53,74 @@ __global__ __launch_bounds__(256) void image_in_fwd_kernel(const float* __restri
 }
 
 // ---------------------------------------------------------------- Cin == 1 wgrad
-// dw[o][tap] = sum_p g[p][o] * img[R(p+tap-P)], db[o] = sum_p g[p][o] for one group of 16 output channels.
-// One pixel per thread per iteration (grid-stride), 16*KK + 16 accumulators in registers, wave-shuffle
-// + LDS block reduction at the end; partial layout per (block, og): [16 o][KK] then [16] bias sums.
+// dw[o][tap] = sum_p g[p][o] * img[R(p+tap-P)], db[o] = sum_p g[p][o].
+// blockIdx.y = channel block (8 output channels per thread: 8*KK + 8 accumulators as packed fp32 pairs, v_pk_fma_f32);
+// one pixel per thread per iteration (grid-stride), wave-shuffle + LDS block reduction at the end; the partial of
+// (block, 16-channel group og) keeps the layout [16 o][KK] then [16] bias sums, each channel block filling its half.
+typedef float f32x2_i __attribute__((ext_vector_type(2)));
 template <typename T, int KS>
 __global__ __launch_bounds__(256) void image_in_wgrad_kernel(const float* __restrict__ img, TV tg, float* __restrict__ partial,
                                                              int cout, long long npix) {
-    constexpr int KK = KS * KS, P = KS / 2, PER = 16 * KK + 16;
-    __shared__ float red[4][PER];
-    const int tid = threadIdx.x, og = blockIdx.y;
-    float acc[16][KK], accb[16];
+    constexpr int KK = KS * KS, P = KS / 2, PER = 16 * KK + 16, HALF = 8 * KK + 8;
+    __shared__ float red[4][HALF];
+    const int tid = threadIdx.x, cb = blockIdx.y, n_og = (gridDim.y + 1) / 2;
+    f32x2_i acc[4][KK], accb[4];
 #pragma unroll
-    for (int o = 0; o < 16; ++o) {
-        accb[o] = 0.f;
+    for (int k = 0; k < 4; ++k) {
+        accb[k] = (f32x2_i){0.f, 0.f};
 #pragma unroll
-        for (int t = 0; t < KK; ++t) acc[o][t] = 0.f;
+        for (int t = 0; t < KK; ++t) acc[k][t] = (f32x2_i){0.f, 0.f};
     }
     const int hw = tg.h * tg.w;
     for (long long pix = (long long)blockIdx.x * 256 + tid; pix < npix; pix += (long long)gridDim.x * 256) {
         const int in_ = (int)(pix / hw), r = (int)(pix % hw);
         const int y = r / tg.w, x = r % tg.w;
-        float gv[16];
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            float v[8];
-            const int gcb = og * 2 + b;
-            if (gcb < tg.cb) load_grad_fold<T>(tg, in_, gcb, y, x, v);
-            else {
-#pragma unroll
-                for (int c = 0; c < 8; ++c) v[c] = 0.f;
-            }
-#pragma unroll
-            for (int c = 0; c < 8; ++c) gv[b * 8 + c] = v[c];
-        }
+        float v[8];
+        load_grad_fold<T>(tg, in_, cb, y, x, v);
         const float* im = img + (long long)in_ * hw;
+        // reflect the KS rows / cols once (the index arithmetic, not the FMAs, dominated this kernel)
+        int ry[KS], rx[KS];
+#pragma unroll
+        for (int u = 0; u < KS; ++u) {
+            ry[u] = min(max(reflect_idx(y + u - P, tg.h), 0), tg.h - 1) * tg.w;
+            rx[u] = min(max(reflect_idx(x + u - P, tg.w), 0), tg.w - 1);
+        }
         float iv[KK];
 #pragma unroll
-        for (int t = 0; t < KK; ++t) iv[t] = img_reflect(im, tg.h, tg.w, y + t / KS - P, x + t % KS - P);
+        for (int t = 0; t < KK; ++t) iv[t] = im[ry[t / KS] + rx[t % KS]];
 #pragma unroll
-        for (int o = 0; o < 16; ++o) {
-            accb[o] += gv[o];
+        for (int k = 0; k < 4; ++k) {
+            const f32x2_i gp = {v[2 * k], v[2 * k + 1]};
+            accb[k] += gp;
 #pragma unroll
-            for (int t = 0; t < KK; ++t) acc[o][t] = fmaf(gv[o], iv[t], acc[o][t]);
+            for (int t = 0; t < KK; ++t) acc[k][t] = __builtin_elementwise_fma(gp, (f32x2_i){iv[t], iv[t]}, acc[k][t]);
         }
     }
     const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
-    for (int o = 0; o < 16; ++o) {
+    for (int k = 0; k < 4; ++k)
 #pragma unroll
-        for (int t = 0; t < KK; ++t) {
-            float v = acc[o][t];
+        for (int hlf = 0; hlf < 2; ++hlf) {
+#pragma unroll
+            for (int t = 0; t < KK; ++t) {
+                float v = hlf ? acc[k][t].y : acc[k][t].x;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+                if (lane == 0) red[wave][(2 * k + hlf) * KK + t] = v;
+            }
+            float v = hlf ? accb[k].y : accb[k].x;
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-            if (lane == 0) red[wave][o * KK + t] = v;
+            if (lane == 0) red[wave][8 * KK + 2 * k + hlf] = v;
         }
-        float v = accb[o];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if (lane == 0) red[wave][16 * KK + o] = v;
-    }
     __syncthreads();
-    float* dst = partial + ((long long)blockIdx.x * gridDim.y + og) * PER;
-    for (int e = tid; e < PER; e += 256) dst[e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    float* dst = partial + ((long long)blockIdx.x * n_og + (cb >> 1)) * PER;
+    for (int e = tid; e < HALF; e += 256) {
+        const float t = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+        if (e < 8 * KK) dst[(cb & 1) * 8 * KK + e] = t;
+        else dst[16 * KK + (cb & 1) * 8 + (e - 8 * KK)] = t;
+    }
+    (void)cout;
 }
 
 // fixed-order reduction over the G block partials: 64 outputs x 4 G-slices per block, 4 load chains per thread
@@ -174,11 +180,19 @@ __global__ __launch_bounds__(256) void image_out_fwd_kernel(TV tx, const float* 
     const int in_ = blockIdx.y;
     if (y >= tx.h || x >= tx.w) return;
     float r = bias ? bias[0] : 0.f;
+    // reflected rows / cols once per pixel (granule offsets inside a plane)
+    int ry[KS], rx[KS];
+#pragma unroll
+    for (int u = 0; u < KS; ++u) {
+        ry[u] = min(max(reflect_idx(y + u - P, tx.h), 0), tx.h - 1) * tx.ws;
+        rx[u] = min(max(reflect_idx(x + u - P, tx.w), 0), tx.w - 1);
+    }
     for (int b = 0; b < tx.cb; ++b) {
+        const char* plane = tx.base + tx.gidx(in_, b, 0, 0) * Elem<T>::gran_bytes;
 #pragma unroll
         for (int t = 0; t < KK; ++t) {
             float v[8];
-            load_act_reflect<T>(tx, in_, b, y + t / KS - P, x + t % KS - P, v);
+            Elem<T>::load(plane + (long long)(ry[t / KS] + rx[t % KS]) * Elem<T>::gran_bytes, v);
 #pragma unroll
             for (int i = 0; i < 8; ++i)
                 if (b * 8 + i < cin) r = fmaf(v[i], wsm[(b * 8 + i) * KK + t], r);
@@ -247,60 +261,86 @@ __global__ __launch_bounds__(256) void image_out_dgrad_kernel(const float* __res
 }
 
 // ---------------------------------------------------------------- Cout == 1 wgrad
-// dw[0][c][tap] = sum_p g[p] * x[R(p+tap-P)][c], db = sum_p g[p] for one group of 16 input channels.
-// Same scheme as image_in_wgrad: one pixel per thread per iteration, 16*KK + 1 register accumulators;
-// partial per (block, cg): [16 c][KK] then [1] bias.
+// dw[0][c][tap] = sum_p g[p] * xpad[p+tap-P][c] (xpad = reflect-padded x), db = sum_p g[p].
+// Re-indexed by the SOURCE position pp = p + tap - P of the padded domain [-P, h-1+P] x [-P, w-1+P]:
+//   dw[c][tap] = sum_pp xpad[pp][c] * g[pp - tap + P]        (g zero outside the image)
+// so each thread loads ONE activation granule per position (instead of one per tap) plus KK scalar g values (fp32 image,
+// cached).  blockIdx.y = channel block (8 input channels, packed fp32 pair accumulators); partial per (block, 16-channel
+// group cg): [16 c][KK] then [1] bias (written by channel block 0).
 template <typename T, int KS>
 __global__ __launch_bounds__(256) void image_out_wgrad_kernel(TV tx, const float* __restrict__ gimg, const float* __restrict__ yimg,
                                                               float* __restrict__ partial, long long npix) {
-    constexpr int KK = KS * KS, P = KS / 2, PER = 16 * KK + 1;
-    __shared__ float red[4][PER];
-    const int tid = threadIdx.x, cg = blockIdx.y;
-    float acc[16][KK], accb = 0.f;
+    constexpr int KK = KS * KS, P = KS / 2, PER = 16 * KK + 1, HALF = 8 * KK + 1;
+    __shared__ float red[4][HALF];
+    const int tid = threadIdx.x, cb = blockIdx.y, n_cg = (gridDim.y + 1) / 2;
+    f32x2_i acc[4][KK];
+    float accb = 0.f;
 #pragma unroll
-    for (int c = 0; c < 16; ++c)
+    for (int k = 0; k < 4; ++k)
 #pragma unroll
-        for (int t = 0; t < KK; ++t) acc[c][t] = 0.f;
-    const int hw = tx.h * tx.w;
-    for (long long pix = (long long)blockIdx.x * 256 + tid; pix < npix; pix += (long long)gridDim.x * 256) {
-        const int in_ = (int)(pix / hw), r = (int)(pix % hw);
-        const int y = r / tx.w, x = r % tx.w;
-        float g = gimg[pix];
-        if (yimg != nullptr && !(yimg[pix] > 0.f)) g = 0.f;
-        accb += g;
+        for (int t = 0; t < KK; ++t) acc[k][t] = (f32x2_i){0.f, 0.f};
+    const int H = tx.h, W = tx.w, hp = H + 2 * P, wp = W + 2 * P;
+    const long long hwp = (long long)hp * wp, total = (long long)tx.n * hwp;
+    for (long long pos = (long long)blockIdx.x * 256 + tid; pos < total; pos += (long long)gridDim.x * 256) {
+        const int in_ = (int)(pos / hwp), r = (int)(pos % hwp);
+        const int py = r / wp - P, px = r % wp - P;
+        float v[8];
+        load_act_reflect<T>(tx, in_, cb, py, px, v);
+        const float* gi = gimg + (long long)in_ * H * W;
+        const float* yi = yimg ? yimg + (long long)in_ * H * W : nullptr;
+        // KS rows / cols of g around pp: clamped offsets + validity once per row / col, branch-free loads
+        int oy[KS], ox[KS];
+        bool vy[KS], vx[KS];
+#pragma unroll
+        for (int u = 0; u < KS; ++u) {
+            const int yy = py - u + P, xx = px - u + P;
+            vy[u] = yy >= 0 && yy < H;
+            vx[u] = xx >= 0 && xx < W;
+            oy[u] = min(max(yy, 0), H - 1) * W;
+            ox[u] = min(max(xx, 0), W - 1);
+        }
+        float g[KK];
 #pragma unroll
         for (int t = 0; t < KK; ++t) {
+            const int o = oy[t / KS] + ox[t % KS];
+            float gv = gi[o];
+            if (yi != nullptr && !(yi[o] > 0.f)) gv = 0.f;
+            g[t] = (vy[t / KS] && vx[t % KS]) ? gv : 0.f;
+        }
+        if (py >= 0 && py < H && px >= 0 && px < W) accb += g[P * KS + P];   // tap (P, P): g at pp itself
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const int xcb = cg * 2 + b;
-                if (xcb < tx.cb) {
-                    float v[8];
-                    load_act_reflect<T>(tx, in_, xcb, y + t / KS - P, x + t % KS - P, v);
+        for (int k = 0; k < 4; ++k) {
+            const f32x2_i xp = {v[2 * k], v[2 * k + 1]};
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) acc[b * 8 + c][t] = fmaf(g, v[c], acc[b * 8 + c][t]);
-                }
-            }
+            for (int t = 0; t < KK; ++t) acc[k][t] = __builtin_elementwise_fma(xp, (f32x2_i){g[t], g[t]}, acc[k][t]);
         }
     }
     const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
-    for (int c = 0; c < 16; ++c)
+    for (int k = 0; k < 4; ++k)
 #pragma unroll
-        for (int t = 0; t < KK; ++t) {
-            float v = acc[c][t];
+        for (int hlf = 0; hlf < 2; ++hlf)
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-            if (lane == 0) red[wave][c * KK + t] = v;
-        }
+            for (int t = 0; t < KK; ++t) {
+                float v = hlf ? acc[k][t].y : acc[k][t].x;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+                if (lane == 0) red[wave][(2 * k + hlf) * KK + t] = v;
+            }
     {
         float v = accb;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if (lane == 0) red[wave][16 * KK] = v;
+        if (lane == 0) red[wave][8 * KK] = v;
     }
     __syncthreads();
-    float* dst = partial + ((long long)blockIdx.x * gridDim.y + cg) * PER;
-    for (int e = tid; e < PER; e += 256) dst[e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    float* dst = partial + ((long long)blockIdx.x * n_cg + (cb >> 1)) * PER;
+    for (int e = tid; e < HALF; e += 256) {
+        const float t = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+        if (e < 8 * KK) dst[(cb & 1) * 8 * KK + e] = t;
+        else if (cb == 0) dst[16 * KK] = t;
+    }
+    (void)npix;
 }
 
 template <int KS>
@@ -377,7 +417,7 @@ extern "C" int mmif_conv2d_image_in_wgrad(const float* img, const mmif_tensor* g
     const int n_og = cdiv(cout, 16);
     hipStream_t st = (hipStream_t)stream;
     float* ws = (float*)workspace;
-#define CALL(T, KS) hipLaunchKernelGGL((image_in_wgrad_kernel<T, KS>), dim3(G, n_og), dim3(256), 0, st, img, tg, ws, cout, npix)
+#define CALL(T, KS) hipLaunchKernelGGL((image_in_wgrad_kernel<T, KS>), dim3(G, tg.cb), dim3(256), 0, st, img, tg, ws, cout, npix)
     DISPATCH_T_KS(gy->dtype, ksize, CALL);
 #undef CALL
     if (int rc = check_launch("image_in_wgrad")) return rc;
@@ -444,7 +484,7 @@ extern "C" int mmif_conv2d_image_out_wgrad(const mmif_tensor* x, const float* gi
     const int n_cg = cdiv(cin, 16);
     hipStream_t st = (hipStream_t)stream;
     float* ws = (float*)workspace;
-#define CALL(T, KS) hipLaunchKernelGGL((image_out_wgrad_kernel<T, KS>), dim3(G, n_cg), dim3(256), 0, st, tx, gimg, y_img, ws, npix)
+#define CALL(T, KS) hipLaunchKernelGGL((image_out_wgrad_kernel<T, KS>), dim3(G, tx.cb), dim3(256), 0, st, tx, gimg, y_img, ws, npix)
     DISPATCH_T_KS(x->dtype, ksize, CALL);
 #undef CALL
     if (int rc = check_launch("image_out_wgrad")) return rc;
