@@ -9,17 +9,23 @@ import torch
 from mmif import tensor as T
 from mmif._lib import lib, IMPL_MFMA
 cin, cout, B, S = [int(a) for a in (sys.argv[1:5] + ["128", "128", "32", "256"][len(sys.argv) - 1:])]
+kind = sys.argv[5] if len(sys.argv) > 5 else "fwd"   # fwd | dgrad
 dev = "cuda:0"
 x = T.BT.alloc(B, cin, S, S, torch.bfloat16, dev); x.buf.normal_()
 y = T.BT.alloc(B, cout, S, S, torch.bfloat16, dev)
 w = torch.randn(cout, cin, 3, 3, device=dev) * 0.03; b = torch.zeros(cout, device=dev)
 pk = T.PackedWeights(cout, cin, 3, dev); pk.pack(w)
-for _ in range(3): T.conv_fwd(x, w, b, y, cin, cout, 3, True, pk, IMPL_MFMA)
+gy = T.BT.alloc(B, cout, S, S, torch.bfloat16, dev, halo=1, zero=True); gy.buf[:, :, 1:-1, 1:-1].normal_(); gy = gy.as_folded()
+gx = T.BT.alloc(B, cin, S, S, torch.bfloat16, dev, halo=1)
+def launch():
+    if kind == "fwd": T.conv_fwd(x, w, b, y, cin, cout, 3, True, pk, IMPL_MFMA)
+    else: T.conv_dgrad(gy, w, x, gx, cin, cout, 3, (1 << gx.cb) - 1, 0, pk, IMPL_MFMA)
+for _ in range(3): launch()
 tr = torch.zeros(1024, 64, dtype=torch.int64, device=dev)
 lib.mmif_debug_set_trace(C.c_void_p(tr.data_ptr()))
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
-T.conv_fwd(x, w, b, y, cin, cout, 3, True, pk, IMPL_MFMA)
+launch()
 e1.record()
 torch.cuda.synchronize(); lib.mmif_debug_set_trace(None)
 traced_ms = e0.elapsed_time(e1)
@@ -28,7 +34,7 @@ n = int(t[0, 0, 63])
 nq = (n - 1) // 5
 # stamps: [0] kernel start; chunk q: 1+5q chunk top, 2+5q barrier passed, 3+5q pending epilogue done, 4+5q k-loop done, 5+5q tile epilogue done
 names = ["wait at barrier", "pending epilogue (waves 4-7)", "k-loop", "tile epilogue (waves 0-3)", "loop overhead"]
-print(f"conv_dma {cin}->{cout} B={B} {S}x{S}: {n} stamps/wave; median cycles over 128 blocks, chunks 1..{nq - 1}; one column per consumer wave")
+print(f"conv_dma {kind} {cin}->{cout} B={B} {S}x{S}: {n} stamps/wave; median cycles over 128 blocks, chunks 1..{nq - 1}; one column per consumer wave")
 for k, nm in enumerate(names):
     lo = [1 + 5 * q + k for q in range(1, nq - 1)]
     hi = [2 + 5 * q + k for q in range(1, nq - 1)]
