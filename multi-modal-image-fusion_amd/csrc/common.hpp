@@ -175,6 +175,27 @@ __device__ inline float block_sum(float v, float* smem /* >= 16 floats */) {
     return r;
 }
 
+// linear index -> (n, c, y, x) of a [n][c][h][w] iteration space; 32-bit arithmetic whenever the index fits (it always does for
+// the shapes on this path) instead of four 64-bit divisions per element.  (Measured: no effect on the glue kernels' time -- they
+// stream at 5+ TB/s either way -- kept because it is the cheaper code.)
+__device__ inline void split_idx(long long i, int cdim, int h, int w, int& n, int& c, int& y, int& x) {
+    if (i < 0xffffffffll) {
+        unsigned u = (unsigned)i;
+        const unsigned q1 = u / (unsigned)w;
+        x = (int)(u - q1 * (unsigned)w);
+        const unsigned q2 = q1 / (unsigned)h;
+        y = (int)(q1 - q2 * (unsigned)h);
+        const unsigned q3 = q2 / (unsigned)cdim;
+        c = (int)(q2 - q3 * (unsigned)cdim);
+        n = (int)q3;
+    } else {
+        x = (int)(i % w);
+        y = (int)((i / w) % h);
+        c = (int)((i / ((long long)w * h)) % cdim);
+        n = (int)(i / ((long long)w * h * cdim));
+    }
+}
+
 inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace mmif

@@ -51,8 +51,8 @@ template <typename T>
 __global__ void nchw_to_blocked_kernel(const float* __restrict__ src, int c, TV dst) {
     const long long total = (long long)dst.n * dst.cb * dst.h * dst.w;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int x = i % dst.w, y = (i / dst.w) % dst.h, b = (i / ((long long)dst.w * dst.h)) % dst.cb;
-        const int n = i / ((long long)dst.w * dst.h * dst.cb);
+        int n, b, y, x;
+        split_idx(i, dst.cb, dst.h, dst.w, n, b, y, x);
         float v[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -67,8 +67,8 @@ template <typename T>
 __global__ void blocked_to_nchw_kernel(TV src, float* __restrict__ dst, int c) {
     const long long total = (long long)src.n * src.cb * src.h * src.w;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int x = i % src.w, y = (i / src.w) % src.h, b = (i / ((long long)src.w * src.h)) % src.cb;
-        const int n = i / ((long long)src.w * src.h * src.cb);
+        int n, b, y, x;
+        split_idx(i, src.cb, src.h, src.w, n, b, y, x);
         float v[8];
         load_grad_fold<T>(src, n, b, y, x, v);  // halo 0: plain load; halo 1: folded gradient
 #pragma unroll
@@ -146,8 +146,8 @@ template <typename T>
 __global__ void fuse_elem_fwd_kernel(TV a, TV b, TV o, int mode) {
     const long long total = (long long)o.n * o.cb * o.h * o.w;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int x = i % o.w, y = (i / o.w) % o.h, c = (i / ((long long)o.w * o.h)) % o.cb;
-        const int n = i / ((long long)o.w * o.h * o.cb);
+        int n, c, y, x;
+        split_idx(i, o.cb, o.h, o.w, n, c, y, x);
         float va[8], vb[8], vo[8];
         Elem<T>::load(a.base + a.gidx(n, c, y, x) * Elem<T>::gran_bytes, va);
         Elem<T>::load(b.base + b.gidx(n, c, y, x) * Elem<T>::gran_bytes, vb);
@@ -163,8 +163,8 @@ template <typename T>
 __global__ void fuse_elem_bwd_kernel(TV a, TV b, TV g, TV ga, TV gb, int mode, int relu_mask) {
     const long long total = (long long)g.n * g.cb * g.hs * g.ws;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int xs = i % g.ws, ys = (i / g.ws) % g.hs, c = (i / ((long long)g.ws * g.hs)) % g.cb;
-        const int n = i / ((long long)g.ws * g.hs * g.cb);
+        int n, c, ys, xs;
+        split_idx(i, g.cb, g.hs, g.ws, n, c, ys, xs);
         float vg[8], va[8], vb[8], oa[8], ob[8];
         Elem<T>::load(g.base + g.gidx(n, c, ys, xs) * Elem<T>::gran_bytes, vg);
         const bool need_ab = relu_mask || mode == MMIF_FUSE_MAX;

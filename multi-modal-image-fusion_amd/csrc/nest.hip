@@ -33,7 +33,8 @@ template <typename T>
 __global__ void maxpool_fwd_kernel(TV x, TV y) {
     const long long total = (long long)y.n * y.cb * y.h * y.w;
     GRID_STRIDE(i, total) {
-        const int xo = i % y.w, yo = (i / y.w) % y.h, c = (i / ((long long)y.w * y.h)) % y.cb, n = i / ((long long)y.w * y.h * y.cb);
+        int n, c, yo, xo;
+        split_idx(i, y.cb, y.h, y.w, n, c, yo, xo);
         float a[8], b[8], d[8], e[8], o[8];
         ld<T>(x, n, c, 2 * yo, 2 * xo, a);
         ld<T>(x, n, c, 2 * yo, 2 * xo + 1, b);
@@ -50,7 +51,8 @@ template <typename T>
 __global__ void maxpool_bwd_kernel(TV x, TV g, TV gx, int accumulate) {
     const long long total = (long long)x.n * x.cb * x.h * x.w;
     GRID_STRIDE(i, total) {
-        const int xi = i % x.w, yi = (i / x.w) % x.h, c = (i / ((long long)x.w * x.h)) % x.cb, n = i / ((long long)x.w * x.h * x.cb);
+        int n, c, yi, xi;
+        split_idx(i, x.cb, x.h, x.w, n, c, yi, xi);
         float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const int yo = yi >> 1, xo = xi >> 1;
         if (yo < g.h && xo < g.w) {
@@ -90,7 +92,8 @@ __global__ void upsample_fwd_kernel(TV x, TV y) {
     const int top = (y.h - 2 * x.h) / 2, left = (y.w - 2 * x.w) / 2;
     const long long total = (long long)y.n * y.cb * y.h * y.w;
     GRID_STRIDE(i, total) {
-        const int xo = i % y.w, yo = (i / y.w) % y.h, c = (i / ((long long)y.w * y.h)) % y.cb, n = i / ((long long)y.w * y.h * y.cb);
+        int n, c, yo, xo;
+        split_idx(i, y.cb, y.h, y.w, n, c, yo, xo);
         float v[8];
         ld<T>(x, n, c, up_src(yo, top, 2 * x.h), up_src(xo, left, 2 * x.w), v);
         st<T>(y, n, c, yo, xo, v);
@@ -104,7 +107,8 @@ __global__ void upsample_bwd_kernel(TV g, TV gx, int accumulate) {
     const int top = (g.h - H2) / 2, left = (g.w - W2) / 2;
     const long long total = (long long)gx.n * gx.cb * gx.h * gx.w;
     GRID_STRIDE(i, total) {
-        const int xi = i % gx.w, yi = (i / gx.w) % gx.h, c = (i / ((long long)gx.w * gx.h)) % gx.cb, n = i / ((long long)gx.w * gx.h * gx.cb);
+        int n, c, yi, xi;
+        split_idx(i, gx.cb, gx.h, gx.w, n, c, yi, xi);
         float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         // candidates: the 2 direct rows / cols plus the (few) reflected pad rows / cols that mirror onto them
         const int bot = g.h - top - H2, right = g.w - left - W2;
@@ -136,7 +140,8 @@ template <typename T>
 __global__ void relu_mask_kernel(TV x, TV g) {
     const long long total = (long long)g.n * g.cb * g.hs * g.ws;
     GRID_STRIDE(i, total) {
-        const int xs = i % g.ws, ys = (i / g.ws) % g.hs, c = (i / ((long long)g.ws * g.hs)) % g.cb, n = i / ((long long)g.ws * g.hs * g.cb);
+        int n, c, ys, xs;
+        split_idx(i, g.cb, g.hs, g.ws, n, c, ys, xs);
         float gv[8], xv[8];
         ld<T>(g, n, c, ys, xs, gv);
         load_act_reflect<T>(x, n, c, ys - g.halo, xs - g.halo, xv);
@@ -205,7 +210,8 @@ __global__ void attn_fwd_kernel(TV a, TV b, TV o, const float* __restrict__ csum
     const float inv_hw = 1.f / ((float)a.h * a.w);
     const float scale = mode == 3 ? 0.5f : 1.f;
     GRID_STRIDE(i, total) {
-        const int x = i % o.w, y = (i / o.w) % o.h, n = i / ((long long)o.w * o.h);
+        int n, c_unused, y, x;
+        split_idx(i, 1, o.h, o.w, n, c_unused, y, x);
         float ws = 0.f;
         if (mode & 1) {
             float s1 = 0.f, s2 = 0.f;
@@ -249,7 +255,8 @@ __global__ void attn_bwd_kernel(TV a, TV b, TV g, TV ga, TV gb, const float* __r
     const float inv_hw = 1.f / ((float)a.h * a.w);
     const float scale = mode == 3 ? 0.5f : 1.f;
     GRID_STRIDE(i, total) {
-        const int x = i % a.w, y = (i / a.w) % a.h, n = i / ((long long)a.w * a.h);
+        int n, c_unused, y, x;
+        split_idx(i, 1, a.h, a.w, n, c_unused, y, x);
         float s1 = 0.f, s2 = 0.f, gw = 0.f;
         if (mode & 1) {
             for (int c = 0; c < a.cb; ++c) {
