@@ -1162,12 +1162,16 @@ int conv_mfma(bool dgrad, int ks, const TV& tin, const TV& tout, const TV& tmask
 
 static inline int pick_mfw(int cout) { return cout <= 16 ? 1 : (cout <= 32 ? 2 : 4); }
 
+// tile groups per (icg, ocg) pair of the register-staged wgrad.  The grid is G * nb persistent blocks; it must fit the resident
+// capacity in ONE round (3 blocks/CU at MFW = 1 -- 136 VGPRs --, else 2; 256 CUs): 1032 blocks on 768 slots ran a second round
+// at 34 % occupancy.
 static int wgrad_G(int cin, int cout) {
-    const int nb = cdiv(cin, 16) * cdiv(cout, pick_mfw(cout) * 16);
-    int G = 1024 / nb;
-    if (G < 64) G = 64;
-    if (G > 512) G = 512;
-    return (G + 7) / 8 * 8;
+    const int mfw = pick_mfw(cout);
+    const int nb = cdiv(cin, 16) * cdiv(cout, mfw * 16);
+    const int capacity = 256 * (mfw == 1 ? 3 : 2);
+    int G = capacity / nb / 8 * 8;
+    if (G > 512) G = 512;   // (768 blocks for a single pair measured 8 % slower than 512)
+    return G < 8 ? 8 : G;
 }
 
 bool wgrad_mfma_supported(int ks, int cin, int cout) { return (ks == 1 || ks == 3) && cin >= 1 && cout >= 1; }
