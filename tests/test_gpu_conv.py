@@ -67,6 +67,9 @@ def test_conv_bf16_vs_oracle_on_rounded_operands(case, impl):
 
 
 DMA_SHAPES = [(128, 128, 2, 37, 53), (176, 112, 1, 64, 48), (72, 64, 2, 33, 40), (64, 184, 1, 40, 72), (96, 96, 3, 16, 16)]
+_rng = np.random.default_rng(20240)
+DMA_SHAPES += [(int(_rng.integers(7, 40)) * 8, int(_rng.integers(7, 32)) * 8, int(_rng.integers(1, 4)), int(_rng.integers(8, 90)),
+                int(_rng.integers(8, 90))) for _ in range(10)]   # seeded random shapes: ragged everything
 
 
 @pytest.mark.parametrize("cin,cout,n,h,w", DMA_SHAPES, ids=[f"{a}-{b}-{n}x{h}x{w}" for a, b, n, h, w in DMA_SHAPES])

@@ -19,11 +19,12 @@ gx = T.BT.alloc(B, cin, S, S, torch.bfloat16, dev, halo=1)
 w = torch.randn(cout, cin, 3, 3, device=dev) * 0.03; b = torch.randn(cout, device=dev)
 pk = T.PackedWeights(cout, cin, 3, dev); pk.pack(w)
 flops = 2.0 * B * S * S * cin * cout * 9
+MASK = int(os.environ.get("BENCH_MASK", str((1 << gx.cb) - 1)), 0)   # dgrad ReLU-mask bits (default: all channel blocks)
 dw = torch.zeros(cout, cin, 3, 3, device=dev); db = torch.zeros(cout, device=dev)
 ws = torch.empty(T.wgrad_workspace_bytes(cin, cout, 3) // 4 + 1, dtype=torch.float32, device=dev)
 def run(kind):
     if kind == "fwd": T.conv_fwd(x, w, b, y, cin, cout, 3, True, pk, IMPL_MFMA)
-    elif kind == "dgrad": T.conv_dgrad(gy, w, x, gx, cin, cout, 3, (1 << gx.cb) - 1, 0, pk, IMPL_MFMA)
+    elif kind == "dgrad": T.conv_dgrad(gy, w, x, gx, cin, cout, 3, MASK, 0, pk, IMPL_MFMA)
     else: T.conv_wgrad(x, gy, dw, db, cin, cout, 3, ws, False, IMPL_MFMA)
 def timeit(kind):
     for _ in range(3): run(kind)
