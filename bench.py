@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=2, help="image pairs in the CPU-oracle sample")
     ap.add_argument("--roofline-tag", default="decode.0:fwd", help="engine op timed with HIP events for `roofline`")
+    ap.add_argument("--hbm-tag", default="auto", help="an HBM-bound engine op timed the same way for `roofline_hbm` ('' = none)")
     return ap.parse_args()
 
 
@@ -127,7 +128,10 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    T.PROFILE_TAGS = {args.roofline_tag}
+    hbm_tag = args.hbm_tag
+    if hbm_tag == "auto":   # the widest thin layer of the model's encoder (Cout = 16): 48 -> 16 forward
+        hbm_tag = {"PFNetv1": "encode1.1.2:fwd", "DenseFuse": "encode.1.2:fwd", "PFNetv2": "encode.1.2:fwd"}.get(args.model, "") if args.mode == "train" else ""
+    T.PROFILE_TAGS = {args.roofline_tag} | ({hbm_tag} if hbm_tag else set())
     T.PROFILE_EVENTS.clear()
     if world > 1:
         dist.barrier()
@@ -172,6 +176,18 @@ def main():
                     if tj:
                         roof["traffic"] = tj["hbm_bytes_per_launch"]
                         roof["algorithmic_bytes"] = tj["algorithmic_bytes_per_launch"]
+        roof_hbm = None
+        evh = T.PROFILE_EVENTS.get(hbm_tag, []) if hbm_tag else []
+        if evh:
+            ms = sum(a.elapsed_time(b) for a, b in evh) / len(evh)
+            spec = [s for s in model._engine.specs if hbm_tag.startswith(s.name + ":")]
+            if spec:
+                s = spec[0]
+                esz = 2 if args.dtype == "bf16" else 4
+                nbytes = float(B) * S * Wd * (s.cin + s.cout) * esz      # algorithmic bytes of one conv pass
+                roof_hbm = {"bound": "hbm", "kernel": f"conv_mfma_kernel {s.cin}->{s.cout} k{s.k} ({hbm_tag})", "achieved": nbytes / (ms * 1e-3) / 1e9,
+                            "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": nbytes / (ms * 1e-3) / PEAK_HBM, "avg_launch_ms": ms,
+                            "launches": len(evh), "traffic": None}
         out = {
             "metric": "image-pairs/sec at 256x256, PFNet train step" if args.mode == "train" else f"image-pairs/sec at {Wd}x{S}, {args.model} inference", "value": value, "unit": "image-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -182,6 +198,7 @@ def main():
                        "step_model_tflops": MODEL_FLOPS_TRAIN.get(args.model, 0) * value / 1e12 if (S == 256 and Wd == 256 and args.mode == "train") else None},
             "final_loss": loss,
             "roofline": roof,
+            "roofline_hbm": roof_hbm,
             "cpu_baseline": None,
         }
         if world == 1 and not args.no_cpu_baseline and args.mode == "train" and Wd == S:

@@ -42,6 +42,37 @@ def test_c_abi_argument_validation_without_gpu():
     assert lib.mmif_conv2d_wgrad_workspace(128, 128, 3) > 0 and lib.mmif_loss_workspace(2, 64, 64) > 0
 
 
+def test_c_abi_validation_of_the_widened_entry_points_without_gpu():
+    """pair conv / SSIM modes / TV / patch feed: bad arguments are rejected before anything is launched (no GPU needed),
+    with the reference's messages where it has one."""
+    from mmif._lib import MmifTensor, lib
+    buf = (ctypes.c_char * 4096)()
+    base = ctypes.addressof(buf)
+    ok = MmifTensor(base, 1, 1, 4, 4, 0, 1, 0, 1, 0)            # bf16 [1][1 block][4][4][8] = 256 B
+    h1 = MmifTensor(base, 1, 1, 4, 4, 1, 1, 0, 1, 0)            # halo-1 view, NOT folded
+    w = (ctypes.c_float * 36)()
+    r = ctypes.byref
+    assert lib.mmif_pairconv_fwd(r(ok), r(ok), w, None, 3, r(ok), r(ok), 1, None, None, None) == -1
+    assert b"nout must be 1 or 2" in lib.mmif_last_error()
+    assert lib.mmif_pairconv_fwd(r(ok), r(ok), None, None, 2, r(ok), r(ok), 1, None, None, None) == -1
+    assert lib.mmif_pairconv_dgrad(r(h1), None, w, 1, None, None, r(h1), r(h1), 0, None, None) == -1
+    assert b"folded first" in lib.mmif_last_error()
+    assert lib.mmif_pairconv_wgrad(r(ok), r(ok), r(ok), None, 1, w, w, 0, None, 0, None) == -3            # workspace
+    assert lib.mmif_pairconv_wgrad_workspace() > 0
+    f = (ctypes.c_float * 16)()
+    assert lib.mmif_ssim_loss_mode(f, f, f, 1, 32, 32, 1.0, 1.0, 7, f, None, f, 1 << 20, None) == -1
+    assert b"only supported ['ssim', 'w-ssim', 'ms-ssim', 'msw-ssim'] mode" in lib.mmif_last_error()
+    assert lib.mmif_ssim_loss_mode(f, f, f, 1, 8, 8, 1.0, 1.0, 1, f, None, f, 1 << 20, None) == -1        # < 11x11
+    assert lib.mmif_ssim_loss_mode(f, f, f, 1, 32, 32, 1.0, 1.0, 1, f, None, f, 16, None) == -3
+    assert lib.mmif_ssim_loss_mode_workspace(2, 256, 256, 2) > lib.mmif_ssim_loss_mode_workspace(2, 256, 256, 1) > 0
+    assert lib.mmif_tv_loss(f, 1, 1, 8, 1.0, 0, f, None, f, 1 << 16, None) == -1                          # needs 2x2
+    assert lib.mmif_tv_loss(f, 1, 8, 8, 1.0, 0, f, None, f, 16, None) == -3
+    assert lib.mmif_patch_feed(f, 4, 8, f, None, 2, 5, f, None) == -1
+    assert b"only supported ['min-max', 'z-score'] mode" in lib.mmif_last_error()
+    assert lib.mmif_patch_feed(None, 4, 8, f, None, 2, 0, f, None) == -1
+    assert lib.mmif_fuse_attn_workspace(2, 64) > 0
+
+
 @pytest.mark.parametrize("name", ["PFNetv1", "PFNetv2", "DenseFuse", "NestFuse", "RFNNest"])
 def test_state_dict_manifest_and_init(name):
     import core.model as M
