@@ -12,7 +12,7 @@ import torch.nn as nn
 from mmif import tensor as T
 from mmif._lib import check, lib
 
-__all__ = ['SSIM', 'SSIMLoss', 'PixelLoss', 'GradLoss', 'TVLoss', 'NormLoss']
+__all__ = ['SSIM', 'MS_SSIM', 'MSW_SSIM', 'SSIMLoss', 'PixelLoss', 'GradLoss', 'TVLoss', 'NormLoss']
 
 eps = 1e-7
 
@@ -136,6 +136,36 @@ class SSIM(nn.Module):
             l = _LossFn.apply(img2[i:i + 1], img1[i:i + 1], img1[i:i + 1], 0, 1.0, float(self.data_range), 0)
             vals.append(1.0 - l)  # loss = 1 - (S(x,f)+S(x,f))/2 = 1 - S
         return {'ssim': torch.stack(vals)}
+
+
+class MS_SSIM(nn.Module):
+    """Multi-scale SSIM (reference core/loss.py:188-208, calc_msssim :113-160): per-sample values [N] of (img1, img2).
+    Runs on csrc/loss_modes.hip; the gradient flows to the SECOND argument (the fused image in every use of the reference)."""
+
+    def __init__(self, win_size=11, data_range=1.0, use_padding=False, size_average=True):
+        super(MS_SSIM, self).__init__()
+        if win_size != 11 or use_padding or not size_average:
+            raise NotImplementedError("the HIP MS-SSIM implements the reference's configuration: 11x11 window, no padding, per-sample mean")
+        self.win_size, self.data_range, self.use_padding, self.size_average = win_size, data_range, use_padding, size_average
+
+    def forward(self, img1, img2):
+        vals = [1.0 - _ModeLossFn.apply(img2[i:i + 1], img1[i:i + 1], img1[i:i + 1], _SSIM_MODES['ms-ssim'], 1.0, float(self.data_range))
+                for i in range(img1.shape[0])]
+        return torch.stack(vals)
+
+
+class MSW_SSIM(nn.Module):
+    """Multi-scale (windows 11/9/7/5/3) sigma-weighted SSIM of a fused image against its two sources
+    (reference core/loss.py:211-237): a 0-dim tensor, differentiable w.r.t. imgf."""
+
+    def __init__(self, win_sizes=(11, 9, 7, 5, 3), data_range=1.0, use_padding=False, size_average=False):
+        super(MSW_SSIM, self).__init__()
+        if tuple(win_sizes) != (11, 9, 7, 5, 3) or use_padding or size_average:
+            raise NotImplementedError("the HIP MSW-SSIM implements win_sizes=(11, 9, 7, 5, 3), no padding, per-pixel weights")
+        self.win_sizes, self.data_range, self.use_padding, self.size_average = tuple(win_sizes), data_range, use_padding, size_average
+
+    def forward(self, img1, img2, imgf):
+        return 1.0 - _ModeLossFn.apply(imgf, img1, img2, _SSIM_MODES['msw-ssim'], 1.0, float(self.data_range))
 
 
 class SSIMLoss(nn.Module):

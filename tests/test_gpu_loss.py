@@ -143,3 +143,25 @@ def test_ssim_mode_errors():
         TVLoss("l3")(z)
     with pytest.raises(Exception, match="161x161"):
         SSIMLoss("ms-ssim")(z, z, z)
+
+
+def test_ms_ssim_and_msw_ssim_classes():
+    """core.loss.MS_SSIM / MSW_SSIM (reference __all__): values vs the oracle / golden F9, gradient w.r.t. the fused image."""
+    from core.loss import MS_SSIM, MSW_SSIM
+    ref = np.load(os.path.join(G, "f9_ssim_modes.npz"))
+    shape = (2, 1, 40, 52)
+    i1n, i2n, fn = O.closed_form_image(shape, 0.3), O.closed_form_image(shape, 1.7), O.closed_form_image(shape, 2.9)
+    f = tg(fn).requires_grad_(True)
+    v = MSW_SSIM()(tg(i1n), tg(i2n), f)
+    want = 1.0 - float(ref["msw-ssim_2x40x52__loss"]) / 0.7        # golden loss was taken with weight 0.7
+    assert abs(float(v.detach()) - want) <= 1e-4
+    (0.7 * (1.0 - v)).backward()
+    close(f.grad.cpu().numpy(), ref["msw-ssim_2x40x52__grad"], 5e-4, "msw grad")
+    shape = (2, 1, 193, 211)
+    an, bn = O.closed_form_image(shape, 0.3), O.closed_form_image(shape, 2.9)
+    ms = MS_SSIM()(tg(an), tg(bn)).cpu().numpy()
+    for i in range(2):       # oracle: loss(a, a, b) = 1 - ms(a, b) for one sample
+        l, _ = O.ssim_mode_loss(an[i:i + 1], an[i:i + 1], bn[i:i + 1], "ms-ssim", need_grad=False)
+        assert abs(ms[i] - (1.0 - float(l))) <= 1e-4, (i, ms[i], 1.0 - float(l))
+    with pytest.raises(NotImplementedError):
+        MSW_SSIM(win_sizes=(11, 7))
