@@ -193,6 +193,11 @@ size_t mmif_ssim_loss_mode_workspace(int32_t n, int32_t h, int32_t w, int32_t mo
 int mmif_ssim_loss_mode(const float* img1, const float* img2, const float* imgf, int32_t n, int32_t h, int32_t w, float weight,
                         float data_range, int32_t mode, float* loss_out, float* grad_out, void* workspace, size_t workspace_bytes,
                         void* stream);
+/* SSIM module core/loss.py:163-185 (calc_ssim :52-110, size_average=True): per-sample means of the ssim map, the cs map and the
+ * clamped source variance of (img1, img2), window 3 | 5 | 7 | 9 | 11 -> out[3][n] on the device.  Values only; workspace as
+ * mmif_ssim_loss_mode_workspace(n, h, w, 1). */
+int mmif_ssim_terms(const float* img1, const float* img2, int32_t n, int32_t h, int32_t w, int32_t win_size, float data_range,
+                    float* out, void* workspace, size_t workspace_bytes, void* stream);
 /* TVLoss core/loss.py:347-358 = NormLoss(l1|l2)(x[1:] - x[:-1]) + NormLoss(x[:, 1:] - x[:, :-1]) over n images [h][w]. */
 size_t mmif_tv_loss_workspace(void);
 int mmif_tv_loss(const float* x, int32_t n, int32_t h, int32_t w, float weight, int32_t l2, float* loss_out, float* grad_out,

@@ -121,21 +121,30 @@ class _TVFn(torch.autograd.Function):
 
 
 class SSIM(nn.Module):
-    """Structural similarity (reference core/loss.py:163-185): returns {'ssim': per-sample mean}."""
+    """Structural similarity (reference core/loss.py:163-185): {'ssim', 'cs', 'sigma'} per-sample means of (img1, img2) for a
+    window of 3 / 5 / 7 / 9 / 11 taps.  'ssim' with the default 11x11 window is differentiable w.r.t. img2 (the fused image in
+    every use of the reference); 'cs' and 'sigma' are values."""
 
     def __init__(self, win_size=11, data_range=1.0, use_padding=False, size_average=True):
         super(SSIM, self).__init__()
-        if win_size != 11 or use_padding or not size_average:
-            raise NotImplementedError("the HIP SSIM kernel implements the training configuration: 11x11 window, no padding, per-sample mean")
+        if win_size not in (3, 5, 7, 9, 11) or use_padding or not size_average:
+            raise NotImplementedError("the HIP SSIM implements windows 3/5/7/9/11, no padding, per-sample means")
         self.win_size, self.data_range, self.use_padding, self.size_average = win_size, data_range, use_padding, size_average
 
     def forward(self, img1, img2):
-        # per-sample means: run the batch-1 kernel per sample slice (evaluation-side API, not the training path)
-        vals = []
-        for i in range(img1.shape[0]):
-            l = _LossFn.apply(img2[i:i + 1], img1[i:i + 1], img1[i:i + 1], 0, 1.0, float(self.data_range), 0)
-            vals.append(1.0 - l)  # loss = 1 - (S(x,f)+S(x,f))/2 = 1 - S
-        return {'ssim': torch.stack(vals)}
+        i1, i2, _ = _prep(img1, img2, img2)
+        n, _, h, w = i1.shape
+        out = torch.empty((3, n), dtype=torch.float32, device=i1.device)
+        ws = torch.empty(lib.mmif_ssim_loss_mode_workspace(n, h, w, 1) // 4 + 1, dtype=torch.float32, device=i1.device)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        check(lib.mmif_ssim_terms(p(i1), p(i2), n, h, w, self.win_size, float(self.data_range), p(out), p(ws), ws.numel() * 4,
+                                  T.stream_ptr()), "ssim_terms")
+        res = {'ssim': out[0], 'cs': out[1], 'sigma': out[2]}
+        if self.win_size == 11 and torch.is_grad_enabled() and img2.requires_grad:
+            # differentiable path: the batch-1 loss kernel per sample (loss = 1 - S with both sources = img1)
+            res['ssim'] = torch.stack([1.0 - _LossFn.apply(img2[i:i + 1], img1[i:i + 1], img1[i:i + 1], 0, 1.0, float(self.data_range), 0)
+                                       for i in range(n)])
+        return res
 
 
 class MS_SSIM(nn.Module):

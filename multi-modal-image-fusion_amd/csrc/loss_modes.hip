@@ -493,6 +493,47 @@ extern "C" int mmif_ssim_loss_mode(const float* img1, const float* img2, const f
     return MMIF_OK;
 }
 
+// out[q][b] = sums[qsel][b] * scale  (tiny gather used by mmif_ssim_terms)
+__global__ void pick_row_kernel(const float* __restrict__ sums, int n, int qsel, float scale, float* __restrict__ out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < n) out[b] = sums[qsel * n + b] * scale;
+}
+
+/* calc_ssim core/loss.py:52-110 with size_average=True: per-sample means of the ssim map, the cs map and the clamped source
+ * variance sigma of (img1, img2) for a window of 3/5/7/9/11 taps -> out[3][n] (device).  Values only. */
+extern "C" int mmif_ssim_terms(const float* img1, const float* img2, int32_t n, int32_t h, int32_t w, int32_t win_size, float data_range,
+                               float* out, void* workspace, size_t workspace_bytes, void* stream) {
+    MMIF_REQUIRE(img1 && img2 && out && workspace, "ssim_terms: NULL argument");
+    MMIF_REQUIRE(win_size == 3 || win_size == 5 || win_size == 7 || win_size == 9 || win_size == 11, "ssim_terms: win_size must be 3, 5, 7, 9 or 11 (got %d)", win_size);
+    MMIF_REQUIRE(n > 0 && h >= win_size && w >= win_size, "ssim_terms: image smaller than the window (%dx%d)", h, w);
+    if (workspace_bytes < mmif_ssim_loss_mode_workspace(n, h, w, 1)) {
+        set_error("ssim_terms: workspace too small");
+        return MMIF_EWORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const float C1 = (0.01f * data_range) * (0.01f * data_range), C2 = (0.03f * data_range) * (0.03f * data_range);
+    const size_t tiles = (size_t)cdiv(h, MT_) * cdiv(w, MT_);
+    float* partial = (float*)workspace;
+    float* sums = partial + 4 * n * tiles;
+    SsimArgs a{img1, img1, img2, n, h, w, C1, C2, st};   // pair 1 = (img1, img2); pair 2 unused
+    const float inv = 1.f / ((float)(h - win_size + 1) * (float)(w - win_size + 1));
+    for (int cs = 0; cs < 2; ++cs) {
+        int rc;
+        switch (win_size) {
+            case 3: rc = run_stats<3>(a, 1.f, 0.f, nullptr, nullptr, 0, cs, nullptr, partial, sums); break;
+            case 5: rc = run_stats<5>(a, 1.f, 0.f, nullptr, nullptr, 0, cs, nullptr, partial, sums); break;
+            case 7: rc = run_stats<7>(a, 1.f, 0.f, nullptr, nullptr, 0, cs, nullptr, partial, sums); break;
+            case 9: rc = run_stats<9>(a, 1.f, 0.f, nullptr, nullptr, 0, cs, nullptr, partial, sums); break;
+            default: rc = run_stats<11>(a, 1.f, 0.f, nullptr, nullptr, 0, cs, nullptr, partial, sums); break;
+        }
+        if (rc) return rc;
+        hipLaunchKernelGGL(pick_row_kernel, dim3(cdiv(n, 64)), dim3(64), 0, st, sums, n, 0, inv, out + cs * n);
+        if (cs == 1) hipLaunchKernelGGL(pick_row_kernel, dim3(cdiv(n, 64)), dim3(64), 0, st, sums, n, 2, inv, out + 2 * n);
+        if (int rc2 = check_launch("ssim_terms pick")) return rc2;
+    }
+    return MMIF_OK;
+}
+
 extern "C" size_t mmif_tv_loss_workspace(void) { return 4096 * sizeof(float); }
 
 extern "C" int mmif_tv_loss(const float* x, int32_t n, int32_t h, int32_t w, float weight, int32_t l2, float* loss_out, float* grad_out,

@@ -79,6 +79,7 @@ SIGNATURES = {
     "mmif_ssim_loss": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _sz, _vp]),
     "mmif_ssim_loss_mode_workspace": (_sz, [_i32, _i32, _i32, _i32]),
     "mmif_ssim_loss_mode": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _f32, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "mmif_ssim_terms": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _sz, _vp]),
     "mmif_tv_loss_workspace": (_sz, []),
     "mmif_tv_loss": (_i32, [_vp, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp, _sz, _vp]),
     "mmif_pixel_loss": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),

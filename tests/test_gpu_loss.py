@@ -165,3 +165,22 @@ def test_ms_ssim_and_msw_ssim_classes():
         assert abs(ms[i] - (1.0 - float(l))) <= 1e-4, (i, ms[i], 1.0 - float(l))
     with pytest.raises(NotImplementedError):
         MSW_SSIM(win_sizes=(11, 7))
+
+
+@pytest.mark.parametrize("win", [11, 7, 3])
+def test_ssim_module_terms_vs_oracle(win):
+    """core.loss.SSIM: {'ssim', 'cs', 'sigma'} per-sample means (reference core/loss.py:163-185) vs the oracle's maps."""
+    from core.loss import SSIM
+    shape = (3, 1, 33, 47)
+    an, bn = O.closed_form_image(shape, 0.3), O.closed_form_image(shape, 2.9)
+    out = SSIM(win)(tg(an), tg(bn))
+    t = O.ssim_full_terms(an, bn, O.create_window(win))
+    for key, ref in (("ssim", t["S"]), ("cs", t["cs"]), ("sigma", t["sigma"])):
+        want = ref.mean(axis=(1, 2, 3))
+        got = out[key].detach().cpu().numpy()
+        assert got.shape == (3,) and np.abs(got - want).max() <= 1e-4 * max(1.0, np.abs(want).max()), (key, got, want)
+    if win == 11:
+        f = tg(bn).requires_grad_(True)
+        s = SSIM()(tg(an), f)['ssim'].sum()
+        s.backward()
+        assert float(f.grad.abs().max()) > 0
