@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--mode", default="train", choices=["train", "infer"],
                     help="infer = forward only under no_grad (test.py path; BASELINE config 5: --mode infer --batch 1 --size 1024 --width 1224)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--model", default="PFNetv1", choices=["PFNetv1", "PFNetv2", "DenseFuse", "NestFuse", "RFNNest"])
+    ap.add_argument("--model", default="PFNetv1", choices=["PFNetv1", "PFNetv2", "DenseFuse", "VIFNet", "NestFuse", "RFNNest"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=2, help="image pairs in the CPU-oracle sample")
     ap.add_argument("--roofline-tag", default="decode.0:fwd", help="engine op timed with HIP events for `roofline`")
@@ -130,7 +130,7 @@ def main():
         step()
     hbm_tag = args.hbm_tag
     if hbm_tag == "auto":   # the widest thin layer of the model's encoder (Cout = 16): 48 -> 16 forward
-        hbm_tag = {"PFNetv1": "encode1.1.2:fwd", "DenseFuse": "encode.1.2:fwd", "PFNetv2": "encode.1.2:fwd"}.get(args.model, "") if args.mode == "train" else ""
+        hbm_tag = {"PFNetv1": "encode1.1.2:fwd", "DenseFuse": "encode.1.2:fwd", "PFNetv2": "encode.1.2:fwd", "VIFNet": "encode.1.2:fwd"}.get(args.model, "") if args.mode == "train" else ""
     T.PROFILE_TAGS = {args.roofline_tag} | ({hbm_tag} if hbm_tag else set())
     T.PROFILE_EVENTS.clear()
     if world > 1:

@@ -12,7 +12,7 @@ from mmif import engine as E
 from .block import *
 from .fusion import *
 
-__all__ = ['PFNetv1', 'PFNetv2', 'DenseFuse', 'NestFuse', 'RFNNest']
+__all__ = ['PFNetv1', 'PFNetv2', 'DenseFuse', 'VIFNet', 'NestFuse', 'RFNNest']
 
 
 class _FusionModel(nn.Module):
@@ -113,6 +113,24 @@ class DenseFuse(_FusionModel):
 
     def _make_engine(self):
         return E.DenseFuseEngine(self)
+
+
+class VIFNet(_FusionModel):
+    '''VIF-Net: An Unsupervised Framework for Infrared and Visible Image Fusion (reference core/model.py:189-206):
+    DenseFuse's shared encoder, concat fusion, PFNetv1's decoder.'''
+
+    def __init__(self):
+        super(VIFNet, self).__init__()
+        self.encode = nn.Sequential(ConvLayer(1, 16), DenseBlock(16, 16))
+        self.decode = nn.Sequential(ConvLayer(128, 128), ConvLayer(128, 64), ConvLayer(64, 32), ConvLayer(32, 16),
+                                    ConvLayer(16, 1, act=None))
+        self._engine_single = False   # forward(img1) alone has no meaning here (the decoder takes 128 channels)
+
+    def fusion(self, feat1, feat2):
+        return concat_fusion((feat1, feat2))
+
+    def _make_engine(self):
+        return E.VIFNetEngine(self)
 
 
 class NestFuse(_FusionModel):

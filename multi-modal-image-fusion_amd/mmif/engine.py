@@ -393,9 +393,30 @@ class PFNetv1Engine(ModelEngine, DenseEncoderMixin):
                 # gradient w.r.t. the concatenated encoder features: only each encoder's last
                 # DenseBlock output (blocks 6,7 / 14,15) has no further contributor
                 g = self.c_dgrad(s, g, x, gx, bits(6, 7, 14, 15), 0, impl)
+        self.enc_bwd_all(img1, img2, F, g, ws, impl)
+        return grads
+
+    def enc_bwd_all(self, img1, img2, F, g, ws, impl):
         self.enc_bwd(self.enc[0], img1, F, g, 0, 0, ws, impl)
         self.enc_bwd(self.enc[1], img2, F, g, 8, 8, ws, impl)
-        return grads
+
+
+class VIFNetEngine(PFNetv1Engine):
+    """reference core/model.py:189-206: PFNetv1's graph with ONE encoder applied to both images (its weight gradients are
+    the sum of the two branches: the second branch accumulates)."""
+
+    def __init__(self, module):
+        m = module
+        def cs(name, layer):
+            return ConvSpec(name, layer.layers[0], layer.act is not None)
+        shared = [cs("encode.0", m.encode[0])] + [cs(f"encode.1.{i}", l) for i, l in enumerate(m.encode[1].layers)]
+        self.enc = [shared, shared]
+        self.dec = [cs(f"decode.{i}", l) for i, l in enumerate(m.decode)]
+        ModelEngine.__init__(self, module, shared + self.dec)
+
+    def enc_bwd_all(self, img1, img2, F, g, ws, impl):
+        self.enc_bwd(self.enc[0], img1, F, g, 0, 0, ws, impl, accumulate_w=False)
+        self.enc_bwd(self.enc[1], img2, F, g, 8, 8, ws, impl, accumulate_w=True)
 
 
 class DenseFuseEngine(ModelEngine, DenseEncoderMixin):

@@ -20,6 +20,7 @@ GPU box.  Fixture map:
   f6_traj.npz                3-step train trajectories (train.py:61-75 semantics)
   f8_feed.npz                data/transform.py norm (3 modes) + transform (8 modes) on an integer-valued 6x6 / 5x5 patch
   f9_ssim_modes.npz          SSIMLoss 'w-ssim' | 'ms-ssim' | 'msw-ssim' (core/loss.py:259-277) and TVLoss (:347-358): value + d/dimgf
+  f10_vifnet.npz / f10_manifest.json   VIFNet (core/model.py:189-206) forward + gradient digests + state_dict manifest
   f7_metric_ssim.json        core/metric.py:316-364 calc_ssim (the SSIM that test.py:49-52 reports) on closed-form images
 """
 import json
@@ -299,6 +300,23 @@ def make_f6():
     np.savez_compressed(os.path.join(HERE, "f6_traj.npz"), **out)
 
 
+def make_f10():
+    """VIFNet: the PFNet/DenseFuse-style net with a shared encoder, concat fusion and PFNetv1's decoder."""
+    out, manifest = {}, {}
+    for shape in ((2, 1, 32, 32), (1, 1, 37, 53)):
+        tag = f"VIFNet_{shape[0]}x{shape[2]}x{shape[3]}"
+        model = load_closed_form(rmodel.VIFNet(), seed=1)
+        manifest["VIFNet"] = [[k, list(v.shape)] for k, v in model.state_dict().items()]
+        i1, i2 = T(closed_form_image(shape, 0.3)), T(closed_form_image(shape, 1.7))
+        y = model(i1, i2)
+        y.backward(T(closed_form_signed(shape, 0.9, 1.0)))
+        out[tag + "__y"] = y.detach().numpy()
+        for k, p in model.named_parameters():
+            out[f"{tag}__dp_{k}"] = digest(p.grad.numpy())
+    np.savez_compressed(os.path.join(HERE, "f10_vifnet.npz"), **out)
+    json.dump(manifest, open(os.path.join(HERE, "f10_manifest.json"), "w"), indent=0)
+
+
 def make_f7():
     """core/metric.py calc_ssim as test.py uses it (data_range=1.0) and with its default data_range=255."""
     import core.metric as rmetric
@@ -372,7 +390,7 @@ def make_f9():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9"]
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10"]
     for w in which:
         globals()["make_" + w]()
         print("wrote", w)

@@ -259,3 +259,28 @@ def test_fusion_functions_hip_vs_golden():
             close(y.detach().cpu().numpy(), ref[f"elem_{mode}__y"], 1e-6)
             close(ta.grad.cpu().numpy(), ref[f"elem_{mode}__da"], 1e-6)
             close(tb.grad.cpu().numpy(), ref[f"elem_{mode}__db"], 1e-6)
+
+
+@pytest.mark.parametrize("shape", [(2, 1, 32, 32), (1, 1, 37, 53)], ids=["2x32x32", "1x37x53"])
+def test_vifnet_fp32_vs_golden_and_bf16(shape):
+    """VIFNet on the engine (PFNetv1's graph with one shared encoder): fp32 vs the reference (golden F10), bf16 vs the oracle."""
+    ref = np.load(os.path.join(G, "f10_vifnet.npz"))
+    man = json.load(open(os.path.join(G, "f10_manifest.json")))
+    tag = f"VIFNet_{shape[0]}x{shape[2]}x{shape[3]}"
+    i1n, i2n, gn = O.closed_form_image(shape, 0.3), O.closed_form_image(shape, 1.7), O.closed_form_signed(shape, 0.9, 1.0)
+    with dtype_ctx("fp32"):
+        m = _model("VIFNet", 1)
+        assert [[k, list(v.shape)] for k, v in m.state_dict().items()] == man["VIFNet"]
+        y = m(tg(i1n), tg(i2n))
+        y.backward(tg(gn))
+        torch.cuda.synchronize()
+        close(y.detach().cpu().numpy(), ref[tag + "__y"], 1e-4, "imgf")
+        for k, p in m.named_parameters():
+            close_digest(p.grad.cpu().numpy(), ref[f"{tag}__dp_{k}"], 2e-4, k)
+    om = O.VIFNet()
+    P = om.init_params(seed=1)
+    y_or = om.forward(P, i1n, i2n)
+    with dtype_ctx("bf16"):
+        m = _model("VIFNet", 1)
+        with torch.no_grad():
+            close(m(tg(i1n), tg(i2n)).cpu().numpy(), y_or, 3e-2, "imgf bf16")

@@ -73,10 +73,10 @@ def test_c_abi_validation_of_the_widened_entry_points_without_gpu():
     assert lib.mmif_fuse_attn_workspace(2, 64) > 0
 
 
-@pytest.mark.parametrize("name", ["PFNetv1", "PFNetv2", "DenseFuse", "NestFuse", "RFNNest"])
+@pytest.mark.parametrize("name", ["PFNetv1", "PFNetv2", "DenseFuse", "VIFNet", "NestFuse", "RFNNest"])
 def test_state_dict_manifest_and_init(name):
     import core.model as M
-    man = json.load(open(os.path.join(G, "f5_manifest.json")))
+    man = json.load(open(os.path.join(G, "f10_manifest.json" if name == "VIFNet" else "f5_manifest.json")))
     torch.manual_seed(0)
     m = getattr(M, name)()
     assert [[k, list(v.shape)] for k, v in m.state_dict().items()] == man[name]

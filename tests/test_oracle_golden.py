@@ -327,3 +327,19 @@ def test_f9_tv_loss(mode):
     loss, grad = O.tv_loss(x, mode, weight=0.3)
     assert abs(float(loss) - float(ref[f"tv_{mode}__loss"])) <= 1e-6
     close(grad, ref[f"tv_{mode}__grad"], 1e-5, mode)
+
+
+@pytest.mark.parametrize("shape", [(2, 1, 32, 32), (1, 1, 37, 53)], ids=["2x32x32", "1x37x53"])
+def test_f10_vifnet(shape):
+    """VIFNet (shared encoder + concat + PFNetv1 decoder): oracle forward / explicit backward vs the reference (golden F10)."""
+    ref = np.load(os.path.join(G, "f10_vifnet.npz"))
+    man = json.load(open(os.path.join(G, "f10_manifest.json")))
+    tag = f"VIFNet_{shape[0]}x{shape[2]}x{shape[3]}"
+    m = O.VIFNet()
+    assert [[k, list(v)] for k, v in m.param_shapes().items()] == man["VIFNet"]
+    P = m.init_params(seed=1)
+    y = m.forward(P, O.closed_form_image(shape, 0.3), O.closed_form_image(shape, 1.7))
+    close(y, ref[tag + "__y"], 2e-5, "imgf")
+    Gd = m.backward(P, O.closed_form_signed(shape, 0.9, 1.0))
+    for k in m.param_shapes():
+        close_digest(Gd[k], ref[f"{tag}__dp_{k}"], 5e-5, k)
