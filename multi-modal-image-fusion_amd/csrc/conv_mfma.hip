@@ -690,6 +690,216 @@ __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void conv_dma_kernel(TV 
                                  pend.tile_y * DT_ROWS + wave * 4 + (g & 1), g, relu, mask_bits, accum_bits);
 }
 
+// ------------------------------------------------------------------ thin layers: asynchronous loader / consumer kernel
+// 3x3 layers with <= 48 output and <= 48 input channels (DenseBlock encoder convs and their dgrads, decode.3): HBM-bound and,
+// with almost no MFMA work per tile, LATENCY-bound in both kernels above.  What they need is several independent tiles per CU in
+// different phases with loads running ahead (a block-barrier ring with one consumer group was
+// measured slower than four independent register-staged blocks).  So:
+//   * persistent block = 4 loader waves + 3 consumer GROUPS of 4 waves (group q takes the block's tiles q, q+3, ...);
+//   * the whole packed weight image (<= 54 KB) is resident in LDS; 16x16-pixel input tiles (all channel blocks) stream by LDS-DMA
+//     through a ring of NS >= 4 slots, D = min(2, NS-3) tiles in flight per loader (counted vmcnt);
+//   * NO block barrier in the steady state: loaders publish "tile landed" and consumers "slot free" through LDS counters
+//     (ds_add_u32 by lane 0, polled with s_sleep), so the two groups and the loaders drift freely against each other.
+// Spin loops are bounded (a failed hand-off would produce wrong numbers, never a hung GPU).
+constexpr int TN_MAXCB = 6;                    // input channel blocks per tile (cin <= 48)
+constexpr int TN_PL = 336;                     // granules per LDS plane (18x18 = 324 used); 5376 B = 0 mod 256
+constexpr int TN_MAXKG = 2 * 36;               // k-group planes of two chunks
+constexpr int TN_GROUPS = 3, TN_LOAD = 4, TN_MAXSLOTS = 8;   // 12 consumer + 4 loader waves = one 1024-thread block per CU
+__host__ __device__ constexpr int tn_ring_bytes(int mf) { return mf == 1 ? 128 * 1024 : (mf == 2 ? 112 * 1024 : 96 * 1024); }
+
+__device__ inline void tn_wait_vmcnt(int n) {   // s_waitcnt vmcnt(n), n wave-uniform in 0..16 (the immediate must be a constant)
+    switch (n) {
+        case 0: __builtin_amdgcn_s_waitcnt(0x0f70); break;
+        case 1: __builtin_amdgcn_s_waitcnt(0x0f71); break;
+        case 2: __builtin_amdgcn_s_waitcnt(0x0f72); break;
+        case 3: __builtin_amdgcn_s_waitcnt(0x0f73); break;
+        case 4: __builtin_amdgcn_s_waitcnt(0x0f74); break;
+        case 5: __builtin_amdgcn_s_waitcnt(0x0f75); break;
+        case 6: __builtin_amdgcn_s_waitcnt(0x0f76); break;
+        case 7: __builtin_amdgcn_s_waitcnt(0x0f77); break;
+        case 8: __builtin_amdgcn_s_waitcnt(0x0f78); break;
+        case 9: __builtin_amdgcn_s_waitcnt(0x0f79); break;
+        case 10: __builtin_amdgcn_s_waitcnt(0x0f7a); break;
+        case 11: __builtin_amdgcn_s_waitcnt(0x0f7b); break;
+        case 12: __builtin_amdgcn_s_waitcnt(0x0f7c); break;
+        case 13: __builtin_amdgcn_s_waitcnt(0x0f7d); break;
+        case 14: __builtin_amdgcn_s_waitcnt(0x0f7e); break;
+        case 15: __builtin_amdgcn_s_waitcnt(0x0f7f); break;
+        default: __builtin_amdgcn_s_waitcnt(0x4f70); break;   // vmcnt(16): bit 14 = vmcnt bit 4
+    }
+}
+// wave-uniform bounded poll of an LDS counter published by other waves
+__device__ inline void tn_wait_counter(volatile unsigned* ctr, unsigned target) {
+    for (int spin = 0; spin < (1 << 22); ++spin) {
+        if (*ctr >= target) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __asm__ volatile("" ::: "memory");
+}
+
+template <int MF, bool DGRAD>
+__global__ __launch_bounds__((4 * TN_GROUPS + TN_LOAD) * 64, 4) void thin_conv_async_kernel(
+    TV tin, TV tout, TV tmask, const uint4* __restrict__ wpk, const float* __restrict__ bias, int n_out, int relu,
+    unsigned long long mask_bits, unsigned long long accum_bits, int tiles_x, int tiles_y, int ntiles) {
+    constexpr int TP = MT + 2;
+    constexpr int NCONS = 4 * TN_GROUPS;
+    __shared__ __attribute__((aligned(16))) char s_in[tn_ring_bytes(MF)];
+    __shared__ __attribute__((aligned(16))) uint4 s_w[TN_MAXKG * MF * 16];
+    __shared__ int2 s_tab[2][36];
+    __shared__ __attribute__((aligned(16))) float s_bias[MF * 16];
+    __shared__ unsigned s_ready[TN_MAXSLOTS], s_done[TN_MAXSLOTS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    const int G = gridDim.x, b = blockIdx.x;
+    const int tpi = tiles_x * tiles_y;
+    const int ncb_tot = tin.cb;
+    const int nch = (ncb_tot + CHUNK_CB - 1) / CHUNK_CB;
+    const int nmine = b < ntiles ? (ntiles - b + G - 1) / G : 0;
+    if (nmine == 0) return;
+    // XCD-aware tile order (block b and all of its tiles b + kG run on XCD b % 8 when G % 8 == 0): contiguous band per XCD
+    auto tile_of = [&](int i, int& in_, int& tile_y, int& tile_x) {
+        int lin = i;
+        if ((G & 7) == 0) {
+            const int q8 = ntiles >> 3, r8 = ntiles & 7, xcd = i & 7;
+            lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (i >> 3);
+        }
+        in_ = lin / tpi;
+        const int trem = lin - in_ * tpi;
+        tile_y = trem / tiles_x;
+        tile_x = trem - tile_y * tiles_x;
+    };
+    const int in_pieces = (ncb_tot * TN_PL + 63) / 64;        // <= 32
+    const int P = (in_pieces + TN_LOAD - 1) / TN_LOAD;        // pieces per loader wave per tile (every loader issues exactly P)
+    const int slot_bytes = P * TN_LOAD * 1024;
+    const int NS = min(TN_MAXSLOTS, tn_ring_bytes(MF) / slot_bytes);   // >= TN_GROUPS + 1 (checked by the host)
+    const int D = min(2, NS - TN_GROUPS);                              // tiles a loader keeps in flight behind the one it publishes
+
+    // ---- one-time setup: k-group tables, bias, counters, resident weights; ONE block barrier, none afterwards
+    if (tid < 72) {
+        const int c = tid / 36, kg = tid % 36;
+        const int ncb = min(CHUNK_CB, ncb_tot - c * CHUNK_CB);
+        if (ncb > 0) {
+            int tap = 0, cb = 0;
+            if (kg < 9 * ncb) { tap = kg / ncb; cb = kg % ncb; }
+            s_tab[c][kg] = make_int2(((c * CHUNK_CB + cb) * TN_PL + (tap / 3) * TP + (tap % 3)) * 16, (c * 36 + kg) * MF * 256);
+        }
+    }
+    if (!DGRAD && tid < MF * 16) s_bias[tid] = (bias != nullptr && tid < n_out) ? bias[tid] : 0.f;
+    if (tid < TN_MAXSLOTS) { s_ready[tid] = 0u; s_done[tid] = 0u; }
+    if (wave >= NCONS) {
+        // the packed image of a single M-block (m16p == MF*16) is contiguous ([chunk][k-group][MF*16 rows][8]); chunk c starts
+        // at k-group plane 36 c in both the image and s_w, and its size is a multiple of 1 KiB
+        int wbytes = 0;
+        for (int c = 0; c < nch; ++c) wbytes += ((9 * min(CHUNK_CB, ncb_tot - c * CHUNK_CB) + 3) / 4 * 4) * MF * 256;
+        const char* src = reinterpret_cast<const char*>(wpk) + lane * 16;
+        char* dst = reinterpret_cast<char*>(s_w);
+        for (int pz = wave - NCONS; pz * 1024 < wbytes; pz += TN_LOAD)
+            __builtin_amdgcn_global_load_lds(MMIF_GPTR(src + (long long)pz * 1024), MMIF_LPTR(dst + pz * 1024), 16, 0, 0);
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+    }
+    __syncthreads();
+
+    if (wave >= NCONS) {
+        // =============================== loader waves ===============================
+        const int lw = wave - NCONS;
+        unsigned geo[8];   // tile independent: plane << 16 | tile row << 8 | tile col of the granule this lane stages (piece lw + 4 i)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            // (pieces past in_pieces -- padding so that every loader issues exactly P -- re-stage the last real piece: same sources)
+            const int slot = min(min(lw + TN_LOAD * i, in_pieces - 1) * 64 + lane, ncb_tot * TN_PL - 1);
+            const int pl = slot / TN_PL, p = min(slot - pl * TN_PL, TP * TP - 1);
+            geo[i] = (unsigned)(pl << 16 | (p / TP) << 8 | (p % TP));
+        }
+        const unsigned plane_bytes = (unsigned)(tin.plane * 16);
+        auto issue_tile = [&](int k) {
+            int in_, ty0, tx0;
+            tile_of(b + k * G, in_, ty0, tx0);
+            const int iy0 = ty0 * MT - tout.halo - 1, ix0 = tx0 * MT - tout.halo - 1;
+            const char* src = tin.base + ((long long)in_ * tin.img + (long long)tin.cb_off * tin.plane) * 16;
+            char* dst = s_in + (k % NS) * slot_bytes;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (i < P) {
+                    const int piece = min(lw + TN_LOAD * i, in_pieces - 1);
+                    const int pl = (int)(geo[i] >> 16);
+                    int y = iy0 + (int)((geo[i] >> 8) & 255u), x = ix0 + (int)(geo[i] & 255u);
+                    if (!DGRAD) {
+                        y = min(max(reflect_idx(y, tin.h), 0), tin.h - 1);
+                        x = min(max(reflect_idx(x, tin.w), 0), tin.w - 1);
+                    } else {   // FOLDED halo-1 gradient: out-of-image taps read its zeroed halo ring
+                        y = min(max(y + 1, 0), tin.hs - 1);
+                        x = min(max(x + 1, 0), tin.ws - 1);
+                    }
+                    const unsigned off = (unsigned)(y * tin.ws + x) * 16u + (unsigned)pl * plane_bytes;
+                    __builtin_amdgcn_global_load_lds(MMIF_GPTR(src + off), MMIF_LPTR(dst + piece * 1024), 16, 0, 0);
+                }
+            }
+        };
+        auto publish = [&](int k) {   // this wave's part of tile k has landed
+            if (lane == 0) atomicAdd(&s_ready[k % NS], 1u);
+        };
+        for (int k = 0; k < nmine; ++k) {
+            if (k >= NS) tn_wait_counter(&s_done[k % NS], 4u * (unsigned)(k / NS));   // the slot's previous tile is consumed
+            issue_tile(k);
+            if (k >= D) {
+                tn_wait_vmcnt(D * P);   // tile k-D landed; the D younger tiles stay in flight
+                publish(k - D);
+            }
+        }
+        for (int k = max(nmine - D, 0); k < nmine; ++k) {
+            tn_wait_vmcnt((nmine - 1 - k) * P);
+            publish(k);
+        }
+        return;
+    }
+
+    // =============================== consumer groups: group q = tiles q, q+3, ...; wave r of a group owns tile rows 4r .. 4r+3
+    const int q = wave >> 2, r = wave & 3;
+    const char* w_lane = reinterpret_cast<const char*>(s_w) + j * 16;
+    for (int k = q; k < nmine; k += TN_GROUPS) {
+        int in_, ty0, tx0;
+        tile_of(b + k * G, in_, ty0, tx0);
+        tn_wait_counter(&s_ready[k % NS], (unsigned)TN_LOAD * (unsigned)(k / NS + 1));
+        const char* in_lane = s_in + (k % NS) * slot_bytes + ((r * 4) * TP + j) * 16;
+        f32x4 acc[MF][4];
+#pragma unroll
+        for (int m = 0; m < MF; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < nch; ++c) {
+            const int ncb = min(CHUNK_CB, ncb_tot - c * CHUNK_CB);
+            const int nkgp = (9 * ncb + 3) / 4 * 4, nsteps = nkgp >> 2;
+            const int2* tab = s_tab[c];
+            int2 off = tab[g];
+            int2 nx = tab[min(4, nkgp - 4) + g];
+            bf16x8 bq[4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) bq[n] = *reinterpret_cast<const bf16x8*>(in_lane + off.x + n * TP * 16);
+            for (int s2 = 0; s2 < nsteps; ++s2) {
+                const int2 nx2 = tab[min(4 * (s2 + 2), nkgp - 4) + g];
+                bf16x8 a[MF], bn[4];
+#pragma unroll
+                for (int m = 0; m < MF; ++m) a[m] = *reinterpret_cast<const bf16x8*>(w_lane + off.y + m * 256);
+#pragma unroll
+                for (int n = 0; n < 4; ++n) bn[n] = *reinterpret_cast<const bf16x8*>(in_lane + nx.x + n * TP * 16);
+#pragma unroll
+                for (int m = 0; m < MF; ++m)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], bq[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+                for (int n = 0; n < 4; ++n) bq[n] = bn[n];
+                off = nx;
+                nx = nx2;
+            }
+        }
+        // every LDS read of this tile has been consumed by an MFMA above: hand the slot back before the (long) epilogue
+        __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) atomicAdd(&s_done[k % NS], 1u);
+        conv_epilogue<MF, DGRAD>(acc, tout, tmask, s_bias, 0, in_, tx0 * MT + j, ty0 * MT + r * 4 + (g & 1), g, relu, mask_bits, accum_bits);
+    }
+}
+
 // ------------------------------------------------------------------ wgrad kernel (K = pixels)
 // block: (pixel-tile group gi, input-channel group of 16, output-channel group of MFW*16).
 // k-step = 2 tile rows = 32 pixels; lane group g of a k-step: tile row 2s + (g>>1), cols 8*(g&1)..+7.
@@ -1109,6 +1319,17 @@ static int launch_conv_mfma(bool dgrad, const TV& tin, const TV& tout, const TV&
     return check_launch(dgrad ? "conv_mfma dgrad" : "conv_mfma fwd");
 }
 
+static int num_cus_() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
 static int g_dma_mode = -1;   // $MMIF_CONV_DMA: 1 (default) = DMA-staged kernel where it applies, 0 = never
 static int g_num_cus = 0;
 static int g_abl = 0;            // $MMIF_CONV_ABLATE (diagnostics): bit 0 = no staging DMAs after the first chunk
@@ -1151,6 +1372,35 @@ int conv_mfma(bool dgrad, int ks, const TV& tin, const TV& tout, const TV& tmask
     if (g_dma_mode == 1 && ks == 3 && mf == 4 && (!dgrad || (tin.halo == 1 && tin.folded)) &&
         tin.plane * 16 * CHUNK_CB < (1ll << 31))
         return launch_conv_dma(dgrad, tin, tout, tmask, w_packed, bias, n_out, relu, mask_bits, accum_bits, st);
+    // thin layers: asynchronous loader / consumer kernel with resident weights (one M-block of <= 48 channels, <= 48 input
+    // channels, a ring of at least TN_GROUPS + 1 tile slots, at least two tiles per persistent block).  Measured (B=32 256x256,
+    // vs conv_mfma_kernel<3,MF>): every dgrad -13 .. -21 %, forward with 32 / 48 outputs -14 % / -30 %; forward with 16 outputs
+    // is +3 .. +16 % (the register-staged kernel runs 4 blocks per SIMD there), so that case stays on the old kernel.
+    if (g_dma_mode == 1 && ks == 3 && mf <= 3 && (dgrad || mf >= 2) && tin.cb <= TN_MAXCB &&
+        (!dgrad || (tin.halo == 1 && tin.folded)) &&
+        tin.plane * 16 * TN_MAXCB < (1ll << 31)) {
+        const int tiles_x = cdiv(tout.ws, MT), tiles_y = cdiv(tout.hs, MT);
+        const long long ntiles = (long long)tiles_x * tiles_y * tout.n;
+        const int P = cdiv(cdiv(tin.cb * TN_PL, 64), TN_LOAD), slot_bytes = P * TN_LOAD * 1024;
+        int G = num_cus_() / 8 * 8;
+        if (G < 8) G = 8;
+        if (tn_ring_bytes(mf) / slot_bytes >= TN_GROUPS + 1 && ntiles >= 2ll * G && ntiles < (1ll << 31)) {
+#define TGO(MF_)                                                                                                                       \
+    do {                                                                                                                               \
+        if (dgrad)                                                                                                                     \
+            hipLaunchKernelGGL((thin_conv_async_kernel<MF_, true>), dim3(G), dim3((4 * TN_GROUPS + TN_LOAD) * 64), 0, st, tin, tout,   \
+                               tmask, (const uint4*)w_packed, bias, n_out, relu, (unsigned long long)mask_bits,                       \
+                               (unsigned long long)accum_bits, tiles_x, tiles_y, (int)ntiles);                                        \
+        else                                                                                                                           \
+            hipLaunchKernelGGL((thin_conv_async_kernel<MF_, false>), dim3(G), dim3((4 * TN_GROUPS + TN_LOAD) * 64), 0, st, tin, tout,  \
+                               tmask, (const uint4*)w_packed, bias, n_out, relu, (unsigned long long)mask_bits,                       \
+                               (unsigned long long)accum_bits, tiles_x, tiles_y, (int)ntiles);                                        \
+        return check_launch(dgrad ? "thin_conv_async dgrad" : "thin_conv_async fwd");                                                 \
+    } while (0)
+            switch (mf) { case 1: TGO(1); case 2: TGO(2); default: TGO(3); }
+#undef TGO
+        }
+    }
 #define GO(KS_, MF_) return launch_conv_mfma<KS_, MF_>(dgrad, tin, tout, tmask, w_packed, bias, n_out, relu, mask_bits, accum_bits, st)
     if (ks == 3) {
         switch (mf) { case 1: GO(3, 1); case 2: GO(3, 2); case 3: GO(3, 3); default: GO(3, 4); }

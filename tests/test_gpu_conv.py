@@ -67,6 +67,10 @@ def test_conv_bf16_vs_oracle_on_rounded_operands(case, impl):
 
 
 DMA_SHAPES = [(128, 128, 2, 37, 53), (176, 112, 1, 64, 48), (72, 64, 2, 33, 40), (64, 184, 1, 40, 72), (96, 96, 3, 16, 16)]
+# thin layers (<= 48 channels either side) take the asynchronous loader/consumer kernel once a persistent block owns at least
+# two tiles: >= 512 tiles of 16x16
+DMA_SHAPES += [(16, 16, 3, 180, 200), (48, 16, 2, 250, 270), (16, 48, 3, 178, 190), (32, 16, 2, 256, 256), (24, 40, 2, 257, 300),
+               (48, 48, 2, 241, 275), (8, 16, 2, 256, 300)]
 _rng = np.random.default_rng(20240)
 DMA_SHAPES += [(int(_rng.integers(7, 40)) * 8, int(_rng.integers(7, 32)) * 8, int(_rng.integers(1, 4)), int(_rng.integers(8, 90)),
                 int(_rng.integers(8, 90))) for _ in range(10)]   # seeded random shapes: ragged everything
