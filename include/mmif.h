@@ -82,6 +82,15 @@ int mmif_fold_halo(const mmif_tensor* t, void* stream);
 size_t mmif_packed_weight_bytes(int32_t cout, int32_t cin, int32_t ksize);
 int mmif_pack_weights(const float* w, int32_t cout, int32_t cin, int32_t ksize, void* packed_fwd,
                       void* packed_dgrad, void* stream);
+/* The same for every layer of a model in one launch (host array of jobs; either image pointer may be NULL).
+ * What a training step calls after the optimiser has changed the master weights. */
+typedef struct mmif_pack_job {
+    const float* w;
+    int32_t cout, cin, ksize, reserved;
+    void* packed_fwd;
+    void* packed_dgrad;
+} mmif_pack_job;
+int mmif_pack_weights_multi(const mmif_pack_job* jobs, int32_t n_jobs, void* stream);
 
 /* ---- ConvLayer: reflect-pad(k/2) conv + bias + ReLU, stride 1, k in {1,3}
  *      replaces core/block.py:98-99 (nn.Conv2d(padding_mode='reflect') + nn.ReLU(inplace)) ---- */

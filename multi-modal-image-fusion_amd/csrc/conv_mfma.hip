@@ -91,6 +91,46 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int cout, int c
     (void)mf;
 }
 
+// All of a model's operand images in ONE launch (20 launches of a few microseconds each per PFNetv1 step otherwise):
+// blockIdx.y = image, the table travels as a kernel argument.
+constexpr int PACK_MAX_IMAGES = 64;
+struct PackImage { const float* w; bf16_t* dst; long long total; int cout, cin, ks, dgrad, m16p; };
+struct PackTable { PackImage im[PACK_MAX_IMAGES]; };
+
+__device__ inline void pack_one(const PackImage& J, long long idx) {
+    const int ks = J.ks, kk = ks * ks, cin = J.cin, m16p = J.m16p;
+    const int n_out = J.dgrad ? cin : J.cout, n_in = J.dgrad ? J.cout : cin;
+    const int ncb = (n_in + 7) / 8;
+    const int e = idx & 7;
+    const long long row = idx >> 3;
+    const int oc = (int)(row % m16p);
+    long long kgp = row / m16p;
+    int c0 = 0, n = 0, kg = 0;
+    for (c0 = 0; c0 < ncb; c0 += CHUNK_CB) {
+        n = ncb - c0 < CHUNK_CB ? ncb - c0 : CHUNK_CB;
+        const int pad = ((kk * n + 3) / 4) * 4;
+        if (kgp < pad) { kg = (int)kgp; break; }
+        kgp -= pad;
+    }
+    float val = 0.f;
+    if (kg < kk * n) {
+        const int tap = kg / n, cb = kg % n;
+        const int u = tap / ks, v = tap % ks;
+        const int ic = (c0 + cb) * 8 + e;
+        if (oc < n_out && ic < n_in) {
+            if (J.dgrad) val = J.w[(((long long)ic * cin + oc) * ks + (ks - 1 - u)) * ks + (ks - 1 - v)];
+            else val = J.w[(((long long)oc * cin + ic) * ks + u) * ks + v];
+        }
+    }
+    J.dst[idx] = f32_to_bf16(val);
+}
+
+__global__ void pack_weights_multi_kernel(PackTable tab) {
+    const PackImage& J = tab.im[blockIdx.y];
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < J.total; idx += (long long)gridDim.x * blockDim.x)
+        pack_one(J, idx);
+}
+
 // ------------------------------------------------------------------ granule loaders (bf16, raw uint4)
 __device__ inline uint4 ld_gran(const TV& t, int in_, int c, int ys, int xs) {
     return *reinterpret_cast<const uint4*>(t.base + t.gidx(in_, c, ys, xs) * 16);
@@ -1509,6 +1549,36 @@ extern "C" void mmif_debug_set_conv_dma(int32_t mode) { mmif::g_dma_mode = mode 
 extern "C" size_t mmif_packed_weight_bytes(int32_t cout, int32_t cin, int32_t ksize) {
     const size_t a = packed_bytes(cout, cin, ksize), b = packed_bytes(cin, cout, ksize);
     return a > b ? a : b;
+}
+
+extern "C" int mmif_pack_weights_multi(const mmif_pack_job* jobs, int32_t n_jobs, void* stream) {
+    MMIF_REQUIRE(jobs != nullptr && n_jobs > 0, "pack_weights_multi: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    PackTable tab;
+    int n = 0;
+    auto flush = [&]() -> int {
+        if (n == 0) return MMIF_OK;
+        hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(64, n), dim3(256), 0, st, tab);
+        n = 0;
+        return check_launch("pack_weights_multi");
+    };
+    for (int i = 0; i < n_jobs; ++i) {
+        const mmif_pack_job& jb = jobs[i];
+        MMIF_REQUIRE(jb.ksize == 1 || jb.ksize == 3, "pack_weights_multi: ksize must be 1 or 3 (job %d)", i);
+        MMIF_REQUIRE(jb.w != nullptr && jb.cout > 0 && jb.cin > 0, "pack_weights_multi: bad arguments (job %d)", i);
+        for (int d = 0; d < 2; ++d) {
+            void* dst = d ? jb.packed_dgrad : jb.packed_fwd;
+            if (dst == nullptr) continue;
+            const int n_out = d ? jb.cin : jb.cout, n_in = d ? jb.cout : jb.cin;
+            PackImage& im = tab.im[n++];
+            im.w = jb.w; im.dst = (bf16_t*)dst; im.total = (long long)(packed_bytes(n_out, n_in, jb.ksize) / 2);
+            im.cout = jb.cout; im.cin = jb.cin; im.ks = jb.ksize; im.dgrad = d;
+            im.m16p = n_mblocks(n_out) * pick_mf(n_out) * 16;
+            if (n == PACK_MAX_IMAGES)
+                if (int rc = flush()) return rc;
+        }
+    }
+    return flush();
 }
 
 extern "C" int mmif_pack_weights(const float* w, int32_t cout, int32_t cin, int32_t ksize, void* packed_fwd, void* packed_dgrad,

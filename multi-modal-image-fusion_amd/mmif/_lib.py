@@ -24,6 +24,11 @@ class MmifTensor(C.Structure):
                 ("halo", C.c_int32), ("cb_total", C.c_int32), ("cb_off", C.c_int32), ("cb", C.c_int32), ("flags", C.c_int32)]
 
 
+class MmifPackJob(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("cout", C.c_int32), ("cin", C.c_int32), ("ksize", C.c_int32), ("reserved", C.c_int32),
+                ("packed_fwd", C.c_void_p), ("packed_dgrad", C.c_void_p)]
+
+
 class MmifError(RuntimeError):
     pass
 
@@ -51,6 +56,7 @@ SIGNATURES = {
     "mmif_fold_halo": (_i32, [_TP, _vp]),
     "mmif_packed_weight_bytes": (_sz, [_i32, _i32, _i32]),
     "mmif_pack_weights": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "mmif_pack_weights_multi": (_i32, [C.POINTER(MmifPackJob), _i32, _vp]),
     "mmif_conv2d_reflect_fwd": (_i32, [_TP, _vp, _vp, _vp, _TP, _i32, _i32, _i32, _i32, _i32, _vp]),
     "mmif_conv2d_reflect_dgrad": (_i32, [_TP, _vp, _vp, _TP, _TP, _i32, _i32, _i32, _u64, _u64, _i32, _vp]),
     "mmif_conv2d_wgrad_workspace": (_sz, [_i32, _i32, _i32]),

@@ -94,8 +94,9 @@ class ConvSpec:
         w = self.conv.weight
         return (version, WEIGHTS_EPOCH[0], w._version, w.data_ptr())
 
-    def refresh(self, version, pack):
-        """Bring the derived weight images (channel permutation, bf16 MFMA packing) up to date."""
+    def refresh(self, version, pack, batch=None):
+        """Bring the derived weight images (channel permutation, bf16 MFMA packing) up to date.  With `batch` (a list) the
+        packing itself is left to the caller: (PackedWeights, weight) pairs for ONE T.pack_many launch."""
         key = self._key(version)
         if self.split and self.perm_version != key:
             w = self.conv.weight.detach()
@@ -107,7 +108,10 @@ class ConvSpec:
                 self.packed = PackedWeights(self.cout, self.cin, self.k, w.device)
                 self.packed_version = None
             if self.packed_version != key:
-                self.packed.pack(self.w.detach())
+                if batch is not None:
+                    batch.append((self.packed, self.w.detach()))
+                else:
+                    self.packed.pack(self.w.detach())
                 self.packed_version = key
 
     def ensure_packed(self, version):
@@ -252,8 +256,10 @@ class ModelEngine:
         dtype = compute_dtype()
         impl = conv_impl()
         use_mfma = dtype == torch.bfloat16 and impl != _lib.IMPL_VALU
+        stale = []
         for s in self.specs:
-            s.refresh(self.weights_version, use_mfma)
+            s.refresh(self.weights_version, use_mfma, stale)
+        T.pack_many(stale)   # all stale operand images of the model in one launch
         imgs = [None if i is None else i.detach().contiguous().float() for i in imgs]
         n, c, h, w = imgs[0].shape
         if c != 1:

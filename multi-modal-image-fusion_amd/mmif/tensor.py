@@ -100,6 +100,17 @@ class PackedWeights:
               "pack_weights")
 
 
+def pack_many(pairs):
+    """[(PackedWeights, fp32 weight tensor), ...] -> every operand image in ONE launch (mmif_pack_weights_multi)."""
+    if not pairs:
+        return
+    jobs = (_lib.MmifPackJob * len(pairs))()
+    for j, (pk, w) in zip(jobs, pairs):
+        j.w, j.cout, j.cin, j.ksize = w.data_ptr(), pk.cout, pk.cin, pk.k
+        j.packed_fwd, j.packed_dgrad = pk.fwd.data_ptr(), pk.dgrad.data_ptr()
+    check(lib.mmif_pack_weights_multi(jobs, len(pairs), stream_ptr()), "pack_weights_multi")
+
+
 # ------------------------------------------------------------------ per-op HIP-event timing (bench.py roofline)
 PROFILE_TAGS = set()     # op tags ("<layer>:fwd|dgrad|wgrad") to time
 PROFILE_EVENTS = {}      # tag -> [(start_event, end_event), ...] recorded on the launch stream

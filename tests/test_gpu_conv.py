@@ -142,3 +142,24 @@ def test_fold_halo_is_reflect_pad_adjoint_and_zeroes_halo(dtype, n, c, h, w):
     ring = got.copy()
     ring[:, :, 1:-1, 1:-1] = 0
     assert np.abs(ring).max() == 0.0, "halo ring must be zero after the fold"
+
+
+@pytest.mark.gpu
+def test_batched_weight_packing_equals_per_layer_packing():
+    """mmif_pack_weights_multi (one launch for every operand image of a model) writes exactly what per-layer mmif_pack_weights does,
+    including more images than one launch's table holds (64)."""
+    from mmif import tensor as T
+    dev = "cuda:0"
+    g = torch.Generator(device="cpu").manual_seed(7)
+    shapes = [(16, 16, 3), (16, 48, 3), (128, 128, 3), (64, 128, 3), (64, 88, 1), (8, 64, 1), (40, 24, 3)] * 5   # 70 images
+    ws = [torch.randn(co, ci, k, k, generator=g).to(dev) for co, ci, k in shapes]
+    single = [T.PackedWeights(co, ci, k, dev) for co, ci, k in shapes]
+    multi = [T.PackedWeights(co, ci, k, dev) for co, ci, k in shapes]
+    for pk in single + multi:   # the buffers hold max(fwd, dgrad) bytes: bytes past an image's end are not written by either
+        pk.fwd.fill_(0xAB), pk.dgrad.fill_(0xCD)
+    for pk, w in zip(single, ws):
+        pk.pack(w)
+    T.pack_many(list(zip(multi, ws)))
+    torch.cuda.synchronize()
+    for a, b in zip(single, multi):
+        assert torch.equal(a.fwd, b.fwd) and torch.equal(a.dgrad, b.dgrad)

@@ -71,6 +71,12 @@ def test_c_abi_validation_of_the_widened_entry_points_without_gpu():
     assert b"only supported ['min-max', 'z-score'] mode" in lib.mmif_last_error()
     assert lib.mmif_patch_feed(None, 4, 8, f, None, 2, 0, f, None) == -1
     assert lib.mmif_fuse_attn_workspace(2, 64) > 0
+    from mmif._lib import MmifPackJob
+    jobs = (MmifPackJob * 1)()
+    assert lib.mmif_pack_weights_multi(jobs, 0, None) == -1
+    jobs[0].w, jobs[0].cout, jobs[0].cin, jobs[0].ksize = base, 16, 16, 5
+    assert lib.mmif_pack_weights_multi(jobs, 1, None) == -1
+    assert b"ksize must be 1 or 3" in lib.mmif_last_error()
 
 
 @pytest.mark.parametrize("name", ["PFNetv1", "PFNetv2", "DenseFuse", "VIFNet", "NestFuse", "RFNNest"])
