@@ -81,10 +81,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # $MMIF_FORCE_DIST=1: take the RCCL code path (init, parameter broadcast, gradient all-reduce, barriers) with one rank too
+    use_dist = world > 1 or os.environ.get("MMIF_FORCE_DIST", "0") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl")  # RCCL on ROCm
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))  # RCCL on ROCm
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
     dev = torch.device("cuda", local_rank)
@@ -100,7 +103,7 @@ def main():
     E.set_compute_dtype(args.dtype)
     torch.manual_seed(0)
     model = getattr(M, args.model)().to(dev)
-    if world > 1:
+    if use_dist:
         broadcast_parameters(model, 0)
     opt = FusedClipAdam(model.parameters(), lr=1e-4, betas=(0.9, 0.999), max_norm=5.0)
     l_ssim, l_pix, l_grad = SSIMLoss('ssim', weight=1.0), PixelLoss('l1', weight=0.01), GradLoss('l1', weight=0.1).to(dev)
@@ -133,19 +136,19 @@ def main():
         hbm_tag = {"PFNetv1": "encode1.1.2:fwd", "DenseFuse": "encode.1.2:fwd", "PFNetv2": "encode.1.2:fwd", "VIFNet": "encode.1.2:fwd"}.get(args.model, "") if args.mode == "train" else ""
     T.PROFILE_TAGS = {args.roofline_tag} | ({hbm_tag} if hbm_tag else set())
     T.PROFILE_EVENTS.clear()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         tot = step()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     T.PROFILE_TAGS = set()
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     loss = float(tot.item())
@@ -204,7 +207,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.mode == "train" and Wd == S:
             out["cpu_baseline"] = cpu_baseline(args.model, S, args.cpu_sample)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

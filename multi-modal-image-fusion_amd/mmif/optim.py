@@ -100,10 +100,11 @@ class FusedClipAdam(torch.optim.Optimizer):
         self._flatten_params(ps)
         flat_g = self._flat_grads(ps)
         total = self._flat_p.numel()
-        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        in_group = dist.is_available() and dist.is_initialized()
+        world = dist.get_world_size() if in_group else 1
         if scalars:
             flat_g[total:total + len(scalars)] = torch.stack([s.detach().float().reshape(()) for s in scalars])
-        if world > 1:
+        if in_group:
             dist.all_reduce(flat_g)  # ONE collective: gradients + loss scalars (SUM); mean taken below
         if scalars:
             self.reduced_scalars = flat_g[total:total + len(scalars)] / world
