@@ -110,6 +110,14 @@ int mmif_conv2d_reflect_fwd(const mmif_tensor* x, const float* w, const void* w_
 int mmif_conv2d_reflect_dgrad(const mmif_tensor* gy, const float* w, const void* w_packed_t, const mmif_tensor* x,
                               const mmif_tensor* gx, int32_t cin, int32_t cout, int32_t ksize, uint64_t mask_bits,
                               uint64_t accum_bits, int32_t impl, void* stream);
+/* The same followed by mmif_fold_halo(gx): on return gx's interior is the gradient w.r.t. the unpadded tensor and its halo ring
+ * is zero (treat it as MMIF_T_FOLDED).  gx's halo ring must be zero on entry (a fresh zeroed buffer, or the result of an
+ * earlier fold), also when accumulating.  The bf16 DMA-staged kernels do the fold inside the border tiles of the dgrad (interior
+ * tiles only, no second pass, the halo values are never rounded to bf16); every other case runs dgrad + the fold kernel.
+ * ($MMIF_DGRAD_FOLD=0 forces the two-kernel form.) */
+int mmif_conv2d_reflect_dgrad_folded(const mmif_tensor* gy, const float* w, const void* w_packed_t, const mmif_tensor* x,
+                                     const mmif_tensor* gx, int32_t cin, int32_t cout, int32_t ksize,
+                                     uint64_t mask_bits, uint64_t accum_bits, int32_t impl, void* stream);
 /* dw[cout][cin][k][k] (=|+=) sum_p fold(gy)[p] * reflect_pad(x)[p+tap]; db[cout] (=|+=) sum_p fold(gy)[p].
  * replaces convolution_backward(weight, bias). */
 size_t mmif_conv2d_wgrad_workspace(int32_t cin, int32_t cout, int32_t ksize);

@@ -12,7 +12,8 @@ int wgrad_valu(int dtype, int ks, const TV& tx, const TV& tg, float* dw, float* 
 // conv_mfma.hip
 bool conv_mfma_supported(bool dgrad, int ks, int cin, int cout);
 int conv_mfma(bool dgrad, int ks, const TV& tin, const TV& tout, const TV& tmask, const void* w_packed, const float* bias,
-              int cin, int cout, int relu, uint64_t mask_bits, uint64_t accum_bits, hipStream_t st);
+              int cin, int cout, int relu, uint64_t mask_bits, uint64_t accum_bits, hipStream_t st, bool fold = false,
+              bool* folded = nullptr);
 bool wgrad_mfma_supported(int ks, int cin, int cout);
 size_t wgrad_mfma_workspace(int cin, int cout, int ks);
 int wgrad_mfma(int ks, const TV& tx, const TV& tg, float* dw, float* db, int cin, int cout, int accumulate, float* ws,
@@ -53,29 +54,48 @@ extern "C" int mmif_conv2d_reflect_fwd(const mmif_tensor* x, const float* w, con
     return conv_valu(false, x->dtype, ksize, tx, ty, ty, w, bias, cin, cout, relu, 0, 0, (hipStream_t)stream);
 }
 
+static int dgrad_impl(const char* what, const mmif_tensor* gy, const float* w, const void* w_packed_t, const mmif_tensor* x,
+                      const mmif_tensor* gx, int32_t cin, int32_t cout, int32_t ksize, uint64_t mask_bits, uint64_t accum_bits,
+                      int32_t impl, void* stream, bool fold) {
+    if (int rc = validate_tensor(gy, "gy")) return rc;
+    if (int rc = validate_tensor(gx, "gx")) return rc;
+    MMIF_REQUIRE(ksize == 1 || ksize == 3, "%s: ksize must be 1 or 3 (got %d)", what, ksize);
+    MMIF_REQUIRE(gx->halo >= ksize / 2, "%s: gx needs halo >= ksize/2", what);
+    MMIF_REQUIRE(gy->dtype == gx->dtype && gy->n == gx->n && gy->h == gx->h && gy->w == gx->w, "%s: gy/gx mismatch", what);
+    MMIF_REQUIRE(cin > 0 && (cin + 7) / 8 == gx->cb, "%s: cin=%d does not match gx.cb=%d", what, cin, gx->cb);
+    MMIF_REQUIRE(cout > 0 && (cout + 7) / 8 == gy->cb, "%s: cout=%d does not match gy.cb=%d", what, cout, gy->cb);
+    TV tg = make_tv(gy), tgx = make_tv(gx), tm = tgx;
+    if (mask_bits) {
+        MMIF_REQUIRE(x != nullptr, "%s: mask_bits set but x is NULL", what);
+        if (int rc = validate_tensor(x, "x")) return rc;
+        MMIF_REQUIRE(x->halo == 0 && x->dtype == gx->dtype && x->n == gx->n && x->h == gx->h && x->w == gx->w && x->cb == gx->cb,
+                     "%s: x does not match gx", what);
+        tm = make_tv(x);
+    }
+    const int im = pick_impl(impl, gy->dtype, conv_mfma_supported(true, ksize, cin, cout) && w_packed_t != nullptr, what);
+    if (im < 0) return MMIF_EINVAL;
+    bool folded = false;
+    int rc;
+    if (im == MMIF_IMPL_MFMA) {
+        rc = conv_mfma(true, ksize, tg, tgx, tm, w_packed_t, nullptr, cin, cout, 0, mask_bits, accum_bits, (hipStream_t)stream, fold, &folded);
+    } else {
+        MMIF_REQUIRE(w != nullptr, "%s: VALU path needs the fp32 master weights", what);
+        rc = conv_valu(true, gy->dtype, ksize, tg, tgx, tm, w, nullptr, cin, cout, 0, mask_bits, accum_bits, (hipStream_t)stream);
+    }
+    if (rc != MMIF_OK || !fold || folded || gx->halo == 0 || ksize == 1) return rc;   // (a 1x1 dgrad never writes the halo)
+    return mmif_fold_halo(gx, stream);   // the kernel chosen wrote the padded domain: fold it with the stand-alone kernel
+}
+
 extern "C" int mmif_conv2d_reflect_dgrad(const mmif_tensor* gy, const float* w, const void* w_packed_t, const mmif_tensor* x,
                                          const mmif_tensor* gx, int32_t cin, int32_t cout, int32_t ksize, uint64_t mask_bits,
                                          uint64_t accum_bits, int32_t impl, void* stream) {
-    if (int rc = validate_tensor(gy, "gy")) return rc;
-    if (int rc = validate_tensor(gx, "gx")) return rc;
-    MMIF_REQUIRE(ksize == 1 || ksize == 3, "conv2d_reflect_dgrad: ksize must be 1 or 3 (got %d)", ksize);
-    MMIF_REQUIRE(gx->halo >= ksize / 2, "conv2d_reflect_dgrad: gx needs halo >= ksize/2");
-    MMIF_REQUIRE(gy->dtype == gx->dtype && gy->n == gx->n && gy->h == gx->h && gy->w == gx->w, "conv2d_reflect_dgrad: gy/gx mismatch");
-    MMIF_REQUIRE(cin > 0 && (cin + 7) / 8 == gx->cb, "conv2d_reflect_dgrad: cin=%d does not match gx.cb=%d", cin, gx->cb);
-    MMIF_REQUIRE(cout > 0 && (cout + 7) / 8 == gy->cb, "conv2d_reflect_dgrad: cout=%d does not match gy.cb=%d", cout, gy->cb);
-    TV tg = make_tv(gy), tgx = make_tv(gx), tm = tgx;
-    if (mask_bits) {
-        MMIF_REQUIRE(x != nullptr, "conv2d_reflect_dgrad: mask_bits set but x is NULL");
-        if (int rc = validate_tensor(x, "x")) return rc;
-        MMIF_REQUIRE(x->halo == 0 && x->dtype == gx->dtype && x->n == gx->n && x->h == gx->h && x->w == gx->w && x->cb == gx->cb,
-                     "conv2d_reflect_dgrad: x does not match gx");
-        tm = make_tv(x);
-    }
-    const int im = pick_impl(impl, gy->dtype, conv_mfma_supported(true, ksize, cin, cout) && w_packed_t != nullptr, "conv2d_reflect_dgrad");
-    if (im < 0) return MMIF_EINVAL;
-    if (im == MMIF_IMPL_MFMA) return conv_mfma(true, ksize, tg, tgx, tm, w_packed_t, nullptr, cin, cout, 0, mask_bits, accum_bits, (hipStream_t)stream);
-    MMIF_REQUIRE(w != nullptr, "conv2d_reflect_dgrad: VALU path needs the fp32 master weights");
-    return conv_valu(true, gy->dtype, ksize, tg, tgx, tm, w, nullptr, cin, cout, 0, mask_bits, accum_bits, (hipStream_t)stream);
+    return dgrad_impl("conv2d_reflect_dgrad", gy, w, w_packed_t, x, gx, cin, cout, ksize, mask_bits, accum_bits, impl, stream, false);
+}
+
+extern "C" int mmif_conv2d_reflect_dgrad_folded(const mmif_tensor* gy, const float* w, const void* w_packed_t, const mmif_tensor* x,
+                                                const mmif_tensor* gx, int32_t cin, int32_t cout, int32_t ksize, uint64_t mask_bits,
+                                                uint64_t accum_bits, int32_t impl, void* stream) {
+    return dgrad_impl("conv2d_reflect_dgrad_folded", gy, w, w_packed_t, x, gx, cin, cout, ksize, mask_bits, accum_bits, impl, stream, true);
 }
 
 extern "C" size_t mmif_conv2d_wgrad_workspace(int32_t cin, int32_t cout, int32_t ksize) {

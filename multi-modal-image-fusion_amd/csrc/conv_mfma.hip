@@ -157,8 +157,9 @@ __device__ inline uint4 load_in_gradfold(const TV& t, int in_, int c, int y, int
 // bound: 16 stores ~ 10k cycles per block).  oxs / oys0: stored column / first stored row (of the lane's row pair 0).
 template <int MF, bool DGRAD>
 __device__ inline void conv_epilogue(const f32x4 (&acc)[MF][4], const TV& tout, const TV& tmask, const float* s_bias, int mb, int in_,
-                                     int oxs, int oys0, int g, int relu, unsigned long long mask_bits, unsigned long long accum_bits) {
-    if (oxs >= tout.ws) return;
+                                     int oxs, int oys0, int g, int relu, unsigned long long mask_bits, unsigned long long accum_bits,
+                                     int xlim, int ylim) {   // stored columns / rows >= xlim / ylim are not written
+    if (oxs >= xlim) return;
     const unsigned row_bytes = (unsigned)tout.ws * 16u;
     const unsigned pix_off = (unsigned)(oys0 * tout.ws + oxs) * 16u;   // inside one plane
     // dgrad: fetch the old gradient / the ReLU-mask activations of ALL the lane's outputs first -- one memory round trip for
@@ -179,7 +180,7 @@ __device__ inline void conv_epilogue(const f32x4 (&acc)[MF][4], const TV& tout, 
                 oldv[m][p2] = make_uint4(0, 0, 0, 0);
                 xmv[m][p2] = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);   // 1.0: mask passes
                 const int oys = oys0 + 2 * p2;
-                if (blk_ok && oys < tout.hs) {
+                if (blk_ok && oys < ylim) {
                     if (do_acc) oldv[m][p2] = *reinterpret_cast<const uint4*>(oplane + (2 * p2) * row_bytes);
                     if (do_mask) {
                         const int y = min(max(reflect_idx(oys - tout.halo, tmask.h), 0), tmask.h - 1);
@@ -210,7 +211,7 @@ __device__ inline void conv_epilogue(const f32x4 (&acc)[MF][4], const TV& tout, 
                 c[4 + r] = __uint_as_float(sw[1]);
             }
             const int oys = oys0 + 2 * p2;
-            if (!blk_ok || oys >= tout.hs) continue;
+            if (!blk_ok || oys >= ylim) continue;
             if (!DGRAD) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
@@ -431,7 +432,7 @@ __global__ __launch_bounds__(256, MF == 1 ? 4 : 2) void conv_mfma_kernel(TV tin,
     }
 
     conv_epilogue<MF, DGRAD>(acc, tout, tmask, s_bias, mb, in_, tile_x * MT + j, tile_y * MT + wave * 4 + (g & 1), g, relu, mask_bits,
-                             accum_bits);
+                             accum_bits, tout.ws, tout.hs);
     TRACE_STAMP();        // epilogue stores issued
     if (tr != nullptr) tr[63] = tr_n;
 #undef TRACE_STAMP
@@ -464,6 +465,99 @@ static_assert(CHUNK_CB * DPL % 64 == 0, "input planes must be whole DMA pieces")
 
 struct DItem { int mb, in_, tile_y, tile_x; };
 
+// ---- dgrad with the reflect-padding adjoint FOLDED IN (org = 1) --------------------------------------------------------------
+// The padded output domain of a 3x3 dgrad is (h+2) x (w+2): tiling all of it costs 9 x 17 tiles of 32 x 16 for a 256 x 256 image
+// where the interior needs 8 x 16, and the halo ring then has to be folded back by a second kernel.  With org = 1 the tiles cover
+// the interior only and the tiles that own stored rows 2 / hs-3 or columns 2 / ws-3 (logical 1, h-2 / 1, w-2: the fold targets)
+// add the ring pixels' values themselves: the ring pixel above stored row 2 is  sum_v Wk[2][v] g[1][X-1+v]  -- the operand
+// fragment the row already uses for tap (0, v), times the weights of tap (2, v) -- so the fold costs 3 extra MFMA steps per chunk
+// for that one row (12 for a border column, with every lane but the target's zeroed; 1 for a corner), no second pass over HBM
+// and no bf16 rounding of the halo values.  The ring itself is never written (it stays zero: 'folded').
+template <int N> struct IC { static constexpr int value = N; };
+
+// One chunk's fold steps of the wave whose row n is stored row 1 + yl + n and whose lane j is stored column 1 + xl + j.
+// in_c / w_c: this lane group's channel-block plane of the staged gradient tile (at the wave's first row, lane's column) and of
+// the chunk's weight planes (tap t at w_c + t * ncb * MF * 256); pitch = granules per tile row.
+template <int MF>
+__device__ inline void dgrad_fold_steps(f32x4 (&acc)[MF][4], const char* in_c, const char* w_c, int ncb, int pitch, int g, int j, int yl,
+                                        int xl, int hs, int ws) {
+    const int nb = hs - 4 - yl;                 // row n of stored row hs-3 (stored row 2 is row 1 of the wave with yl == 0)
+    const int jl = 1 - xl, jr = ws - 4 - xl;    // lanes of stored columns 2 / ws-3
+    const bool has_t = yl == 0, has_b = nb >= 0 && nb < 4, has_l = jl >= 0, has_r = jr >= 0 && jr < MT;
+    if (!(has_t || has_b || has_l || has_r)) return;
+    const bf16x8 zero8 = __builtin_bit_cast(bf16x8, make_uint4(0, 0, 0, 0));
+    const bool kz = g >= ncb;   // lane group past the end of a ragged chunk
+    // gradient fragment at (tile row brow relative to the wave's first, column offset bcol): all lanes (jsel < 0) or lane jsel only
+    auto ldb = [&](int brow, int bcol, int jsel) {
+        bf16x8 b = *reinterpret_cast<const bf16x8*>(in_c + (brow * pitch + bcol) * 16);
+        if (kz || (jsel >= 0 && j != jsel)) b = zero8;
+        return b;
+    };
+    auto lda = [&](int tap, int m) { return *reinterpret_cast<const bf16x8*>(w_c + tap * ncb * (MF * 256) + m * 256); };
+    auto at_row = [&](int n, auto&& f) {   // run f(IC<n>) for a wave-uniform n in 0..3
+        if (n == 0) f(IC<0>()); else if (n == 1) f(IC<1>()); else if (n == 2) f(IC<2>()); else f(IC<3>());
+    };
+    // a ring ROW folds onto one row of one wave: taps (urow, v), v = 0..2, on tile row brow -- all operands first, then the MFMAs
+    auto row_steps = [&](auto nc, int tap0, int brow) {
+        constexpr int n = decltype(nc)::value;
+        bf16x8 b[3], a[3][MF];
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            b[v] = ldb(brow, v, -1);
+#pragma unroll
+            for (int m = 0; m < MF; ++m) a[v][m] = lda(tap0 + v, m);
+        }
+#pragma unroll
+        for (int v = 0; v < 3; ++v)
+#pragma unroll
+            for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[v][m], b[v], acc[m][n], 0, 0, 0);
+    };
+    // a ring COLUMN folds onto one lane of every row: three more k-steps (taps (u, vcol), u = 0..2) of the usual shape -- 4 weight
+    // + 4 gradient fragments, 4 MF MFMAs -- with the next step's operands fetched under the current step's MFMAs
+    auto col_steps = [&](int vcol, int bcol, int jsel) {
+        constexpr int NB = MF == 3 ? 1 : 2;   // (the 128-register budget of the MF = 3 thin kernel has no room for a second operand set)
+        bf16x8 a[NB][MF], b[NB][4];
+        auto fetch = [&](int u, int slot) {
+#pragma unroll
+            for (int m = 0; m < MF; ++m) a[slot][m] = lda(3 * u + vcol, m);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) b[slot][n] = ldb(n + u, bcol, jsel);
+        };
+        if (NB == 2) fetch(0, 0);
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            if (NB == 1) fetch(u, 0);
+            else if (u + 1 < 3) fetch(u + 1, (u + 1) & 1);
+#pragma unroll
+            for (int m = 0; m < MF; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u & (NB - 1)][m], b[u & (NB - 1)][n], acc[m][n], 0, 0, 0);
+        }
+    };
+    auto corner = [&](auto nc, int tap, int brow, int bcol, int jsel) {
+        constexpr int n = decltype(nc)::value;
+        const bf16x8 b = ldb(brow, bcol, jsel);
+#pragma unroll
+        for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lda(tap, m), b, acc[m][n], 0, 0, 0);
+    };
+    if (has_t) {   // ring row 0 -> stored row 2 (n = 1): taps (2, v) on g row 1 = tile row n + 0
+        row_steps(IC<1>(), 6, 1);
+        if (has_l) corner(IC<1>(), 8, 1, 0, jl);
+        if (has_r) corner(IC<1>(), 6, 1, 2, jr);
+    }
+    if (has_b) {   // ring row hs-1 -> stored row hs-3: taps (0, v) on g row hs-2 = tile row n + 2
+        at_row(nb, [&](auto nc) {
+            constexpr int n = decltype(nc)::value;
+            row_steps(nc, 0, n + 2);
+            if (has_l) corner(nc, 2, n + 2, 0, jl);
+            if (has_r) corner(nc, 0, n + 2, 2, jr);
+        });
+    }
+    if (has_l) col_steps(2, 0, jl);   // ring column 0    -> stored column 2:    taps (u, 2) on g column 1
+    if (has_r) col_steps(0, 2, jr);   // ring column ws-1 -> stored column ws-3: taps (u, 0) on g column ws-2
+}
+
 constexpr int D_CONS = 8;                                          // consumer waves (MFMA): wave w owns tile rows 4w..4w+3
 constexpr int D_LOAD = 4;                                          // loader waves (LDS-DMA issue only), one per SIMD
 constexpr int DL_ITERS = (D_PIECES + D_LOAD - 1) / D_LOAD;         // 19 pieces per loader wave per chunk
@@ -474,7 +568,7 @@ __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void conv_dma_kernel(TV 
                                                                               const float* __restrict__ bias, int n_out, int m16p, int relu,
                                                                               unsigned long long mask_bits, unsigned long long accum_bits,
                                                                               int tiles_x, int tiles_y, int nmb, long long* __restrict__ trace,
-                                                                              int abl) {
+                                                                              int abl, int org) {
     constexpr int MF = 4;
     __shared__ __attribute__((aligned(16))) char s_buf[2 * DBUF_BYTES];
     __shared__ int2 s_tab[2][DW_PIECES];
@@ -517,6 +611,9 @@ __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void conv_dma_kernel(TV 
         const int trem = tl - it.in_ * tpi;
         it.tile_y = trem / tiles_x;
         it.tile_x = trem - it.tile_y * tiles_x;
+        // fused fold: a block's items are a whole number of tile rows apart, so without a skew one block would own ONLY left-border
+        // tiles (three extra k-steps per chunk each) and set the kernel's makespan; rotate the columns by row and image
+        if (org) it.tile_x = (it.tile_x + it.tile_y + it.in_) % tiles_x;
         return it;
     };
     const int ncb_tot = tin.cb;
@@ -551,7 +648,7 @@ __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void conv_dma_kernel(TV 
             d_cb |= (unsigned)cb << (2 * i);
         }
         auto make_desc = [&](const DItem& itm) {
-            const int iy0 = itm.tile_y * DT_ROWS - tout.halo - 1, ix0 = itm.tile_x * MT - tout.halo - 1;
+            const int iy0 = itm.tile_y * DT_ROWS - tout.halo - 1 + org, ix0 = itm.tile_x * MT - tout.halo - 1 + org;
 #pragma unroll
             for (int i = 0; i < DL_IN_ITERS; ++i) {
                 int y = iy0 + (int)(d_geo[i] >> 8), x = ix0 + (int)(d_geo[i] & 255u);
@@ -628,8 +725,9 @@ __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void conv_dma_kernel(TV 
         __builtin_amdgcn_s_barrier();
         DTRACE();   // barrier passed
         if (have_pend) {   // waves 4..7: previous tile's outputs, stored under the partner wave's MFMAs (see below)
-            conv_epilogue<MF, DGRAD>(acc, tout, tmask, s_bias[pend_slot], pend.mb, pend.in_, pend.tile_x * MT + j,
-                                     pend.tile_y * DT_ROWS + wave * 4 + (g & 1), g, relu, mask_bits, accum_bits);
+            conv_epilogue<MF, DGRAD>(acc, tout, tmask, s_bias[pend_slot], pend.mb, pend.in_, org + pend.tile_x * MT + j,
+                                     org + pend.tile_y * DT_ROWS + wave * 4 + (g & 1), g, relu, mask_bits, accum_bits, tout.ws - org,
+                                     tout.hs - org);
             have_pend = false;
         }
         DTRACE();   // pending epilogue done
@@ -644,7 +742,7 @@ __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void conv_dma_kernel(TV 
         const char* w_lane = s_buf + buf * DBUF_BYTES + CHUNK_CB * DPL * 16 + j * 16;
         // a wave whose 4 rows lie below the output (ragged last tile row; 258 = 8*32 + 2 for the padded domain of a 256-row
         // dgrad) has nothing to compute: it leaves the MFMA pipe to its SIMD partner and just keeps the barrier count
-        const bool rows_live = !DGRAD || cur.tile_y * DT_ROWS + wave * 4 < tout.hs;
+        const bool rows_live = !DGRAD || org + cur.tile_y * DT_ROWS + wave * 4 < tout.hs - org;
         if (!rows_live) {
         } else if (ncb == CHUNK_CB) {
             // ---- full chunk: k-step s = tap s over channel blocks g = 0..3; fully unrolled (immediate LDS offsets).
@@ -704,6 +802,9 @@ __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void conv_dma_kernel(TV 
                 nx = nx2;
             }
         }
+        if (DGRAD && org && rows_live && !(abl & 4))
+            dgrad_fold_steps<MF>(acc, in_lane + min(g, ncb - 1) * (DPL * 16), w_lane + min(g, ncb - 1) * (MF * 256), ncb, DTP_X, g, j,
+                                 cur.tile_y * DT_ROWS + wave * 4, cur.tile_x * MT, tout.hs, tout.ws);
         DTRACE();   // k-loop done
         if (++c == nch) {
             c = 0;
@@ -711,8 +812,9 @@ __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void conv_dma_kernel(TV 
             // their outputs now, under the partner's remaining MFMAs; waves 4..7 store after the next barrier, under the
             // partner's next k-loop.  (All eight storing at the same point leaves the MFMA pipe idle for a whole epilogue.)
             if (wave < 4) {
-                conv_epilogue<MF, DGRAD>(acc, tout, tmask, s_bias[item_i % 3], cur.mb, cur.in_, cur.tile_x * MT + j,
-                                         cur.tile_y * DT_ROWS + wave * 4 + (g & 1), g, relu, mask_bits, accum_bits);
+                conv_epilogue<MF, DGRAD>(acc, tout, tmask, s_bias[item_i % 3], cur.mb, cur.in_, org + cur.tile_x * MT + j,
+                                         org + cur.tile_y * DT_ROWS + wave * 4 + (g & 1), g, relu, mask_bits, accum_bits, tout.ws - org,
+                                         tout.hs - org);
             } else {
                 pend = cur;
                 pend_slot = item_i % 3;
@@ -726,8 +828,9 @@ __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void conv_dma_kernel(TV 
     if (tr != nullptr) tr[63] = tr_n;
 #undef DTRACE
     if (have_pend)
-        conv_epilogue<MF, DGRAD>(acc, tout, tmask, s_bias[pend_slot], pend.mb, pend.in_, pend.tile_x * MT + j,
-                                 pend.tile_y * DT_ROWS + wave * 4 + (g & 1), g, relu, mask_bits, accum_bits);
+        conv_epilogue<MF, DGRAD>(acc, tout, tmask, s_bias[pend_slot], pend.mb, pend.in_, org + pend.tile_x * MT + j,
+                                 org + pend.tile_y * DT_ROWS + wave * 4 + (g & 1), g, relu, mask_bits, accum_bits, tout.ws - org,
+                                 tout.hs - org);
 }
 
 // ------------------------------------------------------------------ thin layers: asynchronous loader / consumer kernel
@@ -780,8 +883,8 @@ __device__ inline void tn_wait_counter(volatile unsigned* ctr, unsigned target) 
 template <int MF, bool DGRAD>
 __global__ __launch_bounds__((4 * TN_GROUPS + TN_LOAD) * 64, 4) void thin_conv_async_kernel(
     TV tin, TV tout, TV tmask, const uint4* __restrict__ wpk, const float* __restrict__ bias, int n_out, int relu,
-    unsigned long long mask_bits, unsigned long long accum_bits, int tiles_x, int tiles_y, int ntiles) {
-    constexpr int TP = MT + 2;
+    unsigned long long mask_bits, unsigned long long accum_bits, int tiles_x, int tiles_y, int ntiles, int org) {
+    constexpr int TP = MT + 2;   // org: as in conv_dma_kernel (dgrad over the interior of the padded domain, fold steps in the border tiles)
     constexpr int NCONS = 4 * TN_GROUPS;
     __shared__ __attribute__((aligned(16))) char s_in[tn_ring_bytes(MF)];
     __shared__ __attribute__((aligned(16))) uint4 s_w[TN_MAXKG * MF * 16];
@@ -808,6 +911,7 @@ __global__ __launch_bounds__((4 * TN_GROUPS + TN_LOAD) * 64, 4) void thin_conv_a
         const int trem = lin - in_ * tpi;
         tile_y = trem / tiles_x;
         tile_x = trem - tile_y * tiles_x;
+        if (org) tile_x = (tile_x + tile_y + in_) % tiles_x;   // (see conv_dma_kernel: spread the border tiles over the blocks)
     };
     const int in_pieces = (ncb_tot * TN_PL + 63) / 64;        // <= 32
     const int P = (in_pieces + TN_LOAD - 1) / TN_LOAD;        // pieces per loader wave per tile (every loader issues exactly P)
@@ -855,7 +959,7 @@ __global__ __launch_bounds__((4 * TN_GROUPS + TN_LOAD) * 64, 4) void thin_conv_a
         auto issue_tile = [&](int k) {
             int in_, ty0, tx0;
             tile_of(b + k * G, in_, ty0, tx0);
-            const int iy0 = ty0 * MT - tout.halo - 1, ix0 = tx0 * MT - tout.halo - 1;
+            const int iy0 = ty0 * MT - tout.halo - 1 + org, ix0 = tx0 * MT - tout.halo - 1 + org;
             const char* src = tin.base + ((long long)in_ * tin.img + (long long)tin.cb_off * tin.plane) * 16;
             char* dst = s_in + (k % NS) * slot_bytes;
 #pragma unroll
@@ -933,10 +1037,18 @@ __global__ __launch_bounds__((4 * TN_GROUPS + TN_LOAD) * 64, 4) void thin_conv_a
                 nx = nx2;
             }
         }
+        if (DGRAD && org) {
+            for (int c = 0; c < nch; ++c) {
+                const int ncb = min(CHUNK_CB, ncb_tot - c * CHUNK_CB), gc = min(g, ncb - 1);
+                dgrad_fold_steps<MF>(acc, in_lane + (c * CHUNK_CB + gc) * (TN_PL * 16), w_lane + (c * 36 + gc) * (MF * 256), ncb, TP, g, j,
+                                     ty0 * MT + r * 4, tx0 * MT, tout.hs, tout.ws);
+            }
+        }
         // every LDS read of this tile has been consumed by an MFMA above: hand the slot back before the (long) epilogue
         __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) atomicAdd(&s_done[k % NS], 1u);
-        conv_epilogue<MF, DGRAD>(acc, tout, tmask, s_bias, 0, in_, tx0 * MT + j, ty0 * MT + r * 4 + (g & 1), g, relu, mask_bits, accum_bits);
+        conv_epilogue<MF, DGRAD>(acc, tout, tmask, s_bias, 0, in_, org + tx0 * MT + j, org + ty0 * MT + r * 4 + (g & 1), g, relu, mask_bits,
+                                 accum_bits, tout.ws - org, tout.hs - org);
     }
 }
 
@@ -1372,11 +1484,12 @@ static int num_cus_() {
 
 static int g_dma_mode = -1;   // $MMIF_CONV_DMA: 1 (default) = DMA-staged kernel where it applies, 0 = never
 static int g_num_cus = 0;
+static int g_fuse_fold = -1;   // $MMIF_DGRAD_FOLD: 1 (default) = the DMA-staged dgrads fold the reflect halo themselves
 static int g_abl = 0;            // $MMIF_CONV_ABLATE (diagnostics): bit 0 = no staging DMAs after the first chunk
 
 static int launch_conv_dma(bool dgrad, const TV& tin, const TV& tout, const TV& tmask, const void* wpk, const float* bias, int n_out,
-                           int relu, uint64_t mask_bits, uint64_t accum_bits, hipStream_t st) {
-    const int tiles_x = cdiv(tout.ws, MT), tiles_y = cdiv(tout.hs, DT_ROWS);
+                           int relu, uint64_t mask_bits, uint64_t accum_bits, int org, hipStream_t st) {
+    const int tiles_x = cdiv(tout.ws - 2 * org, MT), tiles_y = cdiv(tout.hs - 2 * org, DT_ROWS);
     const int nmb = n_mblocks(n_out);
     const int m16p = nmb * 4 * 16;
     const long long nitems = (long long)tiles_x * tiles_y * tout.n * nmb;
@@ -1391,15 +1504,18 @@ static int launch_conv_dma(bool dgrad, const TV& tin, const TV& tout, const TV& 
     if (nitems < G) G = (int)nitems;
     if (dgrad)
         hipLaunchKernelGGL((conv_dma_kernel<true>), dim3(G), dim3((D_CONS + D_LOAD) * 64), 0, st, tin, tout, tmask, (const uint4*)wpk, bias, n_out, m16p, relu,
-                           (unsigned long long)mask_bits, (unsigned long long)accum_bits, tiles_x, tiles_y, nmb, g_trace, g_abl);
+                           (unsigned long long)mask_bits, (unsigned long long)accum_bits, tiles_x, tiles_y, nmb, g_trace, g_abl, org);
     else
         hipLaunchKernelGGL((conv_dma_kernel<false>), dim3(G), dim3((D_CONS + D_LOAD) * 64), 0, st, tin, tout, tmask, (const uint4*)wpk, bias, n_out, m16p, relu,
-                           (unsigned long long)mask_bits, (unsigned long long)accum_bits, tiles_x, tiles_y, nmb, g_trace, g_abl);
+                           (unsigned long long)mask_bits, (unsigned long long)accum_bits, tiles_x, tiles_y, nmb, g_trace, g_abl, 0);
     return check_launch(dgrad ? "conv_dma dgrad" : "conv_dma fwd");
 }
 
+// fold (dgrad only): the caller wants fold_halo(gx) applied as well and guarantees that gx's halo ring is zero on entry; *folded
+// reports whether the kernel chosen did it (interior tiles + fold steps, ring left zero) -- otherwise the caller runs the fold kernel.
 int conv_mfma(bool dgrad, int ks, const TV& tin, const TV& tout, const TV& tmask, const void* w_packed, const float* bias,
-              int cin, int cout, int relu, uint64_t mask_bits, uint64_t accum_bits, hipStream_t st) {
+              int cin, int cout, int relu, uint64_t mask_bits, uint64_t accum_bits, hipStream_t st, bool fold, bool* folded) {
+    if (folded != nullptr) *folded = false;
     const int n_out = dgrad ? cin : cout;
     const int mf = pick_mf(n_out);
     if (g_dma_mode < 0) {
@@ -1407,11 +1523,17 @@ int conv_mfma(bool dgrad, int ks, const TV& tin, const TV& tout, const TV& tmask
         g_dma_mode = (e != nullptr && e[0] == '0') ? 0 : 1;
         const char* a = getenv("MMIF_CONV_ABLATE");
         g_abl = a != nullptr ? atoi(a) : 0;
+        const char* r = getenv("MMIF_DGRAD_FOLD");
+        g_fuse_fold = (r != nullptr && r[0] == '0') ? 0 : 1;
     }
+    const int org = (dgrad && fold && folded != nullptr && ks == 3 && g_fuse_fold == 1 && tout.halo == 1 && tout.h >= 4 && tout.w >= 4) ? 1 : 0;
     // the DMA-staged kernel: 3x3, 64-row M-blocks, input gradient already folded, tensors within 32-bit plane offsets
     if (g_dma_mode == 1 && ks == 3 && mf == 4 && (!dgrad || (tin.halo == 1 && tin.folded)) &&
         tin.plane * 16 * CHUNK_CB < (1ll << 31))
-        return launch_conv_dma(dgrad, tin, tout, tmask, w_packed, bias, n_out, relu, mask_bits, accum_bits, st);
+    {
+        if (org) *folded = true;
+        return launch_conv_dma(dgrad, tin, tout, tmask, w_packed, bias, n_out, relu, mask_bits, accum_bits, org, st);
+    }
     // thin layers: asynchronous loader / consumer kernel with resident weights (one M-block of <= 48 channels, <= 48 input
     // channels, a ring of at least TN_GROUPS + 1 tile slots, at least two tiles per persistent block).  Measured (B=32 256x256,
     // vs conv_mfma_kernel<3,MF>): every dgrad -13 .. -21 %, forward with 32 / 48 outputs -14 % / -30 %; forward with 16 outputs
@@ -1419,7 +1541,7 @@ int conv_mfma(bool dgrad, int ks, const TV& tin, const TV& tout, const TV& tmask
     if (g_dma_mode == 1 && ks == 3 && mf <= 3 && (dgrad || mf >= 2) && tin.cb <= TN_MAXCB &&
         (!dgrad || (tin.halo == 1 && tin.folded)) &&
         tin.plane * 16 * TN_MAXCB < (1ll << 31)) {
-        const int tiles_x = cdiv(tout.ws, MT), tiles_y = cdiv(tout.hs, MT);
+        const int tiles_x = cdiv(tout.ws - 2 * org, MT), tiles_y = cdiv(tout.hs - 2 * org, MT);
         const long long ntiles = (long long)tiles_x * tiles_y * tout.n;
         const int P = cdiv(cdiv(tin.cb * TN_PL, 64), TN_LOAD), slot_bytes = P * TN_LOAD * 1024;
         int G = num_cus_() / 8 * 8;
@@ -1430,11 +1552,12 @@ int conv_mfma(bool dgrad, int ks, const TV& tin, const TV& tout, const TV& tmask
         if (dgrad)                                                                                                                     \
             hipLaunchKernelGGL((thin_conv_async_kernel<MF_, true>), dim3(G), dim3((4 * TN_GROUPS + TN_LOAD) * 64), 0, st, tin, tout,   \
                                tmask, (const uint4*)w_packed, bias, n_out, relu, (unsigned long long)mask_bits,                       \
-                               (unsigned long long)accum_bits, tiles_x, tiles_y, (int)ntiles);                                        \
+                               (unsigned long long)accum_bits, tiles_x, tiles_y, (int)ntiles, org);                                   \
         else                                                                                                                           \
             hipLaunchKernelGGL((thin_conv_async_kernel<MF_, false>), dim3(G), dim3((4 * TN_GROUPS + TN_LOAD) * 64), 0, st, tin, tout,  \
                                tmask, (const uint4*)w_packed, bias, n_out, relu, (unsigned long long)mask_bits,                       \
-                               (unsigned long long)accum_bits, tiles_x, tiles_y, (int)ntiles);                                        \
+                               (unsigned long long)accum_bits, tiles_x, tiles_y, (int)ntiles, 0);                                     \
+        if (org) *folded = true;                                                                                                       \
         return check_launch(dgrad ? "thin_conv_async dgrad" : "thin_conv_async fwd");                                                 \
     } while (0)
             switch (mf) { case 1: TGO(1); case 2: TGO(2); default: TGO(3); }

@@ -59,6 +59,7 @@ SIGNATURES = {
     "mmif_pack_weights_multi": (_i32, [C.POINTER(MmifPackJob), _i32, _vp]),
     "mmif_conv2d_reflect_fwd": (_i32, [_TP, _vp, _vp, _vp, _TP, _i32, _i32, _i32, _i32, _i32, _vp]),
     "mmif_conv2d_reflect_dgrad": (_i32, [_TP, _vp, _vp, _TP, _TP, _i32, _i32, _i32, _u64, _u64, _i32, _vp]),
+    "mmif_conv2d_reflect_dgrad_folded": (_i32, [_TP, _vp, _vp, _TP, _TP, _i32, _i32, _i32, _u64, _u64, _i32, _vp]),
     "mmif_conv2d_wgrad_workspace": (_sz, [_i32, _i32, _i32]),
     "mmif_conv2d_reflect_wgrad": (_i32, [_TP, _TP, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _sz, _i32, _vp]),
     "mmif_conv2d_image_in_fwd": (_i32, [_vp, _vp, _vp, _TP, _i32, _i32, _i32, _vp]),

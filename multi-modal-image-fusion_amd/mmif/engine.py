@@ -276,9 +276,10 @@ class ModelEngine:
 
     @staticmethod
     def c_dgrad(s, gy, x, gx, mask_bits, accum_bits, impl):
-        """dgrad into the padded-domain view gx, then fold its halo; returns the folded view."""
-        T.conv_dgrad(gy, s.w.detach(), x, gx, s.cin, s.cout, s.k, mask_bits, accum_bits, s.packed, impl, s.name + ":dgrad")
-        return gx.fold_halo_() if s.k > 1 else gx.as_folded()
+        """dgrad into the padded-domain view gx + fold of its halo (one call; the DMA-staged kernels fold inside the dgrad);
+        returns the folded view.  Every gradient buffer starts zeroed and is folded after each contribution, so gx's halo ring
+        is zero on entry as mmif_conv2d_reflect_dgrad_folded requires."""
+        return T.conv_dgrad(gy, s.w.detach(), x, gx, s.cin, s.cout, s.k, mask_bits, accum_bits, s.packed, impl, s.name + ":dgrad", fold=True)
 
     @staticmethod
     def c_wgrad(s, x, gy, ws, impl, accumulate=False):

@@ -141,11 +141,14 @@ def conv_fwd(x, w, bias, y, cin, cout, k, relu, packed=None, impl=_lib.IMPL_AUTO
                                           cin, cout, k, int(relu), impl, stream_ptr()), "conv2d_reflect_fwd")
 
 
-def conv_dgrad(gy, w, x, gx, cin, cout, k, mask_bits=0, accum_bits=0, packed=None, impl=_lib.IMPL_AUTO, tag=None):
+def conv_dgrad(gy, w, x, gx, cin, cout, k, mask_bits=0, accum_bits=0, packed=None, impl=_lib.IMPL_AUTO, tag=None, fold=False):
+    """fold=True: dgrad + fold_halo(gx) in one call (mmif_conv2d_reflect_dgrad_folded; gx's halo ring must be zero on entry);
+    returns the folded view."""
+    fn = lib.mmif_conv2d_reflect_dgrad_folded if fold else lib.mmif_conv2d_reflect_dgrad
     with _timed(tag):
-        check(lib.mmif_conv2d_reflect_dgrad(gy.d, _ptr(w), _ptr(packed.dgrad) if packed is not None else None,
-                                            x.d if x is not None else None, gx.d, cin, cout, k, mask_bits, accum_bits, impl,
-                                            stream_ptr()), "conv2d_reflect_dgrad")
+        check(fn(gy.d, _ptr(w), _ptr(packed.dgrad) if packed is not None else None, x.d if x is not None else None, gx.d, cin, cout,
+                 k, mask_bits, accum_bits, impl, stream_ptr()), "conv2d_reflect_dgrad")
+    return gx.as_folded() if fold else gx
 
 
 def conv_wgrad(x, gy, dw, db, cin, cout, k, ws, accumulate=False, impl=_lib.IMPL_AUTO, tag=None):

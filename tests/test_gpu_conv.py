@@ -163,3 +163,51 @@ def test_batched_weight_packing_equals_per_layer_packing():
     torch.cuda.synchronize()
     for a, b in zip(single, multi):
         assert torch.equal(a.fwd, b.fwd) and torch.equal(a.dgrad, b.dgrad)
+
+
+FOLD_SHAPES = DMA_SHAPES + [(128, 64, 1, 4, 4), (64, 64, 2, 5, 7), (16, 16, 40, 64, 64), (48, 16, 36, 66, 62), (128, 128, 1, 70, 35),
+                            (64, 32, 2, 256, 256)]
+
+
+@pytest.mark.parametrize("cin,cout,n,h,w", FOLD_SHAPES, ids=[f"{a}-{b}-{n}x{h}x{w}" for a, b, n, h, w in FOLD_SHAPES])
+def test_dgrad_with_fused_fold_equals_dgrad_then_fold(cin, cout, n, h, w):
+    """mmif_conv2d_reflect_dgrad_folded: the DMA-staged kernels tile the interior only and fold the reflect halo inside the
+    border tiles (extra MFMA steps); reference = the register-staged kernel on the padded domain + mmif_fold_halo.  Pixels
+    that are no fold target are bit-identical; the targets (logical rows 1 / h-2, cols 1 / w-2) differ only by the bf16
+    rounding of the halo values the fused form never stores; the halo ring stays zero; partial mask / accumulate bits."""
+    from mmif import tensor as T
+    from mmif._lib import IMPL_MFMA, lib
+    dev = "cuda:0"
+    torch.manual_seed(cin * 11 + cout + h)
+    x = T.BT.alloc(n, cin, h, w, torch.bfloat16, dev); x.buf.normal_()
+    gy = T.BT.alloc(n, cout, h, w, torch.bfloat16, dev, halo=1, zero=True); gy.buf[:, :, 1:-1, 1:-1].normal_()
+    gy = gy.as_folded()
+    wt = torch.randn(cout, cin, 3, 3, device=dev) * 0.05
+    pk = T.PackedWeights(cout, cin, 3, dev); pk.pack(wt)
+    mask = 0x5a5a5a5a5a5a & ((1 << x.cb) - 1)
+    acc_bits = 0x333333333333 & ((1 << x.cb) - 1)
+    old = torch.randn(n, x.cb, h, w, 8, device=dev).to(torch.bfloat16)
+    res = {}
+    try:
+        for mode in (0, 1):
+            lib.mmif_debug_set_conv_dma(mode)   # 0: register-staged dgrad + fold kernel; 1: fused where the DMA kernels apply
+            gx = T.BT.alloc(n, cin, h, w, torch.bfloat16, dev, halo=1, zero=True)
+            gx.buf[:, :, 1:-1, 1:-1] = old      # accumulate target: folded gradient, zero ring
+            out = T.conv_dgrad(gy, wt, x, gx, cin, cout, 3, mask, acc_bits, pk, IMPL_MFMA, fold=True)
+            torch.cuda.synchronize()
+            assert out.flags & 1
+            res[mode] = gx.buf.float().clone()
+    finally:
+        lib.mmif_debug_set_conv_dma(1)
+    ref, got = res[0], res[1]
+    for r in (ref, got):   # ring is zero in both forms
+        assert float(r[:, :, 0].abs().max()) == 0 and float(r[:, :, -1].abs().max()) == 0
+        assert float(r[:, :, :, 0].abs().max()) == 0 and float(r[:, :, :, -1].abs().max()) == 0
+    tgt = torch.zeros(h + 2, w + 2, dtype=torch.bool, device=dev)
+    tgt[[2, h - 1], :] = True
+    tgt[:, [2, w - 1]] = True
+    assert torch.equal(ref[:, :, ~tgt], got[:, :, ~tgt]), "non-target pixels differ"
+    a, b = ref[:, :, tgt], got[:, :, tgt]
+    err = (a - b).abs()
+    tol = 2.0 ** -6 * torch.maximum(a.abs(), b.abs()) + 3e-2   # two bf16 roundings of O(1) halo values
+    assert bool((err <= tol).all()), f"fold targets differ by up to {float(err.max())}"

@@ -24,7 +24,7 @@ dw = torch.zeros(cout, cin, 3, 3, device=dev); db = torch.zeros(cout, device=dev
 ws = torch.empty(T.wgrad_workspace_bytes(cin, cout, 3) // 4 + 1, dtype=torch.float32, device=dev)
 def run(kind):
     if kind == "fwd": T.conv_fwd(x, w, b, y, cin, cout, 3, True, pk, IMPL_MFMA)
-    elif kind == "dgrad": T.conv_dgrad(gy, w, x, gx, cin, cout, 3, MASK, 0, pk, IMPL_MFMA)
+    elif kind == "dgrad": T.conv_dgrad(gy, w, x, gx, cin, cout, 3, MASK, 0, pk, IMPL_MFMA, fold=os.environ.get("BENCH_FOLD", "0") == "1")
     else: T.conv_wgrad(x, gy, dw, db, cin, cout, 3, ws, False, IMPL_MFMA)
 def timeit(kind):
     for _ in range(3): run(kind)
