@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--model", default="PFNetv1", choices=["PFNetv1", "PFNetv2", "DenseFuse", "VIFNet", "NestFuse", "RFNNest"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture forward + losses + backward in ONE hipGraph and replay it per step (launch-bound small batches); "
+                         "the gradient all-reduce and clip+Adam stay outside the graph")
     ap.add_argument("--cpu-sample", type=int, default=2, help="image pairs in the CPU-oracle sample")
     ap.add_argument("--roofline-tag", default="decode.0:fwd", help="engine op timed with HIP events for `roofline`")
     ap.add_argument("--hbm-tag", default="auto", help="an HBM-bound engine op timed the same way for `roofline_hbm` ('' = none)")
@@ -131,6 +134,19 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    if args.graph and args.mode == "train":
+        # same kernels, same work per step -- only the ~100 launches of forward / losses / backward become one graph launch
+        from mmif.graph import GraphedStep
+
+        def losses(i1, i2, f):
+            a, b, c = l_ssim(i1, i2, f), l_pix(i1, i2, f, mode='max'), l_grad(i1, i2, f, mode='max')
+            return a + b + c, a, b, c
+        gstep = GraphedStep(model, losses, opt, img1, img2)
+
+        def step():   # noqa: F811
+            return gstep(img1, img2)[0]
+        for _ in range(2):
+            step()
     hbm_tag = args.hbm_tag
     if hbm_tag == "auto":   # the widest thin layer of the model's encoder (Cout = 16): 48 -> 16 forward
         hbm_tag = {"PFNetv1": "encode1.1.2:fwd", "DenseFuse": "encode.1.2:fwd", "PFNetv2": "encode.1.2:fwd", "VIFNet": "encode.1.2:fwd"}.get(args.model, "") if args.mode == "train" else ""
@@ -195,6 +211,7 @@ def main():
             "metric": "image-pairs/sec at 256x256, PFNet train step" if args.mode == "train" else f"image-pairs/sec at {Wd}x{S}, {args.model} inference", "value": value, "unit": "image-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "graph": bool(args.graph and args.mode == "train"),
             "config": {"workload": (f"{args.model} train step (fwd + SSIM/pixel/grad losses + bwd + clip + Adam)" if args.mode == "train" else f"{args.model} forward (no_grad, test.py path)") + f", {Wd}x{S} synthetic IR/visible pairs, "
                                    f"batch {B} per GPU, {args.dtype} feature maps / fp32 accumulate, random-init weights (seed 0)",
                        "global_batch": B * world, "parallelism": f"dp{world}" if world > 1 else "single",

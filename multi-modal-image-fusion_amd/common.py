@@ -21,6 +21,8 @@ def _common_extra(parser):
     parser.add_argument('--model', default='PFNetv1', type=str, help='PFNetv1 | PFNetv2 | DenseFuse | VIFNet | NestFuse | RFNNest')
     parser.add_argument('--dtype', default='fp32', type=str, help='feature-map storage: fp32 (parity) | bf16 (throughput)')
     parser.add_argument('--synthetic', default=0, type=int, help='>0: train on this many synthetic random pairs (no dataset needed)')
+    parser.add_argument('--graph', default=False, type=bool,
+                        help='replay forward + losses + backward of the training batch shape as one hipGraph (launch-bound small batches)')
 
 
 def get_train_args():

@@ -89,6 +89,12 @@ class FusedClipAdam(torch.optim.Optimizer):
         return self._stage
 
     @torch.no_grad()
+    def prepare(self):
+        """Re-point the parameters to the flat buffer NOW (normally done by the first step): anything that records parameter
+        addresses -- a hipGraph capture of the forward/backward (mmif.graph) -- must see the final storage."""
+        self._flatten_params(self._params())
+
+    @torch.no_grad()
     def step(self, closure=None, scalars=None):
         """scalars: optional list of up to 8 0-dim device tensors (loss values) that are summed across
         ranks in the same all-reduce as the gradients; their rank-mean is left in `reduced_scalars`."""

@@ -31,7 +31,17 @@ from mmif.dist import broadcast_parameters
 from mmif.optim import FusedClipAdam
 
 
+def _losses(loss_fn1, loss_fn2, loss_fn3, img1, img2, imgf):
+    l1, l2, l3 = loss_fn1(img1, img2, imgf), loss_fn2(img1, img2, imgf, mode='max'), loss_fn3(img1, img2, imgf, mode='max')
+    return l1 + l2 + l3, l1, l2, l3
+
+
+graphed = None   # GraphedStep of the training batch shape (--graph True)
+
+
 def train_model(model, data_loader, loss_fn1, loss_fn2, loss_fn3, epoch, mode='train', save_dir=None):
+    global graphed
+    use_graph = bool(getattr(args, 'graph', False))
     loss = AverageMeter()
     epoch_idx = epoch + 1
     torch.cuda.synchronize(device)
@@ -41,7 +51,17 @@ def train_model(model, data_loader, loss_fn1, loss_fn2, loss_fn3, epoch, mode='t
         iter_idx = it + 1
         img1 = img1.to(device, non_blocking=True)
         img2 = img2.to(device, non_blocking=True)
-        if mode == 'train':
+        if mode == 'train' and graphed is not None and graphed.matches(img1, img2):
+            # launch-bound batches: forward + losses + backward replayed as one hipGraph (mmif/graph.py)
+            graphed(img1, img2)
+            imgf = graphed.imgf
+            total_loss, loss1, loss2, loss3 = optimizer.reduced_scalars.unbind(0)
+            if args.warmup and epoch < 1:
+                warmup_scheduler.step()
+        elif mode == 'train':
+            if use_graph and graphed is None:
+                from mmif.graph import GraphedStep
+                graphed = GraphedStep(model, lambda a, b, f: _losses(loss_fn1, loss_fn2, loss_fn3, a, b, f), optimizer, img1, img2)
             optimizer.zero_grad(set_to_none=True)
             imgf = model(img1, img2)
             loss1 = loss_fn1(img1, img2, imgf)

@@ -284,3 +284,45 @@ def test_vifnet_fp32_vs_golden_and_bf16(shape):
         m = _model("VIFNet", 1)
         with torch.no_grad():
             close(m(tg(i1n), tg(i2n)).cpu().numpy(), y_or, 3e-2, "imgf bf16")
+
+
+@pytest.mark.gpu
+def test_graphed_step_equals_eager_step():
+    """mmif.graph.GraphedStep (forward + losses + backward replayed as one hipGraph, optimiser outside) walks exactly the
+    trajectory of the eager step: same kernels in the same order => bit-identical parameters and losses after 3 steps, with a
+    fresh batch copied into the graph's static inputs every step."""
+    import core.model as M
+    from core.loss import GradLoss, PixelLoss, SSIMLoss
+    from mmif.graph import GraphedStep
+    from mmif.optim import FusedClipAdam
+    dev = torch.device("cuda", 0)
+    with dtype_ctx("bf16"):
+        l1, l2, l3 = SSIMLoss('ssim', weight=1.0), PixelLoss('l1', weight=0.01), GradLoss('l1', weight=0.1).to(dev)
+
+        def losses(a, b, f):
+            x, y, z = l1(a, b, f), l2(a, b, f, mode='max'), l3(a, b, f, mode='max')
+            return x + y + z, x, y, z
+        g = torch.Generator(device="cpu").manual_seed(5)
+        batches = [(torch.rand(4, 1, 64, 64, generator=g).to(dev), torch.rand(4, 1, 64, 64, generator=g).to(dev)) for _ in range(3)]
+        out = {}
+        for kind in ("eager", "graph"):
+            torch.manual_seed(3)
+            model = M.PFNetv1().to(dev)
+            opt = FusedClipAdam(model.parameters(), lr=1e-3, betas=(0.9, 0.999), max_norm=5.0)
+            if kind == "graph":   # capture (and its eager warm-up passes) must not advance the optimiser
+                gs = GraphedStep(model, losses, opt, *batches[0])
+            tot = []
+            for k, (a, b) in enumerate(batches):
+                if kind == "eager" or k == 1:   # (an eager step between two replays must not disturb the graph's gradients)
+                    opt.zero_grad(set_to_none=True)
+                    ls = losses(a, b, model(a, b))
+                    ls[0].backward()
+                    opt.step(scalars=list(ls))
+                else:
+                    gs(a, b)
+                tot.append(opt.reduced_scalars.clone())
+            torch.cuda.synchronize()
+            out[kind] = (torch.stack(tot).cpu(), [p.detach().clone().cpu() for p in model.parameters()])
+        assert torch.equal(out["eager"][0], out["graph"][0]), (out["eager"][0], out["graph"][0])
+        for p, q in zip(out["eager"][1], out["graph"][1]):
+            assert torch.equal(p, q)
