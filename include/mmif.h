@@ -92,6 +92,40 @@ typedef struct mmif_pack_job {
 } mmif_pack_job;
 int mmif_pack_weights_multi(const mmif_pack_job* jobs, int32_t n_jobs, void* stream);
 
+/* ---- General ConvLayer primitives (row n4: the nets outside the PFNet/DenseFuse hot path) on plain NCHW fp32 tensors ----
+ * nn.Conv2d(cin, cout, k in {1,3,5,7}, stride in {1,2}, padding <= k/2, padding_mode reflect|zeros) (+ ReLU)
+ * replaces core/block.py:56-66 for DeepFuse (core/model.py:152-158, k = 5/7), DBNet (:219-221, stride 2), NestFuse/UNFusion
+ * down_mode='stride' (:338-340).  x [n][cin][h][w], w [cout][cin][k][k], y [n][cout][ho][wo], ho = (h + 2p - k)/s + 1. */
+int mmif_gconv_fwd(const float* x, const float* w, const float* bias, float* y, int32_t n, int32_t cin, int32_t cout,
+                   int32_t h, int32_t wd, int32_t ksize, int32_t stride, int32_t padding, int32_t reflect, int32_t relu,
+                   void* stream);
+/* dx (h x w) from gy (ho x wo, already multiplied by the activation's derivative); reflect padding needs a workspace of
+ * mmif_gconv_dgrad_workspace bytes (the padded-domain map that the reflect adjoint folds). */
+size_t mmif_gconv_dgrad_workspace(int32_t n, int32_t cin, int32_t h, int32_t wd, int32_t padding, int32_t reflect);
+int mmif_gconv_dgrad(const float* gy, const float* w, float* dx, int32_t n, int32_t cin, int32_t cout, int32_t h, int32_t wd,
+                     int32_t ksize, int32_t stride, int32_t padding, int32_t reflect, void* workspace, size_t workspace_bytes,
+                     void* stream);
+/* dw [cout][cin][k][k], db [cout] (may be NULL); deterministic two-stage sum. */
+size_t mmif_gconv_wgrad_workspace(int32_t cin, int32_t cout, int32_t ksize);
+int mmif_gconv_wgrad(const float* x, const float* gy, float* dw, float* db, int32_t n, int32_t cin, int32_t cout, int32_t h,
+                     int32_t wd, int32_t ksize, int32_t stride, int32_t padding, int32_t reflect, void* workspace,
+                     size_t workspace_bytes, void* stream);
+/* nn.ConvTranspose2d(cin, cout, k, stride, padding, output_padding) (core/block.py:67-76; SEDRFuse core/model.py:258-259).
+ * x [n][cin][h][w], w [cin][cout][k][k], y [n][cout][ho][wo], ho = (h-1) s - 2p + k + output_padding.  wgrad: db_scratch receives
+ * per-channel sums of x (NOT a layer gradient; pass NULL) -- the bias gradient is the plane sum of gy. */
+int mmif_gconvt_fwd(const float* x, const float* w, const float* bias, float* y, int32_t n, int32_t cin, int32_t cout,
+                    int32_t h, int32_t wd, int32_t ksize, int32_t stride, int32_t padding, int32_t output_padding, int32_t relu,
+                    void* stream);
+int mmif_gconvt_dgrad(const float* gy, const float* w, float* dx, int32_t n, int32_t cin, int32_t cout, int32_t h, int32_t wd,
+                      int32_t ksize, int32_t stride, int32_t padding, int32_t output_padding, void* stream);
+int mmif_gconvt_wgrad(const float* x, const float* gy, float* dw, float* db_scratch, int32_t n, int32_t cin, int32_t cout,
+                      int32_t h, int32_t wd, int32_t ksize, int32_t stride, int32_t padding, int32_t output_padding,
+                      void* workspace, size_t workspace_bytes, void* stream);
+/* out = g * [y > 0] on plain fp32 arrays (ReLU backward of the layers above) */
+int mmif_relu_bwd(const float* g, const float* y, float* out, int64_t count, void* stream);
+/* out[c] = sum_{n, pixels} x[n][c][.] (deterministic; the bias gradient of a ConvTranspose2d) */
+int mmif_channel_sum(const float* x, float* out, int32_t n, int32_t c, int64_t hw, void* stream);
+
 /* ---- ConvLayer: reflect-pad(k/2) conv + bias + ReLU, stride 1, k in {1,3}
  *      replaces core/block.py:98-99 (nn.Conv2d(padding_mode='reflect') + nn.ReLU(inplace)) ---- */
 /* y = act(bias + corr(reflect_pad(x), w)).  w: fp32 master weights; w_packed: mmif_pack_weights'

@@ -97,6 +97,58 @@ class _ConvLayerFn(torch.autograd.Function):
         return gx, dw, (db if ctx.has_bias else None), None
 
 
+class _GConvFn(torch.autograd.Function):
+    """nn.Conv2d with k in 1/3/5/7, stride 1/2, reflect | zero padding (+ ReLU) on the general HIP kernels (csrc/conv_general.hip):
+    the layers of DeepFuse (k = 5/7), DBNet / NestFuse down_mode='stride' (stride 2) -- NCHW fp32 boundary tensors."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, padding, reflect, relu):
+        T.require_device(x, "ConvLayer input")
+        xd, wd = x.detach().contiguous().float(), weight.detach().contiguous().float()
+        bd = bias.detach().contiguous().float() if bias is not None else None
+        y = T.gconv_fwd(xd, wd, bd, stride, padding, reflect, relu)
+        ctx.saved = (xd, wd, y if relu else None)
+        ctx.meta = (stride, padding, reflect, relu, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xd, wd, y = ctx.saved
+        stride, padding, reflect, relu, has_bias = ctx.meta
+        gy = gy.contiguous().float()
+        if relu:
+            gy = T.relu_bwd(gy, y)
+        dw, db = T.gconv_wgrad(xd, gy, wd.shape[2], stride, padding, reflect, has_bias)
+        dx = T.gconv_dgrad(gy, wd, tuple(xd.shape), stride, padding, reflect) if ctx.needs_input_grad[0] else None
+        return dx, dw, db, None, None, None, None
+
+
+class _GConvTFn(torch.autograd.Function):
+    """nn.ConvTranspose2d(k, stride, padding, output_padding) (+ ReLU) on the general HIP kernels (reference core/block.py:67-76)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, padding, output_padding, relu):
+        T.require_device(x, "ConvLayer input")
+        xd, wd = x.detach().contiguous().float(), weight.detach().contiguous().float()
+        bd = bias.detach().contiguous().float() if bias is not None else None
+        y = T.gconvt_fwd(xd, wd, bd, stride, padding, output_padding, relu)
+        ctx.saved = (xd, wd, y if relu else None)
+        ctx.meta = (stride, padding, output_padding, relu, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xd, wd, y = ctx.saved
+        stride, padding, output_padding, relu, has_bias = ctx.meta
+        gy = gy.contiguous().float()
+        if relu:
+            gy = T.relu_bwd(gy, y)
+        dw = T.gconvt_wgrad(xd, gy, wd.shape[2], stride, padding, output_padding)
+        db = T.channel_sum(gy) if has_bias else None
+        dx = T.gconvt_dgrad(gy, wd, tuple(xd.shape), stride, padding, output_padding) if ctx.needs_input_grad[0] else None
+        return dx, dw, db, None, None, None, None
+
+
 class ConvLayer(nn.Module):
     """reference core/block.py:26-118 -- same constructor signature, same sub-module layout
     (`layers.0` = the nn.Conv2d that owns weight/bias, so state_dict keys are identical), same
@@ -128,16 +180,25 @@ class ConvLayer(nn.Module):
         self.layers = nn.Sequential(*mods)
         self.norm, self.pre_norm, self.act = norm, pre_norm, act
         # the HIP kernels cover exactly what the hot-path models use
-        self._hip = (layer is nn.Conv2d and norm is None and pre_norm is None and act in (nn.ReLU, None) and stride == 1
-                     and dilation == 1 and groups == 1 and ksize in (1, 3) and padding == ksize // 2
+        plain = norm is None and pre_norm is None and act in (nn.ReLU, None) and dilation == 1 and groups == 1
+        self._hip = (layer is nn.Conv2d and plain and stride == 1 and ksize in (1, 3) and padding == ksize // 2
                      and (padding_mode == 'reflect' or ksize == 1) and bias)
+        # the general kernels (csrc/conv_general.hip): k = 5 / 7, stride 2, zero padding, ConvTranspose2d -- fp32 NCHW
+        self._gen = (not self._hip and plain and ksize in (1, 3, 5, 7) and stride in (1, 2) and 0 <= padding <= ksize // 2
+                     and ((layer is nn.Conv2d and padding_mode in ('reflect', 'zeros')) or layer is nn.ConvTranspose2d))
+        self._geom = (stride, padding, padding_mode == 'reflect' and padding > 0)
         self._init_weights()
 
     def forward(self, x):
+        conv = self.layers[0]
         if self._hip:
-            conv = self.layers[0]
             return _ConvLayerFn.apply(x, conv.weight, conv.bias, self.act is not None)
-        # argument combinations outside the hot path (norm layers, strides, other activations ...)
+        if self._gen:
+            stride, padding, reflect = self._geom
+            if isinstance(conv, nn.ConvTranspose2d):
+                return _GConvTFn.apply(x, conv.weight, conv.bias, stride, padding, 1, self.act is not None)
+            return _GConvFn.apply(x, conv.weight, conv.bias, stride, padding, reflect, self.act is not None)
+        # argument combinations outside these (norm layers, other activations, dilation, groups)
         # are not re-implemented: they run as the stock torch modules they are
         return self.layers(x)
 

@@ -57,6 +57,16 @@ SIGNATURES = {
     "mmif_packed_weight_bytes": (_sz, [_i32, _i32, _i32]),
     "mmif_pack_weights": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "mmif_pack_weights_multi": (_i32, [C.POINTER(MmifPackJob), _i32, _vp]),
+    "mmif_gconv_fwd": (_i32, [_vp, _vp, _vp, _vp] + [_i32] * 10 + [_vp]),
+    "mmif_gconv_dgrad_workspace": (_sz, [_i32] * 6),
+    "mmif_gconv_dgrad": (_i32, [_vp, _vp, _vp] + [_i32] * 9 + [_vp, _sz, _vp]),
+    "mmif_gconv_wgrad_workspace": (_sz, [_i32] * 3),
+    "mmif_gconv_wgrad": (_i32, [_vp, _vp, _vp, _vp] + [_i32] * 9 + [_vp, _sz, _vp]),
+    "mmif_gconvt_fwd": (_i32, [_vp, _vp, _vp, _vp] + [_i32] * 10 + [_vp]),
+    "mmif_gconvt_dgrad": (_i32, [_vp, _vp, _vp] + [_i32] * 9 + [_vp]),
+    "mmif_gconvt_wgrad": (_i32, [_vp, _vp, _vp, _vp] + [_i32] * 9 + [_vp, _sz, _vp]),
+    "mmif_relu_bwd": (_i32, [_vp, _vp, _vp, _i64, _vp]),
+    "mmif_channel_sum": (_i32, [_vp, _vp, _i32, _i32, _i64, _vp]),
     "mmif_conv2d_reflect_fwd": (_i32, [_TP, _vp, _vp, _vp, _TP, _i32, _i32, _i32, _i32, _i32, _vp]),
     "mmif_conv2d_reflect_dgrad": (_i32, [_TP, _vp, _vp, _TP, _TP, _i32, _i32, _i32, _u64, _u64, _i32, _vp]),
     "mmif_conv2d_reflect_dgrad_folded": (_i32, [_TP, _vp, _vp, _TP, _TP, _i32, _i32, _i32, _u64, _u64, _i32, _vp]),

@@ -251,3 +251,98 @@ def pairconv_wgrad_workspace_bytes():
 def pairconv_wgrad(xa, xb, ga, gb, nout, dw, db, ws, accumulate=False):
     check(lib.mmif_pairconv_wgrad(xa.d, xb.d, ga.d, _d(gb), nout, _ptr(dw), _ptr(db), int(accumulate), _ptr(ws), ws.numel() * ws.element_size(),
                                   stream_ptr()), "pairconv_wgrad")
+
+
+# ------------------------------------------------------------------ general ConvLayer primitives (plain NCHW fp32; row n4)
+def _f32c(t, name):
+    require_device(t, name)
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise ValueError(f"mmif: {name} must be a contiguous fp32 tensor")
+    return t
+
+
+def gconv_out_size(h, k, s, p):
+    return (h + 2 * p - k) // s + 1
+
+
+def gconv_fwd(x, w, bias, stride, padding, reflect, relu):
+    """nn.Conv2d(k in 1/3/5/7, stride 1/2, reflect | zero padding) (+ ReLU) on NCHW fp32."""
+    _f32c(x, "x"), _f32c(w, "weight")
+    n, cin, h, wd = x.shape
+    cout, _, k, _ = w.shape
+    y = torch.empty((n, cout, gconv_out_size(h, k, stride, padding), gconv_out_size(wd, k, stride, padding)), dtype=torch.float32, device=x.device)
+    check(lib.mmif_gconv_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), n, cin, cout, h, wd, k, stride, padding, int(reflect), int(relu),
+                             stream_ptr()), "gconv_fwd")
+    return y
+
+
+def gconv_dgrad(gy, w, x_shape, stride, padding, reflect):
+    _f32c(gy, "gy"), _f32c(w, "weight")
+    n, cin, h, wd = x_shape
+    cout, _, k, _ = w.shape
+    dx = torch.empty(x_shape, dtype=torch.float32, device=gy.device)
+    nb = lib.mmif_gconv_dgrad_workspace(n, cin, h, wd, padding, int(reflect))
+    ws = torch.empty(nb // 4 + 1, dtype=torch.float32, device=gy.device)
+    check(lib.mmif_gconv_dgrad(_ptr(gy), _ptr(w), _ptr(dx), n, cin, cout, h, wd, k, stride, padding, int(reflect), _ptr(ws), ws.numel() * 4,
+                               stream_ptr()), "gconv_dgrad")
+    return dx
+
+
+def gconv_wgrad(x, gy, k, stride, padding, reflect, want_bias=True):
+    _f32c(x, "x"), _f32c(gy, "gy")
+    n, cin, h, wd = x.shape
+    cout = gy.shape[1]
+    dw = torch.empty((cout, cin, k, k), dtype=torch.float32, device=x.device)
+    db = torch.empty(cout, dtype=torch.float32, device=x.device) if want_bias else None
+    ws = torch.empty(lib.mmif_gconv_wgrad_workspace(cin, cout, k) // 4 + 1, dtype=torch.float32, device=x.device)
+    check(lib.mmif_gconv_wgrad(_ptr(x), _ptr(gy), _ptr(dw), _ptr(db), n, cin, cout, h, wd, k, stride, padding, int(reflect), _ptr(ws),
+                               ws.numel() * 4, stream_ptr()), "gconv_wgrad")
+    return dw, db
+
+
+def gconvt_fwd(x, w, bias, stride, padding, output_padding, relu=False):
+    """nn.ConvTranspose2d (weight [cin][cout][k][k]) (+ ReLU) on NCHW fp32."""
+    _f32c(x, "x"), _f32c(w, "weight")
+    n, cin, h, wd = x.shape
+    _, cout, k, _ = w.shape
+    ho, wo = (h - 1) * stride - 2 * padding + k + output_padding, (wd - 1) * stride - 2 * padding + k + output_padding
+    y = torch.empty((n, cout, ho, wo), dtype=torch.float32, device=x.device)
+    check(lib.mmif_gconvt_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), n, cin, cout, h, wd, k, stride, padding, output_padding, int(relu),
+                              stream_ptr()), "gconvt_fwd")
+    return y
+
+
+def gconvt_dgrad(gy, w, x_shape, stride, padding, output_padding):
+    _f32c(gy, "gy"), _f32c(w, "weight")
+    n, cin, h, wd = x_shape
+    _, cout, k, _ = w.shape
+    dx = torch.empty(x_shape, dtype=torch.float32, device=gy.device)
+    check(lib.mmif_gconvt_dgrad(_ptr(gy), _ptr(w), _ptr(dx), n, cin, cout, h, wd, k, stride, padding, output_padding, stream_ptr()), "gconvt_dgrad")
+    return dx
+
+
+def gconvt_wgrad(x, gy, k, stride, padding, output_padding):
+    _f32c(x, "x"), _f32c(gy, "gy")
+    n, cin, h, wd = x.shape
+    cout = gy.shape[1]
+    dw = torch.empty((cin, cout, k, k), dtype=torch.float32, device=x.device)
+    ws = torch.empty(lib.mmif_gconv_wgrad_workspace(cout, cin, k) // 4 + 1, dtype=torch.float32, device=x.device)
+    check(lib.mmif_gconvt_wgrad(_ptr(x), _ptr(gy), _ptr(dw), None, n, cin, cout, h, wd, k, stride, padding, output_padding, _ptr(ws),
+                                ws.numel() * 4, stream_ptr()), "gconvt_wgrad")
+    return dw
+
+
+def relu_bwd(g, y):
+    _f32c(g, "g"), _f32c(y, "y")
+    out = torch.empty_like(g)
+    check(lib.mmif_relu_bwd(_ptr(g), _ptr(y), _ptr(out), g.numel(), stream_ptr()), "relu_bwd")
+    return out
+
+
+def channel_sum(x):
+    """[n][c][h][w] fp32 -> per-channel sums [c] (deterministic)."""
+    _f32c(x, "x")
+    n, c = x.shape[0], x.shape[1]
+    out = torch.empty(c, dtype=torch.float32, device=x.device)
+    check(lib.mmif_channel_sum(_ptr(x), _ptr(out), n, c, x[0, 0].numel(), stream_ptr()), "channel_sum")
+    return out

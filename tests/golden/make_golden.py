@@ -21,6 +21,7 @@ GPU box.  Fixture map:
   f8_feed.npz                data/transform.py norm (3 modes) + transform (8 modes) on an integer-valued 6x6 / 5x5 patch
   f9_ssim_modes.npz          SSIMLoss 'w-ssim' | 'ms-ssim' | 'msw-ssim' (core/loss.py:259-277) and TVLoss (:347-358): value + d/dimgf
   f10_vifnet.npz / f10_manifest.json   VIFNet (core/model.py:189-206) forward + gradient digests + state_dict manifest
+  f11_general_conv.npz       ConvLayer with k = 5/7, stride 2, zero padding, ConvTranspose2d (core/block.py:56-76): fwd + (dx, dW, db)
   f7_metric_ssim.json        core/metric.py:316-364 calc_ssim (the SSIM that test.py:49-52 reports) on closed-form images
 """
 import json
@@ -164,6 +165,36 @@ def make_f3():
         out[name + "_dw"] = layer.layers[0].weight.grad.numpy()
         out[name + "_db"] = layer.layers[0].bias.grad.numpy()
     np.savez_compressed(os.path.join(HERE, "f3_conv.npz"), **out)
+
+
+# ---------------------------------------------------------------- F11 (row n4: the general ConvLayer forms)
+#            name            cin cout k  stride transposed padding_mode relu  N  H   W
+F11_CASES = [("k5_1_16",       1, 16, 5, 1, False, "reflect", True, 2, 13, 17),
+             ("k7_16_32",     16, 32, 7, 1, False, "reflect", True, 1, 12, 20),
+             ("k7_tiny",       8,  8, 7, 1, False, "reflect", True, 1, 4, 5),
+             ("k5_16_1_lin",  16,  1, 5, 1, False, "reflect", False, 2, 9, 11),
+             ("s2_32_64",     32, 64, 3, 2, False, "reflect", True, 2, 13, 18),
+             ("s2_even",      24, 16, 3, 2, False, "reflect", True, 1, 16, 32),
+             ("zeros_k3",     16, 24, 3, 1, False, "zeros", True, 1, 10, 9),
+             ("convT_24_16",  24, 16, 3, 2, True, "zeros", True, 2, 7, 9),
+             ("convT_lin",     8, 12, 3, 2, True, "zeros", False, 1, 5, 4)]
+
+
+def make_f11():
+    out = {}
+    for name, cin, cout, k, stride, transposed, pmode, relu, N, H, W in F11_CASES:
+        layer = rblock.ConvLayer(cin, cout, ksize=k, stride=stride, act=nn.ReLU if relu else None,
+                                 layer=nn.ConvTranspose2d if transposed else nn.Conv2d, padding_mode=pmode)
+        load_closed_form(layer, seed=11)
+        x = T(closed_form_signed((N, cin, H, W), 0.5, 1.0)).requires_grad_(True)
+        y = layer(x)
+        gy = T(closed_form_signed(tuple(y.shape), 1.5, 1.0))
+        y.backward(gy)
+        out[name + "_y"] = y.detach().numpy()
+        out[name + "_dx"] = x.grad.numpy()
+        out[name + "_dw"] = layer.layers[0].weight.grad.numpy()
+        out[name + "_db"] = layer.layers[0].bias.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, "f11_general_conv.npz"), **out)
 
 
 # ---------------------------------------------------------------- F4
@@ -390,7 +421,7 @@ def make_f9():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10"]
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10", "f11"]
     for w in which:
         globals()["make_" + w]()
         print("wrote", w)

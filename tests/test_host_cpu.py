@@ -71,6 +71,16 @@ def test_c_abi_validation_of_the_widened_entry_points_without_gpu():
     assert b"only supported ['min-max', 'z-score'] mode" in lib.mmif_last_error()
     assert lib.mmif_patch_feed(None, 4, 8, f, None, 2, 0, f, None) == -1
     assert lib.mmif_fuse_attn_workspace(2, 64) > 0
+    assert lib.mmif_gconv_fwd(f, f, None, f, 1, 8, 8, 16, 16, 4, 1, 2, 1, 0, None) == -1
+    assert b"ksize must be 1, 3, 5 or 7" in lib.mmif_last_error()
+    assert lib.mmif_gconv_fwd(f, f, None, f, 1, 8, 8, 16, 16, 3, 3, 1, 1, 0, None) == -1
+    assert b"stride must be 1 or 2" in lib.mmif_last_error()
+    assert lib.mmif_gconv_fwd(f, f, None, f, 1, 8, 8, 3, 16, 7, 1, 3, 1, 0, None) == -1           # reflect 3 on a 3-row image
+    assert lib.mmif_gconv_dgrad(f, f, f, 1, 8, 8, 16, 16, 5, 1, 2, 1, None, 0, None) == -3
+    assert lib.mmif_gconv_dgrad_workspace(2, 8, 16, 16, 2, 1) == 2 * 8 * 20 * 20 * 4 and lib.mmif_gconv_dgrad_workspace(2, 8, 16, 16, 2, 0) == 0
+    assert lib.mmif_gconv_wgrad(f, f, f, None, 1, 8, 8, 16, 16, 5, 1, 2, 1, f, 64, None) == -3
+    assert lib.mmif_gconvt_fwd(f, f, None, f, 1, 8, 8, 4, 4, 3, 2, 1, 2, 0, None) == -1           # output_padding >= stride
+    assert lib.mmif_relu_bwd(None, f, f, 4, None) == -1 and lib.mmif_channel_sum(f, f, 0, 1, 1, None) == -1
     from mmif._lib import MmifPackJob
     jobs = (MmifPackJob * 1)()
     assert lib.mmif_pack_weights_multi(jobs, 0, None) == -1
@@ -128,10 +138,13 @@ def test_conv_layer_signature_and_fallback_rules():
     from core.block import ConvBlock, ConvLayer, DenseBlock, NestDecoder, RFN
     assert ConvLayer(16, 16)._hip and ConvLayer(8, 64, ksize=1)._hip and ConvLayer(16, 1, act=None)._hip
     # argument combinations outside the hot path stay stock torch modules
-    assert not ConvLayer(16, 16, stride=2)._hip
-    assert not ConvLayer(16, 16, norm=nn.BatchNorm2d)._hip
-    assert not ConvLayer(16, 16, act=nn.Tanh)._hip
-    assert not ConvLayer(16, 16, ksize=5)._hip
+    # the general kernels (k 5/7, stride 2, zero padding, ConvTranspose2d) -- still HIP, fp32 NCHW
+    for lay in (ConvLayer(16, 16, stride=2), ConvLayer(16, 16, ksize=5), ConvLayer(1, 16, ksize=7), ConvLayer(16, 16, padding_mode='zeros'),
+                ConvLayer(16, 8, stride=2, layer=nn.ConvTranspose2d)):
+        assert lay._gen and not lay._hip
+    # norm layers / other activations stay stock torch modules
+    for lay in (ConvLayer(16, 16, norm=nn.BatchNorm2d), ConvLayer(16, 16, act=nn.Tanh), ConvLayer(16, 16, dilation=2, padding=2)):
+        assert not lay._hip and not lay._gen
     assert list(DenseBlock(16, 16).state_dict())[0] == "layers.0.layers.0.weight"
     assert sum(p.numel() for p in ConvBlock(16, 64).parameters()) == 16 * 8 * 9 + 8 + 8 * 64 + 64
     assert len(list(RFN(16).parameters())) == 12

@@ -343,3 +343,41 @@ def test_f10_vifnet(shape):
     Gd = m.backward(P, O.closed_form_signed(shape, 0.9, 1.0))
     for k in m.param_shapes():
         close_digest(Gd[k], ref[f"{tag}__dp_{k}"], 5e-5, k)
+
+
+# ------------------------------------------------------------------ F11: general ConvLayer forms (k 5/7, stride 2, zero padding, ConvTranspose2d)
+#            name            cin cout k  stride transposed padding_mode relu  N  H   W
+F11_CASES = [("k5_1_16", 1, 16, 5, 1, False, "reflect", True, 2, 13, 17), ("k7_16_32", 16, 32, 7, 1, False, "reflect", True, 1, 12, 20),
+             ("k7_tiny", 8, 8, 7, 1, False, "reflect", True, 1, 4, 5), ("k5_16_1_lin", 16, 1, 5, 1, False, "reflect", False, 2, 9, 11),
+             ("s2_32_64", 32, 64, 3, 2, False, "reflect", True, 2, 13, 18), ("s2_even", 24, 16, 3, 2, False, "reflect", True, 1, 16, 32),
+             ("zeros_k3", 16, 24, 3, 1, False, "zeros", True, 1, 10, 9), ("convT_24_16", 24, 16, 3, 2, True, "zeros", True, 2, 7, 9),
+             ("convT_lin", 8, 12, 3, 2, True, "zeros", False, 1, 5, 4)]
+
+
+def f11_tensors(case):
+    name, cin, cout, k, stride, transposed, pmode, relu, N, H, W = case
+    w = O.closed_form_param(0, "layers.0.weight", (cin, cout, k, k) if transposed else (cout, cin, k, k), 11)
+    b = O.closed_form_param(1, "layers.0.bias", (cout,), 11)
+    x = O.closed_form_signed((N, cin, H, W), 0.5, 1.0)
+    return w, b, x
+
+
+@pytest.mark.parametrize("case", F11_CASES, ids=[c[0] for c in F11_CASES])
+def test_f11_general_conv_oracle_vs_reference(case):
+    """oracle conv2d_general_* / conv_transpose2d_* == the reference's ConvLayer (nn.Conv2d / nn.ConvTranspose2d autograd)."""
+    name, cin, cout, k, stride, transposed, pmode, relu, N, H, W = case
+    g = np.load(os.path.join(G, "f11_general_conv.npz"))
+    w, b, x = f11_tensors(case)
+    if transposed:
+        y = O.conv_transpose2d_fwd(x, w, b, stride, k // 2, 1, relu)
+    else:
+        y = O.conv2d_general_fwd(x, w, b, stride, k // 2, pmode == "reflect", relu)
+    assert y.shape == g[name + "_y"].shape
+    gy = O.closed_form_signed(y.shape, 1.5, 1.0)
+    if transposed:
+        dx, dw, db = O.conv_transpose2d_bwd(x, w, y, gy, stride, k // 2, 1, relu)
+    else:
+        dx, dw, db = O.conv2d_general_bwd(x, w, y, gy, stride, k // 2, pmode == "reflect", relu)
+    for got, key in ((y, "_y"), (dx, "_dx"), (dw, "_dw"), (db, "_db")):
+        ref = g[name + key]
+        assert np.abs(got - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max()), (name, key)
