@@ -126,6 +126,11 @@ int mmif_relu_bwd(const float* g, const float* y, float* out, int64_t count, voi
 /* out[c] = sum_{n, pixels} x[n][c][.] (deterministic; the bias gradient of a ConvTranspose2d) */
 int mmif_channel_sum(const float* x, float* out, int32_t n, int32_t c, int64_t hw, void* stream);
 
+/* nn.Upsample(scale_factor, mode='bilinear', align_corners=True) (core/block.py:965-973; DBNet core/model.py:223, the up_mode option
+ * of NestFuse / UNFusion / MAFusion) on `planes` = n * c planes of plain fp32 [h][w] -> [H][W]; backward = its adjoint, gathered. */
+int mmif_bilinear_up_fwd(const float* x, float* out, int64_t planes, int32_t h, int32_t w, int32_t H, int32_t W, void* stream);
+int mmif_bilinear_up_bwd(const float* g, float* dx, int64_t planes, int32_t h, int32_t w, int32_t H, int32_t W, void* stream);
+
 /* ---- ConvLayer: reflect-pad(k/2) conv + bias + ReLU, stride 1, k in {1,3}
  *      replaces core/block.py:98-99 (nn.Conv2d(padding_mode='reflect') + nn.ReLU(inplace)) ---- */
 /* y = act(bias + corr(reflect_pad(x), w)).  w: fp32 master weights; w_packed: mmif_pack_weights'

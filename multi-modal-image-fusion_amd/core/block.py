@@ -286,6 +286,20 @@ class Downsample(_Resample):
         self.op = self.down
 
 
+class _BilinearUpFn(torch.autograd.Function):
+    """nn.Upsample(scale_factor, mode='bilinear', align_corners=True) on the HIP kernels (csrc/resample.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        T.require_device(x, "Upsample input")
+        ctx.in_hw = (x.shape[2], x.shape[3])
+        return T.bilinear_up_fwd(x.detach().contiguous().float(), scale)
+
+    @staticmethod
+    def backward(ctx, g):
+        return T.bilinear_up_bwd(g.contiguous().float(), ctx.in_hw), None
+
+
 class Upsample(_Resample):
     """reference core/block.py:965-991"""
 
@@ -295,7 +309,11 @@ class Upsample(_Resample):
             self.up = nn.Upsample(scale_factor=scale_factor, mode=mode)
         else:
             self.up = nn.Upsample(scale_factor=scale_factor, mode=mode, align_corners=True)
-        self.op = self.up
+        self._bilinear = mode == 'bilinear' and int(scale_factor) == scale_factor
+        self.op = self._bilinear_op if self._bilinear else self.up
+
+    def _bilinear_op(self, feat):
+        return _BilinearUpFn.apply(feat, int(self.up.scale_factor))
 
 
 class NestDecoder(nn.Module):

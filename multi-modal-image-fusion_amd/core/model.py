@@ -12,7 +12,7 @@ from mmif import engine as E
 from .block import *
 from .fusion import *
 
-__all__ = ['PFNetv1', 'PFNetv2', 'DenseFuse', 'VIFNet', 'NestFuse', 'RFNNest']
+__all__ = ['PFNetv1', 'PFNetv2', 'DeepFuse', 'DenseFuse', 'VIFNet', 'DBNet', 'NestFuse', 'RFNNest']
 
 
 class _FusionModel(nn.Module):
@@ -96,6 +96,19 @@ class PFNetv2(_FusionModel):
         return E.PFNetv2Engine(self)
 
 
+class DeepFuse(_FusionModel):
+    '''DeepFuse (reference core/model.py:146-162): 5x5 / 7x7 ConvLayers, element-wise fusion.  Runs layer by layer on the general
+    HIP conv kernels (csrc/conv_general.hip, fp32) -- row n4 of the scope table, no fused engine.'''
+
+    def __init__(self):
+        super(DeepFuse, self).__init__()
+        self.encode = nn.Sequential(ConvLayer(1, 16, ksize=5), ConvLayer(16, 32, ksize=7))
+        self.decode = nn.Sequential(ConvLayer(32, 32, ksize=7), ConvLayer(32, 16, ksize=5), ConvLayer(16, 1, ksize=5, act=None))
+
+    def fusion(self, feat1, feat2, mode='sum'):
+        return element_fusion(feat1, feat2, mode)
+
+
 class DenseFuse(_FusionModel):
     '''DenseFuse: A Fusion Approach to Infrared and Visible Images (reference core/model.py:165-186)'''
 
@@ -131,6 +144,31 @@ class VIFNet(_FusionModel):
 
     def _make_engine(self):
         return E.VIFNetEngine(self)
+
+
+class DBNet(_FusionModel):
+    '''A Dual-Branch Network for Infrared and Visible Image Fusion (reference core/model.py:208-245): a detail branch
+    (ConvLayer + DenseBlock) and a semantic branch (three stride-2 ConvLayers, bilinear x8 back to full size), concatenated.
+    Layer by layer: the 3x3 stride-1 layers on the hot-path kernels, stride 2 on the general kernels, csrc/resample.hip.'''
+
+    def __init__(self):
+        super(DBNet, self).__init__()
+        self.encode = ConvLayer(1, 32)
+        self.detail = nn.Sequential(ConvLayer(32, 16), DenseBlock(16, 16))
+        self.semantic = nn.Sequential(ConvLayer(32, 64, stride=2), ConvLayer(64, 128, stride=2), ConvLayer(128, 64, stride=2))
+        self.up = Upsample(mode='bilinear', scale_factor=8)
+        self.decode = nn.Sequential(ConvLayer(128, 64), ConvLayer(64, 32), ConvLayer(32, 16), ConvLayer(16, 1, act=None))
+
+    def encoder(self, img):
+        feat = self.encode(img)
+        return concat_fusion((self.detail(feat), self.up(self.semantic(feat), feat.shape)))
+
+    def fusion(self, feat1, feat2, mode='sum'):
+        if mode == 'sum':
+            return element_fusion(feat1, feat2, mode)
+        elif mode == 'avg':
+            return attention_fusion(feat1, feat2, 'ca', channel_mode=mode)
+        raise ValueError("only supported ['sum', 'avg'] mode")
 
 
 class NestFuse(_FusionModel):

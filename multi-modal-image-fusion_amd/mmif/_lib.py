@@ -67,6 +67,8 @@ SIGNATURES = {
     "mmif_gconvt_wgrad": (_i32, [_vp, _vp, _vp, _vp] + [_i32] * 9 + [_vp, _sz, _vp]),
     "mmif_relu_bwd": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "mmif_channel_sum": (_i32, [_vp, _vp, _i32, _i32, _i64, _vp]),
+    "mmif_bilinear_up_fwd": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
+    "mmif_bilinear_up_bwd": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     "mmif_conv2d_reflect_fwd": (_i32, [_TP, _vp, _vp, _vp, _TP, _i32, _i32, _i32, _i32, _i32, _vp]),
     "mmif_conv2d_reflect_dgrad": (_i32, [_TP, _vp, _vp, _TP, _TP, _i32, _i32, _i32, _u64, _u64, _i32, _vp]),
     "mmif_conv2d_reflect_dgrad_folded": (_i32, [_TP, _vp, _vp, _TP, _TP, _i32, _i32, _i32, _u64, _u64, _i32, _vp]),

@@ -346,3 +346,20 @@ def channel_sum(x):
     out = torch.empty(c, dtype=torch.float32, device=x.device)
     check(lib.mmif_channel_sum(_ptr(x), _ptr(out), n, c, x[0, 0].numel(), stream_ptr()), "channel_sum")
     return out
+
+
+def bilinear_up_fwd(x, scale):
+    """nn.Upsample(scale_factor=scale, mode='bilinear', align_corners=True) on NCHW fp32."""
+    _f32c(x, "x")
+    n, c, h, w = x.shape
+    out = torch.empty((n, c, h * scale, w * scale), dtype=torch.float32, device=x.device)
+    check(lib.mmif_bilinear_up_fwd(_ptr(x), _ptr(out), n * c, h, w, h * scale, w * scale, stream_ptr()), "bilinear_up_fwd")
+    return out
+
+
+def bilinear_up_bwd(g, in_hw):
+    _f32c(g, "g")
+    n, c, H, W = g.shape
+    dx = torch.empty((n, c, in_hw[0], in_hw[1]), dtype=torch.float32, device=g.device)
+    check(lib.mmif_bilinear_up_bwd(_ptr(g), _ptr(dx), n * c, in_hw[0], in_hw[1], H, W, stream_ptr()), "bilinear_up_bwd")
+    return dx

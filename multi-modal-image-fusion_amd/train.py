@@ -168,7 +168,8 @@ if __name__ == '__main__':
     logger, log_dir = make_logger(os.path.join(BASE_DIR, '..', 'checkpoints')) if local_rank == 0 else (None, None)
     train_loader, valid_loader, train_sampler = make_loaders()
 
-    model = {'PFNetv1': PFNetv1, 'PFNetv2': PFNetv2, 'DenseFuse': DenseFuse, 'VIFNet': VIFNet, 'NestFuse': NestFuse, 'RFNNest': RFNNest}[args.model]().to(device)
+    model = {'PFNetv1': PFNetv1, 'PFNetv2': PFNetv2, 'DenseFuse': DenseFuse, 'VIFNet': VIFNet, 'NestFuse': NestFuse, 'RFNNest': RFNNest,
+             'DeepFuse': DeepFuse, 'DBNet': DBNet}[args.model]().to(device)
     if is_distributed:
         broadcast_parameters(model, 0)  # replaces the reference's init_weights.pth + DDP constructor broadcast
 

@@ -22,6 +22,7 @@ GPU box.  Fixture map:
   f9_ssim_modes.npz          SSIMLoss 'w-ssim' | 'ms-ssim' | 'msw-ssim' (core/loss.py:259-277) and TVLoss (:347-358): value + d/dimgf
   f10_vifnet.npz / f10_manifest.json   VIFNet (core/model.py:189-206) forward + gradient digests + state_dict manifest
   f11_general_conv.npz       ConvLayer with k = 5/7, stride 2, zero padding, ConvTranspose2d (core/block.py:56-76): fwd + (dx, dW, db)
+  f12_n4_models.npz / f12_manifest.json   bilinear Upsample (core/block.py:965-991) fwd + dx; DeepFuse, DBNet forward + gradient digests
   f7_metric_ssim.json        core/metric.py:316-364 calc_ssim (the SSIM that test.py:49-52 reports) on closed-form images
 """
 import json
@@ -195,6 +196,33 @@ def make_f11():
         out[name + "_dw"] = layer.layers[0].weight.grad.numpy()
         out[name + "_db"] = layer.layers[0].bias.grad.numpy()
     np.savez_compressed(os.path.join(HERE, "f11_general_conv.npz"), **out)
+
+
+# ---------------------------------------------------------------- F12 (row n4: bilinear up-sampling, DeepFuse, DBNet)
+def make_f12():
+    out, manifest = {}, {}
+    for tag, scale, shape in (("bl_x2", 2, (2, 3, 5, 7)), ("bl_x8", 8, (1, 4, 4, 3)), ("bl_x2_row", 2, (1, 2, 1, 6))):
+        up = rblock.Upsample('bilinear', scale)
+        x = T(closed_form_signed(shape, 0.4, 1.0)).requires_grad_(True)
+        tgt = (shape[0], shape[1], shape[2] * scale, shape[3] * scale)
+        y = up(x, torch.Size(tgt))
+        y.backward(T(closed_form_signed(tgt, 1.3, 1.0)))
+        out[tag + "_y"], out[tag + "_dx"] = y.detach().numpy(), x.grad.numpy()
+    for name, shapes in (("DeepFuse", ((2, 1, 32, 32), (1, 1, 21, 30))), ("DBNet", ((2, 1, 32, 32), (1, 1, 40, 24), (1, 1, 37, 53)))):
+        for shape in shapes:
+            tag = f"{name}_{shape[0]}x{shape[2]}x{shape[3]}"
+            model = load_closed_form(getattr(rmodel, name)(), seed=2)
+            manifest[name] = [[k, list(v.shape)] for k, v in model.state_dict().items()]
+            i1, i2 = T(closed_form_image(shape, 0.3)), T(closed_form_image(shape, 1.7))
+            y = model(i1, i2)
+            y.backward(T(closed_form_signed(shape, 0.9, 1.0)))
+            out[tag + "__y"] = y.detach().numpy()
+            for k, p in model.named_parameters():
+                out[f"{tag}__dp_{k}"] = digest(p.grad.numpy())
+    # (seed 2: with seed 1 one pre-activation of DBNet's decode.1 at 2x32x32 lies within fp32 rounding of zero, so its ReLU mask --
+    # and 1 % of the gradients behind it -- depends on the summation order of the conv that produced it)
+    np.savez_compressed(os.path.join(HERE, "f12_n4_models.npz"), **out)
+    json.dump(manifest, open(os.path.join(HERE, "f12_manifest.json"), "w"), indent=0)
 
 
 # ---------------------------------------------------------------- F4
@@ -421,7 +449,7 @@ def make_f9():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10", "f11"]
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10", "f11", "f12"]
     for w in which:
         globals()["make_" + w]()
         print("wrote", w)

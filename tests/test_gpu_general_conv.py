@@ -75,3 +75,50 @@ def test_general_conv_kernels_vs_oracle_on_ragged_shapes(cin, cout, k, stride, t
     close(dx.cpu().numpy(), dx_ref, 3e-5, "dx")
     close(dw.cpu().numpy(), dw_ref, 3e-5, "dw")
     close(db.cpu().numpy(), db_ref, 3e-5, "db")
+
+
+@pytest.mark.parametrize("tag,scale,shape", [("bl_x2", 2, (2, 3, 5, 7)), ("bl_x8", 8, (1, 4, 4, 3)), ("bl_x2_row", 2, (1, 2, 1, 6))])
+def test_bilinear_upsample_vs_golden(tag, scale, shape):
+    """Upsample('bilinear', scale) of the mirror == the reference's (nn.Upsample align_corners=True), forward and input gradient."""
+    from core.block import Upsample
+    g = np.load(os.path.join(G, "f12_n4_models.npz"))
+    up = Upsample('bilinear', scale)
+    x = torch.from_numpy(O.closed_form_signed(shape, 0.4, 1.0)).cuda().requires_grad_(True)
+    tgt = (shape[0], shape[1], shape[2] * scale, shape[3] * scale)
+    y = up(x, torch.Size(tgt))
+    y.backward(torch.from_numpy(O.closed_form_signed(tgt, 1.3, 1.0)).cuda())
+    close(y.detach().cpu().numpy(), g[tag + "_y"], 1e-5, "y")
+    close(x.grad.cpu().numpy(), g[tag + "_dx"], 2e-5, "dx")
+
+
+@pytest.mark.parametrize("scale,shape", [(2, (2, 5, 33, 47)), (8, (1, 3, 9, 6)), (4, (1, 2, 1, 1)), (3, (2, 1, 17, 2))])
+def test_bilinear_kernels_vs_oracle(scale, shape):
+    from mmif import tensor as T
+    rng = np.random.default_rng(scale * 100 + shape[2])
+    x = rng.standard_normal(shape, dtype=np.float32)
+    y = T.bilinear_up_fwd(torch.from_numpy(x).cuda(), scale)
+    close(y.cpu().numpy(), O.bilinear_up_fwd(x, scale), 1e-5, "y")
+    gy = rng.standard_normal(tuple(y.shape), dtype=np.float32)
+    dx = T.bilinear_up_bwd(torch.from_numpy(gy).cuda(), shape[2:])
+    close(dx.cpu().numpy(), O.bilinear_up_bwd(gy, shape[2:]), 2e-5, "dx")
+
+
+N4_MODELS = [("DeepFuse", (2, 1, 32, 32)), ("DeepFuse", (1, 1, 21, 30)), ("DBNet", (2, 1, 32, 32)), ("DBNet", (1, 1, 40, 24)), ("DBNet", (1, 1, 37, 53))]
+
+
+@pytest.mark.parametrize("name,shape", N4_MODELS, ids=[f"{n}-{s[0]}x{s[2]}x{s[3]}" for n, s in N4_MODELS])
+def test_n4_models_vs_golden(name, shape):
+    """DeepFuse (k 5/7) and DBNet (stride 2 + bilinear x8, incl. the crop to an odd target size) layer by layer on the HIP
+    kernels, fp32: fused image and every parameter gradient against the reference's (closed-form weights and inputs)."""
+    import core.model as M
+    from gpu_util import close_digest, dtype_ctx
+    g = np.load(os.path.join(G, "f12_n4_models.npz"))
+    tag = f"{name}_{shape[0]}x{shape[2]}x{shape[3]}"
+    with dtype_ctx("fp32"):
+        model = load_closed_form(getattr(M, name)(), 2).cuda()
+        i1, i2 = (torch.from_numpy(O.closed_form_image(shape, p)).cuda() for p in (0.3, 1.7))
+        y = model(i1, i2)
+        y.backward(torch.from_numpy(O.closed_form_signed(shape, 0.9, 1.0)).cuda())
+    close(y.detach().cpu().numpy(), g[tag + "__y"], 1e-4, "fused image")
+    for k, p in model.named_parameters():
+        close_digest(p.grad.cpu().numpy(), g[f"{tag}__dp_{k}"], 2e-4, k)

@@ -89,10 +89,10 @@ def test_c_abi_validation_of_the_widened_entry_points_without_gpu():
     assert b"ksize must be 1 or 3" in lib.mmif_last_error()
 
 
-@pytest.mark.parametrize("name", ["PFNetv1", "PFNetv2", "DenseFuse", "VIFNet", "NestFuse", "RFNNest"])
+@pytest.mark.parametrize("name", ["PFNetv1", "PFNetv2", "DenseFuse", "VIFNet", "NestFuse", "RFNNest", "DeepFuse", "DBNet"])
 def test_state_dict_manifest_and_init(name):
     import core.model as M
-    man = json.load(open(os.path.join(G, "f10_manifest.json" if name == "VIFNet" else "f5_manifest.json")))
+    man = json.load(open(os.path.join(G, {"VIFNet": "f10_manifest.json", "DeepFuse": "f12_manifest.json", "DBNet": "f12_manifest.json"}.get(name, "f5_manifest.json"))))
     torch.manual_seed(0)
     m = getattr(M, name)()
     assert [[k, list(v.shape)] for k, v in m.state_dict().items()] == man[name]
@@ -100,7 +100,7 @@ def test_state_dict_manifest_and_init(name):
     for k, v in m.state_dict().items():
         if k.endswith("bias"):
             assert float(v.abs().max()) == 0.0
-    if name in ("NestFuse", "RFNNest"):
+    if name in ("NestFuse", "RFNNest", "DeepFuse"):
         return
     w = m.state_dict()["decode.0.layers.0.weight"]
     fan_in = w.shape[1] * 9
