@@ -131,6 +131,23 @@ int mmif_channel_sum(const float* x, float* out, int32_t n, int32_t c, int64_t h
 int mmif_bilinear_up_fwd(const float* x, float* out, int64_t planes, int32_t h, int32_t w, int32_t H, int32_t W, void* stream);
 int mmif_bilinear_up_bwd(const float* g, float* dx, int64_t planes, int32_t h, int32_t w, int32_t H, int32_t W, void* stream);
 
+/* Norm + activation epilogue of ConvLayer (core/block.py:78-92) on plain NCHW fp32: y = act(gamma * (x - mean) * rstd + beta).
+ * kind 0 = nn.BatchNorm2d in training mode (batch statistics; running_mean / running_var, when given, are updated with `momentum`
+ * and the unbiased variance), 1 = nn.BatchNorm2d in eval mode (running buffers), 2 = nn.GroupNorm(c, c) (one group per channel:
+ * per-(sample, channel) statistics; SEDRFuse core/model.py:249-260).  act: 0 none, 1 ReLU, 2 LeakyReLU(slope), 3 Tanh.
+ * stats receives (mean, rstd) per channel (kinds 0, 1: 2 c floats) or per plane (kind 2: 2 n c floats) for the backward pass.
+ * Backward: dx, dgamma, dbeta (either may be NULL) from x, y (the forward's output), gy. */
+size_t mmif_norm_workspace(int32_t n, int32_t c);
+int mmif_norm_act_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats, float* running_mean,
+                      float* running_var, int32_t n, int32_t c, int64_t hw, int32_t kind, float eps, float momentum, int32_t act,
+                      float slope, void* workspace, size_t workspace_bytes, void* stream);
+int mmif_norm_act_bwd(const float* x, const float* y, const float* gy, const float* stats, const float* gamma, float* dx,
+                      float* dgamma, float* dbeta, int32_t n, int32_t c, int64_t hw, int32_t kind, int32_t act, float slope,
+                      void* workspace, size_t workspace_bytes, void* stream);
+/* activation alone (LeakyReLU / Tanh after a conv without norm: PMGI's decode, core/model.py:579); backward from the output y */
+int mmif_act_fwd(const float* x, float* y, int64_t count, int32_t act, float slope, void* stream);
+int mmif_act_bwd(const float* gy, const float* y, float* dx, int64_t count, int32_t act, float slope, void* stream);
+
 /* ---- ConvLayer: reflect-pad(k/2) conv + bias + ReLU, stride 1, k in {1,3}
  *      replaces core/block.py:98-99 (nn.Conv2d(padding_mode='reflect') + nn.ReLU(inplace)) ---- */
 /* y = act(bias + corr(reflect_pad(x), w)).  w: fp32 master weights; w_packed: mmif_pack_weights'

@@ -14,9 +14,9 @@ from mmif import engine as E
 from mmif import tensor as T
 from mmif.tensor import BT
 
-from .fusion import concat_fusion
+from .fusion import concat_fusion, element_fusion
 
-__all__ = ['ConvLayer', 'DenseBlock', 'ConvBlock', 'RFN', 'NestDecoder', 'Downsample', 'Upsample']
+__all__ = ['ConvLayer', 'ResBlock', 'DenseBlock', 'ConvBlock', 'RFN', 'NestDecoder', 'Downsample', 'Upsample']
 
 
 class _ConvLayerFn(torch.autograd.Function):
@@ -149,6 +149,55 @@ class _GConvTFn(torch.autograd.Function):
         return dx, dw, db, None, None, None, None
 
 
+_ACT_CODE = {None: T.ACT_NONE, nn.ReLU: T.ACT_RELU, nn.LeakyReLU: T.ACT_LEAKY, nn.Tanh: T.ACT_TANH}
+
+
+class _NormActFn(torch.autograd.Function):
+    """norm + activation epilogue of a ConvLayer (reference core/block.py:78-92) on the HIP kernels (csrc/norm.hip):
+    nn.BatchNorm2d (batch statistics + running-buffer update when training, running buffers in eval) or nn.GroupNorm(c, c),
+    then ReLU / LeakyReLU(0.2) / Tanh / nothing.  The nn module only owns the parameters and buffers."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, mod, act):
+        T.require_device(x, "ConvLayer input")
+        xd = x.detach().contiguous().float()
+        if isinstance(mod, nn.BatchNorm2d):
+            kind = T.NORM_BN_TRAIN if (mod.training or not mod.track_running_stats) else T.NORM_BN_EVAL
+            rm, rv = (mod.running_mean, mod.running_var) if mod.track_running_stats else (None, None)
+            momentum = mod.momentum if mod.momentum is not None else 0.1
+            if kind == T.NORM_BN_TRAIN and mod.track_running_stats:
+                mod.num_batches_tracked.add_(1)
+        else:
+            kind, rm, rv, momentum = T.NORM_GN, None, None, 0.0
+        y, stats = T.norm_act_fwd(xd, gamma.detach() if gamma is not None else None, beta.detach() if beta is not None else None, rm, rv, kind,
+                                  mod.eps, momentum, act)
+        ctx.saved = (xd, y, stats, gamma.detach() if gamma is not None else None)
+        ctx.meta = (kind, act, gamma is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xd, y, stats, gamma = ctx.saved
+        kind, act, affine = ctx.meta
+        dx, dg, db = T.norm_act_bwd(xd, y, gy.contiguous().float(), stats, gamma, kind, act, want_affine=affine)
+        return dx, dg, db, None, None
+
+
+class _ActFn(torch.autograd.Function):
+    """LeakyReLU(0.2) / Tanh after a conv without norm (PMGI's decode layer, reference core/model.py:579)."""
+
+    @staticmethod
+    def forward(ctx, x, act):
+        T.require_device(x, "ConvLayer input")
+        y = T.act_fwd(x.detach().contiguous().float(), act)
+        ctx.saved, ctx.act = y, act
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        return T.act_bwd(gy.contiguous().float(), ctx.saved, ctx.act), None
+
+
 class ConvLayer(nn.Module):
     """reference core/block.py:26-118 -- same constructor signature, same sub-module layout
     (`layers.0` = the nn.Conv2d that owns weight/bias, so state_dict keys are identical), same
@@ -180,25 +229,41 @@ class ConvLayer(nn.Module):
         self.layers = nn.Sequential(*mods)
         self.norm, self.pre_norm, self.act = norm, pre_norm, act
         # the HIP kernels cover exactly what the hot-path models use
-        plain = norm is None and pre_norm is None and act in (nn.ReLU, None) and dilation == 1 and groups == 1
-        self._hip = (layer is nn.Conv2d and plain and stride == 1 and ksize in (1, 3) and padding == ksize // 2
-                     and (padding_mode == 'reflect' or ksize == 1) and bias)
+        # what follows the conv: nothing / ReLU fused into the conv kernels, or a norm (+ act) / other activation epilogue kernel
+        epi_ok = (pre_norm is None and norm in (None, nn.BatchNorm2d, nn.GroupNorm) and act in _ACT_CODE and dilation == 1 and groups == 1)
+        self._epilogue = epi_ok and (norm is not None or act in (nn.LeakyReLU, nn.Tanh))
+        plain = epi_ok and not self._epilogue
+        geom_hot = (layer is nn.Conv2d and stride == 1 and ksize in (1, 3) and padding == ksize // 2
+                    and (padding_mode == 'reflect' or ksize == 1) and bias)
         # the general kernels (csrc/conv_general.hip): k = 5 / 7, stride 2, zero padding, ConvTranspose2d -- fp32 NCHW
-        self._gen = (not self._hip and plain and ksize in (1, 3, 5, 7) and stride in (1, 2) and 0 <= padding <= ksize // 2
-                     and ((layer is nn.Conv2d and padding_mode in ('reflect', 'zeros')) or layer is nn.ConvTranspose2d))
+        geom_gen = (ksize in (1, 3, 5, 7) and stride in (1, 2) and 0 <= padding <= ksize // 2
+                    and ((layer is nn.Conv2d and padding_mode in ('reflect', 'zeros')) or layer is nn.ConvTranspose2d))
+        self._hip = plain and geom_hot                       # hot-path kernels, ReLU fused
+        self._gen = plain and not geom_hot and geom_gen      # general kernels, ReLU fused
+        self._conv_hot = geom_hot                            # (which conv kernels an epilogue layer uses)
+        self._epilogue = self._epilogue and (geom_hot or geom_gen)
         self._geom = (stride, padding, padding_mode == 'reflect' and padding > 0)
         self._init_weights()
 
-    def forward(self, x):
+    def _conv(self, x, relu):
         conv = self.layers[0]
-        if self._hip:
-            return _ConvLayerFn.apply(x, conv.weight, conv.bias, self.act is not None)
-        if self._gen:
-            stride, padding, reflect = self._geom
-            if isinstance(conv, nn.ConvTranspose2d):
-                return _GConvTFn.apply(x, conv.weight, conv.bias, stride, padding, 1, self.act is not None)
-            return _GConvFn.apply(x, conv.weight, conv.bias, stride, padding, reflect, self.act is not None)
-        # argument combinations outside these (norm layers, other activations, dilation, groups)
+        if self._conv_hot:
+            return _ConvLayerFn.apply(x, conv.weight, conv.bias, relu)
+        stride, padding, reflect = self._geom
+        if isinstance(conv, nn.ConvTranspose2d):
+            return _GConvTFn.apply(x, conv.weight, conv.bias, stride, padding, 1, relu)
+        return _GConvFn.apply(x, conv.weight, conv.bias, stride, padding, reflect, relu)
+
+    def forward(self, x):
+        if self._hip or self._gen:
+            return self._conv(x, self.act is not None)
+        if self._epilogue:
+            z = self._conv(x, False)
+            if self.norm is None:
+                return _ActFn.apply(z, _ACT_CODE[self.act])
+            mod = self.layers[1]
+            return _NormActFn.apply(z, mod.weight, mod.bias, mod, _ACT_CODE[self.act])
+        # argument combinations outside these (pre_norm, other norms / activations, dilation, groups)
         # are not re-implemented: they run as the stock torch modules they are
         return self.layers(x)
 
@@ -216,6 +281,18 @@ class ConvLayer(nn.Module):
             elif isinstance(m, (nn.BatchNorm2d, nn.GroupNorm)):
                 nn.init.ones_(m.weight)
                 nn.init.zeros_(m.bias)
+
+
+class ResBlock(nn.Module):
+    """reference core/block.py:121-134 (SEDRFuse, DIFNet): two ConvLayers with optional norms, identity shortcut."""
+
+    def __init__(self, in_ch, out_ch, norm1=None, norm2=None):
+        super(ResBlock, self).__init__()
+        self.in_ch, self.out_ch = in_ch, out_ch
+        self.layers = nn.Sequential(ConvLayer(in_ch, out_ch, norm=norm1), ConvLayer(out_ch, out_ch, norm=norm2, act=None))
+
+    def forward(self, x):
+        return element_fusion(self.layers(x), x, 'sum')
 
 
 class DenseBlock(nn.Module):

@@ -12,7 +12,7 @@ from mmif import engine as E
 from .block import *
 from .fusion import *
 
-__all__ = ['PFNetv1', 'PFNetv2', 'DeepFuse', 'DenseFuse', 'VIFNet', 'DBNet', 'NestFuse', 'RFNNest']
+__all__ = ['PFNetv1', 'PFNetv2', 'DeepFuse', 'DenseFuse', 'VIFNet', 'DBNet', 'SEDRFuse', 'NestFuse', 'RFNNest', 'IFCNN', 'DIFNet', 'PMGI']
 
 
 class _FusionModel(nn.Module):
@@ -171,6 +171,49 @@ class DBNet(_FusionModel):
         raise ValueError("only supported ['sum', 'avg'] mode")
 
 
+def _relu_sum(a, b):
+    '''relu(a + b) on the HIP element-wise kernels'''
+    from .block import _ActFn
+    from mmif import tensor as T
+    return _ActFn.apply(element_fusion(a, b, 'sum'), T.ACT_RELU)
+
+
+class SEDRFuse(nn.Module):
+    '''SEDRFuse (reference core/model.py:247-312): symmetric encoder-decoder with a residual block; GroupNorm(c, c) after every
+    conv, two stride-2 convs down, two ConvTranspose2d up, skip connections relu(f_conv + f_deconv).  Layer by layer on the general
+    conv kernels + the norm epilogue kernels (fp32).'''
+
+    def __init__(self, norm=nn.GroupNorm):
+        super(SEDRFuse, self).__init__()
+        self.encode = nn.ModuleList([ConvLayer(1, 64, norm=norm), ConvLayer(64, 128, stride=2, norm=norm),
+                                     ConvLayer(128, 256, stride=2, norm=norm), ResBlock(256, 256, norm1=norm, norm2=norm)])
+        self.decode = nn.ModuleList([ConvLayer(256, 128, stride=2, norm=norm, layer=nn.ConvTranspose2d),
+                                     ConvLayer(128, 64, stride=2, norm=norm, layer=nn.ConvTranspose2d), ConvLayer(64, 1)])
+
+    def encoder(self, img):
+        c1 = self.encode[0](img)
+        c2 = self.encode[1](c1)
+        return c1, c2, self.encode[3](self.encode[2](c2))
+
+    def fusion(self, feat1, feat2):
+        # channel-softmax-weighted L1 activity of each source -> per-pixel weights (tensor-level composition)
+        a1, a2 = torch.abs(feat1), torch.abs(feat2)
+        s1 = spatial_pooling(torch.softmax(a1, dim=1) * a1, mode='sum')
+        s2 = spatial_pooling(torch.softmax(a2, dim=1) * a2, mode='sum')
+        return weighted_fusion(feat1, feat2, s1, s2)
+
+    def decoder(self, f_conv1, f_conv2, f_res):
+        f1 = _relu_sum(f_conv2, self.decode[0](f_res))
+        f2 = _relu_sum(f_conv1, self.decode[1](f1))
+        return self.decode[2](f2)
+
+    def forward(self, img1, img2=None):
+        if img2 is None:
+            return self.decoder(*self.encoder(img1))
+        a, b = self.encoder(img1), self.encoder(img2)
+        return self.decoder(element_fusion(a[0], b[0], mode='max'), element_fusion(a[1], b[1], mode='max'), self.fusion(a[2], b[2]))
+
+
 class NestFuse(_FusionModel):
     '''NestFuse (reference core/model.py:319-363): 1x1 conv_in, four ConvBlock levels with 2x2 max-pool,
     spatial/channel attention fusion per level, UNet++ NestDecoder, 1x1 conv_out.  Every ConvLayer runs on
@@ -226,3 +269,69 @@ class RFNNest(NestFuse):
     def fusion(self, feats1, feats2):
         return (self.RFN1(feats1[0], feats2[0]), self.RFN2(feats1[1], feats2[1]), self.RFN3(feats1[2], feats2[2]),
                 self.RFN4(feats1[3], feats2[3]))
+
+
+class IFCNN(_FusionModel):
+    '''IFCNN (reference core/model.py:514-530): 7x7 conv without activation, BatchNorm ConvLayers, element-wise max fusion.'''
+
+    def __init__(self, norm=nn.BatchNorm2d):
+        super(IFCNN, self).__init__()
+        self.encode = nn.Sequential(ConvLayer(1, 64, ksize=7, act=None), ConvLayer(64, 64, norm=norm))
+        self.decode = nn.Sequential(ConvLayer(64, 64, norm=norm), ConvLayer(64, 1, ksize=1, act=None))
+
+    def fusion(self, feat1, feat2, mode='max'):
+        return element_fusion(feat1, feat2, mode)
+
+
+class DIFNet(_FusionModel):
+    '''DIFNet (reference core/model.py:533-553): residual blocks with BatchNorm, a 3x3 ConvLayer fusing the concatenated features.'''
+
+    def __init__(self, norm=nn.BatchNorm2d):
+        super(DIFNet, self).__init__()
+        self.encode = nn.Sequential(ConvLayer(1, 16), ResBlock(16, 16, norm1=norm), ResBlock(16, 16, norm1=norm))
+        self.fuse = ConvLayer(32, 16, act=None)
+        self.decode = nn.Sequential(ResBlock(16, 16, norm1=norm), ResBlock(16, 16, norm1=norm), ResBlock(16, 16, norm1=norm),
+                                    ConvLayer(16, 1, act=None))
+
+    def fusion(self, feat1, feat2):
+        return self.fuse(concat_fusion((feat1, feat2)))
+
+
+class PMGI(nn.Module):
+    '''PMGI (reference core/model.py:556-624): a gradient and an intensity path of BatchNorm + LeakyReLU ConvLayers that exchange
+    1x1 "transfer" features, all eight feature maps concatenated into a 1x1 Tanh ConvLayer; output tanh / 2 + 0.5.'''
+
+    def __init__(self, norm=nn.BatchNorm2d, act=nn.LeakyReLU):
+        super(PMGI, self).__init__()
+
+        def path():
+            return nn.ModuleList([ConvLayer(3, 16, ksize=5, norm=norm, act=act), ConvLayer(16, 16, norm=norm, act=act),
+                                  ConvLayer(48, 16, norm=norm, act=act), ConvLayer(64, 16, norm=norm, act=act)])
+
+        def transfer():
+            return nn.ModuleList([ConvLayer(32, 16, ksize=1, norm=norm, act=act), ConvLayer(32, 16, ksize=1, norm=norm, act=act)])
+        self.gradient, self.intensity = path(), path()
+        self.transfer1, self.transfer2 = transfer(), transfer()
+        self.decode = ConvLayer(128, 1, ksize=1, act=nn.Tanh)
+
+    def encoder(self, img1, img2):
+        g0 = self.gradient[0](concat_fusion((img1, img1, img2)))
+        i0 = self.intensity[0](concat_fusion((img2, img2, img1)))
+        g1, i1 = self.gradient[1](g0), self.intensity[1](i0)
+        t = concat_fusion((g1, i1))
+        # (the reference routes the intensity path's first exchange through transfer2[1]; transfer1[1] is never called -- kept)
+        g2 = self.gradient[2](concat_fusion((g0, g1, self.transfer1[0](t))))
+        i2 = self.intensity[2](concat_fusion((i0, i1, self.transfer2[1](t))))
+        t = concat_fusion((g2, i2))
+        g3 = self.gradient[3](concat_fusion((g0, g1, g2, self.transfer2[0](t))))
+        i3 = self.intensity[3](concat_fusion((i0, i1, i2, self.transfer2[1](t))))
+        return g0, i0, g1, i1, g2, i2, g3, i3
+
+    def fusion(self, feats):
+        return concat_fusion(feats)
+
+    def decoder(self, feat):
+        return self.decode(feat)
+
+    def forward(self, img1, img2):
+        return self.decoder(self.fusion(self.encoder(img1, img2))) / 2.0 + 0.5

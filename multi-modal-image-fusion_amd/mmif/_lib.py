@@ -69,6 +69,11 @@ SIGNATURES = {
     "mmif_channel_sum": (_i32, [_vp, _vp, _i32, _i32, _i64, _vp]),
     "mmif_bilinear_up_fwd": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     "mmif_bilinear_up_bwd": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
+    "mmif_norm_workspace": (_sz, [_i32, _i32]),
+    "mmif_norm_act_fwd": (_i32, [_vp] * 7 + [_i32, _i32, _i64, _i32, _f32, _f32, _i32, _f32, _vp, _sz, _vp]),
+    "mmif_norm_act_bwd": (_i32, [_vp] * 8 + [_i32, _i32, _i64, _i32, _i32, _f32, _vp, _sz, _vp]),
+    "mmif_act_fwd": (_i32, [_vp, _vp, _i64, _i32, _f32, _vp]),
+    "mmif_act_bwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _f32, _vp]),
     "mmif_conv2d_reflect_fwd": (_i32, [_TP, _vp, _vp, _vp, _TP, _i32, _i32, _i32, _i32, _i32, _vp]),
     "mmif_conv2d_reflect_dgrad": (_i32, [_TP, _vp, _vp, _TP, _TP, _i32, _i32, _i32, _u64, _u64, _i32, _vp]),
     "mmif_conv2d_reflect_dgrad_folded": (_i32, [_TP, _vp, _vp, _TP, _TP, _i32, _i32, _i32, _u64, _u64, _i32, _vp]),

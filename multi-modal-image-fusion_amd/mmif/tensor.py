@@ -363,3 +363,52 @@ def bilinear_up_bwd(g, in_hw):
     dx = torch.empty((n, c, in_hw[0], in_hw[1]), dtype=torch.float32, device=g.device)
     check(lib.mmif_bilinear_up_bwd(_ptr(g), _ptr(dx), n * c, in_hw[0], in_hw[1], H, W, stream_ptr()), "bilinear_up_bwd")
     return dx
+
+
+# ------------------------------------------------------------------ norm + activation epilogues (row n4)
+NORM_BN_TRAIN, NORM_BN_EVAL, NORM_GN = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_TANH = 0, 1, 2, 3
+
+
+def _norm_ws(n, c, dev):
+    return torch.empty(lib.mmif_norm_workspace(n, c) // 4 + 2, dtype=torch.float32, device=dev)
+
+
+def norm_act_fwd(x, gamma, beta, running_mean, running_var, kind, eps, momentum, act, slope=0.2):
+    """y = act(norm(x)) (BatchNorm2d train / eval, GroupNorm(c, c)); returns (y, stats)."""
+    _f32c(x, "x")
+    n, c = x.shape[0], x.shape[1]
+    hw = x[0, 0].numel()
+    y = torch.empty_like(x)
+    stats = torch.empty(2 * (n * c if kind == NORM_GN else c), dtype=torch.float32, device=x.device)
+    ws = _norm_ws(n, c, x.device)
+    check(lib.mmif_norm_act_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(stats), _ptr(running_mean), _ptr(running_var), n, c, hw, kind,
+                                float(eps), float(momentum), act, float(slope), _ptr(ws), ws.numel() * 4, stream_ptr()), "norm_act_fwd")
+    return y, stats
+
+
+def norm_act_bwd(x, y, gy, stats, gamma, kind, act, slope=0.2, want_affine=True):
+    _f32c(x, "x"), _f32c(y, "y"), _f32c(gy, "gy")
+    n, c = x.shape[0], x.shape[1]
+    hw = x[0, 0].numel()
+    dx = torch.empty_like(x)
+    dg = torch.empty(c, dtype=torch.float32, device=x.device) if want_affine else None
+    db = torch.empty(c, dtype=torch.float32, device=x.device) if want_affine else None
+    ws = _norm_ws(n, c, x.device)
+    check(lib.mmif_norm_act_bwd(_ptr(x), _ptr(y), _ptr(gy), _ptr(stats), _ptr(gamma), _ptr(dx), _ptr(dg), _ptr(db), n, c, hw, kind, act,
+                                float(slope), _ptr(ws), ws.numel() * 4, stream_ptr()), "norm_act_bwd")
+    return dx, dg, db
+
+
+def act_fwd(x, act, slope=0.2):
+    _f32c(x, "x")
+    y = torch.empty_like(x)
+    check(lib.mmif_act_fwd(_ptr(x), _ptr(y), x.numel(), act, float(slope), stream_ptr()), "act_fwd")
+    return y
+
+
+def act_bwd(gy, y, act, slope=0.2):
+    _f32c(gy, "gy"), _f32c(y, "y")
+    dx = torch.empty_like(gy)
+    check(lib.mmif_act_bwd(_ptr(gy), _ptr(y), _ptr(dx), gy.numel(), act, float(slope), stream_ptr()), "act_bwd")
+    return dx

@@ -23,6 +23,8 @@ GPU box.  Fixture map:
   f10_vifnet.npz / f10_manifest.json   VIFNet (core/model.py:189-206) forward + gradient digests + state_dict manifest
   f11_general_conv.npz       ConvLayer with k = 5/7, stride 2, zero padding, ConvTranspose2d (core/block.py:56-76): fwd + (dx, dW, db)
   f12_n4_models.npz / f12_manifest.json   bilinear Upsample (core/block.py:965-991) fwd + dx; DeepFuse, DBNet forward + gradient digests
+  f13_n4_norm.npz / f13_manifest.json   ConvLayer with BatchNorm2d / GroupNorm + ReLU / LeakyReLU / Tanh (core/block.py:78-92): y, dx, parameter
+                             gradients, running buffers; SEDRFuse, IFCNN, DIFNet, PMGI forward + gradient / buffer digests
   f7_metric_ssim.json        core/metric.py:316-364 calc_ssim (the SSIM that test.py:49-52 reports) on closed-form images
 """
 import json
@@ -223,6 +225,59 @@ def make_f12():
     # and 1 % of the gradients behind it -- depends on the summation order of the conv that produced it)
     np.savez_compressed(os.path.join(HERE, "f12_n4_models.npz"), **out)
     json.dump(manifest, open(os.path.join(HERE, "f12_manifest.json"), "w"), indent=0)
+
+
+# ---------------------------------------------------------------- F13 (row n4: norm / activation epilogues, SEDRFuse, IFCNN, DIFNet, PMGI)
+#             name        cin cout k stride transposed norm act  train  N  H   W
+F13_CASES = [("bn_relu",   16, 24, 3, 1, False, "bn", "relu", True, 3, 10, 12), ("bn_eval", 16, 24, 3, 1, False, "bn", "relu", False, 2, 9, 8),
+             ("bn_lin",     8, 16, 3, 1, False, "bn", None, True, 2, 7, 9), ("bn_leaky_k5", 3, 16, 5, 1, False, "bn", "leaky", True, 2, 12, 11),
+             ("bn_leaky_k1", 32, 16, 1, 1, False, "bn", "leaky", True, 2, 6, 7), ("gn_relu", 1, 64, 3, 1, False, "gn", "relu", True, 2, 10, 10),
+             ("gn_s2",     24, 32, 3, 2, False, "gn", "relu", True, 2, 11, 14), ("gn_convT", 32, 16, 3, 2, True, "gn", "relu", True, 2, 5, 6),
+             ("tanh_k1",   40, 1, 1, 1, False, None, "tanh", True, 2, 8, 9), ("leaky_k3", 16, 16, 3, 1, False, None, "leaky", True, 1, 9, 9)]
+_NORMS = {"bn": nn.BatchNorm2d, "gn": nn.GroupNorm, None: None}
+_ACTS = {"relu": nn.ReLU, "leaky": nn.LeakyReLU, "tanh": nn.Tanh, None: None}
+
+
+def make_f13():
+    out, manifest = {}, {}
+    for name, cin, cout, k, stride, transposed, norm, act, train, N, H, W in F13_CASES:
+        layer = rblock.ConvLayer(cin, cout, ksize=k, stride=stride, norm=_NORMS[norm], act=_ACTS[act],
+                                 layer=nn.ConvTranspose2d if transposed else nn.Conv2d)
+        load_closed_form(layer, seed=13)
+        if norm == "bn":   # non-trivial running statistics (closed-form loading makes running_var signed: use its magnitude)
+            layer.layers[1].running_var.abs_().add_(0.5)
+            layer.layers[1].num_batches_tracked.zero_()
+        layer.train(train)
+        x = T(closed_form_signed((N, cin, H, W), 0.5, 1.0)).requires_grad_(True)
+        y = layer(x)
+        y.backward(T(closed_form_signed(tuple(y.shape), 1.5, 1.0)))
+        out[name + "_y"], out[name + "_dx"] = y.detach().numpy(), x.grad.numpy()
+        for kname, p in layer.named_parameters():
+            out[f"{name}_dp_{kname}"] = p.grad.numpy()
+        for kname, b in layer.named_buffers():
+            out[f"{name}_buf_{kname}"] = b.detach().numpy().astype(np.float32)
+    for name, shapes in (("SEDRFuse", ((2, 1, 32, 32),)), ("IFCNN", ((2, 1, 32, 32), (1, 1, 21, 30))), ("DIFNet", ((2, 1, 32, 32),)),
+                         ("PMGI", ((2, 1, 32, 32), (1, 1, 19, 26)))):
+        for shape in shapes:
+            tag = f"{name}_{shape[0]}x{shape[2]}x{shape[3]}"
+            model = load_closed_form(getattr(rmodel, name)(), seed=2)
+            for mod in model.modules():
+                if isinstance(mod, nn.BatchNorm2d):
+                    mod.running_var.abs_().add_(0.5)
+                    mod.num_batches_tracked.zero_()
+            model.train()
+            manifest[name] = [[k, list(v.shape)] for k, v in model.state_dict().items()]
+            i1, i2 = T(closed_form_image(shape, 0.3)), T(closed_form_image(shape, 1.7))
+            y = model(i1, i2)
+            y.backward(T(closed_form_signed(tuple(y.shape), 0.9, 1.0)))
+            out[tag + "__y"] = y.detach().numpy()
+            for k, p in model.named_parameters():
+                if p.grad is not None:   # (PMGI never calls transfer1[1], core/model.py:589: no gradient)
+                    out[f"{tag}__dp_{k}"] = digest(p.grad.numpy())
+            for k, b in model.named_buffers():
+                out[f"{tag}__buf_{k}"] = digest(b.detach().numpy().astype(np.float32))
+    np.savez_compressed(os.path.join(HERE, "f13_n4_norm.npz"), **out)
+    json.dump(manifest, open(os.path.join(HERE, "f13_manifest.json"), "w"), indent=0)
 
 
 # ---------------------------------------------------------------- F4
@@ -449,7 +504,7 @@ def make_f9():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10", "f11", "f12"]
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10", "f11", "f12", "f13"]
     for w in which:
         globals()["make_" + w]()
         print("wrote", w)

@@ -122,3 +122,78 @@ def test_n4_models_vs_golden(name, shape):
     close(y.detach().cpu().numpy(), g[tag + "__y"], 1e-4, "fused image")
     for k, p in model.named_parameters():
         close_digest(p.grad.cpu().numpy(), g[f"{tag}__dp_{k}"], 2e-4, k)
+
+
+# ------------------------------------------------------------------ norm / activation epilogues (golden F13)
+from test_oracle_golden import F13_CASES, f13_params  # noqa: E402
+
+_NORMS = {"bn": nn.BatchNorm2d, "gn": nn.GroupNorm, None: None}
+_ACTS = {"relu": nn.ReLU, "leaky": nn.LeakyReLU, "tanh": nn.Tanh, None: None}
+
+
+@pytest.mark.parametrize("case", F13_CASES, ids=[c[0] for c in F13_CASES])
+def test_norm_act_conv_layer_vs_golden(case):
+    """ConvLayer(norm=BatchNorm2d | GroupNorm, act=ReLU | LeakyReLU | Tanh | None) of the mirror: HIP conv + csrc/norm.hip epilogue
+    against the reference: y, dx, every parameter gradient and the BatchNorm buffers after the step (train and eval mode)."""
+    from core.block import ConvLayer
+    name, cin, cout, k, stride, transposed, norm, act, train, N, H, W = case
+    g = np.load(os.path.join(G, "f13_n4_norm.npz"))
+    layer = ConvLayer(cin, cout, ksize=k, stride=stride, norm=_NORMS[norm], act=_ACTS[act], layer=nn.ConvTranspose2d if transposed else nn.Conv2d)
+    assert layer._epilogue and not layer._hip and not layer._gen
+    P = f13_params(case)
+    sd = layer.state_dict()
+    layer.load_state_dict({kk: torch.from_numpy(np.asarray(P[kk])).to(sd[kk].dtype) if kk != "layers.1.num_batches_tracked" else torch.zeros((), dtype=torch.long)
+                           for kk in sd})
+    layer = layer.cuda().train(train)
+    want_dx = not (cin == 1 and layer._conv_hot)   # (the hot-path image-input conv gives no gradient w.r.t. the image)
+    x = torch.from_numpy(O.closed_form_signed((N, cin, H, W), 0.5, 1.0)).cuda().requires_grad_(want_dx)
+    y = layer(x)
+    y.backward(torch.from_numpy(O.closed_form_signed(tuple(y.shape), 1.5, 1.0)).cuda())
+    close(y.detach().cpu().numpy(), g[name + "_y"], 2e-5, "y")
+    if want_dx:
+        close(x.grad.cpu().numpy(), g[name + "_dx"], 5e-5, "dx")
+    for kname, p in layer.named_parameters():
+        ref = g[f"{name}_dp_{kname}"]
+        if norm and kname == "layers.0.bias":   # mathematically zero (the norm removes the mean): rounding noise on both sides
+            assert np.abs(p.grad.cpu().numpy() - ref).max() <= 1e-4
+        else:
+            close(p.grad.cpu().numpy(), ref, 5e-5, kname)
+    for kname, b in layer.named_buffers():
+        close(b.detach().cpu().numpy().astype(np.float32), g[f"{name}_buf_{kname}"], 2e-5, kname)
+
+
+N4B_MODELS = [("SEDRFuse", (2, 1, 32, 32)), ("IFCNN", (2, 1, 32, 32)), ("IFCNN", (1, 1, 21, 30)), ("DIFNet", (2, 1, 32, 32)), ("PMGI", (2, 1, 32, 32)),
+              ("PMGI", (1, 1, 19, 26))]
+
+
+@pytest.mark.parametrize("name,shape", N4B_MODELS, ids=[f"{n}-{s[0]}x{s[2]}x{s[3]}" for n, s in N4B_MODELS])
+def test_n4_norm_models_vs_golden(name, shape):
+    """SEDRFuse (GroupNorm, stride 2, ConvTranspose2d, ResBlock), IFCNN / DIFNet (BatchNorm, k = 7), PMGI (BatchNorm + LeakyReLU,
+    k = 5, Tanh) in training mode on the HIP kernels: fused image, every parameter gradient and every BatchNorm buffer."""
+    import core.model as M
+    from gpu_util import close_digest, dtype_ctx
+    g = np.load(os.path.join(G, "f13_n4_norm.npz"))
+    tag = f"{name}_{shape[0]}x{shape[2]}x{shape[3]}"
+    with dtype_ctx("fp32"):
+        model = load_closed_form(getattr(M, name)(), 2)
+        for mod in model.modules():
+            if isinstance(mod, nn.BatchNorm2d):
+                mod.running_var.abs_().add_(0.5)
+                mod.num_batches_tracked.zero_()
+        model = model.cuda().train()
+        i1, i2 = (torch.from_numpy(O.closed_form_image(shape, p)).cuda() for p in (0.3, 1.7))
+        y = model(i1, i2)
+        y.backward(torch.from_numpy(O.closed_form_signed(tuple(y.shape), 0.9, 1.0)).cuda())
+    close(y.detach().cpu().numpy(), g[tag + "__y"], 2e-4, "fused image")
+    for k, p in model.named_parameters():
+        if f"{tag}__dp_{k}" not in g.files:
+            assert p.grad is None, k   # PMGI's unused transfer1[1]
+            continue
+        dg = g[f"{tag}__dp_{k}"]
+        if k.endswith("bias") and dg[1] < 1e-5 * p.numel() * max(1.0, abs(float(y.numel()))) ** 0.5:
+            # a conv bias whose effect the following norm removes: the exact gradient is zero, both sides hold rounding noise
+            assert float(p.grad.abs().sum()) < 1e-5 * p.numel() * float(y.numel()) ** 0.5, k
+            continue
+        close_digest(p.grad.cpu().numpy(), dg, 2e-3, k)   # (fp32 through several BatchNorms; max-fusion ties)
+    for k, b in model.named_buffers():
+        close_digest(b.detach().cpu().numpy().astype(np.float32), g[f"{tag}__buf_{k}"], 2e-4, k)

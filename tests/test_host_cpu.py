@@ -89,10 +89,13 @@ def test_c_abi_validation_of_the_widened_entry_points_without_gpu():
     assert b"ksize must be 1 or 3" in lib.mmif_last_error()
 
 
-@pytest.mark.parametrize("name", ["PFNetv1", "PFNetv2", "DenseFuse", "VIFNet", "NestFuse", "RFNNest", "DeepFuse", "DBNet"])
+@pytest.mark.parametrize("name", ["PFNetv1", "PFNetv2", "DenseFuse", "VIFNet", "NestFuse", "RFNNest", "DeepFuse", "DBNet", "SEDRFuse", "IFCNN",
+                                  "DIFNet", "PMGI"])
 def test_state_dict_manifest_and_init(name):
     import core.model as M
-    man = json.load(open(os.path.join(G, {"VIFNet": "f10_manifest.json", "DeepFuse": "f12_manifest.json", "DBNet": "f12_manifest.json"}.get(name, "f5_manifest.json"))))
+    man = json.load(open(os.path.join(G, {"VIFNet": "f10_manifest.json", "DeepFuse": "f12_manifest.json", "DBNet": "f12_manifest.json",
+                                          "SEDRFuse": "f13_manifest.json", "IFCNN": "f13_manifest.json", "DIFNet": "f13_manifest.json",
+                                          "PMGI": "f13_manifest.json"}.get(name, "f5_manifest.json"))))
     torch.manual_seed(0)
     m = getattr(M, name)()
     assert [[k, list(v.shape)] for k, v in m.state_dict().items()] == man[name]
@@ -100,7 +103,7 @@ def test_state_dict_manifest_and_init(name):
     for k, v in m.state_dict().items():
         if k.endswith("bias"):
             assert float(v.abs().max()) == 0.0
-    if name in ("NestFuse", "RFNNest", "DeepFuse"):
+    if name in ("NestFuse", "RFNNest", "DeepFuse", "SEDRFuse", "IFCNN", "DIFNet", "PMGI"):
         return
     w = m.state_dict()["decode.0.layers.0.weight"]
     fan_in = w.shape[1] * 9
@@ -142,9 +145,14 @@ def test_conv_layer_signature_and_fallback_rules():
     for lay in (ConvLayer(16, 16, stride=2), ConvLayer(16, 16, ksize=5), ConvLayer(1, 16, ksize=7), ConvLayer(16, 16, padding_mode='zeros'),
                 ConvLayer(16, 8, stride=2, layer=nn.ConvTranspose2d)):
         assert lay._gen and not lay._hip
-    # norm layers / other activations stay stock torch modules
-    for lay in (ConvLayer(16, 16, norm=nn.BatchNorm2d), ConvLayer(16, 16, act=nn.Tanh), ConvLayer(16, 16, dilation=2, padding=2)):
-        assert not lay._hip and not lay._gen
+    # BatchNorm / GroupNorm(c, c) and LeakyReLU / Tanh: HIP conv + the norm / activation epilogue kernels
+    for lay in (ConvLayer(16, 16, norm=nn.BatchNorm2d), ConvLayer(16, 16, act=nn.Tanh), ConvLayer(16, 16, norm=nn.GroupNorm, stride=2),
+                ConvLayer(3, 16, ksize=5, norm=nn.BatchNorm2d, act=nn.LeakyReLU)):
+        assert lay._epilogue and not lay._hip and not lay._gen
+    # everything else stays the stock torch modules
+    for lay in (ConvLayer(16, 16, dilation=2, padding=2), ConvLayer(16, 16, pre_norm=nn.BatchNorm2d), ConvLayer(16, 16, act=nn.Sigmoid),
+                ConvLayer(16, 16, groups=2)):
+        assert not lay._hip and not lay._gen and not lay._epilogue
     assert list(DenseBlock(16, 16).state_dict())[0] == "layers.0.layers.0.weight"
     assert sum(p.numel() for p in ConvBlock(16, 64).parameters()) == 16 * 8 * 9 + 8 + 8 * 64 + 64
     assert len(list(RFN(16).parameters())) == 12

@@ -381,3 +381,66 @@ def test_f11_general_conv_oracle_vs_reference(case):
     for got, key in ((y, "_y"), (dx, "_dx"), (dw, "_dw"), (db, "_db")):
         ref = g[name + key]
         assert np.abs(got - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max()), (name, key)
+
+
+# ------------------------------------------------------------------ F13: norm / activation epilogues of ConvLayer
+#             name        cin cout k stride transposed norm act  train  N  H   W
+F13_CASES = [("bn_relu", 16, 24, 3, 1, False, "bn", "relu", True, 3, 10, 12), ("bn_eval", 16, 24, 3, 1, False, "bn", "relu", False, 2, 9, 8),
+             ("bn_lin", 8, 16, 3, 1, False, "bn", None, True, 2, 7, 9), ("bn_leaky_k5", 3, 16, 5, 1, False, "bn", "leaky", True, 2, 12, 11),
+             ("bn_leaky_k1", 32, 16, 1, 1, False, "bn", "leaky", True, 2, 6, 7), ("gn_relu", 1, 64, 3, 1, False, "gn", "relu", True, 2, 10, 10),
+             ("gn_s2", 24, 32, 3, 2, False, "gn", "relu", True, 2, 11, 14), ("gn_convT", 32, 16, 3, 2, True, "gn", "relu", True, 2, 5, 6),
+             ("tanh_k1", 40, 1, 1, 1, False, None, "tanh", True, 2, 8, 9), ("leaky_k3", 16, 16, 3, 1, False, None, "leaky", True, 1, 9, 9)]
+
+
+def f13_params(case):
+    name, cin, cout, k, stride, transposed, norm, act, train, N, H, W = case
+    keys = ["layers.0.weight", "layers.0.bias"]
+    shapes = [(cin, cout, k, k) if transposed else (cout, cin, k, k), (cout,)]
+    if norm:
+        keys += ["layers.1.weight", "layers.1.bias"]
+        shapes += [(cout,), (cout,)]
+    if norm == "bn":
+        keys += ["layers.1.running_mean", "layers.1.running_var", "layers.1.num_batches_tracked"]
+        shapes += [(cout,), (cout,), ()]
+    P = {kk: O.closed_form_param(i, kk, sh, 13) for i, (kk, sh) in enumerate(zip(keys, shapes))}
+    if norm == "bn":
+        P["layers.1.running_var"] = np.abs(P["layers.1.running_var"]) + 0.5
+    return P
+
+
+@pytest.mark.parametrize("case", F13_CASES, ids=[c[0] for c in F13_CASES])
+def test_f13_norm_act_oracle_vs_reference(case):
+    """oracle conv + norm_act_fwd/bwd == the reference's ConvLayer(norm=BatchNorm2d | GroupNorm, act=ReLU | LeakyReLU | Tanh):
+    output, input / weight / affine gradients, running statistics after the step."""
+    name, cin, cout, k, stride, transposed, norm, act, train, N, H, W = case
+    g = np.load(os.path.join(G, "f13_n4_norm.npz"))
+    P = f13_params(case)
+    w, b = P["layers.0.weight"], P["layers.0.bias"]
+    x = O.closed_form_signed((N, cin, H, W), 0.5, 1.0)
+    p = k // 2
+    z = O.conv_transpose2d_fwd(x, w, b, stride, p, 1, False) if transposed else O.conv2d_general_fwd(x, w, b, stride, p, True, False)
+    running = None
+    if norm:
+        gamma, beta = P["layers.1.weight"], P["layers.1.bias"]
+        kind = "gn" if norm == "gn" else ("bn" if train else "bn_eval")
+        if norm == "bn":
+            running = [P["layers.1.running_mean"].copy(), P["layers.1.running_var"].copy()]
+        y, cache = O.norm_act_fwd(z, gamma, beta, kind, act, 1e-5, running)
+    else:
+        y = O._act(z, act)
+    gy = O.closed_form_signed(y.shape, 1.5, 1.0)
+    if norm:
+        dz, dg, dbt = O.norm_act_bwd(cache, y, gy, gamma)
+    else:
+        dz = gy * O._act_dydz(y, act)
+    dx, dw, db = (O.conv_transpose2d_bwd(x, w, z, dz, stride, p, 1, False) if transposed else O.conv2d_general_bwd(x, w, z, dz, stride, p, True, False))
+    pairs = [(y, "_y"), (dx, "_dx"), (dw, "_dp_layers.0.weight"), (db, "_dp_layers.0.bias")]
+    if norm:
+        pairs += [(dg, "_dp_layers.1.weight"), (dbt, "_dp_layers.1.bias")]
+    if norm == "bn":
+        pairs += [(running[0], "_buf_layers.1.running_mean"), (running[1], "_buf_layers.1.running_var")]
+    for got, key in pairs:
+        ref = g[name + key]
+        # (the conv bias in front of a norm has a mathematically zero gradient: both sides hold rounding noise of ~1e-5 there)
+        tol = 3e-5 if (norm and key == "_dp_layers.0.bias") else 3e-6
+        assert np.abs(got - ref).max() <= tol * max(1.0, np.abs(ref).max()), (name, key, np.abs(got - ref).max())
