@@ -16,7 +16,8 @@ from mmif.tensor import BT
 
 from .fusion import concat_fusion, element_fusion
 
-__all__ = ['ConvLayer', 'ResBlock', 'DenseBlock', 'ConvBlock', 'RFN', 'NestDecoder', 'Downsample', 'Upsample']
+__all__ = ['ConvLayer', 'ResBlock', 'DenseBlock', 'ConvBlock', 'ECB', 'DCB', 'RFN', 'NestEncoder', 'NestDecoder', 'FSDecoder', 'Downsample',
+           'Upsample']
 
 
 class _ConvLayerFn(torch.autograd.Function):
@@ -234,7 +235,9 @@ class ConvLayer(nn.Module):
         self._epilogue = epi_ok and (norm is not None or act in (nn.LeakyReLU, nn.Tanh))
         plain = epi_ok and not self._epilogue
         geom_hot = (layer is nn.Conv2d and stride == 1 and ksize in (1, 3) and padding == ksize // 2
-                    and (padding_mode == 'reflect' or ksize == 1) and bias)
+                    and (padding_mode == 'reflect' or ksize == 1) and bias
+                    and max(in_ch, out_ch) <= 512)   # (a blocked-layout view holds at most 64 channel blocks: wider layers -- UNFusion's
+                                                     # 1024-channel level, MAFusion's 960-channel concats -- take the general kernels)
         # the general kernels (csrc/conv_general.hip): k = 5 / 7, stride 2, zero padding, ConvTranspose2d -- fp32 NCHW
         geom_gen = (ksize in (1, 3, 5, 7) and stride in (1, 2) and 0 <= padding <= ksize // 2
                     and ((layer is nn.Conv2d and padding_mode in ('reflect', 'zeros')) or layer is nn.ConvTranspose2d))
@@ -320,6 +323,20 @@ class ConvBlock(nn.Module):
 
     def forward(self, x):
         return self.layers(x)
+
+
+class ECB(ConvBlock):
+    """UNFusion's encoder block (reference core/block.py:725-728): 1x1 then 3x3"""
+
+    def __init__(self, in_ch, out_ch, ksize1=1, ksize2=3):
+        super(ECB, self).__init__(in_ch, out_ch, ksize1=ksize1, ksize2=ksize2)
+
+
+class DCB(ConvBlock):
+    """UNFusion's decoder block (reference core/block.py:731-734): 3x3 then 3x3"""
+
+    def __init__(self, in_ch, out_ch, ksize1=3, ksize2=3):
+        super(DCB, self).__init__(in_ch, out_ch, ksize1=ksize1, ksize2=ksize2)
 
 
 class RFN(nn.Module):
@@ -415,3 +432,51 @@ class NestDecoder(nn.Module):
         x1_2 = self.DB1_2(concat_fusion((f[0], x1_1, up(x2_1, x1_1.shape))))
         x2_2 = self.DB2_2(concat_fusion((f[1], x2_1, up(x3_1, x2_1.shape))))
         return self.DB1_3(concat_fusion((f[0], x1_1, x1_2, up(x2_2, x1_2.shape))))
+
+
+class NestEncoder(nn.Module):
+    """UNFusion's densely nested encoder (reference core/block.py:762-797): every level re-reads the levels above it through
+    stride-2 ConvLayers (or max-pooling).  feats = (x1, (x2, d1), (x3, d2), (x4, d3)) with d_i the down-sampled level above."""
+
+    def __init__(self, block, in_ch, out_ch, down_mode='stride'):
+        super(NestEncoder, self).__init__()
+        i, o = in_ch, out_ch
+        self.EB2_1 = block(i[1] + i[0], o[1])
+        self.EB3_1 = block(i[2] + i[1], i[2] * 2)
+        self.EB4_1 = block(i[3] + i[2], i[3] * 2)
+        self.EB3_2 = block(i[2] * 3 + o[1], o[2])
+        self.EB4_2 = block(i[3] * 3 + i[2] * 2, i[3] * 4 + i[2])
+        self.EB4_3 = block(i[3] * 7 + i[2] + o[2], o[3])
+        if down_mode == 'maxpool':
+            self.down1, self.down2, self.down3 = nn.MaxPool2d(2, 2), nn.MaxPool2d(2, 2), nn.MaxPool2d(2, 2)
+        elif down_mode == 'stride':
+            self.down1 = ConvLayer(o[1], o[1], stride=2)
+            self.down2 = ConvLayer(i[2] * 2, i[2] * 2, stride=2)
+            self.down3 = ConvLayer(o[2], o[2], stride=2)
+
+    def forward(self, feats):
+        x2_1 = self.EB2_1(concat_fusion(feats[1]))
+        x3_1 = self.EB3_1(concat_fusion(feats[2]))
+        x4_1 = self.EB4_1(concat_fusion(feats[3]))
+        x3_2 = self.EB3_2(concat_fusion((feats[2][0], x3_1, self.down1(x2_1))))
+        x4_2 = self.EB4_2(concat_fusion((feats[3][0], x4_1, self.down2(x3_1))))
+        x4_3 = self.EB4_3(concat_fusion((feats[3][0], x4_1, x4_2, self.down3(x3_2))))
+        return feats[0], x2_1, x3_2, x4_3
+
+
+class FSDecoder(nn.Module):
+    """MAFusion's full-scale skip decoder (U-Net 3+; reference core/block.py:870-939): every decoder level concatenates all four
+    scales, max-pooled down or bilinearly up-sampled (x2 / x4 / x8) to its own size."""
+
+    def __init__(self, block, num_ch, up_mode='bilinear'):
+        super(FSDecoder, self).__init__()
+        cat_ch = sum(num_ch[:4])
+        self.DB1, self.DB2, self.DB3 = block(cat_ch, num_ch[0]), block(cat_ch, num_ch[1]), block(cat_ch, num_ch[2])
+        self.down1, self.down2 = Downsample(2, 2), Downsample(4, 4)
+        self.up1, self.up2, self.up3 = Upsample(up_mode, 2), Upsample(up_mode, 4), Upsample(up_mode, 8)
+
+    def forward(self, feats):
+        f = feats
+        y3 = self.DB3(concat_fusion((self.down2(f[0], f[2].shape), self.down1(f[1], f[2].shape), f[2], self.up1(f[3], f[2].shape))))
+        y2 = self.DB2(concat_fusion((self.down1(f[0], f[1].shape), f[1], self.up1(y3, f[1].shape), self.up2(f[3], f[1].shape))))
+        return self.DB1(concat_fusion((f[0], self.up1(y2, f[0].shape), self.up2(y3, f[0].shape), self.up3(f[3], f[0].shape))))

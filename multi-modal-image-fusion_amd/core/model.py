@@ -12,7 +12,8 @@ from mmif import engine as E
 from .block import *
 from .fusion import *
 
-__all__ = ['PFNetv1', 'PFNetv2', 'DeepFuse', 'DenseFuse', 'VIFNet', 'DBNet', 'SEDRFuse', 'NestFuse', 'RFNNest', 'IFCNN', 'DIFNet', 'PMGI']
+__all__ = ['PFNetv1', 'PFNetv2', 'DeepFuse', 'DenseFuse', 'VIFNet', 'DBNet', 'SEDRFuse', 'NestFuse', 'RFNNest', 'UNFusion', 'MAFusion',
+           'IFCNN', 'DIFNet', 'PMGI']
 
 
 class _FusionModel(nn.Module):
@@ -269,6 +270,68 @@ class RFNNest(NestFuse):
     def fusion(self, feats1, feats2):
         return (self.RFN1(feats1[0], feats2[0]), self.RFN2(feats1[1], feats2[1]), self.RFN3(feats1[2], feats2[2]),
                 self.RFN4(feats1[3], feats2[3]))
+
+
+class UNFusion(_FusionModel):
+    '''UNFusion (reference core/model.py:386-436): four single-conv levels joined by stride-2 ConvLayers, the densely nested
+    NestEncoder (ECB blocks), 'wavg' attention fusion per level, the UNet++ NestDecoder (DCB blocks, bilinear up-sampling).
+    Layer by layer on the HIP conv / resample kernels.'''
+
+    def __init__(self, down_mode='stride', up_mode='bilinear'):
+        super(UNFusion, self).__init__()
+        enc_ch, dec_ch = [16, 32, 48, 64], [16, 64, 256, 1024]
+        self.CB1_0, self.CB2_0 = ConvLayer(1, enc_ch[0]), ConvLayer(enc_ch[0], enc_ch[1])
+        self.CB3_0, self.CB4_0 = ConvLayer(enc_ch[1], enc_ch[2]), ConvLayer(enc_ch[2], enc_ch[3])
+        if down_mode == 'maxpool':
+            self.down1, self.down2, self.down3 = nn.MaxPool2d(2, 2), nn.MaxPool2d(2, 2), nn.MaxPool2d(2, 2)
+        elif down_mode == 'stride':
+            self.down1 = ConvLayer(enc_ch[0], enc_ch[0], stride=2)
+            self.down2 = ConvLayer(enc_ch[1], enc_ch[1], stride=2)
+            self.down3 = ConvLayer(enc_ch[2], enc_ch[2], stride=2)
+        self.encode = NestEncoder(ECB, enc_ch, dec_ch, down_mode)
+        self.decode = NestDecoder(DCB, dec_ch, up_mode)
+        self.conv_out = ConvLayer(dec_ch[0], 1, ksize=1)
+
+    def encoder(self, img):
+        x1 = self.CB1_0(img)
+        d1 = self.down1(x1)
+        x2 = self.CB2_0(d1)
+        d2 = self.down2(x2)
+        x3 = self.CB3_0(d2)
+        d3 = self.down3(x3)
+        return self.encode((x1, (x2, d1), (x3, d2), (self.CB4_0(d3), d3)))
+
+    def fusion(self, feats1, feats2, mode='wavg'):
+        return tuple(attention_fusion(a, b, mode) for a, b in zip(feats1, feats2))
+
+    def decoder(self, feats):
+        return self.conv_out(self.decode(feats))
+
+
+class MAFusion(NestFuse):
+    '''MAFusion (reference core/model.py:473-508): NestFuse's encoder with wider levels and the full-scale skip FSDecoder
+    (bilinear x2 / x4 / x8, max-pool /2 and /4).'''
+
+    def __init__(self, down_mode='maxpool', up_mode='bilinear'):
+        super(MAFusion, self).__init__(down_mode, up_mode)
+        num_ch = [64, 128, 256, 512]
+        self.conv_in = ConvLayer(1, 16, ksize=1)
+        self.CB1_0 = ConvBlock(16, num_ch[0])
+        self.CB2_0 = ConvBlock(num_ch[0], num_ch[1])
+        self.CB3_0 = ConvBlock(num_ch[1], num_ch[2])
+        self.CB4_0 = ConvBlock(num_ch[2], num_ch[3])
+        if down_mode == 'maxpool':
+            self.down1, self.down2, self.down3 = nn.MaxPool2d(2, 2), nn.MaxPool2d(2, 2), nn.MaxPool2d(2, 2)
+        elif down_mode == 'stride':
+            self.down1 = ConvLayer(num_ch[0], num_ch[0], stride=2)
+            self.down2 = ConvLayer(num_ch[1], num_ch[1], stride=2)
+            self.down3 = ConvLayer(num_ch[2], num_ch[2], stride=2)
+        self.decode = FSDecoder(ConvBlock, num_ch, up_mode)
+        self.conv_out = ConvLayer(num_ch[0], 1, ksize=1)
+
+    def _make_engine(self):
+        self._engine_single = False
+        return None   # (the fused NestEngine is NestFuse / RFN-Nest's; MAFusion runs block by block)
 
 
 class IFCNN(_FusionModel):

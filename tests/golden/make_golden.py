@@ -25,6 +25,7 @@ GPU box.  Fixture map:
   f12_n4_models.npz / f12_manifest.json   bilinear Upsample (core/block.py:965-991) fwd + dx; DeepFuse, DBNet forward + gradient digests
   f13_n4_norm.npz / f13_manifest.json   ConvLayer with BatchNorm2d / GroupNorm + ReLU / LeakyReLU / Tanh (core/block.py:78-92): y, dx, parameter
                              gradients, running buffers; SEDRFuse, IFCNN, DIFNet, PMGI forward + gradient / buffer digests
+  f14_n4_nested.npz / f14_manifest.json   UNFusion, MAFusion forward + gradient digests
   f7_metric_ssim.json        core/metric.py:316-364 calc_ssim (the SSIM that test.py:49-52 reports) on closed-form images
 """
 import json
@@ -280,6 +281,24 @@ def make_f13():
     json.dump(manifest, open(os.path.join(HERE, "f13_manifest.json"), "w"), indent=0)
 
 
+# ---------------------------------------------------------------- F14 (row n4: UNFusion, MAFusion -- compositions of the primitives above)
+def make_f14():
+    out, manifest = {}, {}
+    for name, shapes in (("UNFusion", ((1, 1, 32, 32), (1, 1, 37, 53))), ("MAFusion", ((1, 1, 32, 32), (1, 1, 40, 24)))):
+        for shape in shapes:
+            tag = f"{name}_{shape[0]}x{shape[2]}x{shape[3]}"
+            model = load_closed_form(getattr(rmodel, name)(), seed=2)
+            manifest[name] = [[k, list(v.shape)] for k, v in model.state_dict().items()]
+            i1, i2 = T(closed_form_image(shape, 0.3)), T(closed_form_image(shape, 1.7))
+            y = model(i1, i2)
+            y.backward(T(closed_form_signed(tuple(y.shape), 0.9, 1.0)))
+            out[tag + "__y"] = y.detach().numpy()
+            for k, p in model.named_parameters():
+                out[f"{tag}__dp_{k}"] = digest(p.grad.numpy())
+    np.savez_compressed(os.path.join(HERE, "f14_n4_nested.npz"), **out)
+    json.dump(manifest, open(os.path.join(HERE, "f14_manifest.json"), "w"), indent=0)
+
+
 # ---------------------------------------------------------------- F4
 def run_module(mod, inputs, gout_phase):
     xs = [T(a).requires_grad_(True) for a in inputs]
@@ -504,7 +523,7 @@ def make_f9():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10", "f11", "f12", "f13"]
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10", "f11", "f12", "f13", "f14"]
     for w in which:
         globals()["make_" + w]()
         print("wrote", w)

@@ -197,3 +197,24 @@ def test_n4_norm_models_vs_golden(name, shape):
         close_digest(p.grad.cpu().numpy(), dg, 2e-3, k)   # (fp32 through several BatchNorms; max-fusion ties)
     for k, b in model.named_buffers():
         close_digest(b.detach().cpu().numpy().astype(np.float32), g[f"{tag}__buf_{k}"], 2e-4, k)
+
+
+N4C_MODELS = [("UNFusion", (1, 1, 32, 32)), ("UNFusion", (1, 1, 37, 53)), ("MAFusion", (1, 1, 32, 32)), ("MAFusion", (1, 1, 40, 24))]
+
+
+@pytest.mark.parametrize("name,shape", N4C_MODELS, ids=[f"{n}-{s[0]}x{s[2]}x{s[3]}" for n, s in N4C_MODELS])
+def test_n4_nested_models_vs_golden(name, shape):
+    """UNFusion (stride-2 ConvLayers, NestEncoder, 'wavg' fusion, bilinear NestDecoder) and MAFusion (FSDecoder: bilinear x2/x4/x8,
+    max-pool /2 /4) -- compositions of the n4 primitives -- against the reference, fp32, odd sizes included."""
+    import core.model as M
+    from gpu_util import close_digest, dtype_ctx
+    g = np.load(os.path.join(G, "f14_n4_nested.npz"))
+    tag = f"{name}_{shape[0]}x{shape[2]}x{shape[3]}"
+    with dtype_ctx("fp32"):
+        model = load_closed_form(getattr(M, name)(), 2).cuda()
+        i1, i2 = (torch.from_numpy(O.closed_form_image(shape, p)).cuda() for p in (0.3, 1.7))
+        y = model(i1, i2)
+        y.backward(torch.from_numpy(O.closed_form_signed(tuple(y.shape), 0.9, 1.0)).cuda())
+    close(y.detach().cpu().numpy(), g[tag + "__y"], 2e-4, "fused image")
+    for k, p in model.named_parameters():
+        close_digest(p.grad.cpu().numpy(), g[f"{tag}__dp_{k}"], 2e-3, k)
