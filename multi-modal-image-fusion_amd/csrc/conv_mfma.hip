@@ -39,6 +39,11 @@ static inline int pick_mf(int n_out) {
     const int fr = (n_out + 15) / 16;
     return fr <= 4 ? fr : 4;
 }
+// Order in which every 3x3 kernel of this file visits the taps: COLUMN-major -- (u, v) = (0,0), (1,0), (2,0), (0,1), ... -- so that
+// the three steps of one column offset v read the same six tile rows (conv_dma_kernel keeps them in registers: 6 instead of 12
+// operand fragments per column).  All kernels share the order, hence the summation order, hence stay bit-identical to each other.
+__host__ __device__ inline int visit_tap(int i, int ks) { return ks == 3 ? (i % 3) * 3 + i / 3 : i; }
+
 static inline int n_mblocks(int n_out) {
     const int fr = (n_out + 15) / 16, mf = pick_mf(n_out);
     return (fr + mf - 1) / mf;
@@ -392,10 +397,10 @@ __global__ __launch_bounds__(256, MF == 1 ? 4 : 2) void conv_mfma_kernel(TV tin,
             if (e < nkgp * MF * 16) s_w[e] = rw[i];
         }
         // k-group offset table: .x = byte offset into s_in, .y = byte offset into s_w
-        if (tid < nkgp) {
-            int tap = 0, cb = 0;
-            if (tid < nkg) { tap = tid / ncb; cb = tid % ncb; }
-            s_tab[tid] = make_int2((cb * PL + (tap / KS) * TP + (tap % KS)) * 16, tid * MF * 256);
+        if (tid < nkgp) {   // visit position tid -> (tap, channel block) and the weight plane (packed tap-major) that holds it
+            int tap = 0, cb = 0, plane = tid;
+            if (tid < nkg) { tap = visit_tap(tid / ncb, KS); cb = tid % ncb; plane = tap * ncb + cb; }
+            s_tab[tid] = make_int2((cb * PL + (tap / KS) * TP + (tap % KS)) * 16, plane * MF * 256);
         }
         TRACE_STAMP();    // chunk: LDS stores issued (includes the wait for the prefetched data)
         __syncthreads();
@@ -623,9 +628,9 @@ __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void conv_dma_kernel(TV 
     // k-group table of the ragged last chunk: .x = byte offset into the input tile, .y = byte offset into the weight slab
     if (tid < DW_PIECES) {
         const int kg = tid;
-        int tap = 0, cb = 0;
-        if (kg < 9 * ncb_last) { tap = kg / ncb_last; cb = kg % ncb_last; }
-        s_tab[1][kg] = make_int2((cb * DPL + (tap / 3) * DTP_X + (tap % 3)) * 16, kg * MF * 256);
+        int tap = 0, cb = 0, plane = kg;
+        if (kg < 9 * ncb_last) { tap = visit_tap(kg / ncb_last, 3); cb = kg % ncb_last; plane = tap * ncb_last + cb; }
+        s_tab[1][kg] = make_int2((cb * DPL + (tap / 3) * DTP_X + (tap % 3)) * 16, plane * MF * 256);
     }
 
     if (wave >= D_CONS) {
@@ -750,32 +755,60 @@ __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void conv_dma_kernel(TV 
             // sched_group_barrier: the 8 LDS reads ride on the first 8 MFMAs, the other 8 cover the last reads' latency)
             const char* in_g = in_lane + g * (DPL * 16);
             const char* w_g = w_lane + g * (MF * 256);
-            bf16x8 a[2][MF], b[2][4];
-            auto fetch = [&](int s2, int slot) {   // in the order the MFMAs consume them: a0, b0..b3, a1..a3
-                a[slot][0] = *reinterpret_cast<const bf16x8*>(w_g + s2 * 4 * MF * 256);
+            // Column-major tap order (visit_tap): the three steps of column offset v use tile rows u .. u+3 of the SAME six rows, so
+            // a row fragment is read from LDS once per column (18 instead of 36 gradient / activation fragments per chunk; the 36
+            // weight fragments stay).  rows[] is a ring of 8 fragments: row r of column v lives in slot (6 v + r) % 8 -- during step
+            // (v, 2) the four live rows and the next column's first four fill it exactly.  Weights are double buffered per step.
+            bf16x8 a[2][MF], rows[8];
+            auto ld_row = [&](int v, int r) { return *reinterpret_cast<const bf16x8*>(in_g + (r * DTP_X + v) * 16); };
+            auto ld_a = [&](int t, int slot) {
+                const int tap = (t % 3) * 3 + t / 3;
 #pragma unroll
-                for (int n = 0; n < 4; ++n)
-                    b[slot][n] = *reinterpret_cast<const bf16x8*>(in_g + ((s2 / 3) * DTP_X + (s2 % 3)) * 16 + n * DTP_X * 16);
-#pragma unroll
-                for (int m = 1; m < MF; ++m) a[slot][m] = *reinterpret_cast<const bf16x8*>(w_g + s2 * 4 * MF * 256 + m * 256);
+                for (int m = 0; m < MF; ++m) a[slot][m] = *reinterpret_cast<const bf16x8*>(w_g + tap * 4 * MF * 256 + m * 256);
             };
-            fetch(0, 0);
 #pragma unroll
-            for (int s2 = 0; s2 < 9; ++s2) {
-                if (s2 + 1 < 9) fetch(s2 + 1, (s2 + 1) & 1);
+            for (int r = 0; r < 4; ++r) rows[r] = ld_row(0, r);
+            ld_a(0, 0);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int v = t / 3, u = t % 3;
+                int nreads = 0;
+                if (t + 1 < 9) {   // operands of step t+1, in the order its MFMAs consume them
+                    const int v1 = (t + 1) / 3, u1 = (t + 1) % 3;
+                    if (u1 == 0) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) rows[(6 * v1 + r) % 8] = ld_row(v1, r);
+                        nreads += 4;
+                    } else {
+                        rows[(6 * v1 + 3 + u1) % 8] = ld_row(v1, 3 + u1);
+                        nreads += 1;
+                    }
+                    ld_a(t + 1, (t + 1) & 1);
+                    nreads += MF;
+                }
 #pragma unroll
                 for (int m = 0; m < MF; ++m)
 #pragma unroll
                     for (int n = 0; n < 4; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s2 & 1][m], b[s2 & 1][n], acc[m][n], 0, 0, 0);
-                if (s2 + 1 < 9) {
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t & 1][m], rows[(6 * v + u + n) % 8], acc[m][n], 0, 0, 0);
+                if (t + 1 < 9) {   // the LDS reads ride on the first MFMAs, the rest cover the last reads' latency
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) {
+                    for (int r = 0; r < 5; ++r) {
                         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
                     }
-                    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+                    if ((t + 1) % 3 == 0) {   // a new column: 4 + 4 reads
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) {
+                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        }
+                        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+                    } else {                  // 1 + 4 reads
+                        __builtin_amdgcn_sched_group_barrier(0x008, 11, 0);
+                    }
                 }
+                (void)nreads;
             }
         } else {
             const int nkgp = (9 * ncb + 3) / 4 * 4, nsteps = nkgp >> 2;
@@ -924,9 +957,9 @@ __global__ __launch_bounds__((4 * TN_GROUPS + TN_LOAD) * 64, 4) void thin_conv_a
         const int c = tid / 36, kg = tid % 36;
         const int ncb = min(CHUNK_CB, ncb_tot - c * CHUNK_CB);
         if (ncb > 0) {
-            int tap = 0, cb = 0;
-            if (kg < 9 * ncb) { tap = kg / ncb; cb = kg % ncb; }
-            s_tab[c][kg] = make_int2(((c * CHUNK_CB + cb) * TN_PL + (tap / 3) * TP + (tap % 3)) * 16, (c * 36 + kg) * MF * 256);
+            int tap = 0, cb = 0, plane = kg;
+            if (kg < 9 * ncb) { tap = visit_tap(kg / ncb, 3); cb = kg % ncb; plane = tap * ncb + cb; }
+            s_tab[c][kg] = make_int2(((c * CHUNK_CB + cb) * TN_PL + (tap / 3) * TP + (tap % 3)) * 16, (c * 36 + plane) * MF * 256);
         }
     }
     if (!DGRAD && tid < MF * 16) s_bias[tid] = (bias != nullptr && tid < n_out) ? bias[tid] : 0.f;
