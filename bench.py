@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--mode", default="train", choices=["train", "infer"],
                     help="infer = forward only under no_grad (test.py path; BASELINE config 5: --mode infer --batch 1 --size 1024 --width 1224)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--model", default="PFNetv1", choices=["PFNetv1", "PFNetv2", "DenseFuse", "VIFNet", "NestFuse", "RFNNest", "DeepFuse", "DBNet", "SEDRFuse", "IFCNN", "DIFNet", "PMGI", "UNFusion", "MAFusion"])
+    ap.add_argument("--model", default="PFNetv1", choices=["PFNetv1", "PFNetv2", "DenseFuse", "VIFNet", "NestFuse", "RFNNest", "DeepFuse", "DBNet", "SEDRFuse", "IFCNN", "DIFNet", "PMGI", "UNFusion", "MAFusion", "Res2Fusion"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true",
                     help="capture forward + losses + backward in ONE hipGraph and replay it per step (launch-bound small batches); "

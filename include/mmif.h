@@ -121,6 +121,13 @@ int mmif_gconvt_dgrad(const float* gy, const float* w, float* dx, int32_t n, int
 int mmif_gconvt_wgrad(const float* x, const float* gy, float* dw, float* db_scratch, int32_t n, int32_t cin, int32_t cout,
                       int32_t h, int32_t wd, int32_t ksize, int32_t stride, int32_t padding, int32_t output_padding,
                       void* workspace, size_t workspace_bytes, void* stream);
+/* depth-wise ConvLayer (groups == channels, Res2ConvBlock.dwconvs core/block.py:317-325): w [c][1][k][k], k in {1,3}, stride 1, padding k/2 */
+int mmif_dwconv_fwd(const float* x, const float* w, const float* bias, float* y, int32_t n, int32_t c, int32_t h, int32_t wd,
+                    int32_t ksize, int32_t reflect, void* stream);
+int mmif_dwconv_dgrad(const float* gy, const float* w, float* dx, int32_t n, int32_t c, int32_t h, int32_t wd, int32_t ksize,
+                      int32_t reflect, void* stream);
+int mmif_dwconv_wgrad(const float* x, const float* gy, float* dw, float* db, int32_t n, int32_t c, int32_t h, int32_t wd,
+                      int32_t ksize, int32_t reflect, void* stream);
 /* out = g * [y > 0] on plain fp32 arrays (ReLU backward of the layers above) */
 int mmif_relu_bwd(const float* g, const float* y, float* out, int64_t count, void* stream);
 /* out[c] = sum_{n, pixels} x[n][c][.] (deterministic; the bias gradient of a ConvTranspose2d) */
@@ -134,7 +141,7 @@ int mmif_bilinear_up_bwd(const float* g, float* dx, int64_t planes, int32_t h, i
 /* Norm + activation epilogue of ConvLayer (core/block.py:78-92) on plain NCHW fp32: y = act(gamma * (x - mean) * rstd + beta).
  * kind 0 = nn.BatchNorm2d in training mode (batch statistics; running_mean / running_var, when given, are updated with `momentum`
  * and the unbiased variance), 1 = nn.BatchNorm2d in eval mode (running buffers), 2 = nn.GroupNorm(c, c) (one group per channel:
- * per-(sample, channel) statistics; SEDRFuse core/model.py:249-260).  act: 0 none, 1 ReLU, 2 LeakyReLU(slope), 3 Tanh.
+ * per-(sample, channel) statistics; SEDRFuse core/model.py:249-260).  act: 0 none, 1 ReLU, 2 LeakyReLU(slope), 3 Tanh, 4 ReLU6.
  * stats receives (mean, rstd) per channel (kinds 0, 1: 2 c floats) or per plane (kind 2: 2 n c floats) for the backward pass.
  * Backward: dx, dgamma, dbeta (either may be NULL) from x, y (the forward's output), gy. */
 size_t mmif_norm_workspace(int32_t n, int32_t c);

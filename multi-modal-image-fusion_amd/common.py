@@ -18,7 +18,7 @@ __all__ = ['get_train_args', 'get_test_args', 'save_result', 'setup_seed', 'setu
 
 def _common_extra(parser):
     # additions of this engine (the reference hard-codes both by editing list indices in the script)
-    parser.add_argument('--model', default='PFNetv1', type=str, help='PFNetv1 | PFNetv2 | DenseFuse | VIFNet | NestFuse | RFNNest | DeepFuse | DBNet | SEDRFuse | IFCNN | DIFNet | PMGI | UNFusion | MAFusion')
+    parser.add_argument('--model', default='PFNetv1', type=str, help='PFNetv1 | PFNetv2 | DenseFuse | VIFNet | NestFuse | RFNNest | DeepFuse | DBNet | SEDRFuse | IFCNN | DIFNet | PMGI | UNFusion | MAFusion | Res2Fusion')
     parser.add_argument('--dtype', default='fp32', type=str, help='feature-map storage: fp32 (parity) | bf16 (throughput)')
     parser.add_argument('--synthetic', default=0, type=int, help='>0: train on this many synthetic random pairs (no dataset needed)')
     parser.add_argument('--graph', default=False, type=bool,

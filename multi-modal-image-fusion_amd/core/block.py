@@ -16,7 +16,7 @@ from mmif.tensor import BT
 
 from .fusion import concat_fusion, element_fusion
 
-__all__ = ['ConvLayer', 'ResBlock', 'DenseBlock', 'ConvBlock', 'ECB', 'DCB', 'RFN', 'NestEncoder', 'NestDecoder', 'FSDecoder', 'Downsample',
+__all__ = ['ConvLayer', 'ResBlock', 'DenseBlock', 'SepConvBlock', 'Res2ConvBlock', 'ConvBlock', 'ECB', 'DCB', 'RFN', 'NestEncoder', 'NestDecoder', 'FSDecoder', 'Downsample',
            'Upsample']
 
 
@@ -150,7 +150,27 @@ class _GConvTFn(torch.autograd.Function):
         return dx, dw, db, None, None, None, None
 
 
-_ACT_CODE = {None: T.ACT_NONE, nn.ReLU: T.ACT_RELU, nn.LeakyReLU: T.ACT_LEAKY, nn.Tanh: T.ACT_TANH}
+_ACT_CODE = {None: T.ACT_NONE, nn.ReLU: T.ACT_RELU, nn.LeakyReLU: T.ACT_LEAKY, nn.Tanh: T.ACT_TANH, nn.ReLU6: T.ACT_RELU6}
+
+
+class _DwConvFn(torch.autograd.Function):
+    """depth-wise nn.Conv2d (groups == channels, k in {1, 3}, stride 1) on csrc/conv_general.hip -- Res2ConvBlock.dwconvs"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, reflect):
+        T.require_device(x, "ConvLayer input")
+        xd, wd = x.detach().contiguous().float(), weight.detach().contiguous().float()
+        ctx.saved, ctx.meta = (xd, wd), (reflect, bias is not None)
+        return T.dwconv_fwd(xd, wd, bias.detach().contiguous().float() if bias is not None else None, reflect)
+
+    @staticmethod
+    def backward(ctx, gy):
+        xd, wd = ctx.saved
+        reflect, has_bias = ctx.meta
+        gy = gy.contiguous().float()
+        dw, db = T.dwconv_wgrad(xd, gy, wd.shape[2], reflect, has_bias)
+        dx = T.dwconv_dgrad(gy, wd, reflect) if ctx.needs_input_grad[0] else None
+        return dx, dw, db, None
 
 
 class _NormActFn(torch.autograd.Function):
@@ -231,10 +251,13 @@ class ConvLayer(nn.Module):
         self.norm, self.pre_norm, self.act = norm, pre_norm, act
         # the HIP kernels cover exactly what the hot-path models use
         # what follows the conv: nothing / ReLU fused into the conv kernels, or a norm (+ act) / other activation epilogue kernel
-        epi_ok = (pre_norm is None and norm in (None, nn.BatchNorm2d, nn.GroupNorm) and act in _ACT_CODE and dilation == 1 and groups == 1)
-        self._epilogue = epi_ok and (norm is not None or act in (nn.LeakyReLU, nn.Tanh))
+        depthwise = groups > 1 and groups == in_ch == out_ch and layer is nn.Conv2d and stride == 1 and ksize in (1, 3) and padding == ksize // 2
+        epi_ok = (pre_norm is None and norm in (None, nn.BatchNorm2d, nn.GroupNorm) and act in _ACT_CODE and dilation == 1
+                  and (groups == 1 or depthwise))
+        self._epilogue = epi_ok and (norm is not None or act in (nn.LeakyReLU, nn.Tanh, nn.ReLU6) or depthwise)
+        self._depthwise = depthwise
         plain = epi_ok and not self._epilogue
-        geom_hot = (layer is nn.Conv2d and stride == 1 and ksize in (1, 3) and padding == ksize // 2
+        geom_hot = (layer is nn.Conv2d and stride == 1 and ksize in (1, 3) and padding == ksize // 2 and not depthwise
                     and (padding_mode == 'reflect' or ksize == 1) and bias
                     and max(in_ch, out_ch) <= 512)   # (a blocked-layout view holds at most 64 channel blocks: wider layers -- UNFusion's
                                                      # 1024-channel level, MAFusion's 960-channel concats -- take the general kernels)
@@ -244,12 +267,14 @@ class ConvLayer(nn.Module):
         self._hip = plain and geom_hot                       # hot-path kernels, ReLU fused
         self._gen = plain and not geom_hot and geom_gen      # general kernels, ReLU fused
         self._conv_hot = geom_hot                            # (which conv kernels an epilogue layer uses)
-        self._epilogue = self._epilogue and (geom_hot or geom_gen)
+        self._epilogue = self._epilogue and (geom_hot or geom_gen or depthwise)
         self._geom = (stride, padding, padding_mode == 'reflect' and padding > 0)
         self._init_weights()
 
     def _conv(self, x, relu):
         conv = self.layers[0]
+        if self._depthwise:
+            return _DwConvFn.apply(x, conv.weight, conv.bias, self._geom[2])
         if self._conv_hot:
             return _ConvLayerFn.apply(x, conv.weight, conv.bias, relu)
         stride, padding, reflect = self._geom
@@ -263,7 +288,7 @@ class ConvLayer(nn.Module):
         if self._epilogue:
             z = self._conv(x, False)
             if self.norm is None:
-                return _ActFn.apply(z, _ACT_CODE[self.act])
+                return z if self.act is None else _ActFn.apply(z, _ACT_CODE[self.act])
             mod = self.layers[1]
             return _NormActFn.apply(z, mod.weight, mod.bias, mod, _ACT_CODE[self.act])
         # argument combinations outside these (pre_norm, other norms / activations, dilation, groups)
@@ -296,6 +321,63 @@ class ResBlock(nn.Module):
 
     def forward(self, x):
         return element_fusion(self.layers(x), x, 'sum')
+
+
+class SepConvBlock(nn.Module):
+    """reference core/block.py:153-226: point-wise expand (x scale) -> depth-wise k x k -> point-wise project, optional point-wise
+    attention gate and (projected) residual, activation at the end.  Base of Res2ConvBlock."""
+
+    def __init__(self, in_ch, out_ch, scale=4, ksize=3, bias=False, norm=None, act=nn.ReLU6, residual=True, attention=False):
+        super(SepConvBlock, self).__init__()
+        self.norm, self.act, self.residual, self.attention = norm, act(), residual, attention
+        self._act_code = _ACT_CODE.get(act)
+        self.in_ch, self.out_ch, self.scale = in_ch, out_ch, scale
+        hid_ch = in_ch * scale
+        self.pwconv1 = ConvLayer(in_ch, hid_ch, ksize=1, bias=bias, norm=norm, act=act)
+        self.dwconv = ConvLayer(hid_ch, hid_ch, ksize=ksize, groups=hid_ch, bias=bias, norm=norm, act=None)
+        self.pwconv2 = ConvLayer(hid_ch, out_ch, ksize=1, bias=bias, norm=norm, act=None)
+        if attention:
+            self.pwconv = ConvLayer(in_ch, hid_ch, ksize=1, bias=bias, norm=norm, act=act)
+        if residual:
+            self.shortcut = ConvLayer(in_ch, out_ch, ksize=1, bias=bias, norm=norm, act=None) if in_ch != out_ch else nn.Identity()
+
+    def _mix(self, x):
+        return self.dwconv(self.pwconv1(x))
+
+    def _finish(self, out):
+        return _ActFn.apply(out, self._act_code) if (self._act_code is not None and out.is_cuda) else self.act(out)
+
+    def forward(self, x):
+        out = self._mix(x)
+        if self.attention:
+            out = out * self.pwconv(x)
+        out = self.pwconv2(out)
+        if self.residual:
+            out = element_fusion(out, self.shortcut(x), 'sum')
+        return self._finish(out)
+
+
+class Res2ConvBlock(SepConvBlock):
+    """reference core/block.py:286-350 (Res2Fusion): the expanded features are split into `scale` groups of in_ch channels that go
+    through depth-wise convs hierarchically -- group i adds the previous group's output (from the third group on) before its own
+    depth-wise conv (1x1 for the first group, 3x3 after) -- and are concatenated again."""
+
+    def __init__(self, in_ch, out_ch, scale=4, bias=False, norm=None, act=nn.ReLU6, residual=True, attention=False):
+        super(Res2ConvBlock, self).__init__(in_ch, out_ch, scale=scale, bias=bias, norm=norm, act=act, residual=residual, attention=attention)
+        width = in_ch
+        self.dwconvs = nn.ModuleList([ConvLayer(width, width, ksize=3 if i > 0 else 1, groups=width, bias=bias, norm=norm, act=None)
+                                      for i in range(scale)])
+
+    def _mix(self, x):
+        xs = torch.chunk(self.pwconv1(x), self.scale, dim=1)
+        if self.scale == 1:
+            return self.dwconvs[0](xs[0])
+        outs, y = [], None
+        for i in range(self.scale):
+            y = element_fusion(y, xs[i].contiguous(), 'sum') if i > 1 else xs[i]   # (reference: `y + xs[i] if i > 1 else xs[i]`)
+            y = self.dwconvs[i](y)
+            outs.append(y)
+        return concat_fusion(outs)
 
 
 class DenseBlock(nn.Module):

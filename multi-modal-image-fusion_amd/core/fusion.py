@@ -84,6 +84,22 @@ def concat_fusion(tensors, dim=1):
     return torch.cat(tensors, dim)
 
 
+def _nonlocal(t, spatial):
+    """Res2Fusion's non-local attention maps (reference core/fusion.py:96-113 spatial, :137-150 channel): softmax over a min-max
+    normalised energy, applied to the features, plus the identity.  Tensor-level composition (two batched matmuls)."""
+    b, c, h, w = t.shape
+    flat = t.reshape(b, c, -1)
+    if spatial:   # queries: every pixel; keys / values: the 8x8 average-pooled map
+        pooled = torch.nn.functional.avg_pool2d(t, 8, 8).reshape(b, c, -1)
+        q, k, v = flat.permute(0, 2, 1), pooled, pooled.permute(0, 2, 1)
+    else:         # channel x channel
+        q, k, v = flat, flat.permute(0, 2, 1), flat
+    energy = q @ k
+    lo, hi = torch.min(energy), torch.max(energy)
+    attn = torch.softmax((energy - lo) / (hi - lo), dim=-1) @ v
+    return (attn.permute(0, 2, 1) if spatial else attn).reshape(b, c, h, w) + t
+
+
 def spatial_pooling(tensor, mode='l1'):
     if mode == 'sum':
         return tensor.sum(dim=1, keepdim=True)
@@ -96,7 +112,7 @@ def spatial_pooling(tensor, mode='l1'):
     if mode == 'linf':
         return tensor.max(dim=1, keepdim=True)[0]
     if mode == 'nl':
-        raise NotImplementedError("spatial_pooling('nl') is outside the accelerated hot path")
+        return _nonlocal(tensor, spatial=True)
     raise ValueError("only supported ['sum', 'mean', 'l1', 'l2', 'linf', 'nl'] mode")
 
 
@@ -105,8 +121,10 @@ def channel_pooling(tensor, mode='avg'):
         return tensor.mean(dim=(2, 3), keepdim=True)
     if mode == 'max':
         return tensor.amax(dim=(2, 3), keepdim=True)
-    if mode in ('nuclear', 'nl'):
-        raise NotImplementedError(f"channel_pooling('{mode}') is outside the accelerated hot path")
+    if mode == 'nl':
+        return _nonlocal(tensor, spatial=False)
+    if mode == 'nuclear':
+        raise NotImplementedError("channel_pooling('nuclear') is outside the accelerated hot path")
     raise ValueError("only supported ['avg', 'max', 'nuclear', 'nl'] mode")
 
 

@@ -12,7 +12,7 @@ from mmif import engine as E
 from .block import *
 from .fusion import *
 
-__all__ = ['PFNetv1', 'PFNetv2', 'DeepFuse', 'DenseFuse', 'VIFNet', 'DBNet', 'SEDRFuse', 'NestFuse', 'RFNNest', 'UNFusion', 'MAFusion',
+__all__ = ['PFNetv1', 'PFNetv2', 'DeepFuse', 'DenseFuse', 'VIFNet', 'DBNet', 'SEDRFuse', 'NestFuse', 'RFNNest', 'UNFusion', 'Res2Fusion', 'MAFusion',
            'IFCNN', 'DIFNet', 'PMGI']
 
 
@@ -306,6 +306,31 @@ class UNFusion(_FusionModel):
 
     def decoder(self, feats):
         return self.conv_out(self.decode(feats))
+
+
+class Res2Fusion(_FusionModel):
+    '''Res2Fusion (reference core/model.py:439-470): a dense encoder of Res2ConvBlocks (point-wise + hierarchical depth-wise convs,
+    ReLU6) and double non-local attention fusion.  Convs, depth-wise convs and activations on the HIP kernels; the non-local
+    attention maps are tensor-level compositions (batched matmuls).'''
+
+    def __init__(self):
+        super(Res2Fusion, self).__init__()
+        self.conv_in = ConvLayer(1, 16)
+        self.RB1 = Res2ConvBlock(16, 32, 4)
+        self.RB2 = Res2ConvBlock(48, 64, 8)
+        self.decode = nn.Sequential(ConvLayer(112, 64), ConvLayer(64, 32), ConvLayer(32, 16), ConvLayer(16, 1))
+
+    def encoder(self, img):
+        x = self.conv_in(img)
+        x = concat_fusion((x, self.RB1(x)))
+        return concat_fusion((x, self.RB2(x)))
+
+    def fusion(self, feat1, feat2, mode='attn', spatial='nl', channel='nl'):
+        if mode == 'elem':
+            return element_fusion(feat1, feat2, 'mean')
+        elif mode == 'attn':
+            return attention_fusion(feat1, feat2, 'sca', spatial, channel)
+        raise ValueError("only supported ['elem', 'attn'] mode")
 
 
 class MAFusion(NestFuse):

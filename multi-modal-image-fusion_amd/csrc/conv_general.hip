@@ -289,6 +289,85 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
     if (threadIdx.x == 0) out[ch] = t;
 }
 
+// ------------------------------------------------------------------ depth-wise conv (groups == channels), k in {1, 3}, stride 1, reflect | zero padding
+// (Res2Fusion's Res2ConvBlock.dwconvs, reference core/block.py:317-325: ConvLayer(width, width, ksize, groups=width, bias=False, act=None))
+__global__ void dwconv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y,
+                                  long long planes, int c, int h, int wd, int k, int reflect) {
+    const int p = k / 2, kk = k * k;
+    const long long total = planes * h * wd;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int xx = (int)(i % wd), yy = (int)((i / wd) % h);
+        const long long plane = i / ((long long)h * wd);
+        const int ch = (int)(plane % c);
+        const float* pl = x + plane * h * wd;
+        float r = bias != nullptr ? bias[ch] : 0.f;
+        for (int u = 0; u < k; ++u)
+            for (int v = 0; v < k; ++v) r = fmaf(w[ch * kk + u * k + v], gx_load(pl, h, wd, yy + u - p, xx + v - p, reflect), r);
+        y[i] = r;
+    }
+}
+
+// dx[y][x] = sum over the reflect images (iy, ix) of (y, x) in the padded domain of sum_{u,v} w[u][v] g[iy - u + p][ix - v + p]
+__global__ void dwconv_dgrad_kernel(const float* __restrict__ g, const float* __restrict__ w, float* __restrict__ dx, long long planes, int c, int h,
+                                    int wd, int k, int reflect) {
+    const int p = k / 2, kk = k * k;
+    const long long total = planes * h * wd;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % wd), y = (int)((i / wd) % h);
+        const long long plane = i / ((long long)h * wd);
+        const float* wc = w + (plane % c) * kk;
+        const float* pl = g + plane * h * wd;
+        int ys[3], xs[3], ny = 0, nx = 0;   // padded-domain coordinates minus p (i.e. logical, may be < 0 or >= h)
+        ys[ny++] = y;
+        xs[nx++] = x;
+        if (reflect && p > 0) {
+            if (y >= 1 && y <= p) ys[ny++] = -y;
+            if (y <= h - 2 && y >= h - 1 - p) ys[ny++] = 2 * (h - 1) - y;
+            if (x >= 1 && x <= p) xs[nx++] = -x;
+            if (x <= wd - 2 && x >= wd - 1 - p) xs[nx++] = 2 * (wd - 1) - x;
+        }
+        float s = 0.f;
+        for (int a = 0; a < ny; ++a)
+            for (int b = 0; b < nx; ++b)
+                for (int u = 0; u < k; ++u) {
+                    const int oy = ys[a] + p - u;
+                    if (oy < 0 || oy >= h) continue;
+                    for (int v = 0; v < k; ++v) {
+                        const int ox = xs[b] + p - v;
+                        if (ox >= 0 && ox < wd) s = fmaf(wc[u * k + v], pl[(long long)oy * wd + ox], s);
+                    }
+                }
+        dx[i] = s;
+    }
+}
+
+// one block per channel: dw[c][tap] = sum_{n, pixels} g * xpad(shifted), db[c] = sum g   (fixed order)
+__global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ dw,
+                                                           float* __restrict__ db, int n, int c, int h, int wd, int k, int reflect) {
+    __shared__ float red[16];
+    const int ch = blockIdx.x, p = k / 2, kk = k * k;
+    float acc[9], accb = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+    const long long hw = (long long)h * wd;
+    for (int in_ = 0; in_ < n; ++in_) {
+        const float* xp = x + ((long long)in_ * c + ch) * hw;
+        const float* gp = g + ((long long)in_ * c + ch) * hw;
+        for (long long i = threadIdx.x; i < hw; i += 256) {
+            const int xx = (int)(i % wd), yy = (int)(i / wd);
+            const float gv = gp[i];
+            accb += gv;
+            for (int t = 0; t < kk; ++t) acc[t] = fmaf(gv, gx_load(xp, h, wd, yy + t / k - p, xx + t % k - p, reflect), acc[t]);
+        }
+    }
+    for (int t = 0; t < kk; ++t) {
+        const float s = block_sum(acc[t], red);
+        if (threadIdx.x == 0) dw[ch * kk + t] = s;
+    }
+    const float s = block_sum(accb, red);
+    if (threadIdx.x == 0 && db != nullptr) db[ch] = s;
+}
+
 static int grid1d(long long total) {
     long long b = (total + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 65535 * 16 ? 65535 * 16 : b));
@@ -443,4 +522,32 @@ extern "C" int mmif_channel_sum(const float* x, float* out, int32_t n, int32_t c
     MMIF_REQUIRE(x != nullptr && out != nullptr && n > 0 && c > 0 && hw > 0, "channel_sum: bad arguments");
     hipLaunchKernelGGL(channel_sum_kernel, dim3(c), dim3(256), 0, (hipStream_t)stream, x, out, n, c, (long long)hw);
     return check_launch("channel_sum");
+}
+
+// ---- depth-wise ConvLayer (groups == channels): x, y [n][c][h][w]; w [c][1][k][k]; k in {1, 3}, stride 1, padding k/2 ----
+extern "C" int mmif_dwconv_fwd(const float* x, const float* w, const float* bias, float* y, int32_t n, int32_t c, int32_t h, int32_t wd,
+                               int32_t ksize, int32_t reflect, void* stream) {
+    MMIF_REQUIRE(x != nullptr && w != nullptr && y != nullptr && n > 0 && c > 0 && h > 0 && wd > 0, "dwconv_fwd: bad arguments");
+    MMIF_REQUIRE(ksize == 1 || ksize == 3, "dwconv_fwd: ksize must be 1 or 3 (got %d)", ksize);
+    MMIF_REQUIRE(!reflect || ksize == 1 || (h >= 2 && wd >= 2), "dwconv_fwd: reflect padding needs h,w >= 2");
+    hipLaunchKernelGGL(dwconv_fwd_kernel, dim3(grid1d((long long)n * c * h * wd)), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, (long long)n * c,
+                       c, h, wd, ksize, reflect);
+    return check_launch("dwconv_fwd");
+}
+
+extern "C" int mmif_dwconv_dgrad(const float* gy, const float* w, float* dx, int32_t n, int32_t c, int32_t h, int32_t wd, int32_t ksize,
+                                 int32_t reflect, void* stream) {
+    MMIF_REQUIRE(gy != nullptr && w != nullptr && dx != nullptr && n > 0 && c > 0 && h > 0 && wd > 0, "dwconv_dgrad: bad arguments");
+    MMIF_REQUIRE(ksize == 1 || ksize == 3, "dwconv_dgrad: ksize must be 1 or 3 (got %d)", ksize);
+    hipLaunchKernelGGL(dwconv_dgrad_kernel, dim3(grid1d((long long)n * c * h * wd)), dim3(256), 0, (hipStream_t)stream, gy, w, dx, (long long)n * c,
+                       c, h, wd, ksize, reflect);
+    return check_launch("dwconv_dgrad");
+}
+
+extern "C" int mmif_dwconv_wgrad(const float* x, const float* gy, float* dw, float* db, int32_t n, int32_t c, int32_t h, int32_t wd, int32_t ksize,
+                                 int32_t reflect, void* stream) {
+    MMIF_REQUIRE(x != nullptr && gy != nullptr && dw != nullptr && n > 0 && c > 0 && h > 0 && wd > 0, "dwconv_wgrad: bad arguments");
+    MMIF_REQUIRE(ksize == 1 || ksize == 3, "dwconv_wgrad: ksize must be 1 or 3 (got %d)", ksize);
+    hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3(c), dim3(256), 0, (hipStream_t)stream, x, gy, dw, db, n, c, h, wd, ksize, reflect);
+    return check_launch("dwconv_wgrad");
 }

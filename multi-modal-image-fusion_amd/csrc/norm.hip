@@ -9,7 +9,7 @@
 //   norm_bwd_sums_kernel  per plane: sum dz, sum dz * xhat   with dz = gy * act'(y)            (fp64)
 //   norm_bwd_finish       per channel: dgamma = sum_n sum dz xhat, dbeta = sum_n sum dz (+ the per-statistics sums of BatchNorm)
 //   norm_act_bwd_kernel   dx = gamma rstd (dz - mean(dz) - xhat mean(dz xhat))   (train) | gamma rstd dz (eval BatchNorm)
-// act codes: 0 none, 1 ReLU, 2 LeakyReLU(slope), 3 Tanh -- every derivative is a function of the OUTPUT y, so only x and y are kept.
+// act codes: 0 none, 1 ReLU, 2 LeakyReLU(slope), 3 Tanh, 4 ReLU6 -- every derivative is a function of the OUTPUT y, so only x and y are kept.
 #include <math.h>
 
 #include "common.hpp"
@@ -35,12 +35,14 @@ __device__ inline float act_fwd(float z, int act, float slope) {
     if (act == 1) return fmaxf(z, 0.f);
     if (act == 2) return z > 0.f ? z : z * slope;
     if (act == 3) return tanhf(z);
+    if (act == 4) return fminf(fmaxf(z, 0.f), 6.f);
     return z;
 }
 __device__ inline float act_dydz(float y, int act, float slope) {
     if (act == 1) return y > 0.f ? 1.f : 0.f;
     if (act == 2) return y > 0.f ? 1.f : slope;
     if (act == 3) return 1.f - y * y;
+    if (act == 4) return (y > 0.f && y < 6.f) ? 1.f : 0.f;   // hardtanh_backward: zero at and beyond both bounds
     return 1.f;
 }
 
@@ -190,7 +192,7 @@ extern "C" int mmif_norm_act_fwd(const float* x, const float* gamma, const float
                                  float* running_var, int32_t n, int32_t c, int64_t hw, int32_t kind, float eps, float momentum, int32_t act,
                                  float slope, void* workspace, size_t workspace_bytes, void* stream) {
     MMIF_REQUIRE(x != nullptr && y != nullptr && stats != nullptr && n > 0 && c > 0 && hw > 0, "norm_act_fwd: bad arguments");
-    MMIF_REQUIRE(kind >= 0 && kind <= 2 && act >= 0 && act <= 3, "norm_act_fwd: bad kind / activation");
+    MMIF_REQUIRE(kind >= 0 && kind <= 2 && act >= 0 && act <= 4, "norm_act_fwd: bad kind / activation");
     MMIF_REQUIRE(kind != 1 || (running_mean != nullptr && running_var != nullptr), "norm_act_fwd: eval mode needs the running statistics");
     if (kind != 1 && (workspace == nullptr || workspace_bytes < mmif_norm_workspace(n, c))) {
         set_error("norm_act_fwd: workspace too small");
@@ -219,7 +221,7 @@ extern "C" int mmif_norm_act_bwd(const float* x, const float* y, const float* gy
                                  size_t workspace_bytes, void* stream) {
     MMIF_REQUIRE(x != nullptr && y != nullptr && gy != nullptr && stats != nullptr && dx != nullptr && n > 0 && c > 0 && hw > 0,
                  "norm_act_bwd: bad arguments");
-    MMIF_REQUIRE(kind >= 0 && kind <= 2 && act >= 0 && act <= 3, "norm_act_bwd: bad kind / activation");
+    MMIF_REQUIRE(kind >= 0 && kind <= 2 && act >= 0 && act <= 4, "norm_act_bwd: bad kind / activation");
     if (workspace == nullptr || workspace_bytes < mmif_norm_workspace(n, c)) {
         set_error("norm_act_bwd: workspace too small");
         return MMIF_EWORKSPACE;
@@ -238,14 +240,14 @@ extern "C" int mmif_norm_act_bwd(const float* x, const float* y, const float* gy
 }
 
 extern "C" int mmif_act_fwd(const float* x, float* y, int64_t count, int32_t act, float slope, void* stream) {
-    MMIF_REQUIRE(x != nullptr && y != nullptr && count >= 0 && act >= 0 && act <= 3, "act_fwd: bad arguments");
+    MMIF_REQUIRE(x != nullptr && y != nullptr && count >= 0 && act >= 0 && act <= 4, "act_fwd: bad arguments");
     if (count == 0) return MMIF_OK;
     hipLaunchKernelGGL(act_fwd_kernel, dim3(grid1d_n(count)), dim3(256), 0, (hipStream_t)stream, x, y, (long long)count, act, slope);
     return check_launch("act_fwd");
 }
 
 extern "C" int mmif_act_bwd(const float* gy, const float* y, float* dx, int64_t count, int32_t act, float slope, void* stream) {
-    MMIF_REQUIRE(gy != nullptr && y != nullptr && dx != nullptr && count >= 0 && act >= 0 && act <= 3, "act_bwd: bad arguments");
+    MMIF_REQUIRE(gy != nullptr && y != nullptr && dx != nullptr && count >= 0 && act >= 0 && act <= 4, "act_bwd: bad arguments");
     if (count == 0) return MMIF_OK;
     hipLaunchKernelGGL(act_bwd_kernel, dim3(grid1d_n(count)), dim3(256), 0, (hipStream_t)stream, gy, y, dx, (long long)count, act, slope);
     return check_launch("act_bwd");

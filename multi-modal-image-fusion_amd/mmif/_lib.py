@@ -66,6 +66,9 @@ SIGNATURES = {
     "mmif_gconvt_dgrad": (_i32, [_vp, _vp, _vp] + [_i32] * 9 + [_vp]),
     "mmif_gconvt_wgrad": (_i32, [_vp, _vp, _vp, _vp] + [_i32] * 9 + [_vp, _sz, _vp]),
     "mmif_relu_bwd": (_i32, [_vp, _vp, _vp, _i64, _vp]),
+    "mmif_dwconv_fwd": (_i32, [_vp, _vp, _vp, _vp] + [_i32] * 6 + [_vp]),
+    "mmif_dwconv_dgrad": (_i32, [_vp, _vp, _vp] + [_i32] * 6 + [_vp]),
+    "mmif_dwconv_wgrad": (_i32, [_vp, _vp, _vp, _vp] + [_i32] * 6 + [_vp]),
     "mmif_channel_sum": (_i32, [_vp, _vp, _i32, _i32, _i64, _vp]),
     "mmif_bilinear_up_fwd": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     "mmif_bilinear_up_bwd": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),

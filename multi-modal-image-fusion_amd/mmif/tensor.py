@@ -367,7 +367,7 @@ def bilinear_up_bwd(g, in_hw):
 
 # ------------------------------------------------------------------ norm + activation epilogues (row n4)
 NORM_BN_TRAIN, NORM_BN_EVAL, NORM_GN = 0, 1, 2
-ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_TANH = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_TANH, ACT_RELU6 = 0, 1, 2, 3, 4
 
 
 def _norm_ws(n, c, dev):
@@ -412,3 +412,29 @@ def act_bwd(gy, y, act, slope=0.2):
     dx = torch.empty_like(gy)
     check(lib.mmif_act_bwd(_ptr(gy), _ptr(y), _ptr(dx), gy.numel(), act, float(slope), stream_ptr()), "act_bwd")
     return dx
+
+
+# ------------------------------------------------------------------ depth-wise conv (groups == channels)
+def dwconv_fwd(x, w, bias, reflect):
+    _f32c(x, "x"), _f32c(w, "weight")
+    n, c, h, wd = x.shape
+    y = torch.empty_like(x)
+    check(lib.mmif_dwconv_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), n, c, h, wd, w.shape[2], int(reflect), stream_ptr()), "dwconv_fwd")
+    return y
+
+
+def dwconv_dgrad(gy, w, reflect):
+    _f32c(gy, "gy"), _f32c(w, "weight")
+    n, c, h, wd = gy.shape
+    dx = torch.empty_like(gy)
+    check(lib.mmif_dwconv_dgrad(_ptr(gy), _ptr(w), _ptr(dx), n, c, h, wd, w.shape[2], int(reflect), stream_ptr()), "dwconv_dgrad")
+    return dx
+
+
+def dwconv_wgrad(x, gy, k, reflect, want_bias):
+    _f32c(x, "x"), _f32c(gy, "gy")
+    n, c, h, wd = x.shape
+    dw = torch.empty((c, 1, k, k), dtype=torch.float32, device=x.device)
+    db = torch.empty(c, dtype=torch.float32, device=x.device) if want_bias else None
+    check(lib.mmif_dwconv_wgrad(_ptr(x), _ptr(gy), _ptr(dw), _ptr(db), n, c, h, wd, k, int(reflect), stream_ptr()), "dwconv_wgrad")
+    return dw, db

@@ -47,7 +47,7 @@ if __name__ == '__main__':
     device = torch.device('cuda', 0)
     E.set_compute_dtype(args.dtype)
     model = {'PFNetv1': PFNetv1, 'PFNetv2': PFNetv2, 'DenseFuse': DenseFuse, 'VIFNet': VIFNet, 'NestFuse': NestFuse, 'RFNNest': RFNNest,
-             'DeepFuse': DeepFuse, 'DBNet': DBNet, 'SEDRFuse': SEDRFuse, 'IFCNN': IFCNN, 'DIFNet': DIFNet, 'PMGI': PMGI, 'UNFusion': UNFusion, 'MAFusion': MAFusion}[args.model]().to(device)
+             'DeepFuse': DeepFuse, 'DBNet': DBNet, 'SEDRFuse': SEDRFuse, 'IFCNN': IFCNN, 'DIFNet': DIFNet, 'PMGI': PMGI, 'UNFusion': UNFusion, 'MAFusion': MAFusion, 'Res2Fusion': Res2Fusion}[args.model]().to(device)
     if args.ckpt is not None:
         ckpt = os.path.join(BASE_DIR, '..', 'checkpoints', args.ckpt, 'epoch_best.pth')
         assert os.path.isfile(ckpt), f'{ckpt} is not a file'

@@ -169,7 +169,7 @@ if __name__ == '__main__':
     train_loader, valid_loader, train_sampler = make_loaders()
 
     model = {'PFNetv1': PFNetv1, 'PFNetv2': PFNetv2, 'DenseFuse': DenseFuse, 'VIFNet': VIFNet, 'NestFuse': NestFuse, 'RFNNest': RFNNest,
-             'DeepFuse': DeepFuse, 'DBNet': DBNet, 'SEDRFuse': SEDRFuse, 'IFCNN': IFCNN, 'DIFNet': DIFNet, 'PMGI': PMGI, 'UNFusion': UNFusion, 'MAFusion': MAFusion}[args.model]().to(device)
+             'DeepFuse': DeepFuse, 'DBNet': DBNet, 'SEDRFuse': SEDRFuse, 'IFCNN': IFCNN, 'DIFNet': DIFNet, 'PMGI': PMGI, 'UNFusion': UNFusion, 'MAFusion': MAFusion, 'Res2Fusion': Res2Fusion}[args.model]().to(device)
     if is_distributed:
         broadcast_parameters(model, 0)  # replaces the reference's init_weights.pth + DDP constructor broadcast
 

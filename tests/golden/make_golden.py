@@ -26,6 +26,7 @@ GPU box.  Fixture map:
   f13_n4_norm.npz / f13_manifest.json   ConvLayer with BatchNorm2d / GroupNorm + ReLU / LeakyReLU / Tanh (core/block.py:78-92): y, dx, parameter
                              gradients, running buffers; SEDRFuse, IFCNN, DIFNet, PMGI forward + gradient / buffer digests
   f14_n4_nested.npz / f14_manifest.json   UNFusion, MAFusion forward + gradient digests
+  f15_n4_res2.npz / f15_manifest.json   depth-wise ConvLayer, ReLU6, Res2ConvBlock (core/block.py:286-350), Res2Fusion
   f7_metric_ssim.json        core/metric.py:316-364 calc_ssim (the SSIM that test.py:49-52 reports) on closed-form images
 """
 import json
@@ -299,6 +300,44 @@ def make_f14():
     json.dump(manifest, open(os.path.join(HERE, "f14_manifest.json"), "w"), indent=0)
 
 
+# ---------------------------------------------------------------- F15 (row n4: depth-wise ConvLayer, ReLU6, Res2ConvBlock, Res2Fusion)
+def make_f15():
+    out, manifest = {}, {}
+    for name, kw, shape in (("dw_k3", dict(in_ch=16, out_ch=16, ksize=3, groups=16, bias=False, act=None), (2, 16, 9, 11)),
+                            ("dw_k1", dict(in_ch=24, out_ch=24, ksize=1, groups=24, bias=False, act=None), (1, 24, 5, 6)),
+                            ("dw_k3_bias", dict(in_ch=8, out_ch=8, ksize=3, groups=8, act=None), (2, 8, 2, 7)),
+                            ("relu6_k1", dict(in_ch=16, out_ch=64, ksize=1, bias=False, act=nn.ReLU6), (2, 16, 6, 7))):
+        layer = rblock.ConvLayer(**kw)
+        load_closed_form(layer, seed=15)
+        x = T(closed_form_signed(shape, 0.5, 8.0 if name == "relu6_k1" else 1.0)).requires_grad_(True)
+        y = layer(x)
+        y.backward(T(closed_form_signed(tuple(y.shape), 1.5, 1.0)))
+        out[name + "_y"], out[name + "_dx"] = y.detach().numpy(), x.grad.numpy()
+        for kname, p in layer.named_parameters():
+            out[f"{name}_dp_{kname}"] = p.grad.numpy()
+    blk = load_closed_form(rblock.Res2ConvBlock(16, 32, 4), seed=15)
+    x = T(closed_form_signed((2, 16, 10, 12), 0.5, 1.0)).requires_grad_(True)
+    y = blk(x)
+    y.backward(T(closed_form_signed(tuple(y.shape), 1.5, 1.0)))
+    out["res2block_y"], out["res2block_dx"] = y.detach().numpy(), x.grad.numpy()
+    for kname, p in blk.named_parameters():
+        if p.grad is not None:
+            out[f"res2block_dp_{kname}"] = p.grad.numpy()
+    for shape in ((1, 1, 32, 32), (2, 1, 24, 40)):
+        tag = f"Res2Fusion_{shape[0]}x{shape[2]}x{shape[3]}"
+        model = load_closed_form(rmodel.Res2Fusion(), seed=2)
+        manifest["Res2Fusion"] = [[k, list(v.shape)] for k, v in model.state_dict().items()]
+        i1, i2 = T(closed_form_image(shape, 0.3)), T(closed_form_image(shape, 1.7))
+        y = model(i1, i2)
+        y.backward(T(closed_form_signed(tuple(y.shape), 0.9, 1.0)))
+        out[tag + "__y"] = y.detach().numpy()
+        for k, p in model.named_parameters():
+            if p.grad is not None:   # (Res2ConvBlock never calls the dwconv it inherits from SepConvBlock)
+                out[f"{tag}__dp_{k}"] = digest(p.grad.numpy())
+    np.savez_compressed(os.path.join(HERE, "f15_n4_res2.npz"), **out)
+    json.dump(manifest, open(os.path.join(HERE, "f15_manifest.json"), "w"), indent=0)
+
+
 # ---------------------------------------------------------------- F4
 def run_module(mod, inputs, gout_phase):
     xs = [T(a).requires_grad_(True) for a in inputs]
@@ -523,7 +562,7 @@ def make_f9():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10", "f11", "f12", "f13", "f14"]
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10", "f11", "f12", "f13", "f14", "f15"]
     for w in which:
         globals()["make_" + w]()
         print("wrote", w)

@@ -218,3 +218,62 @@ def test_n4_nested_models_vs_golden(name, shape):
     close(y.detach().cpu().numpy(), g[tag + "__y"], 2e-4, "fused image")
     for k, p in model.named_parameters():
         close_digest(p.grad.cpu().numpy(), g[f"{tag}__dp_{k}"], 2e-3, k)
+
+
+# ------------------------------------------------------------------ depth-wise ConvLayer, ReLU6, Res2ConvBlock, Res2Fusion (golden F15)
+from test_oracle_golden import F15_LAYERS  # noqa: E402
+
+
+@pytest.mark.parametrize("case", F15_LAYERS, ids=[c[0] for c in F15_LAYERS])
+def test_depthwise_and_relu6_layers_vs_golden(case):
+    from core.block import ConvLayer
+    name, kw, shape = case
+    kw = dict(kw)
+    if kw.get("act") == "relu6":
+        kw["act"] = nn.ReLU6
+    g = np.load(os.path.join(G, "f15_n4_res2.npz"))
+    layer = load_closed_form(ConvLayer(**kw), 15).cuda()
+    assert layer._epilogue and (layer._depthwise or kw["act"] is nn.ReLU6)
+    x = torch.from_numpy(O.closed_form_signed(shape, 0.5, 8.0 if name == "relu6_k1" else 1.0)).cuda().requires_grad_(True)
+    y = layer(x)
+    y.backward(torch.from_numpy(O.closed_form_signed(tuple(y.shape), 1.5, 1.0)).cuda())
+    close(y.detach().cpu().numpy(), g[name + "_y"], 1e-5, "y")
+    close(x.grad.cpu().numpy(), g[name + "_dx"], 2e-5, "dx")
+    for kname, p in layer.named_parameters():
+        close(p.grad.cpu().numpy(), g[f"{name}_dp_{kname}"], 3e-5, kname)
+
+
+def test_res2_conv_block_vs_golden():
+    """Res2ConvBlock(16, 32, 4): point-wise expand + ReLU6, hierarchical depth-wise convs, point-wise project, projected residual."""
+    from core.block import Res2ConvBlock
+    g = np.load(os.path.join(G, "f15_n4_res2.npz"))
+    blk = load_closed_form(Res2ConvBlock(16, 32, 4), 15).cuda()
+    x = torch.from_numpy(O.closed_form_signed((2, 16, 10, 12), 0.5, 1.0)).cuda().requires_grad_(True)
+    y = blk(x)
+    y.backward(torch.from_numpy(O.closed_form_signed(tuple(y.shape), 1.5, 1.0)).cuda())
+    close(y.detach().cpu().numpy(), g["res2block_y"], 2e-5, "y")
+    close(x.grad.cpu().numpy(), g["res2block_dx"], 5e-5, "dx")
+    for kname, p in blk.named_parameters():
+        if f"res2block_dp_{kname}" in g.files:
+            close(p.grad.cpu().numpy(), g[f"res2block_dp_{kname}"], 1e-4, kname)
+        else:
+            assert p.grad is None, kname   # the inherited, never-called SepConvBlock.dwconv
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 32, 32), (2, 1, 24, 40)], ids=["1x32x32", "2x24x40"])
+def test_res2fusion_vs_golden(shape):
+    import core.model as M
+    from gpu_util import close_digest, dtype_ctx
+    g = np.load(os.path.join(G, "f15_n4_res2.npz"))
+    tag = f"Res2Fusion_{shape[0]}x{shape[2]}x{shape[3]}"
+    with dtype_ctx("fp32"):
+        model = load_closed_form(M.Res2Fusion(), 2).cuda()
+        i1, i2 = (torch.from_numpy(O.closed_form_image(shape, p)).cuda() for p in (0.3, 1.7))
+        y = model(i1, i2)
+        y.backward(torch.from_numpy(O.closed_form_signed(tuple(y.shape), 0.9, 1.0)).cuda())
+    close(y.detach().cpu().numpy(), g[tag + "__y"], 2e-4, "fused image")
+    for k, p in model.named_parameters():
+        if f"{tag}__dp_{k}" in g.files:
+            close_digest(p.grad.cpu().numpy(), g[f"{tag}__dp_{k}"], 2e-3, k)
+        else:
+            assert p.grad is None, k

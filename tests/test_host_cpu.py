@@ -90,12 +90,12 @@ def test_c_abi_validation_of_the_widened_entry_points_without_gpu():
 
 
 @pytest.mark.parametrize("name", ["PFNetv1", "PFNetv2", "DenseFuse", "VIFNet", "NestFuse", "RFNNest", "DeepFuse", "DBNet", "SEDRFuse", "IFCNN",
-                                  "DIFNet", "PMGI", "UNFusion", "MAFusion"])
+                                  "DIFNet", "PMGI", "UNFusion", "MAFusion", "Res2Fusion"])
 def test_state_dict_manifest_and_init(name):
     import core.model as M
     man = json.load(open(os.path.join(G, {"VIFNet": "f10_manifest.json", "DeepFuse": "f12_manifest.json", "DBNet": "f12_manifest.json",
                                           "SEDRFuse": "f13_manifest.json", "IFCNN": "f13_manifest.json", "DIFNet": "f13_manifest.json",
-                                          "PMGI": "f13_manifest.json", "UNFusion": "f14_manifest.json", "MAFusion": "f14_manifest.json"}.get(name, "f5_manifest.json"))))
+                                          "PMGI": "f13_manifest.json", "UNFusion": "f14_manifest.json", "MAFusion": "f14_manifest.json", "Res2Fusion": "f15_manifest.json"}.get(name, "f5_manifest.json"))))
     torch.manual_seed(0)
     m = getattr(M, name)()
     assert [[k, list(v.shape)] for k, v in m.state_dict().items()] == man[name]
@@ -103,7 +103,7 @@ def test_state_dict_manifest_and_init(name):
     for k, v in m.state_dict().items():
         if k.endswith("bias"):
             assert float(v.abs().max()) == 0.0
-    if name in ("NestFuse", "RFNNest", "DeepFuse", "SEDRFuse", "IFCNN", "DIFNet", "PMGI", "UNFusion", "MAFusion"):
+    if name in ("NestFuse", "RFNNest", "DeepFuse", "SEDRFuse", "IFCNN", "DIFNet", "PMGI", "UNFusion", "MAFusion", "Res2Fusion"):
         return
     w = m.state_dict()["decode.0.layers.0.weight"]
     fan_in = w.shape[1] * 9
@@ -150,6 +150,7 @@ def test_conv_layer_signature_and_fallback_rules():
                 ConvLayer(3, 16, ksize=5, norm=nn.BatchNorm2d, act=nn.LeakyReLU)):
         assert lay._epilogue and not lay._hip and not lay._gen
     # everything else stays the stock torch modules
+    assert ConvLayer(16, 16, groups=16, bias=False, act=None)._depthwise and ConvLayer(16, 64, ksize=1, bias=False, act=nn.ReLU6)._epilogue
     for lay in (ConvLayer(16, 16, dilation=2, padding=2), ConvLayer(16, 16, pre_norm=nn.BatchNorm2d), ConvLayer(16, 16, act=nn.Sigmoid),
                 ConvLayer(16, 16, groups=2)):
         assert not lay._hip and not lay._gen and not lay._epilogue

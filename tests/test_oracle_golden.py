@@ -444,3 +444,36 @@ def test_f13_norm_act_oracle_vs_reference(case):
         # (the conv bias in front of a norm has a mathematically zero gradient: both sides hold rounding noise of ~1e-5 there)
         tol = 3e-5 if (norm and key == "_dp_layers.0.bias") else 3e-6
         assert np.abs(got - ref).max() <= tol * max(1.0, np.abs(ref).max()), (name, key, np.abs(got - ref).max())
+
+
+# ------------------------------------------------------------------ F15: depth-wise ConvLayer / ReLU6
+F15_LAYERS = [("dw_k3", dict(in_ch=16, out_ch=16, ksize=3, groups=16, bias=False, act=None), (2, 16, 9, 11)),
+              ("dw_k1", dict(in_ch=24, out_ch=24, ksize=1, groups=24, bias=False, act=None), (1, 24, 5, 6)),
+              ("dw_k3_bias", dict(in_ch=8, out_ch=8, ksize=3, groups=8, act=None), (2, 8, 2, 7)),
+              ("relu6_k1", dict(in_ch=16, out_ch=64, ksize=1, bias=False, act="relu6"), (2, 16, 6, 7))]
+
+
+@pytest.mark.parametrize("case", F15_LAYERS, ids=[c[0] for c in F15_LAYERS])
+def test_f15_depthwise_and_relu6_oracle_vs_reference(case):
+    name, kw, shape = case
+    g = np.load(os.path.join(G, "f15_n4_res2.npz"))
+    cin, cout, k = kw["in_ch"], kw["out_ch"], kw["ksize"]
+    has_bias = kw.get("bias", True)
+    dw = kw.get("groups", 1) > 1
+    w = O.closed_form_param(0, "layers.0.weight", (cout, 1 if dw else cin, k, k), 15)
+    b = O.closed_form_param(1, "layers.0.bias", (cout,), 15) if has_bias else None
+    x = O.closed_form_signed(shape, 0.5, 8.0 if name == "relu6_k1" else 1.0)
+    if dw:
+        y = O.dwconv_fwd(x, w, b, True)
+        gy = O.closed_form_signed(y.shape, 1.5, 1.0)
+        dx, gw, gb = O.dwconv_bwd(x, w, gy, True)
+    else:
+        z = O.conv2d_general_fwd(x, w, b, 1, 0, False, False)
+        y = O._act(z, kw["act"])
+        gy = O.closed_form_signed(y.shape, 1.5, 1.0)
+        dx, gw, gb = O.conv2d_general_bwd(x, w, z, gy * O._act_dydz(y, kw["act"]), 1, 0, False, False)
+        assert float((y == 6).mean()) > 0.01 and float((y == 0).mean()) > 0.01   # both ReLU6 bounds are exercised
+    pairs = [(y, "_y"), (dx, "_dx"), (gw, "_dp_layers.0.weight")] + ([(gb, "_dp_layers.0.bias")] if has_bias else [])
+    for got, key in pairs:
+        ref = g[name + key]
+        assert np.abs(got - ref).max() <= 3e-6 * max(1.0, np.abs(ref).max()), (name, key, np.abs(got - ref).max())
