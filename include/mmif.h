@@ -155,6 +155,18 @@ int mmif_norm_act_bwd(const float* x, const float* y, const float* gy, const flo
 int mmif_act_fwd(const float* x, float* y, int64_t count, int32_t act, float slope, void* stream);
 int mmif_act_bwd(const float* gy, const float* y, float* dx, int64_t count, int32_t act, float slope, void* stream);
 
+/* Resampling glue of the layer-by-layer blocks on plain NCHW fp32 planes: nn.MaxPool2d(k, k) (floor mode; idx = window offset of the
+ * first maximum, 1 byte per output; core/block.py:941-950), nn.Upsample(scale_factor, mode='nearest') (:968-969), and
+ * nn.ReflectionPad2d((left, right, top, bottom)) as Upsample / Downsample use it to match a target shape (:983-991; negative = crop). */
+int mmif_maxpool_nchw_fwd(const float* x, float* y, unsigned char* idx, int64_t planes, int32_t h, int32_t w, int32_t k, void* stream);
+int mmif_maxpool_nchw_bwd(const float* g, const unsigned char* idx, float* dx, int64_t planes, int32_t h, int32_t w, int32_t k, void* stream);
+int mmif_nearest_up_fwd(const float* x, float* y, int64_t planes, int32_t h, int32_t w, int32_t scale, void* stream);
+int mmif_nearest_up_bwd(const float* g, float* dx, int64_t planes, int32_t h, int32_t w, int32_t scale, void* stream);
+int mmif_reflect_pad_fwd(const float* x, float* y, int64_t planes, int32_t h, int32_t w, int32_t left, int32_t right, int32_t top,
+                         int32_t bottom, void* stream);
+int mmif_reflect_pad_bwd(const float* g, float* dx, int64_t planes, int32_t h, int32_t w, int32_t left, int32_t right, int32_t top,
+                         int32_t bottom, void* stream);
+
 /* ---- ConvLayer: reflect-pad(k/2) conv + bias + ReLU, stride 1, k in {1,3}
  *      replaces core/block.py:98-99 (nn.Conv2d(padding_mode='reflect') + nn.ReLU(inplace)) ---- */
 /* y = act(bias + corr(reflect_pad(x), w)).  w: fp32 master weights; w_packed: mmif_pack_weights'

@@ -17,7 +17,7 @@ from mmif.tensor import BT
 from .fusion import concat_fusion, element_fusion
 
 __all__ = ['ConvLayer', 'ResBlock', 'DenseBlock', 'SepConvBlock', 'Res2ConvBlock', 'ConvBlock', 'ECB', 'DCB', 'RFN', 'NestEncoder', 'NestDecoder', 'FSDecoder', 'Downsample',
-           'Upsample']
+           'Upsample', 'MaxPool2d']
 
 
 class _ConvLayerFn(torch.autograd.Function):
@@ -437,6 +437,56 @@ class RFN(nn.Module):
         return f_out + f_res
 
 
+class _MaxPoolFn(torch.autograd.Function):
+    """nn.MaxPool2d(k, k) on csrc/resample.hip (first-maximum tie rule in the backward, like ATen)"""
+
+    @staticmethod
+    def forward(ctx, x, k):
+        y, idx = T.maxpool_nchw_fwd(x.detach().contiguous().float(), k)
+        ctx.saved, ctx.meta = idx, ((x.shape[2], x.shape[3]), k)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return T.maxpool_nchw_bwd(g.contiguous().float(), ctx.saved, *ctx.meta), None
+
+
+class MaxPool2d(nn.MaxPool2d):
+    """nn.MaxPool2d whose forward runs on the HIP kernel for the configurations the models use (kernel == stride, no padding /
+    dilation, floor mode, 4-D GPU input); anything else is the stock module."""
+
+    def forward(self, x):
+        k = self.kernel_size if isinstance(self.kernel_size, int) else None
+        if (x.is_cuda and x.dim() == 4 and k is not None and self.stride == k and self.padding == 0 and self.dilation == 1
+                and not self.ceil_mode and not self.return_indices and x.shape[2] >= k and x.shape[3] >= k):
+            return _MaxPoolFn.apply(x, k)
+        return super(MaxPool2d, self).forward(x)
+
+
+class _NearestUpFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, scale):
+        ctx.scale = scale
+        return T.nearest_up_fwd(x.detach().contiguous().float(), scale)
+
+    @staticmethod
+    def backward(ctx, g):
+        return T.nearest_up_bwd(g.contiguous().float(), ctx.scale), None
+
+
+class _ReflectPadFn(torch.autograd.Function):
+    """nn.ReflectionPad2d((left, right, top, bottom)); negative amounts crop"""
+
+    @staticmethod
+    def forward(ctx, x, pads):
+        ctx.meta = ((x.shape[2], x.shape[3]), pads)
+        return T.reflect_pad_fwd(x.detach().contiguous().float(), pads)
+
+    @staticmethod
+    def backward(ctx, g):
+        return T.reflect_pad_bwd(g.contiguous().float(), *ctx.meta), None
+
+
 class _Resample(nn.Module):
     """shape-matching tail shared by Upsample / Downsample (reference core/block.py:953-961,981-991)"""
 
@@ -444,7 +494,10 @@ class _Resample(nn.Module):
     def _pad(feat, shape):
         pad_h, pad_w = shape[-2] - feat.shape[-2], shape[-1] - feat.shape[-1]
         top, left = pad_h // 2, pad_w // 2
-        return nn.ReflectionPad2d((left, pad_w - left, top, pad_h - top))(feat)
+        pads = (left, pad_w - left, top, pad_h - top)
+        if feat.is_cuda and max(pads[0], pads[1]) < feat.shape[-1] and max(pads[2], pads[3]) < feat.shape[-2]:
+            return _ReflectPadFn.apply(feat, pads)
+        return nn.ReflectionPad2d(pads)(feat)
 
     def forward(self, feat, shape):
         out = self.op(feat)
@@ -458,7 +511,7 @@ class Downsample(_Resample):
 
     def __init__(self, kernel_size=2, stride=2):
         super(Downsample, self).__init__()
-        self.down = nn.MaxPool2d(kernel_size, stride)
+        self.down = MaxPool2d(kernel_size, stride)
         self.op = self.down
 
 
@@ -485,11 +538,14 @@ class Upsample(_Resample):
             self.up = nn.Upsample(scale_factor=scale_factor, mode=mode)
         else:
             self.up = nn.Upsample(scale_factor=scale_factor, mode=mode, align_corners=True)
-        self._bilinear = mode == 'bilinear' and int(scale_factor) == scale_factor
-        self.op = self._bilinear_op if self._bilinear else self.up
+        whole = int(scale_factor) == scale_factor
+        self.op = self._bilinear_op if (mode == 'bilinear' and whole) else (self._nearest_op if (mode == 'nearest' and whole) else self.up)
 
     def _bilinear_op(self, feat):
         return _BilinearUpFn.apply(feat, int(self.up.scale_factor))
+
+    def _nearest_op(self, feat):
+        return _NearestUpFn.apply(feat, int(self.up.scale_factor)) if feat.is_cuda else self.up(feat)
 
 
 class NestDecoder(nn.Module):
@@ -530,7 +586,7 @@ class NestEncoder(nn.Module):
         self.EB4_2 = block(i[3] * 3 + i[2] * 2, i[3] * 4 + i[2])
         self.EB4_3 = block(i[3] * 7 + i[2] + o[2], o[3])
         if down_mode == 'maxpool':
-            self.down1, self.down2, self.down3 = nn.MaxPool2d(2, 2), nn.MaxPool2d(2, 2), nn.MaxPool2d(2, 2)
+            self.down1, self.down2, self.down3 = MaxPool2d(2, 2), MaxPool2d(2, 2), MaxPool2d(2, 2)
         elif down_mode == 'stride':
             self.down1 = ConvLayer(o[1], o[1], stride=2)
             self.down2 = ConvLayer(i[2] * 2, i[2] * 2, stride=2)

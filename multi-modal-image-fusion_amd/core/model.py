@@ -229,7 +229,7 @@ class NestFuse(_FusionModel):
         self.CB3_0 = ConvBlock(num_ch[1], num_ch[2])
         self.CB4_0 = ConvBlock(num_ch[2], num_ch[3])
         if down_mode == 'maxpool':
-            self.down1, self.down2, self.down3 = nn.MaxPool2d(2, 2), nn.MaxPool2d(2, 2), nn.MaxPool2d(2, 2)
+            self.down1, self.down2, self.down3 = MaxPool2d(2, 2), MaxPool2d(2, 2), MaxPool2d(2, 2)
         elif down_mode == 'stride':
             self.down1 = ConvLayer(num_ch[0], num_ch[0], stride=2)
             self.down2 = ConvLayer(num_ch[1], num_ch[1], stride=2)
@@ -283,7 +283,7 @@ class UNFusion(_FusionModel):
         self.CB1_0, self.CB2_0 = ConvLayer(1, enc_ch[0]), ConvLayer(enc_ch[0], enc_ch[1])
         self.CB3_0, self.CB4_0 = ConvLayer(enc_ch[1], enc_ch[2]), ConvLayer(enc_ch[2], enc_ch[3])
         if down_mode == 'maxpool':
-            self.down1, self.down2, self.down3 = nn.MaxPool2d(2, 2), nn.MaxPool2d(2, 2), nn.MaxPool2d(2, 2)
+            self.down1, self.down2, self.down3 = MaxPool2d(2, 2), MaxPool2d(2, 2), MaxPool2d(2, 2)
         elif down_mode == 'stride':
             self.down1 = ConvLayer(enc_ch[0], enc_ch[0], stride=2)
             self.down2 = ConvLayer(enc_ch[1], enc_ch[1], stride=2)
@@ -346,7 +346,7 @@ class MAFusion(NestFuse):
         self.CB3_0 = ConvBlock(num_ch[1], num_ch[2])
         self.CB4_0 = ConvBlock(num_ch[2], num_ch[3])
         if down_mode == 'maxpool':
-            self.down1, self.down2, self.down3 = nn.MaxPool2d(2, 2), nn.MaxPool2d(2, 2), nn.MaxPool2d(2, 2)
+            self.down1, self.down2, self.down3 = MaxPool2d(2, 2), MaxPool2d(2, 2), MaxPool2d(2, 2)
         elif down_mode == 'stride':
             self.down1 = ConvLayer(num_ch[0], num_ch[0], stride=2)
             self.down2 = ConvLayer(num_ch[1], num_ch[1], stride=2)

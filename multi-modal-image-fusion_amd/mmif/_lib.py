@@ -72,6 +72,12 @@ SIGNATURES = {
     "mmif_channel_sum": (_i32, [_vp, _vp, _i32, _i32, _i64, _vp]),
     "mmif_bilinear_up_fwd": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     "mmif_bilinear_up_bwd": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
+    "mmif_maxpool_nchw_fwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
+    "mmif_maxpool_nchw_bwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
+    "mmif_nearest_up_fwd": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _vp]),
+    "mmif_nearest_up_bwd": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _vp]),
+    "mmif_reflect_pad_fwd": (_i32, [_vp, _vp, _i64] + [_i32] * 6 + [_vp]),
+    "mmif_reflect_pad_bwd": (_i32, [_vp, _vp, _i64] + [_i32] * 6 + [_vp]),
     "mmif_norm_workspace": (_sz, [_i32, _i32]),
     "mmif_norm_act_fwd": (_i32, [_vp] * 7 + [_i32, _i32, _i64, _i32, _f32, _f32, _i32, _f32, _vp, _sz, _vp]),
     "mmif_norm_act_bwd": (_i32, [_vp] * 8 + [_i32, _i32, _i64, _i32, _i32, _f32, _vp, _sz, _vp]),

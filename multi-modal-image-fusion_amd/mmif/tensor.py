@@ -438,3 +438,56 @@ def dwconv_wgrad(x, gy, k, reflect, want_bias):
     db = torch.empty(c, dtype=torch.float32, device=x.device) if want_bias else None
     check(lib.mmif_dwconv_wgrad(_ptr(x), _ptr(gy), _ptr(dw), _ptr(db), n, c, h, wd, k, int(reflect), stream_ptr()), "dwconv_wgrad")
     return dw, db
+
+
+# ------------------------------------------------------------------ resampling glue on NCHW fp32 (max-pool, nearest up-sampling, reflect pad / crop)
+def maxpool_nchw_fwd(x, k):
+    _f32c(x, "x")
+    n, c, h, w = x.shape
+    y = torch.empty((n, c, h // k, w // k), dtype=torch.float32, device=x.device)
+    idx = torch.empty((n, c, h // k, w // k), dtype=torch.uint8, device=x.device)
+    check(lib.mmif_maxpool_nchw_fwd(_ptr(x), _ptr(y), _ptr(idx), n * c, h, w, k, stream_ptr()), "maxpool_nchw_fwd")
+    return y, idx
+
+
+def maxpool_nchw_bwd(g, idx, in_hw, k):
+    _f32c(g, "g")
+    n, c = g.shape[0], g.shape[1]
+    dx = torch.empty((n, c, in_hw[0], in_hw[1]), dtype=torch.float32, device=g.device)
+    check(lib.mmif_maxpool_nchw_bwd(_ptr(g), _ptr(idx), _ptr(dx), n * c, in_hw[0], in_hw[1], k, stream_ptr()), "maxpool_nchw_bwd")
+    return dx
+
+
+def nearest_up_fwd(x, scale):
+    _f32c(x, "x")
+    n, c, h, w = x.shape
+    y = torch.empty((n, c, h * scale, w * scale), dtype=torch.float32, device=x.device)
+    check(lib.mmif_nearest_up_fwd(_ptr(x), _ptr(y), n * c, h, w, scale, stream_ptr()), "nearest_up_fwd")
+    return y
+
+
+def nearest_up_bwd(g, scale):
+    _f32c(g, "g")
+    n, c, H, W = g.shape
+    dx = torch.empty((n, c, H // scale, W // scale), dtype=torch.float32, device=g.device)
+    check(lib.mmif_nearest_up_bwd(_ptr(g), _ptr(dx), n * c, H // scale, W // scale, scale, stream_ptr()), "nearest_up_bwd")
+    return dx
+
+
+def reflect_pad_fwd(x, pads):
+    """pads = (left, right, top, bottom) as nn.ReflectionPad2d; negative amounts crop."""
+    _f32c(x, "x")
+    n, c, h, w = x.shape
+    l, r, t, b = pads
+    y = torch.empty((n, c, h + t + b, w + l + r), dtype=torch.float32, device=x.device)
+    check(lib.mmif_reflect_pad_fwd(_ptr(x), _ptr(y), n * c, h, w, l, r, t, b, stream_ptr()), "reflect_pad_fwd")
+    return y
+
+
+def reflect_pad_bwd(g, in_hw, pads):
+    _f32c(g, "g")
+    n, c = g.shape[0], g.shape[1]
+    l, r, t, b = pads
+    dx = torch.empty((n, c, in_hw[0], in_hw[1]), dtype=torch.float32, device=g.device)
+    check(lib.mmif_reflect_pad_bwd(_ptr(g), _ptr(dx), n * c, in_hw[0], in_hw[1], l, r, t, b, stream_ptr()), "reflect_pad_bwd")
+    return dx

@@ -277,3 +277,60 @@ def test_res2fusion_vs_golden(shape):
             close_digest(p.grad.cpu().numpy(), g[f"{tag}__dp_{k}"], 2e-3, k)
         else:
             assert p.grad is None, k
+
+
+# ------------------------------------------------------------------ resampling glue (max-pool, nearest up-sampling, reflect pad / crop)
+@pytest.mark.parametrize("k,shape", [(2, (2, 5, 13, 18)), (4, (1, 3, 17, 16)), (2, (1, 1, 2, 2))])
+def test_maxpool_nchw_vs_numpy(k, shape):
+    from core.block import MaxPool2d
+    rng = np.random.default_rng(k + shape[2])
+    x = rng.integers(-3, 4, size=shape).astype(np.float32)          # small integers: plenty of ties (first maximum wins)
+    xt = torch.from_numpy(x).cuda().requires_grad_(True)
+    y = MaxPool2d(k, k)(xt)
+    n, c, h, w = shape
+    ho, wo = h // k, w // k
+    win = x[:, :, :ho * k, :wo * k].reshape(n, c, ho, k, wo, k).transpose(0, 1, 2, 4, 3, 5).reshape(n, c, ho, wo, k * k)
+    assert np.array_equal(y.detach().cpu().numpy(), win.max(-1))
+    g = rng.standard_normal((n, c, ho, wo)).astype(np.float32)
+    y.backward(torch.from_numpy(g).cuda())
+    dx = np.zeros((n, c, ho, wo, k * k), dtype=np.float32)
+    np.put_along_axis(dx, win.argmax(-1)[..., None], g[..., None], axis=-1)      # argmax = first maximum
+    ref = np.zeros(shape, dtype=np.float32)
+    ref[:, :, :ho * k, :wo * k] = dx.reshape(n, c, ho, wo, k, k).transpose(0, 1, 2, 4, 3, 5).reshape(n, c, ho * k, wo * k)
+    assert np.array_equal(xt.grad.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("scale,shape", [(2, (2, 3, 5, 7)), (4, (1, 2, 3, 2))])
+def test_nearest_upsample_vs_numpy(scale, shape):
+    from core.block import Upsample
+    rng = np.random.default_rng(scale)
+    x = rng.standard_normal(shape).astype(np.float32)
+    xt = torch.from_numpy(x).cuda().requires_grad_(True)
+    tgt = (shape[0], shape[1], shape[2] * scale, shape[3] * scale)
+    y = Upsample('nearest', scale)(xt, torch.Size(tgt))
+    assert np.array_equal(y.detach().cpu().numpy(), x.repeat(scale, axis=2).repeat(scale, axis=3))
+    g = rng.standard_normal(tgt).astype(np.float32)
+    y.backward(torch.from_numpy(g).cuda())
+    ref = g.reshape(shape[0], shape[1], shape[2], scale, shape[3], scale).sum(axis=(3, 5))
+    close(xt.grad.cpu().numpy(), ref, 1e-6, "dx")
+
+
+@pytest.mark.parametrize("pads,shape", [((1, 2, 0, 1), (2, 3, 6, 7)), ((-1, -2, -1, 0), (1, 2, 9, 8)), ((2, -1, 3, 3), (1, 2, 5, 6)), ((0, 0, 1, 0), (1, 1, 2, 1))])
+def test_reflect_pad_and_crop_vs_numpy(pads, shape):
+    """the shape-matching tail of Upsample / Downsample: nn.ReflectionPad2d((l, r, t, b)), negative amounts crop; adjoint by scatter."""
+    from core.block import _ReflectPadFn
+    l, r, t, b = pads
+    rng = np.random.default_rng(abs(l) + shape[2])
+    x = rng.standard_normal(shape).astype(np.float32)
+    n, c, h, w = shape
+    H, W = h + t + b, w + l + r
+    R = lambda i, L: np.where(np.abs(i) >= L, 2 * (L - 1) - np.abs(i), np.abs(i))
+    sy, sx = R(np.arange(H) - t, h), R(np.arange(W) - l, w)
+    xt = torch.from_numpy(x).cuda().requires_grad_(True)
+    y = _ReflectPadFn.apply(xt, pads)
+    assert np.array_equal(y.detach().cpu().numpy(), x[:, :, sy][:, :, :, sx])
+    g = rng.standard_normal((n, c, H, W)).astype(np.float32)
+    y.backward(torch.from_numpy(g).cuda())
+    ref = np.zeros(shape, dtype=np.float64)
+    np.add.at(ref, (slice(None), slice(None), sy[:, None], sx[None, :]), g)
+    close(xt.grad.cpu().numpy(), ref.astype(np.float32), 1e-6, "dx")

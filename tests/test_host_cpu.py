@@ -81,6 +81,8 @@ def test_c_abi_validation_of_the_widened_entry_points_without_gpu():
     assert lib.mmif_gconv_wgrad(f, f, f, None, 1, 8, 8, 16, 16, 5, 1, 2, 1, f, 64, None) == -3
     assert lib.mmif_gconvt_fwd(f, f, None, f, 1, 8, 8, 4, 4, 3, 2, 1, 2, 0, None) == -1           # output_padding >= stride
     assert lib.mmif_relu_bwd(None, f, f, 4, None) == -1 and lib.mmif_channel_sum(f, f, 0, 1, 1, None) == -1
+    assert lib.mmif_reflect_pad_fwd(f, f, 1, 4, 4, 4, 0, 0, 0, None) == -1      # padding must be smaller than the input
+    assert lib.mmif_maxpool_nchw_fwd(f, f, f, 1, 3, 8, 4, None) == -1 and lib.mmif_nearest_up_fwd(f, f, 1, 2, 2, 0, None) == -1
     from mmif._lib import MmifPackJob
     jobs = (MmifPackJob * 1)()
     assert lib.mmif_pack_weights_multi(jobs, 0, None) == -1
