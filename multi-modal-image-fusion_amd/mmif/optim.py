@@ -64,10 +64,10 @@ class FusedClipAdam(torch.optim.Optimizer):
     def _flat_grads(self, ps):
         """The engine's flat gradient buffer when every .grad is a view of it (zero-copy), else a staging copy."""
         total = sum(p.numel() for p in ps)
+        if all(p.grad is None for p in ps):
+            raise RuntimeError("FusedClipAdam.step(): no parameter has a gradient (call backward() first)")
         g0 = ps[0].grad
-        if g0 is None:
-            raise RuntimeError("FusedClipAdam.step(): parameter without gradient")
-        flat = E.FLAT_BUFFERS.get(g0.data_ptr())
+        flat = E.FLAT_BUFFERS.get(g0.data_ptr()) if g0 is not None else None
         if flat is not None and flat.numel() == total + N_TAIL:
             off, ok = 0, True
             for p in ps:
@@ -83,8 +83,11 @@ class FusedClipAdam(torch.optim.Optimizer):
         for p in ps:
             n = p.numel()
             if p.grad is None:
-                raise RuntimeError("FusedClipAdam.step(): parameter without gradient")
-            self._stage[off:off + n].copy_(p.grad.reshape(-1))
+                # a parameter the forward never used (PMGI's transfer1[1], Res2ConvBlock's inherited dwconv): torch.optim.Adam
+                # skips it; a zero gradient does the same here (moments stay zero => zero update, no effect on the clip norm)
+                self._stage[off:off + n].zero_()
+            else:
+                self._stage[off:off + n].copy_(p.grad.reshape(-1))
             off += n
         return self._stage
 

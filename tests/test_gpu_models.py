@@ -326,3 +326,38 @@ def test_graphed_step_equals_eager_step():
         assert torch.equal(out["eager"][0], out["graph"][0]), (out["eager"][0], out["graph"][0])
         for p, q in zip(out["eager"][1], out["graph"][1]):
             assert torch.equal(p, q)
+
+
+@pytest.mark.gpu
+def test_fused_clip_adam_with_unused_parameters_matches_torch_adam():
+    """PMGI never calls transfer1[1] (reference core/model.py:589): those parameters have no gradient.  torch.optim.Adam skips them;
+    FusedClipAdam must leave them untouched too and update the rest exactly like clip_grad_norm_(5) + Adam."""
+    import copy
+    import core.model as M
+    from mmif.optim import FusedClipAdam
+    dev = torch.device("cuda", 0)
+    with dtype_ctx("fp32"):
+        torch.manual_seed(0)
+        m1 = M.PMGI().to(dev)
+        m2 = copy.deepcopy(m1)
+        o1 = FusedClipAdam(m1.parameters(), lr=1e-3, betas=(0.9, 0.999), max_norm=5.0)
+        o2 = torch.optim.Adam(m2.parameters(), lr=1e-3, betas=(0.9, 0.999))
+        a, b = torch.rand(2, 1, 24, 24, device=dev), torch.rand(2, 1, 24, 24, device=dev)
+        for _ in range(2):
+            for m, o in ((m1, o1), (m2, o2)):
+                o.zero_grad(set_to_none=True)
+                (m(a, b) - a).abs().mean().backward()
+                if o is o2:
+                    torch.nn.utils.clip_grad_norm_(m.parameters(), 5.0)
+                o.step()
+    for (k, p), q in zip(m1.named_parameters(), m2.parameters()):
+        if k.endswith("layers.0.bias") and not k.startswith("decode"):
+            # a conv bias in front of a BatchNorm has an exactly-zero gradient; what both sides hold is rounding noise, and Adam
+            # turns noise into +-lr steps -- not comparable (and irrelevant: the BatchNorm removes the bias again)
+            continue
+        assert torch.allclose(p, q, rtol=2e-4, atol=2e-6), k
+    assert m1.transfer1[1].layers[0].weight.grad is None
+    torch.manual_seed(0)
+    fresh = dict(M.PMGI().named_parameters())
+    for k in ("transfer1.1.layers.0.weight", "transfer1.1.layers.1.weight"):   # never used => never updated
+        assert torch.equal(dict(m1.named_parameters())[k].detach().cpu(), fresh[k].detach())
