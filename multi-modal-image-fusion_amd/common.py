@@ -16,37 +16,34 @@ __all__ = ['get_train_args', 'get_test_args', 'save_result', 'setup_seed', 'setu
            'WarmupLR', 'Logger', 'make_logger', 'norm', 'denorm']
 
 
-def _common_extra(parser):
-    # additions of this engine (the reference hard-codes both by editing list indices in the script)
-    parser.add_argument('--model', default='PFNetv1', type=str, help='PFNetv1 | PFNetv2 | DenseFuse | VIFNet | NestFuse | RFNNest | DeepFuse | DBNet | SEDRFuse | IFCNN | DIFNet | PMGI | UNFusion | MAFusion | Res2Fusion')
-    parser.add_argument('--dtype', default='fp32', type=str, help='feature-map storage: fp32 (parity) | bf16 (throughput)')
-    parser.add_argument('--synthetic', default=0, type=int, help='>0: train on this many synthetic random pairs (no dataset needed)')
-    parser.add_argument('--graph', default=False, type=bool,
-                        help='replay forward + losses + backward of the training batch shape as one hipGraph (launch-bound small batches)')
+# flag tables: (name, default, type, help).  The reference's flags (common.py:23-71) keep their names, defaults and -- including the
+# `type=bool` ones, which treat any non-empty string as True -- their argparse behaviour; the last four are this engine's additions
+# (the reference picks model / precision by editing the scripts).
+_MODELS = 'PFNetv1 | PFNetv2 | DenseFuse | VIFNet | NestFuse | RFNNest | DeepFuse | DBNet | SEDRFuse | IFCNN | DIFNet | PMGI | UNFusion | MAFusion | Res2Fusion'
+_EXTRA = [('model', 'PFNetv1', str, _MODELS),
+          ('dtype', 'fp32', str, 'feature-map storage: fp32 (parity) | bf16 (throughput)'),
+          ('synthetic', 0, int, '>0: train on this many synthetic random pairs (no dataset needed)'),
+          ('graph', False, bool, 'replay forward + losses + backward of the training batch shape as one hipGraph (launch-bound small batches)')]
+_TRAIN = [('lr', None, float, 'learning rate'), ('bs', None, int, 'batch size'), ('epoch', None, int, 'number of epoch'),
+          ('use_patches', True, bool, 'use patches or random crop'), ('warmup', False, bool, 'use warmup lr'),
+          ('clip_grad', True, bool, 'clip grad norm'), ('local_rank', 0, int, 'node rank for distributed training'),
+          ('local_world_size', 1, int, 'number of gpus for distributed training'), ('data', 'polar', str, 'dataset folder name')]
+_TEST = [('use_gpu', True, bool, 'use gpu or cpu'), ('data', 'polar', str, 'dataset folder name'), ('ckpt', None, str, 'checkpoint folder name')]
+
+
+def _parse(description, table):
+    ap = argparse.ArgumentParser(description=description)
+    for name, default, kind, text in table + _EXTRA:
+        ap.add_argument('--' + name, default=default, type=kind, help=text)
+    return ap.parse_args()
 
 
 def get_train_args():
-    parser = argparse.ArgumentParser(description='Training')
-    parser.add_argument('--lr', default=None, type=float, help='learning rate')
-    parser.add_argument('--bs', default=None, type=int, help='batch size')
-    parser.add_argument('--epoch', default=None, type=int, help='number of epoch')
-    parser.add_argument('--use_patches', default=True, type=bool, help='use patches or random crop')
-    parser.add_argument('--warmup', default=False, type=bool, help='use warmup lr')
-    parser.add_argument('--clip_grad', default=True, type=bool, help='clip grad norm')
-    parser.add_argument('--local_rank', default=0, type=int, help='node rank for distributed training')
-    parser.add_argument('--local_world_size', default=1, type=int, help='number of gpus for distributed training')
-    parser.add_argument('--data', default='polar', type=str, help='dataset folder name')
-    _common_extra(parser)
-    return parser.parse_args()
+    return _parse('Training', _TRAIN)
 
 
 def get_test_args():
-    parser = argparse.ArgumentParser(description='Testing')
-    parser.add_argument('--use_gpu', default=True, type=bool, help='use gpu or cpu')
-    parser.add_argument('--data', default='polar', type=str, help='dataset folder name')
-    parser.add_argument('--ckpt', default=None, type=str, help='checkpoint folder name')
-    _common_extra(parser)
-    return parser.parse_args()
+    return _parse('Testing', _TEST)
 
 
 def norm(img, mode=None):
@@ -103,19 +100,19 @@ def reduce_value(value, world_size=1, average=True):
 
 
 class AverageMeter(object):
+    """running (sample-weighted) mean: .val last value, .avg mean, .sum, .count (reference common.py:116-133)"""
+
     def __init__(self):
         self.reset()
-
-    def is_empty(self):
-        return self.count == 0
 
     def reset(self):
         self.val = self.avg = self.sum = self.count = 0
 
+    def is_empty(self):
+        return not self.count
+
     def update(self, val, n=1):
-        self.val = val
-        self.sum += val * n
-        self.count += n
+        self.val, self.sum, self.count = val, self.sum + val * n, self.count + n
         self.avg = self.sum / self.count
 
 
