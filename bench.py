@@ -207,6 +207,12 @@ def main():
                 roof_hbm = {"bound": "hbm", "kernel": f"conv_mfma_kernel {s.cin}->{s.cout} k{s.k} ({hbm_tag})", "achieved": nbytes / (ms * 1e-3) / 1e9,
                             "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": nbytes / (ms * 1e-3) / PEAK_HBM, "avg_launch_ms": ms,
                             "launches": len(evh), "traffic": None}
+                tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+                if os.path.isfile(tpath) and B == 32 and S == 256 and Wd == 256 and args.dtype == "bf16" and args.mode == "train":
+                    tj = json.load(open(tpath)).get(hbm_tag if hbm_tag in ("encode1.1.2:fwd",) else "")
+                    if tj:   # (PFNetv1's entry; the other models' tags have no counter pass on file)
+                        roof_hbm["traffic"] = tj["hbm_bytes_per_launch"]
+                        roof_hbm["algorithmic_bytes"] = tj["algorithmic_bytes_per_launch"]
         out = {
             "metric": "image-pairs/sec at 256x256, PFNet train step" if args.mode == "train" else f"image-pairs/sec at {Wd}x{S}, {args.model} inference", "value": value, "unit": "image-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
