@@ -151,6 +151,21 @@ int mmif_norm_act_fwd(const float* x, const float* gamma, const float* beta, flo
 int mmif_norm_act_bwd(const float* x, const float* y, const float* gy, const float* stats, const float* gamma, float* dx,
                       float* dgamma, float* dbeta, int32_t n, int32_t c, int64_t hw, int32_t kind, int32_t act, float slope,
                       void* workspace, size_t workspace_bytes, void* stream);
+/* Cross-rank form of kind 0 (the reference converts its BatchNorm nets with nn.SyncBatchNorm.convert_sync_batchnorm before DDP,
+ * train.py:296): statistics and apply stages are separate calls; between them the host all-reduces (SUM) the fp64 device buffer
+ * chan_sums.  Forward: [2c + 1] doubles = (sum x, sum x^2) per channel, then the element count n*hw, so the count is reduced by the
+ * same collective and never visits the host.  Backward: [2c] doubles = (sum dz, sum dz*xhat) per channel; `count` points at the
+ * forward's reduced count (device memory).  dgamma / dbeta of mmif_bn_bwd_sums are the rank-local sums (they ride in the gradient
+ * all-reduce, as torch's SyncBatchNorm leaves them to DDP).  Without an all-reduce the results equal kind 0's. */
+int mmif_bn_moments(const float* x, double* chan_sums, int32_t n, int32_t c, int64_t hw, void* workspace, size_t workspace_bytes,
+                    void* stream);
+int mmif_bn_apply_fwd(const float* x, const double* chan_sums, const float* gamma, const float* beta, float* y,
+                      float* stats, float* running_mean, float* running_var, int32_t n, int32_t c, int64_t hw, float eps, float momentum,
+                      int32_t act, float slope, void* stream);
+int mmif_bn_bwd_sums(const float* x, const float* y, const float* gy, const float* stats, double* chan_sums, float* dgamma, float* dbeta,
+                     int32_t n, int32_t c, int64_t hw, int32_t act, float slope, void* workspace, size_t workspace_bytes, void* stream);
+int mmif_bn_apply_bwd(const float* x, const float* y, const float* gy, const float* stats, const float* gamma, const double* chan_sums,
+                      const double* count, float* dx, int32_t n, int32_t c, int64_t hw, int32_t act, float slope, void* stream);
 /* activation alone (LeakyReLU / Tanh after a conv without norm: PMGI's decode, core/model.py:579); backward from the output y */
 int mmif_act_fwd(const float* x, float* y, int64_t count, int32_t act, float slope, void* stream);
 int mmif_act_bwd(const float* gy, const float* y, float* dx, int64_t count, int32_t act, float slope, void* stream);

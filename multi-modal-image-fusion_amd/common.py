@@ -1,16 +1,20 @@
 # -*- coding: utf-8 -*-
 """Training plumbing -- API mirror of the reference's common.py (argument parsers :23-71, setup_seed
 :84-93, setup_dist :96-102, reduce_value :105-113, AverageMeter :116-133, WarmupLR :136-166,
-make_logger :169-210, save_result :74-81).  Only plumbing lives here; the hot path is in mmif/."""
+Logger / make_logger :169-210, save_result :74-81): same names, positional orders, keywords, defaults and return
+values, so call sites written against the reference (`WarmupLR(optimizer, 0.001, len(loader))`,
+`log_dir, logger = make_logger(BASE_DIR)`) behave the same.  Only plumbing lives here; the hot path is in mmif/."""
 import argparse
 import logging
 import os
 import random
-import time
+from datetime import datetime
 
 import numpy as np
 import torch
 import torch.distributed as dist
+
+from data.transform import denorm, norm
 
 __all__ = ['get_train_args', 'get_test_args', 'save_result', 'setup_seed', 'setup_dist', 'reduce_value', 'AverageMeter',
            'WarmupLR', 'Logger', 'make_logger', 'norm', 'denorm']
@@ -24,11 +28,12 @@ _EXTRA = [('model', 'PFNetv1', str, _MODELS),
           ('dtype', 'fp32', str, 'feature-map storage: fp32 (parity) | bf16 (throughput)'),
           ('synthetic', 0, int, '>0: train on this many synthetic random pairs (no dataset needed)'),
           ('graph', False, bool, 'replay forward + losses + backward of the training batch shape as one hipGraph (launch-bound small batches)')]
-_TRAIN = [('lr', None, float, 'learning rate'), ('bs', None, int, 'batch size'), ('epoch', None, int, 'number of epoch'),
-          ('use_patches', True, bool, 'use patches or random crop'), ('warmup', False, bool, 'use warmup lr'),
-          ('clip_grad', True, bool, 'clip grad norm'), ('local_rank', 0, int, 'node rank for distributed training'),
-          ('local_world_size', 1, int, 'number of gpus for distributed training'), ('data', 'polar', str, 'dataset folder name')]
-_TEST = [('use_gpu', True, bool, 'use gpu or cpu'), ('data', 'polar', str, 'dataset folder name'), ('ckpt', None, str, 'checkpoint folder name')]
+_TRAIN = [('lr', 1e-4, float, 'learning rate'), ('bs', 16, int, 'batch size'), ('epoch', 12, int, 'num of epochs'),
+          ('use_patches', True, bool, 'enable to train with patches'), ('warmup', False, bool, 'enable to warm up lr'),
+          ('clip_grad', True, bool, 'enable to clip grad norm'), ('local_rank', 0, int, 'node rank for distribution'),
+          ('local_world_size', 1, int, 'num of gpus for distribution'), ('data', 'roadscene', str, 'dataset folder name')]
+_TEST = [('use_gpu', True, bool, 'enable to test on gpu'), ('data', 'roadscene', str, 'dataset folder name'),
+         ('ckpt', '2023-02-26_23-15', str, 'checkpoint folder name')]
 
 
 def _parse(description, table):
@@ -46,28 +51,8 @@ def get_test_args():
     return _parse('Testing', _TEST)
 
 
-def norm(img, mode=None):
-    """data/transform.py:15-29 -- mode None: /255"""
-    img = np.asarray(img, dtype=np.float32)
-    if mode is None:
-        return img / 255.0
-    if mode == 'min-max':
-        return (img - img.min()) / max(img.max() - img.min(), 1e-7)
-    if mode == 'z-score':
-        return (img - img.mean()) / max(img.std(), 1e-7)
-    raise ValueError("only supported [None, 'min-max', 'z-score'] mode")
-
-
-def denorm(img):
-    """data/transform.py:32-35 -- clip to [0,1], *255, uint8 HWC"""
-    arr = img.detach().float().cpu().numpy() if torch.is_tensor(img) else np.asarray(img)
-    arr = np.clip(arr, 0.0, 1.0) * 255.0
-    if arr.ndim == 3:
-        arr = arr.transpose(1, 2, 0)
-    return arr.round().astype(np.uint8)
-
-
 def save_result(pred, img1=None, img2=None):
+    """uint8 HWC image of the prediction (or of img1 | img2 | pred side by side); denorm truncates, as the reference's does"""
     if img1 is not None and img2 is not None:
         return np.concatenate(tuple(map(denorm, (img1, img2, pred))), axis=1)
     return denorm(pred)
@@ -117,39 +102,57 @@ class AverageMeter(object):
 
 
 class WarmupLR(torch.optim.lr_scheduler._LRScheduler):
-    """linear warm-up from start_factor*lr to lr over warmup_iters (reference common.py:136-166)"""
+    """lr = base_lr * factor(iter): `warmup_factor` ('constant') or the line from warmup_factor to 1 ('linear') while
+    iter < warmup_iters, then 1 (reference common.py:136-166, same positional order)"""
 
-    def __init__(self, optimizer, warmup_iters, start_factor=0.001, last_epoch=-1):
-        self.warmup_iters = max(1, warmup_iters)
-        self.start_factor = start_factor
-        super(WarmupLR, self).__init__(optimizer, last_epoch)
+    def __init__(self, optimizer, warmup_factor=0.001, warmup_iters=1000, warmup_method="linear", last_epoch=-1, verbose=False):
+        self.warmup_factor = warmup_factor
+        self.warmup_iters = warmup_iters
+        self.warmup_method = warmup_method
+        super(WarmupLR, self).__init__(optimizer, last_epoch)   # torch >= 2.7 dropped the `verbose` argument
 
     def get_lr(self):
-        t = min(self.last_epoch, self.warmup_iters) / self.warmup_iters
-        f = self.start_factor + (1.0 - self.start_factor) * t
-        return [base * f for base in self.base_lrs]
+        f = self._get_warmup_factor_at_iter(self.warmup_method, self.last_epoch, self.warmup_iters, self.warmup_factor)
+        return [base_lr * f for base_lr in self.base_lrs]
+
+    @staticmethod
+    def _get_warmup_factor_at_iter(method, iter, warmup_iters, warmup_factor):
+        if iter >= warmup_iters:
+            return 1.0
+        if method == 'constant':
+            return warmup_factor
+        elif method == 'linear':
+            alpha = iter / warmup_iters
+            return warmup_factor + (1.0 - warmup_factor) * alpha
+        else:
+            raise ValueError("only supported ['constant', 'linear'] method")
 
 
 class Logger(object):
-    def __init__(self, path_log):
-        self.log_name = os.path.basename(path_log) or 'root'
-        self.out_path = path_log
-        os.makedirs(os.path.dirname(self.out_path), exist_ok=True)
+    def __init__(self, log_path):
+        log_name = os.path.basename(log_path)
+        log_dir = os.path.dirname(log_path)
+        if not os.path.exists(log_dir):
+            os.makedirs(log_dir)
+        self.log_name = log_name if log_name else "train.log"
+        self.log_path = log_path
 
     def init_logger(self):
         logger = logging.getLogger(self.log_name)
-        logger.setLevel(level=logging.INFO)
-        if not logger.handlers:
-            fh = logging.FileHandler(self.out_path, 'a')
-            fh.setFormatter(logging.Formatter('%(asctime)s - %(name)s - %(levelname)s - %(message)s'))
-            ch = logging.StreamHandler()
-            logger.addHandler(fh)
-            logger.addHandler(ch)
+        logger.setLevel(logging.INFO)
+        fh = logging.FileHandler(self.log_path, "w")
+        fh.setLevel(logging.INFO)
+        fh.setFormatter(logging.Formatter("%(asctime)s - %(name)s - %(levelname)s - %(message)s"))
+        ch = logging.StreamHandler()
+        ch.setLevel(logging.INFO)
+        logger.addHandler(fh)
+        logger.addHandler(ch)
         return logger
 
 
-def make_logger(out_dir):
-    time_str = time.strftime('%Y-%m-%d_%H-%M')
-    log_dir = os.path.join(out_dir, time_str)
-    os.makedirs(log_dir, exist_ok=True)
-    return Logger(os.path.join(log_dir, 'train.log')).init_logger(), log_dir
+def make_logger(root_dir):
+    """<root_dir>/../checkpoints/<YYYY-mm-dd_HH-MM>/train.log -> (log_dir, logger)   (reference common.py:200-210)"""
+    time_str = datetime.strftime(datetime.now(), "%Y-%m-%d_%H-%M")
+    log_dir = os.path.join(root_dir, '..', 'checkpoints', time_str)
+    logger = Logger(os.path.join(log_dir, "train.log")).init_logger()
+    return log_dir, logger

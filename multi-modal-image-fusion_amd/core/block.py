@@ -10,6 +10,7 @@ import torch
 import torch.nn as nn
 
 from mmif import _lib
+from mmif import dist as D
 from mmif import engine as E
 from mmif import tensor as T
 from mmif.tensor import BT
@@ -190,17 +191,33 @@ class _NormActFn(torch.autograd.Function):
                 mod.num_batches_tracked.add_(1)
         else:
             kind, rm, rv, momentum = T.NORM_GN, None, None, 0.0
-        y, stats = T.norm_act_fwd(xd, gamma.detach() if gamma is not None else None, beta.detach() if beta is not None else None, rm, rv, kind,
-                                  mod.eps, momentum, act)
-        ctx.saved = (xd, y, stats, gamma.detach() if gamma is not None else None)
+        g = gamma.detach() if gamma is not None else None
+        b = beta.detach() if beta is not None else None
+        count = None
+        if kind == T.NORM_BN_TRAIN and D.sync_bn_active():
+            # nn.SyncBatchNorm semantics (reference train.py:296): statistics over the GLOBAL batch -- per-channel (sum, sum^2, count)
+            # in fp64, one small all-reduce, then normalise; the count stays on the device for the backward pass
+            chan = D.allreduce_sums(T.bn_moments(xd))
+            y, stats = T.bn_apply_fwd(xd, chan, g, b, rm, rv, mod.eps, momentum, act)
+            count = chan[-1:]
+        else:
+            y, stats = T.norm_act_fwd(xd, g, b, rm, rv, kind, mod.eps, momentum, act)
+        ctx.saved = (xd, y, stats, g, count)
         ctx.meta = (kind, act, gamma is not None)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        xd, y, stats, gamma = ctx.saved
+        xd, y, stats, gamma, count = ctx.saved
         kind, act, affine = ctx.meta
-        dx, dg, db = T.norm_act_bwd(xd, y, gy.contiguous().float(), stats, gamma, kind, act, want_affine=affine)
+        gy = gy.contiguous().float()
+        if count is not None:
+            # dgamma / dbeta stay rank-local (they are summed by the gradient all-reduce like every parameter gradient);
+            # dx needs the global (sum dz, sum dz xhat)
+            chan, dg, db = T.bn_bwd_sums(xd, y, gy, stats, act, want_affine=affine)
+            dx = T.bn_apply_bwd(xd, y, gy, stats, gamma, D.allreduce_sums(chan), count, act)
+            return dx, dg, db, None, None
+        dx, dg, db = T.norm_act_bwd(xd, y, gy, stats, gamma, kind, act, want_affine=affine)
         return dx, dg, db, None, None
 
 

@@ -88,6 +88,35 @@ __global__ void norm_finish_kernel(const double* __restrict__ mom, float* __rest
     }
 }
 
+// cross-rank BatchNorm (SyncBatchNorm): chan[2i], chan[2i+1] = sum_n of the plane moments of channel i (fixed order)
+__global__ void norm_chan_reduce_kernel(const double* __restrict__ mom, double* __restrict__ chan, int n, int c, long long hw) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int in_ = 0; in_ < n; ++in_) { s1 += mom[2 * ((long long)in_ * c + i)]; s2 += mom[2 * ((long long)in_ * c + i) + 1]; }
+    chan[2 * i] = s1;
+    chan[2 * i + 1] = s2;
+    if (i == 0) chan[2 * c] = (double)n * (double)hw;   // this rank's element count per channel: summed by the same all-reduce
+}
+
+// ... and mean / rstd (+ running buffers) from channel sums over m = chan[2c] elements (the GLOBAL count after the all-reduce)
+__global__ void norm_finish_chan_kernel(const double* __restrict__ chan, float* __restrict__ stats, int c, float eps,
+                                        float* __restrict__ run_mean, float* __restrict__ run_var, float momentum) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c) return;
+    const double m = chan[2 * c];
+    const double mean = chan[2 * i] / m;
+    double var = chan[2 * i + 1] / m - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[2 * i] = (float)mean;
+    stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    if (run_mean != nullptr) {
+        run_mean[i] = (1.f - momentum) * run_mean[i] + momentum * (float)mean;
+        const double unb = m > 1.0 ? var * m / (m - 1.0) : var;
+        run_var[i] = (1.f - momentum) * run_var[i] + momentum * (float)unb;
+    }
+}
+
 // eval-mode BatchNorm: statistics from the running buffers
 __global__ void norm_running_stats_kernel(const float* __restrict__ run_mean, const float* __restrict__ run_var, float* __restrict__ stats, int c,
                                           float eps) {
@@ -145,8 +174,9 @@ __global__ void norm_bwd_finish_kernel(const double* __restrict__ sums, float* _
 // mode 0: eval BatchNorm (statistics are constants); 1: per-channel batch statistics (sums in chan, m = n hw); 2: per-plane (sums, m = hw)
 __global__ void norm_act_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ gy,
                                     const float* __restrict__ stats, const float* __restrict__ gamma, const double* __restrict__ sums,
-                                    const double* __restrict__ chan, float* __restrict__ dx, int n, int c, long long hw, long long total, int mode,
-                                    int act, float slope) {
+                                    const double* __restrict__ chan, float* __restrict__ dx, double m_chan, const double* __restrict__ m_dev, int c,
+                                    long long hw, long long total, int mode, int act, float slope) {
+    if (m_dev != nullptr) m_chan = *m_dev;   // cross-rank BatchNorm: the global count lives on the device (no host sync)
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const long long plane = i / hw;
         const int ch = (int)(plane % c);
@@ -156,7 +186,7 @@ __global__ void norm_act_bwd_kernel(const float* __restrict__ x, const float* __
         const float dz = gy[i] * act_dydz(y[i], act, slope);
         float r = dz;
         if (mode != 0) {
-            const double m = mode == 1 ? (double)n * (double)hw : (double)hw;
+            const double m = mode == 1 ? m_chan : (double)hw;
             const double* s = mode == 1 ? chan + 2 * ch : sums + 2 * plane;
             const float xh = (x[i] - mean) * rstd;
             r = dz - (float)(s[0] / m) - xh * (float)(s[1] / m);
@@ -234,9 +264,74 @@ extern "C" int mmif_norm_act_bwd(const float* x, const float* y, const float* gy
     if (int rc = check_launch("norm_bwd_sums")) return rc;
     hipLaunchKernelGGL(norm_bwd_finish_kernel, dim3(cdiv(c, 256)), dim3(256), 0, st, sums, dgamma, dbeta, chan, n, c);
     if (int rc = check_launch("norm_bwd_finish")) return rc;
-    hipLaunchKernelGGL(norm_act_bwd_kernel, dim3(grid1d_n(total)), dim3(256), 0, st, x, y, gy, stats, gamma, sums, chan, dx, n, c, (long long)hw,
-                       total, kind == 1 ? 0 : (kind == 0 ? 1 : 2), act, slope);
+    hipLaunchKernelGGL(norm_act_bwd_kernel, dim3(grid1d_n(total)), dim3(256), 0, st, x, y, gy, stats, gamma, sums, chan, dx, (double)n * (double)hw,
+                       (const double*)nullptr, c, (long long)hw, total, kind == 1 ? 0 : (kind == 0 ? 1 : 2), act, slope);
     return check_launch("norm_act_bwd");
+}
+
+// ---- cross-rank BatchNorm (the reference wraps its BatchNorm nets in nn.SyncBatchNorm for DDP, train.py:296): the statistics stage and the
+// apply stage are separate calls; between them the HOST all-reduces the [c][2] fp64 sums (and the element count) over RCCL.
+extern "C" int mmif_bn_moments(const float* x, double* chan_sums, int32_t n, int32_t c, int64_t hw, void* workspace, size_t workspace_bytes,
+                               void* stream) {
+    MMIF_REQUIRE(x != nullptr && chan_sums != nullptr && n > 0 && c > 0 && hw > 0, "bn_moments: bad arguments");
+    if (workspace == nullptr || workspace_bytes < mmif_norm_workspace(n, c)) {
+        set_error("bn_moments: workspace too small");
+        return MMIF_EWORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    double* mom = (double*)workspace;
+    hipLaunchKernelGGL(norm_moments_kernel, dim3(n * c), dim3(256), 0, st, x, mom, (long long)hw);
+    if (int rc = check_launch("norm_moments")) return rc;
+    hipLaunchKernelGGL(norm_chan_reduce_kernel, dim3(cdiv(c, 256)), dim3(256), 0, st, mom, chan_sums, n, c, (long long)hw);
+    return check_launch("bn_moments");
+}
+
+extern "C" int mmif_bn_apply_fwd(const float* x, const double* chan_sums, const float* gamma, const float* beta, float* y,
+                                 float* stats, float* running_mean, float* running_var, int32_t n, int32_t c, int64_t hw, float eps,
+                                 float momentum, int32_t act, float slope, void* stream) {
+    MMIF_REQUIRE(x != nullptr && chan_sums != nullptr && y != nullptr && stats != nullptr && n > 0 && c > 0 && hw > 0, "bn_apply_fwd: bad arguments");
+    MMIF_REQUIRE(act >= 0 && act <= 4, "bn_apply_fwd: bad activation");
+    MMIF_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_apply_fwd: running_mean and running_var come together");
+    hipStream_t st = (hipStream_t)stream;
+    const long long total = (long long)n * c * hw;
+    hipLaunchKernelGGL(norm_finish_chan_kernel, dim3(cdiv(c, 256)), dim3(256), 0, st, chan_sums, stats, c, eps, running_mean, running_var,
+                       momentum);
+    if (int rc = check_launch("norm_finish_chan")) return rc;
+    hipLaunchKernelGGL(norm_act_fwd_kernel, dim3(grid1d_n(total)), dim3(256), 0, st, x, stats, gamma, beta, y, c, (long long)hw, total, 1, act, slope);
+    return check_launch("bn_apply_fwd");
+}
+
+// chan_sums[c][2] = this rank's (sum dz, sum dz xhat); dgamma / dbeta (either may be NULL) are this rank's LOCAL sums -- they travel in the
+// gradient all-reduce like every other parameter gradient (torch's SyncBatchNorm does the same)
+extern "C" int mmif_bn_bwd_sums(const float* x, const float* y, const float* gy, const float* stats, double* chan_sums, float* dgamma,
+                                float* dbeta, int32_t n, int32_t c, int64_t hw, int32_t act, float slope, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+    MMIF_REQUIRE(x != nullptr && y != nullptr && gy != nullptr && stats != nullptr && chan_sums != nullptr && n > 0 && c > 0 && hw > 0,
+                 "bn_bwd_sums: bad arguments");
+    MMIF_REQUIRE(act >= 0 && act <= 4, "bn_bwd_sums: bad activation");
+    if (workspace == nullptr || workspace_bytes < mmif_norm_workspace(n, c)) {
+        set_error("bn_bwd_sums: workspace too small");
+        return MMIF_EWORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    double* sums = (double*)workspace;
+    hipLaunchKernelGGL(norm_bwd_sums_kernel, dim3(n * c), dim3(256), 0, st, x, y, gy, stats, sums, c, (long long)hw, 1, act, slope);
+    if (int rc = check_launch("norm_bwd_sums")) return rc;
+    hipLaunchKernelGGL(norm_bwd_finish_kernel, dim3(cdiv(c, 256)), dim3(256), 0, st, sums, dgamma, dbeta, chan_sums, n, c);
+    return check_launch("bn_bwd_sums");
+}
+
+extern "C" int mmif_bn_apply_bwd(const float* x, const float* y, const float* gy, const float* stats, const float* gamma,
+                                 const double* chan_sums, const double* count, float* dx, int32_t n, int32_t c, int64_t hw, int32_t act, float slope,
+                                 void* stream) {
+    MMIF_REQUIRE(x != nullptr && y != nullptr && gy != nullptr && stats != nullptr && chan_sums != nullptr && dx != nullptr && n > 0 && c > 0 &&
+                     hw > 0 && count != nullptr,
+                 "bn_apply_bwd: bad arguments");
+    MMIF_REQUIRE(act >= 0 && act <= 4, "bn_apply_bwd: bad activation");
+    const long long total = (long long)n * c * hw;
+    hipLaunchKernelGGL(norm_act_bwd_kernel, dim3(grid1d_n(total)), dim3(256), 0, (hipStream_t)stream, x, y, gy, stats, gamma, nullptr, chan_sums, dx,
+                       0.0, count, c, (long long)hw, total, 1, act, slope);
+    return check_launch("bn_apply_bwd");
 }
 
 extern "C" int mmif_act_fwd(const float* x, float* y, int64_t count, int32_t act, float slope, void* stream) {

@@ -4,28 +4,25 @@
 shuffled once.  Differences, both on purpose:
   * patches are kept as uint8 (the reference keeps float32 copies of the same integers) and `device_feed()` uploads
     the whole bank to HBM once; batches are then produced on the device (mmif.feed.DevicePatchFeed);
-  * images are read with PIL and cut with numpy strides (cv2 / patchify / natsort are not needed).
+  * images are read through data/_io.py (cv2 when importable, else PIL with OpenCV's luma) and cut with numpy strides
+    (cv2 / patchify / natsort are not needed).
 `__getitem__` keeps the reference's per-sample host semantics for code that indexes the dataset directly.
 """
 import os
 import random
-import re
 from functools import partial
 
 import numpy as np
 import torch
 from torch.utils.data import Dataset
 
+from ._io import imread_gray, list_pairs
 from .transform import norm, transform
 
 patch_size = 64
 patch_step = 64
 
 __all__ = ['FusionPatches', 'extract_patches']
-
-
-def _natural_key(s):
-    return [int(t) if t.isdigit() else t.lower() for t in re.split(r'(\d+)', s)]
 
 
 def extract_patches(img, size=patch_size, step=patch_step):
@@ -65,15 +62,7 @@ class FusionPatches(Dataset):
         return len(self.patches1)
 
     def _get_data_info(self):
-        img_dir = os.path.join(self.root_dir, 'vis') if self.set_name is None else os.path.join(self.root_dir, self.set_name, 'vis')
-        info1, info2 = [], []
-        for name in sorted(os.listdir(img_dir), key=_natural_key):
-            if name.endswith(('.bmp', '.jpg', '.png')):
-                p1 = os.path.join(img_dir, name)
-                p2 = p1.replace('vis', self.img_type)
-                if os.path.isfile(p2):
-                    info1.append(p1)
-                    info2.append(p2)
+        info1, info2 = list_pairs(self.root_dir, self.set_name, self.img_type)
         if self.set_type in ('train', 'valid'):
             from sklearn.model_selection import train_test_split
             tr1, va1, tr2, va2 = train_test_split(info1, info2, test_size=0.2, random_state=0)
@@ -82,11 +71,9 @@ class FusionPatches(Dataset):
             self.data_info = list(zip(info1, info2))
 
     def _gen_patch_pairs(self):
-        from PIL import Image
         p1, p2 = [], []
         for a, b in self.data_info:
-            i1 = np.asarray(Image.open(a).convert('L'), dtype=np.uint8)
-            i2 = np.asarray(Image.open(b).convert('L'), dtype=np.uint8)
+            i1, i2 = imread_gray(a), imread_gray(b)
             p1.append(extract_patches(i1))
             p2.append(extract_patches(i2))
         if p1:

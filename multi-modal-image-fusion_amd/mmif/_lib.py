@@ -44,7 +44,7 @@ def _load():
 lib = _load()
 
 _TP = C.POINTER(MmifTensor)
-_vp, _i32, _u64, _f32, _sz, _i64 = C.c_void_p, C.c_int32, C.c_uint64, C.c_float, C.c_size_t, C.c_int64
+_vp, _i32, _u64, _f32, _sz, _i64, _f64 = C.c_void_p, C.c_int32, C.c_uint64, C.c_float, C.c_size_t, C.c_int64, C.c_double
 
 # name -> (restype, argtypes); mirrors include/mmif.h one for one
 SIGNATURES = {
@@ -81,6 +81,10 @@ SIGNATURES = {
     "mmif_norm_workspace": (_sz, [_i32, _i32]),
     "mmif_norm_act_fwd": (_i32, [_vp] * 7 + [_i32, _i32, _i64, _i32, _f32, _f32, _i32, _f32, _vp, _sz, _vp]),
     "mmif_norm_act_bwd": (_i32, [_vp] * 8 + [_i32, _i32, _i64, _i32, _i32, _f32, _vp, _sz, _vp]),
+    "mmif_bn_moments": (_i32, [_vp, _vp, _i32, _i32, _i64, _vp, _sz, _vp]),
+    "mmif_bn_apply_fwd": (_i32, [_vp] * 8 + [_i32, _i32, _i64, _f32, _f32, _i32, _f32, _vp]),
+    "mmif_bn_bwd_sums": (_i32, [_vp] * 7 + [_i32, _i32, _i64, _i32, _f32, _vp, _sz, _vp]),
+    "mmif_bn_apply_bwd": (_i32, [_vp] * 8 + [_i32, _i32, _i64, _i32, _f32, _vp]),
     "mmif_act_fwd": (_i32, [_vp, _vp, _i64, _i32, _f32, _vp]),
     "mmif_act_bwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _f32, _vp]),
     "mmif_conv2d_reflect_fwd": (_i32, [_TP, _vp, _vp, _vp, _TP, _i32, _i32, _i32, _i32, _i32, _vp]),

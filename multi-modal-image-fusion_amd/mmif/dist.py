@@ -30,17 +30,48 @@ def shard_batch(n, rank, world):
 
 @torch.no_grad()
 def broadcast_parameters(module, src=0):
-    """ONE broadcast of all parameters (flattened) from `src`."""
-    ps = list(module.parameters())
-    if not ps:
-        return
-    flat = torch.cat([p.data.reshape(-1) for p in ps])
-    dist.broadcast(flat, src)
-    off = 0
-    for p in ps:
-        n = p.numel()
-        p.data.copy_(flat[off:off + n].view(p.shape))
-        off += n
+    """ONE broadcast of all parameters AND floating-point buffers (BatchNorm running statistics) from `src`, flattened -- what the
+    reference gets from init_weights.pth + the DDP constructor (train.py:285-297); integer buffers (num_batches_tracked) follow in a
+    second, tiny broadcast."""
+    ts = [p.data for p in module.parameters()] + [b.data for b in module.buffers() if b.is_floating_point()]
+    if ts:
+        flat = torch.cat([t.reshape(-1).float() for t in ts])
+        dist.broadcast(flat, src)
+        off = 0
+        for t in ts:
+            n = t.numel()
+            t.copy_(flat[off:off + n].view(t.shape))
+            off += n
+    ints = [b.data for b in module.buffers() if not b.is_floating_point()]
+    if ints:
+        flat = torch.cat([t.reshape(-1).to(torch.int64) for t in ints])
+        dist.broadcast(flat, src)
+        off = 0
+        for t in ints:
+            n = t.numel()
+            t.copy_(flat[off:off + n].view(t.shape))
+            off += n
+
+
+# ---- cross-rank BatchNorm -------------------------------------------------------------------------------------------------------
+_SYNC_BN = [True]
+
+
+def set_sync_batchnorm(enabled):
+    """The reference converts every BatchNorm to nn.SyncBatchNorm when it trains distributed (train.py:296); this engine does the same
+    by default: in training mode, with an initialised process group of more than one rank, BatchNorm statistics (forward) and their
+    gradient sums (backward) are all-reduced.  set_sync_batchnorm(False) restores per-rank statistics."""
+    _SYNC_BN[0] = bool(enabled)
+
+
+def sync_bn_active():
+    return _SYNC_BN[0] and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def allreduce_sums(t):
+    """SUM all-reduce of a small fp64 statistics buffer, in place (RCCL on the current stream; gloo in the CPU tests)."""
+    dist.all_reduce(t)
+    return t
 
 
 @torch.no_grad()

@@ -9,7 +9,6 @@ gradient.  The ReLU mask of a producer layer is applied by the LAST kernel that 
 tensor's gradient (mask_bits), accumulation of several consumers' contributions by accum_bits.
 """
 import os
-import threading
 
 import torch
 
@@ -17,7 +16,12 @@ from . import _lib
 from . import tensor as T
 from .tensor import BT, PackedWeights
 
-_cfg = threading.local()
+class _Cfg:
+    """process-wide settings (one process per GPU; a forward on any thread sees set_compute_dtype())"""
+    dtype = None
+
+
+_cfg = _Cfg()
 
 # base data_ptr -> flat gradient buffer (lets mmif.optim find the buffer behind a parameter's .grad view)
 FLAT_BUFFERS = {}

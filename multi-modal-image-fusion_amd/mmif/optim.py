@@ -14,7 +14,7 @@ from . import engine as E
 from ._lib import check, lib
 from .tensor import stream_ptr
 
-N_TAIL = 8  # scalar slots appended to the flat gradient buffer (losses ride along in the all-reduce)
+N_TAIL = E.GRAD_TAIL  # scalar slots appended to the flat gradient buffer (losses ride along in the all-reduce)
 
 
 class FusedClipAdam(torch.optim.Optimizer):
@@ -33,6 +33,58 @@ class FusedClipAdam(torch.optim.Optimizer):
 
     def _params(self):
         return [p for p in self.param_groups[0]["params"] if p.requires_grad]
+
+    def add_param_group(self, param_group):
+        if len(getattr(self, "param_groups", ())) >= 1:
+            raise ValueError("FusedClipAdam supports a single parameter group (the moments live in one flat buffer)")
+        super().add_param_group(param_group)
+
+    # ---- checkpointing: the moments live in flat private buffers, so expose them in torch.optim.Adam's own layout
+    # ({index: {'step', 'exp_avg', 'exp_avg_sq'}}): a resumed run continues the moments and the bias correction, and the
+    # file interchanges with a torch.optim.Adam over the same parameters.
+    def state_dict(self):
+        sd = super().state_dict()
+        state = {}
+        if self._m is not None and self._steps > 0:
+            off = 0
+            for i, p in enumerate(self.param_groups[0]["params"]):
+                if not p.requires_grad:
+                    continue
+                n = p.numel()
+                state[i] = {"step": torch.tensor(float(self._steps)),
+                            "exp_avg": self._m[off:off + n].view(p.shape).clone(),
+                            "exp_avg_sq": self._v[off:off + n].view(p.shape).clone()}
+                off += n
+        sd["state"] = state
+        return sd
+
+    @torch.no_grad()
+    def load_state_dict(self, state_dict):
+        super().load_state_dict({"state": {}, "param_groups": state_dict["param_groups"]})
+        state = state_dict.get("state", {})
+        ps = self._params()
+        self._steps = 0
+        if not state:
+            if self._m is not None:
+                self._m.zero_()
+                self._v.zero_()
+            return
+        self._flatten_params(ps)
+        self._m.zero_()
+        self._v.zero_()
+        off = 0
+        for i, p in enumerate(self.param_groups[0]["params"]):
+            if not p.requires_grad:
+                continue
+            n = p.numel()
+            st = state.get(i, state.get(str(i)))
+            if st is not None:
+                if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                    raise ValueError(f"FusedClipAdam.load_state_dict: moment shape {tuple(st['exp_avg'].shape)} != parameter shape {tuple(p.shape)}")
+                self._m[off:off + n].copy_(st["exp_avg"].reshape(-1))
+                self._v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+                self._steps = max(self._steps, int(float(st["step"])))
+            off += n
 
     def _flatten_params(self, ps):
         dev = ps[0].device

@@ -20,8 +20,13 @@ def _ptr(t):
 
 
 def require_device(t, what):
+    """Every launch goes to the CURRENT device's current stream: refuse CPU tensors and tensors of another GPU
+    (model.to('cuda:1') without torch.cuda.set_device(1) would otherwise launch on device 0 against device-1 pointers)."""
     if not t.is_cuda:
         raise RuntimeError(f"mmif: {what} must live on the GPU (got a {t.device} tensor); the HIP engine has no CPU path")
+    if t.device.index != torch.cuda.current_device():
+        raise RuntimeError(f"mmif: {what} lives on {t.device} but the current device is cuda:{torch.cuda.current_device()}; "
+                           f"call torch.cuda.set_device({t.device.index}) (one process per GPU) before running the model")
 
 
 class BT:
@@ -398,6 +403,47 @@ def norm_act_bwd(x, y, gy, stats, gamma, kind, act, slope=0.2, want_affine=True)
     check(lib.mmif_norm_act_bwd(_ptr(x), _ptr(y), _ptr(gy), _ptr(stats), _ptr(gamma), _ptr(dx), _ptr(dg), _ptr(db), n, c, hw, kind, act,
                                 float(slope), _ptr(ws), ws.numel() * 4, stream_ptr()), "norm_act_bwd")
     return dx, dg, db
+
+
+# cross-rank BatchNorm: statistics and apply stages (the caller all-reduces `chan` = [c][2] fp64 sums in between; mmif/dist.py)
+def bn_moments(x):
+    _f32c(x, "x")
+    n, c = x.shape[0], x.shape[1]
+    chan = torch.empty(2 * c + 1, dtype=torch.float64, device=x.device)   # [c][2] sums + the element count (rides in the all-reduce)
+    ws = _norm_ws(n, c, x.device)
+    check(lib.mmif_bn_moments(_ptr(x), _ptr(chan), n, c, x[0, 0].numel(), _ptr(ws), ws.numel() * 4, stream_ptr()), "bn_moments")
+    return chan
+
+
+def bn_apply_fwd(x, chan, gamma, beta, running_mean, running_var, eps, momentum, act, slope=0.2):
+    n, c = x.shape[0], x.shape[1]
+    y = torch.empty_like(x)
+    stats = torch.empty(2 * c, dtype=torch.float32, device=x.device)
+    check(lib.mmif_bn_apply_fwd(_ptr(x), _ptr(chan), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(stats), _ptr(running_mean),
+                                _ptr(running_var), n, c, x[0, 0].numel(), float(eps), float(momentum), act, float(slope), stream_ptr()),
+          "bn_apply_fwd")
+    return y, stats
+
+
+def bn_bwd_sums(x, y, gy, stats, act, slope=0.2, want_affine=True):
+    _f32c(x, "x"), _f32c(y, "y"), _f32c(gy, "gy")
+    n, c = x.shape[0], x.shape[1]
+    chan = torch.empty(2 * c, dtype=torch.float64, device=x.device)
+    dg = torch.empty(c, dtype=torch.float32, device=x.device) if want_affine else None
+    db = torch.empty(c, dtype=torch.float32, device=x.device) if want_affine else None
+    ws = _norm_ws(n, c, x.device)
+    check(lib.mmif_bn_bwd_sums(_ptr(x), _ptr(y), _ptr(gy), _ptr(stats), _ptr(chan), _ptr(dg), _ptr(db), n, c, x[0, 0].numel(), act,
+                               float(slope), _ptr(ws), ws.numel() * 4, stream_ptr()), "bn_bwd_sums")
+    return chan, dg, db
+
+
+def bn_apply_bwd(x, y, gy, stats, gamma, chan, count, act, slope=0.2):
+    """count: 1-element fp64 device tensor (the forward's all-reduced element count)"""
+    n, c = x.shape[0], x.shape[1]
+    dx = torch.empty_like(x)
+    check(lib.mmif_bn_apply_bwd(_ptr(x), _ptr(y), _ptr(gy), _ptr(stats), _ptr(gamma), _ptr(chan), _ptr(count), _ptr(dx), n, c,
+                                x[0, 0].numel(), act, float(slope), stream_ptr()), "bn_apply_bwd")
+    return dx
 
 
 def act_fwd(x, act, slope=0.2):

@@ -26,6 +26,7 @@ from torch.utils.data import DataLoader, DistributedSampler, TensorDataset
 from common import *
 from core.loss import GradLoss, PixelLoss, SSIMLoss
 from core.model import *
+from data._io import imwrite
 from mmif import engine as E
 from mmif.dist import broadcast_parameters
 from mmif.optim import FusedClipAdam
@@ -92,11 +93,7 @@ def train_model(model, data_loader, loss_fn1, loss_fn2, loss_fn3, epoch, mode='t
     if local_rank == 0:
         logger.info(f'cost time: {cost_time:.3f}s\n')
         if save_dir is not None and imgf is not None:
-            try:
-                import cv2
-                cv2.imwrite(os.path.join(save_dir, f'{epoch_idx:0>2}.png'), save_result(imgf[0], img1[0], img2[0]))
-            except ImportError:
-                pass
+            imwrite(os.path.join(save_dir, f'{epoch_idx:0>2}.png'), save_result(imgf[0], img1[0], img2[0]))
     if is_distributed:
         dist.barrier()
     return loss.avg
@@ -132,7 +129,7 @@ def make_loaders():
             return TensorDataset(torch.rand(n, 1, 256, 256, generator=g), torch.rand(n, 1, 256, 256, generator=g))
         train_set, valid_set = ds(args.synthetic), ds(max(batch_size, args.synthetic // 8))
     else:
-        # whole-image training: the reference's own FusionDataset (cv2 / torchvision based, data/dataset.py) plugs in unchanged
+        # whole-image training (reference train.py:193-202): data/dataset.py mirrors the reference's FusionDataset
         data_dir = os.path.join(BASE_DIR, '..', 'datasets', args.data)
         assert os.path.isdir(data_dir), f'{data_dir} is not a dir (use --synthetic N to train without a dataset)'
         from data.dataset import FusionDataset as Data
@@ -148,9 +145,7 @@ def make_loaders():
 if __name__ == '__main__':
     setup_seed(0)
     args = get_train_args()
-    lr = 1e-4 if args.lr is None else args.lr
-    batch_size = 16 if args.bs is None else args.bs
-    num_epochs = 12 if args.epoch is None else args.epoch
+    lr, batch_size, num_epochs = args.lr, args.bs, args.epoch
     milestones = (round(num_epochs * 2 / 3), round(num_epochs * 8 / 9))
 
     env_world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -165,7 +160,12 @@ if __name__ == '__main__':
     torch.cuda.set_device(device)
     E.set_compute_dtype(args.dtype)
 
-    logger, log_dir = make_logger(os.path.join(BASE_DIR, '..', 'checkpoints')) if local_rank == 0 else (None, None)
+    log_dir, logger = make_logger(BASE_DIR) if local_rank == 0 else (None, None)
+    train_save_dir = valid_save_dir = None
+    if local_rank == 0:   # reference train.py:172-178
+        train_save_dir, valid_save_dir = os.path.join(log_dir, 'train'), os.path.join(log_dir, 'valid')
+        os.makedirs(train_save_dir, exist_ok=True)
+        os.makedirs(valid_save_dir, exist_ok=True)
     train_loader, valid_loader, train_sampler = make_loaders()
 
     model = {'PFNetv1': PFNetv1, 'PFNetv2': PFNetv2, 'DenseFuse': DenseFuse, 'VIFNet': VIFNet, 'NestFuse': NestFuse, 'RFNNest': RFNNest,
@@ -179,16 +179,16 @@ if __name__ == '__main__':
     optimizer = FusedClipAdam(model.parameters(), lr=lr, betas=(0.9, 0.999), max_norm=5.0 if args.clip_grad else None)
     epoch_scheduler = MultiStepLR(optimizer, milestones=milestones, gamma=0.1)
     if args.warmup:
-        warmup_scheduler = WarmupLR(optimizer, len(train_loader))
+        warmup_scheduler = WarmupLR(optimizer, 0.001, len(train_loader))   # reference train.py:323
 
     best_loss, best_epoch = 0.0, 0
     for epoch in range(num_epochs):
         if train_sampler is not None:
             train_sampler.set_epoch(epoch)
         model.train()
-        train_loss = train_model(model, train_loader, loss_fn1, loss_fn2, loss_fn3, epoch, 'train', log_dir)
+        train_loss = train_model(model, train_loader, loss_fn1, loss_fn2, loss_fn3, epoch, 'train', train_save_dir)
         model.eval()
-        valid_loss = train_model(model, valid_loader, loss_fn1, loss_fn2, loss_fn3, epoch, 'valid')
+        valid_loss = train_model(model, valid_loader, loss_fn1, loss_fn2, loss_fn3, epoch, 'valid', valid_save_dir)
         epoch_scheduler.step()
         if local_rank == 0:
             logger.info(f'epoch: {epoch + 1:0>2}, train loss: {train_loss:.4f}, valid loss: {valid_loss:.4f}, lr: {optimizer.param_groups[0]["lr"]}')

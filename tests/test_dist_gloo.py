@@ -87,3 +87,121 @@ def test_data_parallel_equivalence_gloo_world2():
     got = res[0]["flat"][:full.size]
     assert np.abs(got - full).max() <= 2e-5 * np.abs(full).max()
     np.testing.assert_allclose(res[0]["scal"], [losses[3], losses[0], losses[1], losses[2]], rtol=2e-5)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Cross-rank BatchNorm (the reference converts to nn.SyncBatchNorm for DDP, train.py:296): the ORCHESTRATION in
+# core.block._NormActFn -- which sums are all-reduced, that the element count rides along, that dgamma / dbeta stay rank-local --
+# with the four staged C-ABI calls replaced by torch restatements of their contracts (include/mmif.h), so it runs without a GPU.
+# The kernels themselves are checked on the device in tests/test_gpu_dist.py.
+def _bn_stage_stubs(T):
+    def act_dydz(y, act):
+        return {0: torch.ones_like(y), 1: (y > 0).to(y.dtype)}[act]
+
+    def bn_moments(x):
+        n, c = x.shape[:2]
+        s1 = x.double().sum(dim=(0, 2, 3))
+        s2 = (x.double() ** 2).sum(dim=(0, 2, 3))
+        return torch.cat([torch.stack([s1, s2], 1).reshape(-1), torch.tensor([float(n * x[0, 0].numel())], dtype=torch.float64)])
+
+    def bn_apply_fwd(x, chan, gamma, beta, rm, rv, eps, momentum, act, slope=0.2):
+        c = x.shape[1]
+        m = chan[-1]
+        mean = chan[:2 * c].view(c, 2)[:, 0] / m
+        var = (chan[:2 * c].view(c, 2)[:, 1] / m - mean * mean).clamp(min=0)
+        rstd = 1.0 / torch.sqrt(var + eps)
+        if rm is not None:
+            rm.mul_(1 - momentum).add_(momentum * mean.float())
+            rv.mul_(1 - momentum).add_(momentum * (var * m / (m - 1)).float())
+        z = (x - mean.float().view(1, c, 1, 1)) * rstd.float().view(1, c, 1, 1) * gamma.view(1, c, 1, 1) + beta.view(1, c, 1, 1)
+        y = torch.relu(z) if act == 1 else z
+        return y, torch.stack([mean.float(), rstd.float()], 1).reshape(-1)
+
+    def bn_bwd_sums(x, y, gy, stats, act, slope=0.2, want_affine=True):
+        c = x.shape[1]
+        st = stats.view(c, 2)
+        dz = (gy * act_dydz(y, act)).double()
+        xh = ((x - st[:, 0].view(1, c, 1, 1)) * st[:, 1].view(1, c, 1, 1)).double()
+        s1, s2 = dz.sum(dim=(0, 2, 3)), (dz * xh).sum(dim=(0, 2, 3))
+        return torch.stack([s1, s2], 1).reshape(-1), s2.float(), s1.float()
+
+    def bn_apply_bwd(x, y, gy, stats, gamma, chan, count, act, slope=0.2):
+        c = x.shape[1]
+        st = stats.view(c, 2)
+        m = count[0]
+        dz = gy * act_dydz(y, act)
+        xh = (x - st[:, 0].view(1, c, 1, 1)) * st[:, 1].view(1, c, 1, 1)
+        ch = chan.view(c, 2)
+        r = dz - (ch[:, 0] / m).float().view(1, c, 1, 1) - xh * (ch[:, 1] / m).float().view(1, c, 1, 1)
+        return gamma.view(1, c, 1, 1) * st[:, 1].view(1, c, 1, 1) * r
+
+    T.bn_moments, T.bn_apply_fwd, T.bn_bwd_sums, T.bn_apply_bwd = bn_moments, bn_apply_fwd, bn_bwd_sums, bn_apply_bwd
+    T.require_device = lambda t, what: None
+
+
+def _bn_inputs():
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(6, 3, 5, 4, generator=g) * 2.0 + 0.5
+    w = torch.randn(6, 3, 5, 4, generator=g)       # loss = sum(y * w) / per-rank batch (a per-rank mean, like the fusion losses)
+    return x, w
+
+
+def _bn_worker(rank, world, port, out):
+    for p in (ROOT, os.path.join(ROOT, "multi-modal-image-fusion_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    import torch.nn as nn
+    import core.block as B
+    from mmif import tensor as T
+    from mmif.dist import broadcast_parameters, setup_dist, sync_bn_active
+    _bn_stage_stubs(T)
+    setup_dist(rank, world, backend="gloo")
+    assert sync_bn_active()
+    bn = nn.BatchNorm2d(3)
+    with torch.no_grad():
+        bn.weight.copy_(torch.tensor([1.5, -0.7, 0.3]) + rank)       # ranks start apart: the broadcast must align them,
+        bn.bias.copy_(torch.tensor([0.1, 0.2, -0.3]))
+        bn.running_mean.fill_(float(rank))                          # ... buffers included
+        bn.num_batches_tracked.fill_(7 * rank)
+    broadcast_parameters(bn, 0)
+    assert float(bn.running_mean.abs().max()) == 0.0 and int(bn.num_batches_tracked) == 0
+    bn.train()
+    x, w = _bn_inputs()
+    lo, hi = rank * 2, rank * 2 + (2 if rank == 0 else 4)             # UNEQUAL shards (2 and 4 samples): the count must be reduced too
+    xs = x[lo:hi].clone().requires_grad_(True)
+    y = B._NormActFn.apply(xs, bn.weight, bn.bias, bn, 1)
+    (y * w[lo:hi]).sum().backward()
+    out[rank] = dict(y=y.detach().numpy(), dx=xs.grad.numpy(), dg=bn.weight.grad.numpy(), db=bn.bias.grad.numpy(),
+                     rm=bn.running_mean.numpy().copy(), rv=bn.running_var.numpy().copy(), nbt=int(bn.num_batches_tracked))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sync_batchnorm_orchestration_gloo_world2():
+    import torch.nn as nn
+    port = _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_bn_worker, args=(2, port, out), nprocs=2, join=True)
+        res = {k: dict(v) for k, v in out.items()}
+    x, w = _bn_inputs()
+    bn = nn.BatchNorm2d(3).double()
+    with torch.no_grad():
+        bn.weight.copy_(torch.tensor([1.5, -0.7, 0.3]))
+        bn.bias.copy_(torch.tensor([0.1, 0.2, -0.3]))
+    xf = x.double().requires_grad_(True)
+    y = torch.relu(bn(xf))
+    (y * w.double()).sum().backward()
+    got_y = np.concatenate([res[0]["y"], res[1]["y"]])
+    got_dx = np.concatenate([res[0]["dx"], res[1]["dx"]])
+    np.testing.assert_allclose(got_y, y.detach().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(got_dx, xf.grad.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(res[0]["dg"] + res[1]["dg"], bn.weight.grad.numpy(), rtol=1e-4, atol=1e-5)   # summed by the gradient all-reduce
+    np.testing.assert_allclose(res[0]["db"] + res[1]["db"], bn.bias.grad.numpy(), rtol=1e-4, atol=1e-5)
+    for k in ("rm", "rv"):
+        assert np.array_equal(res[0][k], res[1][k])                       # every rank holds the same running statistics
+    np.testing.assert_allclose(res[0]["rm"], bn.running_mean.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(res[0]["rv"], bn.running_var.numpy(), rtol=1e-5, atol=1e-6)
+    assert res[0]["nbt"] == res[1]["nbt"] == 1

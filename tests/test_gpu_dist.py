@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-def _run(rank, world, port, out):
+def _run(rank, world, port, out, model_name="PFNetv1"):
     for p in (ROOT, os.path.join(ROOT, "multi-modal-image-fusion_amd"), os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -41,12 +41,13 @@ def _run(rank, world, port, out):
     dev = torch.device("cuda", 0)
     E.set_compute_dtype("fp32")
     torch.manual_seed(10 + rank)                      # different initial weights per rank: the broadcast must fix that
-    model = M.PFNetv1().to(dev)
+    model = getattr(M, model_name)().to(dev)
     if world > 1:
         broadcast_parameters(model, 0)
     else:
         torch.manual_seed(10)
-        model = M.PFNetv1().to(dev)
+        model = getattr(M, model_name)().to(dev)
+    model.train()
     opt = FusedClipAdam(model.parameters(), lr=1e-3, betas=(0.9, 0.999), max_norm=5.0)
     l1, l2, l3 = SSIMLoss('ssim', weight=1.0), PixelLoss('l1', weight=0.01), GradLoss('l1', weight=0.1).to(dev)
     lo, hi = shard_batch(SHAPE[0], rank, world)
@@ -62,7 +63,7 @@ def _run(rank, world, port, out):
         opt.step(scalars=[tot, a, b, c])
         scal = opt.reduced_scalars.detach().cpu().numpy()
     torch.cuda.synchronize()
-    out[(world, rank)] = dict(P={k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}, scal=scal)
+    out[(model_name, world, rank)] = dict(P={k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}, scal=scal)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -75,9 +76,68 @@ def test_two_rank_step_equals_single_process_full_batch():
         mp.spawn(_run, args=(2, port, out), nprocs=2, join=True)
         mp.spawn(_run, args=(1, port, out), nprocs=1, join=True)
         res = {k: dict(v) for k, v in out.items()}
-    single, r0, r1 = res[(1, 0)], res[(2, 0)], res[(2, 1)]
+    single, r0, r1 = res[("PFNetv1", 1, 0)], res[("PFNetv1", 2, 0)], res[("PFNetv1", 2, 1)]
     for k in single["P"]:
         assert np.array_equal(r0["P"][k], r1["P"][k]), f"ranks diverged on {k}"
         ref = single["P"][k]
         assert np.abs(r0["P"][k] - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), k
     assert np.allclose(r0["scal"], r1["scal"]) and np.allclose(r0["scal"], single["scal"], rtol=2e-5, atol=1e-6)
+
+
+def test_two_rank_batchnorm_model_equals_single_process_full_batch():
+    """A BatchNorm net (DIFNet, reference core/model.py) under data parallel: the reference converts to nn.SyncBatchNorm
+    (train.py:296), i.e. statistics over the GLOBAL batch -- the two-rank run must reproduce the one-process full-batch run, running
+    buffers included, and both ranks must hold identical buffers (only rank 0's reach the checkpoint)."""
+    port = _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_run, args=(2, port, out, "DIFNet"), nprocs=2, join=True)
+        mp.spawn(_run, args=(1, port, out, "DIFNet"), nprocs=1, join=True)
+        res = {k: dict(v) for k, v in out.items()}
+    single, r0, r1 = res[("DIFNet", 1, 0)], res[("DIFNet", 2, 0)], res[("DIFNet", 2, 1)]
+    assert any("running_mean" in k for k in single["P"])
+    for k in single["P"]:
+        assert np.array_equal(r0["P"][k], r1["P"][k]), f"ranks diverged on {k}"
+        ref = single["P"][k]
+        assert np.abs(r0["P"][k].astype(np.float64) - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), k
+    assert np.allclose(r0["scal"], r1["scal"]) and np.allclose(r0["scal"], single["scal"], rtol=1e-4, atol=1e-6)
+
+
+def test_staged_batchnorm_calls_equal_the_fused_ones():
+    """mmif_bn_moments -> mmif_bn_apply_fwd and mmif_bn_bwd_sums -> mmif_bn_apply_bwd without an all-reduce in between == kind 0 of
+    mmif_norm_act_fwd / _bwd (include/mmif.h), bit for bit, running buffers included."""
+    import sys
+    for p in (ROOT, os.path.join(ROOT, "multi-modal-image-fusion_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from mmif import tensor as T
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(3, 5, 9, 7, generator=g) * 1.7 + 0.4).to(dev)
+    gy = torch.randn(3, 5, 9, 7, generator=g).to(dev)
+    gamma, beta = torch.randn(5, generator=g).to(dev), torch.randn(5, generator=g).to(dev)
+    for act in (0, 1, 2, 3):
+        rm1, rv1 = torch.zeros(5, device=dev), torch.ones(5, device=dev)
+        rm2, rv2 = torch.zeros(5, device=dev), torch.ones(5, device=dev)
+        y1, st1 = T.norm_act_fwd(x, gamma, beta, rm1, rv1, T.NORM_BN_TRAIN, 1e-5, 0.1, act)
+        chan = T.bn_moments(x)
+        assert float(chan[-1]) == 3 * 9 * 7
+        y2, st2 = T.bn_apply_fwd(x, chan, gamma, beta, rm2, rv2, 1e-5, 0.1, act)
+        assert torch.equal(y1, y2) and torch.equal(st1, st2) and torch.equal(rm1, rm2) and torch.equal(rv1, rv2)
+        dx1, dg1, db1 = T.norm_act_bwd(x, y1, gy, st1, gamma, T.NORM_BN_TRAIN, act)
+        ch2, dg2, db2 = T.bn_bwd_sums(x, y2, gy, st2, act)
+        dx2 = T.bn_apply_bwd(x, y2, gy, st2, gamma, ch2, chan[-1:], act)
+        assert torch.equal(dx1, dx2) and torch.equal(dg1, dg2) and torch.equal(db1, db2)
+    # against torch's own BatchNorm2d (CPU, fp64)
+    bn = torch.nn.BatchNorm2d(5).double()
+    with torch.no_grad():
+        bn.weight.copy_(gamma.cpu())
+        bn.bias.copy_(beta.cpu())
+    xf = x.cpu().double().requires_grad_(True)
+    yr = torch.relu(bn(xf))
+    (yr * gy.cpu().double()).sum().backward()
+    y2, st2 = T.bn_apply_fwd(x, T.bn_moments(x), gamma, beta, None, None, 1e-5, 0.1, 1)
+    ch2, dg2, db2 = T.bn_bwd_sums(x, y2, gy, st2, 1)
+    dx2 = T.bn_apply_bwd(x, y2, gy, st2, gamma, ch2, chan[-1:], 1)
+    assert (y2.cpu().double() - yr).abs().max() < 1e-5 and (dx2.cpu().double() - xf.grad).abs().max() < 1e-4
+    assert (dg2.cpu().double() - bn.weight.grad).abs().max() < 1e-3 and (db2.cpu().double() - bn.bias.grad).abs().max() < 1e-3

@@ -361,3 +361,68 @@ def test_fused_clip_adam_with_unused_parameters_matches_torch_adam():
     fresh = dict(M.PMGI().named_parameters())
     for k in ("transfer1.1.layers.0.weight", "transfer1.1.layers.1.weight"):   # never used => never updated
         assert torch.equal(dict(m1.named_parameters())[k].detach().cpu(), fresh[k].detach())
+
+
+def _one_step(m, opt, losses, step):
+    shape = (2, 1, 32, 32)
+    i1, i2 = tg(O.closed_form_image(shape, 0.21 + step)), tg(O.closed_form_image(shape, 1.43 + step))
+    opt.zero_grad(set_to_none=True)
+    f = m(i1, i2)
+    tot = losses[0](i1, i2, f) + losses[1](i1, i2, f, mode='max') + losses[2](i1, i2, f, mode='max')
+    tot.backward()
+    opt.step()
+
+
+def test_optimizer_state_dict_resumes_moments_and_bias_correction():
+    """FusedClipAdam keeps exp_avg / exp_avg_sq / step in flat private buffers; state_dict() / load_state_dict() expose them in
+    torch.optim.Adam's layout, so a resumed run takes exactly the step the uninterrupted run takes."""
+    from core.loss import GradLoss, PixelLoss, SSIMLoss
+    from mmif.optim import FusedClipAdam
+    losses = (SSIMLoss('ssim', weight=1.0), PixelLoss('l1', weight=0.01), GradLoss('l1', weight=0.1).to("cuda:0"))
+    with dtype_ctx("fp32"):
+        m = _model("DenseFuse", 2)
+        opt = FusedClipAdam(m.parameters(), lr=1e-3, betas=(0.9, 0.999), max_norm=5.0)
+        assert opt.state_dict()["state"] == {}
+        for step in range(2):
+            _one_step(m, opt, losses, step)
+        sd_m = {k: v.clone() for k, v in m.state_dict().items()}
+        sd_o = opt.state_dict()
+        n_params = len(list(m.parameters()))
+        assert sorted(sd_o["state"]) == list(range(n_params)) and float(sd_o["state"][0]["step"]) == 2.0
+        assert all(sd_o["state"][i]["exp_avg"].shape == p.shape for i, p in enumerate(m.parameters()))
+        _one_step(m, opt, losses, 2)
+        want = {k: v.clone() for k, v in m.state_dict().items()}
+
+        m2 = _model("DenseFuse", 5)                      # other weights: everything must come from the checkpoint
+        m2.load_state_dict(sd_m)
+        opt2 = FusedClipAdam(m2.parameters(), lr=7.0, max_norm=5.0)
+        opt2.load_state_dict(sd_o)
+        assert opt2.param_groups[0]["lr"] == 1e-3
+        _one_step(m2, opt2, losses, 2)
+        for k, v in m2.state_dict().items():
+            assert torch.equal(v, want[k]), k
+        # a fresh optimiser (moments restarted) does NOT land there: the test can tell the difference
+        m3 = _model("DenseFuse", 5)
+        m3.load_state_dict(sd_m)
+        opt3 = FusedClipAdam(m3.parameters(), lr=1e-3, max_norm=5.0)
+        _one_step(m3, opt3, losses, 2)
+        assert any(not torch.equal(v, want[k]) for k, v in m3.state_dict().items())
+        # the layout is torch.optim.Adam's: it loads there
+        ref_opt = torch.optim.Adam(m3.parameters(), lr=1e-3)
+        ref_opt.load_state_dict(sd_o)
+        st = ref_opt.state[next(iter(m3.parameters()))]
+        assert float(st["step"]) == 2.0 and torch.equal(st["exp_avg"].cpu(), sd_o["state"][0]["exp_avg"].cpu())
+        with pytest.raises(ValueError):
+            opt3.add_param_group({"params": [torch.nn.Parameter(torch.zeros(1, device="cuda:0"))]})
+
+
+def test_compute_dtype_is_process_wide():
+    """set_compute_dtype() on one thread governs a forward on any other thread (one process per GPU)."""
+    import threading
+    from mmif import engine as E
+    with dtype_ctx("bf16"):
+        seen = []
+        t = threading.Thread(target=lambda: seen.append(E.compute_dtype()))
+        t.start()
+        t.join()
+        assert seen == [torch.bfloat16]

@@ -1,0 +1,75 @@
+"""The entry points end to end on the device, on a small image dataset written to disk: train.py (whole-image mode through
+data/dataset.py, and patch mode through the on-device feed) and test.py (reference test.py:72-188: dataset -> checkpoint ->
+per-image SSIM + NN.bmp outputs + result lines appended to the checkpoint's train.log)."""
+import glob
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+from PIL import Image
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "multi-modal-image-fusion_amd")
+DATA = "_gputest_data"
+
+
+def _img(h, w, seed):
+    y, x = np.mgrid[0:h, 0:w]
+    return ((np.sin(y * 0.11 + seed) + np.cos(x * 0.07 + seed * 0.5)) * 60 + 128 + ((y * x + seed) % 17)).clip(0, 255).astype(np.uint8)
+
+
+@pytest.fixture(scope="module")
+def dataset():
+    root = os.path.join(ROOT, "datasets", DATA)
+    shutil.rmtree(root, ignore_errors=True)
+    before = set(os.listdir(os.path.join(ROOT, "checkpoints"))) if os.path.isdir(os.path.join(ROOT, "checkpoints")) else set()
+    for split, sizes in (("train", [(272, 300)] * 4 + [(200, 260)] + [(256, 256)] * 5), ("test", [(120, 136), (97, 131), (64, 64)])):
+        for sub in ("vis", "ir"):
+            os.makedirs(os.path.join(root, split, sub))
+        for i, (h, w) in enumerate(sizes):
+            Image.fromarray(_img(h, w, i)).save(os.path.join(root, split, "vis", f"{i + 1}.png"))
+            Image.fromarray(_img(h, w, 50 + i)).save(os.path.join(root, split, "ir", f"{i + 1}.png"))
+    yield root
+    shutil.rmtree(root, ignore_errors=True)
+    ck = os.path.join(ROOT, "checkpoints")
+    if os.path.isdir(ck):
+        for d in set(os.listdir(ck)) - before:
+            shutil.rmtree(os.path.join(ck, d), ignore_errors=True)
+
+
+def _run(script, *args):
+    r = subprocess.run([sys.executable, os.path.join(PKG, script), *args], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, f"{script} {' '.join(args)} failed:\n{r.stdout[-3000:]}\n{r.stderr[-3000:]}"
+    return r.stdout + r.stderr
+
+
+def _newest_ckpt():
+    dirs = sorted(glob.glob(os.path.join(ROOT, "checkpoints", "*")), key=os.path.getmtime)
+    assert dirs, "train.py wrote no checkpoint folder"
+    return dirs[-1]
+
+
+def test_train_whole_images_then_test(dataset):
+    out = _run("train.py", "--data", DATA, "--use_patches", "", "--bs", "2", "--epoch", "2", "--model", "PFNetv1", "--warmup", "1")
+    assert "training done" in out and "train loss" in out
+    ck = _newest_ckpt()
+    for f in ("epoch_best.pth", "epoch_last.pth", "train.log", os.path.join("train", "01.png"), os.path.join("valid", "02.png")):
+        assert os.path.isfile(os.path.join(ck, f)), f
+    w, h = Image.open(os.path.join(ck, "train", "01.png")).size
+    assert (w, h) == (3 * 256, 256)                       # img1 | img2 | fused side by side (common.save_result)
+    out = _run("test.py", "--data", DATA, "--ckpt", os.path.basename(ck), "--model", "PFNetv1")
+    assert out.count("iter: ") == 3 and "fps:" in out
+    for i, (hh, ww) in enumerate([(120, 136), (97, 131), (64, 64)]):
+        im = Image.open(os.path.join(ck, DATA, f"{i + 1:0>2}.bmp"))
+        assert im.size == (ww, hh)
+    log = open(os.path.join(ck, "train.log")).read()
+    assert "iter: 03, ssim:" in log and "fps:" in log
+
+
+def test_train_patches_on_device_feed(dataset):
+    out = _run("train.py", "--data", DATA, "--bs", "8", "--epoch", "1", "--model", "DenseFuse", "--dtype", "bf16")
+    assert "training done" in out

@@ -210,15 +210,22 @@ def test_common_plumbing():
     assert m.avg == 3.0 and m.count == 8
     p = nn.Parameter(torch.zeros(1))
     opt = torch.optim.SGD([p], lr=1.0)
-    sch = C.WarmupLR(opt, warmup_iters=10, start_factor=0.001)
+    sch = C.WarmupLR(opt, 0.001, 10)   # the reference's call form (train.py:323): (optimizer, warmup_factor, warmup_iters)
     lrs = []
     for _ in range(12):
         lrs.append(opt.param_groups[0]["lr"])
         opt.step()
         sch.step()
-    assert abs(lrs[0] - 0.001) < 1e-9 and abs(lrs[10] - 1.0) < 1e-9 and lrs[11] == 1.0 and lrs == sorted(lrs)
+    want = [0.001 + 0.999 * i / 10 for i in range(10)] + [1.0, 1.0]   # common.py:156-166 'linear'
+    assert np.allclose(lrs, want, atol=1e-12) and lrs == sorted(lrs)
+    opt2 = torch.optim.SGD([p], lr=2.0)
+    C.WarmupLR(opt2, warmup_factor=0.25, warmup_iters=3, warmup_method="constant")
+    assert opt2.param_groups[0]["lr"] == 0.5
+    with pytest.raises(ValueError):
+        C.WarmupLR(torch.optim.SGD([p], lr=1.0), 0.1, 3, "cosine")
     img = torch.tensor([[[-0.5, 0.0], [0.5, 1.5]]])
-    assert C.denorm(img).tolist() == [[[0], [0]], [[128], [255]]]
+    assert C.denorm(img).tolist() == [[[0], [0]], [[127], [255]]]   # truncation, as data/transform.py:32-35
+    assert C.save_result(img).tolist() == C.denorm(img).tolist()
     assert abs(float(C.norm(np.array([255.0]))[0]) - 1.0) < 1e-7
     import sys
     argv, sys.argv = sys.argv, ["train.py", "--data", "roadscene", "--bs", "8", "--model", "DenseFuse"]
@@ -226,4 +233,25 @@ def test_common_plumbing():
         a = C.get_train_args()
     finally:
         sys.argv = argv
-    assert a.data == "roadscene" and a.bs == 8 and a.lr is None and a.clip_grad is True and a.model == "DenseFuse"
+    assert a.data == "roadscene" and a.bs == 8 and a.lr == 1e-4 and a.epoch == 12 and a.clip_grad is True and a.model == "DenseFuse"
+    argv, sys.argv = sys.argv, ["test.py"]
+    try:
+        t = C.get_test_args()
+    finally:
+        sys.argv = argv
+    assert t.data == "roadscene" and t.ckpt == "2023-02-26_23-15" and t.use_gpu is True
+
+
+def test_make_logger_layout(tmp_path):
+    """common.py:200-210: <root>/../checkpoints/<time>/train.log, returns (log_dir, logger)"""
+    import common as C
+    root = tmp_path / "pkg"
+    root.mkdir()
+    log_dir, logger = C.make_logger(str(root))
+    assert os.path.isfile(os.path.join(log_dir, "train.log"))
+    assert os.path.normpath(os.path.dirname(log_dir)) == str(tmp_path / "checkpoints")
+    logger.info("hello")
+    for h in list(logger.handlers):
+        h.flush()
+        logger.removeHandler(h)
+    assert "hello" in open(os.path.join(log_dir, "train.log")).read()
