@@ -63,7 +63,13 @@ def _run(rank, world, port, out, model_name="PFNetv1"):
         opt.step(scalars=[tot, a, b, c])
         scal = opt.reduced_scalars.detach().cpu().numpy()
     torch.cuda.synchronize()
-    out[(model_name, world, rank)] = dict(P={k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}, scal=scal)
+    # a conv bias in front of a BatchNorm has an exactly-zero true gradient (the norm removes the mean): what the kernels produce for
+    # it is rounding noise, which Adam's g / sqrt(v) turns into +-lr steps -- such parameters cannot be compared between runs
+    import torch.nn as nn
+    from core.block import ConvLayer
+    noise = [f"{n}.layers.0.bias" for n, mod in model.named_modules()
+             if isinstance(mod, ConvLayer) and mod.norm is nn.BatchNorm2d and mod.layers[0].bias is not None]
+    out[(model_name, world, rank)] = dict(noise=noise, P={k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}, scal=scal)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -95,9 +101,11 @@ def test_two_rank_batchnorm_model_equals_single_process_full_batch():
         mp.spawn(_run, args=(1, port, out, "DIFNet"), nprocs=1, join=True)
         res = {k: dict(v) for k, v in out.items()}
     single, r0, r1 = res[("DIFNet", 1, 0)], res[("DIFNet", 2, 0)], res[("DIFNet", 2, 1)]
-    assert any("running_mean" in k for k in single["P"])
+    assert any("running_mean" in k for k in single["P"]) and len(single["noise"]) >= 5
     for k in single["P"]:
         assert np.array_equal(r0["P"][k], r1["P"][k]), f"ranks diverged on {k}"
+        if k in single["noise"]:
+            continue
         ref = single["P"][k]
         assert np.abs(r0["P"][k].astype(np.float64) - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), k
     assert np.allclose(r0["scal"], r1["scal"]) and np.allclose(r0["scal"], single["scal"], rtol=1e-4, atol=1e-6)
