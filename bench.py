@@ -148,8 +148,9 @@ def main():
         for _ in range(2):
             step()
     hbm_tag = args.hbm_tag
-    if hbm_tag == "auto":   # the widest thin layer of the model's encoder (Cout = 16): 48 -> 16 forward
-        hbm_tag = {"PFNetv1": "encode1.1.2:fwd", "DenseFuse": "encode.1.2:fwd", "PFNetv2": "encode.1.2:fwd", "VIFNet": "encode.1.2:fwd"}.get(args.model, "") if args.mode == "train" else ""
+    enc_stream = args.dtype == "bf16" and os.environ.get("MMIF_ENC_STREAM", "1") != "0" and args.model in ("PFNetv1", "DenseFuse", "PFNetv2", "VIFNet")
+    if hbm_tag == "auto":   # the encoder: ONE streaming launch for its 2 x 4 layers, or (layer-wise) its widest thin layer 48 -> 16
+        hbm_tag = "encode:fwd" if enc_stream else ({"PFNetv1": "encode1.1.2:fwd", "DenseFuse": "encode.1.2:fwd", "PFNetv2": "encode.1.2:fwd", "VIFNet": "encode.1.2:fwd"}.get(args.model, "") if args.mode == "train" else "")
     T.PROFILE_TAGS = {args.roofline_tag} | ({hbm_tag} if hbm_tag else set())
     T.PROFILE_EVENTS.clear()
     if use_dist:
@@ -200,7 +201,21 @@ def main():
         if evh:
             ms = sum(a.elapsed_time(b) for a, b in evh) / len(evh)
             spec = [s for s in model._engine.specs if hbm_tag.startswith(s.name + ":")]
-            if spec:
+            if hbm_tag == "encode:fwd":
+                # algorithmic bytes of the 2 x 4 conv passes it replaces (H*W*(Cin+Cout)*sizeof per pass, the image in fp32)
+                # -- the launch itself only moves the two images and the 128 output planes (`fused_bytes`)
+                per_px = 2 * ((1 * 4 + 16 * 2) + (16 + 16) * 2 + (32 + 16) * 2 + (48 + 16) * 2)
+                nbytes = float(B) * S * Wd * per_px
+                roof_hbm = {"bound": "hbm", "kernel": "enc_stream_fwd_kernel 2 x (1->16, 16->16, 32->16, 48->16) k3 (encode:fwd)",
+                            "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": nbytes / (ms * 1e-3) / PEAK_HBM,
+                            "avg_launch_ms": ms, "launches": len(evh), "traffic": None, "algorithmic_bytes": nbytes,
+                            "fused_bytes": float(B) * S * Wd * 2 * (4 + 64 * 2)}
+                tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
+                if os.path.isfile(tpath) and B == 32 and S == 256 and Wd == 256 and args.mode == "train" and args.model == "PFNetv1":
+                    tj = json.load(open(tpath)).get(hbm_tag)
+                    if tj:
+                        roof_hbm["traffic"] = tj["hbm_bytes_per_launch"]
+            elif spec:
                 s = spec[0]
                 esz = 2 if args.dtype == "bf16" else 4
                 nbytes = float(B) * S * Wd * (s.cin + s.cout) * esz      # algorithmic bytes of one conv pass

@@ -318,6 +318,22 @@ int mmif_grad_loss(const float* img1, const float* img2, const float* imgf, int3
                    float weight, int32_t mode_max, int32_t l2, float* loss_out, float* grad_out, void* workspace,
                    size_t workspace_bytes, void* stream);
 
+/* ---- streaming DenseBlock encoder (core/model.py:73-80 = ConvLayer(1,16) + DenseBlock(16,16): PFNetv1.encode1/2, DenseFuse / PFNetv2 /
+ *      VIFNet .encode), forward, bf16: the four layers as ONE line-buffer kernel (csrc/enc_stream.hip) -- reads the image, writes the
+ *      64 concatenated channels [x0 | x1 | x2 | x3] once.  Bit-identical to mmif_conv2d_image_in_fwd + three mmif_conv2d_reflect_fwd
+ *      (MFMA) calls on the same operands.  `packed[i]` = forward operand image (mmif_pack_weights) of DenseBlock conv i (16+16i -> 16,
+ *      k = 3); every layer has bias (NULL = zeros) and ReLU.  enc_b / out_b: a second, independent branch in the same launch (other
+ *      image, other or the same weights) or NULL.  out_*: bf16 halo-0 views of 8 channel blocks. */
+typedef struct mmif_dense_encoder {
+    const float* img;         /* [n][h][w] fp32 */
+    const float* w0;          /* [16][1][3][3] fp32 */
+    const float* b0;          /* [16] or NULL */
+    const void* packed[3];
+    const float* bias[3];     /* [16] each, or NULL */
+} mmif_dense_encoder;
+int mmif_dense_encoder_fwd(const mmif_dense_encoder* enc_a, const mmif_tensor* out_a, const mmif_dense_encoder* enc_b,
+                           const mmif_tensor* out_b, void* stream);
+
 /* ---- data feed (the step before the hot path).  out[b] = transform(norm(bank[idx[b]]), mode[b]) as fp32 [batch][P][P]:
  *      FusionPatches.__getitem__ data/patches.py:61-74 with norm data/transform.py:15-29 (norm_mode 0: /255.0, 1: 'min-max',
  *      2: 'z-score') and the 8 dihedral variants of transform data/transform.py:38-66 (mode 0..7; NULL = no augmentation), plus

@@ -29,6 +29,10 @@ class MmifPackJob(C.Structure):
                 ("packed_fwd", C.c_void_p), ("packed_dgrad", C.c_void_p)]
 
 
+class MmifDenseEncoder(C.Structure):
+    _fields_ = [("img", C.c_void_p), ("w0", C.c_void_p), ("b0", C.c_void_p), ("packed", C.c_void_p * 3), ("bias", C.c_void_p * 3)]
+
+
 class MmifError(RuntimeError):
     pass
 
@@ -85,6 +89,7 @@ SIGNATURES = {
     "mmif_bn_apply_fwd": (_i32, [_vp] * 8 + [_i32, _i32, _i64, _f32, _f32, _i32, _f32, _vp]),
     "mmif_bn_bwd_sums": (_i32, [_vp] * 7 + [_i32, _i32, _i64, _i32, _f32, _vp, _sz, _vp]),
     "mmif_bn_apply_bwd": (_i32, [_vp] * 8 + [_i32, _i32, _i64, _i32, _f32, _vp]),
+    "mmif_dense_encoder_fwd": (_i32, [C.POINTER(MmifDenseEncoder), _TP, C.POINTER(MmifDenseEncoder), _TP, _vp]),
     "mmif_act_fwd": (_i32, [_vp, _vp, _i64, _i32, _f32, _vp]),
     "mmif_act_bwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _f32, _vp]),
     "mmif_conv2d_reflect_fwd": (_i32, [_TP, _vp, _vp, _vp, _TP, _i32, _i32, _i32, _i32, _i32, _vp]),

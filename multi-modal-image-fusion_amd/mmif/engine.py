@@ -334,6 +334,20 @@ class DenseEncoderMixin:
         ModelEngine.c_fwd(c2, F.view(base, 6), F.view(base + 6, 2), impl)
 
     @staticmethod
+    def enc_fwd_all(branches, F, dtype, impl):
+        """branches: [(specs, img, first channel block in F), ...] (one or two).  bf16 / MFMA: ONE streaming launch for all four
+        layers of all branches (csrc/enc_stream.hip; bit-identical to the layer-wise launches, $MMIF_ENC_STREAM=0 selects those)."""
+        stream = (dtype == torch.bfloat16 and impl != _lib.IMPL_VALU and os.environ.get("MMIF_ENC_STREAM", "1") != "0"
+                  and all(s.relu and s.k == 3 for specs, _, _ in branches for s in specs)
+                  and all([(s.cin, s.cout) for s in specs] == [(1, 16), (16, 16), (32, 16), (48, 16)] for specs, _, _ in branches))
+        if not stream:
+            for specs, img, base in branches:
+                DenseEncoderMixin.enc_fwd(specs, img, F, base, impl)
+            return
+        T.dense_encoder_fwd([(img, specs[0].w.detach(), specs[0].b.detach(), [s.packed for s in specs[1:]],
+                              [s.b.detach() for s in specs[1:]], F.view(base, 8)) for specs, img, base in branches], tag="encode:fwd")
+
+    @staticmethod
     def enc_bwd(specs, img, F, GF, fbase, gbase, ws, impl, accumulate_w=False):
         """GF[gbase:gbase+8] holds dL/d(encoder output) (padded domain), top 2 blocks already masked."""
         first, c0, c1, c2 = specs
@@ -366,8 +380,7 @@ class PFNetv1Engine(ModelEngine, DenseEncoderMixin):
         L = self.lease((n, h, w, dtype), dev)
         L.imgs = (img1, img2)
         F = self.buf(L, "F", n, 128, h, w, dtype, dev)
-        self.enc_fwd(self.enc[0], img1, F, 0, impl)
-        self.enc_fwd(self.enc[1], img2, F, 8, impl)
+        self.enc_fwd_all([(self.enc[0], img1, 0), (self.enc[1], img2, 8)], F, dtype, impl)
         x = F
         for i, s in enumerate(self.dec[:-1]):
             y = self.buf(L, f"D{i}", n, s.cout, h, w, dtype, dev)
@@ -451,11 +464,10 @@ class DenseFuseEngine(ModelEngine, DenseEncoderMixin):
         L = self.lease((n, h, w, dtype, single), dev)
         L.imgs = (img1, img2)
         F = self.buf(L, "F", n, 64 if single else 128, h, w, dtype, dev)
-        self.enc_fwd(self.enc, img1, F, 0, impl)
+        self.enc_fwd_all([(self.enc, img1, 0)] + ([] if single else [(self.enc, img2, 8)]), F, dtype, impl)
         if single:
             x = F
         else:
-            self.enc_fwd(self.enc, img2, F, 8, impl)
             x = self.buf(L, "S", n, 64, h, w, dtype, dev)
             self.fusion_fwd(L, F, x)
         for i, s in enumerate(self.dec[:-1]):

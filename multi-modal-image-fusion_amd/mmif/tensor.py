@@ -166,6 +166,24 @@ def image_in_fwd(img, w, bias, y, cout, k, relu):
     check(lib.mmif_conv2d_image_in_fwd(_ptr(img), _ptr(w), _ptr(bias), y.d, cout, k, int(relu), stream_ptr()), "image_in_fwd")
 
 
+def dense_encoder_fwd(branches, tag=None):
+    """ConvLayer(1,16) + DenseBlock(16,16) of one or two branches as ONE streaming launch (csrc/enc_stream.hip).
+    branches: [(img fp32 [n,1,h,w], w0, b0, (PackedWeights x 3), (bias x 3), out 8-block bf16 view), ...]"""
+    structs = []
+    for img, w0, b0, packed, biases, out in branches:
+        e = _lib.MmifDenseEncoder()
+        e.img, e.w0, e.b0 = img.data_ptr(), w0.data_ptr(), (b0.data_ptr() if b0 is not None else None)
+        for i in range(3):
+            assert (packed[i].cout, packed[i].cin, packed[i].k) == (16, 16 + 16 * i, 3), "DenseBlock(16, 16) operand images expected"
+            e.packed[i] = packed[i].fwd.data_ptr()
+            e.bias[i] = biases[i].data_ptr() if biases[i] is not None else None
+        structs.append((e, out))
+    a, b = structs[0], (structs[1] if len(structs) > 1 else (None, None))
+    with _timed(tag):
+        check(lib.mmif_dense_encoder_fwd(C.byref(a[0]), a[1].d, C.byref(b[0]) if b[0] is not None else None,
+                                         b[1].d if b[1] is not None else None, stream_ptr()), "dense_encoder_fwd")
+
+
 def image_in_wgrad(img, gy, dw, db, cout, k, ws, accumulate=False):
     check(lib.mmif_conv2d_image_in_wgrad(_ptr(img), gy.d, _ptr(dw), _ptr(db), cout, k, int(accumulate), _ptr(ws),
                                          ws.numel() * ws.element_size(), stream_ptr()), "image_in_wgrad")
