@@ -18,6 +18,7 @@
 // kernels (conv_image.hip, conv_mfma.hip), so the results are bit-identical to running the four layers one by one
 // (tests/test_gpu_enc_stream.py).
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace mmif {
 
@@ -30,6 +31,10 @@ constexpr int ES_B0 = 0, ES_B1 = 2 * ES_R0, ES_B2 = ES_B1 + 2 * ES_R1;
 constexpr int ES_SLOTS = ES_B2 + 2 * ES_R2;           // 24 row slots
 constexpr int ES_RING_BYTES = ES_SLOTS * ES_W * 16;   // 12288
 constexpr int ES_WAVES = 4;
+#ifndef ES_ABL
+#define ES_ABL 0   // timing ablations (diagnostic builds only, -DES_ABL=n; results are WRONG when non-zero): 1 no weight-fragment reads,
+#endif             // 2 no input-fragment reads, 4 no global stores, 8 no first-layer FMAs (tools/bench_enc.py)
+constexpr int ES_AHEAD = 4;                          // K steps of operand fetches in flight ahead of the MFMAs
 constexpr int ES_KEEP = ES_W - 6;                     // 26 output columns per interior strip
 // packed operand images (k-group planes of [16 oc][8] bf16 = 256 B): 16->16: 18 -> 20 planes, 32->16: 36, 48->16: 36 + 20
 constexpr int ES_P1 = 20, ES_P2 = 36, ES_P3 = 56;
@@ -75,7 +80,9 @@ __global__ __launch_bounds__(ES_WAVES * 64, 2) void enc_stream_fwd_kernel(EncArg
     const int H = A.h, W = A.w;
     const int y_lo = seg * A.seg_rows, y_hi = min(H, y_lo + A.seg_rows);
     if (y_lo >= y_hi) return;
-    // strip geometry: region [r0, r0 + 32); kept output columns [o_lo, o_hi)
+    // strip geometry: region [r0, r0 + 32); kept output columns [o_lo, o_hi) = those whose 3-layer receptive field lies inside the
+    // region (26 per interior strip, 29 at an image edge).  (Strips of 24 aligned columns -- whole 128-byte lines per stored run --
+    // were measured slower: 11 instead of 10 strips per 256 columns and no gain on the store side)
     const int r0 = W > ES_W ? min(ES_KEEP * strip, W - ES_W) : 0;
     const int o_hi = (r0 + ES_W >= W) ? W : r0 + ES_W - 3;
     int o_lo = 0;
@@ -136,51 +143,65 @@ __global__ __launch_bounds__(ES_WAVES * 64, 2) void enc_stream_fwd_kernel(EncArg
         int rr[3];
 #pragma unroll
         for (int u = 0; u < 3; ++u) rr[u] = rrow(y + u - 1);
+        // K loop: 9 steps over the chunk of 4 channel blocks (x0, x1) -- every lane group takes its own block g of ONE tap per step --
+        // and / or 5 steps over a chunk of 2 blocks (x0 for L = 1, x2 for L = 3): lane groups 0, 1 take tap 2s, groups 2, 3 tap 2s + 1
+        // (k-groups 18, 19 are the zero planes of the operand image).  Same order as the layer-wise kernel (chunk by chunk).
+        constexpr int NQ = L >= 2 ? 9 : 0, ND = (L == 1 || L == 3) ? 5 : 0, NS = NQ + ND;
+        constexpr int TB = L == 1 ? ES_B0 : ES_B2, TR = L == 1 ? ES_R0 : ES_R2;
+        constexpr int CH = L == 1 ? 0 : ES_P2 * 256;   // second chunk of the 48 -> 16 image starts after its 36 planes
+        int rowQ[3], rowD[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int s0 = (ES_B0 + cbh * ES_R0 + rr[u] % ES_R0) * (ES_W * 16);
+            const int s1 = (ES_B1 + cbh * ES_R1 + rr[u] % ES_R1) * (ES_W * 16);
+            rowQ[u] = hsel ? s1 : s0;
+            rowD[u] = (TB + cbh * TR + rr[u] % TR) * (ES_W * 16);
+        }
+        es_bf16x8 fa[NS], fb0[NS], fb1[NS];
+        // operands of step s (compile-time s after unrolling): one weight fragment, two column fragments of the input rows
+        auto fetch = [&](int s) {
+            if (ES_ABL & 3) {   // diagnostics only
+                if (!(ES_ABL & 1) || s == 0) fa[s] = *reinterpret_cast<const es_bf16x8*>(wl + (s % 5) * 1024); else fa[s] = fa[0];
+                if (!(ES_ABL & 2) || s == 0) {
+                    fb0[s] = *reinterpret_cast<const es_bf16x8*>(ring + rowQ[s % 3] + colB[0][s % 3]);
+                    fb1[s] = *reinterpret_cast<const es_bf16x8*>(ring + rowQ[s % 3] + colB[1][s % 3]);
+                } else { fb0[s] = fb0[0]; fb1[s] = fb1[0]; }
+                return;
+            }
+            if (s < NQ) {
+                const int tap = es_tap(s), u = tap / 3, v = tap % 3;
+                fa[s] = *reinterpret_cast<const es_bf16x8*>(wl + tap * 4 * 256);
+                fb0[s] = *reinterpret_cast<const es_bf16x8*>(ring + rowQ[u] + colB[0][v]);
+                fb1[s] = *reinterpret_cast<const es_bf16x8*>(ring + rowQ[u] + colB[1][v]);
+            } else {
+                const int d = s - NQ;
+                const int tA = es_tap(2 * d), uA = tA / 3, vA = tA % 3;
+                const bool padB = 2 * d + 1 >= 9;
+                const int tB = padB ? 0 : es_tap(2 * d + 1), uB = tB / 3, vB = tB % 3;
+                // a_lane carries g * 256 = hsel * 512 + cbh * 256; this lane's plane is tap * 2 + cbh (18 + cbh when padded)
+                const int pA = tA * 2 * 256, pB = padB ? 18 * 256 : tB * 2 * 256;
+                fa[s] = *reinterpret_cast<const es_bf16x8*>(wl + CH + ((hsel ? pB : pA) - hsel * 512));
+                const int bA0 = rowD[uA] + colB[0][vA], bB0 = rowD[uB] + colB[0][vB];
+                const int bA1 = rowD[uA] + colB[1][vA], bB1 = rowD[uB] + colB[1][vB];
+                fb0[s] = *reinterpret_cast<const es_bf16x8*>(ring + (hsel ? bB0 : bA0));
+                fb1[s] = *reinterpret_cast<const es_bf16x8*>(ring + (hsel ? bB1 : bA1));
+            }
+        };
         es_f32x4 acc[2];
         acc[0] = (es_f32x4){0.f, 0.f, 0.f, 0.f};
         acc[1] = (es_f32x4){0.f, 0.f, 0.f, 0.f};
-        if (L >= 2) {
-            // chunk of 4 channel blocks = (x0, x1): every lane group takes its own block g of ONE tap per step
-            int rowQ[3];
+        // software pipeline: the operands of step s + ES_AHEAD are fetched under the MFMAs of step s (a wave has one SIMD
+        // partner at most, so nothing else hides the ~100-cycle LDS latency of each fetch); order pinned with sched_group_barrier
 #pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                const int s0 = (ES_B0 + cbh * ES_R0 + rr[u] % ES_R0) * (ES_W * 16);
-                const int s1 = (ES_B1 + cbh * ES_R1 + rr[u] % ES_R1) * (ES_W * 16);
-                rowQ[u] = hsel ? s1 : s0;
-            }
+        for (int s = 0; s < ES_AHEAD && s < NS; ++s) fetch(s);
+        __builtin_amdgcn_sched_group_barrier(0x100, 3 * (ES_AHEAD < NS ? ES_AHEAD : NS), 0);   // the prologue's DS reads come first
 #pragma unroll
-            for (int s = 0; s < 9; ++s) {
-                const int tap = es_tap(s), u = tap / 3, v = tap % 3;
-                const es_bf16x8 a = *reinterpret_cast<const es_bf16x8*>(wl + tap * 4 * 256);
-                const es_bf16x8 b0 = *reinterpret_cast<const es_bf16x8*>(ring + rowQ[u] + colB[0][v]);
-                const es_bf16x8 b1 = *reinterpret_cast<const es_bf16x8*>(ring + rowQ[u] + colB[1][v]);
-                acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b0, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b1, acc[1], 0, 0, 0);
-            }
-        }
-        if (L == 1 || L == 3) {
-            // chunk of 2 channel blocks (x0 for L = 1, x2 for L = 3): lane groups 0, 1 take tap 2s, groups 2, 3 tap 2s + 1
-            constexpr int TB = L == 1 ? ES_B0 : ES_B2, TR = L == 1 ? ES_R0 : ES_R2;
-            constexpr int CH = L == 1 ? 0 : ES_P2 * 256;   // second chunk of the 48 -> 16 image starts after its 36 planes
-            int rowD[3];
-#pragma unroll
-            for (int u = 0; u < 3; ++u) rowD[u] = (TB + cbh * TR + rr[u] % TR) * (ES_W * 16);
-#pragma unroll
-            for (int s = 0; s < 5; ++s) {
-                const int tA = es_tap(2 * s), uA = tA / 3, vA = tA % 3;
-                const bool padB = 2 * s + 1 >= 9;          // k-groups 18, 19: zero planes of the operand image
-                const int tB = padB ? 0 : es_tap(2 * s + 1), uB = tB / 3, vB = tB % 3;
-                const int pA = tA * 2 * 256, pB = padB ? 18 * 256 : tB * 2 * 256;   // + cbh * 256 (in a_lane: g * 256 = hsel * 512 + cbh * 256)
-                // a_lane already carries g * 256; the plane of this lane is (tap * 2 + cbh): subtract the hsel * 512 it added
-                const int aoff = (hsel ? pB : pA) - hsel * 512;
-                const es_bf16x8 a = *reinterpret_cast<const es_bf16x8*>(wl + CH + aoff);
-                const int bA0 = rowD[uA] + colB[0][vA], bB0 = rowD[uB] + colB[0][vB];
-                const int bA1 = rowD[uA] + colB[1][vA], bB1 = rowD[uB] + colB[1][vB];
-                const es_bf16x8 b0 = *reinterpret_cast<const es_bf16x8*>(ring + (hsel ? bB0 : bA0));
-                const es_bf16x8 b1 = *reinterpret_cast<const es_bf16x8*>(ring + (hsel ? bB1 : bA1));
-                acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b0, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b1, acc[1], 0, 0, 0);
-            }
+        for (int s = 0; s < NS; ++s) {
+            if (s + ES_AHEAD < NS) fetch(s + ES_AHEAD);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[s], fb0[s], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[s], fb1[s], acc[1], 0, 0, 0);
+            if (s + ES_AHEAD < NS) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);   // 3 DS reads
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                           // 2 MFMAs
         }
         // epilogue: pair the two column fragments -> one 16-byte granule per lane, + bias, ReLU, round once
         float c[8];
@@ -200,42 +221,54 @@ __global__ __launch_bounds__(ES_WAVES * 64, 2) void enc_stream_fwd_kernel(EncArg
             constexpr int OB = L == 1 ? ES_B1 : ES_B2, OR = L == 1 ? ES_R1 : ES_R2;
             *reinterpret_cast<uint4*>(ring + ((OB + cb_e * OR + y % OR) * ES_W + px_e) * 16) = gr;
         }
-        if (y >= y_lo && y < y_hi && col_ok_e)
-            *reinterpret_cast<uint4*>(out_img + ((long long)(2 * L + cb_e) * out.plane + (long long)y * out.ws + x_e) * 16) = gr;
+        if (y >= y_lo && y < y_hi && col_ok_e && !(ES_ABL & 4))
+            *reinterpret_cast<uint4*>(out_img + ((ES_ABL & 32) ? (long long)((y & 7) * 64 + lane) : ((long long)(2 * L + cb_e) * out.plane + (long long)y * out.ws + x_e)) * 16) = gr;   // (32: all stores into one L2-resident spot)
     };
 
     // ---- the pipeline
     const int a_lo = max(0, y_lo - 3), a_hi = min(H, y_hi + 3);
     const int b_lo = max(0, y_lo - 2), b_hi = min(H, y_hi + 2);
     const int c_lo = max(0, y_lo - 1), c_hi = min(H, y_hi + 1);
-    float win[3][3], nxt[3];
+    // image rows: a 3-row window in registers plus two rows in flight.  The row a step shifts in was requested two steps earlier
+    // into a FIXED register set (the row loop is unrolled by two so that no in-flight destination is ever copied), i.e. its HBM /
+    // L2 latency is never on the wave's (serial) critical path.
+    float win[3][3], fifo[2][3];
     ld_img_row(a_lo - 1, win[0]);
     ld_img_row(a_lo, win[1]);
     ld_img_row(a_lo + 1, win[2]);
-    for (int r = a_lo - 3; r < y_hi; ++r) {
+    ld_img_row(a_lo + 2, fifo[0]);
+    ld_img_row(a_lo + 3, fifo[1]);
+    auto step = [&](int r, float (&slot)[3]) {
         const int ya = r + 3, yb = r + 2, yc = r + 1;
         if (ya < a_hi) {   // (ya >= a_lo by construction)
-            if (ya + 1 < a_hi) ld_img_row(ya + 2, nxt);   // next step's new image row, in flight during this step
             float v8[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 float acc0 = b0r[i];
 #pragma unroll
-                for (int t = 0; t < 9; ++t) acc0 = fmaf(win[t / 3][t % 3], w0r[i][t], acc0);
+                for (int t = 0; t < ((ES_ABL & 8) ? 1 : 9); ++t) acc0 = fmaf(win[t / 3][t % 3], w0r[i][t], acc0);
                 v8[i] = A.relu0 ? fmaxf(acc0, 0.f) : acc0;
             }
             const uint4 gr = make_uint4(pack_bf16x2(v8[0], v8[1]), pack_bf16x2(v8[2], v8[3]), pack_bf16x2(v8[4], v8[5]), pack_bf16x2(v8[6], v8[7]));
             *reinterpret_cast<uint4*>(ring + ((ES_B0 + cb_a * ES_R0 + ya % ES_R0) * ES_W + px_a) * 16) = gr;
-            if (ya >= y_lo && ya < y_hi && col_ok_a)
-                *reinterpret_cast<uint4*>(out_img + ((long long)cb_a * out.plane + (long long)ya * out.ws + x_a) * 16) = gr;
-            if (ya + 1 < a_hi) {
+            if (ya >= y_lo && ya < y_hi && col_ok_a && !(ES_ABL & 4))
+                *reinterpret_cast<uint4*>(out_img + ((ES_ABL & 32) ? (long long)((ya & 7) * 64 + lane) : ((long long)cb_a * out.plane + (long long)ya * out.ws + x_a)) * 16) = gr;
+            // window of the next row: rows ya, ya + 1, R(ya + 2) (requested two steps ago); request row ya + 4 into the same slot
 #pragma unroll
-                for (int v = 0; v < 3; ++v) { win[0][v] = win[1][v]; win[1][v] = win[2][v]; win[2][v] = nxt[v]; }
+            for (int v = 0; v < 3; ++v) {
+                win[0][v] = win[1][v];
+                win[1][v] = win[2][v];
+                win[2][v] = slot[v];
             }
+            if (!(ES_ABL & 16)) ld_img_row(ya + 4, slot);   // (16: no per-step image loads -> no vmcnt waits in the loop)
         }
         if (yb >= b_lo && yb < b_hi) conv_row(ESI<1>(), yb);
         if (yc >= c_lo && yc < c_hi) conv_row(ESI<2>(), yc);
-        if (r >= y_lo) conv_row(ESI<3>(), r);
+        if (r >= y_lo && r < y_hi) conv_row(ESI<3>(), r);
+    };
+    for (int r = a_lo - 3; r < y_hi; r += 2) {
+        step(r, fifo[0]);
+        step(r + 1, fifo[1]);
     }
 }
 

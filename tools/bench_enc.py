@@ -1,0 +1,49 @@
+"""Time the streaming encoder launch alone (needs a GPU):  python tools/bench_enc.py [B H W]
+Runs the product library (layer-wise and streaming), then every ab/lib*.so variant ($MMIF_LIB) in a child process."""
+import glob
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def one(B, H, W, modes):
+    for p in (ROOT, os.path.join(ROOT, "multi-modal-image-fusion_amd")):
+        sys.path.insert(0, p)
+    import torch
+    import core.model as M
+    from mmif import engine as E, tensor as T
+    E.set_compute_dtype("bf16")
+    torch.manual_seed(0)
+    m = M.PFNetv1().cuda()
+    eng = E.PFNetv1Engine(m)
+    i1, i2 = torch.rand(B, 1, H, W).cuda(), torch.rand(B, 1, H, W).cuda()
+    (i1, i2), _, _, _, dtype, impl = eng.prepare((i1, i2))
+    F = T.BT.alloc(B, 128, H, W, dtype, "cuda")
+    br = [(eng.enc[0], i1, 0), (eng.enc[1], i2, 8)]
+    for label, env in modes:
+        os.environ.update(env)
+        for _ in range(3):
+            eng.enc_fwd_all(br, F, dtype, impl)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            eng.enc_fwd_all(br, F, dtype, impl)
+        e1.record()
+        torch.cuda.synchronize()
+        print(f"{label:28s} {e0.elapsed_time(e1) / 20 * 1e3:8.1f} us", flush=True)
+        for k in env:
+            os.environ.pop(k)
+
+
+if __name__ == "__main__":
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    B, H, W = (int(a) for a in args[:3]) if len(args) >= 3 else (32, 256, 256)
+    if "--child" in sys.argv:
+        one(B, H, W, [("stream " + os.path.basename(os.environ.get("MMIF_LIB", "?")), {})])
+    else:
+        one(B, H, W, [("layer-wise", {"MMIF_ENC_STREAM": "0"}), ("stream", {})])
+        for lib in sorted(glob.glob(os.path.join(ROOT, "ab", "lib*.so"))):
+            subprocess.run([sys.executable, __file__, str(B), str(H), str(W), "--child"], env=dict(os.environ, MMIF_LIB=lib))
