@@ -334,6 +334,16 @@ typedef struct mmif_dense_encoder {
 int mmif_dense_encoder_fwd(const mmif_dense_encoder* enc_a, const mmif_tensor* out_a, const mmif_dense_encoder* enc_b,
                            const mmif_tensor* out_b, void* stream);
 
+/* Weight gradients of the same encoder, all four layers in ONE pass (csrc/enc_wgrad.hip; replaces three mmif_conv2d_reflect_wgrad
+ * calls + mmif_conv2d_image_in_wgrad): x = the forward's [x0 | x1 | x2 | ..] (bf16, halo 0, >= 6 channel blocks), gz = the four
+ * pre-activation gradients [g0 | g1 | g2 | g3] (bf16, 8 blocks; halo 0, or halo 1 folded).  dw0 [16][1][3][3], dwK [16][16K][3][3]
+ * (K = 1..3), dbK [16] (NULL = not wanted).  accumulate != 0 adds to the destinations (shared encoders: second branch).  The first
+ * layer runs on the exact fp32 matrix path against the fp32 image.  Deterministic (fixed-order reduction of per-block partials). */
+size_t mmif_dense_encoder_wgrad_workspace(void);
+int mmif_dense_encoder_wgrad(const float* img, const mmif_tensor* x, const mmif_tensor* gz, float* dw0, float* db0, float* dw1, float* db1,
+                             float* dw2, float* db2, float* dw3, float* db3, int32_t accumulate, void* workspace, size_t workspace_bytes,
+                             void* stream);
+
 /* ---- data feed (the step before the hot path).  out[b] = transform(norm(bank[idx[b]]), mode[b]) as fp32 [batch][P][P]:
  *      FusionPatches.__getitem__ data/patches.py:61-74 with norm data/transform.py:15-29 (norm_mode 0: /255.0, 1: 'min-max',
  *      2: 'z-score') and the 8 dihedral variants of transform data/transform.py:38-66 (mode 0..7; NULL = no augmentation), plus

@@ -1,0 +1,276 @@
+// Weight gradients of the whole DenseBlock encoder -- ConvLayer(1 -> 16) + DenseBlock(16, 16): dW, db of all FOUR layers
+// (reference core/model.py:73-80, core/block.py:137-151; backward of train.py:70) -- in ONE pass over the activations.
+//
+// Layer by layer (wgrad_mfma_kernel x 3 + image_in_wgrad_kernel) the encoder's weight gradients read 160 channel planes per branch:
+// the 48 -> 16 layer reads x0 x1 x2 + g3, the 32 -> 16 layer x0 x1 + g2, the 16 -> 16 layer x0 + g1, the first layer the image + g0
+// -- x0 three times, x1 twice.  Here a block stages ONE 16 x 16-pixel tile of the concatenated activations (x0 | x1 | x2, 18 x 18
+// with the reflect halo), of the four pre-activation gradients (g0 | g1 | g2 | g3) and of the image into LDS and forms every
+// product from it: 112 planes + the image, and each shifted activation fragment (transposing LDS read, ds_read_b64_tr_b16) feeds
+// up to three MFMAs (x0 serves layers 1, 2, 3).
+//   dW_L[o][c][u][v] = sum_pixels gL[o](y, x) * xin[c](R(y+u-1), R(x+v-1))      K = pixels (32 per k-step = two tile rows)
+//   wave u = 0, 1, 2: tap row u -> 3 taps x (3 + 2 + 1) (layer, 16-input-channel block) products = 18 accumulator tiles (bf16 MFMA)
+//   wave 3: the first layer against the fp32 image on the EXACT fp32 matrix path (v_mfma_f32_16x16x4_f32: the image is not rounded;
+//           N = 9 taps + a column of ones = db0) and db1..db3 (bf16 MFMA against ones)
+// No K split between waves -> no cross-wave reduction; per-block partials are reduced in a fixed order by a second kernel
+// (deterministic, no atomics).  ~250 B staged per pixel => HBM-bound; 2 blocks per CU (65 KB LDS each).
+#include "common.hpp"
+
+namespace mmif {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 ew_bf16x8;
+typedef __attribute__((ext_vector_type(4))) short ew_s16x4;
+typedef __attribute__((ext_vector_type(8))) short ew_s16x8;
+typedef __attribute__((ext_vector_type(4))) float ew_f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned ew_u32x4;   // granule as a NATIVE vector (a uint4 struct copy from global memory becomes
+                                                                 // a memcpy into a private array that is never promoted to registers)
+#define EW_LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+
+constexpr int EW_T = 16, EW_TP = 18;
+constexpr int EW_XPL = 324;     // granules per x plane (18 x 18); 5184 B = 64 mod 256 (as wgrad_mfma_kernel's tiles)
+constexpr int EW_GPL = 260;     // granules per g plane (256 used)
+constexpr int EW_NX = 6, EW_NG = 8;
+// per-block partial (floats): dW3 [16][48][9] | dW2 [16][32][9] | dW1 [16][16][9] | layer 0 [16 oc][16: taps 0..8, db0, 6 unused] | db1..3
+constexpr int EW_OFF3 = 0, EW_OFF2 = 16 * 48 * 9, EW_OFF1 = EW_OFF2 + 16 * 32 * 9, EW_OFF0 = EW_OFF1 + 16 * 16 * 9;
+constexpr int EW_OFFB = EW_OFF0 + 256, EW_PER = EW_OFFB + 48;
+constexpr int EW_TILE_BYTES = (EW_NX * EW_XPL + EW_NG * EW_GPL) * 16 + EW_TP * EW_TP * 4;
+constexpr int EW_SM_BYTES = EW_TILE_BYTES > EW_PER * 4 ? EW_TILE_BYTES : EW_PER * 4;
+constexpr int EW_MAXG = 512;
+#ifndef EW_ABL
+#define EW_ABL 0   // timing ablations (diagnostic builds, -DEW_ABL=n; results WRONG when non-zero): 1 no bf16 product waves, 2 no first-layer /
+#endif             // bias wave, 4 no global prefetch after the first tile (tools/bench_enc.py)
+
+__global__ __launch_bounds__(256, 2) void enc_wgrad_kernel(const float* __restrict__ img, TV tx, TV tg, float* __restrict__ partial,
+                                                            int tiles_x, int tpi, int total, int G) {
+    __shared__ __attribute__((aligned(16))) char smem[EW_SM_BYTES];
+    ew_u32x4* s_x = reinterpret_cast<ew_u32x4*>(smem);
+    ew_u32x4* s_g = s_x + EW_NX * EW_XPL;
+    float* s_img = reinterpret_cast<float*>(s_g + EW_NG * EW_GPL);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sl = lane & 15, g = lane >> 4;
+    // XCD-aware tile order: block b runs on XCD b % 8 and walks the tiles of one contiguous band
+    int gi = blockIdx.x;
+    const int H = tx.h, W = tx.w;
+
+    ew_f32x4 acc3[3][3], acc2[3][2], acc1[3], acc0, accb[3];
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+        acc1[v] = (ew_f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < 3; ++b) acc3[v][b] = (ew_f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc2[v][b] = (ew_f32x4){0.f, 0.f, 0.f, 0.f};
+        accb[v] = (ew_f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    acc0 = (ew_f32x4){0.f, 0.f, 0.f, 0.f};
+    const ew_bf16x8 ones = __builtin_bit_cast(ew_bf16x8, make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u));
+
+    // transposing reads: in-group lane sl supplies pixel (sl >> 2), 4-channel chunk (sl & 3) of a 16-channel block
+    const int tr_row = sl >> 2, tr_c = sl & 3;
+    const int lane_plane = tr_c >> 1, lane_byte = (tr_c & 1) * 8;
+    auto tr_frag = [&](const char* base) {
+        const ew_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(EW_LDS_PTR(ew_s16x4, base));
+        const ew_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(EW_LDS_PTR(ew_s16x4, base + 4 * 16));
+        const ew_s16x8 c = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(ew_bf16x8, c);
+    };
+
+    constexpr int NXR = (EW_NX * EW_XPL + 255) / 256;   // 8 x granules per thread per tile
+    ew_u32x4 rx[NXR], rg[EW_NG];
+    float ri[2];
+    // all prefetch loads are unconditional (clamped addresses, zero by select): nothing serialises them
+    auto prefetch = [&](int tile) {
+        const int in_ = tile / tpi, tt = tile - in_ * tpi;
+        const int y0 = (tt / tiles_x) * EW_T, x0 = (tt % tiles_x) * EW_T;
+#pragma unroll
+        for (int i = 0; i < NXR; ++i) {
+            const int e = min(tid + 256 * i, EW_NX * EW_XPL - 1);
+            const int cb = e / EW_XPL, p = e - cb * EW_XPL;
+            const int y = min(max(reflect_idx(y0 + p / EW_TP - 1, H), 0), H - 1);
+            const int x = min(max(reflect_idx(x0 + p % EW_TP - 1, W), 0), W - 1);
+            rx[i] = *reinterpret_cast<const ew_u32x4*>(tx.base + tx.gidx(in_, cb, y, x) * 16);
+        }
+        const int gy = y0 + tid / EW_T, gx = x0 + tid % EW_T;
+        const bool inside = gy < H && gx < W;
+        const int cy = min(gy, H - 1) + tg.halo, cx = min(gx, W - 1) + tg.halo;
+#pragma unroll
+        for (int i = 0; i < EW_NG; ++i) {
+            const ew_u32x4 v = *reinterpret_cast<const ew_u32x4*>(tg.base + tg.gidx(in_, i, cy, cx) * 16);
+            rg[i] = inside ? v : (ew_u32x4){0u, 0u, 0u, 0u};
+        }
+        const float* im = img + (long long)in_ * H * W;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e = min(tid + 256 * i, EW_TP * EW_TP - 1);
+            const int y = min(max(reflect_idx(y0 + e / EW_TP - 1, H), 0), H - 1);
+            const int x = min(max(reflect_idx(x0 + e % EW_TP - 1, W), 0), W - 1);
+            ri[i] = im[(long long)y * W + x];
+        }
+    };
+    if (gi < total) prefetch(gi);
+    for (int tile = gi; tile < total; tile += G) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NXR; ++i) {
+            const int e = tid + 256 * i;
+            if (e < EW_NX * EW_XPL) s_x[e] = rx[i];
+        }
+#pragma unroll
+        for (int i = 0; i < EW_NG; ++i) s_g[i * EW_GPL + tid] = rg[i];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e = tid + 256 * i;
+            if (e < EW_TP * EW_TP) s_img[e] = ri[i];
+        }
+        __syncthreads();
+        if (tile + G < total && !(EW_ABL & 4)) prefetch(tile + G);   // in flight during the MFMAs below
+        if (wave < 3 && !(EW_ABL & 1)) {
+            const int u = wave;
+#pragma unroll 2
+            for (int s = 0; s < 8; ++s) {
+                const int row = 2 * s + (g >> 1), col0 = 8 * (g & 1);
+                ew_bf16x8 a[3];
+#pragma unroll
+                for (int L = 1; L <= 3; ++L)
+                    a[L - 1] = tr_frag(reinterpret_cast<const char*>(s_g) + ((2 * L + lane_plane) * EW_GPL + row * EW_T + col0 + tr_row) * 16 + lane_byte);
+#pragma unroll
+                for (int v = 0; v < 3; ++v) {
+                    ew_bf16x8 bx[3];
+#pragma unroll
+                    for (int b = 0; b < 3; ++b)
+                        bx[b] = tr_frag(reinterpret_cast<const char*>(s_x) + ((2 * b + lane_plane) * EW_XPL + (row + u) * EW_TP + col0 + v + tr_row) * 16 + lane_byte);
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) acc3[v][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], bx[b], acc3[v][b], 0, 0, 0);
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) acc2[v][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], bx[b], acc2[v][b], 0, 0, 0);
+                    acc1[v] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], bx[0], acc1[v], 0, 0, 0);
+                }
+            }
+        } else if (wave == 3 && !(EW_ABL & 2)) {
+            // first layer: D[o][n] += sum_p g0[o](p) * B[p][n],  B[p][n] = image(p + tap n) for n < 9, 1 for n = 9 (-> db0), exact fp32
+            const int un = sl / 3, vn = sl - 3 * un;
+#pragma unroll 1
+            for (int s = 0; s < 8; ++s) {
+                const int row = 2 * s + (g >> 1), col0 = 8 * (g & 1);
+#pragma unroll
+                for (int L = 1; L <= 3; ++L) {
+                    const ew_bf16x8 a = tr_frag(reinterpret_cast<const char*>(s_g) + ((2 * L + lane_plane) * EW_GPL + row * EW_T + col0 + tr_row) * 16 + lane_byte);
+                    accb[L - 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, ones, accb[L - 1], 0, 0, 0);
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int p = 4 * q + g, prow = 2 * s + (p >> 4), pcol = p & 15;
+                    const unsigned short gb = *reinterpret_cast<const unsigned short*>(reinterpret_cast<const char*>(s_g) + ((sl >> 3) * EW_GPL + prow * EW_T + pcol) * 16 + (sl & 7) * 2);
+                    const float af = __uint_as_float((unsigned)gb << 16);
+                    const float iv = s_img[(prow + min(un, 2)) * EW_TP + pcol + vn];
+                    const float bf = sl < 9 ? iv : (sl == 9 ? 1.f : 0.f);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf, acc0, 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- block partial: accumulators -> LDS (natural [o][c][u][v] order) -> one coalesced copy
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+    if (wave < 3) {
+        const int u = wave;
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            const int t = 3 * u + v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int oc = 4 * g + r;
+#pragma unroll
+                for (int b = 0; b < 3; ++b) red[EW_OFF3 + (oc * 48 + 16 * b + sl) * 9 + t] = acc3[v][b][r];
+#pragma unroll
+                for (int b = 0; b < 2; ++b) red[EW_OFF2 + (oc * 32 + 16 * b + sl) * 9 + t] = acc2[v][b][r];
+                red[EW_OFF1 + (oc * 16 + sl) * 9 + t] = acc1[v][r];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int oc = 4 * g + r;
+            red[EW_OFF0 + oc * 16 + sl] = acc0[r];
+            if (sl < 3) red[EW_OFFB + sl * 16 + oc] = accb[sl == 0 ? 0 : (sl == 1 ? 1 : 2)][r];   // every column of a ones product is the sum
+        }
+    }
+    __syncthreads();
+    float* dst = partial + (long long)gi * EW_PER;
+    for (int e = tid; e < EW_PER; e += 256) dst[e] = red[e];
+}
+
+struct EwDst { float* dw0; float* db0; float* dw[3]; float* db[3]; };
+
+// 64 outputs x 4 slices of the G partials per block; fixed summation order
+__global__ __launch_bounds__(256) void enc_wgrad_reduce(const float* __restrict__ partial, EwDst D, int G, int accumulate) {
+    __shared__ float red[4][64];
+    const int o_local = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + o_local;
+    float s = 0.f;
+    if (idx < EW_PER) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;   // 4 independent chains keep loads in flight
+        int k = slice;
+        for (; k + 12 < G; k += 16) {
+            s0 += partial[(long long)k * EW_PER + idx];
+            s1 += partial[(long long)(k + 4) * EW_PER + idx];
+            s2 += partial[(long long)(k + 8) * EW_PER + idx];
+            s3 += partial[(long long)(k + 12) * EW_PER + idx];
+        }
+        for (; k < G; k += 4) s0 += partial[(long long)k * EW_PER + idx];
+        s = (s0 + s1) + (s2 + s3);
+    }
+    red[slice][o_local] = s;
+    __syncthreads();
+    if (slice != 0 || idx >= EW_PER) return;
+    const float t = (red[0][o_local] + red[1][o_local]) + (red[2][o_local] + red[3][o_local]);
+    float* p = nullptr;
+    if (idx < EW_OFF2) p = D.dw[2] + idx;
+    else if (idx < EW_OFF1) p = D.dw[1] + (idx - EW_OFF2);
+    else if (idx < EW_OFF0) p = D.dw[0] + (idx - EW_OFF1);
+    else if (idx < EW_OFFB) {
+        const int oc = (idx - EW_OFF0) >> 4, n = (idx - EW_OFF0) & 15;
+        if (n < 9) p = D.dw0 + oc * 9 + n;
+        else if (n == 9 && D.db0 != nullptr) p = D.db0 + oc;
+    } else {
+        const int L = (idx - EW_OFFB) >> 4, oc = (idx - EW_OFFB) & 15;
+        if (D.db[L] != nullptr) p = D.db[L] + oc;
+    }
+    if (p != nullptr) *p = accumulate ? *p + t : t;
+}
+
+}  // namespace mmif
+
+using namespace mmif;
+
+extern "C" size_t mmif_dense_encoder_wgrad_workspace(void) { return (size_t)EW_MAXG * EW_PER * sizeof(float); }
+
+extern "C" int mmif_dense_encoder_wgrad(const float* img, const mmif_tensor* x, const mmif_tensor* gz, float* dw0, float* db0, float* dw1,
+                                        float* db1, float* dw2, float* db2, float* dw3, float* db3, int32_t accumulate, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
+    if (int rc = validate_tensor(x, "x")) return rc;
+    if (int rc = validate_tensor(gz, "gz")) return rc;
+    MMIF_REQUIRE(img != nullptr && dw0 != nullptr && dw1 != nullptr && dw2 != nullptr && dw3 != nullptr, "dense_encoder_wgrad: NULL image / dW");
+    MMIF_REQUIRE(x->dtype == MMIF_BF16 && gz->dtype == MMIF_BF16, "dense_encoder_wgrad: bf16 tensors expected");
+    MMIF_REQUIRE(x->halo == 0 && x->cb >= 6, "dense_encoder_wgrad: x must be a halo-0 view of >= 6 channel blocks (x0 | x1 | x2)");
+    MMIF_REQUIRE(gz->cb == 8 && (gz->halo == 0 || (gz->flags & MMIF_T_FOLDED)), "dense_encoder_wgrad: gz must be an 8-block view, halo 0 or folded");
+    MMIF_REQUIRE(x->n == gz->n && x->h == gz->h && x->w == gz->w, "dense_encoder_wgrad: x / gz mismatch");
+    MMIF_REQUIRE(x->h >= 2 && x->w >= 2, "reflect padding needs h,w >= 2");
+    if (workspace == nullptr || workspace_bytes < mmif_dense_encoder_wgrad_workspace()) {
+        set_error("dense_encoder_wgrad: workspace too small");
+        return MMIF_EWORKSPACE;
+    }
+    TV tx = make_tv(x), tg = make_tv(gz);
+    const int tiles_x = cdiv(tx.w, EW_T), tiles_y = cdiv(tx.h, EW_T);
+    const int tpi = tiles_x * tiles_y, total = tpi * tx.n;
+    const int G = total < EW_MAXG ? total : EW_MAXG;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(enc_wgrad_kernel, dim3(G), dim3(256), 0, st, img, tx, tg, (float*)workspace, tiles_x, tpi, total, G);
+    if (int rc = check_launch("enc_wgrad")) return rc;
+    EwDst D;
+    D.dw0 = dw0; D.db0 = db0;
+    D.dw[0] = dw1; D.dw[1] = dw2; D.dw[2] = dw3;
+    D.db[0] = db1; D.db[1] = db2; D.db[2] = db3;
+    hipLaunchKernelGGL(enc_wgrad_reduce, dim3(cdiv(EW_PER, 64)), dim3(256), 0, st, (const float*)workspace, D, G, accumulate);
+    return check_launch("enc_wgrad_reduce");
+}

@@ -215,6 +215,8 @@ class ModelEngine:
                 need = max(need, T.image_wgrad_workspace_bytes(max(s.cin, s.cout), s.k))
             else:
                 need = max(need, T.wgrad_workspace_bytes(s.cin, s.cout, s.k))
+        if isinstance(self, DenseEncoderMixin):
+            need = max(need, T.dense_encoder_wgrad_workspace_bytes())
         if self._ws is None or self._ws.device != device or self._ws.numel() * 4 < need:
             self._ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=device)
         return self._ws
@@ -352,13 +354,21 @@ class DenseEncoderMixin:
         """GF[gbase:gbase+8] holds dL/d(encoder output) (padded domain), top 2 blocks already masked."""
         first, c0, c1, c2 = specs
         GF = GF.as_folded()   # every contribution so far has been folded; each dgrad below re-folds what it adds
+        # bf16 / MFMA: the four layers' weight gradients in ONE pass over [x0 | x1 | x2] and the finished [g0 | g1 | g2 | g3]
+        # (csrc/enc_wgrad.hip; $MMIF_ENC_WGRAD=0 selects the layer-wise kernels)
+        fused = (F.dtype == torch.bfloat16 and impl != _lib.IMPL_VALU and os.environ.get("MMIF_ENC_WGRAD", "1") != "0"
+                 and all(s.k == 3 for s in specs) and [(s.cin, s.cout) for s in specs] == [(1, 16), (16, 16), (32, 16), (48, 16)])
         for s, nin in ((c2, 6), (c1, 4), (c0, 2)):
             g = GF.view(gbase + nin, 2)
             x = F.view(fbase, nin)
-            T.conv_wgrad(x, g, s.dw, s.db, s.cin, s.cout, s.k, ws, accumulate_w, impl, s.name + ":wgrad")
+            if not fused:
+                T.conv_wgrad(x, g, s.dw, s.db, s.cin, s.cout, s.k, ws, accumulate_w, impl, s.name + ":wgrad")
             # accumulate into the lower blocks; this conv is the LAST contributor of its top 2 input blocks
             ModelEngine.c_dgrad(s, g, x, GF.view(gbase, nin), bits(nin - 2, nin - 1), all_bits(nin), impl)
-        T.image_in_wgrad(img, GF.view(gbase, 2), first.dw, first.db, first.cout, first.k, ws, accumulate_w)
+        if fused:
+            T.dense_encoder_wgrad(img, F.view(fbase, 6), GF.view(gbase, 8), [(s.dw, s.db) for s in specs], ws, accumulate_w, tag="encode:wgrad")
+        else:
+            T.image_in_wgrad(img, GF.view(gbase, 2), first.dw, first.db, first.cout, first.k, ws, accumulate_w)
 
 
 class PFNetv1Engine(ModelEngine, DenseEncoderMixin):

@@ -184,6 +184,18 @@ def dense_encoder_fwd(branches, tag=None):
                                          b[1].d if b[1] is not None else None, stream_ptr()), "dense_encoder_fwd")
 
 
+def dense_encoder_wgrad_workspace_bytes():
+    return lib.mmif_dense_encoder_wgrad_workspace()
+
+
+def dense_encoder_wgrad(img, x, gz, grads, ws, accumulate=False, tag=None):
+    """dW, db of ConvLayer(1,16) + DenseBlock(16,16) in one pass (csrc/enc_wgrad.hip).  grads = [(dw0, db0), (dw1, db1), (dw2, db2), (dw3, db3)]"""
+    flat = [_ptr(t) for pair in grads for t in pair]
+    with _timed(tag):
+        check(lib.mmif_dense_encoder_wgrad(_ptr(img), x.d, gz.d, *flat, int(accumulate), _ptr(ws), ws.numel() * ws.element_size(), stream_ptr()),
+              "dense_encoder_wgrad")
+
+
 def image_in_wgrad(img, gy, dw, db, cout, k, ws, accumulate=False):
     check(lib.mmif_conv2d_image_in_wgrad(_ptr(img), gy.d, _ptr(dw), _ptr(db), cout, k, int(accumulate), _ptr(ws),
                                          ws.numel() * ws.element_size(), stream_ptr()), "image_in_wgrad")

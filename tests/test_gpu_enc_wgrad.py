@@ -1,0 +1,128 @@
+"""Fused encoder weight gradients (csrc/enc_wgrad.hip, mmif_dense_encoder_wgrad): dW / db of ConvLayer(1,16) + DenseBlock(16,16)
+(reference core/model.py:73-80, core/block.py:137-151) in one pass must agree with the four layer-wise kernels -- same bf16
+operands, fp32 accumulation, only the summation order differs -- and with the fp64 definition evaluated on the same operands;
+the first layer (fp32 image, exact fp32 matrix path) to fp32 accuracy.  Ragged tiles, one-tile images, accumulate mode."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import DEV, dtype_ctx
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(1, 2, 2), (2, 5, 7), (1, 16, 16), (2, 32, 32), (1, 37, 53), (2, 64, 64), (1, 70, 33), (2, 256, 256)]
+
+
+def _setup(n, h, w, seed):
+    import core.model as M
+    from mmif import engine as E
+    from mmif import tensor as T
+    torch.manual_seed(seed)
+    m = M.PFNetv1().to(DEV)
+    eng = E.PFNetv1Engine(m)
+    g = torch.Generator().manual_seed(seed + 1)
+    img = torch.rand(n, 1, h, w, generator=g).to(DEV)
+    x = torch.relu(torch.randn(n, 64, h, w, generator=g) * 0.7).to(DEV)             # stand-in activations (ReLU outputs: half zeros)
+    gz = (torch.randn(n, 64, h, w, generator=g) * (torch.rand(n, 64, h, w, generator=g) > 0.4)).to(DEV)   # masked gradients
+    F = T.BT.from_nchw(x, torch.bfloat16)
+    GF = T.BT.from_nchw(gz, torch.bfloat16, halo=1).as_folded()
+    (img,), *_ = eng.prepare((img,))
+    return eng, T, img, F, GF
+
+
+def _grads(eng):
+    return [(torch.zeros_like(s.conv.weight), torch.zeros_like(s.conv.bias)) for s in eng.enc[0]]
+
+
+@pytest.mark.parametrize("n,h,w", SHAPES, ids=[f"{n}x{h}x{w}" for n, h, w in SHAPES])
+def test_fused_wgrad_vs_layerwise_and_definition(n, h, w):
+    with dtype_ctx("bf16"):
+        eng, T, img, F, GF = _setup(n, h, w, 7 + h)
+        ws = eng.workspace(torch.device(DEV))
+        specs = eng.enc[0]
+        fused = _grads(eng)
+        T.dense_encoder_wgrad(img, F.view(0, 6), GF.view(0, 8), fused, ws)
+        lw = _grads(eng)
+        for k, nin in ((3, 6), (2, 4), (1, 2)):
+            T.conv_wgrad(F.view(0, nin), GF.view(2 * k, 2), lw[k][0], lw[k][1], specs[k].cin, 16, 3, ws, False)
+        T.image_in_wgrad(img, GF.view(0, 2), lw[0][0], lw[0][1], 16, 3, ws, False)
+        torch.cuda.synchronize()
+        # fp64 definition on the SAME (bf16-rounded) operands
+        xr = F.to_nchw(64).double().cpu()
+        gr = GF.to_nchw(64).double().cpu()
+        im = img.double().cpu()
+        for k in range(4):
+            xin = im if k == 0 else xr[:, :16 * k]
+            gk = gr[:, 16 * k:16 * k + 16]
+            xp = torch.nn.functional.pad(xin, (1, 1, 1, 1), mode="reflect")
+            dw = torch.zeros(16, xin.shape[1], 3, 3, dtype=torch.float64)
+            for u in range(3):
+                for v in range(3):
+                    dw[:, :, u, v] = torch.einsum("nohw,nchw->oc", gk, xp[:, :, u:u + h, v:v + w])
+            db = gk.sum(dim=(0, 2, 3))
+            scale = max(1e-6, float(dw.abs().max()))
+            e_f = float((fused[k][0].double().cpu() - dw).abs().max()) / scale
+            e_l = float((lw[k][0].double().cpu() - dw).abs().max()) / scale
+            tol = 2e-5 if k > 0 else 2e-6        # bf16 products are exact in fp32: only the accumulation differs
+            assert e_f <= tol * max(1.0, (n * h * w) ** 0.5 / 16), (k, "fused dW", e_f, "layer-wise", e_l)
+            assert e_f <= max(4 * e_l, 1e-6), (k, "fused dW much worse than layer-wise", e_f, e_l)
+            sb = max(1e-6, float(db.abs().max()))
+            assert float((fused[k][1].double().cpu() - db).abs().max()) / sb <= 2e-5 * max(1.0, (n * h * w) ** 0.5 / 16), (k, "db")
+
+
+def test_accumulate_and_second_branch_offsets():
+    """accumulate adds to the destinations (shared encoders); views at a channel-block offset (the second branch's half)."""
+    with dtype_ctx("bf16"):
+        eng, T, img, F, GF = _setup(2, 40, 24, 5)
+        ws = eng.workspace(torch.device(DEV))
+        a = _grads(eng)
+        T.dense_encoder_wgrad(img, F.view(0, 6), GF.view(0, 8), a, ws)
+        b = [(w.clone(), bb.clone()) for w, bb in a]
+        T.dense_encoder_wgrad(img, F.view(0, 6), GF.view(0, 8), b, ws, accumulate=True)
+        torch.cuda.synchronize()
+        for (w1, b1), (w2, b2) in zip(a, b):
+            assert torch.equal(w2, 2 * w1) and torch.equal(b2, 2 * b1)
+        # the same data placed in the upper half of 128-channel buffers
+        F2 = T.BT.alloc(2, 128, 40, 24, torch.bfloat16, DEV)
+        G2 = T.BT.alloc(2, 128, 40, 24, torch.bfloat16, DEV, halo=1, zero=True)
+        F2.buf.zero_()
+        F2.buf[:, 8:] = F.buf
+        G2.buf[:, 8:] = GF.buf
+        c = _grads(eng)
+        T.dense_encoder_wgrad(img, F2.view(8, 6), G2.as_folded().view(8, 8), c, ws)
+        torch.cuda.synchronize()
+        for (w1, b1), (w3, b3) in zip(a, c):
+            assert torch.equal(w1, w3) and torch.equal(b1, b3)
+        # deterministic
+        d = _grads(eng)
+        T.dense_encoder_wgrad(img, F.view(0, 6), GF.view(0, 8), d, ws)
+        torch.cuda.synchronize()
+        assert all(torch.equal(x1, x2) and torch.equal(y1, y2) for (x1, y1), (x2, y2) in zip(a, d))
+
+
+def test_models_train_step_with_fused_wgrad_matches_layerwise():
+    import core.model as M
+    with dtype_ctx("bf16"):
+        for name in ("PFNetv1", "DenseFuse", "VIFNet"):
+            torch.manual_seed(5)
+            m = getattr(M, name)().to(DEV)
+            g = torch.Generator().manual_seed(9)
+            i1, i2 = torch.rand(2, 1, 45, 70, generator=g).to(DEV), torch.rand(2, 1, 45, 70, generator=g).to(DEV)
+            res = []
+            for flag in ("0", "1"):
+                os.environ["MMIF_ENC_WGRAD"] = flag
+                try:
+                    m.zero_grad(set_to_none=True)
+                    m(i1, i2).square().mean().backward()
+                    torch.cuda.synchronize()
+                    res.append({k: p.grad.clone() for k, p in m.named_parameters()})
+                finally:
+                    os.environ.pop("MMIF_ENC_WGRAD")
+            for k in res[0]:
+                a, b = res[0][k].double(), res[1][k].double()
+                if "encode" not in k:
+                    assert torch.equal(a, b), (name, k)
+                else:
+                    assert float((a - b).abs().max()) <= 1e-4 * max(1e-6, float(a.abs().max())), (name, k)

@@ -22,18 +22,32 @@ def one(B, H, W, modes):
     (i1, i2), _, _, _, dtype, impl = eng.prepare((i1, i2))
     F = T.BT.alloc(B, 128, H, W, dtype, "cuda")
     br = [(eng.enc[0], i1, 0), (eng.enc[1], i2, 8)]
+    GF = T.BT.alloc(B, 128, H, W, dtype, "cuda", halo=1, zero=True).as_folded()
+    GF.buf.normal_()
+    ws = eng.workspace(torch.device("cuda"))
+    grads = [(torch.zeros_like(s.conv.weight), torch.zeros_like(s.conv.bias)) for s in eng.enc[0]]
+
+    def fwd():
+        eng.enc_fwd_all(br, F, dtype, impl)
+
+    def wgrad():   # one branch
+        T.dense_encoder_wgrad(i1, F.view(0, 6), GF.view(0, 8), grads, ws)
+
     for label, env in modes:
         os.environ.update(env)
-        for _ in range(3):
-            eng.enc_fwd_all(br, F, dtype, impl)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(20):
-            eng.enc_fwd_all(br, F, dtype, impl)
-        e1.record()
-        torch.cuda.synchronize()
-        print(f"{label:28s} {e0.elapsed_time(e1) / 20 * 1e3:8.1f} us", flush=True)
+        for name, fn in (("fwd (2 branches)", fwd), ("wgrad (1 branch)", wgrad)):
+            if name.startswith("wgrad") and env.get("MMIF_ENC_STREAM") == "0":
+                continue
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            print(f"{label:28s} {name:18s} {e0.elapsed_time(e1) / 20 * 1e3:8.1f} us", flush=True)
         for k in env:
             os.environ.pop(k)
 
