@@ -1633,12 +1633,22 @@ static int wgrad_dma_G(int cin, int cout) {   // tile groups per (icg, ocg) pair
     return G < 1 ? 1 : G;
 }
 
+// enc_wgrad.hip: single-layer "tap-row" kernel (whole x / g tile staged once per block)
+bool wgrad_taprow_supported(int ks, int cin, int cout);
+size_t wgrad_taprow_workspace(int cin, int cout);
+int wgrad_taprow(const TV& tx, const TV& tg, float* dw, float* db, int cin, int cout, int accumulate, float* ws, hipStream_t st);
+static int g_taprow_mode = -1;   // $MMIF_WGRAD_TAPROW=0: keep the per-input-group kernel (A/B timing)
+
 size_t wgrad_mfma_workspace(int cin, int cout, int ks) {
     const int mfw = pick_mfw(cout);
     const size_t per = (size_t)mfw * 16 * 16 * ks * ks + mfw * 16;
     size_t a = (size_t)wgrad_G(cin, cout) * cdiv(cin, 16) * cdiv(cout, mfw * 16) * per * sizeof(float);
     if (wgrad_dma_shape(ks, cin, cout)) {
         const size_t b = (size_t)wgrad_dma_G(cin, cout) * cdiv(cin, 64) * cdiv(cout, 64) * WD_PER * sizeof(float);
+        if (b > a) a = b;
+    }
+    if (wgrad_taprow_supported(ks, cin, cout)) {
+        const size_t b = wgrad_taprow_workspace(cin, cout);
         if (b > a) a = b;
     }
     return a;
@@ -1685,6 +1695,12 @@ int wgrad_mfma(int ks, const TV& tx, const TV& tg, float* dw, float* db, int cin
     if (g_dma_mode == 1 && wgrad_dma_shape(ks, cin, cout) && tg.halo == 1 && tg.folded && tx.plane * 16 * 8 < (1ll << 31) &&
         tg.plane * 16 * 8 < (1ll << 31))
         return launch_wgrad_dma(tx, tg, dw, db, cin, cout, accumulate, ws, st);
+    if (g_taprow_mode < 0) {
+        const char* e = getenv("MMIF_WGRAD_TAPROW");
+        g_taprow_mode = (e != nullptr && e[0] == '0') ? 0 : 1;
+    }
+    if (g_taprow_mode == 1 && wgrad_taprow_supported(ks, cin, cout) && (tg.halo == 0 || tg.folded) && tx.halo == 0)
+        return wgrad_taprow(tx, tg, dw, db, cin, cout, accumulate, ws, st);
 #define GO(KS_, M_, K_) return launch_wgrad_mfma<KS_, M_, K_>(tx, tg, dw, db, cin, cout, accumulate, ws, st)
     if (ks == 3) {
         switch (mfw) { case 1: GO(3, 1, 4); case 2: GO(3, 2, 2); default: GO(3, 4, 2); }

@@ -125,8 +125,10 @@ __global__ __launch_bounds__(ES_WAVES * 64, 2) void enc_stream_fwd_kernel(EncArg
         for (int t = 0; t < 9; ++t) w0r[i][t] = B.w0[(cb_a * 8 + i) * 9 + t];
     }
     const float* img = B.img + (long long)in_ * H * W;
-    const TV& out = B.out;
-    char* out_img = out.base + ((long long)in_ * out.img + (long long)out.cb_off * out.plane) * 16;
+    // stores: wave-uniform 64-bit image base + a 32-bit lane offset (an image of the widest view is < 4 GB); geometry copied out of
+    // the argument block once (left behind a reference, every store re-read it through the scalar cache and drained lgkmcnt)
+    const unsigned out_plane_b = (unsigned)(B.out.plane * 16), out_row_b = (unsigned)B.out.ws * 16u;
+    char* out_img = B.out.base + ((long long)in_ * B.out.img + (long long)B.out.cb_off * B.out.plane) * 16;
 
     auto rrow = [&](int y) { return min(max(reflect_idx(y, H), 0), H - 1); };
     auto ld_img_row = [&](int y, float (&dst)[3]) {
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(ES_WAVES * 64, 2) void enc_stream_fwd_kernel(EncArg
             *reinterpret_cast<uint4*>(ring + ((OB + cb_e * OR + y % OR) * ES_W + px_e) * 16) = gr;
         }
         if (y >= y_lo && y < y_hi && col_ok_e && !(ES_ABL & 4))
-            *reinterpret_cast<uint4*>(out_img + ((ES_ABL & 32) ? (long long)((y & 7) * 64 + lane) : ((long long)(2 * L + cb_e) * out.plane + (long long)y * out.ws + x_e)) * 16) = gr;   // (32: all stores into one L2-resident spot)
+            *reinterpret_cast<uint4*>(out_img + ((ES_ABL & 32) ? (unsigned)((y & 7) * 64 + lane) * 16u : (unsigned)(2 * L + cb_e) * out_plane_b + (unsigned)y * out_row_b + (unsigned)x_e * 16u)) = gr;   // (32: all stores into one L2-resident spot)
     };
 
     // ---- the pipeline
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(ES_WAVES * 64, 2) void enc_stream_fwd_kernel(EncArg
             const uint4 gr = make_uint4(pack_bf16x2(v8[0], v8[1]), pack_bf16x2(v8[2], v8[3]), pack_bf16x2(v8[4], v8[5]), pack_bf16x2(v8[6], v8[7]));
             *reinterpret_cast<uint4*>(ring + ((ES_B0 + cb_a * ES_R0 + ya % ES_R0) * ES_W + px_a) * 16) = gr;
             if (ya >= y_lo && ya < y_hi && col_ok_a && !(ES_ABL & 4))
-                *reinterpret_cast<uint4*>(out_img + ((ES_ABL & 32) ? (long long)((ya & 7) * 64 + lane) : ((long long)cb_a * out.plane + (long long)ya * out.ws + x_a)) * 16) = gr;
+                *reinterpret_cast<uint4*>(out_img + ((ES_ABL & 32) ? (unsigned)((ya & 7) * 64 + lane) * 16u : (unsigned)cb_a * out_plane_b + (unsigned)ya * out_row_b + (unsigned)x_a * 16u)) = gr;
             // window of the next row: rows ya, ya + 1, R(ya + 2) (requested two steps ago); request row ya + 4 into the same slot
 #pragma unroll
             for (int v = 0; v < 3; ++v) {

@@ -200,6 +200,184 @@ __global__ __launch_bounds__(256, 2) void enc_wgrad_kernel(const float* __restri
     for (int e = tid; e < EW_PER; e += 256) dst[e] = red[e];
 }
 
+// ------------------------------------------------------------------ the same scheme for a single 3x3 layer ("tap-row" wgrad)
+// dW, db of ONE ConvLayer with 16 NXB input and 16 NGB output channels (decoder tails: 64 -> 32, 32 -> 16; the DenseBlock convs when the
+// fused encoder kernel is off): wgrad_mfma_kernel gives every 16-input-channel group its own block, so the gradient tile is re-read
+// NXB times (64 -> 32: 192 planes staged for 96 of data).  Here ONE block stages the whole x tile (all input channels, 18 x 18) and
+// the whole g tile once; wave u = 0, 1, 2 owns tap row u for every (input block, output block) pair -- 3 NXB NGB accumulator tiles,
+// each transposed x fragment feeding NGB MFMAs -- and wave 3 the bias sums.  No K split, per-block partials in the natural
+// [o][c][u][v] order, fixed-order reduction.
+template <int NXB, int NGB>
+__global__ __launch_bounds__(256, 2) void taprow_wgrad_kernel(TV tx, TV tg, float* __restrict__ partial, int tiles_x, int tpi, int total, int G) {
+    constexpr int CIN = 16 * NXB, COUT = 16 * NGB;
+    constexpr int PER = COUT * CIN * 9 + COUT;
+    constexpr int TILE_BYTES = (2 * NXB * EW_XPL + 2 * NGB * EW_GPL) * 16;
+    constexpr int SM_BYTES = TILE_BYTES > PER * 4 ? TILE_BYTES : PER * 4;
+    __shared__ __attribute__((aligned(16))) char smem[SM_BYTES];
+    ew_u32x4* s_x = reinterpret_cast<ew_u32x4*>(smem);
+    ew_u32x4* s_g = s_x + 2 * NXB * EW_XPL;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sl = lane & 15, g = lane >> 4;
+    const int gi = blockIdx.x;
+    const int H = tx.h, W = tx.w;
+    ew_f32x4 acc[3][NXB][NGB], accb[NGB];
+#pragma unroll
+    for (int m = 0; m < NGB; ++m) {
+        accb[m] = (ew_f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int v = 0; v < 3; ++v)
+#pragma unroll
+            for (int b = 0; b < NXB; ++b) acc[v][b][m] = (ew_f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const ew_bf16x8 ones = __builtin_bit_cast(ew_bf16x8, make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u));
+    const int tr_row = sl >> 2, tr_c = sl & 3;
+    const int lane_plane = tr_c >> 1, lane_byte = (tr_c & 1) * 8;
+    auto tr_frag = [&](const char* base) {
+        const ew_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(EW_LDS_PTR(ew_s16x4, base));
+        const ew_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(EW_LDS_PTR(ew_s16x4, base + 4 * 16));
+        const ew_s16x8 c = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(ew_bf16x8, c);
+    };
+    constexpr int NXR = (2 * NXB * EW_XPL + 255) / 256;
+    ew_u32x4 rx[NXR], rg[2 * NGB];
+    auto prefetch = [&](int tile) {
+        const int in_ = tile / tpi, tt = tile - in_ * tpi;
+        const int y0 = (tt / tiles_x) * EW_T, x0 = (tt % tiles_x) * EW_T;
+#pragma unroll
+        for (int i = 0; i < NXR; ++i) {
+            const int e = min(tid + 256 * i, 2 * NXB * EW_XPL - 1);
+            const int cb = e / EW_XPL, p = e - cb * EW_XPL;
+            const int y = min(max(reflect_idx(y0 + p / EW_TP - 1, H), 0), H - 1);
+            const int x = min(max(reflect_idx(x0 + p % EW_TP - 1, W), 0), W - 1);
+            rx[i] = *reinterpret_cast<const ew_u32x4*>(tx.base + tx.gidx(in_, cb, y, x) * 16);
+        }
+        const int gy = y0 + tid / EW_T, gx = x0 + tid % EW_T;
+        const bool inside = gy < H && gx < W;
+        const int cy = min(gy, H - 1) + tg.halo, cx = min(gx, W - 1) + tg.halo;
+#pragma unroll
+        for (int i = 0; i < 2 * NGB; ++i) {
+            const ew_u32x4 v = *reinterpret_cast<const ew_u32x4*>(tg.base + tg.gidx(in_, i, cy, cx) * 16);
+            rg[i] = inside ? v : (ew_u32x4){0u, 0u, 0u, 0u};
+        }
+    };
+    if (gi < total) prefetch(gi);
+    for (int tile = gi; tile < total; tile += G) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NXR; ++i) {
+            const int e = tid + 256 * i;
+            if (e < 2 * NXB * EW_XPL) s_x[e] = rx[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 2 * NGB; ++i) s_g[i * EW_GPL + tid] = rg[i];
+        __syncthreads();
+        if (tile + G < total) prefetch(tile + G);
+        if (wave < 3) {
+            const int u = wave;
+#pragma unroll 2
+            for (int s = 0; s < 8; ++s) {
+                const int row = 2 * s + (g >> 1), col0 = 8 * (g & 1);
+                ew_bf16x8 a[NGB];
+#pragma unroll
+                for (int m = 0; m < NGB; ++m)
+                    a[m] = tr_frag(reinterpret_cast<const char*>(s_g) + ((2 * m + lane_plane) * EW_GPL + row * EW_T + col0 + tr_row) * 16 + lane_byte);
+#pragma unroll
+                for (int v = 0; v < 3; ++v) {
+                    ew_bf16x8 bx[NXB];
+#pragma unroll
+                    for (int b = 0; b < NXB; ++b)
+                        bx[b] = tr_frag(reinterpret_cast<const char*>(s_x) + ((2 * b + lane_plane) * EW_XPL + (row + u) * EW_TP + col0 + v + tr_row) * 16 + lane_byte);
+#pragma unroll
+                    for (int b = 0; b < NXB; ++b)
+#pragma unroll
+                        for (int m = 0; m < NGB; ++m) acc[v][b][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], bx[b], acc[v][b][m], 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll 2
+            for (int s = 0; s < 8; ++s) {
+                const int row = 2 * s + (g >> 1), col0 = 8 * (g & 1);
+#pragma unroll
+                for (int m = 0; m < NGB; ++m) {
+                    const ew_bf16x8 a = tr_frag(reinterpret_cast<const char*>(s_g) + ((2 * m + lane_plane) * EW_GPL + row * EW_T + col0 + tr_row) * 16 + lane_byte);
+                    accb[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, ones, accb[m], 0, 0, 0);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+    if (wave < 3) {
+        const int u = wave;
+#pragma unroll
+        for (int v = 0; v < 3; ++v)
+#pragma unroll
+            for (int b = 0; b < NXB; ++b)
+#pragma unroll
+                for (int m = 0; m < NGB; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) red[((16 * m + 4 * g + r) * CIN + 16 * b + sl) * 9 + 3 * u + v] = acc[v][b][m][r];
+    } else if (sl == 0) {
+#pragma unroll
+        for (int m = 0; m < NGB; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[COUT * CIN * 9 + 16 * m + 4 * g + r] = accb[m][r];
+    }
+    __syncthreads();
+    float* dst = partial + (long long)gi * PER;
+    for (int e = tid; e < PER; e += 256) dst[e] = red[e];
+}
+
+// out[i] = sum_g partial[g][i] (fixed order); the first n_w entries are dW in its natural layout, the rest db
+__global__ __launch_bounds__(256) void taprow_wgrad_reduce(const float* __restrict__ partial, float* __restrict__ dw, float* __restrict__ db, int n_w,
+                                                           int per, int G, int accumulate) {
+    __shared__ float red[4][64];
+    const int o_local = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + o_local;
+    float s = 0.f;
+    if (idx < per) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int k = slice;
+        for (; k + 12 < G; k += 16) {
+            s0 += partial[(long long)k * per + idx];
+            s1 += partial[(long long)(k + 4) * per + idx];
+            s2 += partial[(long long)(k + 8) * per + idx];
+            s3 += partial[(long long)(k + 12) * per + idx];
+        }
+        for (; k < G; k += 4) s0 += partial[(long long)k * per + idx];
+        s = (s0 + s1) + (s2 + s3);
+    }
+    red[slice][o_local] = s;
+    __syncthreads();
+    if (slice != 0 || idx >= per) return;
+    const float t = (red[0][o_local] + red[1][o_local]) + (red[2][o_local] + red[3][o_local]);
+    float* p = idx < n_w ? dw + idx : (db != nullptr ? db + (idx - n_w) : nullptr);
+    if (p != nullptr) *p = accumulate ? *p + t : t;
+}
+
+bool wgrad_taprow_supported(int ks, int cin, int cout) {
+    if (ks != 3 || cin % 16 || cout % 16) return false;
+    const int nxb = cin / 16, ngb = cout / 16;
+    return (ngb == 1 && nxb >= 1 && nxb <= 3) || (ngb == 2 && (nxb == 2 || nxb == 4));
+}
+size_t wgrad_taprow_workspace(int cin, int cout) { return (size_t)EW_MAXG * ((size_t)cout * cin * 9 + cout) * sizeof(float); }
+
+int wgrad_taprow(const TV& tx, const TV& tg, float* dw, float* db, int cin, int cout, int accumulate, float* ws, hipStream_t st) {
+    const int tiles_x = cdiv(tx.w, EW_T), tiles_y = cdiv(tx.h, EW_T);
+    const int tpi = tiles_x * tiles_y, total = tpi * tx.n;
+    const int G = total < EW_MAXG ? total : EW_MAXG;
+    const int nxb = cin / 16, ngb = cout / 16;
+#define GO(X_, G_) hipLaunchKernelGGL((taprow_wgrad_kernel<X_, G_>), dim3(G), dim3(256), 0, st, tx, tg, ws, tiles_x, tpi, total, G)
+    if (ngb == 1) { switch (nxb) { case 1: GO(1, 1); break; case 2: GO(2, 1); break; default: GO(3, 1); break; } }
+    else { if (nxb == 2) GO(2, 2); else GO(4, 2); }
+#undef GO
+    if (int rc = check_launch("wgrad_taprow")) return rc;
+    const int n_w = cout * cin * 9, per = n_w + cout;
+    hipLaunchKernelGGL(taprow_wgrad_reduce, dim3(cdiv(per, 64)), dim3(256), 0, st, (const float*)ws, dw, db, n_w, per, G, accumulate);
+    return check_launch("wgrad_taprow_reduce");
+}
+
 struct EwDst { float* dw0; float* db0; float* dw[3]; float* db[3]; };
 
 // 64 outputs x 4 slices of the G partials per block; fixed summation order
