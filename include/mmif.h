@@ -344,6 +344,14 @@ int mmif_dense_encoder_wgrad(const float* img, const mmif_tensor* x, const mmif_
                              float* dw2, float* db2, float* dw3, float* db3, int32_t accumulate, void* workspace, size_t workspace_bytes,
                              void* stream);
 
+/* Backward chain of the same DenseBlock in GATHER form: the gradient of x_k (k = 2, 1, 0) is ONE dgrad of a virtual layer with 16 input
+ * channels (x_k) and 16 (3 - k) output channels -- DenseBlock convs k+1 .. 3 stacked, each restricted to its x_k input slice -- run on
+ * the contiguous gradient blocks [g_{k+1} | .. | g_3] with accumulate (onto G_k) + ReLU mask in the epilogue
+ * (mmif_conv2d_reflect_dgrad_folded, cin = 16, cout = 16 (3 - k)).  This call writes the three virtual layers' dgrad operand images
+ * (sizes mmif_packed_weight_bytes(16 (3 - k), 16, 3)) from the fp32 weights w1 [16][16][3][3], w2 [16][32][3][3], w3 [16][48][3][3]. */
+int mmif_pack_dense_chain(const float* w1, const float* w2, const float* w3, void* packed_v0, void* packed_v1, void* packed_v2,
+                          void* stream);
+
 /* ---- data feed (the step before the hot path).  out[b] = transform(norm(bank[idx[b]]), mode[b]) as fp32 [batch][P][P]:
  *      FusionPatches.__getitem__ data/patches.py:61-74 with norm data/transform.py:15-29 (norm_mode 0: /255.0, 1: 'min-max',
  *      2: 'z-score') and the 8 dihedral variants of transform data/transform.py:38-66 (mode 0..7; NULL = no augmentation), plus

@@ -1753,6 +1753,55 @@ extern "C" int mmif_pack_weights_multi(const mmif_pack_job* jobs, int32_t n_jobs
     return flush();
 }
 
+// ---- DenseBlock(16, 16) backward chain in GATHER form.  Layer by layer, the dgrad of DenseBlock conv L scatters into all of its
+// inputs: x0's gradient is read-modify-written three times (by convs 3, 2, 1), x1's twice.  Per DESTINATION the same sums are
+//     g(x_k) = mask(G_k + sum_{L > k} dgrad_L(g_L)[channels of x_k])          k = 2, 1, 0
+// i.e. the dgrad of a VIRTUAL layer with 16 input channels (x_k) and 16 (3 - k) output channels -- convs k+1 .. 3 stacked, each
+// restricted to its x_k input slice -- whose output gradient is the contiguous block range [g_{k+1} | .. | g_3].  One dgrad launch
+// per destination (accumulate onto G_k + ReLU mask in the epilogue, fp32 sum of all contributions, ONE bf16 rounding) instead of
+// read-modify-write passes over the lower blocks.  This kernel writes the three virtual layers' dgrad operand images.
+struct ChainSrc { const float* w[3]; bf16_t* dst[3]; long long total[3]; };
+__global__ void pack_dense_chain_kernel(ChainSrc S) {
+    const int k = blockIdx.y;                       // destination x_k; virtual cout = 16 (3 - k), cin = 16
+    const int n_in = 16 * (3 - k), ncb = 2 * (3 - k);
+    const long long total = S.total[k];
+    (void)n_in;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int e = idx & 7;
+        const long long row = idx >> 3;
+        const int oc = (int)(row % 16);             // channel of x_k
+        long long kgp = row / 16;
+        int c0 = 0, n = 0, kg = 0;
+        for (c0 = 0; c0 < ncb; c0 += CHUNK_CB) {
+            n = ncb - c0 < CHUNK_CB ? ncb - c0 : CHUNK_CB;
+            const int pad = ((9 * n + 3) / 4) * 4;
+            if (kgp < pad) { kg = (int)kgp; break; }
+            kgp -= pad;
+        }
+        float val = 0.f;
+        if (kg < 9 * n) {
+            const int tap = kg / n, cb = kg % n;
+            const int u = tap / 3, v = tap % 3;
+            const int ic = (c0 + cb) * 8 + e;       // virtual output channel: conv L = k + 1 + ic / 16, its output ic % 16
+            const int L = k + 1 + ic / 16, o = ic % 16;
+            val = S.w[L - 1][(((long long)o * (16 * L) + 16 * k + oc) * 3 + (2 - u)) * 3 + (2 - v)];
+        }
+        S.dst[k][idx] = f32_to_bf16(val);
+    }
+}
+
+extern "C" int mmif_pack_dense_chain(const float* w1, const float* w2, const float* w3, void* packed_v0, void* packed_v1, void* packed_v2,
+                                     void* stream) {
+    MMIF_REQUIRE(w1 != nullptr && w2 != nullptr && w3 != nullptr && packed_v0 != nullptr && packed_v1 != nullptr && packed_v2 != nullptr,
+                 "pack_dense_chain: NULL argument");
+    ChainSrc S;
+    S.w[0] = w1; S.w[1] = w2; S.w[2] = w3;
+    S.dst[0] = (bf16_t*)packed_v0; S.dst[1] = (bf16_t*)packed_v1; S.dst[2] = (bf16_t*)packed_v2;
+    for (int k = 0; k < 3; ++k) S.total[k] = (long long)(packed_bytes(16, 16 * (3 - k), 3) / 2);
+    hipLaunchKernelGGL(pack_dense_chain_kernel, dim3(8, 3), dim3(256), 0, (hipStream_t)stream, S);
+    return check_launch("pack_dense_chain");
+}
+
 extern "C" int mmif_pack_weights(const float* w, int32_t cout, int32_t cin, int32_t ksize, void* packed_fwd, void* packed_dgrad,
                                  void* stream) {
     MMIF_REQUIRE(ksize == 1 || ksize == 3, "pack_weights: ksize must be 1 or 3");

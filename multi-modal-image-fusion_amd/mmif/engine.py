@@ -288,6 +288,11 @@ class ModelEngine:
         return T.conv_dgrad(gy, s.w.detach(), x, gx, s.cin, s.cout, s.k, mask_bits, accum_bits, s.packed, impl, s.name + ":dgrad", fold=True)
 
     @staticmethod
+    def tag_dgrad(gy, x, gx, cin, cout, packed, tag):
+        """dgrad of a virtual layer (operand image only, no fp32 weights): accumulate onto gx + ReLU mask of x, folded"""
+        return T.conv_dgrad(gy, None, x, gx, cin, cout, 3, all_bits(gx.cb), all_bits(gx.cb), packed, _lib.IMPL_MFMA, tag, fold=True)
+
+    @staticmethod
     def c_wgrad(s, x, gy, ws, impl, accumulate=False):
         if s.split:
             T.conv_wgrad(x, gy, s.grad_target(), s.db, s.cin, s.cout, s.k, ws, False, impl, s.name + ":wgrad")
@@ -350,21 +355,47 @@ class DenseEncoderMixin:
                               [s.b.detach() for s in specs[1:]], F.view(base, 8)) for specs, img, base in branches], tag="encode:fwd")
 
     @staticmethod
+    def chain_images(specs):
+        """dgrad operand images of the DenseBlock's virtual gather layers, re-packed when the weights changed (one launch)"""
+        first, c0, c1, c2 = specs
+        key = (WEIGHTS_EPOCH[0],) + tuple((s.conv.weight._version, s.conv.weight.data_ptr()) for s in (c0, c1, c2))
+        cached = getattr(first, "_chain", None)
+        ws = [s.conv.weight.detach() for s in (c0, c1, c2)]
+        if cached is None or cached[1][0].dgrad.device != ws[0].device:
+            cached = (key, T.pack_dense_chain(*ws, ws[0].device))
+            first._chain = cached
+        elif cached[0] != key:
+            T.repack_dense_chain(cached[1], *ws)
+            cached = (key, cached[1])
+            first._chain = cached
+        return cached[1]
+
+    @staticmethod
     def enc_bwd(specs, img, F, GF, fbase, gbase, ws, impl, accumulate_w=False):
         """GF[gbase:gbase+8] holds dL/d(encoder output) (padded domain), top 2 blocks already masked."""
         first, c0, c1, c2 = specs
         GF = GF.as_folded()   # every contribution so far has been folded; each dgrad below re-folds what it adds
         # bf16 / MFMA: the four layers' weight gradients in ONE pass over [x0 | x1 | x2] and the finished [g0 | g1 | g2 | g3]
         # (csrc/enc_wgrad.hip; $MMIF_ENC_WGRAD=0 selects the layer-wise kernels)
-        fused = (F.dtype == torch.bfloat16 and impl != _lib.IMPL_VALU and os.environ.get("MMIF_ENC_WGRAD", "1") != "0"
-                 and all(s.k == 3 for s in specs) and [(s.cin, s.cout) for s in specs] == [(1, 16), (16, 16), (32, 16), (48, 16)])
+        hot = (F.dtype == torch.bfloat16 and impl != _lib.IMPL_VALU and all(s.k == 3 for s in specs)
+               and [(s.cin, s.cout) for s in specs] == [(1, 16), (16, 16), (32, 16), (48, 16)])
+        fused = hot and os.environ.get("MMIF_ENC_WGRAD", "1") != "0"
+        # ... and the dgrad chain per DESTINATION (gather form: one launch per x_k on the stacked virtual layer, fp32 sum of all
+        # contributions, one rounding) instead of per source layer (read-modify-write of the lower blocks); $MMIF_ENC_CHAIN=0: scatter
+        gather = hot and os.environ.get("MMIF_ENC_CHAIN", "1") != "0"
+        if gather:
+            pk = DenseEncoderMixin.chain_images(specs)
+            for k in (2, 1, 0):
+                ModelEngine.tag_dgrad(GF.view(gbase + 2 * (k + 1), 2 * (3 - k)), F.view(fbase + 2 * k, 2), GF.view(gbase + 2 * k, 2),
+                                      16, 16 * (3 - k), pk[k], f"{first.name}.chain{k}:dgrad")
         for s, nin in ((c2, 6), (c1, 4), (c0, 2)):
             g = GF.view(gbase + nin, 2)
             x = F.view(fbase, nin)
             if not fused:
                 T.conv_wgrad(x, g, s.dw, s.db, s.cin, s.cout, s.k, ws, accumulate_w, impl, s.name + ":wgrad")
             # accumulate into the lower blocks; this conv is the LAST contributor of its top 2 input blocks
-            ModelEngine.c_dgrad(s, g, x, GF.view(gbase, nin), bits(nin - 2, nin - 1), all_bits(nin), impl)
+            if not gather:
+                ModelEngine.c_dgrad(s, g, x, GF.view(gbase, nin), bits(nin - 2, nin - 1), all_bits(nin), impl)
         if fused:
             T.dense_encoder_wgrad(img, F.view(fbase, 6), GF.view(gbase, 8), [(s.dw, s.db) for s in specs], ws, accumulate_w, tag="encode:wgrad")
         else:

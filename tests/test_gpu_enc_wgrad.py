@@ -113,6 +113,7 @@ def test_models_train_step_with_fused_wgrad_matches_layerwise():
             res = []
             for flag in ("0", "1"):
                 os.environ["MMIF_ENC_WGRAD"] = flag
+                os.environ["MMIF_ENC_CHAIN"] = "0"      # same gradient chain in both runs: only the weight-gradient kernels differ
                 try:
                     m.zero_grad(set_to_none=True)
                     m(i1, i2).square().mean().backward()
@@ -120,9 +121,64 @@ def test_models_train_step_with_fused_wgrad_matches_layerwise():
                     res.append({k: p.grad.clone() for k, p in m.named_parameters()})
                 finally:
                     os.environ.pop("MMIF_ENC_WGRAD")
+                    os.environ.pop("MMIF_ENC_CHAIN")
             for k in res[0]:
                 a, b = res[0][k].double(), res[1][k].double()
                 if "encode" not in k:
                     assert torch.equal(a, b), (name, k)
                 else:
                     assert float((a - b).abs().max()) <= 1e-4 * max(1e-6, float(a.abs().max())), (name, k)
+
+
+def test_gather_form_dgrad_chain_vs_definition_and_scatter_form():
+    """DenseBlock backward chain per destination (virtual stacked layers, mmif_pack_dense_chain + one folded dgrad per x_k) against
+    the fp64 definition on the same bf16 operands -- g(x_k) = [x_k > 0] * (G_k + sum_{L>k} dgrad_L(g_L)|x_k), reflect-padding adjoint
+    included -- and against the layer-by-layer (scatter, read-modify-write) form it replaces."""
+    import core.model as M
+    from mmif import engine as E
+    from mmif import tensor as T
+    with dtype_ctx("bf16"):
+        for (n, h, w) in ((2, 32, 32), (1, 37, 53), (1, 64, 80)):
+            torch.manual_seed(3)
+            m = M.PFNetv1().to(DEV)
+            eng = E.PFNetv1Engine(m)
+            g = torch.Generator().manual_seed(11)
+            img = torch.rand(n, 1, h, w, generator=g).to(DEV)
+            (img,), _, _, _, dtype, impl = eng.prepare((img,))
+            specs = eng.enc[0]
+            x = torch.relu(torch.randn(n, 64, h, w, generator=g)).to(DEV)
+            G = torch.randn(n, 64, h, w, generator=g).to(DEV)
+            F = T.BT.from_nchw(x, torch.bfloat16)
+            res = {}
+            for mode in ("1", "0"):
+                GF = T.BT.from_nchw(G, torch.bfloat16, halo=1).as_folded()
+                os.environ["MMIF_ENC_CHAIN"] = mode
+                try:
+                    eng._assign_grad_views(torch.device(DEV))
+                    eng.enc_bwd(specs, img, F, GF, 0, 0, eng.workspace(torch.device(DEV)), impl)
+                finally:
+                    os.environ.pop("MMIF_ENC_CHAIN")
+                torch.cuda.synchronize()
+                assert float(GF.buf[:, :, 0].float().abs().max()) == 0.0 and float(GF.buf[:, :, :, 0].float().abs().max()) == 0.0   # ring stays zero
+                res[mode] = GF.to_nchw(64).double().cpu()
+            # fp64 definition on the bf16-rounded operands
+            xr = F.to_nchw(64).double().cpu()
+            Gr = T.BT.from_nchw(G, torch.bfloat16).to_nchw(64).double().cpu()
+            W = [s.conv.weight.detach().bfloat16().double().cpu() for s in specs[1:]]
+            gz = [None, None, None, Gr[:, 48:64]]
+            for k in (2, 1, 0):
+                t = Gr[:, 16 * k:16 * k + 16].clone()
+                for L in range(k + 1, 4):
+                    xin = xr[:, :16 * L].clone().requires_grad_(True)
+                    y = torch.nn.functional.conv2d(torch.nn.functional.pad(xin, (1, 1, 1, 1), mode="reflect"), W[L - 1])
+                    y.backward(gz[L])
+                    t = t + xin.grad[:, 16 * k:16 * k + 16]
+                gz[k] = t * (xr[:, 16 * k:16 * k + 16] > 0)
+                # (later layers see the bf16-ROUNDED g_k, as the kernels do)
+                gz[k] = gz[k].float().bfloat16().double()
+            want = torch.cat(gz, dim=1)
+            scale = float(want.abs().max())
+            e_gather = float((res["1"] - want).abs().max()) / scale
+            e_scatter = float((res["0"] - want).abs().max()) / scale
+            assert e_gather <= 1.2e-2, (n, h, w, e_gather)          # one bf16 rounding of the sum (+ its propagation through <= 2 layers)
+            assert e_gather <= e_scatter + 1e-3, (e_gather, e_scatter)   # never worse than the form that rounds after every contribution
