@@ -31,6 +31,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
 
 constexpr int MT = 16;        // output tile edge
+constexpr int DT_ROWS_C = 32; // rows of a conv_dma_kernel tile (= DT_ROWS below)
 constexpr int CHUNK_CB = 4;   // channel blocks per K chunk
 
 __host__ __device__ constexpr int plane_granules(int ks) { return ks == 3 ? 336 : 256; }  // bytes = 0 mod 256
@@ -160,17 +161,27 @@ __device__ inline uint4 load_in_gradfold(const TV& t, int in_, int c, int y, int
 // v_permlane16_swap pairs rows n, n+1: lanes with even g end up with all 8 channels of row n, odd g with all
 // 8 channels of row n+1, so every lane issues ONE 16-byte store per row pair (the 8-byte version was store-issue
 // bound: 16 stores ~ 10k cycles per block).  oxs / oys0: stored column / first stored row (of the lane's row pair 0).
-template <int MF, bool DGRAD>
+template <int MF, bool DGRAD, bool LM = false>
 __device__ inline void conv_epilogue(const f32x4 (&acc)[MF][4], const TV& tout, const TV& tmask, const float* s_bias, int mb, int in_,
                                      int oxs, int oys0, int g, int relu, unsigned long long mask_bits, unsigned long long accum_bits,
-                                     int xlim, int ylim) {   // stored columns / rows >= xlim / ylim are not written
+                                     int xlim, int ylim,   // stored columns / rows >= xlim / ylim are not written
+                                     const unsigned char* lmask = nullptr, int lrow0 = 0, int lcol = 0) {
+    // lmask (conv_dma_kernel dgrad): the ReLU-mask SIGN BITS of this tile, one byte per (channel block, tile row, tile column),
+    // staged into LDS by the loader waves ahead of time; lrow0 / lcol = this lane's first tile row / its column
     if (oxs >= xlim) return;
     const unsigned row_bytes = (unsigned)tout.ws * 16u;
     const unsigned pix_off = (unsigned)(oys0 * tout.ws + oxs) * 16u;   // inside one plane
     // dgrad: fetch the old gradient / the ReLU-mask activations of ALL the lane's outputs first -- one memory round trip for
     // the whole epilogue instead of one per 16-channel fragment (and the stores below may alias them as far as the compiler
     // can tell, which would serialise load -> store -> load)
-    uint4 oldv[DGRAD ? MF : 1][2], xmv[DGRAD ? MF : 1][2];
+    uint4 oldv[DGRAD ? MF : 1][2], xmv[(DGRAD && !LM) ? MF : 1][2];
+    unsigned lbits[(DGRAD && LM) ? MF : 1][2];
+    if (DGRAD && LM) {
+#pragma unroll
+        for (int m = 0; m < MF; ++m)
+#pragma unroll
+            for (int p2 = 0; p2 < 2; ++p2) lbits[LM ? m : 0][p2] = lmask[((2 * m + (g >> 1)) * DT_ROWS_C + lrow0 + 2 * p2) * MT + lcol];
+    }
     if (DGRAD) {
         const unsigned mpix_off = (unsigned)min(max(reflect_idx(oxs - tout.halo, tmask.w), 0), tmask.w - 1) * 16u;
 #pragma unroll
@@ -183,13 +194,13 @@ __device__ inline void conv_epilogue(const f32x4 (&acc)[MF][4], const TV& tout, 
 #pragma unroll
             for (int p2 = 0; p2 < 2; ++p2) {
                 oldv[m][p2] = make_uint4(0, 0, 0, 0);
-                xmv[m][p2] = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);   // 1.0: mask passes
+                if (!LM) xmv[m][p2] = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);   // 1.0: mask passes
                 const int oys = oys0 + 2 * p2;
                 if (blk_ok && oys < ylim) {
                     if (do_acc) oldv[m][p2] = *reinterpret_cast<const uint4*>(oplane + (2 * p2) * row_bytes);
-                    if (do_mask) {
+                    if (do_mask && !LM) {
                         const int y = min(max(reflect_idx(oys - tout.halo, tmask.h), 0), tmask.h - 1);
-                        xmv[m][p2] = *reinterpret_cast<const uint4*>(mplane + (unsigned)(y * tmask.ws) * 16u);
+                        xmv[LM ? 0 : m][p2] = *reinterpret_cast<const uint4*>(mplane + (unsigned)(y * tmask.ws) * 16u);
                     }
                 }
             }
@@ -225,7 +236,18 @@ __device__ inline void conv_epilogue(const f32x4 (&acc)[MF][4], const TV& tout, 
                 }
             } else {
                 const uint32_t ow[4] = {oldv[m][p2].x, oldv[m][p2].y, oldv[m][p2].z, oldv[m][p2].w};
-                const uint32_t xw[4] = {xmv[m][p2].x, xmv[m][p2].y, xmv[m][p2].z, xmv[m][p2].w};
+                const uint32_t xw[4] = {xmv[LM ? 0 : m][p2].x, xmv[LM ? 0 : m][p2].y, xmv[LM ? 0 : m][p2].z, xmv[LM ? 0 : m][p2].w};
+                if (LM) {
+                    const unsigned bits = ((mask_bits >> ocb) & 1ull) ? lbits[LM ? m : 0][p2] : 0xffu;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        c[2 * i] += __uint_as_float(ow[i] << 16);
+                        c[2 * i + 1] += __uint_as_float(ow[i] & 0xffff0000u);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if (!((bits >> i) & 1u)) c[i] = 0.f;
+                } else
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     c[2 * i] += __uint_as_float(ow[i] << 16);          // zeros when not accumulating
@@ -457,6 +479,7 @@ __global__ __launch_bounds__(256, MF == 1 ? 4 : 2) void conv_mfma_kernel(TV tin,
 // chunk of the current one, and a tile's epilogue (stores) runs after the NEXT chunk's DMAs are issued.
 // Requires the input gradient of a dgrad to be a FOLDED halo-1 tensor (mmif_fold_halo): its zeroed halo ring is the zero fill.
 constexpr int DT_ROWS = 32;                          // output tile rows (8 waves x 4)
+static_assert(DT_ROWS == DT_ROWS_C, "tile rows");
 constexpr int DTP_Y = DT_ROWS + 2, DTP_X = MT + 2;   // 34 x 18 input tile
 constexpr int DPL = 624;                             // granules per LDS plane (612 used); 9984 B = 0 mod 256
 constexpr int DIN_PIECES = CHUNK_CB * DPL / 64;      // 39 DMA pieces (64 granules = 1 KiB each)
@@ -568,7 +591,7 @@ constexpr int D_LOAD = 4;                                          // loader wav
 constexpr int DL_ITERS = (D_PIECES + D_LOAD - 1) / D_LOAD;         // 19 pieces per loader wave per chunk
 constexpr int DL_IN_ITERS = (DIN_PIECES + D_LOAD - 1) / D_LOAD;    // 10 of them may be input pieces
 
-template <bool DGRAD>
+template <bool DGRAD, bool LMASK>
 __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void conv_dma_kernel(TV tin, TV tout, TV tmask, const uint4* __restrict__ wpk,
                                                                               const float* __restrict__ bias, int n_out, int m16p, int relu,
                                                                               unsigned long long mask_bits, unsigned long long accum_bits,
@@ -578,6 +601,11 @@ __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void conv_dma_kernel(TV 
     __shared__ __attribute__((aligned(16))) char s_buf[2 * DBUF_BYTES];
     __shared__ int2 s_tab[2][DW_PIECES];
     __shared__ __attribute__((aligned(16))) float s_bias[3][MF * 16];
+    // dgrad: ReLU-mask sign bits of two tiles in flight ([item parity][channel block of the M-block][tile row][tile col], one byte =
+    // 8 channels).  The consumers' epilogue used to fetch the mask activations itself -- 8 global round trips on the critical path of
+    // every tile, and all of a tile's k-loop is only 2 chunks for a 64-channel input (decode.1's dgrad).  The LOADER waves have the
+    // time: they fetch the tile's mask granules two chunks ahead, reduce them to bits and park them here.
+    __shared__ unsigned char s_mask[LMASK ? 2 : 1][LMASK ? 8 * DT_ROWS * MT : 16];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: roles, piece indices, LDS bases and M0 stay in SGPRs
@@ -625,6 +653,8 @@ __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void conv_dma_kernel(TV 
     const int nch = (ncb_tot + CHUNK_CB - 1) / CHUNK_CB;
     const int ncb_last = ncb_tot - (nch - 1) * CHUNK_CB;
     const int total_q = count * nch;
+    // loader-staged mask bits need two chunks of lead per tile (and a third buffer with one chunk per tile: not worth the LDS)
+    // (LMASK: the host picks the instantiation -- dgrad, >= 2 chunks per tile, mask bits set)
     // k-group table of the ragged last chunk: .x = byte offset into the input tile, .y = byte offset into the weight slab
     if (tid < DW_PIECES) {
         const int kg = tid;
@@ -696,14 +726,61 @@ __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void conv_dma_kernel(TV 
                 s_bias[slot][t] = (bias != nullptr && oc < n_out) ? bias[oc] : 0.f;
             }
         };
-        DItem cur = decode(first);
+        // ---- mask bits: thread t of the 256 loader threads owns tile pixels t and t + 256 of every channel block of the M-block
+        uint4 mreg[LMASK ? 16 : 1];
+        bool mpend = false;       // mask granules of item `mitem` are in flight / in registers
+        int mpar = 0;
+        auto issue_mask = [&](const DItem& itm) {
+            const int t = tid - D_CONS * 64;
+#pragma unroll
+            for (int cbl = 0; cbl < 8; ++cbl) {
+                const int ocb = itm.mb * 8 + cbl;
+                const bool need = ocb < tout.cb && ((mask_bits >> ocb) & 1ull);   // wave-uniform
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int p = t + 256 * k, row = p >> 4, col = p & 15;
+                    const int oys = org + itm.tile_y * DT_ROWS + row, oxs = org + itm.tile_x * MT + col;
+                    const int y = min(max(reflect_idx(oys - tout.halo, tmask.h), 0), tmask.h - 1);
+                    const int x = min(max(reflect_idx(oxs - tout.halo, tmask.w), 0), tmask.w - 1);
+                    if (need) mreg[LMASK ? 2 * cbl + k : 0] = *reinterpret_cast<const uint4*>(tmask.base + tmask.gidx(itm.in_, min(ocb, tmask.cb - 1), y, x) * 16);
+                }
+            }
+        };
+        auto park_mask = [&](const DItem& itm, int par) {
+            const int t = tid - D_CONS * 64;
+#pragma unroll
+            for (int cbl = 0; cbl < 8; ++cbl) {
+                const int ocb = itm.mb * 8 + cbl;
+                const bool need = ocb < tout.cb && ((mask_bits >> ocb) & 1ull);
+                if (!need) continue;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const uint4 v = mreg[LMASK ? 2 * cbl + k : 0];
+                    const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+                    unsigned bits = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {   // bf16 > 0  <=>  positive as a signed 16-bit integer (activations are never NaN)
+                        bits |= ((short)(wv[i] & 0xffffu) > 0 ? 1u : 0u) << (2 * i);
+                        bits |= ((short)(wv[i] >> 16) > 0 ? 1u : 0u) << (2 * i + 1);
+                    }
+                    s_mask[LMASK ? par : 0][LMASK ? cbl * (DT_ROWS * MT) + t + 256 * k : 0] = (unsigned char)bits;
+                }
+            }
+        };
+        DItem cur = decode(first), mitem = cur;
         make_desc(cur);
         load_bias(cur, 0);
         issue_dma(cur, 0, 0);
         int c = 0, item_i = 0;
+        if (LMASK && nch == 2) { issue_mask(cur); mitem = cur; mpar = 0; mpend = true; }   // chunk 0 is the first tile's chunk nch - 2
         for (int q = 0; q < total_q; ++q) {
-            __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's pieces of chunk q have landed
+            __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's pieces of chunk q (and any mask granules) have landed
             __builtin_amdgcn_s_barrier();         // consumers: chunk q is readable; loaders: the other buffer is free
+            if (LMASK && mpend) {                 // the tile whose chunk nch - 2 just opened: its bits are visible at the NEXT barrier,
+                park_mask(mitem, mpar);           // which opens its last chunk -- before any of its epilogues runs
+                __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                mpend = false;
+            }
             if (++c == nch) {
                 c = 0;
                 ++item_i;
@@ -714,6 +791,7 @@ __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void conv_dma_kernel(TV 
                 }
             }
             if (q + 1 < total_q && !(abl & 1)) issue_dma(cur, c, (q & 1) ^ 1);
+            if (LMASK && q + 1 < total_q && c == nch - 2) { issue_mask(cur); mitem = cur; mpar = item_i & 1; mpend = true; }
         }
         return;
     }
@@ -722,7 +800,7 @@ __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void conv_dma_kernel(TV 
     f32x4 acc[MF][4];
     DItem cur = decode(first), pend = cur;
     bool have_pend = false;
-    int pend_slot = 0;
+    int pend_slot = 0, pend_par = 0;
     int c = 0, item_i = 0;
     for (int q = 0; q < total_q; ++q) {
         const int buf = q & 1;
@@ -730,9 +808,9 @@ __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void conv_dma_kernel(TV 
         __builtin_amdgcn_s_barrier();
         DTRACE();   // barrier passed
         if (have_pend) {   // waves 4..7: previous tile's outputs, stored under the partner wave's MFMAs (see below)
-            conv_epilogue<MF, DGRAD>(acc, tout, tmask, s_bias[pend_slot], pend.mb, pend.in_, org + pend.tile_x * MT + j,
+            conv_epilogue<MF, DGRAD, LMASK>(acc, tout, tmask, s_bias[pend_slot], pend.mb, pend.in_, org + pend.tile_x * MT + j,
                                      org + pend.tile_y * DT_ROWS + wave * 4 + (g & 1), g, relu, mask_bits, accum_bits, tout.ws - org,
-                                     tout.hs - org);
+                                     tout.hs - org, LMASK ? s_mask[LMASK ? pend_par : 0] : nullptr, wave * 4 + (g & 1), j);
             have_pend = false;
         }
         DTRACE();   // pending epilogue done
@@ -845,12 +923,13 @@ __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void conv_dma_kernel(TV 
             // their outputs now, under the partner's remaining MFMAs; waves 4..7 store after the next barrier, under the
             // partner's next k-loop.  (All eight storing at the same point leaves the MFMA pipe idle for a whole epilogue.)
             if (wave < 4) {
-                conv_epilogue<MF, DGRAD>(acc, tout, tmask, s_bias[item_i % 3], cur.mb, cur.in_, org + cur.tile_x * MT + j,
+                conv_epilogue<MF, DGRAD, LMASK>(acc, tout, tmask, s_bias[item_i % 3], cur.mb, cur.in_, org + cur.tile_x * MT + j,
                                          org + cur.tile_y * DT_ROWS + wave * 4 + (g & 1), g, relu, mask_bits, accum_bits, tout.ws - org,
-                                         tout.hs - org);
+                                         tout.hs - org, LMASK ? s_mask[LMASK ? item_i & 1 : 0] : nullptr, wave * 4 + (g & 1), j);
             } else {
                 pend = cur;
                 pend_slot = item_i % 3;
+                pend_par = item_i & 1;
                 have_pend = true;
             }
             ++item_i;
@@ -861,9 +940,9 @@ __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void conv_dma_kernel(TV 
     if (tr != nullptr) tr[63] = tr_n;
 #undef DTRACE
     if (have_pend)
-        conv_epilogue<MF, DGRAD>(acc, tout, tmask, s_bias[pend_slot], pend.mb, pend.in_, org + pend.tile_x * MT + j,
+        conv_epilogue<MF, DGRAD, LMASK>(acc, tout, tmask, s_bias[pend_slot], pend.mb, pend.in_, org + pend.tile_x * MT + j,
                                  org + pend.tile_y * DT_ROWS + wave * 4 + (g & 1), g, relu, mask_bits, accum_bits, tout.ws - org,
-                                 tout.hs - org);
+                                 tout.hs - org, LMASK ? s_mask[LMASK ? pend_par : 0] : nullptr, wave * 4 + (g & 1), j);
 }
 
 // ------------------------------------------------------------------ thin layers: asynchronous loader / consumer kernel
@@ -1520,6 +1599,7 @@ static int g_num_cus = 0;
 static int g_fuse_fold = -1;   // $MMIF_DGRAD_FOLD: 1 (default) = the DMA-staged dgrads fold the reflect halo themselves
 static int g_abl = 0;            // $MMIF_CONV_ABLATE (diagnostics): bit 0 = no staging DMAs after the first chunk
 
+static int g_lmask = -1;
 static int launch_conv_dma(bool dgrad, const TV& tin, const TV& tout, const TV& tmask, const void* wpk, const float* bias, int n_out,
                            int relu, uint64_t mask_bits, uint64_t accum_bits, int org, hipStream_t st) {
     const int tiles_x = cdiv(tout.ws - 2 * org, MT), tiles_y = cdiv(tout.hs - 2 * org, DT_ROWS);
@@ -1535,11 +1615,20 @@ static int launch_conv_dma(bool dgrad, const TV& tin, const TV& tout, const TV& 
     int G = g_num_cus / 8 * 8;   // one persistent block per CU (150 KB of LDS each)
     if (G < 8) G = 8;
     if (nitems < G) G = (int)nitems;
-    if (dgrad)
-        hipLaunchKernelGGL((conv_dma_kernel<true>), dim3(G), dim3((D_CONS + D_LOAD) * 64), 0, st, tin, tout, tmask, (const uint4*)wpk, bias, n_out, m16p, relu,
+    // dgrad with ReLU masks and >= 2 chunks per tile: the loader waves stage the mask bits ($MMIF_DGRAD_LMASK=0: consumers fetch them)
+    if (g_lmask < 0) {
+        const char* e = getenv("MMIF_DGRAD_LMASK");
+        g_lmask = (e != nullptr && e[0] == '0') ? 0 : 1;
+    }
+    const bool lmask = dgrad && g_lmask == 1 && mask_bits != 0 && cdiv(tin.cb, CHUNK_CB) >= 2;
+    if (dgrad && lmask)
+        hipLaunchKernelGGL((conv_dma_kernel<true, true>), dim3(G), dim3((D_CONS + D_LOAD) * 64), 0, st, tin, tout, tmask, (const uint4*)wpk, bias, n_out, m16p, relu,
+                           (unsigned long long)mask_bits, (unsigned long long)accum_bits, tiles_x, tiles_y, nmb, g_trace, g_abl, org);
+    else if (dgrad)
+        hipLaunchKernelGGL((conv_dma_kernel<true, false>), dim3(G), dim3((D_CONS + D_LOAD) * 64), 0, st, tin, tout, tmask, (const uint4*)wpk, bias, n_out, m16p, relu,
                            (unsigned long long)mask_bits, (unsigned long long)accum_bits, tiles_x, tiles_y, nmb, g_trace, g_abl, org);
     else
-        hipLaunchKernelGGL((conv_dma_kernel<false>), dim3(G), dim3((D_CONS + D_LOAD) * 64), 0, st, tin, tout, tmask, (const uint4*)wpk, bias, n_out, m16p, relu,
+        hipLaunchKernelGGL((conv_dma_kernel<false, false>), dim3(G), dim3((D_CONS + D_LOAD) * 64), 0, st, tin, tout, tmask, (const uint4*)wpk, bias, n_out, m16p, relu,
                            (unsigned long long)mask_bits, (unsigned long long)accum_bits, tiles_x, tiles_y, nmb, g_trace, g_abl, 0);
     return check_launch(dgrad ? "conv_dma dgrad" : "conv_dma fwd");
 }
