@@ -189,8 +189,8 @@ def main():
                         "unit": "TFLOP/s", "frac": ach / (PEAK_MFMA_BF16 if args.dtype == "bf16" else 157.3e12),
                         "avg_launch_ms": ms, "launches": len(evs), "traffic": None}
                 # HBM bytes per launch of this kernel from the TCC PMC passes of the same command (separate
-                # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 correction applied; profiles/r01_traffic.json)
-                tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+                # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 correction applied; profiles/r02_traffic.json, tools/prof_pmc.sh)
+                tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
                 if os.path.isfile(tpath) and B == 32 and S == 256 and Wd == 256 and args.dtype == "bf16" and args.mode == "train":
                     tj = json.load(open(tpath)).get(args.roofline_tag)
                     if tj:
