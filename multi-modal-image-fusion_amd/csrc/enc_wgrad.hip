@@ -52,7 +52,11 @@ __global__ __launch_bounds__(256, 2) void enc_wgrad_kernel(const float* __restri
     int gi = blockIdx.x;
     const int H = tx.h, W = tx.w;
 
-    ew_f32x4 acc3[3][3], acc2[3][2], acc1[3], acc0, accb[3];
+    // (wave 3's accumulators -- first layer acc0, bias sums accb -- live in acc3[0][0] / acc3[1][*]: the roles never meet, and a
+    //  union keeps the kernel inside the 256-register budget of two blocks per CU)
+    ew_f32x4 acc3[3][3], acc2[3][2], acc1[3];
+#define acc0 acc3[0][0]
+#define accb acc3[1]
 #pragma unroll
     for (int v = 0; v < 3; ++v) {
         acc1[v] = (ew_f32x4){0.f, 0.f, 0.f, 0.f};
@@ -60,9 +64,7 @@ __global__ __launch_bounds__(256, 2) void enc_wgrad_kernel(const float* __restri
         for (int b = 0; b < 3; ++b) acc3[v][b] = (ew_f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc2[v][b] = (ew_f32x4){0.f, 0.f, 0.f, 0.f};
-        accb[v] = (ew_f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    acc0 = (ew_f32x4){0.f, 0.f, 0.f, 0.f};
     const ew_bf16x8 ones = __builtin_bit_cast(ew_bf16x8, make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u));
 
     // transposing reads: in-group lane sl supplies pixel (sl >> 2), 4-channel chunk (sl & 3) of a 16-channel block
@@ -126,30 +128,51 @@ __global__ __launch_bounds__(256, 2) void enc_wgrad_kernel(const float* __restri
         if (tile + G < total && !(EW_ABL & 4)) prefetch(tile + G);   // in flight during the MFMAs below
         if (wave < 3 && !(EW_ABL & 1)) {
             const int u = wave;
-#pragma unroll 2
-            for (int s = 0; s < 8; ++s) {
+            // 8 k-steps x 3 tap columns = 24 groups of (3 activation fragments -> 6 MFMAs); the fragments of group i + 1 (and the three
+            // gradient fragments of the next k-step) are fetched under the MFMAs of group i: at two waves per SIMD nothing else hides
+            // the ~130-cycle latency of the transposing LDS reads (compute-only time of this kernel 115 -> see DESIGN.md)
+            auto ldA = [&](int s, ew_bf16x8 (&a)[3]) {
                 const int row = 2 * s + (g >> 1), col0 = 8 * (g & 1);
-                ew_bf16x8 a[3];
 #pragma unroll
                 for (int L = 1; L <= 3; ++L)
                     a[L - 1] = tr_frag(reinterpret_cast<const char*>(s_g) + ((2 * L + lane_plane) * EW_GPL + row * EW_T + col0 + tr_row) * 16 + lane_byte);
+            };
+            auto ldB = [&](int s, int v, ew_bf16x8 (&bx)[3]) {
+                const int row = 2 * s + (g >> 1), col0 = 8 * (g & 1);
 #pragma unroll
-                for (int v = 0; v < 3; ++v) {
-                    ew_bf16x8 bx[3];
-#pragma unroll
-                    for (int b = 0; b < 3; ++b)
-                        bx[b] = tr_frag(reinterpret_cast<const char*>(s_x) + ((2 * b + lane_plane) * EW_XPL + (row + u) * EW_TP + col0 + v + tr_row) * 16 + lane_byte);
-#pragma unroll
-                    for (int b = 0; b < 3; ++b) acc3[v][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], bx[b], acc3[v][b], 0, 0, 0);
-#pragma unroll
-                    for (int b = 0; b < 2; ++b) acc2[v][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], bx[b], acc2[v][b], 0, 0, 0);
-                    acc1[v] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], bx[0], acc1[v], 0, 0, 0);
+                for (int b = 0; b < 3; ++b)
+                    bx[b] = tr_frag(reinterpret_cast<const char*>(s_x) + ((2 * b + lane_plane) * EW_XPL + (row + u) * EW_TP + col0 + v + tr_row) * 16 + lane_byte);
+            };
+            ew_bf16x8 a[3], an[3], bx[2][3];   // (the gradient fragments of the next k-step arrive during its last group: one copy, after use)
+            ldA(0, a);
+            ldB(0, 0, bx[0]);
+#pragma unroll 6   // two k-steps per trip: every fragment buffer index below is a compile-time constant, nothing in flight is ever copied
+            for (int i = 0; i < 24; ++i) {
+                const int s = i / 3, v = i % 3;
+                if (i + 1 < 24) {
+                    const int s1 = (i + 1) / 3, v1 = (i + 1) % 3;
+                    if (v1 == 0) ldA(s1, an);
+                    ldB(s1, v1, bx[(i + 1) & 1]);
                 }
+#pragma unroll
+                for (int b = 0; b < 3; ++b) acc3[v][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], bx[i & 1][b], acc3[v][b], 0, 0, 0);
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc2[v][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], bx[i & 1][b], acc2[v][b], 0, 0, 0);
+                acc1[v] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], bx[i & 1][0], acc1[v], 0, 0, 0);
+                if (i + 1 < 24) {   // next group's DS reads first,
+                    if ((i + 1) % 3 == 0) __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+                    else __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);                                              // then this group's MFMAs
+                if (v == 2) { a[0] = an[0]; a[1] = an[1]; a[2] = an[2]; }
+                (void)s;
             }
         } else if (wave == 3 && !(EW_ABL & 2)) {
             // first layer: D[o][n] += sum_p g0[o](p) * B[p][n],  B[p][n] = image(p + tap n) for n < 9, 1 for n = 9 (-> db0), exact fp32
             const int un = sl / 3, vn = sl - 3 * un;
-#pragma unroll 1
+            // (four accumulator chains -- a dependent v_mfma_f32_16x16x4_f32 issues every 40 cycles, independent ones every 32 -- in
+            //  tiles of acc3 / acc2 this wave does not otherwise use; summed when the partial is written)
+#pragma unroll 2
             for (int s = 0; s < 8; ++s) {
                 const int row = 2 * s + (g >> 1), col0 = 8 * (g & 1);
 #pragma unroll
@@ -157,14 +180,21 @@ __global__ __launch_bounds__(256, 2) void enc_wgrad_kernel(const float* __restri
                     const ew_bf16x8 a = tr_frag(reinterpret_cast<const char*>(s_g) + ((2 * L + lane_plane) * EW_GPL + row * EW_T + col0 + tr_row) * 16 + lane_byte);
                     accb[L - 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, ones, accb[L - 1], 0, 0, 0);
                 }
+                float af[8], bf[8];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const int p = 4 * q + g, prow = 2 * s + (p >> 4), pcol = p & 15;
                     const unsigned short gb = *reinterpret_cast<const unsigned short*>(reinterpret_cast<const char*>(s_g) + ((sl >> 3) * EW_GPL + prow * EW_T + pcol) * 16 + (sl & 7) * 2);
-                    const float af = __uint_as_float((unsigned)gb << 16);
+                    af[q] = __uint_as_float((unsigned)gb << 16);
                     const float iv = s_img[(prow + min(un, 2)) * EW_TP + pcol + vn];
-                    const float bf = sl < 9 ? iv : (sl == 9 ? 1.f : 0.f);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf, acc0, 0, 0, 0);
+                    bf[q] = sl < 9 ? iv : (sl == 9 ? 1.f : 0.f);
+                }
+#pragma unroll
+                for (int q = 0; q < 8; q += 4) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[q], bf[q], acc0, 0, 0, 0);
+                    acc3[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[q + 1], bf[q + 1], acc3[0][1], 0, 0, 0);
+                    acc3[0][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[q + 2], bf[q + 2], acc3[0][2], 0, 0, 0);
+                    acc3[2][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[q + 3], bf[q + 3], acc3[2][0], 0, 0, 0);
                 }
             }
         }
@@ -191,14 +221,17 @@ __global__ __launch_bounds__(256, 2) void enc_wgrad_kernel(const float* __restri
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int oc = 4 * g + r;
-            red[EW_OFF0 + oc * 16 + sl] = acc0[r];
-            if (sl < 3) red[EW_OFFB + sl * 16 + oc] = accb[sl == 0 ? 0 : (sl == 1 ? 1 : 2)][r];   // every column of a ones product is the sum
+            red[EW_OFF0 + oc * 16 + sl] = (acc0[r] + acc3[0][1][r]) + (acc3[0][2][r] + acc3[2][0][r]);
+            const float bsum = sl == 0 ? accb[0][r] : (sl == 1 ? accb[1][r] : accb[2][r]);   // every column of a ones product is the sum
+            if (sl < 3) red[EW_OFFB + sl * 16 + oc] = bsum;
         }
     }
     __syncthreads();
     float* dst = partial + (long long)gi * EW_PER;
     for (int e = tid; e < EW_PER; e += 256) dst[e] = red[e];
 }
+#undef acc0
+#undef accb
 
 // ------------------------------------------------------------------ the same scheme for a single 3x3 layer ("tap-row" wgrad)
 // dW, db of ONE ConvLayer with 16 NXB input and 16 NGB output channels (decoder tails: 64 -> 32, 32 -> 16; the DenseBlock convs when the
