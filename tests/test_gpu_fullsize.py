@@ -95,3 +95,69 @@ def test_nest_512_samples_do_not_interact(name):
         for b in range(2):
             one = m(i1[b:b + 1].contiguous(), i2[b:b + 1].contiguous())
             assert torch.equal(both[b:b + 1], one), f"sample {b}: max diff {float((both[b:b + 1] - one).abs().max()):.3e}"
+
+
+def test_encoder_round2_kernels_at_full_size():
+    """B=32 256x256 (config 2): the fused encoder passes against the layer-wise kernels they replace, through properties that
+    need no CPU reference: streaming forward == four layers BIT for bit; fused weight gradients exactly linear under a
+    power-of-two scaling of the gradient and within fp32 summation-order noise of the layer-wise kernels; gather-form gradient
+    chain within one bf16 rounding per accumulated contribution of the scatter form."""
+    import os
+    import core.model as M
+    from mmif import engine as E
+    from mmif import tensor as T
+    B, S = 32, 256
+    with dtype_ctx("bf16"):
+        torch.manual_seed(3)
+        m = M.PFNetv1().cuda()
+        eng = E.PFNetv1Engine(m)
+        g = torch.Generator().manual_seed(11)
+        i1, i2 = torch.rand(B, 1, S, S, generator=g).cuda(), torch.rand(B, 1, S, S, generator=g).cuda()
+        (i1, i2), _, _, _, dtype, impl = eng.prepare((i1, i2))
+        dev = torch.device("cuda", 0)
+        Fa, Fb = T.BT.alloc(B, 128, S, S, dtype, dev), T.BT.alloc(B, 128, S, S, dtype, dev)
+        br = [(eng.enc[0], i1, 0), (eng.enc[1], i2, 8)]
+        os.environ["MMIF_ENC_STREAM"] = "0"
+        try:
+            eng.enc_fwd_all(br, Fa, dtype, impl)
+        finally:
+            os.environ.pop("MMIF_ENC_STREAM")
+        eng.enc_fwd_all(br, Fb, dtype, impl)
+        torch.cuda.synchronize()
+        assert torch.equal(Fa.buf.view(torch.int16), Fb.buf.view(torch.int16))
+        # weight gradients
+        ws = eng.workspace(dev)
+        G = T.BT.alloc(B, 64, S, S, dtype, dev, halo=1, zero=True)
+        G.buf[:, :, 1:-1, 1:-1].copy_((torch.randn(B, 8, S, S, 8, generator=g) * (torch.rand(B, 8, S, S, 8, generator=g) > 0.5)).to(dev))
+        G2 = T.BT.alloc(B, 64, S, S, dtype, dev, halo=1, zero=True)
+        G2.buf.copy_(G.buf * 2)
+        def grads():
+            return [(torch.zeros_like(s.conv.weight), torch.zeros_like(s.conv.bias)) for s in eng.enc[0]]
+        a, b, c = grads(), grads(), grads()
+        T.dense_encoder_wgrad(i1, Fb.view(0, 6), G.as_folded().view(0, 8), a, ws)
+        T.dense_encoder_wgrad(i1, Fb.view(0, 6), G2.as_folded().view(0, 8), b, ws)
+        for k, nin in ((3, 6), (2, 4), (1, 2)):
+            T.conv_wgrad(Fb.view(0, nin), G.as_folded().view(2 * k, 2), c[k][0], c[k][1], 16 * k, 16, 3, ws, False)
+        T.image_in_wgrad(i1, G.as_folded().view(0, 2), c[0][0], c[0][1], 16, 3, ws, False)
+        torch.cuda.synchronize()
+        for k in range(4):
+            assert torch.equal(b[k][0], 2 * a[k][0]) and torch.equal(b[k][1], 2 * a[k][1]), k       # exact: scaling by 2 commutes with every rounding
+            close(a[k][0].cpu().numpy(), c[k][0].cpu().numpy(), 2e-4, f"dW{k}")
+            close(a[k][1].cpu().numpy(), c[k][1].cpu().numpy(), 2e-4, f"db{k}")
+        # gradient chain: gather vs scatter form on the same inputs
+        res = {}
+        for mode in ("1", "0"):
+            GF = T.BT.alloc(B, 64, S, S, dtype, dev, halo=1, zero=True)
+            GF.buf.copy_(G.buf)
+            os.environ["MMIF_ENC_CHAIN"] = mode
+            try:
+                eng._assign_grad_views(dev)
+                eng.enc_bwd(eng.enc[0], i1, Fb, GF.as_folded(), 0, 0, ws, impl)
+            finally:
+                os.environ.pop("MMIF_ENC_CHAIN")
+            torch.cuda.synchronize()
+            assert float(GF.buf[:, :, 0].float().abs().max()) == 0.0       # the halo ring stays zero (folded convention)
+            res[mode] = GF.buf.float()
+        assert torch.equal(res["1"][:, 6:], res["0"][:, 6:])               # g3 is an input
+        d = (res["1"] - res["0"]).abs().max().item() / res["0"].abs().max().item()
+        assert d < 3e-2, d
