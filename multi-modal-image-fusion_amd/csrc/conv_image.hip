@@ -202,6 +202,46 @@ __global__ __launch_bounds__(256) void image_out_fwd_kernel(TV tx, const float* 
     img[((long long)in_ * tx.h + y) * tx.w + x] = r;
 }
 
+// bf16, 3x3, 16 input channels (the last layer of every PFNet / DenseFuse decoder): the kernel above issues 18 granule loads per
+// pixel through the vector-memory path (288 B per pixel for 32 B of data: load-issue bound, 50 us at B=32 256x256).  Here a block
+// stages the 18 x 18 x 2-plane reflect-padded tile into LDS once (2.5 loads per thread) and every pixel reads its 18 granules from
+// there; weights live in registers.  Same FMA order (channel block, tap, channel) => bit-identical.
+__global__ __launch_bounds__(256) void image_out_fwd_tiled_kernel(TV tx, const float* __restrict__ w, const float* __restrict__ bias,
+                                                                  float* __restrict__ img, int relu, int tiles_x) {
+    constexpr int TP = ITILE + 2;
+    __shared__ __attribute__((aligned(16))) uint4 s_x[2][TP * TP];
+    const int tid = threadIdx.x;
+    const int x0 = (blockIdx.x % tiles_x) * ITILE, y0 = (blockIdx.x / tiles_x) * ITILE;
+    const int in_ = blockIdx.y;
+    for (int e = tid; e < 2 * TP * TP; e += 256) {
+        const int b = e / (TP * TP), p = e - b * (TP * TP);
+        const int y = min(max(reflect_idx(y0 + p / TP - 1, tx.h), 0), tx.h - 1);
+        const int x = min(max(reflect_idx(x0 + p % TP - 1, tx.w), 0), tx.w - 1);
+        s_x[b][p] = *reinterpret_cast<const uint4*>(tx.base + tx.gidx(in_, b, y, x) * 16);
+    }
+    float wr[16][9];
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wr[c][t] = w[c * 9 + t];
+    __syncthreads();
+    const int txx = tid & 15, tyy = tid >> 4;
+    const int x = x0 + txx, y = y0 + tyy;
+    if (y >= tx.h || x >= tx.w) return;
+    float r = bias ? bias[0] : 0.f;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            float v[8];
+            Elem<bf16_t>::load(&s_x[b][(tyy + t / 3) * TP + txx + t % 3], v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) r = fmaf(v[i], wr[b * 8 + i][t], r);
+        }
+    if (relu) r = fmaxf(r, 0.f);
+    img[((long long)in_ * tx.h + y) * tx.w + x] = r;
+}
+
 // ---------------------------------------------------------------- Cout == 1 dgrad
 // gx[y][x][c] (+)= sum_{u,v} W[0][c][k-1-u][k-1-v] * g0(y+u-p, x+v-p) over the stored domain of gx.
 template <typename T, int KS>
@@ -437,6 +477,10 @@ extern "C" int mmif_conv2d_image_out_fwd(const mmif_tensor* x, const float* w, c
     const int tiles_x = cdiv(tx.w, ITILE), tiles_y = cdiv(tx.h, ITILE);
     const size_t shm = (size_t)cin * ksize * ksize * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
+    if (x->dtype == MMIF_BF16 && ksize == 3 && cin == 16 && x->cb == 2) {
+        hipLaunchKernelGGL(image_out_fwd_tiled_kernel, dim3(tiles_x * tiles_y, tx.n), dim3(256), 0, st, tx, w, bias, img, relu, tiles_x);
+        return check_launch("image_out_fwd");
+    }
 #define CALL(T, KS) hipLaunchKernelGGL((image_out_fwd_kernel<T, KS>), dim3(tiles_x * tiles_y, tx.n), dim3(256), shm, st, tx, w, bias, img, cin, relu, tiles_x)
     DISPATCH_T_KS(x->dtype, ksize, CALL);
 #undef CALL
