@@ -128,3 +128,23 @@ def test_argument_validation():
     t = _lib.MmifTensor(None, 1, 1, 8, 8, 0, 8, 0, 8, 0)
     assert _lib.lib.mmif_dense_encoder_fwd(C.byref(e), C.byref(t), None, None, None) != 0
     assert b"dense_encoder_fwd" in _lib.lib.mmif_last_error()
+
+
+def test_stream_geometry_fuzz():
+    """seeded random shapes (strip / segment / ragged-edge geometry of the streaming kernel): bit-identical to the layer-wise path"""
+    import random
+    rnd = random.Random(1234)
+    shapes = [(rnd.randint(1, 3), rnd.randint(2, 90), rnd.randint(2, 140)) for _ in range(24)] + [(1, 2, 33), (1, 33, 2), (1, 3, 58), (5, 31, 59)]
+    with dtype_ctx("bf16"):
+        for n, h, w in shapes:
+            eng, T, i1, i2, dtype, impl = _engine_and_buffers(n, h, w, 100 + h * w)
+            Fa, Fb = T.BT.alloc(n, 128, h, w, dtype, DEV), T.BT.alloc(n, 128, h, w, dtype, DEV)
+            br = [(eng.enc[0], i1, 0), (eng.enc[1], i2, 8)]
+            os.environ["MMIF_ENC_STREAM"] = "0"
+            try:
+                eng.enc_fwd_all(br, Fa, dtype, impl)
+            finally:
+                os.environ.pop("MMIF_ENC_STREAM")
+            eng.enc_fwd_all(br, Fb, dtype, impl)
+            torch.cuda.synchronize()
+            assert torch.equal(Fa.buf.view(torch.int16), Fb.buf.view(torch.int16)), (n, h, w)

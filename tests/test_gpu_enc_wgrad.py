@@ -182,3 +182,40 @@ def test_gather_form_dgrad_chain_vs_definition_and_scatter_form():
             e_scatter = float((res["0"] - want).abs().max()) / scale
             assert e_gather <= 1.2e-2, (n, h, w, e_gather)          # one bf16 rounding of the sum (+ its propagation through <= 2 layers)
             assert e_gather <= e_scatter + 1e-3, (e_gather, e_scatter)   # never worse than the form that rounds after every contribution
+
+
+def test_wgrad_kernels_geometry_fuzz():
+    """seeded random shapes: the fused encoder wgrad and the tap-row single-layer wgrad (64->32, 32->16, 48->16) against the
+    per-input-group kernels they replace ($MMIF_WGRAD_TAPROW=0 is read once per process, so the reference here is the VALU family)"""
+    import random
+    from mmif import _lib
+    rnd = random.Random(4321)
+    shapes = [(rnd.randint(1, 3), rnd.randint(2, 70), rnd.randint(2, 90)) for _ in range(12)]
+    with dtype_ctx("bf16"):
+        for n, h, w in shapes:
+            eng, T, img, F, GF = _setup(n, h, w, 50 + h * w)
+            ws = eng.workspace(torch.device(DEV))
+            fused = _grads(eng)
+            T.dense_encoder_wgrad(img, F.view(0, 6), GF.view(0, 8), fused, ws)
+            for k, nin in ((3, 6), (2, 4), (1, 2)):
+                dw, db = torch.zeros_like(fused[k][0]), torch.zeros_like(fused[k][1])
+                T.conv_wgrad(F.view(0, nin), GF.view(2 * k, 2), dw, db, 16 * k, 16, 3, ws, False, _lib.IMPL_VALU)
+                torch.cuda.synchronize()
+                scale = max(1e-6, float(dw.abs().max()))
+                assert float((fused[k][0] - dw).abs().max()) / scale < 1e-4, (n, h, w, k)
+                assert float((fused[k][1] - db).abs().max()) / max(1e-6, float(db.abs().max())) < 1e-4, (n, h, w, k)
+            # tap-row kernel (MFMA dispatch) vs the VALU kernel on a 64 -> 32 and a 32 -> 16 layer
+            for cin, cout in ((64, 32), (32, 16)):
+                g = torch.Generator().manual_seed(h * 7 + w)
+                x = T.BT.from_nchw(torch.relu(torch.randn(n, cin, h, w, generator=g)).to(DEV), torch.bfloat16)
+                gy = T.BT.from_nchw(torch.randn(n, cout, h, w, generator=g).to(DEV), torch.bfloat16, halo=1).as_folded()
+                wsl = torch.empty(T.wgrad_workspace_bytes(cin, cout, 3) // 4 + 1, dtype=torch.float32, device=DEV)
+                out = {}
+                for impl in (_lib.IMPL_MFMA, _lib.IMPL_VALU):
+                    dw, db = torch.zeros(cout, cin, 3, 3, device=DEV), torch.zeros(cout, device=DEV)
+                    T.conv_wgrad(x, gy, dw, db, cin, cout, 3, wsl, False, impl)
+                    out[impl] = (dw, db)
+                torch.cuda.synchronize()
+                a, b = out[_lib.IMPL_MFMA], out[_lib.IMPL_VALU]
+                assert float((a[0] - b[0]).abs().max()) / max(1e-6, float(b[0].abs().max())) < 1e-4, (n, h, w, cin, cout)
+                assert float((a[1] - b[1]).abs().max()) / max(1e-6, float(b[1].abs().max())) < 1e-4, (n, h, w, cin, cout)
