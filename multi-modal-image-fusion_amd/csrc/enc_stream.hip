@@ -302,6 +302,8 @@ static int es_check_branch(const mmif_dense_encoder* e, const mmif_tensor* out, 
     if (int rc = validate_tensor(out, "out")) return rc;
     MMIF_REQUIRE(out->dtype == MMIF_BF16 && out->halo == 0 && out->cb == 8, "dense_encoder_fwd: %s: out must be a bf16 halo-0 view of 8 channel blocks", which);
     MMIF_REQUIRE(out->h >= 2 && out->w >= 2, "reflect padding needs h,w >= 2");
+    MMIF_REQUIRE((long long)out->cb_total * out->h * out->w * 16 < (1ll << 32),
+                 "dense_encoder_fwd: %s: one image of the output allocation must stay below 4 GiB (32-bit lane offsets)", which);
     return MMIF_OK;
 }
 
