@@ -219,3 +219,39 @@ def test_wgrad_kernels_geometry_fuzz():
                 a, b = out[_lib.IMPL_MFMA], out[_lib.IMPL_VALU]
                 assert float((a[0] - b[0]).abs().max()) / max(1e-6, float(b[0].abs().max())) < 1e-4, (n, h, w, cin, cout)
                 assert float((a[1] - b[1]).abs().max()) / max(1e-6, float(b[1].abs().max())) < 1e-4, (n, h, w, cin, cout)
+
+
+def test_fused_encoder_paths_vs_layerwise_all_models_and_modes():
+    """every engine that owns a DenseBlock encoder -- PFNetv1, VIFNet (shared encoder, accumulating second branch), DenseFuse (two
+    inputs and the auto-encoder call forward(img)), PFNetv2 -- trained for one step with the three fused encoder passes on
+    (streaming forward, gather chain, fused weight gradients) and all off: same output bit for bit, parameter gradients within the
+    bf16 rounding differences of the gradient chain."""
+    import core.model as M
+    flags = ("MMIF_ENC_STREAM", "MMIF_ENC_CHAIN", "MMIF_ENC_WGRAD")
+    with dtype_ctx("bf16"):
+        for name, single in (("PFNetv1", False), ("VIFNet", False), ("DenseFuse", False), ("DenseFuse", True), ("PFNetv2", False)):
+            torch.manual_seed(7)
+            m = getattr(M, name)().to(DEV)
+            g = torch.Generator().manual_seed(3)
+            i1, i2 = torch.rand(2, 1, 40, 56, generator=g).to(DEV), torch.rand(2, 1, 40, 56, generator=g).to(DEV)
+            res = []
+            for on in ("0", "1"):
+                for f in flags:
+                    os.environ[f] = on
+                try:
+                    m.zero_grad(set_to_none=True)
+                    y = m(i1) if single else m(i1, i2)
+                    (y * y).mean().backward()
+                    torch.cuda.synchronize()
+                    res.append((y.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters()}))
+                finally:
+                    for f in flags:
+                        os.environ.pop(f)
+            assert torch.equal(res[0][0], res[1][0]), (name, single)
+            for k in res[0][1]:
+                a, b = res[0][1][k].double(), res[1][1][k].double()
+                scale = max(1e-7, float(a.abs().max()))
+                if "encode" in k:
+                    assert float((a - b).abs().max()) <= 2e-2 * scale, (name, single, k, float((a - b).abs().max()) / scale)
+                else:
+                    assert torch.equal(a, b), (name, single, k)
