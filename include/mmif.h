@@ -318,6 +318,16 @@ int mmif_grad_loss(const float* img1, const float* img2, const float* imgf, int3
                    float weight, int32_t mode_max, int32_t l2, float* loss_out, float* grad_out, void* workspace,
                    size_t workspace_bytes, void* stream);
 
+/* Backward of ONE thin 3x3 ConvLayer (64 -> 32, 32 -> 16: decode.2 / decode.3 of every PFNet / DenseFuse decoder, core/model.py:83-85) in one
+ * launch: gx = [x > 0] * dgrad(gy) in the folded convention -- what mmif_conv2d_reflect_dgrad_folded(mask_bits = all, accum_bits = 0)
+ * writes, bit for bit -- AND dw / db as mmif_conv2d_reflect_wgrad, from a single staging of the gradient and activation tiles (160 / 80
+ * channel planes instead of 256 / 128).  gy: folded halo-1; x: the layer's forward input (halo 0); gx: halo 1 with a zero ring.
+ * Workspace: mmif_conv2d_wgrad_workspace(cin, cout, 3).  mmif_conv2d_bwd_pair_supported tells which layers it covers. */
+int mmif_conv2d_bwd_pair_supported(int32_t cin, int32_t cout, int32_t ksize);
+int mmif_conv2d_reflect_bwd_pair(const mmif_tensor* gy, const void* w_packed_t, const mmif_tensor* x, const mmif_tensor* gx, float* dw, float* db,
+                                 int32_t cin, int32_t cout, int32_t ksize, int32_t accumulate, void* workspace, size_t workspace_bytes,
+                                 void* stream);
+
 /* ---- streaming DenseBlock encoder (core/model.py:73-80 = ConvLayer(1,16) + DenseBlock(16,16): PFNetv1.encode1/2, DenseFuse / PFNetv2 /
  *      VIFNet .encode), forward, bf16: the four layers as ONE line-buffer kernel (csrc/enc_stream.hip) -- reads the image, writes the
  *      64 concatenated channels [x0 | x1 | x2 | x3] once.  Bit-identical to mmif_conv2d_image_in_fwd + three mmif_conv2d_reflect_fwd

@@ -18,6 +18,10 @@ bool wgrad_mfma_supported(int ks, int cin, int cout);
 size_t wgrad_mfma_workspace(int cin, int cout, int ks);
 int wgrad_mfma(int ks, const TV& tx, const TV& tg, float* dw, float* db, int cin, int cout, int accumulate, float* ws,
                hipStream_t st);
+bool bwd_pair_supported(int ks, int cin, int cout);
+size_t bwd_pair_workspace(int cin, int cout);
+int bwd_pair(const TV& tx, const TV& tg, const TV& tgx, const void* wpk_dgrad, float* dw, float* db, int cin, int cout, int accumulate, float* ws,
+             hipStream_t st);
 }  // namespace mmif
 
 using namespace mmif;
@@ -124,4 +128,29 @@ extern "C" int mmif_conv2d_reflect_wgrad(const mmif_tensor* x, const mmif_tensor
     TV tx = make_tv(x), tg = make_tv(gy);
     if (im == MMIF_IMPL_MFMA) return wgrad_mfma(ksize, tx, tg, dw, db, cin, cout, accumulate, (float*)workspace, (hipStream_t)stream);
     return wgrad_valu(x->dtype, ksize, tx, tg, dw, db, cin, cout, accumulate, (float*)workspace, (hipStream_t)stream);
+}
+
+// Backward of one thin 3x3 ConvLayer in ONE launch: gx = [x > 0] * dgrad(gy) (folded convention, as mmif_conv2d_reflect_dgrad_folded with
+// every channel block masked and none accumulated) AND dw, db (as mmif_conv2d_reflect_wgrad) from a single staging of the g and x tiles.
+extern "C" int mmif_conv2d_bwd_pair_supported(int32_t cin, int32_t cout, int32_t ksize) { return bwd_pair_supported(ksize, cin, cout) ? 1 : 0; }
+
+extern "C" int mmif_conv2d_reflect_bwd_pair(const mmif_tensor* gy, const void* w_packed_t, const mmif_tensor* x, const mmif_tensor* gx, float* dw,
+                                            float* db, int32_t cin, int32_t cout, int32_t ksize, int32_t accumulate, void* workspace,
+                                            size_t workspace_bytes, void* stream) {
+    if (int rc = validate_tensor(gy, "gy")) return rc;
+    if (int rc = validate_tensor(x, "x")) return rc;
+    if (int rc = validate_tensor(gx, "gx")) return rc;
+    MMIF_REQUIRE(bwd_pair_supported(ksize, cin, cout), "conv2d_reflect_bwd_pair: unsupported layer %d -> %d k%d", cin, cout, ksize);
+    MMIF_REQUIRE(w_packed_t != nullptr && dw != nullptr, "conv2d_reflect_bwd_pair: NULL operand image / dw");
+    MMIF_REQUIRE(gy->dtype == MMIF_BF16 && x->dtype == MMIF_BF16 && gx->dtype == MMIF_BF16, "conv2d_reflect_bwd_pair: bf16 tensors expected");
+    MMIF_REQUIRE(gy->halo == 1 && (gy->flags & MMIF_T_FOLDED), "conv2d_reflect_bwd_pair: gy must be a folded halo-1 gradient");
+    MMIF_REQUIRE(x->halo == 0 && gx->halo == 1, "conv2d_reflect_bwd_pair: x halo 0, gx halo 1 expected");
+    MMIF_REQUIRE(gy->n == x->n && gy->h == x->h && gy->w == x->w && gx->n == x->n && gx->h == x->h && gx->w == x->w, "conv2d_reflect_bwd_pair: shape mismatch");
+    MMIF_REQUIRE((cin + 7) / 8 == x->cb && x->cb == gx->cb && (cout + 7) / 8 == gy->cb, "conv2d_reflect_bwd_pair: channel blocks do not match");
+    MMIF_REQUIRE(x->h >= 4 && x->w >= 4, "conv2d_reflect_bwd_pair: needs h, w >= 4 (fold steps inside the border tiles)");
+    if (workspace == nullptr || workspace_bytes < bwd_pair_workspace(cin, cout)) {
+        set_error("conv2d_reflect_bwd_pair: workspace too small");
+        return MMIF_EWORKSPACE;
+    }
+    return bwd_pair(make_tv(x), make_tv(gy), make_tv(gx), w_packed_t, dw, db, cin, cout, accumulate, (float*)workspace, (hipStream_t)stream);
 }

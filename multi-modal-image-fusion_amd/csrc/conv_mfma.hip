@@ -506,7 +506,7 @@ template <int N> struct IC { static constexpr int value = N; };
 // One chunk's fold steps of the wave whose row n is stored row 1 + yl + n and whose lane j is stored column 1 + xl + j.
 // in_c / w_c: this lane group's channel-block plane of the staged gradient tile (at the wave's first row, lane's column) and of
 // the chunk's weight planes (tap t at w_c + t * ncb * MF * 256); pitch = granules per tile row.
-template <int MF>
+template <int MF, int NBUF = (MF == 3 ? 1 : 2)>
 __device__ inline void dgrad_fold_steps(f32x4 (&acc)[MF][4], const char* in_c, const char* w_c, int ncb, int pitch, int g, int j, int yl,
                                         int xl, int hs, int ws) {
     const int nb = hs - 4 - yl;                 // row n of stored row hs-3 (stored row 2 is row 1 of the wave with yl == 0)
@@ -543,7 +543,7 @@ __device__ inline void dgrad_fold_steps(f32x4 (&acc)[MF][4], const char* in_c, c
     // a ring COLUMN folds onto one lane of every row: three more k-steps (taps (u, vcol), u = 0..2) of the usual shape -- 4 weight
     // + 4 gradient fragments, 4 MF MFMAs -- with the next step's operands fetched under the current step's MFMAs
     auto col_steps = [&](int vcol, int bcol, int jsel) {
-        constexpr int NB = MF == 3 ? 1 : 2;   // (the 128-register budget of the MF = 3 thin kernel has no room for a second operand set)
+        constexpr int NB = NBUF;   // (default 1 for MF = 3: the 128-register budget of the thin kernel has no room for a second operand set)
         bf16x8 a[NB][MF], b[NB][4];
         auto fetch = [&](int u, int slot) {
 #pragma unroll
@@ -1562,6 +1562,237 @@ __global__ __launch_bounds__(256) void wgrad_dma_reduce(const float* __restrict_
 
 // ------------------------------------------------------------------ host side
 static long long* g_trace = nullptr;  // device buffer [1024][64] for the optional phase trace
+// ------------------------------------------------------------------ fused backward of ONE thin 3x3 layer: dgrad + wgrad ("bwd pair")
+// decode.2 (64 -> 32) and decode.3 (32 -> 16) of every PFNet / DenseFuse decoder: their dgrad (read g + the ReLU-mask activations x, write
+// gx) and their wgrad (read x + g again) move 256 / 128 planes for 160 / 80 of data.  Here a block stages ONE 18 x 18 tile of g (zero
+// ring) and of x (reflect halo) and both products come out of it:
+//   waves 0..3  dgrad of tile rows 4w .. 4w+3 over all 16 NXB input channels (MFMA, the thin kernel's k-group order and fold steps =>
+//               bit-identical to it), ReLU mask from the x tile already in LDS, gx stored in the folded convention (interior only);
+//   waves 4..6  weight gradient, tap row u = wave - 4 (the tap-row scheme of enc_wgrad.hip); wave 7 the bias sums.
+// The dgrad operand image (<= 36 KB) is resident in LDS; per-block wgrad partials in natural order, fixed-order reduction.
+constexpr int BP_PL = 324;   // granules per staged plane (18 x 18)
+template <int NXB, int NGB>
+__global__ __launch_bounds__(512, NXB == 4 ? 1 : 2) void bwd_pair_kernel(TV tx, TV tg, TV tgx, const uint4* __restrict__ wpk, float* __restrict__ partial,
+                                                                         int tiles_x, int tpi, int total, int G) {
+    constexpr int MF = NXB, TP = MT + 2;
+    constexpr int CIN = 16 * NXB, COUT = 16 * NGB;
+    constexpr int NCB = 2 * NGB;                          // channel blocks of g = K chunk of the dgrad (<= 4: one chunk)
+    constexpr int NKG = 9 * NCB, NKGP = (NKG + 3) / 4 * 4;
+    constexpr int WBYTES = NKGP * MF * 256;
+    constexpr int PER = COUT * CIN * 9 + COUT;
+    constexpr int TILE_BYTES = (2 * NXB + NCB) * BP_PL * 16 + WBYTES;
+    constexpr int SM_BYTES = TILE_BYTES > PER * 4 ? TILE_BYTES : PER * 4;
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    __shared__ __attribute__((aligned(16))) char smem[SM_BYTES];
+    __shared__ int2 s_tab[NKGP];
+    u32x4* s_x = reinterpret_cast<u32x4*>(smem);
+    u32x4* s_g = s_x + 2 * NXB * BP_PL;
+    char* s_w = reinterpret_cast<char*>(s_g + NCB * BP_PL);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    const int gi = blockIdx.x;
+    const int H = tx.h, W = tx.w;
+    // resident dgrad operand image + k-group table (.x byte offset into a g plane set, .y into the image)
+    for (int e = tid; e < WBYTES / 16; e += 512) reinterpret_cast<uint4*>(s_w)[e] = wpk[e];
+    if (tid < NKGP) {
+        int tap = 0, cb = 0, plane = tid;
+        if (tid < NKG) { tap = visit_tap(tid / NCB, 3); cb = tid % NCB; plane = tap * NCB + cb; }
+        s_tab[tid] = make_int2((cb * BP_PL + (tap / 3) * TP + (tap % 3)) * 16, plane * MF * 256);
+    }
+    // ONE accumulator file for the three roles (they never meet in a wave; separate arrays would cost the union of their registers):
+    // weight-gradient waves: uacc[(v NXB + b) NGB + m], persistent; bias wave: uacc[m]; dgrad waves: uacc[4 m + n], cleared per tile
+    constexpr int NACC = 3 * NXB * NGB > 4 * MF ? 3 * NXB * NGB : 4 * MF;
+    f32x4 uacc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) uacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#define WACC(v, b, m) uacc[((v) * NXB + (b)) * NGB + (m)]
+#define DACC(m, n) uacc[4 * (m) + (n)]
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u));
+    const int tr_row = j >> 2, tr_c = j & 3;
+    const int lane_plane = tr_c >> 1, lane_byte = (tr_c & 1) * 8;
+    auto tr_frag = [&](const char* base) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, base));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, base + 4 * 16));
+        const s16x8 c = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8, c);
+    };
+    constexpr int NXR = (2 * NXB * BP_PL + 511) / 512, NGR = (NCB * BP_PL + 511) / 512;
+    u32x4 rx[NXR], rg[NGR];
+    auto prefetch = [&](int tile) {
+        const int in_ = tile / tpi, tt = tile - in_ * tpi;
+        const int y0 = (tt / tiles_x) * MT, x0 = (tt % tiles_x) * MT;
+#pragma unroll
+        for (int i = 0; i < NXR; ++i) {
+            const int e = min(tid + 512 * i, 2 * NXB * BP_PL - 1);
+            const int cb = e / BP_PL, p = e - cb * BP_PL;
+            const int y = min(max(reflect_idx(y0 + p / TP - 1, H), 0), H - 1);
+            const int x = min(max(reflect_idx(x0 + p % TP - 1, W), 0), W - 1);
+            rx[i] = *reinterpret_cast<const u32x4*>(tx.base + tx.gidx(in_, cb, y, x) * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < NGR; ++i) {   // g in STORED coordinates (halo 1, folded: the ring is zero = the zero padding of the dgrad)
+            const int e = min(tid + 512 * i, NCB * BP_PL - 1);
+            const int cb = e / BP_PL, p = e - cb * BP_PL;
+            const int ys = y0 + p / TP, xs = x0 + p % TP;
+            const bool inside = ys < tg.hs && xs < tg.ws;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(tg.base + tg.gidx(in_, cb, min(ys, tg.hs - 1), min(xs, tg.ws - 1)) * 16);
+            rg[i] = inside ? v : (u32x4){0u, 0u, 0u, 0u};
+        }
+    };
+    if (gi < total) prefetch(gi);
+    for (int tile = gi; tile < total; tile += G) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NXR; ++i) {
+            const int e = tid + 512 * i;
+            if (e < 2 * NXB * BP_PL) s_x[e] = rx[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NGR; ++i) {
+            const int e = tid + 512 * i;
+            if (e < NCB * BP_PL) s_g[e] = rg[i];
+        }
+        __syncthreads();
+        const int in_ = tile / tpi, tt = tile - in_ * tpi;
+        const int ty0 = tt / tiles_x, tx0 = tt % tiles_x;
+        if (tile + G < total) prefetch(tile + G);
+        if (wave < 4) {
+            // ---------------- dgrad: rows 4 wave .. 4 wave + 3, all MF m-fragments
+            f32x4 (&acc)[MF][4] = *reinterpret_cast<f32x4 (*)[MF][4]>(&uacc[0]);
+#pragma unroll
+            for (int m = 0; m < MF; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const char* in_lane = reinterpret_cast<const char*>(s_g) + ((wave * 4) * TP + j) * 16;
+            const char* w_lane = s_w + j * 16;
+            int2 off = s_tab[g];
+#pragma unroll 1
+            for (int s = 0; s < NKGP / 4; ++s) {
+                const int2 nxt = s_tab[min(4 * (s + 1), NKGP - 4) + g];
+                bf16x8 a[MF], b[4];
+#pragma unroll
+                for (int m = 0; m < MF; ++m) a[m] = *reinterpret_cast<const bf16x8*>(w_lane + off.y + m * 256);
+#pragma unroll
+                for (int n = 0; n < 4; ++n) b[n] = *reinterpret_cast<const bf16x8*>(in_lane + off.x + n * TP * 16);
+#pragma unroll
+                for (int m = 0; m < MF; ++m)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], b[n], acc[m][n], 0, 0, 0);
+                off = nxt;
+            }
+            {
+                const int gc = min(g, NCB - 1);
+                dgrad_fold_steps<MF, 1>(acc, in_lane + gc * (BP_PL * 16), w_lane + gc * (MF * 256), NCB, TP, g, j, ty0 * MT + wave * 4, tx0 * MT, tgx.hs, tgx.ws);
+            }
+            // epilogue: pair rows -> one granule per lane, ReLU mask from the x tile in LDS, store the interior of the folded gradient
+            const int oxs = 1 + tx0 * MT + j;
+#pragma unroll
+            for (int m = 0; m < MF; ++m) {
+                const int ocb = 2 * m + (g >> 1);
+                char* oplane = tgx.base + ((long long)in_ * tgx.img + (long long)(tgx.cb_off + ocb) * tgx.plane) * 16;
+#pragma unroll
+                for (int p2 = 0; p2 < 2; ++p2) {
+                    float c[8];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[m][2 * p2][r]), __float_as_uint(acc[m][2 * p2 + 1][r]), false, false);
+                        c[r] = __uint_as_float(sw[0]);
+                        c[4 + r] = __uint_as_float(sw[1]);
+                    }
+                    const int row = wave * 4 + (g & 1) + 2 * p2;
+                    const int oys = 1 + ty0 * MT + row;
+                    if (oys >= tgx.hs - 1 || oxs >= tgx.ws - 1) continue;
+                    const u32x4 xm = s_x[ocb * BP_PL + (row + 1) * TP + j + 1];
+                    const uint32_t xw[4] = {xm.x, xm.y, xm.z, xm.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (!((short)(xw[i] & 0xffffu) > 0)) c[2 * i] = 0.f;
+                        if (!((short)(xw[i] >> 16) > 0)) c[2 * i + 1] = 0.f;
+                    }
+                    *reinterpret_cast<uint4*>(oplane + ((long long)oys * tgx.ws + oxs) * 16) =
+                        make_uint4(pack_bf16x2(c[0], c[1]), pack_bf16x2(c[2], c[3]), pack_bf16x2(c[4], c[5]), pack_bf16x2(c[6], c[7]));
+                }
+            }
+        } else if (wave < 7) {
+            // ---------------- wgrad, tap row u: g centre (tile rows 1..16, cols 1..16), x shifted by (u, v)
+            const int u = wave - 4;
+#pragma unroll 1
+            for (int s = 0; s < 8; ++s) {
+                const int row = 2 * s + (g >> 1), col0 = 8 * (g & 1);
+                bf16x8 a[NGB];
+#pragma unroll
+                for (int m = 0; m < NGB; ++m)
+                    a[m] = tr_frag(reinterpret_cast<const char*>(s_g) + ((2 * m + lane_plane) * BP_PL + (row + 1) * TP + col0 + 1 + tr_row) * 16 + lane_byte);
+#pragma unroll
+                for (int v = 0; v < 3; ++v) {
+                    bf16x8 bx[NXB];
+#pragma unroll
+                    for (int b = 0; b < NXB; ++b)
+                        bx[b] = tr_frag(reinterpret_cast<const char*>(s_x) + ((2 * b + lane_plane) * BP_PL + (row + u) * TP + col0 + v + tr_row) * 16 + lane_byte);
+#pragma unroll
+                    for (int b = 0; b < NXB; ++b)
+#pragma unroll
+                        for (int m = 0; m < NGB; ++m) WACC(v, b, m) = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], bx[b], WACC(v, b, m), 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll 2
+            for (int s = 0; s < 8; ++s) {
+                const int row = 2 * s + (g >> 1), col0 = 8 * (g & 1);
+#pragma unroll
+                for (int m = 0; m < NGB; ++m) {
+                    const bf16x8 a = tr_frag(reinterpret_cast<const char*>(s_g) + ((2 * m + lane_plane) * BP_PL + (row + 1) * TP + col0 + 1 + tr_row) * 16 + lane_byte);
+                    uacc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, ones, uacc[m], 0, 0, 0);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+    if (wave >= 4 && wave < 7) {
+        const int u = wave - 4;
+#pragma unroll
+        for (int v = 0; v < 3; ++v)
+#pragma unroll
+            for (int b = 0; b < NXB; ++b)
+#pragma unroll
+                for (int m = 0; m < NGB; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) red[((16 * m + 4 * g + r) * CIN + 16 * b + j) * 9 + 3 * u + v] = WACC(v, b, m)[r];
+    } else if (wave == 7 && j == 0) {
+#pragma unroll
+        for (int m = 0; m < NGB; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[COUT * CIN * 9 + 16 * m + 4 * g + r] = uacc[m][r];
+    }
+#undef WACC
+#undef DACC
+    __syncthreads();
+    float* dst = partial + (long long)gi * PER;
+    for (int e = tid; e < PER; e += 512) dst[e] = red[e];
+}
+
+int taprow_reduce_launch(const float* ws, float* dw, float* db, int cin, int cout, int G, int accumulate, hipStream_t st);   // enc_wgrad.hip
+static int num_cus_();
+constexpr int BP_MAXG = 512;
+bool bwd_pair_supported(int ks, int cin, int cout) { return ks == 3 && ((cin == 64 && cout == 32) || (cin == 32 && cout == 16)); }
+size_t bwd_pair_workspace(int cin, int cout) { return (size_t)BP_MAXG * ((size_t)cout * cin * 9 + cout) * sizeof(float); }
+int bwd_pair(const TV& tx, const TV& tg, const TV& tgx, const void* wpk_dgrad, float* dw, float* db, int cin, int cout, int accumulate, float* ws,
+             hipStream_t st) {
+    const int tiles_x = cdiv(tx.w, MT), tiles_y = cdiv(tx.h, MT);
+    const int tpi = tiles_x * tiles_y, total = tpi * tx.n;
+    const int cap = (cin == 64 ? 1 : 2) * num_cus_();
+    const int G = total < cap ? total : (cap < BP_MAXG ? cap : BP_MAXG);
+    if (cin == 64)
+        hipLaunchKernelGGL((bwd_pair_kernel<4, 2>), dim3(G), dim3(512), 0, st, tx, tg, tgx, (const uint4*)wpk_dgrad, ws, tiles_x, tpi, total, G);
+    else
+        hipLaunchKernelGGL((bwd_pair_kernel<2, 1>), dim3(G), dim3(512), 0, st, tx, tg, tgx, (const uint4*)wpk_dgrad, ws, tiles_x, tpi, total, G);
+    if (int rc = check_launch("bwd_pair")) return rc;
+    return taprow_reduce_launch(ws, dw, db, cin, cout, G, accumulate, st);
+}
+
 bool conv_mfma_supported(bool dgrad, int ks, int cin, int cout) {
     (void)dgrad;
     return (ks == 1 || ks == 3) && cin >= 1 && cout >= 1;

@@ -396,6 +396,13 @@ bool wgrad_taprow_supported(int ks, int cin, int cout) {
 }
 size_t wgrad_taprow_workspace(int cin, int cout) { return (size_t)EW_MAXG * ((size_t)cout * cin * 9 + cout) * sizeof(float); }
 
+// fixed-order reduction of G natural-layout partials ([cout][cin][3][3] then [cout]) -- shared with the fused backward kernel of conv_mfma.hip
+int taprow_reduce_launch(const float* ws, float* dw, float* db, int cin, int cout, int G, int accumulate, hipStream_t st) {
+    const int n_w = cout * cin * 9, per = n_w + cout;
+    hipLaunchKernelGGL(taprow_wgrad_reduce, dim3(cdiv(per, 64)), dim3(256), 0, st, ws, dw, db, n_w, per, G, accumulate);
+    return check_launch("wgrad_taprow_reduce");
+}
+
 int wgrad_taprow(const TV& tx, const TV& tg, float* dw, float* db, int cin, int cout, int accumulate, float* ws, hipStream_t st) {
     const int tiles_x = cdiv(tx.w, EW_T), tiles_y = cdiv(tx.h, EW_T);
     const int tpi = tiles_x * tiles_y, total = tpi * tx.n;

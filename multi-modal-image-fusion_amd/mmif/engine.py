@@ -288,6 +288,16 @@ class ModelEngine:
         return T.conv_dgrad(gy, s.w.detach(), x, gx, s.cin, s.cout, s.k, mask_bits, accum_bits, s.packed, impl, s.name + ":dgrad", fold=True)
 
     @staticmethod
+    def pair_ok(s, dtype, impl, h, w):
+        """this layer's backward runs as ONE launch (csrc/conv_mfma.hip bwd_pair_kernel; $MMIF_BWD_PAIR=0: dgrad and wgrad apart)"""
+        return (dtype == torch.bfloat16 and impl != _lib.IMPL_VALU and not s.split and s.relu and s.packed is not None and h >= 4 and w >= 4
+                and T.bwd_pair_supported(s.cin, s.cout, s.k) and os.environ.get("MMIF_BWD_PAIR", "1") != "0")
+
+    @staticmethod
+    def c_bwd_pair(s, gy, x, gx, ws):
+        return T.conv_bwd_pair(gy, x, gx, s.dw, s.db, s.cin, s.cout, s.k, s.packed, ws, False, s.name + ":bwd")
+
+    @staticmethod
     def tag_dgrad(gy, x, gx, cin, cout, packed, tag):
         """dgrad of a virtual layer (operand image only, no fp32 weights): accumulate onto gx + ReLU mask of x, folded"""
         return T.conv_dgrad(gy, None, x, gx, cin, cout, 3, all_bits(gx.cb), all_bits(gx.cb), packed, _lib.IMPL_MFMA, tag, fold=True)
@@ -450,8 +460,11 @@ class PFNetv1Engine(ModelEngine, DenseEncoderMixin):
         g = g.fold_halo_() if last.k > 1 else g.as_folded()
         for i in range(len(self.dec) - 2, -1, -1):
             s, x = self.dec[i], acts[i]
-            self.c_wgrad(s, x, g, ws, impl)
             gx = self.buf(L, f"G{i}", n, s.cin, h, w, dtype, dev, halo=1)
+            if i > 0 and self.pair_ok(s, dtype, impl, h, w):
+                g = self.c_bwd_pair(s, g, x, gx, ws)      # thin layer: dgrad (every block masked) + wgrad in one launch
+                continue
+            self.c_wgrad(s, x, g, ws, impl)
             if i > 0:
                 g = self.c_dgrad(s, g, x, gx, all_bits(gx.cb), 0, impl)
             else:
@@ -539,8 +552,11 @@ class DenseFuseEngine(ModelEngine, DenseEncoderMixin):
         g = g.fold_halo_() if last.k > 1 else g.as_folded()
         for i in range(len(self.dec) - 2, -1, -1):
             s, x = self.dec[i], acts[i]
-            self.c_wgrad(s, x, g, ws, impl)
             gx = self.buf(L, f"G{i}", n, s.cin, h, w, dtype, dev, halo=1)
+            if i > 0 and self.pair_ok(s, dtype, impl, h, w):
+                g = self.c_bwd_pair(s, g, x, gx, ws)
+                continue
+            self.c_wgrad(s, x, g, ws, impl)
             if i > 0:
                 g = self.c_dgrad(s, g, x, gx, all_bits(gx.cb), 0, impl)
             elif single:

@@ -162,6 +162,18 @@ def conv_wgrad(x, gy, dw, db, cin, cout, k, ws, accumulate=False, impl=_lib.IMPL
                                             ws.numel() * ws.element_size(), impl, stream_ptr()), "conv2d_reflect_wgrad")
 
 
+def bwd_pair_supported(cin, cout, k):
+    return bool(lib.mmif_conv2d_bwd_pair_supported(cin, cout, k))
+
+
+def conv_bwd_pair(gy, x, gx, dw, db, cin, cout, k, packed, ws, accumulate=False, tag=None):
+    """dgrad (all blocks masked by x, folded) + wgrad of one thin 3x3 layer in one launch; returns the folded gx view."""
+    with _timed(tag):
+        check(lib.mmif_conv2d_reflect_bwd_pair(gy.d, _ptr(packed.dgrad), x.d, gx.d, _ptr(dw), _ptr(db), cin, cout, k, int(accumulate), _ptr(ws),
+                                               ws.numel() * ws.element_size(), stream_ptr()), "conv2d_reflect_bwd_pair")
+    return gx.as_folded()
+
+
 def image_in_fwd(img, w, bias, y, cout, k, relu):
     check(lib.mmif_conv2d_image_in_fwd(_ptr(img), _ptr(w), _ptr(bias), y.d, cout, k, int(relu), stream_ptr()), "image_in_fwd")
 

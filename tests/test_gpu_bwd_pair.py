@@ -1,0 +1,86 @@
+"""Fused backward of one thin 3x3 layer (csrc/conv_mfma.hip bwd_pair_kernel, mmif_conv2d_reflect_bwd_pair): the input gradient must be
+BIT-IDENTICAL to mmif_conv2d_reflect_dgrad_folded (same k-group order, fold steps and mask), dW / db within fp32 summation-order noise
+of mmif_conv2d_reflect_wgrad; ragged tiles, image borders (fold targets), both supported layer shapes."""
+import os
+
+import pytest
+import torch
+
+from gpu_util import DEV, dtype_ctx
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(1, 4, 4), (2, 16, 16), (1, 5, 37), (2, 33, 18), (1, 40, 56), (2, 64, 64), (1, 70, 33), (2, 128, 128), (8, 128, 128)]
+
+
+@pytest.mark.parametrize("cin,cout", [(64, 32), (32, 16)])
+@pytest.mark.parametrize("n,h,w", SHAPES, ids=[f"{n}x{h}x{w}" for n, h, w in SHAPES])
+def test_bwd_pair_vs_separate_kernels(cin, cout, n, h, w):
+    from mmif import tensor as T
+    from mmif._lib import IMPL_MFMA
+    with dtype_ctx("bf16"):
+        g = torch.Generator().manual_seed(h * 131 + w + cin)
+        x = T.BT.from_nchw(torch.relu(torch.randn(n, cin, h, w, generator=g)).to(DEV), torch.bfloat16)
+        gy = T.BT.from_nchw(torch.randn(n, cout, h, w, generator=g).to(DEV), torch.bfloat16, halo=1).as_folded()
+        wgt = (torch.randn(cout, cin, 3, 3, generator=g) * 0.05).to(DEV)
+        pk = T.PackedWeights(cout, cin, 3, DEV)
+        pk.pack(wgt)
+        ws = torch.empty(T.wgrad_workspace_bytes(cin, cout, 3) // 4 + 1, dtype=torch.float32, device=DEV)
+        assert T.bwd_pair_supported(cin, cout, 3)
+        gx_a = T.BT.alloc(n, cin, h, w, torch.bfloat16, DEV, halo=1, zero=True)
+        dw_a, db_a = torch.zeros(cout, cin, 3, 3, device=DEV), torch.zeros(cout, device=DEV)
+        T.conv_bwd_pair(gy, x, gx_a, dw_a, db_a, cin, cout, 3, pk, ws)
+        gx_b = T.BT.alloc(n, cin, h, w, torch.bfloat16, DEV, halo=1, zero=True)
+        dw_b, db_b = torch.zeros_like(dw_a), torch.zeros_like(db_a)
+        T.conv_dgrad(gy, wgt, x, gx_b, cin, cout, 3, (1 << gx_b.cb) - 1, 0, pk, IMPL_MFMA, fold=True)
+        T.conv_wgrad(x, gy, dw_b, db_b, cin, cout, 3, ws, False, IMPL_MFMA)
+        torch.cuda.synchronize()
+        a, b = gx_a.buf.view(torch.int16), gx_b.buf.view(torch.int16)
+        # the reference folds inside its border tiles too when it runs on the DMA-staged kernel (64 input channels) or the thin kernel
+        # (large problems): then everything is bit-identical.  Otherwise (small 32-channel cases: register-staged dgrad + fold kernel,
+        # which rounds the halo values to bf16 before adding them) only the pixels that are no fold target are.
+        same_algo = cin == 64 or n * ((h + 15) // 16) * ((w + 15) // 16) >= 512
+        if same_algo:
+            if not torch.equal(a, b):
+                d = (a != b).nonzero()
+                raise AssertionError(f"gx: {d.shape[0]} of {a.numel()} elements differ; first at [n, cb, ys, xs, e] = {d[0].tolist()}")
+        else:
+            tgt = torch.zeros(h + 2, w + 2, dtype=torch.bool, device=a.device)
+            tgt[[2, h - 1], :] = True
+            tgt[:, [2, w - 1]] = True
+            diff = (a != b)
+            assert not bool(diff[:, :, ~tgt].any()), "a pixel that is no fold target differs"
+            fa, fb = gx_a.buf.float(), gx_b.buf.float()
+            assert float((fa - fb).abs().max()) <= 2.0 ** -6 * float(fb.abs().max())      # two extra bf16 roundings on the fold targets
+        assert float(gx_a.buf[:, :, 0].float().abs().max()) == 0.0 and float(gx_a.buf[:, :, :, -1].float().abs().max()) == 0.0   # ring untouched
+        assert float((dw_a - dw_b).abs().max()) <= 1e-4 * max(1e-6, float(dw_b.abs().max()))
+        assert float((db_a - db_b).abs().max()) <= 1e-4 * max(1e-6, float(db_b.abs().max()))
+        # accumulate mode adds to dW / db
+        T.conv_bwd_pair(gy, x, gx_a, dw_a, db_a, cin, cout, 3, pk, ws, accumulate=True)
+        torch.cuda.synchronize()
+        assert float((dw_a - 2 * dw_b).abs().max()) <= 2e-4 * max(1e-6, float(dw_b.abs().max()))
+
+
+def test_models_with_and_without_bwd_pair():
+    import core.model as M
+    with dtype_ctx("bf16"):
+        for name in ("PFNetv1", "DenseFuse"):
+            torch.manual_seed(5)
+            m = getattr(M, name)().to(DEV)
+            g = torch.Generator().manual_seed(9)
+            i1, i2 = torch.rand(2, 1, 45, 70, generator=g).to(DEV), torch.rand(2, 1, 45, 70, generator=g).to(DEV)
+            res = []
+            for flag in ("0", "1"):
+                os.environ["MMIF_BWD_PAIR"] = flag
+                try:
+                    m.zero_grad(set_to_none=True)
+                    m(i1, i2).square().mean().backward()
+                    torch.cuda.synchronize()
+                    res.append({k: p.grad.clone() for k, p in m.named_parameters()})
+                finally:
+                    os.environ.pop("MMIF_BWD_PAIR")
+            # at this size the separate path folds decode.3's input gradient with the stand-alone kernel (halo values rounded to bf16
+            # first), the fused kernel inside its border tiles: the gradients upstream differ by that rounding on the fold targets
+            for k in res[0]:
+                a, b = res[0][k].double(), res[1][k].double()
+                assert float((a - b).abs().max()) <= 2e-2 * max(1e-7, float(a.abs().max())), (name, k)
