@@ -1601,14 +1601,6 @@ __global__ __launch_bounds__(512, NXB == 4 ? 1 : 2) void bwd_pair_kernel(TV tx, 
         if (tid < NKG) { tap = visit_tap(tid / NCB, 3); cb = tid % NCB; plane = tap * NCB + cb; }
         s_tab[tid] = make_int2((cb * BP_PL + (tap / 3) * TP + (tap % 3)) * 16, plane * MF * 256);
     }
-    // ONE accumulator file for the three roles (they never meet in a wave; separate arrays would cost the union of their registers):
-    // weight-gradient waves: uacc[(v NXB + b) NGB + m], persistent; bias wave: uacc[m]; dgrad waves: uacc[4 m + n], cleared per tile
-    constexpr int NACC = 3 * NXB * NGB > 4 * MF ? 3 * NXB * NGB : 4 * MF;
-    f32x4 uacc[NACC];
-#pragma unroll
-    for (int i = 0; i < NACC; ++i) uacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#define WACC(v, b, m) uacc[((v) * NXB + (b)) * NGB + (m)]
-#define DACC(m, n) uacc[4 * (m) + (n)]
     const bf16x8 ones = __builtin_bit_cast(bf16x8, make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u));
     const int tr_row = j >> 2, tr_c = j & 3;
     const int lane_plane = tr_c >> 1, lane_byte = (tr_c & 1) * 8;
@@ -1641,8 +1633,8 @@ __global__ __launch_bounds__(512, NXB == 4 ? 1 : 2) void bwd_pair_kernel(TV tx, 
             rg[i] = inside ? v : (u32x4){0u, 0u, 0u, 0u};
         }
     };
-    if (gi < total) prefetch(gi);
-    for (int tile = gi; tile < total; tile += G) {
+    // every wave runs this at the top of a tile: publish the prefetched tile, start the next prefetch (block-wide: two barriers)
+    auto stage = [&](int tile) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < NXR; ++i) {
@@ -1655,12 +1647,19 @@ __global__ __launch_bounds__(512, NXB == 4 ? 1 : 2) void bwd_pair_kernel(TV tx, 
             if (e < NCB * BP_PL) s_g[e] = rg[i];
         }
         __syncthreads();
-        const int in_ = tile / tpi, tt = tile - in_ * tpi;
-        const int ty0 = tt / tiles_x, tx0 = tt % tiles_x;
         if (tile + G < total) prefetch(tile + G);
-        if (wave < 4) {
-            // ---------------- dgrad: rows 4 wave .. 4 wave + 3, all MF m-fragments
-            f32x4 (&acc)[MF][4] = *reinterpret_cast<f32x4 (*)[MF][4]>(&uacc[0]);
+    };
+    if (gi < total) prefetch(gi);
+    float* red = reinterpret_cast<float*>(smem);
+    // The three roles keep separate tile loops (same trip count, same barriers): their accumulators never share a live range, so the
+    // kernel needs max(role) registers, not the sum.
+    if (wave < 4) {
+        // ---------------- dgrad: rows 4 wave .. 4 wave + 3 of every tile, all MF m-fragments
+        for (int tile = gi; tile < total; tile += G) {
+            stage(tile);
+            const int in_ = tile / tpi, tt = tile - in_ * tpi;
+            const int ty0 = tt / tiles_x, tx0 = tt % tiles_x;
+            f32x4 acc[MF][4];
 #pragma unroll
             for (int m = 0; m < MF; ++m)
 #pragma unroll
@@ -1715,10 +1714,21 @@ __global__ __launch_bounds__(512, NXB == 4 ? 1 : 2) void bwd_pair_kernel(TV tx, 
                         make_uint4(pack_bf16x2(c[0], c[1]), pack_bf16x2(c[2], c[3]), pack_bf16x2(c[4], c[5]), pack_bf16x2(c[6], c[7]));
                 }
             }
-        } else if (wave < 7) {
-            // ---------------- wgrad, tap row u: g centre (tile rows 1..16, cols 1..16), x shifted by (u, v)
-            const int u = wave - 4;
-#pragma unroll 1
+        }
+        __syncthreads();
+    } else if (wave < 7) {
+        // ---------------- wgrad, tap row u: g centre (tile rows 1..16, cols 1..16), x shifted by (u, v)
+        const int u = wave - 4;
+        f32x4 wacc[3][NXB][NGB];
+#pragma unroll
+        for (int v = 0; v < 3; ++v)
+#pragma unroll
+            for (int b = 0; b < NXB; ++b)
+#pragma unroll
+                for (int m = 0; m < NGB; ++m) wacc[v][b][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int tile = gi; tile < total; tile += G) {
+            stage(tile);
+#pragma unroll 2
             for (int s = 0; s < 8; ++s) {
                 const int row = 2 * s + (g >> 1), col0 = 8 * (g & 1);
                 bf16x8 a[NGB];
@@ -1734,25 +1744,11 @@ __global__ __launch_bounds__(512, NXB == 4 ? 1 : 2) void bwd_pair_kernel(TV tx, 
 #pragma unroll
                     for (int b = 0; b < NXB; ++b)
 #pragma unroll
-                        for (int m = 0; m < NGB; ++m) WACC(v, b, m) = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], bx[b], WACC(v, b, m), 0, 0, 0);
-                }
-            }
-        } else {
-#pragma unroll 2
-            for (int s = 0; s < 8; ++s) {
-                const int row = 2 * s + (g >> 1), col0 = 8 * (g & 1);
-#pragma unroll
-                for (int m = 0; m < NGB; ++m) {
-                    const bf16x8 a = tr_frag(reinterpret_cast<const char*>(s_g) + ((2 * m + lane_plane) * BP_PL + (row + 1) * TP + col0 + 1 + tr_row) * 16 + lane_byte);
-                    uacc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, ones, uacc[m], 0, 0, 0);
+                        for (int m = 0; m < NGB; ++m) wacc[v][b][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], bx[b], wacc[v][b][m], 0, 0, 0);
                 }
             }
         }
-    }
-    __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);
-    if (wave >= 4 && wave < 7) {
-        const int u = wave - 4;
+        __syncthreads();
 #pragma unroll
         for (int v = 0; v < 3; ++v)
 #pragma unroll
@@ -1760,15 +1756,31 @@ __global__ __launch_bounds__(512, NXB == 4 ? 1 : 2) void bwd_pair_kernel(TV tx, 
 #pragma unroll
                 for (int m = 0; m < NGB; ++m)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) red[((16 * m + 4 * g + r) * CIN + 16 * b + j) * 9 + 3 * u + v] = WACC(v, b, m)[r];
-    } else if (wave == 7 && j == 0) {
+                    for (int r = 0; r < 4; ++r) red[((16 * m + 4 * g + r) * CIN + 16 * b + j) * 9 + 3 * u + v] = wacc[v][b][m][r];
+    } else {
+        f32x4 accb[NGB];
 #pragma unroll
-        for (int m = 0; m < NGB; ++m)
+        for (int m = 0; m < NGB; ++m) accb[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int tile = gi; tile < total; tile += G) {
+            stage(tile);
+#pragma unroll 2
+            for (int s = 0; s < 8; ++s) {
+                const int row = 2 * s + (g >> 1), col0 = 8 * (g & 1);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) red[COUT * CIN * 9 + 16 * m + 4 * g + r] = uacc[m][r];
+                for (int m = 0; m < NGB; ++m) {
+                    const bf16x8 a = tr_frag(reinterpret_cast<const char*>(s_g) + ((2 * m + lane_plane) * BP_PL + (row + 1) * TP + col0 + 1 + tr_row) * 16 + lane_byte);
+                    accb[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, ones, accb[m], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+        if (j == 0) {
+#pragma unroll
+            for (int m = 0; m < NGB; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[COUT * CIN * 9 + 16 * m + 4 * g + r] = accb[m][r];
+        }
     }
-#undef WACC
-#undef DACC
     __syncthreads();
     float* dst = partial + (long long)gi * PER;
     for (int e = tid; e < PER; e += 512) dst[e] = red[e];
