@@ -264,6 +264,96 @@ __device__ inline void conv_epilogue(const f32x4 (&acc)[MF][4], const TV& tout, 
     }
 }
 
+// The same epilogue with the arithmetic done BEFORE the row swap, on packed pairs (conv_dma_kernel: a wave's epilogue runs
+// beside its SIMD partner's MFMAs, and a lone wave only reaches ~65 % of the MFMA rate -- `tools/trace_dma.py`: 3.4-3.7 k
+// ticks per epilogue, ~550 wave-wide VALU instructions at 4 cycles each -- so every epilogue instruction is MFMA time):
+// bias with v_pk_add_f32, rounding two values per v_cvt_pk_bf16_f32, ReLU as a signed 16-bit v_pk_max_i16 against 0 on
+// the rounded pair (bf16 <= -0  <=>  negative int16; against -32768 when the layer has no ReLU), then TWO
+// v_permlane16_swap per row pair instead of four, and for the dgrad the loader-staged mask byte expanded to four dword masks.
+// Results are bit-identical to conv_epilogue (ReLU commutes with the rounding; the mask zeroes whole bf16 values).
+// Forward, and dgrad with LDS mask bits and nothing to accumulate.
+typedef short i16x2_t __attribute__((ext_vector_type(2)));
+template <int MF, bool DGRAD>
+__device__ inline void conv_epilogue_packed(const f32x4 (&acc)[MF][4], const TV& tout, const float* s_bias, int mb, int in_, int ox0, int oy0, int lrow,
+                                            int relu, unsigned long long mask_bits, int xlim, int ylim, const unsigned char* lmask = nullptr,
+                                            long long* tr = nullptr, int* tr_n = nullptr) {
+    // ox0 / oy0: stored column of the tile's first column / stored row of this WAVE's first row; lrow: the wave's first tile row.
+    // Everything lane dependent (j = lane & 15, g = lane >> 4) is recomputed here behind an asm the compiler cannot hoist: kept live
+    // across the k-loop these were the values conv_dma_kernel spilled (scratch reloads + s_waitcnt vmcnt(0) at the head of an epilogue)
+    int lane_;
+    __asm__ volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_));
+    const int lcol = lane_ & 15, g = lane_ >> 4, gh = lane_ >> 5;
+    const int oxs = ox0 + lcol, oys0 = oy0 + (g & 1), lrow0 = lrow + (g & 1);
+#ifdef EPI_TRACE
+#define ESTAMP() do { if (tr != nullptr && *tr_n < 62) tr[(*tr_n)++] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define ESTAMP() do { } while (0)
+#endif
+    if (oxs >= xlim) return;
+    const unsigned row_bytes = (unsigned)tout.ws * 16u;
+    const unsigned pix_off = (unsigned)(oys0 * tout.ws + oxs) * 16u;
+    const uint32_t floor2 = relu ? 0u : 0x80008000u;
+    const i16x2_t floorv = __builtin_bit_cast(i16x2_t, floor2);
+    const bool row_ok[2] = {oys0 < ylim, oys0 + 2 < ylim};
+    // every LDS operand of the epilogue up front: ONE round trip through an LDS pipe that is busy with the partner wave's k-loop
+    float4 bq[DGRAD ? 1 : MF];
+    unsigned lb[DGRAD ? MF : 1][2];
+#pragma unroll
+    for (int m = 0; m < MF; ++m) {
+        if (!DGRAD) bq[DGRAD ? 0 : m] = *reinterpret_cast<const float4*>(&s_bias[m * 16 + g * 4]);   // this lane's channels 16 m + 4 g + r
+        else {
+#pragma unroll
+            for (int p2 = 0; p2 < 2; ++p2) lb[DGRAD ? m : 0][p2] = lmask[((2 * m + gh) * DT_ROWS_C + lrow0 + 2 * p2) * MT + lcol];
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MF; ++m) {
+        const int ocb = (mb * MF + m) * 2 + gh;
+        const bool blk_ok = ocb < tout.cb;
+        f32x2_t b01 = {0.f, 0.f}, b23 = {0.f, 0.f};
+        if (!DGRAD) {
+            b01 = (f32x2_t){bq[DGRAD ? 0 : m].x, bq[DGRAD ? 0 : m].y};
+            b23 = (f32x2_t){bq[DGRAD ? 0 : m].z, bq[DGRAD ? 0 : m].w};
+        }
+        char* oplane = tout.base + ((long long)in_ * tout.img + (long long)(tout.cb_off + min(ocb, tout.cb - 1)) * tout.plane) * 16 + pix_off;
+        const bool do_mask = DGRAD && ((mask_bits >> ocb) & 1ull);
+        ESTAMP();
+#pragma unroll
+        for (int p2 = 0; p2 < 2; ++p2) {
+            uint32_t pk[2][2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const f32x4 a = acc[m][2 * p2 + e];
+                f32x2_t lo = {a[0], a[1]}, hi = {a[2], a[3]};
+                if (!DGRAD) { lo += b01; hi += b23; }
+                uint32_t w0 = __builtin_bit_cast(uint32_t, __builtin_convertvector(lo, bf16x2_t));
+                uint32_t w1 = __builtin_bit_cast(uint32_t, __builtin_convertvector(hi, bf16x2_t));
+                if (!DGRAD) {
+                    w0 = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2_t, w0), floorv));
+                    w1 = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2_t, w1), floorv));
+                }
+                pk[e][0] = w0;
+                pk[e][1] = w1;
+            }
+            // even g: all 8 channels of row 2 p2; odd g: of row 2 p2 + 1  (channels 4 g' .. 4 g' + 7, g' = g & ~1)
+            const auto s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+            const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+            uint4 o = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+            if (DGRAD) {
+                const unsigned bits = do_mask ? lb[DGRAD ? m : 0][p2] : 0xffu;
+                auto dmask = [&](int i) {   // bits 2i, 2i+1 -> 0x0000ffff / 0xffff0000 halves
+                    const uint32_t l = (uint32_t)__builtin_amdgcn_sbfe((int)bits, 2 * i, 1), h = (uint32_t)__builtin_amdgcn_sbfe((int)bits, 2 * i + 1, 1);
+                    return (l & 0xffffu) | (h & 0xffff0000u);
+                };
+                o.x &= dmask(0); o.y &= dmask(1); o.z &= dmask(2); o.w &= dmask(3);
+            }
+            if (blk_ok && row_ok[p2]) *reinterpret_cast<uint4*>(oplane + (2 * p2) * row_bytes) = o;
+        }
+    }
+    ESTAMP();
+#undef ESTAMP
+}
+
 // ------------------------------------------------------------------ forward / dgrad kernel
 // (min waves per SIMD: the Cout <= 16 instantiations are HBM-bound and want bytes in flight, i.e. occupancy: 128 VGPRs -> 4 blocks/CU)
 template <int KS, int MF, bool DGRAD>
@@ -613,8 +703,11 @@ __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void conv_dma_kernel(TV 
     // diagnostics (tools/trace_dma.py): lane 0 of every consumer wave of the first 128 blocks stamps s_memtime per phase
     int tr_n = 0;
     long long* tr = (trace != nullptr && blockIdx.x < 128 && lane == 0 && wave < D_CONS) ? trace + ((long long)blockIdx.x * 8 + wave) * 64 : nullptr;
-#define DTRACE() do { if (tr != nullptr && tr_n < 62) tr[tr_n++] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
-    DTRACE();
+#define DTRACE() do { if (tr != nullptr && tr_n < 62 && !(abl & 256)) tr[tr_n++] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+    // $MMIF_CONV_ABLATE bit 8: stamp only the top of every third chunk (the period over the whole launch instead of the phases of
+    // its first 12 chunks)
+#define DTRACE_TOP(q) do { if (tr != nullptr && tr_n < 62 && (!(abl & 256) || (q) % 3 == 0)) tr[tr_n++] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+    if (tr != nullptr && tr_n < 62) tr[tr_n++] = (long long)__builtin_amdgcn_s_memtime();
     const int tpi = tiles_x * tiles_y;
     const int nitems = tpi * tout.n * nmb;
     // this block's items: first + i * stride, i < count (XCD x = blockIdx % 8 owns a contiguous band of items)
@@ -798,19 +891,40 @@ __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void conv_dma_kernel(TV 
 
     // =============================== consumer waves ===============================
     f32x4 acc[MF][4];
+    // epilogue of item `itm` (bias slot / mask parity of that item): the packed form wherever it applies
+#define DMA_EPILOGUE(itm, slot, par)                                                                                                          \
+    do {                                                                                                                                      \
+        const int oxs_ = org + (itm).tile_x * MT + j, oys0_ = org + (itm).tile_y * DT_ROWS + wave * 4 + (g & 1);                              \
+        if constexpr (!DGRAD) {                                                                                                               \
+            conv_epilogue_packed<MF, false>(acc, tout, s_bias[slot], (itm).mb, (itm).in_, org + (itm).tile_x * MT,                            \
+                                            org + (itm).tile_y * DT_ROWS + wave * 4, wave * 4, relu, mask_bits, tout.ws - org, tout.hs - org,  \
+                                            nullptr, tr, &tr_n);                                                                                     \
+        } else if constexpr (LMASK) {                                                                                                         \
+            if (accum_bits == 0)                                                                                                              \
+                conv_epilogue_packed<MF, true>(acc, tout, s_bias[slot], (itm).mb, (itm).in_, org + (itm).tile_x * MT,                         \
+                                               org + (itm).tile_y * DT_ROWS + wave * 4, wave * 4, relu, mask_bits, tout.ws - org,             \
+                                               tout.hs - org, s_mask[LMASK ? (par) : 0]);                                                     \
+            else                                                                                                                              \
+                conv_epilogue<MF, true, true>(acc, tout, tmask, s_bias[slot], (itm).mb, (itm).in_, oxs_, oys0_, g, relu, mask_bits,           \
+                                              accum_bits, tout.ws - org, tout.hs - org, s_mask[LMASK ? (par) : 0], wave * 4 + (g & 1), j);    \
+        } else {                                                                                                                              \
+            conv_epilogue<MF, true, false>(acc, tout, tmask, s_bias[slot], (itm).mb, (itm).in_, oxs_, oys0_, g, relu, mask_bits, accum_bits,  \
+                                           tout.ws - org, tout.hs - org, nullptr, wave * 4 + (g & 1), j);                                     \
+        }                                                                                                                                     \
+    } while (0)
     DItem cur = decode(first), pend = cur;
     bool have_pend = false;
     int pend_slot = 0, pend_par = 0;
     int c = 0, item_i = 0;
     for (int q = 0; q < total_q; ++q) {
         const int buf = q & 1;
-        DTRACE();   // chunk top
+        DTRACE_TOP(q);   // chunk top
         __builtin_amdgcn_s_barrier();
         DTRACE();   // barrier passed
         if (have_pend) {   // waves 4..7: previous tile's outputs, stored under the partner wave's MFMAs (see below)
-            conv_epilogue<MF, DGRAD, LMASK>(acc, tout, tmask, s_bias[pend_slot], pend.mb, pend.in_, org + pend.tile_x * MT + j,
-                                     org + pend.tile_y * DT_ROWS + wave * 4 + (g & 1), g, relu, mask_bits, accum_bits, tout.ws - org,
-                                     tout.hs - org, LMASK ? s_mask[LMASK ? pend_par : 0] : nullptr, wave * 4 + (g & 1), j);
+            __builtin_amdgcn_s_setprio(3);   // (measured neutral; the epilogue is ~180 VALU instructions either way)
+            DMA_EPILOGUE(pend, pend_slot, pend_par);
+            __builtin_amdgcn_s_setprio(0);
             have_pend = false;
         }
         DTRACE();   // pending epilogue done
@@ -923,9 +1037,7 @@ __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void conv_dma_kernel(TV 
             // their outputs now, under the partner's remaining MFMAs; waves 4..7 store after the next barrier, under the
             // partner's next k-loop.  (All eight storing at the same point leaves the MFMA pipe idle for a whole epilogue.)
             if (wave < 4) {
-                conv_epilogue<MF, DGRAD, LMASK>(acc, tout, tmask, s_bias[item_i % 3], cur.mb, cur.in_, org + cur.tile_x * MT + j,
-                                         org + cur.tile_y * DT_ROWS + wave * 4 + (g & 1), g, relu, mask_bits, accum_bits, tout.ws - org,
-                                         tout.hs - org, LMASK ? s_mask[LMASK ? item_i & 1 : 0] : nullptr, wave * 4 + (g & 1), j);
+                DMA_EPILOGUE(cur, item_i % 3, item_i & 1);
             } else {
                 pend = cur;
                 pend_slot = item_i % 3;
@@ -937,12 +1049,11 @@ __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void conv_dma_kernel(TV 
         }
         DTRACE();   // tile epilogue (waves 0..3) done
     }
-    if (tr != nullptr) tr[63] = tr_n;
+    if (tr != nullptr) { tr[63] = tr_n; tr[62] = (long long)__builtin_amdgcn_s_memtime(); }   // [62]: end of the block's last chunk
 #undef DTRACE
-    if (have_pend)
-        conv_epilogue<MF, DGRAD, LMASK>(acc, tout, tmask, s_bias[pend_slot], pend.mb, pend.in_, org + pend.tile_x * MT + j,
-                                 org + pend.tile_y * DT_ROWS + wave * 4 + (g & 1), g, relu, mask_bits, accum_bits, tout.ws - org,
-                                 tout.hs - org, LMASK ? s_mask[LMASK ? pend_par : 0] : nullptr, wave * 4 + (g & 1), j);
+#undef DTRACE_TOP
+    if (have_pend) DMA_EPILOGUE(pend, pend_slot, pend_par);
+#undef DMA_EPILOGUE
 }
 
 // ------------------------------------------------------------------ thin layers: asynchronous loader / consumer kernel

@@ -117,15 +117,18 @@ def pack_many(pairs):
 
 
 # ------------------------------------------------------------------ per-op HIP-event timing (bench.py roofline)
-PROFILE_TAGS = set()     # op tags ("<layer>:fwd|dgrad|wgrad") to time
+PROFILE_TAGS = set()     # op tags ("<layer>:fwd|dgrad|wgrad") to time; "*" = every tagged op (tools/layer_times.py)
 PROFILE_EVENTS = {}      # tag -> [(start_event, end_event), ...] recorded on the launch stream
+PROFILE_SHAPES = {}      # tag -> (n, h, w, cin, cout, k) of the last timed conv call with that tag
 
 
 class _timed:
     __slots__ = ("tag", "e0")
 
-    def __init__(self, tag):
-        self.tag = tag if (tag is not None and tag in PROFILE_TAGS) else None
+    def __init__(self, tag, shape=None):
+        if shape is not None and tag is not None and PROFILE_TAGS:
+            PROFILE_SHAPES[tag] = shape
+        self.tag = tag if (tag is not None and (tag in PROFILE_TAGS or "*" in PROFILE_TAGS)) else None
 
     def __enter__(self):
         if self.tag is not None:
@@ -141,7 +144,7 @@ class _timed:
 
 # ------------------------------------------------------------------ op wrappers
 def conv_fwd(x, w, bias, y, cin, cout, k, relu, packed=None, impl=_lib.IMPL_AUTO, tag=None):
-    with _timed(tag):
+    with _timed(tag, (x.n, x.h, x.w, cin, cout, k)):
         check(lib.mmif_conv2d_reflect_fwd(x.d, _ptr(w), _ptr(packed.fwd) if packed is not None else None, _ptr(bias), y.d,
                                           cin, cout, k, int(relu), impl, stream_ptr()), "conv2d_reflect_fwd")
 
@@ -150,14 +153,14 @@ def conv_dgrad(gy, w, x, gx, cin, cout, k, mask_bits=0, accum_bits=0, packed=Non
     """fold=True: dgrad + fold_halo(gx) in one call (mmif_conv2d_reflect_dgrad_folded; gx's halo ring must be zero on entry);
     returns the folded view."""
     fn = lib.mmif_conv2d_reflect_dgrad_folded if fold else lib.mmif_conv2d_reflect_dgrad
-    with _timed(tag):
+    with _timed(tag, (gy.n, gy.h, gy.w, cin, cout, k)):
         check(fn(gy.d, _ptr(w), _ptr(packed.dgrad) if packed is not None else None, x.d if x is not None else None, gx.d, cin, cout,
                  k, mask_bits, accum_bits, impl, stream_ptr()), "conv2d_reflect_dgrad")
     return gx.as_folded() if fold else gx
 
 
 def conv_wgrad(x, gy, dw, db, cin, cout, k, ws, accumulate=False, impl=_lib.IMPL_AUTO, tag=None):
-    with _timed(tag):
+    with _timed(tag, (x.n, x.h, x.w, cin, cout, k)):
         check(lib.mmif_conv2d_reflect_wgrad(x.d, gy.d, _ptr(dw), _ptr(db), cin, cout, k, int(accumulate), _ptr(ws),
                                             ws.numel() * ws.element_size(), impl, stream_ptr()), "conv2d_reflect_wgrad")
 
@@ -168,7 +171,7 @@ def bwd_pair_supported(cin, cout, k):
 
 def conv_bwd_pair(gy, x, gx, dw, db, cin, cout, k, packed, ws, accumulate=False, tag=None):
     """dgrad (all blocks masked by x, folded) + wgrad of one thin 3x3 layer in one launch; returns the folded gx view."""
-    with _timed(tag):
+    with _timed(tag, (gy.n, gy.h, gy.w, cin, cout, k)):
         check(lib.mmif_conv2d_reflect_bwd_pair(gy.d, _ptr(packed.dgrad), x.d, gx.d, _ptr(dw), _ptr(db), cin, cout, k, int(accumulate), _ptr(ws),
                                                ws.numel() * ws.element_size(), stream_ptr()), "conv2d_reflect_bwd_pair")
     return gx.as_folded()

@@ -40,6 +40,15 @@ for k, nm in enumerate(names):
     hi = [2 + 5 * q + k for q in range(1, nq - 1)]
     d = t[:, :, hi] - t[:, :, lo]
     print(f"  {nm:30s}", np.median(d, axis=(0, 2)).round(0))
+nch = (cin if kind == "fwd" else cout) // 32
+print(f"  per chunk position c = q % {nch} (median over blocks; wave 0 | wave 4): barrier wait, pending epilogue, k-loop, tile epilogue, overhead, period")
+for q in range(1, nq - 1):
+    row = []
+    for wv in (0, 4):
+        d = [np.median(t[:, wv, 2 + 5 * q + k] - t[:, wv, 1 + 5 * q + k]) for k in range(5)]
+        d.append(np.median(t[:, wv, 1 + 5 * (q + 1)] - t[:, wv, 1 + 5 * q]))
+        row.append(" ".join(f"{v:6.0f}" for v in d))
+    print(f"   q={q:2d} c={q % nch}: {row[0]}  |  {row[1]}")
 tops = t[:, :, [1 + 5 * q for q in range(1, nq)]]
 print("  chunk period (top -> top)     ", np.median(np.diff(tops, axis=2), axis=(0, 2)).round(0))
 arr = t[:, :, [1 + 5 * q for q in range(2, nq)]]
