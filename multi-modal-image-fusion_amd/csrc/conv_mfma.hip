@@ -1592,30 +1592,49 @@ __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void wgrad_dma_kernel(TV
         __builtin_amdgcn_s_barrier();
         const char* s_x = s_buf + (k & 1) * WD_BUF_BYTES;
         const char* s_g = s_x + WD_XPIECES * 1024;
+        // K = pixels.  k-step s2 covers tile rows s2 (lane groups g = 0, 1: columns 0-7 / 8-15) and s2 + 8 (g = 2, 3), so the
+        // activation fragment of tap (u, v) at step s2 -- rows s2 + u and s2 + 8 + u -- IS the fragment of tap (0, v) at step s2 + u:
+        // a ring of three rows, ONE new row (3 fragments = 6 transposing reads) per k-step + the 4 reads of the two gradient
+        // fragments = 10 reads of 512 B per 18 MFMAs.  (With rows 2 s2, 2 s2 + 1 per step and every tap re-read it was 22 -- 156 B / clk
+        // on four SIMDs against the 128 B / clk of the LDS: decode.0's wgrad 0.55 ms; carrying only the u = 2 row 16: 0.45 ms.)
+        const int rsel = 8 * (g >> 1), col0 = 8 * (g & 1);
+        auto ld_x = [&](int xrow, int v) {
+            const char* base = s_x + (((2 * icf + lane_plane) * WG_XPL) + (xrow + rsel) * TP + col0 + v + tr_row) * 16 + lane_byte;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, base));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, base + 4 * 16));
+            return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        };
+        auto ld_g = [&](int grow, int m) {
+            const char* base = s_g + (((2 * (mp * 2 + m) + lane_plane) * WG_GPL) + (grow + rsel) * MT + col0 + tr_row) * 16 + lane_byte;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, base));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, base + 4 * 16));
+            return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        };
+        bf16x8 xr[3][3], a[2][2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int v = 0; v < 3; ++v) xr[r][v] = ld_x(r, v);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) a[0][m] = ld_g(0, m);
 #pragma unroll
         for (int s2 = 0; s2 < 8; ++s2) {
-            const int row = 2 * s2 + (g >> 1), col0 = 8 * (g & 1);
-            bf16x8 a[2];
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                const char* base = s_g + (((2 * (mp * 2 + m) + lane_plane) * WG_GPL) + row * MT + col0 + tr_row) * 16 + lane_byte;
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, base));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, base + 4 * 16));
-                a[m] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            for (int v = 0; v < 3; ++v) xr[(s2 + 2) % 3][v] = ld_x(s2 + 2, v);   // used by this step's last three taps
+            if (s2 + 1 < 8) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) a[(s2 + 1) & 1][m] = ld_g(s2 + 1, m);
             }
             if (icf == 0) {
 #pragma unroll
-                for (int m = 0; m < 2; ++m) accb[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], ones, accb[m], 0, 0, 0);
+                for (int m = 0; m < 2; ++m) accb[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s2 & 1][m], ones, accb[m], 0, 0, 0);
             }
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int u = t / 3, v = t % 3;
-                const char* base = s_x + (((2 * icf + lane_plane) * WG_XPL) + (row + u) * TP + col0 + v + tr_row) * 16 + lane_byte;
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, base));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, base + 4 * 16));
-                const bf16x8 bb = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
-                for (int m = 0; m < 2; ++m) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], bb, acc[m][t], 0, 0, 0);
+                for (int m = 0; m < 2; ++m)
+                    acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s2 & 1][m], xr[(s2 + u) % 3][v], acc[m][t], 0, 0, 0);
             }
         }
     }
