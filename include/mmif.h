@@ -328,6 +328,18 @@ int mmif_conv2d_reflect_bwd_pair(const mmif_tensor* gy, const void* w_packed_t, 
                                  int32_t cin, int32_t cout, int32_t ksize, int32_t accumulate, void* workspace, size_t workspace_bytes,
                                  void* stream);
 
+/* Backward of ONE wide 3x3 ConvLayer (Cin, Cout multiples of 64: decode.0 128 -> 128 and decode.1 128 -> 64 of PFNetv1, core/model.py:83-84;
+ * DenseFuse's decode.0) as one call = mmif_conv2d_reflect_wgrad followed by mmif_conv2d_reflect_dgrad_folded(mask_bits, accum_bits = 0), with
+ * one difference in HBM traffic: the weight-gradient kernel, which stages the activation tiles anyway, leaves their ReLU SIGN BYTES (one
+ * byte per pixel and 8 channels) in `signs`, and the input-gradient kernel reads those instead of the activations (1/16 of the bytes).
+ * gy: folded halo-1; x: the layer's forward input (halo 0); gx: halo 1 with a zero ring; mask_bits: channel blocks of gx masked with
+ * [x > 0].  Workspace: mmif_conv2d_wgrad_workspace(cin, cout, 3); signs: mmif_conv2d_bwd_wide_signs_bytes(n, cin, h, w) bytes, scratch. */
+int mmif_conv2d_bwd_wide_supported(int32_t cin, int32_t cout, int32_t ksize);
+size_t mmif_conv2d_bwd_wide_signs_bytes(int32_t n, int32_t cin, int32_t h, int32_t w);
+int mmif_conv2d_reflect_bwd_wide(const mmif_tensor* gy, const void* w_packed_t, const mmif_tensor* x, const mmif_tensor* gx, float* dw, float* db,
+                                 int32_t cin, int32_t cout, int32_t ksize, uint64_t mask_bits, int32_t accumulate, void* workspace,
+                                 size_t workspace_bytes, void* signs, size_t signs_bytes, void* stream);
+
 /* ---- streaming DenseBlock encoder (core/model.py:73-80 = ConvLayer(1,16) + DenseBlock(16,16): PFNetv1.encode1/2, DenseFuse / PFNetv2 /
  *      VIFNet .encode), forward, bf16: the four layers as ONE line-buffer kernel (csrc/enc_stream.hip) -- reads the image, writes the
  *      64 concatenated channels [x0 | x1 | x2 | x3] once.  Bit-identical to mmif_conv2d_image_in_fwd + three mmif_conv2d_reflect_fwd

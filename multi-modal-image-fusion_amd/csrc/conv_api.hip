@@ -22,6 +22,10 @@ bool bwd_pair_supported(int ks, int cin, int cout);
 size_t bwd_pair_workspace(int cin, int cout);
 int bwd_pair(const TV& tx, const TV& tg, const TV& tgx, const void* wpk_dgrad, float* dw, float* db, int cin, int cout, int accumulate, float* ws,
              hipStream_t st);
+bool bwd_wide_supported(int ks, int cin, int cout);
+size_t bwd_wide_signs_bytes(int n, int cin, int h, int w);
+int bwd_wide(const TV& tx, const TV& tg, const TV& tgx, const void* wpk_dgrad, float* dw, float* db, int cin, int cout, uint64_t mask_bits,
+             int accumulate, float* ws, unsigned char* signs, hipStream_t st);
 }  // namespace mmif
 
 using namespace mmif;
@@ -153,4 +157,37 @@ extern "C" int mmif_conv2d_reflect_bwd_pair(const mmif_tensor* gy, const void* w
         return MMIF_EWORKSPACE;
     }
     return bwd_pair(make_tv(x), make_tv(gy), make_tv(gx), w_packed_t, dw, db, cin, cout, accumulate, (float*)workspace, (hipStream_t)stream);
+}
+
+// Backward of one WIDE 3x3 ConvLayer (Cin, Cout multiples of 64) as one call: the weight-gradient kernel also leaves the ReLU sign bytes of
+// x in `signs`, the input-gradient kernel reads those instead of x.  Same results as mmif_conv2d_reflect_wgrad followed by
+// mmif_conv2d_reflect_dgrad_folded(mask_bits, accum_bits = 0).
+extern "C" int mmif_conv2d_bwd_wide_supported(int32_t cin, int32_t cout, int32_t ksize) { return bwd_wide_supported(ksize, cin, cout) ? 1 : 0; }
+extern "C" size_t mmif_conv2d_bwd_wide_signs_bytes(int32_t n, int32_t cin, int32_t h, int32_t w) { return bwd_wide_signs_bytes(n, cin, h, w); }
+
+extern "C" int mmif_conv2d_reflect_bwd_wide(const mmif_tensor* gy, const void* w_packed_t, const mmif_tensor* x, const mmif_tensor* gx, float* dw,
+                                            float* db, int32_t cin, int32_t cout, int32_t ksize, uint64_t mask_bits, int32_t accumulate,
+                                            void* workspace, size_t workspace_bytes, void* signs, size_t signs_bytes, void* stream) {
+    if (int rc = validate_tensor(gy, "gy")) return rc;
+    if (int rc = validate_tensor(x, "x")) return rc;
+    if (int rc = validate_tensor(gx, "gx")) return rc;
+    MMIF_REQUIRE(bwd_wide_supported(ksize, cin, cout), "conv2d_reflect_bwd_wide: unsupported layer %d -> %d k%d", cin, cout, ksize);
+    MMIF_REQUIRE(w_packed_t != nullptr && dw != nullptr, "conv2d_reflect_bwd_wide: NULL operand image / dw");
+    MMIF_REQUIRE(gy->dtype == MMIF_BF16 && x->dtype == MMIF_BF16 && gx->dtype == MMIF_BF16, "conv2d_reflect_bwd_wide: bf16 tensors expected");
+    MMIF_REQUIRE(gy->halo == 1 && (gy->flags & MMIF_T_FOLDED), "conv2d_reflect_bwd_wide: gy must be a folded halo-1 gradient");
+    MMIF_REQUIRE(x->halo == 0 && gx->halo == 1, "conv2d_reflect_bwd_wide: x halo 0, gx halo 1 expected");
+    MMIF_REQUIRE(gy->n == x->n && gy->h == x->h && gy->w == x->w && gx->n == x->n && gx->h == x->h && gx->w == x->w, "conv2d_reflect_bwd_wide: shape mismatch");
+    MMIF_REQUIRE(cin / 8 == x->cb && x->cb == gx->cb && cout / 8 == gy->cb, "conv2d_reflect_bwd_wide: channel blocks do not match");
+    MMIF_REQUIRE(x->h >= 4 && x->w >= 4, "conv2d_reflect_bwd_wide: needs h, w >= 4 (fold steps inside the border tiles)");
+    MMIF_REQUIRE((long long)(x->h + 2) * (x->w + 2) * 16 * 8 < (1ll << 31), "conv2d_reflect_bwd_wide: 8 channel planes must stay below 2 GiB (32-bit staging offsets)");
+    if (workspace == nullptr || workspace_bytes < wgrad_mfma_workspace(cin, cout, ksize)) {
+        set_error("conv2d_reflect_bwd_wide: workspace too small");
+        return MMIF_EWORKSPACE;
+    }
+    if (signs == nullptr || signs_bytes < bwd_wide_signs_bytes(x->n, cin, x->h, x->w)) {
+        set_error("conv2d_reflect_bwd_wide: sign-byte buffer too small (mmif_conv2d_bwd_wide_signs_bytes)");
+        return MMIF_EWORKSPACE;
+    }
+    return bwd_wide(make_tv(x), make_tv(gy), make_tv(gx), w_packed_t, dw, db, cin, cout, mask_bits, accumulate, (float*)workspace,
+                    (unsigned char*)signs, (hipStream_t)stream);
 }

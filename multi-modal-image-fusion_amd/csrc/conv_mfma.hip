@@ -681,12 +681,24 @@ constexpr int D_LOAD = 4;                                          // loader wav
 constexpr int DL_ITERS = (D_PIECES + D_LOAD - 1) / D_LOAD;         // 19 pieces per loader wave per chunk
 constexpr int DL_IN_ITERS = (DIN_PIECES + D_LOAD - 1) / D_LOAD;    // 10 of them may be input pieces
 
-template <bool DGRAD, bool LMASK>
+// ReLU sign bytes of an activation tensor, in the PADDED domain of its gradient: [n][cb][hs = h + 2][pitch] bytes, bit i of the byte
+// at (row Y, column X) = channel 8 cb + i of image pixel (Y - 1, X - 1) is > 0.  The byte of column X lives at X + SIGN_XOFF, so that
+// the 16 columns of a dgrad tile (first stored column 1 + 16 k) are one aligned 16-byte load.  Written by wgrad_dma_kernel (which has
+// the activation tile in LDS anyway), read by conv_dma_kernel<true, 2>: 1/16 of the bytes of the activations themselves.
+constexpr int SIGN_XOFF = 15;
+struct SignMap {
+    unsigned char* p;
+    int cb, hs, pitch;
+};
+static inline int sign_pitch(int w) { return (cdiv(w, MT) + 2) * MT; }
+
+// (LMASK: 0 = none, 1 = the loaders reduce the mask ACTIVATIONS to sign bytes, 2 = they fetch ready sign bytes -- struct SignMap)
+template <bool DGRAD, int LMASK>
 __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void conv_dma_kernel(TV tin, TV tout, TV tmask, const uint4* __restrict__ wpk,
                                                                               const float* __restrict__ bias, int n_out, int m16p, int relu,
                                                                               unsigned long long mask_bits, unsigned long long accum_bits,
                                                                               int tiles_x, int tiles_y, int nmb, long long* __restrict__ trace,
-                                                                              int abl, int org) {
+                                                                              int abl, int org, SignMap sgn) {
     constexpr int MF = 4;
     __shared__ __attribute__((aligned(16))) char s_buf[2 * DBUF_BYTES];
     __shared__ int2 s_tab[2][DW_PIECES];
@@ -695,7 +707,7 @@ __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void conv_dma_kernel(TV 
     // 8 channels).  The consumers' epilogue used to fetch the mask activations itself -- 8 global round trips on the critical path of
     // every tile, and all of a tile's k-loop is only 2 chunks for a 64-channel input (decode.1's dgrad).  The LOADER waves have the
     // time: they fetch the tile's mask granules two chunks ahead, reduce them to bits and park them here.
-    __shared__ unsigned char s_mask[LMASK ? 2 : 1][LMASK ? 8 * DT_ROWS * MT : 16];
+    __shared__ __attribute__((aligned(16))) unsigned char s_mask[LMASK ? 2 : 1][LMASK ? 8 * DT_ROWS * MT : 16];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: roles, piece indices, LDS bases and M0 stay in SGPRs
@@ -820,11 +832,22 @@ __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void conv_dma_kernel(TV 
             }
         };
         // ---- mask bits: thread t of the 256 loader threads owns tile pixels t and t + 256 of every channel block of the M-block
-        uint4 mreg[LMASK ? 16 : 1];
+        uint4 mreg[LMASK == 1 ? 16 : 1];
         bool mpend = false;       // mask granules of item `mitem` are in flight / in registers
         int mpar = 0;
         auto issue_mask = [&](const DItem& itm) {
             const int t = tid - D_CONS * 64;
+            if (LMASK == 2) {
+                // ready-made sign bytes (written by the layer's weight-gradient kernel): thread t owns the 16 columns of
+                // (channel block t >> 5, tile row t & 31) -- ONE 16-byte load per thread and tile instead of 16 granules
+                const int cbl = t >> 5, row = t & 31;
+                const int ocb = itm.mb * 8 + cbl;
+                const bool need = ocb < tout.cb && ((mask_bits >> ocb) & 1ull);
+                const int ys = min(org + itm.tile_y * DT_ROWS + row, sgn.hs - 1), xs = org + itm.tile_x * MT;
+                mreg[0] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+                if (need) mreg[0] = *reinterpret_cast<const uint4*>(sgn.p + (((long long)itm.in_ * sgn.cb + min(ocb, sgn.cb - 1)) * sgn.hs + ys) * sgn.pitch + xs + SIGN_XOFF);
+                return;
+            }
 #pragma unroll
             for (int cbl = 0; cbl < 8; ++cbl) {
                 const int ocb = itm.mb * 8 + cbl;
@@ -835,12 +858,16 @@ __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void conv_dma_kernel(TV 
                     const int oys = org + itm.tile_y * DT_ROWS + row, oxs = org + itm.tile_x * MT + col;
                     const int y = min(max(reflect_idx(oys - tout.halo, tmask.h), 0), tmask.h - 1);
                     const int x = min(max(reflect_idx(oxs - tout.halo, tmask.w), 0), tmask.w - 1);
-                    if (need) mreg[LMASK ? 2 * cbl + k : 0] = *reinterpret_cast<const uint4*>(tmask.base + tmask.gidx(itm.in_, min(ocb, tmask.cb - 1), y, x) * 16);
+                    if (need) mreg[LMASK == 1 ? 2 * cbl + k : 0] = *reinterpret_cast<const uint4*>(tmask.base + tmask.gidx(itm.in_, min(ocb, tmask.cb - 1), y, x) * 16);
                 }
             }
         };
         auto park_mask = [&](const DItem& itm, int par) {
             const int t = tid - D_CONS * 64;
+            if (LMASK == 2) {
+                *reinterpret_cast<uint4*>(&s_mask[LMASK ? par : 0][LMASK ? t * MT : 0]) = mreg[0];   // [cbl][row][16 cols], t = cbl * 32 + row
+                return;
+            }
 #pragma unroll
             for (int cbl = 0; cbl < 8; ++cbl) {
                 const int ocb = itm.mb * 8 + cbl;
@@ -848,7 +875,7 @@ __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void conv_dma_kernel(TV 
                 if (!need) continue;
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
-                    const uint4 v = mreg[LMASK ? 2 * cbl + k : 0];
+                    const uint4 v = mreg[LMASK == 1 ? 2 * cbl + k : 0];
                     const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
                     unsigned bits = 0;
 #pragma unroll
@@ -899,7 +926,7 @@ __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void conv_dma_kernel(TV 
             conv_epilogue_packed<MF, false>(acc, tout, s_bias[slot], (itm).mb, (itm).in_, org + (itm).tile_x * MT,                            \
                                             org + (itm).tile_y * DT_ROWS + wave * 4, wave * 4, relu, mask_bits, tout.ws - org, tout.hs - org,  \
                                             nullptr, tr, &tr_n);                                                                                     \
-        } else if constexpr (LMASK) {                                                                                                         \
+        } else if constexpr (LMASK != 0) {                                                                                                    \
             if (accum_bits == 0)                                                                                                              \
                 conv_epilogue_packed<MF, true>(acc, tout, s_bias[slot], (itm).mb, (itm).in_, org + (itm).tile_x * MT,                         \
                                                org + (itm).tile_y * DT_ROWS + wave * 4, wave * 4, relu, mask_bits, tout.ws - org,             \
@@ -921,6 +948,11 @@ __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void conv_dma_kernel(TV 
         DTRACE_TOP(q);   // chunk top
         __builtin_amdgcn_s_barrier();
         DTRACE();   // barrier passed
+        // lane coordinates re-derived per chunk behind an asm the compiler cannot hoist: nothing lane dependent stays live across the
+        // loop (at the 168-register budget the allocator otherwise spills one of them and reloads it -- scratch + vmcnt(0) -- per chunk)
+        int lane_q;
+        __asm__ volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_q));
+        const int j = lane_q & 15, g = lane_q >> 4;
         if (have_pend) {   // waves 4..7: previous tile's outputs, stored under the partner wave's MFMAs (see below)
             __builtin_amdgcn_s_setprio(3);   // (measured neutral; the epilogue is ~180 VALU instructions either way)
             DMA_EPILOGUE(pend, pend_slot, pend_par);
@@ -1508,7 +1540,7 @@ constexpr int WDL_ITERS = (WD_PIECES + D_LOAD - 1) / D_LOAD;   // 19 pieces per 
 constexpr int WD_PER = 64 * 64 * 9 + 64;                   // floats per block partial: dW[64 oc][64 ic][9], db[64]
 
 __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void wgrad_dma_kernel(TV tx, TV tg, float* __restrict__ partial, int tiles_x,
-                                                                               int tpi, int total, int G, int n_icg, int n_ocg) {
+                                                                               int tpi, int total, int G, int n_icg, int n_ocg, SignMap sgn) {
     constexpr int TP = MT + 2;
     __shared__ __attribute__((aligned(16))) char s_buf[2 * WD_BUF_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1564,11 +1596,44 @@ __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void wgrad_dma_kernel(TV
                 }
             }
         };
+        // ReLU sign bytes of the activation tile (struct SignMap; the layer's dgrad reads them instead of the activations), by the
+        // blocks of the first output-channel group: loader thread t owns 8 adjacent pixels of one plane -- (plane t >> 5, tile row
+        // (t & 31) >> 1, columns 8 (t & 1) .. + 7) -- 8 LDS granules in, ONE 8-byte store out.  The LDS reads are asm: the compiler
+        // orders a C++ read of this buffer after ALL outstanding LDS-DMA (vmcnt(0)), i.e. after the NEXT tile's staging has landed.
+        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+        auto emit_signs = [&](int tile, int buf) {
+            const int in_ = tile / tpi, tt = tile - in_ * tpi;
+            const int y0 = (tt / tiles_x) * MT, x0 = (tt % tiles_x) * MT;
+            const int t = lw * 64 + lane, pl = t >> 5, py = (t & 31) >> 1, px0 = 8 * (t & 1);
+            if (y0 + py >= tx.h || icg * 8 + pl >= tx.cb) return;
+            const unsigned lds0 = (unsigned)(size_t)(s_buf + buf * WD_BUF_BYTES) + (unsigned)((pl * WG_XPL + (py + 1) * TP + px0 + 1) * 16);
+            u32x4_t v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) __asm__ volatile("ds_read_b128 %0, %1" : "=v"(v[i]) : "v"(lds0 + 16u * i));
+            __asm__ volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+            const unsigned one2 = 0x00010001u;
+            unsigned out[2] = {0u, 0u};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                unsigned r = 0;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {   // per dword: bit 0 = low bf16 > 0, bit 16 = high bf16 > 0 (positive as int16)
+                    unsigned q;
+                    __asm__("v_pk_min_i16 %0, %1, %2\n\tv_pk_max_i16 %0, %0, 0" : "=&v"(q) : "v"(v[i][d]), "v"(one2));
+                    r |= q << (2 * d);
+                }
+                out[i >> 2] |= ((r | (r >> 15)) & 0xffu) << (8 * (i & 3));
+            }
+            unsigned char* dst = sgn.p + (((long long)in_ * sgn.cb + icg * 8 + pl) * sgn.hs + y0 + py + 1) * sgn.pitch + x0 + px0 + 1 + SIGN_XOFF;
+            *reinterpret_cast<uint2*>(dst) = make_uint2(out[0], out[1]);   // (columns past a ragged image edge land in the row's padding)
+        };
+        const bool signs = sgn.p != nullptr && ocg == 0;
         if (ntile > 0) issue(gi, 0);
         for (int k = 0; k < ntile; ++k) {
             __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's pieces of tile k have landed
             __builtin_amdgcn_s_barrier();
             if (k + 1 < ntile) issue(gi + (k + 1) * G, (k & 1) ^ 1);
+            if (signs) emit_signs(gi + k * G, k & 1);
         }
         return;
     }
@@ -1935,6 +2000,23 @@ int bwd_pair(const TV& tx, const TV& tg, const TV& tgx, const void* wpk_dgrad, f
     return taprow_reduce_launch(ws, dw, db, cin, cout, G, accumulate, st);
 }
 
+// ---- backward of a WIDE 3x3 layer (Cin, Cout multiples of 64: decode.0 / decode.1) as one call: wgrad_dma_kernel also leaves the
+// ReLU sign bytes of the layer's input activations, conv_dma_kernel<true, 2> (dgrad, fused fold) reads those instead of the
+// activations themselves -- for decode.1 (128 -> 64, every input block masked) that is 0.54 of the dgrad's 1.34 GB.
+static int launch_wgrad_dma(const TV& tx, const TV& tg, float* dw, float* db, int cin, int cout, int accumulate, float* ws, hipStream_t st, SignMap sgn);
+static int launch_conv_dma(bool dgrad, const TV& tin, const TV& tout, const TV& tmask, const void* wpk, const float* bias, int n_out, int relu,
+                           uint64_t mask_bits, uint64_t accum_bits, int org, hipStream_t st, SignMap sgn);
+static void init_modes();
+bool bwd_wide_supported(int ks, int cin, int cout) { return ks == 3 && cin >= 64 && cout >= 64 && cin % 64 == 0 && cout % 64 == 0 && cin <= 512; }
+size_t bwd_wide_signs_bytes(int n, int cin, int h, int w) { return (size_t)n * (cin / 8) * (h + 2) * sign_pitch(w); }
+int bwd_wide(const TV& tx, const TV& tg, const TV& tgx, const void* wpk_dgrad, float* dw, float* db, int cin, int cout, uint64_t mask_bits,
+             int accumulate, float* ws, unsigned char* signs, hipStream_t st) {
+    init_modes();
+    const SignMap sgn{signs, tx.cb, tx.h + 2, sign_pitch(tx.w)};
+    if (int rc = launch_wgrad_dma(tx, tg, dw, db, cin, cout, accumulate, ws, st, mask_bits != 0 ? sgn : SignMap{nullptr, 0, 0, 0})) return rc;
+    return launch_conv_dma(true, tg, tgx, tx, wpk_dgrad, nullptr, cin, 0, mask_bits, 0, 1, st, sgn);
+}
+
 bool conv_mfma_supported(bool dgrad, int ks, int cin, int cout) {
     (void)dgrad;
     return (ks == 1 || ks == 3) && cin >= 1 && cout >= 1;
@@ -1973,8 +2055,19 @@ static int g_fuse_fold = -1;   // $MMIF_DGRAD_FOLD: 1 (default) = the DMA-staged
 static int g_abl = 0;            // $MMIF_CONV_ABLATE (diagnostics): bit 0 = no staging DMAs after the first chunk
 
 static int g_lmask = -1;
+// the environment switches, read once -- by whichever entry point runs first (a process whose first MFMA call was a weight gradient used
+// to leave g_fuse_fold unset, i.e. the stand-alone fold kernel for the rest of its life)
+static void init_modes() {
+    if (g_dma_mode >= 0 && g_fuse_fold >= 0) return;
+    const char* e = getenv("MMIF_CONV_DMA");
+    if (g_dma_mode < 0) g_dma_mode = (e != nullptr && e[0] == '0') ? 0 : 1;   // (mmif_debug_set_conv_dma may have set it already)
+    const char* a = getenv("MMIF_CONV_ABLATE");
+    g_abl = a != nullptr ? atoi(a) : 0;
+    const char* r = getenv("MMIF_DGRAD_FOLD");
+    g_fuse_fold = (r != nullptr && r[0] == '0') ? 0 : 1;
+}
 static int launch_conv_dma(bool dgrad, const TV& tin, const TV& tout, const TV& tmask, const void* wpk, const float* bias, int n_out,
-                           int relu, uint64_t mask_bits, uint64_t accum_bits, int org, hipStream_t st) {
+                           int relu, uint64_t mask_bits, uint64_t accum_bits, int org, hipStream_t st, SignMap sgn = SignMap{nullptr, 0, 0, 0}) {
     const int tiles_x = cdiv(tout.ws - 2 * org, MT), tiles_y = cdiv(tout.hs - 2 * org, DT_ROWS);
     const int nmb = n_mblocks(n_out);
     const int m16p = nmb * 4 * 16;
@@ -1994,15 +2087,14 @@ static int launch_conv_dma(bool dgrad, const TV& tin, const TV& tout, const TV& 
         g_lmask = (e != nullptr && e[0] == '0') ? 0 : 1;
     }
     const bool lmask = dgrad && g_lmask == 1 && mask_bits != 0 && cdiv(tin.cb, CHUNK_CB) >= 2;
-    if (dgrad && lmask)
-        hipLaunchKernelGGL((conv_dma_kernel<true, true>), dim3(G), dim3((D_CONS + D_LOAD) * 64), 0, st, tin, tout, tmask, (const uint4*)wpk, bias, n_out, m16p, relu,
-                           (unsigned long long)mask_bits, (unsigned long long)accum_bits, tiles_x, tiles_y, nmb, g_trace, g_abl, org);
-    else if (dgrad)
-        hipLaunchKernelGGL((conv_dma_kernel<true, false>), dim3(G), dim3((D_CONS + D_LOAD) * 64), 0, st, tin, tout, tmask, (const uint4*)wpk, bias, n_out, m16p, relu,
-                           (unsigned long long)mask_bits, (unsigned long long)accum_bits, tiles_x, tiles_y, nmb, g_trace, g_abl, org);
-    else
-        hipLaunchKernelGGL((conv_dma_kernel<false, false>), dim3(G), dim3((D_CONS + D_LOAD) * 64), 0, st, tin, tout, tmask, (const uint4*)wpk, bias, n_out, m16p, relu,
-                           (unsigned long long)mask_bits, (unsigned long long)accum_bits, tiles_x, tiles_y, nmb, g_trace, g_abl, 0);
+#define DMA_GO(D_, L_, ORG_)                                                                                                                  \
+    hipLaunchKernelGGL((conv_dma_kernel<D_, L_>), dim3(G), dim3((D_CONS + D_LOAD) * 64), 0, st, tin, tout, tmask, (const uint4*)wpk, bias, n_out, \
+                       m16p, relu, (unsigned long long)mask_bits, (unsigned long long)accum_bits, tiles_x, tiles_y, nmb, g_trace, g_abl, ORG_, sgn)
+    if (dgrad && lmask && sgn.p != nullptr) DMA_GO(true, 2, org);
+    else if (dgrad && lmask) DMA_GO(true, 1, org);
+    else if (dgrad) DMA_GO(true, 0, org);
+    else DMA_GO(false, 0, 0);
+#undef DMA_GO
     return check_launch(dgrad ? "conv_dma dgrad" : "conv_dma fwd");
 }
 
@@ -2013,14 +2105,7 @@ int conv_mfma(bool dgrad, int ks, const TV& tin, const TV& tout, const TV& tmask
     if (folded != nullptr) *folded = false;
     const int n_out = dgrad ? cin : cout;
     const int mf = pick_mf(n_out);
-    if (g_dma_mode < 0) {
-        const char* e = getenv("MMIF_CONV_DMA");
-        g_dma_mode = (e != nullptr && e[0] == '0') ? 0 : 1;
-        const char* a = getenv("MMIF_CONV_ABLATE");
-        g_abl = a != nullptr ? atoi(a) : 0;
-        const char* r = getenv("MMIF_DGRAD_FOLD");
-        g_fuse_fold = (r != nullptr && r[0] == '0') ? 0 : 1;
-    }
+    init_modes();
     const int org = (dgrad && fold && folded != nullptr && ks == 3 && g_fuse_fold == 1 && tout.halo == 1 && tout.h >= 4 && tout.w >= 4) ? 1 : 0;
     // the DMA-staged kernel: 3x3, 64-row M-blocks, input gradient already folded, tensors within 32-bit plane offsets
     if (g_dma_mode == 1 && ks == 3 && mf == 4 && (!dgrad || (tin.halo == 1 && tin.folded)) &&
@@ -2116,14 +2201,15 @@ size_t wgrad_mfma_workspace(int cin, int cout, int ks) {
     return a;
 }
 
-static int launch_wgrad_dma(const TV& tx, const TV& tg, float* dw, float* db, int cin, int cout, int accumulate, float* ws, hipStream_t st) {
+static int launch_wgrad_dma(const TV& tx, const TV& tg, float* dw, float* db, int cin, int cout, int accumulate, float* ws, hipStream_t st,
+                            SignMap sgn = SignMap{nullptr, 0, 0, 0}) {
     const int tiles_x = cdiv(tx.w, MT), tiles_y = cdiv(tx.h, MT);
     const int tpi = tiles_x * tiles_y, total = tpi * tx.n;
     const int n_icg = cdiv(cin, 64), n_ocg = cdiv(cout, 64);
     int G = wgrad_dma_G(cin, cout);
     if (G > total) G = total;   // every tile group owns at least one tile (the reduce sums all G partials)
     hipLaunchKernelGGL(wgrad_dma_kernel, dim3(G * n_icg * n_ocg), dim3((D_CONS + D_LOAD) * 64), 0, st, tx, tg, ws, tiles_x, tpi, total, G,
-                       n_icg, n_ocg);
+                       n_icg, n_ocg, sgn);
     if (int rc = check_launch("wgrad_dma")) return rc;
     const int n = cout * cin * 9 + cout;
     hipLaunchKernelGGL(wgrad_dma_reduce, dim3(cdiv(n, 64)), dim3(256), 0, st, ws, dw, db, cin, cout, G, n_icg, n_ocg, accumulate);
@@ -2150,10 +2236,7 @@ static int launch_wgrad_mfma(const TV& tx, const TV& tg, float* dw, float* db, i
 int wgrad_mfma(int ks, const TV& tx, const TV& tg, float* dw, float* db, int cin, int cout, int accumulate, float* ws,
                hipStream_t st) {
     const int mfw = pick_mfw(cout);
-    if (g_dma_mode < 0) {
-        const char* e = getenv("MMIF_CONV_DMA");
-        g_dma_mode = (e != nullptr && e[0] == '0') ? 0 : 1;
-    }
+    init_modes();
     if (g_dma_mode == 1 && wgrad_dma_shape(ks, cin, cout) && tg.halo == 1 && tg.folded && tx.plane * 16 * 8 < (1ll << 31) &&
         tg.plane * 16 * 8 < (1ll << 31))
         return launch_wgrad_dma(tx, tg, dw, db, cin, cout, accumulate, ws, st);

@@ -294,6 +294,21 @@ class ModelEngine:
                 and T.bwd_pair_supported(s.cin, s.cout, s.k) and os.environ.get("MMIF_BWD_PAIR", "1") != "0")
 
     @staticmethod
+    def wide_ok(s, dtype, impl, x, gx):
+        """this layer's backward runs as wgrad (leaving ReLU sign bytes) + dgrad reading them (csrc/conv_mfma.hip bwd_wide;
+        $MMIF_BWD_WIDE=0: the two calls apart, the dgrad reading the activations)"""
+        return (dtype == torch.bfloat16 and impl != _lib.IMPL_VALU and not s.split and s.packed is not None and x.h >= 4 and x.w >= 4
+                and x.halo == 0 and gx.halo == 1 and x.cb * 8 == s.cin and T.bwd_wide_supported(s.cin, s.cout, s.k)
+                and (x.h + 2) * (x.w + 2) * 128 < (1 << 31) and os.environ.get("MMIF_BWD_WIDE", "1") != "0")
+
+    def c_bwd_wide(self, s, gy, x, gx, mask_bits, ws):
+        need = T.bwd_wide_signs_bytes(x.n, s.cin, x.h, x.w)
+        sg = getattr(self, "_signs", None)
+        if sg is None or sg.numel() < need or sg.device != x.buf.device:
+            sg = self._signs = torch.empty(need, dtype=torch.uint8, device=x.buf.device)
+        return T.conv_bwd_wide(gy, x, gx, s.dw, s.db, s.cin, s.cout, s.k, s.packed, mask_bits, ws, sg, False, s.name + ":bwd")
+
+    @staticmethod
     def c_bwd_pair(s, gy, x, gx, ws):
         return T.conv_bwd_pair(gy, x, gx, s.dw, s.db, s.cin, s.cout, s.k, s.packed, ws, False, s.name + ":bwd")
 
@@ -464,13 +479,14 @@ class PFNetv1Engine(ModelEngine, DenseEncoderMixin):
             if i > 0 and self.pair_ok(s, dtype, impl, h, w):
                 g = self.c_bwd_pair(s, g, x, gx, ws)      # thin layer: dgrad (every block masked) + wgrad in one launch
                 continue
+            # gradient w.r.t. the concatenated encoder features (i == 0): only each encoder's last DenseBlock output
+            # (blocks 6,7 / 14,15) has no further contributor
+            mb = all_bits(gx.cb) if i > 0 else bits(6, 7, 14, 15)
+            if self.wide_ok(s, dtype, impl, x, gx):
+                g = self.c_bwd_wide(s, g, x, gx, mb, ws)  # wide layer: the wgrad leaves the ReLU sign bytes the dgrad masks with
+                continue
             self.c_wgrad(s, x, g, ws, impl)
-            if i > 0:
-                g = self.c_dgrad(s, g, x, gx, all_bits(gx.cb), 0, impl)
-            else:
-                # gradient w.r.t. the concatenated encoder features: only each encoder's last
-                # DenseBlock output (blocks 6,7 / 14,15) has no further contributor
-                g = self.c_dgrad(s, g, x, gx, bits(6, 7, 14, 15), 0, impl)
+            g = self.c_dgrad(s, g, x, gx, mb, 0, impl)
         self.enc_bwd_all(img1, img2, F, g, ws, impl)
         return grads
 
@@ -556,13 +572,14 @@ class DenseFuseEngine(ModelEngine, DenseEncoderMixin):
             if i > 0 and self.pair_ok(s, dtype, impl, h, w):
                 g = self.c_bwd_pair(s, g, x, gx, ws)
                 continue
+            # i == 0: the auto-encoder's input is the DenseBlock output (only its last conv, blocks 6,7, has no further contributor);
+            # x = f1 + f2 is not a ReLU output
+            mb = all_bits(gx.cb) if i > 0 else (bits(6, 7) if single else 0)
+            if self.wide_ok(s, dtype, impl, x, gx):
+                g = self.c_bwd_wide(s, g, x, gx, mb, ws)
+                continue
             self.c_wgrad(s, x, g, ws, impl)
-            if i > 0:
-                g = self.c_dgrad(s, g, x, gx, all_bits(gx.cb), 0, impl)
-            elif single:
-                g = self.c_dgrad(s, g, x, gx, bits(6, 7), 0, impl)
-            else:
-                g = self.c_dgrad(s, g, x, gx, 0, 0, impl)  # x = f1 + f2 is not a ReLU output
+            g = self.c_dgrad(s, g, x, gx, mb, 0, impl)
         if single:
             self.enc_bwd(self.enc, img1, F, g, 0, 0, ws, impl)
             return grads

@@ -177,6 +177,24 @@ def conv_bwd_pair(gy, x, gx, dw, db, cin, cout, k, packed, ws, accumulate=False,
     return gx.as_folded()
 
 
+def bwd_wide_supported(cin, cout, k):
+    return bool(lib.mmif_conv2d_bwd_wide_supported(cin, cout, k))
+
+
+def bwd_wide_signs_bytes(n, cin, h, w):
+    return lib.mmif_conv2d_bwd_wide_signs_bytes(n, cin, h, w)
+
+
+def conv_bwd_wide(gy, x, gx, dw, db, cin, cout, k, packed, mask_bits, ws, signs, accumulate=False, tag=None):
+    """wgrad + dgrad (blocks in mask_bits masked by x, folded) of one wide 3x3 layer; the wgrad kernel leaves x's ReLU sign bytes in
+    `signs` (uint8 scratch, bwd_wide_signs_bytes) for the dgrad kernel; returns the folded gx view."""
+    with _timed(tag, (gy.n, gy.h, gy.w, cin, cout, k)):
+        check(lib.mmif_conv2d_reflect_bwd_wide(gy.d, _ptr(packed.dgrad), x.d, gx.d, _ptr(dw), _ptr(db), cin, cout, k, mask_bits, int(accumulate),
+                                               _ptr(ws), ws.numel() * ws.element_size(), _ptr(signs), signs.numel(), stream_ptr()),
+              "conv2d_reflect_bwd_wide")
+    return gx.as_folded()
+
+
 def image_in_fwd(img, w, bias, y, cout, k, relu):
     check(lib.mmif_conv2d_image_in_fwd(_ptr(img), _ptr(w), _ptr(bias), y.d, cout, k, int(relu), stream_ptr()), "image_in_fwd")
 
