@@ -19,69 +19,113 @@ constexpr int LIN = LT + WIN - 1; // 26
 // ------------------------------------------------------------------ SSIM, pass 1
 // per map pixel: S(x1,f) + S(x2,f) (block partial) and the adjoint inputs
 //   mA = Ap1 + Ap2, mB = Bp1 + Bp2, mC1 = Cp1, mC2 = Cp2   
-__global__ __launch_bounds__(256) void ssim_stats_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
-                                                         const float* __restrict__ f, int H, int W, Win11 win, float C1,
-                                                         float C2, float* __restrict__ maps /* [4][n][Hm][Wm] or null */,
-                                                         float* __restrict__ partial, int tiles_x) {
-    __shared__ float in[3][LIN][LIN + 1];
-    __shared__ float hb[8][LIN][LT + 1];
+// 32 x 32 map pixels per block (round 2; 16 x 16 with one output per thread and a scalar LDS read per tap was LDS-issue bound:
+// 142 reads per pixel).  Both passes slide the 11-tap window over registers: a thread of the horizontal pass owns 4 adjacent
+// columns of one row for 4 of the 8 quantities (16 floats of two images in, 4 x 4 sums out), a thread of the vertical pass one
+// column x 4 rows for all 8 (14 rows in) -- 33 LDS instructions per pixel.  Every sum keeps the tap order k = 0..10 of the
+// 16 x 16 version, so map values and gradients are bit-identical to it; only the order of the block partials changed.
+constexpr int ST = 32;                // tile edge
+constexpr int SIN = ST + WIN - 1;     // 42
+constexpr int SPI = 44;               // row pitch of the staged images (floats; rows stay 16-byte aligned)
+constexpr int SPH = 36;               // row pitch of the horizontal sums
+
+__device__ inline void ld16(const float* p, float (&v)[16]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float4 q = *reinterpret_cast<const float4*>(p + 4 * i);
+        v[4 * i] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w;
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void ssim_stats_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
+                                                            const float* __restrict__ f, int H, int W, Win11 win, float C1,
+                                                            float C2, float* __restrict__ maps /* [4][n][Hm][Wm] or null */,
+                                                            float* __restrict__ partial, int tiles_x) {
+    __shared__ __attribute__((aligned(16))) float in[3][SIN][SPI];
+    __shared__ __attribute__((aligned(16))) float hb[8][SIN][SPH];
     __shared__ float red[16];
     const int Hm = H - WIN + 1, Wm = W - WIN + 1;
-    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    const int mx0 = (blockIdx.x % tiles_x) * LT, my0 = (blockIdx.x / tiles_x) * LT;
+    const int tid = threadIdx.x;
+    const int mx0 = (blockIdx.x % tiles_x) * ST, my0 = (blockIdx.x / tiles_x) * ST;
     const int in_ = blockIdx.y;
     const long long ibase = (long long)in_ * H * W;
-    for (int e = tid; e < LIN * LIN; e += 256) {
-        const int py = e / LIN, px = e % LIN;
+    for (int e = tid; e < SIN * SPI; e += 256) {
+        const int py = e / SPI, px = e % SPI;
         const int y = my0 + py, x = mx0 + px;
-        const bool ok = (y < H) && (x < W);
-        const long long i = ibase + (long long)y * W + x;
-        in[0][py][px] = ok ? x1[i] : 0.f;
-        in[1][py][px] = ok ? x2[i] : 0.f;
-        in[2][py][px] = ok ? f[i] : 0.f;
+        const bool ok = (y < H) && (x < W) && px < SIN;
+        const long long i = ibase + (long long)min(y, H - 1) * W + min(x, W - 1);
+        const float a = x1[i], b = x2[i], c = f[i];
+        in[0][py][px] = ok ? a : 0.f;
+        in[1][py][px] = ok ? b : 0.f;
+        in[2][py][px] = ok ? c : 0.f;
     }
     __syncthreads();
-    // horizontal 11-tap pass: 26 rows x 16 cols x 8 quantities
-    for (int e = tid; e < LIN * LT; e += 256) {
-        const int py = e / LT, px = e % LT;
-        float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // horizontal pass: item = (set, row, column group of 4); set 0 -> {x1, x1^2, x1 f, f}, set 1 -> {x2, x2^2, x2 f, f^2};
+    // each set is padded to whole waves (336 -> 384 items)
+#pragma unroll 1
+    for (int r = 0; r < 3; ++r) {
+        const int it = tid + 256 * r, set = it / 384, idx = it - set * 384;
+        if (idx >= SIN * 8) continue;
+        const int py = idx >> 3, cg = idx & 7;
+        float xa[16], fc[16];
+        ld16(&in[set][py][4 * cg], xa);
+        ld16(&in[2][py][4 * cg], fc);
+        float s[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s[q][j] = 0.f;
 #pragma unroll
         for (int k = 0; k < WIN; ++k) {
-            const float a = in[0][py][px + k], b = in[1][py][px + k], c = in[2][py][px + k], wk = win.t[k];
-            s[0] = fmaf(wk, a, s[0]);
-            s[1] = fmaf(wk, b, s[1]);
-            s[2] = fmaf(wk, c, s[2]);
-            s[3] = fmaf(wk, a * a, s[3]);
-            s[4] = fmaf(wk, b * b, s[4]);
-            s[5] = fmaf(wk, c * c, s[5]);
-            s[6] = fmaf(wk, a * c, s[6]);
-            s[7] = fmaf(wk, b * c, s[7]);
-        }
+            const float wk = win.t[k];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) hb[q][py][px] = s[q];
+            for (int j = 0; j < 4; ++j) {
+                const float a = xa[j + k], c = fc[j + k];
+                s[0][j] = fmaf(wk, a, s[0][j]);
+                s[1][j] = fmaf(wk, a * a, s[1][j]);
+                s[2][j] = fmaf(wk, a * c, s[2][j]);
+                s[3][j] = fmaf(wk, set ? c * c : c, s[3][j]);
+            }
+        }
+        const int q0 = set ? 1 : 0, q1 = set ? 4 : 3, q2 = set ? 7 : 6, q3 = set ? 5 : 2;
+        *reinterpret_cast<float4*>(&hb[q0][py][4 * cg]) = make_float4(s[0][0], s[0][1], s[0][2], s[0][3]);
+        *reinterpret_cast<float4*>(&hb[q1][py][4 * cg]) = make_float4(s[1][0], s[1][1], s[1][2], s[1][3]);
+        *reinterpret_cast<float4*>(&hb[q2][py][4 * cg]) = make_float4(s[2][0], s[2][1], s[2][2], s[2][3]);
+        *reinterpret_cast<float4*>(&hb[q3][py][4 * cg]) = make_float4(s[3][0], s[3][1], s[3][2], s[3][3]);
     }
     __syncthreads();
-    float m[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // vertical pass: column tx, rows 4 rg .. 4 rg + 3, all 8 quantities
+    const int tx = tid & 31, rg = tid >> 5;
+    float m[8][4];
 #pragma unroll
-    for (int k = 0; k < WIN; ++k) {
-        const float wk = win.t[k];
+    for (int q = 0; q < 8; ++q) {
+        float v[14];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) m[q] = fmaf(wk, hb[q][ty + k][tx], m[q]);
+        for (int i = 0; i < 14; ++i) v[i] = hb[q][4 * rg + i][tx];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < WIN; ++k) acc = fmaf(win.t[k], v[j + k], acc);
+            m[q][j] = acc;
+        }
     }
-    const int my = my0 + ty, mx = mx0 + tx;
-    const bool valid = (my < Hm) && (mx < Wm);
     float ssum = 0.f;
-    if (valid) {
-        const float mu1 = m[0], mu2 = m[1], muf = m[2];
-        const float sf_raw = m[5] - muf * muf;
+    const long long msz = (long long)gridDim.y * Hm * Wm;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int my = my0 + 4 * rg + j, mx = mx0 + tx;
+        if (!((my < Hm) && (mx < Wm))) continue;
+        const float mu1 = m[0][j], mu2 = m[1][j], muf = m[2][j];
+        const float sf_raw = m[5][j] - muf * muf;
         const float sf = fmaxf(sf_raw, 0.f);
         const float kf = sf_raw > 0.f ? 1.f : 0.f;
         float A = 0.f, B = 0.f, Cs[2];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const float mux = s == 0 ? mu1 : mu2;
-            const float ex2 = s == 0 ? m[3] : m[4];
-            const float exf = s == 0 ? m[6] : m[7];
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const float mux = s2 == 0 ? mu1 : mu2;
+            const float ex2 = s2 == 0 ? m[3][j] : m[4][j];
+            const float exf = s2 == 0 ? m[6][j] : m[7][j];
             const float sx = fmaxf(ex2 - mux * mux, 0.f);
             const float sxf = exf - mux * muf;
             const float m1 = 2.f * mux * muf + C1, m2 = mux * mux + muf * muf + C1;
@@ -94,10 +138,9 @@ __global__ __launch_bounds__(256) void ssim_stats_kernel(const float* __restrict
             const float Ap = 2.f * mux * v1 * inv - 2.f * muf * S / m2 - 2.f * mux * m1 * inv - 2.f * muf * Bp;
             A += Ap;
             B += Bp;
-            Cs[s] = Cp;
+            Cs[s2] = Cp;
         }
         if (maps != nullptr) {
-            const long long msz = (long long)gridDim.y * Hm * Wm;
             const long long mi = ((long long)in_ * Hm + my) * Wm + mx;
             maps[mi] = A;
             maps[msz + mi] = B;
@@ -111,53 +154,72 @@ __global__ __launch_bounds__(256) void ssim_stats_kernel(const float* __restrict
 
 // ------------------------------------------------------------------ SSIM, pass 2 (adjoint correlation)
 // grad[y][x] = scale * ( (G^T*mA) + 2 f (G^T*mB) + x1 (G^T*mC1) + x2 (G^T*mC2) ),
-// (G^T*M)[y][x] = sum_{u,v} G[u][v] M[y-u][x-v], M zero outside the map.
-__global__ __launch_bounds__(256) void ssim_grad_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
-                                                        const float* __restrict__ f, int H, int W, Win11 win,
-                                                        const float* __restrict__ maps, float scale,
-                                                        float* __restrict__ grad, int tiles_x) {
-    __shared__ float in[4][LIN][LIN + 1];
-    __shared__ float hb[4][LIN][LT + 1];
+// (G^T*M)[y][x] = sum_{u,v} G[u][v] M[y-u][x-v], M zero outside the map.  Same 32 x 32 / sliding-window structure as pass 1.
+__global__ __launch_bounds__(256, 2) void ssim_grad_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
+                                                           const float* __restrict__ f, int H, int W, Win11 win,
+                                                           const float* __restrict__ maps, float scale,
+                                                           float* __restrict__ grad, int tiles_x) {
+    __shared__ __attribute__((aligned(16))) float in[4][SIN][SPI];
+    __shared__ __attribute__((aligned(16))) float hb[4][SIN][SPH];
     const int Hm = H - WIN + 1, Wm = W - WIN + 1;
-    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    const int x0 = (blockIdx.x % tiles_x) * LT, y0 = (blockIdx.x / tiles_x) * LT;
+    const int tid = threadIdx.x;
+    const int x0 = (blockIdx.x % tiles_x) * ST, y0 = (blockIdx.x / tiles_x) * ST;
     const int in_ = blockIdx.y;
     const long long msz = (long long)gridDim.y * Hm * Wm;
     // map tile origin: (y0 - 10, x0 - 10)
-    for (int e = tid; e < LIN * LIN; e += 256) {
-        const int py = e / LIN, px = e % LIN;
+    for (int e = tid; e < SIN * SPI; e += 256) {
+        const int py = e / SPI, px = e % SPI;
         const int my = y0 - (WIN - 1) + py, mx = x0 - (WIN - 1) + px;
-        const bool ok = my >= 0 && my < Hm && mx >= 0 && mx < Wm;
-        const long long mi = ((long long)in_ * Hm + my) * Wm + mx;
+        const bool ok = my >= 0 && my < Hm && mx >= 0 && mx < Wm && px < SIN;
+        const long long mi = ((long long)in_ * Hm + min(max(my, 0), Hm - 1)) * Wm + min(max(mx, 0), Wm - 1);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) in[q][py][px] = ok ? maps[q * msz + mi] : 0.f;
+        for (int q = 0; q < 4; ++q) {
+            const float v = maps[q * msz + mi];
+            in[q][py][px] = ok ? v : 0.f;
+        }
     }
     __syncthreads();
     // out[x] = sum_v G[v] M[x - v]  -> with tile offset: M index px = tx + (WIN-1) - v
-    for (int e = tid; e < LIN * LT; e += 256) {
-        const int py = e / LT, px = e % LT;
-        float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int r = 0; r < 2; ++r) {
+        const int idx = tid + 256 * r;
+        if (idx >= SIN * 8) continue;
+        const int py = idx >> 3, cg = idx & 7;
 #pragma unroll
-        for (int k = 0; k < WIN; ++k) {
-            const float wk = win.t[k];
+        for (int q = 0; q < 4; ++q) {
+            float v[16];
+            ld16(&in[q][py][4 * cg], v);
+            float s[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) s[q] = fmaf(wk, in[q][py][px + (WIN - 1) - k], s[q]);
+            for (int k = 0; k < WIN; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s[j] = fmaf(win.t[k], v[j + (WIN - 1) - k], s[j]);
+            *reinterpret_cast<float4*>(&hb[q][py][4 * cg]) = make_float4(s[0], s[1], s[2], s[3]);
         }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) hb[q][py][px] = s[q];
     }
     __syncthreads();
-    float m[4] = {0.f, 0.f, 0.f, 0.f};
+    const int tx = tid & 31, rg = tid >> 5;
+    float m[4][4];
 #pragma unroll
-    for (int k = 0; k < WIN; ++k) {
-        const float wk = win.t[k];
+    for (int q = 0; q < 4; ++q) {
+        float v[14];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) m[q] = fmaf(wk, hb[q][ty + (WIN - 1) - k][tx], m[q]);
+        for (int i = 0; i < 14; ++i) v[i] = hb[q][4 * rg + i][tx];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < WIN; ++k) acc = fmaf(win.t[k], v[j + (WIN - 1) - k], acc);
+            m[q][j] = acc;
+        }
     }
-    const int y = y0 + ty, x = x0 + tx;
-    if (y < H && x < W) {
-        const long long i = ((long long)in_ * H + y) * W + x;
-        grad[i] = scale * (m[0] + 2.f * f[i] * m[1] + x1[i] * m[2] + x2[i] * m[3]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int y = y0 + 4 * rg + j, x = x0 + tx;
+        if (y < H && x < W) {
+            const long long i = ((long long)in_ * H + y) * W + x;
+            grad[i] = scale * (m[0][j] + 2.f * f[i] * m[1][j] + x1[i] * m[2][j] + x2[i] * m[3][j]);
+        }
     }
 }
 
@@ -345,7 +407,7 @@ extern "C" int mmif_ssim_loss(const float* img1, const float* img2, const float*
     gaussian_window(win);
     const float C1 = (0.01f * data_range) * (0.01f * data_range), C2 = (0.03f * data_range) * (0.03f * data_range);
     const int Hm = h - WIN + 1, Wm = w - WIN + 1;
-    const int tmx = cdiv(Wm, LT), tmy = cdiv(Hm, LT);
+    const int tmx = cdiv(Wm, ST), tmy = cdiv(Hm, ST);
     float* partial = (float*)workspace;
     const int np = tmx * tmy * n;
     float* maps = grad_out ? partial + (((size_t)np + 63) / 64) * 64 : nullptr;
@@ -356,7 +418,7 @@ extern "C" int mmif_ssim_loss(const float* img1, const float* img2, const float*
                        loss_out);
     if (int rc = check_launch("ssim_finish")) return rc;
     if (grad_out) {
-        const int tx = cdiv(w, LT), ty = cdiv(h, LT);
+        const int tx = cdiv(w, ST), ty = cdiv(h, ST);
         const float scale = -weight * 0.5f / ((float)n * Hm * Wm);
         hipLaunchKernelGGL(ssim_grad_kernel, dim3(tx * ty, n), dim3(256), 0, st, img1, img2, imgf, h, w, win, maps, scale,
                            grad_out, tx);
