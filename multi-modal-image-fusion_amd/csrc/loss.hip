@@ -14,7 +14,6 @@ struct Win11 {
 
 constexpr int LT = 16;            // tile edge
 constexpr int WIN = 11;
-constexpr int LIN = LT + WIN - 1; // 26
 
 // ------------------------------------------------------------------ SSIM, pass 1
 // per map pixel: S(x1,f) + S(x2,f) (block partial) and the adjoint inputs

@@ -163,12 +163,13 @@ class FusedClipAdam(torch.optim.Optimizer):
         total = self._flat_p.numel()
         in_group = dist.is_available() and dist.is_initialized()
         world = dist.get_world_size() if in_group else 1
-        if scalars:
-            flat_g[total:total + len(scalars)] = torch.stack([s.detach().float().reshape(()) for s in scalars])
+        if scalars:   # straight into the tail of the flat buffer (one small launch)
+            torch.stack([s.detach().float().reshape(()) for s in scalars], out=flat_g[total:total + len(scalars)])
         if in_group:
             dist.all_reduce(flat_g)  # ONE collective: gradients + loss scalars (SUM); mean taken below
         if scalars:
-            self.reduced_scalars = flat_g[total:total + len(scalars)] / world
+            tail = flat_g[total:total + len(scalars)]
+            self.reduced_scalars = tail / world if world > 1 else tail.clone()
         g = self.param_groups[0]
         self._steps += 1
         p = lambda t: C.c_void_p(t.data_ptr())
