@@ -160,6 +160,31 @@ __device__ inline void load_grad_fold(const TV& t, int in, int c, int y, int x, 
 
 // block-wide sum of one float per thread (blockDim.x multiple of 64, <= 1024); result valid in
 // thread 0.  Deterministic for a fixed block size.
+// XCD-aware walk of `total` tiles by G persistent blocks (block b runs on XCD b % 8, each XCD has its own L2): XCD x owns the contiguous
+// band [x total/8, (x+1) total/8) and its G/8 blocks walk it side by side, so the halos that neighbouring tiles share are hits in that
+// XCD's L2.  (A plain b, b + G, b + 2G walk puts neighbouring tiles on different XCDs: the 18 x 18-tile kernels fetched 1.7x their
+// algorithmic bytes through the fabric, `profiles/r02_pmc_tcc_*`.)  Tiles of block b: first + i * stride, i < count.
+struct TileWalk {
+    int first, stride, count;
+};
+__device__ inline TileWalk xcd_walk(int total, int G, int b) {
+    TileWalk t;
+    if ((G & 7) == 0) {
+        const int xcd = b & 7, slot = b >> 3, nsl = G >> 3;
+        const int q8 = total >> 3, r8 = total & 7;
+        const int band0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+        const int blen = q8 + (xcd < r8 ? 1 : 0);
+        t.first = band0 + slot;
+        t.stride = nsl;
+        t.count = blen > slot ? (blen - slot + nsl - 1) / nsl : 0;
+    } else {
+        t.first = b;
+        t.stride = G;
+        t.count = b < total ? (total - b + G - 1) / G : 0;
+    }
+    return t;
+}
+
 __device__ inline float block_sum(float v, float* smem /* >= 16 floats */) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);

@@ -1386,8 +1386,9 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(TV tx, TV tg, float* __
             rg[i] = (inside && gcb0 + i < tg.cb) ? v : make_uint4(0, 0, 0, 0);
         }
     };
-    if (gi < total) prefetch(gi);
-    for (int tile = gi; tile < total; tile += G) {
+    const TileWalk tw = xcd_walk(total, G, gi);
+    if (tw.count > 0) prefetch(tw.first);
+    for (int it = 0, tile = tw.first; it < tw.count; ++it, tile += tw.stride) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
@@ -1413,7 +1414,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(TV tx, TV tg, float* __
             }
         }
         __syncthreads();
-        if (tile + G < total) prefetch(tile + G);  // in flight during the MFMAs below
+        if (it + 1 < tw.count) prefetch(tile + tw.stride);  // in flight during the MFMAs below
 #pragma unroll
         for (int ss = 0; ss < KSTEPS; ++ss) {
             const int s = km * KSTEPS + ss;
@@ -1551,7 +1552,8 @@ __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void wgrad_dma_kernel(TV
     if ((G & 7) == 0) { pair = (b >> 3) % npairs; gi = ((b >> 3) / npairs) * 8 + (b & 7); }   // blocks sharing tiles: same XCD
     else { pair = b % npairs; gi = b / npairs; }
     const int icg = pair % n_icg, ocg = pair / n_icg;
-    const int ntile = gi < total ? (total - gi + G - 1) / G : 0;
+    const TileWalk tw = xcd_walk(total, G, gi);   // (gi % 8 = the block's XCD when G is a multiple of 8)
+    const int ntile = tw.count;
 
     if (wave >= D_CONS) {
         // ---------------- loader waves ----------------
@@ -1628,12 +1630,12 @@ __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void wgrad_dma_kernel(TV
             *reinterpret_cast<uint2*>(dst) = make_uint2(out[0], out[1]);   // (columns past a ragged image edge land in the row's padding)
         };
         const bool signs = sgn.p != nullptr && ocg == 0;
-        if (ntile > 0) issue(gi, 0);
+        if (ntile > 0) issue(tw.first, 0);
         for (int k = 0; k < ntile; ++k) {
             __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's pieces of tile k have landed
             __builtin_amdgcn_s_barrier();
-            if (k + 1 < ntile) issue(gi + (k + 1) * G, (k & 1) ^ 1);
-            if (signs) emit_signs(gi + k * G, k & 1);
+            if (k + 1 < ntile) issue(tw.first + (k + 1) * tw.stride, (k & 1) ^ 1);
+            if (signs) emit_signs(tw.first + k * tw.stride, k & 1);
         }
         return;
     }
@@ -1829,7 +1831,8 @@ __global__ __launch_bounds__(512, NXB == 4 ? 1 : 2) void bwd_pair_kernel(TV tx, 
         }
     };
     // every wave runs this at the top of a tile: publish the prefetched tile, start the next prefetch (block-wide: two barriers)
-    auto stage = [&](int tile) {
+    const TileWalk tw = xcd_walk(total, G, gi);
+    auto stage = [&](int tile, int it) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < NXR; ++i) {
@@ -1842,16 +1845,16 @@ __global__ __launch_bounds__(512, NXB == 4 ? 1 : 2) void bwd_pair_kernel(TV tx, 
             if (e < NCB * BP_PL) s_g[e] = rg[i];
         }
         __syncthreads();
-        if (tile + G < total) prefetch(tile + G);
+        if (it + 1 < tw.count) prefetch(tile + tw.stride);
     };
-    if (gi < total) prefetch(gi);
+    if (tw.count > 0) prefetch(tw.first);
     float* red = reinterpret_cast<float*>(smem);
     // The three roles keep separate tile loops (same trip count, same barriers): their accumulators never share a live range, so the
     // kernel needs max(role) registers, not the sum.
     if (wave < 4) {
         // ---------------- dgrad: rows 4 wave .. 4 wave + 3 of every tile, all MF m-fragments
-        for (int tile = gi; tile < total; tile += G) {
-            stage(tile);
+        for (int it = 0, tile = tw.first; it < tw.count; ++it, tile += tw.stride) {
+            stage(tile, it);
             const int in_ = tile / tpi, tt = tile - in_ * tpi;
             const int ty0 = tt / tiles_x, tx0 = tt % tiles_x;
             f32x4 acc[MF][4];
@@ -1921,8 +1924,8 @@ __global__ __launch_bounds__(512, NXB == 4 ? 1 : 2) void bwd_pair_kernel(TV tx, 
             for (int b = 0; b < NXB; ++b)
 #pragma unroll
                 for (int m = 0; m < NGB; ++m) wacc[v][b][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int tile = gi; tile < total; tile += G) {
-            stage(tile);
+        for (int it = 0, tile = tw.first; it < tw.count; ++it, tile += tw.stride) {
+            stage(tile, it);
 #pragma unroll 2
             for (int s = 0; s < 8; ++s) {
                 const int row = 2 * s + (g >> 1), col0 = 8 * (g & 1);
@@ -1956,8 +1959,8 @@ __global__ __launch_bounds__(512, NXB == 4 ? 1 : 2) void bwd_pair_kernel(TV tx, 
         f32x4 accb[NGB];
 #pragma unroll
         for (int m = 0; m < NGB; ++m) accb[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int tile = gi; tile < total; tile += G) {
-            stage(tile);
+        for (int it = 0, tile = tw.first; it < tw.count; ++it, tile += tw.stride) {
+            stage(tile, it);
 #pragma unroll 2
             for (int s = 0; s < 8; ++s) {
                 const int row = 2 * s + (g >> 1), col0 = 8 * (g & 1);

@@ -80,37 +80,54 @@ __global__ __launch_bounds__(256, 2) void enc_wgrad_kernel(const float* __restri
     constexpr int NXR = (EW_NX * EW_XPL + 255) / 256;   // 8 x granules per thread per tile
     ew_u32x4 rx[NXR], rg[EW_NG];
     float ri[2];
-    // all prefetch loads are unconditional (clamped addresses, zero by select): nothing serialises them
+    // all prefetch loads are unconditional (clamped addresses, zero by select): nothing serialises them.  Address arithmetic in 32 bits from
+    // per-thread descriptors packed once (channel block << 16 | tile row << 8 | tile column): recomputing e / 324, e % 18 and three
+    // 64-bit products per load made the issue of a tile's 18 loads a 3.4 k-tick phase of its 14.8 k-tick period (`s_memtime` trace)
+    unsigned xpk[NXR], ipk[2];
+#pragma unroll
+    for (int i = 0; i < NXR; ++i) {
+        const int e = min(tid + 256 * i, EW_NX * EW_XPL - 1);
+        const int cb = e / EW_XPL, p = e - cb * EW_XPL;
+        xpk[i] = (unsigned)(cb << 16 | (p / EW_TP) << 8 | (p % EW_TP));
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int e = min(tid + 256 * i, EW_TP * EW_TP - 1);
+        ipk[i] = (unsigned)((e / EW_TP) << 8 | (e % EW_TP));
+    }
+    const unsigned xplane = (unsigned)tx.plane, gplane = (unsigned)tg.plane;   // (the host checks that an image stays below 2^31 granules)
+    const unsigned xcb0 = (unsigned)tx.cb_off * xplane, gcb0 = (unsigned)tg.cb_off * gplane;
     auto prefetch = [&](int tile) {
         const int in_ = tile / tpi, tt = tile - in_ * tpi;
         const int y0 = (tt / tiles_x) * EW_T, x0 = (tt % tiles_x) * EW_T;
+        const char* xb = tx.base + (long long)in_ * tx.img * 16;
+        const char* gb = tg.base + (long long)in_ * tg.img * 16;
 #pragma unroll
         for (int i = 0; i < NXR; ++i) {
-            const int e = min(tid + 256 * i, EW_NX * EW_XPL - 1);
-            const int cb = e / EW_XPL, p = e - cb * EW_XPL;
-            const int y = min(max(reflect_idx(y0 + p / EW_TP - 1, H), 0), H - 1);
-            const int x = min(max(reflect_idx(x0 + p % EW_TP - 1, W), 0), W - 1);
-            rx[i] = *reinterpret_cast<const ew_u32x4*>(tx.base + tx.gidx(in_, cb, y, x) * 16);
+            const int y = min(max(reflect_idx(y0 + (int)((xpk[i] >> 8) & 255u) - 1, H), 0), H - 1);
+            const int x = min(max(reflect_idx(x0 + (int)(xpk[i] & 255u) - 1, W), 0), W - 1);
+            const unsigned off = xcb0 + (xpk[i] >> 16) * xplane + (unsigned)(y + tx.halo) * (unsigned)tx.ws + (unsigned)(x + tx.halo);
+            rx[i] = *reinterpret_cast<const ew_u32x4*>(xb + (unsigned long long)off * 16u);
         }
         const int gy = y0 + tid / EW_T, gx = x0 + tid % EW_T;
         const bool inside = gy < H && gx < W;
-        const int cy = min(gy, H - 1) + tg.halo, cx = min(gx, W - 1) + tg.halo;
+        const unsigned goff = gcb0 + (unsigned)(min(gy, H - 1) + tg.halo) * (unsigned)tg.ws + (unsigned)(min(gx, W - 1) + tg.halo);
 #pragma unroll
         for (int i = 0; i < EW_NG; ++i) {
-            const ew_u32x4 v = *reinterpret_cast<const ew_u32x4*>(tg.base + tg.gidx(in_, i, cy, cx) * 16);
+            const ew_u32x4 v = *reinterpret_cast<const ew_u32x4*>(gb + (unsigned long long)(goff + i * gplane) * 16u);
             rg[i] = inside ? v : (ew_u32x4){0u, 0u, 0u, 0u};
         }
         const float* im = img + (long long)in_ * H * W;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int e = min(tid + 256 * i, EW_TP * EW_TP - 1);
-            const int y = min(max(reflect_idx(y0 + e / EW_TP - 1, H), 0), H - 1);
-            const int x = min(max(reflect_idx(x0 + e % EW_TP - 1, W), 0), W - 1);
-            ri[i] = im[(long long)y * W + x];
+            const int y = min(max(reflect_idx(y0 + (int)(ipk[i] >> 8) - 1, H), 0), H - 1);
+            const int x = min(max(reflect_idx(x0 + (int)(ipk[i] & 255u) - 1, W), 0), W - 1);
+            ri[i] = im[(unsigned)(y * W + x)];
         }
     };
-    if (gi < total) prefetch(gi);
-    for (int tile = gi; tile < total; tile += G) {
+    const TileWalk tw = xcd_walk(total, G, gi);
+    if (tw.count > 0) prefetch(tw.first);
+    for (int it = 0, tile = tw.first; it < tw.count; ++it, tile += tw.stride) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < NXR; ++i) {
@@ -125,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void enc_wgrad_kernel(const float* __restri
             if (e < EW_TP * EW_TP) s_img[e] = ri[i];
         }
         __syncthreads();
-        if (tile + G < total && !(EW_ABL & 4)) prefetch(tile + G);   // in flight during the MFMAs below
+        if (it + 1 < tw.count && !(EW_ABL & 4)) prefetch(tile + tw.stride);   // in flight during the MFMAs below
         if (wave < 3 && !(EW_ABL & 1)) {
             const int u = wave;
             // 8 k-steps x 3 tap columns = 24 groups of (3 activation fragments -> 6 MFMAs); the fragments of group i + 1 (and the three
@@ -294,8 +311,9 @@ __global__ __launch_bounds__(256, 2) void taprow_wgrad_kernel(TV tx, TV tg, floa
             rg[i] = inside ? v : (ew_u32x4){0u, 0u, 0u, 0u};
         }
     };
-    if (gi < total) prefetch(gi);
-    for (int tile = gi; tile < total; tile += G) {
+    const TileWalk tw = xcd_walk(total, G, gi);
+    if (tw.count > 0) prefetch(tw.first);
+    for (int it = 0, tile = tw.first; it < tw.count; ++it, tile += tw.stride) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < NXR; ++i) {
@@ -305,7 +323,7 @@ __global__ __launch_bounds__(256, 2) void taprow_wgrad_kernel(TV tx, TV tg, floa
 #pragma unroll
         for (int i = 0; i < 2 * NGB; ++i) s_g[i * EW_GPL + tid] = rg[i];
         __syncthreads();
-        if (tile + G < total) prefetch(tile + G);
+        if (it + 1 < tw.count) prefetch(tile + tw.stride);
         if (wave < 3) {
             const int u = wave;
 #pragma unroll 2
@@ -474,6 +492,8 @@ extern "C" int mmif_dense_encoder_wgrad(const float* img, const mmif_tensor* x, 
     MMIF_REQUIRE(gz->cb == 8 && (gz->halo == 0 || (gz->flags & MMIF_T_FOLDED)), "dense_encoder_wgrad: gz must be an 8-block view, halo 0 or folded");
     MMIF_REQUIRE(x->n == gz->n && x->h == gz->h && x->w == gz->w, "dense_encoder_wgrad: x / gz mismatch");
     MMIF_REQUIRE(x->h >= 2 && x->w >= 2, "reflect padding needs h,w >= 2");
+    MMIF_REQUIRE((long long)x->cb_total * x->h * x->w < (1ll << 31) && (long long)gz->cb_total * (gz->h + 2) * (gz->w + 2) < (1ll << 31),
+                 "dense_encoder_wgrad: one image of x / gz must stay below 2^31 granules (32-bit tile offsets)");
     if (workspace == nullptr || workspace_bytes < mmif_dense_encoder_wgrad_workspace()) {
         set_error("dense_encoder_wgrad: workspace too small");
         return MMIF_EWORKSPACE;
