@@ -208,6 +208,14 @@ int mmif_conv2d_reflect_dgrad(const mmif_tensor* gy, const float* w, const void*
 int mmif_conv2d_reflect_dgrad_folded(const mmif_tensor* gy, const float* w, const void* w_packed_t, const mmif_tensor* x,
                                      const mmif_tensor* gx, int32_t cin, int32_t cout, int32_t ksize,
                                      uint64_t mask_bits, uint64_t accum_bits, int32_t impl, void* stream);
+/* The same with the accumulate operand taken from ANOTHER tensor: gx = [mask] (fold(dgrad(gy)) + gx_old) on the blocks in accum_bits.
+ * gx_old: gx's shape / halo / channel blocks, folded.  bf16 thin layers only (the asynchronous kernel): ask
+ * mmif_conv2d_dgrad_onto_supported first.  Use: DenseFuse / VIFNet, where both encoder branches start from the ONE gradient of
+ * f1 + f2 (core/fusion.py:21-29 'sum') -- no per-branch copy of it. */
+int mmif_conv2d_dgrad_onto_supported(const mmif_tensor* gy, const mmif_tensor* gx, int32_t cin, int32_t cout, int32_t ksize);
+int mmif_conv2d_reflect_dgrad_folded_onto(const mmif_tensor* gy, const void* w_packed_t, const mmif_tensor* x, const mmif_tensor* gx_old,
+                                          const mmif_tensor* gx, int32_t cin, int32_t cout, int32_t ksize, uint64_t mask_bits,
+                                          uint64_t accum_bits, void* stream);
 /* dw[cout][cin][k][k] (=|+=) sum_p fold(gy)[p] * reflect_pad(x)[p+tap]; db[cout] (=|+=) sum_p fold(gy)[p].
  * replaces convolution_backward(weight, bias). */
 size_t mmif_conv2d_wgrad_workspace(int32_t cin, int32_t cout, int32_t ksize);

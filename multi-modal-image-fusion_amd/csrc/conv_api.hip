@@ -13,7 +13,8 @@ int wgrad_valu(int dtype, int ks, const TV& tx, const TV& tg, float* dw, float* 
 bool conv_mfma_supported(bool dgrad, int ks, int cin, int cout);
 int conv_mfma(bool dgrad, int ks, const TV& tin, const TV& tout, const TV& tmask, const void* w_packed, const float* bias,
               int cin, int cout, int relu, uint64_t mask_bits, uint64_t accum_bits, hipStream_t st, bool fold = false,
-              bool* folded = nullptr);
+              bool* folded = nullptr, const TV* told = nullptr);
+bool conv_dgrad_onto_supported(int ks, int cin, int cout, const TV& tin, const TV& tout);
 bool wgrad_mfma_supported(int ks, int cin, int cout);
 size_t wgrad_mfma_workspace(int cin, int cout, int ks);
 int wgrad_mfma(int ks, const TV& tx, const TV& tg, float* dw, float* db, int cin, int cout, int accumulate, float* ws,
@@ -64,7 +65,7 @@ extern "C" int mmif_conv2d_reflect_fwd(const mmif_tensor* x, const float* w, con
 
 static int dgrad_impl(const char* what, const mmif_tensor* gy, const float* w, const void* w_packed_t, const mmif_tensor* x,
                       const mmif_tensor* gx, int32_t cin, int32_t cout, int32_t ksize, uint64_t mask_bits, uint64_t accum_bits,
-                      int32_t impl, void* stream, bool fold) {
+                      int32_t impl, void* stream, bool fold, const mmif_tensor* gx_old = nullptr) {
     if (int rc = validate_tensor(gy, "gy")) return rc;
     if (int rc = validate_tensor(gx, "gx")) return rc;
     MMIF_REQUIRE(ksize == 1 || ksize == 3, "%s: ksize must be 1 or 3 (got %d)", what, ksize);
@@ -84,8 +85,18 @@ static int dgrad_impl(const char* what, const mmif_tensor* gy, const float* w, c
     if (im < 0) return MMIF_EINVAL;
     bool folded = false;
     int rc;
+    TV told;
+    if (gx_old != nullptr) {
+        if (int rc2 = validate_tensor(gx_old, "gx_old")) return rc2;
+        MMIF_REQUIRE(gx_old->dtype == gx->dtype && gx_old->n == gx->n && gx_old->h == gx->h && gx_old->w == gx->w && gx_old->halo == gx->halo &&
+                         gx_old->cb == gx->cb,
+                     "%s: gx_old must have gx's shape, halo and channel blocks", what);
+        MMIF_REQUIRE(im == MMIF_IMPL_MFMA && fold, "%s: gx_old needs the folded MFMA path", what);
+        told = make_tv(gx_old);
+    }
     if (im == MMIF_IMPL_MFMA) {
-        rc = conv_mfma(true, ksize, tg, tgx, tm, w_packed_t, nullptr, cin, cout, 0, mask_bits, accum_bits, (hipStream_t)stream, fold, &folded);
+        rc = conv_mfma(true, ksize, tg, tgx, tm, w_packed_t, nullptr, cin, cout, 0, mask_bits, accum_bits, (hipStream_t)stream, fold, &folded,
+                       gx_old != nullptr ? &told : nullptr);
     } else {
         MMIF_REQUIRE(w != nullptr, "%s: VALU path needs the fp32 master weights", what);
         rc = conv_valu(true, gy->dtype, ksize, tg, tgx, tm, w, nullptr, cin, cout, 0, mask_bits, accum_bits, (hipStream_t)stream);
@@ -104,6 +115,21 @@ extern "C" int mmif_conv2d_reflect_dgrad_folded(const mmif_tensor* gy, const flo
                                                 const mmif_tensor* gx, int32_t cin, int32_t cout, int32_t ksize, uint64_t mask_bits,
                                                 uint64_t accum_bits, int32_t impl, void* stream) {
     return dgrad_impl("conv2d_reflect_dgrad_folded", gy, w, w_packed_t, x, gx, cin, cout, ksize, mask_bits, accum_bits, impl, stream, true);
+}
+
+// gx = fold(dgrad(gy)) + gx_old on the channel blocks in accum_bits (plain on the others), masked by mask_bits: the accumulate operand
+// comes from ANOTHER tensor (DenseFuse / VIFNet: both encoder branches start from the one gradient of f1 + f2 -- no per-branch copy).
+extern "C" int mmif_conv2d_dgrad_onto_supported(const mmif_tensor* gy, const mmif_tensor* gx, int32_t cin, int32_t cout, int32_t ksize) {
+    if (validate_tensor(gy, "gy") != MMIF_OK || validate_tensor(gx, "gx") != MMIF_OK) return 0;
+    if (gy->dtype != MMIF_BF16 || gx->dtype != MMIF_BF16 || gy->halo != 1 || !(gy->flags & MMIF_T_FOLDED) || gx->halo != 1) return 0;
+    return conv_dgrad_onto_supported(ksize, cin, cout, make_tv(gy), make_tv(gx)) ? 1 : 0;
+}
+extern "C" int mmif_conv2d_reflect_dgrad_folded_onto(const mmif_tensor* gy, const void* w_packed_t, const mmif_tensor* x, const mmif_tensor* gx_old,
+                                                     const mmif_tensor* gx, int32_t cin, int32_t cout, int32_t ksize, uint64_t mask_bits,
+                                                     uint64_t accum_bits, void* stream) {
+    MMIF_REQUIRE(gx_old != nullptr && w_packed_t != nullptr, "conv2d_reflect_dgrad_folded_onto: NULL gx_old / operand image");
+    return dgrad_impl("conv2d_reflect_dgrad_folded_onto", gy, nullptr, w_packed_t, x, gx, cin, cout, ksize, mask_bits, accum_bits, MMIF_IMPL_MFMA,
+                      stream, true, gx_old);
 }
 
 extern "C" size_t mmif_conv2d_wgrad_workspace(int32_t cin, int32_t cout, int32_t ksize) {

@@ -165,7 +165,8 @@ template <int MF, bool DGRAD, bool LM = false>
 __device__ inline void conv_epilogue(const f32x4 (&acc)[MF][4], const TV& tout, const TV& tmask, const float* s_bias, int mb, int in_,
                                      int oxs, int oys0, int g, int relu, unsigned long long mask_bits, unsigned long long accum_bits,
                                      int xlim, int ylim,   // stored columns / rows >= xlim / ylim are not written
-                                     const unsigned char* lmask = nullptr, int lrow0 = 0, int lcol = 0) {
+                                     const unsigned char* lmask = nullptr, int lrow0 = 0, int lcol = 0,
+                                     const TV* told = nullptr /* dgrad: accumulate ONTO this tensor's values instead of tout's (same n, h, w, halo) */) {
     // lmask (conv_dma_kernel dgrad): the ReLU-mask SIGN BITS of this tile, one byte per (channel block, tile row, tile column),
     // staged into LDS by the loader waves ahead of time; lrow0 / lcol = this lane's first tile row / its column
     if (oxs >= xlim) return;
@@ -189,6 +190,10 @@ __device__ inline void conv_epilogue(const f32x4 (&acc)[MF][4], const TV& tout, 
             const int ocb = (mb * MF + m) * 2 + (g >> 1);
             const bool blk_ok = ocb < tout.cb;
             const char* oplane = tout.base + ((long long)in_ * tout.img + (long long)(tout.cb_off + min(ocb, tout.cb - 1)) * tout.plane) * 16 + pix_off;
+            if (told != nullptr)
+                oplane = told->base + ((long long)in_ * told->img + (long long)(told->cb_off + min(ocb, told->cb - 1)) * told->plane) * 16 +
+                         (unsigned)(oys0 * told->ws + oxs) * 16u;
+            const unsigned old_row_bytes = told != nullptr ? (unsigned)told->ws * 16u : row_bytes;
             const char* mplane = tmask.base + ((long long)in_ * tmask.img + (long long)(tmask.cb_off + min(ocb, tmask.cb - 1)) * tmask.plane) * 16 + mpix_off;
             const bool do_acc = (accum_bits >> ocb) & 1ull, do_mask = (mask_bits >> ocb) & 1ull;
 #pragma unroll
@@ -197,7 +202,7 @@ __device__ inline void conv_epilogue(const f32x4 (&acc)[MF][4], const TV& tout, 
                 if (!LM) xmv[m][p2] = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);   // 1.0: mask passes
                 const int oys = oys0 + 2 * p2;
                 if (blk_ok && oys < ylim) {
-                    if (do_acc) oldv[m][p2] = *reinterpret_cast<const uint4*>(oplane + (2 * p2) * row_bytes);
+                    if (do_acc) oldv[m][p2] = *reinterpret_cast<const uint4*>(oplane + (2 * p2) * old_row_bytes);
                     if (do_mask && !LM) {
                         const int y = min(max(reflect_idx(oys - tout.halo, tmask.h), 0), tmask.h - 1);
                         xmv[LM ? 0 : m][p2] = *reinterpret_cast<const uint4*>(mplane + (unsigned)(y * tmask.ws) * 16u);
@@ -1138,7 +1143,7 @@ __device__ inline void tn_wait_counter(volatile unsigned* ctr, unsigned target) 
 template <int MF, bool DGRAD>
 __global__ __launch_bounds__((4 * TN_GROUPS + TN_LOAD) * 64, 4) void thin_conv_async_kernel(
     TV tin, TV tout, TV tmask, const uint4* __restrict__ wpk, const float* __restrict__ bias, int n_out, int relu,
-    unsigned long long mask_bits, unsigned long long accum_bits, int tiles_x, int tiles_y, int ntiles, int org) {
+    unsigned long long mask_bits, unsigned long long accum_bits, int tiles_x, int tiles_y, int ntiles, int org, TV told, int use_old) {
     constexpr int TP = MT + 2;   // org: as in conv_dma_kernel (dgrad over the interior of the padded domain, fold steps in the border tiles)
     constexpr int NCONS = 4 * TN_GROUPS;
     __shared__ __attribute__((aligned(16))) char s_in[tn_ring_bytes(MF)];
@@ -1303,7 +1308,7 @@ __global__ __launch_bounds__((4 * TN_GROUPS + TN_LOAD) * 64, 4) void thin_conv_a
         __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) atomicAdd(&s_done[k % NS], 1u);
         conv_epilogue<MF, DGRAD>(acc, tout, tmask, s_bias, 0, in_, org + tx0 * MT + j, org + ty0 * MT + r * 4 + (g & 1), g, relu, mask_bits,
-                                 accum_bits, tout.ws - org, tout.hs - org);
+                                 accum_bits, tout.ws - org, tout.hs - org, nullptr, 0, 0, (DGRAD && use_old) ? &told : nullptr);
     }
 }
 
@@ -2103,8 +2108,29 @@ static int launch_conv_dma(bool dgrad, const TV& tin, const TV& tout, const TV& 
 
 // fold (dgrad only): the caller wants fold_halo(gx) applied as well and guarantees that gx's halo ring is zero on entry; *folded
 // reports whether the kernel chosen did it (interior tiles + fold steps, ring left zero) -- otherwise the caller runs the fold kernel.
+static bool thin_async_ok(bool dgrad, int ks, int mf, const TV& tin, const TV& tout, int org) {
+    if (!(g_dma_mode == 1 && ks == 3 && mf <= 3 && (dgrad || mf >= 2) && tin.cb <= TN_MAXCB && (!dgrad || (tin.halo == 1 && tin.folded)) &&
+          tin.plane * 16 * TN_MAXCB < (1ll << 31)))
+        return false;
+    const int tiles_x = cdiv(tout.ws - 2 * org, MT), tiles_y = cdiv(tout.hs - 2 * org, MT);
+    const long long ntiles = (long long)tiles_x * tiles_y * tout.n;
+    const int P = cdiv(cdiv(tin.cb * TN_PL, 64), TN_LOAD), slot_bytes = P * TN_LOAD * 1024;
+    int G = num_cus_() / 8 * 8;
+    if (G < 8) G = 8;
+    return tn_ring_bytes(mf) / slot_bytes >= TN_GROUPS + 1 && ntiles >= 2ll * G && ntiles < (1ll << 31);
+}
+bool conv_dgrad_onto_supported(int ks, int cin, int cout, const TV& tin, const TV& tout) {
+    (void)cout;
+    init_modes();
+    const int org = (ks == 3 && g_fuse_fold == 1 && tout.halo == 1 && tout.h >= 4 && tout.w >= 4) ? 1 : 0;
+    return org == 1 && thin_async_ok(true, ks, pick_mf(cin), tin, tout, org);
+}
+
+// told (dgrad): accumulate onto THAT tensor's values instead of tout's own; only the thin asynchronous kernel implements it -- the
+// call fails (MMIF_EINVAL) when the layer / shape would take another kernel (conv_dgrad_onto_supported tells beforehand)
+bool conv_dgrad_onto_supported(int ks, int cin, int cout, const TV& tin, const TV& tout);
 int conv_mfma(bool dgrad, int ks, const TV& tin, const TV& tout, const TV& tmask, const void* w_packed, const float* bias,
-              int cin, int cout, int relu, uint64_t mask_bits, uint64_t accum_bits, hipStream_t st, bool fold, bool* folded) {
+              int cin, int cout, int relu, uint64_t mask_bits, uint64_t accum_bits, hipStream_t st, bool fold, bool* folded, const TV* told) {
     if (folded != nullptr) *folded = false;
     const int n_out = dgrad ? cin : cout;
     const int mf = pick_mf(n_out);
@@ -2114,6 +2140,10 @@ int conv_mfma(bool dgrad, int ks, const TV& tin, const TV& tout, const TV& tmask
     if (g_dma_mode == 1 && ks == 3 && mf == 4 && (!dgrad || (tin.halo == 1 && tin.folded)) &&
         tin.plane * 16 * CHUNK_CB < (1ll << 31))
     {
+        if (told != nullptr) {
+            set_error("conv dgrad: accumulate-onto-another-tensor is only implemented by the thin asynchronous kernel");
+            return MMIF_EINVAL;
+        }
         if (org) *folded = true;
         return launch_conv_dma(dgrad, tin, tout, tmask, w_packed, bias, n_out, relu, mask_bits, accum_bits, org, st);
     }
@@ -2121,31 +2151,34 @@ int conv_mfma(bool dgrad, int ks, const TV& tin, const TV& tout, const TV& tmask
     // channels, a ring of at least TN_GROUPS + 1 tile slots, at least two tiles per persistent block).  Measured (B=32 256x256,
     // vs conv_mfma_kernel<3,MF>): every dgrad -13 .. -21 %, forward with 32 / 48 outputs -14 % / -30 %; forward with 16 outputs
     // is +3 .. +16 % (the register-staged kernel runs 4 blocks per SIMD there), so that case stays on the old kernel.
-    if (g_dma_mode == 1 && ks == 3 && mf <= 3 && (dgrad || mf >= 2) && tin.cb <= TN_MAXCB &&
-        (!dgrad || (tin.halo == 1 && tin.folded)) &&
-        tin.plane * 16 * TN_MAXCB < (1ll << 31)) {
+    if (thin_async_ok(dgrad, ks, mf, tin, tout, org)) {
         const int tiles_x = cdiv(tout.ws - 2 * org, MT), tiles_y = cdiv(tout.hs - 2 * org, MT);
         const long long ntiles = (long long)tiles_x * tiles_y * tout.n;
-        const int P = cdiv(cdiv(tin.cb * TN_PL, 64), TN_LOAD), slot_bytes = P * TN_LOAD * 1024;
         int G = num_cus_() / 8 * 8;
         if (G < 8) G = 8;
-        if (tn_ring_bytes(mf) / slot_bytes >= TN_GROUPS + 1 && ntiles >= 2ll * G && ntiles < (1ll << 31)) {
+        {
+            const TV told_v = told != nullptr ? *told : tout;
+            const int use_old = told != nullptr ? 1 : 0;
 #define TGO(MF_)                                                                                                                       \
     do {                                                                                                                               \
         if (dgrad)                                                                                                                     \
             hipLaunchKernelGGL((thin_conv_async_kernel<MF_, true>), dim3(G), dim3((4 * TN_GROUPS + TN_LOAD) * 64), 0, st, tin, tout,   \
                                tmask, (const uint4*)w_packed, bias, n_out, relu, (unsigned long long)mask_bits,                       \
-                               (unsigned long long)accum_bits, tiles_x, tiles_y, (int)ntiles, org);                                   \
+                               (unsigned long long)accum_bits, tiles_x, tiles_y, (int)ntiles, org, told_v, use_old);                  \
         else                                                                                                                           \
             hipLaunchKernelGGL((thin_conv_async_kernel<MF_, false>), dim3(G), dim3((4 * TN_GROUPS + TN_LOAD) * 64), 0, st, tin, tout,  \
                                tmask, (const uint4*)w_packed, bias, n_out, relu, (unsigned long long)mask_bits,                       \
-                               (unsigned long long)accum_bits, tiles_x, tiles_y, (int)ntiles, 0);                                     \
+                               (unsigned long long)accum_bits, tiles_x, tiles_y, (int)ntiles, 0, told_v, 0);                          \
         if (org) *folded = true;                                                                                                       \
         return check_launch(dgrad ? "thin_conv_async dgrad" : "thin_conv_async fwd");                                                 \
     } while (0)
             switch (mf) { case 1: TGO(1); case 2: TGO(2); default: TGO(3); }
 #undef TGO
         }
+    }
+    if (told != nullptr) {
+        set_error("conv dgrad: accumulate-onto-another-tensor is only implemented by the thin asynchronous kernel (this layer / shape takes another)");
+        return MMIF_EINVAL;
     }
 #define GO(KS_, MF_) return launch_conv_mfma<KS_, MF_>(dgrad, tin, tout, tmask, w_packed, bias, n_out, relu, mask_bits, accum_bits, st)
     if (ks == 3) {

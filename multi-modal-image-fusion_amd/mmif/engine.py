@@ -396,8 +396,10 @@ class DenseEncoderMixin:
         return cached[1]
 
     @staticmethod
-    def enc_bwd(specs, img, F, GF, fbase, gbase, ws, impl, accumulate_w=False):
-        """GF[gbase:gbase+8] holds dL/d(encoder output) (padded domain), top 2 blocks already masked."""
+    def enc_bwd(specs, img, F, GF, fbase, gbase, ws, impl, accumulate_w=False, onto=None):
+        """GF[gbase:gbase+8] holds dL/d(encoder output) (padded domain), top 2 blocks already masked.
+        onto (8-block folded view): blocks 0..5 of GF are NOT initialised -- the chain adds its contributions to onto's blocks
+        instead and writes the sums to GF (DenseFuse / VIFNet: both branches start from the one gradient of f1 + f2)."""
         first, c0, c1, c2 = specs
         GF = GF.as_folded()   # every contribution so far has been folded; each dgrad below re-folds what it adds
         # bf16 / MFMA: the four layers' weight gradients in ONE pass over [x0 | x1 | x2] and the finished [g0 | g1 | g2 | g3]
@@ -411,8 +413,12 @@ class DenseEncoderMixin:
         if gather:
             pk = DenseEncoderMixin.chain_images(specs)
             for k in (2, 1, 0):
-                ModelEngine.tag_dgrad(GF.view(gbase + 2 * (k + 1), 2 * (3 - k)), F.view(fbase + 2 * k, 2), GF.view(gbase + 2 * k, 2),
-                                      16, 16 * (3 - k), pk[k], f"{first.name}.chain{k}:dgrad")
+                gy, xk, dst = GF.view(gbase + 2 * (k + 1), 2 * (3 - k)), F.view(fbase + 2 * k, 2), GF.view(gbase + 2 * k, 2)
+                if onto is not None:
+                    T.conv_dgrad_onto(gy, xk, onto.view(2 * k, 2), dst, 16, 16 * (3 - k), 3, all_bits(2), all_bits(2), pk[k],
+                                      f"{first.name}.chain{k}:dgrad")
+                else:
+                    ModelEngine.tag_dgrad(gy, xk, dst, 16, 16 * (3 - k), pk[k], f"{first.name}.chain{k}:dgrad")
         for s, nin in ((c2, 6), (c1, 4), (c0, 2)):
             g = GF.view(gbase + nin, 2)
             x = F.view(fbase, nin)
@@ -587,10 +593,26 @@ class DenseFuseEngine(ModelEngine, DenseEncoderMixin):
         # ReLU mask only on the DenseBlock's last conv output (blocks 6,7), the rest are masked by
         # their last contributor inside enc_bwd
         GF = self.buf(L, "GF", n, 128, h, w, dtype, dev, halo=1)
+        if self.share_fused_grad(g, GF, dtype, impl):
+            # 'sum' fusion: d(f1 + f2) IS each branch's gradient.  Only the masked top blocks (6,7 / 14,15) are materialised per branch;
+            # the chain reads the lower blocks' starting values straight from g ($MMIF_FUSE_SHARE=0: copy them per branch first)
+            T.fuse_elem_bwd(F.view(6, 2), F.view(14, 2), g.view(6, 2), GF.view(6, 2), GF.view(14, 2), self.fusion_mode, True)
+            self.enc_bwd(self.enc, img1, F, GF, 0, 0, ws, impl, accumulate_w=False, onto=g)
+            self.enc_bwd(self.enc, img2, F, GF, 8, 8, ws, impl, accumulate_w=True, onto=g)
+            return grads
         self.fusion_bwd(L, F, g, GF, ws)
         self.enc_bwd(self.enc, img1, F, GF, 0, 0, ws, impl, accumulate_w=False)
         self.enc_bwd(self.enc, img2, F, GF, 8, 8, ws, impl, accumulate_w=True)
         return grads
+
+    def share_fused_grad(self, g, GF, dtype, impl):
+        specs = self.enc
+        hot = (dtype == torch.bfloat16 and impl != _lib.IMPL_VALU and all(s.k == 3 for s in specs)
+               and [(s.cin, s.cout) for s in specs] == [(1, 16), (16, 16), (32, 16), (48, 16)])
+        return (hot and type(self).fusion_bwd is DenseFuseEngine.fusion_bwd and self.fusion_mode == _lib.FUSE_SUM
+                and os.environ.get("MMIF_ENC_CHAIN", "1") != "0" and os.environ.get("MMIF_FUSE_SHARE", "1") != "0"
+                and all(T.dgrad_onto_supported(GF.as_folded().view(2 * (k + 1), 2 * (3 - k)), GF.view(2 * k, 2), 16, 16 * (3 - k), 3)
+                        for k in (2, 1, 0)))
 
     def fusion_fwd(self, L, F, out):
         T.fuse_elem_fwd(F.view(0, 8), F.view(8, 8), out, self.fusion_mode)

@@ -159,6 +159,19 @@ def conv_dgrad(gy, w, x, gx, cin, cout, k, mask_bits=0, accum_bits=0, packed=Non
     return gx.as_folded() if fold else gx
 
 
+def dgrad_onto_supported(gy, gx, cin, cout, k):
+    return bool(lib.mmif_conv2d_dgrad_onto_supported(gy.d, gx.d, cin, cout, k))
+
+
+def conv_dgrad_onto(gy, x, gx_old, gx, cin, cout, k, mask_bits, accum_bits, packed, tag=None):
+    """gx = [mask](fold(dgrad(gy)) + gx_old) on the blocks in accum_bits: the accumulate operand comes from another tensor; returns the
+    folded gx view (gx's halo ring must be zero on entry)"""
+    with _timed(tag, (gy.n, gy.h, gy.w, cin, cout, k)):
+        check(lib.mmif_conv2d_reflect_dgrad_folded_onto(gy.d, _ptr(packed.dgrad), x.d if x is not None else None, gx_old.d, gx.d, cin, cout, k,
+                                                        mask_bits, accum_bits, stream_ptr()), "conv2d_reflect_dgrad_folded_onto")
+    return gx.as_folded()
+
+
 def conv_wgrad(x, gy, dw, db, cin, cout, k, ws, accumulate=False, impl=_lib.IMPL_AUTO, tag=None):
     with _timed(tag, (x.n, x.h, x.w, cin, cout, k)):
         check(lib.mmif_conv2d_reflect_wgrad(x.d, gy.d, _ptr(dw), _ptr(db), cin, cout, k, int(accumulate), _ptr(ws),

@@ -255,3 +255,29 @@ def test_fused_encoder_paths_vs_layerwise_all_models_and_modes():
                     assert float((a - b).abs().max()) <= 2e-2 * scale, (name, single, k, float((a - b).abs().max()) / scale)
                 else:
                     assert torch.equal(a, b), (name, single, k)
+
+
+def test_densefuse_shared_fused_gradient_is_bit_identical():
+    """'sum' fusion: the per-branch copies of d(f1 + f2) are replaced by the chain reading its accumulate operand from the shared
+    gradient (mmif_conv2d_reflect_dgrad_folded_onto); $MMIF_FUSE_SHARE=0 restores the copies -- same bits either way"""
+    import os
+    import core.model as M
+    from gpu_util import DEV, dtype_ctx
+    with dtype_ctx("bf16"):
+        torch.manual_seed(3)
+        m = M.DenseFuse().to(DEV)
+        g = torch.Generator().manual_seed(4)
+        for shape in ((8, 1, 128, 128), (2, 1, 45, 70)):     # the second one is too small for the asynchronous kernel: falls back by itself
+            i1, i2 = torch.rand(*shape, generator=g).to(DEV), torch.rand(*shape, generator=g).to(DEV)
+            res = []
+            for flag in ("0", "1"):
+                os.environ["MMIF_FUSE_SHARE"] = flag
+                try:
+                    m.zero_grad(set_to_none=True)
+                    m(i1, i2).square().mean().backward()
+                    torch.cuda.synchronize()
+                    res.append({k: p.grad.clone() for k, p in m.named_parameters()})
+                finally:
+                    os.environ.pop("MMIF_FUSE_SHARE", None)
+            for k in res[0]:
+                assert torch.equal(res[0][k], res[1][k]), f"{shape} {k}"
