@@ -178,6 +178,8 @@ extern "C" int mmif_conv2d_reflect_bwd_pair(const mmif_tensor* gy, const void* w
     MMIF_REQUIRE(gy->n == x->n && gy->h == x->h && gy->w == x->w && gx->n == x->n && gx->h == x->h && gx->w == x->w, "conv2d_reflect_bwd_pair: shape mismatch");
     MMIF_REQUIRE((cin + 7) / 8 == x->cb && x->cb == gx->cb && (cout + 7) / 8 == gy->cb, "conv2d_reflect_bwd_pair: channel blocks do not match");
     MMIF_REQUIRE(x->h >= 4 && x->w >= 4, "conv2d_reflect_bwd_pair: needs h, w >= 4 (fold steps inside the border tiles)");
+    MMIF_REQUIRE((long long)x->cb_total * x->h * x->w < (1ll << 31) && (long long)gy->cb_total * (gy->h + 2) * (gy->w + 2) < (1ll << 31),
+                 "conv2d_reflect_bwd_pair: one image of x / gy must stay below 2^31 granules (32-bit tile offsets)");
     if (workspace == nullptr || workspace_bytes < bwd_pair_workspace(cin, cout)) {
         set_error("conv2d_reflect_bwd_pair: workspace too small");
         return MMIF_EWORKSPACE;

@@ -1814,24 +1814,41 @@ __global__ __launch_bounds__(512, NXB == 4 ? 1 : 2) void bwd_pair_kernel(TV tx, 
     };
     constexpr int NXR = (2 * NXB * BP_PL + 511) / 512, NGR = (NCB * BP_PL + 511) / 512;
     u32x4 rx[NXR], rg[NGR];
+    // tile-independent part of every staged granule's address, packed once (channel block << 16 | tile row << 8 | tile column);
+    // 32-bit offsets per tile (see enc_wgrad_kernel: e / 324, e % 18 and 64-bit products per load were a phase of their own)
+    unsigned xpk[NXR], gpk[NGR];
+#pragma unroll
+    for (int i = 0; i < NXR; ++i) {
+        const int e = min(tid + 512 * i, 2 * NXB * BP_PL - 1);
+        const int cb = e / BP_PL, p = e - cb * BP_PL;
+        xpk[i] = (unsigned)(cb << 16 | (p / TP) << 8 | (p % TP));
+    }
+#pragma unroll
+    for (int i = 0; i < NGR; ++i) {
+        const int e = min(tid + 512 * i, NCB * BP_PL - 1);
+        const int cb = e / BP_PL, p = e - cb * BP_PL;
+        gpk[i] = (unsigned)(cb << 16 | (p / TP) << 8 | (p % TP));
+    }
+    const unsigned xplane = (unsigned)tx.plane, gplane = (unsigned)tg.plane;   // (conv_api.hip: an image stays below 2^31 granules)
+    const unsigned xcb0 = (unsigned)tx.cb_off * xplane, gcb0 = (unsigned)tg.cb_off * gplane;
     auto prefetch = [&](int tile) {
         const int in_ = tile / tpi, tt = tile - in_ * tpi;
         const int y0 = (tt / tiles_x) * MT, x0 = (tt % tiles_x) * MT;
+        const char* xb = tx.base + (long long)in_ * tx.img * 16;
+        const char* gb = tg.base + (long long)in_ * tg.img * 16;
 #pragma unroll
         for (int i = 0; i < NXR; ++i) {
-            const int e = min(tid + 512 * i, 2 * NXB * BP_PL - 1);
-            const int cb = e / BP_PL, p = e - cb * BP_PL;
-            const int y = min(max(reflect_idx(y0 + p / TP - 1, H), 0), H - 1);
-            const int x = min(max(reflect_idx(x0 + p % TP - 1, W), 0), W - 1);
-            rx[i] = *reinterpret_cast<const u32x4*>(tx.base + tx.gidx(in_, cb, y, x) * 16);
+            const int y = min(max(reflect_idx(y0 + (int)((xpk[i] >> 8) & 255u) - 1, H), 0), H - 1);
+            const int x = min(max(reflect_idx(x0 + (int)(xpk[i] & 255u) - 1, W), 0), W - 1);
+            const unsigned off = xcb0 + (xpk[i] >> 16) * xplane + (unsigned)(y + tx.halo) * (unsigned)tx.ws + (unsigned)(x + tx.halo);
+            rx[i] = *reinterpret_cast<const u32x4*>(xb + (unsigned long long)off * 16u);
         }
 #pragma unroll
         for (int i = 0; i < NGR; ++i) {   // g in STORED coordinates (halo 1, folded: the ring is zero = the zero padding of the dgrad)
-            const int e = min(tid + 512 * i, NCB * BP_PL - 1);
-            const int cb = e / BP_PL, p = e - cb * BP_PL;
-            const int ys = y0 + p / TP, xs = x0 + p % TP;
+            const int ys = y0 + (int)((gpk[i] >> 8) & 255u), xs = x0 + (int)(gpk[i] & 255u);
             const bool inside = ys < tg.hs && xs < tg.ws;
-            const u32x4 v = *reinterpret_cast<const u32x4*>(tg.base + tg.gidx(in_, cb, min(ys, tg.hs - 1), min(xs, tg.ws - 1)) * 16);
+            const unsigned off = gcb0 + (gpk[i] >> 16) * gplane + (unsigned)min(ys, tg.hs - 1) * (unsigned)tg.ws + (unsigned)min(xs, tg.ws - 1);
+            const u32x4 v = *reinterpret_cast<const u32x4*>(gb + (unsigned long long)off * 16u);
             rg[i] = inside ? v : (u32x4){0u, 0u, 0u, 0u};
         }
     };
