@@ -52,11 +52,10 @@ __global__ __launch_bounds__(256, 2) void enc_wgrad_kernel(const float* __restri
     int gi = blockIdx.x;
     const int H = tx.h, W = tx.w;
 
-    // (wave 3's accumulators -- first layer acc0, bias sums accb -- live in acc3[0][0] / acc3[1][*]: the roles never meet, and a
+    // (wave 3's accumulators -- the first layer's four chains -- live in tiles of acc3 the wave does not otherwise use: the roles never meet, and a
     //  union keeps the kernel inside the 256-register budget of two blocks per CU)
-    ew_f32x4 acc3[3][3], acc2[3][2], acc1[3];
+    ew_f32x4 acc3[3][3], acc2[3][2], acc1[3], accbw = {0.f, 0.f, 0.f, 0.f};
 #define acc0 acc3[0][0]
-#define accb acc3[1]
 #pragma unroll
     for (int v = 0; v < 3; ++v) {
         acc1[v] = (ew_f32x4){0.f, 0.f, 0.f, 0.f};
@@ -176,6 +175,9 @@ __global__ __launch_bounds__(256, 2) void enc_wgrad_kernel(const float* __restri
 #pragma unroll
                 for (int b = 0; b < 2; ++b) acc2[v][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], bx[i & 1][b], acc2[v][b], 0, 0, 0);
                 acc1[v] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], bx[i & 1][0], acc1[v], 0, 0, 0);
+                // db of layer u + 1: a ones product of the gradient fragment this wave holds anyway (it used to cost wave 3, the
+                // long pole of the tile, three more transposing fragment reads and MFMAs per k-step)
+                if (v == 0) accbw = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u == 0 ? a[0] : (u == 1 ? a[1] : a[2]), ones, accbw, 0, 0, 0);
                 if (i + 1 < 24) {   // next group's DS reads first,
                     if ((i + 1) % 3 == 0) __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
                     else __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
@@ -191,12 +193,6 @@ __global__ __launch_bounds__(256, 2) void enc_wgrad_kernel(const float* __restri
             //  tiles of acc3 / acc2 this wave does not otherwise use; summed when the partial is written)
 #pragma unroll 2
             for (int s = 0; s < 8; ++s) {
-                const int row = 2 * s + (g >> 1), col0 = 8 * (g & 1);
-#pragma unroll
-                for (int L = 1; L <= 3; ++L) {
-                    const ew_bf16x8 a = tr_frag(reinterpret_cast<const char*>(s_g) + ((2 * L + lane_plane) * EW_GPL + row * EW_T + col0 + tr_row) * 16 + lane_byte);
-                    accb[L - 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, ones, accb[L - 1], 0, 0, 0);
-                }
                 float af[8], bf[8];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
@@ -234,13 +230,15 @@ __global__ __launch_bounds__(256, 2) void enc_wgrad_kernel(const float* __restri
                 red[EW_OFF1 + (oc * 16 + sl) * 9 + t] = acc1[v][r];
             }
         }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (sl == 0) red[EW_OFFB + u * 16 + 4 * g + r] = accbw[r];   // every column of a ones product is the sum
     } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int oc = 4 * g + r;
             red[EW_OFF0 + oc * 16 + sl] = (acc0[r] + acc3[0][1][r]) + (acc3[0][2][r] + acc3[2][0][r]);
-            const float bsum = sl == 0 ? accb[0][r] : (sl == 1 ? accb[1][r] : accb[2][r]);   // every column of a ones product is the sum
-            if (sl < 3) red[EW_OFFB + sl * 16 + oc] = bsum;
+
         }
     }
     __syncthreads();
@@ -248,7 +246,6 @@ __global__ __launch_bounds__(256, 2) void enc_wgrad_kernel(const float* __restri
     for (int e = tid; e < EW_PER; e += 256) dst[e] = red[e];
 }
 #undef acc0
-#undef accb
 
 // ------------------------------------------------------------------ the same scheme for a single 3x3 layer ("tap-row" wgrad)
 // dW, db of ONE ConvLayer with 16 NXB input and 16 NGB output channels (decoder tails: 64 -> 32, 32 -> 16; the DenseBlock convs when the
