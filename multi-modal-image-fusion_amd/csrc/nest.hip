@@ -201,13 +201,26 @@ __global__ void plane_sums_finish(const float* __restrict__ partial, float* __re
     out[i] = s;
 }
 
+// per-(n, channel) coefficients of the channel branch, once per call instead of once per pixel (they were 8 divisions per granule in the
+// pixel loops): wc = m1 / max(m1 + m2, eps); backward: da = (1/dc - m1/dc^2 [ms >= eps]) / HW, db = (-m1/dc^2 [ms >= eps]) / HW.
+// Same expressions, same fp32 values as the per-pixel form.
+__global__ void attn_coef_kernel(const float* __restrict__ csum, float* __restrict__ coef, int count, float inv_hw) {
+    const float EPSV = 1e-7f;
+    const int ci = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ci >= count) return;
+    const float m1 = csum[ci * 2] * inv_hw, m2 = csum[ci * 2 + 1] * inv_hw;
+    const float ms = m1 + m2, dc = fmaxf(ms, EPSV), wc = m1 / dc, pc = ms >= EPSV ? 1.f : 0.f;
+    coef[ci] = wc;
+    coef[count + ci] = (1.f / dc - m1 / (dc * dc) * pc) * inv_hw;
+    coef[2 * count + ci] = (-m1 / (dc * dc) * pc) * inv_hw;
+}
+
 // mode bits: 1 = spatial branch, 2 = channel branch; both -> 'sca' = mean of the two
 template <typename T>
-__global__ void attn_fwd_kernel(TV a, TV b, TV o, const float* __restrict__ csum, int mode) {
+__global__ void attn_fwd_kernel(TV a, TV b, TV o, const float* __restrict__ coef, int mode) {
     const float EPSV = 1e-7f;
     const long long total = (long long)o.n * o.h * o.w;
     const int C = a.cb * 8;
-    const float inv_hw = 1.f / ((float)a.h * a.w);
     const float scale = mode == 3 ? 0.5f : 1.f;
     GRID_STRIDE(i, total) {
         int n, c_unused, y, x;
@@ -233,8 +246,7 @@ __global__ void attn_fwd_kernel(TV a, TV b, TV o, const float* __restrict__ csum
                 float r = 0.f;
                 if (mode & 1) r += ws * va[k] + (1.f - ws) * vb[k];
                 if (mode & 2) {
-                    const float m1 = csum[((long long)n * C + c * 8 + k) * 2] * inv_hw, m2 = csum[((long long)n * C + c * 8 + k) * 2 + 1] * inv_hw;
-                    const float wc = m1 / fmaxf(m1 + m2, EPSV);
+                    const float wc = coef[(long long)n * C + c * 8 + k];
                     r += wc * va[k] + (1.f - wc) * vb[k];
                 }
                 vo[k] = r * scale;
@@ -247,12 +259,12 @@ __global__ void attn_fwd_kernel(TV a, TV b, TV o, const float* __restrict__ csum
 // backward of attention fusion; gsum = plane sums of g*(a-b) (MODE 1 above).  ga/gb: gradient views (interior written,
 // accumulate optional).  Derivation: oracle/fusion_oracle.py:_attn_branch_bwd.
 template <typename T>
-__global__ void attn_bwd_kernel(TV a, TV b, TV g, TV ga, TV gb, const float* __restrict__ csum, const float* __restrict__ gsum,
+__global__ void attn_bwd_kernel(TV a, TV b, TV g, TV ga, TV gb, const float* __restrict__ coef, const float* __restrict__ gsum,
                                 int mode, int accumulate) {
     const float EPSV = 1e-7f;
     const long long total = (long long)a.n * a.h * a.w;
     const int C = a.cb * 8;
-    const float inv_hw = 1.f / ((float)a.h * a.w);
+    const long long cnt = (long long)a.n * C;
     const float scale = mode == 3 ? 0.5f : 1.f;
     GRID_STRIDE(i, total) {
         int n, c_unused, y, x;
@@ -286,11 +298,10 @@ __global__ void attn_bwd_kernel(TV a, TV b, TV g, TV ga, TV gb, const float* __r
                 }
                 if (mode & 2) {
                     const long long ci = (long long)n * C + c * 8 + k;
-                    const float m1 = csum[ci * 2] * inv_hw, m2 = csum[ci * 2 + 1] * inv_hw;
-                    const float ms = m1 + m2, dc = fmaxf(ms, EPSV), wc = m1 / dc, pc = ms >= EPSV ? 1.f : 0.f;
+                    const float wc = coef[ci];
                     const float gwc = gsum[ci] * scale;     // dL/dwc
-                    ra += gk * wc + gwc * (1.f / dc - m1 / (dc * dc) * pc) * inv_hw;
-                    rb += gk * (1.f - wc) + gwc * (-m1 / (dc * dc) * pc) * inv_hw;
+                    ra += gk * wc + gwc * coef[cnt + ci];
+                    rb += gk * (1.f - wc) + gwc * coef[2 * cnt + ci];
                 }
                 oa[k] = ra;
                 ob[k] = rb;
@@ -377,7 +388,7 @@ extern "C" int mmif_relu_mask(const mmif_tensor* x, const mmif_tensor* g, void* 
 static int attn_mode(int32_t mode) { return mode == 0 ? 1 : (mode == 1 ? 2 : (mode == 2 ? 3 : -1)); }  // sa, ca, sca
 
 extern "C" size_t mmif_fuse_attn_workspace(int32_t n, int32_t c) {
-    return (size_t)n * ((c + 7) / 8 * 8) * (3 + 2 * PS_SLICES) * sizeof(float);  // sums + per-slice partials
+    return (size_t)n * ((c + 7) / 8 * 8) * (6 + 2 * PS_SLICES) * sizeof(float);  // sums + per-slice partials + per-channel coefficients
 }
 
 extern "C" int mmif_fuse_attn_fwd(const mmif_tensor* a, const mmif_tensor* b, const mmif_tensor* out, int32_t mode,
@@ -399,15 +410,17 @@ extern "C" int mmif_fuse_attn_fwd(const mmif_tensor* a, const mmif_tensor* b, co
     hipStream_t st = (hipStream_t)stream;
     TV ta = make_tv(a), tb = make_tv(b), to = make_tv(out);
     float* csum = (float*)workspace;
+    float* coef = csum + (size_t)a->n * a->cb * 8 * (3 + 2 * PS_SLICES);
     if (m & 2) {
         const int cnt = a->n * a->cb * 8;
         float* part = csum + (size_t)cnt * 3;
         if (a->dtype == MMIF_F32) hipLaunchKernelGGL((plane_sums_kernel<float, 0>), dim3(ta.n * ta.cb, PS_SLICES), dim3(256), 0, st, ta, tb, ta, part);
         else hipLaunchKernelGGL((plane_sums_kernel<bf16_t, 0>), dim3(ta.n * ta.cb, PS_SLICES), dim3(256), 0, st, ta, tb, ta, part);
         hipLaunchKernelGGL(plane_sums_finish, dim3((cnt * 2 + 255) / 256), dim3(256), 0, st, part, csum, cnt * 2);
+        hipLaunchKernelGGL(attn_coef_kernel, dim3((cnt + 255) / 256), dim3(256), 0, st, csum, coef, cnt, 1.f / ((float)a->h * a->w));
         if (int rc = check_launch("attn plane sums")) return rc;
     }
-    LAUNCH_T(a->dtype, attn_fwd_kernel, grid_for((long long)to.n * to.h * to.w), ta, tb, to, csum, m);
+    LAUNCH_T(a->dtype, attn_fwd_kernel, grid_for((long long)to.n * to.h * to.w), ta, tb, to, coef, m);
     return check_launch("attn_fwd");
 }
 
@@ -434,6 +447,7 @@ extern "C" int mmif_fuse_attn_bwd(const mmif_tensor* a, const mmif_tensor* b, co
     TV ta = make_tv(a), tb = make_tv(b), tg = make_tv(g), tga = make_tv(ga), tgb = make_tv(gb);
     float* csum = (float*)workspace;
     float* gsum = csum + (size_t)a->n * a->cb * 8 * 2;
+    float* coef = csum + (size_t)a->n * a->cb * 8 * (3 + 2 * PS_SLICES);
     if (m & 2) {
         const int cnt = a->n * a->cb * 8;
         float* part = csum + (size_t)cnt * 3;
@@ -441,11 +455,12 @@ extern "C" int mmif_fuse_attn_bwd(const mmif_tensor* a, const mmif_tensor* b, co
         if (a->dtype == MMIF_F32) hipLaunchKernelGGL((plane_sums_kernel<float, 0>), grid, dim3(256), 0, st, ta, tb, ta, part);
         else hipLaunchKernelGGL((plane_sums_kernel<bf16_t, 0>), grid, dim3(256), 0, st, ta, tb, ta, part);
         hipLaunchKernelGGL(plane_sums_finish, dim3((cnt * 2 + 255) / 256), dim3(256), 0, st, part, csum, cnt * 2);
+        hipLaunchKernelGGL(attn_coef_kernel, dim3((cnt + 255) / 256), dim3(256), 0, st, csum, coef, cnt, 1.f / ((float)a->h * a->w));
         if (a->dtype == MMIF_F32) hipLaunchKernelGGL((plane_sums_kernel<float, 1>), grid, dim3(256), 0, st, ta, tb, tg, part);
         else hipLaunchKernelGGL((plane_sums_kernel<bf16_t, 1>), grid, dim3(256), 0, st, ta, tb, tg, part);
         hipLaunchKernelGGL(plane_sums_finish, dim3((cnt + 255) / 256), dim3(256), 0, st, part, gsum, cnt);
         if (int rc = check_launch("attn plane sums (bwd)")) return rc;
     }
-    LAUNCH_T(a->dtype, attn_bwd_kernel, grid_for((long long)ta.n * ta.h * ta.w), ta, tb, tg, tga, tgb, csum, gsum, m, accumulate);
+    LAUNCH_T(a->dtype, attn_bwd_kernel, grid_for((long long)ta.n * ta.h * ta.w), ta, tb, tg, tga, tgb, coef, gsum, m, accumulate);
     return check_launch("attn_bwd");
 }
