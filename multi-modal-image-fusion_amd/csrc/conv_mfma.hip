@@ -792,6 +792,7 @@ __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void conv_dma_kernel(TV 
             d_geo[i] = (unsigned)((p / DTP_X) << 8 | (p % DTP_X));
             d_cb |= (unsigned)cb << (2 * i);
         }
+        const unsigned plane_bytes = (unsigned)(tin.plane * 16);
         auto make_desc = [&](const DItem& itm) {
             const int iy0 = itm.tile_y * DT_ROWS - tout.halo - 1 + org, ix0 = itm.tile_x * MT - tout.halo - 1 + org;
 #pragma unroll
@@ -804,10 +805,11 @@ __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void conv_dma_kernel(TV 
                     y = min(max(y + 1, 0), tin.hs - 1);
                     x = min(max(x + 1, 0), tin.ws - 1);
                 }
-                d_off[i] = (unsigned)(y * tin.ws + x) * 16u;
+                // pixel offset + the piece's chunk-local plane: nothing but the load itself is left per chunk (a v_mul_lo_u32 per
+                // piece and chunk is quarter rate, and loader VALU time is MFMA time of the consumers on the same SIMD)
+                d_off[i] = (__umul24((unsigned)y, (unsigned)tin.ws) + (unsigned)x) * 16u + ((d_cb >> (2 * i)) & 3u) * plane_bytes;
             }
         };
-        const unsigned plane_bytes = (unsigned)(tin.plane * 16);
         auto issue_dma = [&](const DItem& itm, int c, int buf) {
             const int ncb = min(CHUNK_CB, ncb_tot - c * CHUNK_CB);
             const int nkgp = (9 * ncb + 3) / 4 * 4;
@@ -819,8 +821,11 @@ __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void conv_dma_kernel(TV 
             for (int i = 0; i < DL_ITERS; ++i) {
                 const int P = lw + D_LOAD * i;   // wave-uniform piece index
                 if (i < DL_IN_ITERS && P < DIN_PIECES) {
-                    const unsigned cbc = min((d_cb >> (2 * (i < DL_IN_ITERS ? i : 0))) & 3u, (unsigned)(ncb - 1));
-                    const unsigned off = d_off[i < DL_IN_ITERS ? i : 0] + cbc * plane_bytes;
+                    unsigned off = d_off[i < DL_IN_ITERS ? i : 0];
+                    if (ncb != CHUNK_CB) {   // ragged last chunk (wave uniform): planes past the end re-read the last valid one
+                        const unsigned cb = (d_cb >> (2 * (i < DL_IN_ITERS ? i : 0))) & 3u;
+                        off -= (cb - min(cb, (unsigned)(ncb - 1))) * plane_bytes;
+                    }
                     __builtin_amdgcn_global_load_lds(MMIF_GPTR(src_in + off), MMIF_LPTR(dst_in + P * 1024), 16, 0, 0);
                 } else if (P >= DIN_PIECES && P < D_PIECES) {
                     const int kg = P - DIN_PIECES;
@@ -1578,27 +1583,36 @@ __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void wgrad_dma_kernel(TV
             }
         }
         const unsigned xplane = (unsigned)(tx.plane * 16), gplane = (unsigned)(tg.plane * 16);
+        // per piece, tile independent: byte offset of its plane (ragged last channel group: planes past the tensor re-read its last
+        // plane -- those dW rows / columns are never reduced).  The per-tile part is one 24-bit multiply-add per piece.
+        unsigned pl_off[WDL_ITERS];
+        {
+            const int xpl_max0 = min(8, tx.cb - icg * 8) - 1, gpl_max0 = min(8, tg.cb - ocg * 8) - 1;
+#pragma unroll
+            for (int i = 0; i < WDL_ITERS; ++i) {
+                const int P = lw + D_LOAD * i, pl = (int)(geo[i] >> 16);
+                pl_off[i] = P < WD_XPIECES ? (unsigned)min(pl, xpl_max0) * xplane : (unsigned)min(pl, gpl_max0) * gplane;
+            }
+        }
         auto issue = [&](int tile, int buf) {
             const int in_ = tile / tpi, tt = tile - in_ * tpi;
             const int y0 = (tt / tiles_x) * MT, x0 = (tt % tiles_x) * MT;
             const char* src_x = tx.base + ((long long)in_ * tx.img + (long long)(tx.cb_off + icg * 8) * tx.plane) * 16;
             const char* src_g = tg.base + ((long long)in_ * tg.img + (long long)(tg.cb_off + ocg * 8) * tg.plane) * 16;
-            // ragged last channel group: planes past the tensor re-read its last plane (those dW rows/cols are never reduced)
-            const int xpl_max = min(8, tx.cb - icg * 8) - 1, gpl_max = min(8, tg.cb - ocg * 8) - 1;
             char* dst = s_buf + buf * WD_BUF_BYTES;
 #pragma unroll
             for (int i = 0; i < WDL_ITERS; ++i) {
                 const int P = lw + D_LOAD * i;   // wave uniform
-                const int pl = (int)(geo[i] >> 16), py = (int)((geo[i] >> 8) & 255u), px = (int)(geo[i] & 255u);
+                const int py = (int)((geo[i] >> 8) & 255u), px = (int)(geo[i] & 255u);
                 if (P < WD_XPIECES) {
                     const int y = min(max(reflect_idx(y0 + py - 1, tx.h), 0), tx.h - 1);
                     const int x = min(max(reflect_idx(x0 + px - 1, tx.w), 0), tx.w - 1);
-                    const unsigned off = (unsigned)(y * tx.ws + x) * 16u + (unsigned)min(pl, xpl_max) * xplane;
+                    const unsigned off = (__umul24((unsigned)y, (unsigned)tx.ws) + (unsigned)x) * 16u + pl_off[i];
                     __builtin_amdgcn_global_load_lds(MMIF_GPTR(src_x + off), MMIF_LPTR(dst + P * 1024), 16, 0, 0);
                 } else if (P < WD_PIECES) {
                     // pixels of a ragged tile that lie outside the image read the zeroed halo ring (stored row h+1 / col w+1)
                     const int y = min(y0 + py, tg.h) + 1, x = min(x0 + px, tg.w) + 1;
-                    const unsigned off = (unsigned)(y * tg.ws + x) * 16u + (unsigned)min(pl, gpl_max) * gplane;
+                    const unsigned off = (__umul24((unsigned)y, (unsigned)tg.ws) + (unsigned)x) * 16u + pl_off[i];
                     __builtin_amdgcn_global_load_lds(MMIF_GPTR(src_g + off), MMIF_LPTR(dst + P * 1024), 16, 0, 0);
                 }
             }
