@@ -128,6 +128,7 @@ def main():
         f = model(img1, img2)
         a, b, c = l_ssim(img1, img2, f), l_pix(img1, img2, f, mode='max'), l_grad(img1, img2, f, mode='max')
         tot = a + b + c
+        opt.stage_scalars([tot, a, b, c])      # (data parallel) the loss values ride in the early gradient all-reduce
         tot.backward()
         opt.step(scalars=[tot, a, b, c])
         return tot

@@ -13,6 +13,7 @@ import os
 import torch
 
 from . import _lib
+from . import dist as D
 from . import tensor as T
 from .tensor import BT, PackedWeights
 
@@ -197,14 +198,32 @@ class ModelEngine:
     def _assign_grad_views(self, device):
         flat = self._grad_buffer(device)
         views, off = {}, 0
+        self._goff = {}
         for p in self.params():
             views[id(p)] = flat[off:off + p.numel()].view(p.shape)
+            self._goff[id(p)] = (off, p.numel())
             off += p.numel()
         for s in self.specs:
             s.dw = views[id(s.conv.weight)]
             s.db = views[id(s.conv.bias)]
         # hand autograd FRESH view objects (sole owners), so AccumulateGrad can adopt them as .grad without a copy
         return flat, [views[id(p)].view(p.shape) for p in self.params()]
+
+    def early_reduce(self, flat, specs):
+        """Data parallel: start the all-reduce of these layers' finished gradients (a contiguous range of the flat buffer, + the staged
+        loss scalars when the range ends at the tail) while the rest of the backward runs -- mmif/dist.py.  Plain flow only: a
+        backward that finds .grad already set is accumulating, and its gradients are not final."""
+        if not D.early_reduce_armed() or any(p.grad is not None for p in self.params()):
+            return False
+        rng = [self._goff[id(t)] for s in specs for t in (s.conv.weight, s.conv.bias) if t is not None and id(t) in self._goff]
+        if not rng:
+            return False
+        lo, hi = min(o for o, _ in rng), max(o + n for o, n in rng)
+        if sum(n for _, n in rng) != hi - lo:      # not contiguous in the parameter order: leave it to the optimizer
+            return False
+        if hi == flat.numel() - GRAD_TAIL:
+            hi += D.staged_tail(flat)
+        return D.early_allreduce(flat, lo, hi)
 
     def workspace(self, device):
         need = 0
@@ -493,6 +512,7 @@ class PFNetv1Engine(ModelEngine, DenseEncoderMixin):
                 continue
             self.c_wgrad(s, x, g, ws, impl)
             g = self.c_dgrad(s, g, x, gx, mb, 0, impl)
+        self.early_reduce(flat, self.dec)      # (data parallel) the decoder's gradients leave while the encoder's backward runs
         self.enc_bwd_all(img1, img2, F, g, ws, impl)
         return grads
 
@@ -586,6 +606,7 @@ class DenseFuseEngine(ModelEngine, DenseEncoderMixin):
                 continue
             self.c_wgrad(s, x, g, ws, impl)
             g = self.c_dgrad(s, g, x, gx, mb, 0, impl)
+        self.early_reduce(flat, self.dec)
         if single:
             self.enc_bwd(self.enc, img1, F, g, 0, 0, ws, impl)
             return grads

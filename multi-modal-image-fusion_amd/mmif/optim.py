@@ -10,6 +10,7 @@ import ctypes as C
 import torch
 import torch.distributed as dist
 
+from . import dist as D
 from . import engine as E
 from ._lib import check, lib
 from .tensor import stream_ptr
@@ -27,6 +28,7 @@ class FusedClipAdam(torch.optim.Optimizer):
         if len(self.param_groups) != 1:
             raise ValueError("FusedClipAdam supports a single parameter group")
         self._flat_p = self._m = self._v = self._ws = self._stage = None
+        self._last_flat = None
         self._steps = 0
         self.grad_norm = None  # device float[1]: pre-clip global L2 norm of the last step
         self.reduced_scalars = None
@@ -144,6 +146,19 @@ class FusedClipAdam(torch.optim.Optimizer):
         return self._stage
 
     @torch.no_grad()
+    def stage_scalars(self, scalars):
+        """Call BEFORE backward() with the loss values of this step (up to 8 0-dim device tensors): they are parked in the tail slots of
+        the engine's flat gradient buffer so that they travel in the EARLY gradient all-reduce (mmif/dist.py); step(scalars=the same
+        list) then only reads them back.  A no-op (step() writes them itself) until the buffer is known, i.e. on the first step."""
+        flat = self._last_flat
+        if flat is None or not scalars or len(scalars) > N_TAIL or not D.early_reduce_armed():
+            return False
+        total = flat.numel() - N_TAIL
+        torch.stack([s.detach().float().reshape(()) for s in scalars], out=flat[total:total + len(scalars)])
+        D.stage_tail(flat, len(scalars))
+        return True
+
+    @torch.no_grad()
     def prepare(self):
         """Re-point the parameters to the flat buffer NOW (normally done by the first step): anything that records parameter
         addresses -- a hipGraph capture of the forward/backward (mmif.graph) -- must see the final storage."""
@@ -160,13 +175,27 @@ class FusedClipAdam(torch.optim.Optimizer):
         ps = self._params()
         self._flatten_params(ps)
         flat_g = self._flat_grads(ps)
+        self._last_flat = flat_g if E.FLAT_BUFFERS.get(flat_g.data_ptr()) is flat_g else None
         total = self._flat_p.numel()
         in_group = dist.is_available() and dist.is_initialized()
         world = dist.get_world_size() if in_group else 1
-        if scalars:   # straight into the tail of the flat buffer (one small launch)
-            torch.stack([s.detach().float().reshape(()) for s in scalars], out=flat_g[total:total + len(scalars)])
+        early = D.take_early(flat_g) if in_group else None     # (lo, hi): that range is reduced already (mmif/dist.py)
+        k = len(scalars) if scalars else 0
+        tail_done = early is not None and early[1] >= total + k and k > 0
+        if k and not tail_done:   # straight into the tail of the flat buffer (one small launch)
+            torch.stack([s.detach().float().reshape(()) for s in scalars], out=flat_g[total:total + k])
         if in_group:
-            dist.all_reduce(flat_g)  # ONE collective: gradients + loss scalars (SUM); mean taken below
+            if early is None:
+                dist.all_reduce(flat_g)  # ONE collective: gradients + loss scalars (SUM); mean taken below
+            else:
+                lo, hi = early
+                if lo > 0:
+                    dist.all_reduce(flat_g[0:lo])
+                if hi < total:
+                    dist.all_reduce(flat_g[hi:total])
+                if k and not tail_done:
+                    dist.all_reduce(flat_g[total:total + N_TAIL])
+            D.arm_early_reduce(True)
         if scalars:
             tail = flat_g[total:total + len(scalars)]
             self.reduced_scalars = tail / world if world > 1 else tail.clone()

@@ -69,6 +69,8 @@ def train_model(model, data_loader, loss_fn1, loss_fn2, loss_fn3, epoch, mode='t
             loss2 = loss_fn2(img1, img2, imgf, mode='max')
             loss3 = loss_fn3(img1, img2, imgf, mode='max')
             total_loss = loss1 + loss2 + loss3
+            if hasattr(optimizer, "stage_scalars"):   # (data parallel) the loss values ride in the early gradient all-reduce
+                optimizer.stage_scalars([total_loss, loss1, loss2, loss3])
             total_loss.backward()
             # clip_grad_norm_(5) + Adam + (distributed) gradient & loss all-reduce: one fused step
             optimizer.step(scalars=[total_loss, loss1, loss2, loss3])

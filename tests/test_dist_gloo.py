@@ -205,3 +205,64 @@ def test_sync_batchnorm_orchestration_gloo_world2():
     np.testing.assert_allclose(res[0]["rm"], bn.running_mean.numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(res[0]["rv"], bn.running_var.numpy(), rtol=1e-5, atol=1e-6)
     assert res[0]["nbt"] == res[1]["nbt"] == 1
+
+
+# ---- early (two-bucket) gradient all-reduce protocol: mmif/dist.py early_allreduce / take_early, on gloo ------------------------------
+def _early_worker(rank, world, port, q):
+    import os
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "multi-modal-image-fusion_amd"))
+    from mmif import dist as D
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        total, tail = 100, 8
+        g = torch.Generator().manual_seed(100 + rank)
+        flat = torch.randn(total + tail, generator=g)
+        ref = flat.clone()
+        dist.all_reduce(ref)                                   # what ONE collective over everything gives
+        lo = 30                                                # "decoder" = [30, 100), tail staged -> early range [30, 104)
+        D.arm_early_reduce(True)
+        assert D.early_reduce_armed()
+        D.stage_tail(flat, 4)
+        assert D.early_allreduce(flat, lo, total + D.staged_tail(flat))
+        assert D.staged_tail(flat) == 0                        # consumed by the early call
+        flat[0:lo] += 0.0                                      # ("encoder backward" keeps writing the other range meanwhile)
+        lo2, hi2 = D.take_early(flat)
+        assert (lo2, hi2) == (lo, total + 4)
+        dist.all_reduce(flat[0:lo2])
+        ok = torch.equal(flat[:total + 4], ref[:total + 4])
+        # a backward whose step never came: the next early call drains the pending handle first
+        flat2 = torch.ones(total + tail) * (rank + 1)
+        D.early_allreduce(flat2, 10, 20)
+        D.early_allreduce(flat2, 10, 20)                       # second call waits for the first, then reduces again
+        D.drain_early()
+        want = float(sum(r + 1 for r in range(world))) * world  # reduced twice
+        ok2 = bool((flat2[10:20] == want).all()) and bool((flat2[:10] == rank + 1).all())
+        # kill switch
+        os.environ["MMIF_EARLY_REDUCE"] = "0"
+        D.arm_early_reduce(True)
+        off = not D.early_reduce_armed() and D.early_allreduce(flat2, 0, 5) is False
+        os.environ.pop("MMIF_EARLY_REDUCE")
+        q.put((rank, ok, ok2, off))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_early_allreduce_protocol_two_ranks():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29650 + (os.getpid() % 200)
+    procs = [ctx.Process(target=_early_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok, ok2, off in res:
+        assert ok, f"rank {rank}: early + late ranges differ from one all-reduce"
+        assert ok2, f"rank {rank}: drain semantics"
+        assert off, f"rank {rank}: MMIF_EARLY_REDUCE=0 must disable the early path"

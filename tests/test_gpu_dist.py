@@ -1,6 +1,7 @@
 """Data parallel on the device: two processes (both on cuda:0, gloo transport -- RCCL refuses two ranks on one GPU) run
-the REAL train step (HIP engine + losses + FusedClipAdam with its single [gradients | loss scalars] all-reduce) on the
-two halves of a batch; parameters and reduced loss scalars after two steps must match one process on the whole batch.
+the REAL train step (HIP engine + losses + FusedClipAdam with its [gradients | loss scalars] all-reduce: one collective on the first
+step, the early decoder bucket + late encoder bucket of mmif/dist.py afterwards) on the two halves of a batch; parameters and reduced
+loss scalars after two steps must match one process on the whole batch.
 The 8-GPU RCCL run itself is the driver's; this pins the code path it takes."""
 import os
 import socket
@@ -52,13 +53,14 @@ def _run(rank, world, port, out, model_name="PFNetv1"):
     l1, l2, l3 = SSIMLoss('ssim', weight=1.0), PixelLoss('l1', weight=0.01), GradLoss('l1', weight=0.1).to(dev)
     lo, hi = shard_batch(SHAPE[0], rank, world)
     scal = None
-    for step in range(2):
+    for step in range(2):      # step 0: one all-reduce; step 1: the two-bucket early reduce (armed by the first distributed step)
         i1 = torch.from_numpy(O.closed_form_image(SHAPE, 0.3 + step)).to(dev)[lo:hi].contiguous()
         i2 = torch.from_numpy(O.closed_form_image(SHAPE, 1.7 + step)).to(dev)[lo:hi].contiguous()
         opt.zero_grad(set_to_none=True)
         f = model(i1, i2)
         a, b, c = l1(i1, i2, f), l2(i1, i2, f, mode='max'), l3(i1, i2, f, mode='max')
         tot = a + b + c
+        opt.stage_scalars([tot, a, b, c])         # (a no-op on step 0: the flat buffer is not known yet)
         tot.backward()
         opt.step(scalars=[tot, a, b, c])
         scal = opt.reduced_scalars.detach().cpu().numpy()
@@ -69,7 +71,9 @@ def _run(rank, world, port, out, model_name="PFNetv1"):
     from core.block import ConvLayer
     noise = [f"{n}.layers.0.bias" for n, mod in model.named_modules()
              if isinstance(mod, ConvLayer) and mod.norm is nn.BatchNorm2d and mod.layers[0].bias is not None]
-    out[(model_name, world, rank)] = dict(noise=noise, P={k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}, scal=scal)
+    from mmif import dist as D
+    out[(model_name, world, rank)] = dict(noise=noise, P={k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}, scal=scal,
+                                          early=D.early_reduce_count())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -86,8 +90,10 @@ def test_two_rank_step_equals_single_process_full_batch():
     for k in single["P"]:
         assert np.array_equal(r0["P"][k], r1["P"][k]), f"ranks diverged on {k}"
         ref = single["P"][k]
-        assert np.abs(r0["P"][k] - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), k
+        assert np.abs(r0["P"][k] - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), k   # (identical with $MMIF_EARLY_REDUCE=0)
     assert np.allclose(r0["scal"], r1["scal"]) and np.allclose(r0["scal"], single["scal"], rtol=2e-5, atol=1e-6)
+    want = 0 if os.environ.get("MMIF_EARLY_REDUCE", "1") == "0" else 1
+    assert r0["early"] == want and r1["early"] == want and single["early"] == 0, "step 1 must take the two-bucket path"
 
 
 def test_two_rank_batchnorm_model_equals_single_process_full_batch():
