@@ -192,6 +192,8 @@ class NestEngine(ModelEngine):
         gi = db_bwd("DB2_1", GR[1].as_folded().view(*slot(1, 1)), (0,), ())
         T.upsample_bwd(gi.view(0, uo[1]), GR[2].view(*slot(2, 0)), True)            # into f2
         gf = [GR[l].as_folded().view(*slot(l, 0)) for l in range(3)] + [GR[3].as_folded()]
+        # (data parallel) the decoder's gradients are final: their all-reduce runs beside the fusion / encoder backward
+        self.early_reduce(flat, [s for pr in self.db.values() for s in pr] + [self.conv_out])
 
         # ---- fusion backward -> G_E_l = [grad feat(img1) | grad feat(img2)]
         GE = [G(f"E{l}", 2 * c[l], l) for l in range(4)]
