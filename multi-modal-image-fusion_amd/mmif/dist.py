@@ -97,11 +97,18 @@ def allreduce_flat(flat, scalars=None):
 #                 reduces the whole buffer as before.
 # Off ($MMIF_EARLY_REDUCE=0, or never armed) nothing changes.  Only armed by FusedClipAdam when a process group with a collective
 # backend is up; never inside a hipGraph capture; only for the plain one-backward-per-step flow (all .grad None at backward).
-_EARLY = {"armed": False, "pending": {}, "tail": {}, "count": 0}
+_EARLY = {"armed": False, "pending": {}, "tail": {}, "count": 0, "blessed": None}
 
 
-def arm_early_reduce(on=True):
+def arm_early_reduce(on=True, flat=None):
+    """flat: the ONE gradient buffer the optimizer consumed zero-copy on its last step -- only that buffer may be reduced early (a
+    buffer whose gradients get copied elsewhere before step() would be reduced twice)"""
     _EARLY["armed"] = bool(on) and os.environ.get("MMIF_EARLY_REDUCE", "1") != "0"
+    _EARLY["blessed"] = flat.data_ptr() if (flat is not None and _EARLY["armed"]) else None
+
+
+def pending_early():
+    return len(_EARLY["pending"])
 
 
 def stage_tail(flat, k):
@@ -125,7 +132,7 @@ def early_reduce_armed():
 @torch.no_grad()
 def early_allreduce(flat, lo, hi):
     """async SUM all-reduce of flat[lo:hi]; the handle is kept until take_early(flat)"""
-    if not early_reduce_armed() or hi <= lo:
+    if not early_reduce_armed() or hi <= lo or _EARLY["blessed"] != flat.data_ptr():
         return False
     if flat.is_cuda and torch.cuda.is_current_stream_capturing():
         return False

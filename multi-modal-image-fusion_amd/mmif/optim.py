@@ -180,6 +180,11 @@ class FusedClipAdam(torch.optim.Optimizer):
         in_group = dist.is_available() and dist.is_initialized()
         world = dist.get_world_size() if in_group else 1
         early = D.take_early(flat_g) if in_group else None     # (lo, hi): that range is reduced already (mmif/dist.py)
+        if in_group and D.pending_early():
+            D.drain_early()
+            raise RuntimeError("FusedClipAdam.step(): part of the engine's gradient buffer was all-reduced during backward, but the "
+                               "gradients this step consumes live elsewhere (they were replaced or copied after backward); "
+                               "set MMIF_EARLY_REDUCE=0 for such a flow")
         k = len(scalars) if scalars else 0
         tail_done = early is not None and early[1] >= total + k and k > 0
         if k and not tail_done:   # straight into the tail of the flat buffer (one small launch)
@@ -195,7 +200,7 @@ class FusedClipAdam(torch.optim.Optimizer):
                     dist.all_reduce(flat_g[hi:total])
                 if k and not tail_done:
                     dist.all_reduce(flat_g[total:total + N_TAIL])
-            D.arm_early_reduce(True)
+            D.arm_early_reduce(self._last_flat is not None, self._last_flat)
         if scalars:
             tail = flat_g[total:total + len(scalars)]
             self.reduced_scalars = tail / world if world > 1 else tail.clone()
