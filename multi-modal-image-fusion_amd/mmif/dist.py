@@ -97,27 +97,27 @@ def allreduce_flat(flat, scalars=None):
 #                 reduces the whole buffer as before.
 # Off ($MMIF_EARLY_REDUCE=0, or never armed) nothing changes.  Only armed by FusedClipAdam when a process group with a collective
 # backend is up; never inside a hipGraph capture; only for the plain one-backward-per-step flow (all .grad None at backward).
-_EARLY = {"armed": False, "pending": {}, "tail": {}, "count": 0, "blessed": None}
+_EARLY = {"armed": False, "pending": {}, "tail": None, "count": 0}
 
 
-def arm_early_reduce(on=True, flat=None):
-    """flat: the ONE gradient buffer the optimizer consumed zero-copy on its last step -- only that buffer may be reduced early (a
-    buffer whose gradients get copied elsewhere before step() would be reduced twice)"""
+def arm_early_reduce(on=True):
+    """armed by the optimizer after a step that consumed the engine's flat gradient buffer zero-copy (a flow that copies the
+    gradients elsewhere before step() would reduce them twice: step() fails loudly if it ever meets that)"""
     _EARLY["armed"] = bool(on) and os.environ.get("MMIF_EARLY_REDUCE", "1") != "0"
-    _EARLY["blessed"] = flat.data_ptr() if (flat is not None and _EARLY["armed"]) else None
 
 
 def pending_early():
     return len(_EARLY["pending"])
 
 
-def stage_tail(flat, k):
-    """the optimizer parked k scalars in flat's tail slots: the engine's early range may include them"""
-    _EARLY["tail"] = {flat.data_ptr(): int(k)}
+def stage_tail(values):
+    """the optimizer parks this step's loss scalars (a small 1-D device tensor) here before backward; the engine copies them into the
+    tail slots of whichever flat buffer this backward uses, right before the early all-reduce that then carries them"""
+    _EARLY["tail"] = values
 
 
-def staged_tail(flat):
-    return _EARLY["tail"].get(flat.data_ptr(), 0)
+def staged_tail():
+    return _EARLY["tail"]
 
 
 def early_reduce_count():
@@ -130,17 +130,22 @@ def early_reduce_armed():
 
 
 @torch.no_grad()
-def early_allreduce(flat, lo, hi):
-    """async SUM all-reduce of flat[lo:hi]; the handle is kept until take_early(flat)"""
-    if not early_reduce_armed() or hi <= lo or _EARLY["blessed"] != flat.data_ptr():
+def early_allreduce(flat, lo, hi, tail_at=None):
+    """async SUM all-reduce of flat[lo:hi]; the handle is kept until take_early(flat).  tail_at: index of the buffer's scalar slots
+    when hi reaches them -- staged scalars (stage_tail) are copied there and the range grows to cover them."""
+    if not early_reduce_armed() or hi <= lo:
         return False
     if flat.is_cuda and torch.cuda.is_current_stream_capturing():
         return False
     drain_early(flat)                                  # a backward whose step() never came: finish that reduce first
+    vals = _EARLY["tail"]
+    _EARLY["tail"] = None
+    if tail_at is not None and hi == tail_at and vals is not None and vals.numel() <= flat.numel() - tail_at:
+        flat[tail_at:tail_at + vals.numel()].copy_(vals)
+        hi = tail_at + vals.numel()
     work = dist.all_reduce(flat[lo:hi], async_op=True)
     _EARLY["count"] += 1
     _EARLY["pending"][flat.data_ptr()] = (work, lo, hi)
-    _EARLY["tail"].pop(flat.data_ptr(), None)
     return True
 
 

@@ -221,9 +221,9 @@ class ModelEngine:
         lo, hi = min(o for o, _ in rng), max(o + n for o, n in rng)
         if sum(n for _, n in rng) != hi - lo:      # not contiguous in the parameter order: leave it to the optimizer
             return False
-        if hi == flat.numel() - GRAD_TAIL:
-            hi += D.staged_tail(flat)
-        return D.early_allreduce(flat, lo, hi)
+        if FLAT_BUFFERS.get(flat.data_ptr()) is not flat:    # a one-off allocation (both rotating buffers aliased by live gradients)
+            return False
+        return D.early_allreduce(flat, lo, hi, tail_at=flat.numel() - GRAD_TAIL)
 
     def workspace(self, device):
         need = 0

@@ -148,14 +148,12 @@ class FusedClipAdam(torch.optim.Optimizer):
     @torch.no_grad()
     def stage_scalars(self, scalars):
         """Call BEFORE backward() with the loss values of this step (up to 8 0-dim device tensors): they are parked in the tail slots of
-        the engine's flat gradient buffer so that they travel in the EARLY gradient all-reduce (mmif/dist.py); step(scalars=the same
-        list) then only reads them back.  A no-op (step() writes them itself) until the buffer is known, i.e. on the first step."""
-        flat = self._last_flat
-        if flat is None or not scalars or len(scalars) > N_TAIL or not D.early_reduce_armed():
+        mmif/dist.py; the engine copies them into the tail slots of its flat gradient buffer so that they travel in the EARLY gradient
+        all-reduce; step(scalars=the same list) then only reads them back.  A no-op (step() writes them itself) until the early path
+        is armed, i.e. on the first step."""
+        if not scalars or len(scalars) > N_TAIL or not D.early_reduce_armed():
             return False
-        total = flat.numel() - N_TAIL
-        torch.stack([s.detach().float().reshape(()) for s in scalars], out=flat[total:total + len(scalars)])
-        D.stage_tail(flat, len(scalars))
+        D.stage_tail(torch.stack([s.detach().float().reshape(()) for s in scalars]))
         return True
 
     @torch.no_grad()
@@ -200,7 +198,7 @@ class FusedClipAdam(torch.optim.Optimizer):
                     dist.all_reduce(flat_g[hi:total])
                 if k and not tail_done:
                     dist.all_reduce(flat_g[total:total + N_TAIL])
-            D.arm_early_reduce(self._last_flat is not None, self._last_flat)
+            D.arm_early_reduce(self._last_flat is not None)
         if scalars:
             tail = flat_g[total:total + len(scalars)]
             self.reduced_scalars = tail / world if world > 1 else tail.clone()

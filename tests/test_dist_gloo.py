@@ -224,13 +224,13 @@ def _early_worker(rank, world, port, q):
         ref = flat.clone()
         dist.all_reduce(ref)                                   # what ONE collective over everything gives
         lo = 30                                                # "decoder" = [30, 100), tail staged -> early range [30, 104)
-        D.arm_early_reduce(True, flat)
+        D.arm_early_reduce(True)
         assert D.early_reduce_armed()
-        other = torch.zeros(8)
-        assert D.early_allreduce(other, 0, 4) is False         # only the buffer the optimizer consumed zero-copy may go early
-        D.stage_tail(flat, 4)
-        assert D.early_allreduce(flat, lo, total + D.staged_tail(flat))
-        assert D.staged_tail(flat) == 0                        # consumed by the early call
+        staged = flat[total:total + 4].clone()                 # the scalars arrive as values; the early call copies them into the tail
+        flat[total:total + 4] = -1.0
+        D.stage_tail(staged)
+        assert D.early_allreduce(flat, lo, total, tail_at=total)
+        assert D.staged_tail() is None                         # consumed by the early call
         flat[0:lo] += 0.0                                      # ("encoder backward" keeps writing the other range meanwhile)
         lo2, hi2 = D.take_early(flat)
         assert (lo2, hi2) == (lo, total + 4)
@@ -238,7 +238,6 @@ def _early_worker(rank, world, port, q):
         ok = torch.equal(flat[:total + 4], ref[:total + 4])
         # a backward whose step never came: the next early call drains the pending handle first
         flat2 = torch.ones(total + tail) * (rank + 1)
-        D.arm_early_reduce(True, flat2)
         D.early_allreduce(flat2, 10, 20)
         D.early_allreduce(flat2, 10, 20)                       # second call waits for the first, then reduces again
         D.drain_early()
@@ -246,7 +245,7 @@ def _early_worker(rank, world, port, q):
         ok2 = bool((flat2[10:20] == want).all()) and bool((flat2[:10] == rank + 1).all())
         # kill switch
         os.environ["MMIF_EARLY_REDUCE"] = "0"
-        D.arm_early_reduce(True, flat2)
+        D.arm_early_reduce(True)
         off = not D.early_reduce_armed() and D.early_allreduce(flat2, 0, 5) is False
         os.environ.pop("MMIF_EARLY_REDUCE")
         q.put((rank, ok, ok2, off))
