@@ -292,6 +292,10 @@ int mmif_maxpool2x2_bwd(const mmif_tensor* x, const mmif_tensor* g, const mmif_t
 int mmif_upsample2x_fwd(const mmif_tensor* x, const mmif_tensor* y, void* stream);
 int mmif_upsample2x_bwd(const mmif_tensor* g, const mmif_tensor* gx, int32_t accumulate, void* stream);
 int mmif_relu_mask(const mmif_tensor* x, const mmif_tensor* g, void* stream); /* g *= [x > 0], in place */
+/* the two backward kernels with that threshold_backward applied to what they write (the LAST contribution to the gradient of a ReLU
+ * output: the pool's own input x / the given x) -- saves the separate pass over the gradient */
+int mmif_maxpool2x2_bwd_relu(const mmif_tensor* x, const mmif_tensor* g, const mmif_tensor* gx, int32_t accumulate, void* stream);
+int mmif_upsample2x_bwd_relu(const mmif_tensor* g, const mmif_tensor* gx, int32_t accumulate, const mmif_tensor* x, void* stream);
 
 /* ---- losses (core/loss.py); images fp32 [n][h][w] ---- */
 size_t mmif_loss_workspace(int32_t n, int32_t h, int32_t w);

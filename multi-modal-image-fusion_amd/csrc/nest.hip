@@ -48,7 +48,7 @@ __global__ void maxpool_fwd_kernel(TV x, TV y) {
 
 // gx[input pixel] (+)= g[pool cell] if this pixel is the FIRST maximum of its cell (torch's tie rule), else 0
 template <typename T>
-__global__ void maxpool_bwd_kernel(TV x, TV g, TV gx, int accumulate) {
+__global__ void maxpool_bwd_kernel(TV x, TV g, TV gx, int accumulate, int relu_mask) {
     const long long total = (long long)x.n * x.cb * x.h * x.w;
     GRID_STRIDE(i, total) {
         int n, c, yi, xi;
@@ -79,6 +79,12 @@ __global__ void maxpool_bwd_kernel(TV x, TV g, TV gx, int accumulate) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) o[k] += old[k];
         }
+        if (relu_mask) {   // this was the last contribution to the gradient of the ReLU output x: threshold_backward here, not in a pass of its own
+            float xv[8];
+            ld<T>(x, n, c, yi, xi, xv);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = xv[k] > 0.f ? o[k] : 0.f;
+        }
         st<T>(gx, n, c, yi + gx.halo, xi + gx.halo, o);
     }
 }
@@ -102,7 +108,7 @@ __global__ void upsample_fwd_kernel(TV x, TV y) {
 
 // gx[i][j] (+)= sum of g over every y position that reads x[i][j]
 template <typename T>
-__global__ void upsample_bwd_kernel(TV g, TV gx, int accumulate) {
+__global__ void upsample_bwd_kernel(TV g, TV gx, int accumulate, TV xm, int relu_mask) {
     const int H2 = 2 * gx.h, W2 = 2 * gx.w;
     const int top = (g.h - H2) / 2, left = (g.w - W2) / 2;
     const long long total = (long long)gx.n * gx.cb * gx.h * gx.w;
@@ -130,6 +136,12 @@ __global__ void upsample_bwd_kernel(TV g, TV gx, int accumulate) {
             ld<T>(gx, n, c, yi + gx.halo, xi + gx.halo, old);
 #pragma unroll
             for (int k = 0; k < 8; ++k) o[k] += old[k];
+        }
+        if (relu_mask) {   // last contribution to the gradient of the ReLU output xm
+            float xv[8];
+            ld<T>(xm, n, c, yi, xi, xv);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = xv[k] > 0.f ? o[k] : 0.f;
         }
         st<T>(gx, n, c, yi + gx.halo, xi + gx.halo, o);
     }
@@ -342,7 +354,8 @@ extern "C" int mmif_maxpool2x2_fwd(const mmif_tensor* x, const mmif_tensor* y, v
     return check_launch("maxpool_fwd");
 }
 
-extern "C" int mmif_maxpool2x2_bwd(const mmif_tensor* x, const mmif_tensor* g, const mmif_tensor* gx, int32_t accumulate, void* stream) {
+static int maxpool2x2_bwd_impl(const mmif_tensor* x, const mmif_tensor* g, const mmif_tensor* gx, int32_t accumulate, int32_t relu_mask,
+                               void* stream) {
     if (int rc = validate_tensor(x, "x")) return rc;
     if (int rc = validate_tensor(g, "g")) return rc;
     if (int rc = validate_tensor(gx, "gx")) return rc;
@@ -350,8 +363,15 @@ extern "C" int mmif_maxpool2x2_bwd(const mmif_tensor* x, const mmif_tensor* g, c
                  "maxpool2x2_bwd: shape mismatch");
     hipStream_t st = (hipStream_t)stream;
     TV tx = make_tv(x), tg = make_tv(g), tgx = make_tv(gx);
-    LAUNCH_T(x->dtype, maxpool_bwd_kernel, grid_for((long long)tx.n * tx.cb * tx.h * tx.w), tx, tg, tgx, accumulate);
+    LAUNCH_T(x->dtype, maxpool_bwd_kernel, grid_for((long long)tx.n * tx.cb * tx.h * tx.w), tx, tg, tgx, accumulate, relu_mask);
     return check_launch("maxpool_bwd");
+}
+extern "C" int mmif_maxpool2x2_bwd(const mmif_tensor* x, const mmif_tensor* g, const mmif_tensor* gx, int32_t accumulate, void* stream) {
+    return maxpool2x2_bwd_impl(x, g, gx, accumulate, 0, stream);
+}
+// ... followed by gx *= [x > 0] (x, the pool's input, is a ReLU output and this was the last contribution to its gradient)
+extern "C" int mmif_maxpool2x2_bwd_relu(const mmif_tensor* x, const mmif_tensor* g, const mmif_tensor* gx, int32_t accumulate, void* stream) {
+    return maxpool2x2_bwd_impl(x, g, gx, accumulate, 1, stream);
 }
 
 extern "C" int mmif_upsample2x_fwd(const mmif_tensor* x, const mmif_tensor* y, void* stream) {
@@ -365,14 +385,26 @@ extern "C" int mmif_upsample2x_fwd(const mmif_tensor* x, const mmif_tensor* y, v
     return check_launch("upsample_fwd");
 }
 
-extern "C" int mmif_upsample2x_bwd(const mmif_tensor* g, const mmif_tensor* gx, int32_t accumulate, void* stream) {
+static int upsample2x_bwd_impl(const mmif_tensor* g, const mmif_tensor* gx, int32_t accumulate, const mmif_tensor* xmask, void* stream) {
     if (int rc = validate_tensor(g, "g")) return rc;
     if (int rc = validate_tensor(gx, "gx")) return rc;
     MMIF_REQUIRE(same_nc(g, gx) && g->h >= 2 * gx->h && g->w >= 2 * gx->w, "upsample2x_bwd: shape mismatch");
+    if (xmask != nullptr) {
+        if (int rc = validate_tensor(xmask, "x")) return rc;
+        MMIF_REQUIRE(same_nc(xmask, gx) && xmask->halo == 0 && xmask->h == gx->h && xmask->w == gx->w, "upsample2x_bwd_relu: x does not match gx");
+    }
     hipStream_t st = (hipStream_t)stream;
-    TV tg = make_tv(g), tgx = make_tv(gx);
-    LAUNCH_T(g->dtype, upsample_bwd_kernel, grid_for((long long)tgx.n * tgx.cb * tgx.h * tgx.w), tg, tgx, accumulate);
+    TV tg = make_tv(g), tgx = make_tv(gx), tm = make_tv(xmask != nullptr ? xmask : gx);
+    LAUNCH_T(g->dtype, upsample_bwd_kernel, grid_for((long long)tgx.n * tgx.cb * tgx.h * tgx.w), tg, tgx, accumulate, tm, xmask != nullptr ? 1 : 0);
     return check_launch("upsample_bwd");
+}
+extern "C" int mmif_upsample2x_bwd(const mmif_tensor* g, const mmif_tensor* gx, int32_t accumulate, void* stream) {
+    return upsample2x_bwd_impl(g, gx, accumulate, nullptr, stream);
+}
+// ... followed by gx *= [x > 0] (x: the ReLU output whose gradient gx is; this was its last contribution)
+extern "C" int mmif_upsample2x_bwd_relu(const mmif_tensor* g, const mmif_tensor* gx, int32_t accumulate, const mmif_tensor* x, void* stream) {
+    MMIF_REQUIRE(x != nullptr, "upsample2x_bwd_relu: x is NULL");
+    return upsample2x_bwd_impl(g, gx, accumulate, x, stream);
 }
 
 extern "C" int mmif_relu_mask(const mmif_tensor* x, const mmif_tensor* g, void* stream) {

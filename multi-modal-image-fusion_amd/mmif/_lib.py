@@ -127,6 +127,8 @@ SIGNATURES = {
     "mmif_upsample2x_fwd": (_i32, [_TP, _TP, _vp]),
     "mmif_upsample2x_bwd": (_i32, [_TP, _TP, _i32, _vp]),
     "mmif_relu_mask": (_i32, [_TP, _TP, _vp]),
+    "mmif_maxpool2x2_bwd_relu": (_i32, [_TP, _TP, _TP, _i32, _vp]),
+    "mmif_upsample2x_bwd_relu": (_i32, [_TP, _TP, _i32, _TP, _vp]),
     "mmif_loss_workspace": (_sz, [_i32, _i32, _i32]),
     "mmif_ssim_loss": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _sz, _vp]),
     "mmif_ssim_loss_mode_workspace": (_sz, [_i32, _i32, _i32, _i32]),

@@ -177,14 +177,11 @@ class NestEngine(ModelEngine):
 
         # order: DB1_3, DB2_2, DB1_2, DB3_1, DB1_1, DB2_1 (every gradient is complete when it is consumed)
         gi = db_bwd("DB1_3", gX13, (), (2,))                       # x1_2 slot: only consumer -> masked here
-        T.upsample_bwd(gi.view(0, uo[0]), GX22, False)
-        T.relu_mask_(X22, GX22)
+        T.upsample_bwd(gi.view(0, uo[0]), GX22, False, relu_of=X22)      # (the ReLU mask of x2_2 rides in its only contribution)
         gi = db_bwd("DB2_2", GX22.as_folded(), (), ())
-        T.upsample_bwd(gi.view(0, uo[1]), GX31, False)
-        T.relu_mask_(X31, GX31)
+        T.upsample_bwd(gi.view(0, uo[1]), GX31, False, relu_of=X31)
         gi = db_bwd("DB1_2", GR[0].as_folded().view(*slot(0, 2)), (0, 1), (1,))     # accumulate into f0, x1_1; x1_1 done -> mask
-        T.upsample_bwd(gi.view(0, uo[0]), GR[1].view(*slot(1, 1)), True)            # + DB2_2's contribution to x2_1
-        T.relu_mask_(R[1].view(*slot(1, 1)), GR[1].view(*slot(1, 1)))
+        T.upsample_bwd(gi.view(0, uo[0]), GR[1].view(*slot(1, 1)), True, relu_of=R[1].view(*slot(1, 1)))   # + DB2_2's contribution to x2_1: the last one -> mask
         gi = db_bwd("DB3_1", GX31.as_folded(), (), ())
         T.upsample_bwd(gi.view(0, uo[2]), GR[3], False)                             # gradient of the fused level-3 feature
         gi = db_bwd("DB1_1", GR[0].as_folded().view(*slot(0, 1)), (0,), ())
@@ -228,8 +225,9 @@ class NestEngine(ModelEngine):
                 s3, s1 = self.cb[l]
                 e = E[l].view(k * cb(c[l]), cb(c[l]))
                 ge = GE[l].view(k * cb(c[l]), cb(c[l]))
-                T.relu_mask_(e, ge)                        # all contributions (fusion + pool of level l+1) are in
-                ge = ge.as_folded()
+                if l == 3:
+                    T.relu_mask_(e, ge)                    # level 3 has the fusion's contribution only
+                ge = ge.as_folded()                        # (levels 0..2: masked by the max-pool backward of level l + 1 below, their last contribution)
                 hbuf = L.bufs[f"H{l}_{k}"]
                 x = L.bufs[f"A0_{k}"] if l == 0 else L.bufs[f"P{l}_{k}"]
                 self.c_wgrad(s1, hbuf, ge, ws, impl, acc_w)
@@ -241,5 +239,5 @@ class NestEngine(ModelEngine):
                     T.image_in_wgrad(img, ga0, ci.dw, ci.db, 16, ci.k, ws, acc_w)
                 else:
                     gp = self.c_dgrad(s3, gh, None, G(f"P{l}_{k}", c[l - 1], l), 0, 0, impl)
-                    T.maxpool_bwd(E[l - 1].view(k * cb(c[l - 1]), cb(c[l - 1])), gp, GE[l - 1].view(k * cb(c[l - 1]), cb(c[l - 1])), True)
+                    T.maxpool_bwd(E[l - 1].view(k * cb(c[l - 1]), cb(c[l - 1])), gp, GE[l - 1].view(k * cb(c[l - 1]), cb(c[l - 1])), True, relu=True)
         return grads

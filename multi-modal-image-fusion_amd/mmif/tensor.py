@@ -295,16 +295,22 @@ def maxpool_fwd(x, y):
     check(lib.mmif_maxpool2x2_fwd(x.d, y.d, stream_ptr()), "maxpool2x2_fwd")
 
 
-def maxpool_bwd(x, g, gx, accumulate):
-    check(lib.mmif_maxpool2x2_bwd(x.d, g.d, gx.d, int(accumulate), stream_ptr()), "maxpool2x2_bwd")
+def maxpool_bwd(x, g, gx, accumulate, relu=False):
+    """relu=True: also gx *= [x > 0] (x is a ReLU output and this is the last contribution to its gradient)"""
+    fn = lib.mmif_maxpool2x2_bwd_relu if relu else lib.mmif_maxpool2x2_bwd
+    check(fn(x.d, g.d, gx.d, int(accumulate), stream_ptr()), "maxpool2x2_bwd")
 
 
 def upsample_fwd(x, y):
     check(lib.mmif_upsample2x_fwd(x.d, y.d, stream_ptr()), "upsample2x_fwd")
 
 
-def upsample_bwd(g, gx, accumulate):
-    check(lib.mmif_upsample2x_bwd(g.d, gx.d, int(accumulate), stream_ptr()), "upsample2x_bwd")
+def upsample_bwd(g, gx, accumulate, relu_of=None):
+    """relu_of: the ReLU output whose gradient gx is -- gx *= [relu_of > 0] after this (last) contribution"""
+    if relu_of is not None:
+        check(lib.mmif_upsample2x_bwd_relu(g.d, gx.d, int(accumulate), relu_of.d, stream_ptr()), "upsample2x_bwd_relu")
+    else:
+        check(lib.mmif_upsample2x_bwd(g.d, gx.d, int(accumulate), stream_ptr()), "upsample2x_bwd")
 
 
 def relu_mask_(x, g):
