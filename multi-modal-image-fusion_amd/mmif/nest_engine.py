@@ -164,7 +164,8 @@ class NestEngine(ModelEngine):
             ghd = self.buf(L, "G_HD_" + name, n, s3.cout, hs[row][0], hs[row][1], dtype, dev, halo=1)
             self.c_wgrad(s1, hd, g, ws, impl)
             g_hd = self.c_dgrad(s1, g, hd, ghd, all_bits(ghd.cb), 0, impl)
-            T.upsample_fwd(src, R[row].view(0, uo[row]))          # re-materialise this block's U operand
+            if name not in ("DB1_3", "DB2_2", "DB3_1"):           # (the LAST block of a row in the forward order still finds its own U there)
+                T.upsample_fwd(src, R[row].view(0, uo[row]))      # re-materialise this block's U operand
             xin = self._row_in(L, row, nf)
             self.c_wgrad(s3, xin, g_hd, ws, impl)
             ab = mb = 0
