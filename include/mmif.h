@@ -262,6 +262,9 @@ int mmif_fuse_attn_fwd(const mmif_tensor* a, const mmif_tensor* b, const mmif_te
 int mmif_fuse_attn_bwd(const mmif_tensor* a, const mmif_tensor* b, const mmif_tensor* g, const mmif_tensor* ga,
                        const mmif_tensor* gb, int32_t mode, int32_t accumulate, void* workspace, size_t workspace_bytes,
                        void* stream);
+/* ... when `workspace` still holds what mmif_fuse_attn_fwd left there for the same a, b, mode: the channel sums are reused */
+int mmif_fuse_attn_bwd_cached(const mmif_tensor* a, const mmif_tensor* b, const mmif_tensor* g, const mmif_tensor* ga, const mmif_tensor* gb,
+                              int32_t mode, int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- PFNetv2's self-learned fusion (core/model.py:120-124,134-141): the conv stack ConvLayer(2,2) -> ConvLayer(2,2) ->
  *      ConvLayer(2,1,act=None) applied to every channel pair (feat1[:,i], feat2[:,i]) with SHARED weights.  One "pair conv"

@@ -456,9 +456,9 @@ extern "C" int mmif_fuse_attn_fwd(const mmif_tensor* a, const mmif_tensor* b, co
     return check_launch("attn_fwd");
 }
 
-extern "C" int mmif_fuse_attn_bwd(const mmif_tensor* a, const mmif_tensor* b, const mmif_tensor* g, const mmif_tensor* ga,
-                                  const mmif_tensor* gb, int32_t mode, int32_t accumulate, void* workspace, size_t workspace_bytes,
-                                  void* stream) {
+static int fuse_attn_bwd_impl(const mmif_tensor* a, const mmif_tensor* b, const mmif_tensor* g, const mmif_tensor* ga,
+                              const mmif_tensor* gb, int32_t mode, int32_t accumulate, void* workspace, size_t workspace_bytes,
+                              void* stream, bool cached) {
     if (int rc = validate_tensor(a, "a")) return rc;
     if (int rc = validate_tensor(b, "b")) return rc;
     if (int rc = validate_tensor(g, "g")) return rc;
@@ -484,10 +484,12 @@ extern "C" int mmif_fuse_attn_bwd(const mmif_tensor* a, const mmif_tensor* b, co
         const int cnt = a->n * a->cb * 8;
         float* part = csum + (size_t)cnt * 3;
         const dim3 grid(ta.n * ta.cb, PS_SLICES);
-        if (a->dtype == MMIF_F32) hipLaunchKernelGGL((plane_sums_kernel<float, 0>), grid, dim3(256), 0, st, ta, tb, ta, part);
-        else hipLaunchKernelGGL((plane_sums_kernel<bf16_t, 0>), grid, dim3(256), 0, st, ta, tb, ta, part);
-        hipLaunchKernelGGL(plane_sums_finish, dim3((cnt * 2 + 255) / 256), dim3(256), 0, st, part, csum, cnt * 2);
-        hipLaunchKernelGGL(attn_coef_kernel, dim3((cnt + 255) / 256), dim3(256), 0, st, csum, coef, cnt, 1.f / ((float)a->h * a->w));
+        if (!cached) {   // (cached: csum / coef of these a, b are still in the workspace from mmif_fuse_attn_fwd)
+            if (a->dtype == MMIF_F32) hipLaunchKernelGGL((plane_sums_kernel<float, 0>), grid, dim3(256), 0, st, ta, tb, ta, part);
+            else hipLaunchKernelGGL((plane_sums_kernel<bf16_t, 0>), grid, dim3(256), 0, st, ta, tb, ta, part);
+            hipLaunchKernelGGL(plane_sums_finish, dim3((cnt * 2 + 255) / 256), dim3(256), 0, st, part, csum, cnt * 2);
+            hipLaunchKernelGGL(attn_coef_kernel, dim3((cnt + 255) / 256), dim3(256), 0, st, csum, coef, cnt, 1.f / ((float)a->h * a->w));
+        }
         if (a->dtype == MMIF_F32) hipLaunchKernelGGL((plane_sums_kernel<float, 1>), grid, dim3(256), 0, st, ta, tb, tg, part);
         else hipLaunchKernelGGL((plane_sums_kernel<bf16_t, 1>), grid, dim3(256), 0, st, ta, tb, tg, part);
         hipLaunchKernelGGL(plane_sums_finish, dim3((cnt + 255) / 256), dim3(256), 0, st, part, gsum, cnt);
@@ -495,4 +497,17 @@ extern "C" int mmif_fuse_attn_bwd(const mmif_tensor* a, const mmif_tensor* b, co
     }
     LAUNCH_T(a->dtype, attn_bwd_kernel, grid_for((long long)ta.n * ta.h * ta.w), ta, tb, tg, tga, tgb, coef, gsum, m, accumulate);
     return check_launch("attn_bwd");
+}
+
+extern "C" int mmif_fuse_attn_bwd(const mmif_tensor* a, const mmif_tensor* b, const mmif_tensor* g, const mmif_tensor* ga,
+                                  const mmif_tensor* gb, int32_t mode, int32_t accumulate, void* workspace, size_t workspace_bytes,
+                                  void* stream) {
+    return fuse_attn_bwd_impl(a, b, g, ga, gb, mode, accumulate, workspace, workspace_bytes, stream, false);
+}
+// the same when `workspace` is the buffer mmif_fuse_attn_fwd ran on for these a, b (same mode) and nothing has written it since: the
+// channel sums and coefficients are reused instead of recomputed (one pass over a and b less)
+extern "C" int mmif_fuse_attn_bwd_cached(const mmif_tensor* a, const mmif_tensor* b, const mmif_tensor* g, const mmif_tensor* ga,
+                                         const mmif_tensor* gb, int32_t mode, int32_t accumulate, void* workspace, size_t workspace_bytes,
+                                         void* stream) {
+    return fuse_attn_bwd_impl(a, b, g, ga, gb, mode, accumulate, workspace, workspace_bytes, stream, true);
 }

@@ -118,6 +118,7 @@ SIGNATURES = {
     "mmif_fuse_attn_workspace": (_sz, [_i32, _i32]),
     "mmif_fuse_attn_fwd": (_i32, [_TP, _TP, _TP, _i32, _vp, _sz, _vp]),
     "mmif_fuse_attn_bwd": (_i32, [_TP, _TP, _TP, _TP, _TP, _i32, _i32, _vp, _sz, _vp]),
+    "mmif_fuse_attn_bwd_cached": (_i32, [_TP, _TP, _TP, _TP, _TP, _i32, _i32, _vp, _sz, _vp]),
     "mmif_pairconv_fwd": (_i32, [_TP, _TP, _vp, _vp, _i32, _TP, _TP, _i32, _TP, _TP, _vp]),
     "mmif_pairconv_dgrad": (_i32, [_TP, _TP, _vp, _i32, _TP, _TP, _TP, _TP, _u64, _TP, _vp]),
     "mmif_pairconv_wgrad_workspace": (_sz, []),

@@ -66,8 +66,9 @@ class NestEngine(ModelEngine):
         L.hs = hs
         B = lambda name, ch, lvl, halo=0: self.buf(L, name, n, ch, hs[lvl][0], hs[lvl][1], dtype, dev, halo)
         cb = lambda ch: ch // 8
-        if self._attn_ws is None or self._attn_ws.device != dev or self._attn_ws.numel() < n * c[3] * 3 + 8:
-            self._attn_ws = T.attn_workspace(n, c[3], dev)
+        # one attention workspace per level, owned by the lease: the backward reuses the channel sums its forward left there
+        if getattr(L, "attn_ws", None) is None or L.attn_ws[0].device != dev:
+            L.attn_ws = [T.attn_workspace(n, c[l], dev) for l in range(4)]
         # ---- encoders (shared weights), features into E_l = [img1 | img2]
         E = [B(f"E{l}", 2 * c[l], l) for l in range(4)]
         for k, img in enumerate((img1, img2)):
@@ -93,7 +94,7 @@ class NestEngine(ModelEngine):
         for l in range(4):
             e1, e2 = E[l].view(0, cb(c[l])), E[l].view(cb(c[l]), cb(c[l]))
             if not self.rfn:
-                T.attn_fwd(e1, e2, fslot[l], T.ATTN_MODES["sca"], self._attn_ws)
+                T.attn_fwd(e1, e2, fslot[l], T.ATTN_MODES["sca"], L.attn_ws[l])
             else:
                 r = self.rfns[l]
                 res = B(f"RES{l}", c[l], l)
@@ -199,7 +200,7 @@ class NestEngine(ModelEngine):
             e1, e2 = E[l].view(0, cb(c[l])), E[l].view(cb(c[l]), cb(c[l]))
             g1, g2 = GE[l].view(0, cb(c[l])), GE[l].view(cb(c[l]), cb(c[l]))
             if not self.rfn:
-                T.attn_bwd(e1, e2, gf[l], g1, g2, T.ATTN_MODES["sca"], False, self._attn_ws)
+                T.attn_bwd(e1, e2, gf[l], g1, g2, T.ATTN_MODES["sca"], False, L.attn_ws[l], cached=True)
             else:
                 r = self.rfns[l]
                 res, fc = L.bufs[f"RES{l}"], L.bufs[f"FC{l}"]

@@ -328,8 +328,10 @@ def attn_fwd(a, b, out, mode, ws):
     check(lib.mmif_fuse_attn_fwd(a.d, b.d, out.d, mode, _ptr(ws), ws.numel() * 4, stream_ptr()), "fuse_attn_fwd")
 
 
-def attn_bwd(a, b, g, ga, gb, mode, accumulate, ws):
-    check(lib.mmif_fuse_attn_bwd(a.d, b.d, g.d, ga.d, gb.d, mode, int(accumulate), _ptr(ws), ws.numel() * 4, stream_ptr()), "fuse_attn_bwd")
+def attn_bwd(a, b, g, ga, gb, mode, accumulate, ws, cached=False):
+    """cached=True: ws is the workspace attn_fwd ran on for these a, b, mode and has not been written since (channel sums reused)"""
+    fn = lib.mmif_fuse_attn_bwd_cached if cached else lib.mmif_fuse_attn_bwd
+    check(fn(a.d, b.d, g.d, ga.d, gb.d, mode, int(accumulate), _ptr(ws), ws.numel() * 4, stream_ptr()), "fuse_attn_bwd")
 
 
 def _d(t):
