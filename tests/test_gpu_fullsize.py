@@ -161,3 +161,69 @@ def test_encoder_round2_kernels_at_full_size():
         assert torch.equal(res["1"][:, 6:], res["0"][:, 6:])               # g3 is an input
         d = (res["1"] - res["0"]).abs().max().item() / res["0"].abs().max().item()
         assert d < 3e-2, d
+
+
+def test_decoder_round2_kernels_at_full_size():
+    """B=32 256x256 (config 2), the wide decoder layers' backward through sign bytes and the thin layers' fused backward, against the
+    separate kernels they replace -- properties that need no CPU reference: decode.1 (128 -> 64, every block masked) and decode.0
+    (128 -> 128, PFNetv1's partial mask) give the SAME bits for gx / dW / db as mmif_conv2d_reflect_wgrad + _dgrad_folded reading the
+    activations; the sign bytes equal [x > 0] of the whole tensor; weight gradients are exactly linear under a power-of-two scaling of
+    the gradient; the DenseFuse chain's accumulate-onto-another-tensor form equals copy + accumulate bit for bit."""
+    from mmif import tensor as T
+    from mmif._lib import IMPL_MFMA
+    B, S = 32, 256
+    dev = torch.device("cuda", 0)
+    with dtype_ctx("bf16"):
+        g = torch.Generator().manual_seed(21)
+        for cin, cout, mb in ((128, 64, (1 << 16) - 1), (128, 128, (1 << 6) | (1 << 7) | (1 << 14) | (1 << 15))):
+            x = T.BT.alloc(B, cin, S, S, torch.bfloat16, dev)
+            x.buf.copy_(torch.relu(torch.randn(x.buf.shape, generator=g)).to(dev))
+            gy = T.BT.alloc(B, cout, S, S, torch.bfloat16, dev, halo=1, zero=True)
+            gy.buf[:, :, 1:-1, 1:-1].copy_(torch.randn(B, cout // 8, S, S, 8, generator=g).to(dev))
+            gy = gy.as_folded()
+            wgt = (torch.randn(cout, cin, 3, 3, generator=g) * 0.03).to(dev)
+            pk = T.PackedWeights(cout, cin, 3, dev)
+            pk.pack(wgt)
+            ws = torch.empty(T.wgrad_workspace_bytes(cin, cout, 3) // 4 + 1, dtype=torch.float32, device=dev)
+            signs = torch.empty(T.bwd_wide_signs_bytes(B, cin, S, S), dtype=torch.uint8, device=dev)
+            gx_a = T.BT.alloc(B, cin, S, S, torch.bfloat16, dev, halo=1, zero=True)
+            dw_a, db_a = torch.zeros(cout, cin, 3, 3, device=dev), torch.zeros(cout, device=dev)
+            T.conv_bwd_wide(gy, x, gx_a, dw_a, db_a, cin, cout, 3, pk, mb, ws, signs)
+            gx_b = T.BT.alloc(B, cin, S, S, torch.bfloat16, dev, halo=1, zero=True)
+            dw_b, db_b = torch.zeros_like(dw_a), torch.zeros_like(db_a)
+            T.conv_wgrad(x, gy, dw_b, db_b, cin, cout, 3, ws, False, IMPL_MFMA)
+            T.conv_dgrad(gy, wgt, x, gx_b, cin, cout, 3, mb, 0, pk, IMPL_MFMA, fold=True)
+            torch.cuda.synchronize()
+            assert torch.equal(gx_a.buf.view(torch.int16), gx_b.buf.view(torch.int16)), (cin, cout)
+            assert torch.equal(dw_a, dw_b) and torch.equal(db_a, db_b)
+            pitch = (S // 16 + 2) * 16
+            sg = signs.view(B, cin // 8, S + 2, pitch)[:, :, 1:S + 1, 16:16 + S]
+            want = ((x.buf.float() > 0).to(torch.int32) << torch.arange(8, device=dev, dtype=torch.int32)).sum(-1).to(torch.uint8)
+            assert torch.equal(sg, want)
+            gy2 = T.BT.alloc(B, cout, S, S, torch.bfloat16, dev, halo=1, zero=True)          # linearity: g -> 4 g  =>  dW -> 4 dW exactly
+            gy2.buf.copy_(gy.buf * 4)
+            dw_c, db_c = torch.zeros_like(dw_a), torch.zeros_like(db_a)
+            T.conv_bwd_wide(gy2.as_folded(), x, gx_a, dw_c, db_c, cin, cout, 3, pk, mb, ws, signs)
+            torch.cuda.synchronize()
+            assert torch.equal(dw_c, dw_a * 4) and torch.equal(db_c, db_a * 4)
+            del x, gy, gy2, gx_a, gx_b, signs
+        # accumulate-onto-another-tensor (the DenseFuse chain's form) == copy + accumulate, bit for bit
+        gsrc = T.BT.alloc(B, 48, S, S, torch.bfloat16, dev, halo=1, zero=True)
+        gsrc.buf[:, :, 1:-1, 1:-1].copy_(torch.randn(B, 6, S, S, 8, generator=g).to(dev))
+        gsrc = gsrc.as_folded()
+        xk = T.BT.alloc(B, 16, S, S, torch.bfloat16, dev)
+        xk.buf.copy_(torch.relu(torch.randn(xk.buf.shape, generator=g)).to(dev))
+        old = T.BT.alloc(B, 16, S, S, torch.bfloat16, dev, halo=1, zero=True)
+        old.buf[:, :, 1:-1, 1:-1].copy_(torch.randn(B, 2, S, S, 8, generator=g).to(dev))
+        old = old.as_folded()
+        wv = (torch.randn(48, 16, 3, 3, generator=g) * 0.05).to(dev)      # virtual stacked layer 16 -> 48 (its dgrad maps 48 -> 16)
+        pkv = T.PackedWeights(48, 16, 3, dev)
+        pkv.pack(wv)
+        dst_a = T.BT.alloc(B, 16, S, S, torch.bfloat16, dev, halo=1, zero=True)
+        assert T.dgrad_onto_supported(gsrc, dst_a, 16, 48, 3)
+        T.conv_dgrad_onto(gsrc, xk, old, dst_a, 16, 48, 3, 0b11, 0b11, pkv)
+        dst_b = T.BT.alloc(B, 16, S, S, torch.bfloat16, dev, halo=1, zero=True)
+        dst_b.buf.copy_(old.buf)
+        T.conv_dgrad(gsrc, None, xk, dst_b.as_folded(), 16, 48, 3, 0b11, 0b11, pkv, IMPL_MFMA, fold=True)
+        torch.cuda.synchronize()
+        assert torch.equal(dst_a.buf.view(torch.int16), dst_b.buf.view(torch.int16))
