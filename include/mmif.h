@@ -287,6 +287,13 @@ size_t mmif_pairconv_wgrad_workspace(void);
 int mmif_pairconv_wgrad(const mmif_tensor* xa, const mmif_tensor* xb, const mmif_tensor* ga, const mmif_tensor* gb,
                         int32_t nout, float* dw, float* db, int32_t accumulate, void* workspace, size_t workspace_bytes,
                         void* stream);
+/* mmif_pairconv_dgrad + mmif_pairconv_wgrad of one layer in ONE pass (they read the same two tensors: ga/gb and xa/xb):
+ * gxa/gxb bit-identical to mmif_pairconv_dgrad, dw/db equal to mmif_pairconv_wgrad up to fp32 summation order.  xa/xb are
+ * always required (the weight gradient's operand); the workspace is mmif_pairconv_wgrad_workspace() bytes. */
+int mmif_pairconv_bwd(const mmif_tensor* ga, const mmif_tensor* gb, const float* w, int32_t nout, const mmif_tensor* xa,
+                      const mmif_tensor* xb, const mmif_tensor* gxa, const mmif_tensor* gxb, uint64_t mask_bits,
+                      const mmif_tensor* add, float* dw, float* db, int32_t accumulate, void* workspace,
+                      size_t workspace_bytes, void* stream);
 
 /* ---- NestFuse glue: nn.MaxPool2d(2,2) (core/model.py:332-335), nn.Upsample(x2,'nearest') + ReflectionPad2d to the
  *      skip's shape (core/block.py:965-991), threshold_backward of a ReLU output ---- */

@@ -78,6 +78,42 @@ __device__ inline void drop_tile(const uint4 (&r)[PSL][Quads<T>::NQ], uint4* __r
     }
 }
 
+// the same two phases for any operand: REFLECT as in stage_tile; returns the in-image bits of this thread's PSL slots
+template <typename T, bool REFLECT>
+__device__ inline unsigned fetch_tile(const TV& t, int n, int c, int y0, int x0, uint4 (&r)[PSL][Quads<T>::NQ]) {
+    unsigned okm = 0;
+#pragma unroll
+    for (int i = 0; i < PSL; ++i) {
+        const int e = min((int)threadIdx.x + 256 * i, PLN - 1);
+        int y = y0 - 1 + e / PTP, x = x0 - 1 + e % PTP;
+        bool ok = true;
+        if (REFLECT) {
+            y = reflect_idx(y, t.h);
+            x = reflect_idx(x, t.w);
+        } else {
+            ok = y >= 0 && y < t.h && x >= 0 && x < t.w;
+        }
+        y = min(max(y, 0), t.h - 1);
+        x = min(max(x, 0), t.w - 1);
+        const uint4* p = reinterpret_cast<const uint4*>(t.base + t.gidx(n, c, y + t.halo, x + t.halo) * Elem<T>::gran_bytes);
+#pragma unroll
+        for (int q = 0; q < Quads<T>::NQ; ++q) r[i][q] = p[q];
+        okm |= (ok ? 1u : 0u) << i;
+    }
+    return okm;
+}
+template <typename T>
+__device__ inline void drop_tile_masked(const uint4 (&r)[PSL][Quads<T>::NQ], unsigned okm, uint4* __restrict__ s) {
+#pragma unroll
+    for (int i = 0; i < PSL; ++i) {
+        const int e = threadIdx.x + 256 * i;
+        if (e < PLN) {
+#pragma unroll
+            for (int q = 0; q < Quads<T>::NQ; ++q) s[q * PLN + e] = ((okm >> i) & 1u) ? r[i][q] : make_uint4(0, 0, 0, 0);
+        }
+    }
+}
+
 template <typename T>
 __device__ inline void tile_read(const uint4* __restrict__ s, int idx, f32x2 (&v)[4]) {
     if (Quads<T>::NQ == 1) {
@@ -243,6 +279,7 @@ __global__ __launch_bounds__(256) void pairconv_dgrad_kernel(TV ga, TV gb, const
 // dw[o][c][tap] = sum over (n, channel, p) of g_o[p] * reflect_pad(x_c)[p + tap - 1];  db[o] = sum g_o.
 // Persistent blocks walking tiles, NOUT*19 register accumulators per thread, block reduction -> partial[block][NOUT*19].
 constexpr int PAIR_WG_BLOCKS = 2048;
+constexpr int PAIR_BWD_BLOCKS = 2048;
 
 template <typename T, int NOUT>
 __global__ __launch_bounds__(256, 4) void pairconv_wgrad_kernel(TV xa, TV xb, TV ga, TV gb, float* __restrict__ partial, int tiles_x,
@@ -328,6 +365,238 @@ __global__ __launch_bounds__(256) void pairconv_wgrad_reduce(const float* __rest
     if (threadIdx.x == 0) {
         float* dst = e < nout * 18 ? dw + e : db + (e - nout * 18);
         *dst = accumulate ? *dst + tot : tot;
+    }
+}
+
+// ---- backward of one pair-conv layer in ONE pass: the dgrad above and the wgrad above read the same two tensors (the layer's
+// output gradient g and its input x: taps for one, ReLU mask for the other), so apart they move 10 tensor passes through HBM and
+// together 6.  Persistent blocks walk 16x16 tiles of gx's STORED domain [h+2][w+2]; thread (ty, tx) owns padded position
+// p = (y0 + ty - 1, x0 + tx - 1): it writes gx_a/gx_b[p] and, when p is inside the image, adds g[p] * reflect_pad(x)[p + tap - 1]
+// to its NOUT*19 accumulators.  bf16 storage: the weight-gradient products run as v_dot2c_f32_bf16 on the raw granules (two
+// channels per instruction, no unpacking: the products are exact in fp32 either way); the dgrad keeps fp32 weights.
+template <typename T>
+__device__ inline void unpack_gran(const uint4 (&r)[Quads<T>::NQ], float (&v)[8]) {
+    if (Quads<T>::NQ == 1) {
+        const uint32_t w[4] = {r[0].x, r[0].y, r[0].z, r[0].w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+    } else {
+        const uint4 a = r[0], b = r[Quads<T>::NQ - 1];
+        const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = __uint_as_float(w[i]);
+    }
+}
+template <bool BF> struct WAcc;
+template <> struct WAcc<true> {
+    typedef float type;
+    static __device__ inline float zero() { return 0.f; }
+    static __device__ inline float hsum(float v) { return v; }
+};
+template <> struct WAcc<false> {
+    typedef f32x2 type;
+    static __device__ inline f32x2 zero() { return splat(0.f); }
+    static __device__ inline float hsum(f32x2 v) { return v.x + v.y; }
+};
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ inline float dot2_bf16(uint32_t a, uint32_t b, float c) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), c, false);
+}
+__device__ inline float dot8_bf16(const uint4& a, const uint4& b, float c) {
+    return dot2_bf16(a.w, b.w, dot2_bf16(a.z, b.z, dot2_bf16(a.y, b.y, dot2_bf16(a.x, b.x, c))));
+}
+
+template <typename T, int NOUT>
+__global__ __launch_bounds__(256, Quads<T>::NQ == 1 ? 3 : 2) void pairconv_bwd_kernel(TV ga, TV gb, const float* __restrict__ w, TV xa, TV xb, TV gxa, TV gxb,
+                                                              unsigned long long mask_bits, TV add, int has_add,
+                                                              float* __restrict__ partial, int tiles_x, int tiles_y, unsigned ntiles) {
+    constexpr int PER = NOUT * 19;
+    constexpr int NQ = Quads<T>::NQ;
+    constexpr bool BF = NQ == 1;
+    typedef typename WAcc<BF>::type acc_t;
+    __shared__ __attribute__((aligned(16))) uint4 s_g[NOUT][NQ * PLN], s_x[2][NQ * PLN];
+    __shared__ float red[4][PER];
+    acc_t acc[NOUT][2][9], accb[NOUT];
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+        accb[o] = WAcc<BF>::zero();
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[o][0][t] = acc[o][1][t] = WAcc<BF>::zero();
+    }
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    // two-phase staging: the next tile's 4 operand windows (and this thread's granule of the residual gradient) are in flight
+    // in registers while this tile is consumed.  Addresses = wave-uniform plane base + a 32-bit in-plane offset that ga/gb and
+    // xa/xb share (the C ABI checks equal shapes and halos).
+    constexpr unsigned GB = Elem<T>::gran_bytes;
+    uint4 rg[NOUT][PSL][NQ], rx[2][PSL][NQ], radd[NQ];
+    unsigned okm = 0;
+    int ei[PSL], ej[PSL];
+#pragma unroll
+    for (int k = 0; k < PSL; ++k) {
+        const int e = min((int)threadIdx.x + 256 * k, PLN - 1);
+        ei[k] = e / PTP;
+        ej[k] = e - ei[k] * PTP;
+    }
+    const int H = ga.h, W = ga.w;
+    auto fetch = [&](unsigned tile) {
+        const TileId tn = tile_of(tile, tiles_x, tiles_y, gxa.cb);
+        const char* pga = ga.base + ((long long)tn.n * ga.img + (long long)(ga.cb_off + tn.c) * ga.plane) * GB;
+        const char* pgb = gb.base + ((long long)tn.n * gb.img + (long long)(gb.cb_off + tn.c) * gb.plane) * GB;
+        const char* pxa = xa.base + ((long long)tn.n * xa.img + (long long)(xa.cb_off + tn.c) * xa.plane) * GB;
+        const char* pxb = xb.base + ((long long)tn.n * xb.img + (long long)(xb.cb_off + tn.c) * xb.plane) * GB;
+        okm = 0;
+        // slot (i, j) <-> logical (y0 - 2 + i, x0 - 2 + j): g zero outside the image, x reflected
+#pragma unroll
+        for (int k = 0; k < PSL; ++k) {
+            const int y = tn.y0 - 2 + ei[k], x = tn.x0 - 2 + ej[k];
+            const bool ok = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+            const unsigned og = (unsigned)((min(max(y, 0), H - 1) + ga.halo) * ga.ws + min(max(x, 0), W - 1) + ga.halo) * GB;
+            const unsigned ox = (unsigned)(min(max(reflect_idx(y, H), 0), H - 1) * xa.ws + min(max(reflect_idx(x, W), 0), W - 1)) * GB;
+            okm |= (ok ? 1u : 0u) << k;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                rg[0][k][q] = *reinterpret_cast<const uint4*>(pga + og + 16 * q);
+                if (NOUT == 2) rg[NOUT - 1][k][q] = *reinterpret_cast<const uint4*>(pgb + og + 16 * q);
+                rx[0][k][q] = *reinterpret_cast<const uint4*>(pxa + ox + 16 * q);
+                rx[1][k][q] = *reinterpret_cast<const uint4*>(pxb + ox + 16 * q);
+            }
+        }
+        if (has_add) {   // halo 0 or folded (ring zeroed): the stored value at the clamped position, masked by bit 2 of okm
+            const int y = tn.y0 + ty - 1, x = tn.x0 + tx - 1;
+            const bool ok = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+            const char* pad = add.base + ((long long)tn.n * add.img + (long long)(add.cb_off + tn.c) * add.plane) * GB;
+            const unsigned oa = (unsigned)((min(max(y, 0), H - 1) + add.halo) * add.ws + min(max(x, 0), W - 1) + add.halo) * GB;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) radd[q] = *reinterpret_cast<const uint4*>(pad + oa + 16 * q);
+            okm |= (ok ? 1u : 0u) << 2;
+        }
+    };
+    if (blockIdx.x < ntiles) fetch(blockIdx.x);
+    for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const TileId ti = tile_of(tile, tiles_x, tiles_y, gxa.cb);
+        const int n = ti.n, c = ti.c;
+        __syncthreads();
+        drop_tile_masked<T>(rg[0], okm, s_g[0]);
+        if (NOUT == 2) drop_tile_masked<T>(rg[NOUT - 1], okm, s_g[NOUT - 1]);
+        drop_tile_masked<T>(rx[0], 3u, s_x[0]);
+        drop_tile_masked<T>(rx[1], 3u, s_x[1]);
+        __syncthreads();
+        float addv[8];
+        const bool add_ok = (okm >> 2) & 1u;
+        if (has_add) unpack_gran<T>(radd, addv);
+        if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x);
+        const int ys = ti.y0 + ty, xs = ti.x0 + tx;
+        if (ys >= gxa.hs || xs >= gxa.ws) continue;
+        const int py = ys - 1, px = xs - 1;
+        const int ctr = (ty + 1) * PTP + tx + 1;
+        {
+            f32x2 pa[4], pb[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pa[k] = pb[k] = splat(0.f);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int idx = (ty + 2 - t / 3) * PTP + tx + 2 - t % 3;   // g at p - tap + 1
+                f32x2 g0[4], g1[4];
+                tile_read<T>(s_g[0], idx, g0);
+                if (NOUT == 2) tile_read<T>(s_g[NOUT - 1], idx, g1);
+                const f32x2 w00 = splat(w[(0 * 2 + 0) * 9 + t]), w01 = splat(w[(0 * 2 + 1) * 9 + t]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    pa[k] = pk_fma(w00, g0[k], pa[k]);
+                    pb[k] = pk_fma(w01, g0[k], pb[k]);
+                }
+                if (NOUT == 2) {
+                    const f32x2 w10 = splat(w[(1 * 2 + 0) * 9 + t]), w11 = splat(w[(1 * 2 + 1) * 9 + t]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        pa[k] = pk_fma(w10, g1[k], pa[k]);
+                        pb[k] = pk_fma(w11, g1[k], pb[k]);
+                    }
+                }
+            }
+            float da[8], db[8];
+            unpack_pairs(pa, da);
+            unpack_pairs(pb, db);
+            if (has_add && add_ok) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { da[k] += addv[k]; db[k] += addv[k]; }
+            }
+            if ((mask_bits >> c) & 1ull) {   // x(R(p)) sits at the tile centre
+                f32x2 va[4], vb[4];
+                tile_read<T>(s_x[0], ctr, va);
+                tile_read<T>(s_x[1], ctr, vb);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    da[2 * k] = va[k].x > 0.f ? da[2 * k] : 0.f;
+                    da[2 * k + 1] = va[k].y > 0.f ? da[2 * k + 1] : 0.f;
+                    db[2 * k] = vb[k].x > 0.f ? db[2 * k] : 0.f;
+                    db[2 * k + 1] = vb[k].y > 0.f ? db[2 * k + 1] : 0.f;
+                }
+            }
+            Elem<T>::store(gxa.base + gxa.gidx(n, c, ys, xs) * Elem<T>::gran_bytes, da);
+            Elem<T>::store(gxb.base + gxb.gidx(n, c, ys, xs) * Elem<T>::gran_bytes, db);
+        }
+        if (py < 0 || py >= gxa.h || px < 0 || px >= gxa.w) continue;
+        if constexpr (BF) {
+            uint4 g[NOUT];
+            g[0] = s_g[0][ctr];
+            if (NOUT == 2) g[NOUT - 1] = s_g[NOUT - 1][ctr];
+            const uint4 ones = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) accb[o] = dot8_bf16(g[o], ones, accb[o]);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int idx = (ty + t / 3) * PTP + tx + t % 3;
+                const uint4 va = s_x[0][idx], vb = s_x[1][idx];
+#pragma unroll
+                for (int o = 0; o < NOUT; ++o) {
+                    acc[o][0][t] = dot8_bf16(g[o], va, acc[o][0][t]);
+                    acc[o][1][t] = dot8_bf16(g[o], vb, acc[o][1][t]);
+                }
+            }
+        } else {
+            f32x2 g[NOUT][4];
+            tile_read<T>(s_g[0], ctr, g[0]);
+            if (NOUT == 2) tile_read<T>(s_g[NOUT - 1], ctr, g[NOUT - 1]);
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) accb[o] += (g[o][0] + g[o][1]) + (g[o][2] + g[o][3]);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                f32x2 va[4], vb[4];
+                const int idx = (ty + t / 3) * PTP + tx + t % 3;
+                tile_read<T>(s_x[0], idx, va);
+                tile_read<T>(s_x[1], idx, vb);
+#pragma unroll
+                for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        acc[o][0][t] = pk_fma(g[o][k], va[k], acc[o][0][t]);
+                        acc[o][1][t] = pk_fma(g[o][k], vb[k], acc[o][1][t]);
+                    }
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                float v = WAcc<BF>::hsum(acc[o][cc][t]);
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+                if (lane == 0) red[wave][(o * 2 + cc) * 9 + t] = v;
+            }
+        float v = WAcc<BF>::hsum(accb[o]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) red[wave][NOUT * 18 + o] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < PER) {
+        const int e = threadIdx.x;
+        partial[(long long)blockIdx.x * PER + e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
     }
 }
 
@@ -447,4 +716,52 @@ extern "C" int mmif_pairconv_wgrad(const mmif_tensor* xa, const mmif_tensor* xb,
     PAIR_LAUNCH(xa->dtype, nout, pairconv_wgrad_kernel, G, txa, txb, tga, tgb, partial, tiles_x, tiles_y, (unsigned)ntiles);
     hipLaunchKernelGGL(pairconv_wgrad_reduce, dim3(nout * 19), dim3(256), 0, st, partial, G, nout * 19, nout, dw, db, accumulate);
     return check_launch("pairconv_wgrad");
+}
+
+// dgrad + wgrad of one pair-conv layer in one pass (pairconv_bwd_kernel): the arguments of mmif_pairconv_dgrad followed by the
+// outputs of mmif_pairconv_wgrad.  xa/xb are always required here (they are the weight gradient's operand).
+extern "C" int mmif_pairconv_bwd(const mmif_tensor* ga, const mmif_tensor* gb, const float* w, int32_t nout, const mmif_tensor* xa,
+                                 const mmif_tensor* xb, const mmif_tensor* gxa, const mmif_tensor* gxb, uint64_t mask_bits,
+                                 const mmif_tensor* add, float* dw, float* db, int32_t accumulate, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
+    if (int rc = validate_tensor(ga, "ga")) return rc;
+    if (int rc = validate_tensor(xa, "xa")) return rc;
+    if (int rc = validate_tensor(xb, "xb")) return rc;
+    if (int rc = validate_tensor(gxa, "gxa")) return rc;
+    if (int rc = validate_tensor(gxb, "gxb")) return rc;
+    MMIF_REQUIRE(nout == 1 || nout == 2, "pairconv_bwd: nout must be 1 or 2 (got %d)", nout);
+    MMIF_REQUIRE(w != nullptr && dw != nullptr && db != nullptr, "pairconv_bwd: w/dw/db is NULL");
+    MMIF_REQUIRE(same_shape(ga, gxa) && same_shape(ga, gxb) && gxa->halo == 1 && gxb->halo == 1, "pairconv_bwd: gx must be halo-1 views of g's shape");
+    MMIF_REQUIRE(same_shape(ga, xa) && same_shape(ga, xb) && xa->halo == 0 && xb->halo == 0, "pairconv_bwd: xa/xb shape mismatch");
+    MMIF_REQUIRE(ga->h >= 2 && ga->w >= 2, "pairconv_bwd: reflect padding needs h, w >= 2");
+    MMIF_REQUIRE(ga->halo == 0 || (ga->flags & MMIF_T_FOLDED), "pairconv_bwd: a halo-1 gradient must be folded first (mmif_fold_halo)");
+    if (nout == 2) {
+        MMIF_REQUIRE(gb != nullptr, "pairconv_bwd: gb is NULL with nout = 2");
+        if (int rc = validate_tensor(gb, "gb")) return rc;
+        MMIF_REQUIRE(same_shape(ga, gb), "pairconv_bwd: gb shape mismatch");
+        MMIF_REQUIRE(gb->halo == 0 || (gb->flags & MMIF_T_FOLDED), "pairconv_bwd: a halo-1 gradient must be folded first (mmif_fold_halo)");
+    }
+    if (add) {
+        if (int rc = validate_tensor(add, "add")) return rc;
+        MMIF_REQUIRE(same_shape(ga, add), "pairconv_bwd: add shape mismatch");
+        MMIF_REQUIRE(add->halo == 0 || (add->flags & MMIF_T_FOLDED), "pairconv_bwd: a halo-1 residual gradient must be folded first (mmif_fold_halo)");
+    }
+    MMIF_REQUIRE(nout == 1 || gb->halo == ga->halo, "pairconv_bwd: ga and gb must have the same halo");
+    MMIF_REQUIRE((long long)(ga->h + 2) * (ga->w + 2) * 32 < (1ll << 31), "pairconv_bwd: plane too large for 32-bit in-plane offsets");
+    if (workspace == nullptr || workspace_bytes < mmif_pairconv_wgrad_workspace()) {
+        set_error("pairconv_bwd: workspace too small");
+        return MMIF_EWORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    TV tga = make_tv(ga), tgb = make_tv(nout == 2 ? gb : ga), txa = make_tv(xa), txb = make_tv(xb);
+    TV tgxa = make_tv(gxa), tgxb = make_tv(gxb), tadd = make_tv(add ? add : ga);
+    const int tiles_x = cdiv(tgxa.ws, PT), tiles_y = cdiv(tgxa.hs, PT);
+    const long long ntiles = (long long)tgxa.n * tgxa.cb * tiles_x * tiles_y;
+    MMIF_REQUIRE(ntiles < (1ll << 31), "pairconv_bwd: too many tiles");
+    const int G = (int)(ntiles < PAIR_BWD_BLOCKS ? ntiles : PAIR_BWD_BLOCKS);
+    float* partial = (float*)workspace;
+    PAIR_LAUNCH(ga->dtype, nout, pairconv_bwd_kernel, G, tga, tgb, w, txa, txb, tgxa, tgxb, (unsigned long long)mask_bits, tadd, add ? 1 : 0,
+                partial, tiles_x, tiles_y, (unsigned)ntiles);
+    hipLaunchKernelGGL(pairconv_wgrad_reduce, dim3(nout * 19), dim3(256), 0, st, partial, G, nout * 19, nout, dw, db, accumulate);
+    return check_launch("pairconv_bwd");
 }

@@ -123,6 +123,7 @@ SIGNATURES = {
     "mmif_pairconv_dgrad": (_i32, [_TP, _TP, _vp, _i32, _TP, _TP, _TP, _TP, _u64, _TP, _vp]),
     "mmif_pairconv_wgrad_workspace": (_sz, []),
     "mmif_pairconv_wgrad": (_i32, [_TP, _TP, _TP, _TP, _i32, _vp, _vp, _i32, _vp, _sz, _vp]),
+    "mmif_pairconv_bwd": (_i32, [_TP, _TP, _vp, _i32, _TP, _TP, _TP, _TP, _u64, _TP, _vp, _vp, _i32, _vp, _sz, _vp]),
     "mmif_maxpool2x2_fwd": (_i32, [_TP, _TP, _vp]),
     "mmif_maxpool2x2_bwd": (_i32, [_TP, _TP, _TP, _i32, _vp]),
     "mmif_upsample2x_fwd": (_i32, [_TP, _TP, _vp]),

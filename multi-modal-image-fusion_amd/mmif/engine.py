@@ -678,6 +678,14 @@ class PFNetv2Engine(DenseFuseEngine):
         GH2 = self.buf(L, "GH2", n, 128, h, w, dtype, dev, halo=1)
         a, b = F.view(0, 8), F.view(8, 8)
         h1a, h1b, h2a, h2b = H1.view(0, 8), H1.view(8, 8), H2.view(0, 8), H2.view(8, 8)
+        if os.environ.get("MMIF_PAIR_BWD", "1") != "0":   # dgrad + wgrad of each layer in one pass (csrc/pair.hip pairconv_bwd_kernel)
+            T.pairconv_bwd(g, None, f2.w.detach(), 1, h2a, h2b, GH2.view(0, 8), GH2.view(8, 8), f2.dw, f2.db, ws, all_bits(8))
+            g2 = GH2.fold_halo_()
+            T.pairconv_bwd(g2.view(0, 8), g2.view(8, 8), f1.w.detach(), 2, h1a, h1b, GH1.view(0, 8), GH1.view(8, 8), f1.dw, f1.db, ws, all_bits(8))
+            g1 = GH1.fold_halo_()
+            T.pairconv_bwd(g1.view(0, 8), g1.view(8, 8), f0.w.detach(), 2, a, b, GF.view(0, 8), GF.view(8, 8), f0.dw, f0.db, ws, bits(6, 7), add=g)
+            GF.fold_halo_()
+            return
         # fuse.2 (2 -> 1, no activation): g is dL/d(fused features), not masked
         T.pairconv_wgrad(h2a, h2b, g, None, 1, f2.dw, f2.db, ws)
         T.pairconv_dgrad(g, None, f2.w.detach(), 1, h2a, h2b, GH2.view(0, 8), GH2.view(8, 8), all_bits(8))

@@ -355,6 +355,12 @@ def pairconv_wgrad(xa, xb, ga, gb, nout, dw, db, ws, accumulate=False):
                                   stream_ptr()), "pairconv_wgrad")
 
 
+def pairconv_bwd(ga, gb, w, nout, xa, xb, gxa, gxb, dw, db, ws, mask_bits=0, add=None, accumulate=False):
+    """pairconv_dgrad + pairconv_wgrad of one layer in one pass over (g, x)"""
+    check(lib.mmif_pairconv_bwd(ga.d, _d(gb), _ptr(w), nout, xa.d, xb.d, gxa.d, gxb.d, mask_bits, _d(add), _ptr(dw), _ptr(db), int(accumulate),
+                                _ptr(ws), ws.numel() * ws.element_size(), stream_ptr()), "pairconv_bwd")
+
+
 # ------------------------------------------------------------------ general ConvLayer primitives (plain NCHW fp32; row n4)
 def _f32c(t, name):
     require_device(t, name)

@@ -59,6 +59,8 @@ def test_c_abi_validation_of_the_widened_entry_points_without_gpu():
     assert b"folded first" in lib.mmif_last_error()
     assert lib.mmif_pairconv_wgrad(r(ok), r(ok), r(ok), None, 1, w, w, 0, None, 0, None) == -3            # workspace
     assert lib.mmif_pairconv_wgrad_workspace() > 0
+    assert lib.mmif_pairconv_bwd(r(ok), None, w, 1, r(ok), r(ok), r(h1), r(h1), 0, None, w, w, 0, None, 0, None) == -3   # workspace
+    assert lib.mmif_pairconv_bwd(r(ok), None, w, 2, r(ok), r(ok), r(h1), r(h1), 0, None, w, w, 0, None, 0, None) == -1   # gb missing
     f = (ctypes.c_float * 16)()
     assert lib.mmif_ssim_loss_mode(f, f, f, 1, 32, 32, 1.0, 1.0, 7, f, None, f, 1 << 20, None) == -1
     assert b"only supported ['ssim', 'w-ssim', 'ms-ssim', 'msw-ssim'] mode" in lib.mmif_last_error()
