@@ -211,6 +211,168 @@ __global__ __launch_bounds__(256, 4) void pairconv_fwd_kernel(TV a, TV b, const 
     if (NOUT == 2) Elem<T>::store(ob.base + ob.gidx(n, c, y, x) * Elem<T>::gran_bytes, out[NOUT - 1]);
 }
 
+// ---- bf16 forward with 1 x 4 output strips.  The kernel above is instruction bound (per output 144 v_pk_fma_f32 + 144 shift / and
+// operations that turn 18 bf16 granules into fp32 pairs + addressing: ~540 vector instructions, 263 us of issue time at B = 32 256^2):
+// neighbouring outputs unpack the same granules again.  Here a thread owns 4 consecutive outputs of a row and walks the 3 x 6 granule
+// window once (9 granule unpacks per output and operand instead of 18 for both), 32 x 32 output tiles (halo re-reads 1.13 x instead of
+// 1.27 x).  Taps are visited in the same order per output (row-major, a before b), so the results are bit-identical.
+// LDS: 34 x 34 window, columns interleaved mod 4 so that the j-th granule of the 8 strips of a row is contiguous (conflict-free
+// ds_read_b128), row pitch 40 granules = 640 B = 128 mod 256 so that the two rows of a 16-lane pass use disjoint banks.
+constexpr int FT = 32, FW = FT + 2, FQ = 9, FPITCH = 40;
+constexpr int FSL = (FW * FW + 255) / 256;   // staged granules per thread and operand (5)
+__device__ inline void unpack_q(const uint4& a, f32x2 (&v)[4]) {
+    const uint32_t w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (f32x2){__uint_as_float(w[i] << 16), __uint_as_float(w[i] & 0xffff0000u)};
+}
+
+template <int NOUT>
+__global__ __launch_bounds__(256, 3) void pairconv_fwd_strip_kernel(TV a, TV b, const float* __restrict__ w, const float* __restrict__ bias,
+                                                                    TV oa, TV ob, int relu, TV r1, TV r2, int has_res, int tiles_x, int tiles_y) {
+    typedef bf16_t T;
+    constexpr unsigned GB = 16;
+    __shared__ __attribute__((aligned(16))) uint4 s_a[FW * FPITCH], s_b[FW * FPITCH];
+    // 32-bit tile decode (wave-uniform)
+    const unsigned tile = blockIdx.x, utx = (unsigned)tiles_x, uty = (unsigned)tiles_y, ucb = (unsigned)a.cb;
+    const unsigned q1 = tile / utx, q2 = q1 / uty, q3 = q2 / ucb;
+    const int x0 = (int)(tile - q1 * utx) * FT, y0 = (int)(q1 - q2 * uty) * FT, c = (int)(q2 - q3 * ucb), n = (int)q3;
+    {   // stage both operands in one round trip: 2 * FSL loads in flight, one shared 32-bit in-plane offset per slot
+        const char* pa = a.base + ((long long)n * a.img + (long long)(a.cb_off + c) * a.plane) * GB;
+        const char* pb = b.base + ((long long)n * b.img + (long long)(b.cb_off + c) * b.plane) * GB;
+        uint4 ra[FSL], rb[FSL];
+        int slot[FSL];
+#pragma unroll
+        for (int k = 0; k < FSL; ++k) {
+            const int e = min((int)threadIdx.x + 256 * k, FW * FW - 1);
+            const int i = e / FW, jp = e - i * FW;
+            const int y = min(max(reflect_idx(y0 - 1 + i, a.h), 0), a.h - 1), x = min(max(reflect_idx(x0 - 1 + jp, a.w), 0), a.w - 1);
+            const unsigned off = (unsigned)(y * a.ws + x) * GB;
+            ra[k] = *reinterpret_cast<const uint4*>(pa + off);
+            rb[k] = *reinterpret_cast<const uint4*>(pb + off);
+            slot[k] = i * FPITCH + (jp & 3) * FQ + (jp >> 2);
+        }
+#pragma unroll
+        for (int k = 0; k < FSL; ++k)
+            if ((int)threadIdx.x + 256 * k < FW * FW) {
+                s_a[slot[k]] = ra[k];
+                s_b[slot[k]] = rb[k];
+            }
+    }
+    __syncthreads();
+    const int sx = threadIdx.x & 7, row = threadIdx.x >> 3;
+    const int y = y0 + row, xb0 = x0 + 4 * sx;
+    const bool active = y < a.h && xb0 < a.w;
+    f32x2 acc[NOUT][4][4];
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+        const float bo = bias ? bias[o] : 0.f;
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[o][p][k] = splat(bo);
+    }
+#pragma unroll 1   // (fully unrolled, the compiler hoists all 36 unpacked granules: spills)
+    for (int u = 0; u < 3; ++u) {
+        const int rb_ = (row + u) * FPITCH + sx;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {   // window column 4*sx + j feeds output p = j - v through tap column v
+            f32x2 va[4], vb[4];
+            unpack_q(s_a[rb_ + (j & 3) * FQ + (j >> 2)], va);
+            unpack_q(s_b[rb_ + (j & 3) * FQ + (j >> 2)], vb);
+#pragma unroll
+            for (int v = 2; v >= 0; --v) {
+                const int p = j - v;
+                if (p < 0 || p > 3) continue;
+#pragma unroll
+                for (int o = 0; o < NOUT; ++o) {
+                    const f32x2 wa = splat(w[(o * 2 + 0) * 9 + u * 3 + v]), wb = splat(w[(o * 2 + 1) * 9 + u * 3 + v]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[o][p][k] = pk_fma(wb, vb[k], pk_fma(wa, va[k], acc[o][p][k]));
+                }
+            }
+        }
+    }
+    // epilogue through LDS: a thread's 4 granules are 64 B apart from its neighbour's (every store instruction would write a quarter
+    // of 32 cache lines); drop them p-major into the (now free) windows and store rows of 32 granules = 4 whole lines instead.
+    // residuals that are other tensors (PFNetv2's last fuse layer: operands H2, residuals feat1 / feat2), one output: the tile goes
+    // through LDS in fp32 (channels 0-3 in one window, 4-7 in the other) and (out + r1) + r2 is formed in the row-contiguous phase
+    const bool lazy_res = NOUT == 1 && has_res == 1;
+    uint4 pk[NOUT + 1][4];
+    if (active) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            float out[NOUT][8];
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) {
+                unpack_pairs(acc[o][p], out[o]);
+                if (relu) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) out[o][k] = fmaxf(out[o][k], 0.f);
+                }
+            }
+            if (has_res == 2) {  // + feat1 + feat2 (core/model.py:141), added to output 0: the residuals ARE the operands, whose
+                                 // centre granules sit in the windows (window column 4*sx + p + 1, row + 1)
+                f32x2 ua[4], ub[4];
+                const int ctr = (row + 1) * FPITCH + sx + ((p + 1) & 3) * FQ + ((p + 1) >> 2);
+                unpack_q(s_a[ctr], ua);
+                unpack_q(s_b[ctr], ub);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    out[0][2 * k] = (out[0][2 * k] + ua[k].x) + ub[k].x;
+                    out[0][2 * k + 1] = (out[0][2 * k + 1] + ua[k].y) + ub[k].y;
+                }
+            } else if (has_res && !lazy_res && xb0 + p < a.w) {
+                float uu[8], vv[8];
+                Elem<T>::load(r1.base + r1.gidx(n, c, y, xb0 + p) * GB, uu);
+                Elem<T>::load(r2.base + r2.gidx(n, c, y, xb0 + p) * GB, vv);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) out[0][k] = (out[0][k] + uu[k]) + vv[k];
+            }
+            if (lazy_res) {   // fp32 halves: the residuals are added where they can be loaded a row at a time (below)
+                pk[0][p] = make_uint4(__float_as_uint(out[0][0]), __float_as_uint(out[0][1]), __float_as_uint(out[0][2]), __float_as_uint(out[0][3]));
+                pk[NOUT][p] = make_uint4(__float_as_uint(out[0][4]), __float_as_uint(out[0][5]), __float_as_uint(out[0][6]), __float_as_uint(out[0][7]));
+            } else {
+#pragma unroll
+                for (int o = 0; o < NOUT; ++o)
+                    pk[o][p] = make_uint4(pack_bf16x2(out[o][0], out[o][1]), pack_bf16x2(out[o][2], out[o][3]), pack_bf16x2(out[o][4], out[o][5]),
+                                          pack_bf16x2(out[o][6], out[o][7]));
+            }
+        }
+    }
+    __syncthreads();   // every wave is done with the operand windows
+    if (active) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            s_a[row * FPITCH + p * FQ + sx] = pk[0][p];
+            if (NOUT == 2) s_b[row * FPITCH + p * FQ + sx] = pk[NOUT - 1][p];
+            else if (lazy_res) s_b[row * FPITCH + p * FQ + sx] = pk[NOUT][p];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int e = threadIdx.x + 256 * k, r = e >> 5, col = e & 31;
+        const int yy = y0 + r, xx = x0 + col;
+        if (yy < a.h && xx < a.w) {
+            const int sl = r * FPITCH + (col & 3) * FQ + (col >> 2);
+            if (lazy_res) {
+                const uint4 lo = s_a[sl], hi = s_b[sl];
+                float o8[8] = {__uint_as_float(lo.x), __uint_as_float(lo.y), __uint_as_float(lo.z), __uint_as_float(lo.w),
+                               __uint_as_float(hi.x), __uint_as_float(hi.y), __uint_as_float(hi.z), __uint_as_float(hi.w)};
+                float uu[8], vv[8];
+                Elem<T>::load(r1.base + r1.gidx(n, c, yy, xx) * GB, uu);
+                Elem<T>::load(r2.base + r2.gidx(n, c, yy, xx) * GB, vv);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) o8[q] = (o8[q] + uu[q]) + vv[q];
+                Elem<T>::store(oa.base + oa.gidx(n, c, yy, xx) * GB, o8);
+                continue;
+            }
+            *reinterpret_cast<uint4*>(oa.base + oa.gidx(n, c, yy, xx) * GB) = s_a[sl];
+            if (NOUT == 2) *reinterpret_cast<uint4*>(ob.base + ob.gidx(n, c, yy, xx) * GB) = s_b[sl];
+        }
+    }
+}
+
 // gxa/gxb (halo 1): padded-domain gradient w.r.t. the operands A, B:
 //   gx_c[p] = sum_o sum_tap w[o][c][tap] * g_o[p - tap + 1]   (g zero outside the image), p in [-1, h] x [-1, w]
 //   (+ add[p]: the residual path's gradient, same for A and B)   then  * [x_c(R(p)) > 0] for the masked channel blocks.
@@ -646,6 +808,24 @@ extern "C" int mmif_pairconv_fwd(const mmif_tensor* a, const mmif_tensor* b, con
     const int tiles_x = cdiv(ta.w, PT), tiles_y = cdiv(ta.h, PT);
     const long long ntiles = (long long)ta.n * ta.cb * tiles_x * tiles_y;
     MMIF_REQUIRE(ntiles < (1ll << 31), "pairconv_fwd: too many tiles");
+    const char* env = getenv("MMIF_PAIR_STRIP");   // read per call (A/B and the bit-identity test flip it inside one process)
+    const bool strips = !(env && env[0] == '0');
+    if (a->dtype == MMIF_BF16 && strips && (long long)ta.h * ta.w * 16 < (1ll << 31)) {
+        const int sx_ = cdiv(ta.w, FT), sy_ = cdiv(ta.h, FT);
+        const long long nt = (long long)ta.n * ta.cb * sx_ * sy_;
+        MMIF_REQUIRE(nt < (1ll << 31), "pairconv_fwd: too many tiles");
+        // residuals that are the operands themselves (PFNetv2: feat1, feat2) come out of the LDS windows
+        const bool res_ops = has_res && res1->data == a->data && res1->cb_off == a->cb_off && res1->cb_total == a->cb_total &&
+                             res2->data == b->data && res2->cb_off == b->cb_off && res2->cb_total == b->cb_total;
+        const int res_mode = has_res ? (res_ops ? 2 : 1) : 0;
+        if (nout == 2)
+            hipLaunchKernelGGL((pairconv_fwd_strip_kernel<2>), dim3((unsigned)nt), dim3(256), 0, st, ta, tb, w, bias, toa, tob, relu, t1, t2,
+                               res_mode, sx_, sy_);
+        else
+            hipLaunchKernelGGL((pairconv_fwd_strip_kernel<1>), dim3((unsigned)nt), dim3(256), 0, st, ta, tb, w, bias, toa, tob, relu, t1, t2,
+                               res_mode, sx_, sy_);
+        return check_launch("pairconv_fwd");
+    }
     PAIR_LAUNCH(a->dtype, nout, pairconv_fwd_kernel, (unsigned)ntiles, ta, tb, w, bias, toa, tob, relu, t1, t2, has_res ? 1 : 0, tiles_x, tiles_y);
     return check_launch("pairconv_fwd");
 }

@@ -76,3 +76,37 @@ def test_pfnetv2_trains_the_same_with_and_without_the_fused_pass():
             assert float((ga - gb).abs().max()) <= 2e-4 * max(1e-6, float(gb.abs().max())), k
         else:   # everything upstream of the fusion sees bit-identical feature gradients
             assert torch.equal(ga, gb), k
+
+
+FWD_SHAPES = [(1, 2, 2), (1, 4, 4), (2, 16, 16), (1, 5, 37), (2, 33, 18), (1, 40, 56), (2, 64, 64), (1, 70, 33), (4, 128, 128)]
+
+
+@pytest.mark.parametrize("nout,relu,res", [(2, True, None), (2, False, None), (1, False, "operands"), (1, False, "other"), (1, True, None)])
+@pytest.mark.parametrize("n,h,w", FWD_SHAPES, ids=[f"{n}x{h}x{w}" for n, h, w in FWD_SHAPES])
+def test_pairconv_fwd_strip_kernel_is_bit_identical(nout, relu, res, n, h, w):
+    """bf16 forward with 1 x 4 output strips on 32 x 32 tiles (pairconv_fwd_strip_kernel) vs the one-output-per-thread kernel
+    ($MMIF_PAIR_STRIP=0): same tap order per output, so every bit must agree -- ragged tiles, borders, residual, both widths."""
+    from mmif import tensor as T
+    with dtype_ctx("bf16"):
+        gen = torch.Generator().manual_seed(h * 17 + w + nout)
+        ch = 24
+        X = T.BT.from_nchw(torch.randn(n, 2 * ch, h, w, generator=gen).to(DEV), torch.bfloat16)
+        cb = ch // 8
+        a, b = X.view(0, cb), X.view(cb, cb)
+        wgt = (torch.randn(nout, 2, 3, 3, generator=gen) * 0.3).to(DEV)
+        bias = torch.randn(nout, generator=gen).to(DEV)
+        outs = {}
+        for mode in ("1", "0"):
+            os.environ["MMIF_PAIR_STRIP"] = mode
+            try:
+                O = T.BT.alloc(n, 2 * ch, h, w, torch.bfloat16, DEV, zero=True)
+                r1, r2 = {None: (None, None), "operands": (a, b), "other": (b, a)}[res]   # "operands": taken from the LDS windows
+                T.pairconv_fwd(a, b, wgt, bias, nout, O.view(0, cb), O.view(cb, cb) if nout == 2 else None, relu, r1, r2)
+                torch.cuda.synchronize()
+                outs[mode] = O.buf.view(torch.int16).clone()
+            finally:
+                os.environ.pop("MMIF_PAIR_STRIP", None)
+        assert float(outs["0"].float().abs().max()) > 0
+        if not torch.equal(outs["1"], outs["0"]):
+            d = (outs["1"] != outs["0"]).nonzero()
+            raise AssertionError(f"{d.shape[0]} of {outs['0'].numel()} elements differ; first at [n, cb, y, x, e] = {d[0].tolist()}")
