@@ -28,6 +28,8 @@ constexpr int SIN = ST + WIN - 1;     // 42
 constexpr int SPI = 44;               // row pitch of the staged images (floats; rows stay 16-byte aligned)
 constexpr int SPH = 36;               // row pitch of the horizontal sums
 
+typedef float lf32x2 __attribute__((ext_vector_type(2)));
+
 __device__ inline void ld16(const float* p, float (&v)[16]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -69,44 +71,49 @@ __global__ __launch_bounds__(256, 2) void ssim_stats_kernel(const float* __restr
         float xa[16], fc[16];
         ld16(&in[set][py][4 * cg], xa);
         ld16(&in[2][py][4 * cg], fc);
-        float s[4][4];
+        // the four quantities of a position as two register pairs (a, a^2), (a c, c | c^2), formed once per position; the 11 taps
+        // are then 2 v_pk_fma_f32 per (tap, column) instead of 2 multiplies + 4 FMAs (same products, same order per sum)
+        lf32x2 pa[14], pc[14];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int i = 0; i < 14; ++i) {
+            const float a = xa[i], c = fc[i];
+            pa[i] = (lf32x2){a, a * a};
+            pc[i] = (lf32x2){a * c, set ? c * c : c};
+        }
+        lf32x2 s01[4], s23[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) s[q][j] = 0.f;
+        for (int j = 0; j < 4; ++j) s01[j] = s23[j] = (lf32x2){0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < WIN; ++k) {
-            const float wk = win.t[k];
+            const lf32x2 wk = (lf32x2){win.t[k], win.t[k]};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float a = xa[j + k], c = fc[j + k];
-                s[0][j] = fmaf(wk, a, s[0][j]);
-                s[1][j] = fmaf(wk, a * a, s[1][j]);
-                s[2][j] = fmaf(wk, a * c, s[2][j]);
-                s[3][j] = fmaf(wk, set ? c * c : c, s[3][j]);
+                s01[j] = __builtin_elementwise_fma(wk, pa[j + k], s01[j]);
+                s23[j] = __builtin_elementwise_fma(wk, pc[j + k], s23[j]);
             }
         }
         const int q0 = set ? 1 : 0, q1 = set ? 4 : 3, q2 = set ? 7 : 6, q3 = set ? 5 : 2;
-        *reinterpret_cast<float4*>(&hb[q0][py][4 * cg]) = make_float4(s[0][0], s[0][1], s[0][2], s[0][3]);
-        *reinterpret_cast<float4*>(&hb[q1][py][4 * cg]) = make_float4(s[1][0], s[1][1], s[1][2], s[1][3]);
-        *reinterpret_cast<float4*>(&hb[q2][py][4 * cg]) = make_float4(s[2][0], s[2][1], s[2][2], s[2][3]);
-        *reinterpret_cast<float4*>(&hb[q3][py][4 * cg]) = make_float4(s[3][0], s[3][1], s[3][2], s[3][3]);
+        *reinterpret_cast<float4*>(&hb[q0][py][4 * cg]) = make_float4(s01[0].x, s01[1].x, s01[2].x, s01[3].x);
+        *reinterpret_cast<float4*>(&hb[q1][py][4 * cg]) = make_float4(s01[0].y, s01[1].y, s01[2].y, s01[3].y);
+        *reinterpret_cast<float4*>(&hb[q2][py][4 * cg]) = make_float4(s23[0].x, s23[1].x, s23[2].x, s23[3].x);
+        *reinterpret_cast<float4*>(&hb[q3][py][4 * cg]) = make_float4(s23[0].y, s23[1].y, s23[2].y, s23[3].y);
     }
     __syncthreads();
     // vertical pass: column tx, rows 4 rg .. 4 rg + 3, all 8 quantities
     const int tx = tid & 31, rg = tid >> 5;
     float m[8][4];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        float v[14];
+    for (int q = 0; q < 8; q += 2) {   // two quantities per v_pk_fma_f32
+        lf32x2 v[14];
 #pragma unroll
-        for (int i = 0; i < 14; ++i) v[i] = hb[q][4 * rg + i][tx];
+        for (int i = 0; i < 14; ++i) v[i] = (lf32x2){hb[q][4 * rg + i][tx], hb[q + 1][4 * rg + i][tx]};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float acc = 0.f;
+            lf32x2 acc = (lf32x2){0.f, 0.f};
 #pragma unroll
-            for (int k = 0; k < WIN; ++k) acc = fmaf(win.t[k], v[j + k], acc);
-            m[q][j] = acc;
+            for (int k = 0; k < WIN; ++k) acc = __builtin_elementwise_fma((lf32x2){win.t[k], win.t[k]}, v[j + k], acc);
+            m[q][j] = acc.x;
+            m[q + 1][j] = acc.y;
         }
     }
     float ssum = 0.f;
@@ -185,31 +192,39 @@ __global__ __launch_bounds__(256, 2) void ssim_grad_kernel(const float* __restri
         if (idx >= SIN * 8) continue;
         const int py = idx >> 3, cg = idx & 7;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float v[16];
-            ld16(&in[q][py][4 * cg], v);
-            float s[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < 4; q += 2) {   // two maps per v_pk_fma_f32
+            float v0[16], v1[16];
+            ld16(&in[q][py][4 * cg], v0);
+            ld16(&in[q + 1][py][4 * cg], v1);
+            lf32x2 v[14];
+#pragma unroll
+            for (int i = 0; i < 14; ++i) v[i] = (lf32x2){v0[i], v1[i]};
+            lf32x2 s2[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s2[j] = (lf32x2){0.f, 0.f};
 #pragma unroll
             for (int k = 0; k < WIN; ++k)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) s[j] = fmaf(win.t[k], v[j + (WIN - 1) - k], s[j]);
-            *reinterpret_cast<float4*>(&hb[q][py][4 * cg]) = make_float4(s[0], s[1], s[2], s[3]);
+                for (int j = 0; j < 4; ++j) s2[j] = __builtin_elementwise_fma((lf32x2){win.t[k], win.t[k]}, v[j + (WIN - 1) - k], s2[j]);
+            *reinterpret_cast<float4*>(&hb[q][py][4 * cg]) = make_float4(s2[0].x, s2[1].x, s2[2].x, s2[3].x);
+            *reinterpret_cast<float4*>(&hb[q + 1][py][4 * cg]) = make_float4(s2[0].y, s2[1].y, s2[2].y, s2[3].y);
         }
     }
     __syncthreads();
     const int tx = tid & 31, rg = tid >> 5;
     float m[4][4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        float v[14];
+    for (int q = 0; q < 4; q += 2) {
+        lf32x2 v[14];
 #pragma unroll
-        for (int i = 0; i < 14; ++i) v[i] = hb[q][4 * rg + i][tx];
+        for (int i = 0; i < 14; ++i) v[i] = (lf32x2){hb[q][4 * rg + i][tx], hb[q + 1][4 * rg + i][tx]};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float acc = 0.f;
+            lf32x2 acc = (lf32x2){0.f, 0.f};
 #pragma unroll
-            for (int k = 0; k < WIN; ++k) acc = fmaf(win.t[k], v[j + (WIN - 1) - k], acc);
-            m[q][j] = acc;
+            for (int k = 0; k < WIN; ++k) acc = __builtin_elementwise_fma((lf32x2){win.t[k], win.t[k]}, v[j + (WIN - 1) - k], acc);
+            m[q][j] = acc.x;
+            m[q + 1][j] = acc.y;
         }
     }
 #pragma unroll
