@@ -227,3 +227,53 @@ def test_decoder_round2_kernels_at_full_size():
         T.conv_dgrad(gsrc, None, xk, dst_b.as_folded(), 16, 48, 3, 0b11, 0b11, pkv, IMPL_MFMA, fold=True)
         torch.cuda.synchronize()
         assert torch.equal(dst_a.buf.view(torch.int16), dst_b.buf.view(torch.int16))
+
+
+def test_pfnetv2_pair_kernels_at_full_size():
+    """PFNetv2's pair-conv kernels at B=32 256x256 (64 channel pairs): the strip forward is bit-identical to the
+    one-output-per-thread kernel, the one-pass backward's operand gradients are bit-identical to pairconv_dgrad and its weight
+    gradients agree with pairconv_wgrad and are exactly linear in g (x4 scaling is exact in bf16 / fp32)."""
+    import os
+    from mmif import tensor as T
+    dev = "cuda:0"
+    n, ch, h, w = 32, 64, 256, 256
+    cb = ch // 8
+    with dtype_ctx("bf16"):
+        gen = torch.Generator().manual_seed(11)
+        X = T.BT.alloc(n, 2 * ch, h, w, torch.bfloat16, dev)
+        X.buf.copy_(torch.relu(torch.randn(X.buf.shape, generator=gen)).to(dev))
+        G = T.BT.alloc(n, 2 * ch, h, w, torch.bfloat16, dev, halo=1, zero=True)
+        G.buf[:, :, 1:-1, 1:-1].copy_(torch.randn(n, 2 * cb, h, w, 8, generator=gen).to(dev))
+        G = G.as_folded()
+        a, b, ga, gb = X.view(0, cb), X.view(cb, cb), G.view(0, cb), G.view(cb, cb)
+        wgt = (torch.randn(2, 2, 3, 3, generator=gen) * 0.3).to(dev)
+        bias = torch.randn(2, generator=gen).to(dev)
+        outs = {}
+        for mode in ("1", "0"):
+            os.environ["MMIF_PAIR_STRIP"] = mode
+            try:
+                Y = T.BT.alloc(n, 2 * ch, h, w, torch.bfloat16, dev, zero=True)
+                T.pairconv_fwd(a, b, wgt, bias, 2, Y.view(0, cb), Y.view(cb, cb), True)
+                torch.cuda.synchronize()
+                outs[mode] = Y.buf.view(torch.int16).clone()
+            finally:
+                os.environ.pop("MMIF_PAIR_STRIP", None)
+        assert torch.equal(outs["1"], outs["0"]) and float(outs["0"].float().abs().max()) > 0
+        ws = torch.empty(T.pairconv_wgrad_workspace_bytes() // 4, dtype=torch.float32, device=dev)
+        GA = T.BT.alloc(n, 2 * ch, h, w, torch.bfloat16, dev, halo=1, zero=True)
+        GB = T.BT.alloc(n, 2 * ch, h, w, torch.bfloat16, dev, halo=1, zero=True)
+        dw1, db1 = torch.zeros(2, 2, 3, 3, device=dev), torch.zeros(2, device=dev)
+        dw2, db2 = torch.zeros_like(dw1), torch.zeros_like(db1)
+        bits = (1 << cb) - 1
+        T.pairconv_bwd(ga, gb, wgt, 2, a, b, GA.view(0, cb), GA.view(cb, cb), dw1, db1, ws, bits)
+        T.pairconv_dgrad(ga, gb, wgt, 2, a, b, GB.view(0, cb), GB.view(cb, cb), bits)
+        T.pairconv_wgrad(a, b, ga, gb, 2, dw2, db2, ws)
+        torch.cuda.synchronize()
+        assert torch.equal(GA.buf.view(torch.int16), GB.buf.view(torch.int16))
+        assert float((dw1 - dw2).abs().max()) <= 2e-4 * float(dw2.abs().max())
+        assert float((db1 - db2).abs().max()) <= 2e-4 * max(1.0, float(db2.abs().max()))
+        G.buf.mul_(4.0)
+        dw4, db4 = torch.zeros_like(dw1), torch.zeros_like(db1)
+        T.pairconv_bwd(ga, gb, wgt, 2, a, b, GA.view(0, cb), GA.view(cb, cb), dw4, db4, ws, bits)
+        torch.cuda.synchronize()
+        assert torch.equal(dw4, 4 * dw1) and torch.equal(db4, 4 * db1)
