@@ -254,7 +254,8 @@ __global__ __launch_bounds__(256) void image_out_dgrad_kernel(const float* __res
     for (int e = threadIdx.x; e < cin * KK; e += 256) wsm[e] = w[e];
     __syncthreads();
     const int txx = threadIdx.x & 15, tyy = threadIdx.x >> 4;
-    const int xs = (blockIdx.x % tiles_x) * ITILE + txx, ys = (blockIdx.x / tiles_x) * ITILE + tyy;
+    const unsigned tile = xcd_tile(blockIdx.x, gridDim.x);   // neighbouring tiles share cache lines of gx: keep them on one XCD
+    const int xs = (int)(tile % (unsigned)tiles_x) * ITILE + txx, ys = (int)(tile / (unsigned)tiles_x) * ITILE + tyy;
     const int in_ = blockIdx.y;
     if (ys >= tgx.hs || xs >= tgx.ws) return;
     const int y = ys - tgx.halo, x = xs - tgx.halo;
