@@ -139,6 +139,13 @@ __device__ inline void unpack_pairs(const f32x2 (&v)[4], float (&u)[8]) {
     for (int i = 0; i < 4; ++i) { u[2 * i] = v[i].x; u[2 * i + 1] = v[i].y; }
 }
 
+// thread -> tile pixel (16 x 16 tiles, one granule per thread).  ds_read_b128 is served in four NON-contiguous 16-lane groups
+// ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, and the same + 32): with lane = 16 ty + tx a group reads half of one tile row and half of
+// the next, whose 16-byte slots overlap mod 256 B at a row pitch of 18 granules (2-way conflicts: SQ_LDS_BANK_CONFLICT was 1.6 x the
+// active LDS cycles of pairconv_bwd_kernel).  Flipping the row bit of the lanes with tx in 4..11 makes every group one whole tile row =
+// 256 contiguous bytes.  Global accesses touch the same lines as before (a permutation inside the wave).
+__device__ inline int tile_row_flip(int tx) { return (tx >= 4 && tx < 12) ? 1 : 0; }
+
 struct TileId { int n, c, y0, x0; };
 // 32-bit arithmetic on purpose: 64-bit divisions of the (wave-uniform) tile index cost ~900 scalar instructions per block
 __device__ inline TileId tile_of(unsigned tile, int tiles_x, int tiles_y, int cb) {
@@ -163,7 +170,7 @@ __global__ __launch_bounds__(256, 4) void pairconv_fwd_kernel(TV a, TV b, const 
     stage_tile<T, true>(a, ti.n, ti.c, ti.y0, ti.x0, s_a);
     stage_tile<T, true>(b, ti.n, ti.c, ti.y0, ti.x0, s_b);
     __syncthreads();
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int tx = threadIdx.x & 15, ty = (threadIdx.x >> 4) ^ tile_row_flip(tx);
     const int y = ti.y0 + ty, x = ti.x0 + tx, n = ti.n, c = ti.c;
     if (y >= a.h || x >= a.w) return;
     f32x2 acc[NOUT][4];
@@ -387,7 +394,7 @@ __global__ __launch_bounds__(256) void pairconv_dgrad_kernel(TV ga, TV gb, const
     stage_tile<T, false>(ga, ti.n, ti.c, ti.y0 - 1, ti.x0 - 1, s_a);
     if (NOUT == 2) stage_tile<T, false>(gb, ti.n, ti.c, ti.y0 - 1, ti.x0 - 1, s_b);
     __syncthreads();
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int tx = threadIdx.x & 15, ty = (threadIdx.x >> 4) ^ tile_row_flip(tx);
     const int ys = ti.y0 + ty, xs = ti.x0 + tx, n = ti.n, c = ti.c;
     if (ys >= gxa.hs || xs >= gxa.ws) return;
     const int py = ys - 1, px = xs - 1;
@@ -458,7 +465,7 @@ __global__ __launch_bounds__(256, 4) void pairconv_wgrad_kernel(TV xa, TV xb, TV
 #pragma unroll
         for (int t = 0; t < 9; ++t) acc[o][0][t] = acc[o][1][t] = splat(0.f);
     }
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int tx = threadIdx.x & 15, ty = (threadIdx.x >> 4) ^ tile_row_flip(tx);
     for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const TileId ti = tile_of(tile, tiles_x, tiles_y, xa.cb);
         __syncthreads();
@@ -576,7 +583,9 @@ __global__ __launch_bounds__(256, Quads<T>::NQ == 1 ? 3 : 2) void pairconv_bwd_k
     constexpr int NQ = Quads<T>::NQ;
     constexpr bool BF = NQ == 1;
     typedef typename WAcc<BF>::type acc_t;
-    __shared__ __attribute__((aligned(16))) uint4 s_g[NOUT][NQ * PLN], s_x[2][NQ * PLN];
+    // g is kept in LDS as fp32 (two planes, as the fp32 storage type has them anyway): its 9 dgrad taps per output are then plain
+    // 16-byte reads instead of a read + 8 shift / and operations each (161 of ~700 vector instructions per output)
+    __shared__ __attribute__((aligned(16))) uint4 s_g[NOUT][2 * PLN], s_x[2][NQ * PLN];
     __shared__ float red[4][PER];
     acc_t acc[NOUT][2][9], accb[NOUT];
 #pragma unroll
@@ -585,7 +594,7 @@ __global__ __launch_bounds__(256, Quads<T>::NQ == 1 ? 3 : 2) void pairconv_bwd_k
 #pragma unroll
         for (int t = 0; t < 9; ++t) acc[o][0][t] = acc[o][1][t] = WAcc<BF>::zero();
     }
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int tx = threadIdx.x & 15, ty = (threadIdx.x >> 4) ^ tile_row_flip(tx);
     // two-phase staging: the next tile's 4 operand windows (and this thread's granule of the residual gradient) are in flight
     // in registers while this tile is consumed.  Addresses = wave-uniform plane base + a 32-bit in-plane offset that ga/gb and
     // xa/xb share (the C ABI checks equal shapes and halos).
@@ -638,8 +647,22 @@ __global__ __launch_bounds__(256, Quads<T>::NQ == 1 ? 3 : 2) void pairconv_bwd_k
         const TileId ti = tile_of(tile, tiles_x, tiles_y, gxa.cb);
         const int n = ti.n, c = ti.c;
         __syncthreads();
-        drop_tile_masked<T>(rg[0], okm, s_g[0]);
-        if (NOUT == 2) drop_tile_masked<T>(rg[NOUT - 1], okm, s_g[NOUT - 1]);
+        if constexpr (BF) {
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+                for (int i = 0; i < PSL; ++i) {
+                    const int e = threadIdx.x + 256 * i;
+                    if (e < PLN) {
+                        const uint4 r = ((okm >> i) & 1u) ? rg[o][i][0] : make_uint4(0, 0, 0, 0);
+                        s_g[o][e] = make_uint4(r.x << 16, r.x & 0xffff0000u, r.y << 16, r.y & 0xffff0000u);
+                        s_g[o][PLN + e] = make_uint4(r.z << 16, r.z & 0xffff0000u, r.w << 16, r.w & 0xffff0000u);
+                    }
+                }
+        } else {
+            drop_tile_masked<T>(rg[0], okm, s_g[0]);
+            if (NOUT == 2) drop_tile_masked<T>(rg[NOUT - 1], okm, s_g[NOUT - 1]);
+        }
         drop_tile_masked<T>(rx[0], 3u, s_x[0]);
         drop_tile_masked<T>(rx[1], 3u, s_x[1]);
         __syncthreads();
@@ -659,8 +682,8 @@ __global__ __launch_bounds__(256, Quads<T>::NQ == 1 ? 3 : 2) void pairconv_bwd_k
             for (int t = 0; t < 9; ++t) {
                 const int idx = (ty + 2 - t / 3) * PTP + tx + 2 - t % 3;   // g at p - tap + 1
                 f32x2 g0[4], g1[4];
-                tile_read<T>(s_g[0], idx, g0);
-                if (NOUT == 2) tile_read<T>(s_g[NOUT - 1], idx, g1);
+                tile_read<float>(s_g[0], idx, g0);
+                if (NOUT == 2) tile_read<float>(s_g[NOUT - 1], idx, g1);
                 const f32x2 w00 = splat(w[(0 * 2 + 0) * 9 + t]), w01 = splat(w[(0 * 2 + 1) * 9 + t]);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -701,8 +724,11 @@ __global__ __launch_bounds__(256, Quads<T>::NQ == 1 ? 3 : 2) void pairconv_bwd_k
         if (py < 0 || py >= gxa.h || px < 0 || px >= gxa.w) continue;
         if constexpr (BF) {
             uint4 g[NOUT];
-            g[0] = s_g[0][ctr];
-            if (NOUT == 2) g[NOUT - 1] = s_g[NOUT - 1][ctr];
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) {   // back to the bf16 granule (exact: the fp32 values are widened bf16)
+                const uint4 lo = s_g[o][ctr], hi = s_g[o][PLN + ctr];
+                g[o] = make_uint4((lo.x >> 16) | lo.y, (lo.z >> 16) | lo.w, (hi.x >> 16) | hi.y, (hi.z >> 16) | hi.w);
+            }
             const uint4 ones = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
 #pragma unroll
             for (int o = 0; o < NOUT; ++o) accb[o] = dot8_bf16(g[o], ones, accb[o]);
