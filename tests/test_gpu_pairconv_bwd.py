@@ -25,7 +25,12 @@ def test_pairconv_bwd_vs_separate_kernels(dt, nout, masked, with_add, n, h, w):
         ch = 16
         X = T.BT.from_nchw(torch.relu(torch.randn(n, 2 * ch, h, w, generator=gen)).to(DEV), tdt)
         G = T.BT.from_nchw(torch.randn(n, 2 * ch, h, w, generator=gen).to(DEV), tdt, halo=1).as_folded()
-        add = T.BT.from_nchw(torch.randn(n, ch, h, w, generator=gen).to(DEV), tdt) if with_add else None
+        # the residual gradient as the engine hands it over: a folded halo-1 tensor (odd seeds) or a plain halo-0 one
+        add = None
+        if with_add:
+            add = T.BT.from_nchw(torch.randn(n, ch, h, w, generator=gen).to(DEV), tdt, halo=(h + w) % 2)
+            if add.halo:
+                add = add.as_folded()
         cb = ch // 8
         xa, xb, ga, gb = X.view(0, cb), X.view(cb, cb), G.view(0, cb), (G.view(cb, cb) if nout == 2 else None)
         wgt = (torch.randn(nout, 2, 3, 3, generator=gen) * 0.3).to(DEV)
