@@ -222,6 +222,10 @@ __device__ inline void conv_epilogue(const f32x4 (&acc)[MF][4], const TV& tout, 
             bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
         }
         char* oplane = tout.base + ((long long)in_ * tout.img + (long long)(tout.cb_off + min(ocb, tout.cb - 1)) * tout.plane) * 16 + pix_off;
+        // both row pairs are finished before the first is stored: a store between the two made the compiler wait for IT (vmcnt(0))
+        // before it touched the second pair's pre-loaded operands -- one HBM write latency inside every dgrad epilogue
+        uint4 outv[2];
+        bool outok[2] = {false, false};
 #pragma unroll
         for (int p2 = 0; p2 < 2; ++p2) {
             float c[8];
@@ -263,9 +267,12 @@ __device__ inline void conv_epilogue(const f32x4 (&acc)[MF][4], const TV& tout, 
                     if (!((hi & 0x8000u) == 0 && (hi & 0x7fffu) != 0)) c[2 * i + 1] = 0.f;
                 }
             }
-            *reinterpret_cast<uint4*>(oplane + (2 * p2) * row_bytes) =
-                make_uint4(pack_bf16x2(c[0], c[1]), pack_bf16x2(c[2], c[3]), pack_bf16x2(c[4], c[5]), pack_bf16x2(c[6], c[7]));
+            outv[p2] = make_uint4(pack_bf16x2(c[0], c[1]), pack_bf16x2(c[2], c[3]), pack_bf16x2(c[4], c[5]), pack_bf16x2(c[6], c[7]));
+            outok[p2] = true;
         }
+#pragma unroll
+        for (int p2 = 0; p2 < 2; ++p2)
+            if (outok[p2]) *reinterpret_cast<uint4*>(oplane + (2 * p2) * row_bytes) = outv[p2];
     }
 }
 
@@ -1137,9 +1144,16 @@ __device__ inline void tn_wait_vmcnt(int n) {   // s_waitcnt vmcnt(n), n wave-un
     }
 }
 // wave-uniform bounded poll of an LDS counter published by other waves
+// The read is an asm ds_read_b32: as a C++ `volatile` read of a generic pointer it compiled to flat_load_dword + s_waitcnt vmcnt(0) --
+// i.e. every poll first waited for ALL of the wave's outstanding vector-memory operations: a consumer's epilogue stores of the previous
+// tile (a full HBM write latency per tile and group: the kernel took ~1.5 us per tile and CU whatever its epilogue loaded), a loader's
+// in-flight LDS-DMA of the tiles behind the one whose slot it waits for.
 __device__ inline void tn_wait_counter(volatile unsigned* ctr, unsigned target) {
+    const unsigned a = (unsigned)(size_t)ctr;   // LDS byte offset (low half of the generic address)
     for (int spin = 0; spin < (1 << 22); ++spin) {
-        if (*ctr >= target) break;
+        unsigned v;
+        __asm__ volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+        if (v >= target) break;
         __builtin_amdgcn_s_sleep(1);
     }
     __asm__ volatile("" ::: "memory");
