@@ -1260,7 +1260,13 @@ __global__ __launch_bounds__((4 * TN_GROUPS + TN_LOAD) * 64, 4) void thin_conv_a
             }
         };
         auto publish = [&](int k) {   // this wave's part of tile k has landed
-            if (lane == 0) atomicAdd(&s_ready[k % NS], 1u);
+            // asm: before a C++ atomicAdd on LDS the compiler drains the wave's LDS-DMA (s_waitcnt vmcnt(0): "may alias"), i.e. ALL the
+            // younger tiles this loader keeps in flight -- each publish then cost a full HBM latency and the kernel ~1.5 us per tile and
+            // CU whatever D was.  tn_wait_vmcnt above has already waited for exactly the tile being published.
+            if (lane == 0) {
+                const unsigned a = (unsigned)(size_t)&s_ready[k % NS], one = 1u;
+                __asm__ volatile("ds_add_u32 %0, %1" : : "v"(a), "v"(one) : "memory");
+            }
         };
         for (int k = 0; k < nmine; ++k) {
             if (k >= NS) tn_wait_counter(&s_done[k % NS], 4u * (unsigned)(k / NS));   // the slot's previous tile is consumed
