@@ -202,7 +202,13 @@ __device__ inline void conv_epilogue(const f32x4 (&acc)[MF][4], const TV& tout, 
                 if (!LM) xmv[m][p2] = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);   // 1.0: mask passes
                 const int oys = oys0 + 2 * p2;
                 if (blk_ok && oys < ylim) {
-                    if (do_acc) oldv[m][p2] = *reinterpret_cast<const uint4*>(oplane + (2 * p2) * old_row_bytes);
+                    // (global address space spelled out: with the base selected between two tensors this was a FLAT load, which counts
+                    // in lgkmcnt as well and made the waits around the LDS traffic wait for HBM)
+                    if (do_acc) {
+                        typedef unsigned gu32x4 __attribute__((ext_vector_type(4)));
+                        const gu32x4 ov = *reinterpret_cast<const __attribute__((address_space(1))) gu32x4*>((unsigned long long)(oplane + (2 * p2) * old_row_bytes));
+                        oldv[m][p2] = make_uint4(ov.x, ov.y, ov.z, ov.w);
+                    }
                     if (do_mask && !LM) {
                         const int y = min(max(reflect_idx(oys - tout.halo, tmask.h), 0), tmask.h - 1);
                         xmv[LM ? 0 : m][p2] = *reinterpret_cast<const uint4*>(mplane + (unsigned)(y * tmask.ws) * 16u);
