@@ -37,9 +37,11 @@ extern "C" {
 #define MMIF_F32 0
 #define MMIF_BF16 1
 
-#define MMIF_IMPL_AUTO 0 /* bf16 -> MFMA kernels, fp32 -> VALU kernels */
+#define MMIF_IMPL_AUTO 0 /* bf16 -> MFMA kernels; fp32 -> split-bf16 MFMA kernels (X3) for 3x3 layers given their operand image, else VALU */
 #define MMIF_IMPL_VALU 1 /* LDS-tiled fp32-accumulate VALU kernels (any dtype) */
 #define MMIF_IMPL_MFMA 2 /* v_mfma_f32_16x16x32_bf16 kernels (bf16 storage only) */
+#define MMIF_IMPL_X3 3   /* fp32 storage, contraction on the matrix pipe as three bf16 products (hi*hi + hi*lo + lo*hi,
+                          * fp32 accumulate): the parity-grade fast path for fp32 tensors, 3x3 layers (csrc/conv_x3.hip) */
 
 #define MMIF_OK 0
 #define MMIF_EINVAL (-1)   /* bad argument / unsupported shape */
@@ -84,13 +86,22 @@ int mmif_pack_weights(const float* w, int32_t cout, int32_t cin, int32_t ksize, 
                       void* packed_dgrad, void* stream);
 /* The same for every layer of a model in one launch (host array of jobs; either image pointer may be NULL).
  * What a training step calls after the optimiser has changed the master weights. */
+#define MMIF_PACK_BF16 0 /* mmif_pack_weights' images (bf16 tensors) */
+#define MMIF_PACK_X3 1   /* mmif_pack_weights_x3's images (fp32 tensors, split-bf16 kernels) */
 typedef struct mmif_pack_job {
     const float* w;
-    int32_t cout, cin, ksize, reserved;
+    int32_t cout, cin, ksize;
+    int32_t format;   /* MMIF_PACK_BF16 | MMIF_PACK_X3 */
     void* packed_fwd;
     void* packed_dgrad;
 } mmif_pack_job;
 int mmif_pack_weights_multi(const mmif_pack_job* jobs, int32_t n_jobs, void* stream);
+/* Operand images of the split-bf16 ("x3") kernels that run the 3x3 ConvLayers of FP32 tensors on the matrix pipe at fp32-grade
+ * accuracy (core/block.py:56-66 computes in fp32; BASELINE north star: within 1e-3 of it): every weight is stored as hi = bf16(w) and
+ * lo = bf16(w - hi); layout [m-block][16-channel chunk][hi | lo][tap][2 channel blocks][32 or 64 out channels][8] (csrc/conv_x3.hip).
+ * Pass them as w_packed / w_packed_t of the conv entry points below when the tensors are fp32.  ksize must be 3. */
+size_t mmif_packed_weight_bytes_x3(int32_t cout, int32_t cin, int32_t ksize);
+int mmif_pack_weights_x3(const float* w, int32_t cout, int32_t cin, int32_t ksize, void* packed_fwd, void* packed_dgrad, void* stream);
 
 /* ---- General ConvLayer primitives (row n4: the nets outside the PFNet/DenseFuse hot path) on plain NCHW fp32 tensors ----
  * nn.Conv2d(cin, cout, k in {1,3,5,7}, stride in {1,2}, padding <= k/2, padding_mode reflect|zeros) (+ ReLU)
@@ -185,7 +196,7 @@ int mmif_reflect_pad_bwd(const float* g, float* dx, int64_t planes, int32_t h, i
 /* ---- ConvLayer: reflect-pad(k/2) conv + bias + ReLU, stride 1, k in {1,3}
  *      replaces core/block.py:98-99 (nn.Conv2d(padding_mode='reflect') + nn.ReLU(inplace)) ---- */
 /* y = act(bias + corr(reflect_pad(x), w)).  w: fp32 master weights; w_packed: mmif_pack_weights'
- * fwd image (may be NULL for MMIF_IMPL_VALU). */
+ * fwd image for bf16 tensors, mmif_pack_weights_x3's for fp32 tensors (NULL: the VALU kernels). */
 int mmif_conv2d_reflect_fwd(const mmif_tensor* x, const float* w, const void* w_packed, const float* bias,
                             const mmif_tensor* y, int32_t cin, int32_t cout, int32_t ksize, int32_t relu,
                             int32_t impl, void* stream);

@@ -33,8 +33,8 @@ class _ConvLayerFn(torch.autograd.Function):
         dev = x.device
         wd, bd = weight.detach(), bias.detach() if bias is not None else None
         packed = None
-        if dtype == torch.bfloat16 and impl != _lib.IMPL_VALU and cin > 1 and cout > 1:
-            packed = T.PackedWeights(cout, cin, k, dev)
+        if E.wants_packed(dtype, impl) and cin > 1 and cout > 1:
+            packed = T.PackedWeights(cout, cin, k, dev, _lib.BF16 if dtype == torch.bfloat16 else _lib.F32)
             packed.pack(wd)
         if cin == 1:
             xin = x.detach().contiguous().float()

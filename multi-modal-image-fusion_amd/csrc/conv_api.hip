@@ -27,15 +27,34 @@ bool bwd_wide_supported(int ks, int cin, int cout);
 size_t bwd_wide_signs_bytes(int n, int cin, int h, int w);
 int bwd_wide(const TV& tx, const TV& tg, const TV& tgx, const void* wpk_dgrad, float* dw, float* db, int cin, int cout, uint64_t mask_bits,
              int accumulate, float* ws, unsigned char* signs, hipStream_t st);
+// conv_x3.hip
+bool conv_x3_supported(bool dgrad, int ks, int cin, int cout, const TV& tin, const TV& tout);
+int conv_x3(bool dgrad, const TV& tin, const TV& tout, const TV& tmask, const void* wpk, const float* bias, int cin, int cout, int relu,
+            uint64_t mask_bits, uint64_t accum_bits, hipStream_t st);
+bool wgrad_x3_supported(int ks, int cin, int cout, const TV& tx, const TV& tg);
+size_t wgrad_x3_workspace(int cin, int cout, int ks);
+int wgrad_x3(const TV& tx, const TV& tg, float* dw, float* db, int cin, int cout, int accumulate, float* ws, hipStream_t st);
 }  // namespace mmif
 
 using namespace mmif;
 
-static int pick_impl(int impl, int dtype, bool mfma_ok, const char* what) {
-    if (impl == MMIF_IMPL_AUTO) return (dtype == MMIF_BF16 && mfma_ok) ? MMIF_IMPL_MFMA : MMIF_IMPL_VALU;
+// AUTO: bf16 tensors -> the bf16 MFMA kernels, fp32 tensors -> the split-bf16 MFMA kernels (x3_ok: shape covered and, for forward /
+// dgrad, the x3 operand image given), else the fp32 FMA kernels.
+static int pick_impl(int impl, int dtype, bool mfma_ok, const char* what, bool x3_ok = false) {
+    if (impl == MMIF_IMPL_AUTO) {
+        if (dtype == MMIF_BF16) return mfma_ok ? MMIF_IMPL_MFMA : MMIF_IMPL_VALU;
+        return x3_ok ? MMIF_IMPL_X3 : MMIF_IMPL_VALU;
+    }
     if (impl == MMIF_IMPL_MFMA && (dtype != MMIF_BF16 || !mfma_ok)) {
         set_error("%s: MFMA implementation unavailable for this dtype/shape", what);
         return -1;
+    }
+    if (impl == MMIF_IMPL_X3) {
+        if (dtype != MMIF_F32 || !x3_ok) {
+            set_error("%s: split-bf16 (X3) implementation needs fp32 tensors, a 3x3 layer, its x3 operand image and folded gradients", what);
+            return -1;
+        }
+        return impl;
     }
     if (impl != MMIF_IMPL_VALU && impl != MMIF_IMPL_MFMA) {
         set_error("%s: bad impl %d", what, impl);
@@ -55,9 +74,11 @@ extern "C" int mmif_conv2d_reflect_fwd(const mmif_tensor* x, const float* w, con
     MMIF_REQUIRE(cin > 0 && (cin + 7) / 8 == x->cb, "conv2d_reflect_fwd: cin=%d does not match x.cb=%d", cin, x->cb);
     MMIF_REQUIRE(cout > 0 && (cout + 7) / 8 == y->cb, "conv2d_reflect_fwd: cout=%d does not match y.cb=%d", cout, y->cb);
     MMIF_REQUIRE(ksize == 1 || (x->h >= 2 && x->w >= 2), "reflect padding needs h,w >= 2");
-    const int im = pick_impl(impl, x->dtype, conv_mfma_supported(false, ksize, cin, cout) && w_packed != nullptr, "conv2d_reflect_fwd");
-    if (im < 0) return MMIF_EINVAL;
     TV tx = make_tv(x), ty = make_tv(y);
+    const int im = pick_impl(impl, x->dtype, conv_mfma_supported(false, ksize, cin, cout) && w_packed != nullptr, "conv2d_reflect_fwd",
+                             x->dtype == MMIF_F32 && w_packed != nullptr && conv_x3_supported(false, ksize, cin, cout, tx, ty));
+    if (im < 0) return MMIF_EINVAL;
+    if (im == MMIF_IMPL_X3) return conv_x3(false, tx, ty, ty, w_packed, bias, cin, cout, relu, 0, 0, (hipStream_t)stream);
     if (im == MMIF_IMPL_MFMA) return conv_mfma(false, ksize, tx, ty, ty, w_packed, bias, cin, cout, relu, 0, 0, (hipStream_t)stream);
     MMIF_REQUIRE(w != nullptr, "conv2d_reflect_fwd: VALU path needs the fp32 master weights");
     return conv_valu(false, x->dtype, ksize, tx, ty, ty, w, bias, cin, cout, relu, 0, 0, (hipStream_t)stream);
@@ -81,7 +102,8 @@ static int dgrad_impl(const char* what, const mmif_tensor* gy, const float* w, c
                      "%s: x does not match gx", what);
         tm = make_tv(x);
     }
-    const int im = pick_impl(impl, gy->dtype, conv_mfma_supported(true, ksize, cin, cout) && w_packed_t != nullptr, what);
+    const int im = pick_impl(impl, gy->dtype, conv_mfma_supported(true, ksize, cin, cout) && w_packed_t != nullptr, what,
+                             gy->dtype == MMIF_F32 && w_packed_t != nullptr && conv_x3_supported(true, ksize, cin, cout, tg, tgx));
     if (im < 0) return MMIF_EINVAL;
     bool folded = false;
     int rc;
@@ -94,7 +116,9 @@ static int dgrad_impl(const char* what, const mmif_tensor* gy, const float* w, c
         MMIF_REQUIRE(im == MMIF_IMPL_MFMA && fold, "%s: gx_old needs the folded MFMA path", what);
         told = make_tv(gx_old);
     }
-    if (im == MMIF_IMPL_MFMA) {
+    if (im == MMIF_IMPL_X3) {
+        rc = conv_x3(true, tg, tgx, tm, w_packed_t, nullptr, cin, cout, 0, mask_bits, accum_bits, (hipStream_t)stream);
+    } else if (im == MMIF_IMPL_MFMA) {
         rc = conv_mfma(true, ksize, tg, tgx, tm, w_packed_t, nullptr, cin, cout, 0, mask_bits, accum_bits, (hipStream_t)stream, fold, &folded,
                        gx_old != nullptr ? &told : nullptr);
     } else {
@@ -134,8 +158,9 @@ extern "C" int mmif_conv2d_reflect_dgrad_folded_onto(const mmif_tensor* gy, cons
 
 extern "C" size_t mmif_conv2d_wgrad_workspace(int32_t cin, int32_t cout, int32_t ksize) {
     size_t a = wgrad_valu_workspace(cin, cout, ksize);
-    size_t b = wgrad_mfma_workspace(cin, cout, ksize);
-    return a > b ? a : b;
+    const size_t b = wgrad_mfma_workspace(cin, cout, ksize), c = wgrad_x3_workspace(cin, cout, ksize);
+    if (b > a) a = b;
+    return c > a ? c : a;
 }
 
 extern "C" int mmif_conv2d_reflect_wgrad(const mmif_tensor* x, const mmif_tensor* gy, float* dw, float* db, int32_t cin,
@@ -153,9 +178,11 @@ extern "C" int mmif_conv2d_reflect_wgrad(const mmif_tensor* x, const mmif_tensor
         set_error("conv2d_reflect_wgrad: workspace too small (%zu < %zu)", workspace_bytes, mmif_conv2d_wgrad_workspace(cin, cout, ksize));
         return MMIF_EWORKSPACE;
     }
-    const int im = pick_impl(impl, x->dtype, wgrad_mfma_supported(ksize, cin, cout), "conv2d_reflect_wgrad");
-    if (im < 0) return MMIF_EINVAL;
     TV tx = make_tv(x), tg = make_tv(gy);
+    const int im = pick_impl(impl, x->dtype, wgrad_mfma_supported(ksize, cin, cout), "conv2d_reflect_wgrad",
+                             x->dtype == MMIF_F32 && wgrad_x3_supported(ksize, cin, cout, tx, tg));
+    if (im < 0) return MMIF_EINVAL;
+    if (im == MMIF_IMPL_X3) return wgrad_x3(tx, tg, dw, db, cin, cout, accumulate, (float*)workspace, (hipStream_t)stream);
     if (im == MMIF_IMPL_MFMA) return wgrad_mfma(ksize, tx, tg, dw, db, cin, cout, accumulate, (float*)workspace, (hipStream_t)stream);
     return wgrad_valu(x->dtype, ksize, tx, tg, dw, db, cin, cout, accumulate, (float*)workspace, (hipStream_t)stream);
 }

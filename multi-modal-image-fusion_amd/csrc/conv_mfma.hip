@@ -2361,6 +2361,8 @@ extern "C" size_t mmif_packed_weight_bytes(int32_t cout, int32_t cin, int32_t ks
     return a > b ? a : b;
 }
 
+namespace mmif { int conv_x3_pack_multi(const mmif_pack_job* jobs, int n_jobs, hipStream_t st); }   // conv_x3.hip: packs the MMIF_PACK_X3 jobs, skips the others
+
 extern "C" int mmif_pack_weights_multi(const mmif_pack_job* jobs, int32_t n_jobs, void* stream) {
     MMIF_REQUIRE(jobs != nullptr && n_jobs > 0, "pack_weights_multi: bad arguments");
     hipStream_t st = (hipStream_t)stream;
@@ -2372,10 +2374,13 @@ extern "C" int mmif_pack_weights_multi(const mmif_pack_job* jobs, int32_t n_jobs
         n = 0;
         return check_launch("pack_weights_multi");
     };
+    bool any_x3 = false;
     for (int i = 0; i < n_jobs; ++i) {
         const mmif_pack_job& jb = jobs[i];
         MMIF_REQUIRE(jb.ksize == 1 || jb.ksize == 3, "pack_weights_multi: ksize must be 1 or 3 (job %d)", i);
         MMIF_REQUIRE(jb.w != nullptr && jb.cout > 0 && jb.cin > 0, "pack_weights_multi: bad arguments (job %d)", i);
+        MMIF_REQUIRE(jb.format == MMIF_PACK_BF16 || jb.format == MMIF_PACK_X3, "pack_weights_multi: bad format (job %d)", i);
+        if (jb.format == MMIF_PACK_X3) { any_x3 = true; continue; }   // split-bf16 images of fp32 tensors: conv_x3.hip, below
         for (int d = 0; d < 2; ++d) {
             void* dst = d ? jb.packed_dgrad : jb.packed_fwd;
             if (dst == nullptr) continue;
@@ -2388,7 +2393,8 @@ extern "C" int mmif_pack_weights_multi(const mmif_pack_job* jobs, int32_t n_jobs
                 if (int rc = flush()) return rc;
         }
     }
-    return flush();
+    if (int rc = flush()) return rc;
+    return any_x3 ? conv_x3_pack_multi(jobs, n_jobs, st) : MMIF_OK;
 }
 
 // ---- DenseBlock(16, 16) backward chain in GATHER form.  Layer by layer, the dgrad of DenseBlock conv L scatters into all of its

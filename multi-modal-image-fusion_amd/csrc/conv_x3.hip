@@ -1,0 +1,629 @@
+// fp32-grade 3x3 convolution on the gfx950 MATRIX pipe: "bf16 x 3" split-operand kernels for fp32 tensors.
+//
+// The reference computes its ConvLayers in fp32 (core/block.py:56-66, 98-99) and BASELINE.json's north star asks for results within
+// 1e-3 of that.  gfx950 has no TF32 / xf32 MFMA and its fp32-input MFMA runs at the VALU rate (157 TFLOP/s), so the parity path used to
+// be the fp32 FMA kernels of conv_valu.hip (0.42 k image pairs / s).  Here every fp32 operand is split ONCE, while it is staged into LDS,
+// into two bf16 values
+//        x = hi + lo + r,   hi = bf16(x),   lo = bf16(x - hi),   |r| <= 2^-18 |x|
+// and a product a * b is accumulated (fp32, inside the MFMA) as  a_hi b_hi + a_hi b_lo + a_lo b_hi: three v_mfma_f32_32x32x16_bf16 per
+// K = 16 step, i.e. 1/3 of the 2.5 PFLOP/s bf16 peak = 830 TFLOP/s of "fp32-grade" work, 5.3x the fp32 pipe.  The dropped terms
+// (a_lo b_lo and the residuals) are below 2^-16 relative to |a b|; end to end the engine stays within ~1e-5 of the fp32 oracle
+// (tests/test_gpu_x3.py), two orders of magnitude inside the north-star bar.  HBM tensors stay plain fp32 blocked NHWC, so every other
+// kernel of the fp32 path (image-side layers, losses, fold, fusion, optimiser) is untouched.
+//
+// conv_x3_kernel<MB, DGRAD>: forward and input gradient (one formulation, see conv_valu.hip).  Persistent block of 8 waves, output tile
+//   32 columns x 16 rows x 32*MB channels, wave w owns rows 2w, 2w+1 (2 x MB accumulator tiles of 32 x 32).  K runs in chunks of 16
+//   input channels x 9 taps; per chunk the 18 x 34 input tile (2 channel blocks) is loaded as fp32 into registers one chunk AHEAD, split
+//   into hi / lo bf16 images and written to the other LDS buffer after the chunk's MFMAs (double buffered, one barrier per chunk); the
+//   pre-split weight images come from mmif_pack_weights_x3.  One 32x32x16 MFMA = one tap x 16 channels: lanes 0-31 hold the channel
+//   block 2c of pixel / output channel (lane & 31), lanes 32-63 block 2c+1, so every operand fetch is one ds_read_b128 of a contiguous
+//   512-byte run per half wave (conflict free for any 16-byte aligned start: MI355X_MICROARCH.md, LDS lane groups).
+// wgrad_x3_kernel: weight gradient, K = pixels.  Block of 12 waves owns a 64 x 64 (out, in) channel pair and walks 8 x 16 pixel tiles;
+//   wave (u, jt, mt) keeps dW[32 oc][32 ic] of the three taps (u, 0..2) in 48 accumulator registers; operands are fetched from the
+//   pixel-major hi / lo tiles with the LDS transpose read (ds_read_b64_tr_b16), 16 pixels of one tile row per k-step.
+#include "common.hpp"
+#include <stdlib.h>
+
+namespace mmif {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 x3_bf16x8;
+typedef __attribute__((ext_vector_type(4))) short x3_s16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float x3_f4;        // native vectors: HIP's float4 / uint4 are structs, and arrays of them that
+typedef __attribute__((ext_vector_type(4))) unsigned x3_u4;     // travel through the staging lambdas were left in scratch / promoted to LDS
+#define X3_LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+
+constexpr int X3_TW = 32, X3_TH = 16;            // output tile (columns x rows)
+constexpr int X3_IW = X3_TW + 2, X3_IH = X3_TH + 2;
+constexpr int X3_ING = 2 * X3_IH * X3_IW;        // granules of one precision half of an input chunk (2 channel blocks): 1224
+constexpr int X3_THREADS = 512;
+constexpr int X3_IN_ROUNDS = (X3_ING + X3_THREADS - 1) / X3_THREADS;   // 3
+
+__host__ __device__ constexpr int x3_mb(int n_out) { return n_out > 32 ? 2 : 1; }
+static inline int x3_nmb(int n_out) { return cdiv(n_out, 32 * x3_mb(n_out)); }
+static inline int x3_nch(int n_in) { return cdiv(cdiv(n_in, 8), 2); }
+// operand image: [m-block][chunk][hi | lo][tap u*3+v][channel block 0 / 1 of the chunk][32*MB out channels][8 in channels] bf16
+static size_t x3_packed_bytes(int n_out, int n_in) {
+    return (size_t)x3_nmb(n_out) * x3_nch(n_in) * 2 * 9 * 2 * 32 * x3_mb(n_out) * 16;
+}
+
+// fp32 -> (hi, lo) bf16 pair of one value (round to nearest even twice; x - hi is exact in fp32)
+__host__ __device__ inline void x3_split(float x, bf16_t& hi, bf16_t& lo) {
+    hi = f32_to_bf16(x);
+    lo = f32_to_bf16(x - bf16_to_f32(hi));
+}
+
+// ------------------------------------------------------------------ weight packing
+constexpr int X3_PACK_MAX = 64;
+struct X3PackImage { const float* w; bf16_t* dst; long long total; int cout, cin, dgrad, mbw, nch; };
+struct X3PackTable { X3PackImage im[X3_PACK_MAX]; };
+
+// dgrad == 0: out = o, in = c, Wk[u][v] = W[o][c][u][v];  dgrad == 1: out = c, in = o, Wk[u][v] = W[o][c][2-u][2-v]
+__global__ void x3_pack_kernel(X3PackTable tab) {
+    const X3PackImage& J = tab.im[blockIdx.y];
+    const int n_out = J.dgrad ? J.cin : J.cout, n_in = J.dgrad ? J.cout : J.cin;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < J.total; idx += (long long)gridDim.x * blockDim.x) {
+        // idx enumerates the bf16 elements of the HI half images; the LO element sits 9*2*mbw*8 elements further
+        const int e = (int)(idx & 7);
+        long long r = idx >> 3;
+        const int ocl = (int)(r % J.mbw); r /= J.mbw;
+        const int cbl = (int)(r & 1); r >>= 1;
+        const int tap = (int)(r % 9); r /= 9;
+        const int ch = (int)(r % J.nch);
+        const int mb = (int)(r / J.nch);
+        const int oc = mb * J.mbw + ocl, ic = (ch * 2 + cbl) * 8 + e;
+        const int u = tap / 3, v = tap % 3;
+        float val = 0.f;
+        if (oc < n_out && ic < n_in) {
+            if (J.dgrad) val = J.w[(((long long)ic * J.cin + oc) * 3 + (2 - u)) * 3 + (2 - v)];
+            else val = J.w[(((long long)oc * J.cin + ic) * 3 + u) * 3 + v];
+        }
+        bf16_t hi, lo;
+        x3_split(val, hi, lo);
+        const long long half = (long long)9 * 2 * J.mbw * 8;
+        const long long within = ((long long)(tap * 2 + cbl) * J.mbw + ocl) * 8 + e;
+        const long long base = ((long long)mb * J.nch + ch) * 2 * half;
+        J.dst[base + within] = hi;
+        J.dst[base + half + within] = lo;
+    }
+}
+
+// ------------------------------------------------------------------ staging helpers
+struct X3Gran { x3_f4 a, b; };   // one fp32 granule (8 channels of one pixel)
+
+__device__ inline void x3_split_pair(float v0, float v1, unsigned& h, unsigned& l) {
+    h = pack_bf16x2(v0, v1);
+    l = pack_bf16x2(v0 - __uint_as_float(h << 16), v1 - __uint_as_float(h & 0xffff0000u));
+}
+__device__ inline void x3_split_gran(const X3Gran& g, x3_u4& hi, x3_u4& lo) {
+    unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+    x3_split_pair(g.a.x, g.a.y, h0, l0);
+    x3_split_pair(g.a.z, g.a.w, h1, l1);
+    x3_split_pair(g.b.x, g.b.y, h2, l2);
+    x3_split_pair(g.b.z, g.b.w, h3, l3);
+    hi = (x3_u4){h0, h1, h2, h3};
+    lo = (x3_u4){l0, l1, l2, l3};
+}
+
+__device__ inline x3_bf16x8 x3_frag(const x3_u4& v) { return __builtin_bit_cast(x3_bf16x8, v); }
+
+// ------------------------------------------------------------------ forward / dgrad
+template <int MB, bool DGRAD>
+__global__ __launch_bounds__(X3_THREADS) void conv_x3_kernel(TV tin, TV tout, TV tmask, const uint4* __restrict__ wpk,
+                                                              const float* __restrict__ bias, int n_out, int nch, int nmb, int relu,
+                                                              unsigned long long mask_bits, unsigned long long accum_bits, int tiles_x,
+                                                              int tiles_per_img, int total_tiles) {
+    constexpr int MBW = 32 * MB;
+    constexpr int WG = 9 * 2 * MBW;               // weight granules of one precision half of a chunk
+    constexpr int W_ROUNDS = (2 * WG + X3_THREADS - 1) / X3_THREADS;
+    constexpr int BUF_G = 2 * X3_ING + 2 * WG;    // [in hi][in lo][w hi][w lo]
+    __shared__ __attribute__((aligned(16))) x3_u4 s_buf[2 * BUF_G];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const TileWalk tw = xcd_walk(total_tiles, gridDim.x, blockIdx.x);
+    const int per_tile = nch * nmb;
+    const int nsteps = tw.count * per_tile;
+    if (nsteps == 0) return;
+
+    // item of step s: tile ti = s / per_tile, m-block mb = (s / nch) % nmb, chunk c = s % nch
+    X3Gran rin[X3_IN_ROUNDS];
+    x3_u4 rw[W_ROUNDS];
+
+    auto issue = [&](int s) {
+        const int c = s % nch, mb = (s / nch) % nmb, ti = s / per_tile;
+        const int tile = tw.first + ti * tw.stride;
+        const int in_ = tile / tiles_per_img, tt = tile - in_ * tiles_per_img;
+        const int ys0 = (tt / tiles_x) * X3_TH, xs0 = (tt % tiles_x) * X3_TW;
+        const int iy0 = ys0 - tout.halo - 1, ix0 = xs0 - tout.halo - 1;   // logical origin of the input tile
+#pragma unroll
+        for (int k = 0; k < X3_IN_ROUNDS; ++k) {
+            const int e = tid + X3_THREADS * k;
+            rin[k].a = (x3_f4){0.f, 0.f, 0.f, 0.f};
+            rin[k].b = rin[k].a;
+            if (e < X3_ING) {
+                const int cbl = e >= X3_IH * X3_IW ? 1 : 0, rem = e - cbl * (X3_IH * X3_IW);
+                const int py = rem / X3_IW, px = rem - py * X3_IW;
+                int y = iy0 + py, x = ix0 + px;
+                const int cb = c * 2 + cbl;
+                bool ok = cb < tin.cb;
+                if (DGRAD) {
+                    ok = ok && y >= 0 && y < tin.h && x >= 0 && x < tin.w;
+                    y += tin.halo; x += tin.halo;
+                } else {
+                    y = min(max(reflect_idx(y, tin.h), 0), tin.h - 1);
+                    x = min(max(reflect_idx(x, tin.w), 0), tin.w - 1);
+                }
+                if (ok) {
+                    const x3_f4* p = reinterpret_cast<const x3_f4*>(tin.base + tin.gidx(in_, cb, y, x) * 32);
+                    rin[k].a = p[0];
+                    rin[k].b = p[1];
+                }
+            }
+        }
+        const x3_u4* src = reinterpret_cast<const x3_u4*>(wpk) + ((long long)mb * nch + c) * (2 * WG);
+#pragma unroll
+        for (int k = 0; k < W_ROUNDS; ++k) {
+            const int e = tid + X3_THREADS * k;
+            if (e < 2 * WG) rw[k] = src[e];
+        }
+    };
+    auto commit = [&](int buf) {
+        x3_u4* dst = s_buf + buf * BUF_G;
+#pragma unroll
+        for (int k = 0; k < X3_IN_ROUNDS; ++k) {
+            const int e = tid + X3_THREADS * k;
+            if (e < X3_ING) {
+                x3_u4 hi, lo;
+                x3_split_gran(rin[k], hi, lo);
+                dst[e] = hi;
+                dst[X3_ING + e] = lo;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < W_ROUNDS; ++k) {
+            const int e = tid + X3_THREADS * k;
+            if (e < 2 * WG) dst[2 * X3_ING + e] = rw[k];
+        }
+    };
+
+    f32x16 acc[MB][2];
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.f;
+
+    const int cbl = lane >> 5, nl = lane & 31;
+    const int bbase = (cbl * X3_IH + 2 * wave) * X3_IW + nl;   // + i * X3_IW + v
+    const int abase = cbl * MBW + nl;                           // + tap * 2 * MBW + m * 32
+
+    issue(0);
+    commit(0);
+    __syncthreads();
+
+    for (int s = 0; s < nsteps; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nsteps) issue(s + 1);
+        // ---------------- the chunk's 27 * 2 * MB MFMAs ----------------
+        {
+            const x3_u4* in_hi = s_buf + buf * BUF_G;
+            const x3_u4* in_lo = in_hi + X3_ING;
+            const x3_u4* w_hi = in_lo + X3_ING;
+            const x3_u4* w_lo = w_hi + WG;
+#pragma unroll
+            for (int v = 0; v < 3; ++v) {
+                x3_bf16x8 bh[4], bl[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    bh[i] = x3_frag(in_hi[bbase + i * X3_IW + v]);
+                    bl[i] = x3_frag(in_lo[bbase + i * X3_IW + v]);
+                }
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const int tap = u * 3 + v;
+                    x3_bf16x8 ah[MB], al[MB];
+#pragma unroll
+                    for (int m = 0; m < MB; ++m) {
+                        ah[m] = x3_frag(w_hi[abase + tap * 2 * MBW + m * 32]);
+                        al[m] = x3_frag(w_lo[abase + tap * 2 * MBW + m * 32]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int m = 0; m < MB; ++m) acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh[j + u], acc[m][j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int m = 0; m < MB; ++m) acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl[j + u], acc[m][j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int m = 0; m < MB; ++m) acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh[j + u], acc[m][j], 0, 0, 0);
+                }
+            }
+        }
+        // ---------------- epilogue after the item's last chunk ----------------
+        if (s % nch == nch - 1) {
+            const int mb = (s / nch) % nmb, ti = s / per_tile;
+            const int tile = tw.first + ti * tw.stride;
+            const int in_ = tile / tiles_per_img, tt = tile - in_ * tiles_per_img;
+            const int ys0 = (tt / tiles_x) * X3_TH, xs0 = (tt % tiles_x) * X3_TW;
+            const int xs = xs0 + nl, half = lane >> 5;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int ys = ys0 + 2 * wave + j;
+                const bool inside = ys < tout.hs && xs < tout.ws;
+#pragma unroll
+                for (int m = 0; m < MB; ++m) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int ocb = (mb * MB + m) * 4 + q;          // channel block of the out view
+                        x3_f4 v = {acc[m][j][4 * q], acc[m][j][4 * q + 1], acc[m][j][4 * q + 2], acc[m][j][4 * q + 3]};
+                        if (inside && ocb < tout.cb) {
+                            x3_f4* dst = reinterpret_cast<x3_f4*>(tout.base + tout.gidx(in_, ocb, ys, xs) * 32 + half * 16);
+                            if (!DGRAD) {
+                                const int oc0 = ocb * 8 + 4 * half;
+                                if (bias != nullptr) {
+                                    if (oc0 + 3 < n_out) {
+                                        const x3_f4 b4 = *reinterpret_cast<const x3_f4*>(bias + oc0);
+                                        v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+                                    } else {
+                                        if (oc0 + 0 < n_out) v.x += bias[oc0 + 0];
+                                        if (oc0 + 1 < n_out) v.y += bias[oc0 + 1];
+                                        if (oc0 + 2 < n_out) v.z += bias[oc0 + 2];
+                                    }
+                                }
+                                if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                            } else {
+                                if ((accum_bits >> ocb) & 1ull) {
+                                    const x3_f4 o = *dst;
+                                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                                }
+                                if ((mask_bits >> ocb) & 1ull) {
+                                    const int oy = min(max(reflect_idx(ys - tout.halo, tmask.h), 0), tmask.h - 1);
+                                    const int ox = min(max(reflect_idx(xs - tout.halo, tmask.w), 0), tmask.w - 1);
+                                    const x3_f4 xm = *reinterpret_cast<const x3_f4*>(tmask.base + tmask.gidx(in_, ocb, oy, ox) * 32 + half * 16);
+                                    v.x = xm.x > 0.f ? v.x : 0.f; v.y = xm.y > 0.f ? v.y : 0.f;
+                                    v.z = xm.z > 0.f ? v.z : 0.f; v.w = xm.w > 0.f ? v.w : 0.f;
+                                }
+                            }
+                            *dst = v;
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.f;
+                }
+            }
+        }
+        if (s + 1 < nsteps) commit(buf ^ 1);
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------ wgrad
+constexpr int XW_TH = 8, XW_TW = 16;             // pixel tile (rows x columns) = 8 k-steps of 16 pixels
+constexpr int XW_XH = XW_TH + 2, XW_XW = XW_TW + 2;
+constexpr int XW_XPL = XW_XH * XW_XW;            // 180 granules per x plane  (= 4 mod 16: the four planes a half wave's transposing read touches
+constexpr int XW_GPL = XW_TH * XW_TW + 4;        // 132 granules per g plane      fall on disjoint bank quarters)
+constexpr int XW_XG = 8 * XW_XPL, XW_GG = 8 * XW_GPL;          // one precision half of the x / g tile (8 channel blocks each)
+constexpr int XW_BUF_G = 2 * XW_XG + 2 * XW_GG;                // [x hi][x lo][g hi][g lo] = 4992 granules
+constexpr int XW_THREADS = 768;
+constexpr int XW_NX = 8 * XW_XH * XW_XW, XW_NG = 8 * XW_TH * XW_TW;   // staged elements: 1440 + 1024
+constexpr int XW_ROUNDS = (XW_NX + XW_NG + XW_THREADS - 1) / XW_THREADS;   // 4
+constexpr int XW_PER = 64 * 64 * 9 + 64;         // floats per block partial: dW[64 oc][64 ic][9], db[64]
+
+__global__ __launch_bounds__(XW_THREADS) void wgrad_x3_kernel(TV tx, TV tg, float* __restrict__ partial, int cin, int cout, int tiles_x, int tpi,
+                                                               int total, int G, int n_icg, int n_ocg) {
+    __shared__ __attribute__((aligned(16))) x3_u4 s_buf[2 * XW_BUF_G];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int npairs = n_icg * n_ocg;
+    const int b = blockIdx.x;
+    int gi, pair;
+    if ((G & 7) == 0) { pair = (b >> 3) % npairs; gi = ((b >> 3) / npairs) * 8 + (b & 7); }   // blocks sharing tiles: same XCD
+    else { pair = b % npairs; gi = b / npairs; }
+    const int icg = pair % n_icg, ocg = pair / n_icg;
+    const TileWalk tw = xcd_walk(total, G, gi);
+    const int ntile = tw.count;
+
+    const int u = wave % 3, jt = (wave / 3) & 1, mt = wave / 6;     // tap row, input-channel tile, output-channel tile (32 each)
+    const bool active = (ocg * 64 + mt * 32 < cout) && (icg * 64 + jt * 32 < cin);
+    const bool want_db = (u == 0 && jt == 0 && icg == 0 && ocg * 64 + mt * 32 < cout);
+
+    X3Gran rin[XW_ROUNDS];
+    auto issue = [&](int k_tile) {
+        const int tile = tw.first + k_tile * tw.stride;
+        const int in_ = tile / tpi, tt = tile - in_ * tpi;
+        const int y0 = (tt / tiles_x) * XW_TH, x0 = (tt % tiles_x) * XW_TW;
+#pragma unroll
+        for (int k = 0; k < XW_ROUNDS; ++k) {
+            const int e = tid + XW_THREADS * k;
+            rin[k].a = (x3_f4){0.f, 0.f, 0.f, 0.f};
+            rin[k].b = rin[k].a;
+            if (e < XW_NX) {
+                const int cb = e / (XW_XH * XW_XW), rem = e - cb * (XW_XH * XW_XW);
+                const int py = rem / XW_XW, px = rem - py * XW_XW;
+                const int y = min(max(reflect_idx(y0 + py - 1, tx.h), 0), tx.h - 1);
+                const int x = min(max(reflect_idx(x0 + px - 1, tx.w), 0), tx.w - 1);
+                if (icg * 8 + cb < tx.cb) {
+                    const x3_f4* p = reinterpret_cast<const x3_f4*>(tx.base + tx.gidx(in_, icg * 8 + cb, y, x) * 32);
+                    rin[k].a = p[0];
+                    rin[k].b = p[1];
+                }
+            } else if (e < XW_NX + XW_NG) {
+                const int e2 = e - XW_NX;
+                const int cb = e2 / (XW_TH * XW_TW), rem = e2 - cb * (XW_TH * XW_TW);
+                const int py = rem / XW_TW, px = rem - py * XW_TW;
+                const int y = y0 + py, x = x0 + px;
+                if (ocg * 8 + cb < tg.cb && y < tg.h && x < tg.w) {
+                    const x3_f4* p = reinterpret_cast<const x3_f4*>(tg.base + tg.gidx(in_, ocg * 8 + cb, y + tg.halo, x + tg.halo) * 32);
+                    rin[k].a = p[0];
+                    rin[k].b = p[1];
+                }
+            }
+        }
+    };
+    auto commit = [&](int buf) {
+        x3_u4* dst = s_buf + buf * XW_BUF_G;
+#pragma unroll
+        for (int k = 0; k < XW_ROUNDS; ++k) {
+            const int e = tid + XW_THREADS * k;
+            x3_u4 hi, lo;
+            x3_split_gran(rin[k], hi, lo);
+            if (e < XW_NX) {   // e enumerates [cb][py][px] with the plane stride XW_XPL = XW_XH * XW_XW
+                dst[e] = hi;
+                dst[XW_XG + e] = lo;
+            } else if (e < XW_NX + XW_NG) {
+                const int e2 = e - XW_NX;
+                const int cb = e2 / (XW_TH * XW_TW), rem = e2 - cb * (XW_TH * XW_TW);
+                dst[2 * XW_XG + cb * XW_GPL + rem] = hi;
+                dst[2 * XW_XG + XW_GG + cb * XW_GPL + rem] = lo;
+            }
+        }
+    };
+
+    f32x16 acc[3], accb;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; acc[2][r] = 0.f; accb[r] = 0.f; }
+    const x3_u4 ones_u = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+    const x3_bf16x8 ones = __builtin_bit_cast(x3_bf16x8, ones_u);
+
+    // transposing read: within a 16-lane group, lane sl supplies the address of (pixel sl >> 2, 8-byte piece sl & 3 of the 16-channel
+    // record = channel block (sl & 3) >> 1, byte 8 * (sl & 1)) and receives channel sl of pixels 0..3 (tests/test_gpu_probe.py)
+    const int sl = lane & 15, chalf = (lane >> 4) & 1, kg = lane >> 5;
+    const int lane_cb = 2 * chalf + ((sl & 3) >> 1), lane_byte = (sl & 1) * 8, lane_px = 8 * kg + (sl >> 2);
+
+    if (ntile > 0) {
+        issue(0);
+        commit(0);
+    }
+    __syncthreads();
+    for (int k = 0; k < ntile; ++k) {
+        const int buf = k & 1;
+        if (k + 1 < ntile) issue(k + 1);
+        if (active) {
+            const char* s_xh = reinterpret_cast<const char*>(s_buf + buf * XW_BUF_G);
+            const char* s_xl = s_xh + XW_XG * 16;
+            const char* s_gh = s_xl + XW_XG * 16;
+            const char* s_gl = s_gh + XW_GG * 16;
+            auto ld_tr = [&](const char* base) {
+                const x3_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(X3_LDS_PTR(x3_s16x4, base));
+                const x3_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(X3_LDS_PTR(x3_s16x4, base + 4 * 16));
+                return __builtin_bit_cast(x3_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            };
+            const int goff = (((mt * 4 + lane_cb) * XW_GPL) + lane_px) * 16 + lane_byte;              // + ry * XW_TW * 16
+            const int xoff = (((jt * 4 + lane_cb) * XW_XPL) + u * XW_XW + lane_px) * 16 + lane_byte;  // + (ry * XW_XW + v) * 16
+#pragma unroll
+            for (int ry = 0; ry < XW_TH; ++ry) {
+                const x3_bf16x8 gh = ld_tr(s_gh + goff + ry * XW_TW * 16), gl = ld_tr(s_gl + goff + ry * XW_TW * 16);
+                x3_bf16x8 xh[3], xl[3];
+#pragma unroll
+                for (int v = 0; v < 3; ++v) {
+                    xh[v] = ld_tr(s_xh + xoff + (ry * XW_XW + v) * 16);
+                    xl[v] = ld_tr(s_xl + xoff + (ry * XW_XW + v) * 16);
+                }
+#pragma unroll
+                for (int v = 0; v < 3; ++v) acc[v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gl, xh[v], acc[v], 0, 0, 0);
+#pragma unroll
+                for (int v = 0; v < 3; ++v) acc[v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh, xl[v], acc[v], 0, 0, 0);
+#pragma unroll
+                for (int v = 0; v < 3; ++v) acc[v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh, xh[v], acc[v], 0, 0, 0);
+                if (want_db) {
+                    accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gl, ones, accb, 0, 0, 0);
+                    accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh, ones, accb, 0, 0, 0);
+                }
+            }
+        }
+        if (k + 1 < ntile) commit(buf ^ 1);
+        __syncthreads();
+    }
+    // lane l reg r of acc[v]: oc = 32 mt + (r & 3) + 8 (r >> 2) + 4 (l >> 5), ic = 32 jt + (l & 31), tap (u, v)
+    if (active) {
+        float* dst = partial + ((long long)gi * npairs + pair) * XW_PER;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int oc = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), ic = 32 * jt + (lane & 31);
+#pragma unroll
+            for (int v = 0; v < 3; ++v) dst[(oc * 64 + ic) * 9 + u * 3 + v] = acc[v][r];
+            if (want_db && (lane & 31) == 0) dst[64 * 64 * 9 + oc] = accb[r];
+        }
+    }
+}
+
+// dw / db = fixed-order sum of the G block partials of each (icg, ocg) pair
+__global__ __launch_bounds__(256) void wgrad_x3_reduce(const float* __restrict__ partial, float* __restrict__ dw, float* __restrict__ db,
+                                                       int cin, int cout, int G, int n_icg, int n_ocg, int accumulate) {
+    __shared__ float red[4][64];
+    const int total_w = cout * cin * 9;
+    const int o_local = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + o_local;
+    const int npairs = n_icg * n_ocg;
+    long long off = -1;
+    if (idx < total_w) {
+        const int tap = idx % 9, c = (idx / 9) % cin, o = idx / (9 * cin);
+        off = (long long)((c / 64) + n_icg * (o / 64)) * XW_PER + ((o % 64) * 64 + (c % 64)) * 9 + tap;
+    } else if (idx < total_w + cout) {
+        const int o = idx - total_w;
+        off = (long long)(0 + n_icg * (o / 64)) * XW_PER + 64 * 64 * 9 + (o % 64);
+    }
+    float s = 0.f;
+    if (off >= 0) {
+        const long long stride = (long long)npairs * XW_PER;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int gi = slice;
+        for (; gi + 12 < G; gi += 16) {
+            s0 += partial[gi * stride + off];
+            s1 += partial[(gi + 4) * stride + off];
+            s2 += partial[(gi + 8) * stride + off];
+            s3 += partial[(gi + 12) * stride + off];
+        }
+        for (; gi < G; gi += 4) s0 += partial[gi * stride + off];
+        s = (s0 + s1) + (s2 + s3);
+    }
+    red[slice][o_local] = s;
+    __syncthreads();
+    if (slice == 0 && off >= 0) {
+        const float t = (red[0][o_local] + red[1][o_local]) + (red[2][o_local] + red[3][o_local]);
+        if (idx < total_w) dw[idx] = accumulate ? dw[idx] + t : t;
+        else if (db != nullptr) db[idx - total_w] = accumulate ? db[idx - total_w] + t : t;
+    }
+}
+
+// ------------------------------------------------------------------ host side
+static int x3_num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+static bool x3_enabled() {   // $MMIF_X3=0: fp32 tensors stay on the fp32 FMA kernels (A/B timing, cross-checks)
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("MMIF_X3");
+        on = (e != nullptr && e[0] == '0') ? 0 : 1;
+    }
+    return on == 1;
+}
+
+static bool x3_grad_ok(const TV& t) { return t.halo == 0 || (t.halo == 1 && t.folded); }
+static bool x3_small(const TV& t) { return t.plane * 32 < (1ll << 31); }
+
+bool conv_x3_supported(bool dgrad, int ks, int cin, int cout, const TV& tin, const TV& tout) {
+    if (!x3_enabled() || ks != 3 || cin < 1 || cout < 1) return false;
+    if (dgrad && !x3_grad_ok(tin)) return false;
+    if ((dgrad ? cin : cout) > 64 * 8) return false;   // mask / accum bits address 64 channel blocks
+    return tin.h >= 2 && tin.w >= 2 && x3_small(tin) && x3_small(tout);
+}
+
+size_t conv_x3_packed_bytes(int cout, int cin, int ks) {
+    if (ks != 3) return 16;
+    const size_t a = x3_packed_bytes(cout, cin), b = x3_packed_bytes(cin, cout);
+    return a > b ? a : b;
+}
+
+int conv_x3_pack_multi(const mmif_pack_job* jobs, int n_jobs, hipStream_t st) {
+    X3PackTable tab;
+    int n = 0;
+    auto flush = [&]() -> int {
+        if (n == 0) return MMIF_OK;
+        hipLaunchKernelGGL(x3_pack_kernel, dim3(64, n), dim3(256), 0, st, tab);
+        n = 0;
+        return check_launch("pack_weights_x3");
+    };
+    for (int i = 0; i < n_jobs; ++i) {
+        const mmif_pack_job& jb = jobs[i];
+        if (jb.format != MMIF_PACK_X3 || jb.ksize != 3) continue;   // (1x1 layers of fp32 tensors stay on the fp32 FMA kernels: nothing to pack)
+        for (int d = 0; d < 2; ++d) {
+            void* dst = d ? jb.packed_dgrad : jb.packed_fwd;
+            if (dst == nullptr) continue;
+            const int n_out = d ? jb.cin : jb.cout, n_in = d ? jb.cout : jb.cin;
+            X3PackImage& im = tab.im[n++];
+            im.w = jb.w; im.dst = (bf16_t*)dst; im.cout = jb.cout; im.cin = jb.cin; im.dgrad = d;
+            im.mbw = 32 * x3_mb(n_out); im.nch = x3_nch(n_in);
+            im.total = (long long)x3_nmb(n_out) * im.nch * 9 * 2 * im.mbw * 8;   // elements of the hi halves
+            if (n == X3_PACK_MAX)
+                if (int rc = flush()) return rc;
+        }
+    }
+    return flush();
+}
+
+template <int MB>
+static int launch_conv_x3(bool dgrad, const TV& tin, const TV& tout, const TV& tmask, const void* wpk, const float* bias, int n_out, int n_in,
+                          int relu, uint64_t mask_bits, uint64_t accum_bits, hipStream_t st) {
+    const int tiles_x = cdiv(tout.ws, X3_TW), tiles_y = cdiv(tout.hs, X3_TH);
+    const int tpi = tiles_x * tiles_y, total = tpi * tout.n;
+    int G = x3_num_cus();
+    if (total < G) G = total;
+    const int nch = x3_nch(n_in), nmb = x3_nmb(n_out);
+    if (dgrad)
+        hipLaunchKernelGGL((conv_x3_kernel<MB, true>), dim3(G), dim3(X3_THREADS), 0, st, tin, tout, tmask, (const uint4*)wpk, bias, n_out, nch, nmb,
+                           relu, (unsigned long long)mask_bits, (unsigned long long)accum_bits, tiles_x, tpi, total);
+    else
+        hipLaunchKernelGGL((conv_x3_kernel<MB, false>), dim3(G), dim3(X3_THREADS), 0, st, tin, tout, tmask, (const uint4*)wpk, bias, n_out, nch, nmb,
+                           relu, (unsigned long long)mask_bits, (unsigned long long)accum_bits, tiles_x, tpi, total);
+    return check_launch(dgrad ? "conv_x3 dgrad" : "conv_x3 fwd");
+}
+
+// forward: tin = x, tout = y;  dgrad: tin = gy (halo 0 or folded halo 1), tout = gx (the padded domain is written; the caller folds)
+int conv_x3(bool dgrad, const TV& tin, const TV& tout, const TV& tmask, const void* wpk, const float* bias, int cin, int cout, int relu,
+            uint64_t mask_bits, uint64_t accum_bits, hipStream_t st) {
+    const int n_out = dgrad ? cin : cout, n_in = dgrad ? cout : cin;
+    if (x3_mb(n_out) == 2) return launch_conv_x3<2>(dgrad, tin, tout, tmask, wpk, bias, n_out, n_in, relu, mask_bits, accum_bits, st);
+    return launch_conv_x3<1>(dgrad, tin, tout, tmask, wpk, bias, n_out, n_in, relu, mask_bits, accum_bits, st);
+}
+
+bool wgrad_x3_supported(int ks, int cin, int cout, const TV& tx, const TV& tg) {
+    return x3_enabled() && ks == 3 && cin >= 1 && cout >= 1 && x3_grad_ok(tg) && tx.halo == 0 && tx.h >= 2 && tx.w >= 2 && x3_small(tx) && x3_small(tg);
+}
+
+static int wgrad_x3_G(int cin, int cout) {
+    const int npairs = cdiv(cin, 64) * cdiv(cout, 64);
+    int G = x3_num_cus() / npairs;
+    if (G >= 8) G &= ~7;
+    return G < 1 ? 1 : G;
+}
+
+size_t wgrad_x3_workspace(int cin, int cout, int ks) {
+    if (ks != 3) return 0;
+    const size_t npairs = (size_t)cdiv(cin, 64) * cdiv(cout, 64);
+    size_t G = 256 / npairs;   // upper bound of wgrad_x3_G on any gfx950 part (<= 256 CUs) without asking the device
+    if (G < 1) G = 1;
+    const size_t dyn = (size_t)wgrad_x3_G(cin, cout);
+    if (dyn > G) G = dyn;
+    return G * npairs * XW_PER * sizeof(float);
+}
+
+int wgrad_x3(const TV& tx, const TV& tg, float* dw, float* db, int cin, int cout, int accumulate, float* ws, hipStream_t st) {
+    const int tiles_x = cdiv(tx.w, XW_TW), tiles_y = cdiv(tx.h, XW_TH);
+    const int tpi = tiles_x * tiles_y, total = tpi * tx.n;
+    const int n_icg = cdiv(cin, 64), n_ocg = cdiv(cout, 64);
+    int G = wgrad_x3_G(cin, cout);
+    if (total < G) G = total;
+    hipLaunchKernelGGL(wgrad_x3_kernel, dim3(G * n_icg * n_ocg), dim3(XW_THREADS), 0, st, tx, tg, ws, cin, cout, tiles_x, tpi, total, G, n_icg, n_ocg);
+    if (int rc = check_launch("wgrad_x3")) return rc;
+    const int n = cout * cin * 9 + cout;
+    hipLaunchKernelGGL(wgrad_x3_reduce, dim3(cdiv(n, 64)), dim3(256), 0, st, ws, dw, db, cin, cout, G, n_icg, n_ocg, accumulate);
+    return check_launch("wgrad_x3_reduce");
+}
+
+}  // namespace mmif
+
+using namespace mmif;
+
+extern "C" size_t mmif_packed_weight_bytes_x3(int32_t cout, int32_t cin, int32_t ksize) { return conv_x3_packed_bytes(cout, cin, ksize); }
+
+extern "C" int mmif_pack_weights_x3(const float* w, int32_t cout, int32_t cin, int32_t ksize, void* packed_fwd, void* packed_dgrad, void* stream) {
+    MMIF_REQUIRE(ksize == 3, "pack_weights_x3: ksize must be 3");
+    MMIF_REQUIRE(w != nullptr && cout > 0 && cin > 0, "pack_weights_x3: bad arguments");
+    mmif_pack_job jb;
+    jb.w = w; jb.cout = cout; jb.cin = cin; jb.ksize = ksize; jb.format = MMIF_PACK_X3; jb.packed_fwd = packed_fwd; jb.packed_dgrad = packed_dgrad;
+    return conv_x3_pack_multi(&jb, 1, (hipStream_t)stream);
+}

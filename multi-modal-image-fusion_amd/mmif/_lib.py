@@ -14,7 +14,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MMIF_LIB") or os.path.join(os.path.dirname(_HERE), "libmmif_hip.so")
 
 F32, BF16 = 0, 1
-IMPL_AUTO, IMPL_VALU, IMPL_MFMA = 0, 1, 2
+IMPL_AUTO, IMPL_VALU, IMPL_MFMA, IMPL_X3 = 0, 1, 2, 3
+PACK_BF16, PACK_X3 = 0, 1
 FUSE_SUM, FUSE_MEAN, FUSE_MAX = 0, 1, 2
 T_FOLDED = 1
 
@@ -25,7 +26,7 @@ class MmifTensor(C.Structure):
 
 
 class MmifPackJob(C.Structure):
-    _fields_ = [("w", C.c_void_p), ("cout", C.c_int32), ("cin", C.c_int32), ("ksize", C.c_int32), ("reserved", C.c_int32),
+    _fields_ = [("w", C.c_void_p), ("cout", C.c_int32), ("cin", C.c_int32), ("ksize", C.c_int32), ("format", C.c_int32),
                 ("packed_fwd", C.c_void_p), ("packed_dgrad", C.c_void_p)]
 
 
@@ -61,6 +62,8 @@ SIGNATURES = {
     "mmif_packed_weight_bytes": (_sz, [_i32, _i32, _i32]),
     "mmif_pack_weights": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "mmif_pack_weights_multi": (_i32, [C.POINTER(MmifPackJob), _i32, _vp]),
+    "mmif_packed_weight_bytes_x3": (_sz, [_i32, _i32, _i32]),
+    "mmif_pack_weights_x3": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "mmif_gconv_fwd": (_i32, [_vp, _vp, _vp, _vp] + [_i32] * 10 + [_vp]),
     "mmif_gconv_dgrad_workspace": (_sz, [_i32] * 6),
     "mmif_gconv_dgrad": (_i32, [_vp, _vp, _vp] + [_i32] * 9 + [_vp, _sz, _vp]),

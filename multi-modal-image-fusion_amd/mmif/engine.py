@@ -49,8 +49,21 @@ def set_compute_dtype(dtype):
 
 
 def conv_impl():
-    """MMIF_IMPL_AUTO unless $MMIF_CONV_IMPL = valu | mfma (cross-checking the two kernel families)."""
-    return {"valu": _lib.IMPL_VALU, "mfma": _lib.IMPL_MFMA}.get(os.environ.get("MMIF_CONV_IMPL", "auto").lower(), _lib.IMPL_AUTO)
+    """MMIF_IMPL_AUTO unless $MMIF_CONV_IMPL = valu | mfma | x3 (cross-checking the kernel families)."""
+    return {"valu": _lib.IMPL_VALU, "mfma": _lib.IMPL_MFMA, "x3": _lib.IMPL_X3}.get(os.environ.get("MMIF_CONV_IMPL", "auto").lower(), _lib.IMPL_AUTO)
+
+
+def x3_enabled():
+    """fp32 tensors: 3x3 layers on the matrix pipe as split-bf16 products (csrc/conv_x3.hip, ~1e-5 of the fp32 FMA kernels' results);
+    $MMIF_X3=0 keeps them on the fp32 FMA kernels (the library reads the same switch)."""
+    return os.environ.get("MMIF_X3", "1") != "0"
+
+
+def wants_packed(dtype, impl):
+    """do the conv kernels this (storage dtype, impl) pair selects take operand images?"""
+    if impl == _lib.IMPL_VALU:
+        return False
+    return dtype == torch.bfloat16 or x3_enabled()
 
 
 def bits(*blocks):
@@ -99,9 +112,10 @@ class ConvSpec:
         w = self.conv.weight
         return (version, WEIGHTS_EPOCH[0], w._version, w.data_ptr())
 
-    def refresh(self, version, pack, batch=None):
-        """Bring the derived weight images (channel permutation, bf16 MFMA packing) up to date.  With `batch` (a list) the
-        packing itself is left to the caller: (PackedWeights, weight) pairs for ONE T.pack_many launch."""
+    def refresh(self, version, pack, batch=None, fmt=_lib.BF16):
+        """Bring the derived weight images (channel permutation, MFMA operand packing in the format of the storage dtype) up to
+        date.  With `batch` (a list) the packing itself is left to the caller: (PackedWeights, weight) pairs for ONE T.pack_many
+        launch."""
         key = self._key(version)
         if self.split and self.perm_version != key:
             w = self.conv.weight.detach()
@@ -109,8 +123,8 @@ class ConvSpec:
             self.perm_version = key
         if pack and self.cin > 1 and self.cout > 1 and not self.pair:
             w = self.conv.weight
-            if self.packed is None or self.packed.fwd.device != w.device:
-                self.packed = PackedWeights(self.cout, self.cin, self.k, w.device)
+            if self.packed is None or self.packed.fwd.device != w.device or self.packed.fmt != fmt:
+                self.packed = PackedWeights(self.cout, self.cin, self.k, w.device, fmt)
                 self.packed_version = None
             if self.packed_version != key:
                 if batch is not None:
@@ -280,10 +294,11 @@ class ModelEngine:
     def prepare(self, imgs):
         dtype = compute_dtype()
         impl = conv_impl()
-        use_mfma = dtype == torch.bfloat16 and impl != _lib.IMPL_VALU
+        use_mfma = wants_packed(dtype, impl)
+        fmt = _lib.BF16 if dtype == torch.bfloat16 else _lib.F32
         stale = []
         for s in self.specs:
-            s.refresh(self.weights_version, use_mfma, stale)
+            s.refresh(self.weights_version, use_mfma, stale, fmt)
         T.pack_many(stale)   # all stale operand images of the model in one launch
         imgs = [None if i is None else i.detach().contiguous().float() for i in imgs]
         n, c, h, w = imgs[0].shape

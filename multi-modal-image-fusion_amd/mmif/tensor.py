@@ -91,18 +91,38 @@ class BT:
 
 
 class PackedWeights:
-    """bf16 MFMA operand images of one conv layer's weights (forward + dgrad)."""
-    __slots__ = ("fwd", "dgrad", "cout", "cin", "k")
+    """MFMA operand images of one conv layer's weights (forward + dgrad).  fmt = BF16: the bf16 kernels' images (bf16 tensors);
+    fmt = F32: the split-bf16 "x3" images, hi = bf16(w) / lo = bf16(w - hi), of the fp32-grade kernels that run fp32 tensors'
+    3x3 layers on the matrix pipe (csrc/conv_x3.hip; a 1x1 layer has no x3 image and stays on the fp32 FMA kernels)."""
+    __slots__ = ("fwd", "dgrad", "cout", "cin", "k", "fmt")
 
-    def __init__(self, cout, cin, k, device):
-        nbytes = lib.mmif_packed_weight_bytes(cout, cin, k)
+    def __init__(self, cout, cin, k, device, fmt=BF16):
+        assert fmt in (BF16, F32)
+        nbytes = lib.mmif_packed_weight_bytes_x3(cout, cin, k) if fmt == F32 else lib.mmif_packed_weight_bytes(cout, cin, k)
         self.fwd = torch.empty(nbytes, dtype=torch.uint8, device=device)
         self.dgrad = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        self.cout, self.cin, self.k = cout, cin, k
+        self.cout, self.cin, self.k, self.fmt = cout, cin, k, fmt
+
+    @property
+    def usable(self):
+        return self.fmt == BF16 or self.k == 3
 
     def pack(self, w):
+        if self.fmt == F32:
+            if self.k == 3:
+                check(lib.mmif_pack_weights_x3(_ptr(w), self.cout, self.cin, self.k, _ptr(self.fwd), _ptr(self.dgrad), stream_ptr()),
+                      "pack_weights_x3")
+            return
         check(lib.mmif_pack_weights(_ptr(w), self.cout, self.cin, self.k, _ptr(self.fwd), _ptr(self.dgrad), stream_ptr()),
               "pack_weights")
+
+
+def _image(packed, which, code):
+    """pointer to a layer's operand image when it is in the format the tensors' dtype needs (else NULL: the kernels that take the fp32
+    master weights run)"""
+    if packed is None or packed.fmt != code or not packed.usable:
+        return None
+    return _ptr(getattr(packed, which))
 
 
 def pack_many(pairs):
@@ -112,6 +132,7 @@ def pack_many(pairs):
     jobs = (_lib.MmifPackJob * len(pairs))()
     for j, (pk, w) in zip(jobs, pairs):
         j.w, j.cout, j.cin, j.ksize = w.data_ptr(), pk.cout, pk.cin, pk.k
+        j.format = _lib.PACK_X3 if pk.fmt == F32 else _lib.PACK_BF16
         j.packed_fwd, j.packed_dgrad = pk.fwd.data_ptr(), pk.dgrad.data_ptr()
     check(lib.mmif_pack_weights_multi(jobs, len(pairs), stream_ptr()), "pack_weights_multi")
 
@@ -145,7 +166,7 @@ class _timed:
 # ------------------------------------------------------------------ op wrappers
 def conv_fwd(x, w, bias, y, cin, cout, k, relu, packed=None, impl=_lib.IMPL_AUTO, tag=None):
     with _timed(tag, (x.n, x.h, x.w, cin, cout, k)):
-        check(lib.mmif_conv2d_reflect_fwd(x.d, _ptr(w), _ptr(packed.fwd) if packed is not None else None, _ptr(bias), y.d,
+        check(lib.mmif_conv2d_reflect_fwd(x.d, _ptr(w), _image(packed, "fwd", x.code), _ptr(bias), y.d,
                                           cin, cout, k, int(relu), impl, stream_ptr()), "conv2d_reflect_fwd")
 
 
@@ -154,7 +175,7 @@ def conv_dgrad(gy, w, x, gx, cin, cout, k, mask_bits=0, accum_bits=0, packed=Non
     returns the folded view."""
     fn = lib.mmif_conv2d_reflect_dgrad_folded if fold else lib.mmif_conv2d_reflect_dgrad
     with _timed(tag, (gy.n, gy.h, gy.w, cin, cout, k)):
-        check(fn(gy.d, _ptr(w), _ptr(packed.dgrad) if packed is not None else None, x.d if x is not None else None, gx.d, cin, cout,
+        check(fn(gy.d, _ptr(w), _image(packed, "dgrad", gy.code), x.d if x is not None else None, gx.d, cin, cout,
                  k, mask_bits, accum_bits, impl, stream_ptr()), "conv2d_reflect_dgrad")
     return gx.as_folded() if fold else gx
 

@@ -1,0 +1,140 @@
+"""The split-bf16 ("x3") kernels that run the 3x3 ConvLayers of FP32 tensors on the matrix pipe (csrc/conv_x3.hip): operand images,
+forward, input gradient (mask / accumulate bits, halo-0 and folded halo-1 upstream gradients) and weight gradient against the fp32 FMA
+kernels on identical operands and against the fp64 definition.  The reference computes these layers in fp32 (core/block.py:56-66,
+98-99); the north-star bar is 1e-3 relative, the split products are held to 3e-5 here (2^-16 per product, fp32 accumulate)."""
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import close
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+X3_TOL = 3e-5
+
+
+def _split(w):
+    """numpy model of x3_split: hi = bf16(w) (RNE), lo = bf16(w - hi)"""
+    t = torch.from_numpy(np.ascontiguousarray(w, dtype=np.float32))
+    hi = t.bfloat16()
+    lo = (t - hi.float()).bfloat16()
+    return hi, lo
+
+
+@pytest.mark.parametrize("cout,cin", [(128, 128), (16, 48), (64, 128), (40, 24), (72, 136)])
+def test_x3_operand_images_bit_exact(cout, cin):
+    """mmif_pack_weights_x3: [m-block][chunk][hi | lo][tap][2 channel blocks][32*MB out][8 in] -- every element against the layout
+    formula, forward and (flipped, transposed) dgrad images"""
+    from mmif import tensor as T
+    from mmif._lib import F32
+    torch.manual_seed(cout * 131 + cin)
+    w = (torch.randn(cout, cin, 3, 3) * 0.1)
+    pk = T.PackedWeights(cout, cin, 3, DEV, F32)
+    pk.pack(w.to(DEV))
+    torch.cuda.synchronize()
+    wn = w.numpy()
+    for dgrad, img in ((0, pk.fwd), (1, pk.dgrad)):
+        n_out, n_in = (cin, cout) if dgrad else (cout, cin)
+        mb = 2 if n_out > 32 else 1
+        mbw = 32 * mb
+        nmb, nch = -(-n_out // mbw), -(-(-(-n_in // 8)) // 2)
+        wk = np.zeros((nmb * mbw, nch * 16, 3, 3), np.float32)   # [out][in][u][v] in the kernel's view
+        if dgrad:
+            wk[:n_out, :n_in] = wn.transpose(1, 0, 2, 3)[:, :, ::-1, ::-1]
+        else:
+            wk[:n_out, :n_in] = wn
+        want = wk.reshape(nmb, mbw, nch, 2, 8, 9).transpose(0, 2, 5, 3, 1, 4)   # [mb][ch][tap][cbl][ocl][e]
+        hi, lo = _split(want)
+        both = torch.stack((hi, lo), dim=2).contiguous()                        # [mb][ch][hi|lo][tap][cbl][ocl][e]
+        got = img.cpu().view(torch.bfloat16)[:both.numel()].view(both.shape)
+        assert torch.equal(got.view(torch.int16), both.view(torch.int16)), f"dgrad={dgrad}"
+
+
+SHAPES = [(128, 128, 2, 37, 53), (16, 16, 2, 40, 70), (48, 16, 1, 33, 64), (16, 48, 2, 31, 45), (64, 32, 1, 64, 48), (32, 16, 2, 16, 32),
+          (128, 64, 1, 19, 33), (24, 40, 2, 9, 100), (136, 88, 1, 20, 36), (8, 8, 1, 2, 2), (72, 152, 1, 17, 34), (64, 64, 3, 8, 16)]
+
+
+@pytest.mark.parametrize("cin,cout,n,h,w", SHAPES, ids=[f"{a}-{b}-{n}x{h}x{w}" for a, b, n, h, w in SHAPES])
+@pytest.mark.parametrize("ghalo", [0, 1])
+def test_x3_kernels_vs_fp32_fma_kernels(cin, cout, n, h, w, ghalo):
+    """forward (bias + ReLU), dgrad (partial mask / accumulate bit sets) and wgrad: IMPL_X3 vs IMPL_VALU on the same fp32 tensors --
+    ragged tiles, ragged 16-channel chunks (cin % 16 = 8), ragged 32 / 64-channel groups"""
+    from mmif import tensor as T
+    from mmif._lib import F32, IMPL_VALU, IMPL_X3
+    torch.manual_seed(cin * 7 + cout + h)
+    x = T.BT.alloc(n, cin, h, w, torch.float32, DEV); x.buf.normal_()
+    gy = T.BT.alloc(n, cout, h, w, torch.float32, DEV, halo=ghalo, zero=True)
+    if ghalo:
+        gy.buf[:, :, 1:-1, 1:-1].normal_()
+        gy = gy.as_folded()
+    else:
+        gy.buf.normal_()
+    wt = torch.randn(cout, cin, 3, 3, device=DEV) * 0.05
+    b = torch.randn(cout, device=DEV)
+    pk = T.PackedWeights(cout, cin, 3, DEV, F32); pk.pack(wt)
+    ws = torch.empty(T.wgrad_workspace_bytes(cin, cout, 3) // 4 + 1, dtype=torch.float32, device=DEV)
+    mask = 0x5a5a5a5a5a5a & ((1 << x.cb) - 1)
+    acc_bits = 0x333333333333 & ((1 << x.cb) - 1)
+    res = {}
+    for impl in (IMPL_VALU, IMPL_X3):
+        y = T.BT.alloc(n, cout, h, w, torch.float32, DEV)
+        gx = T.BT.alloc(n, cin, h, w, torch.float32, DEV, halo=1, zero=True)
+        gx.buf.fill_(0.25)
+        dw, db = torch.full_like(wt, 0.5), torch.full_like(b, -0.5)
+        T.conv_fwd(x, wt, b, y, cin, cout, 3, True, pk, impl)
+        T.conv_dgrad(gy, wt, x, gx, cin, cout, 3, mask, acc_bits, pk, impl)
+        T.conv_wgrad(x, gy, dw, db, cin, cout, 3, ws, True, impl)
+        torch.cuda.synchronize()
+        res[impl] = [t.cpu().numpy() for t in (y.buf, gx.buf, dw, db)]
+    for (a, r, what) in zip(res[IMPL_X3], res[IMPL_VALU], ("y", "gx", "dw", "db")):
+        close(a, r, X3_TOL, what)
+
+
+def test_x3_forward_vs_fp64_definition():
+    """x3 forward on a 128 -> 128 layer against torch's fp64 conv on the CPU (reflect padding): the absolute error budget of the split
+    (2^-16 relative per product) next to the fp32 FMA kernel's own rounding"""
+    import torch.nn.functional as F
+    from mmif import tensor as T
+    from mmif._lib import F32, IMPL_VALU, IMPL_X3
+    torch.manual_seed(5)
+    n, c, h, w = 1, 128, 24, 40
+    xn = torch.randn(n, c, h, w)
+    wt = torch.randn(c, c, 3, 3) * 0.03
+    b = torch.randn(c)
+    ref = F.conv2d(F.pad(xn.double(), (1, 1, 1, 1), mode="reflect"), wt.double(), b.double()).clamp_min(0).numpy()
+    x = T.BT.from_nchw(xn.to(DEV), torch.float32)
+    pk = T.PackedWeights(c, c, 3, DEV, F32); pk.pack(wt.to(DEV))
+    errs = {}
+    for impl in (IMPL_VALU, IMPL_X3):
+        y = T.BT.alloc(n, c, h, w, torch.float32, DEV)
+        T.conv_fwd(x, wt.to(DEV), b.to(DEV), y, c, c, 3, True, pk, impl)
+        errs[impl] = np.abs(y.to_nchw(c).cpu().numpy() - ref).max() / np.abs(ref).max()
+    print("fp32 FMA err", errs[IMPL_VALU], "x3 err", errs[IMPL_X3])
+    assert errs[IMPL_X3] < 2e-5, errs
+
+
+def test_x3_is_the_default_for_fp32_and_can_be_forced_off():
+    """AUTO on fp32 tensors takes the x3 kernels when the layer's x3 image is passed (bit-identical to IMPL_X3), the fp32 FMA kernels
+    without it (bit-identical to IMPL_VALU); asking for IMPL_X3 on bf16 tensors or without the image is an error, not a fallback"""
+    from mmif import tensor as T
+    from mmif._lib import BF16, F32, IMPL_AUTO, IMPL_VALU, IMPL_X3, MmifError
+    torch.manual_seed(9)
+    n, cin, cout, h, w = 1, 32, 32, 20, 33
+    x = T.BT.alloc(n, cin, h, w, torch.float32, DEV); x.buf.normal_()
+    wt = torch.randn(cout, cin, 3, 3, device=DEV) * 0.05
+    b = torch.randn(cout, device=DEV)
+    pk = T.PackedWeights(cout, cin, 3, DEV, F32); pk.pack(wt)
+    out = {}
+    for key, impl, p in (("auto", IMPL_AUTO, pk), ("x3", IMPL_X3, pk), ("auto_nopk", IMPL_AUTO, None), ("valu", IMPL_VALU, pk)):
+        y = T.BT.alloc(n, cout, h, w, torch.float32, DEV)
+        T.conv_fwd(x, wt, b, y, cin, cout, 3, True, p, impl)
+        out[key] = y.buf.clone()
+    assert torch.equal(out["auto"], out["x3"]) and torch.equal(out["auto_nopk"], out["valu"])
+    assert not torch.equal(out["x3"], out["valu"])
+    y = T.BT.alloc(n, cout, h, w, torch.float32, DEV)
+    with pytest.raises(MmifError):
+        T.conv_fwd(x, wt, b, y, cin, cout, 3, True, None, IMPL_X3)
+    pkb = T.PackedWeights(cout, cin, 3, DEV, BF16); pkb.pack(wt)
+    with pytest.raises(MmifError):    # a bf16-format image is not an x3 image: never reinterpreted
+        T.conv_fwd(x, wt, b, y, cin, cout, 3, True, pkb, IMPL_X3)
