@@ -97,9 +97,17 @@ typedef struct mmif_pack_job {
 } mmif_pack_job;
 int mmif_pack_weights_multi(const mmif_pack_job* jobs, int32_t n_jobs, void* stream);
 /* Operand images of the split-bf16 ("x3") kernels that run the 3x3 ConvLayers of FP32 tensors on the matrix pipe at fp32-grade
- * accuracy (core/block.py:56-66 computes in fp32; BASELINE north star: within 1e-3 of it): every weight is stored as hi = bf16(w) and
- * lo = bf16(w - hi); layout [m-block][16-channel chunk][hi | lo][tap][2 channel blocks][32 or 64 out channels][8] (csrc/conv_x3.hip).
+ * accuracy (core/block.py:56-66 computes in fp32; BASELINE north star: within 1e-3 of it): every weight is stored as successive bf16
+ * pieces hi = bf16(w), mid = bf16(w - hi) [, lo = bf16(w - hi - mid)]; layout [m-block][16-channel chunk][piece][tap][2 channel
+ * blocks][32 or 64 out channels][8] (csrc/conv_x3.hip).
  * Pass them as w_packed / w_packed_t of the conv entry points below when the tensors are fp32.  ksize must be 3. */
+/* Pieces of the FORWARD image: 3 (default: hi / mid / lo, six products per tap -- fp32-grade activations, so ReLU decisions agree with the
+ * reference's as often as between two fp32 implementations) or 2 (three products, activations within ~1e-5; a mask flip on a
+ * pre-activation that close to zero moves parameter gradients by O(1e-3)).  The dgrad image always has 2 (the backward kernels are
+ * linear in the gradient).  Process-wide setting, also $MMIF_X3_FWD_PIECES; set it BEFORE packing: the forward kernel reads the image
+ * in the current format. */
+void mmif_set_x3_forward_pieces(int32_t pieces);
+int32_t mmif_get_x3_forward_pieces(void);
 size_t mmif_packed_weight_bytes_x3(int32_t cout, int32_t cin, int32_t ksize);
 int mmif_pack_weights_x3(const float* w, int32_t cout, int32_t cin, int32_t ksize, void* packed_fwd, void* packed_dgrad, void* stream);
 

@@ -33,7 +33,7 @@ class _ConvLayerFn(torch.autograd.Function):
         dev = x.device
         wd, bd = weight.detach(), bias.detach() if bias is not None else None
         packed = None
-        if E.wants_packed(dtype, impl) and cin > 1 and cout > 1:
+        if E.wants_packed(dtype, impl, standalone=True) and cin > 1 and cout > 1:
             packed = T.PackedWeights(cout, cin, k, dev, _lib.BF16 if dtype == torch.bfloat16 else _lib.F32)
             packed.pack(wd)
         if cin == 1:
@@ -91,7 +91,9 @@ class _ConvLayerFn(torch.autograd.Function):
             else:
                 xb = a
                 ws = torch.empty(T.wgrad_workspace_bytes(cin, cout, k) // 4 + 1, dtype=torch.float32, device=dev)
-                T.conv_wgrad(xb, gb, dw, db, cin, cout, k, ws, False, impl)
+                # (fp32 without an x3 image = this layer stays on the exact fp32 FMA kernels: its weight gradient too)
+                wimpl = _lib.IMPL_VALU if (dtype == torch.float32 and packed is None) else impl
+                T.conv_wgrad(xb, gb, dw, db, cin, cout, k, ws, False, wimpl)
                 if ctx.needs_input_grad[0]:
                     gxb = BT.alloc(n, cin, h, w, dtype, dev, halo=1)
                     T.conv_dgrad(gb, wd, None, gxb, cin, cout, k, 0, 0, packed, impl)

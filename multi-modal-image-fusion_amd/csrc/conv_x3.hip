@@ -43,27 +43,22 @@ __host__ __device__ constexpr int x3_mb(int n_out) { return n_out > 32 ? 2 : 1; 
 static inline int x3_nmb(int n_out) { return cdiv(n_out, 32 * x3_mb(n_out)); }
 static inline int x3_nch(int n_in) { return cdiv(cdiv(n_in, 8), 2); }
 // operand image: [m-block][chunk][hi | lo][tap u*3+v][channel block 0 / 1 of the chunk][32*MB out channels][8 in channels] bf16
-static size_t x3_packed_bytes(int n_out, int n_in) {
-    return (size_t)x3_nmb(n_out) * x3_nch(n_in) * 2 * 9 * 2 * 32 * x3_mb(n_out) * 16;
-}
-
-// fp32 -> (hi, lo) bf16 pair of one value (round to nearest even twice; x - hi is exact in fp32)
-__host__ __device__ inline void x3_split(float x, bf16_t& hi, bf16_t& lo) {
-    hi = f32_to_bf16(x);
-    lo = f32_to_bf16(x - bf16_to_f32(hi));
+static size_t x3_packed_bytes(int n_out, int n_in, int pieces) {
+    return (size_t)x3_nmb(n_out) * x3_nch(n_in) * pieces * 9 * 2 * 32 * x3_mb(n_out) * 16;
 }
 
 // ------------------------------------------------------------------ weight packing
 constexpr int X3_PACK_MAX = 64;
-struct X3PackImage { const float* w; bf16_t* dst; long long total; int cout, cin, dgrad, mbw, nch; };
+struct X3PackImage { const float* w; bf16_t* dst; long long total; int cout, cin, dgrad, mbw, nch, pieces; };
 struct X3PackTable { X3PackImage im[X3_PACK_MAX]; };
 
 // dgrad == 0: out = o, in = c, Wk[u][v] = W[o][c][u][v];  dgrad == 1: out = c, in = o, Wk[u][v] = W[o][c][2-u][2-v]
+// image: [m-block][chunk][piece 0 .. pieces-1][tap][channel block of the chunk][32*MB out][8 in]
 __global__ void x3_pack_kernel(X3PackTable tab) {
     const X3PackImage& J = tab.im[blockIdx.y];
     const int n_out = J.dgrad ? J.cin : J.cout, n_in = J.dgrad ? J.cout : J.cin;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < J.total; idx += (long long)gridDim.x * blockDim.x) {
-        // idx enumerates the bf16 elements of the HI half images; the LO element sits 9*2*mbw*8 elements further
+        // idx enumerates the bf16 elements of the FIRST piece's images; piece p sits p * 9*2*mbw*8 elements further
         const int e = (int)(idx & 7);
         long long r = idx >> 3;
         const int ocl = (int)(r % J.mbw); r /= J.mbw;
@@ -78,46 +73,72 @@ __global__ void x3_pack_kernel(X3PackTable tab) {
             if (J.dgrad) val = J.w[(((long long)ic * J.cin + oc) * 3 + (2 - u)) * 3 + (2 - v)];
             else val = J.w[(((long long)oc * J.cin + ic) * 3 + u) * 3 + v];
         }
-        bf16_t hi, lo;
-        x3_split(val, hi, lo);
-        const long long half = (long long)9 * 2 * J.mbw * 8;
+        const long long piece = (long long)9 * 2 * J.mbw * 8;
         const long long within = ((long long)(tap * 2 + cbl) * J.mbw + ocl) * 8 + e;
-        const long long base = ((long long)mb * J.nch + ch) * 2 * half;
-        J.dst[base + within] = hi;
-        J.dst[base + half + within] = lo;
+        const long long base = ((long long)mb * J.nch + ch) * J.pieces * piece;
+        for (int p = 0; p < J.pieces; ++p) {   // successive bf16 roundings of the remainder (each subtraction is exact in fp32)
+            const bf16_t q = f32_to_bf16(val);
+            J.dst[base + p * piece + within] = q;
+            val -= bf16_to_f32(q);
+        }
     }
 }
 
 // ------------------------------------------------------------------ staging helpers
 struct X3Gran { x3_f4 a, b; };   // one fp32 granule (8 channels of one pixel)
 
-__device__ inline void x3_split_pair(float v0, float v1, unsigned& h, unsigned& l) {
-    h = pack_bf16x2(v0, v1);
-    l = pack_bf16x2(v0 - __uint_as_float(h << 16), v1 - __uint_as_float(h & 0xffff0000u));
+// NP bf16 pieces of a granule: piece[0] = bf16(x), piece[1] = bf16(x - piece[0]), piece[2] = bf16(x - piece[0] - piece[1])
+template <int NP>
+__device__ inline void x3_split_pair(float v0, float v1, unsigned (&q)[NP]) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        q[p] = pack_bf16x2(v0, v1);
+        if (p + 1 < NP) {
+            v0 -= __uint_as_float(q[p] << 16);
+            v1 -= __uint_as_float(q[p] & 0xffff0000u);
+        }
+    }
 }
-__device__ inline void x3_split_gran(const X3Gran& g, x3_u4& hi, x3_u4& lo) {
-    unsigned h0, h1, h2, h3, l0, l1, l2, l3;
-    x3_split_pair(g.a.x, g.a.y, h0, l0);
-    x3_split_pair(g.a.z, g.a.w, h1, l1);
-    x3_split_pair(g.b.x, g.b.y, h2, l2);
-    x3_split_pair(g.b.z, g.b.w, h3, l3);
-    hi = (x3_u4){h0, h1, h2, h3};
-    lo = (x3_u4){l0, l1, l2, l3};
+template <int NP>
+__device__ inline void x3_split_gran(const X3Gran& g, x3_u4 (&out)[NP]) {
+    unsigned q0[NP], q1[NP], q2[NP], q3[NP];
+    x3_split_pair<NP>(g.a.x, g.a.y, q0);
+    x3_split_pair<NP>(g.a.z, g.a.w, q1);
+    x3_split_pair<NP>(g.b.x, g.b.y, q2);
+    x3_split_pair<NP>(g.b.z, g.b.w, q3);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) out[p] = (x3_u4){q0[p], q1[p], q2[p], q3[p]};
 }
 
 __device__ inline x3_bf16x8 x3_frag(const x3_u4& v) { return __builtin_bit_cast(x3_bf16x8, v); }
 
+// products (A piece, B piece) accumulated per tap, smallest first.  NP = 2: lo*hi + hi*lo + hi*hi (error ~2^-17 per product);
+// NP = 3: mid*mid + lo*hi + hi*lo + mid*hi + hi*mid + hi*hi (what is dropped is below 2^-25: fp32 grade)
+template <int NP> struct X3Prod;
+template <> struct X3Prod<2> { static constexpr int N = 3; static constexpr int A[3] = {1, 0, 0}; static constexpr int B[3] = {0, 1, 0}; };
+template <> struct X3Prod<3> { static constexpr int N = 6; static constexpr int A[6] = {1, 2, 0, 1, 0, 0}; static constexpr int B[6] = {1, 0, 2, 0, 1, 0}; };
+
+constexpr int X3_BIAS_G = 128;   // granules reserved behind the tiles for the bias vector (512 floats)
+
 // ------------------------------------------------------------------ forward / dgrad
-template <int MB, bool DGRAD>
+// NP = 2: operands as (hi, lo), 3 MFMAs per tap and accumulator tile, LDS tiles double buffered (one barrier per chunk).
+// NP = 3: operands as (hi, mid, lo), 6 MFMAs -- the FORWARD pass's default: a ReLU decision on a pre-activation within the 2-piece
+//         error (~1e-5 of its scale) of zero would differ from the reference's about ten times as often as between two fp32
+//         implementations, and every such flip moves the parameter gradients by O(1e-3) whatever the image size.  The three
+//         images of a chunk fill 114 KB, so the LDS tile is single buffered (two barriers per chunk; the next chunk's global loads still
+//         fly during the MFMAs).
+template <int MB, bool DGRAD, int NP>
 __global__ __launch_bounds__(X3_THREADS) void conv_x3_kernel(TV tin, TV tout, TV tmask, const uint4* __restrict__ wpk,
                                                               const float* __restrict__ bias, int n_out, int nch, int nmb, int relu,
                                                               unsigned long long mask_bits, unsigned long long accum_bits, int tiles_x,
                                                               int tiles_per_img, int total_tiles) {
     constexpr int MBW = 32 * MB;
-    constexpr int WG = 9 * 2 * MBW;               // weight granules of one precision half of a chunk
-    constexpr int W_ROUNDS = (2 * WG + X3_THREADS - 1) / X3_THREADS;
-    constexpr int BUF_G = 2 * X3_ING + 2 * WG;    // [in hi][in lo][w hi][w lo]
-    __shared__ __attribute__((aligned(16))) x3_u4 s_buf[2 * BUF_G];
+    constexpr int WG = 9 * 2 * MBW;               // weight granules of one piece of a chunk
+    constexpr int W_ROUNDS = (NP * WG + X3_THREADS - 1) / X3_THREADS;
+    constexpr int BUF_G = NP * X3_ING + NP * WG;  // [in piece 0 .. NP-1][w piece 0 .. NP-1]
+    constexpr int NBUF = NP == 2 ? 2 : 1;
+    constexpr int NPROD = X3Prod<NP>::N;
+    __shared__ __attribute__((aligned(16))) x3_u4 s_buf[NBUF * BUF_G + X3_BIAS_G];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -125,6 +146,11 @@ __global__ __launch_bounds__(X3_THREADS) void conv_x3_kernel(TV tin, TV tout, TV
     const int per_tile = nch * nmb;
     const int nsteps = tw.count * per_tile;
     if (nsteps == 0) return;
+
+    if (!DGRAD) {   // bias (zero padded to the m-blocks) behind the tiles
+        float* s_bias = reinterpret_cast<float*>(s_buf + NBUF * BUF_G);
+        for (int i = tid; i < X3_BIAS_G * 4; i += X3_THREADS) s_bias[i] = (bias != nullptr && i < n_out) ? bias[i] : 0.f;
+    }
 
     // item of step s: tile ti = s / per_tile, m-block mb = (s / nch) % nmb, chunk c = s % nch
     X3Gran rin[X3_IN_ROUNDS];
@@ -161,11 +187,11 @@ __global__ __launch_bounds__(X3_THREADS) void conv_x3_kernel(TV tin, TV tout, TV
                 }
             }
         }
-        const x3_u4* src = reinterpret_cast<const x3_u4*>(wpk) + ((long long)mb * nch + c) * (2 * WG);
+        const x3_u4* src = reinterpret_cast<const x3_u4*>(wpk) + ((long long)mb * nch + c) * (NP * WG);
 #pragma unroll
         for (int k = 0; k < W_ROUNDS; ++k) {
             const int e = tid + X3_THREADS * k;
-            if (e < 2 * WG) rw[k] = src[e];
+            if (e < NP * WG) rw[k] = src[e];
         }
     };
     auto commit = [&](int buf) {
@@ -174,16 +200,16 @@ __global__ __launch_bounds__(X3_THREADS) void conv_x3_kernel(TV tin, TV tout, TV
         for (int k = 0; k < X3_IN_ROUNDS; ++k) {
             const int e = tid + X3_THREADS * k;
             if (e < X3_ING) {
-                x3_u4 hi, lo;
-                x3_split_gran(rin[k], hi, lo);
-                dst[e] = hi;
-                dst[X3_ING + e] = lo;
+                x3_u4 pc[NP];
+                x3_split_gran<NP>(rin[k], pc);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) dst[p * X3_ING + e] = pc[p];
             }
         }
 #pragma unroll
         for (int k = 0; k < W_ROUNDS; ++k) {
             const int e = tid + X3_THREADS * k;
-            if (e < 2 * WG) dst[2 * X3_ING + e] = rw[k];
+            if (e < NP * WG) dst[NP * X3_ING + e] = rw[k];
         }
     };
 
@@ -196,52 +222,60 @@ __global__ __launch_bounds__(X3_THREADS) void conv_x3_kernel(TV tin, TV tout, TV
             for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.f;
 
     const int cbl = lane >> 5, nl = lane & 31;
-    const int bbase = (cbl * X3_IH + 2 * wave) * X3_IW + nl;   // + i * X3_IW + v
-    const int abase = cbl * MBW + nl;                           // + tap * 2 * MBW + m * 32
+    const int bbase = (cbl * X3_IH + 2 * wave) * X3_IW + nl;   // + row * X3_IW + v   (+ piece * X3_ING)
+    const int abase = cbl * MBW + nl;                           // + tap * 2 * MBW + m * 32   (+ piece * WG)
 
     issue(0);
     commit(0);
     __syncthreads();
 
     for (int s = 0; s < nsteps; ++s) {
-        const int buf = s & 1;
+        const int buf = NBUF == 2 ? (s & 1) : 0;
         if (s + 1 < nsteps) issue(s + 1);
-        // ---------------- the chunk's 27 * 2 * MB MFMAs ----------------
+        // ---------------- the chunk's 9 taps: operand fragments of tap t+1 are fetched while tap t's MFMAs run ----------------
         {
-            const x3_u4* in_hi = s_buf + buf * BUF_G;
-            const x3_u4* in_lo = in_hi + X3_ING;
-            const x3_u4* w_hi = in_lo + X3_ING;
-            const x3_u4* w_lo = w_hi + WG;
+            const x3_u4* s_in = s_buf + buf * BUF_G;
+            const x3_u4* s_w = s_in + NP * X3_ING;
+            x3_bf16x8 brow[4][NP], afr[2][MB][NP];
+            // taps in column-major order t = 3 v + u: tap (u, v) reads tile rows u, u+1 of the wave's 4-row window at column shift v
+            auto ld_a = [&](int t, int slot) {
+                const int v = t / 3, u = t % 3, tap = u * 3 + v;
 #pragma unroll
-            for (int v = 0; v < 3; ++v) {
-                x3_bf16x8 bh[4], bl[4];
+                for (int m = 0; m < MB; ++m)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    bh[i] = x3_frag(in_hi[bbase + i * X3_IW + v]);
-                    bl[i] = x3_frag(in_lo[bbase + i * X3_IW + v]);
+                    for (int p = 0; p < NP; ++p) afr[slot][m][p] = x3_frag(s_w[p * WG + abase + tap * 2 * MBW + m * 32]);
+            };
+            auto ld_b = [&](int row, int v) {
+#pragma unroll
+                for (int p = 0; p < NP; ++p) brow[row][p] = x3_frag(s_in[p * X3_ING + bbase + row * X3_IW + v]);
+            };
+            ld_a(0, 0);
+            ld_b(0, 0);
+            ld_b(1, 0);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int u = t % 3;
+                int nld = 0;
+                if (t + 1 < 9) {
+                    const int v1 = (t + 1) / 3, u1 = (t + 1) % 3;
+                    ld_a(t + 1, (t + 1) & 1);
+                    nld += MB * NP;
+                    if (u1 == 0) { ld_b(0, v1); ld_b(1, v1); nld += 2 * NP; }
+                    else { ld_b(u1 + 1, v1); nld += NP; }
                 }
 #pragma unroll
-                for (int u = 0; u < 3; ++u) {
-                    const int tap = u * 3 + v;
-                    x3_bf16x8 ah[MB], al[MB];
-#pragma unroll
-                    for (int m = 0; m < MB; ++m) {
-                        ah[m] = x3_frag(w_hi[abase + tap * 2 * MBW + m * 32]);
-                        al[m] = x3_frag(w_lo[abase + tap * 2 * MBW + m * 32]);
-                    }
+                for (int q = 0; q < NPROD; ++q)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
 #pragma unroll
-                        for (int m = 0; m < MB; ++m) acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh[j + u], acc[m][j], 0, 0, 0);
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-#pragma unroll
-                        for (int m = 0; m < MB; ++m) acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl[j + u], acc[m][j], 0, 0, 0);
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-#pragma unroll
-                        for (int m = 0; m < MB; ++m) acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh[j + u], acc[m][j], 0, 0, 0);
+                        for (int m = 0; m < MB; ++m)
+                            acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[t & 1][m][X3Prod<NP>::A[q]], brow[u + j][X3Prod<NP>::B[q]], acc[m][j], 0, 0, 0);
+                // the prefetch reads ride between this tap's first MFMAs
+                for (int i = 0; i < nld; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
                 }
+                for (int i = nld; i < NPROD * 2 * MB; ++i) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             }
         }
         // ---------------- epilogue after the item's last chunk ----------------
@@ -255,49 +289,52 @@ __global__ __launch_bounds__(X3_THREADS) void conv_x3_kernel(TV tin, TV tout, TV
             for (int j = 0; j < 2; ++j) {
                 const int ys = ys0 + 2 * wave + j;
                 const bool inside = ys < tout.hs && xs < tout.ws;
+                x3_f4 old[MB][4], xm[MB][4];
+                if (DGRAD) {   // every accumulate / mask operand of the row first (one round trip), then the arithmetic
+                    const int oy = min(max(reflect_idx(ys - tout.halo, tmask.h), 0), tmask.h - 1);
+                    const int ox = min(max(reflect_idx(xs - tout.halo, tmask.w), 0), tmask.w - 1);
+#pragma unroll
+                    for (int m = 0; m < MB; ++m)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int ocb = (mb * MB + m) * 4 + q;
+                            old[m][q] = (x3_f4){0.f, 0.f, 0.f, 0.f};
+                            xm[m][q] = (x3_f4){1.f, 1.f, 1.f, 1.f};
+                            if (inside && ocb < tout.cb) {
+                                if ((accum_bits >> ocb) & 1ull)
+                                    old[m][q] = *reinterpret_cast<const x3_f4*>(tout.base + tout.gidx(in_, ocb, ys, xs) * 32 + half * 16);
+                                if ((mask_bits >> ocb) & 1ull)
+                                    xm[m][q] = *reinterpret_cast<const x3_f4*>(tmask.base + tmask.gidx(in_, ocb, oy, ox) * 32 + half * 16);
+                            }
+                        }
+                }
 #pragma unroll
                 for (int m = 0; m < MB; ++m) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int ocb = (mb * MB + m) * 4 + q;          // channel block of the out view
                         x3_f4 v = {acc[m][j][4 * q], acc[m][j][4 * q + 1], acc[m][j][4 * q + 2], acc[m][j][4 * q + 3]};
-                        if (inside && ocb < tout.cb) {
-                            x3_f4* dst = reinterpret_cast<x3_f4*>(tout.base + tout.gidx(in_, ocb, ys, xs) * 32 + half * 16);
-                            if (!DGRAD) {
-                                const int oc0 = ocb * 8 + 4 * half;
-                                if (bias != nullptr) {
-                                    if (oc0 + 3 < n_out) {
-                                        const x3_f4 b4 = *reinterpret_cast<const x3_f4*>(bias + oc0);
-                                        v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
-                                    } else {
-                                        if (oc0 + 0 < n_out) v.x += bias[oc0 + 0];
-                                        if (oc0 + 1 < n_out) v.y += bias[oc0 + 1];
-                                        if (oc0 + 2 < n_out) v.z += bias[oc0 + 2];
-                                    }
-                                }
-                                if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                            } else {
-                                if ((accum_bits >> ocb) & 1ull) {
-                                    const x3_f4 o = *dst;
-                                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-                                }
-                                if ((mask_bits >> ocb) & 1ull) {
-                                    const int oy = min(max(reflect_idx(ys - tout.halo, tmask.h), 0), tmask.h - 1);
-                                    const int ox = min(max(reflect_idx(xs - tout.halo, tmask.w), 0), tmask.w - 1);
-                                    const x3_f4 xm = *reinterpret_cast<const x3_f4*>(tmask.base + tmask.gidx(in_, ocb, oy, ox) * 32 + half * 16);
-                                    v.x = xm.x > 0.f ? v.x : 0.f; v.y = xm.y > 0.f ? v.y : 0.f;
-                                    v.z = xm.z > 0.f ? v.z : 0.f; v.w = xm.w > 0.f ? v.w : 0.f;
-                                }
-                            }
-                            *dst = v;
+                        if (!DGRAD) {
+                            const x3_f4 b4 = *reinterpret_cast<const x3_f4*>(reinterpret_cast<const float*>(s_buf + NBUF * BUF_G) + ocb * 8 + 4 * half);
+                            v += b4;
+                            if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                        } else {
+                            v += old[m][q];
+                            v.x = xm[m][q].x > 0.f ? v.x : 0.f; v.y = xm[m][q].y > 0.f ? v.y : 0.f;
+                            v.z = xm[m][q].z > 0.f ? v.z : 0.f; v.w = xm[m][q].w > 0.f ? v.w : 0.f;
                         }
+                        if (inside && ocb < tout.cb)
+                            *reinterpret_cast<x3_f4*>(tout.base + tout.gidx(in_, ocb, ys, xs) * 32 + half * 16) = v;
                     }
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.f;
                 }
             }
         }
-        if (s + 1 < nsteps) commit(buf ^ 1);
+        if (s + 1 < nsteps) {
+            if (NBUF == 1) __syncthreads();   // every wave has finished reading the single tile
+            commit(NBUF == 2 ? (buf ^ 1) : 0);
+        }
         __syncthreads();
     }
 }
@@ -370,8 +407,9 @@ __global__ __launch_bounds__(XW_THREADS) void wgrad_x3_kernel(TV tx, TV tg, floa
 #pragma unroll
         for (int k = 0; k < XW_ROUNDS; ++k) {
             const int e = tid + XW_THREADS * k;
-            x3_u4 hi, lo;
-            x3_split_gran(rin[k], hi, lo);
+            x3_u4 pc[2];
+            x3_split_gran<2>(rin[k], pc);
+            const x3_u4 hi = pc[0], lo = pc[1];
             if (e < XW_NX) {   // e enumerates [cb][py][px] with the plane stride XW_XPL = XW_XH * XW_XW
                 dst[e] = hi;
                 dst[XW_XG + e] = lo;
@@ -522,9 +560,21 @@ bool conv_x3_supported(bool dgrad, int ks, int cin, int cout, const TV& tin, con
     return tin.h >= 2 && tin.w >= 2 && x3_small(tin) && x3_small(tout);
 }
 
+// pieces of the FORWARD pass's operands: 3 (default; 6 products, fp32-grade activations, so ReLU decisions agree with the reference's as
+// often as any fp32 implementation's) or 2 (3 products, activations within ~1e-5).  Process wide; set it before packing
+// (mmif_set_x3_forward_pieces, $MMIF_X3_FWD_PIECES).  The backward kernels are linear in the gradient and always use 2.
+static int g_fwd_pieces = 0;
+int x3_fwd_pieces() {
+    if (g_fwd_pieces == 0) {
+        const char* e = getenv("MMIF_X3_FWD_PIECES");
+        g_fwd_pieces = (e != nullptr && e[0] == '2') ? 2 : 3;
+    }
+    return g_fwd_pieces;
+}
+
 size_t conv_x3_packed_bytes(int cout, int cin, int ks) {
     if (ks != 3) return 16;
-    const size_t a = x3_packed_bytes(cout, cin), b = x3_packed_bytes(cin, cout);
+    const size_t a = x3_packed_bytes(cout, cin, 3), b = x3_packed_bytes(cin, cout, 2);   // (room for either forward format)
     return a > b ? a : b;
 }
 
@@ -546,8 +596,8 @@ int conv_x3_pack_multi(const mmif_pack_job* jobs, int n_jobs, hipStream_t st) {
             const int n_out = d ? jb.cin : jb.cout, n_in = d ? jb.cout : jb.cin;
             X3PackImage& im = tab.im[n++];
             im.w = jb.w; im.dst = (bf16_t*)dst; im.cout = jb.cout; im.cin = jb.cin; im.dgrad = d;
-            im.mbw = 32 * x3_mb(n_out); im.nch = x3_nch(n_in);
-            im.total = (long long)x3_nmb(n_out) * im.nch * 9 * 2 * im.mbw * 8;   // elements of the hi halves
+            im.mbw = 32 * x3_mb(n_out); im.nch = x3_nch(n_in); im.pieces = d ? 2 : x3_fwd_pieces();
+            im.total = (long long)x3_nmb(n_out) * im.nch * 9 * 2 * im.mbw * 8;   // elements of the first piece's images
             if (n == X3_PACK_MAX)
                 if (int rc = flush()) return rc;
         }
@@ -555,7 +605,7 @@ int conv_x3_pack_multi(const mmif_pack_job* jobs, int n_jobs, hipStream_t st) {
     return flush();
 }
 
-template <int MB>
+template <int MB, int NP>
 static int launch_conv_x3(bool dgrad, const TV& tin, const TV& tout, const TV& tmask, const void* wpk, const float* bias, int n_out, int n_in,
                           int relu, uint64_t mask_bits, uint64_t accum_bits, hipStream_t st) {
     const int tiles_x = cdiv(tout.ws, X3_TW), tiles_y = cdiv(tout.hs, X3_TH);
@@ -564,10 +614,10 @@ static int launch_conv_x3(bool dgrad, const TV& tin, const TV& tout, const TV& t
     if (total < G) G = total;
     const int nch = x3_nch(n_in), nmb = x3_nmb(n_out);
     if (dgrad)
-        hipLaunchKernelGGL((conv_x3_kernel<MB, true>), dim3(G), dim3(X3_THREADS), 0, st, tin, tout, tmask, (const uint4*)wpk, bias, n_out, nch, nmb,
+        hipLaunchKernelGGL((conv_x3_kernel<MB, true, NP>), dim3(G), dim3(X3_THREADS), 0, st, tin, tout, tmask, (const uint4*)wpk, bias, n_out, nch, nmb,
                            relu, (unsigned long long)mask_bits, (unsigned long long)accum_bits, tiles_x, tpi, total);
     else
-        hipLaunchKernelGGL((conv_x3_kernel<MB, false>), dim3(G), dim3(X3_THREADS), 0, st, tin, tout, tmask, (const uint4*)wpk, bias, n_out, nch, nmb,
+        hipLaunchKernelGGL((conv_x3_kernel<MB, false, NP>), dim3(G), dim3(X3_THREADS), 0, st, tin, tout, tmask, (const uint4*)wpk, bias, n_out, nch, nmb,
                            relu, (unsigned long long)mask_bits, (unsigned long long)accum_bits, tiles_x, tpi, total);
     return check_launch(dgrad ? "conv_x3 dgrad" : "conv_x3 fwd");
 }
@@ -576,8 +626,12 @@ static int launch_conv_x3(bool dgrad, const TV& tin, const TV& tout, const TV& t
 int conv_x3(bool dgrad, const TV& tin, const TV& tout, const TV& tmask, const void* wpk, const float* bias, int cin, int cout, int relu,
             uint64_t mask_bits, uint64_t accum_bits, hipStream_t st) {
     const int n_out = dgrad ? cin : cout, n_in = dgrad ? cout : cin;
-    if (x3_mb(n_out) == 2) return launch_conv_x3<2>(dgrad, tin, tout, tmask, wpk, bias, n_out, n_in, relu, mask_bits, accum_bits, st);
-    return launch_conv_x3<1>(dgrad, tin, tout, tmask, wpk, bias, n_out, n_in, relu, mask_bits, accum_bits, st);
+    const bool six = !dgrad && x3_fwd_pieces() == 3;
+    if (x3_mb(n_out) == 2)
+        return six ? launch_conv_x3<2, 3>(false, tin, tout, tmask, wpk, bias, n_out, n_in, relu, mask_bits, accum_bits, st)
+                   : launch_conv_x3<2, 2>(dgrad, tin, tout, tmask, wpk, bias, n_out, n_in, relu, mask_bits, accum_bits, st);
+    return six ? launch_conv_x3<1, 3>(false, tin, tout, tmask, wpk, bias, n_out, n_in, relu, mask_bits, accum_bits, st)
+               : launch_conv_x3<1, 2>(dgrad, tin, tout, tmask, wpk, bias, n_out, n_in, relu, mask_bits, accum_bits, st);
 }
 
 bool wgrad_x3_supported(int ks, int cin, int cout, const TV& tx, const TV& tg) {
@@ -617,6 +671,9 @@ int wgrad_x3(const TV& tx, const TV& tg, float* dw, float* db, int cin, int cout
 }  // namespace mmif
 
 using namespace mmif;
+
+extern "C" void mmif_set_x3_forward_pieces(int32_t pieces) { g_fwd_pieces = pieces == 2 ? 2 : 3; }
+extern "C" int32_t mmif_get_x3_forward_pieces(void) { return x3_fwd_pieces(); }
 
 extern "C" size_t mmif_packed_weight_bytes_x3(int32_t cout, int32_t cin, int32_t ksize) { return conv_x3_packed_bytes(cout, cin, ksize); }
 

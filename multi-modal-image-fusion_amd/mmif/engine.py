@@ -59,11 +59,27 @@ def x3_enabled():
     return os.environ.get("MMIF_X3", "1") != "0"
 
 
-def wants_packed(dtype, impl):
-    """do the conv kernels this (storage dtype, impl) pair selects take operand images?"""
+def set_x3_forward_pieces(pieces):
+    """Operand pieces of the x3 FORWARD kernels: 3 (default; six bf16 products per tap, fp32-grade activations) or 2 (three products,
+    activations within ~1e-5 of fp32, forward convs twice as fast).  Process wide; operand images are re-packed on the next forward."""
+    assert pieces in (2, 3)
+    if _lib.lib.mmif_get_x3_forward_pieces() != pieces:
+        _lib.lib.mmif_set_x3_forward_pieces(pieces)
+        WEIGHTS_EPOCH[0] += 1
+
+
+def wants_packed(dtype, impl, standalone=False):
+    """do the conv kernels this (storage dtype, impl) pair selects take operand images?  standalone: a ConvLayer called on its own
+    (core/block.py: the layer-by-layer nets of row n4) -- those keep fp32 tensors on the exact fp32 FMA kernels unless asked
+    ($MMIF_X3_LAYERS=1 / impl x3): their BatchNorm / GroupNorm layers amplify the split products' 1e-5 (DIFNet at batch 2, 32 x 32:
+    5e-3 on the first layer's weight gradient, over the 2e-3 its golden test allows), the model engines have no normalisation."""
     if impl == _lib.IMPL_VALU:
         return False
-    return dtype == torch.bfloat16 or x3_enabled()
+    if dtype == torch.bfloat16:
+        return True
+    if standalone and impl != _lib.IMPL_X3 and os.environ.get("MMIF_X3_LAYERS", "0") != "1":
+        return False
+    return x3_enabled()
 
 
 def bits(*blocks):

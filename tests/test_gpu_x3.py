@@ -14,18 +14,31 @@ DEV = "cuda:0"
 X3_TOL = 3e-5
 
 
-def _split(w):
-    """numpy model of x3_split: hi = bf16(w) (RNE), lo = bf16(w - hi)"""
+def _split(w, pieces):
+    """numpy model of the split: piece p = bf16 (RNE) of what the earlier pieces left"""
     t = torch.from_numpy(np.ascontiguousarray(w, dtype=np.float32))
-    hi = t.bfloat16()
-    lo = (t - hi.float()).bfloat16()
-    return hi, lo
+    out = []
+    for _ in range(pieces):
+        q = t.bfloat16()
+        out.append(q)
+        t = t - q.float()
+    return out
+
+
+@pytest.fixture(params=[3, 2], ids=["fwd6", "fwd3"])
+def fwd_pieces(request):
+    from mmif import engine as E
+    from mmif._lib import lib
+    prev = lib.mmif_get_x3_forward_pieces()
+    E.set_x3_forward_pieces(request.param)
+    yield request.param
+    E.set_x3_forward_pieces(prev)
 
 
 @pytest.mark.parametrize("cout,cin", [(128, 128), (16, 48), (64, 128), (40, 24), (72, 136)])
-def test_x3_operand_images_bit_exact(cout, cin):
-    """mmif_pack_weights_x3: [m-block][chunk][hi | lo][tap][2 channel blocks][32*MB out][8 in] -- every element against the layout
-    formula, forward and (flipped, transposed) dgrad images"""
+def test_x3_operand_images_bit_exact(cout, cin, fwd_pieces):
+    """mmif_pack_weights_x3: [m-block][chunk][piece][tap][2 channel blocks][32*MB out][8 in] -- every element against the layout
+    formula, forward (2 or 3 pieces) and (flipped, transposed, 2 pieces) dgrad images"""
     from mmif import tensor as T
     from mmif._lib import F32
     torch.manual_seed(cout * 131 + cin)
@@ -35,6 +48,7 @@ def test_x3_operand_images_bit_exact(cout, cin):
     torch.cuda.synchronize()
     wn = w.numpy()
     for dgrad, img in ((0, pk.fwd), (1, pk.dgrad)):
+        pieces = 2 if dgrad else fwd_pieces
         n_out, n_in = (cin, cout) if dgrad else (cout, cin)
         mb = 2 if n_out > 32 else 1
         mbw = 32 * mb
@@ -45,8 +59,7 @@ def test_x3_operand_images_bit_exact(cout, cin):
         else:
             wk[:n_out, :n_in] = wn
         want = wk.reshape(nmb, mbw, nch, 2, 8, 9).transpose(0, 2, 5, 3, 1, 4)   # [mb][ch][tap][cbl][ocl][e]
-        hi, lo = _split(want)
-        both = torch.stack((hi, lo), dim=2).contiguous()                        # [mb][ch][hi|lo][tap][cbl][ocl][e]
+        both = torch.stack(_split(want, pieces), dim=2).contiguous()            # [mb][ch][piece][tap][cbl][ocl][e]
         got = img.cpu().view(torch.bfloat16)[:both.numel()].view(both.shape)
         assert torch.equal(got.view(torch.int16), both.view(torch.int16)), f"dgrad={dgrad}"
 
@@ -57,9 +70,10 @@ SHAPES = [(128, 128, 2, 37, 53), (16, 16, 2, 40, 70), (48, 16, 1, 33, 64), (16, 
 
 @pytest.mark.parametrize("cin,cout,n,h,w", SHAPES, ids=[f"{a}-{b}-{n}x{h}x{w}" for a, b, n, h, w in SHAPES])
 @pytest.mark.parametrize("ghalo", [0, 1])
-def test_x3_kernels_vs_fp32_fma_kernels(cin, cout, n, h, w, ghalo):
-    """forward (bias + ReLU), dgrad (partial mask / accumulate bit sets) and wgrad: IMPL_X3 vs IMPL_VALU on the same fp32 tensors --
-    ragged tiles, ragged 16-channel chunks (cin % 16 = 8), ragged 32 / 64-channel groups"""
+def test_x3_kernels_vs_fp32_fma_kernels(cin, cout, n, h, w, ghalo, fwd_pieces):
+    """forward (bias + ReLU), dgrad (partial mask / accumulate bit sets; upstream gradient and old values vary per element) and wgrad:
+    IMPL_X3 vs IMPL_VALU on the same fp32 tensors -- ragged tiles, ragged 16-channel chunks (cin % 16 = 8), ragged 32 / 64-channel
+    groups.  The 3-piece forward (six products) must agree to fp32 rounding (2e-6), everything with 2 pieces to 3e-5."""
     from mmif import tensor as T
     from mmif._lib import F32, IMPL_VALU, IMPL_X3
     torch.manual_seed(cin * 7 + cout + h)
@@ -80,7 +94,7 @@ def test_x3_kernels_vs_fp32_fma_kernels(cin, cout, n, h, w, ghalo):
     for impl in (IMPL_VALU, IMPL_X3):
         y = T.BT.alloc(n, cout, h, w, torch.float32, DEV)
         gx = T.BT.alloc(n, cin, h, w, torch.float32, DEV, halo=1, zero=True)
-        gx.buf.fill_(0.25)
+        gx.buf.copy_(torch.sin(torch.arange(gx.buf.numel(), device=DEV, dtype=torch.float32)).view_as(gx.buf))   # old values differ per element
         dw, db = torch.full_like(wt, 0.5), torch.full_like(b, -0.5)
         T.conv_fwd(x, wt, b, y, cin, cout, 3, True, pk, impl)
         T.conv_dgrad(gy, wt, x, gx, cin, cout, 3, mask, acc_bits, pk, impl)
@@ -88,12 +102,12 @@ def test_x3_kernels_vs_fp32_fma_kernels(cin, cout, n, h, w, ghalo):
         torch.cuda.synchronize()
         res[impl] = [t.cpu().numpy() for t in (y.buf, gx.buf, dw, db)]
     for (a, r, what) in zip(res[IMPL_X3], res[IMPL_VALU], ("y", "gx", "dw", "db")):
-        close(a, r, X3_TOL, what)
+        close(a, r, 2e-6 if (what == "y" and fwd_pieces == 3) else X3_TOL, what)
 
 
-def test_x3_forward_vs_fp64_definition():
-    """x3 forward on a 128 -> 128 layer against torch's fp64 conv on the CPU (reflect padding): the absolute error budget of the split
-    (2^-16 relative per product) next to the fp32 FMA kernel's own rounding"""
+def test_x3_forward_vs_fp64_definition(fwd_pieces):
+    """x3 forward on a 128 -> 128 layer against torch's fp64 conv on the CPU (reflect padding): the error of the split (2 pieces: 2^-17
+    relative per product; 3 pieces: fp32 accumulation only) next to the fp32 FMA kernel's own rounding"""
     import torch.nn.functional as F
     from mmif import tensor as T
     from mmif._lib import F32, IMPL_VALU, IMPL_X3
@@ -111,7 +125,7 @@ def test_x3_forward_vs_fp64_definition():
         T.conv_fwd(x, wt.to(DEV), b.to(DEV), y, c, c, 3, True, pk, impl)
         errs[impl] = np.abs(y.to_nchw(c).cpu().numpy() - ref).max() / np.abs(ref).max()
     print("fp32 FMA err", errs[IMPL_VALU], "x3 err", errs[IMPL_X3])
-    assert errs[IMPL_X3] < 2e-5, errs
+    assert errs[IMPL_X3] < (2e-5 if fwd_pieces == 2 else 3 * max(errs[IMPL_VALU], 2e-7)), errs
 
 
 def test_x3_is_the_default_for_fp32_and_can_be_forced_off():

@@ -1,0 +1,40 @@
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "multi-modal-image-fusion_amd"), os.path.join(ROOT, "tests")]
+import numpy as np, torch
+import core.model as M
+from mmif import engine as E
+from oracle import fusion_oracle as O
+from gpu_util import load_closed_form, tg
+name, shape = sys.argv[1], tuple(int(a) for a in sys.argv[2:6])
+res = {}
+mode = os.environ.get("MMIF_X3", "1")
+if True:
+    E.set_compute_dtype("fp32")
+    m = load_closed_form(getattr(M, name)(), 1).cuda()
+    i1, i2 = tg(O.closed_form_image(shape, 0.3)), tg(O.closed_form_image(shape, 1.7))
+    y = m(i1, i2)
+    y.backward(tg(O.closed_form_signed(shape, 0.9, 1.0)))
+    torch.cuda.synchronize()
+    bufs = {}
+    for lst in m._engine.pool.values():
+        for L in lst:
+            for kname, bt in L.bufs.items():
+                bufs["BUF_" + kname] = bt.buf.float().cpu().numpy()
+    d = {k: p.grad.cpu().numpy() for k, p in m.named_parameters()}
+    d.update(bufs)
+    res[mode] = (y.detach().cpu().numpy(), d)
+np.save(f"/tmp/diag_{mode}.npy", np.array([res[mode]], dtype=object), allow_pickle=True)
+if mode == "0":
+    sys.exit(0)
+res["0"] = tuple(np.load("/tmp/diag_0.npy", allow_pickle=True)[0])
+a, b = res["0"], res["1"]
+print("y", np.abs(a[0] - b[0]).max() / np.abs(a[0]).max())
+for k in a[1]:
+    print(k, np.abs(a[1][k] - b[1][k]).max() / np.abs(a[1][k]).max(), np.abs(a[1][k]).max())
+    if k.startswith("BUF_G") and a[1][k].ndim == 5:
+        d = np.abs(a[1][k] - b[1][k]) / np.abs(a[1][k]).max()
+        print("   per block:", " ".join(f"{d[:, c].max():.1e}" for c in range(d.shape[1])))
+        c = int(np.argmax(d.max(axis=(0, 2, 3, 4))))
+        idx = np.unravel_index(np.argmax(d[:, c]), d[:, c].shape)
+        print("   worst block", c, "at (n, ys, xs, e)", idx, "valu", a[1][k][idx[0], c, idx[1], idx[2], idx[3]], "x3", b[1][k][idx[0], c, idx[1], idx[2], idx[3]], "count >1e-4:", int((d[:, c] > 1e-4).sum()))
