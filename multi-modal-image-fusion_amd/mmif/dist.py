@@ -90,20 +90,33 @@ def allreduce_flat(flat, scalars=None):
 # A fusion net's backward finishes its decoder first (PFNetv1: 98 % of the 272 k parameters) and then spends ~1 ms of a 4 ms step in
 # the encoder chains.  With one process per GPU the all-reduce of the flat gradient buffer was the only thing on the device between the
 # last backward kernel and clip + Adam (RCCL launch + two cross-stream hand-offs: 85 us even with ONE rank).  Protocol:
-#   optimizer   : FusedClipAdam.stage_scalars([...]) before backward (optional) parks the loss values in the tail slots of the buffer;
-#   engine      : after the decoder's gradients are written, early_allreduce(flat, lo, hi) starts an ASYNC all-reduce of
-#                 flat[lo:hi] (decoder gradients + tail) on RCCL's stream; the compute stream goes on with the encoder backward;
-#   optimizer   : step() waits for that handle and all-reduces only flat[0:lo] (encoder gradients); without a pending handle it
-#                 reduces the whole buffer as before.
+#   optimizer   : FusedClipAdam.stage_scalars([...]) before backward (optional) parks the loss values for the tail slots of the buffer;
+#   engine      : every backward starts with begin_backward() (a new generation); after the decoder's gradients are written,
+#                 early_allreduce(flat, lo, hi) COPIES flat[lo:hi] (+ the staged scalars) into a scratch buffer and starts an ASYNC
+#                 all-reduce of the copy on RCCL's stream; the compute stream goes on with the encoder backward;
+#   optimizer   : step() -> take_early(flat): when the handle belongs to the LATEST backward, it is waited for and the reduced copy is
+#                 written back over flat[lo:hi]; step() then all-reduces only flat[0:lo] (encoder gradients).  Otherwise -- no handle, or
+#                 a handle of an earlier backward (a skipped optimizer step, gradient accumulation, hipGraph warm-up backwards) -- the
+#                 whole buffer is reduced as before.
+# The early collective is SPECULATIVE: it never modifies the gradient buffer until step() accepts it, so a backward without a matching
+# step() cannot leave half-reduced gradients behind, and a stale handle can only be discarded (round 2 reduced in place: a backward
+# with no step() left a handle that the next step() either tripped over or trusted for the wrong gradients).  (Gradients edited by
+# hand between backward and step() would be overwritten for the decoder range: use $MMIF_EARLY_REDUCE=0 for such a flow.)
 # Off ($MMIF_EARLY_REDUCE=0, or never armed) nothing changes.  Only armed by FusedClipAdam when a process group with a collective
-# backend is up; never inside a hipGraph capture; only for the plain one-backward-per-step flow (all .grad None at backward).
-_EARLY = {"armed": False, "pending": {}, "tail": None, "count": 0}
+# backend is up; never inside a hipGraph capture; only for a backward that finds every .grad None.
+_EARLY = {"armed": False, "pending": {}, "tail": None, "count": 0, "gen": 0, "scratch": {}}
 
 
 def arm_early_reduce(on=True):
-    """armed by the optimizer after a step that consumed the engine's flat gradient buffer zero-copy (a flow that copies the
-    gradients elsewhere before step() would reduce them twice: step() fails loudly if it ever meets that)"""
+    """armed by the optimizer after a step that consumed the engine's flat gradient buffer zero-copy"""
     _EARLY["armed"] = bool(on) and os.environ.get("MMIF_EARLY_REDUCE", "1") != "0"
+
+
+def begin_backward():
+    """every engine backward: a new generation -- handles of earlier backwards are stale from here on (their reduced copies are
+    simply dropped by take_early / the next early_allreduce)"""
+    _EARLY["gen"] += 1
+    return _EARLY["gen"]
 
 
 def pending_early():
@@ -111,8 +124,8 @@ def pending_early():
 
 
 def stage_tail(values):
-    """the optimizer parks this step's loss scalars (a small 1-D device tensor) here before backward; the engine copies them into the
-    tail slots of whichever flat buffer this backward uses, right before the early all-reduce that then carries them"""
+    """the optimizer parks this step's loss scalars (a small 1-D device tensor) here before backward; the early all-reduce of that
+    backward carries them; step() clears whatever is still parked"""
     _EARLY["tail"] = values
 
 
@@ -131,38 +144,51 @@ def early_reduce_armed():
 
 @torch.no_grad()
 def early_allreduce(flat, lo, hi, tail_at=None):
-    """async SUM all-reduce of flat[lo:hi]; the handle is kept until take_early(flat).  tail_at: index of the buffer's scalar slots
-    when hi reaches them -- staged scalars (stage_tail) are copied there and the range grows to cover them."""
+    """async SUM all-reduce of a COPY of flat[lo:hi]; the handle is kept until take_early(flat).  tail_at: index of the buffer's scalar
+    slots when hi reaches them -- staged scalars (stage_tail) ride behind the gradients and the accepted range grows to cover them."""
+    drain_early()                                      # handles of earlier backwards (never consumed): wait and drop, ALL buffers
     if not early_reduce_armed() or hi <= lo:
         return False
     if flat.is_cuda and torch.cuda.is_current_stream_capturing():
         return False
-    drain_early(flat)                                  # a backward whose step() never came: finish that reduce first
     vals = _EARLY["tail"]
     _EARLY["tail"] = None
+    ntail = 0
     if tail_at is not None and hi == tail_at and vals is not None and vals.numel() <= flat.numel() - tail_at:
-        flat[tail_at:tail_at + vals.numel()].copy_(vals)
-        hi = tail_at + vals.numel()
-    work = dist.all_reduce(flat[lo:hi], async_op=True)
+        ntail = vals.numel()
+    n = hi - lo
+    key = flat.data_ptr()
+    scratch = _EARLY["scratch"].get(key)
+    if scratch is None or scratch.numel() < n + ntail or scratch.device != flat.device:
+        scratch = _EARLY["scratch"][key] = torch.empty(n + 8, dtype=flat.dtype, device=flat.device)
+    scratch[:n].copy_(flat[lo:hi])
+    if ntail:
+        scratch[n:n + ntail].copy_(vals)
+    work = dist.all_reduce(scratch[:n + ntail], async_op=True)
     _EARLY["count"] += 1
-    _EARLY["pending"][flat.data_ptr()] = (work, lo, hi)
+    _EARLY["pending"][key] = (work, lo, hi, ntail, _EARLY["gen"], scratch)
     return True
 
 
 def take_early(flat):
-    """-> (lo, hi) of the range whose all-reduce has been waited for (the current stream is ordered after it), or None"""
+    """-> (lo, hi) of the range of `flat` that now holds all-reduced values (hi includes the scalar slots that rode along), or None:
+    no handle for this buffer, or its handle is from an earlier backward than the latest one (the buffer may have changed since)."""
     ent = _EARLY["pending"].pop(flat.data_ptr(), None)
     if ent is None:
         return None
-    work, lo, hi = ent
-    work.wait()
-    return lo, hi
+    work, lo, hi, ntail, gen, scratch = ent
+    work.wait()                                        # (orders the current stream after the collective)
+    if gen != _EARLY["gen"]:
+        return None
+    n = hi - lo
+    flat[lo:hi + ntail].copy_(scratch[:n + ntail])
+    return lo, hi + ntail
 
 
 def drain_early(flat=None):
+    """wait for and DROP pending handles (their reduced copies are never written back)"""
     keys = [flat.data_ptr()] if flat is not None else list(_EARLY["pending"].keys())
     for k in keys:
         ent = _EARLY["pending"].pop(k, None)
         if ent is not None:
             ent[0].wait()
-

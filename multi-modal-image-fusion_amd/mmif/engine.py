@@ -396,6 +396,7 @@ class _EngineFn(torch.autograd.Function):
         lease = ctx.lease
         if lease is None:
             raise RuntimeError("mmif: backward called twice on the same forward (buffers were recycled)")
+        D.begin_backward()
         grads = ctx.engine.backward(lease, gout.contiguous().float())
         lease.busy = False
         ctx.lease = None

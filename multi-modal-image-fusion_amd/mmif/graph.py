@@ -12,6 +12,7 @@ a launch (one, mmif_pack_weights_multi) that the graph simply contains.
 """
 import torch
 
+from . import dist as D
 from . import engine as E
 
 
@@ -22,6 +23,10 @@ class GraphedStep:
         self.img1, self.img2 = img1.clone(), img2.clone()          # static inputs: replay reads these addresses
         if hasattr(optimizer, "prepare"):
             optimizer.prepare()                                    # FusedClipAdam moves the parameters into one flat buffer: before capture
+        # data parallel: the warm-up backwards below have no optimizer step and the captured backward must not contain a collective:
+        # no early gradient all-reduce from here to the end of the capture (the next eager optimizer step re-arms it)
+        D.arm_early_reduce(False)
+        D.drain_early()
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
         side.wait_stream(cur)
@@ -43,6 +48,7 @@ class GraphedStep:
             self.outs[0].backward()
         # the gradient tensors the captured backward writes; an eager step in between (ragged last batch, another shape)
         # re-points p.grad elsewhere, so every replay hands these back to the optimiser
+        D.drain_early()
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.grads = [p.grad for p in self.params]
 

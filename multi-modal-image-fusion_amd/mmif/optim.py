@@ -177,12 +177,12 @@ class FusedClipAdam(torch.optim.Optimizer):
         total = self._flat_p.numel()
         in_group = dist.is_available() and dist.is_initialized()
         world = dist.get_world_size() if in_group else 1
-        early = D.take_early(flat_g) if in_group else None     # (lo, hi): that range is reduced already (mmif/dist.py)
-        if in_group and D.pending_early():
+        # (lo, hi): that range holds the result of the LATEST backward's early all-reduce (mmif/dist.py); anything else that is still
+        # pending belongs to a backward this step does not consume (skipped step, another buffer): speculative copies, dropped
+        early = D.take_early(flat_g) if (in_group and self._last_flat is not None) else None
+        if in_group:
             D.drain_early()
-            raise RuntimeError("FusedClipAdam.step(): part of the engine's gradient buffer was all-reduced during backward, but the "
-                               "gradients this step consumes live elsewhere (they were replaced or copied after backward); "
-                               "set MMIF_EARLY_REDUCE=0 for such a flow")
+        D.stage_tail(None)     # scalars parked for a backward whose early reduce never ran must not ride in a later one
         k = len(scalars) if scalars else 0
         tail_done = early is not None and early[1] >= total + k and k > 0
         if k and not tail_done:   # straight into the tail of the flat buffer (one small launch)

@@ -226,23 +226,33 @@ def _early_worker(rank, world, port, q):
         lo = 30                                                # "decoder" = [30, 100), tail staged -> early range [30, 104)
         D.arm_early_reduce(True)
         assert D.early_reduce_armed()
-        staged = flat[total:total + 4].clone()                 # the scalars arrive as values; the early call copies them into the tail
+        staged = flat[total:total + 4].clone()                 # the scalars arrive as values; they ride behind the gradients
         flat[total:total + 4] = -1.0
         D.stage_tail(staged)
+        D.begin_backward()
+        before = flat.clone()
         assert D.early_allreduce(flat, lo, total, tail_at=total)
         assert D.staged_tail() is None                         # consumed by the early call
+        assert torch.equal(flat, before)                       # speculative: the buffer is untouched until step() accepts the result
         flat[0:lo] += 0.0                                      # ("encoder backward" keeps writing the other range meanwhile)
         lo2, hi2 = D.take_early(flat)
         assert (lo2, hi2) == (lo, total + 4)
         dist.all_reduce(flat[0:lo2])
         ok = torch.equal(flat[:total + 4], ref[:total + 4])
-        # a backward whose step never came: the next early call drains the pending handle first
+        # a backward whose step never came: its handle is dropped by the next early call, the buffer keeps its LOCAL values
         flat2 = torch.ones(total + tail) * (rank + 1)
+        D.begin_backward()
         D.early_allreduce(flat2, 10, 20)
-        D.early_allreduce(flat2, 10, 20)                       # second call waits for the first, then reduces again
+        D.begin_backward()
+        D.early_allreduce(flat2, 10, 20)                       # waits for and drops the first, reduces a fresh copy
+        assert D.pending_early() == 1
         D.drain_early()
-        want = float(sum(r + 1 for r in range(world))) * world  # reduced twice
-        ok2 = bool((flat2[10:20] == want).all()) and bool((flat2[:10] == rank + 1).all())
+        ok2 = bool((flat2 == rank + 1).all()) and D.pending_early() == 0
+        # a handle of an EARLIER backward than the latest one is not accepted (skipped step / gradient accumulation / graph warm-up)
+        D.begin_backward()
+        D.early_allreduce(flat2, 10, 20)
+        D.begin_backward()                                     # another backward ran (no early reduce of its own)
+        ok2 = ok2 and D.take_early(flat2) is None and bool((flat2 == rank + 1).all()) and D.pending_early() == 0
         # kill switch
         os.environ["MMIF_EARLY_REDUCE"] = "0"
         D.arm_early_reduce(True)

@@ -96,6 +96,119 @@ def test_two_rank_step_equals_single_process_full_batch():
     assert r0["early"] == want and r1["early"] == want and single["early"] == 0, "step 1 must take the two-bucket path"
 
 
+def _run_seq(rank, world, port, out, backend, key):
+    """eager step -> backward WITHOUT a step (a skipped iteration) -> eager step -> GraphedStep (its warm-up backwards have no step
+    either) -> two graphed steps; with a process group the early / late gradient buckets of mmif/dist.py are live throughout"""
+    for p in (ROOT, os.path.join(ROOT, "multi-modal-image-fusion_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    import core.model as M
+    from core.loss import GradLoss, PixelLoss, SSIMLoss
+    from mmif import dist as D
+    from mmif import engine as E
+    from mmif.dist import broadcast_parameters, shard_batch
+    from mmif.graph import GraphedStep
+    from mmif.optim import FusedClipAdam
+    from oracle import fusion_oracle as O
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    if backend is not None:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    E.set_compute_dtype("fp32")
+    torch.manual_seed(10)
+    model = M.PFNetv1().to(dev)
+    if backend is not None:
+        broadcast_parameters(model, 0)
+    opt = FusedClipAdam(model.parameters(), lr=1e-3, betas=(0.9, 0.999), max_norm=5.0)
+    l1, l2, l3 = SSIMLoss('ssim', weight=1.0), PixelLoss('l1', weight=0.01), GradLoss('l1', weight=0.1).to(dev)
+    lo, hi = shard_batch(SHAPE[0], rank, world)
+
+    def batch(step):
+        return tuple(torch.from_numpy(O.closed_form_image(SHAPE, ph + step)).to(dev)[lo:hi].contiguous() for ph in (0.3, 1.7))
+
+    def losses(i1, i2, f):
+        a, b, c = l1(i1, i2, f), l2(i1, i2, f, mode='max'), l3(i1, i2, f, mode='max')
+        return a + b + c, a, b, c
+
+    def eager(step, do_step=True):
+        i1, i2 = batch(step)
+        opt.zero_grad(set_to_none=True)
+        outs = losses(i1, i2, model(i1, i2))
+        opt.stage_scalars(list(outs))
+        outs[0].backward()
+        if do_step:
+            opt.step(scalars=list(outs))
+    eager(0)
+    eager(1, do_step=False)        # backward with no step: its early all-reduce (if any) must not leak into the next step
+    eager(2)
+    i1, i2 = batch(3)
+    g = GraphedStep(model, losses, opt, i1, i2)
+    g(i1, i2)
+    g(*batch(4))
+    eager(5)                       # and an eager step after the graph: the early path re-arms
+    torch.cuda.synchronize()
+    out[key + (rank,)] = dict(P={k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}, scal=opt.reduced_scalars.detach().cpu().numpy(),
+                              early=D.early_reduce_count(), pending=D.pending_early())
+    if backend is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_two_rank_skipped_step_and_graphed_steps_equal_single_process():
+    """a backward without a matching step() -- a skipped iteration, GraphedStep's warm-up -- used to leave an early
+    all-reduce handle behind that the next step() tripped over or trusted for the wrong gradients.  Two ranks through eager + skipped +
+    graphed steps == one process on the full batch; nothing left pending."""
+    port = _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_run_seq, args=(2, port, out, "gloo", ("seq", 2)), nprocs=2, join=True)
+        mp.spawn(_run_seq, args=(1, port, out, None, ("seq", 1)), nprocs=1, join=True)
+        res = {k: dict(v) for k, v in out.items()}
+    single, r0, r1 = res[("seq", 1, 0)], res[("seq", 2, 0)], res[("seq", 2, 1)]
+    for k in single["P"]:
+        assert np.array_equal(r0["P"][k], r1["P"][k]), f"ranks diverged on {k}"
+        ref = single["P"][k]
+        assert np.abs(r0["P"][k] - ref).max() <= 5e-5 * max(1.0, np.abs(ref).max()), k
+    assert np.allclose(r0["scal"], r1["scal"]) and np.allclose(r0["scal"], single["scal"], rtol=5e-5, atol=1e-6)
+    assert r0["pending"] == r1["pending"] == 0
+    if os.environ.get("MMIF_EARLY_REDUCE", "1") != "0":
+        assert r0["early"] >= 2 and r1["early"] >= 2, "the eager steps after the first must take the two-bucket path"
+
+
+@pytest.mark.parametrize("early", ["1", "0"])
+def test_single_rank_nccl_path(early):
+    """The RCCL code path itself (every other multi-rank test runs on gloo: RCCL refuses two ranks on one GPU): world_size 1, backend
+    'nccl', a fresh child process: init -> one flat parameter broadcast -> eager / skipped / graphed steps with the asynchronous decoder
+    bucket on RCCL's stream while the encoder backward runs on the compute stream, the encoder bucket + loss scalars in step().  With one
+    rank every collective is the identity, so parameters and reduced scalars must equal the no-process-group run BIT FOR BIT -- with the
+    two-bucket path and with $MMIF_EARLY_REDUCE=0 (a wrong stream order or a stale scratch copy shows up as a different bit)."""
+    port = _free_port()
+    prev = os.environ.get("MMIF_EARLY_REDUCE")
+    os.environ["MMIF_EARLY_REDUCE"] = early
+    try:
+        with mp.Manager() as mgr:
+            out = mgr.dict()
+            mp.spawn(_run_seq, args=(1, port, out, "nccl", ("nccl", 1)), nprocs=1, join=True)
+            mp.spawn(_run_seq, args=(1, port, out, None, ("plain", 1)), nprocs=1, join=True)
+            res = {k: dict(v) for k, v in out.items()}
+    finally:
+        if prev is None:
+            os.environ.pop("MMIF_EARLY_REDUCE", None)
+        else:
+            os.environ["MMIF_EARLY_REDUCE"] = prev
+    a, b = res[("nccl", 1, 0)], res[("plain", 1, 0)]
+    for k in b["P"]:
+        assert np.array_equal(a["P"][k], b["P"][k]), f"RCCL path differs from the plain path on {k}"
+    assert np.array_equal(a["scal"], b["scal"])
+    assert a["pending"] == 0 and b["early"] == 0
+    assert (a["early"] >= 2) if early == "1" else (a["early"] == 0)
+
+
 def test_two_rank_batchnorm_model_equals_single_process_full_batch():
     """A BatchNorm net (DIFNet, reference core/model.py) under data parallel: the reference converts to nn.SyncBatchNorm
     (train.py:296), i.e. statistics over the GLOBAL batch -- the two-rank run must reproduce the one-process full-batch run, running

@@ -210,17 +210,21 @@ def test_nestfuse_bf16_mfma_runs_close():
         close(y.cpu().numpy(), y_or, 5e-2, "imgf")
 
 
+@pytest.mark.parametrize("impl,gtol", [("valu", 1e-3), ("auto", 2e-3)], ids=["fp32-fma", "x3"])
 @pytest.mark.parametrize("name", ["NestFuse", "RFNNest"])
-def test_nest_engine_odd_size_vs_oracle(name):
+def test_nest_engine_odd_size_vs_oracle(name, impl, gtol):
     """Odd pyramid sizes (36x44 -> 18x22 -> 9x11 -> 4x5): the up-sampled 8x10 map is reflect-padded to 9x11
-    (core/block.py:981-991); fused engine (HIP pool / upsample / attention / RFN adds) vs the CPU oracle."""
+    (core/block.py:981-991); fused engine (HIP pool / upsample / attention / RFN adds) vs the CPU oracle, 3x3 layers on the fp32 FMA
+    kernels and on the split-bf16 matrix-pipe kernels (the 1x1 layers are fp32 FMA in both).  The gradient bar is the flip-noise floor of
+    this small case (max-pool winners and ReLU signs decided on near ties: one different decision moves a bias gradient by ~1e-3 here
+    whichever fp32-grade forward made it): 1e-3 held by the FMA kernels, 1.03e-3 measured on the x3 kernels."""
     shape = (2, 1, 36, 44)
     om = O.MODELS[name]()
     P = om.init_params(seed=3)
     i1n, i2n, gn = O.closed_form_image(shape, 0.3), O.closed_form_image(shape, 1.7), O.closed_form_signed(shape, 0.9, 1.0)
     y_or = om.forward(P, i1n, i2n)
     G_or = om.backward(P, gn)
-    with dtype_ctx("fp32"):
+    with dtype_ctx("fp32", impl):
         m = _model(name, 3)
         assert m._make_engine() is not None
         y = m(tg(i1n), tg(i2n))
@@ -228,7 +232,7 @@ def test_nest_engine_odd_size_vs_oracle(name):
         torch.cuda.synchronize()
         close(y.detach().cpu().numpy(), y_or, 2e-4, "imgf")
         for k, p in m.named_parameters():
-            close(p.grad.cpu().numpy(), G_or[k], 1e-3, k)
+            close(p.grad.cpu().numpy(), G_or[k], gtol, k)
 
 
 def test_fusion_functions_hip_vs_golden():
