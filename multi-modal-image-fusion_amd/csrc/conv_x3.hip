@@ -33,11 +33,8 @@ typedef __attribute__((ext_vector_type(4))) float x3_f4;        // native vector
 typedef __attribute__((ext_vector_type(4))) unsigned x3_u4;     // travel through the staging lambdas were left in scratch / promoted to LDS
 #define X3_LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
 
-constexpr int X3_TW = 32, X3_TH = 16;            // output tile (columns x rows)
-constexpr int X3_IW = X3_TW + 2, X3_IH = X3_TH + 2;
-constexpr int X3_ING = 2 * X3_IH * X3_IW;        // granules of one precision half of an input chunk (2 channel blocks): 1224
-constexpr int X3_THREADS = 512;
-constexpr int X3_IN_ROUNDS = (X3_ING + X3_THREADS - 1) / X3_THREADS;   // 3
+constexpr int X3_TW = 32;                        // output tile columns; rows = 2 per wave (16 with 8 waves, 8 with 4)
+constexpr int X3_IW = X3_TW + 2;
 
 __host__ __device__ constexpr int x3_mb(int n_out) { return n_out > 32 ? 2 : 1; }
 static inline int x3_nmb(int n_out) { return cdiv(n_out, 32 * x3_mb(n_out)); }
@@ -121,39 +118,63 @@ template <> struct X3Prod<3> { static constexpr int N = 6; static constexpr int 
 constexpr int X3_BIAS_G = 128;   // granules reserved behind the tiles for the bias vector (512 floats)
 
 // ------------------------------------------------------------------ forward / dgrad
-// NP = 2: operands as (hi, lo), 3 MFMAs per tap and accumulator tile, LDS tiles double buffered (one barrier per chunk).
+// NP = 2: operands as (hi, lo), 3 MFMAs per tap and accumulator tile; the BACKWARD kernels (linear in the gradient: 1e-5 is plenty).
 // NP = 3: operands as (hi, mid, lo), 6 MFMAs -- the FORWARD pass's default: a ReLU decision on a pre-activation within the 2-piece
 //         error (~1e-5 of its scale) of zero would differ from the reference's about ten times as often as between two fp32
-//         implementations, and every such flip moves the parameter gradients by O(1e-3) whatever the image size.  The three
-//         images of a chunk fill 114 KB, so the LDS tile is single buffered (two barriers per chunk; the next chunk's global loads still
-//         fly during the MFMAs).
-template <int MB, bool DGRAD, int NP>
-__global__ __launch_bounds__(X3_THREADS) void conv_x3_kernel(TV tin, TV tout, TV tmask, const uint4* __restrict__ wpk,
-                                                              const float* __restrict__ bias, int n_out, int nch, int nmb, int relu,
+//         implementations, and every such flip moves the parameter gradients by O(1e-3) whatever the image size.
+// One LDS tile (single buffered, two barriers per chunk) of CKB channel blocks: 4 (32 channels) with 2 pieces, 2 with 3 -- either way
+// 150 / 114 KB and 216 MFMAs per wave between barriers; the next chunk's global loads fly during the MFMAs, the split + LDS write
+// follows them.  (First version: 16-channel chunks, double buffered, one barrier per 108 MFMAs: the staging phases of the two waves of a
+// SIMD coincide at the barrier and are fully exposed -- 41 % of the MFMA peak against 52 % for the 216-MFMA chunks.)
+// NW = 8 waves: one block per CU (the instantiation in use).  NW = 4 -- TWO blocks of four waves per CU on 16-channel chunks and 8-row
+// tiles, so that the two waves of a SIMD are not tied to one barrier -- was built and measured: 1.99 vs 2.01 ms on decode.0's dgrad;
+// the waves overlap better but each block stages the whole weight chunk for half the pixels.  What the SQ counters say about these
+// kernels (profiles/r03_pmc_sq_x3.txt): the matrix pipe is busy 58 % (2 pieces) / 74 % (3 pieces) of the cycles, i.e. a constant
+// ~5 k cycles per 16 input channels of split + LDS-write + issue work that no barrier arrangement removes, at 1.7-1.8 GHz (the chip
+// clocks dense MFMA work down: the 2.5 PFLOP/s peak assumes 2.4 GHz).
+template <int MB, bool DGRAD, int NP, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void conv_x3_kernel(TV tin, TV tout, TV tmask, const uint4* __restrict__ wpk,
+                                                              const float* __restrict__ bias, int n_out, int nch16, int nmb, int relu,
                                                               unsigned long long mask_bits, unsigned long long accum_bits, int tiles_x,
                                                               int tiles_per_img, int total_tiles) {
     constexpr int MBW = 32 * MB;
-    constexpr int WG = 9 * 2 * MBW;               // weight granules of one piece of a chunk
-    constexpr int W_ROUNDS = (NP * WG + X3_THREADS - 1) / X3_THREADS;
-    constexpr int BUF_G = NP * X3_ING + NP * WG;  // [in piece 0 .. NP-1][w piece 0 .. NP-1]
-    constexpr int NBUF = NP == 2 ? 2 : 1;
+    constexpr int WG = 9 * 2 * MBW;               // weight granules of one piece of a 16-channel sub-chunk
+    constexpr int X3_THREADS = 64 * NW, X3_TH = 2 * NW, X3_IH = X3_TH + 2;
+    constexpr int CKB = (NP == 2 && NW == 8) ? 4 : 2;   // channel blocks per LDS chunk
+    constexpr int KK = CKB / 2;                   // 16-channel sub-chunks (MFMA k-steps per tap) per chunk
+    constexpr int PL = X3_IH * X3_IW;             // granules of one channel-block plane of the input tile: 612
+    constexpr int ING = CKB * PL;                 // input granules per piece
+    constexpr int IN_ROUNDS = (ING + X3_THREADS - 1) / X3_THREADS;
+    constexpr int WGC = KK * NP * WG;             // weight granules per chunk: [sub-chunk][piece][tap][cb 0/1][oc][8], as packed
+    constexpr int W_ROUNDS = (WGC + X3_THREADS - 1) / X3_THREADS;
+    constexpr int BUF_G = NP * ING + WGC;
     constexpr int NPROD = X3Prod<NP>::N;
-    __shared__ __attribute__((aligned(16))) x3_u4 s_buf[NBUF * BUF_G + X3_BIAS_G];
+    __shared__ __attribute__((aligned(16))) x3_u4 s_buf[BUF_G + X3_BIAS_G];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const TileWalk tw = xcd_walk(total_tiles, gridDim.x, blockIdx.x);
+    const int nch = (nch16 + KK - 1) / KK;        // LDS chunks per item
     const int per_tile = nch * nmb;
     const int nsteps = tw.count * per_tile;
     if (nsteps == 0) return;
 
-    if (!DGRAD) {   // bias (zero padded to the m-blocks) behind the tiles
-        float* s_bias = reinterpret_cast<float*>(s_buf + NBUF * BUF_G);
+    if (!DGRAD) {   // bias (zero padded to the m-blocks) behind the tile
+        float* s_bias = reinterpret_cast<float*>(s_buf + BUF_G);
         for (int i = tid; i < X3_BIAS_G * 4; i += X3_THREADS) s_bias[i] = (bias != nullptr && i < n_out) ? bias[i] : 0.f;
     }
 
+    // the granules this thread stages, chunk independent: channel block << 16 | tile row << 8 | tile column
+    unsigned geo[IN_ROUNDS];
+#pragma unroll
+    for (int k = 0; k < IN_ROUNDS; ++k) {
+        const int e = min(tid + X3_THREADS * k, ING - 1);
+        const int cb = e / PL, rem = e - cb * PL, py = rem / X3_IW;
+        geo[k] = (unsigned)(cb << 16 | py << 8 | (rem - py * X3_IW));
+    }
+
     // item of step s: tile ti = s / per_tile, m-block mb = (s / nch) % nmb, chunk c = s % nch
-    X3Gran rin[X3_IN_ROUNDS];
+    X3Gran rin[IN_ROUNDS];
     x3_u4 rw[W_ROUNDS];
 
     auto issue = [&](int s) {
@@ -162,54 +183,51 @@ __global__ __launch_bounds__(X3_THREADS) void conv_x3_kernel(TV tin, TV tout, TV
         const int in_ = tile / tiles_per_img, tt = tile - in_ * tiles_per_img;
         const int ys0 = (tt / tiles_x) * X3_TH, xs0 = (tt % tiles_x) * X3_TW;
         const int iy0 = ys0 - tout.halo - 1, ix0 = xs0 - tout.halo - 1;   // logical origin of the input tile
+        const char* base = tin.base + ((long long)in_ * tin.img + (long long)(tin.cb_off + c * CKB) * tin.plane) * 32;
+        const int ncb = tin.cb - c * CKB;                                   // channel blocks this chunk really has
 #pragma unroll
-        for (int k = 0; k < X3_IN_ROUNDS; ++k) {
-            const int e = tid + X3_THREADS * k;
+        for (int k = 0; k < IN_ROUNDS; ++k) {
+            const int cb = (int)(geo[k] >> 16), py = (int)((geo[k] >> 8) & 255u), px = (int)(geo[k] & 255u);
             rin[k].a = (x3_f4){0.f, 0.f, 0.f, 0.f};
             rin[k].b = rin[k].a;
-            if (e < X3_ING) {
-                const int cbl = e >= X3_IH * X3_IW ? 1 : 0, rem = e - cbl * (X3_IH * X3_IW);
-                const int py = rem / X3_IW, px = rem - py * X3_IW;
-                int y = iy0 + py, x = ix0 + px;
-                const int cb = c * 2 + cbl;
-                bool ok = cb < tin.cb;
-                if (DGRAD) {
-                    ok = ok && y >= 0 && y < tin.h && x >= 0 && x < tin.w;
-                    y += tin.halo; x += tin.halo;
-                } else {
-                    y = min(max(reflect_idx(y, tin.h), 0), tin.h - 1);
-                    x = min(max(reflect_idx(x, tin.w), 0), tin.w - 1);
-                }
-                if (ok) {
-                    const x3_f4* p = reinterpret_cast<const x3_f4*>(tin.base + tin.gidx(in_, cb, y, x) * 32);
-                    rin[k].a = p[0];
-                    rin[k].b = p[1];
-                }
+            int y = iy0 + py, x = ix0 + px;
+            bool ok = cb < ncb && tid + X3_THREADS * k < ING;
+            if (DGRAD) {
+                ok = ok && y >= 0 && y < tin.h && x >= 0 && x < tin.w;
+                y += tin.halo; x += tin.halo;
+            } else {
+                y = min(max(reflect_idx(y, tin.h), 0), tin.h - 1);
+                x = min(max(reflect_idx(x, tin.w), 0), tin.w - 1);
+            }
+            if (ok) {
+                const x3_f4* p = reinterpret_cast<const x3_f4*>(base + ((unsigned)cb * (unsigned)tin.plane + (unsigned)(y * tin.ws + x)) * 32u);   // (32-bit: x3_small)
+                rin[k].a = p[0];
+                rin[k].b = p[1];
             }
         }
-        const x3_u4* src = reinterpret_cast<const x3_u4*>(wpk) + ((long long)mb * nch + c) * (NP * WG);
+        const x3_u4* src = reinterpret_cast<const x3_u4*>(wpk) + ((long long)mb * nch16 + c * KK) * (NP * WG);
+        const int nw = min(KK, nch16 - c * KK) * (NP * WG);
 #pragma unroll
         for (int k = 0; k < W_ROUNDS; ++k) {
             const int e = tid + X3_THREADS * k;
-            if (e < NP * WG) rw[k] = src[e];
+            if (e < nw) rw[k] = src[e];
         }
     };
-    auto commit = [&](int buf) {
-        x3_u4* dst = s_buf + buf * BUF_G;
+    auto commit = [&]() {
 #pragma unroll
-        for (int k = 0; k < X3_IN_ROUNDS; ++k) {
+        for (int k = 0; k < IN_ROUNDS; ++k) {
             const int e = tid + X3_THREADS * k;
-            if (e < X3_ING) {
+            if (e < ING) {
                 x3_u4 pc[NP];
                 x3_split_gran<NP>(rin[k], pc);
 #pragma unroll
-                for (int p = 0; p < NP; ++p) dst[p * X3_ING + e] = pc[p];
+                for (int p = 0; p < NP; ++p) s_buf[p * ING + e] = pc[p];
             }
         }
 #pragma unroll
         for (int k = 0; k < W_ROUNDS; ++k) {
             const int e = tid + X3_THREADS * k;
-            if (e < NP * WG) dst[NP * X3_ING + e] = rw[k];
+            if (e < WGC) s_buf[NP * ING + e] = rw[k];   // (sub-chunks past the layer's last one: stale registers, never read)
         }
     };
 
@@ -222,60 +240,63 @@ __global__ __launch_bounds__(X3_THREADS) void conv_x3_kernel(TV tin, TV tout, TV
             for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.f;
 
     const int cbl = lane >> 5, nl = lane & 31;
-    const int bbase = (cbl * X3_IH + 2 * wave) * X3_IW + nl;   // + row * X3_IW + v   (+ piece * X3_ING)
-    const int abase = cbl * MBW + nl;                           // + tap * 2 * MBW + m * 32   (+ piece * WG)
+    const int bbase = (cbl * X3_IH + 2 * wave) * X3_IW + nl;   // + kk * 2 * PL + row * X3_IW + v   (+ piece * ING)
+    const int abase = cbl * MBW + nl;                           // + kk * NP * WG + piece * WG + tap * 2 * MBW + m * 32
 
     issue(0);
-    commit(0);
+    commit();
     __syncthreads();
 
     for (int s = 0; s < nsteps; ++s) {
-        const int buf = NBUF == 2 ? (s & 1) : 0;
         if (s + 1 < nsteps) issue(s + 1);
-        // ---------------- the chunk's 9 taps: operand fragments of tap t+1 are fetched while tap t's MFMAs run ----------------
-        {
-            const x3_u4* s_in = s_buf + buf * BUF_G;
-            const x3_u4* s_w = s_in + NP * X3_ING;
-            x3_bf16x8 brow[4][NP], afr[2][MB][NP];
-            // taps in column-major order t = 3 v + u: tap (u, v) reads tile rows u, u+1 of the wave's 4-row window at column shift v
-            auto ld_a = [&](int t, int slot) {
-                const int v = t / 3, u = t % 3, tap = u * 3 + v;
+        // ---------------- the chunk's KK x 9 taps: operand fragments of tap t+1 are fetched while tap t's MFMAs run ----------------
+        const int nkk = min(KK, nch16 - (s % nch) * KK);
 #pragma unroll
-                for (int m = 0; m < MB; ++m)
+        for (int kk = 0; kk < KK; ++kk) {
+            if (kk < nkk) {
+                const x3_u4* s_in = s_buf + kk * 2 * PL;
+                const x3_u4* s_w = s_buf + NP * ING + kk * NP * WG;
+                x3_bf16x8 brow[4][NP], afr[2][MB][NP];
+                // taps in column-major order t = 3 v + u: tap (u, v) reads tile rows u, u+1 of the wave's 4-row window at column shift v
+                auto ld_a = [&](int t, int slot) {
+                    const int v = t / 3, u = t % 3, tap = u * 3 + v;
 #pragma unroll
-                    for (int p = 0; p < NP; ++p) afr[slot][m][p] = x3_frag(s_w[p * WG + abase + tap * 2 * MBW + m * 32]);
-            };
-            auto ld_b = [&](int row, int v) {
+                    for (int m = 0; m < MB; ++m)
 #pragma unroll
-                for (int p = 0; p < NP; ++p) brow[row][p] = x3_frag(s_in[p * X3_ING + bbase + row * X3_IW + v]);
-            };
-            ld_a(0, 0);
-            ld_b(0, 0);
-            ld_b(1, 0);
+                        for (int p = 0; p < NP; ++p) afr[slot][m][p] = x3_frag(s_w[p * WG + abase + tap * 2 * MBW + m * 32]);
+                };
+                auto ld_b = [&](int row, int v) {
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int u = t % 3;
-                int nld = 0;
-                if (t + 1 < 9) {
-                    const int v1 = (t + 1) / 3, u1 = (t + 1) % 3;
-                    ld_a(t + 1, (t + 1) & 1);
-                    nld += MB * NP;
-                    if (u1 == 0) { ld_b(0, v1); ld_b(1, v1); nld += 2 * NP; }
-                    else { ld_b(u1 + 1, v1); nld += NP; }
+                    for (int p = 0; p < NP; ++p) brow[row][p] = x3_frag(s_in[p * ING + bbase + row * X3_IW + v]);
+                };
+                ld_a(0, 0);
+                ld_b(0, 0);
+                ld_b(1, 0);
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int u = t % 3;
+                    int nld = 0;
+                    if (t + 1 < 9) {
+                        const int v1 = (t + 1) / 3, u1 = (t + 1) % 3;
+                        ld_a(t + 1, (t + 1) & 1);
+                        nld += MB * NP;
+                        if (u1 == 0) { ld_b(0, v1); ld_b(1, v1); nld += 2 * NP; }
+                        else { ld_b(u1 + 1, v1); nld += NP; }
+                    }
+#pragma unroll
+                    for (int q = 0; q < NPROD; ++q)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int m = 0; m < MB; ++m)
+                                acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[t & 1][m][X3Prod<NP>::A[q]], brow[u + j][X3Prod<NP>::B[q]], acc[m][j], 0, 0, 0);
+                    // the prefetch reads ride between this tap's first MFMAs
+                    for (int i = 0; i < nld; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                    }
+                    for (int i = nld; i < NPROD * 2 * MB; ++i) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 }
-#pragma unroll
-                for (int q = 0; q < NPROD; ++q)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-#pragma unroll
-                        for (int m = 0; m < MB; ++m)
-                            acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[t & 1][m][X3Prod<NP>::A[q]], brow[u + j][X3Prod<NP>::B[q]], acc[m][j], 0, 0, 0);
-                // the prefetch reads ride between this tap's first MFMAs
-                for (int i = 0; i < nld; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
-                }
-                for (int i = nld; i < NPROD * 2 * MB; ++i) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             }
         }
         // ---------------- epilogue after the item's last chunk ----------------
@@ -289,39 +310,51 @@ __global__ __launch_bounds__(X3_THREADS) void conv_x3_kernel(TV tin, TV tout, TV
             for (int j = 0; j < 2; ++j) {
                 const int ys = ys0 + 2 * wave + j;
                 const bool inside = ys < tout.hs && xs < tout.ws;
-                x3_f4 old[MB][4], xm[MB][4];
-                if (DGRAD) {   // every accumulate / mask operand of the row first (one round trip), then the arithmetic
-                    const int oy = min(max(reflect_idx(ys - tout.halo, tmask.h), 0), tmask.h - 1);
-                    const int ox = min(max(reflect_idx(xs - tout.halo, tmask.w), 0), tmask.w - 1);
+                const int oy = DGRAD ? min(max(reflect_idx(ys - tout.halo, tmask.h), 0), tmask.h - 1) : 0;
+                const int ox = DGRAD ? min(max(reflect_idx(xs - tout.halo, tmask.w), 0), tmask.w - 1) : 0;
+                const int ysc = min(ys, tout.hs - 1), xsc = min(xs, tout.ws - 1);   // in-range twin of the lane's position: every load below is
+#pragma unroll                                                                      // unconditional per lane (a load under its own branch gets
+                for (int m = 0; m < MB; ++m) {                                      // its own s_waitcnt vmcnt(0): 16 serial round trips per item)
+                    x3_f4 old[4], xm[4];
+                    if (DGRAD) {   // the four accumulate / mask operands of this 32-channel group in ONE round trip, then the arithmetic
 #pragma unroll
-                    for (int m = 0; m < MB; ++m)
+                        for (int q = 0; q < 4; ++q) {
+                            old[q] = (x3_f4){0.f, 0.f, 0.f, 0.f};
+                            xm[q] = (x3_f4){1.f, 1.f, 1.f, 1.f};
+                        }
+                        if (accum_bits != 0ull) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const int ocbc = min((mb * MB + m) * 4 + q, tout.cb - 1);
+                                old[q] = *reinterpret_cast<const x3_f4*>(tout.base + tout.gidx(in_, ocbc, ysc, xsc) * 32 + half * 16);
+                            }
+                        }
+                        if (mask_bits != 0ull) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const int ocbc = min((mb * MB + m) * 4 + q, tout.cb - 1);
+                                xm[q] = *reinterpret_cast<const x3_f4*>(tmask.base + tmask.gidx(in_, ocbc, oy, ox) * 32 + half * 16);
+                            }
+                        }
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const int ocb = (mb * MB + m) * 4 + q;
-                            old[m][q] = (x3_f4){0.f, 0.f, 0.f, 0.f};
-                            xm[m][q] = (x3_f4){1.f, 1.f, 1.f, 1.f};
-                            if (inside && ocb < tout.cb) {
-                                if ((accum_bits >> ocb) & 1ull)
-                                    old[m][q] = *reinterpret_cast<const x3_f4*>(tout.base + tout.gidx(in_, ocb, ys, xs) * 32 + half * 16);
-                                if ((mask_bits >> ocb) & 1ull)
-                                    xm[m][q] = *reinterpret_cast<const x3_f4*>(tmask.base + tmask.gidx(in_, ocb, oy, ox) * 32 + half * 16);
-                            }
+                            if (!((accum_bits >> ocb) & 1ull)) old[q] = (x3_f4){0.f, 0.f, 0.f, 0.f};
+                            if (!((mask_bits >> ocb) & 1ull)) xm[q] = (x3_f4){1.f, 1.f, 1.f, 1.f};
                         }
-                }
-#pragma unroll
-                for (int m = 0; m < MB; ++m) {
+                    }
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int ocb = (mb * MB + m) * 4 + q;          // channel block of the out view
                         x3_f4 v = {acc[m][j][4 * q], acc[m][j][4 * q + 1], acc[m][j][4 * q + 2], acc[m][j][4 * q + 3]};
                         if (!DGRAD) {
-                            const x3_f4 b4 = *reinterpret_cast<const x3_f4*>(reinterpret_cast<const float*>(s_buf + NBUF * BUF_G) + ocb * 8 + 4 * half);
+                            const x3_f4 b4 = *reinterpret_cast<const x3_f4*>(reinterpret_cast<const float*>(s_buf + BUF_G) + ocb * 8 + 4 * half);
                             v += b4;
                             if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                         } else {
-                            v += old[m][q];
-                            v.x = xm[m][q].x > 0.f ? v.x : 0.f; v.y = xm[m][q].y > 0.f ? v.y : 0.f;
-                            v.z = xm[m][q].z > 0.f ? v.z : 0.f; v.w = xm[m][q].w > 0.f ? v.w : 0.f;
+                            v += old[q];
+                            v.x = xm[q].x > 0.f ? v.x : 0.f; v.y = xm[q].y > 0.f ? v.y : 0.f;
+                            v.z = xm[q].z > 0.f ? v.z : 0.f; v.w = xm[q].w > 0.f ? v.w : 0.f;
                         }
                         if (inside && ocb < tout.cb)
                             *reinterpret_cast<x3_f4*>(tout.base + tout.gidx(in_, ocb, ys, xs) * 32 + half * 16) = v;
@@ -332,8 +365,8 @@ __global__ __launch_bounds__(X3_THREADS) void conv_x3_kernel(TV tin, TV tout, TV
             }
         }
         if (s + 1 < nsteps) {
-            if (NBUF == 1) __syncthreads();   // every wave has finished reading the single tile
-            commit(NBUF == 2 ? (buf ^ 1) : 0);
+            __syncthreads();   // every wave has finished reading the tile
+            commit();
         }
         __syncthreads();
     }
@@ -365,82 +398,121 @@ __global__ __launch_bounds__(XW_THREADS) void wgrad_x3_kernel(TV tx, TV tg, floa
     const TileWalk tw = xcd_walk(total, G, gi);
     const int ntile = tw.count;
 
-    const int u = wave % 3, jt = (wave / 3) & 1, mt = wave / 6;     // tap row, input-channel tile, output-channel tile (32 each)
+    // wave (v, jt, mt): tap COLUMN v, input-channel tile jt, output-channel tile mt (32 each); it owns the three taps (0..2, v): the
+    // activation row a tap (u, v) needs at k-step ry is tile row ry + u, i.e. a three-row register ring with ONE new row per k-step
+    // (2 + 2 fragments per 9 MFMAs; with a fixed tap ROW per wave every k-step re-read all three column shifts: 6 + 2 -- 111 B / clk
+    // of transposing reads on four SIMDs, at the LDS's limit for three waves per SIMD)
+    const int v = wave % 3, jt = (wave / 3) & 1, mt = wave / 6;
     const bool active = (ocg * 64 + mt * 32 < cout) && (icg * 64 + jt * 32 < cin);
-    const bool want_db = (u == 0 && jt == 0 && icg == 0 && ocg * 64 + mt * 32 < cout);
+    const bool want_db = (v == 0 && jt == 0 && icg == 0 && ocg * 64 + mt * 32 < cout);
 
-    X3Gran rin[XW_ROUNDS];
-    auto issue = [&](int k_tile) {
+    // channel blocks this block's groups really have: only those are staged (the planes of the others stay zero from here on)
+    const int nxcb = min(8, tx.cb - icg * 8), ngcb = min(8, tg.cb - ocg * 8);
+    const int n_x = nxcb * (XW_XH * XW_XW), n_all = n_x + ngcb * (XW_TH * XW_TW);
+    for (int i = tid; i < 2 * XW_BUF_G; i += XW_THREADS) s_buf[i] = (x3_u4){0u, 0u, 0u, 0u};
+    unsigned geo[XW_ROUNDS];   // tile independent: is-g << 24 | channel block << 16 | tile row << 8 | tile column
+#pragma unroll
+    for (int k = 0; k < XW_ROUNDS; ++k) {
+        const int e = min(tid + XW_THREADS * k, n_all - 1);
+        if (e < n_x) {
+            const int cb = e / (XW_XH * XW_XW), rem = e - cb * (XW_XH * XW_XW), py = rem / XW_XW;
+            geo[k] = (unsigned)(cb << 16 | py << 8 | (rem - py * XW_XW));
+        } else {
+            const int e2 = e - n_x;
+            const int cb = e2 / (XW_TH * XW_TW), rem = e2 - cb * (XW_TH * XW_TW), py = rem / XW_TW;
+            geo[k] = (unsigned)(1u << 24 | cb << 16 | py << 8 | (rem - py * XW_TW));
+        }
+    }
+
+    // staging of the next tile in two halves (rounds 0-1 during k-steps 0-3, rounds 2-3 during k-steps 4-7: the other LDS buffer is free for
+    // the whole tile), so only two granules per thread are in flight -- four kept the kernel 20 registers over its budget (scratch)
+    static_assert(XW_ROUNDS == 4, "two staging halves of two rounds");
+    X3Gran rin[2];
+    auto issue = [&](int k_tile, int half) {
         const int tile = tw.first + k_tile * tw.stride;
         const int in_ = tile / tpi, tt = tile - in_ * tpi;
         const int y0 = (tt / tiles_x) * XW_TH, x0 = (tt % tiles_x) * XW_TW;
+        const char* bx = tx.base + ((long long)in_ * tx.img + (long long)(tx.cb_off + icg * 8) * tx.plane) * 32;
+        const char* bg = tg.base + ((long long)in_ * tg.img + (long long)(tg.cb_off + ocg * 8) * tg.plane) * 32;
+        const unsigned xplane = (unsigned)tx.plane, gplane = (unsigned)tg.plane;
 #pragma unroll
-        for (int k = 0; k < XW_ROUNDS; ++k) {
-            const int e = tid + XW_THREADS * k;
-            rin[k].a = (x3_f4){0.f, 0.f, 0.f, 0.f};
-            rin[k].b = rin[k].a;
-            if (e < XW_NX) {
-                const int cb = e / (XW_XH * XW_XW), rem = e - cb * (XW_XH * XW_XW);
-                const int py = rem / XW_XW, px = rem - py * XW_XW;
-                const int y = min(max(reflect_idx(y0 + py - 1, tx.h), 0), tx.h - 1);
-                const int x = min(max(reflect_idx(x0 + px - 1, tx.w), 0), tx.w - 1);
-                if (icg * 8 + cb < tx.cb) {
-                    const x3_f4* p = reinterpret_cast<const x3_f4*>(tx.base + tx.gidx(in_, icg * 8 + cb, y, x) * 32);
-                    rin[k].a = p[0];
-                    rin[k].b = p[1];
-                }
-            } else if (e < XW_NX + XW_NG) {
-                const int e2 = e - XW_NX;
-                const int cb = e2 / (XW_TH * XW_TW), rem = e2 - cb * (XW_TH * XW_TW);
-                const int py = rem / XW_TW, px = rem - py * XW_TW;
-                const int y = y0 + py, x = x0 + px;
-                if (ocg * 8 + cb < tg.cb && y < tg.h && x < tg.w) {
-                    const x3_f4* p = reinterpret_cast<const x3_f4*>(tg.base + tg.gidx(in_, ocg * 8 + cb, y + tg.halo, x + tg.halo) * 32);
-                    rin[k].a = p[0];
-                    rin[k].b = p[1];
+        for (int kr = 0; kr < 2; ++kr) {
+            const int k = 2 * half + kr;
+            const unsigned gk = half ? geo[2 + kr] : geo[kr];
+            const int cb = (int)((gk >> 16) & 255u), py = (int)((gk >> 8) & 255u), px = (int)(gk & 255u);
+            rin[kr].a = (x3_f4){0.f, 0.f, 0.f, 0.f};
+            rin[kr].b = rin[kr].a;
+            if (tid + XW_THREADS * k < n_all) {
+                if (!(gk >> 24)) {
+                    const int y = min(max(reflect_idx(y0 + py - 1, tx.h), 0), tx.h - 1);
+                    const int x = min(max(reflect_idx(x0 + px - 1, tx.w), 0), tx.w - 1);
+                    const x3_f4* p = reinterpret_cast<const x3_f4*>(bx + ((unsigned)cb * xplane + (unsigned)(y * tx.ws + x)) * 32u);   // (32-bit: x3_small)
+                    rin[kr].a = p[0];
+                    rin[kr].b = p[1];
+                } else {
+                    const int y = y0 + py, x = x0 + px;
+                    if (y < tg.h && x < tg.w) {
+                        const x3_f4* p = reinterpret_cast<const x3_f4*>(bg + ((unsigned)cb * gplane + (unsigned)((y + tg.halo) * tg.ws + x + tg.halo)) * 32u);
+                        rin[kr].a = p[0];
+                        rin[kr].b = p[1];
+                    }
                 }
             }
         }
     };
-    auto commit = [&](int buf) {
+    auto commit = [&](int buf, int half) {
         x3_u4* dst = s_buf + buf * XW_BUF_G;
 #pragma unroll
-        for (int k = 0; k < XW_ROUNDS; ++k) {
-            const int e = tid + XW_THREADS * k;
-            x3_u4 pc[2];
-            x3_split_gran<2>(rin[k], pc);
-            const x3_u4 hi = pc[0], lo = pc[1];
-            if (e < XW_NX) {   // e enumerates [cb][py][px] with the plane stride XW_XPL = XW_XH * XW_XW
-                dst[e] = hi;
-                dst[XW_XG + e] = lo;
-            } else if (e < XW_NX + XW_NG) {
-                const int e2 = e - XW_NX;
-                const int cb = e2 / (XW_TH * XW_TW), rem = e2 - cb * (XW_TH * XW_TW);
-                dst[2 * XW_XG + cb * XW_GPL + rem] = hi;
-                dst[2 * XW_XG + XW_GG + cb * XW_GPL + rem] = lo;
+        for (int kr = 0; kr < 2; ++kr) {
+            const int k = 2 * half + kr;
+            const unsigned gk = half ? geo[2 + kr] : geo[kr];
+            if (tid + XW_THREADS * k < n_all) {
+                const int cb = (int)((gk >> 16) & 255u), py = (int)((gk >> 8) & 255u), px = (int)(gk & 255u);
+                x3_u4 pc[2];
+                x3_split_gran<2>(rin[kr], pc);
+                if (!(gk >> 24)) {
+                    const int o = cb * XW_XPL + py * XW_XW + px;
+                    dst[o] = pc[0];
+                    dst[XW_XG + o] = pc[1];
+                } else {
+                    const int o = 2 * XW_XG + cb * XW_GPL + py * XW_TW + px;
+                    dst[o] = pc[0];
+                    dst[XW_GG + o] = pc[1];
+                }
             }
         }
     };
 
-    f32x16 acc[3], accb;
+    f32x16 acc[3];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; acc[2][r] = 0.f; accb[r] = 0.f; }
-    const x3_u4 ones_u = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
-    const x3_bf16x8 ones = __builtin_bit_cast(x3_bf16x8, ones_u);
+    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; acc[2][r] = 0.f; }
+    // bias gradient = row sums of the gradient fragments, on TWO v_mfma_f32_16x16x32 (8 accumulator registers instead of the 16 of a
+    // 32 x 32 tile -- this kernel lives at its 168-register budget): read as a 16x16x32 A operand, lane l of the 32x32x16 fragment is
+    // row l & 15, k-group l >> 4, i.e. k-groups 0 / 2 hold channels 0-15 (pixels 0-7 / 8-15) and k-groups 1 / 3 channels 16-31; a B
+    // operand of ones in k-groups {0, 2} (resp. {1, 3}) and zeros elsewhere sums exactly one half
+    x3_f4 accb[2] = {(x3_f4){0.f, 0.f, 0.f, 0.f}, (x3_f4){0.f, 0.f, 0.f, 0.f}};
+    const unsigned one2 = 0x3f803f80u;
+    const unsigned sel0 = ((lane >> 4) & 1) ? 0u : one2, sel1 = ((lane >> 4) & 1) ? one2 : 0u;
+    const x3_bf16x8 ones0 = __builtin_bit_cast(x3_bf16x8, ((x3_u4){sel0, sel0, sel0, sel0}));
+    const x3_bf16x8 ones1 = __builtin_bit_cast(x3_bf16x8, ((x3_u4){sel1, sel1, sel1, sel1}));
 
     // transposing read: within a 16-lane group, lane sl supplies the address of (pixel sl >> 2, 8-byte piece sl & 3 of the 16-channel
     // record = channel block (sl & 3) >> 1, byte 8 * (sl & 1)) and receives channel sl of pixels 0..3 (tests/test_gpu_probe.py)
     const int sl = lane & 15, chalf = (lane >> 4) & 1, kg = lane >> 5;
     const int lane_cb = 2 * chalf + ((sl & 3) >> 1), lane_byte = (sl & 1) * 8, lane_px = 8 * kg + (sl >> 2);
 
+    __syncthreads();   // the zero fill
     if (ntile > 0) {
-        issue(0);
-        commit(0);
+        issue(0, 0);
+        commit(0, 0);
+        issue(0, 1);
+        commit(0, 1);
     }
     __syncthreads();
     for (int k = 0; k < ntile; ++k) {
         const int buf = k & 1;
-        if (k + 1 < ntile) issue(k + 1);
+        const bool more = k + 1 < ntile;
+        if (more) issue(k + 1, 0);
         if (active) {
             const char* s_xh = reinterpret_cast<const char*>(s_buf + buf * XW_BUF_G);
             const char* s_xl = s_xh + XW_XG * 16;
@@ -451,41 +523,73 @@ __global__ __launch_bounds__(XW_THREADS) void wgrad_x3_kernel(TV tx, TV tg, floa
                 const x3_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(X3_LDS_PTR(x3_s16x4, base + 4 * 16));
                 return __builtin_bit_cast(x3_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
             };
-            const int goff = (((mt * 4 + lane_cb) * XW_GPL) + lane_px) * 16 + lane_byte;              // + ry * XW_TW * 16
-            const int xoff = (((jt * 4 + lane_cb) * XW_XPL) + u * XW_XW + lane_px) * 16 + lane_byte;  // + (ry * XW_XW + v) * 16
+            const int goff = (((mt * 4 + lane_cb) * XW_GPL) + lane_px) * 16 + lane_byte;          // + ry * XW_TW * 16
+            const int xoff = (((jt * 4 + lane_cb) * XW_XPL) + lane_px + v) * 16 + lane_byte;      // + row * XW_XW * 16
+            // activation rows ry, ry + 1, ry + 2 live in a four-slot ring (slot = row & 3): row ry + 3 and the gradient fragments of
+            // step ry + 1 are fetched while step ry's nine MFMAs run
+            x3_bf16x8 xh[4], xl[4], gh[2], gl[2];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                xh[r] = ld_tr(s_xh + xoff + r * XW_XW * 16);
+                xl[r] = ld_tr(s_xl + xoff + r * XW_XW * 16);
+            }
+            gh[0] = ld_tr(s_gh + goff);
+            gl[0] = ld_tr(s_gl + goff);
 #pragma unroll
             for (int ry = 0; ry < XW_TH; ++ry) {
-                const x3_bf16x8 gh = ld_tr(s_gh + goff + ry * XW_TW * 16), gl = ld_tr(s_gl + goff + ry * XW_TW * 16);
-                x3_bf16x8 xh[3], xl[3];
-#pragma unroll
-                for (int v = 0; v < 3; ++v) {
-                    xh[v] = ld_tr(s_xh + xoff + (ry * XW_XW + v) * 16);
-                    xl[v] = ld_tr(s_xl + xoff + (ry * XW_XW + v) * 16);
+                if (ry == XW_TH / 2 && more) {   // second half of the next tile's staging
+                    commit(buf ^ 1, 0);
+                    issue(k + 1, 1);
+                }
+                if (ry + 1 < XW_TH) {
+                    xh[(ry + 3) & 3] = ld_tr(s_xh + xoff + (ry + 3) * XW_XW * 16);
+                    xl[(ry + 3) & 3] = ld_tr(s_xl + xoff + (ry + 3) * XW_XW * 16);
+                    gh[(ry + 1) & 1] = ld_tr(s_gh + goff + (ry + 1) * XW_TW * 16);
+                    gl[(ry + 1) & 1] = ld_tr(s_gl + goff + (ry + 1) * XW_TW * 16);
                 }
 #pragma unroll
-                for (int v = 0; v < 3; ++v) acc[v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gl, xh[v], acc[v], 0, 0, 0);
+                for (int u = 0; u < 3; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gl[ry & 1], xh[(ry + u) & 3], acc[u], 0, 0, 0);
 #pragma unroll
-                for (int v = 0; v < 3; ++v) acc[v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh, xl[v], acc[v], 0, 0, 0);
+                for (int u = 0; u < 3; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh[ry & 1], xl[(ry + u) & 3], acc[u], 0, 0, 0);
 #pragma unroll
-                for (int v = 0; v < 3; ++v) acc[v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh, xh[v], acc[v], 0, 0, 0);
+                for (int u = 0; u < 3; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh[ry & 1], xh[(ry + u) & 3], acc[u], 0, 0, 0);
                 if (want_db) {
-                    accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gl, ones, accb, 0, 0, 0);
-                    accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh, ones, accb, 0, 0, 0);
+                    accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gl[ry & 1], ones0, accb[0], 0, 0, 0);
+                    accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gl[ry & 1], ones1, accb[1], 0, 0, 0);
+                    accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh[ry & 1], ones0, accb[0], 0, 0, 0);
+                    accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh[ry & 1], ones1, accb[1], 0, 0, 0);
+                }
+                if (ry + 1 < XW_TH) {   // the 8 transposing reads (16 instructions) ride between the first MFMAs
+                    for (int i = 0; i < 8; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 }
             }
         }
-        if (k + 1 < ntile) commit(buf ^ 1);
+        else if (more) {   // (a wave without a live channel tile still stages)
+            commit(buf ^ 1, 0);
+            issue(k + 1, 1);
+        }
+        if (more) commit(buf ^ 1, 1);
         __syncthreads();
     }
-    // lane l reg r of acc[v]: oc = 32 mt + (r & 3) + 8 (r >> 2) + 4 (l >> 5), ic = 32 jt + (l & 31), tap (u, v)
+    // lane l reg r of acc[u]: oc = 32 mt + (r & 3) + 8 (r >> 2) + 4 (l >> 5), ic = 32 jt + (l & 31), tap (u, v)
     if (active) {
         float* dst = partial + ((long long)gi * npairs + pair) * XW_PER;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int oc = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), ic = 32 * jt + (lane & 31);
 #pragma unroll
-            for (int v = 0; v < 3; ++v) dst[(oc * 64 + ic) * 9 + u * 3 + v] = acc[v][r];
-            if (want_db && (lane & 31) == 0) dst[64 * 64 * 9 + oc] = accb[r];
+            for (int u = 0; u < 3; ++u) dst[(oc * 64 + ic) * 9 + u * 3 + v] = acc[u][r];
+        }
+        // 16x16x32 C layout: lane l, reg r = row 4 (l >> 4) + r, column l & 15; rows of accb[h] = channels 16 h .. 16 h + 15
+        if (want_db && (lane & 15) == 0) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[64 * 64 * 9 + 32 * mt + 16 * h + 4 * (lane >> 4) + r] = accb[h][r];
         }
     }
 }
@@ -551,7 +655,7 @@ static bool x3_enabled() {   // $MMIF_X3=0: fp32 tensors stay on the fp32 FMA ke
 }
 
 static bool x3_grad_ok(const TV& t) { return t.halo == 0 || (t.halo == 1 && t.folded); }
-static bool x3_small(const TV& t) { return t.plane * 32 < (1ll << 31); }
+static bool x3_small(const TV& t) { return t.plane * 32 * 8 < (1ll << 32); }   // 8 planes addressed with 32-bit byte offsets
 
 bool conv_x3_supported(bool dgrad, int ks, int cin, int cout, const TV& tin, const TV& tout) {
     if (!x3_enabled() || ks != 3 || cin < 1 || cout < 1) return false;
@@ -605,19 +709,20 @@ int conv_x3_pack_multi(const mmif_pack_job* jobs, int n_jobs, hipStream_t st) {
     return flush();
 }
 
-template <int MB, int NP>
+template <int MB, int NP, int NW>
 static int launch_conv_x3(bool dgrad, const TV& tin, const TV& tout, const TV& tmask, const void* wpk, const float* bias, int n_out, int n_in,
                           int relu, uint64_t mask_bits, uint64_t accum_bits, hipStream_t st) {
-    const int tiles_x = cdiv(tout.ws, X3_TW), tiles_y = cdiv(tout.hs, X3_TH);
+    const int tiles_x = cdiv(tout.ws, X3_TW), tiles_y = cdiv(tout.hs, 2 * NW);
     const int tpi = tiles_x * tiles_y, total = tpi * tout.n;
-    int G = x3_num_cus();
+    int G = x3_num_cus() * (NW == 4 ? 2 : 1);
     if (total < G) G = total;
     const int nch = x3_nch(n_in), nmb = x3_nmb(n_out);
+    constexpr int X3_THREADS = 64 * NW;
     if (dgrad)
-        hipLaunchKernelGGL((conv_x3_kernel<MB, true, NP>), dim3(G), dim3(X3_THREADS), 0, st, tin, tout, tmask, (const uint4*)wpk, bias, n_out, nch, nmb,
+        hipLaunchKernelGGL((conv_x3_kernel<MB, true, NP, NW>), dim3(G), dim3(X3_THREADS), 0, st, tin, tout, tmask, (const uint4*)wpk, bias, n_out, nch, nmb,
                            relu, (unsigned long long)mask_bits, (unsigned long long)accum_bits, tiles_x, tpi, total);
     else
-        hipLaunchKernelGGL((conv_x3_kernel<MB, false, NP>), dim3(G), dim3(X3_THREADS), 0, st, tin, tout, tmask, (const uint4*)wpk, bias, n_out, nch, nmb,
+        hipLaunchKernelGGL((conv_x3_kernel<MB, false, NP, NW>), dim3(G), dim3(X3_THREADS), 0, st, tin, tout, tmask, (const uint4*)wpk, bias, n_out, nch, nmb,
                            relu, (unsigned long long)mask_bits, (unsigned long long)accum_bits, tiles_x, tpi, total);
     return check_launch(dgrad ? "conv_x3 dgrad" : "conv_x3 fwd");
 }
@@ -628,10 +733,10 @@ int conv_x3(bool dgrad, const TV& tin, const TV& tout, const TV& tmask, const vo
     const int n_out = dgrad ? cin : cout, n_in = dgrad ? cout : cin;
     const bool six = !dgrad && x3_fwd_pieces() == 3;
     if (x3_mb(n_out) == 2)
-        return six ? launch_conv_x3<2, 3>(false, tin, tout, tmask, wpk, bias, n_out, n_in, relu, mask_bits, accum_bits, st)
-                   : launch_conv_x3<2, 2>(dgrad, tin, tout, tmask, wpk, bias, n_out, n_in, relu, mask_bits, accum_bits, st);
-    return six ? launch_conv_x3<1, 3>(false, tin, tout, tmask, wpk, bias, n_out, n_in, relu, mask_bits, accum_bits, st)
-               : launch_conv_x3<1, 2>(dgrad, tin, tout, tmask, wpk, bias, n_out, n_in, relu, mask_bits, accum_bits, st);
+        return six ? launch_conv_x3<2, 3, 8>(false, tin, tout, tmask, wpk, bias, n_out, n_in, relu, mask_bits, accum_bits, st)
+                   : launch_conv_x3<2, 2, 8>(dgrad, tin, tout, tmask, wpk, bias, n_out, n_in, relu, mask_bits, accum_bits, st);
+    return six ? launch_conv_x3<1, 3, 8>(false, tin, tout, tmask, wpk, bias, n_out, n_in, relu, mask_bits, accum_bits, st)
+               : launch_conv_x3<1, 2, 8>(dgrad, tin, tout, tmask, wpk, bias, n_out, n_in, relu, mask_bits, accum_bits, st);
 }
 
 bool wgrad_x3_supported(int ks, int cin, int cout, const TV& tx, const TV& tg) {
