@@ -525,46 +525,33 @@ __global__ __launch_bounds__(XW_THREADS) void wgrad_x3_kernel(TV tx, TV tg, floa
             };
             const int goff = (((mt * 4 + lane_cb) * XW_GPL) + lane_px) * 16 + lane_byte;          // + ry * XW_TW * 16
             const int xoff = (((jt * 4 + lane_cb) * XW_XPL) + lane_px + v) * 16 + lane_byte;      // + row * XW_XW * 16
-            // activation rows ry, ry + 1, ry + 2 live in a four-slot ring (slot = row & 3): row ry + 3 and the gradient fragments of
-            // step ry + 1 are fetched while step ry's nine MFMAs run
-            x3_bf16x8 xh[4], xl[4], gh[2], gl[2];
+            // activation rows ry, ry + 1, ry + 2 live in a three-slot register ring (slot = row % 3): ONE new row per k-step
+            x3_bf16x8 xh[3], xl[3];
 #pragma unroll
-            for (int r = 0; r < 3; ++r) {
+            for (int r = 0; r < 2; ++r) {
                 xh[r] = ld_tr(s_xh + xoff + r * XW_XW * 16);
                 xl[r] = ld_tr(s_xl + xoff + r * XW_XW * 16);
             }
-            gh[0] = ld_tr(s_gh + goff);
-            gl[0] = ld_tr(s_gl + goff);
 #pragma unroll
             for (int ry = 0; ry < XW_TH; ++ry) {
                 if (ry == XW_TH / 2 && more) {   // second half of the next tile's staging
                     commit(buf ^ 1, 0);
                     issue(k + 1, 1);
                 }
-                if (ry + 1 < XW_TH) {
-                    xh[(ry + 3) & 3] = ld_tr(s_xh + xoff + (ry + 3) * XW_XW * 16);
-                    xl[(ry + 3) & 3] = ld_tr(s_xl + xoff + (ry + 3) * XW_XW * 16);
-                    gh[(ry + 1) & 1] = ld_tr(s_gh + goff + (ry + 1) * XW_TW * 16);
-                    gl[(ry + 1) & 1] = ld_tr(s_gl + goff + (ry + 1) * XW_TW * 16);
-                }
+                xh[(ry + 2) % 3] = ld_tr(s_xh + xoff + (ry + 2) * XW_XW * 16);
+                xl[(ry + 2) % 3] = ld_tr(s_xl + xoff + (ry + 2) * XW_XW * 16);
+                const x3_bf16x8 gh = ld_tr(s_gh + goff + ry * XW_TW * 16), gl = ld_tr(s_gl + goff + ry * XW_TW * 16);
 #pragma unroll
-                for (int u = 0; u < 3; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gl[ry & 1], xh[(ry + u) & 3], acc[u], 0, 0, 0);
+                for (int u = 0; u < 3; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gl, xh[(ry + u) % 3], acc[u], 0, 0, 0);
 #pragma unroll
-                for (int u = 0; u < 3; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh[ry & 1], xl[(ry + u) & 3], acc[u], 0, 0, 0);
+                for (int u = 0; u < 3; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh, xl[(ry + u) % 3], acc[u], 0, 0, 0);
 #pragma unroll
-                for (int u = 0; u < 3; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh[ry & 1], xh[(ry + u) & 3], acc[u], 0, 0, 0);
+                for (int u = 0; u < 3; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh, xh[(ry + u) % 3], acc[u], 0, 0, 0);
                 if (want_db) {
-                    accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gl[ry & 1], ones0, accb[0], 0, 0, 0);
-                    accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gl[ry & 1], ones1, accb[1], 0, 0, 0);
-                    accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh[ry & 1], ones0, accb[0], 0, 0, 0);
-                    accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh[ry & 1], ones1, accb[1], 0, 0, 0);
-                }
-                if (ry + 1 < XW_TH) {   // the 8 transposing reads (16 instructions) ride between the first MFMAs
-                    for (int i = 0; i < 8; ++i) {
-                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    }
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gl, ones0, accb[0], 0, 0, 0);
+                    accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gl, ones1, accb[1], 0, 0, 0);
+                    accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh, ones0, accb[0], 0, 0, 0);
+                    accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh, ones1, accb[1], 0, 0, 0);
                 }
             }
         }
