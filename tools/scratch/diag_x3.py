@@ -11,7 +11,7 @@ res = {}
 mode = os.environ.get("MMIF_X3", "1")
 if True:
     E.set_compute_dtype("fp32")
-    m = load_closed_form(getattr(M, name)(), 1).cuda()
+    m = load_closed_form(getattr(M, name)(), int(os.environ.get('SEED', '1'))).cuda()
     i1, i2 = tg(O.closed_form_image(shape, 0.3)), tg(O.closed_form_image(shape, 1.7))
     y = m(i1, i2)
     y.backward(tg(O.closed_form_signed(shape, 0.9, 1.0)))
