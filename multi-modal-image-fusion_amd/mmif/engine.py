@@ -48,15 +48,35 @@ def set_compute_dtype(dtype):
     _cfg.dtype = dtype
 
 
+# A/B switches ($MMIF_...): read from the environment ONCE and cached -- the per-step host path only looks them up in this dict.  A process
+# that changes one at run time (the tests do) calls reload_switches().
+_SW = {}
+
+
+def switch(name, default="1"):
+    v = _SW.get(name)
+    if v is None:
+        v = _SW[name] = os.environ.get(name, default) != "0"
+    return v
+
+
+def reload_switches():
+    _SW.clear()
+
+
 def conv_impl():
     """MMIF_IMPL_AUTO unless $MMIF_CONV_IMPL = valu | mfma | x3 (cross-checking the kernel families)."""
-    return {"valu": _lib.IMPL_VALU, "mfma": _lib.IMPL_MFMA, "x3": _lib.IMPL_X3}.get(os.environ.get("MMIF_CONV_IMPL", "auto").lower(), _lib.IMPL_AUTO)
+    v = _SW.get("MMIF_CONV_IMPL")
+    if v is None:
+        v = _SW["MMIF_CONV_IMPL"] = {"valu": _lib.IMPL_VALU, "mfma": _lib.IMPL_MFMA, "x3": _lib.IMPL_X3}.get(
+            os.environ.get("MMIF_CONV_IMPL", "auto").lower(), _lib.IMPL_AUTO)
+    return v
 
 
 def x3_enabled():
     """fp32 tensors: 3x3 layers on the matrix pipe as split-bf16 products (csrc/conv_x3.hip, ~1e-5 of the fp32 FMA kernels' results);
-    $MMIF_X3=0 keeps them on the fp32 FMA kernels (the library reads the same switch)."""
-    return os.environ.get("MMIF_X3", "1") != "0"
+    $MMIF_X3=0 keeps them on the fp32 FMA kernels (the library reads the same switch, once per process)."""
+    return switch("MMIF_X3")
 
 
 def set_x3_forward_pieces(pieces):
@@ -77,7 +97,7 @@ def wants_packed(dtype, impl, standalone=False):
         return False
     if dtype == torch.bfloat16:
         return True
-    if standalone and impl != _lib.IMPL_X3 and os.environ.get("MMIF_X3_LAYERS", "0") != "1":
+    if standalone and impl != _lib.IMPL_X3 and not switch("MMIF_X3_LAYERS", "0"):
         return False
     return x3_enabled()
 
@@ -341,7 +361,7 @@ class ModelEngine:
     def pair_ok(s, dtype, impl, h, w):
         """this layer's backward runs as ONE launch (csrc/conv_mfma.hip bwd_pair_kernel; $MMIF_BWD_PAIR=0: dgrad and wgrad apart)"""
         return (dtype == torch.bfloat16 and impl != _lib.IMPL_VALU and not s.split and s.relu and s.packed is not None and h >= 4 and w >= 4
-                and T.bwd_pair_supported(s.cin, s.cout, s.k) and os.environ.get("MMIF_BWD_PAIR", "1") != "0")
+                and T.bwd_pair_supported(s.cin, s.cout, s.k) and switch("MMIF_BWD_PAIR"))
 
     @staticmethod
     def wide_ok(s, dtype, impl, x, gx):
@@ -349,7 +369,7 @@ class ModelEngine:
         $MMIF_BWD_WIDE=0: the two calls apart, the dgrad reading the activations)"""
         return (dtype == torch.bfloat16 and impl != _lib.IMPL_VALU and not s.split and s.packed is not None and x.h >= 4 and x.w >= 4
                 and x.halo == 0 and gx.halo == 1 and x.cb * 8 == s.cin and T.bwd_wide_supported(s.cin, s.cout, s.k)
-                and (x.h + 2) * (x.w + 2) * 128 < (1 << 31) and os.environ.get("MMIF_BWD_WIDE", "1") != "0")
+                and (x.h + 2) * (x.w + 2) * 128 < (1 << 31) and switch("MMIF_BWD_WIDE"))
 
     def c_bwd_wide(self, s, gy, x, gx, mask_bits, ws):
         need = T.bwd_wide_signs_bytes(x.n, s.cin, x.h, x.w)
@@ -420,7 +440,7 @@ class DenseEncoderMixin:
     def enc_fwd_all(branches, F, dtype, impl):
         """branches: [(specs, img, first channel block in F), ...] (one or two).  bf16 / MFMA: ONE streaming launch for all four
         layers of all branches (csrc/enc_stream.hip; bit-identical to the layer-wise launches, $MMIF_ENC_STREAM=0 selects those)."""
-        stream = (dtype == torch.bfloat16 and impl != _lib.IMPL_VALU and os.environ.get("MMIF_ENC_STREAM", "1") != "0"
+        stream = (dtype == torch.bfloat16 and impl != _lib.IMPL_VALU and switch("MMIF_ENC_STREAM")
                   and all(s.relu and s.k == 3 for specs, _, _ in branches for s in specs)
                   and all([(s.cin, s.cout) for s in specs] == [(1, 16), (16, 16), (32, 16), (48, 16)] for specs, _, _ in branches))
         if not stream:
@@ -457,10 +477,10 @@ class DenseEncoderMixin:
         # (csrc/enc_wgrad.hip; $MMIF_ENC_WGRAD=0 selects the layer-wise kernels)
         hot = (F.dtype == torch.bfloat16 and impl != _lib.IMPL_VALU and all(s.k == 3 for s in specs)
                and [(s.cin, s.cout) for s in specs] == [(1, 16), (16, 16), (32, 16), (48, 16)])
-        fused = hot and os.environ.get("MMIF_ENC_WGRAD", "1") != "0"
+        fused = hot and switch("MMIF_ENC_WGRAD")
         # ... and the dgrad chain per DESTINATION (gather form: one launch per x_k on the stacked virtual layer, fp32 sum of all
         # contributions, one rounding) instead of per source layer (read-modify-write of the lower blocks); $MMIF_ENC_CHAIN=0: scatter
-        gather = hot and os.environ.get("MMIF_ENC_CHAIN", "1") != "0"
+        gather = hot and switch("MMIF_ENC_CHAIN")
         if gather:
             pk = DenseEncoderMixin.chain_images(specs)
             for k in (2, 1, 0):
@@ -663,7 +683,7 @@ class DenseFuseEngine(ModelEngine, DenseEncoderMixin):
         hot = (dtype == torch.bfloat16 and impl != _lib.IMPL_VALU and all(s.k == 3 for s in specs)
                and [(s.cin, s.cout) for s in specs] == [(1, 16), (16, 16), (32, 16), (48, 16)])
         return (hot and type(self).fusion_bwd is DenseFuseEngine.fusion_bwd and self.fusion_mode == _lib.FUSE_SUM
-                and os.environ.get("MMIF_ENC_CHAIN", "1") != "0" and os.environ.get("MMIF_FUSE_SHARE", "1") != "0"
+                and switch("MMIF_ENC_CHAIN") and switch("MMIF_FUSE_SHARE")
                 and all(T.dgrad_onto_supported(GF.as_folded().view(2 * (k + 1), 2 * (3 - k)), GF.view(2 * k, 2), 16, 16 * (3 - k), 3)
                         for k in (2, 1, 0)))
 
@@ -710,7 +730,7 @@ class PFNetv2Engine(DenseFuseEngine):
         GH2 = self.buf(L, "GH2", n, 128, h, w, dtype, dev, halo=1)
         a, b = F.view(0, 8), F.view(8, 8)
         h1a, h1b, h2a, h2b = H1.view(0, 8), H1.view(8, 8), H2.view(0, 8), H2.view(8, 8)
-        if os.environ.get("MMIF_PAIR_BWD", "1") != "0":   # dgrad + wgrad of each layer in one pass (csrc/pair.hip pairconv_bwd_kernel)
+        if switch("MMIF_PAIR_BWD"):   # dgrad + wgrad of each layer in one pass (csrc/pair.hip pairconv_bwd_kernel)
             T.pairconv_bwd(g, None, f2.w.detach(), 1, h2a, h2b, GH2.view(0, 8), GH2.view(8, 8), f2.dw, f2.db, ws, all_bits(8))
             g2 = GH2.fold_halo_()
             T.pairconv_bwd(g2.view(0, 8), g2.view(8, 8), f1.w.detach(), 2, h1a, h1b, GH1.view(0, 8), GH1.view(8, 8), f1.dw, f1.db, ws, all_bits(8))

@@ -54,6 +54,12 @@ def load_closed_form(module, seed):
     return module
 
 
+def reload_switches():
+    """the engine caches its $MMIF_... A/B switches: call after changing one at run time"""
+    from mmif import engine as E
+    E.reload_switches()
+
+
 class dtype_ctx:
     """with dtype_ctx('bf16', impl='mfma'): ... -- select the engine's storage dtype / kernel family."""
 
@@ -66,6 +72,7 @@ class dtype_ctx:
         self.prev_impl = os.environ.get("MMIF_CONV_IMPL")
         E.set_compute_dtype(self.dtype)
         os.environ["MMIF_CONV_IMPL"] = self.impl
+        E.reload_switches()
 
     def __exit__(self, *a):
         from mmif import engine as E
@@ -74,3 +81,4 @@ class dtype_ctx:
             os.environ.pop("MMIF_CONV_IMPL", None)
         else:
             os.environ["MMIF_CONV_IMPL"] = self.prev_impl
+        E.reload_switches()

@@ -72,6 +72,7 @@ def test_models_with_and_without_bwd_pair():
             res = []
             for flag in ("0", "1"):
                 os.environ["MMIF_BWD_PAIR"] = flag
+                __import__("mmif.engine").engine.reload_switches()
                 try:
                     m.zero_grad(set_to_none=True)
                     m(i1, i2).square().mean().backward()
@@ -79,6 +80,7 @@ def test_models_with_and_without_bwd_pair():
                     res.append({k: p.grad.clone() for k, p in m.named_parameters()})
                 finally:
                     os.environ.pop("MMIF_BWD_PAIR")
+                    __import__("mmif.engine").engine.reload_switches()
             # at this size the separate path folds decode.3's input gradient with the stand-alone kernel (halo values rounded to bf16
             # first), the fused kernel inside its border tiles: the gradients upstream differ by that rounding on the fold targets
             for k in res[0]:

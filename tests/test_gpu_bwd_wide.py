@@ -98,6 +98,7 @@ def test_models_with_and_without_bwd_wide():
             res = []
             for flag in ("0", "1"):
                 os.environ["MMIF_BWD_WIDE"] = flag
+                __import__("mmif.engine").engine.reload_switches()
                 try:
                     m.zero_grad(set_to_none=True)
                     m(i1, i2).square().mean().backward()
@@ -105,5 +106,6 @@ def test_models_with_and_without_bwd_wide():
                     res.append({k: p.grad.clone() for k, p in m.named_parameters()})
                 finally:
                     os.environ.pop("MMIF_BWD_WIDE", None)
+                    __import__("mmif.engine").engine.reload_switches()
             for k in res[0]:
                 assert torch.equal(res[0][k], res[1][k]), f"{name} {k}: the sign-byte path changed a gradient"

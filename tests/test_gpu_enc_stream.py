@@ -43,10 +43,12 @@ def test_stream_equals_layerwise_bit_for_bit(n, h, w):
         Fb.buf.fill_(7.0)
         br = [(eng.enc[0], i1, 0), (eng.enc[1], i2, 8)]
         os.environ["MMIF_ENC_STREAM"] = "0"
+        __import__("mmif.engine").engine.reload_switches()
         try:
             eng.enc_fwd_all(br, Fa, dtype, impl)
         finally:
             os.environ.pop("MMIF_ENC_STREAM")
+            __import__("mmif.engine").engine.reload_switches()
         eng.enc_fwd_all(br, Fb, dtype, impl)
         torch.cuda.synchronize()
         a, b = Fa.buf.view(torch.int16), Fb.buf.view(torch.int16)
@@ -95,6 +97,7 @@ def test_models_use_the_streaming_encoder_and_match_layerwise():
             res = []
             for flag in ("0", "1"):
                 os.environ["MMIF_ENC_STREAM"] = flag
+                __import__("mmif.engine").engine.reload_switches()
                 try:
                     T.PROFILE_TAGS.add("encode:fwd")
                     T.PROFILE_EVENTS.pop("encode:fwd", None)
@@ -106,6 +109,7 @@ def test_models_use_the_streaming_encoder_and_match_layerwise():
                     res.append((y.detach().clone(), [p.grad.clone() for p in m.parameters()], used))
                 finally:
                     os.environ.pop("MMIF_ENC_STREAM")
+                    __import__("mmif.engine").engine.reload_switches()
                     T.PROFILE_TAGS.discard("encode:fwd")
             assert res[0][2] == 0 and res[1][2] == 1, "the streaming launch must run exactly when enabled"
             assert torch.equal(res[0][0], res[1][0]), name
@@ -114,10 +118,13 @@ def test_models_use_the_streaming_encoder_and_match_layerwise():
             if name == "DenseFuse":
                 with torch.no_grad():
                     os.environ["MMIF_ENC_STREAM"] = "0"
+                    __import__("mmif.engine").engine.reload_switches()
                     y0 = m(i1)
                     os.environ["MMIF_ENC_STREAM"] = "1"
+                    __import__("mmif.engine").engine.reload_switches()
                     y1 = m(i1)
                     os.environ.pop("MMIF_ENC_STREAM")
+                    __import__("mmif.engine").engine.reload_switches()
                 assert torch.equal(y0, y1)
 
 
@@ -141,10 +148,12 @@ def test_stream_geometry_fuzz():
             Fa, Fb = T.BT.alloc(n, 128, h, w, dtype, DEV), T.BT.alloc(n, 128, h, w, dtype, DEV)
             br = [(eng.enc[0], i1, 0), (eng.enc[1], i2, 8)]
             os.environ["MMIF_ENC_STREAM"] = "0"
+            __import__("mmif.engine").engine.reload_switches()
             try:
                 eng.enc_fwd_all(br, Fa, dtype, impl)
             finally:
                 os.environ.pop("MMIF_ENC_STREAM")
+                __import__("mmif.engine").engine.reload_switches()
             eng.enc_fwd_all(br, Fb, dtype, impl)
             torch.cuda.synchronize()
             assert torch.equal(Fa.buf.view(torch.int16), Fb.buf.view(torch.int16)), (n, h, w)

@@ -113,7 +113,9 @@ def test_models_train_step_with_fused_wgrad_matches_layerwise():
             res = []
             for flag in ("0", "1"):
                 os.environ["MMIF_ENC_WGRAD"] = flag
+                __import__("mmif.engine").engine.reload_switches()
                 os.environ["MMIF_ENC_CHAIN"] = "0"      # same gradient chain in both runs: only the weight-gradient kernels differ
+                __import__("mmif.engine").engine.reload_switches()
                 try:
                     m.zero_grad(set_to_none=True)
                     m(i1, i2).square().mean().backward()
@@ -121,7 +123,9 @@ def test_models_train_step_with_fused_wgrad_matches_layerwise():
                     res.append({k: p.grad.clone() for k, p in m.named_parameters()})
                 finally:
                     os.environ.pop("MMIF_ENC_WGRAD")
+                    __import__("mmif.engine").engine.reload_switches()
                     os.environ.pop("MMIF_ENC_CHAIN")
+                    __import__("mmif.engine").engine.reload_switches()
             for k in res[0]:
                 a, b = res[0][k].double(), res[1][k].double()
                 if "encode" not in k:
@@ -153,11 +157,13 @@ def test_gather_form_dgrad_chain_vs_definition_and_scatter_form():
             for mode in ("1", "0"):
                 GF = T.BT.from_nchw(G, torch.bfloat16, halo=1).as_folded()
                 os.environ["MMIF_ENC_CHAIN"] = mode
+                __import__("mmif.engine").engine.reload_switches()
                 try:
                     eng._assign_grad_views(torch.device(DEV))
                     eng.enc_bwd(specs, img, F, GF, 0, 0, eng.workspace(torch.device(DEV)), impl)
                 finally:
                     os.environ.pop("MMIF_ENC_CHAIN")
+                    __import__("mmif.engine").engine.reload_switches()
                 torch.cuda.synchronize()
                 assert float(GF.buf[:, :, 0].float().abs().max()) == 0.0 and float(GF.buf[:, :, :, 0].float().abs().max()) == 0.0   # ring stays zero
                 res[mode] = GF.to_nchw(64).double().cpu()
@@ -272,6 +278,7 @@ def test_densefuse_shared_fused_gradient_is_bit_identical():
             res = []
             for flag in ("0", "1"):
                 os.environ["MMIF_FUSE_SHARE"] = flag
+                __import__("mmif.engine").engine.reload_switches()
                 try:
                     m.zero_grad(set_to_none=True)
                     m(i1, i2).square().mean().backward()
@@ -279,5 +286,6 @@ def test_densefuse_shared_fused_gradient_is_bit_identical():
                     res.append({k: p.grad.clone() for k, p in m.named_parameters()})
                 finally:
                     os.environ.pop("MMIF_FUSE_SHARE", None)
+                    __import__("mmif.engine").engine.reload_switches()
             for k in res[0]:
                 assert torch.equal(res[0][k], res[1][k]), f"{shape} {k}"

@@ -189,10 +189,12 @@ def test_encoder_round2_kernels_at_full_size():
         Fa, Fb = T.BT.alloc(B, 128, S, S, dtype, dev), T.BT.alloc(B, 128, S, S, dtype, dev)
         br = [(eng.enc[0], i1, 0), (eng.enc[1], i2, 8)]
         os.environ["MMIF_ENC_STREAM"] = "0"
+        __import__("mmif.engine").engine.reload_switches()
         try:
             eng.enc_fwd_all(br, Fa, dtype, impl)
         finally:
             os.environ.pop("MMIF_ENC_STREAM")
+            __import__("mmif.engine").engine.reload_switches()
         eng.enc_fwd_all(br, Fb, dtype, impl)
         torch.cuda.synchronize()
         assert torch.equal(Fa.buf.view(torch.int16), Fb.buf.view(torch.int16))
@@ -221,11 +223,13 @@ def test_encoder_round2_kernels_at_full_size():
             GF = T.BT.alloc(B, 64, S, S, dtype, dev, halo=1, zero=True)
             GF.buf.copy_(G.buf)
             os.environ["MMIF_ENC_CHAIN"] = mode
+            __import__("mmif.engine").engine.reload_switches()
             try:
                 eng._assign_grad_views(dev)
                 eng.enc_bwd(eng.enc[0], i1, Fb, GF.as_folded(), 0, 0, ws, impl)
             finally:
                 os.environ.pop("MMIF_ENC_CHAIN")
+                __import__("mmif.engine").engine.reload_switches()
             torch.cuda.synchronize()
             assert float(GF.buf[:, :, 0].float().abs().max()) == 0.0       # the halo ring stays zero (folded convention)
             res[mode] = GF.buf.float()
@@ -322,6 +326,7 @@ def test_pfnetv2_pair_kernels_at_full_size():
         outs = {}
         for mode in ("1", "0"):
             os.environ["MMIF_PAIR_STRIP"] = mode
+            __import__("mmif.engine").engine.reload_switches()
             try:
                 Y = T.BT.alloc(n, 2 * ch, h, w, torch.bfloat16, dev, zero=True)
                 T.pairconv_fwd(a, b, wgt, bias, 2, Y.view(0, cb), Y.view(cb, cb), True)
@@ -329,6 +334,7 @@ def test_pfnetv2_pair_kernels_at_full_size():
                 outs[mode] = Y.buf.view(torch.int16).clone()
             finally:
                 os.environ.pop("MMIF_PAIR_STRIP", None)
+                __import__("mmif.engine").engine.reload_switches()
         assert torch.equal(outs["1"], outs["0"]) and float(outs["0"].float().abs().max()) > 0
         ws = torch.empty(T.pairconv_wgrad_workspace_bytes() // 4, dtype=torch.float32, device=dev)
         GA = T.BT.alloc(n, 2 * ch, h, w, torch.bfloat16, dev, halo=1, zero=True)

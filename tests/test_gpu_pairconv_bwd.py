@@ -63,6 +63,7 @@ def test_pfnetv2_trains_the_same_with_and_without_the_fused_pass():
     res = {}
     for mode in ("1", "0"):
         os.environ["MMIF_PAIR_BWD"] = mode
+        __import__("mmif.engine").engine.reload_switches()
         try:
             with dtype_ctx("bf16"):
                 m = load_closed_form(M.PFNetv2(), 3).to(DEV)
@@ -74,6 +75,7 @@ def test_pfnetv2_trains_the_same_with_and_without_the_fused_pass():
                 res[mode] = (out.detach().float().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters()})
         finally:
             os.environ.pop("MMIF_PAIR_BWD", None)
+            __import__("mmif.engine").engine.reload_switches()
     assert torch.equal(res["1"][0], res["0"][0])
     for k, ga in res["1"][1].items():
         gb = res["0"][1][k]
@@ -103,6 +105,7 @@ def test_pairconv_fwd_strip_kernel_is_bit_identical(nout, relu, res, n, h, w):
         outs = {}
         for mode in ("1", "0"):
             os.environ["MMIF_PAIR_STRIP"] = mode
+            __import__("mmif.engine").engine.reload_switches()
             try:
                 O = T.BT.alloc(n, 2 * ch, h, w, torch.bfloat16, DEV, zero=True)
                 r1, r2 = {None: (None, None), "operands": (a, b), "other": (b, a)}[res]   # "operands": taken from the LDS windows
@@ -111,6 +114,7 @@ def test_pairconv_fwd_strip_kernel_is_bit_identical(nout, relu, res, n, h, w):
                 outs[mode] = O.buf.view(torch.int16).clone()
             finally:
                 os.environ.pop("MMIF_PAIR_STRIP", None)
+                __import__("mmif.engine").engine.reload_switches()
         assert float(outs["0"].float().abs().max()) > 0
         if not torch.equal(outs["1"], outs["0"]):
             d = (outs["1"] != outs["0"]).nonzero()

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""profiles/r03_traffic.json from the two TCC counter passes of tools/prof_pmc.sh (run on the GPU box, repo root):
+    tools/make_traffic.py <tag> > gpurun_out/traffic_<tag>.json
+HBM bytes per launch of the two roofline kernels of the default bench (PFNetv1 train B=32 256x256 bf16): decode.0's forward
+(conv_dma_kernel<false, 0>: decode.0 and decode.1 alternate per step; decode.0 is the launch with the larger WRITE_SIZE) and the streaming
+encoder forward.  gfx950: FETCH_SIZE tallies the 128-byte requests of 16-byte-per-lane streaming reads as 64 bytes (MI355X_MICROARCH.md,
+HBM section) -> read bytes = 2 x FETCH_SIZE; WRITE_SIZE as counted.  The file is stamped with the sha256 of the library the passes ran
+on: bench.py prints `traffic` only for that build."""
+import csv, glob, hashlib, json, os, sys
+from collections import defaultdict
+
+tag = sys.argv[1]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def per_dispatch(counter, sub):
+    path = glob.glob(os.path.join(ROOT, "gpurun_out", f"pmc_{tag}_{counter}", "**", "*counter_collection.csv"), recursive=True)[0]
+    vals = defaultdict(float)
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if sub in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                vals[int(r["Dispatch_Id"])] += float(r["Counter_Value"])
+    return [vals[k] for k in sorted(vals)]
+
+
+def entry(name, fetch, write, algo, note=""):
+    f, w = sum(fetch) / len(fetch), sum(write) / len(write)
+    return {"kernel": name, "launches": len(fetch), "FETCH_SIZE_KB_raw": f, "WRITE_SIZE_KB_raw": w,
+            "correction": "read bytes = 2 x FETCH_SIZE (gfx950 counts 128-B requests of 16-B/lane streaming reads as 64 B), write bytes = WRITE_SIZE" + note,
+            "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0, "algorithmic_bytes_per_launch": algo}
+
+
+h = hashlib.sha256(open(os.path.join(ROOT, "multi-modal-image-fusion_amd", "libmmif_hip.so"), "rb").read()).hexdigest()
+fd, wd = per_dispatch("FETCH_SIZE", "conv_dma_kernel<false"), per_dispatch("WRITE_SIZE", "conv_dma_kernel<false")
+# decode.0 / decode.1 alternate; decode.0 writes 128 channels, decode.1 64
+w_even, w_odd = wd[0::2], wd[1::2]
+first_is_d0 = sum(w_even) >= sum(w_odd)
+f0, w0 = (fd[0::2], w_even) if first_is_d0 else (fd[1::2], w_odd)
+fe, we = per_dispatch("FETCH_SIZE", "enc_stream_fwd_kernel"), per_dispatch("WRITE_SIZE", "enc_stream_fwd_kernel")
+B, S = 32, 256
+out = {"workload": "PFNetv1 train B=32 256x256 bf16", "lib_sha256": h,
+       "command": f"tools/prof_pmc.sh {tag}: rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separately, WRITE_SIZE) --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline",
+       "kernels": {
+           "decode.0:fwd": entry("conv_dma_kernel<false, 0> 128->128 k3 (decode.0 forward)", f0, w0, float(B) * S * S * 256 * 2),
+           "encode:fwd": entry("enc_stream_fwd_kernel, both encoder branches", fe, we, float(B) * S * S * 2 * (4 + 64 * 2),
+                               "; the image loads are 4 B/lane (uncalibrated width): counted like the 16-B reads, an upper bound"),
+       }}
+print(json.dumps(out, indent=1))

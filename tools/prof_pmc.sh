@@ -13,5 +13,6 @@ for c in FETCH_SIZE WRITE_SIZE; do
   python3 tools/pmc_per_dispatch.py $csv "conv_dma_kernel<false" > gpurun_out/pmc_${tag}_${c}_decode_fwd.txt
   python3 tools/pmc_per_dispatch.py $csv "enc_stream_fwd_kernel" > gpurun_out/pmc_${tag}_${c}_enc_stream.txt
   head -12 gpurun_out/pmc_${tag}_$c.txt
-  find gpurun_out/pmc_${tag}_$c -name "*.csv" -size +1M -delete
+  python3 tools/make_traffic.py ${tag} > gpurun_out/${tag}_traffic.json 2>/dev/null || true
 done
+find gpurun_out/pmc_${tag}_FETCH_SIZE gpurun_out/pmc_${tag}_WRITE_SIZE -name "*.csv" -size +1M -delete
