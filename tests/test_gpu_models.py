@@ -252,7 +252,7 @@ def test_nestfuse_bf16_mfma_runs_close():
         close(y.cpu().numpy(), y_or, 5e-2, "imgf")
 
 
-@pytest.mark.parametrize("impl,gtol", [("valu", 1e-3), ("auto", 1e-2)], ids=["fp32-fma", "x3"])
+@pytest.mark.parametrize("impl,gtol", [("valu", 1e-3), ("auto", 6e-2)], ids=["fp32-fma", "x3"])
 @pytest.mark.parametrize("name", ["NestFuse", "RFNNest"])
 def test_nest_engine_odd_size_vs_oracle(name, impl, gtol):
     """Odd pyramid sizes (36x44 -> 18x22 -> 9x11 -> 4x5): the up-sampled 8x10 map is reflect-padded to 9x11
@@ -260,8 +260,10 @@ def test_nest_engine_odd_size_vs_oracle(name, impl, gtol):
     kernels and on the split-bf16 matrix-pipe kernels (the 1x1 layers are fp32 FMA in both).  The gradient bar is the flip-noise floor of
     this small case -- the pyramid ends in 4 x 5 maps, where max-pool winners and ReLU signs decided on near ties move a gradient by
     percents whichever fp32-grade forward made the decision (the x3 and the FMA kernels, whose activations agree to 1e-6, differ by up
-    to 3e-2 on CB3_0's gradients here): 1e-3 held by the FMA kernels, whose summation order is the oracle's; <= 5.6e-3 measured on the
-    x3 kernels, held to 1e-2.  The fused image is held to 2e-4 on both."""
+    to 3e-2 on CB3_0's gradients here, and the numpy oracle's own BLAS summation order changes with the host's core count): 1e-3 held by
+    the FMA kernels; 5.6e-3 ... 3.1e-2 measured on the x3 kernels on different boxes, held to 6e-2 -- a smoke bound; what pins the x3
+    path is the fused image (2e-4 here, on both), the per-kernel tests at 3e-5 / 2e-6 (tests/test_gpu_x3.py) and the goldens of the
+    models without pooling."""
     shape = (2, 1, 36, 44)
     om = O.MODELS[name]()
     P = om.init_params(seed=3)
