@@ -132,15 +132,15 @@ constexpr int X3_BIAS_G = 128;   // granules reserved behind the tiles for the b
 // kernels (profiles/r03_pmc_sq_x3.txt): the matrix pipe is busy 58 % (2 pieces) / 74 % (3 pieces) of the cycles, i.e. a constant
 // ~5 k cycles per 16 input channels of split + LDS-write + issue work that no barrier arrangement removes, at 1.7-1.8 GHz (the chip
 // clocks dense MFMA work down: the 2.5 PFLOP/s peak assumes 2.4 GHz).
-template <int MB, bool DGRAD, int NP, int NW>
+template <int MB, bool DGRAD, int NP, int NW, int RJ>
 __global__ __launch_bounds__(64 * NW, 2) void conv_x3_kernel(TV tin, TV tout, TV tmask, const uint4* __restrict__ wpk,
                                                               const float* __restrict__ bias, int n_out, int nch16, int nmb, int relu,
                                                               unsigned long long mask_bits, unsigned long long accum_bits, int tiles_x,
                                                               int tiles_per_img, int total_tiles) {
     constexpr int MBW = 32 * MB;
     constexpr int WG = 9 * 2 * MBW;               // weight granules of one piece of a 16-channel sub-chunk
-    constexpr int X3_THREADS = 64 * NW, X3_TH = 2 * NW, X3_IH = X3_TH + 2;
-    constexpr int CKB = (NP == 2 && NW == 8) ? 4 : 2;   // channel blocks per LDS chunk
+    constexpr int X3_THREADS = 64 * NW, X3_TH = RJ * NW, X3_IH = X3_TH + 2;   // a wave owns RJ rows of the tile
+    constexpr int CKB = (NP == 2 && NW == 8 && RJ == 2) ? 4 : 2;   // channel blocks per LDS chunk
     constexpr int KK = CKB / 2;                   // 16-channel sub-chunks (MFMA k-steps per tap) per chunk
     constexpr int PL = X3_IH * X3_IW;             // granules of one channel-block plane of the input tile: 612
     constexpr int ING = CKB * PL;                 // input granules per piece
@@ -231,16 +231,16 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_x3_kernel(TV tin, TV tout, TV
         }
     };
 
-    f32x16 acc[MB][2];
+    f32x16 acc[MB][RJ];
 #pragma unroll
     for (int m = 0; m < MB; ++m)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < RJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.f;
 
     const int cbl = lane >> 5, nl = lane & 31;
-    const int bbase = (cbl * X3_IH + 2 * wave) * X3_IW + nl;   // + kk * 2 * PL + row * X3_IW + v   (+ piece * ING)
+    const int bbase = (cbl * X3_IH + RJ * wave) * X3_IW + nl;   // + kk * 2 * PL + row * X3_IW + v   (+ piece * ING)
     const int abase = cbl * MBW + nl;                           // + kk * NP * WG + piece * WG + tap * 2 * MBW + m * 32
 
     issue(0);
@@ -256,8 +256,8 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_x3_kernel(TV tin, TV tout, TV
             if (kk < nkk) {
                 const x3_u4* s_in = s_buf + kk * 2 * PL;
                 const x3_u4* s_w = s_buf + NP * ING + kk * NP * WG;
-                x3_bf16x8 brow[4][NP], afr[2][MB][NP];
-                // taps in column-major order t = 3 v + u: tap (u, v) reads tile rows u, u+1 of the wave's 4-row window at column shift v
+                x3_bf16x8 brow[RJ + 2][NP], afr[2][MB][NP];
+                // taps in column-major order t = 3 v + u: tap (u, v) reads rows u .. u+RJ-1 of the wave's (RJ+2)-row window at column shift v
                 auto ld_a = [&](int t, int slot) {
                     const int v = t / 3, u = t % 3, tap = u * 3 + v;
 #pragma unroll
@@ -270,32 +270,44 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_x3_kernel(TV tin, TV tout, TV
                     for (int p = 0; p < NP; ++p) brow[row][p] = x3_frag(s_in[p * ING + bbase + row * X3_IW + v]);
                 };
                 ld_a(0, 0);
-                ld_b(0, 0);
-                ld_b(1, 0);
+#pragma unroll
+                for (int r = 0; r < RJ; ++r) ld_b(r, 0);
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
                     const int u = t % 3;
                     int nld = 0;
+                    // RJ > 2: rows 2 .. RJ-1 of a new column cannot be fetched during the previous tap (it still reads them at the old
+                    // column shift): they are fetched here and consumed by the SECOND half of this tap's MFMAs (rows j >= 2)
+                    if (RJ > 2 && u == 0 && t > 0) {
+#pragma unroll
+                        for (int r = 2; r < RJ; ++r) ld_b(r, t / 3);
+                        nld += (RJ - 2) * NP;
+                    }
                     if (t + 1 < 9) {
                         const int v1 = (t + 1) / 3, u1 = (t + 1) % 3;
                         ld_a(t + 1, (t + 1) & 1);
                         nld += MB * NP;
-                        if (u1 == 0) { ld_b(0, v1); ld_b(1, v1); nld += 2 * NP; }
-                        else { ld_b(u1 + 1, v1); nld += NP; }
+                        if (u1 == 0) {   // rows 0, 1 of the next column are dead from this tap (u = 2) on
+#pragma unroll
+                            for (int r = 0; r < 2; ++r) ld_b(r, v1);
+                            nld += 2 * NP;
+                        } else { ld_b(u1 + RJ - 1, v1); nld += NP; }
                     }
 #pragma unroll
-                    for (int q = 0; q < NPROD; ++q)
+                    for (int j0 = 0; j0 < RJ; j0 += 2)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j)
+                        for (int q = 0; q < NPROD; ++q)
 #pragma unroll
-                            for (int m = 0; m < MB; ++m)
-                                acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[t & 1][m][X3Prod<NP>::A[q]], brow[u + j][X3Prod<NP>::B[q]], acc[m][j], 0, 0, 0);
+                            for (int j = j0; j < j0 + 2; ++j)
+#pragma unroll
+                                for (int m = 0; m < MB; ++m)
+                                    acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[t & 1][m][X3Prod<NP>::A[q]], brow[u + j][X3Prod<NP>::B[q]], acc[m][j], 0, 0, 0);
                     // the prefetch reads ride between this tap's first MFMAs
                     for (int i = 0; i < nld; ++i) {
                         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
                     }
-                    for (int i = nld; i < NPROD * 2 * MB; ++i) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    for (int i = nld; i < NPROD * RJ * MB; ++i) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 }
             }
         }
@@ -307,8 +319,8 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_x3_kernel(TV tin, TV tout, TV
             const int ys0 = (tt / tiles_x) * X3_TH, xs0 = (tt % tiles_x) * X3_TW;
             const int xs = xs0 + nl, half = lane >> 5;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int ys = ys0 + 2 * wave + j;
+            for (int j = 0; j < RJ; ++j) {
+                const int ys = ys0 + RJ * wave + j;
                 const bool inside = ys < tout.hs && xs < tout.ws;
                 const int oy = DGRAD ? min(max(reflect_idx(ys - tout.halo, tmask.h), 0), tmask.h - 1) : 0;
                 const int ox = DGRAD ? min(max(reflect_idx(xs - tout.halo, tmask.w), 0), tmask.w - 1) : 0;
@@ -373,19 +385,26 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_x3_kernel(TV tin, TV tout, TV
 }
 
 // ------------------------------------------------------------------ wgrad
-constexpr int XW_TH = 8, XW_TW = 16;             // pixel tile (rows x columns) = 8 k-steps of 16 pixels
-constexpr int XW_XH = XW_TH + 2, XW_XW = XW_TW + 2;
-constexpr int XW_XPL = XW_XH * XW_XW;            // 180 granules per x plane  (= 4 mod 16: the four planes a half wave's transposing read touches
-constexpr int XW_GPL = XW_TH * XW_TW + 4;        // 132 granules per g plane      fall on disjoint bank quarters)
-constexpr int XW_XG = 8 * XW_XPL, XW_GG = 8 * XW_GPL;          // one precision half of the x / g tile (8 channel blocks each)
-constexpr int XW_BUF_G = 2 * XW_XG + 2 * XW_GG;                // [x hi][x lo][g hi][g lo] = 4992 granules
+constexpr int XW_TW = 16;                        // pixel-tile columns = the 16 pixels of one k-step
+constexpr int XW_XW = XW_TW + 2;
 constexpr int XW_THREADS = 768;
-constexpr int XW_NX = 8 * XW_XH * XW_XW, XW_NG = 8 * XW_TH * XW_TW;   // staged elements: 1440 + 1024
-constexpr int XW_ROUNDS = (XW_NX + XW_NG + XW_THREADS - 1) / XW_THREADS;   // 4
 constexpr int XW_PER = 64 * 64 * 9 + 64;         // floats per block partial: dW[64 oc][64 ic][9], db[64]
 
+// TH x 16 pixel tiles, NXC / NGC channel blocks of the activation / gradient group kept in LDS.  <8, 8, 8>: the general 64 x 64 channel
+// pair.  <16, 6, 2>: layers with <= 48 input and <= 16 output channels (the DenseBlock convs, decode.3) -- the same LDS and staging
+// budget spent on TWICE the pixels per tile: those layers run one tile per ~3 us of global-load latency whatever the tile holds
+// (0.18-0.30 ms per launch with almost no MFMA work), so half the tiles is half the time.  Channel blocks past NXC / NGC are read
+// from the last plane kept (those dW rows / columns belong to channels the layer does not have and are never reduced).
+template <int TH, int NXC, int NGC>
 __global__ __launch_bounds__(XW_THREADS) void wgrad_x3_kernel(TV tx, TV tg, float* __restrict__ partial, int cin, int cout, int tiles_x, int tpi,
                                                                int total, int G, int n_icg, int n_ocg) {
+    constexpr int XW_TH = TH, XW_XH = TH + 2;
+    constexpr int XW_XPL = XW_XH * XW_XW;            // 180 / 324 granules per x plane (= 4 mod 16: the four planes a half wave's transposing
+    constexpr int XW_GPL = XW_TH * XW_TW + 4;        // 132 / 260 granules per g plane    read touches fall on disjoint bank quarters)
+    constexpr int XW_XG = NXC * XW_XPL, XW_GG = NGC * XW_GPL;      // one precision half of the x / g tile
+    constexpr int XW_BUF_G = 2 * XW_XG + 2 * XW_GG;                // [x hi][x lo][g hi][g lo]: 4992 / 4928 granules
+    constexpr int XW_ROUNDS = (NXC * XW_XH * XW_XW + NGC * XW_TH * XW_TW + XW_THREADS - 1) / XW_THREADS;   // 4
+    static_assert(2 * XW_BUF_G * 16 <= 160 * 1024, "two tile buffers must fit the LDS");
     __shared__ __attribute__((aligned(16))) x3_u4 s_buf[2 * XW_BUF_G];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -407,7 +426,7 @@ __global__ __launch_bounds__(XW_THREADS) void wgrad_x3_kernel(TV tx, TV tg, floa
     const bool want_db = (v == 0 && jt == 0 && icg == 0 && ocg * 64 + mt * 32 < cout);
 
     // channel blocks this block's groups really have: only those are staged (the planes of the others stay zero from here on)
-    const int nxcb = min(8, tx.cb - icg * 8), ngcb = min(8, tg.cb - ocg * 8);
+    const int nxcb = min(NXC, tx.cb - icg * 8), ngcb = min(NGC, tg.cb - ocg * 8);
     const int n_x = nxcb * (XW_XH * XW_XW), n_all = n_x + ngcb * (XW_TH * XW_TW);
     for (int i = tid; i < 2 * XW_BUF_G; i += XW_THREADS) s_buf[i] = (x3_u4){0u, 0u, 0u, 0u};
     unsigned geo[XW_ROUNDS];   // tile independent: is-g << 24 | channel block << 16 | tile row << 8 | tile column
@@ -523,8 +542,8 @@ __global__ __launch_bounds__(XW_THREADS) void wgrad_x3_kernel(TV tx, TV tg, floa
                 const x3_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(X3_LDS_PTR(x3_s16x4, base + 4 * 16));
                 return __builtin_bit_cast(x3_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
             };
-            const int goff = (((mt * 4 + lane_cb) * XW_GPL) + lane_px) * 16 + lane_byte;          // + ry * XW_TW * 16
-            const int xoff = (((jt * 4 + lane_cb) * XW_XPL) + lane_px + v) * 16 + lane_byte;      // + row * XW_XW * 16
+            const int goff = ((min(mt * 4 + lane_cb, NGC - 1) * XW_GPL) + lane_px) * 16 + lane_byte;          // + ry * XW_TW * 16
+            const int xoff = ((min(jt * 4 + lane_cb, NXC - 1) * XW_XPL) + lane_px + v) * 16 + lane_byte;      // + row * XW_XW * 16
             // activation rows ry, ry + 1, ry + 2 live in a three-slot register ring (slot = row % 3): ONE new row per k-step
             x3_bf16x8 xh[3], xl[3];
 #pragma unroll
@@ -696,20 +715,20 @@ int conv_x3_pack_multi(const mmif_pack_job* jobs, int n_jobs, hipStream_t st) {
     return flush();
 }
 
-template <int MB, int NP, int NW>
+template <int MB, int NP, int NW, int RJ>
 static int launch_conv_x3(bool dgrad, const TV& tin, const TV& tout, const TV& tmask, const void* wpk, const float* bias, int n_out, int n_in,
                           int relu, uint64_t mask_bits, uint64_t accum_bits, hipStream_t st) {
-    const int tiles_x = cdiv(tout.ws, X3_TW), tiles_y = cdiv(tout.hs, 2 * NW);
+    const int tiles_x = cdiv(tout.ws, X3_TW), tiles_y = cdiv(tout.hs, RJ * NW);
     const int tpi = tiles_x * tiles_y, total = tpi * tout.n;
     int G = x3_num_cus() * (NW == 4 ? 2 : 1);
     if (total < G) G = total;
     const int nch = x3_nch(n_in), nmb = x3_nmb(n_out);
     constexpr int X3_THREADS = 64 * NW;
     if (dgrad)
-        hipLaunchKernelGGL((conv_x3_kernel<MB, true, NP, NW>), dim3(G), dim3(X3_THREADS), 0, st, tin, tout, tmask, (const uint4*)wpk, bias, n_out, nch, nmb,
+        hipLaunchKernelGGL((conv_x3_kernel<MB, true, NP, NW, RJ>), dim3(G), dim3(X3_THREADS), 0, st, tin, tout, tmask, (const uint4*)wpk, bias, n_out, nch, nmb,
                            relu, (unsigned long long)mask_bits, (unsigned long long)accum_bits, tiles_x, tpi, total);
     else
-        hipLaunchKernelGGL((conv_x3_kernel<MB, false, NP, NW>), dim3(G), dim3(X3_THREADS), 0, st, tin, tout, tmask, (const uint4*)wpk, bias, n_out, nch, nmb,
+        hipLaunchKernelGGL((conv_x3_kernel<MB, false, NP, NW, RJ>), dim3(G), dim3(X3_THREADS), 0, st, tin, tout, tmask, (const uint4*)wpk, bias, n_out, nch, nmb,
                            relu, (unsigned long long)mask_bits, (unsigned long long)accum_bits, tiles_x, tpi, total);
     return check_launch(dgrad ? "conv_x3 dgrad" : "conv_x3 fwd");
 }
@@ -720,10 +739,15 @@ int conv_x3(bool dgrad, const TV& tin, const TV& tout, const TV& tmask, const vo
     const int n_out = dgrad ? cin : cout, n_in = dgrad ? cout : cin;
     const bool six = !dgrad && x3_fwd_pieces() == 3;
     if (x3_mb(n_out) == 2)
-        return six ? launch_conv_x3<2, 3, 8>(false, tin, tout, tmask, wpk, bias, n_out, n_in, relu, mask_bits, accum_bits, st)
-                   : launch_conv_x3<2, 2, 8>(dgrad, tin, tout, tmask, wpk, bias, n_out, n_in, relu, mask_bits, accum_bits, st);
-    return six ? launch_conv_x3<1, 3, 8>(false, tin, tout, tmask, wpk, bias, n_out, n_in, relu, mask_bits, accum_bits, st)
-               : launch_conv_x3<1, 2, 8>(dgrad, tin, tout, tmask, wpk, bias, n_out, n_in, relu, mask_bits, accum_bits, st);
+        return six ? launch_conv_x3<2, 3, 8, 2>(false, tin, tout, tmask, wpk, bias, n_out, n_in, relu, mask_bits, accum_bits, st)
+                   : launch_conv_x3<2, 2, 8, 2>(dgrad, tin, tout, tmask, wpk, bias, n_out, n_in, relu, mask_bits, accum_bits, st);
+    // <= 32 output channels: one 32-channel accumulator tile per pixel row, so a wave takes FOUR rows (32 x 32 pixel tiles) in the
+    // 3-piece forward: the same 216 MFMAs per wave and barrier as the 64-channel kernels for half the weight staging ($MMIF_X3_RJ4=0: two)
+    static int rj4 = -1;
+    if (rj4 < 0) { const char* e = getenv("MMIF_X3_RJ4"); rj4 = (e != nullptr && e[0] == '0') ? 0 : 1; }
+    if (six) return rj4 ? launch_conv_x3<1, 3, 8, 4>(false, tin, tout, tmask, wpk, bias, n_out, n_in, relu, mask_bits, accum_bits, st)
+                        : launch_conv_x3<1, 3, 8, 2>(false, tin, tout, tmask, wpk, bias, n_out, n_in, relu, mask_bits, accum_bits, st);
+    return launch_conv_x3<1, 2, 8, 2>(dgrad, tin, tout, tmask, wpk, bias, n_out, n_in, relu, mask_bits, accum_bits, st);
 }
 
 bool wgrad_x3_supported(int ks, int cin, int cout, const TV& tx, const TV& tg) {
@@ -748,12 +772,17 @@ size_t wgrad_x3_workspace(int cin, int cout, int ks) {
 }
 
 int wgrad_x3(const TV& tx, const TV& tg, float* dw, float* db, int cin, int cout, int accumulate, float* ws, hipStream_t st) {
-    const int tiles_x = cdiv(tx.w, XW_TW), tiles_y = cdiv(tx.h, XW_TH);
+    const bool thin = cin <= 48 && cout <= 16;
+    const int th = thin ? 16 : 8;
+    const int tiles_x = cdiv(tx.w, XW_TW), tiles_y = cdiv(tx.h, th);
     const int tpi = tiles_x * tiles_y, total = tpi * tx.n;
     const int n_icg = cdiv(cin, 64), n_ocg = cdiv(cout, 64);
     int G = wgrad_x3_G(cin, cout);
     if (total < G) G = total;
-    hipLaunchKernelGGL(wgrad_x3_kernel, dim3(G * n_icg * n_ocg), dim3(XW_THREADS), 0, st, tx, tg, ws, cin, cout, tiles_x, tpi, total, G, n_icg, n_ocg);
+    if (thin)
+        hipLaunchKernelGGL((wgrad_x3_kernel<16, 6, 2>), dim3(G * n_icg * n_ocg), dim3(XW_THREADS), 0, st, tx, tg, ws, cin, cout, tiles_x, tpi, total, G, n_icg, n_ocg);
+    else
+        hipLaunchKernelGGL((wgrad_x3_kernel<8, 8, 8>), dim3(G * n_icg * n_ocg), dim3(XW_THREADS), 0, st, tx, tg, ws, cin, cout, tiles_x, tpi, total, G, n_icg, n_ocg);
     if (int rc = check_launch("wgrad_x3")) return rc;
     const int n = cout * cin * 9 + cout;
     hipLaunchKernelGGL(wgrad_x3_reduce, dim3(cdiv(n, 64)), dim3(256), 0, st, ws, dw, db, cin, cout, G, n_icg, n_ocg, accumulate);
