@@ -154,6 +154,11 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_x3_kernel(TV tin, TV tout, TV
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const TileWalk tw = xcd_walk(total_tiles, gridDim.x, blockIdx.x);
+    // timing ablations ($MMIF_X3_ABLATE, results are garbage), each after the first step: 1 no input loads (NB: the tile is then all
+    // zeros and the chip clocks zero-operand MFMAs ~25 % higher -- that run measures DVFS, not the loads), 2 no weight loads, 4 no split +
+    // LDS writes, 8 no MFMAs.  decode.0 forward, 6 products: 2.82 ms; 2: 2.76; 4: 2.65; 8: 0.86 (all staging + epilogue); 1: 2.09.
+    const int abl = relu >> 8;
+    relu &= 255;
     const int nch = (nch16 + KK - 1) / KK;        // LDS chunks per item
     const int per_tile = nch * nmb;
     const int nsteps = tw.count * per_tile;
@@ -174,6 +179,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_x3_kernel(TV tin, TV tout, TV
     }
 
     // item of step s: tile ti = s / per_tile, m-block mb = (s / nch) % nmb, chunk c = s % nch
+    bool done_first = false;
     X3Gran rin[IN_ROUNDS];
     x3_u4 rw[W_ROUNDS];
 
@@ -199,7 +205,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_x3_kernel(TV tin, TV tout, TV
                 y = min(max(reflect_idx(y, tin.h), 0), tin.h - 1);
                 x = min(max(reflect_idx(x, tin.w), 0), tin.w - 1);
             }
-            if (ok) {
+            if (ok && !((abl & 1) && s > 0)) {
                 const x3_f4* p = reinterpret_cast<const x3_f4*>(base + ((unsigned)cb * (unsigned)tin.plane + (unsigned)(y * tin.ws + x)) * 32u);   // (32-bit: x3_small)
                 rin[k].a = p[0];
                 rin[k].b = p[1];
@@ -210,10 +216,11 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_x3_kernel(TV tin, TV tout, TV
 #pragma unroll
         for (int k = 0; k < W_ROUNDS; ++k) {
             const int e = tid + X3_THREADS * k;
-            if (e < nw) rw[k] = src[e];
+            if (e < nw && !((abl & 2) && s > 0)) rw[k] = src[e];
         }
     };
     auto commit = [&]() {
+        if (abl & 4) { if (done_first) return; done_first = true; }
 #pragma unroll
         for (int k = 0; k < IN_ROUNDS; ++k) {
             const int e = tid + X3_THREADS * k;
@@ -253,7 +260,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_x3_kernel(TV tin, TV tout, TV
         const int nkk = min(KK, nch16 - (s % nch) * KK);
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
-            if (kk < nkk) {
+            if (kk < nkk && !((abl & 8) && s > 0)) {
                 const x3_u4* s_in = s_buf + kk * 2 * PL;
                 const x3_u4* s_w = s_buf + NP * ING + kk * NP * WG;
                 x3_bf16x8 brow[RJ + 2][NP], afr[2][MB][NP];
@@ -724,6 +731,9 @@ static int launch_conv_x3(bool dgrad, const TV& tin, const TV& tout, const TV& t
     if (total < G) G = total;
     const int nch = x3_nch(n_in), nmb = x3_nmb(n_out);
     constexpr int X3_THREADS = 64 * NW;
+    static int abl = -1;
+    if (abl < 0) { const char* e = getenv("MMIF_X3_ABLATE"); abl = e != nullptr ? atoi(e) : 0; }
+    relu = (relu & 255) | (abl << 8);
     if (dgrad)
         hipLaunchKernelGGL((conv_x3_kernel<MB, true, NP, NW, RJ>), dim3(G), dim3(X3_THREADS), 0, st, tin, tout, tmask, (const uint4*)wpk, bias, n_out, nch, nmb,
                            relu, (unsigned long long)mask_bits, (unsigned long long)accum_bits, tiles_x, tpi, total);
