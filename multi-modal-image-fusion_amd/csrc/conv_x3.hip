@@ -154,9 +154,11 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_x3_kernel(TV tin, TV tout, TV
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const TileWalk tw = xcd_walk(total_tiles, gridDim.x, blockIdx.x);
-    // timing ablations ($MMIF_X3_ABLATE, results are garbage), each after the first step: 1 no input loads (NB: the tile is then all
-    // zeros and the chip clocks zero-operand MFMAs ~25 % higher -- that run measures DVFS, not the loads), 2 no weight loads, 4 no split +
-    // LDS writes, 8 no MFMAs.  decode.0 forward, 6 products: 2.82 ms; 2: 2.76; 4: 2.65; 8: 0.86 (all staging + epilogue); 1: 2.09.
+    // timing ablations ($MMIF_X3_ABLATE, results are garbage), each after the first step: 1 no input loads (the first step's data is
+    // kept: an all-zero tile clocks ~25 % higher and measures DVFS, not the loads), 2 no weight loads, 4 no split + LDS writes, 8 no
+    // MFMAs.  decode.0, 128 -> 128, B = 32: forward (6 products) 2.75 ms, 1: 2.57, 4: 2.62, 5: 2.45, 8: 0.88; dgrad 1.95 / 1.78 / 1.84 /
+    // 1.69 / 0.97; wgrad 1.62 / 1.29 / 1.54 / 1.18 / 0.82 -- the weight gradient waits for its tile loads (two half-tile round trips per
+    // 7 us tile; all four granules in flight at once did not fit the 168-register budget: 24 bytes of scratch, 1.70 ms)
     const int abl = relu >> 8;
     relu &= 255;
     const int nch = (nch16 + KK - 1) / KK;        // LDS chunks per item
@@ -194,8 +196,10 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_x3_kernel(TV tin, TV tout, TV
 #pragma unroll
         for (int k = 0; k < IN_ROUNDS; ++k) {
             const int cb = (int)(geo[k] >> 16), py = (int)((geo[k] >> 8) & 255u), px = (int)(geo[k] & 255u);
-            rin[k].a = (x3_f4){0.f, 0.f, 0.f, 0.f};
-            rin[k].b = rin[k].a;
+            if (!((abl & 1) && s > 0)) {   // (ablation 1 keeps the first step's REAL data: an all-zero tile would clock ~25 % higher)
+                rin[k].a = (x3_f4){0.f, 0.f, 0.f, 0.f};
+                rin[k].b = rin[k].a;
+            }
             int y = iy0 + py, x = ix0 + px;
             bool ok = cb < ncb && tid + X3_THREADS * k < ING;
             if (DGRAD) {
@@ -423,6 +427,8 @@ __global__ __launch_bounds__(XW_THREADS) void wgrad_x3_kernel(TV tx, TV tg, floa
     const int icg = pair % n_icg, ocg = pair / n_icg;
     const TileWalk tw = xcd_walk(total, G, gi);
     const int ntile = tw.count;
+    const int abl = tiles_x >> 16;     // timing ablations as in conv_x3_kernel (1 no loads, 4 no split + LDS writes, 8 no MFMAs)
+    tiles_x &= 0xffff;
 
     // wave (v, jt, mt): tap COLUMN v, input-channel tile jt, output-channel tile mt (32 each); it owns the three taps (0..2, v): the
     // activation row a tap (u, v) needs at k-step ry is tile row ry + u, i.e. a three-row register ring with ONE new row per k-step
@@ -453,6 +459,7 @@ __global__ __launch_bounds__(XW_THREADS) void wgrad_x3_kernel(TV tx, TV tg, floa
     // staging of the next tile in two halves (rounds 0-1 during k-steps 0-3, rounds 2-3 during k-steps 4-7: the other LDS buffer is free for
     // the whole tile), so only two granules per thread are in flight -- four kept the kernel 20 registers over its budget (scratch)
     static_assert(XW_ROUNDS == 4, "two staging halves of two rounds");
+    int k_done = 0;
     X3Gran rin[2];
     auto issue = [&](int k_tile, int half) {
         const int tile = tw.first + k_tile * tw.stride;
@@ -466,6 +473,7 @@ __global__ __launch_bounds__(XW_THREADS) void wgrad_x3_kernel(TV tx, TV tg, floa
             const int k = 2 * half + kr;
             const unsigned gk = half ? geo[2 + kr] : geo[kr];
             const int cb = (int)((gk >> 16) & 255u), py = (int)((gk >> 8) & 255u), px = (int)(gk & 255u);
+            if ((abl & 1) && k_tile > 0) continue;
             rin[kr].a = (x3_f4){0.f, 0.f, 0.f, 0.f};
             rin[kr].b = rin[kr].a;
             if (tid + XW_THREADS * k < n_all) {
@@ -487,6 +495,7 @@ __global__ __launch_bounds__(XW_THREADS) void wgrad_x3_kernel(TV tx, TV tg, floa
         }
     };
     auto commit = [&](int buf, int half) {
+        if ((abl & 4) && k_done > 1) return;
         x3_u4* dst = s_buf + buf * XW_BUF_G;
 #pragma unroll
         for (int kr = 0; kr < 2; ++kr) {
@@ -538,8 +547,9 @@ __global__ __launch_bounds__(XW_THREADS) void wgrad_x3_kernel(TV tx, TV tg, floa
     for (int k = 0; k < ntile; ++k) {
         const int buf = k & 1;
         const bool more = k + 1 < ntile;
+        k_done = k;
         if (more) issue(k + 1, 0);
-        if (active) {
+        if (active && !((abl & 8) && k > 0)) {
             const char* s_xh = reinterpret_cast<const char*>(s_buf + buf * XW_BUF_G);
             const char* s_xl = s_xh + XW_XG * 16;
             const char* s_gh = s_xl + XW_XG * 16;
@@ -789,10 +799,13 @@ int wgrad_x3(const TV& tx, const TV& tg, float* dw, float* db, int cin, int cout
     const int n_icg = cdiv(cin, 64), n_ocg = cdiv(cout, 64);
     int G = wgrad_x3_G(cin, cout);
     if (total < G) G = total;
+    static int abl = -1;
+    if (abl < 0) { const char* e = getenv("MMIF_X3_ABLATE"); abl = e != nullptr ? atoi(e) : 0; }
+    const int tx_abl = tiles_x | (abl << 16);
     if (thin)
-        hipLaunchKernelGGL((wgrad_x3_kernel<16, 6, 2>), dim3(G * n_icg * n_ocg), dim3(XW_THREADS), 0, st, tx, tg, ws, cin, cout, tiles_x, tpi, total, G, n_icg, n_ocg);
+        hipLaunchKernelGGL((wgrad_x3_kernel<16, 6, 2>), dim3(G * n_icg * n_ocg), dim3(XW_THREADS), 0, st, tx, tg, ws, cin, cout, tx_abl, tpi, total, G, n_icg, n_ocg);
     else
-        hipLaunchKernelGGL((wgrad_x3_kernel<8, 8, 8>), dim3(G * n_icg * n_ocg), dim3(XW_THREADS), 0, st, tx, tg, ws, cin, cout, tiles_x, tpi, total, G, n_icg, n_ocg);
+        hipLaunchKernelGGL((wgrad_x3_kernel<8, 8, 8>), dim3(G * n_icg * n_ocg), dim3(XW_THREADS), 0, st, tx, tg, ws, cin, cout, tx_abl, tpi, total, G, n_icg, n_ocg);
     if (int rc = check_launch("wgrad_x3")) return rc;
     const int n = cout * cin * 9 + cout;
     hipLaunchKernelGGL(wgrad_x3_reduce, dim3(cdiv(n, 64)), dim3(256), 0, st, ws, dw, db, cin, cout, G, n_icg, n_ocg, accumulate);
