@@ -158,7 +158,8 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_x3_kernel(TV tin, TV tout, TV
     // kept: an all-zero tile clocks ~25 % higher and measures DVFS, not the loads), 2 no weight loads, 4 no split + LDS writes, 8 no
     // MFMAs.  decode.0, 128 -> 128, B = 32: forward (6 products) 2.75 ms, 1: 2.57, 4: 2.62, 5: 2.45, 8: 0.88; dgrad 1.95 / 1.78 / 1.84 /
     // 1.69 / 0.97; wgrad 1.62 / 1.29 / 1.54 / 1.18 / 0.82 -- the weight gradient waits for its tile loads (two half-tile round trips per
-    // 7 us tile; all four granules in flight at once did not fit the 168-register budget: 24 bytes of scratch, 1.70 ms)
+    // 7 us tile; all four granules in flight at once did not fit the 168-register budget: 24 bytes of scratch, 1.70 ms; warming L2 two tiles
+    // ahead with one 4-byte load per granule made it slower, 1.95 ms: the memory system is busy, not cold)
     const int abl = relu >> 8;
     relu &= 255;
     const int nch = (nch16 + KK - 1) / KK;        // LDS chunks per item
