@@ -41,7 +41,7 @@ extern "C" {
 #define MMIF_IMPL_VALU 1 /* LDS-tiled fp32-accumulate VALU kernels (any dtype) */
 #define MMIF_IMPL_MFMA 2 /* v_mfma_f32_16x16x32_bf16 kernels (bf16 storage only) */
 #define MMIF_IMPL_X3 3   /* fp32 storage, contraction on the matrix pipe as three bf16 products (hi*hi + hi*lo + lo*hi,
-                          * fp32 accumulate): the parity-grade fast path for fp32 tensors, 3x3 layers (csrc/conv_x3.hip) */
+                          * fp32 accumulate): the parity-grade fast path for fp32 tensors, 3x3 and 1x1 layers (csrc/conv_x3.hip) */
 
 #define MMIF_OK 0
 #define MMIF_EINVAL (-1)   /* bad argument / unsupported shape */
@@ -100,7 +100,7 @@ int mmif_pack_weights_multi(const mmif_pack_job* jobs, int32_t n_jobs, void* str
  * accuracy (core/block.py:56-66 computes in fp32; BASELINE north star: within 1e-3 of it): every weight is stored as successive bf16
  * pieces hi = bf16(w), mid = bf16(w - hi) [, lo = bf16(w - hi - mid)]; layout [m-block][16-channel chunk][piece][tap][2 channel
  * blocks][32 or 64 out channels][8] (csrc/conv_x3.hip).
- * Pass them as w_packed / w_packed_t of the conv entry points below when the tensors are fp32.  ksize must be 3. */
+ * Pass them as w_packed / w_packed_t of the conv entry points below when the tensors are fp32.  ksize 1 or 3. */
 /* Pieces of the FORWARD image: 3 (default: hi / mid / lo, six products per tap -- fp32-grade activations, so ReLU decisions agree with the
  * reference's as often as between two fp32 implementations) or 2 (three products, activations within ~1e-5; a mask flip on a
  * pre-activation that close to zero moves parameter gradients by O(1e-3)).  The dgrad image always has 2 (the backward kernels are

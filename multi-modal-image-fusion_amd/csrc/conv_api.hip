@@ -30,10 +30,10 @@ int bwd_wide(const TV& tx, const TV& tg, const TV& tgx, const void* wpk_dgrad, f
 // conv_x3.hip
 bool conv_x3_supported(bool dgrad, int ks, int cin, int cout, const TV& tin, const TV& tout);
 int conv_x3(bool dgrad, const TV& tin, const TV& tout, const TV& tmask, const void* wpk, const float* bias, int cin, int cout, int relu,
-            uint64_t mask_bits, uint64_t accum_bits, hipStream_t st);
+            uint64_t mask_bits, uint64_t accum_bits, hipStream_t st, int ks);
 bool wgrad_x3_supported(int ks, int cin, int cout, const TV& tx, const TV& tg);
 size_t wgrad_x3_workspace(int cin, int cout, int ks);
-int wgrad_x3(const TV& tx, const TV& tg, float* dw, float* db, int cin, int cout, int accumulate, float* ws, hipStream_t st);
+int wgrad_x3(const TV& tx, const TV& tg, float* dw, float* db, int cin, int cout, int accumulate, float* ws, hipStream_t st, int ks);
 }  // namespace mmif
 
 using namespace mmif;
@@ -78,7 +78,7 @@ extern "C" int mmif_conv2d_reflect_fwd(const mmif_tensor* x, const float* w, con
     const int im = pick_impl(impl, x->dtype, conv_mfma_supported(false, ksize, cin, cout) && w_packed != nullptr, "conv2d_reflect_fwd",
                              x->dtype == MMIF_F32 && w_packed != nullptr && conv_x3_supported(false, ksize, cin, cout, tx, ty));
     if (im < 0) return MMIF_EINVAL;
-    if (im == MMIF_IMPL_X3) return conv_x3(false, tx, ty, ty, w_packed, bias, cin, cout, relu, 0, 0, (hipStream_t)stream);
+    if (im == MMIF_IMPL_X3) return conv_x3(false, tx, ty, ty, w_packed, bias, cin, cout, relu, 0, 0, (hipStream_t)stream, ksize);
     if (im == MMIF_IMPL_MFMA) return conv_mfma(false, ksize, tx, ty, ty, w_packed, bias, cin, cout, relu, 0, 0, (hipStream_t)stream);
     MMIF_REQUIRE(w != nullptr, "conv2d_reflect_fwd: VALU path needs the fp32 master weights");
     return conv_valu(false, x->dtype, ksize, tx, ty, ty, w, bias, cin, cout, relu, 0, 0, (hipStream_t)stream);
@@ -117,7 +117,7 @@ static int dgrad_impl(const char* what, const mmif_tensor* gy, const float* w, c
         told = make_tv(gx_old);
     }
     if (im == MMIF_IMPL_X3) {
-        rc = conv_x3(true, tg, tgx, tm, w_packed_t, nullptr, cin, cout, 0, mask_bits, accum_bits, (hipStream_t)stream);
+        rc = conv_x3(true, tg, tgx, tm, w_packed_t, nullptr, cin, cout, 0, mask_bits, accum_bits, (hipStream_t)stream, ksize);
     } else if (im == MMIF_IMPL_MFMA) {
         rc = conv_mfma(true, ksize, tg, tgx, tm, w_packed_t, nullptr, cin, cout, 0, mask_bits, accum_bits, (hipStream_t)stream, fold, &folded,
                        gx_old != nullptr ? &told : nullptr);
@@ -182,7 +182,7 @@ extern "C" int mmif_conv2d_reflect_wgrad(const mmif_tensor* x, const mmif_tensor
     const int im = pick_impl(impl, x->dtype, wgrad_mfma_supported(ksize, cin, cout), "conv2d_reflect_wgrad",
                              x->dtype == MMIF_F32 && wgrad_x3_supported(ksize, cin, cout, tx, tg));
     if (im < 0) return MMIF_EINVAL;
-    if (im == MMIF_IMPL_X3) return wgrad_x3(tx, tg, dw, db, cin, cout, accumulate, (float*)workspace, (hipStream_t)stream);
+    if (im == MMIF_IMPL_X3) return wgrad_x3(tx, tg, dw, db, cin, cout, accumulate, (float*)workspace, (hipStream_t)stream, ksize);
     if (im == MMIF_IMPL_MFMA) return wgrad_mfma(ksize, tx, tg, dw, db, cin, cout, accumulate, (float*)workspace, (hipStream_t)stream);
     return wgrad_valu(x->dtype, ksize, tx, tg, dw, db, cin, cout, accumulate, (float*)workspace, (hipStream_t)stream);
 }

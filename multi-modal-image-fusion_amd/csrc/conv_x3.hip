@@ -34,19 +34,18 @@ typedef __attribute__((ext_vector_type(4))) unsigned x3_u4;     // travel throug
 #define X3_LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
 
 constexpr int X3_TW = 32;                        // output tile columns; rows = 2 per wave (16 with 8 waves, 8 with 4)
-constexpr int X3_IW = X3_TW + 2;
 
 __host__ __device__ constexpr int x3_mb(int n_out) { return n_out > 32 ? 2 : 1; }
 static inline int x3_nmb(int n_out) { return cdiv(n_out, 32 * x3_mb(n_out)); }
 static inline int x3_nch(int n_in) { return cdiv(cdiv(n_in, 8), 2); }
 // operand image: [m-block][chunk][hi | lo][tap u*3+v][channel block 0 / 1 of the chunk][32*MB out channels][8 in channels] bf16
-static size_t x3_packed_bytes(int n_out, int n_in, int pieces) {
-    return (size_t)x3_nmb(n_out) * x3_nch(n_in) * pieces * 9 * 2 * 32 * x3_mb(n_out) * 16;
+static size_t x3_packed_bytes(int n_out, int n_in, int pieces, int ks = 3) {
+    return (size_t)x3_nmb(n_out) * x3_nch(n_in) * pieces * ks * ks * 2 * 32 * x3_mb(n_out) * 16;
 }
 
 // ------------------------------------------------------------------ weight packing
 constexpr int X3_PACK_MAX = 64;
-struct X3PackImage { const float* w; bf16_t* dst; long long total; int cout, cin, dgrad, mbw, nch, pieces; };
+struct X3PackImage { const float* w; bf16_t* dst; long long total; int cout, cin, dgrad, mbw, nch, pieces, ks; };
 struct X3PackTable { X3PackImage im[X3_PACK_MAX]; };
 
 // dgrad == 0: out = o, in = c, Wk[u][v] = W[o][c][u][v];  dgrad == 1: out = c, in = o, Wk[u][v] = W[o][c][2-u][2-v]
@@ -60,17 +59,18 @@ __global__ void x3_pack_kernel(X3PackTable tab) {
         long long r = idx >> 3;
         const int ocl = (int)(r % J.mbw); r /= J.mbw;
         const int cbl = (int)(r & 1); r >>= 1;
-        const int tap = (int)(r % 9); r /= 9;
+        const int ks = J.ks, taps = ks * ks;
+        const int tap = (int)(r % taps); r /= taps;
         const int ch = (int)(r % J.nch);
         const int mb = (int)(r / J.nch);
         const int oc = mb * J.mbw + ocl, ic = (ch * 2 + cbl) * 8 + e;
-        const int u = tap / 3, v = tap % 3;
+        const int u = tap / ks, v = tap % ks;
         float val = 0.f;
         if (oc < n_out && ic < n_in) {
-            if (J.dgrad) val = J.w[(((long long)ic * J.cin + oc) * 3 + (2 - u)) * 3 + (2 - v)];
-            else val = J.w[(((long long)oc * J.cin + ic) * 3 + u) * 3 + v];
+            if (J.dgrad) val = J.w[(((long long)ic * J.cin + oc) * ks + (ks - 1 - u)) * ks + (ks - 1 - v)];
+            else val = J.w[(((long long)oc * J.cin + ic) * ks + u) * ks + v];
         }
-        const long long piece = (long long)9 * 2 * J.mbw * 8;
+        const long long piece = (long long)taps * 2 * J.mbw * 8;
         const long long within = ((long long)(tap * 2 + cbl) * J.mbw + ocl) * 8 + e;
         const long long base = ((long long)mb * J.nch + ch) * J.pieces * piece;
         for (int p = 0; p < J.pieces; ++p) {   // successive bf16 roundings of the remainder (each subtraction is exact in fp32)
@@ -132,15 +132,16 @@ constexpr int X3_BIAS_G = 128;   // granules reserved behind the tiles for the b
 // kernels (profiles/r03_pmc_sq_x3.txt): the matrix pipe is busy 58 % (2 pieces) / 74 % (3 pieces) of the cycles, i.e. a constant
 // ~5 k cycles per 16 input channels of split + LDS-write + issue work that no barrier arrangement removes, at 1.7-1.8 GHz (the chip
 // clocks dense MFMA work down: the 2.5 PFLOP/s peak assumes 2.4 GHz).
-template <int MB, bool DGRAD, int NP, int NW, int RJ>
+template <int MB, bool DGRAD, int NP, int NW, int RJ, int KS>
 __global__ __launch_bounds__(64 * NW, 2) void conv_x3_kernel(TV tin, TV tout, TV tmask, const uint4* __restrict__ wpk,
                                                               const float* __restrict__ bias, int n_out, int nch16, int nmb, int relu,
                                                               unsigned long long mask_bits, unsigned long long accum_bits, int tiles_x,
                                                               int tiles_per_img, int total_tiles) {
     constexpr int MBW = 32 * MB;
-    constexpr int WG = 9 * 2 * MBW;               // weight granules of one piece of a 16-channel sub-chunk
-    constexpr int X3_THREADS = 64 * NW, X3_TH = RJ * NW, X3_IH = X3_TH + 2;   // a wave owns RJ rows of the tile
-    constexpr int CKB = (NP == 2 && NW == 8 && RJ == 2) ? 4 : 2;   // channel blocks per LDS chunk
+    constexpr int TAPS = KS * KS, PD = KS / 2;    // KS = 1: the same kernel without halo and with one tap (HBM-bound: NestFuse's 1x1 layers)
+    constexpr int WG = TAPS * 2 * MBW;            // weight granules of one piece of a 16-channel sub-chunk
+    constexpr int X3_THREADS = 64 * NW, X3_TH = RJ * NW, X3_IH = X3_TH + 2 * PD, X3_IW = X3_TW + 2 * PD;   // a wave owns RJ rows of the tile
+    constexpr int CKB = KS == 1 ? (NP == 2 ? 8 : 4) : ((NP == 2 && NW == 8 && RJ == 2) ? 4 : 2);   // channel blocks per LDS chunk
     constexpr int KK = CKB / 2;                   // 16-channel sub-chunks (MFMA k-steps per tap) per chunk
     constexpr int PL = X3_IH * X3_IW;             // granules of one channel-block plane of the input tile: 612
     constexpr int ING = CKB * PL;                 // input granules per piece
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_x3_kernel(TV tin, TV tout, TV
         const int tile = tw.first + ti * tw.stride;
         const int in_ = tile / tiles_per_img, tt = tile - in_ * tiles_per_img;
         const int ys0 = (tt / tiles_x) * X3_TH, xs0 = (tt % tiles_x) * X3_TW;
-        const int iy0 = ys0 - tout.halo - 1, ix0 = xs0 - tout.halo - 1;   // logical origin of the input tile
+        const int iy0 = ys0 - tout.halo - PD, ix0 = xs0 - tout.halo - PD;   // logical origin of the input tile
         const char* base = tin.base + ((long long)in_ * tin.img + (long long)(tin.cb_off + c * CKB) * tin.plane) * 32;
         const int ncb = tin.cb - c * CKB;                                   // channel blocks this chunk really has
 #pragma unroll
@@ -268,10 +269,10 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_x3_kernel(TV tin, TV tout, TV
             if (kk < nkk && !((abl & 8) && s > 0)) {
                 const x3_u4* s_in = s_buf + kk * 2 * PL;
                 const x3_u4* s_w = s_buf + NP * ING + kk * NP * WG;
-                x3_bf16x8 brow[RJ + 2][NP], afr[2][MB][NP];
+                x3_bf16x8 brow[RJ + 2 * PD][NP], afr[2][MB][NP];
                 // taps in column-major order t = 3 v + u: tap (u, v) reads rows u .. u+RJ-1 of the wave's (RJ+2)-row window at column shift v
                 auto ld_a = [&](int t, int slot) {
-                    const int v = t / 3, u = t % 3, tap = u * 3 + v;
+                    const int v = t / KS, u = t % KS, tap = u * KS + v;
 #pragma unroll
                     for (int m = 0; m < MB; ++m)
 #pragma unroll
@@ -285,18 +286,18 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_x3_kernel(TV tin, TV tout, TV
 #pragma unroll
                 for (int r = 0; r < RJ; ++r) ld_b(r, 0);
 #pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const int u = t % 3;
+                for (int t = 0; t < TAPS; ++t) {
+                    const int u = t % KS;
                     int nld = 0;
                     // RJ > 2: rows 2 .. RJ-1 of a new column cannot be fetched during the previous tap (it still reads them at the old
                     // column shift): they are fetched here and consumed by the SECOND half of this tap's MFMAs (rows j >= 2)
                     if (RJ > 2 && u == 0 && t > 0) {
 #pragma unroll
-                        for (int r = 2; r < RJ; ++r) ld_b(r, t / 3);
+                        for (int r = 2; r < RJ; ++r) ld_b(r, t / KS);
                         nld += (RJ - 2) * NP;
                     }
-                    if (t + 1 < 9) {
-                        const int v1 = (t + 1) / 3, u1 = (t + 1) % 3;
+                    if (t + 1 < TAPS) {
+                        const int v1 = (t + 1) / KS, u1 = (t + 1) % KS;
                         ld_a(t + 1, (t + 1) & 1);
                         nld += MB * NP;
                         if (u1 == 0) {   // rows 0, 1 of the next column are dead from this tap (u = 2) on
@@ -398,20 +399,20 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_x3_kernel(TV tin, TV tout, TV
 
 // ------------------------------------------------------------------ wgrad
 constexpr int XW_TW = 16;                        // pixel-tile columns = the 16 pixels of one k-step
-constexpr int XW_XW = XW_TW + 2;
 constexpr int XW_THREADS = 768;
-constexpr int XW_PER = 64 * 64 * 9 + 64;         // floats per block partial: dW[64 oc][64 ic][9], db[64]
 
 // TH x 16 pixel tiles, NXC / NGC channel blocks of the activation / gradient group kept in LDS.  <8, 8, 8>: the general 64 x 64 channel
 // pair.  <16, 6, 2>: layers with <= 48 input and <= 16 output channels (the DenseBlock convs, decode.3) -- the same LDS and staging
 // budget spent on TWICE the pixels per tile: those layers run one tile per ~3 us of global-load latency whatever the tile holds
 // (0.18-0.30 ms per launch with almost no MFMA work), so half the tiles is half the time.  Channel blocks past NXC / NGC are read
 // from the last plane kept (those dW rows / columns belong to channels the layer does not have and are never reduced).
-template <int TH, int NXC, int NGC>
+template <int TH, int NXC, int NGC, int KS>
 __global__ __launch_bounds__(XW_THREADS) void wgrad_x3_kernel(TV tx, TV tg, float* __restrict__ partial, int cin, int cout, int tiles_x, int tpi,
                                                                int total, int G, int n_icg, int n_ocg) {
-    constexpr int XW_TH = TH, XW_XH = TH + 2;
-    constexpr int XW_XPL = XW_XH * XW_XW;            // 180 / 324 granules per x plane (= 4 mod 16: the four planes a half wave's transposing
+    constexpr int PD = KS / 2, TAPS = KS * KS;       // KS = 1: no halo, one tap; the three wave groups v split the k-steps instead of the tap columns
+    constexpr int XW_TH = TH, XW_XH = TH + 2 * PD, XW_XW = XW_TW + 2 * PD;
+    constexpr int XW_PER = 64 * 64 * TAPS + 64;      // floats per block partial: dW[64 oc][64 ic][taps], db[64]
+    constexpr int XW_XPL = XW_XH * XW_XW + (KS == 1 ? 4 : 0);   // 180 / 324 / 132 granules per x plane (= 4 mod 16: the four planes a half wave's transposing
     constexpr int XW_GPL = XW_TH * XW_TW + 4;        // 132 / 260 granules per g plane    read touches fall on disjoint bank quarters)
     constexpr int XW_XG = NXC * XW_XPL, XW_GG = NGC * XW_GPL;      // one precision half of the x / g tile
     constexpr int XW_BUF_G = 2 * XW_XG + 2 * XW_GG;                // [x hi][x lo][g hi][g lo]: 4992 / 4928 granules
@@ -437,7 +438,7 @@ __global__ __launch_bounds__(XW_THREADS) void wgrad_x3_kernel(TV tx, TV tg, floa
     // of transposing reads on four SIMDs, at the LDS's limit for three waves per SIMD)
     const int v = wave % 3, jt = (wave / 3) & 1, mt = wave / 6;
     const bool active = (ocg * 64 + mt * 32 < cout) && (icg * 64 + jt * 32 < cin);
-    const bool want_db = (v == 0 && jt == 0 && icg == 0 && ocg * 64 + mt * 32 < cout);
+    const bool want_db = ((v == 0 || KS == 1) && jt == 0 && icg == 0 && ocg * 64 + mt * 32 < cout);
 
     // channel blocks this block's groups really have: only those are staged (the planes of the others stay zero from here on)
     const int nxcb = min(NXC, tx.cb - icg * 8), ngcb = min(NGC, tg.cb - ocg * 8);
@@ -459,9 +460,9 @@ __global__ __launch_bounds__(XW_THREADS) void wgrad_x3_kernel(TV tx, TV tg, floa
 
     // staging of the next tile in two halves (rounds 0-1 during k-steps 0-3, rounds 2-3 during k-steps 4-7: the other LDS buffer is free for
     // the whole tile), so only two granules per thread are in flight -- four kept the kernel 20 registers over its budget (scratch)
-    static_assert(XW_ROUNDS == 4, "two staging halves of two rounds");
+    constexpr int HALF_R = (XW_ROUNDS + 1) / 2;
     int k_done = 0;
-    X3Gran rin[2];
+    X3Gran rin[HALF_R];
     auto issue = [&](int k_tile, int half) {
         const int tile = tw.first + k_tile * tw.stride;
         const int in_ = tile / tpi, tt = tile - in_ * tpi;
@@ -470,17 +471,18 @@ __global__ __launch_bounds__(XW_THREADS) void wgrad_x3_kernel(TV tx, TV tg, floa
         const char* bg = tg.base + ((long long)in_ * tg.img + (long long)(tg.cb_off + ocg * 8) * tg.plane) * 32;
         const unsigned xplane = (unsigned)tx.plane, gplane = (unsigned)tg.plane;
 #pragma unroll
-        for (int kr = 0; kr < 2; ++kr) {
-            const int k = 2 * half + kr;
-            const unsigned gk = half ? geo[2 + kr] : geo[kr];
+        for (int kr = 0; kr < HALF_R; ++kr) {
+            const int k = HALF_R * half + kr;
+            if (k >= XW_ROUNDS) continue;
+            const unsigned gk = half ? geo[min(HALF_R + kr, XW_ROUNDS - 1)] : geo[kr];
             const int cb = (int)((gk >> 16) & 255u), py = (int)((gk >> 8) & 255u), px = (int)(gk & 255u);
             if ((abl & 1) && k_tile > 0) continue;
             rin[kr].a = (x3_f4){0.f, 0.f, 0.f, 0.f};
             rin[kr].b = rin[kr].a;
             if (tid + XW_THREADS * k < n_all) {
                 if (!(gk >> 24)) {
-                    const int y = min(max(reflect_idx(y0 + py - 1, tx.h), 0), tx.h - 1);
-                    const int x = min(max(reflect_idx(x0 + px - 1, tx.w), 0), tx.w - 1);
+                    const int y = min(max(reflect_idx(y0 + py - PD, tx.h), 0), tx.h - 1);
+                    const int x = min(max(reflect_idx(x0 + px - PD, tx.w), 0), tx.w - 1);
                     const x3_f4* p = reinterpret_cast<const x3_f4*>(bx + ((unsigned)cb * xplane + (unsigned)(y * tx.ws + x)) * 32u);   // (32-bit: x3_small)
                     rin[kr].a = p[0];
                     rin[kr].b = p[1];
@@ -499,9 +501,10 @@ __global__ __launch_bounds__(XW_THREADS) void wgrad_x3_kernel(TV tx, TV tg, floa
         if ((abl & 4) && k_done > 1) return;
         x3_u4* dst = s_buf + buf * XW_BUF_G;
 #pragma unroll
-        for (int kr = 0; kr < 2; ++kr) {
-            const int k = 2 * half + kr;
-            const unsigned gk = half ? geo[2 + kr] : geo[kr];
+        for (int kr = 0; kr < HALF_R; ++kr) {
+            const int k = HALF_R * half + kr;
+            if (k >= XW_ROUNDS) continue;
+            const unsigned gk = half ? geo[min(HALF_R + kr, XW_ROUNDS - 1)] : geo[kr];
             if (tid + XW_THREADS * k < n_all) {
                 const int cb = (int)((gk >> 16) & 255u), py = (int)((gk >> 8) & 255u), px = (int)(gk & 255u);
                 x3_u4 pc[2];
@@ -561,7 +564,30 @@ __global__ __launch_bounds__(XW_THREADS) void wgrad_x3_kernel(TV tx, TV tg, floa
                 return __builtin_bit_cast(x3_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
             };
             const int goff = ((min(mt * 4 + lane_cb, NGC - 1) * XW_GPL) + lane_px) * 16 + lane_byte;          // + ry * XW_TW * 16
-            const int xoff = ((min(jt * 4 + lane_cb, NXC - 1) * XW_XPL) + lane_px + v) * 16 + lane_byte;      // + row * XW_XW * 16
+            const int xoff = ((min(jt * 4 + lane_cb, NXC - 1) * XW_XPL) + lane_px + (KS == 1 ? 0 : v)) * 16 + lane_byte;      // + row * XW_XW * 16
+            if constexpr (KS == 1) {
+                // one tap: wave group v takes the k-steps ry = v, v + 3, .. (its partial goes to its own slot, summed by the reduce kernel)
+#pragma unroll
+                for (int ry = 0; ry < XW_TH; ++ry) {
+                    if (ry == XW_TH / 2 && more) {   // second half of the next tile's staging
+                        commit(buf ^ 1, 0);
+                        issue(k + 1, 1);
+                    }
+                    if (ry % 3 == v) {
+                        const x3_bf16x8 xh = ld_tr(s_xh + xoff + ry * XW_XW * 16), xl = ld_tr(s_xl + xoff + ry * XW_XW * 16);
+                        const x3_bf16x8 gh = ld_tr(s_gh + goff + ry * XW_TW * 16), gl = ld_tr(s_gl + goff + ry * XW_TW * 16);
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gl, xh, acc[0], 0, 0, 0);
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh, xl, acc[0], 0, 0, 0);
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh, xh, acc[0], 0, 0, 0);
+                        if (want_db) {
+                            accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gl, ones0, accb[0], 0, 0, 0);
+                            accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gl, ones1, accb[1], 0, 0, 0);
+                            accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh, ones0, accb[0], 0, 0, 0);
+                            accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh, ones1, accb[1], 0, 0, 0);
+                        }
+                    }
+                }
+            } else {
             // activation rows ry, ry + 1, ry + 2 live in a three-slot register ring (slot = row % 3): ONE new row per k-step
             x3_bf16x8 xh[3], xl[3];
 #pragma unroll
@@ -591,6 +617,7 @@ __global__ __launch_bounds__(XW_THREADS) void wgrad_x3_kernel(TV tx, TV tg, floa
                     accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh, ones1, accb[1], 0, 0, 0);
                 }
             }
+            }
         }
         else if (more) {   // (a wave without a live channel tile still stages)
             commit(buf ^ 1, 0);
@@ -601,38 +628,42 @@ __global__ __launch_bounds__(XW_THREADS) void wgrad_x3_kernel(TV tx, TV tg, floa
     }
     // lane l reg r of acc[u]: oc = 32 mt + (r & 3) + 8 (r >> 2) + 4 (l >> 5), ic = 32 jt + (l & 31), tap (u, v)
     if (active) {
-        float* dst = partial + ((long long)gi * npairs + pair) * XW_PER;
+        float* dst = partial + ((long long)(KS == 1 ? gi * 3 + v : gi) * npairs + pair) * XW_PER;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int oc = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), ic = 32 * jt + (lane & 31);
+            if (KS == 1) dst[oc * 64 + ic] = acc[0][r];
+            else {
 #pragma unroll
-            for (int u = 0; u < 3; ++u) dst[(oc * 64 + ic) * 9 + u * 3 + v] = acc[u][r];
+                for (int u = 0; u < 3; ++u) dst[(oc * 64 + ic) * 9 + u * 3 + v] = acc[u][r];
+            }
         }
         // 16x16x32 C layout: lane l, reg r = row 4 (l >> 4) + r, column l & 15; rows of accb[h] = channels 16 h .. 16 h + 15
         if (want_db && (lane & 15) == 0) {
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dst[64 * 64 * 9 + 32 * mt + 16 * h + 4 * (lane >> 4) + r] = accb[h][r];
+                for (int r = 0; r < 4; ++r) dst[64 * 64 * TAPS + 32 * mt + 16 * h + 4 * (lane >> 4) + r] = accb[h][r];
         }
     }
 }
 
 // dw / db = fixed-order sum of the G block partials of each (icg, ocg) pair
 __global__ __launch_bounds__(256) void wgrad_x3_reduce(const float* __restrict__ partial, float* __restrict__ dw, float* __restrict__ db,
-                                                       int cin, int cout, int G, int n_icg, int n_ocg, int accumulate) {
+                                                       int cin, int cout, int G, int n_icg, int n_ocg, int accumulate, int taps) {
     __shared__ float red[4][64];
-    const int total_w = cout * cin * 9;
+    const int XW_PER = 64 * 64 * taps + 64;
+    const int total_w = cout * cin * taps;
     const int o_local = threadIdx.x & 63, slice = threadIdx.x >> 6;
     const int idx = blockIdx.x * 64 + o_local;
     const int npairs = n_icg * n_ocg;
     long long off = -1;
     if (idx < total_w) {
-        const int tap = idx % 9, c = (idx / 9) % cin, o = idx / (9 * cin);
-        off = (long long)((c / 64) + n_icg * (o / 64)) * XW_PER + ((o % 64) * 64 + (c % 64)) * 9 + tap;
+        const int tap = idx % taps, c = (idx / taps) % cin, o = idx / (taps * cin);
+        off = (long long)((c / 64) + n_icg * (o / 64)) * XW_PER + ((o % 64) * 64 + (c % 64)) * taps + tap;
     } else if (idx < total_w + cout) {
         const int o = idx - total_w;
-        off = (long long)(0 + n_icg * (o / 64)) * XW_PER + 64 * 64 * 9 + (o % 64);
+        off = (long long)(0 + n_icg * (o / 64)) * XW_PER + 64 * 64 * taps + (o % 64);
     }
     float s = 0.f;
     if (off >= 0) {
@@ -682,10 +713,10 @@ static bool x3_grad_ok(const TV& t) { return t.halo == 0 || (t.halo == 1 && t.fo
 static bool x3_small(const TV& t) { return t.plane * 32 * 8 < (1ll << 32); }   // 8 planes addressed with 32-bit byte offsets
 
 bool conv_x3_supported(bool dgrad, int ks, int cin, int cout, const TV& tin, const TV& tout) {
-    if (!x3_enabled() || ks != 3 || cin < 1 || cout < 1) return false;
+    if (!x3_enabled() || (ks != 3 && ks != 1) || cin < 1 || cout < 1) return false;
     if (dgrad && !x3_grad_ok(tin)) return false;
     if ((dgrad ? cin : cout) > 64 * 8) return false;   // mask / accum bits address 64 channel blocks
-    return tin.h >= 2 && tin.w >= 2 && x3_small(tin) && x3_small(tout);
+    return (ks == 1 || (tin.h >= 2 && tin.w >= 2)) && x3_small(tin) && x3_small(tout);
 }
 
 // pieces of the FORWARD pass's operands: 3 (default; 6 products, fp32-grade activations, so ReLU decisions agree with the reference's as
@@ -701,8 +732,8 @@ int x3_fwd_pieces() {
 }
 
 size_t conv_x3_packed_bytes(int cout, int cin, int ks) {
-    if (ks != 3) return 16;
-    const size_t a = x3_packed_bytes(cout, cin, 3), b = x3_packed_bytes(cin, cout, 2);   // (room for either forward format)
+    if (ks != 3 && ks != 1) return 16;
+    const size_t a = x3_packed_bytes(cout, cin, 3, ks), b = x3_packed_bytes(cin, cout, 2, ks);   // (room for either forward format)
     return a > b ? a : b;
 }
 
@@ -717,15 +748,15 @@ int conv_x3_pack_multi(const mmif_pack_job* jobs, int n_jobs, hipStream_t st) {
     };
     for (int i = 0; i < n_jobs; ++i) {
         const mmif_pack_job& jb = jobs[i];
-        if (jb.format != MMIF_PACK_X3 || jb.ksize != 3) continue;   // (1x1 layers of fp32 tensors stay on the fp32 FMA kernels: nothing to pack)
+        if (jb.format != MMIF_PACK_X3 || (jb.ksize != 3 && jb.ksize != 1)) continue;
         for (int d = 0; d < 2; ++d) {
             void* dst = d ? jb.packed_dgrad : jb.packed_fwd;
             if (dst == nullptr) continue;
             const int n_out = d ? jb.cin : jb.cout, n_in = d ? jb.cout : jb.cin;
             X3PackImage& im = tab.im[n++];
             im.w = jb.w; im.dst = (bf16_t*)dst; im.cout = jb.cout; im.cin = jb.cin; im.dgrad = d;
-            im.mbw = 32 * x3_mb(n_out); im.nch = x3_nch(n_in); im.pieces = d ? 2 : x3_fwd_pieces();
-            im.total = (long long)x3_nmb(n_out) * im.nch * 9 * 2 * im.mbw * 8;   // elements of the first piece's images
+            im.mbw = 32 * x3_mb(n_out); im.nch = x3_nch(n_in); im.pieces = d ? 2 : x3_fwd_pieces(); im.ks = jb.ksize;
+            im.total = (long long)x3_nmb(n_out) * im.nch * jb.ksize * jb.ksize * 2 * im.mbw * 8;   // elements of the first piece's images
             if (n == X3_PACK_MAX)
                 if (int rc = flush()) return rc;
         }
@@ -733,7 +764,7 @@ int conv_x3_pack_multi(const mmif_pack_job* jobs, int n_jobs, hipStream_t st) {
     return flush();
 }
 
-template <int MB, int NP, int NW, int RJ>
+template <int MB, int NP, int NW, int RJ, int KS = 3>
 static int launch_conv_x3(bool dgrad, const TV& tin, const TV& tout, const TV& tmask, const void* wpk, const float* bias, int n_out, int n_in,
                           int relu, uint64_t mask_bits, uint64_t accum_bits, hipStream_t st) {
     const int tiles_x = cdiv(tout.ws, X3_TW), tiles_y = cdiv(tout.hs, RJ * NW);
@@ -746,19 +777,26 @@ static int launch_conv_x3(bool dgrad, const TV& tin, const TV& tout, const TV& t
     if (abl < 0) { const char* e = getenv("MMIF_X3_ABLATE"); abl = e != nullptr ? atoi(e) : 0; }
     relu = (relu & 255) | (abl << 8);
     if (dgrad)
-        hipLaunchKernelGGL((conv_x3_kernel<MB, true, NP, NW, RJ>), dim3(G), dim3(X3_THREADS), 0, st, tin, tout, tmask, (const uint4*)wpk, bias, n_out, nch, nmb,
+        hipLaunchKernelGGL((conv_x3_kernel<MB, true, NP, NW, RJ, KS>), dim3(G), dim3(X3_THREADS), 0, st, tin, tout, tmask, (const uint4*)wpk, bias, n_out, nch, nmb,
                            relu, (unsigned long long)mask_bits, (unsigned long long)accum_bits, tiles_x, tpi, total);
     else
-        hipLaunchKernelGGL((conv_x3_kernel<MB, false, NP, NW, RJ>), dim3(G), dim3(X3_THREADS), 0, st, tin, tout, tmask, (const uint4*)wpk, bias, n_out, nch, nmb,
+        hipLaunchKernelGGL((conv_x3_kernel<MB, false, NP, NW, RJ, KS>), dim3(G), dim3(X3_THREADS), 0, st, tin, tout, tmask, (const uint4*)wpk, bias, n_out, nch, nmb,
                            relu, (unsigned long long)mask_bits, (unsigned long long)accum_bits, tiles_x, tpi, total);
     return check_launch(dgrad ? "conv_x3 dgrad" : "conv_x3 fwd");
 }
 
 // forward: tin = x, tout = y;  dgrad: tin = gy (halo 0 or folded halo 1), tout = gx (the padded domain is written; the caller folds)
 int conv_x3(bool dgrad, const TV& tin, const TV& tout, const TV& tmask, const void* wpk, const float* bias, int cin, int cout, int relu,
-            uint64_t mask_bits, uint64_t accum_bits, hipStream_t st) {
+            uint64_t mask_bits, uint64_t accum_bits, hipStream_t st, int ks) {
     const int n_out = dgrad ? cin : cout, n_in = dgrad ? cout : cin;
     const bool six = !dgrad && x3_fwd_pieces() == 3;
+    if (ks == 1) {
+        if (x3_mb(n_out) == 2)
+            return six ? launch_conv_x3<2, 3, 8, 2, 1>(false, tin, tout, tmask, wpk, bias, n_out, n_in, relu, mask_bits, accum_bits, st)
+                       : launch_conv_x3<2, 2, 8, 2, 1>(dgrad, tin, tout, tmask, wpk, bias, n_out, n_in, relu, mask_bits, accum_bits, st);
+        return six ? launch_conv_x3<1, 3, 8, 2, 1>(false, tin, tout, tmask, wpk, bias, n_out, n_in, relu, mask_bits, accum_bits, st)
+                   : launch_conv_x3<1, 2, 8, 2, 1>(dgrad, tin, tout, tmask, wpk, bias, n_out, n_in, relu, mask_bits, accum_bits, st);
+    }
     if (x3_mb(n_out) == 2)
         return six ? launch_conv_x3<2, 3, 8, 2>(false, tin, tout, tmask, wpk, bias, n_out, n_in, relu, mask_bits, accum_bits, st)
                    : launch_conv_x3<2, 2, 8, 2>(dgrad, tin, tout, tmask, wpk, bias, n_out, n_in, relu, mask_bits, accum_bits, st);
@@ -772,7 +810,7 @@ int conv_x3(bool dgrad, const TV& tin, const TV& tout, const TV& tmask, const vo
 }
 
 bool wgrad_x3_supported(int ks, int cin, int cout, const TV& tx, const TV& tg) {
-    return x3_enabled() && ks == 3 && cin >= 1 && cout >= 1 && x3_grad_ok(tg) && tx.halo == 0 && tx.h >= 2 && tx.w >= 2 && x3_small(tx) && x3_small(tg);
+    return x3_enabled() && (ks == 3 || ks == 1) && cin >= 1 && cout >= 1 && x3_grad_ok(tg) && tx.halo == 0 && (ks == 1 || (tx.h >= 2 && tx.w >= 2)) && x3_small(tx) && x3_small(tg);
 }
 
 static int wgrad_x3_G(int cin, int cout) {
@@ -783,16 +821,36 @@ static int wgrad_x3_G(int cin, int cout) {
 }
 
 size_t wgrad_x3_workspace(int cin, int cout, int ks) {
+    if (ks == 1) {   // three k-split partials per block
+        const size_t npairs = (size_t)cdiv(cin, 64) * cdiv(cout, 64);
+        size_t G = 256 / npairs;
+        if (G < 1) G = 1;
+        const size_t dyn = (size_t)wgrad_x3_G(cin, cout);
+        if (dyn > G) G = dyn;
+        return 3 * G * npairs * (64 * 64 + 64) * sizeof(float);
+    }
     if (ks != 3) return 0;
     const size_t npairs = (size_t)cdiv(cin, 64) * cdiv(cout, 64);
     size_t G = 256 / npairs;   // upper bound of wgrad_x3_G on any gfx950 part (<= 256 CUs) without asking the device
     if (G < 1) G = 1;
     const size_t dyn = (size_t)wgrad_x3_G(cin, cout);
     if (dyn > G) G = dyn;
-    return G * npairs * XW_PER * sizeof(float);
+    return G * npairs * (64 * 64 * 9 + 64) * sizeof(float);
 }
 
-int wgrad_x3(const TV& tx, const TV& tg, float* dw, float* db, int cin, int cout, int accumulate, float* ws, hipStream_t st) {
+int wgrad_x3(const TV& tx, const TV& tg, float* dw, float* db, int cin, int cout, int accumulate, float* ws, hipStream_t st, int ks) {
+    if (ks == 1) {
+        const int tiles_x = cdiv(tx.w, XW_TW), tiles_y = cdiv(tx.h, 8);
+        const int tpi = tiles_x * tiles_y, total = tpi * tx.n;
+        const int n_icg = cdiv(cin, 64), n_ocg = cdiv(cout, 64);
+        int G = wgrad_x3_G(cin, cout);
+        if (total < G) G = total;
+        hipLaunchKernelGGL((wgrad_x3_kernel<8, 8, 8, 1>), dim3(G * n_icg * n_ocg), dim3(XW_THREADS), 0, st, tx, tg, ws, cin, cout, tiles_x, tpi, total, G, n_icg, n_ocg);
+        if (int rc = check_launch("wgrad_x3 1x1")) return rc;
+        const int n = cout * cin + cout;
+        hipLaunchKernelGGL(wgrad_x3_reduce, dim3(cdiv(n, 64)), dim3(256), 0, st, ws, dw, db, cin, cout, 3 * G, n_icg, n_ocg, accumulate, 1);
+        return check_launch("wgrad_x3_reduce");
+    }
     const bool thin = cin <= 48 && cout <= 16;
     const int th = thin ? 16 : 8;
     const int tiles_x = cdiv(tx.w, XW_TW), tiles_y = cdiv(tx.h, th);
@@ -804,12 +862,12 @@ int wgrad_x3(const TV& tx, const TV& tg, float* dw, float* db, int cin, int cout
     if (abl < 0) { const char* e = getenv("MMIF_X3_ABLATE"); abl = e != nullptr ? atoi(e) : 0; }
     const int tx_abl = tiles_x | (abl << 16);
     if (thin)
-        hipLaunchKernelGGL((wgrad_x3_kernel<16, 6, 2>), dim3(G * n_icg * n_ocg), dim3(XW_THREADS), 0, st, tx, tg, ws, cin, cout, tx_abl, tpi, total, G, n_icg, n_ocg);
+        hipLaunchKernelGGL((wgrad_x3_kernel<16, 6, 2, 3>), dim3(G * n_icg * n_ocg), dim3(XW_THREADS), 0, st, tx, tg, ws, cin, cout, tx_abl, tpi, total, G, n_icg, n_ocg);
     else
-        hipLaunchKernelGGL((wgrad_x3_kernel<8, 8, 8>), dim3(G * n_icg * n_ocg), dim3(XW_THREADS), 0, st, tx, tg, ws, cin, cout, tx_abl, tpi, total, G, n_icg, n_ocg);
+        hipLaunchKernelGGL((wgrad_x3_kernel<8, 8, 8, 3>), dim3(G * n_icg * n_ocg), dim3(XW_THREADS), 0, st, tx, tg, ws, cin, cout, tx_abl, tpi, total, G, n_icg, n_ocg);
     if (int rc = check_launch("wgrad_x3")) return rc;
     const int n = cout * cin * 9 + cout;
-    hipLaunchKernelGGL(wgrad_x3_reduce, dim3(cdiv(n, 64)), dim3(256), 0, st, ws, dw, db, cin, cout, G, n_icg, n_ocg, accumulate);
+    hipLaunchKernelGGL(wgrad_x3_reduce, dim3(cdiv(n, 64)), dim3(256), 0, st, ws, dw, db, cin, cout, G, n_icg, n_ocg, accumulate, 9);
     return check_launch("wgrad_x3_reduce");
 }
 
@@ -823,7 +881,7 @@ extern "C" int32_t mmif_get_x3_forward_pieces(void) { return x3_fwd_pieces(); }
 extern "C" size_t mmif_packed_weight_bytes_x3(int32_t cout, int32_t cin, int32_t ksize) { return conv_x3_packed_bytes(cout, cin, ksize); }
 
 extern "C" int mmif_pack_weights_x3(const float* w, int32_t cout, int32_t cin, int32_t ksize, void* packed_fwd, void* packed_dgrad, void* stream) {
-    MMIF_REQUIRE(ksize == 3, "pack_weights_x3: ksize must be 3");
+    MMIF_REQUIRE(ksize == 3 || ksize == 1, "pack_weights_x3: ksize must be 1 or 3");
     MMIF_REQUIRE(w != nullptr && cout > 0 && cin > 0, "pack_weights_x3: bad arguments");
     mmif_pack_job jb;
     jb.w = w; jb.cout = cout; jb.cin = cin; jb.ksize = ksize; jb.format = MMIF_PACK_X3; jb.packed_fwd = packed_fwd; jb.packed_dgrad = packed_dgrad;

@@ -92,8 +92,8 @@ class BT:
 
 class PackedWeights:
     """MFMA operand images of one conv layer's weights (forward + dgrad).  fmt = BF16: the bf16 kernels' images (bf16 tensors);
-    fmt = F32: the split-bf16 "x3" images, hi = bf16(w) / lo = bf16(w - hi), of the fp32-grade kernels that run fp32 tensors'
-    3x3 layers on the matrix pipe (csrc/conv_x3.hip; a 1x1 layer has no x3 image and stays on the fp32 FMA kernels)."""
+    fmt = F32: the split-bf16 "x3" images (successive bf16 pieces of every weight) of the fp32-grade kernels that run fp32 tensors'
+    3x3 and 1x1 layers on the matrix pipe (csrc/conv_x3.hip)."""
     __slots__ = ("fwd", "dgrad", "cout", "cin", "k", "fmt")
 
     def __init__(self, cout, cin, k, device, fmt=BF16):
@@ -105,11 +105,11 @@ class PackedWeights:
 
     @property
     def usable(self):
-        return self.fmt == BF16 or self.k == 3
+        return self.fmt == BF16 or self.k in (1, 3)
 
     def pack(self, w):
         if self.fmt == F32:
-            if self.k == 3:
+            if self.k in (1, 3):
                 check(lib.mmif_pack_weights_x3(_ptr(w), self.cout, self.cin, self.k, _ptr(self.fwd), _ptr(self.dgrad), stream_ptr()),
                       "pack_weights_x3")
             return

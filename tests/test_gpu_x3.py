@@ -35,15 +35,16 @@ def fwd_pieces(request):
     E.set_x3_forward_pieces(prev)
 
 
+@pytest.mark.parametrize("ks", [3, 1])
 @pytest.mark.parametrize("cout,cin", [(128, 128), (16, 48), (64, 128), (40, 24), (72, 136)])
-def test_x3_operand_images_bit_exact(cout, cin, fwd_pieces):
+def test_x3_operand_images_bit_exact(cout, cin, ks, fwd_pieces):
     """mmif_pack_weights_x3: [m-block][chunk][piece][tap][2 channel blocks][32*MB out][8 in] -- every element against the layout
     formula, forward (2 or 3 pieces) and (flipped, transposed, 2 pieces) dgrad images"""
     from mmif import tensor as T
     from mmif._lib import F32
     torch.manual_seed(cout * 131 + cin)
-    w = (torch.randn(cout, cin, 3, 3) * 0.1)
-    pk = T.PackedWeights(cout, cin, 3, DEV, F32)
+    w = (torch.randn(cout, cin, ks, ks) * 0.1)
+    pk = T.PackedWeights(cout, cin, ks, DEV, F32)
     pk.pack(w.to(DEV))
     torch.cuda.synchronize()
     wn = w.numpy()
@@ -53,12 +54,12 @@ def test_x3_operand_images_bit_exact(cout, cin, fwd_pieces):
         mb = 2 if n_out > 32 else 1
         mbw = 32 * mb
         nmb, nch = -(-n_out // mbw), -(-(-(-n_in // 8)) // 2)
-        wk = np.zeros((nmb * mbw, nch * 16, 3, 3), np.float32)   # [out][in][u][v] in the kernel's view
+        wk = np.zeros((nmb * mbw, nch * 16, ks, ks), np.float32)   # [out][in][u][v] in the kernel's view
         if dgrad:
             wk[:n_out, :n_in] = wn.transpose(1, 0, 2, 3)[:, :, ::-1, ::-1]
         else:
             wk[:n_out, :n_in] = wn
-        want = wk.reshape(nmb, mbw, nch, 2, 8, 9).transpose(0, 2, 5, 3, 1, 4)   # [mb][ch][tap][cbl][ocl][e]
+        want = wk.reshape(nmb, mbw, nch, 2, 8, ks * ks).transpose(0, 2, 5, 3, 1, 4)   # [mb][ch][tap][cbl][ocl][e]
         both = torch.stack(_split(want, pieces), dim=2).contiguous()            # [mb][ch][piece][tap][cbl][ocl][e]
         got = img.cpu().view(torch.bfloat16)[:both.numel()].view(both.shape)
         assert torch.equal(got.view(torch.int16), both.view(torch.int16)), f"dgrad={dgrad}"
@@ -68,9 +69,13 @@ SHAPES = [(128, 128, 2, 37, 53), (16, 16, 2, 40, 70), (48, 16, 1, 33, 64), (16, 
           (128, 64, 1, 19, 33), (24, 40, 2, 9, 100), (136, 88, 1, 20, 36), (8, 8, 1, 2, 2), (72, 152, 1, 17, 34), (64, 64, 3, 8, 16)]
 
 
-@pytest.mark.parametrize("cin,cout,n,h,w", SHAPES, ids=[f"{a}-{b}-{n}x{h}x{w}" for a, b, n, h, w in SHAPES])
+SHAPES_1x1 = [(88, 64, 2, 37, 53), (152, 304, 1, 20, 36), (32, 64, 2, 16, 32), (8, 16, 1, 2, 2), (136, 72, 1, 9, 100), (64, 32, 1, 40, 24)]
+
+
+@pytest.mark.parametrize("cin,cout,n,h,w,ks", [s + (3,) for s in SHAPES] + [s + (1,) for s in SHAPES_1x1],
+                         ids=[f"{a}-{b}-{n}x{h}x{w}" for a, b, n, h, w in SHAPES] + [f"1x1-{a}-{b}-{n}x{h}x{w}" for a, b, n, h, w in SHAPES_1x1])
 @pytest.mark.parametrize("ghalo", [0, 1])
-def test_x3_kernels_vs_fp32_fma_kernels(cin, cout, n, h, w, ghalo, fwd_pieces):
+def test_x3_kernels_vs_fp32_fma_kernels(cin, cout, n, h, w, ks, ghalo, fwd_pieces):
     """forward (bias + ReLU), dgrad (partial mask / accumulate bit sets; upstream gradient and old values vary per element) and wgrad:
     IMPL_X3 vs IMPL_VALU on the same fp32 tensors -- ragged tiles, ragged 16-channel chunks (cin % 16 = 8), ragged 32 / 64-channel
     groups.  The 3-piece forward (six products) must agree to fp32 rounding (2e-6), everything with 2 pieces to 3e-5."""
@@ -84,10 +89,10 @@ def test_x3_kernels_vs_fp32_fma_kernels(cin, cout, n, h, w, ghalo, fwd_pieces):
         gy = gy.as_folded()
     else:
         gy.buf.normal_()
-    wt = torch.randn(cout, cin, 3, 3, device=DEV) * 0.05
+    wt = torch.randn(cout, cin, ks, ks, device=DEV) * 0.05
     b = torch.randn(cout, device=DEV)
-    pk = T.PackedWeights(cout, cin, 3, DEV, F32); pk.pack(wt)
-    ws = torch.empty(T.wgrad_workspace_bytes(cin, cout, 3) // 4 + 1, dtype=torch.float32, device=DEV)
+    pk = T.PackedWeights(cout, cin, ks, DEV, F32); pk.pack(wt)
+    ws = torch.empty(T.wgrad_workspace_bytes(cin, cout, ks) // 4 + 1, dtype=torch.float32, device=DEV)
     mask = 0x5a5a5a5a5a5a & ((1 << x.cb) - 1)
     acc_bits = 0x333333333333 & ((1 << x.cb) - 1)
     res = {}
@@ -96,9 +101,9 @@ def test_x3_kernels_vs_fp32_fma_kernels(cin, cout, n, h, w, ghalo, fwd_pieces):
         gx = T.BT.alloc(n, cin, h, w, torch.float32, DEV, halo=1, zero=True)
         gx.buf.copy_(torch.sin(torch.arange(gx.buf.numel(), device=DEV, dtype=torch.float32)).view_as(gx.buf))   # old values differ per element
         dw, db = torch.full_like(wt, 0.5), torch.full_like(b, -0.5)
-        T.conv_fwd(x, wt, b, y, cin, cout, 3, True, pk, impl)
-        T.conv_dgrad(gy, wt, x, gx, cin, cout, 3, mask, acc_bits, pk, impl)
-        T.conv_wgrad(x, gy, dw, db, cin, cout, 3, ws, True, impl)
+        T.conv_fwd(x, wt, b, y, cin, cout, ks, True, pk, impl)
+        T.conv_dgrad(gy, wt, x, gx, cin, cout, ks, mask, acc_bits, pk, impl)
+        T.conv_wgrad(x, gy, dw, db, cin, cout, ks, ws, True, impl)
         torch.cuda.synchronize()
         res[impl] = [t.cpu().numpy() for t in (y.buf, gx.buf, dw, db)]
     for (a, r, what) in zip(res[IMPL_X3], res[IMPL_VALU], ("y", "gx", "dw", "db")):
