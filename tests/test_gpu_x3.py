@@ -157,3 +157,43 @@ def test_x3_is_the_default_for_fp32_and_can_be_forced_off():
     pkb = T.PackedWeights(cout, cin, 3, DEV, BF16); pkb.pack(wt)
     with pytest.raises(MmifError):    # a bf16-format image is not an x3 image: never reinterpreted
         T.conv_fwd(x, wt, b, y, cin, cout, 3, True, pkb, IMPL_X3)
+
+
+def test_forward_relu_decisions_agree_with_fp32_kernels():
+    """Why the forward pass uses three pieces (six products): the ReLU decision [pre-activation > 0] of decode.0 (128 -> 128) at
+    2 x 256 x 256 on the x3 kernels against the fp32 FMA kernels, on post-ReLU-like inputs.  With six products the two agree as two fp32
+    implementations do (a handful of 16.8 M decisions, all on pre-activations at fp32 rounding noise); with three products the count is
+    an order of magnitude larger -- each such flip moves the parameter gradients of every layer below by O(1 / sqrt(pixels))."""
+    from mmif import engine as E
+    from mmif import tensor as T
+    from mmif._lib import F32, IMPL_VALU, IMPL_X3, lib
+    torch.manual_seed(77)
+    n, c, S = 2, 128, 256
+    x = T.BT.alloc(n, c, S, S, torch.float32, DEV)
+    x.buf.normal_().clamp_(min=0)                     # what a ReLU layer hands on
+    wt = torch.randn(c, c, 3, 3, device=DEV) * (2.0 / (c * 9)) ** 0.5
+    b = torch.randn(c, device=DEV) * 0.05
+    y0 = T.BT.alloc(n, c, S, S, torch.float32, DEV)
+    T.conv_fwd(x, wt, b, y0, c, c, 3, True, None, IMPL_VALU)
+    ref = y0.buf > 0
+    prev = lib.mmif_get_x3_forward_pieces()
+    flips = {}
+    try:
+        for pieces in (3, 2):
+            E.set_x3_forward_pieces(pieces)
+            pk = T.PackedWeights(c, c, 3, DEV, F32); pk.pack(wt)
+            y = T.BT.alloc(n, c, S, S, torch.float32, DEV)
+            T.conv_fwd(x, wt, b, y, c, c, 3, True, pk, IMPL_X3)
+            torch.cuda.synchronize()
+            diff = (y.buf > 0) != ref
+            flips[pieces] = int(diff.sum())
+            # a flipped element is one whose value is at the kernels' own error level on BOTH sides
+            worst = max(float((y.buf.abs() * diff).max()), float((y0.buf.abs() * diff).max()))
+            scale = float(y0.buf.max())
+            assert worst <= (1e-6 if pieces == 3 else 5e-5) * scale, (pieces, worst, scale)
+    finally:
+        E.set_x3_forward_pieces(prev)
+    total = ref.numel()
+    print(f"ReLU decisions that differ from the fp32 FMA kernels, of {total}: six products {flips[3]}, three products {flips[2]}")
+    assert flips[3] <= 32, flips                       # fp32 summation-order noise
+    assert flips[3] * 4 <= max(flips[2], 8), flips      # ... and several times rarer than with three products
