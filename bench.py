@@ -181,7 +181,9 @@ def parity_leg(args, dev, img1, img2):
         err_img = float(np.abs(f.detach().cpu().numpy() - ref["imgf"]).max() / np.abs(ref["imgf"]).max())
         gerr = max(float(np.abs(p.grad.cpu().numpy() - ref["grads"][k]).max() / max(np.abs(ref["grads"][k]).max(), 1e-12)) for k, p in m.named_parameters())
         B = img1.shape[0]
-        return {"dtype": f"fp32 storage; 3x3 layers as split-bf16 MFMA products ({2 * lib.mmif_get_x3_forward_pieces()} per tap forward, 3 backward), fp32 accumulate",
+        mode = lib.mmif_get_x3_forward_pieces()
+        fwd = {16: "3 products of scaled fp16 pieces", 3: "6 products of bf16 pieces", 2: "3 products of bf16 pieces"}[mode]
+        return {"dtype": f"fp32 storage; 3x3 / 1x1 layers as split-operand MFMA products (forward: {fwd}; backward: 3 products of bf16 pieces), fp32 accumulate",
                 "value": B * args.parity_steps / dt, "unit": "image-pairs/s", "ms_per_step": dt / args.parity_steps * 1e3, "steps": args.parity_steps,
                 "rel_err_vs_oracle": err_img, "loss_abs_err_vs_oracle": abs(float(tot.item()) - float(ref["losses"][3])), "grad_rel_err_vs_oracle": gerr,
                 "oracle_sample": "2 pairs 64x64, closed-form weights / images: max |fused image - oracle| / max|oracle|; max over parameters of max |grad - oracle| / max|oracle grad|",
@@ -320,8 +322,8 @@ def main():
                     # fp32 tensors: the split-bf16 kernel issues `prods` bf16 MFMA products per algorithmic product; its roofline is the
                     # bf16 matrix peak over the MFMA flops it really executes
                     from mmif._lib import lib as _l
-                    prods = 2 * _l.mmif_get_x3_forward_pieces() if args.roofline_tag.endswith(":fwd") else 3
-                    kname = f"conv_x3_kernel ({prods} bf16 products per tap)"
+                    prods = {16: 3, 3: 6, 2: 3}[_l.mmif_get_x3_forward_pieces()] if args.roofline_tag.endswith(":fwd") else 3
+                    kname = f"conv_x3_kernel ({prods} half-precision MFMA products per tap)"
                     ach *= prods
                 roof = {"bound": "mfma", "kernel": f"{kname} {s.cin}->{s.cout} k{s.k} ({args.roofline_tag})",
                         "achieved": ach / 1e12, "peak": PEAK_MFMA_BF16 / 1e12,

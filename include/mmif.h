@@ -101,11 +101,13 @@ int mmif_pack_weights_multi(const mmif_pack_job* jobs, int32_t n_jobs, void* str
  * pieces hi = bf16(w), mid = bf16(w - hi) [, lo = bf16(w - hi - mid)]; layout [m-block][16-channel chunk][piece][tap][2 channel
  * blocks][32 or 64 out channels][8] (csrc/conv_x3.hip).
  * Pass them as w_packed / w_packed_t of the conv entry points below when the tensors are fp32.  ksize 1 or 3. */
-/* Pieces of the FORWARD image: 3 (default: hi / mid / lo, six products per tap -- fp32-grade activations, so ReLU decisions agree with the
- * reference's as often as between two fp32 implementations) or 2 (three products, activations within ~1e-5; a mask flip on a
- * pre-activation that close to zero moves parameter gradients by O(1e-3)).  The dgrad image always has 2 (the backward kernels are
- * linear in the gradient).  Process-wide setting, also $MMIF_X3_FWD_PIECES; set it BEFORE packing: the forward kernel reads the image
- * in the current format. */
+/* Operand format of the FORWARD image / kernels: 16 (default) = two SCALED FP16 pieces (2^10 w = hi + lo), three products per tap,
+ * 2^-23 per product -- fp32-grade activations, so ReLU decisions agree with the reference's as often as between two fp32
+ * implementations; activations are scaled per staged tile (any magnitude up to 2^114), weights saturate at |w| >= 64;  3 = three bf16
+ * pieces, six products, the same accuracy on bf16's own range at twice the forward MFMA work;  2 = two bf16 pieces, three products, activations within
+ * ~1e-5 (a mask flip on a pre-activation that close to zero moves parameter gradients by O(1e-3)).  The dgrad image always has two bf16
+ * pieces (the backward kernels are linear in the gradient: no decisions to protect).  Process-wide setting, also
+ * $MMIF_X3_FWD_PIECES; set it BEFORE packing: the forward kernel reads the image in the current format. */
 void mmif_set_x3_forward_pieces(int32_t pieces);
 int32_t mmif_get_x3_forward_pieces(void);
 size_t mmif_packed_weight_bytes_x3(int32_t cout, int32_t cin, int32_t ksize);

@@ -43,9 +43,16 @@ static size_t x3_packed_bytes(int n_out, int n_in, int pieces, int ks = 3) {
     return (size_t)x3_nmb(n_out) * x3_nch(n_in) * pieces * ks * ks * 2 * 32 * x3_mb(n_out) * 16;
 }
 
+// scaled-fp16 pieces of the forward operands (see x3_split_pair_h below)
+typedef _Float16 x3_h8 __attribute__((ext_vector_type(8)));
+constexpr float X3_SW = 1024.f, X3_HMAX = 65000.f;   // weights: fixed 2^10 (|w| < 64; smaller than 1.2e-4 = subnormal lo piece)
+constexpr int X3_SW_EXP = 10;
+__host__ __device__ inline unsigned short x3_f16_bits(float v) { return __builtin_bit_cast(unsigned short, (_Float16)v); }
+__host__ __device__ inline float x3_f16_val(unsigned short b) { return (float)__builtin_bit_cast(_Float16, b); }
+
 // ------------------------------------------------------------------ weight packing
 constexpr int X3_PACK_MAX = 64;
-struct X3PackImage { const float* w; bf16_t* dst; long long total; int cout, cin, dgrad, mbw, nch, pieces, ks; };
+struct X3PackImage { const float* w; bf16_t* dst; long long total; int cout, cin, dgrad, mbw, nch, pieces, ks, f16; };
 struct X3PackTable { X3PackImage im[X3_PACK_MAX]; };
 
 // dgrad == 0: out = o, in = c, Wk[u][v] = W[o][c][u][v];  dgrad == 1: out = c, in = o, Wk[u][v] = W[o][c][2-u][2-v]
@@ -73,6 +80,13 @@ __global__ void x3_pack_kernel(X3PackTable tab) {
         const long long piece = (long long)taps * 2 * J.mbw * 8;
         const long long within = ((long long)(tap * 2 + cbl) * J.mbw + ocl) * 8 + e;
         const long long base = ((long long)mb * J.nch + ch) * J.pieces * piece;
+        if (J.f16) {   // two fp16 pieces of 2^10 w (saturating), see x3_split_pair_h
+            val = fminf(fmaxf(val * X3_SW, -X3_HMAX), X3_HMAX);
+            const unsigned short h = x3_f16_bits(val);
+            J.dst[base + within] = h;
+            J.dst[base + piece + within] = x3_f16_bits(val - x3_f16_val(h));
+            continue;
+        }
         for (int p = 0; p < J.pieces; ++p) {   // successive bf16 roundings of the remainder (each subtraction is exact in fp32)
             const bf16_t q = f32_to_bf16(val);
             J.dst[base + p * piece + within] = q;
@@ -109,6 +123,37 @@ __device__ inline void x3_split_gran(const X3Gran& g, x3_u4 (&out)[NP]) {
 
 __device__ inline x3_bf16x8 x3_frag(const x3_u4& v) { return __builtin_bit_cast(x3_bf16x8, v); }
 
+// ---- the FP16 form of the split (forward pass, "F16" kernels): two fp16 pieces of the value SCALED by a power of two,
+//          s x = hi + lo + r,   hi = fp16(s x),   lo = fp16(s x - hi),   |r| <= 2^-24 |s x|        (11 + 11 significant bits)
+// so the three products hi*hi + hi*lo + lo*hi already carry 2^-23 per product -- fp32 grade with THREE MFMAs instead of the six the bf16
+// pieces (8 bits each) need.  What fp16 lacks is range, so the scale is ADAPTIVE: weights carry a fixed 2^10 (1.2e-4 <= |w| < 64 at
+// full precision, saturating beyond), activations the largest power of two that keeps the block's staged tile below 2^15 -- the block
+// takes the maximum |x| of every chunk it stages (registers -> wave reduce -> 8 LDS slots, read after the barrier the staging needs
+// anyway) and the exponent of an item is the running minimum over its chunks; when a later chunk forces a smaller exponent the fp32
+// accumulators are rescaled by that power of two (exact), and the epilogue scales back.  Every piece is therefore exact to 2^-24 of the
+// LARGEST magnitude that enters the sum, whatever the tensor's scale (1e-30 or 1e30: test_fp16_forward_range_window).  The backward
+// kernels keep the bf16 pieces (gradients sit around 1e-7 .. 1e-2 and 1e-5 is all they need).
+__device__ inline void x3_split_pair_h(float v0, float v1, unsigned (&q)[2]) {   // v0, v1 already scaled (|v| < 2^15 by construction)
+    const unsigned short h0 = x3_f16_bits(v0), h1 = x3_f16_bits(v1);
+    q[0] = (unsigned)h0 | ((unsigned)h1 << 16);
+    q[1] = (unsigned)x3_f16_bits(v0 - x3_f16_val(h0)) | ((unsigned)x3_f16_bits(v1 - x3_f16_val(h1)) << 16);
+}
+__device__ inline float x3_pow2(int e) { return __uint_as_float((unsigned)(127 + e) << 23); }   // 2^e, -126 <= e <= 127
+__device__ inline void x3_split_gran_h(const X3Gran& g, float sx, x3_u4 (&out)[2]) {
+    unsigned q0[2], q1[2], q2[2], q3[2];
+    x3_split_pair_h(g.a.x * sx, g.a.y * sx, q0);
+    x3_split_pair_h(g.a.z * sx, g.a.w * sx, q1);
+    x3_split_pair_h(g.b.x * sx, g.b.y * sx, q2);
+    x3_split_pair_h(g.b.z * sx, g.b.w * sx, q3);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) out[p] = (x3_u4){q0[p], q1[p], q2[p], q3[p]};
+}
+template <bool F16>
+__device__ inline f32x16 x3_mfma(const x3_bf16x8& a, const x3_bf16x8& b, const f32x16& c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(x3_h8, a), __builtin_bit_cast(x3_h8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
 // products (A piece, B piece) accumulated per tap, smallest first.  NP = 2: lo*hi + hi*lo + hi*hi (error ~2^-17 per product);
 // NP = 3: mid*mid + lo*hi + hi*lo + mid*hi + hi*mid + hi*hi (what is dropped is below 2^-25: fp32 grade)
 template <int NP> struct X3Prod;
@@ -132,7 +177,7 @@ constexpr int X3_BIAS_G = 128;   // granules reserved behind the tiles for the b
 // kernels (profiles/r03_pmc_sq_x3.txt): the matrix pipe is busy 58 % (2 pieces) / 74 % (3 pieces) of the cycles, i.e. a constant
 // ~5 k cycles per 16 input channels of split + LDS-write + issue work that no barrier arrangement removes, at 1.7-1.8 GHz (the chip
 // clocks dense MFMA work down: the 2.5 PFLOP/s peak assumes 2.4 GHz).
-template <int MB, bool DGRAD, int NP, int NW, int RJ, int KS>
+template <int MB, bool DGRAD, int NP, int NW, int RJ, int KS, bool F16 = false>
 __global__ __launch_bounds__(64 * NW, 2) void conv_x3_kernel(TV tin, TV tout, TV tmask, const uint4* __restrict__ wpk,
                                                               const float* __restrict__ bias, int n_out, int nch16, int nmb, int relu,
                                                               unsigned long long mask_bits, unsigned long long accum_bits, int tiles_x,
@@ -150,7 +195,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_x3_kernel(TV tin, TV tout, TV
     constexpr int W_ROUNDS = (WGC + X3_THREADS - 1) / X3_THREADS;
     constexpr int BUF_G = NP * ING + WGC;
     constexpr int NPROD = X3Prod<NP>::N;
-    __shared__ __attribute__((aligned(16))) x3_u4 s_buf[BUF_G + X3_BIAS_G];
+    __shared__ __attribute__((aligned(16))) x3_u4 s_buf[BUF_G + X3_BIAS_G + 2];   // + 8 floats: the waves' tile maxima (F16)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -225,14 +270,38 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_x3_kernel(TV tin, TV tout, TV
             if (e < nw && !((abl & 2) && s > 0)) rw[k] = src[e];
         }
     };
+    // F16: the exponent the chunk being staged is scaled with (running minimum over the item's chunks), set by stage_scale()
+    int e_stage = 0;
+    auto tile_max = [&]() {      // every wave's maximum |x| of the staged registers -> LDS slot (read after the next barrier)
+        float m = 0.f;
+#pragma unroll
+        for (int k = 0; k < IN_ROUNDS; ++k)
+            m = fmaxf(m, fmaxf(fmaxf(fmaxf(fabsf(rin[k].a.x), fabsf(rin[k].a.y)), fmaxf(fabsf(rin[k].a.z), fabsf(rin[k].a.w))),
+                             fmaxf(fmaxf(fabsf(rin[k].b.x), fabsf(rin[k].b.y)), fmaxf(fabsf(rin[k].b.z), fabsf(rin[k].b.w)))));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if (lane == 0) reinterpret_cast<float*>(s_buf + BUF_G + X3_BIAS_G)[wave] = m;
+    };
+    auto stage_scale = [&](bool first_chunk) {   // after the barrier: block maximum -> exponent with max * 2^e in [2^14, 2^15)
+        const float* sm = reinterpret_cast<const float*>(s_buf + BUF_G + X3_BIAS_G);
+        float m = 0.f;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) m = fmaxf(m, sm[i]);
+        const int k = (int)((__float_as_uint(m) >> 23) & 255u) - 126;       // m = f * 2^k, f in [0.5, 1)
+        int e = m > 0.f ? 15 - k : 100;
+        e = min(max(e, -100), 100);
+        e_stage = first_chunk ? e : min(e_stage, e);
+    };
     auto commit = [&]() {
         if (abl & 4) { if (done_first) return; done_first = true; }
+        const float sx = F16 ? x3_pow2(e_stage) : 1.f;
 #pragma unroll
         for (int k = 0; k < IN_ROUNDS; ++k) {
             const int e = tid + X3_THREADS * k;
             if (e < ING) {
                 x3_u4 pc[NP];
-                x3_split_gran<NP>(rin[k], pc);
+                if constexpr (F16) x3_split_gran_h(rin[k], sx, pc);
+                else x3_split_gran<NP>(rin[k], pc);
 #pragma unroll
                 for (int p = 0; p < NP; ++p) s_buf[p * ING + e] = pc[p];
             }
@@ -257,11 +326,28 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_x3_kernel(TV tin, TV tout, TV
     const int abase = cbl * MBW + nl;                           // + kk * NP * WG + piece * WG + tap * 2 * MBW + m * 32
 
     issue(0);
+    if constexpr (F16) {
+        tile_max();
+        __syncthreads();
+        stage_scale(true);
+    }
     commit();
     __syncthreads();
+    int e_acc = e_stage, e_cur = e_stage;   // F16: exponent the accumulators hold / the chunk in LDS was staged with
 
     for (int s = 0; s < nsteps; ++s) {
         if (s + 1 < nsteps) issue(s + 1);
+        if constexpr (F16) {   // this chunk was staged with e_cur <= the exponent of the item's earlier chunks: bring the accumulators down
+            if (s % nch == 0) e_acc = e_cur;
+            else if (e_cur < e_acc) {
+                const float f = x3_pow2(max(e_cur - e_acc, -126));
+#pragma unroll
+                for (int m = 0; m < MB; ++m)
+#pragma unroll
+                    for (int j = 0; j < RJ; ++j) acc[m][j] *= f;
+                e_acc = e_cur;
+            }
+        }
         // ---------------- the chunk's KK x 9 taps: operand fragments of tap t+1 are fetched while tap t's MFMAs run ----------------
         const int nkk = min(KK, nch16 - (s % nch) * KK);
 #pragma unroll
@@ -314,7 +400,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_x3_kernel(TV tin, TV tout, TV
                             for (int j = j0; j < j0 + 2; ++j)
 #pragma unroll
                                 for (int m = 0; m < MB; ++m)
-                                    acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[t & 1][m][X3Prod<NP>::A[q]], brow[u + j][X3Prod<NP>::B[q]], acc[m][j], 0, 0, 0);
+                                    acc[m][j] = x3_mfma<F16>(afr[t & 1][m][X3Prod<NP>::A[q]], brow[u + j][X3Prod<NP>::B[q]], acc[m][j]);
                     // the prefetch reads ride between this tap's first MFMAs
                     for (int i = 0; i < nld; ++i) {
                         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
@@ -374,6 +460,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_x3_kernel(TV tin, TV tout, TV
                         x3_f4 v = {acc[m][j][4 * q], acc[m][j][4 * q + 1], acc[m][j][4 * q + 2], acc[m][j][4 * q + 3]};
                         if (!DGRAD) {
                             const x3_f4 b4 = *reinterpret_cast<const x3_f4*>(reinterpret_cast<const float*>(s_buf + BUF_G) + ocb * 8 + 4 * half);
+                            if constexpr (F16) v *= x3_pow2(max(-(e_acc + X3_SW_EXP), -126));   // the accumulators hold 2^(e_acc + 10) z
                             v += b4;
                             if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                         } else {
@@ -390,7 +477,12 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_x3_kernel(TV tin, TV tout, TV
             }
         }
         if (s + 1 < nsteps) {
+            if constexpr (F16) tile_max();
             __syncthreads();   // every wave has finished reading the tile
+            if constexpr (F16) {
+                stage_scale((s + 1) % nch == 0);
+                e_cur = e_stage;
+            }
             commit();
         }
         __syncthreads();
@@ -719,14 +811,17 @@ bool conv_x3_supported(bool dgrad, int ks, int cin, int cout, const TV& tin, con
     return (ks == 1 || (tin.h >= 2 && tin.w >= 2)) && x3_small(tin) && x3_small(tout);
 }
 
-// pieces of the FORWARD pass's operands: 3 (default; 6 products, fp32-grade activations, so ReLU decisions agree with the reference's as
-// often as any fp32 implementation's) or 2 (3 products, activations within ~1e-5).  Process wide; set it before packing
-// (mmif_set_x3_forward_pieces, $MMIF_X3_FWD_PIECES).  The backward kernels are linear in the gradient and always use 2.
+// operand format of the FORWARD pass: 16 (default) = two SCALED FP16 pieces, 3 products, fp32-grade (2^-23 per product); 3 = three bf16
+// pieces, 6 products, fp32-grade, no range limits (activations beyond +-4.1e3 or weights beyond +-64 saturate in the fp16 form); 2 = two
+// bf16 pieces, 3 products, activations within ~1e-5 (ReLU decisions differ from the reference's ~10x as often as between two fp32
+// implementations).  Process wide; set it before packing (mmif_set_x3_forward_pieces, $MMIF_X3_FWD_PIECES = 16 | 3 | 2).  The
+// backward kernels are linear in the gradient and always use two bf16 pieces.
 static int g_fwd_pieces = 0;
+static int x3_norm_mode(int m) { return (m == 2 || m == 3) ? m : 16; }
 int x3_fwd_pieces() {
     if (g_fwd_pieces == 0) {
         const char* e = getenv("MMIF_X3_FWD_PIECES");
-        g_fwd_pieces = (e != nullptr && e[0] == '2') ? 2 : 3;
+        g_fwd_pieces = x3_norm_mode(e != nullptr ? atoi(e) : 16);
     }
     return g_fwd_pieces;
 }
@@ -755,7 +850,9 @@ int conv_x3_pack_multi(const mmif_pack_job* jobs, int n_jobs, hipStream_t st) {
             const int n_out = d ? jb.cin : jb.cout, n_in = d ? jb.cout : jb.cin;
             X3PackImage& im = tab.im[n++];
             im.w = jb.w; im.dst = (bf16_t*)dst; im.cout = jb.cout; im.cin = jb.cin; im.dgrad = d;
-            im.mbw = 32 * x3_mb(n_out); im.nch = x3_nch(n_in); im.pieces = d ? 2 : x3_fwd_pieces(); im.ks = jb.ksize;
+            im.mbw = 32 * x3_mb(n_out); im.nch = x3_nch(n_in); im.ks = jb.ksize;
+            im.f16 = (!d && x3_fwd_pieces() == 16) ? 1 : 0;
+            im.pieces = (d || im.f16) ? 2 : x3_fwd_pieces();
             im.total = (long long)x3_nmb(n_out) * im.nch * jb.ksize * jb.ksize * 2 * im.mbw * 8;   // elements of the first piece's images
             if (n == X3_PACK_MAX)
                 if (int rc = flush()) return rc;
@@ -764,7 +861,7 @@ int conv_x3_pack_multi(const mmif_pack_job* jobs, int n_jobs, hipStream_t st) {
     return flush();
 }
 
-template <int MB, int NP, int NW, int RJ, int KS = 3>
+template <int MB, int NP, int NW, int RJ, int KS = 3, bool F16 = false>
 static int launch_conv_x3(bool dgrad, const TV& tin, const TV& tout, const TV& tmask, const void* wpk, const float* bias, int n_out, int n_in,
                           int relu, uint64_t mask_bits, uint64_t accum_bits, hipStream_t st) {
     const int tiles_x = cdiv(tout.ws, X3_TW), tiles_y = cdiv(tout.hs, RJ * NW);
@@ -780,7 +877,7 @@ static int launch_conv_x3(bool dgrad, const TV& tin, const TV& tout, const TV& t
         hipLaunchKernelGGL((conv_x3_kernel<MB, true, NP, NW, RJ, KS>), dim3(G), dim3(X3_THREADS), 0, st, tin, tout, tmask, (const uint4*)wpk, bias, n_out, nch, nmb,
                            relu, (unsigned long long)mask_bits, (unsigned long long)accum_bits, tiles_x, tpi, total);
     else
-        hipLaunchKernelGGL((conv_x3_kernel<MB, false, NP, NW, RJ, KS>), dim3(G), dim3(X3_THREADS), 0, st, tin, tout, tmask, (const uint4*)wpk, bias, n_out, nch, nmb,
+        hipLaunchKernelGGL((conv_x3_kernel<MB, false, NP, NW, RJ, KS, F16>), dim3(G), dim3(X3_THREADS), 0, st, tin, tout, tmask, (const uint4*)wpk, bias, n_out, nch, nmb,
                            relu, (unsigned long long)mask_bits, (unsigned long long)accum_bits, tiles_x, tpi, total);
     return check_launch(dgrad ? "conv_x3 dgrad" : "conv_x3 fwd");
 }
@@ -789,24 +886,28 @@ static int launch_conv_x3(bool dgrad, const TV& tin, const TV& tout, const TV& t
 int conv_x3(bool dgrad, const TV& tin, const TV& tout, const TV& tmask, const void* wpk, const float* bias, int cin, int cout, int relu,
             uint64_t mask_bits, uint64_t accum_bits, hipStream_t st, int ks) {
     const int n_out = dgrad ? cin : cout, n_in = dgrad ? cout : cin;
-    const bool six = !dgrad && x3_fwd_pieces() == 3;
+    const bool six = !dgrad && x3_fwd_pieces() == 3, h16 = !dgrad && x3_fwd_pieces() == 16;
+#define X3_ARGS tin, tout, tmask, wpk, bias, n_out, n_in, relu, mask_bits, accum_bits, st
     if (ks == 1) {
-        if (x3_mb(n_out) == 2)
-            return six ? launch_conv_x3<2, 3, 8, 2, 1>(false, tin, tout, tmask, wpk, bias, n_out, n_in, relu, mask_bits, accum_bits, st)
-                       : launch_conv_x3<2, 2, 8, 2, 1>(dgrad, tin, tout, tmask, wpk, bias, n_out, n_in, relu, mask_bits, accum_bits, st);
-        return six ? launch_conv_x3<1, 3, 8, 2, 1>(false, tin, tout, tmask, wpk, bias, n_out, n_in, relu, mask_bits, accum_bits, st)
-                   : launch_conv_x3<1, 2, 8, 2, 1>(dgrad, tin, tout, tmask, wpk, bias, n_out, n_in, relu, mask_bits, accum_bits, st);
+        if (x3_mb(n_out) == 2) {
+            if (h16) return launch_conv_x3<2, 2, 8, 2, 1, true>(false, X3_ARGS);
+            return six ? launch_conv_x3<2, 3, 8, 2, 1>(false, X3_ARGS) : launch_conv_x3<2, 2, 8, 2, 1>(dgrad, X3_ARGS);
+        }
+        if (h16) return launch_conv_x3<1, 2, 8, 2, 1, true>(false, X3_ARGS);
+        return six ? launch_conv_x3<1, 3, 8, 2, 1>(false, X3_ARGS) : launch_conv_x3<1, 2, 8, 2, 1>(dgrad, X3_ARGS);
     }
-    if (x3_mb(n_out) == 2)
-        return six ? launch_conv_x3<2, 3, 8, 2>(false, tin, tout, tmask, wpk, bias, n_out, n_in, relu, mask_bits, accum_bits, st)
-                   : launch_conv_x3<2, 2, 8, 2>(dgrad, tin, tout, tmask, wpk, bias, n_out, n_in, relu, mask_bits, accum_bits, st);
+    if (x3_mb(n_out) == 2) {
+        if (h16) return launch_conv_x3<2, 2, 8, 2, 3, true>(false, X3_ARGS);
+        return six ? launch_conv_x3<2, 3, 8, 2>(false, X3_ARGS) : launch_conv_x3<2, 2, 8, 2>(dgrad, X3_ARGS);
+    }
     // <= 32 output channels: one 32-channel accumulator tile per pixel row, so a wave takes FOUR rows (32 x 32 pixel tiles) in the
     // 3-piece forward: the same 216 MFMAs per wave and barrier as the 64-channel kernels for half the weight staging ($MMIF_X3_RJ4=0: two)
     static int rj4 = -1;
     if (rj4 < 0) { const char* e = getenv("MMIF_X3_RJ4"); rj4 = (e != nullptr && e[0] == '0') ? 0 : 1; }
-    if (six) return rj4 ? launch_conv_x3<1, 3, 8, 4>(false, tin, tout, tmask, wpk, bias, n_out, n_in, relu, mask_bits, accum_bits, st)
-                        : launch_conv_x3<1, 3, 8, 2>(false, tin, tout, tmask, wpk, bias, n_out, n_in, relu, mask_bits, accum_bits, st);
-    return launch_conv_x3<1, 2, 8, 2>(dgrad, tin, tout, tmask, wpk, bias, n_out, n_in, relu, mask_bits, accum_bits, st);
+    if (h16) return launch_conv_x3<1, 2, 8, 2, 3, true>(false, X3_ARGS);
+    if (six) return rj4 ? launch_conv_x3<1, 3, 8, 4>(false, X3_ARGS) : launch_conv_x3<1, 3, 8, 2>(false, X3_ARGS);
+    return launch_conv_x3<1, 2, 8, 2>(dgrad, X3_ARGS);
+#undef X3_ARGS
 }
 
 bool wgrad_x3_supported(int ks, int cin, int cout, const TV& tx, const TV& tg) {
@@ -875,7 +976,7 @@ int wgrad_x3(const TV& tx, const TV& tg, float* dw, float* db, int cin, int cout
 
 using namespace mmif;
 
-extern "C" void mmif_set_x3_forward_pieces(int32_t pieces) { g_fwd_pieces = pieces == 2 ? 2 : 3; }
+extern "C" void mmif_set_x3_forward_pieces(int32_t pieces) { g_fwd_pieces = x3_norm_mode(pieces); }
 extern "C" int32_t mmif_get_x3_forward_pieces(void) { return x3_fwd_pieces(); }
 
 extern "C" size_t mmif_packed_weight_bytes_x3(int32_t cout, int32_t cin, int32_t ksize) { return conv_x3_packed_bytes(cout, cin, ksize); }

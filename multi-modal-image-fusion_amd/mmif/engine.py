@@ -80,9 +80,10 @@ def x3_enabled():
 
 
 def set_x3_forward_pieces(pieces):
-    """Operand pieces of the x3 FORWARD kernels: 3 (default; six bf16 products per tap, fp32-grade activations) or 2 (three products,
-    activations within ~1e-5 of fp32, forward convs twice as fast).  Process wide; operand images are re-packed on the next forward."""
-    assert pieces in (2, 3)
+    """Operand format of the x3 FORWARD kernels: 16 (default) = two scaled fp16 pieces, three products per tap, fp32-grade; 3 = three
+    bf16 pieces, six products, fp32-grade (weights beyond |w| >= 64 too); 2 = two bf16 pieces, three products, activations within ~1e-5 of
+    fp32.  Process wide; operand images are re-packed on the next forward."""
+    assert pieces in (2, 3, 16)
     if _lib.lib.mmif_get_x3_forward_pieces() != pieces:
         _lib.lib.mmif_set_x3_forward_pieces(pieces)
         WEIGHTS_EPOCH[0] += 1
