@@ -2110,6 +2110,7 @@ static int num_cus_() {
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
         if (n <= 0) n = 256;
+        if (const char* e = getenv("MMIF_NUM_CUS")) n = atoi(e) > 0 ? atoi(e) : n;   // (experiments: persistent grids on part of the chip)
     }
     return n;
 }
@@ -2142,6 +2143,7 @@ static int launch_conv_dma(bool dgrad, const TV& tin, const TV& tout, const TV& 
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_num_cus = prop.multiProcessorCount;
         if (g_num_cus <= 0) g_num_cus = 256;
+        if (const char* e = getenv("MMIF_NUM_CUS")) g_num_cus = atoi(e) > 0 ? atoi(e) : g_num_cus;
     }
     int G = g_num_cus / 8 * 8;   // one persistent block per CU (150 KB of LDS each)
     if (G < 8) G = 8;

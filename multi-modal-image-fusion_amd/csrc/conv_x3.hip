@@ -788,6 +788,7 @@ static int x3_num_cus() {
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
         if (n <= 0) n = 256;
+        if (const char* e = getenv("MMIF_NUM_CUS")) n = atoi(e) > 0 ? atoi(e) : n;   // (experiments: persistent grids on part of the chip)
     }
     return n;
 }
