@@ -491,16 +491,18 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_x3_kernel(TV tin, TV tout, TV
 
 // ------------------------------------------------------------------ wgrad
 constexpr int XW_TW = 16;                        // pixel-tile columns = the 16 pixels of one k-step
-constexpr int XW_THREADS = 768;
+constexpr int XW_THREADS = 768;                  // (the 12-wave instantiations; wgrad_x3_kernel's NWV)
 
 // TH x 16 pixel tiles, NXC / NGC channel blocks of the activation / gradient group kept in LDS.  <8, 8, 8>: the general 64 x 64 channel
 // pair.  <16, 6, 2>: layers with <= 48 input and <= 16 output channels (the DenseBlock convs, decode.3) -- the same LDS and staging
 // budget spent on TWICE the pixels per tile: those layers run one tile per ~3 us of global-load latency whatever the tile holds
 // (0.18-0.30 ms per launch with almost no MFMA work), so half the tiles is half the time.  Channel blocks past NXC / NGC are read
 // from the last plane kept (those dW rows / columns belong to channels the layer does not have and are never reduced).
-template <int TH, int NXC, int NGC, int KS>
-__global__ __launch_bounds__(XW_THREADS) void wgrad_x3_kernel(TV tx, TV tg, float* __restrict__ partial, int cin, int cout, int tiles_x, int tpi,
+template <int TH, int NXC, int NGC, int KS, int NWV = 12>
+__global__ __launch_bounds__(64 * NWV, 12 / NWV) void wgrad_x3_kernel(TV tx, TV tg, float* __restrict__ partial, int cin, int cout, int tiles_x, int tpi,
                                                                int total, int G, int n_icg, int n_ocg) {
+    constexpr int XW_THREADS = 64 * NWV;             // 12 waves (v, jt, mt).  (NWV = 6, <8, 4, 2>: six-wave blocks, two per CU, for cin <= 32 -- measured
+                                                     // slower, 0.224 vs 0.188 ms on 16 -> 16: twice the tiles cost more than the second block hides; not instantiated)
     constexpr int PD = KS / 2, TAPS = KS * KS;       // KS = 1: no halo, one tap; the three wave groups v split the k-steps instead of the tap columns
     constexpr int XW_TH = TH, XW_XH = TH + 2 * PD, XW_XW = XW_TW + 2 * PD;
     constexpr int XW_PER = 64 * 64 * TAPS + 64;      // floats per block partial: dW[64 oc][64 ic][taps], db[64]
@@ -529,6 +531,9 @@ __global__ __launch_bounds__(XW_THREADS) void wgrad_x3_kernel(TV tx, TV tg, floa
     // (2 + 2 fragments per 9 MFMAs; with a fixed tap ROW per wave every k-step re-read all three column shifts: 6 + 2 -- 111 B / clk
     // of transposing reads on four SIMDs, at the LDS's limit for three waves per SIMD)
     const int v = wave % 3, jt = (wave / 3) & 1, mt = wave / 6;
+    // (waves whose channel tile the layer does not have -- 9 of 12 for a 16 -> 16 DenseBlock conv -- only stage.  Splitting the tile's
+    // k-steps among them instead, partial sums meeting in LDS after the last tile, was built and measured: 0.185 vs 0.187 ms -- those
+    // layers wait for their tile loads, not for the matrix pipe)
     const bool active = (ocg * 64 + mt * 32 < cout) && (icg * 64 + jt * 32 < cin);
     const bool want_db = ((v == 0 || KS == 1) && jt == 0 && icg == 0 && ocg * 64 + mt * 32 < cout);
 
@@ -695,18 +700,20 @@ __global__ __launch_bounds__(XW_THREADS) void wgrad_x3_kernel(TV tx, TV tg, floa
                 }
                 xh[(ry + 2) % 3] = ld_tr(s_xh + xoff + (ry + 2) * XW_XW * 16);
                 xl[(ry + 2) % 3] = ld_tr(s_xl + xoff + (ry + 2) * XW_XW * 16);
-                const x3_bf16x8 gh = ld_tr(s_gh + goff + ry * XW_TW * 16), gl = ld_tr(s_gl + goff + ry * XW_TW * 16);
+                {
+                    const x3_bf16x8 gh = ld_tr(s_gh + goff + ry * XW_TW * 16), gl = ld_tr(s_gl + goff + ry * XW_TW * 16);
 #pragma unroll
-                for (int u = 0; u < 3; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gl, xh[(ry + u) % 3], acc[u], 0, 0, 0);
+                    for (int u = 0; u < 3; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gl, xh[(ry + u) % 3], acc[u], 0, 0, 0);
 #pragma unroll
-                for (int u = 0; u < 3; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh, xl[(ry + u) % 3], acc[u], 0, 0, 0);
+                    for (int u = 0; u < 3; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh, xl[(ry + u) % 3], acc[u], 0, 0, 0);
 #pragma unroll
-                for (int u = 0; u < 3; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh, xh[(ry + u) % 3], acc[u], 0, 0, 0);
-                if (want_db) {
-                    accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gl, ones0, accb[0], 0, 0, 0);
-                    accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gl, ones1, accb[1], 0, 0, 0);
-                    accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh, ones0, accb[0], 0, 0, 0);
-                    accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh, ones1, accb[1], 0, 0, 0);
+                    for (int u = 0; u < 3; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh, xh[(ry + u) % 3], acc[u], 0, 0, 0);
+                    if (want_db) {
+                        accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gl, ones0, accb[0], 0, 0, 0);
+                        accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gl, ones1, accb[1], 0, 0, 0);
+                        accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh, ones0, accb[0], 0, 0, 0);
+                        accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh, ones1, accb[1], 0, 0, 0);
+                    }
                 }
             }
             }
@@ -721,13 +728,14 @@ __global__ __launch_bounds__(XW_THREADS) void wgrad_x3_kernel(TV tx, TV tg, floa
     // lane l reg r of acc[u]: oc = 32 mt + (r & 3) + 8 (r >> 2) + 4 (l >> 5), ic = 32 jt + (l & 31), tap (u, v)
     if (active) {
         float* dst = partial + ((long long)(KS == 1 ? gi * 3 + v : gi) * npairs + pair) * XW_PER;
+        // stored REGISTER-major, [mt][jt][v][u][r][lane] (256 contiguous bytes per store instruction; in dW order every lane wrote its own
+        // 4 bytes of a different cache line: 36 lines per instruction); wgrad_x3_reduce undoes the mapping
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int oc = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), ic = 32 * jt + (lane & 31);
-            if (KS == 1) dst[oc * 64 + ic] = acc[0][r];
+            if (KS == 1) dst[((mt * 2 + jt) * 16 + r) * 64 + lane] = acc[0][r];
             else {
 #pragma unroll
-                for (int u = 0; u < 3; ++u) dst[(oc * 64 + ic) * 9 + u * 3 + v] = acc[u][r];
+                for (int u = 0; u < 3; ++u) dst[((((mt * 2 + jt) * 3 + v) * 3 + u) * 16 + r) * 64 + lane] = acc[u][r];
             }
         }
         // 16x16x32 C layout: lane l, reg r = row 4 (l >> 4) + r, column l & 15; rows of accb[h] = channels 16 h .. 16 h + 15
@@ -752,7 +760,11 @@ __global__ __launch_bounds__(256) void wgrad_x3_reduce(const float* __restrict__
     long long off = -1;
     if (idx < total_w) {
         const int tap = idx % taps, c = (idx / taps) % cin, o = idx / (taps * cin);
-        off = (long long)((c / 64) + n_icg * (o / 64)) * XW_PER + ((o % 64) * 64 + (c % 64)) * taps + tap;
+        // the wave tile (mt, jt) and the accumulator register / lane that hold dW[o][c]: oc = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), ic = lane & 31
+        const int mt = (o % 64) / 32, jt = (c % 64) / 32, oc_t = o % 32;
+        const int r = (oc_t & 3) + 4 * (oc_t >> 3), ln = ((oc_t >> 2) & 1) * 32 + (c % 32);
+        const int tile = taps == 1 ? (mt * 2 + jt) : ((mt * 2 + jt) * 3 + tap % 3) * 3 + tap / 3;
+        off = (long long)((c / 64) + n_icg * (o / 64)) * XW_PER + (tile * 16 + r) * 64 + ln;
     } else if (idx < total_w + cout) {
         const int o = idx - total_w;
         off = (long long)(0 + n_icg * (o / 64)) * XW_PER + 64 * 64 * taps + (o % 64);
@@ -867,7 +879,9 @@ static int launch_conv_x3(bool dgrad, const TV& tin, const TV& tout, const TV& t
                           int relu, uint64_t mask_bits, uint64_t accum_bits, hipStream_t st) {
     const int tiles_x = cdiv(tout.ws, X3_TW), tiles_y = cdiv(tout.hs, RJ * NW);
     const int tpi = tiles_x * tiles_y, total = tpi * tout.n;
-    int G = x3_num_cus() * (NW == 4 ? 2 : 1);
+    static int nw4_blocks = -1;   // four-wave blocks per CU (persistent grid): $MMIF_X3_NW4_BLOCKS, default 3 (42 KB of LDS, < 168 VGPRs each)
+    if (nw4_blocks < 0) { const char* e = getenv("MMIF_X3_NW4_BLOCKS"); nw4_blocks = e != nullptr && atoi(e) > 0 ? atoi(e) : 3; }
+    int G = x3_num_cus() * (NW == 4 ? nw4_blocks : 1);
     if (total < G) G = total;
     const int nch = x3_nch(n_in), nmb = x3_nmb(n_out);
     constexpr int X3_THREADS = 64 * NW;
@@ -905,6 +919,17 @@ int conv_x3(bool dgrad, const TV& tin, const TV& tout, const TV& tmask, const vo
     // 3-piece forward: the same 216 MFMAs per wave and barrier as the 64-channel kernels for half the weight staging ($MMIF_X3_RJ4=0: two)
     static int rj4 = -1;
     if (rj4 < 0) { const char* e = getenv("MMIF_X3_RJ4"); rj4 = (e != nullptr && e[0] == '0') ? 0 : 1; }
+    // thin layers (<= 32 out, <= 64 in: the DenseBlock convs and the decoder's tail) have almost no MFMA work per tile and run at the
+    // latency of ONE tile's loads per block: four-wave blocks (8-row tiles, 16-channel chunks, 42 KB of LDS, 146 VGPRs) put THREE
+    // independent blocks on a CU: forward 16->16 102 -> 77 us, 32->16 161 -> 144, 48->16 258 -> 212, 64->32 348 -> 324; dgrad 16->16
+    // 160 -> 123, 32->16 204 -> 175 (two blocks: half of that; four: over-subscribed, slower; the 64-out-channel kernels on four-wave
+    // blocks: +-0).  $MMIF_X3_THIN_NW4=0: the eight-wave kernel
+    static int thin4 = -1;
+    if (thin4 < 0) { const char* e = getenv("MMIF_X3_THIN_NW4"); thin4 = (e != nullptr && e[0] == '0') ? 0 : 1; }
+    if (thin4 && n_in <= 64 && !six) {
+        if (h16) return launch_conv_x3<1, 2, 4, 2, 3, true>(false, X3_ARGS);
+        return launch_conv_x3<1, 2, 4, 2>(dgrad, X3_ARGS);
+    }
     if (h16) return launch_conv_x3<1, 2, 8, 2, 3, true>(false, X3_ARGS);
     if (six) return rj4 ? launch_conv_x3<1, 3, 8, 4>(false, X3_ARGS) : launch_conv_x3<1, 3, 8, 2>(false, X3_ARGS);
     return launch_conv_x3<1, 2, 8, 2>(dgrad, X3_ARGS);

@@ -22,7 +22,7 @@ pk = T.PackedWeights(cout, cin, 3, dev, F32); pk.pack(w)
 flops = 2.0 * B * S * S * cin * cout * 9
 dw = torch.zeros(cout, cin, 3, 3, device=dev); db = torch.zeros(cout, device=dev)
 ws = torch.empty(T.wgrad_workspace_bytes(cin, cout, 3) // 4 + 1, dtype=torch.float32, device=dev)
-MASK = (1 << gx.cb) - 1
+MASK = 0 if os.environ.get("BENCH_NOMASK") else (1 << gx.cb) - 1
 def run(kind, impl):
     if kind == "fwd": T.conv_fwd(x, w, b, y, cin, cout, 3, True, pk, impl)
     elif kind == "dgrad": T.conv_dgrad(gy, w, x, gx, cin, cout, 3, MASK, 0, pk, impl, fold=True)
