@@ -335,8 +335,12 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_x3_kernel(TV tin, TV tout, TV
     __syncthreads();
     int e_acc = e_stage, e_cur = e_stage;   // F16: exponent the accumulators hold / the chunk in LDS was staged with
 
+    // the next chunk's address arithmetic + loads (~300 instructions) leave the matrix pipe idle for the wave that issues them, and the two
+    // waves of a SIMD run in step between the barriers: waves 0 .. NW/2-1 issue BEFORE the chunk's MFMAs, their SIMD partners (wave + NW/2)
+    // between the chunk's two 16-channel k-steps, so that one of the two feeds the pipe meanwhile ($MMIF_X3_ABLATE bit 4: all up front)
+    const bool issue_late = KK >= 2 && wave >= NW / 2 && !(abl & 16);
     for (int s = 0; s < nsteps; ++s) {
-        if (s + 1 < nsteps) issue(s + 1);
+        if (s + 1 < nsteps && !issue_late) issue(s + 1);
         if constexpr (F16) {   // this chunk was staged with e_cur <= the exponent of the item's earlier chunks: bring the accumulators down
             if (s % nch == 0) e_acc = e_cur;
             else if (e_cur < e_acc) {
@@ -352,6 +356,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_x3_kernel(TV tin, TV tout, TV
         const int nkk = min(KK, nch16 - (s % nch) * KK);
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
+            if (kk == 1 && issue_late && s + 1 < nsteps) issue(s + 1);
             if (kk < nkk && !((abl & 8) && s > 0)) {
                 const x3_u4* s_in = s_buf + kk * 2 * PL;
                 const x3_u4* s_w = s_buf + NP * ING + kk * NP * WG;
@@ -694,7 +699,7 @@ __global__ __launch_bounds__(64 * NWV, 12 / NWV) void wgrad_x3_kernel(TV tx, TV 
             }
 #pragma unroll
             for (int ry = 0; ry < XW_TH; ++ry) {
-                if (ry == XW_TH / 2 && more) {   // second half of the next tile's staging
+                if (ry == XW_TH / 2 && more) {   // second half of the next tile's staging (the three waves of a SIMD one k-step apart: +-0)
                     commit(buf ^ 1, 0);
                     issue(k + 1, 1);
                 }
