@@ -171,6 +171,11 @@ constexpr int X3_BIAS_G = 128;   // granules reserved behind the tiles for the b
 // 150 / 114 KB and 216 MFMAs per wave between barriers; the next chunk's global loads fly during the MFMAs, the split + LDS write
 // follows them.  (First version: 16-channel chunks, double buffered, one barrier per 108 MFMAs: the staging phases of the two waves of a
 // SIMD coincide at the barrier and are fully exposed -- 41 % of the MFMA peak against 52 % for the 216-MFMA chunks.)
+// (A PIPELINED form -- two 16-channel sub-chunk buffers, one barrier per sub-chunk, the two waves of a SIMD taking "stage s+1" and
+// "MFMAs of s" in opposite order so that one of them always feeds the matrix pipe -- was built for the bf16-piece kernels: 2.02 vs 2.02 ms
+// on decode.0's dgrad, and 5.96 vs 5.86 ms on 64 CUs, where the clock is not the limit; with the mask operands requested a whole
+// sub-chunk ahead of the epilogue, 2.10 vs 1.96.  Its ablations: no MFMAs 1.14 ms, no loads / split / MFMAs 0.69 ms -- the epilogue's
+// 2 x 1 GB of fp32 gradient writes and mask reads plus the barriers; staging and MFMA time ADD in either form.)
 // NW = 8 waves: one block per CU (the instantiation in use).  NW = 4 -- TWO blocks of four waves per CU on 16-channel chunks and 8-row
 // tiles, so that the two waves of a SIMD are not tied to one barrier -- was built and measured: 1.99 vs 2.01 ms on decode.0's dgrad;
 // the waves overlap better but each block stages the whole weight chunk for half the pixels.  What the SQ counters say about these
@@ -447,9 +452,11 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_x3_kernel(TV tin, TV tout, TV
                         }
                         if (mask_bits != 0ull) {
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const int ocbc = min((mb * MB + m) * 4 + q, tout.cb - 1);
-                                xm[q] = *reinterpret_cast<const x3_f4*>(tmask.base + tmask.gidx(in_, ocbc, oy, ox) * 32 + half * 16);
+                            for (int q = 0; q < 4; ++q) {   // blocks the mask does not cover read one hot line (uniform address select, no branch)
+                                const int ocb = (mb * MB + m) * 4 + q;
+                                const bool need = ((mask_bits >> ocb) & 1ull) && ocb < tmask.cb;
+                                const char* pm = need ? tmask.base + tmask.gidx(in_, ocb, oy, ox) * 32 + half * 16 : tmask.base;
+                                xm[q] = *reinterpret_cast<const x3_f4*>(pm);
                             }
                         }
 #pragma unroll
@@ -493,6 +500,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_x3_kernel(TV tin, TV tout, TV
         __syncthreads();
     }
 }
+
 
 // ------------------------------------------------------------------ wgrad
 constexpr int XW_TW = 16;                        // pixel-tile columns = the 16 pixels of one k-step
