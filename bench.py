@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--model", default="PFNetv1", choices=["PFNetv1", "PFNetv2", "DenseFuse", "VIFNet", "NestFuse", "RFNNest", "DeepFuse", "DBNet", "SEDRFuse", "IFCNN", "DIFNet", "PMGI", "UNFusion", "MAFusion", "Res2Fusion"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--separate-losses", action="store_true", help="the three loss modules + torch additions instead of core.loss.FusionLoss (one call)")
     ap.add_argument("--graph", action="store_true",
                     help="capture forward + losses + backward in ONE hipGraph and replay it per step (launch-bound small batches); "
                          "the gradient all-reduce and clip+Adam stay outside the graph")
@@ -133,7 +134,7 @@ def parity_leg(args, dev, img1, img2):
     oracle on a small closed-form sample (2 pairs of 64 x 64: fused image, total loss, every parameter gradient)."""
     import numpy as np
     import core.model as M
-    from core.loss import GradLoss, PixelLoss, SSIMLoss
+    from core.loss import FusionLoss, GradLoss, PixelLoss, SSIMLoss
     from mmif import engine as E
     from mmif._lib import lib
     from mmif.optim import FusedClipAdam
@@ -142,11 +143,12 @@ def parity_leg(args, dev, img1, img2):
     E.set_compute_dtype("fp32")
     try:
         l_ssim, l_pix, l_grad = SSIMLoss('ssim', weight=1.0), PixelLoss('l1', weight=0.01), GradLoss('l1', weight=0.1).to(dev)
+        l_all = None if args.separate_losses else FusionLoss(l_ssim, l_pix, l_grad, 'max', 'max')
 
         def one(model, opt, a, b):
             opt.zero_grad(set_to_none=True)
             f = model(a, b)
-            tot = l_ssim(a, b, f) + l_pix(a, b, f, mode='max') + l_grad(a, b, f, mode='max')
+            tot = l_all(a, b, f) if l_all is not None else l_ssim(a, b, f) + l_pix(a, b, f, mode='max') + l_grad(a, b, f, mode='max')
             tot.backward()
             opt.step()
             return f, tot
@@ -228,7 +230,7 @@ def main():
     torch.cuda.set_device(dev)
 
     import core.model as M
-    from core.loss import GradLoss, PixelLoss, SSIMLoss
+    from core.loss import FusionLoss, GradLoss, PixelLoss, SSIMLoss
     from mmif import engine as E
     from mmif import tensor as T
     from mmif.dist import broadcast_parameters
@@ -241,6 +243,9 @@ def main():
         broadcast_parameters(model, 0)
     opt = FusedClipAdam(model.parameters(), lr=1e-4, betas=(0.9, 0.999), max_norm=5.0)
     l_ssim, l_pix, l_grad = SSIMLoss('ssim', weight=1.0), PixelLoss('l1', weight=0.01), GradLoss('l1', weight=0.1).to(dev)
+    # the three terms + their sum + the three gradient contributions as ONE device call (same kernels; --separate-losses: three modules
+    # and torch additions, as the reference's train.py:64-69 writes it)
+    l_all = None if args.separate_losses else FusionLoss(l_ssim, l_pix, l_grad, 'max', 'max')
 
     B, S = args.batch, args.size
     Wd = args.width or S
@@ -257,11 +262,16 @@ def main():
             return infer_step()
         opt.zero_grad(set_to_none=True)
         f = model(img1, img2)
-        a, b, c = l_ssim(img1, img2, f), l_pix(img1, img2, f, mode='max'), l_grad(img1, img2, f, mode='max')
-        tot = a + b + c
-        opt.stage_scalars([tot, a, b, c])      # (data parallel) the loss values ride in the early gradient all-reduce
+        if l_all is not None:
+            tot = l_all(img1, img2, f)
+            vals = l_all.values
+        else:
+            a, b, c = l_ssim(img1, img2, f), l_pix(img1, img2, f, mode='max'), l_grad(img1, img2, f, mode='max')
+            tot = a + b + c
+            vals = [tot, a, b, c]
+        opt.stage_scalars(vals)      # (data parallel) the loss values ride in the early gradient all-reduce
         tot.backward()
-        opt.step(scalars=[tot, a, b, c])
+        opt.step(scalars=vals)
         return tot
 
     for _ in range(args.warmup):
@@ -271,6 +281,9 @@ def main():
         from mmif.graph import GraphedStep
 
         def losses(i1, i2, f):
+            if l_all is not None:
+                tot = l_all(i1, i2, f)
+                return (tot,) + tuple(l_all.values[1:4].unbind(0))
             a, b, c = l_ssim(i1, i2, f), l_pix(i1, i2, f, mode='max'), l_grad(i1, i2, f, mode='max')
             return a + b + c, a, b, c
         gstep = GraphedStep(model, losses, opt, img1, img2)

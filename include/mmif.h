@@ -360,6 +360,14 @@ int mmif_pixel_loss(const float* img1, const float* img2, const float* imgf, int
 int mmif_grad_loss(const float* img1, const float* img2, const float* imgf, int32_t n, int32_t h, int32_t w,
                    float weight, int32_t mode_max, int32_t l2, float* loss_out, float* grad_out, void* workspace,
                    size_t workspace_bytes, void* stream);
+/* The three loss terms of the reference's train step (train.py:64-69: SSIMLoss('ssim') + PixelLoss + GradLoss, their sum, the three
+ * d/dimgf contributions autograd adds up) as ONE call: the kernels of the three entry points above, the pixel and Sobel kernels adding
+ * onto the SSIM term's gradient, one finish kernel.  loss_out = {l1 + l2 + l3, l1, l2, l3, total again} (5 floats on the device); grad_out (or NULL)
+ * = d(total)/d(imgf).  Weights as the modules' `weight`; *_max = mode 'max' (else 'avg'); *_l2 = mode 'l2' (else 'l1'). */
+size_t mmif_fusion_loss_workspace(int32_t n, int32_t h, int32_t w);
+int mmif_fusion_loss(const float* img1, const float* img2, const float* imgf, int32_t n, int32_t h, int32_t w, float w_ssim,
+                     float data_range, float w_pixel, int32_t pixel_max, int32_t pixel_l2, float w_grad, int32_t grad_max,
+                     int32_t grad_l2, float* loss_out, float* grad_out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Backward of ONE thin 3x3 ConvLayer (64 -> 32, 32 -> 16: decode.2 / decode.3 of every PFNet / DenseFuse decoder, core/model.py:83-85) in one
  * launch: gx = [x > 0] * dgrad(gy) in the folded convention -- what mmif_conv2d_reflect_dgrad_folded(mask_bits = all, accum_bits = 0)

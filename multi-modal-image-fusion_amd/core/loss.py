@@ -12,7 +12,7 @@ import torch.nn as nn
 from mmif import tensor as T
 from mmif._lib import check, lib
 
-__all__ = ['SSIM', 'MS_SSIM', 'MSW_SSIM', 'SSIMLoss', 'PixelLoss', 'GradLoss', 'TVLoss', 'NormLoss']
+__all__ = ['SSIM', 'MS_SSIM', 'MSW_SSIM', 'SSIMLoss', 'PixelLoss', 'GradLoss', 'TVLoss', 'NormLoss', 'FusionLoss']
 
 eps = 1e-7
 
@@ -250,3 +250,58 @@ class GradLoss(nn.Module):
         if mode not in ('avg', 'max'):
             return None  # as the reference (core/loss.py:335-344)
         return _LossFn.apply(imgf, img1, img2, 2, float(self.weight), mode == 'max', _norm_code(self.mode))
+
+
+class _FusionLossFn(torch.autograd.Function):
+    """mmif_fusion_loss: {total, ssim, pixel, grad} and d(total)/d(imgf) of the train step's three terms in one call."""
+
+    @staticmethod
+    def forward(ctx, imgf, img1, img2, cfg):
+        i1, i2, f = _prep(img1, img2, imgf)
+        n, _, h, w = f.shape
+        need = ctx.needs_input_grad[0]
+        vals = torch.empty(5, dtype=torch.float32, device=f.device)
+        grad = torch.empty_like(f) if need else None
+        key = ("fusion", n, h, w, f.device)
+        ws = _ws_cache.get(key)
+        if ws is None:
+            ws = _ws_cache[key] = torch.empty(lib.mmif_fusion_loss_workspace(n, h, w) // 4 + 1, dtype=torch.float32, device=f.device)
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        w_ssim, data_range, w_pixel, pixel_max, pixel_l2, w_grad, grad_max, grad_l2 = cfg
+        check(lib.mmif_fusion_loss(p(i1), p(i2), p(f), n, h, w, w_ssim, data_range, w_pixel, pixel_max, pixel_l2, w_grad, grad_max, grad_l2,
+                                   p(vals), p(grad), p(ws), ws.numel() * 4, T.stream_ptr()), "fusion_loss")
+        ctx.grad = grad
+        total, parts = vals[4], vals[:4]
+        ctx.mark_non_differentiable(parts)
+        return total, parts
+
+    @staticmethod
+    def backward(ctx, g, _gparts):
+        if ctx.grad is None:
+            return None, None, None, None
+        return ctx.grad * g, None, None, None
+
+
+class FusionLoss(nn.Module):
+    """loss_fn1(img1, img2, imgf) + loss_fn2(img1, img2, imgf, mode=pixel_mode) + loss_fn3(img1, img2, imgf, mode=grad_mode) of the
+    reference's train step (train.py:64-69) as one device call instead of three modules, two additions and autograd's two gradient
+    additions.  Takes the three modules the reference builds (train.py:171-173); SSIMLoss must be in mode 'ssim'.  forward returns the
+    total (what .backward() is called on); `.values` = the detached device vector [total, l1, l2, l3] of the last call (for logging and
+    for the data-parallel scalar reduce)."""
+
+    def __init__(self, loss_fn1, loss_fn2, loss_fn3, pixel_mode='max', grad_mode='max'):
+        super().__init__()
+        if getattr(loss_fn1, 'mode', 'ssim') != 'ssim':
+            raise ValueError("FusionLoss fuses SSIMLoss('ssim') only; use the modules separately for the other SSIM modes")
+        for m in (pixel_mode, grad_mode):
+            if m not in ('max', 'avg'):
+                raise ValueError("only supports 'max' and 'avg' modes.")
+        self.fn1, self.fn2, self.fn3 = loss_fn1, loss_fn2, loss_fn3
+        self.pixel_mode, self.grad_mode = pixel_mode, grad_mode
+        self.values = None
+
+    def forward(self, img1, img2, imgf):
+        cfg = (float(self.fn1.weight), float(self.fn1.data_range), float(self.fn2.weight), int(self.pixel_mode == 'max'), _norm_code(self.fn2.mode),
+               float(self.fn3.weight), int(self.grad_mode == 'max'), _norm_code(self.fn3.mode))
+        total, self.values = _FusionLossFn.apply(imgf, img1, img2, cfg)
+        return total

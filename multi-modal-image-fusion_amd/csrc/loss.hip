@@ -252,7 +252,7 @@ __global__ void ssim_finish_kernel(const float* __restrict__ partial, int np, fl
 __global__ __launch_bounds__(256) void pixel_loss_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
                                                          const float* __restrict__ f, long long total, float gscale,
                                                          int mode_max, int l2, float* __restrict__ grad,
-                                                         float* __restrict__ partial) {
+                                                         float* __restrict__ partial, int accum) {
     __shared__ float red[16];
     float s = 0.f;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void pixel_loss_kernel(const float* __restrict
             g = 0.5f * (l2 ? 2.f * (d1 + d2)
                            : ((d1 > 0.f ? 1.f : (d1 < 0.f ? -1.f : 0.f)) + (d2 > 0.f ? 1.f : (d2 < 0.f ? -1.f : 0.f))));
         }
-        if (grad) grad[i] = gscale * g;
+        if (grad) grad[i] = accum ? grad[i] + gscale * g : gscale * g;   // (accum: mmif_fusion_loss adds onto the SSIM term's gradient)
     }
     const float t = block_sum(s, red);
     if (threadIdx.x == 0) partial[blockIdx.x] = t;
@@ -282,6 +282,27 @@ __global__ void scale_finish_kernel(const float* __restrict__ partial, int np, f
     if (threadIdx.x == 0) loss[0] = scale * t;
 }
 
+// the three terms of the reference's train step (train.py:64-69) from their block partials: out = {l1 + l2 + l3, l1, l2, l3}
+__global__ void fusion_finish_kernel(const float* __restrict__ ps, int ns, float w_ssim, float inv_count, const float* __restrict__ pp, int npx,
+                                     float scale_px, const float* __restrict__ pg, int ngr, float scale_gr, float* __restrict__ out) {
+    __shared__ float red[16];
+    float a = 0.f, b = 0.f, c = 0.f;
+    for (int i = threadIdx.x; i < ns; i += blockDim.x) a += ps[i];
+    for (int i = threadIdx.x; i < npx; i += blockDim.x) b += pp[i];
+    for (int i = threadIdx.x; i < ngr; i += blockDim.x) c += pg[i];
+    const float ta = block_sum(a, red);
+    __syncthreads();
+    const float tb = block_sum(b, red);
+    __syncthreads();
+    const float tc = block_sum(c, red);
+    if (threadIdx.x == 0) {
+        const float l1 = w_ssim * (1.f - 0.5f * ta * inv_count), l2 = scale_px * tb, l3 = scale_gr * tc;
+        out[0] = (l1 + l2) + l3;
+        out[1] = l1; out[2] = l2; out[3] = l3;
+        out[4] = out[0];   // (the total once more: the host side hands it out as its own 0-dim tensor)
+    }
+}
+
 // ------------------------------------------------------------------ Sobel gradient loss
 constexpr int GH = 3;                 // image halo in LDS
 constexpr int GIN = LT + 2 * GH;      // 22
@@ -293,7 +314,7 @@ __device__ inline float sgnf(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f :
 __global__ __launch_bounds__(256) void grad_loss_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
                                                         const float* __restrict__ f, int H, int W, float gscale,
                                                         int mode_max, int l2, float* __restrict__ grad,
-                                                        float* __restrict__ partial, int tiles_x) {
+                                                        float* __restrict__ partial, int tiles_x, int accum) {
     __shared__ float in[3][GIN][GIN + 1];
     __shared__ float dx[GD][GD + 1], dy[GD][GD + 1];
     __shared__ float red[16];
@@ -379,7 +400,8 @@ __global__ __launch_bounds__(256) void grad_loss_kernel(const float* __restrict_
         float g = 0.f;
         for (int a = 0; a < ny; ++a)
             for (int b = 0; b < nx; ++b) g += Tq(ys[a], xs[b]);
-        grad[ibase + (long long)y * W + x] = gscale * g;
+        float* gp = grad + ibase + (long long)y * W + x;
+        *gp = accum ? *gp + gscale * g : gscale * g;
     }
     const float t = block_sum(lsum, red);
     if (tid == 0) partial[(long long)in_ * gridDim.x + blockIdx.x] = t;
@@ -454,7 +476,7 @@ extern "C" int mmif_pixel_loss(const float* img1, const float* img2, const float
     if (nb > 2048) nb = 2048;
     float* partial = (float*)workspace;
     hipLaunchKernelGGL(pixel_loss_kernel, dim3(nb), dim3(256), 0, st, img1, img2, imgf, total, weight / (float)total, mode_max,
-                       l2, grad_out, partial);
+                       l2, grad_out, partial, 0);
     if (int rc = check_launch("pixel_loss")) return rc;
     hipLaunchKernelGGL(scale_finish_kernel, dim3(1), dim3(256), 0, st, partial, nb, weight / (float)total, loss_out);
     return check_launch("pixel_finish");
@@ -473,8 +495,65 @@ extern "C" int mmif_grad_loss(const float* img1, const float* img2, const float*
     const long long total = (long long)n * h * w;
     float* partial = (float*)workspace;
     hipLaunchKernelGGL(grad_loss_kernel, dim3(tx * ty, n), dim3(256), 0, st, img1, img2, imgf, h, w, weight / (float)total,
-                       mode_max, l2, grad_out, partial, tx);
+                       mode_max, l2, grad_out, partial, tx, 0);
     if (int rc = check_launch("grad_loss")) return rc;
     hipLaunchKernelGGL(scale_finish_kernel, dim3(1), dim3(256), 0, st, partial, tx * ty * n, weight / (float)total, loss_out);
     return check_launch("grad_finish");
+}
+
+// SSIMLoss('ssim') + PixelLoss + GradLoss of one train step as ONE call (reference train.py:64-69: three modules, their sum, three
+// gradient contributions added by autograd): the same kernels as the three calls above, the pixel and Sobel kernels adding onto the
+// SSIM term's gradient, one finish kernel.  loss_out = {total, ssim, pixel, grad, total} (5 floats on the device).
+static size_t fusion_parts(int32_t n, int32_t h, int32_t w, size_t* o_px, size_t* o_gr, size_t* o_maps) {
+    const int Hm = h - WIN + 1, Wm = w - WIN + 1;
+    const size_t ns = (size_t)cdiv(Wm, ST) * cdiv(Hm, ST) * n, ngr = (size_t)cdiv(w, LT) * cdiv(h, LT) * n;
+    auto up = [](size_t v) { return (v + 63) / 64 * 64; };
+    *o_px = up(ns);
+    *o_gr = *o_px + 2048;
+    *o_maps = *o_gr + up(ngr);
+    return *o_maps + (size_t)4 * n * (h > 10 ? h - 10 : 0) * (w > 10 ? w - 10 : 0);
+}
+extern "C" size_t mmif_fusion_loss_workspace(int32_t n, int32_t h, int32_t w) {
+    size_t a, b, c;
+    return fusion_parts(n, h, w, &a, &b, &c) * sizeof(float);
+}
+extern "C" int mmif_fusion_loss(const float* img1, const float* img2, const float* imgf, int32_t n, int32_t h, int32_t w, float w_ssim,
+                                float data_range, float w_pixel, int32_t pixel_max, int32_t pixel_l2, float w_grad, int32_t grad_max,
+                                int32_t grad_l2, float* loss_out, float* grad_out, void* workspace, size_t workspace_bytes, void* stream) {
+    MMIF_REQUIRE(h >= WIN && w >= WIN, "fusion_loss: image smaller than the 11x11 window (%dx%d)", h, w);
+    size_t o_px, o_gr, o_maps;
+    if (workspace_bytes < fusion_parts(n, h, w, &o_px, &o_gr, &o_maps) * sizeof(float)) {
+        set_error("fusion_loss: workspace too small");
+        return MMIF_EWORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    Win11 win;
+    gaussian_window(win);
+    const float C1 = (0.01f * data_range) * (0.01f * data_range), C2 = (0.03f * data_range) * (0.03f * data_range);
+    const int Hm = h - WIN + 1, Wm = w - WIN + 1;
+    const int tmx = cdiv(Wm, ST), tmy = cdiv(Hm, ST);
+    float* ps = (float*)workspace;
+    float *pp = ps + o_px, *pg = ps + o_gr, *maps = grad_out ? ps + o_maps : nullptr;
+    const int ns = tmx * tmy * n;
+    hipLaunchKernelGGL(ssim_stats_kernel, dim3(tmx * tmy, n), dim3(256), 0, st, img1, img2, imgf, h, w, win, C1, C2, maps, ps, tmx);
+    if (int rc = check_launch("fusion_loss ssim_stats")) return rc;
+    if (grad_out) {
+        const int tx = cdiv(w, ST), ty = cdiv(h, ST);
+        hipLaunchKernelGGL(ssim_grad_kernel, dim3(tx * ty, n), dim3(256), 0, st, img1, img2, imgf, h, w, win, maps,
+                           -w_ssim * 0.5f / ((float)n * Hm * Wm), grad_out, tx);
+        if (int rc = check_launch("fusion_loss ssim_grad")) return rc;
+    }
+    const long long total = (long long)n * h * w;
+    int nb = cdiv(total, 256);
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(pixel_loss_kernel, dim3(nb), dim3(256), 0, st, img1, img2, imgf, total, w_pixel / (float)total, pixel_max, pixel_l2,
+                       grad_out, pp, 1);
+    if (int rc = check_launch("fusion_loss pixel")) return rc;
+    const int tx = cdiv(w, LT), ty = cdiv(h, LT);
+    hipLaunchKernelGGL(grad_loss_kernel, dim3(tx * ty, n), dim3(256), 0, st, img1, img2, imgf, h, w, w_grad / (float)total, grad_max, grad_l2,
+                       grad_out, pg, tx, 1);
+    if (int rc = check_launch("fusion_loss grad")) return rc;
+    hipLaunchKernelGGL(fusion_finish_kernel, dim3(1), dim3(256), 0, st, ps, ns, w_ssim, 1.f / ((float)n * Hm * Wm), pp, nb,
+                       w_pixel / (float)total, pg, tx * ty * n, w_grad / (float)total, loss_out);
+    return check_launch("fusion_loss finish");
 }

@@ -145,6 +145,8 @@ SIGNATURES = {
     "mmif_tv_loss": (_i32, [_vp, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp, _sz, _vp]),
     "mmif_pixel_loss": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     "mmif_grad_loss": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "mmif_fusion_loss_workspace": (_sz, [_i32, _i32, _i32]),
+    "mmif_fusion_loss": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _f32, _f32, _i32, _i32, _f32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     "mmif_patch_feed": (_i32, [_vp, _i64, _i32, _vp, _vp, _i32, _i32, _vp, _vp]),
     "mmif_clip_adam_workspace": (_sz, [_i64]),
     "mmif_clip_adam_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i32, _f32, _f32, _vp, _vp, _sz, _vp]),

@@ -18,6 +18,13 @@ from .tensor import stream_ptr
 N_TAIL = E.GRAD_TAIL  # scalar slots appended to the flat gradient buffer (losses ride along in the all-reduce)
 
 
+def _scalar_vector(scalars):
+    """a list of 0-dim tensors, or already one 1-d tensor (core.loss.FusionLoss.values: no stack kernel)"""
+    if torch.is_tensor(scalars):
+        return scalars.detach().float()
+    return torch.stack([s.detach().float().reshape(()) for s in scalars])
+
+
 class FusedClipAdam(torch.optim.Optimizer):
     """Adam(lr, betas, eps, weight_decay=0) with optional global-norm clipping, bias-corrected exactly as
     torch.optim.Adam; parameters are re-pointed to one flat fp32 buffer on first use."""
@@ -151,9 +158,9 @@ class FusedClipAdam(torch.optim.Optimizer):
         mmif/dist.py; the engine copies them into the tail slots of its flat gradient buffer so that they travel in the EARLY gradient
         all-reduce; step(scalars=the same list) then only reads them back.  A no-op (step() writes them itself) until the early path
         is armed, i.e. on the first step."""
-        if not scalars or len(scalars) > N_TAIL or not D.early_reduce_armed():
+        if scalars is None or len(scalars) == 0 or len(scalars) > N_TAIL or not D.early_reduce_armed():
             return False
-        D.stage_tail(torch.stack([s.detach().float().reshape(()) for s in scalars]))
+        D.stage_tail(_scalar_vector(scalars))
         return True
 
     @torch.no_grad()
@@ -164,7 +171,8 @@ class FusedClipAdam(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None, scalars=None):
-        """scalars: optional list of up to 8 0-dim device tensors (loss values) that are summed across
+        """scalars: optional list of up to 8 0-dim device tensors (loss values), or ONE 1-d device tensor of them (core.loss.FusionLoss
+        `.values`), that are summed across
         ranks in the same all-reduce as the gradients; their rank-mean is left in `reduced_scalars`."""
         loss = None
         if closure is not None:
@@ -183,10 +191,13 @@ class FusedClipAdam(torch.optim.Optimizer):
         if in_group:
             D.drain_early()
         D.stage_tail(None)     # scalars parked for a backward whose early reduce never ran must not ride in a later one
-        k = len(scalars) if scalars else 0
+        k = len(scalars) if scalars is not None else 0
         tail_done = early is not None and early[1] >= total + k and k > 0
         if k and not tail_done:   # straight into the tail of the flat buffer (one small launch)
-            torch.stack([s.detach().float().reshape(()) for s in scalars], out=flat_g[total:total + k])
+            if torch.is_tensor(scalars):
+                flat_g[total:total + k].copy_(scalars.detach())
+            else:
+                torch.stack([s.detach().float().reshape(()) for s in scalars], out=flat_g[total:total + k])
         if in_group:
             if early is None:
                 dist.all_reduce(flat_g)  # ONE collective: gradients + loss scalars (SUM); mean taken below
@@ -199,8 +210,8 @@ class FusedClipAdam(torch.optim.Optimizer):
                 if k and not tail_done:
                     dist.all_reduce(flat_g[total:total + N_TAIL])
             D.arm_early_reduce(self._last_flat is not None)
-        if scalars:
-            tail = flat_g[total:total + len(scalars)]
+        if k:
+            tail = flat_g[total:total + k]
             self.reduced_scalars = tail / world if world > 1 else tail.clone()
         g = self.param_groups[0]
         self._steps += 1

@@ -24,7 +24,7 @@ from torch.optim.lr_scheduler import MultiStepLR
 from torch.utils.data import DataLoader, DistributedSampler, TensorDataset
 
 from common import *
-from core.loss import GradLoss, PixelLoss, SSIMLoss
+from core.loss import FusionLoss, GradLoss, PixelLoss, SSIMLoss
 from core.model import *
 from data._io import imwrite
 from mmif import engine as E
@@ -32,7 +32,19 @@ from mmif.dist import broadcast_parameters
 from mmif.optim import FusedClipAdam
 
 
+_fused = {}
+
+
 def _losses(loss_fn1, loss_fn2, loss_fn3, img1, img2, imgf):
+    """loss1 + loss2 + loss3 of the reference's step (train.py:64-69); with SSIMLoss('ssim') as ONE device call (core.loss.FusionLoss:
+    the same kernels, their sum and the sum of their gradients without torch glue kernels)"""
+    if getattr(loss_fn1, 'mode', None) == 'ssim' and not getattr(loss_fn1, 'use_padding', False):
+        key = (id(loss_fn1), id(loss_fn2), id(loss_fn3))
+        fl = _fused.get(key)
+        if fl is None:
+            fl = _fused[key] = FusionLoss(loss_fn1, loss_fn2, loss_fn3, 'max', 'max')
+        total = fl(img1, img2, imgf)
+        return total, fl.values[1], fl.values[2], fl.values[3]
     l1, l2, l3 = loss_fn1(img1, img2, imgf), loss_fn2(img1, img2, imgf, mode='max'), loss_fn3(img1, img2, imgf, mode='max')
     return l1 + l2 + l3, l1, l2, l3
 
@@ -65,10 +77,7 @@ def train_model(model, data_loader, loss_fn1, loss_fn2, loss_fn3, epoch, mode='t
                 graphed = GraphedStep(model, lambda a, b, f: _losses(loss_fn1, loss_fn2, loss_fn3, a, b, f), optimizer, img1, img2)
             optimizer.zero_grad(set_to_none=True)
             imgf = model(img1, img2)
-            loss1 = loss_fn1(img1, img2, imgf)
-            loss2 = loss_fn2(img1, img2, imgf, mode='max')
-            loss3 = loss_fn3(img1, img2, imgf, mode='max')
-            total_loss = loss1 + loss2 + loss3
+            total_loss, loss1, loss2, loss3 = _losses(loss_fn1, loss_fn2, loss_fn3, img1, img2, imgf)
             if hasattr(optimizer, "stage_scalars"):   # (data parallel) the loss values ride in the early gradient all-reduce
                 optimizer.stage_scalars([total_loss, loss1, loss2, loss3])
             total_loss.backward()

@@ -184,3 +184,49 @@ def test_ssim_module_terms_vs_oracle(win):
         s = SSIM()(tg(an), f)['ssim'].sum()
         s.backward()
         assert float(f.grad.abs().max()) > 0
+
+
+@pytest.mark.parametrize("pm,gm,shape", [("max", "max", (2, 1, 64, 80)), ("avg", "max", (3, 1, 33, 47)), ("max", "avg", (1, 1, 256, 256))])
+def test_fusion_loss_equals_the_three_modules(pm, gm, shape):
+    """core.loss.FusionLoss (ONE device call for the three terms of train.py:64-69) against the three modules + torch's additions:
+    the terms bit for bit (same kernels, same partial sums), the total to one fp32 rounding, d(total)/d(imgf) to the rounding of a
+    different summation order of the three contributions; and the known answers of golden F1 through the fused call."""
+    from core.loss import FusionLoss
+    torch.manual_seed(5)
+    x1, x2 = torch.rand(shape).to("cuda:0"), torch.rand(shape).to("cuda:0")
+    l1, l2, l3 = _losses()
+    y = torch.rand(shape).to("cuda:0").requires_grad_(True)
+    a, b, c = l1(x1, x2, y), l2(x1, x2, y, mode=pm), l3(x1, x2, y, mode=gm)
+    (a + b + c).backward()
+    g_sep = y.grad.clone()
+    y.grad = None
+    fl = FusionLoss(l1, l2, l3, pm, gm)
+    tot = fl(x1, x2, y)
+    tot.backward()
+    v = fl.values.cpu().numpy()
+    assert v[1] == a.item() and v[2] == b.item() and v[3] == c.item()
+    assert tot.item() == v[0] and abs(v[0] - (a + b + c).item()) <= 1.2e-7 * abs(v[0])
+    close(y.grad.cpu().numpy(), g_sep.cpu().numpy(), 2e-6, "d total / d imgf")
+    assert not fl.values.requires_grad and tot.requires_grad
+    # scaled upstream gradient, and no gradient requested
+    y.grad = None
+    (3.0 * fl(x1, x2, y)).backward()
+    close(y.grad.cpu().numpy(), 3.0 * g_sep.cpu().numpy(), 2e-6, "3 x")
+    with torch.no_grad():
+        assert fl(x1, x2, y).item() == v[0]
+    with pytest.raises(ValueError):
+        FusionLoss(l1, l2, l3, 'nope', 'max')
+
+
+def test_fusion_loss_known_answers():
+    ref = json.load(open(os.path.join(G, "f1_loss_known_answer.json")))
+    from core.loss import FusionLoss
+    torch.manual_seed(0)
+    x1 = torch.rand(2, 1, 256, 256).to("cuda:0")
+    x2 = torch.rand(2, 1, 256, 256).to("cuda:0")
+    y = torch.rand(2, 1, 256, 256).to("cuda:0")
+    fl = FusionLoss(*_losses(), 'max', 'max')
+    tot = fl(x1, x2, y).item()
+    v = fl.values.cpu().numpy()
+    assert abs(v[1] - ref["ssim"]) < 5e-6 and abs(v[2] - ref["pixel_max"]) < 1e-7 and abs(v[3] - ref["grad_max"]) < 1e-6
+    assert abs(tot - ref["total_max"]) < 6e-6
