@@ -273,11 +273,12 @@ class _FusionLossFn(torch.autograd.Function):
         ctx.grad = grad
         total, parts = vals[4], vals[:4]
         ctx.mark_non_differentiable(parts)
+        ctx.set_materialize_grads(False)   # (no zeros tensor for the parts' gradient slot on every backward)
         return total, parts
 
     @staticmethod
     def backward(ctx, g, _gparts):
-        if ctx.grad is None:
+        if ctx.grad is None or g is None:
             return None, None, None, None
         return ctx.grad * g, None, None, None
 

@@ -282,19 +282,32 @@ __global__ void scale_finish_kernel(const float* __restrict__ partial, int np, f
     if (threadIdx.x == 0) loss[0] = scale * t;
 }
 
-// the three terms of the reference's train step (train.py:64-69) from their block partials: out = {l1 + l2 + l3, l1, l2, l3}
-__global__ void fusion_finish_kernel(const float* __restrict__ ps, int ns, float w_ssim, float inv_count, const float* __restrict__ pp, int npx,
-                                     float scale_px, const float* __restrict__ pg, int ngr, float scale_gr, float* __restrict__ out) {
+// the three terms of the reference's train step (train.py:64-69) from their block partials: out = {l1 + l2 + l3, l1, l2, l3, total}.
+// 1024 threads bring the partials into LDS with a few wide round trips (they were written by other XCDs: ~2 us per dependent access),
+// then threads 0..255 add them in the order of the single-term finish kernels (thread t: t, t + 256, ...), so each term is
+// bit-identical to its own entry point's.  Partial lists beyond the LDS budget are read directly.
+constexpr int FF_CAP = 12288;   // floats of LDS staging (48 KB)
+__device__ inline float ff_ordered_sum(const float* __restrict__ p, int n, float* lds) {
+    const bool staged = n <= FF_CAP;
+    __syncthreads();
+    if (staged)
+        for (int i = threadIdx.x; i < n; i += blockDim.x) lds[i] = p[i];
+    __syncthreads();
+    float s = 0.f;
+    if (threadIdx.x < 256) {
+        if (staged) for (int i = threadIdx.x; i < n; i += 256) s += lds[i];
+        else for (int i = threadIdx.x; i < n; i += 256) s += p[i];
+    }
+    return s;
+}
+__global__ __launch_bounds__(1024) void fusion_finish_kernel(const float* __restrict__ ps, int ns, float w_ssim, float inv_count,
+                                                             const float* __restrict__ pp, int npx, float scale_px, const float* __restrict__ pg,
+                                                             int ngr, float scale_gr, float* __restrict__ out) {
     __shared__ float red[16];
-    float a = 0.f, b = 0.f, c = 0.f;
-    for (int i = threadIdx.x; i < ns; i += blockDim.x) a += ps[i];
-    for (int i = threadIdx.x; i < npx; i += blockDim.x) b += pp[i];
-    for (int i = threadIdx.x; i < ngr; i += blockDim.x) c += pg[i];
-    const float ta = block_sum(a, red);
-    __syncthreads();
-    const float tb = block_sum(b, red);
-    __syncthreads();
-    const float tc = block_sum(c, red);
+    __shared__ float stage[FF_CAP];
+    const float ta = block_sum(ff_ordered_sum(ps, ns, stage), red);
+    const float tb = block_sum(ff_ordered_sum(pp, npx, stage), red);
+    const float tc = block_sum(ff_ordered_sum(pg, ngr, stage), red);
     if (threadIdx.x == 0) {
         const float l1 = w_ssim * (1.f - 0.5f * ta * inv_count), l2 = scale_px * tb, l3 = scale_gr * tc;
         out[0] = (l1 + l2) + l3;
@@ -553,7 +566,7 @@ extern "C" int mmif_fusion_loss(const float* img1, const float* img2, const floa
     hipLaunchKernelGGL(grad_loss_kernel, dim3(tx * ty, n), dim3(256), 0, st, img1, img2, imgf, h, w, w_grad / (float)total, grad_max, grad_l2,
                        grad_out, pg, tx, 1);
     if (int rc = check_launch("fusion_loss grad")) return rc;
-    hipLaunchKernelGGL(fusion_finish_kernel, dim3(1), dim3(256), 0, st, ps, ns, w_ssim, 1.f / ((float)n * Hm * Wm), pp, nb,
+    hipLaunchKernelGGL(fusion_finish_kernel, dim3(1), dim3(1024), 0, st, ps, ns, w_ssim, 1.f / ((float)n * Hm * Wm), pp, nb,
                        w_pixel / (float)total, pg, tx * ty * n, w_grad / (float)total, loss_out);
     return check_launch("fusion_loss finish");
 }
