@@ -208,6 +208,37 @@ __device__ inline float block_sum(float v, float* smem /* >= 16 floats */) {
     return r;
 }
 
+// Fixed-order sum of the G per-block partials of one output element (the partials sit `stride` floats apart), as the reduce kernels of the
+// weight gradients need it: a block = 64 outputs x RED_SLICES slices of the G range (1024 threads), 4 independent load chains per thread,
+// i.e. 64 loads of one output in flight and G / 64 dependent round trips (the partials were written by other XCDs: ~1-2 us each; with 4
+// slices -- 256 threads -- a G = 256 reduce ran 16 of them: 8-14 us per launch, seven launches per train step).  Returns the sum in the
+// slice-0 threads; every thread of the block must call it.  SL = 4 (256 threads) for short partial lists (G <= 64: the 64-channel-pair
+// weight gradients), where 16 slices only add waves.
+constexpr int RED_SLICES = 16;
+template <int SL = RED_SLICES>
+__device__ inline float partial_sum(const float* __restrict__ partial, long long off, long long stride, int G, bool valid, float (*red)[64]) {
+    const int o_local = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (valid) {
+        int g = slice;
+        for (; g + 3 * SL < G; g += 4 * SL) {
+            s0 += partial[g * stride + off];
+            s1 += partial[(g + SL) * stride + off];
+            s2 += partial[(g + 2 * SL) * stride + off];
+            s3 += partial[(g + 3 * SL) * stride + off];
+        }
+        for (; g < G; g += SL) s0 += partial[g * stride + off];
+    }
+    red[slice][o_local] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    float t = 0.f;
+    if (slice == 0) {
+#pragma unroll
+        for (int q = 0; q < SL; q += 4) t += (red[q][o_local] + red[q + 1][o_local]) + (red[q + 2][o_local] + red[q + 3][o_local]);
+    }
+    return t;
+}
+
 // linear index -> (n, c, y, x) of a [n][c][h][w] iteration space; 32-bit arithmetic whenever the index fits (it always does for
 // the shapes on this path) instead of four 64-bit divisions per element.  (Measured: no effect on the glue kernels' time -- they
 // stream at 5+ TB/s either way -- kept because it is the cheaper code.)

@@ -123,30 +123,11 @@ __global__ __launch_bounds__(256) void image_in_wgrad_kernel(const float* __rest
     (void)cout;
 }
 
-// fixed-order reduction over the G block partials: 64 outputs x 4 G-slices per block, 4 load chains per thread
-__device__ inline float sliced_sum(const float* __restrict__ partial, long long off, long long stride, int G, int slice,
-                                   float (*red)[64], int o_local, bool valid) {
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    if (valid) {
-        int g = slice;
-        for (; g + 12 < G; g += 16) {
-            s0 += partial[g * stride + off];
-            s1 += partial[(g + 4) * stride + off];
-            s2 += partial[(g + 8) * stride + off];
-            s3 += partial[(g + 12) * stride + off];
-        }
-        for (; g < G; g += 4) s0 += partial[g * stride + off];
-    }
-    red[slice][o_local] = (s0 + s1) + (s2 + s3);
-    __syncthreads();
-    return (red[0][o_local] + red[1][o_local]) + (red[2][o_local] + red[3][o_local]);
-}
-
 template <int KS>
-__global__ __launch_bounds__(256) void image_in_wgrad_reduce(const float* __restrict__ partial, float* __restrict__ dw,
+__global__ __launch_bounds__(64 * RED_SLICES) void image_in_wgrad_reduce(const float* __restrict__ partial, float* __restrict__ dw,
                                                              float* __restrict__ db, int cout, int G, int n_og, int accumulate) {
     constexpr int KK = KS * KS, PER = 16 * KK + 16;
-    __shared__ float red[4][64];
+    __shared__ float red[RED_SLICES][64];
     const int o_local = threadIdx.x & 63, slice = threadIdx.x >> 6;
     const int idx = blockIdx.x * 64 + o_local;
     long long off = 0;
@@ -160,7 +141,7 @@ __global__ __launch_bounds__(256) void image_in_wgrad_reduce(const float* __rest
         off = (long long)(o / 16) * PER + 16 * KK + (o % 16);
         valid = true;
     }
-    const float t = sliced_sum(partial, off, (long long)n_og * PER, G, slice, red, o_local, valid);
+    const float t = partial_sum(partial, off, (long long)n_og * PER, G, valid, red);
     if (slice == 0 && valid) {
         if (idx < cout * KK) dw[idx] = accumulate ? dw[idx] + t : t;
         else if (db) db[idx - cout * KK] = accumulate ? db[idx - cout * KK] + t : t;
@@ -390,10 +371,10 @@ __global__ __launch_bounds__(256) void image_out_wgrad_kernel(TV tx, const float
 }
 
 template <int KS>
-__global__ __launch_bounds__(256) void image_out_wgrad_reduce(const float* __restrict__ partial, float* __restrict__ dw,
+__global__ __launch_bounds__(64 * RED_SLICES) void image_out_wgrad_reduce(const float* __restrict__ partial, float* __restrict__ dw,
                                                               float* __restrict__ db, int cin, int G, int n_cg, int accumulate) {
     constexpr int KK = KS * KS, PER = 16 * KK + 1;
-    __shared__ float red[4][64];
+    __shared__ float red[RED_SLICES][64];
     const int o_local = threadIdx.x & 63, slice = threadIdx.x >> 6;
     const int idx = blockIdx.x * 64 + o_local;
     long long off = 0;
@@ -406,7 +387,7 @@ __global__ __launch_bounds__(256) void image_out_wgrad_reduce(const float* __res
         off = 16 * KK;  // bias sum lives in channel group 0
         valid = true;
     }
-    const float t = sliced_sum(partial, off, (long long)n_cg * PER, G, slice, red, o_local, valid);
+    const float t = partial_sum(partial, off, (long long)n_cg * PER, G, valid, red);
     if (slice == 0 && valid) {
         if (idx < cin * KK) dw[idx] = accumulate ? dw[idx] + t : t;
         else if (db) db[0] = accumulate ? db[0] + t : t;
@@ -468,8 +449,8 @@ extern "C" int mmif_conv2d_image_in_wgrad(const float* img, const mmif_tensor* g
 #undef CALL
     if (int rc = check_launch("image_in_wgrad")) return rc;
     const int n = cout * ksize * ksize + cout;
-    if (ksize == 3) hipLaunchKernelGGL((image_in_wgrad_reduce<3>), dim3(cdiv(n, 64)), dim3(256), 0, st, ws, dw, db, cout, G, n_og, accumulate);
-    else hipLaunchKernelGGL((image_in_wgrad_reduce<1>), dim3(cdiv(n, 64)), dim3(256), 0, st, ws, dw, db, cout, G, n_og, accumulate);
+    if (ksize == 3) hipLaunchKernelGGL((image_in_wgrad_reduce<3>), dim3(cdiv(n, 64)), dim3(64 * RED_SLICES), 0, st, ws, dw, db, cout, G, n_og, accumulate);
+    else hipLaunchKernelGGL((image_in_wgrad_reduce<1>), dim3(cdiv(n, 64)), dim3(64 * RED_SLICES), 0, st, ws, dw, db, cout, G, n_og, accumulate);
     return check_launch("image_in_wgrad_reduce");
 }
 
@@ -542,7 +523,7 @@ extern "C" int mmif_conv2d_image_out_wgrad(const mmif_tensor* x, const float* gi
 #undef CALL
     if (int rc = check_launch("image_out_wgrad")) return rc;
     const int n = cin * ksize * ksize + 1;
-    if (ksize == 3) hipLaunchKernelGGL((image_out_wgrad_reduce<3>), dim3(cdiv(n, 64)), dim3(256), 0, st, ws, dw, db, cin, G, n_cg, accumulate);
-    else hipLaunchKernelGGL((image_out_wgrad_reduce<1>), dim3(cdiv(n, 64)), dim3(256), 0, st, ws, dw, db, cin, G, n_cg, accumulate);
+    if (ksize == 3) hipLaunchKernelGGL((image_out_wgrad_reduce<3>), dim3(cdiv(n, 64)), dim3(64 * RED_SLICES), 0, st, ws, dw, db, cin, G, n_cg, accumulate);
+    else hipLaunchKernelGGL((image_out_wgrad_reduce<1>), dim3(cdiv(n, 64)), dim3(64 * RED_SLICES), 0, st, ws, dw, db, cin, G, n_cg, accumulate);
     return check_launch("image_out_wgrad_reduce");
 }

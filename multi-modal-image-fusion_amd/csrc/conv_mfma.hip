@@ -1764,12 +1764,12 @@ __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void wgrad_dma_kernel(TV
 }
 
 // dw / db = fixed-order sum of the G block partials of each (icg, ocg) pair
-__global__ __launch_bounds__(256) void wgrad_dma_reduce(const float* __restrict__ partial, float* __restrict__ dw, float* __restrict__ db,
+template <int SL>
+__global__ __launch_bounds__(64 * SL) void wgrad_dma_reduce(const float* __restrict__ partial, float* __restrict__ dw, float* __restrict__ db,
                                                         int cin, int cout, int G, int n_icg, int n_ocg, int accumulate) {
-    __shared__ float red[4][64];
+    __shared__ float red[SL][64];
     const int total_w = cout * cin * 9;
-    const int o_local = threadIdx.x & 63, slice = threadIdx.x >> 6;
-    const int idx = blockIdx.x * 64 + o_local;
+    const int idx = blockIdx.x * 64 + (threadIdx.x & 63);
     const int npairs = n_icg * n_ocg;
     long long off = -1;
     if (idx < total_w) {
@@ -1779,24 +1779,8 @@ __global__ __launch_bounds__(256) void wgrad_dma_reduce(const float* __restrict_
         const int o = idx - total_w;
         off = (long long)(0 + n_icg * (o / 64)) * WD_PER + 64 * 64 * 9 + (o % 64);
     }
-    float s = 0.f;
-    if (off >= 0) {
-        const long long stride = (long long)npairs * WD_PER;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        int gi = slice;
-        for (; gi + 12 < G; gi += 16) {
-            s0 += partial[gi * stride + off];
-            s1 += partial[(gi + 4) * stride + off];
-            s2 += partial[(gi + 8) * stride + off];
-            s3 += partial[(gi + 12) * stride + off];
-        }
-        for (; gi < G; gi += 4) s0 += partial[gi * stride + off];
-        s = (s0 + s1) + (s2 + s3);
-    }
-    red[slice][o_local] = s;
-    __syncthreads();
-    if (slice == 0 && off >= 0) {
-        const float t = (red[0][o_local] + red[1][o_local]) + (red[2][o_local] + red[3][o_local]);
+    const float t = partial_sum<SL>(partial, off, (long long)npairs * WD_PER, G, off >= 0, red);
+    if ((threadIdx.x >> 6) == 0 && off >= 0) {
         if (idx < total_w) dw[idx] = accumulate ? dw[idx] + t : t;
         else if (db != nullptr) db[idx - total_w] = accumulate ? db[idx - total_w] + t : t;
     }
@@ -2307,7 +2291,9 @@ static int launch_wgrad_dma(const TV& tx, const TV& tg, float* dw, float* db, in
                        n_icg, n_ocg, sgn);
     if (int rc = check_launch("wgrad_dma")) return rc;
     const int n = cout * cin * 9 + cout;
-    hipLaunchKernelGGL(wgrad_dma_reduce, dim3(cdiv(n, 64)), dim3(256), 0, st, ws, dw, db, cin, cout, G, n_icg, n_ocg, accumulate);
+    const int RG = G;
+    if (RG > 64) hipLaunchKernelGGL(wgrad_dma_reduce<16>, dim3(cdiv(n, 64)), dim3(1024), 0, st, ws, dw, db, cin, cout, G, n_icg, n_ocg, accumulate);
+    else hipLaunchKernelGGL(wgrad_dma_reduce<4>, dim3(cdiv(n, 64)), dim3(256), 0, st, ws, dw, db, cin, cout, G, n_icg, n_ocg, accumulate);
     return check_launch("wgrad_dma_reduce");
 }
 

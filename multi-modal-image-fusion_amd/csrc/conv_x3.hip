@@ -762,13 +762,13 @@ __global__ __launch_bounds__(64 * NWV, 12 / NWV) void wgrad_x3_kernel(TV tx, TV 
 }
 
 // dw / db = fixed-order sum of the G block partials of each (icg, ocg) pair
-__global__ __launch_bounds__(256) void wgrad_x3_reduce(const float* __restrict__ partial, float* __restrict__ dw, float* __restrict__ db,
+template <int SL>
+__global__ __launch_bounds__(64 * SL) void wgrad_x3_reduce(const float* __restrict__ partial, float* __restrict__ dw, float* __restrict__ db,
                                                        int cin, int cout, int G, int n_icg, int n_ocg, int accumulate, int taps) {
-    __shared__ float red[4][64];
+    __shared__ float red[SL][64];
     const int XW_PER = 64 * 64 * taps + 64;
     const int total_w = cout * cin * taps;
-    const int o_local = threadIdx.x & 63, slice = threadIdx.x >> 6;
-    const int idx = blockIdx.x * 64 + o_local;
+    const int idx = blockIdx.x * 64 + (threadIdx.x & 63);
     const int npairs = n_icg * n_ocg;
     long long off = -1;
     if (idx < total_w) {
@@ -782,24 +782,8 @@ __global__ __launch_bounds__(256) void wgrad_x3_reduce(const float* __restrict__
         const int o = idx - total_w;
         off = (long long)(0 + n_icg * (o / 64)) * XW_PER + 64 * 64 * taps + (o % 64);
     }
-    float s = 0.f;
-    if (off >= 0) {
-        const long long stride = (long long)npairs * XW_PER;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        int gi = slice;
-        for (; gi + 12 < G; gi += 16) {
-            s0 += partial[gi * stride + off];
-            s1 += partial[(gi + 4) * stride + off];
-            s2 += partial[(gi + 8) * stride + off];
-            s3 += partial[(gi + 12) * stride + off];
-        }
-        for (; gi < G; gi += 4) s0 += partial[gi * stride + off];
-        s = (s0 + s1) + (s2 + s3);
-    }
-    red[slice][o_local] = s;
-    __syncthreads();
-    if (slice == 0 && off >= 0) {
-        const float t = (red[0][o_local] + red[1][o_local]) + (red[2][o_local] + red[3][o_local]);
+    const float t = partial_sum<SL>(partial, off, (long long)npairs * XW_PER, G, off >= 0, red);
+    if ((threadIdx.x >> 6) == 0 && off >= 0) {
         if (idx < total_w) dw[idx] = accumulate ? dw[idx] + t : t;
         else if (db != nullptr) db[idx - total_w] = accumulate ? db[idx - total_w] + t : t;
     }
@@ -988,7 +972,9 @@ int wgrad_x3(const TV& tx, const TV& tg, float* dw, float* db, int cin, int cout
         hipLaunchKernelGGL((wgrad_x3_kernel<8, 8, 8, 1>), dim3(G * n_icg * n_ocg), dim3(XW_THREADS), 0, st, tx, tg, ws, cin, cout, tiles_x, tpi, total, G, n_icg, n_ocg);
         if (int rc = check_launch("wgrad_x3 1x1")) return rc;
         const int n = cout * cin + cout;
-        hipLaunchKernelGGL(wgrad_x3_reduce, dim3(cdiv(n, 64)), dim3(256), 0, st, ws, dw, db, cin, cout, 3 * G, n_icg, n_ocg, accumulate, 1);
+        const int RG = 3 * G;
+        if (RG > 64) hipLaunchKernelGGL(wgrad_x3_reduce<16>, dim3(cdiv(n, 64)), dim3(1024), 0, st, ws, dw, db, cin, cout, 3 * G, n_icg, n_ocg, accumulate, 1);
+    else hipLaunchKernelGGL(wgrad_x3_reduce<4>, dim3(cdiv(n, 64)), dim3(256), 0, st, ws, dw, db, cin, cout, 3 * G, n_icg, n_ocg, accumulate, 1);
         return check_launch("wgrad_x3_reduce");
     }
     const bool thin = cin <= 48 && cout <= 16;
@@ -1007,7 +993,9 @@ int wgrad_x3(const TV& tx, const TV& tg, float* dw, float* db, int cin, int cout
         hipLaunchKernelGGL((wgrad_x3_kernel<8, 8, 8, 3>), dim3(G * n_icg * n_ocg), dim3(XW_THREADS), 0, st, tx, tg, ws, cin, cout, tx_abl, tpi, total, G, n_icg, n_ocg);
     if (int rc = check_launch("wgrad_x3")) return rc;
     const int n = cout * cin * 9 + cout;
-    hipLaunchKernelGGL(wgrad_x3_reduce, dim3(cdiv(n, 64)), dim3(256), 0, st, ws, dw, db, cin, cout, G, n_icg, n_ocg, accumulate, 9);
+    const int RG = G;
+    if (RG > 64) hipLaunchKernelGGL(wgrad_x3_reduce<16>, dim3(cdiv(n, 64)), dim3(1024), 0, st, ws, dw, db, cin, cout, G, n_icg, n_ocg, accumulate, 9);
+    else hipLaunchKernelGGL(wgrad_x3_reduce<4>, dim3(cdiv(n, 64)), dim3(256), 0, st, ws, dw, db, cin, cout, G, n_icg, n_ocg, accumulate, 9);
     return check_launch("wgrad_x3_reduce");
 }
 

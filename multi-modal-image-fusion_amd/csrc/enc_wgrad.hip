@@ -378,28 +378,12 @@ __global__ __launch_bounds__(256, 2) void taprow_wgrad_kernel(TV tx, TV tg, floa
 }
 
 // out[i] = sum_g partial[g][i] (fixed order); the first n_w entries are dW in its natural layout, the rest db
-__global__ __launch_bounds__(256) void taprow_wgrad_reduce(const float* __restrict__ partial, float* __restrict__ dw, float* __restrict__ db, int n_w,
+__global__ __launch_bounds__(64 * RED_SLICES) void taprow_wgrad_reduce(const float* __restrict__ partial, float* __restrict__ dw, float* __restrict__ db, int n_w,
                                                            int per, int G, int accumulate) {
-    __shared__ float red[4][64];
-    const int o_local = threadIdx.x & 63, slice = threadIdx.x >> 6;
-    const int idx = blockIdx.x * 64 + o_local;
-    float s = 0.f;
-    if (idx < per) {
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        int k = slice;
-        for (; k + 12 < G; k += 16) {
-            s0 += partial[(long long)k * per + idx];
-            s1 += partial[(long long)(k + 4) * per + idx];
-            s2 += partial[(long long)(k + 8) * per + idx];
-            s3 += partial[(long long)(k + 12) * per + idx];
-        }
-        for (; k < G; k += 4) s0 += partial[(long long)k * per + idx];
-        s = (s0 + s1) + (s2 + s3);
-    }
-    red[slice][o_local] = s;
-    __syncthreads();
-    if (slice != 0 || idx >= per) return;
-    const float t = (red[0][o_local] + red[1][o_local]) + (red[2][o_local] + red[3][o_local]);
+    __shared__ float red[RED_SLICES][64];
+    const int idx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const float t = partial_sum(partial, idx, per, G, idx < per, red);
+    if ((threadIdx.x >> 6) != 0 || idx >= per) return;
     float* p = idx < n_w ? dw + idx : (db != nullptr ? db + (idx - n_w) : nullptr);
     if (p != nullptr) *p = accumulate ? *p + t : t;
 }
@@ -414,7 +398,7 @@ size_t wgrad_taprow_workspace(int cin, int cout) { return (size_t)EW_MAXG * ((si
 // fixed-order reduction of G natural-layout partials ([cout][cin][3][3] then [cout]) -- shared with the fused backward kernel of conv_mfma.hip
 int taprow_reduce_launch(const float* ws, float* dw, float* db, int cin, int cout, int G, int accumulate, hipStream_t st) {
     const int n_w = cout * cin * 9, per = n_w + cout;
-    hipLaunchKernelGGL(taprow_wgrad_reduce, dim3(cdiv(per, 64)), dim3(256), 0, st, ws, dw, db, n_w, per, G, accumulate);
+    hipLaunchKernelGGL(taprow_wgrad_reduce, dim3(cdiv(per, 64)), dim3(64 * RED_SLICES), 0, st, ws, dw, db, n_w, per, G, accumulate);
     return check_launch("wgrad_taprow_reduce");
 }
 
@@ -429,34 +413,18 @@ int wgrad_taprow(const TV& tx, const TV& tg, float* dw, float* db, int cin, int 
 #undef GO
     if (int rc = check_launch("wgrad_taprow")) return rc;
     const int n_w = cout * cin * 9, per = n_w + cout;
-    hipLaunchKernelGGL(taprow_wgrad_reduce, dim3(cdiv(per, 64)), dim3(256), 0, st, (const float*)ws, dw, db, n_w, per, G, accumulate);
+    hipLaunchKernelGGL(taprow_wgrad_reduce, dim3(cdiv(per, 64)), dim3(64 * RED_SLICES), 0, st, (const float*)ws, dw, db, n_w, per, G, accumulate);
     return check_launch("wgrad_taprow_reduce");
 }
 
 struct EwDst { float* dw0; float* db0; float* dw[3]; float* db[3]; };
 
 // 64 outputs x 4 slices of the G partials per block; fixed summation order
-__global__ __launch_bounds__(256) void enc_wgrad_reduce(const float* __restrict__ partial, EwDst D, int G, int accumulate) {
-    __shared__ float red[4][64];
-    const int o_local = threadIdx.x & 63, slice = threadIdx.x >> 6;
-    const int idx = blockIdx.x * 64 + o_local;
-    float s = 0.f;
-    if (idx < EW_PER) {
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;   // 4 independent chains keep loads in flight
-        int k = slice;
-        for (; k + 12 < G; k += 16) {
-            s0 += partial[(long long)k * EW_PER + idx];
-            s1 += partial[(long long)(k + 4) * EW_PER + idx];
-            s2 += partial[(long long)(k + 8) * EW_PER + idx];
-            s3 += partial[(long long)(k + 12) * EW_PER + idx];
-        }
-        for (; k < G; k += 4) s0 += partial[(long long)k * EW_PER + idx];
-        s = (s0 + s1) + (s2 + s3);
-    }
-    red[slice][o_local] = s;
-    __syncthreads();
-    if (slice != 0 || idx >= EW_PER) return;
-    const float t = (red[0][o_local] + red[1][o_local]) + (red[2][o_local] + red[3][o_local]);
+__global__ __launch_bounds__(64 * RED_SLICES) void enc_wgrad_reduce(const float* __restrict__ partial, EwDst D, int G, int accumulate) {
+    __shared__ float red[RED_SLICES][64];
+    const int idx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const float t = partial_sum(partial, idx, EW_PER, G, idx < EW_PER, red);
+    if ((threadIdx.x >> 6) != 0 || idx >= EW_PER) return;
     float* p = nullptr;
     if (idx < EW_OFF2) p = D.dw[2] + idx;
     else if (idx < EW_OFF1) p = D.dw[1] + (idx - EW_OFF2);
@@ -506,6 +474,6 @@ extern "C" int mmif_dense_encoder_wgrad(const float* img, const mmif_tensor* x, 
     D.dw0 = dw0; D.db0 = db0;
     D.dw[0] = dw1; D.dw[1] = dw2; D.dw[2] = dw3;
     D.db[0] = db1; D.db[1] = db2; D.db[2] = db3;
-    hipLaunchKernelGGL(enc_wgrad_reduce, dim3(cdiv(EW_PER, 64)), dim3(256), 0, st, (const float*)workspace, D, G, accumulate);
+    hipLaunchKernelGGL(enc_wgrad_reduce, dim3(cdiv(EW_PER, 64)), dim3(64 * RED_SLICES), 0, st, (const float*)workspace, D, G, accumulate);
     return check_launch("enc_wgrad_reduce");
 }
