@@ -384,8 +384,12 @@ int mmif_conv2d_reflect_bwd_pair(const mmif_tensor* gy, const void* w_packed_t, 
  * one difference in HBM traffic: the weight-gradient kernel, which stages the activation tiles anyway, leaves their ReLU SIGN BYTES (one
  * byte per pixel and 8 channels) in `signs`, and the input-gradient kernel reads those instead of the activations (1/16 of the bytes).
  * gy: folded halo-1; x: the layer's forward input (halo 0); gx: halo 1 with a zero ring; mask_bits: channel blocks of gx masked with
- * [x > 0].  Workspace: mmif_conv2d_wgrad_workspace(cin, cout, 3); signs: mmif_conv2d_bwd_wide_signs_bytes(n, cin, h, w) bytes, scratch. */
+ * [x > 0].  Workspace: mmif_conv2d_wgrad_workspace(cin, cout, 3); signs: mmif_conv2d_bwd_wide_signs_bytes(n, cin, h, w) bytes, scratch.
+ * fp32 tensors (mmif_conv2d_bwd_wide_supported_f32: any 3x3 / 1x1 layer the split-operand kernels of csrc/conv_x3.hip take, x3 operand
+ * image as w_packed_t): the same contract -- the split-operand weight gradient leaves the map ([n][ceil(cb / 4)][h][w] dwords, one byte per
+ * pixel and channel block), the split-operand dgrad masks with it: 1/32 of the bytes of x. */
 int mmif_conv2d_bwd_wide_supported(int32_t cin, int32_t cout, int32_t ksize);
+int mmif_conv2d_bwd_wide_supported_f32(int32_t cin, int32_t cout, int32_t ksize);
 size_t mmif_conv2d_bwd_wide_signs_bytes(int32_t n, int32_t cin, int32_t h, int32_t w);
 int mmif_conv2d_reflect_bwd_wide(const mmif_tensor* gy, const void* w_packed_t, const mmif_tensor* x, const mmif_tensor* gx, float* dw, float* db,
                                  int32_t cin, int32_t cout, int32_t ksize, uint64_t mask_bits, int32_t accumulate, void* workspace,

@@ -30,10 +30,11 @@ int bwd_wide(const TV& tx, const TV& tg, const TV& tgx, const void* wpk_dgrad, f
 // conv_x3.hip
 bool conv_x3_supported(bool dgrad, int ks, int cin, int cout, const TV& tin, const TV& tout);
 int conv_x3(bool dgrad, const TV& tin, const TV& tout, const TV& tmask, const void* wpk, const float* bias, int cin, int cout, int relu,
-            uint64_t mask_bits, uint64_t accum_bits, hipStream_t st, int ks);
+            uint64_t mask_bits, uint64_t accum_bits, hipStream_t st, int ks, const unsigned* signs = nullptr);
 bool wgrad_x3_supported(int ks, int cin, int cout, const TV& tx, const TV& tg);
 size_t wgrad_x3_workspace(int cin, int cout, int ks);
-int wgrad_x3(const TV& tx, const TV& tg, float* dw, float* db, int cin, int cout, int accumulate, float* ws, hipStream_t st, int ks);
+int wgrad_x3(const TV& tx, const TV& tg, float* dw, float* db, int cin, int cout, int accumulate, float* ws, hipStream_t st, int ks, unsigned* signs = nullptr);
+size_t x3_signs_bytes(int n, int cb, int h, int w);
 }  // namespace mmif
 
 using namespace mmif;
@@ -218,7 +219,14 @@ extern "C" int mmif_conv2d_reflect_bwd_pair(const mmif_tensor* gy, const void* w
 // x in `signs`, the input-gradient kernel reads those instead of x.  Same results as mmif_conv2d_reflect_wgrad followed by
 // mmif_conv2d_reflect_dgrad_folded(mask_bits, accum_bits = 0).
 extern "C" int mmif_conv2d_bwd_wide_supported(int32_t cin, int32_t cout, int32_t ksize) { return bwd_wide_supported(ksize, cin, cout) ? 1 : 0; }
-extern "C" size_t mmif_conv2d_bwd_wide_signs_bytes(int32_t n, int32_t cin, int32_t h, int32_t w) { return bwd_wide_signs_bytes(n, cin, h, w); }
+extern "C" size_t mmif_conv2d_bwd_wide_signs_bytes(int32_t n, int32_t cin, int32_t h, int32_t w) {   // (enough for either tensor dtype's sign layout)
+    const size_t a = cin % 8 == 0 ? bwd_wide_signs_bytes(n, cin, h, w) : 0, b = x3_signs_bytes(n, (cin + 7) / 8, h, w);
+    return a > b ? a : b;
+}
+// fp32 tensors: any 3x3 / 1x1 layer the split-operand kernels take (csrc/conv_x3.hip) -- the tensor-dependent conditions are checked by the call
+extern "C" int mmif_conv2d_bwd_wide_supported_f32(int32_t cin, int32_t cout, int32_t ksize) {
+    return (ksize == 3 || ksize == 1) && cin >= 1 && cout >= 1 && cin <= 512 ? 1 : 0;
+}
 
 extern "C" int mmif_conv2d_reflect_bwd_wide(const mmif_tensor* gy, const void* w_packed_t, const mmif_tensor* x, const mmif_tensor* gx, float* dw,
                                             float* db, int32_t cin, int32_t cout, int32_t ksize, uint64_t mask_bits, int32_t accumulate,
@@ -226,6 +234,28 @@ extern "C" int mmif_conv2d_reflect_bwd_wide(const mmif_tensor* gy, const void* w
     if (int rc = validate_tensor(gy, "gy")) return rc;
     if (int rc = validate_tensor(x, "x")) return rc;
     if (int rc = validate_tensor(gx, "gx")) return rc;
+    if (gy->dtype == MMIF_F32 && x->dtype == MMIF_F32 && gx->dtype == MMIF_F32) {
+        // fp32 tensors: the split-operand weight gradient leaves its sign map ([n][ceil(cb / 4)][h][w] dwords), the split-operand dgrad
+        // masks with it, the stand-alone fold follows -- bit for bit mmif_conv2d_reflect_wgrad + mmif_conv2d_reflect_dgrad_folded
+        MMIF_REQUIRE(w_packed_t != nullptr && dw != nullptr, "conv2d_reflect_bwd_wide: NULL operand image / dw");
+        MMIF_REQUIRE(x->halo == 0 && gx->halo == 1, "conv2d_reflect_bwd_wide: x halo 0, gx halo 1 expected");
+        MMIF_REQUIRE(gy->n == x->n && gy->h == x->h && gy->w == x->w && gx->n == x->n && gx->h == x->h && gx->w == x->w, "conv2d_reflect_bwd_wide: shape mismatch");
+        MMIF_REQUIRE((cin + 7) / 8 == x->cb && x->cb == gx->cb && (cout + 7) / 8 == gy->cb, "conv2d_reflect_bwd_wide: channel blocks do not match");
+        const TV tx = make_tv(x), tg = make_tv(gy), tgx = make_tv(gx);
+        MMIF_REQUIRE(wgrad_x3_supported(ksize, cin, cout, tx, tg) && conv_x3_supported(true, ksize, cin, cout, tg, tgx),
+                     "conv2d_reflect_bwd_wide: layer %d -> %d k%d / tensors not covered by the split-operand kernels", cin, cout, ksize);
+        if (workspace == nullptr || workspace_bytes < wgrad_x3_workspace(cin, cout, ksize)) {
+            set_error("conv2d_reflect_bwd_wide: workspace too small");
+            return MMIF_EWORKSPACE;
+        }
+        if (signs == nullptr || signs_bytes < x3_signs_bytes(x->n, x->cb, x->h, x->w)) {
+            set_error("conv2d_reflect_bwd_wide: sign-byte buffer too small (mmif_conv2d_bwd_wide_signs_bytes)");
+            return MMIF_EWORKSPACE;
+        }
+        if (int rc = wgrad_x3(tx, tg, dw, db, cin, cout, accumulate, (float*)workspace, (hipStream_t)stream, ksize, (unsigned*)signs)) return rc;
+        if (int rc = conv_x3(true, tg, tgx, tx, w_packed_t, nullptr, cin, cout, 0, mask_bits, 0, (hipStream_t)stream, ksize, (const unsigned*)signs)) return rc;
+        return ksize == 1 ? MMIF_OK : mmif_fold_halo(gx, stream);
+    }
     MMIF_REQUIRE(bwd_wide_supported(ksize, cin, cout), "conv2d_reflect_bwd_wide: unsupported layer %d -> %d k%d", cin, cout, ksize);
     MMIF_REQUIRE(w_packed_t != nullptr && dw != nullptr, "conv2d_reflect_bwd_wide: NULL operand image / dw");
     MMIF_REQUIRE(gy->dtype == MMIF_BF16 && x->dtype == MMIF_BF16 && gx->dtype == MMIF_BF16, "conv2d_reflect_bwd_wide: bf16 tensors expected");

@@ -186,7 +186,7 @@ template <int MB, bool DGRAD, int NP, int NW, int RJ, int KS, bool F16 = false>
 __global__ __launch_bounds__(64 * NW, 2) void conv_x3_kernel(TV tin, TV tout, TV tmask, const uint4* __restrict__ wpk,
                                                               const float* __restrict__ bias, int n_out, int nch16, int nmb, int relu,
                                                               unsigned long long mask_bits, unsigned long long accum_bits, int tiles_x,
-                                                              int tiles_per_img, int total_tiles) {
+                                                              int tiles_per_img, int total_tiles, const unsigned* __restrict__ signs) {
     constexpr int MBW = 32 * MB;
     constexpr int TAPS = KS * KS, PD = KS / 2;    // KS = 1: the same kernel without halo and with one tap (HBM-bound: NestFuse's 1x1 layers)
     constexpr int WG = TAPS * 2 * MBW;            // weight granules of one piece of a 16-channel sub-chunk
@@ -450,7 +450,14 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_x3_kernel(TV tin, TV tout, TV
                                 old[q] = *reinterpret_cast<const x3_f4*>(tout.base + tout.gidx(in_, ocbc, ysc, xsc) * 32 + half * 16);
                             }
                         }
-                        if (mask_bits != 0ull) {
+                        if (mask_bits != 0ull && signs != nullptr) {   // the sign map wgrad_x3_kernel left: one dword = the 4 blocks of this group
+                            const unsigned sg = signs[(((long long)in_ * ((tmask.cb + 3) >> 2) + (mb * MB + m)) * tmask.h + oy) * tmask.w + ox];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const unsigned nib = (sg >> (8 * q + 4 * half)) & 15u;
+                                xm[q] = (x3_f4){(nib & 1u) ? 1.f : 0.f, (nib & 2u) ? 1.f : 0.f, (nib & 4u) ? 1.f : 0.f, (nib & 8u) ? 1.f : 0.f};
+                            }
+                        } else if (mask_bits != 0ull) {
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {   // blocks the mask does not cover read one hot line (uniform address select, no branch)
                                 const int ocb = (mb * MB + m) * 4 + q;
@@ -511,9 +518,9 @@ constexpr int XW_THREADS = 768;                  // (the 12-wave instantiations;
 // budget spent on TWICE the pixels per tile: those layers run one tile per ~3 us of global-load latency whatever the tile holds
 // (0.18-0.30 ms per launch with almost no MFMA work), so half the tiles is half the time.  Channel blocks past NXC / NGC are read
 // from the last plane kept (those dW rows / columns belong to channels the layer does not have and are never reduced).
-template <int TH, int NXC, int NGC, int KS, int NWV = 12>
+template <int TH, int NXC, int NGC, int KS, bool SIGNS = false, int NWV = 12>
 __global__ __launch_bounds__(64 * NWV, 12 / NWV) void wgrad_x3_kernel(TV tx, TV tg, float* __restrict__ partial, int cin, int cout, int tiles_x, int tpi,
-                                                               int total, int G, int n_icg, int n_ocg) {
+                                                               int total, int G, int n_icg, int n_ocg, unsigned* __restrict__ signs) {
     constexpr int XW_THREADS = 64 * NWV;             // 12 waves (v, jt, mt).  (NWV = 6, <8, 4, 2>: six-wave blocks, two per CU, for cin <= 32 -- measured
                                                      // slower, 0.224 vs 0.188 ms on 16 -> 16: twice the tiles cost more than the second block hides; not instantiated)
     constexpr int PD = KS / 2, TAPS = KS * KS;       // KS = 1: no halo, one tap; the three wave groups v split the k-steps instead of the tap columns
@@ -573,10 +580,16 @@ __global__ __launch_bounds__(64 * NWV, 12 / NWV) void wgrad_x3_kernel(TV tx, TV 
     constexpr int HALF_R = (XW_ROUNDS + 1) / 2;
     int k_done = 0;
     X3Gran rin[HALF_R];
+    // ReLU sign map of x for the dgrad that follows (mmif_conv2d_reflect_bwd_wide on fp32 tensors): one byte per pixel and channel block,
+    // bit i = channel i > 0, as [n][ceil(cb / 4)][h][w][4 blocks]; every x granule passes through this kernel's staging anyway -- the blocks
+    // of output-channel group 0 write the interior pixels of their tiles.  The dgrad then masks with 1/32 of the bytes of x itself.
+    const bool write_signs = SIGNS && signs != nullptr && ocg == 0;   // (a template switch: the map costs the kernel ~5 registers it does not have)
+    int c_in = 0, c_y0 = 0, c_x0 = 0;   // the tile whose staging registers are about to be committed
     auto issue = [&](int k_tile, int half) {
         const int tile = tw.first + k_tile * tw.stride;
         const int in_ = tile / tpi, tt = tile - in_ * tpi;
         const int y0 = (tt / tiles_x) * XW_TH, x0 = (tt % tiles_x) * XW_TW;
+        c_in = in_; c_y0 = y0; c_x0 = x0;
         const char* bx = tx.base + ((long long)in_ * tx.img + (long long)(tx.cb_off + icg * 8) * tx.plane) * 32;
         const char* bg = tg.base + ((long long)in_ * tg.img + (long long)(tg.cb_off + ocg * 8) * tg.plane) * 32;
         const unsigned xplane = (unsigned)tx.plane, gplane = (unsigned)tg.plane;
@@ -623,6 +636,18 @@ __global__ __launch_bounds__(64 * NWV, 12 / NWV) void wgrad_x3_kernel(TV tx, TV 
                     const int o = cb * XW_XPL + py * XW_XW + px;
                     dst[o] = pc[0];
                     dst[XW_XG + o] = pc[1];
+                    if (SIGNS && write_signs) {
+                        const int y = c_y0 + py - PD, x = c_x0 + px - PD;
+                        if (py >= PD && py < PD + XW_TH && px >= PD && px < PD + XW_TW && y < tx.h && x < tx.w) {
+                            const X3Gran& g = rin[kr];
+                            const unsigned bits = (g.a.x > 0.f) | (g.a.y > 0.f) << 1 | (g.a.z > 0.f) << 2 | (g.a.w > 0.f) << 3 | (g.b.x > 0.f) << 4 |
+                                                  (g.b.y > 0.f) << 5 | (g.b.z > 0.f) << 6 | (g.b.w > 0.f) << 7;
+                            const int cbg = icg * 8 + cb;
+                            // (32-bit offset: the map is 1/32 of x, which x3_small keeps below 2^31 bytes)
+                            reinterpret_cast<unsigned char*>(signs)[(((unsigned)(c_in * ((tx.cb + 3) >> 2) + (cbg >> 2)) * (unsigned)tx.h + (unsigned)y) * (unsigned)tx.w + (unsigned)x) * 4u + (unsigned)(cbg & 3)] =
+                                (unsigned char)bits;
+                        }
+                    }
                 } else {
                     const int o = 2 * XW_XG + cb * XW_GPL + py * XW_TW + px;
                     dst[o] = pc[0];
@@ -873,7 +898,7 @@ int conv_x3_pack_multi(const mmif_pack_job* jobs, int n_jobs, hipStream_t st) {
 
 template <int MB, int NP, int NW, int RJ, int KS = 3, bool F16 = false>
 static int launch_conv_x3(bool dgrad, const TV& tin, const TV& tout, const TV& tmask, const void* wpk, const float* bias, int n_out, int n_in,
-                          int relu, uint64_t mask_bits, uint64_t accum_bits, hipStream_t st) {
+                          int relu, uint64_t mask_bits, uint64_t accum_bits, hipStream_t st, const unsigned* signs) {
     const int tiles_x = cdiv(tout.ws, X3_TW), tiles_y = cdiv(tout.hs, RJ * NW);
     const int tpi = tiles_x * tiles_y, total = tpi * tout.n;
     static int nw4_blocks = -1;   // four-wave blocks per CU (persistent grid): $MMIF_X3_NW4_BLOCKS, default 3 (42 KB of LDS, < 168 VGPRs each)
@@ -887,19 +912,19 @@ static int launch_conv_x3(bool dgrad, const TV& tin, const TV& tout, const TV& t
     relu = (relu & 255) | (abl << 8);
     if (dgrad)
         hipLaunchKernelGGL((conv_x3_kernel<MB, true, NP, NW, RJ, KS>), dim3(G), dim3(X3_THREADS), 0, st, tin, tout, tmask, (const uint4*)wpk, bias, n_out, nch, nmb,
-                           relu, (unsigned long long)mask_bits, (unsigned long long)accum_bits, tiles_x, tpi, total);
+                           relu, (unsigned long long)mask_bits, (unsigned long long)accum_bits, tiles_x, tpi, total, signs);
     else
         hipLaunchKernelGGL((conv_x3_kernel<MB, false, NP, NW, RJ, KS, F16>), dim3(G), dim3(X3_THREADS), 0, st, tin, tout, tmask, (const uint4*)wpk, bias, n_out, nch, nmb,
-                           relu, (unsigned long long)mask_bits, (unsigned long long)accum_bits, tiles_x, tpi, total);
+                           relu, (unsigned long long)mask_bits, (unsigned long long)accum_bits, tiles_x, tpi, total, (const unsigned*)nullptr);
     return check_launch(dgrad ? "conv_x3 dgrad" : "conv_x3 fwd");
 }
 
 // forward: tin = x, tout = y;  dgrad: tin = gy (halo 0 or folded halo 1), tout = gx (the padded domain is written; the caller folds)
 int conv_x3(bool dgrad, const TV& tin, const TV& tout, const TV& tmask, const void* wpk, const float* bias, int cin, int cout, int relu,
-            uint64_t mask_bits, uint64_t accum_bits, hipStream_t st, int ks) {
+            uint64_t mask_bits, uint64_t accum_bits, hipStream_t st, int ks, const unsigned* signs) {
     const int n_out = dgrad ? cin : cout, n_in = dgrad ? cout : cin;
     const bool six = !dgrad && x3_fwd_pieces() == 3, h16 = !dgrad && x3_fwd_pieces() == 16;
-#define X3_ARGS tin, tout, tmask, wpk, bias, n_out, n_in, relu, mask_bits, accum_bits, st
+#define X3_ARGS tin, tout, tmask, wpk, bias, n_out, n_in, relu, mask_bits, accum_bits, st, signs
     if (ks == 1) {
         if (x3_mb(n_out) == 2) {
             if (h16) return launch_conv_x3<2, 2, 8, 2, 1, true>(false, X3_ARGS);
@@ -962,14 +987,17 @@ size_t wgrad_x3_workspace(int cin, int cout, int ks) {
     return G * npairs * (64 * 64 * 9 + 64) * sizeof(float);
 }
 
-int wgrad_x3(const TV& tx, const TV& tg, float* dw, float* db, int cin, int cout, int accumulate, float* ws, hipStream_t st, int ks) {
+size_t x3_signs_bytes(int n, int cb, int h, int w) { return (size_t)n * ((cb + 3) / 4) * h * w * 4; }
+
+int wgrad_x3(const TV& tx, const TV& tg, float* dw, float* db, int cin, int cout, int accumulate, float* ws, hipStream_t st, int ks, unsigned* signs) {
     if (ks == 1) {
         const int tiles_x = cdiv(tx.w, XW_TW), tiles_y = cdiv(tx.h, 8);
         const int tpi = tiles_x * tiles_y, total = tpi * tx.n;
         const int n_icg = cdiv(cin, 64), n_ocg = cdiv(cout, 64);
         int G = wgrad_x3_G(cin, cout);
         if (total < G) G = total;
-        hipLaunchKernelGGL((wgrad_x3_kernel<8, 8, 8, 1>), dim3(G * n_icg * n_ocg), dim3(XW_THREADS), 0, st, tx, tg, ws, cin, cout, tiles_x, tpi, total, G, n_icg, n_ocg);
+        if (signs != nullptr) hipLaunchKernelGGL((wgrad_x3_kernel<8, 8, 8, 1, true>), dim3(G * n_icg * n_ocg), dim3(XW_THREADS), 0, st, tx, tg, ws, cin, cout, tiles_x, tpi, total, G, n_icg, n_ocg, signs);
+        else hipLaunchKernelGGL((wgrad_x3_kernel<8, 8, 8, 1>), dim3(G * n_icg * n_ocg), dim3(XW_THREADS), 0, st, tx, tg, ws, cin, cout, tiles_x, tpi, total, G, n_icg, n_ocg, signs);
         if (int rc = check_launch("wgrad_x3 1x1")) return rc;
         const int n = cout * cin + cout;
         const int RG = 3 * G;
@@ -987,10 +1015,10 @@ int wgrad_x3(const TV& tx, const TV& tg, float* dw, float* db, int cin, int cout
     static int abl = -1;
     if (abl < 0) { const char* e = getenv("MMIF_X3_ABLATE"); abl = e != nullptr ? atoi(e) : 0; }
     const int tx_abl = tiles_x | (abl << 16);
-    if (thin)
-        hipLaunchKernelGGL((wgrad_x3_kernel<16, 6, 2, 3>), dim3(G * n_icg * n_ocg), dim3(XW_THREADS), 0, st, tx, tg, ws, cin, cout, tx_abl, tpi, total, G, n_icg, n_ocg);
-    else
-        hipLaunchKernelGGL((wgrad_x3_kernel<8, 8, 8, 3>), dim3(G * n_icg * n_ocg), dim3(XW_THREADS), 0, st, tx, tg, ws, cin, cout, tx_abl, tpi, total, G, n_icg, n_ocg);
+#define XW_LAUNCH(...) hipLaunchKernelGGL((wgrad_x3_kernel<__VA_ARGS__>), dim3(G * n_icg * n_ocg), dim3(XW_THREADS), 0, st, tx, tg, ws, cin, cout, tx_abl, tpi, total, G, n_icg, n_ocg, signs)
+    if (thin) { if (signs != nullptr) XW_LAUNCH(16, 6, 2, 3, true); else XW_LAUNCH(16, 6, 2, 3); }
+    else { if (signs != nullptr) XW_LAUNCH(8, 8, 8, 3, true); else XW_LAUNCH(8, 8, 8, 3); }
+#undef XW_LAUNCH
     if (int rc = check_launch("wgrad_x3")) return rc;
     const int n = cout * cin * 9 + cout;
     const int RG = G;

@@ -98,6 +98,7 @@ SIGNATURES = {
     "mmif_conv2d_bwd_pair_supported": (_i32, [_i32, _i32, _i32]),
     "mmif_conv2d_reflect_bwd_pair": (_i32, [_TP, _vp, _TP, _TP, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
     "mmif_conv2d_bwd_wide_supported": (_i32, [_i32, _i32, _i32]),
+    "mmif_conv2d_bwd_wide_supported_f32": (_i32, [_i32, _i32, _i32]),
     "mmif_conv2d_bwd_wide_signs_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "mmif_conv2d_reflect_bwd_wide": (_i32, [_TP, _vp, _TP, _TP, _vp, _vp, _i32, _i32, _i32, _u64, _i32, _vp, _sz, _vp, _sz, _vp]),
     "mmif_pack_dense_chain": (_i32, [_vp] * 7),

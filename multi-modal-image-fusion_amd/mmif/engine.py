@@ -368,6 +368,10 @@ class ModelEngine:
     def wide_ok(s, dtype, impl, x, gx):
         """this layer's backward runs as wgrad (leaving ReLU sign bytes) + dgrad reading them (csrc/conv_mfma.hip bwd_wide;
         $MMIF_BWD_WIDE=0: the two calls apart, the dgrad reading the activations)"""
+        if dtype == torch.float32:   # split-operand kernels (csrc/conv_x3.hip): any layer they take; the map is 1/32 of the bytes of x
+            return (impl != _lib.IMPL_VALU and x3_enabled() and not s.split and s.packed is not None and s.packed.fmt == _lib.F32
+                    and x.halo == 0 and gx.halo == 1 and x.cb == (s.cin + 7) // 8 and gx.cb == x.cb and x.h >= 2 and x.w >= 2
+                    and T.bwd_wide_supported(s.cin, s.cout, s.k, dtype) and switch("MMIF_BWD_WIDE"))
         return (dtype == torch.bfloat16 and impl != _lib.IMPL_VALU and not s.split and s.packed is not None and x.h >= 4 and x.w >= 4
                 and x.halo == 0 and gx.halo == 1 and x.cb * 8 == s.cin and T.bwd_wide_supported(s.cin, s.cout, s.k)
                 and (x.h + 2) * (x.w + 2) * 128 < (1 << 31) and switch("MMIF_BWD_WIDE"))

@@ -211,7 +211,9 @@ def conv_bwd_pair(gy, x, gx, dw, db, cin, cout, k, packed, ws, accumulate=False,
     return gx.as_folded()
 
 
-def bwd_wide_supported(cin, cout, k):
+def bwd_wide_supported(cin, cout, k, dtype=torch.bfloat16):
+    if dtype == torch.float32:
+        return bool(lib.mmif_conv2d_bwd_wide_supported_f32(cin, cout, k))
     return bool(lib.mmif_conv2d_bwd_wide_supported(cin, cout, k))
 
 

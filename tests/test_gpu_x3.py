@@ -114,6 +114,38 @@ def test_x3_kernels_vs_fp32_fma_kernels(cin, cout, n, h, w, ks, ghalo, fwd_piece
         close(a, r, 2e-6 if (what == "y" and fwd_pieces in (3, 16)) else X3_TOL, what)
 
 
+@pytest.mark.parametrize("cin,cout,n,h,w,ks", [s + (3,) for s in SHAPES] + [s + (1,) for s in SHAPES_1x1[:3]],
+                         ids=[f"{a}-{b}-{n}x{h}x{w}" for a, b, n, h, w in SHAPES] + [f"1x1-{a}-{b}-{n}x{h}x{w}" for a, b, n, h, w in SHAPES_1x1[:3]])
+def test_bwd_wide_fp32_equals_wgrad_plus_folded_dgrad(cin, cout, n, h, w, ks):
+    """mmif_conv2d_reflect_bwd_wide on fp32 tensors (the split-operand weight gradient leaves the ReLU sign map of x, the split-operand
+    dgrad masks with it) == mmif_conv2d_reflect_wgrad followed by mmif_conv2d_reflect_dgrad_folded, BIT FOR BIT: same kernels, and the
+    map holds exactly [x > 0] -- zeros and negative values of x included, partial mask-bit sets, ragged tiles and channel groups."""
+    from mmif import tensor as T
+    from mmif._lib import F32, IMPL_X3
+    torch.manual_seed(cin + 3 * cout + w)
+    x = T.BT.alloc(n, cin, h, w, torch.float32, DEV); x.buf.normal_()
+    x.buf[x.buf.abs() < 0.3] = 0.0                     # plenty of exact zeros (post-ReLU activations have them)
+    gy = T.BT.alloc(n, cout, h, w, torch.float32, DEV, halo=1, zero=True)
+    gy.buf[:, :, 1:-1, 1:-1].normal_()
+    gy = gy.as_folded()
+    wt = torch.randn(cout, cin, ks, ks, device=DEV) * 0.05
+    pk = T.PackedWeights(cout, cin, ks, DEV, F32); pk.pack(wt)
+    ws = torch.empty(T.wgrad_workspace_bytes(cin, cout, ks) // 4 + 1, dtype=torch.float32, device=DEV)
+    assert T.bwd_wide_supported(cin, cout, ks, torch.float32)
+    for mask in ((1 << x.cb) - 1, 0x5a5a5a5a5a5a & ((1 << x.cb) - 1), 0):
+        gx_a = T.BT.alloc(n, cin, h, w, torch.float32, DEV, halo=1, zero=True)
+        gx_b = T.BT.alloc(n, cin, h, w, torch.float32, DEV, halo=1, zero=True)
+        dw_a, db_a = torch.zeros_like(wt), torch.zeros(cout, device=DEV)
+        dw_b, db_b = torch.zeros_like(wt), torch.zeros(cout, device=DEV)
+        T.conv_wgrad(x, gy, dw_a, db_a, cin, cout, ks, ws, False, IMPL_X3)
+        T.conv_dgrad(gy, wt, x, gx_a, cin, cout, ks, mask, 0, pk, IMPL_X3, fold=True)
+        signs = torch.full((T.bwd_wide_signs_bytes(n, cin, h, w),), 0xa5, dtype=torch.uint8, device=DEV)   # stale scratch
+        T.conv_bwd_wide(gy, x, gx_b, dw_b, db_b, cin, cout, ks, pk, mask, ws, signs)
+        torch.cuda.synchronize()
+        assert torch.equal(dw_a, dw_b) and torch.equal(db_a, db_b), f"mask {mask:#x}: weight gradient"
+        assert torch.equal(gx_a.buf, gx_b.buf), f"mask {mask:#x}: input gradient"
+
+
 def test_x3_forward_vs_fp64_definition(fwd_pieces):
     """x3 forward on a 128 -> 128 layer against torch's fp64 conv on the CPU (reflect padding): the error of the split (2 pieces: 2^-17
     relative per product; 3 pieces: fp32 accumulation only) next to the fp32 FMA kernel's own rounding"""

@@ -26,7 +26,9 @@ MASK = 0 if os.environ.get("BENCH_NOMASK") else (1 << gx.cb) - 1
 def run(kind, impl):
     if kind == "fwd": T.conv_fwd(x, w, b, y, cin, cout, 3, True, pk, impl)
     elif kind == "dgrad": T.conv_dgrad(gy, w, x, gx, cin, cout, 3, MASK, 0, pk, impl, fold=True)
+    elif kind == "wide": T.conv_bwd_wide(gy, x, gx, dw, db, cin, cout, 3, pk, MASK, ws, signs)   # wgrad (+ sign map) + dgrad masking with it + fold
     else: T.conv_wgrad(x, gy, dw, db, cin, cout, 3, ws, False, impl)
+signs = torch.empty(T.bwd_wide_signs_bytes(B, cin, S, S), dtype=torch.uint8, device=dev)
 def timeit(kind, impl, iters):
     for _ in range(2): run(kind, impl)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -35,6 +37,6 @@ def timeit(kind, impl, iters):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters
 for name, impl, it in (("x3", IMPL_X3, iters),) + ((("valu", IMPL_VALU, 2),) if with_valu else ()):
-    for kind in ("fwd", "dgrad", "wgrad"):
+    for kind in ("fwd", "dgrad", "wgrad") + (("wide",) if name == "x3" else ()):
         ms = timeit(kind, impl, it)
         print(f"{name} {kind} {cin}->{cout} B={B} {S}x{S}: {ms:.3f} ms  {flops / ms / 1e9:.0f} TFLOP/s fp32-equivalent ({3 * flops / ms / 1e9:.0f} bf16 MFMA)", flush=True)
