@@ -51,6 +51,8 @@ def _run(rank, world, port, out, model_name="PFNetv1"):
     model.train()
     opt = FusedClipAdam(model.parameters(), lr=1e-3, betas=(0.9, 0.999), max_norm=5.0)
     l1, l2, l3 = SSIMLoss('ssim', weight=1.0), PixelLoss('l1', weight=0.01), GradLoss('l1', weight=0.1).to(dev)
+    from core.loss import FusionLoss
+    fused = FusionLoss(l1, l2, l3, 'max', 'max')
     lo, hi = shard_batch(SHAPE[0], rank, world)
     scal = None
     for step in range(2):      # step 0: one all-reduce; step 1: the two-bucket early reduce (armed by the first distributed step)
@@ -58,11 +60,14 @@ def _run(rank, world, port, out, model_name="PFNetv1"):
         i2 = torch.from_numpy(O.closed_form_image(SHAPE, 1.7 + step)).to(dev)[lo:hi].contiguous()
         opt.zero_grad(set_to_none=True)
         f = model(i1, i2)
-        a, b, c = l1(i1, i2, f), l2(i1, i2, f, mode='max'), l3(i1, i2, f, mode='max')
-        tot = a + b + c
-        opt.stage_scalars([tot, a, b, c])         # (a no-op on step 0: the flat buffer is not known yet)
+        # bench.py's / train.py's path: one fused loss call, its ready 4-vector as the scalars (_run_seq below passes a list of 0-dim
+        # tensors).  Both world sizes take the same path: Adam's first steps turn a last-bit difference of a near-zero gradient into a
+        # visible parameter difference, so the comparison wants identical arithmetic up to the batch split
+        tot = fused(i1, i2, f)
+        vals = fused.values
+        opt.stage_scalars(vals)         # (a no-op on step 0: the flat buffer is not known yet)
         tot.backward()
-        opt.step(scalars=[tot, a, b, c])
+        opt.step(scalars=vals)
         scal = opt.reduced_scalars.detach().cpu().numpy()
     torch.cuda.synchronize()
     # a conv bias in front of a BatchNorm has an exactly-zero true gradient (the norm removes the mean): what the kernels produce for
