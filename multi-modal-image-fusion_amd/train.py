@@ -89,10 +89,7 @@ def train_model(model, data_loader, loss_fn1, loss_fn2, loss_fn3, epoch, mode='t
         else:
             with torch.no_grad():
                 imgf = model(img1, img2)
-                loss1 = loss_fn1(img1, img2, imgf)
-                loss2 = loss_fn2(img1, img2, imgf, mode='max')
-                loss3 = loss_fn3(img1, img2, imgf, mode='max')
-                total_loss = loss1 + loss2 + loss3
+                total_loss, loss1, loss2, loss3 = _losses(loss_fn1, loss_fn2, loss_fn3, img1, img2, imgf)
             if is_distributed:
                 vals = torch.stack([total_loss, loss1, loss2, loss3])
                 total_loss, loss1, loss2, loss3 = reduce_value(vals, world_size).unbind(0)
