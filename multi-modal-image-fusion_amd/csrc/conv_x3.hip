@@ -786,6 +786,200 @@ __global__ __launch_bounds__(64 * NWV, 12 / NWV) void wgrad_x3_kernel(TV tx, TV 
     }
 }
 
+
+// ------------------------------------------------------------------ wgrad, thin layers (<= 48 in, <= 16 out: the DenseBlock convs, decode.3)
+// wgrad_x3_kernel gives such a layer 3 of its 12 waves to compute with (on 32 x 32 tiles of which a quarter is real), keeps ONE tile's
+// loads in flight per CU and pays a 12-wave barrier per tile: 0.19-0.28 ms per launch where the bytes take 0.06-0.11.  Here: blocks of
+// FOUR waves on 8 x 16-pixel tiles, three of them per CU (44 KB of LDS, < 168 registers) -- the same trick as the thin forward / dgrad
+// kernels: the blocks hide each other's load latency --, 16 x 16 x 32 MFMAs (no padding: M = 16 output channels, N = 16 input channels,
+// K = the 32 pixels of two tile rows) and the same two-piece products.  Work item (j, v) = input-channel block j x tap column v: it owns
+// dW[16][16 j .. 16 j + 15][u = 0..2][v] in 12 accumulator registers; a wave takes items wave, wave + 4, ...
+constexpr int XT_TH = 8, XT_TW = 16, XT_XH = XT_TH + 2, XT_XW = XT_TW + 2;
+constexpr int XT_XPL = XT_XH * XT_XW + 4, XT_GPL = XT_TH * XT_TW + 4;    // 184 / 132 granules per plane (= 4, 4 mod 16: see wgrad_x3_kernel)
+constexpr int XT_THREADS = 256;
+constexpr int XT_PER = 9 * 3 * 4 * 64 + 64;                            // floats per block partial: [item][u][reg][lane], db[16] (+ pad)
+template <int NXC, bool SIGNS = false>
+__global__ __launch_bounds__(XT_THREADS, 3) void wgrad_x3_thin_kernel(TV tx, TV tg, float* __restrict__ partial, int tiles_x, int tpi, int total,
+                                                                      unsigned* __restrict__ signs) {
+    constexpr int XG = NXC * XT_XPL, GG = 2 * XT_GPL;                  // granules of one piece of the x / g tile
+    constexpr int N_X = NXC * XT_XH * XT_XW, N_ALL = N_X + 2 * XT_TH * XT_TW;
+    constexpr int ROUNDS = (N_ALL + XT_THREADS - 1) / XT_THREADS;       // 3 / 4 / 6
+    constexpr int NITEM = 3 * (NXC / 2), MAXI = (NITEM + 3) / 4;        // 3 / 6 / 9 items, 1 / 2 / 3 per wave
+    __shared__ __attribute__((aligned(16))) x3_u4 s_buf[2 * XG + 2 * GG];   // [x hi][x lo][g hi][g lo]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const TileWalk tw = xcd_walk(total, gridDim.x, blockIdx.x);
+    for (int i = tid; i < 2 * XG + 2 * GG; i += XT_THREADS) s_buf[i] = (x3_u4){0u, 0u, 0u, 0u};   // (the planes of absent channel blocks stay zero)
+    unsigned geo[ROUNDS];   // is-g << 24 | channel block << 16 | tile row << 8 | tile column
+#pragma unroll
+    for (int k = 0; k < ROUNDS; ++k) {
+        const int e = min(tid + XT_THREADS * k, N_ALL - 1);
+        if (e < N_X) {
+            const int cb = e / (XT_XH * XT_XW), rem = e - cb * (XT_XH * XT_XW), py = rem / XT_XW;
+            geo[k] = (unsigned)(cb << 16 | py << 8 | (rem - py * XT_XW));
+        } else {
+            const int e2 = e - N_X;
+            const int cb = e2 / (XT_TH * XT_TW), rem = e2 - cb * (XT_TH * XT_TW), py = rem / XT_TW;
+            geo[k] = (unsigned)(1u << 24 | cb << 16 | py << 8 | (rem - py * XT_TW));
+        }
+    }
+    X3Gran rin[ROUNDS];
+    int c_in = 0, c_y0 = 0, c_x0 = 0;   // the tile in the staging registers (SIGNS: the ReLU sign map of x, as wgrad_x3_kernel writes it)
+    auto issue = [&](int k_tile) {
+        const int tile = tw.first + k_tile * tw.stride;
+        const int in_ = tile / tpi, tt = tile - in_ * tpi;
+        const int y0 = (tt / tiles_x) * XT_TH, x0 = (tt % tiles_x) * XT_TW;
+        c_in = in_; c_y0 = y0; c_x0 = x0;
+        const char* bx = tx.base + ((long long)in_ * tx.img + (long long)tx.cb_off * tx.plane) * 32;
+        const char* bg = tg.base + ((long long)in_ * tg.img + (long long)tg.cb_off * tg.plane) * 32;
+#pragma unroll
+        for (int k = 0; k < ROUNDS; ++k) {
+            const int cb = (int)((geo[k] >> 16) & 255u), py = (int)((geo[k] >> 8) & 255u), px = (int)(geo[k] & 255u);
+            rin[k].a = (x3_f4){0.f, 0.f, 0.f, 0.f};
+            rin[k].b = rin[k].a;
+            if (tid + XT_THREADS * k >= N_ALL) continue;
+            if (!(geo[k] >> 24)) {
+                if (cb < tx.cb) {
+                    const int y = min(max(reflect_idx(y0 + py - 1, tx.h), 0), tx.h - 1);
+                    const int x = min(max(reflect_idx(x0 + px - 1, tx.w), 0), tx.w - 1);
+                    const x3_f4* p = reinterpret_cast<const x3_f4*>(bx + ((unsigned)cb * (unsigned)tx.plane + (unsigned)(y * tx.ws + x)) * 32u);
+                    rin[k].a = p[0];
+                    rin[k].b = p[1];
+                }
+            } else {
+                const int y = y0 + py, x = x0 + px;
+                if (cb < tg.cb && y < tg.h && x < tg.w) {
+                    const x3_f4* p = reinterpret_cast<const x3_f4*>(bg + ((unsigned)cb * (unsigned)tg.plane + (unsigned)((y + tg.halo) * tg.ws + x + tg.halo)) * 32u);
+                    rin[k].a = p[0];
+                    rin[k].b = p[1];
+                }
+            }
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int k = 0; k < ROUNDS; ++k) {
+            if (tid + XT_THREADS * k >= N_ALL) continue;
+            const int cb = (int)((geo[k] >> 16) & 255u), py = (int)((geo[k] >> 8) & 255u), px = (int)(geo[k] & 255u);
+            x3_u4 pc[2];
+            x3_split_gran<2>(rin[k], pc);
+            if (!(geo[k] >> 24)) {
+                const int o = cb * XT_XPL + py * XT_XW + px;
+                s_buf[o] = pc[0];
+                s_buf[XG + o] = pc[1];
+                if (SIGNS) {
+                    const int y = c_y0 + py - 1, x = c_x0 + px - 1;
+                    if (py >= 1 && py <= XT_TH && px >= 1 && px <= XT_TW && y < tx.h && x < tx.w && cb < tx.cb) {
+                        const X3Gran& g = rin[k];
+                        const unsigned bits = (g.a.x > 0.f) | (g.a.y > 0.f) << 1 | (g.a.z > 0.f) << 2 | (g.a.w > 0.f) << 3 | (g.b.x > 0.f) << 4 |
+                                              (g.b.y > 0.f) << 5 | (g.b.z > 0.f) << 6 | (g.b.w > 0.f) << 7;
+                        reinterpret_cast<unsigned char*>(signs)[(((unsigned)(c_in * ((tx.cb + 3) >> 2) + (cb >> 2)) * (unsigned)tx.h + (unsigned)y) * (unsigned)tx.w + (unsigned)x) * 4u + (unsigned)(cb & 3)] =
+                            (unsigned char)bits;
+                    }
+                }
+            } else {
+                const int o = 2 * XG + cb * XT_GPL + py * XT_TW + px;
+                s_buf[o] = pc[0];
+                s_buf[GG + o] = pc[1];
+            }
+        }
+    };
+
+    typedef __attribute__((ext_vector_type(4))) float f32x4_;
+    f32x4_ acc[MAXI][3], accb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i)
+#pragma unroll
+        for (int u = 0; u < 3; ++u) acc[i][u] = (f32x4_){0.f, 0.f, 0.f, 0.f};
+    const x3_bf16x8 ones = __builtin_bit_cast(x3_bf16x8, ((x3_u4){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}));
+    // operand fragments of a 16 x 16 x 32 MFMA: lane l = channel l & 15, k-group l >> 4 = pixels 8 (l >> 4) .. + 7 of the k-step's 32
+    // (two tile rows of 16); the transposing read (see wgrad_x3_kernel): lane sl of a 16-lane group addresses pixel sl >> 2 (+ 4 for the
+    // second read), channel block (sl & 3) >> 1 of the 16-channel record, byte 8 (sl & 1), and receives channel sl of four pixels
+    const int sl = lane & 15, g4 = lane >> 4;
+    const int l_cb = (sl & 3) >> 1, l_byte = (sl & 1) * 8, l_row = g4 >> 1, l_col = 8 * (g4 & 1) + (sl >> 2);
+    auto ld_tr = [&](const char* base) {
+        const x3_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(X3_LDS_PTR(x3_s16x4, base));
+        const x3_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(X3_LDS_PTR(x3_s16x4, base + 4 * 16));
+        return __builtin_bit_cast(x3_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    const char* s_xh = reinterpret_cast<const char*>(s_buf);
+    const char* s_xl = s_xh + XG * 16;
+    const char* s_gh = s_xl + XG * 16;
+    const char* s_gl = s_gh + GG * 16;
+    const int goff = ((l_cb * XT_GPL) + l_row * XT_TW + l_col) * 16 + l_byte;                 // + ry * XT_TW * 16
+
+    __syncthreads();   // the zero fill
+    const int ntile = tw.count;
+    if (ntile > 0) {
+        issue(0);
+        commit();
+    }
+    __syncthreads();
+    for (int k = 0; k < ntile; ++k) {
+        if (k + 1 < ntile) issue(k + 1);
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+            const int item = wave + 4 * i;             // (wave uniform)
+            if (item >= NITEM) break;
+            const int j = item / 3, v = item - 3 * j;
+            const int xoff = (((2 * j + l_cb) * XT_XPL) + l_row * XT_XW + l_col + v) * 16 + l_byte;   // + (ry + u) * XT_XW * 16
+#pragma unroll
+            for (int ry = 0; ry < XT_TH; ry += 2) {
+                const x3_bf16x8 gh = ld_tr(s_gh + goff + ry * XT_TW * 16), gl = ld_tr(s_gl + goff + ry * XT_TW * 16);
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const x3_bf16x8 xh = ld_tr(s_xh + xoff + (ry + u) * XT_XW * 16), xl = ld_tr(s_xl + xoff + (ry + u) * XT_XW * 16);
+                    acc[i][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gl, xh, acc[i][u], 0, 0, 0);
+                    acc[i][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh, xl, acc[i][u], 0, 0, 0);
+                    acc[i][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh, xh, acc[i][u], 0, 0, 0);
+                }
+                if (item == 0) {   // bias gradient: row sums of the gradient fragments
+                    accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gl, ones, accb, 0, 0, 0);
+                    accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh, ones, accb, 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();   // every wave has read the tile
+        if (k + 1 < ntile) commit();
+        __syncthreads();
+    }
+    // block partial, register-major: [item][u][reg][lane]; C layout of the MFMA: lane l reg r = dW[oc = 4 (l >> 4) + r][ic = 16 j + (l & 15)]
+    float* dst = partial + (long long)blockIdx.x * XT_PER;
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+        const int item = wave + 4 * i;
+        if (item >= NITEM) break;
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[((item * 3 + u) * 4 + r) * 64 + lane] = acc[i][u][r];
+    }
+    if (wave == 0 && (lane & 15) == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[9 * 3 * 4 * 64 + 4 * (lane >> 4) + r] = accb[r];
+    }
+}
+
+__global__ __launch_bounds__(64 * RED_SLICES) void wgrad_x3_thin_reduce(const float* __restrict__ partial, float* __restrict__ dw, float* __restrict__ db,
+                                                                       int cin, int cout, int G, int accumulate) {
+    __shared__ float red[RED_SLICES][64];
+    const int total_w = cout * cin * 9;
+    const int idx = blockIdx.x * 64 + (threadIdx.x & 63);
+    long long off = -1;
+    if (idx < total_w) {
+        const int tap = idx % 9, c = (idx / 9) % cin, o = idx / (9 * cin);
+        const int item = (c / 16) * 3 + tap % 3, u = tap / 3;
+        off = ((item * 3 + u) * 4 + (o & 3)) * 64 + (o >> 2) * 16 + (c % 16);
+    } else if (idx < total_w + cout) {
+        off = 9 * 3 * 4 * 64 + (idx - total_w);
+    }
+    const float t = partial_sum(partial, off, XT_PER, G, off >= 0, red);
+    if ((threadIdx.x >> 6) == 0 && off >= 0) {
+        if (idx < total_w) dw[idx] = accumulate ? dw[idx] + t : t;
+        else if (db != nullptr) db[idx - total_w] = accumulate ? db[idx - total_w] + t : t;
+    }
+}
+
 // dw / db = fixed-order sum of the G block partials of each (icg, ocg) pair
 template <int SL>
 __global__ __launch_bounds__(64 * SL) void wgrad_x3_reduce(const float* __restrict__ partial, float* __restrict__ dw, float* __restrict__ db,
@@ -1006,6 +1200,25 @@ int wgrad_x3(const TV& tx, const TV& tg, float* dw, float* db, int cin, int cout
         return check_launch("wgrad_x3_reduce");
     }
     const bool thin = cin <= 48 && cout <= 16;
+    static int thin4 = -1;   // $MMIF_X3_THIN_WGRAD=0: thin layers on wgrad_x3_kernel<16, 6, 2>
+    if (thin4 < 0) { const char* e = getenv("MMIF_X3_THIN_WGRAD"); thin4 = (e != nullptr && e[0] == '0') ? 0 : 1; }
+    if (thin && thin4) {
+        const int tiles_x = cdiv(tx.w, XT_TW), tiles_y = cdiv(tx.h, XT_TH);
+        const int tpi = tiles_x * tiles_y, total = tpi * tx.n;
+        int G = x3_num_cus() * (cin <= 16 ? 5 : (cin <= 32 ? 4 : 3));   // blocks per CU: what the registers (92 / 128 / 168) and the LDS (20 / 32 / 44 KB) allow
+        if (total < G) G = total;
+        if ((size_t)G * XT_PER * sizeof(float) <= wgrad_x3_workspace(cin, cout, 3)) {
+#define XT_LAUNCH(...) hipLaunchKernelGGL((wgrad_x3_thin_kernel<__VA_ARGS__>), dim3(G), dim3(XT_THREADS), 0, st, tx, tg, ws, tiles_x, tpi, total, signs)
+            if (cin <= 16) { if (signs != nullptr) XT_LAUNCH(2, true); else XT_LAUNCH(2); }
+            else if (cin <= 32) { if (signs != nullptr) XT_LAUNCH(4, true); else XT_LAUNCH(4); }
+            else { if (signs != nullptr) XT_LAUNCH(6, true); else XT_LAUNCH(6); }
+#undef XT_LAUNCH
+            if (int rc = check_launch("wgrad_x3 thin")) return rc;
+            const int n = cout * cin * 9 + cout;
+            hipLaunchKernelGGL(wgrad_x3_thin_reduce, dim3(cdiv(n, 64)), dim3(64 * RED_SLICES), 0, st, ws, dw, db, cin, cout, G, accumulate);
+            return check_launch("wgrad_x3_thin_reduce");
+        }
+    }
     const int th = thin ? 16 : 8;
     const int tiles_x = cdiv(tx.w, XW_TW), tiles_y = cdiv(tx.h, th);
     const int tpi = tiles_x * tiles_y, total = tpi * tx.n;
