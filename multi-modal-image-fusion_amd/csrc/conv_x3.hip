@@ -963,20 +963,22 @@ __global__ __launch_bounds__(XT_THREADS, 3) void wgrad_x3_thin_kernel(TV tx, TV 
 __global__ __launch_bounds__(64 * RED_SLICES) void wgrad_x3_thin_reduce(const float* __restrict__ partial, float* __restrict__ dw, float* __restrict__ db,
                                                                        int cin, int cout, int G, int accumulate) {
     __shared__ float red[RED_SLICES][64];
-    const int total_w = cout * cin * 9;
-    const int idx = blockIdx.x * 64 + (threadIdx.x & 63);
-    long long off = -1;
-    if (idx < total_w) {
-        const int tap = idx % 9, c = (idx / 9) % cin, o = idx / (9 * cin);
-        const int item = (c / 16) * 3 + tap % 3, u = tap / 3;
-        off = ((item * 3 + u) * 4 + (o & 3)) * 64 + (o >> 2) * 16 + (c % 16);
-    } else if (idx < total_w + cout) {
-        off = 9 * 3 * 4 * 64 + (idx - total_w);
+    // the partial's order: [item][u][reg][lane] for the layer's items (all blocks but the last), then db[16] behind all nine (the last block)
+    const int e = (blockIdx.x + 1 < gridDim.x ? blockIdx.x * 64 : 9 * 3 * 4 * 64) + (threadIdx.x & 63);
+    long long dst = -1;
+    if (e < 9 * 3 * 4 * 64) {
+        const int ln = e & 63, r = (e >> 6) & 3, u = (e >> 8) % 3, item = e / 768;
+        const int j = item / 3, v = item - 3 * j;
+        const int o = 4 * (ln >> 4) + r, c = 16 * j + (ln & 15);
+        if (o < cout && c < cin) dst = ((long long)o * cin + c) * 9 + u * 3 + v;
+    } else if (e < 9 * 3 * 4 * 64 + 16) {
+        const int o = e - 9 * 3 * 4 * 64;
+        if (o < cout) dst = -2 - o;
     }
-    const float t = partial_sum(partial, off, XT_PER, G, off >= 0, red);
-    if ((threadIdx.x >> 6) == 0 && off >= 0) {
-        if (idx < total_w) dw[idx] = accumulate ? dw[idx] + t : t;
-        else if (db != nullptr) db[idx - total_w] = accumulate ? db[idx - total_w] + t : t;
+    const float t = partial_sum(partial, e, XT_PER, G, dst != -1, red);
+    if ((threadIdx.x >> 6) == 0 && dst != -1) {
+        if (dst >= 0) dw[dst] = accumulate ? dw[dst] + t : t;
+        else if (db != nullptr) { const int o = (int)(-2 - dst); db[o] = accumulate ? db[o] + t : t; }
     }
 }
 
@@ -984,27 +986,32 @@ __global__ __launch_bounds__(64 * RED_SLICES) void wgrad_x3_thin_reduce(const fl
 template <int SL>
 __global__ __launch_bounds__(64 * SL) void wgrad_x3_reduce(const float* __restrict__ partial, float* __restrict__ dw, float* __restrict__ db,
                                                        int cin, int cout, int G, int n_icg, int n_ocg, int accumulate, int taps) {
+    // threads walk the PARTIAL's order (register-major tiles: 64 consecutive threads read 64 consecutive floats of every block's partial)
+    // and scatter the one result each to dW's order; walking dW's order instead read 64 different cache lines per load instruction
     __shared__ float red[SL][64];
     const int XW_PER = 64 * 64 * taps + 64;
-    const int total_w = cout * cin * taps;
-    const int idx = blockIdx.x * 64 + (threadIdx.x & 63);
     const int npairs = n_icg * n_ocg;
-    long long off = -1;
-    if (idx < total_w) {
-        const int tap = idx % taps, c = (idx / taps) % cin, o = idx / (taps * cin);
-        // the wave tile (mt, jt) and the accumulator register / lane that hold dW[o][c]: oc = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), ic = lane & 31
-        const int mt = (o % 64) / 32, jt = (c % 64) / 32, oc_t = o % 32;
-        const int r = (oc_t & 3) + 4 * (oc_t >> 3), ln = ((oc_t >> 2) & 1) * 32 + (c % 32);
-        const int tile = taps == 1 ? (mt * 2 + jt) : ((mt * 2 + jt) * 3 + tap % 3) * 3 + tap / 3;
-        off = (long long)((c / 64) + n_icg * (o / 64)) * XW_PER + (tile * 16 + r) * 64 + ln;
-    } else if (idx < total_w + cout) {
-        const int o = idx - total_w;
-        off = (long long)(0 + n_icg * (o / 64)) * XW_PER + 64 * 64 * taps + (o % 64);
+    const long long idx = (long long)blockIdx.x * 64 + (threadIdx.x & 63);      // over npairs x XW_PER
+    const int pair = (int)(idx / XW_PER), e = (int)(idx - (long long)pair * XW_PER);
+    const int icg = pair % n_icg, ocg = pair / n_icg;
+    long long dst = -1;           // index into dw (>= 0), or -2 - o for db[o]
+    if (pair < npairs) {
+        if (e < 64 * 64 * taps) {
+            const int ln = e & 63, r = (e >> 6) & 15, tile = e >> 10;
+            int mt, jt, tap;
+            if (taps == 1) { mt = tile >> 1; jt = tile & 1; tap = 0; }
+            else { const int u = tile % 3, v = (tile / 3) % 3, mj = tile / 9; mt = mj >> 1; jt = mj & 1; tap = u * 3 + v; }
+            const int o = ocg * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5), c = icg * 64 + jt * 32 + (ln & 31);
+            if (o < cout && c < cin) dst = ((long long)o * cin + c) * taps + tap;
+        } else if (icg == 0) {
+            const int o = ocg * 64 + (e - 64 * 64 * taps);
+            if (o < cout) dst = -2 - o;
+        }
     }
-    const float t = partial_sum<SL>(partial, off, (long long)npairs * XW_PER, G, off >= 0, red);
-    if ((threadIdx.x >> 6) == 0 && off >= 0) {
-        if (idx < total_w) dw[idx] = accumulate ? dw[idx] + t : t;
-        else if (db != nullptr) db[idx - total_w] = accumulate ? db[idx - total_w] + t : t;
+    const float t = partial_sum<SL>(partial, idx, (long long)npairs * XW_PER, G, dst != -1, red);
+    if ((threadIdx.x >> 6) == 0 && dst != -1) {
+        if (dst >= 0) dw[dst] = accumulate ? dw[dst] + t : t;
+        else if (db != nullptr) { const int o = (int)(-2 - dst); db[o] = accumulate ? db[o] + t : t; }
     }
 }
 
@@ -1193,7 +1200,7 @@ int wgrad_x3(const TV& tx, const TV& tg, float* dw, float* db, int cin, int cout
         if (signs != nullptr) hipLaunchKernelGGL((wgrad_x3_kernel<8, 8, 8, 1, true>), dim3(G * n_icg * n_ocg), dim3(XW_THREADS), 0, st, tx, tg, ws, cin, cout, tiles_x, tpi, total, G, n_icg, n_ocg, signs);
         else hipLaunchKernelGGL((wgrad_x3_kernel<8, 8, 8, 1>), dim3(G * n_icg * n_ocg), dim3(XW_THREADS), 0, st, tx, tg, ws, cin, cout, tiles_x, tpi, total, G, n_icg, n_ocg, signs);
         if (int rc = check_launch("wgrad_x3 1x1")) return rc;
-        const int n = cout * cin + cout;
+        const int n = n_icg * n_ocg * (64 * 64 + 64);   // the reduce walks the partial's order
         const int RG = 3 * G;
         if (RG > 64) hipLaunchKernelGGL(wgrad_x3_reduce<16>, dim3(cdiv(n, 64)), dim3(1024), 0, st, ws, dw, db, cin, cout, 3 * G, n_icg, n_ocg, accumulate, 1);
     else hipLaunchKernelGGL(wgrad_x3_reduce<4>, dim3(cdiv(n, 64)), dim3(256), 0, st, ws, dw, db, cin, cout, 3 * G, n_icg, n_ocg, accumulate, 1);
@@ -1214,8 +1221,8 @@ int wgrad_x3(const TV& tx, const TV& tg, float* dw, float* db, int cin, int cout
             else { if (signs != nullptr) XT_LAUNCH(6, true); else XT_LAUNCH(6); }
 #undef XT_LAUNCH
             if (int rc = check_launch("wgrad_x3 thin")) return rc;
-            const int n = cout * cin * 9 + cout;
-            hipLaunchKernelGGL(wgrad_x3_thin_reduce, dim3(cdiv(n, 64)), dim3(64 * RED_SLICES), 0, st, ws, dw, db, cin, cout, G, accumulate);
+            const int n = (cin <= 16 ? 3 : (cin <= 32 ? 6 : 9)) * 768;   // the items this layer has (partial order; the bias sums sit behind all nine)
+            hipLaunchKernelGGL(wgrad_x3_thin_reduce, dim3(n / 64 + 1), dim3(64 * RED_SLICES), 0, st, ws, dw, db, cin, cout, G, accumulate);
             return check_launch("wgrad_x3_thin_reduce");
         }
     }
@@ -1233,7 +1240,7 @@ int wgrad_x3(const TV& tx, const TV& tg, float* dw, float* db, int cin, int cout
     else { if (signs != nullptr) XW_LAUNCH(8, 8, 8, 3, true); else XW_LAUNCH(8, 8, 8, 3); }
 #undef XW_LAUNCH
     if (int rc = check_launch("wgrad_x3")) return rc;
-    const int n = cout * cin * 9 + cout;
+    const int n = n_icg * n_ocg * (64 * 64 * 9 + 64);   // the reduce walks the partial's order
     const int RG = G;
     if (RG > 64) hipLaunchKernelGGL(wgrad_x3_reduce<16>, dim3(cdiv(n, 64)), dim3(1024), 0, st, ws, dw, db, cin, cout, G, n_icg, n_ocg, accumulate, 9);
     else hipLaunchKernelGGL(wgrad_x3_reduce<4>, dim3(cdiv(n, 64)), dim3(256), 0, st, ws, dw, db, cin, cout, G, n_icg, n_ocg, accumulate, 9);
