@@ -59,7 +59,7 @@ def parse():
                          "the gradient all-reduce and clip+Adam stay outside the graph")
     ap.add_argument("--cpu-sample", type=int, default=8, help="image pairs per step of the CPU sample")
     ap.add_argument("--no-parity-path", action="store_true", help="skip the second timed leg on the parity-grade fp32 / split-bf16 path")
-    ap.add_argument("--parity-steps", type=int, default=8)
+    ap.add_argument("--parity-steps", type=int, default=16)
     ap.add_argument("--roofline-tag", default="decode.0:fwd", help="engine op timed with HIP events for `roofline`")
     ap.add_argument("--hbm-tag", default="auto", help="an HBM-bound engine op timed the same way for `roofline_hbm` ('' = none)")
     return ap.parse_args()
@@ -155,7 +155,7 @@ def parity_leg(args, dev, img1, img2):
         torch.manual_seed(0)
         model = getattr(M, args.model)().to(dev)
         opt = FusedClipAdam(model.parameters(), lr=1e-4, betas=(0.9, 0.999), max_norm=5.0)
-        for _ in range(2):
+        for _ in range(6):     # (warm-up as the main leg's: packing, leases, the clock's ramp after the idle oracle / setup phase)
             one(model, opt, img1, img2)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
