@@ -1,26 +1,32 @@
-// fp32-grade 3x3 convolution on the gfx950 MATRIX pipe: "bf16 x 3" split-operand kernels for fp32 tensors.
+// fp32-grade 3x3 / 1x1 convolution on the gfx950 MATRIX pipe: split-operand ("x3") kernels for fp32 tensors.
 //
 // The reference computes its ConvLayers in fp32 (core/block.py:56-66, 98-99) and BASELINE.json's north star asks for results within
 // 1e-3 of that.  gfx950 has no TF32 / xf32 MFMA and its fp32-input MFMA runs at the VALU rate (157 TFLOP/s), so the parity path used to
 // be the fp32 FMA kernels of conv_valu.hip (0.42 k image pairs / s).  Here every fp32 operand is split ONCE, while it is staged into LDS,
-// into two bf16 values
-//        x = hi + lo + r,   hi = bf16(x),   lo = bf16(x - hi),   |r| <= 2^-18 |x|
-// and a product a * b is accumulated (fp32, inside the MFMA) as  a_hi b_hi + a_hi b_lo + a_lo b_hi: three v_mfma_f32_32x32x16_bf16 per
-// K = 16 step, i.e. 1/3 of the 2.5 PFLOP/s bf16 peak = 830 TFLOP/s of "fp32-grade" work, 5.3x the fp32 pipe.  The dropped terms
-// (a_lo b_lo and the residuals) are below 2^-16 relative to |a b|; end to end the engine stays within ~1e-5 of the fp32 oracle
-// (tests/test_gpu_x3.py), two orders of magnitude inside the north-star bar.  HBM tensors stay plain fp32 blocked NHWC, so every other
-// kernel of the fp32 path (image-side layers, losses, fold, fusion, optimiser) is untouched.
+// into 16-bit pieces
+//        x = hi + lo + r,   hi = round16(x),   lo = round16(x - hi)
+// and a product a * b is accumulated (fp32, inside the MFMA) as  a_lo b_hi + a_hi b_lo + a_hi b_hi: three v_mfma_f32_32x32x16 per K = 16
+// step, i.e. 1/3 of the 2.5 PFLOP/s 16-bit peak = 830 TFLOP/s of "fp32-grade" work, 5.3x the fp32 pipe.
+//   * FORWARD: fp16 pieces of the value scaled per staged tile (11 + 11 bits: 2^-23 per product -- fp32 grade, which the forward needs
+//     because a ReLU decision on a pre-activation within the error of zero would differ from the reference's; x3_split_pair_h below);
+//     bf16 pieces (8 + 8 bits, 2^-17) as `mmif_set_x3_forward_pieces(2)`, three bf16 pieces / six products as (3).
+//   * BACKWARD (dgrad, wgrad): bf16 pieces, three products -- linear in the gradient, 1e-5 is plenty.
+// HBM tensors stay plain fp32 blocked NHWC, so every other kernel of the fp32 path (image-side layers, losses, fold, fusion, optimiser)
+// is untouched.
 //
-// conv_x3_kernel<MB, DGRAD>: forward and input gradient (one formulation, see conv_valu.hip).  Persistent block of 8 waves, output tile
-//   32 columns x 16 rows x 32*MB channels, wave w owns rows 2w, 2w+1 (2 x MB accumulator tiles of 32 x 32).  K runs in chunks of 16
-//   input channels x 9 taps; per chunk the 18 x 34 input tile (2 channel blocks) is loaded as fp32 into registers one chunk AHEAD, split
-//   into hi / lo bf16 images and written to the other LDS buffer after the chunk's MFMAs (double buffered, one barrier per chunk); the
-//   pre-split weight images come from mmif_pack_weights_x3.  One 32x32x16 MFMA = one tap x 16 channels: lanes 0-31 hold the channel
-//   block 2c of pixel / output channel (lane & 31), lanes 32-63 block 2c+1, so every operand fetch is one ds_read_b128 of a contiguous
-//   512-byte run per half wave (conflict free for any 16-byte aligned start: MI355X_MICROARCH.md, LDS lane groups).
+// conv_x3_kernel<MB, DGRAD, NP, NW, RJ, KS, F16>: forward and input gradient (one formulation, see conv_valu.hip).  Persistent blocks,
+//   output tile 32 columns x (RJ x NW) rows x 32 MB channels, a wave owns RJ rows.  K runs in LDS chunks of 16 / 32 input channels x KS^2
+//   taps; per chunk the input tile is loaded as fp32 into registers one chunk AHEAD, split and written to the (single) LDS buffer after
+//   the chunk's MFMAs, between two barriers; the pre-split weight images come from mmif_pack_weights_x3.  One 32x32x16 MFMA = one tap x
+//   16 channels: lanes 0-31 hold the channel block 2c of pixel / output channel (lane & 31), lanes 32-63 block 2c+1, so every operand
+//   fetch is one ds_read_b128 of a contiguous 512-byte run per half wave (conflict free for any 16-byte aligned start:
+//   MI355X_MICROARCH.md, LDS lane groups).  NW = 8, one block per CU: the 64-channel kernels.  NW = 4, three blocks per CU: layers
+//   with <= 32 output and <= 64 input channels (latency bound: the blocks hide each other's loads).
 // wgrad_x3_kernel: weight gradient, K = pixels.  Block of 12 waves owns a 64 x 64 (out, in) channel pair and walks 8 x 16 pixel tiles;
-//   wave (u, jt, mt) keeps dW[32 oc][32 ic] of the three taps (u, 0..2) in 48 accumulator registers; operands are fetched from the
-//   pixel-major hi / lo tiles with the LDS transpose read (ds_read_b64_tr_b16), 16 pixels of one tile row per k-step.
+//   wave (v, jt, mt) keeps dW[32 oc][32 ic] of the three taps (0..2, v) in 48 accumulator registers; operands are fetched from the
+//   pixel-major hi / lo tiles with the LDS transpose read (ds_read_b64_tr_b16), 16 pixels of one tile row per k-step.  It can leave the
+//   ReLU sign map of x for the dgrad that follows (mmif_conv2d_reflect_bwd_wide).
+// wgrad_x3_thin_kernel: the same for <= 48 input / <= 16 output channels: four-wave blocks, 3-5 per CU, 16x16x32 MFMAs.
 #include "common.hpp"
 #include <stdlib.h>
 
