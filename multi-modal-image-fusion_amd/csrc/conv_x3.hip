@@ -188,7 +188,7 @@ constexpr int X3_BIAS_G = 128;   // granules reserved behind the tiles for the b
 // kernels (profiles/r03_pmc_sq_x3.txt): the matrix pipe is busy 58 % (2 pieces) / 74 % (3 pieces) of the cycles, i.e. a constant
 // ~5 k cycles per 16 input channels of split + LDS-write + issue work that no barrier arrangement removes, at 1.7-1.8 GHz (the chip
 // clocks dense MFMA work down: the 2.5 PFLOP/s peak assumes 2.4 GHz).
-template <int MB, bool DGRAD, int NP, int NW, int RJ, int KS, bool F16 = false>
+template <int MB, bool DGRAD, int NP, int NW, int RJ, int KS, bool F16 = false, bool M16 = false>
 __global__ __launch_bounds__(64 * NW, 2) void conv_x3_kernel(TV tin, TV tout, TV tmask, const uint4* __restrict__ wpk,
                                                               const float* __restrict__ bias, int n_out, int nch16, int nmb, int relu,
                                                               unsigned long long mask_bits, unsigned long long accum_bits, int tiles_x,
@@ -331,6 +331,14 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_x3_kernel(TV tin, TV tout, TV
         for (int j = 0; j < RJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.f;
+    // M16 (layers with <= 16 output channels): 16 x 16 x 32 MFMAs -- M = the 16 output channels (a 32 x 32 tile would be half padding,
+    // and these layers' MFMA time, not their bytes, was what they took: 48 -> 16 0.21 ms against 0.11 for the bytes), N = 16 pixels,
+    // K = TWO TAPS x 16 channels: lane l = output channel / pixel l & 15, k-group l >> 4 = (tap of the pair) x (channel block of the
+    // chunk).  Taps (0,1) (2,3) (4,5) (6,7) (8, none): five MFMA steps per 16 channels instead of nine of twice the length.
+    x3_f4 acc16[RJ][2];
+#pragma unroll
+    for (int j = 0; j < RJ; ++j) { acc16[j][0] = (x3_f4){0.f, 0.f, 0.f, 0.f}; acc16[j][1] = acc16[j][0]; }
+    static_assert(!M16 || (MB == 1 && KS == 3 && NP == 2 && CKB == 2), "M16: the 16-channel-chunk, two-piece, 3x3 kernels only");
 
     const int cbl = lane >> 5, nl = lane & 31;
     const int bbase = (cbl * X3_IH + RJ * wave) * X3_IW + nl;   // + kk * 2 * PL + row * X3_IW + v   (+ piece * ING)
@@ -360,6 +368,10 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_x3_kernel(TV tin, TV tout, TV
                 for (int m = 0; m < MB; ++m)
 #pragma unroll
                     for (int j = 0; j < RJ; ++j) acc[m][j] *= f;
+                if constexpr (M16) {
+#pragma unroll
+                    for (int j = 0; j < RJ; ++j) { acc16[j][0] *= f; acc16[j][1] *= f; }
+                }
                 e_acc = e_cur;
             }
         }
@@ -368,6 +380,47 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_x3_kernel(TV tin, TV tout, TV
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
             if (kk == 1 && issue_late && s + 1 < nsteps) issue(s + 1);
+            if constexpr (M16) {
+                if (!((abl & 8) && s > 0)) {
+                    const x3_u4* s_in = s_buf;
+                    const x3_u4* s_w = s_buf + NP * ING;
+                    const int i16 = lane & 15, t2 = (lane >> 5) & 1, cb16 = (lane >> 4) & 1;   // k-group l >> 4 = 2 * (tap of the pair) + channel block
+                    const int b0 = (cb16 * X3_IH + RJ * wave) * X3_IW + i16, a0 = cb16 * MBW + i16;
+#pragma unroll
+                    for (int pr = 0; pr < 5; ++pr) {
+                        constexpr int dummy = 0; (void)dummy;
+                        const int tA = 2 * pr, tB = 2 * pr + 1 < TAPS ? 2 * pr + 1 : 2 * pr;   // (the pad half of pair 4 reads tap 8 again and is zeroed)
+                        const int tl = t2 ? tB : tA;
+                        const int ul = tl / 3, vl = tl - 3 * ul;
+                        x3_bf16x8 af[NP], bf[RJ][2][NP];
+                        const bool pad = (2 * pr + 1 >= TAPS) && t2;
+#pragma unroll
+                        for (int p = 0; p < NP; ++p) {
+                            x3_u4 w = s_w[p * WG + tl * 2 * MBW + a0];
+                            if (pad) w = (x3_u4){0u, 0u, 0u, 0u};
+                            af[p] = x3_frag(w);
+                        }
+#pragma unroll
+                        for (int j = 0; j < RJ; ++j)
+#pragma unroll
+                            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                                for (int p = 0; p < NP; ++p) bf[j][h][p] = x3_frag(s_in[p * ING + b0 + (j + ul) * X3_IW + 16 * h + vl]);
+#pragma unroll
+                        for (int q = 0; q < NPROD; ++q)
+#pragma unroll
+                            for (int j = 0; j < RJ; ++j)
+#pragma unroll
+                                for (int h = 0; h < 2; ++h) {
+                                    if constexpr (F16)
+                                        acc16[j][h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(x3_h8, af[X3Prod<NP>::A[q]]),
+                                                                                             __builtin_bit_cast(x3_h8, bf[j][h][X3Prod<NP>::B[q]]), acc16[j][h], 0, 0, 0);
+                                    else
+                                        acc16[j][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[X3Prod<NP>::A[q]], bf[j][h][X3Prod<NP>::B[q]], acc16[j][h], 0, 0, 0);
+                                }
+                    }
+                }
+            } else
             if (kk < nkk && !((abl & 8) && s > 0)) {
                 const x3_u4* s_in = s_buf + kk * 2 * PL;
                 const x3_u4* s_w = s_buf + NP * ING + kk * NP * WG;
@@ -427,6 +480,56 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_x3_kernel(TV tin, TV tout, TV
             }
         }
         // ---------------- epilogue after the item's last chunk ----------------
+        if (M16 && s % nch == nch - 1) {
+            // C layout of the 16 x 16 x 32 MFMA: lane l, reg r = output channel 4 (l >> 4) + r of pixel l & 15: one half granule per lane
+            const int ti = s / per_tile;
+            const int tile = tw.first + ti * tw.stride;
+            const int in_ = tile / tiles_per_img, tt = tile - in_ * tiles_per_img;
+            const int ys0 = (tt / tiles_x) * X3_TH, xs0 = (tt % tiles_x) * X3_TW;
+            const int g4 = lane >> 4, ocb = g4 >> 1, half = g4 & 1;
+            const bool has_cb = ocb < tout.cb;
+            const bool masked = DGRAD && ((mask_bits >> ocb) & 1ull), accum = DGRAD && ((accum_bits >> ocb) & 1ull);
+#pragma unroll
+            for (int j = 0; j < RJ; ++j) {
+                const int ys = ys0 + RJ * wave + j;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int xs = xs0 + 16 * h + (lane & 15);
+                    const bool inside = ys < tout.hs && xs < tout.ws && has_cb;
+                    x3_f4 v = acc16[j][h];
+                    if (!DGRAD) {
+                        if constexpr (F16) v *= x3_pow2(max(-(e_acc + X3_SW_EXP), -126));
+                        v += *reinterpret_cast<const x3_f4*>(reinterpret_cast<const float*>(s_buf + BUF_G) + 4 * g4);
+                        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    } else {
+                        const int ysc = min(ys, tout.hs - 1), xsc = min(xs, tout.ws - 1), ocbc = min(ocb, tout.cb - 1);
+                        if (accum_bits != 0ull) {
+                            const x3_f4 old = *reinterpret_cast<const x3_f4*>(tout.base + tout.gidx(in_, ocbc, ysc, xsc) * 32 + half * 16);
+                            if (accum) v += old;
+                        }
+                        if (mask_bits != 0ull) {
+                            const int oy = min(max(reflect_idx(ys - tout.halo, tmask.h), 0), tmask.h - 1);
+                            const int ox = min(max(reflect_idx(xs - tout.halo, tmask.w), 0), tmask.w - 1);
+                            x3_f4 xm;
+                            if (signs != nullptr) {
+                                const unsigned sg = signs[(((long long)in_ * ((tmask.cb + 3) >> 2) + 0) * tmask.h + oy) * tmask.w + ox];
+                                const unsigned nib = (sg >> (8 * ocb + 4 * half)) & 15u;
+                                xm = (x3_f4){(nib & 1u) ? 1.f : 0.f, (nib & 2u) ? 1.f : 0.f, (nib & 4u) ? 1.f : 0.f, (nib & 8u) ? 1.f : 0.f};
+                            } else {
+                                const char* pm = (masked && ocb < tmask.cb) ? tmask.base + tmask.gidx(in_, ocb, oy, ox) * 32 + half * 16 : tmask.base;
+                                xm = *reinterpret_cast<const x3_f4*>(pm);
+                            }
+                            if (masked) {
+                                v.x = xm.x > 0.f ? v.x : 0.f; v.y = xm.y > 0.f ? v.y : 0.f;
+                                v.z = xm.z > 0.f ? v.z : 0.f; v.w = xm.w > 0.f ? v.w : 0.f;
+                            }
+                        }
+                    }
+                    if (inside) *reinterpret_cast<x3_f4*>(tout.base + tout.gidx(in_, ocb, ys, xs) * 32 + half * 16) = v;
+                    acc16[j][h] = (x3_f4){0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        } else
         if (s % nch == nch - 1) {
             const int mb = (s / nch) % nmb, ti = s / per_tile;
             const int tile = tw.first + ti * tw.stride;
@@ -1103,7 +1206,7 @@ int conv_x3_pack_multi(const mmif_pack_job* jobs, int n_jobs, hipStream_t st) {
     return flush();
 }
 
-template <int MB, int NP, int NW, int RJ, int KS = 3, bool F16 = false>
+template <int MB, int NP, int NW, int RJ, int KS = 3, bool F16 = false, bool M16 = false>
 static int launch_conv_x3(bool dgrad, const TV& tin, const TV& tout, const TV& tmask, const void* wpk, const float* bias, int n_out, int n_in,
                           int relu, uint64_t mask_bits, uint64_t accum_bits, hipStream_t st, const unsigned* signs) {
     const int tiles_x = cdiv(tout.ws, X3_TW), tiles_y = cdiv(tout.hs, RJ * NW);
@@ -1118,10 +1221,10 @@ static int launch_conv_x3(bool dgrad, const TV& tin, const TV& tout, const TV& t
     if (abl < 0) { const char* e = getenv("MMIF_X3_ABLATE"); abl = e != nullptr ? atoi(e) : 0; }
     relu = (relu & 255) | (abl << 8);
     if (dgrad)
-        hipLaunchKernelGGL((conv_x3_kernel<MB, true, NP, NW, RJ, KS>), dim3(G), dim3(X3_THREADS), 0, st, tin, tout, tmask, (const uint4*)wpk, bias, n_out, nch, nmb,
+        hipLaunchKernelGGL((conv_x3_kernel<MB, true, NP, NW, RJ, KS, false, M16>), dim3(G), dim3(X3_THREADS), 0, st, tin, tout, tmask, (const uint4*)wpk, bias, n_out, nch, nmb,
                            relu, (unsigned long long)mask_bits, (unsigned long long)accum_bits, tiles_x, tpi, total, signs);
     else
-        hipLaunchKernelGGL((conv_x3_kernel<MB, false, NP, NW, RJ, KS, F16>), dim3(G), dim3(X3_THREADS), 0, st, tin, tout, tmask, (const uint4*)wpk, bias, n_out, nch, nmb,
+        hipLaunchKernelGGL((conv_x3_kernel<MB, false, NP, NW, RJ, KS, F16, M16>), dim3(G), dim3(X3_THREADS), 0, st, tin, tout, tmask, (const uint4*)wpk, bias, n_out, nch, nmb,
                            relu, (unsigned long long)mask_bits, (unsigned long long)accum_bits, tiles_x, tpi, total, (const unsigned*)nullptr);
     return check_launch(dgrad ? "conv_x3 dgrad" : "conv_x3 fwd");
 }
@@ -1156,6 +1259,12 @@ int conv_x3(bool dgrad, const TV& tin, const TV& tout, const TV& tmask, const vo
     static int thin4 = -1;
     if (thin4 < 0) { const char* e = getenv("MMIF_X3_THIN_NW4"); thin4 = (e != nullptr && e[0] == '0') ? 0 : 1; }
     if (thin4 && n_in <= 64 && !six) {
+        static int m16 = -1;   // $MMIF_X3_M16=0: <= 16 output channels on the 32-wide tiles too
+        if (m16 < 0) { const char* e = getenv("MMIF_X3_M16"); m16 = (e != nullptr && e[0] == '0') ? 0 : 1; }
+        if (m16 && n_out <= 16) {
+            if (h16) return launch_conv_x3<1, 2, 4, 2, 3, true, true>(false, X3_ARGS);
+            return launch_conv_x3<1, 2, 4, 2, 3, false, true>(dgrad, X3_ARGS);
+        }
         if (h16) return launch_conv_x3<1, 2, 4, 2, 3, true>(false, X3_ARGS);
         return launch_conv_x3<1, 2, 4, 2>(dgrad, X3_ARGS);
     }
