@@ -399,9 +399,22 @@ def main():
             out["parity_path"] = parity_leg(args, dev, img1, img2)
         if world == 1 and not args.no_cpu_baseline and args.mode == "train" and Wd == S:
             out["cpu_baseline"] = cpu_baseline(args.model, S, args.cpu_sample)
-        print(json.dumps(out))
+    else:
+        out = None
     if use_dist:
         dist.destroy_process_group()
+    # the JSON line is the LAST thing on stdout: RCCL prints a version banner through C stdio, which -- stdout being a pipe -- sits in
+    # libc's buffer until exit, i.e. would land AFTER a line printed here; every rank flushes it out now, rank 0 prints a moment later
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    if out is not None:
+        if use_dist:
+            time.sleep(0.3)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
