@@ -354,3 +354,31 @@ def test_pfnetv2_pair_kernels_at_full_size():
         T.pairconv_bwd(ga, gb, wgt, 2, a, b, GA.view(0, cb), GA.view(cb, cb), dw4, db4, ws, bits)
         torch.cuda.synchronize()
         assert torch.equal(dw4, 4 * dw1) and torch.equal(db4, 4 * db1)
+
+
+@pytest.mark.parametrize("name", ["PFNetv1", "DenseFuse"])
+def test_parity_path_step_vs_fp32_fma_family_256(name):
+    """The whole fp32 train step at the bench's resolution (4 pairs of 256 x 256: multi-tile launches of every split-operand kernel --
+    the 64-channel forward / dgrad / wgrad, the four-wave thin forward / dgrad with 16-wide tiles, the thin weight gradient, the sign-map
+    backward) against the SAME step on the fp32 FMA kernels (`MMIF_CONV_IMPL=valu`): fused image, the four loss values and every
+    parameter gradient inside BASELINE's north-star tolerance (1e-3 relative) -- in fact ~1e-5 -- at a size the CPU oracle cannot run."""
+    from core.loss import FusionLoss, GradLoss, PixelLoss, SSIMLoss
+    shape = (4, 1, 256, 256)
+    i1 = torch.from_numpy(O.closed_form_image(shape, 0.3)).cuda()
+    i2 = torch.from_numpy(O.closed_form_image(shape, 1.7)).cuda()
+    res = {}
+    for impl in ("valu", "auto"):
+        with dtype_ctx("fp32", impl):
+            m = _model(name)
+            m.train()
+            fl = FusionLoss(SSIMLoss('ssim', weight=1.0), PixelLoss('l1', weight=0.01), GradLoss('l1', weight=0.1).cuda(), 'max', 'max')
+            f = m(i1, i2)
+            fl(i1, i2, f).backward()
+            torch.cuda.synchronize()
+            res[impl] = (f.detach().cpu().numpy(), fl.values.cpu().numpy(), {k: p.grad.detach().cpu().numpy() for k, p in m.named_parameters()})
+    close(res["auto"][0], res["valu"][0], 1e-5, "fused image")
+    assert np.abs(res["auto"][1] - res["valu"][1]).max() <= 1e-5, (res["auto"][1], res["valu"][1])
+    worst = 0.0
+    for k, g in res["valu"][2].items():
+        worst = max(worst, close(res["auto"][2][k], g, 1e-3, f"d loss / d {k}"))
+    assert worst <= 2e-4, worst   # (measured ~2e-5: the backward's two-piece products; a ReLU-decision flip would show as ~1e-3)
