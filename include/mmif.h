@@ -415,7 +415,9 @@ int mmif_dense_encoder_fwd(const mmif_dense_encoder* enc_a, const mmif_tensor* o
  * calls + mmif_conv2d_image_in_wgrad): x = the forward's [x0 | x1 | x2 | ..] (bf16, halo 0, >= 6 channel blocks), gz = the four
  * pre-activation gradients [g0 | g1 | g2 | g3] (bf16, 8 blocks; halo 0, or halo 1 folded).  dw0 [16][1][3][3], dwK [16][16K][3][3]
  * (K = 1..3), dbK [16] (NULL = not wanted).  accumulate != 0 adds to the destinations (shared encoders: second branch).  The first
- * layer runs on the exact fp32 matrix path against the fp32 image.  Deterministic (fixed-order reduction of per-block partials). */
+ * layer runs on the exact fp32 matrix path against the fp32 image.  Deterministic (fixed-order reduction of per-block partials).
+ * fp32 tensors: the same call -- the first layer on mmif_conv2d_image_in_wgrad's kernel, the three DenseBlock convs in one split-operand
+ * pass (csrc/conv_x3.hip, wgrad_x3_dense_kernel). */
 size_t mmif_dense_encoder_wgrad_workspace(void);
 int mmif_dense_encoder_wgrad(const float* img, const mmif_tensor* x, const mmif_tensor* gz, float* dw0, float* db0, float* dw1, float* db1,
                              float* dw2, float* db2, float* dw3, float* db3, int32_t accumulate, void* workspace, size_t workspace_bytes,

@@ -1032,12 +1032,16 @@ __global__ __launch_bounds__(XT_THREADS, 3) void wgrad_x3_thin_kernel(TV tx, TV 
             if (item >= NITEM) break;
             const int j = item / 3, v = item - 3 * j;
             const int xoff = (((2 * j + l_cb) * XT_XPL) + l_row * XT_XW + l_col + v) * 16 + l_byte;   // + (ry + u) * XT_XW * 16
+            x3_bf16x8 xh_keep, xl_keep;   // the tap-row u = 2 fragments (tile rows ry + 2, ry + 3) are the u = 0 fragments of the next k-step
 #pragma unroll
             for (int ry = 0; ry < XT_TH; ry += 2) {
                 const x3_bf16x8 gh = ld_tr(s_gh + goff + ry * XT_TW * 16), gl = ld_tr(s_gl + goff + ry * XT_TW * 16);
 #pragma unroll
                 for (int u = 0; u < 3; ++u) {
-                    const x3_bf16x8 xh = ld_tr(s_xh + xoff + (ry + u) * XT_XW * 16), xl = ld_tr(s_xl + xoff + (ry + u) * XT_XW * 16);
+                    x3_bf16x8 xh, xl;
+                    if (u == 0 && ry > 0) { xh = xh_keep; xl = xl_keep; }
+                    else { xh = ld_tr(s_xh + xoff + (ry + u) * XT_XW * 16); xl = ld_tr(s_xl + xoff + (ry + u) * XT_XW * 16); }
+                    if (u == 2) { xh_keep = xh; xl_keep = xl; }
                     acc[i][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gl, xh, acc[i][u], 0, 0, 0);
                     acc[i][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh, xl, acc[i][u], 0, 0, 0);
                     acc[i][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh, xh, acc[i][u], 0, 0, 0);
@@ -1067,6 +1071,201 @@ __global__ __launch_bounds__(XT_THREADS, 3) void wgrad_x3_thin_kernel(TV tx, TV 
 #pragma unroll
         for (int r = 0; r < 4; ++r) dst[9 * 3 * 4 * 64 + 4 * (lane >> 4) + r] = accb[r];
     }
+}
+
+// The three DenseBlock convs of one encoder (16 -> 16, 32 -> 16, 48 -> 16: core/block.py:137-151) in ONE pass over [x0 | x1 | x2] and
+// [g1 | g2 | g3] -- the fp32 form of csrc/enc_wgrad.hip: the same blocks and items as wgrad_x3_thin_kernel, item = (layer L, input block
+// j < L, tap column v), 18 of them; every activation tile is staged once instead of up to three times (0.8 GB per encoder instead of 1.2).
+constexpr int XD_PER = 18 * 768 + 64;                                  // floats per block partial: [item][u][reg][lane], db[3][16] (+ pad)
+__global__ __launch_bounds__(XT_THREADS, 2) void wgrad_x3_dense_kernel(TV tx, TV tg, float* __restrict__ partial, int tiles_x, int tpi, int total) {
+    constexpr int NXC = 6;
+    constexpr bool SIGNS = false;
+    unsigned* const signs = nullptr;
+    constexpr int XG = NXC * XT_XPL, GG = 6 * XT_GPL;                  // x0 | x1 | x2 and g1 | g2 | g3 (16 channels each), one piece
+    constexpr int N_X = NXC * XT_XH * XT_XW, N_ALL = N_X + 6 * XT_TH * XT_TW;
+    constexpr int ROUNDS = (N_ALL + XT_THREADS - 1) / XT_THREADS;       // 8
+    constexpr int NITEM = 18, MAXI = 5;                                 // items (layer L = 1..3, input block j < L, tap column v): 3 + 6 + 9
+    __shared__ __attribute__((aligned(16))) x3_u4 s_buf[2 * XG + 2 * GG];   // [x hi][x lo][g hi][g lo]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const TileWalk tw = xcd_walk(total, gridDim.x, blockIdx.x);
+    for (int i = tid; i < 2 * XG + 2 * GG; i += XT_THREADS) s_buf[i] = (x3_u4){0u, 0u, 0u, 0u};   // (the planes of absent channel blocks stay zero)
+    unsigned geo[ROUNDS];   // is-g << 24 | channel block << 16 | tile row << 8 | tile column
+#pragma unroll
+    for (int k = 0; k < ROUNDS; ++k) {
+        const int e = min(tid + XT_THREADS * k, N_ALL - 1);
+        if (e < N_X) {
+            const int cb = e / (XT_XH * XT_XW), rem = e - cb * (XT_XH * XT_XW), py = rem / XT_XW;
+            geo[k] = (unsigned)(cb << 16 | py << 8 | (rem - py * XT_XW));
+        } else {
+            const int e2 = e - N_X;
+            const int cb = e2 / (XT_TH * XT_TW), rem = e2 - cb * (XT_TH * XT_TW), py = rem / XT_TW;
+            geo[k] = (unsigned)(1u << 24 | cb << 16 | py << 8 | (rem - py * XT_TW));
+        }
+    }
+    X3Gran rin[ROUNDS];
+    int c_in = 0, c_y0 = 0, c_x0 = 0;   // the tile in the staging registers (SIGNS: the ReLU sign map of x, as wgrad_x3_kernel writes it)
+    auto issue = [&](int k_tile) {
+        const int tile = tw.first + k_tile * tw.stride;
+        const int in_ = tile / tpi, tt = tile - in_ * tpi;
+        const int y0 = (tt / tiles_x) * XT_TH, x0 = (tt % tiles_x) * XT_TW;
+        c_in = in_; c_y0 = y0; c_x0 = x0;
+        const char* bx = tx.base + ((long long)in_ * tx.img + (long long)tx.cb_off * tx.plane) * 32;
+        const char* bg = tg.base + ((long long)in_ * tg.img + (long long)tg.cb_off * tg.plane) * 32;
+#pragma unroll
+        for (int k = 0; k < ROUNDS; ++k) {
+            const int cb = (int)((geo[k] >> 16) & 255u), py = (int)((geo[k] >> 8) & 255u), px = (int)(geo[k] & 255u);
+            rin[k].a = (x3_f4){0.f, 0.f, 0.f, 0.f};
+            rin[k].b = rin[k].a;
+            if (tid + XT_THREADS * k >= N_ALL) continue;
+            if (!(geo[k] >> 24)) {
+                if (cb < tx.cb) {
+                    const int y = min(max(reflect_idx(y0 + py - 1, tx.h), 0), tx.h - 1);
+                    const int x = min(max(reflect_idx(x0 + px - 1, tx.w), 0), tx.w - 1);
+                    const x3_f4* p = reinterpret_cast<const x3_f4*>(bx + ((unsigned)cb * (unsigned)tx.plane + (unsigned)(y * tx.ws + x)) * 32u);
+                    rin[k].a = p[0];
+                    rin[k].b = p[1];
+                }
+            } else {
+                const int y = y0 + py, x = x0 + px;
+                if (cb < tg.cb && y < tg.h && x < tg.w) {
+                    const x3_f4* p = reinterpret_cast<const x3_f4*>(bg + ((unsigned)cb * (unsigned)tg.plane + (unsigned)((y + tg.halo) * tg.ws + x + tg.halo)) * 32u);
+                    rin[k].a = p[0];
+                    rin[k].b = p[1];
+                }
+            }
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int k = 0; k < ROUNDS; ++k) {
+            if (tid + XT_THREADS * k >= N_ALL) continue;
+            const int cb = (int)((geo[k] >> 16) & 255u), py = (int)((geo[k] >> 8) & 255u), px = (int)(geo[k] & 255u);
+            x3_u4 pc[2];
+            x3_split_gran<2>(rin[k], pc);
+            if (!(geo[k] >> 24)) {
+                const int o = cb * XT_XPL + py * XT_XW + px;
+                s_buf[o] = pc[0];
+                s_buf[XG + o] = pc[1];
+                if (SIGNS) {
+                    const int y = c_y0 + py - 1, x = c_x0 + px - 1;
+                    if (py >= 1 && py <= XT_TH && px >= 1 && px <= XT_TW && y < tx.h && x < tx.w && cb < tx.cb) {
+                        const X3Gran& g = rin[k];
+                        const unsigned bits = (g.a.x > 0.f) | (g.a.y > 0.f) << 1 | (g.a.z > 0.f) << 2 | (g.a.w > 0.f) << 3 | (g.b.x > 0.f) << 4 |
+                                              (g.b.y > 0.f) << 5 | (g.b.z > 0.f) << 6 | (g.b.w > 0.f) << 7;
+                        reinterpret_cast<unsigned char*>(signs)[(((unsigned)(c_in * ((tx.cb + 3) >> 2) + (cb >> 2)) * (unsigned)tx.h + (unsigned)y) * (unsigned)tx.w + (unsigned)x) * 4u + (unsigned)(cb & 3)] =
+                            (unsigned char)bits;
+                    }
+                }
+            } else {
+                const int o = 2 * XG + cb * XT_GPL + py * XT_TW + px;
+                s_buf[o] = pc[0];
+                s_buf[GG + o] = pc[1];
+            }
+        }
+    };
+
+    typedef __attribute__((ext_vector_type(4))) float f32x4_;
+    f32x4_ acc[MAXI][3], accb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i)
+#pragma unroll
+        for (int u = 0; u < 3; ++u) acc[i][u] = (f32x4_){0.f, 0.f, 0.f, 0.f};
+    const x3_bf16x8 ones = __builtin_bit_cast(x3_bf16x8, ((x3_u4){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}));
+    // operand fragments of a 16 x 16 x 32 MFMA: lane l = channel l & 15, k-group l >> 4 = pixels 8 (l >> 4) .. + 7 of the k-step's 32
+    // (two tile rows of 16); the transposing read (see wgrad_x3_kernel): lane sl of a 16-lane group addresses pixel sl >> 2 (+ 4 for the
+    // second read), channel block (sl & 3) >> 1 of the 16-channel record, byte 8 (sl & 1), and receives channel sl of four pixels
+    const int sl = lane & 15, g4 = lane >> 4;
+    const int l_cb = (sl & 3) >> 1, l_byte = (sl & 1) * 8, l_row = g4 >> 1, l_col = 8 * (g4 & 1) + (sl >> 2);
+    auto ld_tr = [&](const char* base) {
+        const x3_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(X3_LDS_PTR(x3_s16x4, base));
+        const x3_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(X3_LDS_PTR(x3_s16x4, base + 4 * 16));
+        return __builtin_bit_cast(x3_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    const char* s_xh = reinterpret_cast<const char*>(s_buf);
+    const char* s_xl = s_xh + XG * 16;
+    const char* s_gh = s_xl + XG * 16;
+    const char* s_gl = s_gh + GG * 16;
+
+    __syncthreads();   // the zero fill
+    const int ntile = tw.count;
+    if (ntile > 0) {
+        issue(0);
+        commit();
+    }
+    __syncthreads();
+    for (int k = 0; k < ntile; ++k) {
+        if (k + 1 < ntile) issue(k + 1);
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+            const int item = wave + 4 * i;             // (wave uniform)
+            if (item >= NITEM) break;
+            const int L = item < 3 ? 1 : (item < 9 ? 2 : 3), rel = item - (L == 1 ? 0 : (L == 2 ? 3 : 9));
+            const int j = rel / 3, v = rel - 3 * j;
+            const int xoff = (((2 * j + l_cb) * XT_XPL) + l_row * XT_XW + l_col + v) * 16 + l_byte;   // + (ry + u) * XT_XW * 16
+            const int goff = (((2 * (L - 1) + l_cb) * XT_GPL) + l_row * XT_TW + l_col) * 16 + l_byte;  // + ry * XT_TW * 16
+            x3_bf16x8 xh_keep, xl_keep;   // the tap-row u = 2 fragments (tile rows ry + 2, ry + 3) are the u = 0 fragments of the next k-step
+#pragma unroll
+            for (int ry = 0; ry < XT_TH; ry += 2) {
+                const x3_bf16x8 gh = ld_tr(s_gh + goff + ry * XT_TW * 16), gl = ld_tr(s_gl + goff + ry * XT_TW * 16);
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    x3_bf16x8 xh, xl;
+                    if (u == 0 && ry > 0) { xh = xh_keep; xl = xl_keep; }
+                    else { xh = ld_tr(s_xh + xoff + (ry + u) * XT_XW * 16); xl = ld_tr(s_xl + xoff + (ry + u) * XT_XW * 16); }
+                    if (u == 2) { xh_keep = xh; xl_keep = xl; }
+                    acc[i][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gl, xh, acc[i][u], 0, 0, 0);
+                    acc[i][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh, xl, acc[i][u], 0, 0, 0);
+                    acc[i][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh, xh, acc[i][u], 0, 0, 0);
+                }
+                if (rel == 0) {   // (items 0, 3, 9 = waves 0, 3, 1: one per wave) bias gradient of layer L: row sums of the gradient fragments
+                    accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gl, ones, accb, 0, 0, 0);
+                    accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh, ones, accb, 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();   // every wave has read the tile
+        if (k + 1 < ntile) commit();
+        __syncthreads();
+    }
+    // block partial, register-major: [item][u][reg][lane]; C layout of the MFMA: lane l reg r = dW[oc = 4 (l >> 4) + r][ic = 16 j + (l & 15)]
+    float* dst = partial + (long long)blockIdx.x * XD_PER;
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+        const int item = wave + 4 * i;
+        if (item >= NITEM) break;
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[((item * 3 + u) * 4 + r) * 64 + lane] = acc[i][u][r];
+    }
+    if ((wave == 0 || wave == 3 || wave == 1) && (lane & 15) == 0) {
+        const int L = wave == 0 ? 1 : (wave == 3 ? 2 : 3);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[18 * 768 + 16 * (L - 1) + 4 * (lane >> 4) + r] = accb[r];
+    }
+}
+
+__global__ __launch_bounds__(64 * RED_SLICES) void wgrad_x3_dense_reduce(const float* __restrict__ partial, float* __restrict__ dw1, float* __restrict__ db1,
+                                                                        float* __restrict__ dw2, float* __restrict__ db2, float* __restrict__ dw3,
+                                                                        float* __restrict__ db3, int G, int accumulate) {
+    __shared__ float red[RED_SLICES][64];
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63);      // the partial's order
+    float* dst = nullptr;
+    if (e < 18 * 768) {
+        const int ln = e & 63, r = (e >> 6) & 3, u = (e >> 8) % 3, item = e / 768;
+        const int L = item < 3 ? 1 : (item < 9 ? 2 : 3), rel = item - (L == 1 ? 0 : (L == 2 ? 3 : 9));
+        const int j = rel / 3, v = rel - 3 * j;
+        const int o = 4 * (ln >> 4) + r, c = 16 * j + (ln & 15);
+        float* dw = L == 1 ? dw1 : (L == 2 ? dw2 : dw3);
+        dst = dw + ((long long)o * (16 * L) + c) * 9 + u * 3 + v;
+    } else if (e < 18 * 768 + 48) {
+        const int L = (e - 18 * 768) / 16 + 1, o = (e - 18 * 768) % 16;
+        float* db = L == 1 ? db1 : (L == 2 ? db2 : db3);
+        if (db != nullptr) dst = db + o;
+    }
+    const float t = partial_sum(partial, e, XD_PER, G, dst != nullptr, red);
+    if ((threadIdx.x >> 6) == 0 && dst != nullptr) *dst = accumulate ? *dst + t : t;
 }
 
 __global__ __launch_bounds__(64 * RED_SLICES) void wgrad_x3_thin_reduce(const float* __restrict__ partial, float* __restrict__ dw, float* __restrict__ db,
@@ -1362,6 +1561,24 @@ int wgrad_x3(const TV& tx, const TV& tg, float* dw, float* db, int cin, int cout
     return check_launch("wgrad_x3_reduce");
 }
 
+
+// dW / db of the three DenseBlock convs of one encoder: tx = [x0 | x1 | x2] (>= 6 channel blocks), tg = [g1 | g2 | g3] (6 blocks)
+bool wgrad_x3_dense_supported(const TV& tx, const TV& tg) {
+    return x3_enabled() && x3_grad_ok(tg) && tx.halo == 0 && tx.h >= 2 && tx.w >= 2 && x3_small(tx) && x3_small(tg) && tx.cb >= 6 && tg.cb == 6;
+}
+size_t wgrad_x3_dense_workspace() { return (size_t)2 * 256 * XD_PER * sizeof(float); }
+int wgrad_x3_dense(const TV& tx, const TV& tg, float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3, int accumulate, float* ws,
+                   hipStream_t st) {
+    const int tiles_x = cdiv(tx.w, XT_TW), tiles_y = cdiv(tx.h, XT_TH);
+    const int tpi = tiles_x * tiles_y, total = tpi * tx.n;
+    int G = x3_num_cus() * 2;
+    if (G > 512) G = 512;
+    if (total < G) G = total;
+    hipLaunchKernelGGL(wgrad_x3_dense_kernel, dim3(G), dim3(XT_THREADS), 0, st, tx, tg, ws, tiles_x, tpi, total);
+    if (int rc = check_launch("wgrad_x3 dense")) return rc;
+    hipLaunchKernelGGL(wgrad_x3_dense_reduce, dim3((18 * 768 + 64) / 64), dim3(64 * RED_SLICES), 0, st, ws, dw1, db1, dw2, db2, dw3, db3, G, accumulate);
+    return check_launch("wgrad_x3_dense_reduce");
+}
 }  // namespace mmif
 
 using namespace mmif;

@@ -442,9 +442,23 @@ __global__ __launch_bounds__(64 * RED_SLICES) void enc_wgrad_reduce(const float*
 
 }  // namespace mmif
 
+namespace mmif {
+// conv_x3.hip: the fp32 (split-operand) form of this pass for the three DenseBlock convs
+bool wgrad_x3_dense_supported(const TV& tx, const TV& tg);
+size_t wgrad_x3_dense_workspace();
+int wgrad_x3_dense(const TV& tx, const TV& tg, float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3, int accumulate, float* ws,
+                   hipStream_t st);
+}  // namespace mmif
+
 using namespace mmif;
 
-extern "C" size_t mmif_dense_encoder_wgrad_workspace(void) { return (size_t)EW_MAXG * EW_PER * sizeof(float); }
+extern "C" int mmif_conv2d_image_in_wgrad(const float* img, const mmif_tensor* gy, float* dw, float* db, int32_t cout, int32_t ksize, int32_t accumulate,
+                                          void* workspace, size_t workspace_bytes, void* stream);
+
+extern "C" size_t mmif_dense_encoder_wgrad_workspace(void) {
+    const size_t a = (size_t)EW_MAXG * EW_PER * sizeof(float), b = wgrad_x3_dense_workspace();
+    return a > b ? a : b;
+}
 
 extern "C" int mmif_dense_encoder_wgrad(const float* img, const mmif_tensor* x, const mmif_tensor* gz, float* dw0, float* db0, float* dw1,
                                         float* db1, float* dw2, float* db2, float* dw3, float* db3, int32_t accumulate, void* workspace,
@@ -452,6 +466,24 @@ extern "C" int mmif_dense_encoder_wgrad(const float* img, const mmif_tensor* x, 
     if (int rc = validate_tensor(x, "x")) return rc;
     if (int rc = validate_tensor(gz, "gz")) return rc;
     MMIF_REQUIRE(img != nullptr && dw0 != nullptr && dw1 != nullptr && dw2 != nullptr && dw3 != nullptr, "dense_encoder_wgrad: NULL image / dW");
+    if (x->dtype == MMIF_F32 && gz->dtype == MMIF_F32) {
+        // fp32 tensors: the first layer on the image-side kernel, the three DenseBlock convs in ONE split-operand pass (csrc/conv_x3.hip)
+        MMIF_REQUIRE(x->halo == 0 && x->cb >= 6, "dense_encoder_wgrad: x must be a halo-0 view of >= 6 channel blocks (x0 | x1 | x2)");
+        MMIF_REQUIRE(gz->cb == 8 && (gz->halo == 0 || (gz->flags & MMIF_T_FOLDED)), "dense_encoder_wgrad: gz must be an 8-block view, halo 0 or folded");
+        MMIF_REQUIRE(x->n == gz->n && x->h == gz->h && x->w == gz->w, "dense_encoder_wgrad: x / gz mismatch");
+        if (workspace == nullptr || workspace_bytes < mmif_dense_encoder_wgrad_workspace()) {
+            set_error("dense_encoder_wgrad: workspace too small");
+            return MMIF_EWORKSPACE;
+        }
+        mmif_tensor g0 = *gz, g123 = *gz;
+        g0.cb = 2;
+        g123.cb_off = gz->cb_off + 2;
+        g123.cb = 6;
+        const TV tx = make_tv(x), tg = make_tv(&g123);
+        MMIF_REQUIRE(wgrad_x3_dense_supported(tx, tg), "dense_encoder_wgrad: tensors not covered by the split-operand kernels");
+        if (int rc = mmif_conv2d_image_in_wgrad(img, &g0, dw0, db0, 16, 3, accumulate, workspace, workspace_bytes, stream)) return rc;
+        return wgrad_x3_dense(tx, tg, dw1, db1, dw2, db2, dw3, db3, accumulate, (float*)workspace, (hipStream_t)stream);
+    }
     MMIF_REQUIRE(x->dtype == MMIF_BF16 && gz->dtype == MMIF_BF16, "dense_encoder_wgrad: bf16 tensors expected");
     MMIF_REQUIRE(x->halo == 0 && x->cb >= 6, "dense_encoder_wgrad: x must be a halo-0 view of >= 6 channel blocks (x0 | x1 | x2)");
     MMIF_REQUIRE(gz->cb == 8 && (gz->halo == 0 || (gz->flags & MMIF_T_FOLDED)), "dense_encoder_wgrad: gz must be an 8-block view, halo 0 or folded");

@@ -482,7 +482,10 @@ class DenseEncoderMixin:
         # (csrc/enc_wgrad.hip; $MMIF_ENC_WGRAD=0 selects the layer-wise kernels)
         hot = (F.dtype == torch.bfloat16 and impl != _lib.IMPL_VALU and all(s.k == 3 for s in specs)
                and [(s.cin, s.cout) for s in specs] == [(1, 16), (16, 16), (32, 16), (48, 16)])
-        fused = hot and switch("MMIF_ENC_WGRAD")
+        # fp32 on the split-operand kernels: the same fused weight-gradient call (wgrad_x3_dense_kernel); the dgrad chain stays per layer
+        hot32 = (F.dtype == torch.float32 and impl != _lib.IMPL_VALU and x3_enabled() and all(s.k == 3 for s in specs)
+                 and [(s.cin, s.cout) for s in specs] == [(1, 16), (16, 16), (32, 16), (48, 16)] and F.halo == 0)
+        fused = (hot or hot32) and switch("MMIF_ENC_WGRAD")
         # ... and the dgrad chain per DESTINATION (gather form: one launch per x_k on the stacked virtual layer, fp32 sum of all
         # contributions, one rounding) instead of per source layer (read-modify-write of the lower blocks); $MMIF_ENC_CHAIN=0: scatter
         gather = hot and switch("MMIF_ENC_CHAIN")

@@ -289,3 +289,49 @@ def test_densefuse_shared_fused_gradient_is_bit_identical():
                     __import__("mmif.engine").engine.reload_switches()
             for k in res[0]:
                 assert torch.equal(res[0][k], res[1][k]), f"{shape} {k}"
+
+
+@pytest.mark.parametrize("n,h,w", [(1, 2, 2), (2, 5, 7), (1, 37, 53), (2, 64, 64), (1, 70, 33), (4, 128, 128)], ids=lambda v: str(v))
+def test_fused_wgrad_fp32_vs_layerwise_split_operand_kernels(n, h, w):
+    """fp32 tensors: mmif_dense_encoder_wgrad = image_in_wgrad + ONE split-operand pass over [x0 | x1 | x2] / [g1 | g2 | g3]
+    (csrc/conv_x3.hip, wgrad_x3_dense_kernel) against the three layer-wise split-operand weight gradients (same two-piece products, only
+    the grouping of the pixel sums differs: 2e-6) and against the fp32 FMA kernels (3e-5); accumulate mode; views at a channel-block offset."""
+    import core.model as M
+    from mmif import engine as E
+    from mmif import tensor as T
+    from mmif._lib import IMPL_VALU, IMPL_X3
+    with dtype_ctx("fp32"):
+        torch.manual_seed(3 + h)
+        eng = E.PFNetv1Engine(M.PFNetv1().to(DEV))
+        g = torch.Generator().manual_seed(h + w)
+        img = torch.rand(n, 1, h, w, generator=g).to(DEV)
+        x = torch.relu(torch.randn(n, 128, h, w, generator=g) * 0.7).to(DEV)
+        gz = (torch.randn(n, 128, h, w, generator=g) * (torch.rand(n, 128, h, w, generator=g) > 0.4)).to(DEV)
+        F = T.BT.from_nchw(x, torch.float32)
+        GF = T.BT.from_nchw(gz, torch.float32, halo=1).as_folded()
+        (img,), *_ = eng.prepare((img,))
+        ws = eng.workspace(torch.device(DEV))
+        specs = eng.enc[0]
+        for base in (0, 8):                               # first / second encoder's half of the 128-channel buffers
+            fused = _grads(eng)
+            T.dense_encoder_wgrad(img, F.view(base, 6), GF.view(base, 8), fused, ws)
+            res = {}
+            for impl in (IMPL_X3, IMPL_VALU):
+                lw = _grads(eng)
+                for k, nin in ((3, 6), (2, 4), (1, 2)):
+                    T.conv_wgrad(F.view(base, nin), GF.view(base + 2 * k, 2), lw[k][0], lw[k][1], specs[k].cin, 16, 3, ws, False, impl)
+                T.image_in_wgrad(img, GF.view(base, 2), lw[0][0], lw[0][1], 16, 3, ws, False)
+                res[impl] = lw
+            torch.cuda.synchronize()
+            for k in range(4):
+                for t in (0, 1):
+                    a = fused[k][t].double().cpu()
+                    for impl, tol in ((IMPL_X3, 2e-6), (IMPL_VALU, 3e-5)):
+                        r = res[impl][k][t].double().cpu()
+                        e = float((a - r).abs().max()) / max(1e-6, float(r.abs().max()))
+                        assert e <= tol, (base, k, "dW" if t == 0 else "db", impl, e)
+            twice = [(a.clone(), b.clone()) for a, b in fused]
+            T.dense_encoder_wgrad(img, F.view(base, 6), GF.view(base, 8), twice, ws, accumulate=True)
+            torch.cuda.synchronize()
+            for (w1, b1), (w2, b2) in zip(fused, twice):
+                assert torch.equal(w2, 2 * w1) and torch.equal(b2, 2 * b1)
