@@ -430,6 +430,9 @@ int mmif_dense_encoder_wgrad(const float* img, const mmif_tensor* x, const mmif_
  * (sizes mmif_packed_weight_bytes(16 (3 - k), 16, 3)) from the fp32 weights w1 [16][16][3][3], w2 [16][32][3][3], w3 [16][48][3][3]. */
 int mmif_pack_dense_chain(const float* w1, const float* w2, const float* w3, void* packed_v0, void* packed_v1, void* packed_v2,
                           void* stream);
+/* The same for fp32 tensors: x3-format images (mmif_packed_weight_bytes_x3(16 (3 - k), 16, 3)) for the split-operand dgrad kernels. */
+int mmif_pack_dense_chain_x3(const float* w1, const float* w2, const float* w3, void* packed_v0, void* packed_v1, void* packed_v2,
+                             void* stream);
 
 /* ---- data feed (the step before the hot path).  out[b] = transform(norm(bank[idx[b]]), mode[b]) as fp32 [batch][P][P]:
  *      FusionPatches.__getitem__ data/patches.py:61-74 with norm data/transform.py:15-29 (norm_mode 0: /255.0, 1: 'min-max',

@@ -58,7 +58,8 @@ __host__ __device__ inline float x3_f16_val(unsigned short b) { return (float)__
 
 // ------------------------------------------------------------------ weight packing
 constexpr int X3_PACK_MAX = 64;
-struct X3PackImage { const float* w; bf16_t* dst; long long total; int cout, cin, dgrad, mbw, nch, pieces, ks, f16; };
+struct X3PackImage { const float* w; bf16_t* dst; long long total; int cout, cin, dgrad, mbw, nch, pieces, ks, f16;
+                     const float *w2, *w3; int chain_k; };   // chain_k >= 0: the DenseBlock's virtual gather layer k (mmif_pack_dense_chain_x3)
 struct X3PackTable { X3PackImage im[X3_PACK_MAX]; };
 
 // dgrad == 0: out = o, in = c, Wk[u][v] = W[o][c][u][v];  dgrad == 1: out = c, in = o, Wk[u][v] = W[o][c][2-u][2-v]
@@ -80,7 +81,13 @@ __global__ void x3_pack_kernel(X3PackTable tab) {
         const int u = tap / ks, v = tap % ks;
         float val = 0.f;
         if (oc < n_out && ic < n_in) {
-            if (J.dgrad) val = J.w[(((long long)ic * J.cin + oc) * ks + (ks - 1 - u)) * ks + (ks - 1 - v)];
+            if (J.chain_k >= 0) {
+                // virtual layer k: "output" (gradient) channel ic = 16 (L - k - 1) + o of DenseBlock conv L = k+1 .. 3, input channel oc = x_k's
+                // channel 16 k + oc of that conv; dgrad form (flipped taps)
+                const int L = J.chain_k + 1 + ic / 16, o = ic % 16, cinL = 16 * L;
+                const float* src = L == 1 ? J.w : (L == 2 ? J.w2 : J.w3);
+                val = src[(((long long)o * cinL + 16 * J.chain_k + oc) * 3 + (2 - u)) * 3 + (2 - v)];
+            } else if (J.dgrad) val = J.w[(((long long)ic * J.cin + oc) * ks + (ks - 1 - u)) * ks + (ks - 1 - v)];
             else val = J.w[(((long long)oc * J.cin + ic) * ks + u) * ks + v];
         }
         const long long piece = (long long)taps * 2 * J.mbw * 8;
@@ -1393,7 +1400,7 @@ int conv_x3_pack_multi(const mmif_pack_job* jobs, int n_jobs, hipStream_t st) {
             if (dst == nullptr) continue;
             const int n_out = d ? jb.cin : jb.cout, n_in = d ? jb.cout : jb.cin;
             X3PackImage& im = tab.im[n++];
-            im.w = jb.w; im.dst = (bf16_t*)dst; im.cout = jb.cout; im.cin = jb.cin; im.dgrad = d;
+            im.w = jb.w; im.dst = (bf16_t*)dst; im.cout = jb.cout; im.cin = jb.cin; im.dgrad = d; im.chain_k = -1; im.w2 = im.w3 = nullptr;
             im.mbw = 32 * x3_mb(n_out); im.nch = x3_nch(n_in); im.ks = jb.ksize;
             im.f16 = (!d && x3_fwd_pieces() == 16) ? 1 : 0;
             im.pieces = (d || im.f16) ? 2 : x3_fwd_pieces();
@@ -1594,4 +1601,24 @@ extern "C" int mmif_pack_weights_x3(const float* w, int32_t cout, int32_t cin, i
     mmif_pack_job jb;
     jb.w = w; jb.cout = cout; jb.cin = cin; jb.ksize = ksize; jb.format = MMIF_PACK_X3; jb.packed_fwd = packed_fwd; jb.packed_dgrad = packed_dgrad;
     return conv_x3_pack_multi(&jb, 1, (hipStream_t)stream);
+}
+
+// dgrad operand images (x3 format) of the DenseBlock's three virtual gather layers: layer k has 16 input channels (x_k) and 16 (3 - k)
+// output channels (convs k+1 .. 3 stacked, each restricted to its x_k input slice) -- mmif_pack_dense_chain for fp32 tensors.
+extern "C" int mmif_pack_dense_chain_x3(const float* w1, const float* w2, const float* w3, void* packed_v0, void* packed_v1, void* packed_v2,
+                                        void* stream) {
+    MMIF_REQUIRE(w1 != nullptr && w2 != nullptr && w3 != nullptr && packed_v0 != nullptr && packed_v1 != nullptr && packed_v2 != nullptr,
+                 "pack_dense_chain_x3: NULL argument");
+    X3PackTable tab;
+    void* dst[3] = {packed_v0, packed_v1, packed_v2};
+    for (int k = 0; k < 3; ++k) {
+        X3PackImage& im = tab.im[k];
+        const int n_out = 16, n_in = 16 * (3 - k);      // the dgrad kernel's view: out = x_k's channels, in = the stacked gradient channels
+        im.w = w1; im.w2 = w2; im.w3 = w3; im.chain_k = k;
+        im.dst = (bf16_t*)dst[k]; im.cout = n_in; im.cin = n_out; im.dgrad = 1;
+        im.mbw = 32 * x3_mb(n_out); im.nch = x3_nch(n_in); im.ks = 3; im.f16 = 0; im.pieces = 2;
+        im.total = (long long)x3_nmb(n_out) * im.nch * 9 * 2 * im.mbw * 8;
+    }
+    hipLaunchKernelGGL(x3_pack_kernel, dim3(64, 3), dim3(256), 0, (hipStream_t)stream, tab);
+    return check_launch("pack_dense_chain_x3");
 }

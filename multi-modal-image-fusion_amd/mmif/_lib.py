@@ -102,6 +102,7 @@ SIGNATURES = {
     "mmif_conv2d_bwd_wide_signs_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "mmif_conv2d_reflect_bwd_wide": (_i32, [_TP, _vp, _TP, _TP, _vp, _vp, _i32, _i32, _i32, _u64, _i32, _vp, _sz, _vp, _sz, _vp]),
     "mmif_pack_dense_chain": (_i32, [_vp] * 7),
+    "mmif_pack_dense_chain_x3": (_i32, [_vp] * 7),
     "mmif_dense_encoder_wgrad_workspace": (_sz, []),
     "mmif_dense_encoder_wgrad": (_i32, [_vp, _TP, _TP] + [_vp] * 8 + [_i32, _vp, _sz, _vp]),
     "mmif_act_fwd": (_i32, [_vp, _vp, _i64, _i32, _f32, _vp]),

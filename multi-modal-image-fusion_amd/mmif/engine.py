@@ -390,7 +390,8 @@ class ModelEngine:
     @staticmethod
     def tag_dgrad(gy, x, gx, cin, cout, packed, tag):
         """dgrad of a virtual layer (operand image only, no fp32 weights): accumulate onto gx + ReLU mask of x, folded"""
-        return T.conv_dgrad(gy, None, x, gx, cin, cout, 3, all_bits(gx.cb), all_bits(gx.cb), packed, _lib.IMPL_MFMA, tag, fold=True)
+        impl = _lib.IMPL_MFMA if packed.fmt == _lib.BF16 else _lib.IMPL_X3
+        return T.conv_dgrad(gy, None, x, gx, cin, cout, 3, all_bits(gx.cb), all_bits(gx.cb), packed, impl, tag, fold=True)
 
     @staticmethod
     def c_wgrad(s, x, gy, ws, impl, accumulate=False):
@@ -456,14 +457,14 @@ class DenseEncoderMixin:
                               [s.b.detach() for s in specs[1:]], F.view(base, 8)) for specs, img, base in branches], tag="encode:fwd")
 
     @staticmethod
-    def chain_images(specs):
+    def chain_images(specs, fmt=_lib.BF16):
         """dgrad operand images of the DenseBlock's virtual gather layers, re-packed when the weights changed (one launch)"""
         first, c0, c1, c2 = specs
-        key = (WEIGHTS_EPOCH[0],) + tuple((s.conv.weight._version, s.conv.weight.data_ptr()) for s in (c0, c1, c2))
+        key = (WEIGHTS_EPOCH[0], fmt) + tuple((s.conv.weight._version, s.conv.weight.data_ptr()) for s in (c0, c1, c2))
         cached = getattr(first, "_chain", None)
         ws = [s.conv.weight.detach() for s in (c0, c1, c2)]
-        if cached is None or cached[1][0].dgrad.device != ws[0].device:
-            cached = (key, T.pack_dense_chain(*ws, ws[0].device))
+        if cached is None or cached[1][0].dgrad.device != ws[0].device or cached[1][0].fmt != fmt:
+            cached = (key, T.pack_dense_chain(*ws, ws[0].device, fmt))
             first._chain = cached
         elif cached[0] != key:
             T.repack_dense_chain(cached[1], *ws)
@@ -488,9 +489,9 @@ class DenseEncoderMixin:
         fused = (hot or hot32) and switch("MMIF_ENC_WGRAD")
         # ... and the dgrad chain per DESTINATION (gather form: one launch per x_k on the stacked virtual layer, fp32 sum of all
         # contributions, one rounding) instead of per source layer (read-modify-write of the lower blocks); $MMIF_ENC_CHAIN=0: scatter
-        gather = hot and switch("MMIF_ENC_CHAIN")
+        gather = (hot or (hot32 and onto is None)) and switch("MMIF_ENC_CHAIN")
         if gather:
-            pk = DenseEncoderMixin.chain_images(specs)
+            pk = DenseEncoderMixin.chain_images(specs, _lib.F32 if hot32 else _lib.BF16)
             for k in (2, 1, 0):
                 gy, xk, dst = GF.view(gbase + 2 * (k + 1), 2 * (3 - k)), F.view(fbase + 2 * k, 2), GF.view(gbase + 2 * k, 2)
                 if onto is not None:

@@ -253,17 +253,17 @@ def dense_encoder_fwd(branches, tag=None):
                                          b[1].d if b[1] is not None else None, stream_ptr()), "dense_encoder_fwd")
 
 
-def pack_dense_chain(w1, w2, w3, device):
-    """dgrad operand images of the DenseBlock's three virtual gather layers (x0 <- convs 1..3, x1 <- convs 2..3, x2 <- conv 3)."""
-    pk = [PackedWeights(16 * (3 - k), 16, 3, device) for k in range(3)]
-    check(lib.mmif_pack_dense_chain(_ptr(w1), _ptr(w2), _ptr(w3), _ptr(pk[0].dgrad), _ptr(pk[1].dgrad), _ptr(pk[2].dgrad), stream_ptr()),
-          "pack_dense_chain")
+def pack_dense_chain(w1, w2, w3, device, fmt=BF16):
+    """dgrad operand images of the DenseBlock's three virtual gather layers (x0 <- convs 1..3, x1 <- convs 2..3, x2 <- conv 3);
+    fmt = F32: the split-operand (x3) images for fp32 tensors."""
+    pk = [PackedWeights(16 * (3 - k), 16, 3, device, fmt) for k in range(3)]
+    repack_dense_chain(pk, w1, w2, w3)
     return pk
 
 
 def repack_dense_chain(pk, w1, w2, w3):
-    check(lib.mmif_pack_dense_chain(_ptr(w1), _ptr(w2), _ptr(w3), _ptr(pk[0].dgrad), _ptr(pk[1].dgrad), _ptr(pk[2].dgrad), stream_ptr()),
-          "pack_dense_chain")
+    fn = lib.mmif_pack_dense_chain_x3 if pk[0].fmt == F32 else lib.mmif_pack_dense_chain
+    check(fn(_ptr(w1), _ptr(w2), _ptr(w3), _ptr(pk[0].dgrad), _ptr(pk[1].dgrad), _ptr(pk[2].dgrad), stream_ptr()), "pack_dense_chain")
 
 
 def dense_encoder_wgrad_workspace_bytes():

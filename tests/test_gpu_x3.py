@@ -288,3 +288,40 @@ def test_fp16_forward_range_window():
         assert np.isfinite(got).all() and np.abs(got).max() <= np.abs(ref).max()
     finally:
         E.set_x3_forward_pieces(prev)
+
+
+def test_fp32_encoder_backward_gather_chain_and_fused_wgrad_vs_layerwise():
+    """The fp32 encoder backward in its fused forms -- the dgrad chain per DESTINATION on the stacked virtual layers
+    (mmif_pack_dense_chain_x3 + the 16-wide thin dgrad kernel) and the one-pass weight gradient (wgrad_x3_dense_kernel) -- against the
+    layer-wise scatter form ($MMIF_ENC_CHAIN=0 $MMIF_ENC_WGRAD=0): every parameter gradient of PFNetv1 to the rounding of a different
+    summation order (the gather form adds all contributions of an x_k in one fp32 accumulator before the mask)."""
+    import os
+    import core.model as M
+    from core.loss import FusionLoss, GradLoss, PixelLoss, SSIMLoss
+    from gpu_util import dtype_ctx, load_closed_form, reload_switches
+    from oracle import fusion_oracle as O
+    shape = (2, 1, 72, 88)
+    i1 = torch.from_numpy(O.closed_form_image(shape, 0.3)).to(DEV)
+    i2 = torch.from_numpy(O.closed_form_image(shape, 1.7)).to(DEV)
+    res = {}
+    prev = {k: os.environ.get(k) for k in ("MMIF_ENC_CHAIN", "MMIF_ENC_WGRAD")}
+    try:
+        for mode in ("0", "1"):
+            os.environ["MMIF_ENC_CHAIN"] = os.environ["MMIF_ENC_WGRAD"] = mode
+            reload_switches()
+            with dtype_ctx("fp32"):
+                m = load_closed_form(M.PFNetv1(), 1).to(DEV)
+                m.train()
+                fl = FusionLoss(SSIMLoss('ssim', weight=1.0), PixelLoss('l1', weight=0.01), GradLoss('l1', weight=0.1).to(DEV), 'max', 'max')
+                fl(i1, i2, m(i1, i2)).backward()
+                torch.cuda.synchronize()
+                res[mode] = {k: p.grad.detach().cpu().numpy() for k, p in m.named_parameters()}
+    finally:
+        for k, v in prev.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        reload_switches()
+    for k, g in res["0"].items():
+        close(res["1"][k], g, 2e-5, k)
