@@ -16,7 +16,7 @@ this process touches the GPU) and relays rank 0's line; a box with fewer than N 
 
 Rank 0 prints ONE JSON line (contract in the task description) including
   roofline     -- the dominant kernel timed live with HIP events inside the timed region
-  parity_path  -- the same step on the parity-grade path (fp32 tensors, 3x3 layers on the matrix pipe as split-bf16 products,
+  parity_path  -- the same step on the parity-grade path (fp32 tensors, 3x3 / 1x1 layers on the matrix pipe as split-operand products,
                   csrc/conv_x3.hip) timed the same way, with its error against the CPU oracle on a small sample (N = 1 only)
   cpu_baseline -- the torch-CPU restatement of the step (oracle/torch_cpu_step.py, "port") timed on this box's host cores
 """
@@ -129,8 +129,8 @@ def measured_traffic(tag, match):
 
 
 def parity_leg(args, dev, img1, img2):
-    """The same train step on the parity-grade path: fp32 feature maps, 3x3 layers on the matrix pipe as split-bf16 products (six per
-    tap forward, three backward: csrc/conv_x3.hip), everything else fp32.  Timed like the main leg; its error is taken against the CPU
+    """The same train step on the parity-grade path: fp32 feature maps, 3x3 / 1x1 layers on the matrix pipe as split-operand products (three
+    per tap: fp16 pieces forward, bf16 pieces backward; csrc/conv_x3.hip), everything else fp32.  Timed like the main leg; its error is taken against the CPU
     oracle on a small closed-form sample (2 pairs of 64 x 64: fused image, total loss, every parameter gradient)."""
     import numpy as np
     import core.model as M
