@@ -206,7 +206,10 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_x3_kernel(TV tin, TV tout, TV
     constexpr int X3_THREADS = 64 * NW, X3_TH = RJ * NW, X3_IH = X3_TH + 2 * PD, X3_IW = X3_TW + 2 * PD;   // a wave owns RJ rows of the tile
     constexpr int CKB = KS == 1 ? (NP == 2 ? 8 : 4) : ((NP == 2 && NW == 8 && RJ == 2) ? 4 : 2);   // channel blocks per LDS chunk
     constexpr int KK = CKB / 2;                   // 16-channel sub-chunks (MFMA k-steps per tap) per chunk
-    constexpr int PL = X3_IH * X3_IW;             // granules of one channel-block plane of the input tile: 612
+    // granules of one channel-block plane of the input tile: 612 (340 on 8-row tiles).  M16: a multiple of 16 -- its fragment read takes lanes
+    // 0-15 from plane 0 and lanes 16-31 from plane 1, and a ds_read_b128 lane group ({0-3, 12-15, 20-27}, ..) is conflict free when the two
+    // runs sit a whole number of 256-byte bank sweeps apart (with 340 it was 2-way on a quarter of the group: 35 % extra LDS cycles)
+    constexpr int PL = M16 ? (X3_IH * X3_IW + 15) / 16 * 16 : X3_IH * X3_IW;
     constexpr int ING = CKB * PL;                 // input granules per piece
     constexpr int IN_ROUNDS = (ING + X3_THREADS - 1) / X3_THREADS;
     constexpr int WGC = KK * NP * WG;             // weight granules per chunk: [sub-chunk][piece][tap][cb 0/1][oc][8], as packed
@@ -348,7 +351,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_x3_kernel(TV tin, TV tout, TV
     static_assert(!M16 || (MB == 1 && KS == 3 && NP == 2 && CKB == 2), "M16: the 16-channel-chunk, two-piece, 3x3 kernels only");
 
     const int cbl = lane >> 5, nl = lane & 31;
-    const int bbase = (cbl * X3_IH + RJ * wave) * X3_IW + nl;   // + kk * 2 * PL + row * X3_IW + v   (+ piece * ING)
+    const int bbase = cbl * PL + RJ * wave * X3_IW + nl;         // + kk * 2 * PL + row * X3_IW + v   (+ piece * ING)
     const int abase = cbl * MBW + nl;                           // + kk * NP * WG + piece * WG + tap * 2 * MBW + m * 32
 
     issue(0);
@@ -392,7 +395,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_x3_kernel(TV tin, TV tout, TV
                     const x3_u4* s_in = s_buf;
                     const x3_u4* s_w = s_buf + NP * ING;
                     const int i16 = lane & 15, t2 = (lane >> 5) & 1, cb16 = (lane >> 4) & 1;   // k-group l >> 4 = 2 * (tap of the pair) + channel block
-                    const int b0 = (cb16 * X3_IH + RJ * wave) * X3_IW + i16, a0 = cb16 * MBW + i16;
+                    const int b0 = cb16 * PL + RJ * wave * X3_IW + i16, a0 = cb16 * MBW + i16;
 #pragma unroll
                     for (int pr = 0; pr < 5; ++pr) {
                         constexpr int dummy = 0; (void)dummy;
@@ -911,7 +914,8 @@ __global__ __launch_bounds__(64 * NWV, 12 / NWV) void wgrad_x3_kernel(TV tx, TV 
 // K = the 32 pixels of two tile rows) and the same two-piece products.  Work item (j, v) = input-channel block j x tap column v: it owns
 // dW[16][16 j .. 16 j + 15][u = 0..2][v] in 12 accumulator registers; a wave takes items wave, wave + 4, ...
 constexpr int XT_TH = 8, XT_TW = 16, XT_XH = XT_TH + 2, XT_XW = XT_TW + 2;
-constexpr int XT_XPL = XT_XH * XT_XW + 4, XT_GPL = XT_TH * XT_TW + 4;    // 184 / 132 granules per plane (= 4, 4 mod 16: see wgrad_x3_kernel)
+constexpr int XT_XPL = XT_XH * XT_XW, XT_GPL = XT_TH * XT_TW + 4;        // 180 / 132 granules per plane: both = 4 mod 16, so that the two planes a 32-lane
+                                                                         // group of the transposing read touches fall on disjoint bank halves (184 was 2-way: 35 % extra cycles)
 constexpr int XT_THREADS = 256;
 constexpr int XT_PER = 9 * 3 * 4 * 64 + 64;                            // floats per block partial: [item][u][reg][lane], db[16] (+ pad)
 template <int NXC, bool SIGNS = false>
