@@ -34,10 +34,23 @@ for _p in (ROOT, os.path.join(ROOT, "multi-modal-image-fusion_amd")):
 import torch
 import torch.distributed as dist
 
-MODEL_FLOPS_TRAIN = {"PFNetv1": 107.04e9, "PFNetv2": 36.82e9, "DenseFuse": 34.56e9}  # per pair @256x256
-MODEL_BYTES_TRAIN_BF16 = {"PFNetv1": 366.1e6}
+# algorithmic work of one train step per image pair (SURVEY.md section 8d / BASELINE.md section 3): (GFLOP, MB of bf16 tensors, side)
+MODEL_WORK_TRAIN = {"PFNetv1": (107.04e9, 366.1e6, 256), "PFNetv2": (36.82e9, 517.1e6, 256), "DenseFuse": (34.56e9, 240.3e6, 256),
+                    "NestFuse": (1828.4e9, 4006.9e6, 512), "RFNNest": (2665.9e9, 6324.5e6, 512)}
+MODEL_FLOPS_TRAIN = {k: v[0] for k, v in MODEL_WORK_TRAIN.items() if v[2] == 256}
 PEAK_MFMA_BF16 = 2.5e15   # dense, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_MATRIX_FP32 = 157e12
 PEAK_HBM = 8.0e12
+
+
+def ideal_pairs_per_s(model, h, w, dtype):
+    """SURVEY 8(d)'s "ideal pairs/s/GPU": 1 / max(t_MFMA, t_HBM) of the step's algorithmic flops and bytes at the peaks above (fp32 storage
+    doubles the bytes; flops priced at the bf16 matrix peak either way: the fp32 path issues half-precision MFMA products)"""
+    if model not in MODEL_WORK_TRAIN:
+        return None
+    fl, by, side = MODEL_WORK_TRAIN[model]
+    scale = (h * w) / float(side * side)
+    return 1.0 / max(fl * scale / PEAK_MFMA_BF16, by * scale * (2 if dtype == "fp32" else 1) / PEAK_HBM)
 
 
 def parse():
@@ -60,7 +73,10 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=8, help="image pairs per step of the CPU sample")
     ap.add_argument("--no-parity-path", action="store_true", help="skip the second timed leg on the parity-grade fp32 / split-bf16 path")
     ap.add_argument("--parity-steps", type=int, default=16)
-    ap.add_argument("--roofline-tag", default="decode.0:fwd", help="engine op timed with HIP events for `roofline`")
+    ap.add_argument("--roofline-layer", default="decode.0", help="engine layer whose forward / dgrad / wgrad launches are timed with HIP events; "
+                    "`roofline` reports the one with the largest share of the step, `roofline_kernels` all three")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend for N > 1 (nccl = RCCL; gloo: debugging)")
+    ap.add_argument("--one-device", action="store_true", help="debug: every rank on cuda:0 (gloo only) -- exercises the N > 1 plumbing on a 1-GPU box")
     ap.add_argument("--hbm-tag", default="auto", help="an HBM-bound engine op timed the same way for `roofline_hbm` ('' = none)")
     return ap.parse_args()
 
@@ -75,29 +91,39 @@ def _cpu_model():
     return "unknown CPU"
 
 
-def cpu_baseline(model_name, size, n_pairs, budget_s=12.0):
+def cpu_baseline(model_name, size, n_pairs, budget_s=24.0):
     """The torch-CPU restatement of the SAME train step (oracle/torch_cpu_step.py: stock torch CPU ops, pinned to the reference's goldens
-    F5 / F6 by tests/test_torch_cpu_step.py) on this box's host cores, with the intra-op thread count torch picks: one untimed step,
-    then timed steps of n_pairs pairs until budget_s is spent (at most 4)."""
+    F5 / F6 by tests/test_torch_cpu_step.py) on this box's host cores with min(32, cores) intra-op threads (128 threads on a small
+    conv step measure the thread pool, not the cores: round 3's one-step sample moved +-70 % run to run): one untimed step, then at
+    least 3 timed steps of n_pairs pairs (more while budget_s lasts, at most 8); `value` is the BEST step, the median is beside it."""
     from oracle import torch_cpu_step as TC
     if model_name not in ("PFNetv1", "DenseFuse"):
         return None
-    m = TC.TorchCpuModel(model_name)
-    P = m.init_params(0)
-    opt = TC.make_optimizer(P)
-    g = torch.Generator().manual_seed(0)
-    shape = (n_pairs, 1, size, size)
-    i1, i2 = torch.rand(shape, generator=g), torch.rand(shape, generator=g)
-    TC.train_step(m, P, opt, i1[:max(1, n_pairs // 4)], i2[:max(1, n_pairs // 4)])   # thread pool / allocator warm-up
-    t0, steps = time.time(), 0
-    while steps < 4 and (steps == 0 or time.time() - t0 < budget_s):
-        TC.train_step(m, P, opt, i1, i2)
-        steps += 1
-    dt = time.time() - t0
-    return {"value": n_pairs * steps / dt, "unit": "image-pairs/s", "cores": int(torch.get_num_threads()), "kind": "port",
-            "sample": f"{steps} train step(s) of {model_name} on {n_pairs} pairs {size}x{size} fp32, torch {torch.__version__} CPU ops "
-                      f"(oracle/torch_cpu_step.py), {dt:.1f} s; torch.get_num_threads() = {torch.get_num_threads()}, os.cpu_count() = {os.cpu_count()}, "
-                      f"CPU: {_cpu_model()}"}
+    prev_threads = torch.get_num_threads()
+    threads = max(1, min(32, os.cpu_count() or 1))
+    torch.set_num_threads(threads)
+    try:
+        m = TC.TorchCpuModel(model_name)
+        P = m.init_params(0)
+        opt = TC.make_optimizer(P)
+        g = torch.Generator().manual_seed(0)
+        shape = (n_pairs, 1, size, size)
+        i1, i2 = torch.rand(shape, generator=g), torch.rand(shape, generator=g)
+        TC.train_step(m, P, opt, i1, i2)   # thread pool / allocator warm-up at the timed shape
+        times, t_start = [], time.time()
+        while len(times) < 3 or (len(times) < 8 and time.time() - t_start < budget_s):
+            t0 = time.time()
+            TC.train_step(m, P, opt, i1, i2)
+            times.append(time.time() - t0)
+        ts = sorted(times)
+        med = ts[len(ts) // 2]
+        return {"value": n_pairs / ts[0], "unit": "image-pairs/s", "cores": threads, "kind": "port", "median_value": n_pairs / med,
+                "steps": len(times), "step_seconds": [round(t, 3) for t in times],
+                "sample": f"best of {len(times)} train steps of {model_name} on {n_pairs} pairs {size}x{size} fp32 (one untimed warm-up step first), "
+                          f"torch {torch.__version__} CPU ops (oracle/torch_cpu_step.py), {sum(times):.1f} s; torch.set_num_threads({threads}), "
+                          f"os.cpu_count() = {os.cpu_count()}, CPU: {_cpu_model()}"}
+    finally:
+        torch.set_num_threads(prev_threads)
 
 
 def lib_sha256():
@@ -111,10 +137,10 @@ def lib_sha256():
 
 
 def measured_traffic(tag, match):
-    """HBM bytes per launch of the kernel behind `tag` from the TCC counter passes on file (profiles/r03_traffic.json, written by
+    """HBM bytes per launch of the kernel behind `tag` from the TCC counter passes on file (profiles/r04_traffic.json, written by
     tools/make_traffic.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this command) -- only when those passes ran on
     THIS library build (sha256 of the .so) and this workload; otherwise (None, reason)."""
-    tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
     if not os.path.isfile(tpath):
         return None, "no counter pass on file"
     tj = json.load(open(tpath))
@@ -125,20 +151,94 @@ def measured_traffic(tag, match):
     ent = tj.get("kernels", {}).get(tag)
     if not ent:
         return None, "kernel not in the counter pass on file"
-    return ent, f"profiles/r03_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, lib {tj['lib_sha256'][:12]})"
+    return ent, f"profiles/{TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, lib {tj['lib_sha256'][:12]})"
+
+
+TRAFFIC_FILE = "r04_traffic.json"
+KIND_KERNEL_BF16 = {"fwd": "conv_dma_kernel<false>", "dgrad": "conv_dma_kernel<true> (ReLU sign bytes, in-tile reflect fold)",
+                    "wgrad": "wgrad_dma_kernel + wgrad_dma_reduce"}
+KIND_KERNEL_FP32 = {"fwd": "conv_x3_kernel<fwd>", "dgrad": "conv_x3_kernel<dgrad> + fold", "wgrad": "wgrad_x3_kernel + wgrad_x3_reduce"}
+
+
+def conv_rooflines(T, engine, layer, B, S, Wd, dtype, step_ms, workload_id=None):
+    """`roofline` objects of the forward / dgrad / wgrad launches of one conv layer from the HIP events bench recorded inside the timed
+    region (T.PROFILE_EVENTS): ALGORITHMIC flops (2 B H W Cin Cout k^2 per pass) over the average launch duration.  bf16:
+    against the dense bf16 MFMA peak.  fp32 tensors (split-operand kernels): the algorithmic rate against the fp32 matrix peak (157
+    TFLOP/s -- the kernels beat it because they issue half-precision products) AND the executed MFMA rate (products_per_tap x the
+    algorithmic flops) against the bf16 peak, as separate fields."""
+    spec = [s for s in engine.specs if s.name == layer]
+    if not spec:
+        return {}
+    sp = spec[0]
+    flops = 2.0 * B * S * Wd * sp.cin * sp.cout * sp.k * sp.k
+    out = {}
+    for kind in ("fwd", "dgrad", "wgrad"):
+        evs = T.PROFILE_EVENTS.get(f"{layer}:{kind}", [])
+        if not evs:
+            continue
+        ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
+        ach = flops / (ms * 1e-3)
+        r = {"bound": "mfma", "kernel": f"{(KIND_KERNEL_FP32 if dtype == 'fp32' else KIND_KERNEL_BF16)[kind]} {sp.cin}->{sp.cout} k{sp.k} ({layer}:{kind})",
+             "achieved": ach / 1e12, "peak": (PEAK_MATRIX_FP32 if dtype == "fp32" else PEAK_MFMA_BF16) / 1e12, "unit": "TFLOP/s",
+             "frac": ach / (PEAK_MATRIX_FP32 if dtype == "fp32" else PEAK_MFMA_BF16), "avg_launch_ms": ms, "launches": len(evs),
+             "step_share": ms / step_ms if step_ms else None, "traffic": None,
+             "algorithmic_bytes": float(B) * S * Wd * (sp.cin + sp.cout) * (2 if dtype == "bf16" else 4)}
+        if dtype == "fp32":
+            from mmif._lib import lib as _l
+            prods = {16: 3, 3: 6, 2: 3}[_l.mmif_get_x3_forward_pieces()] if kind == "fwd" else 3
+            r["products_per_tap"] = prods
+            r["executed_mfma_tflops"] = ach * prods / 1e12
+            r["executed_frac_of_bf16_mfma_peak"] = ach * prods / PEAK_MFMA_BF16
+            r["peak_note"] = "peak = fp32 matrix (157 TFLOP/s); the split-operand kernels issue products_per_tap half-precision MFMA products per algorithmic product"
+        if workload_id is not None:
+            # HBM bytes per launch from the TCC PMC passes of the same command (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs,
+            # gfx950 correction applied, tools/prof_pmc.sh + tools/make_traffic.py) -- only when taken on THIS library build
+            ent, src = measured_traffic(f"{layer}:{kind}", workload_id)
+            r["traffic"] = ent["hbm_bytes_per_launch"] if ent else None
+            r["traffic_source"] = src
+        out[kind] = r
+    return out
+
+
+def oracle_error_sample(model_name, shape, dev, losses):
+    """one train step's fused image, total loss and every parameter gradient on the current compute dtype against the CPU oracle"""
+    import numpy as np
+    import core.model as M
+    from mmif.optim import FusedClipAdam
+    from oracle import fusion_oracle as O
+    l_ssim, l_pix, l_grad = losses
+    i1n, i2n = O.closed_form_image(shape, 0.3), O.closed_form_image(shape, 1.7)
+    om = O.MODELS[model_name]()
+    P = om.init_params(seed=1)
+    ref = O.train_step(om, P, O.AdamState(P), i1n, i2n, clip=None)
+    m = getattr(M, model_name)()
+    m.load_state_dict({k: torch.from_numpy(O.closed_form_param(i, k, tuple(v.shape), 1)) for i, (k, v) in enumerate(m.state_dict().items())})
+    m = m.to(dev)
+    o2 = FusedClipAdam(m.parameters(), lr=1e-4, max_norm=0.0)
+    i1, i2 = torch.from_numpy(i1n).to(dev), torch.from_numpy(i2n).to(dev)
+    o2.zero_grad(set_to_none=True)
+    f = m(i1, i2)
+    tot = l_ssim(i1, i2, f) + l_pix(i1, i2, f, mode='max') + l_grad(i1, i2, f, mode='max')
+    tot.backward()
+    torch.cuda.synchronize()
+    assert float(np.abs(ref["imgf"]).max()) > 0
+    err_img = float(np.abs(f.detach().cpu().numpy() - ref["imgf"]).max() / np.abs(ref["imgf"]).max())
+    gerr = max(float(np.abs(p.grad.cpu().numpy() - ref["grads"][k]).max() / max(np.abs(ref["grads"][k]).max(), 1e-12)) for k, p in m.named_parameters())
+    return {"shape": "x".join(str(v) for v in (shape[0],) + shape[2:]), "rel_err_vs_oracle": err_img,
+            "loss_abs_err_vs_oracle": abs(float(tot.item()) - float(ref["losses"][3])), "grad_rel_err_vs_oracle": gerr}
 
 
 def parity_leg(args, dev, img1, img2):
     """The same train step on the parity-grade path: fp32 feature maps, 3x3 / 1x1 layers on the matrix pipe as split-operand products (three
-    per tap: fp16 pieces forward, bf16 pieces backward; csrc/conv_x3.hip), everything else fp32.  Timed like the main leg; its error is taken against the CPU
-    oracle on a small closed-form sample (2 pairs of 64 x 64: fused image, total loss, every parameter gradient)."""
-    import numpy as np
+    per tap: fp16 pieces forward, bf16 pieces backward; csrc/conv_x3.hip), everything else fp32.  Timed like the main leg, with the same
+    per-kernel HIP events on --roofline-layer; its error is taken against the CPU oracle on two small closed-form samples (2 pairs of
+    64 x 64 and one ragged 37 x 53 pair: fused image, total loss, every parameter gradient)."""
     import core.model as M
     from core.loss import FusionLoss, GradLoss, PixelLoss, SSIMLoss
     from mmif import engine as E
+    from mmif import tensor as T
     from mmif._lib import lib
     from mmif.optim import FusedClipAdam
-    from oracle import fusion_oracle as O
     prev = E.compute_dtype()
     E.set_compute_dtype("fp32")
     try:
@@ -157,51 +257,54 @@ def parity_leg(args, dev, img1, img2):
         opt = FusedClipAdam(model.parameters(), lr=1e-4, betas=(0.9, 0.999), max_norm=5.0)
         for _ in range(6):     # (warm-up as the main leg's: packing, leases, the clock's ramp after the idle oracle / setup phase)
             one(model, opt, img1, img2)
+        T.PROFILE_TAGS = {f"{args.roofline_layer}:{k}" for k in ("fwd", "dgrad", "wgrad")}
+        T.PROFILE_EVENTS.clear()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.parity_steps):
             one(model, opt, img1, img2)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        T.PROFILE_TAGS = set()
+        B, S, Wd = img1.shape[0], img1.shape[2], img1.shape[3]
+        value = B * args.parity_steps / dt
+        roofs = conv_rooflines(T, model._engine, args.roofline_layer, B, S, Wd, "fp32", dt / args.parity_steps * 1e3)
+        T.PROFILE_EVENTS.clear()
         del model, opt
-        # error against the oracle, small sample
-        shape = (2, 1, 64, 64)
-        i1n, i2n = O.closed_form_image(shape, 0.3), O.closed_form_image(shape, 1.7)
-        om = O.MODELS[args.model]()
-        P = om.init_params(seed=1)
-        ref = O.train_step(om, P, O.AdamState(P), i1n, i2n, clip=None)
-        m = getattr(M, args.model)()
-        m.load_state_dict({k: torch.from_numpy(O.closed_form_param(i, k, tuple(v.shape), 1)) for i, (k, v) in enumerate(m.state_dict().items())})
-        m = m.to(dev)
-        o2 = FusedClipAdam(m.parameters(), lr=1e-4, max_norm=0.0)
-        i1, i2 = torch.from_numpy(i1n).to(dev), torch.from_numpy(i2n).to(dev)
-        o2.zero_grad(set_to_none=True)
-        f = m(i1, i2)
-        tot = l_ssim(i1, i2, f) + l_pix(i1, i2, f, mode='max') + l_grad(i1, i2, f, mode='max')
-        tot.backward()
-        torch.cuda.synchronize()
-        err_img = float(np.abs(f.detach().cpu().numpy() - ref["imgf"]).max() / np.abs(ref["imgf"]).max())
-        gerr = max(float(np.abs(p.grad.cpu().numpy() - ref["grads"][k]).max() / max(np.abs(ref["grads"][k]).max(), 1e-12)) for k, p in m.named_parameters())
-        B = img1.shape[0]
+        samples = [oracle_error_sample(args.model, shp, dev, (l_ssim, l_pix, l_grad)) for shp in ((2, 1, 64, 64), (1, 1, 37, 53))]
         mode = lib.mmif_get_x3_forward_pieces()
         fwd = {16: "3 products of scaled fp16 pieces", 3: "6 products of bf16 pieces", 2: "3 products of bf16 pieces"}[mode]
+        ideal = ideal_pairs_per_s(args.model, S, Wd, "fp32")
+        dom = max(roofs.values(), key=lambda r: r["step_share"]) if roofs else None
         return {"dtype": f"fp32 storage; 3x3 / 1x1 layers as split-operand MFMA products (forward: {fwd}; backward: 3 products of bf16 pieces), fp32 accumulate",
-                "value": B * args.parity_steps / dt, "unit": "image-pairs/s", "ms_per_step": dt / args.parity_steps * 1e3, "steps": args.parity_steps,
-                "rel_err_vs_oracle": err_img, "loss_abs_err_vs_oracle": abs(float(tot.item()) - float(ref["losses"][3])), "grad_rel_err_vs_oracle": gerr,
-                "oracle_sample": "2 pairs 64x64, closed-form weights / images: max |fused image - oracle| / max|oracle|; max over parameters of max |grad - oracle| / max|oracle grad|",
+                "value": value, "unit": "image-pairs/s", "ms_per_step": dt / args.parity_steps * 1e3, "steps": args.parity_steps,
+                "step_frac_of_ideal": value / (ideal / 3.0) if ideal else None,
+                "ideal_note": "ideal = SURVEY 8(d) max(t_MFMA, t_HBM) with 3 half-precision products per algorithmic product at the bf16 MFMA peak and fp32 bytes",
+                "roofline": dom, "roofline_kernels": roofs,
+                "rel_err_vs_oracle": max(e["rel_err_vs_oracle"] for e in samples), "loss_abs_err_vs_oracle": max(e["loss_abs_err_vs_oracle"] for e in samples),
+                "grad_rel_err_vs_oracle": max(e["grad_rel_err_vs_oracle"] for e in samples), "oracle_samples": samples,
+                "oracle_sample": "2 pairs 64x64 and 1 pair 37x53, closed-form weights / images: max |fused image - oracle| / max|oracle|; max over parameters of max |grad - oracle| / max|oracle grad| (worst of the two samples)",
                 "tolerance": "BASELINE north star: 1e-3 relative"}
     finally:
         E.set_compute_dtype(prev)
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def self_launch(args):
     """`python bench.py --gpus N` (N > 1) without a launcher environment: start the N ranks as a CHILD torch.distributed.run -- this
-    process has not initialised the GPU (torch.cuda.device_count() does not) and never will -- relay the output, return its code."""
+    process has not initialised the GPU (torch.cuda.device_count() does not) and never will -- relay the output, return its code.
+    The rendezvous port is one the kernel just handed out (bind to port 0)."""
     import subprocess
     have = torch.cuda.device_count()
-    if have < args.gpus:
+    if have < args.gpus and not (args.one_device and args.backend == "gloo"):
         raise SystemExit(f"bench.py: --gpus {args.gpus} but this box has {have} visible GPU(s); refusing to report a {have}-GPU run as {args.gpus}")
-    port = os.environ.get("MASTER_PORT", str(29500 + os.getpid() % 2000))
+    port = os.environ.get("MASTER_PORT") or str(free_port())
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
@@ -210,20 +313,30 @@ def self_launch(args):
 
 def main():
     args = parse()
+    if args.one_device and args.backend != "gloo":
+        raise SystemExit("bench.py: --one-device is a debugging aid for --backend gloo (RCCL wants one device per rank)")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE = {world} rank(s)")
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.one_device else int(os.environ.get("LOCAL_RANK", "0"))
+    if rank != 0:
+        # stdout belongs to rank 0's JSON line: whatever the other ranks (or the libraries in them: RCCL's banner goes through C stdio and
+        # sits in libc's buffer until exit) print goes to stderr from here on
+        sys.stdout.flush()
+        os.dup2(2, 1)
     # $MMIF_FORCE_DIST=1: take the RCCL code path (init, parameter broadcast, gradient all-reduce, barriers) with one rank too
     use_dist = world > 1 or os.environ.get("MMIF_FORCE_DIST", "0") == "1"
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))  # RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))  # RCCL on ROCm
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
     dev = torch.device("cuda", local_rank)
@@ -296,7 +409,7 @@ def main():
     enc_stream = args.dtype == "bf16" and os.environ.get("MMIF_ENC_STREAM", "1") != "0" and args.model in ("PFNetv1", "DenseFuse", "PFNetv2", "VIFNet")
     if hbm_tag == "auto":   # the encoder: ONE streaming launch for its 2 x 4 layers, or (layer-wise) its widest thin layer 48 -> 16
         hbm_tag = "encode:fwd" if enc_stream else ({"PFNetv1": "encode1.1.2:fwd", "DenseFuse": "encode.1.2:fwd", "PFNetv2": "encode.1.2:fwd", "VIFNet": "encode.1.2:fwd"}.get(args.model, "") if args.mode == "train" else "")
-    T.PROFILE_TAGS = {args.roofline_tag} | ({hbm_tag} if hbm_tag else set())
+    T.PROFILE_TAGS = {f"{args.roofline_layer}:{k}" for k in ("fwd", "dgrad", "wgrad")} | ({hbm_tag} if hbm_tag else set())
     T.PROFILE_EVENTS.clear()
     if use_dist:
         dist.barrier()
@@ -319,36 +432,10 @@ def main():
         pairs = B * world * args.steps
         value = pairs / dt
         workload_id = f"{args.model} {args.mode} B={B} {Wd}x{S} {args.dtype}"
-        # dominant kernel, timed live (HIP events on the launch stream, inside the timed region)
-        evs = T.PROFILE_EVENTS.get(args.roofline_tag, [])
-        roof = None
-        if evs:
-            ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
-            spec = [s for s in model._engine.specs if args.roofline_tag.startswith(s.name + ":")]
-            if spec:
-                s = spec[0]
-                flops = 2.0 * B * S * Wd * s.cin * s.cout * s.k * s.k
-                ach = flops / (ms * 1e-3)
-                dma = os.environ.get("MMIF_CONV_DMA", "1") != "0" and s.k == 3 and s.cout >= 49 and args.dtype == "bf16"
-                kname = "conv_dma_kernel" if dma else "conv_mfma_kernel"
-                if args.dtype == "fp32":
-                    # fp32 tensors: the split-bf16 kernel issues `prods` bf16 MFMA products per algorithmic product; its roofline is the
-                    # bf16 matrix peak over the MFMA flops it really executes
-                    from mmif._lib import lib as _l
-                    prods = {16: 3, 3: 6, 2: 3}[_l.mmif_get_x3_forward_pieces()] if args.roofline_tag.endswith(":fwd") else 3
-                    kname = f"conv_x3_kernel ({prods} half-precision MFMA products per tap)"
-                    ach *= prods
-                roof = {"bound": "mfma", "kernel": f"{kname} {s.cin}->{s.cout} k{s.k} ({args.roofline_tag})",
-                        "achieved": ach / 1e12, "peak": PEAK_MFMA_BF16 / 1e12,
-                        "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_BF16,
-                        "avg_launch_ms": ms, "launches": len(evs), "traffic": None}
-                # HBM bytes per launch of this kernel from the TCC PMC passes of the same command (separate rocprofv3 --pmc FETCH_SIZE /
-                # WRITE_SIZE runs, gfx950 correction applied, tools/prof_pmc.sh + tools/make_traffic.py) -- only when they were taken on
-                # THIS library build; a stale file prints null
-                roof["algorithmic_bytes"] = float(B) * S * Wd * (s.cin + s.cout) * (2 if args.dtype == "bf16" else 4)
-                ent, src = measured_traffic(args.roofline_tag, workload_id)
-                roof["traffic"] = ent["hbm_bytes_per_launch"] if ent else None
-                roof["traffic_source"] = src
+        # the wide layer's three launches, timed live (HIP events on the launch stream, inside the timed region); `roofline` is the one
+        # with the largest share of the step
+        roofs = conv_rooflines(T, model._engine, args.roofline_layer, B, S, Wd, args.dtype, dt / args.steps * 1e3, workload_id) if getattr(model, "_engine", None) is not None else {}
+        roof = max(roofs.values(), key=lambda r: r["step_share"]) if roofs else None
         roof_hbm = None
         evh = T.PROFILE_EVENTS.get(hbm_tag, []) if hbm_tag else []
         if evh:
@@ -356,7 +443,6 @@ def main():
             spec = [s for s in model._engine.specs if hbm_tag.startswith(s.name + ":")]
             if hbm_tag == "encode:fwd":
                 # algorithmic bytes of the 2 x 4 conv passes it replaces (H*W*(Cin+Cout)*sizeof per pass, the image in fp32)
-                # -- the launch itself only moves the two images and the 128 output planes (`fused_bytes`)
                 # -- the launch itself only moves the images and the output planes (`fused_bytes`): achieved / frac are the bytes the launch
                 # REALLY moves (the counter figure when one is on file for this build, else fused_bytes) over its duration; the rate in
                 # terms of the layer-wise passes it replaces is reported apart (it is not a bandwidth and may exceed the peak)
@@ -379,6 +465,7 @@ def main():
                             "achieved": nbytes / (ms * 1e-3) / 1e9,
                             "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": nbytes / (ms * 1e-3) / PEAK_HBM, "avg_launch_ms": ms,
                             "launches": len(evh), "traffic": ent["hbm_bytes_per_launch"] if ent else None, "traffic_source": src, "algorithmic_bytes": nbytes}
+        ideal = ideal_pairs_per_s(args.model, S, Wd, args.dtype) if args.mode == "train" else None
         out = {
             "metric": "image-pairs/sec at 256x256, PFNet train step" if args.mode == "train" else f"image-pairs/sec at {Wd}x{S}, {args.model} inference", "value": value, "unit": "image-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -387,9 +474,14 @@ def main():
             "config": {"workload": (f"{args.model} train step (fwd + SSIM/pixel/grad losses + bwd + clip + Adam)" if args.mode == "train" else f"{args.model} forward (no_grad, test.py path)") + f", {Wd}x{S} synthetic IR/visible pairs, "
                                    f"batch {B} per GPU, {args.dtype} feature maps / fp32 accumulate, random-init weights (seed 0)",
                        "global_batch": B * world, "parallelism": f"dp{world}" if world > 1 else "single",
+                       "backend": (args.backend if use_dist else None),
                        "step_model_tflops": MODEL_FLOPS_TRAIN.get(args.model, 0) * value / 1e12 if (S == 256 and Wd == 256 and args.mode == "train") else None},
             "final_loss": loss,
+            # value per GPU over SURVEY 8(d)'s ideal pairs/s/GPU = 1 / max(t_MFMA, t_HBM) of the step's algorithmic flops / bytes at the peaks
+            "step_frac_of_ideal": (value / world) / ideal if ideal else None,
+            "ideal_pairs_per_s_per_gpu": ideal,
             "roofline": roof,
+            "roofline_kernels": roofs or None,
             "roofline_hbm": roof_hbm,
             "parity_path": None,
             "cpu_baseline": None,
@@ -402,9 +494,10 @@ def main():
     else:
         out = None
     if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
-    # the JSON line is the LAST thing on stdout: RCCL prints a version banner through C stdio, which -- stdout being a pipe -- sits in
-    # libc's buffer until exit, i.e. would land AFTER a line printed here; every rank flushes it out now, rank 0 prints a moment later
+    # the JSON line is the LAST thing on stdout: ranks other than 0 have had their stdout pointed at stderr since start-up, and rank 0
+    # empties Python's and libc's buffers (RCCL's banner goes through C stdio) before it prints
     import ctypes
     sys.stdout.flush()
     try:
@@ -412,8 +505,6 @@ def main():
     except OSError:
         pass
     if out is not None:
-        if use_dist:
-            time.sleep(0.3)
         print(json.dumps(out), flush=True)
 
 

@@ -387,7 +387,10 @@ int mmif_conv2d_reflect_bwd_pair(const mmif_tensor* gy, const void* w_packed_t, 
  * [x > 0].  Workspace: mmif_conv2d_wgrad_workspace(cin, cout, 3); signs: mmif_conv2d_bwd_wide_signs_bytes(n, cin, h, w) bytes, scratch.
  * fp32 tensors (mmif_conv2d_bwd_wide_supported_f32: any 3x3 / 1x1 layer the split-operand kernels of csrc/conv_x3.hip take, x3 operand
  * image as w_packed_t): the same contract -- the split-operand weight gradient leaves the map ([n][ceil(cb / 4)][h][w] dwords, one byte per
- * pixel and channel block), the split-operand dgrad masks with it: 1/32 of the bytes of x. */
+ * pixel and channel block), the split-operand dgrad masks with it: 1/32 of the bytes of x.
+ * `accumulate`: bit 0 = add onto dw / db; bits 1-2 = phase -- 0: both halves; 1 (value 2): weight gradient + sign map only; 2 (value 4):
+ * input gradient only, reading the map a phase-1 call left.  Two calls (2 | a, then 4) give the bits of one call with phase 0 and let a
+ * caller time the two kernels apart (bench.py's per-kernel roofline). */
 int mmif_conv2d_bwd_wide_supported(int32_t cin, int32_t cout, int32_t ksize);
 int mmif_conv2d_bwd_wide_supported_f32(int32_t cin, int32_t cout, int32_t ksize);
 size_t mmif_conv2d_bwd_wide_signs_bytes(int32_t n, int32_t cin, int32_t h, int32_t w);

@@ -26,7 +26,7 @@ int bwd_pair(const TV& tx, const TV& tg, const TV& tgx, const void* wpk_dgrad, f
 bool bwd_wide_supported(int ks, int cin, int cout);
 size_t bwd_wide_signs_bytes(int n, int cin, int h, int w);
 int bwd_wide(const TV& tx, const TV& tg, const TV& tgx, const void* wpk_dgrad, float* dw, float* db, int cin, int cout, uint64_t mask_bits,
-             int accumulate, float* ws, unsigned char* signs, hipStream_t st);
+             int accumulate, float* ws, unsigned char* signs, hipStream_t st, int phase);
 // conv_x3.hip
 bool conv_x3_supported(bool dgrad, int ks, int cin, int cout, const TV& tin, const TV& tout);
 int conv_x3(bool dgrad, const TV& tin, const TV& tout, const TV& tmask, const void* wpk, const float* bias, int cin, int cout, int relu,
@@ -234,6 +234,11 @@ extern "C" int mmif_conv2d_reflect_bwd_wide(const mmif_tensor* gy, const void* w
     if (int rc = validate_tensor(gy, "gy")) return rc;
     if (int rc = validate_tensor(x, "x")) return rc;
     if (int rc = validate_tensor(gx, "gx")) return rc;
+    // accumulate: bit 0 = add onto dw / db; bits 1-2 = phase (0: both halves, 1: weight gradient + sign map only, 2: input gradient only,
+    // reading the map phase 1 left) -- the two halves of one backward as two calls, so that a caller can time each kernel
+    const int phase = (accumulate >> 1) & 3;
+    accumulate &= 1;
+    MMIF_REQUIRE(phase <= 2, "conv2d_reflect_bwd_wide: phase bits of `accumulate` must be 0, 1 or 2");
     if (gy->dtype == MMIF_F32 && x->dtype == MMIF_F32 && gx->dtype == MMIF_F32) {
         // fp32 tensors: the split-operand weight gradient leaves its sign map ([n][ceil(cb / 4)][h][w] dwords), the split-operand dgrad
         // masks with it, the stand-alone fold follows -- bit for bit mmif_conv2d_reflect_wgrad + mmif_conv2d_reflect_dgrad_folded
@@ -252,7 +257,9 @@ extern "C" int mmif_conv2d_reflect_bwd_wide(const mmif_tensor* gy, const void* w
             set_error("conv2d_reflect_bwd_wide: sign-byte buffer too small (mmif_conv2d_bwd_wide_signs_bytes)");
             return MMIF_EWORKSPACE;
         }
-        if (int rc = wgrad_x3(tx, tg, dw, db, cin, cout, accumulate, (float*)workspace, (hipStream_t)stream, ksize, (unsigned*)signs)) return rc;
+        if (phase != 2)
+            if (int rc = wgrad_x3(tx, tg, dw, db, cin, cout, accumulate, (float*)workspace, (hipStream_t)stream, ksize, (unsigned*)signs)) return rc;
+        if (phase == 1) return MMIF_OK;
         if (int rc = conv_x3(true, tg, tgx, tx, w_packed_t, nullptr, cin, cout, 0, mask_bits, 0, (hipStream_t)stream, ksize, (const unsigned*)signs)) return rc;
         return ksize == 1 ? MMIF_OK : mmif_fold_halo(gx, stream);
     }
@@ -274,5 +281,5 @@ extern "C" int mmif_conv2d_reflect_bwd_wide(const mmif_tensor* gy, const void* w
         return MMIF_EWORKSPACE;
     }
     return bwd_wide(make_tv(x), make_tv(gy), make_tv(gx), w_packed_t, dw, db, cin, cout, mask_bits, accumulate, (float*)workspace,
-                    (unsigned char*)signs, (hipStream_t)stream);
+                    (unsigned char*)signs, (hipStream_t)stream, phase);
 }

@@ -2059,10 +2059,12 @@ static void init_modes();
 bool bwd_wide_supported(int ks, int cin, int cout) { return ks == 3 && cin >= 64 && cout >= 64 && cin % 64 == 0 && cout % 64 == 0 && cin <= 512; }
 size_t bwd_wide_signs_bytes(int n, int cin, int h, int w) { return (size_t)n * (cin / 8) * (h + 2) * sign_pitch(w); }
 int bwd_wide(const TV& tx, const TV& tg, const TV& tgx, const void* wpk_dgrad, float* dw, float* db, int cin, int cout, uint64_t mask_bits,
-             int accumulate, float* ws, unsigned char* signs, hipStream_t st) {
+             int accumulate, float* ws, unsigned char* signs, hipStream_t st, int phase) {
     init_modes();
     const SignMap sgn{signs, tx.cb, tx.h + 2, sign_pitch(tx.w)};
-    if (int rc = launch_wgrad_dma(tx, tg, dw, db, cin, cout, accumulate, ws, st, mask_bits != 0 ? sgn : SignMap{nullptr, 0, 0, 0})) return rc;
+    if (phase != 2)   // (phase 1 / 2: only the weight-gradient / only the input-gradient half -- per-kernel timing, mmif.h)
+        if (int rc = launch_wgrad_dma(tx, tg, dw, db, cin, cout, accumulate, ws, st, mask_bits != 0 ? sgn : SignMap{nullptr, 0, 0, 0})) return rc;
+    if (phase == 1) return MMIF_OK;
     return launch_conv_dma(true, tg, tgx, tx, wpk_dgrad, nullptr, cin, 0, mask_bits, 0, 1, st, sgn);
 }
 

@@ -570,7 +570,10 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_x3_kernel(TV tin, TV tout, TV
                             }
                         }
                         if (mask_bits != 0ull && signs != nullptr) {   // the sign map wgrad_x3_kernel left: one dword = the 4 blocks of this group
-                            const unsigned sg = signs[(((long long)in_ * ((tmask.cb + 3) >> 2) + (mb * MB + m)) * tmask.h + oy) * tmask.w + ox];
+                            // (the last 64-wide m-block of a layer with cin % 64 in (0, 32] has a second group past the map: clamp the
+                            // group like the `old` loads clamp their block -- its values are never stored, ocb >= tout.cb)
+                            const int ngrp = (tmask.cb + 3) >> 2, grp = min(mb * MB + m, ngrp - 1);
+                            const unsigned sg = signs[(((long long)in_ * ngrp + grp) * tmask.h + oy) * tmask.w + ox];
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
                                 const unsigned nib = (sg >> (8 * q + 4 * half)) & 15u;

@@ -223,11 +223,23 @@ def bwd_wide_signs_bytes(n, cin, h, w):
 
 def conv_bwd_wide(gy, x, gx, dw, db, cin, cout, k, packed, mask_bits, ws, signs, accumulate=False, tag=None):
     """wgrad + dgrad (blocks in mask_bits masked by x, folded) of one wide 3x3 layer; the wgrad kernel leaves x's ReLU sign bytes in
-    `signs` (uint8 scratch, bwd_wide_signs_bytes) for the dgrad kernel; returns the folded gx view."""
-    with _timed(tag, (gy.n, gy.h, gy.w, cin, cout, k)):
-        check(lib.mmif_conv2d_reflect_bwd_wide(gy.d, _ptr(packed.dgrad), x.d, gx.d, _ptr(dw), _ptr(db), cin, cout, k, mask_bits, int(accumulate),
+    `signs` (uint8 scratch, bwd_wide_signs_bytes) for the dgrad kernel; returns the folded gx view.  When the profiler asks for the
+    layer's ':wgrad' / ':dgrad' tag the two halves run as two calls (phase bits of `accumulate`, mmif.h) -- the same two kernels in the
+    same order, each bracketed by its own events."""
+    def call(acc):
+        check(lib.mmif_conv2d_reflect_bwd_wide(gy.d, _ptr(packed.dgrad), x.d, gx.d, _ptr(dw), _ptr(db), cin, cout, k, mask_bits, acc,
                                                _ptr(ws), ws.numel() * ws.element_size(), _ptr(signs), signs.numel(), stream_ptr()),
               "conv2d_reflect_bwd_wide")
+    shape = (gy.n, gy.h, gy.w, cin, cout, k)
+    base = tag[:-4] if (tag is not None and tag.endswith(":bwd")) else None
+    if base is not None and PROFILE_TAGS and (base + ":wgrad" in PROFILE_TAGS or base + ":dgrad" in PROFILE_TAGS):
+        with _timed(base + ":wgrad", shape):
+            call(int(accumulate) | 2)
+        with _timed(base + ":dgrad", shape):
+            call(4)
+    else:
+        with _timed(tag, shape):
+            call(int(accumulate))
     return gx.as_folded()
 
 

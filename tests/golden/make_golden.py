@@ -49,7 +49,7 @@ import core.block as rblock      # noqa: E402  (reference)
 import core.fusion as rfusion    # noqa: E402
 import core.loss as rloss        # noqa: E402
 import core.model as rmodel      # noqa: E402
-from oracle.fusion_oracle import closed_form_image, closed_form_param, closed_form_signed  # noqa: E402
+from oracle.fusion_oracle import assert_alive, closed_form_image, closed_form_param, closed_form_signed, live_param  # noqa: E402
 
 assert os.path.realpath(rblock.__file__).startswith(os.path.realpath(REF)), rblock.__file__
 torch.set_num_threads(8)
@@ -63,6 +63,29 @@ def load_closed_form(module, seed=0):
         new[k] = T(closed_form_param(i, k, tuple(v.shape), seed))
     module.load_state_dict(new)
     return module
+
+
+def load_live(module, name):
+    """the live closed-form set of NestFuse / RFN-Nest (oracle.LIVE_PARAMS): the final ReLU passes 30-60 % of the pixels"""
+    sd = module.state_dict()
+    module.load_state_dict({k: T(live_param(name, i, k, tuple(v.shape))) for i, (k, v) in enumerate(sd.items())})
+    return module
+
+
+# tensors that are zero BY DEFINITION of the case they pin (everything else must be alive, see save())
+ZERO_BY_DESIGN = {"attn_zero__y", "attn_zero__da",            # all-zero features: the clamp(min=1e-7) branch, core/fusion.py:33
+                  "c_g_grad",                                 # constant fused image: the Sobel gradient of a constant is 0
+                  "bn_eval_buf_layers.1.num_batches_tracked", # eval mode / a BatchNorm PMGI never calls: the counter stays 0
+                  "PMGI_2x32x32__buf_transfer1.1.layers.1.num_batches_tracked", "PMGI_1x19x26__buf_transfer1.1.layers.1.num_batches_tracked"}
+
+
+def save(fname, out):
+    """np.savez_compressed with a liveness gate: a fixture that is all-zero pins nothing (the round-3 NestFuse / RFN-Nest F5 cases
+    compared 0 with 0 for three rounds), so the generator refuses to write one unless the case is zero by design."""
+    for k, v in out.items():
+        if k not in ZERO_BY_DESIGN:
+            assert_alive(v, f"{fname}:{k}")
+    np.savez_compressed(os.path.join(HERE, fname), **out)
 
 
 def digest(a):
@@ -138,7 +161,7 @@ def make_f2():
     for case in "abcd":
         for k, v in loss_case(*f2_inputs(case)).items():
             out[f"{case}_{k}"] = v
-    np.savez_compressed(os.path.join(HERE, "f2_loss_grads.npz"), **out)
+    save("f2_loss_grads.npz", out)
 
 
 # ---------------------------------------------------------------- F3
@@ -169,7 +192,7 @@ def make_f3():
         out[name + "_dx"] = x.grad.numpy()
         out[name + "_dw"] = layer.layers[0].weight.grad.numpy()
         out[name + "_db"] = layer.layers[0].bias.grad.numpy()
-    np.savez_compressed(os.path.join(HERE, "f3_conv.npz"), **out)
+    save("f3_conv.npz", out)
 
 
 # ---------------------------------------------------------------- F11 (row n4: the general ConvLayer forms)
@@ -199,7 +222,7 @@ def make_f11():
         out[name + "_dx"] = x.grad.numpy()
         out[name + "_dw"] = layer.layers[0].weight.grad.numpy()
         out[name + "_db"] = layer.layers[0].bias.grad.numpy()
-    np.savez_compressed(os.path.join(HERE, "f11_general_conv.npz"), **out)
+    save("f11_general_conv.npz", out)
 
 
 # ---------------------------------------------------------------- F12 (row n4: bilinear up-sampling, DeepFuse, DBNet)
@@ -225,7 +248,7 @@ def make_f12():
                 out[f"{tag}__dp_{k}"] = digest(p.grad.numpy())
     # (seed 2: with seed 1 one pre-activation of DBNet's decode.1 at 2x32x32 lies within fp32 rounding of zero, so its ReLU mask --
     # and 1 % of the gradients behind it -- depends on the summation order of the conv that produced it)
-    np.savez_compressed(os.path.join(HERE, "f12_n4_models.npz"), **out)
+    save("f12_n4_models.npz", out)
     json.dump(manifest, open(os.path.join(HERE, "f12_manifest.json"), "w"), indent=0)
 
 
@@ -278,7 +301,7 @@ def make_f13():
                     out[f"{tag}__dp_{k}"] = digest(p.grad.numpy())
             for k, b in model.named_buffers():
                 out[f"{tag}__buf_{k}"] = digest(b.detach().numpy().astype(np.float32))
-    np.savez_compressed(os.path.join(HERE, "f13_n4_norm.npz"), **out)
+    save("f13_n4_norm.npz", out)
     json.dump(manifest, open(os.path.join(HERE, "f13_manifest.json"), "w"), indent=0)
 
 
@@ -296,7 +319,7 @@ def make_f14():
             out[tag + "__y"] = y.detach().numpy()
             for k, p in model.named_parameters():
                 out[f"{tag}__dp_{k}"] = digest(p.grad.numpy())
-    np.savez_compressed(os.path.join(HERE, "f14_n4_nested.npz"), **out)
+    save("f14_n4_nested.npz", out)
     json.dump(manifest, open(os.path.join(HERE, "f14_manifest.json"), "w"), indent=0)
 
 
@@ -334,7 +357,7 @@ def make_f15():
         for k, p in model.named_parameters():
             if p.grad is not None:   # (Res2ConvBlock never calls the dwconv it inherits from SepConvBlock)
                 out[f"{tag}__dp_{k}"] = digest(p.grad.numpy())
-    np.savez_compressed(os.path.join(HERE, "f15_n4_res2.npz"), **out)
+    save("f15_n4_res2.npz", out)
     json.dump(manifest, open(os.path.join(HERE, "f15_manifest.json"), "w"), indent=0)
 
 
@@ -415,30 +438,37 @@ def make_f4():
     y = rfusion.attention_fusion(ta, tb, "sca")
     y.backward(T(gy))
     out["attn_relu__y"], out["attn_relu__da"], out["attn_relu__db"] = y.detach().numpy(), ta.grad.numpy(), tb.grad.numpy()
-    np.savez_compressed(os.path.join(HERE, "f4_blocks.npz"), **out)
+    save("f4_blocks.npz", out)
 
 
 # ---------------------------------------------------------------- F5
-F5_CASES = [("PFNetv1", (2, 1, 32, 32)), ("PFNetv2", (2, 1, 32, 32)), ("DenseFuse", (2, 1, 32, 32)),
-            ("NestFuse", (1, 1, 32, 32)), ("RFNNest", (1, 1, 32, 32)), ("PFNetv1", (1, 1, 37, 53))]
+# (model, shape, parameter set): closed-form seed 1, or "live" = oracle.LIVE_PARAMS for the two nets that end in a ReLU
+# (core/model.py:344) -- with seed 1 that ReLU is dead on every pixel (y = 0, all gradients 0).  2x36x44 walks the odd pyramid
+# 36x44 -> 18x22 -> 9x11 -> 4x5 (Upsample._pad, core/block.py:981-991) with two samples.
+F5_CASES = [("PFNetv1", (2, 1, 32, 32), 1), ("PFNetv2", (2, 1, 32, 32), 1), ("DenseFuse", (2, 1, 32, 32), 1),
+            ("NestFuse", (1, 1, 32, 32), "live"), ("RFNNest", (1, 1, 32, 32), "live"),
+            ("NestFuse", (2, 1, 36, 44), "live"), ("RFNNest", (2, 1, 36, 44), "live"), ("PFNetv1", (1, 1, 37, 53), 1)]
 
 
 def make_f5():
     out, manifest = {}, {}
-    for name, shape in F5_CASES:
+    for name, shape, pset in F5_CASES:
         tag = f"{name}_{shape[0]}x{shape[2]}x{shape[3]}"
-        model = load_closed_form(getattr(rmodel, name)(), seed=1)
+        model = getattr(rmodel, name)()
+        model = load_live(model, name) if pset == "live" else load_closed_form(model, seed=pset)
         manifest[name] = [[k, list(v.shape)] for k, v in model.state_dict().items()]
         i1, i2 = T(closed_form_image(shape, 0.3)), T(closed_form_image(shape, 1.7))
         y = model(i1, i2)
         gy = T(closed_form_signed(shape, 0.9, 1.0))
         y.backward(gy)
         out[tag + "__y"] = y.detach().numpy()
+        if pset == "live":     # post-ReLU output: part of the mask open, part closed
+            assert_alive(out[tag + "__y"], tag + "__y", 0.3, 0.7)
         for k, p in model.named_parameters():
             out[f"{tag}__dp_{k}"] = digest(p.grad.numpy())
         if name == "DenseFuse":  # auto-encoder mode, core/model.py:43-51
             out[tag + "__y_ae"] = model(i1).detach().numpy()
-    np.savez_compressed(os.path.join(HERE, "f5_models.npz"), **out)
+    save("f5_models.npz", out)
     json.dump(manifest, open(os.path.join(HERE, "f5_manifest.json"), "w"), indent=0)
 
 
@@ -469,7 +499,7 @@ def make_f6():
         out[name + "__rows"] = np.array(rows, dtype=np.float64)
         for k, p in model.state_dict().items():
             out[f"{name}__w_{k}"] = digest(p.numpy())
-    np.savez_compressed(os.path.join(HERE, "f6_traj.npz"), **out)
+    save("f6_traj.npz", out)
 
 
 def make_f10():
@@ -485,7 +515,7 @@ def make_f10():
         out[tag + "__y"] = y.detach().numpy()
         for k, p in model.named_parameters():
             out[f"{tag}__dp_{k}"] = digest(p.grad.numpy())
-    np.savez_compressed(os.path.join(HERE, "f10_vifnet.npz"), **out)
+    save("f10_vifnet.npz", out)
     json.dump(manifest, open(os.path.join(HERE, "f10_manifest.json"), "w"), indent=0)
 
 
@@ -524,7 +554,7 @@ def make_f8():
             n = rtf.norm(patch.copy(), mode=nm)
             for mode in range(8):
                 out[f"P{P}_{tag}_m{mode}"] = np.ascontiguousarray(rtf.transform(n, mode=mode)).astype(np.float32)
-    np.savez_compressed(os.path.join(HERE, "f8_feed.npz"), **out)
+    save("f8_feed.npz", out)
 
 
 def make_f9():
@@ -558,7 +588,7 @@ def make_f9():
         loss.backward()
         out[f"tv_{mode}__loss"] = np.float64(loss.item())
         out[f"tv_{mode}__grad"] = x.grad.numpy()
-    np.savez_compressed(os.path.join(HERE, "f9_ssim_modes.npz"), **out)
+    save("f9_ssim_modes.npz", out)
 
 
 if __name__ == "__main__":

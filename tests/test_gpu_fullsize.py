@@ -14,7 +14,7 @@ import pytest
 import torch
 
 from oracle import fusion_oracle as O
-from gpu_util import close, dtype_ctx, load_closed_form, tg
+from gpu_util import close, dtype_ctx, load_closed_form, load_live, tg
 
 pytestmark = pytest.mark.gpu
 
@@ -22,8 +22,17 @@ RF = 8  # PFNetv1: 4 encoder + 4 decoder 3x3 convs -> receptive-field radius 8
 
 
 def _model(name, seed=1):
+    """closed-form seed 1 for the nets without an output activation; NestFuse / RFN-Nest end in a ReLU that seed 1 kills on every
+    pixel (the round-3 full-size tests compared zero images and zero gradients): they get the live set (oracle.LIVE_PARAMS: 53 % /
+    46 % of the pixels of a 512 x 512 uniform-random pair pass the final ReLU, measured on the reference)"""
     import core.model as M
-    return load_closed_form(getattr(M, name)(), seed).to("cuda:0")
+    m = getattr(M, name)()
+    return (load_live(m, name) if name in O.LIVE_PARAMS else load_closed_form(m, seed)).to("cuda:0")
+
+
+def _assert_alive_image(y, what):
+    frac = float((y > 0).float().mean())
+    assert float(y.abs().max()) > 0 and 0.2 <= frac <= 0.8, f"{what}: {frac:.3f} of the fused pixels are positive -- the test would be vacuous"
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
@@ -92,6 +101,7 @@ def test_nest_512_samples_do_not_interact(name):
         m = _model(name)
         both = m(i1, i2)
         assert bool(torch.isfinite(both).all())
+        _assert_alive_image(both, name)
         for b in range(2):
             one = m(i1[b:b + 1].contiguous(), i2[b:b + 1].contiguous())
             assert torch.equal(both[b:b + 1], one), f"sample {b}: max diff {float((both[b:b + 1] - one).abs().max()):.3e}"
@@ -114,9 +124,13 @@ def test_nest_512_backward_is_mean_of_per_sample_gradients(name):
             t, gr = _loss_grads(m, i1[b:b + 1].contiguous(), i2[b:b + 1].contiguous())
             tots.append(t)
             acc = gr if acc is None else {k: acc[k] + v for k, v in gr.items()}
+        with torch.no_grad():
+            _assert_alive_image(m(i1, i2), name)
     assert np.isfinite(tot) and abs(tot - np.mean(tots)) <= 1e-5 * abs(tot)
+    gnorm = float(torch.sqrt(sum((g.double() ** 2).sum() for g in full.values())))
+    assert gnorm > 1e-3, f"gradient norm {gnorm}: nothing flows"
     for k in full:
-        assert bool(torch.isfinite(full[k]).all()), k
+        assert bool(torch.isfinite(full[k]).all()) and float(full[k].abs().max()) > 0, k       # every parameter gets a gradient
         close(full[k].cpu().numpy(), (acc[k] / 2).cpu().numpy(), 2e-3, k)
 
 

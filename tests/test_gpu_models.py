@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from oracle import fusion_oracle as O
-from gpu_util import G, close, close_digest, dtype_ctx, load_closed_form, rel_err, tg
+from gpu_util import G, close, close_digest, dtype_ctx, load_closed_form, load_live, rel_err, tg
 
 pytestmark = pytest.mark.gpu
 
@@ -180,13 +180,10 @@ def test_cpu_tensors_fail_loudly():
         m(torch.zeros(1, 1, 16, 16), torch.zeros(1, 1, 16, 16))
 
 
-LAYERWISE = [("PFNetv2", (2, 1, 32, 32)), ("NestFuse", (1, 1, 32, 32)), ("RFNNest", (1, 1, 32, 32))]
-
-
-@pytest.mark.parametrize("name,shape", LAYERWISE, ids=[n for n, _ in LAYERWISE])
-def test_layerwise_models_fp32_vs_golden(name, shape):
-    """PFNetv2 / NestFuse / RFN-Nest: every ConvLayer (k=1 and k=3, channel counts 2..384) through the HIP
-    kernels, glued layer by layer; forward + parameter-gradient digests vs the reference (golden F5)."""
+def test_pfnetv2_layerwise_fp32_vs_golden():
+    """PFNetv2 against the reference (golden F5): forward + parameter-gradient digests.  (NestFuse / RFN-Nest: tests/test_gpu_nest.py,
+    on the live parameter set -- with closed-form seed 1 their final ReLU is dead and the fixtures were all-zero.)"""
+    name, shape = "PFNetv2", (2, 1, 32, 32)
     ref = np.load(os.path.join(G, "f5_models.npz"))
     man = json.load(open(os.path.join(G, "f5_manifest.json")))
     tag = f"{name}_{shape[0]}x{shape[2]}x{shape[3]}"
@@ -237,21 +234,6 @@ def test_pfnetv2_engine_ragged_vs_oracle_and_layerwise(dtype, ytol, gtol):
                 close(m(i1).cpu().numpy(), om.forward(P, i1n, None), 2e-4, "auto-encoder")
 
 
-def test_nestfuse_bf16_mfma_runs_close():
-    """bf16 / MFMA kernels on NestFuse's odd channel counts (8, 56, 88, 120, 136, 152, 184 ...) and 1x1 convs."""
-    shape = (1, 1, 32, 32)
-    om = O.NestFuse()
-    P = om.init_params(seed=1)
-    i1n, i2n = O.closed_form_image(shape, 0.3), O.closed_form_image(shape, 1.7)
-    y_or = om.forward(P, i1n, i2n)
-    with dtype_ctx("bf16", "mfma"):
-        m = _model("NestFuse", 1)
-        with torch.no_grad():
-            y = m(tg(i1n), tg(i2n))
-        torch.cuda.synchronize()
-        close(y.cpu().numpy(), y_or, 5e-2, "imgf")
-
-
 @pytest.mark.parametrize("impl,gtol", [("valu", 1e-3), ("auto", 6e-2)], ids=["fp32-fma", "x3"])
 @pytest.mark.parametrize("name", ["NestFuse", "RFNNest"])
 def test_nest_engine_odd_size_vs_oracle(name, impl, gtol):
@@ -266,12 +248,14 @@ def test_nest_engine_odd_size_vs_oracle(name, impl, gtol):
     models without pooling."""
     shape = (2, 1, 36, 44)
     om = O.MODELS[name]()
-    P = om.init_params(seed=3)
+    P = om.init_params_live()          # (oracle.LIVE_PARAMS: about half of the output pixels pass the final ReLU)
     i1n, i2n, gn = O.closed_form_image(shape, 0.3), O.closed_form_image(shape, 1.7), O.closed_form_signed(shape, 0.9, 1.0)
     y_or = om.forward(P, i1n, i2n)
+    O.assert_alive(y_or, name, 0.3, 0.7)
     G_or = om.backward(P, gn)
     with dtype_ctx("fp32", impl):
-        m = _model(name, 3)
+        import core.model as M
+        m = load_live(getattr(M, name)(), name).to("cuda:0")
         assert m._make_engine() is not None
         y = m(tg(i1n), tg(i2n))
         y.backward(tg(gn))
@@ -301,7 +285,8 @@ def test_fusion_functions_hip_vs_golden():
         y = F.attention_fusion(ta, tb, "sca")
         y.backward(tg(gy))
         assert float(y.abs().max()) == 0.0
-        close(ta.grad.cpu().numpy(), ref["attn_zero__da"], 1e-5, "zero da")
+        close(ta.grad.cpu().numpy(), ref["attn_zero__da"], 1e-5, "zero da", allow_zero=True)     # (zero by design: the clamp branch)
+        close(tb.grad.cpu().numpy(), ref["attn_zero__db"], 1e-5, "zero db")
         for mode in ("sum", "mean", "max"):
             ta, tb = tg(a).requires_grad_(True), tg(b).requires_grad_(True)
             y = F.element_fusion(ta, tb, mode)

@@ -73,3 +73,40 @@ def test_train_whole_images_then_test(dataset):
 def test_train_patches_on_device_feed(dataset):
     out = _run("train.py", "--data", DATA, "--bs", "8", "--epoch", "1", "--model", "DenseFuse", "--dtype", "bf16")
     assert "training done" in out
+
+
+def test_bench_two_ranks_gloo_one_device():
+    """bench.py's N > 1 plumbing end to end before the driver's first SCALE run does it: `--gpus 2` without a launcher environment starts
+    a child torch.distributed.run (free rendezvous port), both ranks share cuda:0 over gloo (the only backend that allows it: RCCL wants
+    one device per rank, and this box has one), parameters are broadcast, gradients all-reduced early + late, and rank 0's JSON line is
+    the LAST thing on stdout (the other ranks' stdout goes to stderr)."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--one-device", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-parity-path"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, f"bench.py --gpus 2 failed:\n{r.stdout[-3000:]}\n{r.stderr[-3000:]}"
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    out = json.loads(lines[-1])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 64 and out["config"]["parallelism"] == "dp2" and out["config"]["backend"] == "gloo"
+    assert out["scaling"] == "weak" and out["steps"] == 3 and out["value"] > 0
+    assert np.isfinite(out["final_loss"]) and 0.0 < out["final_loss"] < 10.0
+    assert out["roofline"] is not None and set(out["roofline_kernels"]) == {"fwd", "dgrad", "wgrad"}
+    assert out["parity_path"] is None and out["cpu_baseline"] is None       # N = 1 only
+
+
+def test_bench_single_gpu_line_has_the_contract_fields():
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--batch", "4", "--size", "64", "--cpu-sample", "2",
+                        "--parity-steps", "2"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, f"bench.py failed:\n{r.stdout[-3000:]}\n{r.stderr[-3000:]}"
+    out = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline", "step_frac_of_ideal"):
+        assert k in out, k
+    rf = out["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert rf["step_share"] == max(v["step_share"] for v in out["roofline_kernels"].values())
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["steps"] >= 3 and cb["cores"] <= 32 and cb["value"] >= cb["median_value"] > 0
+    pp = out["parity_path"]
+    assert pp["rel_err_vs_oracle"] < 1e-3 and pp["grad_rel_err_vs_oracle"] < 1e-3 and len(pp["oracle_samples"]) == 2
+    assert pp["roofline"]["peak"] == 157.0 and pp["roofline"]["products_per_tap"] == 3 and pp["roofline"]["executed_mfma_tflops"] > pp["roofline"]["achieved"]

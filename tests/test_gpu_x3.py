@@ -146,6 +146,47 @@ def test_bwd_wide_fp32_equals_wgrad_plus_folded_dgrad(cin, cout, n, h, w, ks):
         assert torch.equal(gx_a.buf, gx_b.buf), f"mask {mask:#x}: input gradient"
 
 
+@pytest.mark.parametrize("cin,cout", [(72, 64), (68, 32), (136, 64)])
+def test_bwd_wide_fp32_exact_sign_buffer(cin, cout):
+    """the fp32 bwd_wide dgrad read the sign map one 32-channel group too far for cin % 64 in (0, 32] (72, 136, ...; 68 also
+    has cin % 8 != 0), past a buffer sized exactly like the x3 layout ([n][ceil(cb / 4)][h][w] dwords).  The group index is clamped now:
+    the call accepts a buffer of exactly that size (the last bytes of an allocation), gives the bits of the two separate calls, and
+    leaves the bytes behind the map untouched."""
+    from mmif import tensor as T
+    from mmif._lib import F32, IMPL_X3
+    n, h, w, ks = 2, 20, 36, 3
+    torch.manual_seed(cin)
+    x = T.BT.alloc(n, cin, h, w, torch.float32, DEV); x.buf.normal_()
+    x.buf[x.buf.abs() < 0.3] = 0.0
+    if cin % 8:
+        x.buf.view(n, -1, h, w, 8)[:, -1, :, :, cin % 8:] = 0.0
+    gy = T.BT.alloc(n, cout, h, w, torch.float32, DEV, halo=1, zero=True)
+    gy.buf[:, :, 1:-1, 1:-1].normal_()
+    gy = gy.as_folded()
+    wt = torch.randn(cout, cin, ks, ks, device=DEV) * 0.05
+    pk = T.PackedWeights(cout, cin, ks, DEV, F32); pk.pack(wt)
+    ws = torch.empty(T.wgrad_workspace_bytes(cin, cout, ks) // 4 + 1, dtype=torch.float32, device=DEV)
+    if not T.bwd_wide_supported(cin, cout, ks, torch.float32):
+        pytest.skip("shape not on the sign-map path")
+    exact = n * ((x.cb + 3) // 4) * h * w * 4
+    guard = 4096
+    store = torch.full((exact + guard,), 0xa5, dtype=torch.uint8, device=DEV)
+    mask = (1 << x.cb) - 1
+    gx_a = T.BT.alloc(n, cin, h, w, torch.float32, DEV, halo=1, zero=True)
+    gx_b = T.BT.alloc(n, cin, h, w, torch.float32, DEV, halo=1, zero=True)
+    dw_a, db_a = torch.zeros_like(wt), torch.zeros(cout, device=DEV)
+    dw_b, db_b = torch.zeros_like(wt), torch.zeros(cout, device=DEV)
+    T.conv_wgrad(x, gy, dw_a, db_a, cin, cout, ks, ws, False, IMPL_X3)
+    T.conv_dgrad(gy, wt, x, gx_a, cin, cout, ks, mask, 0, pk, IMPL_X3, fold=True)
+    T.conv_bwd_wide(gy, x, gx_b, dw_b, db_b, cin, cout, ks, pk, mask, ws, store[:exact])
+    torch.cuda.synchronize()
+    assert torch.equal(dw_a, dw_b) and torch.equal(db_a, db_b)
+    assert torch.equal(gx_a.buf, gx_b.buf) and float(gx_a.buf.abs().max()) > 0
+    assert bool((store[exact:] == 0xa5).all()), "bytes behind the sign map were written"
+    with pytest.raises(RuntimeError):      # one byte short is refused
+        T.conv_bwd_wide(gy, x, gx_b, dw_b, db_b, cin, cout, ks, pk, mask, ws, store[:exact - 1])
+
+
 def test_x3_forward_vs_fp64_definition(fwd_pieces):
     """x3 forward on a 128 -> 128 layer against torch's fp64 conv on the CPU (reflect padding): the error of the split (2 pieces: 2^-17
     relative per product; 3 pieces: fp32 accumulation only) next to the fp32 FMA kernel's own rounding"""

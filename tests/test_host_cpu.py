@@ -5,6 +5,7 @@ import ctypes
 import json
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -257,3 +258,32 @@ def test_make_logger_layout(tmp_path):
         h.flush()
         logger.removeHandler(h)
     assert "hello" in open(os.path.join(log_dir, "train.log")).read()
+
+
+def test_bench_self_launch_refuses_a_smaller_box(monkeypatch):
+    """bench.py --gpus N on a box with fewer GPUs must not report an N-GPU line: self_launch exits with the "refusing" message before it
+    starts anything (this container has 0 GPUs); the rendezvous port comes from the kernel (bind to port 0), not from the pid."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    args = bench.parse()
+    import torch
+    if torch.cuda.device_count() >= 8:
+        pytest.skip("this box really has 8 GPUs")
+    with pytest.raises(SystemExit) as ei:
+        bench.self_launch(args)
+    assert "refusing" in str(ei.value) and "--gpus 8" in str(ei.value)
+    with pytest.raises(SystemExit) as ei:       # the whole entry point takes that exit too
+        bench.main()
+    assert "refusing" in str(ei.value)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--one-device"])     # debugging aid: gloo only
+    with pytest.raises(SystemExit) as ei:
+        bench.main()
+    assert "gloo" in str(ei.value)
+    p1, p2 = bench.free_port(), bench.free_port()
+    assert 1024 < p1 < 65536 and 1024 < p2 < 65536
+    # SURVEY 8(d)'s ideal for the headline config: 1 / max(42.8 us, 45.8 us) = 21.8 k pairs/s
+    assert abs(bench.ideal_pairs_per_s("PFNetv1", 256, 256, "bf16") - 21850) < 100

@@ -239,26 +239,45 @@ def test_f4_fusion_functions():
 
 
 # ------------------------------------------------------------------ F5
-F5_CASES = [("PFNetv1", (2, 1, 32, 32)), ("PFNetv2", (2, 1, 32, 32)), ("DenseFuse", (2, 1, 32, 32)),
-            ("NestFuse", (1, 1, 32, 32)), ("RFNNest", (1, 1, 32, 32)), ("PFNetv1", (1, 1, 37, 53))]
+# parameter set: closed-form seed 1, or "live" (oracle.LIVE_PARAMS) for the nets whose last layer is a ReLU -- seed 1 kills it everywhere
+F5_CASES = [("PFNetv1", (2, 1, 32, 32), 1), ("PFNetv2", (2, 1, 32, 32), 1), ("DenseFuse", (2, 1, 32, 32), 1),
+            ("NestFuse", (1, 1, 32, 32), "live"), ("RFNNest", (1, 1, 32, 32), "live"),
+            ("NestFuse", (2, 1, 36, 44), "live"), ("RFNNest", (2, 1, 36, 44), "live"), ("PFNetv1", (1, 1, 37, 53), 1)]
 
 
-@pytest.mark.parametrize("name,shape", F5_CASES, ids=[f"{n}-{s[2]}x{s[3]}" for n, s in F5_CASES])
-def test_f5_models(name, shape):
+@pytest.mark.parametrize("name,shape,pset", F5_CASES, ids=[f"{n}-{s[0]}x{s[2]}x{s[3]}" for n, s, _ in F5_CASES])
+def test_f5_models(name, shape, pset):
     ref = np.load(os.path.join(G, "f5_models.npz"))
     man = json.load(open(os.path.join(G, "f5_manifest.json")))
     tag = f"{name}_{shape[0]}x{shape[2]}x{shape[3]}"
     m = O.MODELS[name]()
     assert [[k, list(s)] for k, s in m.param_shapes().items()] == man[name]
-    P = m.init_params(seed=1)
+    P = m.init_params_live() if pset == "live" else m.init_params(seed=pset)
     i1, i2 = O.closed_form_image(shape, 0.3), O.closed_form_image(shape, 1.7)
     y = m.forward(P, i1, i2)
+    if pset == "live":
+        O.assert_alive(ref[tag + "__y"], tag, 0.3, 0.7)
     close(y, ref[tag + "__y"], 5e-5, "y")
     Gd = m.backward(P, O.closed_form_signed(shape, 0.9, 1.0))
     for k in P:
         close_digest(Gd[k], ref[f"{tag}__dp_{k}"], 1e-4, k)
     if name == "DenseFuse":
         close(m.forward(P, i1), ref[tag + "__y_ae"], 5e-5, "auto-encoder")
+
+
+def test_no_golden_fixture_is_all_zero():
+    """a fixture that is all-zero pins nothing: every tensor of every committed fixture is alive except the ones that are zero by the
+    definition of their case (the list the generator's save() gate uses)"""
+    import glob
+    zero_by_design = {"attn_zero__y", "attn_zero__da", "c_g_grad", "bn_eval_buf_layers.1.num_batches_tracked",
+                      "PMGI_2x32x32__buf_transfer1.1.layers.1.num_batches_tracked", "PMGI_1x19x26__buf_transfer1.1.layers.1.num_batches_tracked"}
+    files = sorted(glob.glob(os.path.join(G, "*.npz")))
+    assert len(files) >= 13
+    for f in files:
+        d = np.load(f)
+        for k in d.files:
+            if k not in zero_by_design:
+                O.assert_alive(d[k], f"{os.path.basename(f)}:{k}")
 
 
 # ------------------------------------------------------------------ F6

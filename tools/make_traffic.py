@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""profiles/r03_traffic.json from the two TCC counter passes of tools/prof_pmc.sh (run on the GPU box, repo root):
+"""profiles/r04_traffic.json from the two TCC counter passes of tools/prof_pmc.sh (run on the GPU box, repo root):
     tools/make_traffic.py <tag> > gpurun_out/traffic_<tag>.json
-HBM bytes per launch of the two roofline kernels of the default bench (PFNetv1 train B=32 256x256 bf16): decode.0's forward
-(conv_dma_kernel<false, 0>: decode.0 and decode.1 alternate per step; decode.0 is the launch with the larger WRITE_SIZE) and the streaming
+HBM bytes per launch of the roofline kernels of the default bench (PFNetv1 train B=32 256x256 bf16): decode.0's forward
+(conv_dma_kernel<false, 0>: decode.0 and decode.1 alternate per step; decode.0 is the launch with the larger WRITE_SIZE), its dgrad and
+weight gradient (conv_dma_kernel<true, 2> / wgrad_dma_kernel: decode.0 is the launch with the larger FETCH_SIZE) and the streaming
 encoder forward.  gfx950: FETCH_SIZE tallies the 128-byte requests of 16-byte-per-lane streaming reads as 64 bytes (MI355X_MICROARCH.md,
 HBM section) -> read bytes = 2 x FETCH_SIZE; WRITE_SIZE as counted.  The file is stamped with the sha256 of the library the passes ran
 on: bench.py prints `traffic` only for that build."""
@@ -36,13 +37,26 @@ fd, wd = per_dispatch("FETCH_SIZE", "conv_dma_kernel<false"), per_dispatch("WRIT
 w_even, w_odd = wd[0::2], wd[1::2]
 first_is_d0 = sum(w_even) >= sum(w_odd)
 f0, w0 = (fd[0::2], w_even) if first_is_d0 else (fd[1::2], w_odd)
+def pick_larger_fetch(sub):
+    f, w = per_dispatch("FETCH_SIZE", sub), per_dispatch("WRITE_SIZE", sub)
+    if len(f) < 2 or len(f) != len(w):
+        return None
+    first = sum(f[0::2]) >= sum(f[1::2])
+    return (f[0::2], w[0::2]) if first else (f[1::2], w[1::2])
+
+
+dg, wg = pick_larger_fetch("conv_dma_kernel<true"), pick_larger_fetch("wgrad_dma_kernel")
 fe, we = per_dispatch("FETCH_SIZE", "enc_stream_fwd_kernel"), per_dispatch("WRITE_SIZE", "enc_stream_fwd_kernel")
 B, S = 32, 256
 out = {"workload": "PFNetv1 train B=32 256x256 bf16", "lib_sha256": h,
-       "command": f"tools/prof_pmc.sh {tag}: rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separately, WRITE_SIZE) --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline",
+       "command": f"tools/prof_pmc.sh {tag}: rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separately, WRITE_SIZE) --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity-path",
        "kernels": {
            "decode.0:fwd": entry("conv_dma_kernel<false, 0> 128->128 k3 (decode.0 forward)", f0, w0, float(B) * S * S * 256 * 2),
            "encode:fwd": entry("enc_stream_fwd_kernel, both encoder branches", fe, we, float(B) * S * S * 2 * (4 + 64 * 2),
                                "; the image loads are 4 B/lane (uncalibrated width): counted like the 16-B reads, an upper bound"),
        }}
+if dg:
+    out["kernels"]["decode.0:dgrad"] = entry("conv_dma_kernel<true, 2> 128->128 k3 (decode.0 input gradient, sign bytes)", dg[0], dg[1], float(B) * S * S * 256 * 2)
+if wg:
+    out["kernels"]["decode.0:wgrad"] = entry("wgrad_dma_kernel 128->128 k3 (decode.0 weight gradient; leaves the sign bytes)", wg[0], wg[1], float(B) * S * S * 256 * 2)
 print(json.dumps(out, indent=1))
