@@ -43,14 +43,15 @@ PEAK_MATRIX_FP32 = 157e12
 PEAK_HBM = 8.0e12
 
 
-def ideal_pairs_per_s(model, h, w, dtype):
-    """SURVEY 8(d)'s "ideal pairs/s/GPU": 1 / max(t_MFMA, t_HBM) of the step's algorithmic flops and bytes at the peaks above (fp32 storage
-    doubles the bytes; flops priced at the bf16 matrix peak either way: the fp32 path issues half-precision MFMA products)"""
+def ideal_pairs_per_s(model, h, w, dtype, products=1):
+    """SURVEY 8(d)'s "ideal pairs/s/GPU": 1 / max(t_MFMA, t_HBM) of the step's algorithmic flops and bytes at the peaks above.  fp32
+    storage doubles the bytes; `products` = half-precision MFMA products the path issues per algorithmic product (3 on the split-operand
+    fp32 path), priced at the bf16 matrix peak"""
     if model not in MODEL_WORK_TRAIN:
         return None
     fl, by, side = MODEL_WORK_TRAIN[model]
     scale = (h * w) / float(side * side)
-    return 1.0 / max(fl * scale / PEAK_MFMA_BF16, by * scale * (2 if dtype == "fp32" else 1) / PEAK_HBM)
+    return 1.0 / max(products * fl * scale / PEAK_MFMA_BF16, by * scale * (2 if dtype == "fp32" else 1) / PEAK_HBM)
 
 
 def parse():
@@ -274,12 +275,12 @@ def parity_leg(args, dev, img1, img2):
         samples = [oracle_error_sample(args.model, shp, dev, (l_ssim, l_pix, l_grad)) for shp in ((2, 1, 64, 64), (1, 1, 37, 53))]
         mode = lib.mmif_get_x3_forward_pieces()
         fwd = {16: "3 products of scaled fp16 pieces", 3: "6 products of bf16 pieces", 2: "3 products of bf16 pieces"}[mode]
-        ideal = ideal_pairs_per_s(args.model, S, Wd, "fp32")
+        ideal = ideal_pairs_per_s(args.model, S, Wd, "fp32", products=3)
         dom = max(roofs.values(), key=lambda r: r["step_share"]) if roofs else None
         return {"dtype": f"fp32 storage; 3x3 / 1x1 layers as split-operand MFMA products (forward: {fwd}; backward: 3 products of bf16 pieces), fp32 accumulate",
                 "value": value, "unit": "image-pairs/s", "ms_per_step": dt / args.parity_steps * 1e3, "steps": args.parity_steps,
-                "step_frac_of_ideal": value / (ideal / 3.0) if ideal else None,
-                "ideal_note": "ideal = SURVEY 8(d) max(t_MFMA, t_HBM) with 3 half-precision products per algorithmic product at the bf16 MFMA peak and fp32 bytes",
+                "step_frac_of_ideal": value / ideal if ideal else None, "ideal_pairs_per_s_per_gpu": ideal,
+                "ideal_note": "ideal = SURVEY 8(d) 1 / max(t_MFMA, t_HBM) with 3 half-precision products per algorithmic product at the bf16 MFMA peak and fp32 bytes",
                 "roofline": dom, "roofline_kernels": roofs,
                 "rel_err_vs_oracle": max(e["rel_err_vs_oracle"] for e in samples), "loss_abs_err_vs_oracle": max(e["loss_abs_err_vs_oracle"] for e in samples),
                 "grad_rel_err_vs_oracle": max(e["grad_rel_err_vs_oracle"] for e in samples), "oracle_samples": samples,
@@ -465,7 +466,7 @@ def main():
                             "achieved": nbytes / (ms * 1e-3) / 1e9,
                             "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": nbytes / (ms * 1e-3) / PEAK_HBM, "avg_launch_ms": ms,
                             "launches": len(evh), "traffic": ent["hbm_bytes_per_launch"] if ent else None, "traffic_source": src, "algorithmic_bytes": nbytes}
-        ideal = ideal_pairs_per_s(args.model, S, Wd, args.dtype) if args.mode == "train" else None
+        ideal = ideal_pairs_per_s(args.model, S, Wd, args.dtype, 3 if args.dtype == "fp32" else 1) if args.mode == "train" else None
         out = {
             "metric": "image-pairs/sec at 256x256, PFNet train step" if args.mode == "train" else f"image-pairs/sec at {Wd}x{S}, {args.model} inference", "value": value, "unit": "image-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,

@@ -459,7 +459,11 @@ def make_f5():
         manifest[name] = [[k, list(v.shape)] for k, v in model.state_dict().items()]
         i1, i2 = T(closed_form_image(shape, 0.3)), T(closed_form_image(shape, 1.7))
         y = model(i1, i2)
-        gy = T(closed_form_signed(shape, 0.9, 1.0))
+        # upstream gradient: a random-sign tensor for the seed-1 cases; the live cases take a smooth positive one (as a loss gives): with
+        # random signs every parameter gradient is a sum of ~3000 cancelling terms, and ONE ReLU decision taken the other way on a
+        # pre-activation within rounding of zero -- by either fp32 implementation -- moves it by 1 / sqrt(3000) = 2 % (measured on the HIP
+        # kernels at 2x36x44: 9e-3 on decode.DB1_3 in BOTH kernel families, 1e-6 on every other case)
+        gy = T(closed_form_image(shape, 0.9)) if pset == "live" else T(closed_form_signed(shape, 0.9, 1.0))
         y.backward(gy)
         out[tag + "__y"] = y.detach().numpy()
         if pset == "live":     # post-ReLU output: part of the mask open, part closed

@@ -54,7 +54,8 @@ def test_loss_grads_vs_reference_autograd(case):
     rt = 5e-3 if case == "c" else 3e-4  # case c: sigma_f^2 == 0, the reference's own fp32 gradient is ill-conditioned
     for l, key, tol in ((a, "g_ssim", rt), (b, "g_pixel", 1e-5), (c, "g_grad", 1e-5)):
         g, = torch.autograd.grad(l, tf, retain_graph=True)
-        close(g.cpu().numpy(), ref[f"{case}_{key}"], tol, key)
+        # (case c, g_grad: the Sobel gradient of a constant fused image is zero by design -- the engine's must be exactly zero too)
+        close(g.cpu().numpy(), ref[f"{case}_{key}"], tol, key, allow_zero=(case == "c" and key == "g_grad"))
     g, = torch.autograd.grad(a + b + c, tf)
     close(g.cpu().numpy(), ref[f"{case}_g_total"], rt, "g_total")
     assert abs(l2(t1, t2, tf, mode='avg').item() - ref[f"{case}_l_pixel_avg"]) < 1e-7

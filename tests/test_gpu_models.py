@@ -234,22 +234,19 @@ def test_pfnetv2_engine_ragged_vs_oracle_and_layerwise(dtype, ytol, gtol):
                 close(m(i1).cpu().numpy(), om.forward(P, i1n, None), 2e-4, "auto-encoder")
 
 
-@pytest.mark.parametrize("impl,gtol", [("valu", 1e-3), ("auto", 6e-2)], ids=["fp32-fma", "x3"])
+@pytest.mark.parametrize("impl,gtol", [("valu", 1e-3), ("auto", 1e-3)], ids=["fp32-fma", "x3"])
 @pytest.mark.parametrize("name", ["NestFuse", "RFNNest"])
 def test_nest_engine_odd_size_vs_oracle(name, impl, gtol):
     """Odd pyramid sizes (36x44 -> 18x22 -> 9x11 -> 4x5): the up-sampled 8x10 map is reflect-padded to 9x11
-    (core/block.py:981-991); fused engine (HIP pool / upsample / attention / RFN adds) vs the CPU oracle, 3x3 layers on the fp32 FMA
-    kernels and on the split-bf16 matrix-pipe kernels (the 1x1 layers are fp32 FMA in both).  The gradient bar is the flip-noise floor of
-    this small case -- the pyramid ends in 4 x 5 maps, where max-pool winners and ReLU signs decided on near ties move a gradient by
-    percents whichever fp32-grade forward made the decision (the x3 and the FMA kernels, whose activations agree to 1e-6, differ by up
-    to 3e-2 on CB3_0's gradients here, and the numpy oracle's own BLAS summation order changes with the host's core count): 1e-3 held by
-    the FMA kernels; 5.6e-3 ... 3.1e-2 measured on the x3 kernels on different boxes, held to 6e-2 -- a smoke bound; what pins the x3
-    path is the fused image (2e-4 here, on both), the per-kernel tests at 3e-5 / 2e-6 (tests/test_gpu_x3.py) and the goldens of the
-    models without pooling."""
+    (core/block.py:981-991); fused engine (HIP pool / upsample / attention / RFN adds) vs the CPU oracle on the live parameter set, every
+    parameter gradient element by element (the golden test holds digests), 3x3 layers on the fp32 FMA kernels and on the split-operand
+    matrix-pipe kernels.  Smooth positive upstream gradient: with round 3's random-sign gradient a parameter gradient was a sum of
+    ~3000 cancelling terms and ONE ReLU decision on a pre-activation within rounding of zero moved it by 1-3 % in either family (a 6e-2
+    "smoke bound" then); now such a flip costs 1 / 3000 and both families are held to 1e-3."""
     shape = (2, 1, 36, 44)
     om = O.MODELS[name]()
     P = om.init_params_live()          # (oracle.LIVE_PARAMS: about half of the output pixels pass the final ReLU)
-    i1n, i2n, gn = O.closed_form_image(shape, 0.3), O.closed_form_image(shape, 1.7), O.closed_form_signed(shape, 0.9, 1.0)
+    i1n, i2n, gn = O.closed_form_image(shape, 0.3), O.closed_form_image(shape, 1.7), O.closed_form_image(shape, 0.9)   # (smooth positive gy)
     y_or = om.forward(P, i1n, i2n)
     O.assert_alive(y_or, name, 0.3, 0.7)
     G_or = om.backward(P, gn)
