@@ -282,10 +282,13 @@ def test_nest_models_bf16_vs_bf16_storage_oracle(name, shape):
     stores them) sits 4.4-8e-2 of max|y| from its fp32 run on the fused image and 1.6-3 % (median over parameters, relative L2; up to
     17 % on RFN-Nest's first layers) on the gradients -- up to 20 layers of 0.4 % roundings, three max-pools and a ReLU per layer that
     turn a rounding into a decision -- and two bf16 runs with different fp32 summation orders (engine, emulation) decorrelate the same
-    way.  So the engine is held to the emulation AND to the fp32 oracle within that noise: image max error 9e-2 / relative L2 8e-2,
-    every parameter gradient cosine >= 0.95 and relative L2 <= 0.35, median relative L2 <= 8e-2, the output's ReLU mask equal on
-    >= 96 % of the pixels.  A plumbing error (wrong slot, view, permuted weight, missing contribution) is O(1) on all of these; the
-    kernels themselves are pinned bit-tight above and in tests/test_gpu_conv.py."""
+    way on the fused image (its last layer sums 64 cancelling terms: a 0.4 % rounding of x1_3 is 4 % of max|y|).  The GRADIENTS are the
+    sharp check: against the emulation the engine measures 1e-3 ... 5e-3 median relative L2 over the parameters (worst 2.1e-2, cosine
+    >= 0.9998) -- held to median 1.5e-2, every parameter relative L2 <= 6e-2 and cosine >= 0.995; against the fp32 oracle to the
+    emulation's own distance (every parameter cosine >= 0.95 and relative L2 <= 0.35, median <= 8e-2).  Fused image: max error 9e-2 /
+    relative L2 8e-2 of both (measured 2.8-5.6e-2 / 0.9-4.9e-2 vs the emulation), ReLU mask of the output equal on >= 96 % of the
+    pixels.  A plumbing error (wrong slot, view, permuted weight, missing contribution) is O(1) on all of these; the kernels themselves
+    are pinned bit-tight above and in tests/test_gpu_conv.py."""
     om = O.MODELS[name]()
     P = om.init_params_live()
     i1n, i2n, gn = O.closed_form_image(shape, 0.3), O.closed_form_image(shape, 1.7), O.closed_form_image(shape, 0.9)
@@ -313,9 +316,10 @@ def test_nest_models_bf16_vs_bf16_storage_oracle(name, shape):
         for k, g in grads.items():
             O.assert_alive(Gr[k], k)
             c, l2 = _cos(g, Gr[k]), _rel_l2(g, Gr[k])
-            assert c >= 0.95 and l2 <= 0.35, f"{k} vs {what}: cosine {c:.4f}, relative L2 {l2:.3e}"
+            emu = what.startswith("bf16")
+            assert c >= (0.995 if emu else 0.95) and l2 <= (6e-2 if emu else 0.35), f"{k} vs {what}: cosine {c:.4f}, relative L2 {l2:.3e}"
             l2s.append(l2)
             worst_cos = min(worst_cos, (k, c), key=lambda t: t[1])
-        assert np.median(l2s) <= 8e-2, (what, np.median(l2s))
+        assert np.median(l2s) <= (1.5e-2 if what.startswith("bf16") else 8e-2), (what, np.median(l2s))
         rep.append(f"vs {what}: imgf max {ey:.2e} l2 {l2y:.2e}; gradients median l2 {np.median(l2s):.2e} max l2 {max(l2s):.2e} min cos {worst_cos[1]:.4f} ({worst_cos[0]})")
     print(f"{name} {shape}: " + " | ".join(rep))
