@@ -458,6 +458,9 @@ void mmif_debug_set_trace(void* device_buf);
 /* kernel-generation switch for cross-checks: 1 (default, also $MMIF_CONV_DMA) = DMA-staged conv / wgrad kernels where they apply,
  * 0 = the register-staged kernels everywhere. */
 void mmif_debug_set_conv_dma(int32_t mode);
+/* 1 (default, also $MMIF_CONV1X1_STREAM) = bf16 1x1 layers (forward, dgrad without an accumulate operand) on the streaming kernel of
+ * csrc/conv1x1.hip; 0 = the register-staged conv_mfma_kernel<1, ...>.  Bit-identical results either way. */
+void mmif_debug_set_conv1x1_stream(int32_t mode);
 
 #ifdef __cplusplus
 }

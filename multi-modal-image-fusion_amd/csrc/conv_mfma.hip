@@ -2174,6 +2174,9 @@ bool conv_dgrad_onto_supported(int ks, int cin, int cout, const TV& tin, const T
 // told (dgrad): accumulate onto THAT tensor's values instead of tout's own; only the thin asynchronous kernel implements it -- the
 // call fails (MMIF_EINVAL) when the layer / shape would take another kernel (conv_dgrad_onto_supported tells beforehand)
 bool conv_dgrad_onto_supported(int ks, int cin, int cout, const TV& tin, const TV& tout);
+bool conv1x1_stream_ok(bool dgrad, const TV& tin, const TV& tout, const TV& tmask, int n_out, int m16p, uint64_t mask_bits, uint64_t accum_bits);   // conv1x1.hip
+int conv1x1_stream(bool dgrad, const TV& tin, const TV& tout, const TV& tmask, const void* wpk, const float* bias, int n_out, int m16p, int relu,
+                   uint64_t mask_bits, hipStream_t st);
 int conv_mfma(bool dgrad, int ks, const TV& tin, const TV& tout, const TV& tmask, const void* w_packed, const float* bias,
               int cin, int cout, int relu, uint64_t mask_bits, uint64_t accum_bits, hipStream_t st, bool fold, bool* folded, const TV* told) {
     if (folded != nullptr) *folded = false;
@@ -2181,6 +2184,12 @@ int conv_mfma(bool dgrad, int ks, const TV& tin, const TV& tout, const TV& tmask
     const int mf = pick_mf(n_out);
     init_modes();
     const int org = (dgrad && fold && folded != nullptr && ks == 3 && g_fuse_fold == 1 && tout.halo == 1 && tout.h >= 4 && tout.w >= 4) ? 1 : 0;
+    // 1x1 layers: the streaming kernel (csrc/conv1x1.hip: weights resident in LDS, B fragments straight from global memory)
+    if (ks == 1 && told == nullptr) {
+        const int m16p = n_mblocks(n_out) * mf * 16;
+        if (conv1x1_stream_ok(dgrad, tin, tout, tmask, n_out, m16p, mask_bits, accum_bits))
+            return conv1x1_stream(dgrad, tin, tout, tmask, w_packed, bias, n_out, m16p, relu, mask_bits, st);
+    }
     // the DMA-staged kernel: 3x3, 64-row M-blocks, input gradient already folded, tensors within 32-bit plane offsets
     if (g_dma_mode == 1 && ks == 3 && mf == 4 && (!dgrad || (tin.halo == 1 && tin.folded)) &&
         tin.plane * 16 * CHUNK_CB < (1ll << 31))
