@@ -1351,7 +1351,11 @@ __global__ __launch_bounds__((4 * TN_GROUPS + TN_LOAD) * 64, 4) void thin_conv_a
 constexpr int WG_XPL = 324;   // x-tile plane stride in granules  (5184 B = 64 mod 256)
 constexpr int WG_GPL = 260;   // g-tile plane stride in granules  (4160 B = 64 mod 256)
 
-template <int KS, int MFW, int KSPLIT>
+// ICF = 16-channel input fragments per block (round 4).  A 1x1 layer has one tap, so a block that owns 16 input channels runs 4 MFMAs
+// per k-step behind a full stage of the 64-channel g tile: NestFuse's 152 -> 64 layer staged 10 x (2 + 8) planes per tile for 27 planes
+// of data and ran at 2.1 TB/s.  With ICF = 4 a block owns 64 input channels (3 x (8 + 8) planes), the g fragments feed four times the
+// MFMAs.  3x3 layers keep ICF = 1 (their 64-channel pairs go to wgrad_dma_kernel).
+template <int KS, int MFW, int KSPLIT, int ICF = 1>
 __global__ __launch_bounds__(256) void wgrad_mfma_kernel(TV tx, TV tg, float* __restrict__ partial, int tiles_x,
                                                          int tpi, int total, int G, int n_icg, int n_ocg) {
     constexpr int KK = KS * KS, P = KS / 2, TP = MT + KS - 1;
@@ -1359,14 +1363,15 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(TV tx, TV tg, float* __
     constexpr int MGROUPS = 4 / KSPLIT;                  // wave groups along M
     constexpr int MW = MFW / MGROUPS;                    // M-frags per wave
     constexpr int KSTEPS = 8 / KSPLIT;                   // k-steps per wave per tile
-    constexpr int PER = MFW * 16 * 16 * KK + MFW * 16;   // floats per block partial
-    constexpr int TILE_BYTES = (2 * XPL + MFW * 2 * WG_GPL) * 16;
+    constexpr int ICW = 16 * ICF;                        // input channels per block
+    constexpr int PER = MFW * 16 * ICW * KK + MFW * 16;  // floats per block partial
+    constexpr int TILE_BYTES = (2 * ICF * XPL + MFW * 2 * WG_GPL) * 16;
     constexpr int RED_BYTES = PER * 4;
     constexpr int SM_BYTES = TILE_BYTES > RED_BYTES ? TILE_BYTES : RED_BYTES;
     static_assert(MFW % MGROUPS == 0, "bad wave split");
     __shared__ __attribute__((aligned(16))) char smem[SM_BYTES];
     uint4* s_x = reinterpret_cast<uint4*>(smem);
-    uint4* s_g = s_x + 2 * XPL;
+    uint4* s_g = s_x + 2 * ICF * XPL;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int sl = lane & 15, g = lane >> 4;
@@ -1379,15 +1384,15 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(TV tx, TV tg, float* __
     if ((G & 7) == 0) { pair = (b >> 3) % npairs; gi = ((b >> 3) / npairs) * 8 + (b & 7); }
     else { pair = b % npairs; gi = b / npairs; }
     const int icg = pair % n_icg, ocg = pair / n_icg;
-    const int xcb0 = icg * 2, gcb0 = ocg * MFW * 2;
+    const int xcb0 = icg * 2 * ICF, gcb0 = ocg * MFW * 2;
 
-    f32x4 acc[MW][KK];
+    f32x4 acc[MW][KK * ICF];
     f32x4 accb[MW];
 #pragma unroll
     for (int m = 0; m < MW; ++m) {
         accb[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int t = 0; t < KK; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < KK * ICF; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     // constant all-ones bf16 operand for the bias-gradient column sums
     const uint4 ones_u = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
@@ -1397,7 +1402,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(TV tx, TV tg, float* __
     const int tr_row = sl >> 2, tr_c = sl & 3;
     const int lane_plane = tr_c >> 1, lane_byte = (tr_c & 1) * 8;
 
-    constexpr int NX = (2 * TP * TP + 255) / 256;      // x granules per thread per tile
+    constexpr int NX = (2 * ICF * TP * TP + 255) / 256;   // x granules per thread per tile
     constexpr int NG = MFW * 2;                         // g granules per thread per tile (one per plane)
     uint4 rx[NX], rg[NG];
     // all prefetch loads are unconditional (clamped addresses, zero by select): nothing serialises them
@@ -1406,7 +1411,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(TV tx, TV tg, float* __
         const int y0 = (tt / tiles_x) * MT, x0 = (tt % tiles_x) * MT;
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            const int e = min(tid + 256 * i, 2 * TP * TP - 1);
+            const int e = min(tid + 256 * i, 2 * ICF * TP * TP - 1);
             const int cb = e / (TP * TP), p = e % (TP * TP);
             const int y = min(max(reflect_idx(y0 + p / TP - P, tx.h), 0), tx.h - 1);
             const int x = min(max(reflect_idx(x0 + p % TP - P, tx.w), 0), tx.w - 1);
@@ -1430,7 +1435,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(TV tx, TV tg, float* __
         for (int i = 0; i < NX; ++i) {
             const int e = tid + 256 * i;
             const int cb = e / (TP * TP), p = e % (TP * TP);
-            if (cb < 2) s_x[cb * XPL + p] = rx[i];
+            if (cb < 2 * ICF) s_x[cb * XPL + p] = rx[i];
         }
 #pragma unroll
         for (int i = 0; i < NG; ++i) s_g[i * WG_GPL + tid] = rg[i];
@@ -1472,22 +1477,24 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(TV tx, TV tg, float* __
                 for (int m = 0; m < MW; ++m) accb[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], ones, accb[m], 0, 0, 0);
             }
 #pragma unroll
+            for (int f = 0; f < ICF; ++f)
+#pragma unroll
             for (int t = 0; t < KK; ++t) {
                 const int u = t / KS, v = t % KS;
                 const char* base = reinterpret_cast<const char*>(s_x) +
-                                   ((lane_plane * XPL) + (row + u) * TP + col0 + v + tr_row) * 16 + lane_byte;
+                                   (((2 * f + lane_plane) * XPL) + (row + u) * TP + col0 + v + tr_row) * 16 + lane_byte;
                 const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, base));
                 const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, base + 4 * 16));
                 const s16x8 c = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                 const bf16x8 bb = __builtin_bit_cast(bf16x8, c);
 #pragma unroll
-                for (int m = 0; m < MW; ++m) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], bb, acc[m][t], 0, 0, 0);
+                for (int m = 0; m < MW; ++m) acc[m][f * KK + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], bb, acc[m][f * KK + t], 0, 0, 0);
             }
         }
     }
     // ---- combine the KSPLIT K-slices through LDS, then write the block partial ----
     // lane (g, sl) reg r holds (oc = 16*frag + 4g + r, ic = sl) for tap t; bias sums: any column (all equal)
-    float* red = reinterpret_cast<float*>(smem);  // [MFW*16 oc][16 ic][KK] + [MFW*16]
+    float* red = reinterpret_cast<float*>(smem);  // [MFW*16 oc][16 ICF ic][KK] + [MFW*16]
     for (int w = 0; w < KSPLIT; ++w) {
         __syncthreads();
         if (km == w) {
@@ -1497,12 +1504,12 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(TV tx, TV tg, float* __
                 for (int r = 0; r < 4; ++r) {
                     const int oc = 16 * (mm * MW + m) + 4 * g + r;
 #pragma unroll
-                    for (int t = 0; t < KK; ++t) {
-                        float* pp = &red[(oc * 16 + sl) * KK + t];
-                        *pp = (w == 0 ? 0.f : *pp) + acc[m][t][r];
+                    for (int ft = 0; ft < KK * ICF; ++ft) {
+                        float* pp = &red[(oc * ICW + (ft / KK) * 16 + sl) * KK + ft % KK];
+                        *pp = (w == 0 ? 0.f : *pp) + acc[m][ft][r];
                     }
                     if (sl == 0) {
-                        float* pp = &red[MFW * 16 * 16 * KK + oc];
+                        float* pp = &red[MFW * 16 * ICW * KK + oc];
                         *pp = (w == 0 ? 0.f : *pp) + accb[m][r];
                     }
                 }
@@ -1515,12 +1522,12 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(TV tx, TV tg, float* __
 }
 
 // 64 outputs x 4 G-slices per block: coalesced across outputs, 4-way parallel over G, fixed order
-template <int KS, int MFW>
+template <int KS, int MFW, int ICF = 1>
 __global__ __launch_bounds__(256) void wgrad_mfma_reduce(const float* __restrict__ partial, float* __restrict__ dw,
                                                          float* __restrict__ db, int cin, int cout, int G, int n_icg,
                                                          int n_ocg, int accumulate) {
-    constexpr int KK = KS * KS;
-    constexpr int PER = MFW * 16 * 16 * KK + MFW * 16;
+    constexpr int KK = KS * KS, ICW = 16 * ICF;
+    constexpr int PER = MFW * 16 * ICW * KK + MFW * 16;
     __shared__ float red[4][64];
     const int total_w = cout * cin * KK;
     const int o_local = threadIdx.x & 63, slice = threadIdx.x >> 6;
@@ -1528,12 +1535,12 @@ __global__ __launch_bounds__(256) void wgrad_mfma_reduce(const float* __restrict
     long long off = -1;
     if (idx < total_w) {
         const int tap = idx % KK, c = (idx / KK) % cin, o = idx / (KK * cin);
-        const int icg = c / 16, ic = c % 16, ocg = o / (MFW * 16), oc = o % (MFW * 16);
-        off = ((long long)icg * n_ocg + ocg) * PER + (oc * 16 + ic) * KK + tap;
+        const int icg = c / ICW, ic = c % ICW, ocg = o / (MFW * 16), oc = o % (MFW * 16);
+        off = ((long long)icg * n_ocg + ocg) * PER + (oc * ICW + ic) * KK + tap;
     } else if (idx < total_w + cout) {
         const int o = idx - total_w;
         const int ocg = o / (MFW * 16), oc = o % (MFW * 16);
-        off = ((long long)0 * n_ocg + ocg) * PER + MFW * 16 * 16 * KK + oc;
+        off = ((long long)0 * n_ocg + ocg) * PER + MFW * 16 * ICW * KK + oc;
     }
     float s = 0.f;
     if (off >= 0) {
@@ -2248,9 +2255,12 @@ static inline int pick_mfw(int cout) { return cout <= 16 ? 1 : (cout <= 32 ? 2 :
 // tile groups per (icg, ocg) pair of the register-staged wgrad.  The grid is G * nb persistent blocks; it must fit the resident
 // capacity in ONE round (3 blocks/CU at MFW = 1 -- 136 VGPRs --, else 2; 256 CUs): 1032 blocks on 768 slots ran a second round
 // at 34 % occupancy.
-static int wgrad_G(int cin, int cout) {
+// input-channel fragments per block of the register-staged kernel: 1x1 layers with 64-row output groups take up to 4 (see the kernel)
+static inline int pick_icf(int ks, int cin, int cout) { return (ks == 1 && pick_mfw(cout) == 4) ? (cin > 32 ? 4 : (cin > 16 ? 2 : 1)) : 1; }
+
+static int wgrad_G(int cin, int cout, int icf = 1) {
     const int mfw = pick_mfw(cout);
-    const int nb = cdiv(cin, 16) * cdiv(cout, mfw * 16);
+    const int nb = cdiv(cin, 16 * icf) * cdiv(cout, mfw * 16);
     const int capacity = 256 * (mfw == 1 ? 3 : 2);
     int G = capacity / nb / 8 * 8;
     if (G > 512) G = 512;   // (768 blocks for a single pair measured 8 % slower than 512)
@@ -2275,11 +2285,16 @@ bool wgrad_taprow_supported(int ks, int cin, int cout);
 size_t wgrad_taprow_workspace(int cin, int cout);
 int wgrad_taprow(const TV& tx, const TV& tg, float* dw, float* db, int cin, int cout, int accumulate, float* ws, hipStream_t st);
 static int g_taprow_mode = -1;   // $MMIF_WGRAD_TAPROW=0: keep the per-input-group kernel (A/B timing)
+static int g_wg1_wide = 1;       // $MMIF_WGRAD1X1_WIDE=0: 1x1 weight gradients on 16-input-channel blocks as before (A/B timing)
 
 size_t wgrad_mfma_workspace(int cin, int cout, int ks) {
-    const int mfw = pick_mfw(cout);
-    const size_t per = (size_t)mfw * 16 * 16 * ks * ks + mfw * 16;
-    size_t a = (size_t)wgrad_G(cin, cout) * cdiv(cin, 16) * cdiv(cout, mfw * 16) * per * sizeof(float);
+    const int mfw = pick_mfw(cout), icf = pick_icf(ks, cin, cout);
+    size_t a = 0;
+    for (int f = 1; f <= icf; f *= 2) {   // (either block width may run: $MMIF_WGRAD1X1_WIDE)
+        const size_t per = (size_t)mfw * 16 * 16 * f * ks * ks + mfw * 16;
+        const size_t b = (size_t)wgrad_G(cin, cout, f) * cdiv(cin, 16 * f) * cdiv(cout, mfw * 16) * per * sizeof(float);
+        if (b > a) a = b;
+    }
     if (wgrad_dma_shape(ks, cin, cout)) {
         const size_t b = (size_t)wgrad_dma_G(cin, cout) * cdiv(cin, 64) * cdiv(cout, 64) * WD_PER * sizeof(float);
         if (b > a) a = b;
@@ -2308,19 +2323,19 @@ static int launch_wgrad_dma(const TV& tx, const TV& tg, float* dw, float* db, in
     return check_launch("wgrad_dma_reduce");
 }
 
-template <int KS, int MFW, int KSPLIT>
+template <int KS, int MFW, int KSPLIT, int ICF = 1>
 static int launch_wgrad_mfma(const TV& tx, const TV& tg, float* dw, float* db, int cin, int cout, int accumulate, float* ws,
                              hipStream_t st) {
     const int tiles_x = cdiv(tx.w, MT), tiles_y = cdiv(tx.h, MT);
     const int tpi = tiles_x * tiles_y, total = tpi * tx.n;
-    int G = wgrad_G(cin, cout);
+    int G = wgrad_G(cin, cout, ICF);
     if (G > total) G = total;  // (no longer a multiple of 8: the kernel falls back to the plain block order)
-    const int n_icg = cdiv(cin, 16), n_ocg = cdiv(cout, MFW * 16);
-    hipLaunchKernelGGL((wgrad_mfma_kernel<KS, MFW, KSPLIT>), dim3(G * n_icg * n_ocg), dim3(256), 0, st, tx, tg, ws, tiles_x, tpi,
+    const int n_icg = cdiv(cin, 16 * ICF), n_ocg = cdiv(cout, MFW * 16);
+    hipLaunchKernelGGL((wgrad_mfma_kernel<KS, MFW, KSPLIT, ICF>), dim3(G * n_icg * n_ocg), dim3(256), 0, st, tx, tg, ws, tiles_x, tpi,
                        total, G, n_icg, n_ocg);
     if (int rc = check_launch("wgrad_mfma")) return rc;
     const int n = cout * cin * KS * KS + cout;
-    hipLaunchKernelGGL((wgrad_mfma_reduce<KS, MFW>), dim3(cdiv(n, 64)), dim3(256), 0, st, ws, dw, db, cin, cout, G, n_icg, n_ocg,
+    hipLaunchKernelGGL((wgrad_mfma_reduce<KS, MFW, ICF>), dim3(cdiv(n, 64)), dim3(256), 0, st, ws, dw, db, cin, cout, G, n_icg, n_ocg,
                        accumulate);
     return check_launch("wgrad_mfma_reduce");
 }
@@ -2335,6 +2350,8 @@ int wgrad_mfma(int ks, const TV& tx, const TV& tg, float* dw, float* db, int cin
     if (g_taprow_mode < 0) {
         const char* e = getenv("MMIF_WGRAD_TAPROW");
         g_taprow_mode = (e != nullptr && e[0] == '0') ? 0 : 1;
+        const char* e2 = getenv("MMIF_WGRAD1X1_WIDE");
+        g_wg1_wide = (e2 != nullptr && e2[0] == '0') ? 0 : 1;
     }
     if (g_taprow_mode == 1 && wgrad_taprow_supported(ks, cin, cout) && (tg.halo == 0 || tg.folded) && tx.halo == 0)
         return wgrad_taprow(tx, tg, dw, db, cin, cout, accumulate, ws, st);
@@ -2342,7 +2359,16 @@ int wgrad_mfma(int ks, const TV& tx, const TV& tg, float* dw, float* db, int cin
     if (ks == 3) {
         switch (mfw) { case 1: GO(3, 1, 4); case 2: GO(3, 2, 2); default: GO(3, 4, 2); }
     } else {
-        switch (mfw) { case 1: GO(1, 1, 4); case 2: GO(1, 2, 2); default: GO(1, 4, 2); }
+        switch (mfw) {
+            case 1: GO(1, 1, 4);
+            case 2: GO(1, 2, 2);
+            default:
+                switch (g_wg1_wide ? pick_icf(1, cin, cout) : 1) {
+                    case 4: return launch_wgrad_mfma<1, 4, 2, 4>(tx, tg, dw, db, cin, cout, accumulate, ws, st);
+                    case 2: return launch_wgrad_mfma<1, 4, 2, 2>(tx, tg, dw, db, cin, cout, accumulate, ws, st);
+                    default: GO(1, 4, 2);
+                }
+        }
     }
 #undef GO
 }

@@ -97,3 +97,29 @@ def test_streaming_1x1_is_the_kernel_that_runs_and_accumulate_falls_back():
     torch.cuda.synchronize()
     want = np.einsum("oc,nohw->nchw", bf16_round(wt.cpu().numpy())[:, :, 0, 0].astype(np.float64), bf16_round(gn.numpy()).astype(np.float64)) + bf16_round(old.numpy())
     close(gx.to_nchw(cin).cpu().numpy(), want.astype(np.float32), 8e-3, "accumulating 1x1 dgrad")
+
+
+@pytest.mark.parametrize("cin,cout,n,h,w", SHAPES, ids=[f"{a}-{b}-{n}x{h}x{w}" for a, b, n, h, w in SHAPES])
+def test_1x1_weight_gradient_wide_blocks_vs_fp64(cin, cout, n, h, w):
+    """1x1 weight gradients (wgrad_mfma_kernel<1, 4, 2, ICF>: a block owns up to 64 input channels per staged 64-channel gradient tile,
+    round 4) against the fp64 definition on the same bf16-rounded operands: dW[o, c] = sum_p g[o, p] x[c, p], db[o] = sum_p g[o, p];
+    fp32 accumulation over up to 4 k pixels per block partial -> 2e-4 of max|dW|.  Accumulate flag on top of existing values."""
+    from mmif import tensor as T
+    from mmif._lib import IMPL_MFMA
+    torch.manual_seed(cin + 5 * cout)
+    xn, gn = torch.randn(n, cin, h, w), torch.randn(n, cout, h, w)
+    xb = T.BT.from_nchw(xn.to(DEV), torch.bfloat16)
+    gy = T.BT.from_nchw(gn.to(DEV), torch.bfloat16, halo=1).as_folded()
+    ws = torch.empty(T.wgrad_workspace_bytes(cin, cout, 1) // 4 + 1, dtype=torch.float32, device=DEV)
+    dw, db = torch.full((cout, cin, 1, 1), 0.5, device=DEV), torch.full((cout,), -0.25, device=DEV)
+    T.conv_wgrad(xb, gy, dw, db, cin, cout, 1, ws, True, IMPL_MFMA)
+    dw2, db2 = torch.empty(cout, cin, 1, 1, device=DEV), torch.empty(cout, device=DEV)
+    T.conv_wgrad(xb, gy, dw2, db2, cin, cout, 1, ws, False, IMPL_MFMA)
+    torch.cuda.synchronize()
+    xq, gq = bf16_round(xn.numpy()).astype(np.float64), bf16_round(gn.numpy()).astype(np.float64)
+    want = np.einsum("nohw,nchw->oc", gq, xq)[:, :, None, None]
+    wantb = gq.sum(axis=(0, 2, 3))
+    close(dw2.cpu().numpy(), want, 2e-4, "dW")
+    close(db2.cpu().numpy(), wantb, 2e-4, "db")
+    close(dw.cpu().numpy(), want + 0.5, 2e-4, "dW accumulate")
+    close(db.cpu().numpy(), wantb - 0.25, 2e-4, "db accumulate")
