@@ -433,6 +433,23 @@ int mmif_dense_encoder_wgrad(const float* img, const mmif_tensor* x, const mmif_
  * (sizes mmif_packed_weight_bytes(16 (3 - k), 16, 3)) from the fp32 weights w1 [16][16][3][3], w2 [16][32][3][3], w3 [16][48][3][3]. */
 int mmif_pack_dense_chain(const float* w1, const float* w2, const float* w3, void* packed_v0, void* packed_v1, void* packed_v2,
                           void* stream);
+/* The whole chain as ONE streaming launch (csrc/enc_chain.hip, bf16): a line-buffer pipeline like mmif_dense_encoder_fwd's, walking down the
+ * image -- g2 = [x2 > 0](G2 + A32 g3), g1 = [x1 > 0](G1 + A21 g2 + A31 g3), g0 = [x0 > 0](G0 + A10 g1 + A20 g2 + A30 g3) with the adjoint of
+ * reflect padding applied in place (rows 1 / h-2: a second k-loop pass; columns: the edge strips carry columns -1 / w and fold them with one
+ * cross-lane add).  g3: 2-block view of the finished gradient of x3; glow: 6-block view G0 | G1 | G2 of the gradient the decoder left
+ * (halo 0, or halo 1 folded -- DenseFuse passes the ONE gradient of f1 + f2 for both branches); x: 6-block view x0 | x1 | x2 of the forward's
+ * output (halo 0); packed[k]: the dgrad operand image of virtual layer k of mmif_pack_dense_chain; out: 8-block view that receives
+ * g0 | g1 | g2 | g3 (halo 0 or 1; it must NOT overlap g3 / glow: strips and row segments recompute their margins from the inputs).  h, w >= 4.
+ * chain_b: a second, independent branch in the same launch, or NULL.  Same sums as three mmif_conv2d_reflect_dgrad_folded calls on the
+ * virtual layers (fp32 accumulation of every contribution + G, one bf16 rounding); 176 instead of 240 channel planes of HBM traffic. */
+typedef struct mmif_dense_chain {
+    const mmif_tensor* g3;
+    const mmif_tensor* glow;
+    const mmif_tensor* x;
+    const void* packed[3];
+    const mmif_tensor* out;
+} mmif_dense_chain;
+int mmif_dense_encoder_chain(const mmif_dense_chain* chain_a, const mmif_dense_chain* chain_b, void* stream);
 /* The same for fp32 tensors: x3-format images (mmif_packed_weight_bytes_x3(16 (3 - k), 16, 3)) for the split-operand dgrad kernels. */
 int mmif_pack_dense_chain_x3(const float* w1, const float* w2, const float* w3, void* packed_v0, void* packed_v1, void* packed_v2,
                              void* stream);

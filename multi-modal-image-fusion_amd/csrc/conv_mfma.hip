@@ -823,7 +823,10 @@ __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void conv_dma_kernel(TV 
                 d_off[i] = (__umul24((unsigned)y, (unsigned)tin.ws) + (unsigned)x) * 16u + ((d_cb >> (2 * i)) & 3u) * plane_bytes;
             }
         };
-        auto issue_dma = [&](const DItem& itm, int c, int buf) {
+        auto issue_dma = [&](const DItem& itm, int c, int buf, int item_no = 0) {
+            // timing ablations (results are garbage): $MMIF_CONV_ABLATE bit 1 = no WEIGHT pieces on every second item (what a weight chunk
+            // shared by two pixel tiles could save at most), bit 3 = no INPUT pieces on every second item (an input tile shared by two M-blocks)
+            const bool skip_w = (abl & 2) && (item_no & 1), skip_in = (abl & 8) && (item_no & 1);
             const int ncb = min(CHUNK_CB, ncb_tot - c * CHUNK_CB);
             const int nkgp = (9 * ncb + 3) / 4 * 4;
             char* dst_in = s_buf + buf * DBUF_BYTES;
@@ -839,10 +842,10 @@ __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void conv_dma_kernel(TV 
                         const unsigned cb = (d_cb >> (2 * (i < DL_IN_ITERS ? i : 0))) & 3u;
                         off -= (cb - min(cb, (unsigned)(ncb - 1))) * plane_bytes;
                     }
-                    __builtin_amdgcn_global_load_lds(MMIF_GPTR(src_in + off), MMIF_LPTR(dst_in + P * 1024), 16, 0, 0);
+                    if (!skip_in) __builtin_amdgcn_global_load_lds(MMIF_GPTR(src_in + off), MMIF_LPTR(dst_in + P * 1024), 16, 0, 0);
                 } else if (P >= DIN_PIECES && P < D_PIECES) {
                     const int kg = P - DIN_PIECES;
-                    if (kg < nkgp)
+                    if (kg < nkgp && !skip_w)
                         __builtin_amdgcn_global_load_lds(MMIF_GPTR(src_w + (long long)kg * m16p * 16), MMIF_LPTR(dst_w + kg * 1024), 16, 0, 0);
                 }
             }
@@ -933,7 +936,7 @@ __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void conv_dma_kernel(TV 
                     load_bias(cur, item_i % 3);
                 }
             }
-            if (q + 1 < total_q && !(abl & 1)) issue_dma(cur, c, (q & 1) ^ 1);
+            if (q + 1 < total_q && !(abl & 1)) issue_dma(cur, c, (q & 1) ^ 1, item_i);
             if (LMASK && q + 1 < total_q && c == nch - 2) { issue_mask(cur); mitem = cur; mpar = item_i & 1; mpend = true; }
         }
         return;

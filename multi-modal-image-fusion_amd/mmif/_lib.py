@@ -34,6 +34,11 @@ class MmifDenseEncoder(C.Structure):
     _fields_ = [("img", C.c_void_p), ("w0", C.c_void_p), ("b0", C.c_void_p), ("packed", C.c_void_p * 3), ("bias", C.c_void_p * 3)]
 
 
+class MmifDenseChain(C.Structure):
+    _fields_ = [("g3", C.POINTER(MmifTensor)), ("glow", C.POINTER(MmifTensor)), ("x", C.POINTER(MmifTensor)), ("packed", C.c_void_p * 3),
+                ("out", C.POINTER(MmifTensor))]
+
+
 class MmifError(RuntimeError):
     pass
 
@@ -103,6 +108,7 @@ SIGNATURES = {
     "mmif_conv2d_reflect_bwd_wide": (_i32, [_TP, _vp, _TP, _TP, _vp, _vp, _i32, _i32, _i32, _u64, _i32, _vp, _sz, _vp, _sz, _vp]),
     "mmif_pack_dense_chain": (_i32, [_vp] * 7),
     "mmif_pack_dense_chain_x3": (_i32, [_vp] * 7),
+    "mmif_dense_encoder_chain": (_i32, [C.POINTER(MmifDenseChain), C.POINTER(MmifDenseChain), _vp]),
     "mmif_dense_encoder_wgrad_workspace": (_sz, []),
     "mmif_dense_encoder_wgrad": (_i32, [_vp, _TP, _TP] + [_vp] * 8 + [_i32, _vp, _sz, _vp]),
     "mmif_act_fwd": (_i32, [_vp, _vp, _i64, _i32, _f32, _vp]),

@@ -473,6 +473,17 @@ class DenseEncoderMixin:
         return cached[1]
 
     @staticmethod
+    def chain_out(first, F):
+        """[g0 | g1 | g2 | g3] of one encoder branch: the streaming chain's output (it is not an in-place kernel), read by the branch's
+        weight-gradient pass right after -- one buffer per encoder (a shared encoder's second branch reuses it: stream order)"""
+        key = (F.n, F.h, F.w, F.buf.device)
+        cached = getattr(first, "_gz", None)
+        if cached is None or cached[0] != key:
+            cached = (key, BT.alloc(F.n, 64, F.h, F.w, torch.bfloat16, F.buf.device))
+            first._gz = cached
+        return cached[1]
+
+    @staticmethod
     def enc_bwd(specs, img, F, GF, fbase, gbase, ws, impl, accumulate_w=False, onto=None):
         """GF[gbase:gbase+8] holds dL/d(encoder output) (padded domain), top 2 blocks already masked.
         onto (8-block folded view): blocks 0..5 of GF are NOT initialised -- the chain adds its contributions to onto's blocks
@@ -490,7 +501,15 @@ class DenseEncoderMixin:
         # ... and the dgrad chain per DESTINATION (gather form: one launch per x_k on the stacked virtual layer, fp32 sum of all
         # contributions, one rounding) instead of per source layer (read-modify-write of the lower blocks); $MMIF_ENC_CHAIN=0: scatter
         gather = (hot or (hot32 and onto is None)) and switch("MMIF_ENC_CHAIN")
-        if gather:
+        # bf16: the three destinations as ONE streaming launch (csrc/enc_chain.hip: line-buffer pipeline, reflect adjoint in place) that
+        # leaves [g0 | g1 | g2 | g3] in a buffer of its own; $MMIF_ENC_CHAIN_STREAM=0: one gather-form dgrad launch per destination, in place
+        gz = GF.view(gbase, 8)
+        if gather and hot and F.h >= 4 and F.w >= 4 and switch("MMIF_ENC_CHAIN_STREAM"):
+            pk = DenseEncoderMixin.chain_images(specs, _lib.BF16)
+            gz = DenseEncoderMixin.chain_out(first, F)
+            glow = onto.view(0, 6) if onto is not None else GF.view(gbase, 6)
+            T.dense_encoder_chain([(GF.view(gbase + 6, 2), glow, F.view(fbase, 6), pk, gz)], tag=f"{first.name}.chain:dgrad")
+        elif gather:
             pk = DenseEncoderMixin.chain_images(specs, _lib.F32 if hot32 else _lib.BF16)
             for k in (2, 1, 0):
                 gy, xk, dst = GF.view(gbase + 2 * (k + 1), 2 * (3 - k)), F.view(fbase + 2 * k, 2), GF.view(gbase + 2 * k, 2)
@@ -500,7 +519,7 @@ class DenseEncoderMixin:
                 else:
                     ModelEngine.tag_dgrad(gy, xk, dst, 16, 16 * (3 - k), pk[k], f"{first.name}.chain{k}:dgrad")
         for s, nin in ((c2, 6), (c1, 4), (c0, 2)):
-            g = GF.view(gbase + nin, 2)
+            g = gz.view(nin, 2)
             x = F.view(fbase, nin)
             if not fused:
                 T.conv_wgrad(x, g, s.dw, s.db, s.cin, s.cout, s.k, ws, accumulate_w, impl, s.name + ":wgrad")
@@ -508,9 +527,9 @@ class DenseEncoderMixin:
             if not gather:
                 ModelEngine.c_dgrad(s, g, x, GF.view(gbase, nin), bits(nin - 2, nin - 1), all_bits(nin), impl)
         if fused:
-            T.dense_encoder_wgrad(img, F.view(fbase, 6), GF.view(gbase, 8), [(s.dw, s.db) for s in specs], ws, accumulate_w, tag="encode:wgrad")
+            T.dense_encoder_wgrad(img, F.view(fbase, 6), gz, [(s.dw, s.db) for s in specs], ws, accumulate_w, tag="encode:wgrad")
         else:
-            T.image_in_wgrad(img, GF.view(gbase, 2), first.dw, first.db, first.cout, first.k, ws, accumulate_w)
+            T.image_in_wgrad(img, gz.view(0, 2), first.dw, first.db, first.cout, first.k, ws, accumulate_w)
 
 
 class PFNetv1Engine(ModelEngine, DenseEncoderMixin):

@@ -278,6 +278,22 @@ def repack_dense_chain(pk, w1, w2, w3):
     check(fn(_ptr(w1), _ptr(w2), _ptr(w3), _ptr(pk[0].dgrad), _ptr(pk[1].dgrad), _ptr(pk[2].dgrad), stream_ptr()), "pack_dense_chain")
 
 
+def dense_encoder_chain(branches, tag=None):
+    """The DenseBlock's backward gradient chain of one or two branches as ONE streaming launch (csrc/enc_chain.hip).
+    branches: [(g3 2-block view, glow 6-block view, x 6-block view, chain images (pack_dense_chain), out 8-block view), ...]"""
+    structs, keep = [], []
+    for g3, glow, x, pk, out in branches:
+        e = _lib.MmifDenseChain()
+        e.g3, e.glow, e.x, e.out = C.pointer(g3._d), C.pointer(glow._d), C.pointer(x._d), C.pointer(out._d)
+        for k in range(3):
+            assert pk[k].fmt == BF16 and (pk[k].cout, pk[k].cin, pk[k].k) == (16 * (3 - k), 16, 3), "pack_dense_chain images expected"
+            e.packed[k] = pk[k].dgrad.data_ptr()
+        structs.append(e)
+        keep.append((g3, glow, x, out))
+    with _timed(tag):
+        check(lib.mmif_dense_encoder_chain(C.byref(structs[0]), C.byref(structs[1]) if len(structs) > 1 else None, stream_ptr()), "dense_encoder_chain")
+
+
 def dense_encoder_wgrad_workspace_bytes():
     return lib.mmif_dense_encoder_wgrad_workspace()
 

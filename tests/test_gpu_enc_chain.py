@@ -1,0 +1,143 @@
+"""The streaming backward chain of the DenseBlock encoder (csrc/enc_chain.hip, mmif_dense_encoder_chain; reference core/block.py:137-151
+under autograd): g2 = [x2 > 0](G2 + A32 g3), g1 = [x1 > 0](G1 + A21 g2 + A31 g3), g0 = [x0 > 0](G0 + A10 g1 + A20 g2 + A30 g3) with
+A = adjoint of (reflect pad + 3x3 correlation).
+
+* against the fp64 definition built from the ORACLE's conv backward (oracle/fusion_oracle.py:conv2d_reflect_bwd, pinned to the reference's
+  autograd by golden F3 / F4) on the same bf16 operands, every stage's input taken from the kernel's own (rounded) previous stage: one
+  bf16 rounding of the fp32 sum -- this is the check of the in-place reflect adjoint (rows 1 / h-2: second k-loop pass; columns: the
+  edge strips' cross-lane fold; corners: both);
+* against the three gather-form dgrad launches it replaces (same operand images): within one bf16 rounding;
+* shapes: single strip (w <= 30), two strips with the right edge strip clamped, ten strips, several row segments, h = w = 4 (every row
+  and column is a border or a fold target), two branches in one launch, halo-0 and halo-1 inputs / outputs, channel-slot views.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fusion_oracle as O
+from gpu_util import bf16_round, close
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+ULP = 2.0 ** -8
+
+SHAPES = [(2, 37, 53), (1, 16, 16), (1, 4, 4), (2, 5, 31), (1, 9, 30), (3, 64, 29), (1, 33, 32), (1, 20, 57), (2, 40, 256), (1, 300, 64), (1, 7, 4)]
+
+
+def _setup(n, h, w, seed):
+    from mmif import tensor as T
+    g = torch.Generator().manual_seed(seed)
+    xs = torch.randn(n, 64, h, w, generator=g)
+    xs[xs.abs() < 0.5] = 0.0                                   # ReLU-style activations: zeros and negatives mask the gradient
+    xs = xs.abs() * (torch.rand(n, 64, h, w, generator=g) > 0.3)
+    G = torch.randn(n, 64, h, w, generator=g)
+    ws = [torch.randn(16, 16 * (i + 1), 3, 3, generator=g) * (0.25 / (i + 1)) for i in range(3)]
+    F = T.BT.from_nchw(xs.to(DEV), torch.bfloat16)
+    GF = T.BT.from_nchw(G.to(DEV), torch.bfloat16, halo=1).as_folded()
+    pk = T.pack_dense_chain(*[t.to(DEV) for t in ws], DEV)
+    return xs, G, ws, F, GF, pk
+
+
+def _oracle_chain(xs, G, ws, got):
+    """fp64 stage by stage; stage inputs = the kernel's own rounded outputs `got` (so each stage is held to ONE rounding)"""
+    xq = bf16_round(xs.numpy()).astype(np.float64)
+    Gq = bf16_round(G.numpy()).astype(np.float64)
+    wq = [bf16_round(t.numpy()).astype(np.float64) for t in ws]
+    g3 = Gq[:, 48:64]
+    out = {}
+    g = {3: g3}
+    for k in (2, 1, 0):
+        acc = Gq[:, 16 * k:16 * k + 16].copy()
+        for l in range(k + 1, 4):                      # conv l reads [x0 .. x(l-1)]; its input gradient's x_k slice
+            xin = xq[:, :16 * l]
+            gx, _, _ = O.conv2d_reflect_bwd(xin, wq[l - 1], None, g[l], relu=False, need_gx=True)
+            acc += gx[:, 16 * k:16 * k + 16]
+        out[k] = acc * (xq[:, 16 * k:16 * k + 16] > 0)
+        g[k] = got[:, 16 * k:16 * k + 16].astype(np.float64)      # next stages see what the kernel stored
+    return out
+
+
+@pytest.mark.parametrize("n,h,w", SHAPES, ids=[f"{n}x{h}x{w}" for n, h, w in SHAPES])
+def test_streaming_chain_vs_fp64_definition_and_gather_launches(n, h, w):
+    from mmif import tensor as T
+    from mmif._lib import IMPL_MFMA
+    xs, G, ws, F, GF, pk = _setup(n, h, w, 100 * h + w)
+    out = T.BT.alloc(n, 64, h, w, torch.bfloat16, DEV)
+    out.buf.fill_(3.0)
+    T.dense_encoder_chain([(GF.view(6, 2), GF.view(0, 6), F.view(0, 6), pk, out)])
+    torch.cuda.synchronize()
+    got = out.to_nchw(64).cpu().numpy()
+    assert np.array_equal(got[:, 48:], bf16_round(G.numpy())[:, 48:]), "g3 is copied through"
+    want = _oracle_chain(xs, G, ws, got)
+    for k in (2, 1, 0):
+        ref = want[k]
+        assert np.abs(ref).max() > 0
+        err = np.abs(got[:, 16 * k:16 * k + 16] - ref) / np.maximum(np.abs(ref), 1e-2 * np.abs(ref).max())
+        assert err.max() <= 1.01 * ULP, f"g{k}: {err.max():.3e} at {np.unravel_index(err.argmax(), err.shape)}"
+    # the gather-form launches on the same operand images, in place on a copy of G
+    GC = T.BT.alloc(n, 64, h, w, torch.bfloat16, DEV, halo=1, zero=True)
+    GC.buf.copy_(GF.buf)
+    GC = GC.as_folded()
+    for k in (2, 1, 0):
+        T.conv_dgrad(GC.view(2 * (k + 1), 2 * (3 - k)), None, F.view(2 * k, 2), GC.view(2 * k, 2), 16, 16 * (3 - k), 3, 3, 3, pk[k], IMPL_MFMA, fold=True)
+    torch.cuda.synchronize()
+    ref = GC.to_nchw(64).cpu().numpy()
+    for k in (2, 1, 0):
+        a, r = got[:, 16 * k:16 * k + 16], ref[:, 16 * k:16 * k + 16]
+        err = np.abs(a - r) / np.maximum(np.abs(r), 1e-2 * np.abs(r).max())
+        # (a stage's input may already differ by one rounding between the two forms: two roundings' worth on the output)
+        assert err.max() <= 4 * ULP and (err > 0).mean() < 0.2, f"g{k} vs gather form: {err.max():.3e}, {(err > 0).mean():.3f} differ"
+
+
+def test_streaming_chain_two_branches_halo_and_slot_views():
+    """two branches in one launch (PFNetv1: blocks 0-7 / 8-15 of one gradient buffer), output with halo 1 inside a wider allocation,
+    accumulate operand from ANOTHER tensor (DenseFuse: the one gradient of f1 + f2 serves both branches): each branch equals its own
+    single-branch launch bit for bit, neighbours of the output slots and the output's halo ring stay untouched"""
+    from mmif import tensor as T
+    n, h, w = 2, 21, 45
+    xs, G, ws, F, GF, pk = _setup(n, h, w, 7)
+    xs2, G2, ws2, F2, GF2, pk2 = _setup(n, h, w, 8)
+    big = T.BT.alloc(n, 8 * 20, h, w, torch.bfloat16, DEV, halo=1, zero=True)
+    big.buf.fill_(5.0)
+    oa, ob = big.view(1, 8), big.view(11, 8)
+    T.dense_encoder_chain([(GF.view(6, 2), GF.view(0, 6), F.view(0, 6), pk, oa), (GF2.view(6, 2), GF.view(0, 6), F2.view(0, 6), pk2, ob)])
+    sa, sb = T.BT.alloc(n, 64, h, w, torch.bfloat16, DEV), T.BT.alloc(n, 64, h, w, torch.bfloat16, DEV)
+    T.dense_encoder_chain([(GF.view(6, 2), GF.view(0, 6), F.view(0, 6), pk, sa)])
+    T.dense_encoder_chain([(GF2.view(6, 2), GF.view(0, 6), F2.view(0, 6), pk2, sb)])     # glow from the OTHER tensor (GF), g3 from GF2
+    torch.cuda.synchronize()
+    assert torch.equal(oa.to_nchw(64), sa.to_nchw(64)) and torch.equal(ob.to_nchw(64), sb.to_nchw(64))
+    b = big.buf.float()
+    assert float((b[:, 0] - 5).abs().max()) == 0 and float((b[:, 9:11] - 5).abs().max()) == 0 and float((b[:, 19] - 5).abs().max()) == 0
+    assert float((b[:, 1:9, 0] - 5).abs().max()) == 0 and float((b[:, 1:9, :, -1] - 5).abs().max()) == 0      # halo ring untouched
+    assert float(sa.to_nchw(64).abs().max()) > 0
+    with pytest.raises(RuntimeError):      # in place is refused
+        T.dense_encoder_chain([(GF.view(6, 2), GF.view(0, 6), F.view(0, 6), pk, GF.view(0, 8))])
+
+
+@pytest.mark.parametrize("name", ["PFNetv1", "DenseFuse", "VIFNet", "PFNetv2"])
+def test_models_with_streaming_chain_equal_gather_form(name):
+    """whole train-step gradients with the streaming chain on and off ($MMIF_ENC_CHAIN_STREAM): every parameter gradient within
+    bf16 rounding noise of the gather-form launches (the decoder's are bit-identical: they do not depend on the chain)"""
+    import os
+    import core.model as M
+    from gpu_util import dtype_ctx, load_closed_form, reload_switches, tg
+    shape = (2, 1, 40, 72)
+    i1, i2, gy = tg(O.closed_form_image(shape, 0.3)), tg(O.closed_form_image(shape, 1.7)), tg(O.closed_form_image(shape, 0.9))
+    res = {}
+    for mode in ("1", "0"):
+        os.environ["MMIF_ENC_CHAIN_STREAM"] = mode
+        try:
+            with dtype_ctx("bf16"):
+                m = load_closed_form(getattr(M, name)(), 1).to(DEV)
+                y = m(i1, i2)
+                y.backward(gy)
+                torch.cuda.synchronize()
+                res[mode] = {k: p.grad.detach().cpu().numpy() for k, p in m.named_parameters()}
+        finally:
+            os.environ.pop("MMIF_ENC_CHAIN_STREAM", None)
+            reload_switches()
+    for k, g in res["0"].items():
+        if k.startswith("decode"):
+            assert np.array_equal(res["1"][k], g), k
+        else:
+            close(res["1"][k], g, 2e-2, k)

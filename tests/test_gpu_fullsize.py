@@ -237,12 +237,14 @@ def test_encoder_round2_kernels_at_full_size():
             GF = T.BT.alloc(B, 64, S, S, dtype, dev, halo=1, zero=True)
             GF.buf.copy_(G.buf)
             os.environ["MMIF_ENC_CHAIN"] = mode
+            os.environ["MMIF_ENC_CHAIN_STREAM"] = "0"          # (the in-place gather-form launches; the streaming kernel is checked below)
             __import__("mmif.engine").engine.reload_switches()
             try:
                 eng._assign_grad_views(dev)
                 eng.enc_bwd(eng.enc[0], i1, Fb, GF.as_folded(), 0, 0, ws, impl)
             finally:
                 os.environ.pop("MMIF_ENC_CHAIN")
+                os.environ.pop("MMIF_ENC_CHAIN_STREAM")
                 __import__("mmif.engine").engine.reload_switches()
             torch.cuda.synchronize()
             assert float(GF.buf[:, :, 0].float().abs().max()) == 0.0       # the halo ring stays zero (folded convention)
@@ -250,6 +252,18 @@ def test_encoder_round2_kernels_at_full_size():
         assert torch.equal(res["1"][:, 6:], res["0"][:, 6:])               # g3 is an input
         d = (res["1"] - res["0"]).abs().max().item() / res["0"].abs().max().item()
         assert d < 3e-2, d
+        # round 4: the chain as ONE streaming launch (csrc/enc_chain.hip) at full size: [g0 | g1 | g2 | g3] in its own buffer, within one
+        # bf16 rounding per stage of the gather-form launches (10 strips x row segments x 32 images; same operand images)
+        GF = T.BT.alloc(B, 64, S, S, dtype, dev, halo=1, zero=True)
+        GF.buf.copy_(G.buf)
+        eng.enc_bwd(eng.enc[0], i1, Fb, GF.as_folded(), 0, 0, ws, impl)
+        torch.cuda.synchronize()
+        assert torch.equal(GF.buf, G.buf)                                  # not in place: the inputs are untouched
+        gz = eng.enc[0][0]._gz[1].buf.float()
+        ref = res["1"][:, :, 1:-1, 1:-1]
+        assert torch.equal(gz[:, 6:], ref[:, 6:])
+        err = (gz - ref).abs() / torch.maximum(ref.abs(), 1e-2 * ref.abs().max())
+        assert float(err.max()) <= 4 * 2.0 ** -8 and float((err > 0).float().mean()) < 0.2, (float(err.max()), float((err > 0).float().mean()))
 
 
 def test_decoder_round2_kernels_at_full_size():
