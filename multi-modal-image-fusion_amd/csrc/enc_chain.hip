@@ -62,6 +62,8 @@ struct ECPre {                 // one step's global operands, requested two step
     uint4 xk[3];               // mask operands x2, x1, x0 at the same places
 };
 
+__device__ inline void ec_touch(const uint4& v) { __asm__ volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w) : "memory"); }
+
 __global__ __launch_bounds__(EC_WAVES * 64, 2) void enc_chain_bwd_kernel(ChainArgs A) {
     __shared__ __attribute__((aligned(16))) uint4 s_w[EC_WPLANES * 16];
     __shared__ __attribute__((aligned(16))) char s_ring[EC_WAVES][EC_RING_BYTES];
@@ -85,7 +87,9 @@ __global__ __launch_bounds__(EC_WAVES * 64, 2) void enc_chain_bwd_kernel(ChainAr
     // strip geometry: region [r0, r0 + 32) of image columns, r0 = -1 for the first strip (column -1 and column w belong to the edge strips);
     // kept output columns [o_lo, o_hi) = those whose 3-destination dependency cone lies inside the region or beyond the image edge
     auto strip_r0 = [&](int s) { return A.nstrips == 1 ? -1 : min(-1 + EC_KEEP * s, W - (EC_W - 1)); };
-    auto strip_hi = [&](int r) { return (r + EC_W >= W + 1) ? W : r + EC_W - 3; };
+    // (a strip that does not hold column w cannot fold onto column w-2, and g0 at column c reaches g2 at c + 2: its kept columns end at
+    // w - 5; the edge strip, whose region starts at w - 31, takes over from there)
+    auto strip_hi = [&](int r) { return (r + EC_W >= W + 1) ? W : min(r + EC_W - 3, W - 4); };
     const int r0 = strip_r0(strip);
     const int o_hi = strip_hi(r0);
     const int o_lo = strip == 0 ? 0 : max(r0 + 3, strip_hi(strip_r0(strip - 1)));
@@ -245,35 +249,58 @@ __global__ __launch_bounds__(EC_WAVES * 64, 2) void enc_chain_bwd_kernel(ChainAr
             constexpr int OB = L == 1 ? EC_B1 : EC_B2, OR = L == 1 ? EC_R1 : EC_R2;
             *reinterpret_cast<uint4*>(ring + ((OB + cb_e * OR + y % OR) * EC_W + px_e) * 16) = gr;
         }
-        if (y >= y_lo && y < y_hi && keep_e)
-            *reinterpret_cast<uint4*>(out_img + (unsigned)(2 * (3 - L) + cb_e) * o_plane + (unsigned)y * o_row + (unsigned)x_e * 16u + o_org) = gr;
+        return gr;     // (stored to the output tensor by the NEXT step, see the pipeline)
     };
 
     // ---- the pipeline
     const int a_lo = max(0, y_lo - 3), a_hi = min(H, y_hi + 3);
     const int b_lo = max(0, y_lo - 2), b_hi = min(H, y_hi + 2);
     const int c_lo = max(0, y_lo - 1), c_hi = min(H, y_hi + 1);
+    // Global memory traffic of a step happens at ONE point, its top: loads and stores share one in-order counter on this hardware, so a
+    // wait for prefetched operands is a wait for every store issued before it -- with the rows' stores inside the step (first version) each
+    // of the four uses of prefetched data drained the store of the row just finished: 4.0 us per row step against the forward's 2.9.
+    // Now a step (1) takes its operands (requested two steps ago: landed long since), (2) stores the rows the PREVIOUS step produced
+    // (kept in 16 registers), (3) requests the operands of step r + 2, (4) computes -- nothing waits on anything younger than a step.
     ECPre S0, S1;
     const int r_first = a_lo - 3;
     request(r_first, S0);
     request(r_first + 1, S1);
+    uint4 pend[4];                     // g3 row r+2 (copy), g2 row r+1, g1 row r, g0 row r-1 of the previous step r-1
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pend[i] = make_uint4(0, 0, 0, 0);
+    auto flush = [&](int rp) {         // rows produced by step rp: g3 copy at rp + 3, g2 at rp + 2, g1 at rp + 1, g0 at rp
+        const int ya = rp + 3;
+        if (ya >= a_lo && ya < a_hi && ya >= y_lo && ya < y_hi && keep_a)     // [g0 | g1 | g2 | g3] contiguous for the weight-gradient pass
+            *reinterpret_cast<uint4*>(out_img + (unsigned)(6 + cb_a) * o_plane + (unsigned)ya * o_row + (unsigned)x_a * 16u + o_org) = pend[0];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {  // k = 0: g2 (blocks 4, 5) at row rp + 2 ... k = 2: g0 at row rp
+            const int y = rp + 2 - k;
+            if (y >= y_lo && y < y_hi && keep_e)
+                *reinterpret_cast<uint4*>(out_img + (unsigned)(2 * (2 - k) + cb_e) * o_plane + (unsigned)y * o_row + (unsigned)x_e * 16u + o_org) = pend[1 + k];
+        }
+    };
     auto step = [&](int r, ECPre& S) {
+        const ECPre cur = S;           // (1)  (the empty asm pins the wait HERE: left to the first use, it would sit behind the stores and
+        ec_touch(cur.g3v);             //       requests below and become a wait for them)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { ec_touch(cur.gk[k]); ec_touch(cur.xk[k]); }
+        flush(r - 1);                  // (2)
+        request(r + 2, S);             // (3)
         const int ya = r + 3, yb = r + 2, yc = r + 1;
         if (ya >= a_lo && ya < a_hi) {
-            const uint4 gv = in_a ? S.g3v : make_uint4(0, 0, 0, 0);
-            *reinterpret_cast<uint4*>(ring + ((EC_B0 + cb_a * EC_R0 + ya % EC_R0) * EC_W + px_a) * 16) = gv;
-            if (ya >= y_lo && ya < y_hi && keep_a)     // [g0 | g1 | g2 | g3] contiguous for the weight-gradient pass
-                *reinterpret_cast<uint4*>(out_img + (unsigned)(6 + cb_a) * o_plane + (unsigned)ya * o_row + (unsigned)x_a * 16u + o_org) = gv;
+            pend[0] = in_a ? cur.g3v : make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(ring + ((EC_B0 + cb_a * EC_R0 + ya % EC_R0) * EC_W + px_a) * 16) = pend[0];
         }
-        if (yb >= b_lo && yb < b_hi) conv_row(ECI<1>(), yb, S.gk[0], S.xk[0]);
-        if (yc >= c_lo && yc < c_hi) conv_row(ECI<2>(), yc, S.gk[1], S.xk[1]);
-        if (r >= y_lo && r < y_hi) conv_row(ECI<3>(), r, S.gk[2], S.xk[2]);
-        request(r + 2, S);
+        if (yb >= b_lo && yb < b_hi) pend[1] = conv_row(ECI<1>(), yb, cur.gk[0], cur.xk[0]);
+        if (yc >= c_lo && yc < c_hi) pend[2] = conv_row(ECI<2>(), yc, cur.gk[1], cur.xk[1]);
+        if (r >= y_lo && r < y_hi) pend[3] = conv_row(ECI<3>(), r, cur.gk[2], cur.xk[2]);
     };
-    for (int r = r_first; r < y_hi; r += 2) {
+    int r = r_first;
+    for (; r < y_hi; r += 2) {
         step(r, S0);
         step(r + 1, S1);
     }
+    flush(r - 1);
 }
 
 // items-per-launch heuristic (as enc_stream.hip): every (strip, segment, image, branch) is one wave; 2 blocks of 4 waves fit a CU

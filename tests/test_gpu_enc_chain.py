@@ -84,9 +84,12 @@ def test_streaming_chain_vs_fp64_definition_and_gather_launches(n, h, w):
     ref = GC.to_nchw(64).cpu().numpy()
     for k in (2, 1, 0):
         a, r = got[:, 16 * k:16 * k + 16], ref[:, 16 * k:16 * k + 16]
-        err = np.abs(a - r) / np.maximum(np.abs(r), 1e-2 * np.abs(r).max())
-        # (a stage's input may already differ by one rounding between the two forms: two roundings' worth on the output)
-        assert err.max() <= 4 * ULP and (err > 0).mean() < 0.2, f"g{k} vs gather form: {err.max():.3e}, {(err > 0).mean():.3f} differ"
+        # a stage's input may already differ by one rounding between the two forms; and on small images the gather form runs the
+        # register-staged dgrad + the stand-alone fold kernel, which adds the (already rounded) halo values in bf16 -- its fold targets carry
+        # two roundings + a bf16 add where this kernel (and the DMA-staged kernels' in-tile fold) round the fp32 sum once: held in absolute
+        # terms, as tests/test_gpu_fullsize.py does for the same reason.  (This kernel is the one held to the fp64 definition, above.)
+        err = np.abs(a - r) / np.abs(r).max()
+        assert err.max() <= 2.0 ** -6 and (err > 0).mean() < 0.5, f"g{k} vs gather form: {err.max():.3e}, {(err > 0).mean():.3f} differ"
 
 
 def test_streaming_chain_two_branches_halo_and_slot_views():
@@ -98,17 +101,21 @@ def test_streaming_chain_two_branches_halo_and_slot_views():
     xs, G, ws, F, GF, pk = _setup(n, h, w, 7)
     xs2, G2, ws2, F2, GF2, pk2 = _setup(n, h, w, 8)
     big = T.BT.alloc(n, 8 * 20, h, w, torch.bfloat16, DEV, halo=1, zero=True)
-    big.buf.fill_(5.0)
-    oa, ob = big.view(1, 8), big.view(11, 8)
+    for blk in (0, 9, 10, 19):
+        big.buf[:, blk] = 5.0          # neighbours of the two output slots (the slots' own halo ring stays zero: a halo-1 tensor that is
+    oa, ob = big.view(1, 8), big.view(11, 8)   # not flagged folded is read with fold-on-load, which would add a non-zero ring to the fold targets)
     T.dense_encoder_chain([(GF.view(6, 2), GF.view(0, 6), F.view(0, 6), pk, oa), (GF2.view(6, 2), GF.view(0, 6), F2.view(0, 6), pk2, ob)])
     sa, sb = T.BT.alloc(n, 64, h, w, torch.bfloat16, DEV), T.BT.alloc(n, 64, h, w, torch.bfloat16, DEV)
     T.dense_encoder_chain([(GF.view(6, 2), GF.view(0, 6), F.view(0, 6), pk, sa)])
     T.dense_encoder_chain([(GF2.view(6, 2), GF.view(0, 6), F2.view(0, 6), pk2, sb)])     # glow from the OTHER tensor (GF), g3 from GF2
     torch.cuda.synchronize()
-    assert torch.equal(oa.to_nchw(64), sa.to_nchw(64)) and torch.equal(ob.to_nchw(64), sb.to_nchw(64))
+    assert torch.equal(oa.to_nchw(64), sa.to_nchw(64)), "branch a"
+    assert torch.equal(ob.to_nchw(64), sb.to_nchw(64)), "branch b"
     b = big.buf.float()
-    assert float((b[:, 0] - 5).abs().max()) == 0 and float((b[:, 9:11] - 5).abs().max()) == 0 and float((b[:, 19] - 5).abs().max()) == 0
-    assert float((b[:, 1:9, 0] - 5).abs().max()) == 0 and float((b[:, 1:9, :, -1] - 5).abs().max()) == 0      # halo ring untouched
+    assert float((b[:, [0, 9, 10, 19]] - 5).abs().max()) == 0, "blocks around the slots"
+    for sl in (slice(1, 9), slice(11, 19)):
+        assert float(b[:, sl, 0].abs().max()) == 0 and float(b[:, sl, -1].abs().max()) == 0 and float(b[:, sl, :, 0].abs().max()) == 0 and \
+            float(b[:, sl, :, -1].abs().max()) == 0, "halo ring of the output slots stays zero"
     assert float(sa.to_nchw(64).abs().max()) > 0
     with pytest.raises(RuntimeError):      # in place is refused
         T.dense_encoder_chain([(GF.view(6, 2), GF.view(0, 6), F.view(0, 6), pk, GF.view(0, 8))])

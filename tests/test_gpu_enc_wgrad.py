@@ -157,12 +157,14 @@ def test_gather_form_dgrad_chain_vs_definition_and_scatter_form():
             for mode in ("1", "0"):
                 GF = T.BT.from_nchw(G, torch.bfloat16, halo=1).as_folded()
                 os.environ["MMIF_ENC_CHAIN"] = mode
+                os.environ["MMIF_ENC_CHAIN_STREAM"] = "0"     # (the in-place launches; the streaming kernel: tests/test_gpu_enc_chain.py)
                 __import__("mmif.engine").engine.reload_switches()
                 try:
                     eng._assign_grad_views(torch.device(DEV))
                     eng.enc_bwd(specs, img, F, GF, 0, 0, eng.workspace(torch.device(DEV)), impl)
                 finally:
                     os.environ.pop("MMIF_ENC_CHAIN")
+                    os.environ.pop("MMIF_ENC_CHAIN_STREAM")
                     __import__("mmif.engine").engine.reload_switches()
                 torch.cuda.synchronize()
                 assert float(GF.buf[:, :, 0].float().abs().max()) == 0.0 and float(GF.buf[:, :, :, 0].float().abs().max()) == 0.0   # ring stays zero
