@@ -51,7 +51,8 @@ struct ChainArgs {
     int n, h, w;
     int nstrips, nseg, seg_rows;
     int items;                 // per branch: n * nseg * nstrips
-};
+    int abl;                   // timing ablations ($MMIF_EC_ABLATE, results are garbage): 1 no operand requests after the first two, 2 no
+};                             // output stores, 4 no k-loops
 
 template <int N> struct ECI { static constexpr int value = N; };
 __device__ inline int ec_tap(int i) { return (i % 3) * 3 + i / 3; }   // visit order of the 3x3 taps (conv_mfma.hip visit_tap)
@@ -136,6 +137,7 @@ __global__ __launch_bounds__(EC_WAVES * 64, 2) void enc_chain_bwd_kernel(ChainAr
     auto crow = [&](int y) { return (unsigned)min(max(y, 0), H - 1); };
     // request the global operands of step r (rows clamped into the image: what lies outside is never used)
     auto request = [&](int r, ECPre& S) {
+        if ((A.abl & 1) && r > y_lo) return;
         S.g3v = *reinterpret_cast<const uint4*>(g3_img + (unsigned)cb_a * g3_plane + crow(r + 3) * g3_row + (unsigned)xc_a * 16u + g3_org);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {   // k = 0: dst x2 at row r + 2; 1: dst x1 at r + 1; 2: dst x0 at r
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(EC_WAVES * 64, 2) void enc_chain_bwd_kernel(ChainAr
         acc[1] = (ec_f32x4){0.f, 0.f, 0.f, 0.f};
         // pass 0: the row's own taps.  pass 1 (rows 1 and h-2 only): the adjoint of reflect padding -- padded row -1 (h) received tap row 2 (0)
         // times row 0 (h-1), and folds onto row 1 (h-2)
-        const int npass = (y == 1 || y == H - 2) ? 2 : 1;
+        const int npass = (A.abl & 4) ? 0 : ((y == 1 || y == H - 2) ? 2 : 1);
         for (int pass = 0; pass < npass; ++pass) {
             int rows[3];     // gradient row feeding tap row u, -1 = zero
             if (pass == 0) {
@@ -269,6 +271,7 @@ __global__ __launch_bounds__(EC_WAVES * 64, 2) void enc_chain_bwd_kernel(ChainAr
 #pragma unroll
     for (int i = 0; i < 4; ++i) pend[i] = make_uint4(0, 0, 0, 0);
     auto flush = [&](int rp) {         // rows produced by step rp: g3 copy at rp + 3, g2 at rp + 2, g1 at rp + 1, g0 at rp
+        if (A.abl & 2) return;
         const int ya = rp + 3;
         if (ya >= a_lo && ya < a_hi && ya >= y_lo && ya < y_hi && keep_a)     // [g0 | g1 | g2 | g3] contiguous for the weight-gradient pass
             *reinterpret_cast<uint4*>(out_img + (unsigned)(6 + cb_a) * o_plane + (unsigned)ya * o_row + (unsigned)x_a * 16u + o_org) = pend[0];
@@ -368,6 +371,9 @@ extern "C" int mmif_dense_encoder_chain(const mmif_dense_chain* ca, const mmif_d
     A.n = ca->out->n; A.h = ca->out->h; A.w = ca->out->w;
     ec_geometry(A.n, A.h, A.w, nb, A.nstrips, A.nseg, A.seg_rows);
     A.items = A.n * A.nseg * A.nstrips;
+    static int abl = -1;
+    if (abl < 0) { const char* e = getenv("MMIF_EC_ABLATE"); abl = e != nullptr ? atoi(e) : 0; }
+    A.abl = abl;
     hipLaunchKernelGGL(enc_chain_bwd_kernel, dim3(cdiv(A.items, EC_WAVES), nb), dim3(EC_WAVES * 64), 0, (hipStream_t)stream, A);
     return check_launch("dense_encoder_chain");
 }

@@ -473,18 +473,42 @@ class DenseEncoderMixin:
         return cached[1]
 
     @staticmethod
-    def chain_out(first, F):
+    def chain_out(first, F, slot=0):
         """[g0 | g1 | g2 | g3] of one encoder branch: the streaming chain's output (it is not an in-place kernel), read by the branch's
-        weight-gradient pass right after -- one buffer per encoder (a shared encoder's second branch reuses it: stream order)"""
+        weight-gradient pass afterwards -- one 8-block view per branch slot of a buffer kept with the encoder's first layer"""
         key = (F.n, F.h, F.w, F.buf.device)
         cached = getattr(first, "_gz", None)
         if cached is None or cached[0] != key:
-            cached = (key, BT.alloc(F.n, 64, F.h, F.w, torch.bfloat16, F.buf.device))
+            cached = (key, BT.alloc(F.n, 128, F.h, F.w, torch.bfloat16, F.buf.device))
             first._gz = cached
-        return cached[1]
+        return cached[1].view(8 * slot, 8)
 
     @staticmethod
-    def enc_bwd(specs, img, F, GF, fbase, gbase, ws, impl, accumulate_w=False, onto=None):
+    def chain_streams(specs, F, impl):
+        """this encoder's backward chain runs as the streaming launch (csrc/enc_chain.hip)"""
+        return (F.dtype == torch.bfloat16 and impl != _lib.IMPL_VALU and all(s.k == 3 for s in specs)
+                and [(s.cin, s.cout) for s in specs] == [(1, 16), (16, 16), (32, 16), (48, 16)]
+                and F.h >= 4 and F.w >= 4 and switch("MMIF_ENC_CHAIN") and switch("MMIF_ENC_CHAIN_STREAM"))
+
+    @staticmethod
+    def chain_all(branches, F, GF, impl):
+        """branches: [(specs, fbase, gbase, onto), (...)] -- the backward chains of BOTH encoder branches as ONE streaming launch; returns
+        their [g0 | g1 | g2 | g3] views for enc_bwd(gz=...), or None per branch when the streaming kernel does not apply"""
+        if len(branches) != 2 or not all(DenseEncoderMixin.chain_streams(sp, F, impl) for sp, _, _, _ in branches):
+            return [None] * len(branches)
+        GFf = GF.as_folded()
+        args, outs = [], []
+        for slot, (specs, fbase, gbase, onto) in enumerate(branches):
+            pk = DenseEncoderMixin.chain_images(specs, _lib.BF16)
+            gz = DenseEncoderMixin.chain_out(specs[0], F, slot)
+            glow = onto.view(0, 6) if onto is not None else GFf.view(gbase, 6)
+            args.append((GFf.view(gbase + 6, 2), glow, F.view(fbase, 6), pk, gz))
+            outs.append(gz)
+        T.dense_encoder_chain(args, tag="encode.chain:dgrad")
+        return outs
+
+    @staticmethod
+    def enc_bwd(specs, img, F, GF, fbase, gbase, ws, impl, accumulate_w=False, onto=None, gz=None):
         """GF[gbase:gbase+8] holds dL/d(encoder output) (padded domain), top 2 blocks already masked.
         onto (8-block folded view): blocks 0..5 of GF are NOT initialised -- the chain adds its contributions to onto's blocks
         instead and writes the sums to GF (DenseFuse / VIFNet: both branches start from the one gradient of f1 + f2)."""
@@ -503,13 +527,16 @@ class DenseEncoderMixin:
         gather = (hot or (hot32 and onto is None)) and switch("MMIF_ENC_CHAIN")
         # bf16: the three destinations as ONE streaming launch (csrc/enc_chain.hip: line-buffer pipeline, reflect adjoint in place) that
         # leaves [g0 | g1 | g2 | g3] in a buffer of its own; $MMIF_ENC_CHAIN_STREAM=0: one gather-form dgrad launch per destination, in place
-        gz = GF.view(gbase, 8)
-        if gather and hot and F.h >= 4 and F.w >= 4 and switch("MMIF_ENC_CHAIN_STREAM"):
+        chain_done = gz is not None          # (chain_all ran this branch's chain already, in one launch with the other branch's)
+        if chain_done:
+            pass
+        elif gather and hot and F.h >= 4 and F.w >= 4 and switch("MMIF_ENC_CHAIN_STREAM"):
             pk = DenseEncoderMixin.chain_images(specs, _lib.BF16)
             gz = DenseEncoderMixin.chain_out(first, F)
             glow = onto.view(0, 6) if onto is not None else GF.view(gbase, 6)
             T.dense_encoder_chain([(GF.view(gbase + 6, 2), glow, F.view(fbase, 6), pk, gz)], tag=f"{first.name}.chain:dgrad")
         elif gather:
+            gz = GF.view(gbase, 8)
             pk = DenseEncoderMixin.chain_images(specs, _lib.F32 if hot32 else _lib.BF16)
             for k in (2, 1, 0):
                 gy, xk, dst = GF.view(gbase + 2 * (k + 1), 2 * (3 - k)), F.view(fbase + 2 * k, 2), GF.view(gbase + 2 * k, 2)
@@ -518,13 +545,16 @@ class DenseEncoderMixin:
                                       f"{first.name}.chain{k}:dgrad")
                 else:
                     ModelEngine.tag_dgrad(gy, xk, dst, 16, 16 * (3 - k), pk[k], f"{first.name}.chain{k}:dgrad")
+        if gz is None:
+            gz = GF.view(gbase, 8)
+        scatter = not (gather or chain_done)
         for s, nin in ((c2, 6), (c1, 4), (c0, 2)):
             g = gz.view(nin, 2)
             x = F.view(fbase, nin)
             if not fused:
                 T.conv_wgrad(x, g, s.dw, s.db, s.cin, s.cout, s.k, ws, accumulate_w, impl, s.name + ":wgrad")
             # accumulate into the lower blocks; this conv is the LAST contributor of its top 2 input blocks
-            if not gather:
+            if scatter:
                 ModelEngine.c_dgrad(s, g, x, GF.view(gbase, nin), bits(nin - 2, nin - 1), all_bits(nin), impl)
         if fused:
             T.dense_encoder_wgrad(img, F.view(fbase, 6), gz, [(s.dw, s.db) for s in specs], ws, accumulate_w, tag="encode:wgrad")
@@ -597,8 +627,9 @@ class PFNetv1Engine(ModelEngine, DenseEncoderMixin):
         return grads
 
     def enc_bwd_all(self, img1, img2, F, g, ws, impl):
-        self.enc_bwd(self.enc[0], img1, F, g, 0, 0, ws, impl)
-        self.enc_bwd(self.enc[1], img2, F, g, 8, 8, ws, impl)
+        gz = self.chain_all([(self.enc[0], 0, 0, None), (self.enc[1], 8, 8, None)], F, g, impl)
+        self.enc_bwd(self.enc[0], img1, F, g, 0, 0, ws, impl, gz=gz[0])
+        self.enc_bwd(self.enc[1], img2, F, g, 8, 8, ws, impl, gz=gz[1])
 
 
 class VIFNetEngine(PFNetv1Engine):
@@ -615,8 +646,9 @@ class VIFNetEngine(PFNetv1Engine):
         ModelEngine.__init__(self, module, shared + self.dec)
 
     def enc_bwd_all(self, img1, img2, F, g, ws, impl):
-        self.enc_bwd(self.enc[0], img1, F, g, 0, 0, ws, impl, accumulate_w=False)
-        self.enc_bwd(self.enc[1], img2, F, g, 8, 8, ws, impl, accumulate_w=True)
+        gz = self.chain_all([(self.enc[0], 0, 0, None), (self.enc[1], 8, 8, None)], F, g, impl)
+        self.enc_bwd(self.enc[0], img1, F, g, 0, 0, ws, impl, accumulate_w=False, gz=gz[0])
+        self.enc_bwd(self.enc[1], img2, F, g, 8, 8, ws, impl, accumulate_w=True, gz=gz[1])
 
 
 class DenseFuseEngine(ModelEngine, DenseEncoderMixin):
@@ -698,12 +730,14 @@ class DenseFuseEngine(ModelEngine, DenseEncoderMixin):
             # 'sum' fusion: d(f1 + f2) IS each branch's gradient.  Only the masked top blocks (6,7 / 14,15) are materialised per branch;
             # the chain reads the lower blocks' starting values straight from g ($MMIF_FUSE_SHARE=0: copy them per branch first)
             T.fuse_elem_bwd(F.view(6, 2), F.view(14, 2), g.view(6, 2), GF.view(6, 2), GF.view(14, 2), self.fusion_mode, True)
-            self.enc_bwd(self.enc, img1, F, GF, 0, 0, ws, impl, accumulate_w=False, onto=g)
-            self.enc_bwd(self.enc, img2, F, GF, 8, 8, ws, impl, accumulate_w=True, onto=g)
+            gz = self.chain_all([(self.enc, 0, 0, g), (self.enc, 8, 8, g)], F, GF, impl)
+            self.enc_bwd(self.enc, img1, F, GF, 0, 0, ws, impl, accumulate_w=False, onto=g, gz=gz[0])
+            self.enc_bwd(self.enc, img2, F, GF, 8, 8, ws, impl, accumulate_w=True, onto=g, gz=gz[1])
             return grads
         self.fusion_bwd(L, F, g, GF, ws)
-        self.enc_bwd(self.enc, img1, F, GF, 0, 0, ws, impl, accumulate_w=False)
-        self.enc_bwd(self.enc, img2, F, GF, 8, 8, ws, impl, accumulate_w=True)
+        gz = self.chain_all([(self.enc, 0, 0, None), (self.enc, 8, 8, None)], F, GF, impl)
+        self.enc_bwd(self.enc, img1, F, GF, 0, 0, ws, impl, accumulate_w=False, gz=gz[0])
+        self.enc_bwd(self.enc, img2, F, GF, 8, 8, ws, impl, accumulate_w=True, gz=gz[1])
         return grads
 
     def share_fused_grad(self, g, GF, dtype, impl):
