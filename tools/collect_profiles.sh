@@ -2,7 +2,8 @@
 # copy one round's evidence from gpurun_out/ (scratch, merged back from the GPU box) into profiles/ (tracked):  tools/collect_profiles.sh r03
 tag=$1
 for f in bench_line.json decode_fwd_per_dispatch.txt kernel_stats_bench_pfnetv1_b32_256_bf16.txt kernel_stats_bench_pfnetv1_b32_256_fp32_x3.txt \
-         pmc_sq_bench_pfnetv1_b32_256_bf16.txt pmc_sq_x3.txt pmc_tcc_fetch_size.txt pmc_tcc_write_size.txt traffic.json; do
+         pmc_sq_bench_pfnetv1_b32_256_bf16.txt pmc_sq_x3.txt pmc_tcc_fetch_size.txt pmc_tcc_write_size.txt traffic.json \
+         kernel_stats_nestfuse_b4_512_bf16.txt kernel_stats_rfnnest_b4_512_bf16.txt kernel_stats_densefuse_b32_256_bf16.txt ubench_staging_ablation.txt ubench_chain_ablation.txt; do
   [ -f gpurun_out/${tag}_$f ] && cp gpurun_out/${tag}_$f profiles/${tag}_$f
 done
 if [ -f gpurun_out/${tag}_config_sweep.txt ]; then

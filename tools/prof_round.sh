@@ -15,7 +15,7 @@ print("# conv_dma_kernel<false, 0> dispatches in launch order: decode.0 (128->12
 d0, d1 = d[0::2], d[1::2]
 print("decode.0 fwd:", " ".join(f"{v:.1f}" for v in d0), f"| mean {sum(d0) / len(d0):.1f}")
 print("decode.1 fwd:", " ".join(f"{v:.1f}" for v in d1), f"| mean {sum(d1) / len(d1):.1f}")
-for pat, nm in (("conv_dma_kernel<true", "dgrad decode.0 / decode.1"), ("wgrad_dma_kernel", "wgrad decode.0 / decode.1")):
+for pat, nm in (("conv_dma_kernel<true", "dgrad decode.1 / decode.0"), ("wgrad_dma_kernel", "wgrad decode.1 / decode.0")):   # (the backward runs decode.1 first)
     d = [(e - s) / 1e3 for n, s, e in rows if pat in n]
     if d:
         a, b = d[0::2], d[1::2]
