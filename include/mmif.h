@@ -110,6 +110,13 @@ int mmif_pack_weights_multi(const mmif_pack_job* jobs, int32_t n_jobs, void* str
  * $MMIF_X3_FWD_PIECES; set it BEFORE packing: the forward kernel reads the image in the current format. */
 void mmif_set_x3_forward_pieces(int32_t pieces);
 int32_t mmif_get_x3_forward_pieces(void);
+/* 1 when fp32 tensors are taken by the split-operand kernels ($MMIF_X3 != 0, read once per process); what a caller that plans launches
+ * around them (sign-map backward, fused encoder weight gradients) must consult instead of the environment. */
+int32_t mmif_get_x3_enabled(void);
+/* How many weight values the scaled-fp16 forward operand images (forward pieces = 16: the default) CLAMPED since the last reset: the fixed 2^10
+ * weight scale holds |w| < ~63.5.  Synchronises the device: call after loading / initialising weights, never per step.  > 0 means the
+ * fp32 forward is not parity-grade for those layers -- use mmif_set_x3_forward_pieces(3).  reset != 0 clears the counter.  -1 on error. */
+int32_t mmif_x3_pack_saturations(int32_t reset);
 size_t mmif_packed_weight_bytes_x3(int32_t cout, int32_t cin, int32_t ksize);
 int mmif_pack_weights_x3(const float* w, int32_t cout, int32_t cin, int32_t ksize, void* packed_fwd, void* packed_dgrad, void* stream);
 

@@ -64,6 +64,8 @@ struct X3PackTable { X3PackImage im[X3_PACK_MAX]; };
 
 // dgrad == 0: out = o, in = c, Wk[u][v] = W[o][c][u][v];  dgrad == 1: out = c, in = o, Wk[u][v] = W[o][c][2-u][2-v]
 // image: [m-block][chunk][piece 0 .. pieces-1][tap][channel block of the chunk][32*MB out][8 in]
+__device__ unsigned g_x3_sat_count = 0;   // weights clamped by the fp16 operand split since the last reset
+
 __global__ void x3_pack_kernel(X3PackTable tab) {
     const X3PackImage& J = tab.im[blockIdx.y];
     const int n_out = J.dgrad ? J.cin : J.cout, n_in = J.dgrad ? J.cout : J.cin;
@@ -94,6 +96,9 @@ __global__ void x3_pack_kernel(X3PackTable tab) {
         const long long within = ((long long)(tap * 2 + cbl) * J.mbw + ocl) * 8 + e;
         const long long base = ((long long)mb * J.nch + ch) * J.pieces * piece;
         if (J.f16) {   // two fp16 pieces of 2^10 w (saturating), see x3_split_pair_h
+            // a weight with |w| >= ~63.5 does not fit the fixed 2^10 scale: it is clamped, and COUNTED (mmif_x3_pack_saturations) -- the
+            // fp32 path is the parity-grade path, a silently saturated forward defeats its purpose
+            if (fabsf(val * X3_SW) > X3_HMAX) atomicAdd(&g_x3_sat_count, 1u);
             val = fminf(fmaxf(val * X3_SW, -X3_HMAX), X3_HMAX);
             const unsigned short h = x3_f16_bits(val);
             J.dst[base + within] = h;
@@ -1599,6 +1604,21 @@ using namespace mmif;
 
 extern "C" void mmif_set_x3_forward_pieces(int32_t pieces) { g_fwd_pieces = x3_norm_mode(pieces); }
 extern "C" int32_t mmif_get_x3_forward_pieces(void) { return x3_fwd_pieces(); }
+// 1 when fp32 tensors take the split-operand kernels ($MMIF_X3, read ONCE per process by the library): callers that plan their launches
+// (the Python engine) ask here instead of re-reading the environment, so the two can never disagree
+// number of weight values the scaled-fp16 forward images clamped (|w| >= 65000 / 2^10) since the last reset; SYNCHRONISES the device -- call it
+// after loading / initialising weights, not per step.  A non-zero count means the fp32 forward is wrong for those weights: switch the layer
+// to mmif_set_x3_forward_pieces(3) (bf16 pieces carry fp32's exponent range).
+extern "C" int32_t mmif_x3_pack_saturations(int32_t reset) {
+    unsigned v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_x3_sat_count), sizeof(v)) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    if (reset) {
+        const unsigned z = 0;
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_x3_sat_count), &z, sizeof(z));
+    }
+    return (int32_t)(v > 0x7fffffffu ? 0x7fffffff : v);
+}
+extern "C" int32_t mmif_get_x3_enabled(void) { return x3_enabled() ? 1 : 0; }
 
 extern "C" size_t mmif_packed_weight_bytes_x3(int32_t cout, int32_t cin, int32_t ksize) { return conv_x3_packed_bytes(cout, cin, ksize); }
 

