@@ -26,6 +26,10 @@ _cfg = _Cfg()
 
 # base data_ptr -> flat gradient buffer (lets mmif.optim find the buffer behind a parameter's .grad view)
 FLAT_BUFFERS = {}
+# None, or a list that ModelEngine.run() fills with (parameter, stand-in leaf) pairs: while set, the autograd node of a forward hangs off
+# fresh leaves instead of the parameters, so that the gradients are accumulated by AccumulateGrad nodes created NOW, on the current
+# stream (a parameter's own accumulator lives -- bound to the stream it was created on -- as long as any older autograd graph does)
+FRESH_LEAVES = [None]
 # bumped by every fused optimiser step: the packed bf16 weight images must be rebuilt
 WEIGHTS_EPOCH = [0]
 GRAD_TAIL = 8  # scalar slots after the gradients (loss values ride along in the gradient all-reduce)
@@ -323,7 +327,11 @@ class ModelEngine:
         ps = self.params()
         need_grad = torch.is_grad_enabled() and (any(p.requires_grad for p in ps) or img1.requires_grad)
         if need_grad:
-            return _EngineFn.apply(self, img1, img2, *ps)
+            leaves = ps
+            if FRESH_LEAVES[0] is not None:      # graph capture (mmif/graph.py): fresh leaf identities, their gradients handed over by the caller
+                leaves = [p.detach().requires_grad_(p.requires_grad) for p in ps]
+                FRESH_LEAVES[0].extend(zip(ps, leaves))
+            return _EngineFn.apply(self, img1, img2, *leaves)
         with torch.no_grad():
             out, lease = self.forward(img1, img2)
             lease.busy = False
@@ -619,7 +627,7 @@ class PFNetv1Engine(ModelEngine, DenseEncoderMixin):
         last = self.dec[-1]
         out = torch.empty((n, 1, h, w), dtype=torch.float32, device=dev)
         T.image_out_fwd(x, last.w.detach(), last.b.detach(), out, last.cin, last.k, last.relu)
-        L.out = out if last.relu else None
+        L.out = out.detach() if last.relu else None     # (an alias: the returned object gets a grad_fn, which must not be kept alive by the lease)
         return out, L
 
     def backward(self, L, gout):
@@ -714,7 +722,7 @@ class DenseFuseEngine(ModelEngine, DenseEncoderMixin):
         last = self.dec[-1]
         out = torch.empty((n, 1, h, w), dtype=torch.float32, device=dev)
         T.image_out_fwd(x, last.w.detach(), last.b.detach(), out, last.cin, last.k, last.relu)
-        L.out = out if last.relu else None
+        L.out = out.detach() if last.relu else None     # (an alias: the returned object gets a grad_fn, which must not be kept alive by the lease)
         return out, L
 
     def backward(self, L, gout):

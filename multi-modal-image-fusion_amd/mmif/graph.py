@@ -25,6 +25,7 @@ class GraphedStep:
             optimizer.prepare()                                    # FusedClipAdam moves the parameters into one flat buffer: before capture
         # data parallel: the warm-up backwards below have no optimizer step and the captured backward must not contain a collective:
         # no early gradient all-reduce from here to the end of the capture (the next eager optimizer step re-arms it)
+        self.params = [p for p in model.parameters() if p.requires_grad]
         D.arm_early_reduce(False)
         D.drain_early()
         cur = torch.cuda.current_stream()
@@ -33,8 +34,8 @@ class GraphedStep:
         with torch.cuda.stream(side):                              # eager steps on a side stream: lazy init, buffer leases, allocator
             for _ in range(max(1, warmup)):
                 optimizer.zero_grad(set_to_none=True)
-                outs = loss_fn(self.img1, self.img2, model(self.img1, self.img2))
-                outs[0].backward()
+                outs = loss_fn(self.img1, self.img2, self._forward())
+                self._backward(outs[0])
         cur.wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
@@ -43,14 +44,35 @@ class GraphedStep:
         # them stale now so that the captured forward CONTAINS the re-pack launch -- a replay never runs the host-side check
         E.WEIGHTS_EPOCH[0] += 1
         with torch.cuda.graph(self.graph):
-            self.imgf = model(self.img1, self.img2)
+            self.imgf = self._forward()
             self.outs = tuple(loss_fn(self.img1, self.img2, self.imgf))
-            self.outs[0].backward()
+            self._backward(self.outs[0])
         # the gradient tensors the captured backward writes; an eager step in between (ragged last batch, another shape)
         # re-points p.grad elsewhere, so every replay hands these back to the optimiser
         D.drain_early()
-        self.params = [p for p in model.parameters() if p.requires_grad]
         self.grads = [p.grad for p in self.params]
+
+    def _forward(self):
+        E.FRESH_LEAVES[0] = self._leaves = []
+        try:
+            return self.model(self.img1, self.img2)
+        finally:
+            E.FRESH_LEAVES[0] = None
+
+    def _backward(self, total):
+        """total.backward() onto fresh leaves.  A parameter's AccumulateGrad node runs on the stream that was current when it was created
+        and lives as long as any autograd graph that reaches the parameter -- a loss tensor of an earlier eager step that the caller
+        still holds is enough.  Such a node runs on the DEFAULT stream, which then joins the capture through the autograd engine's event
+        waits, and hipStreamEndCapture of this ROCm crashes on a null stream among the capture's parallel streams (SIGSEGV in
+        hip::Stream::EndCapture; round 4: bench.py --model NestFuse --graph).  The engine models therefore hang their autograd node off
+        stand-in leaves while E.FRESH_LEAVES is set (mmif/engine.py: ModelEngine.run): their accumulators are born on the current
+        stream and adopt the engine's gradient views without a copy, and the views are handed to the parameters here.  (Layer-wise
+        models, core/block.py, use their parameters directly: for those the old rule of torch's graph capture holds -- no autograd graph
+        of an earlier default-stream step may be alive.)"""
+        total.backward()
+        for p, q in self._leaves:
+            p.grad = q.grad
+        self._leaves.clear()
 
     def matches(self, img1, img2):
         return img1.shape == self.img1.shape and img2.shape == self.img2.shape and img1.dtype == self.img1.dtype

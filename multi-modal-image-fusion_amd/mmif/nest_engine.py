@@ -118,7 +118,7 @@ class NestEngine(ModelEngine):
             self._db_fwd(L, name, row, nf, src, dst, impl)
         out = torch.empty((n, 1, h, w), dtype=torch.float32, device=dev)
         T.image_out_fwd(X13, self.conv_out.w.detach(), self.conv_out.b.detach(), out, c[0], self.conv_out.k, self.conv_out.relu)
-        L.out = out if self.conv_out.relu else None
+        L.out = out.detach() if self.conv_out.relu else None     # (an alias without the grad_fn the returned object gets)
         return out, L
 
     def _row_in(self, L, row, nf):

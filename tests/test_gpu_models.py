@@ -362,6 +362,57 @@ def test_graphed_step_equals_eager_step():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["PFNetv1", "NestFuse", "RFNNest"])
+def test_graphed_step_after_eager_steps_with_live_loss_tensors(name):
+    """Round 4: bench.py --model NestFuse --graph died with SIGSEGV inside hipStreamEndCapture.  Eager optimiser steps on the default
+    stream BEFORE the capture leave AccumulateGrad nodes bound to that stream for as long as anything reaches the old autograd graph (a
+    loss tensor the caller still holds; until round 4 also the engine's own lease, through the output image it kept); the captured
+    backward then ran them on the null stream, which joined the capture.  GraphedStep now differentiates with torch.autograd.grad:
+    capture after eager steps -- old losses deliberately kept alive -- works, and a replay produces the eager step's gradients bit for bit."""
+    import core.model as M
+    from core.loss import FusionLoss, GradLoss, PixelLoss, SSIMLoss
+    from mmif.graph import GraphedStep
+    from mmif.optim import FusedClipAdam
+    dev = torch.device("cuda", 0)
+    with dtype_ctx("bf16"):
+        torch.manual_seed(4)
+        model = getattr(M, name)().to(dev)
+        opt = FusedClipAdam(model.parameters(), lr=1e-4, betas=(0.9, 0.999), max_norm=5.0)
+        fl = FusionLoss(SSIMLoss('ssim', weight=1.0), PixelLoss('l1', weight=0.01), GradLoss('l1', weight=0.1).to(dev), 'max', 'max')
+
+        def losses(a, b, f):
+            tot = fl(a, b, f)
+            return (tot,) + tuple(fl.values[1:4].unbind(0))
+        g = torch.Generator(device="cpu").manual_seed(6)
+        a, b = torch.rand(2, 1, 64, 96, generator=g).to(dev), torch.rand(2, 1, 64, 96, generator=g).to(dev)
+        keep = []
+        for _ in range(2):
+            opt.zero_grad(set_to_none=True)
+            ls = losses(a, b, model(a, b))
+            ls[0].backward()
+            opt.step(scalars=list(ls))
+            keep.append(ls)                                     # the old graphs stay reachable
+        gs = GraphedStep(model, losses, opt, a, b)
+        outs = gs(a, b, step_optimizer=False)
+        torch.cuda.synchronize()
+        got = [None if p.grad is None else p.grad.clone() for p in model.parameters()]
+        got_l = [float(o.detach()) for o in outs]
+        opt.zero_grad(set_to_none=True)
+        ls = losses(a, b, model(a, b))
+        ls[0].backward()
+        torch.cuda.synchronize()
+        assert got_l == [float(o.detach()) for o in ls]
+        n = 0
+        for p, q in zip(model.parameters(), got):
+            assert (p.grad is None) == (q is None)
+            if q is not None:
+                assert torch.equal(p.grad, q)
+                n += int(q.abs().max() > 0)
+        assert n > 10
+        del keep
+
+
+@pytest.mark.gpu
 def test_fused_clip_adam_with_unused_parameters_matches_torch_adam():
     """PMGI never calls transfer1[1] (reference core/model.py:589): those parameters have no gradient.  torch.optim.Adam skips them;
     FusedClipAdam must leave them untouched too and update the rest exactly like clip_grad_norm_(5) + Adam."""
