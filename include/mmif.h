@@ -107,7 +107,9 @@ int mmif_pack_weights_multi(const mmif_pack_job* jobs, int32_t n_jobs, void* str
  * pieces, six products, the same accuracy on bf16's own range at twice the forward MFMA work;  2 = two bf16 pieces, three products, activations within
  * ~1e-5 (a mask flip on a pre-activation that close to zero moves parameter gradients by O(1e-3)).  The dgrad image always has two bf16
  * pieces (the backward kernels are linear in the gradient: no decisions to protect).  Process-wide setting, also
- * $MMIF_X3_FWD_PIECES; set it BEFORE packing: the forward kernel reads the image in the current format. */
+ * $MMIF_X3_FWD_PIECES.  It selects the format of the NEXT packs: the library remembers the format each forward image was packed in
+ * (by device address) and a forward launch reads the image in THAT format, whatever the setting is by then (round 4; an image packed by
+ * another process / library instance is read in the current setting). */
 void mmif_set_x3_forward_pieces(int32_t pieces);
 int32_t mmif_get_x3_forward_pieces(void);
 /* 1 when fp32 tensors are taken by the split-operand kernels ($MMIF_X3 != 0, read once per process); what a caller that plans launches

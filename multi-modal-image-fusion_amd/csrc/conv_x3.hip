@@ -29,6 +29,8 @@
 // wgrad_x3_thin_kernel: the same for <= 48 input / <= 16 output channels: four-wave blocks, 3-5 per CU, 16x16x32 MFMAs.
 #include "common.hpp"
 #include <stdlib.h>
+#include <mutex>
+#include <unordered_map>
 
 namespace mmif {
 
@@ -1389,6 +1391,22 @@ int x3_fwd_pieces() {
     return g_fwd_pieces;
 }
 
+// The format of every forward operand image this process has packed, by device address: the forward launches dispatch on the IMAGE's
+// format, not on the process-wide mode -- a mode change between a pack and a later forward (mmif_set_x3_forward_pieces without a re-pack;
+// ADVICE r3) can no longer make a kernel read fp16 pieces as bf16 pieces.  Host-side, in call order = stream order; a replayed hipGraph
+// carries its own pack + forward launches with the format they were captured in.  An address never packed here falls back to the mode.
+static std::mutex g_fmt_mu;
+static std::unordered_map<const void*, int> g_fwd_fmt;
+static void x3_note_format(const void* img, int pieces) {
+    std::lock_guard<std::mutex> lk(g_fmt_mu);
+    g_fwd_fmt[img] = pieces;
+}
+static int x3_image_format(const void* img) {
+    std::lock_guard<std::mutex> lk(g_fmt_mu);
+    auto it = g_fwd_fmt.find(img);
+    return it != g_fwd_fmt.end() ? it->second : x3_fwd_pieces();
+}
+
 size_t conv_x3_packed_bytes(int cout, int cin, int ks) {
     if (ks != 3 && ks != 1) return 16;
     const size_t a = x3_packed_bytes(cout, cin, 3, ks), b = x3_packed_bytes(cin, cout, 2, ks);   // (room for either forward format)
@@ -1416,6 +1434,7 @@ int conv_x3_pack_multi(const mmif_pack_job* jobs, int n_jobs, hipStream_t st) {
             im.mbw = 32 * x3_mb(n_out); im.nch = x3_nch(n_in); im.ks = jb.ksize;
             im.f16 = (!d && x3_fwd_pieces() == 16) ? 1 : 0;
             im.pieces = (d || im.f16) ? 2 : x3_fwd_pieces();
+            if (!d) x3_note_format(dst, x3_fwd_pieces());
             im.total = (long long)x3_nmb(n_out) * im.nch * jb.ksize * jb.ksize * 2 * im.mbw * 8;   // elements of the first piece's images
             if (n == X3_PACK_MAX)
                 if (int rc = flush()) return rc;
@@ -1451,7 +1470,8 @@ static int launch_conv_x3(bool dgrad, const TV& tin, const TV& tout, const TV& t
 int conv_x3(bool dgrad, const TV& tin, const TV& tout, const TV& tmask, const void* wpk, const float* bias, int cin, int cout, int relu,
             uint64_t mask_bits, uint64_t accum_bits, hipStream_t st, int ks, const unsigned* signs) {
     const int n_out = dgrad ? cin : cout, n_in = dgrad ? cout : cin;
-    const bool six = !dgrad && x3_fwd_pieces() == 3, h16 = !dgrad && x3_fwd_pieces() == 16;
+    const int fmt = dgrad ? 2 : x3_image_format(wpk);
+    const bool six = !dgrad && fmt == 3, h16 = !dgrad && fmt == 16;
 #define X3_ARGS tin, tout, tmask, wpk, bias, n_out, n_in, relu, mask_bits, accum_bits, st, signs
     if (ks == 1) {
         if (x3_mb(n_out) == 2) {

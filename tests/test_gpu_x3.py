@@ -403,3 +403,38 @@ def test_out_of_range_weights_switch_the_forward_to_bf16_pieces():
     finally:
         E.set_x3_forward_pieces(16)
         lib.mmif_x3_pack_saturations(1)
+
+
+def test_forward_dispatches_on_the_format_the_image_was_packed_in():
+    """mmif_set_x3_forward_pieces used to change how EVERY later forward read its operand image, also images packed in
+    the old format (fp16 pieces read as bf16 pieces = garbage).  The library now remembers each forward image's format at pack time and the
+    launch follows the image: a mode change without a re-pack leaves the result bit-identical; after a re-pack the new format is used
+    (a different kernel: equal within the formats' common 1e-6)."""
+    from mmif import tensor as T
+    from mmif._lib import F32, IMPL_X3, lib
+    torch.manual_seed(11)
+    cin, cout, n, h, w = 32, 64, 1, 20, 36
+    x = T.BT.from_nchw(torch.randn(n, cin, h, w).to(DEV), torch.float32)
+    wt = (torch.randn(cout, cin, 3, 3) * 0.1).to(DEV)
+    b = torch.randn(cout).to(DEV)
+    assert lib.mmif_get_x3_forward_pieces() == 16
+    try:
+        pk = T.PackedWeights(cout, cin, 3, DEV, fmt=F32)
+        pk.pack(wt)
+        outs = []
+        for mode in (16, 3, 2, 16):
+            lib.mmif_set_x3_forward_pieces(mode)                 # (the raw entry point: no epoch bump, no re-pack)
+            y = T.BT.alloc(n, cout, h, w, torch.float32, DEV)
+            T.conv_fwd(x, wt, b, y, cin, cout, 3, True, pk, IMPL_X3)
+            torch.cuda.synchronize()
+            outs.append(y.to_nchw(cout).clone())
+        for o in outs[1:]:
+            assert torch.equal(o, outs[0]), "a mode change without a re-pack must not change how the image is read"
+        lib.mmif_set_x3_forward_pieces(3)
+        pk.pack(wt)
+        y = T.BT.alloc(n, cout, h, w, torch.float32, DEV)
+        T.conv_fwd(x, wt, b, y, cin, cout, 3, True, pk, IMPL_X3)
+        torch.cuda.synchronize()
+        close(y.to_nchw(cout).cpu().numpy(), outs[0].cpu().numpy(), 2e-6, "three bf16 pieces vs scaled fp16 pieces")
+    finally:
+        lib.mmif_set_x3_forward_pieces(16)
