@@ -487,6 +487,9 @@ void mmif_debug_set_conv_dma(int32_t mode);
 /* 1 (default, also $MMIF_CONV1X1_STREAM) = bf16 1x1 layers (forward, dgrad without an accumulate operand) on the streaming kernel of
  * csrc/conv1x1.hip; 0 = the register-staged conv_mfma_kernel<1, ...>.  Bit-identical results either way. */
 void mmif_debug_set_conv1x1_stream(int32_t mode);
+/* mmif_conv2d_reflect_bwd_pair: 1 (default, $MMIF_BWD_PAIR_DMA) = tiles staged by a loader wave's LDS-DMA into a double-buffered tile
+ * (bwd_pair_dma_kernel, round 4), 0 = the register-staged kernel; bit-identical results (tests/test_gpu_bwd_pair.py). */
+void mmif_debug_set_bwd_pair_dma(int32_t mode);
 
 #ifdef __cplusplus
 }

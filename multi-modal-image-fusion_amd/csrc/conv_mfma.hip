@@ -2040,9 +2040,251 @@ __global__ __launch_bounds__(512, NXB == 4 ? 1 : 2) void bwd_pair_kernel(TV tx, 
     for (int e = tid; e < PER; e += 512) dst[e] = red[e];
 }
 
+// ---- round 4: the same kernel with its tiles staged by LDS-DMA.  bwd_pair_kernel fetches the next tile into registers (9 granules per
+// thread), and every tile pays two block barriers around the register -> LDS copy with no MFMA running (SQ counters: the matrix pipe busy
+// ~40 % of the launch, 12.9 k cycles per tile against 5.4 k of MFMAs on the busiest SIMD).  Here wave 7 is a LOADER: it requests tile
+// k + 1 straight into the other half of a double-buffered LDS tile (global_load_lds, 61 / 31 one-KiB pieces) while waves 0..6 work on tile
+// k -- ONE barrier per tile, no staging registers.  (The loader must be a wave that reads no LDS: with DMA in flight the compiler drains
+// vmcnt before any LDS access of that wave.)  The bias sums moved into the tap-row-1 wave, which already holds the transposed gradient
+// fragments (same MFMA(a, ones) sequence => bit-identical); dgrad / wgrad k-loops, fold steps and epilogue are bwd_pair_kernel's.
+// LDS: 2 x 61 KiB + 36 KiB image = 158 KiB (<4, 2>: one block per CU), 2 x 31 KiB + 10 KiB (<2, 1>: two blocks per CU).
+template <int NXB, int NGB>
+__global__ __launch_bounds__(512, NXB == 4 ? 1 : 2) void bwd_pair_dma_kernel(TV tx, TV tg, TV tgx, const uint4* __restrict__ wpk, float* __restrict__ partial,
+                                                                             int tiles_x, int tpi, int total, int G, int abl) {
+    constexpr int MF = NXB, TP = MT + 2;
+    constexpr int CIN = 16 * NXB, COUT = 16 * NGB;
+    constexpr int NCB = 2 * NGB;
+    constexpr int NKG = 9 * NCB, NKGP = (NKG + 3) / 4 * 4;
+    constexpr int WBYTES = NKGP * MF * 256;
+    constexpr int PER = COUT * CIN * 9 + COUT;
+    constexpr int NX = 2 * NXB * BP_PL, NT = NX + NCB * BP_PL;   // granules of the x planes / of a whole tile (x planes, then g planes)
+    constexpr int NP = (NT + 63) / 64;                            // DMA pieces per tile
+    constexpr int BUF_BYTES = NP * 1024;
+    constexpr int TILE_BYTES = 2 * BUF_BYTES + WBYTES;
+    constexpr int SM_BYTES = TILE_BYTES > PER * 4 ? TILE_BYTES : PER * 4;
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    __shared__ __attribute__((aligned(16))) char smem[SM_BYTES];
+    __shared__ int2 s_tab[NKGP];
+    char* s_w = smem + 2 * BUF_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    const int gi = blockIdx.x;
+    const int H = tx.h, W = tx.w;
+    for (int e = tid; e < WBYTES / 16; e += 512) reinterpret_cast<uint4*>(s_w)[e] = wpk[e];
+    if (tid < NKGP) {
+        int tap = 0, cb = 0, plane = tid;
+        if (tid < NKG) { tap = visit_tap(tid / NCB, 3); cb = tid % NCB; plane = tap * NCB + cb; }
+        s_tab[tid] = make_int2((cb * BP_PL + (tap / 3) * TP + (tap % 3)) * 16, plane * MF * 256);
+    }
+    const TileWalk tw = xcd_walk(total, G, gi);
+    float* red = reinterpret_cast<float*>(smem);
+    if (wave == 7) {
+        // ---------------- loader: tile-independent part of every granule this lane requests (plane << 16 | tile row << 8 | tile column)
+        unsigned pk[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int e = min(i * 64 + lane, NT - 1);   // (the last piece's spare lanes re-request the last granule into the buffer's padding)
+            const int cb = e / BP_PL, p = e - cb * BP_PL;
+            pk[i] = (unsigned)(cb << 16 | (p / TP) << 8 | (p % TP));
+        }
+        const unsigned xplane = (unsigned)tx.plane, gplane = (unsigned)tg.plane;
+        const unsigned xcb0 = (unsigned)tx.cb_off * xplane, gcb0 = (unsigned)tg.cb_off * gplane;
+        auto issue = [&](int tile, int sel) {
+            const int in_ = tile / tpi, tt = tile - in_ * tpi;
+            const int y0 = (tt / tiles_x) * MT, x0 = (tt % tiles_x) * MT;
+            const char* xb = tx.base + (long long)in_ * tx.img * 16;
+            const char* gb = tg.base + (long long)in_ * tg.img * 16;
+            char* dst = smem + sel * BUF_BYTES;
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const bool all_x = i * 64 + 63 < NX, all_g = i * 64 >= NX;
+                const unsigned cb = pk[i] >> 16;
+                const int r = (int)((pk[i] >> 8) & 255u), c = (int)(pk[i] & 255u);
+                unsigned offx = 0u, offg = 0u;
+                if (!all_g) {   // x: reflect halo
+                    const int y = min(max(reflect_idx(y0 + r - 1, H), 0), H - 1);
+                    const int x = min(max(reflect_idx(x0 + c - 1, W), 0), W - 1);
+                    offx = xcb0 + cb * xplane + (unsigned)(y + tx.halo) * (unsigned)tx.ws + (unsigned)(x + tx.halo);
+                }
+                if (!all_x) {   // g in STORED coordinates (halo 1, folded): rows / columns past the stored domain read its zero ring
+                    const int ys = min(y0 + r, tg.hs - 1), xs = min(x0 + c, tg.ws - 1);
+                    offg = gcb0 + (cb - (unsigned)(2 * NXB)) * gplane + (unsigned)ys * (unsigned)tg.ws + (unsigned)xs;
+                }
+                const char* src = all_x ? xb + (unsigned long long)offx * 16u
+                                        : (all_g ? gb + (unsigned long long)offg * 16u
+                                                 : (cb < (unsigned)(2 * NXB) ? xb + (unsigned long long)offx * 16u : gb + (unsigned long long)offg * 16u));
+                __builtin_amdgcn_global_load_lds(MMIF_GPTR(src), MMIF_LPTR(dst + i * 1024), 16, 0, 0);
+            }
+        };
+        if (tw.count > 0) issue(tw.first, 0);
+        for (int it = 0, tile = tw.first; it < tw.count; ++it, tile += tw.stride) {
+            __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): tile `it` has landed
+            __syncthreads();                      // ... and everybody is done with tile it - 1 (the other buffer)
+            if (it + 1 < tw.count && !(abl & 1)) issue(tile + tw.stride, (it + 1) & 1);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        __syncthreads();
+    } else if (wave < 4) {
+        // ---------------- dgrad: rows 4 wave .. 4 wave + 3 of every tile, all MF m-fragments
+        for (int it = 0, tile = tw.first; it < tw.count; ++it, tile += tw.stride) {
+            __syncthreads();
+            const u32x4* s_x = reinterpret_cast<const u32x4*>(smem + (it & 1) * BUF_BYTES);
+            const u32x4* s_g = s_x + NX;
+            const int in_ = tile / tpi, tt = tile - in_ * tpi;
+            const int ty0 = tt / tiles_x, tx0 = tt % tiles_x;
+            f32x4 acc[MF][4];
+#pragma unroll
+            for (int m = 0; m < MF; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const char* in_lane = reinterpret_cast<const char*>(s_g) + ((wave * 4) * TP + j) * 16;
+            const char* w_lane = s_w + j * 16;
+            // k-loop, software pipelined: the fragments of k-step s + 1 are requested before the MFMAs of step s (two waves per SIMD do not
+            // hide an LDS round trip per step: the un-pipelined loop ran the matrix pipe 44 % of its time)
+            constexpr int NS = NKGP / 4;
+            bf16x8 a[2][MF], b[2][4];
+            {
+                const int2 off = s_tab[g];
+#pragma unroll
+                for (int m = 0; m < MF; ++m) a[0][m] = *reinterpret_cast<const bf16x8*>(w_lane + off.y + m * 256);
+#pragma unroll
+                for (int n = 0; n < 4; ++n) b[0][n] = *reinterpret_cast<const bf16x8*>(in_lane + off.x + n * TP * 16);
+            }
+            if (!(abl & 8))
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                if (s + 1 < NS) {
+                    const int2 off = s_tab[4 * (s + 1) + g];
+#pragma unroll
+                    for (int m = 0; m < MF; ++m) a[(s + 1) & 1][m] = *reinterpret_cast<const bf16x8*>(w_lane + off.y + m * 256);
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) b[(s + 1) & 1][n] = *reinterpret_cast<const bf16x8*>(in_lane + off.x + n * TP * 16);
+                }
+#pragma unroll
+                for (int m = 0; m < MF; ++m)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s & 1][m], b[s & 1][n], acc[m][n], 0, 0, 0);
+            }
+            if (!(abl & 32)) {
+                const int gc = min(g, NCB - 1);
+                dgrad_fold_steps<MF, 1>(acc, in_lane + gc * (BP_PL * 16), w_lane + gc * (MF * 256), NCB, TP, g, j, ty0 * MT + wave * 4, tx0 * MT, tgx.hs, tgx.ws);
+            }
+            const int oxs = 1 + tx0 * MT + j;
+#pragma unroll
+            for (int m = 0; m < MF; ++m) {
+                if (abl & 16) break;
+                const int ocb = 2 * m + (g >> 1);
+                char* oplane = tgx.base + ((long long)in_ * tgx.img + (long long)(tgx.cb_off + ocb) * tgx.plane) * 16;
+#pragma unroll
+                for (int p2 = 0; p2 < 2; ++p2) {
+                    float c[8];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[m][2 * p2][r]), __float_as_uint(acc[m][2 * p2 + 1][r]), false, false);
+                        c[r] = __uint_as_float(sw[0]);
+                        c[4 + r] = __uint_as_float(sw[1]);
+                    }
+                    const int row = wave * 4 + (g & 1) + 2 * p2;
+                    const int oys = 1 + ty0 * MT + row;
+                    if (oys >= tgx.hs - 1 || oxs >= tgx.ws - 1 || (abl & 2)) continue;
+                    const u32x4 xm = s_x[ocb * BP_PL + (row + 1) * TP + j + 1];
+                    const uint32_t xw[4] = {xm.x, xm.y, xm.z, xm.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (!((short)(xw[i] & 0xffffu) > 0)) c[2 * i] = 0.f;
+                        if (!((short)(xw[i] >> 16) > 0)) c[2 * i + 1] = 0.f;
+                    }
+                    *reinterpret_cast<uint4*>(oplane + ((long long)oys * tgx.ws + oxs) * 16) =
+                        make_uint4(pack_bf16x2(c[0], c[1]), pack_bf16x2(c[2], c[3]), pack_bf16x2(c[4], c[5]), pack_bf16x2(c[6], c[7]));
+                }
+            }
+        }
+        __syncthreads();
+    } else {
+        // ---------------- wgrad, tap row u (waves 4..6); the tap-row-1 wave also sums the bias gradient from its g fragments
+        const int u = wave - 4;
+        const bf16x8 ones = __builtin_bit_cast(bf16x8, make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u));
+        const int tr_row = j >> 2, tr_c = j & 3;
+        const int lane_plane = tr_c >> 1, lane_byte = (tr_c & 1) * 8;
+        auto tr_frag = [&](const char* base) {
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, base));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, base + 4 * 16));
+            const s16x8 c = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            return __builtin_bit_cast(bf16x8, c);
+        };
+        f32x4 wacc[3][NXB][NGB], accb[NGB];
+#pragma unroll
+        for (int m = 0; m < NGB; ++m) accb[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int v = 0; v < 3; ++v)
+#pragma unroll
+            for (int b = 0; b < NXB; ++b)
+#pragma unroll
+                for (int m = 0; m < NGB; ++m) wacc[v][b][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int it = 0, tile = tw.first; it < tw.count; ++it, tile += tw.stride) {
+            __syncthreads();
+            const char* s_x = smem + (it & 1) * BUF_BYTES;
+            const char* s_g = s_x + NX * 16;
+            // 24 groups (pixel-row pair s, tap column v) of NXB x NGB MFMAs, software pipelined: the x fragments of group i + 1 (and the g
+            // fragments of the next row pair) are requested before the MFMAs of group i
+            const char* xl = s_x + (lane_plane * BP_PL + ((g >> 1) + u) * TP + 8 * (g & 1) + tr_row) * 16 + lane_byte;
+            const char* gl = s_g + (lane_plane * BP_PL + ((g >> 1) + 1) * TP + 8 * (g & 1) + 1 + tr_row) * 16 + lane_byte;
+            bf16x8 a[2][NGB], bx[2][NXB];
+#pragma unroll
+            for (int m = 0; m < NGB; ++m) a[0][m] = tr_frag(gl + (2 * m * BP_PL) * 16);
+#pragma unroll
+            for (int b = 0; b < NXB; ++b) bx[0][b] = tr_frag(xl + (2 * b * BP_PL) * 16);
+            if (!(abl & 4))
+#pragma unroll
+            for (int i = 0; i < 24; ++i) {
+                const int s = i / 3, v = i % 3;
+                if (i + 1 < 24) {
+                    const int s1 = (i + 1) / 3, v1 = (i + 1) % 3;
+#pragma unroll
+                    for (int b = 0; b < NXB; ++b) bx[(i + 1) & 1][b] = tr_frag(xl + (2 * b * BP_PL + 2 * s1 * TP + v1) * 16);
+                    if (v1 == 0) {
+#pragma unroll
+                        for (int m = 0; m < NGB; ++m) a[s1 & 1][m] = tr_frag(gl + (2 * m * BP_PL + 2 * s1 * TP) * 16);
+                    }
+                }
+                if (u == 1 && v == 0) {
+#pragma unroll
+                    for (int m = 0; m < NGB; ++m) accb[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s & 1][m], ones, accb[m], 0, 0, 0);
+                }
+#pragma unroll
+                for (int b = 0; b < NXB; ++b)
+#pragma unroll
+                    for (int m = 0; m < NGB; ++m) wacc[v][b][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s & 1][m], bx[i & 1][b], wacc[v][b][m], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < 3; ++v)
+#pragma unroll
+            for (int b = 0; b < NXB; ++b)
+#pragma unroll
+                for (int m = 0; m < NGB; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) red[((16 * m + 4 * g + r) * CIN + 16 * b + j) * 9 + 3 * u + v] = wacc[v][b][m][r];
+        if (u == 1 && j == 0) {
+#pragma unroll
+            for (int m = 0; m < NGB; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[COUT * CIN * 9 + 16 * m + 4 * g + r] = accb[m][r];
+        }
+    }
+    __syncthreads();
+    float* dst = partial + (long long)gi * PER;
+    for (int e = tid; e < PER; e += 512) dst[e] = red[e];
+}
+
 int taprow_reduce_launch(const float* ws, float* dw, float* db, int cin, int cout, int G, int accumulate, hipStream_t st);   // enc_wgrad.hip
 static int num_cus_();
 constexpr int BP_MAXG = 512;
+static int g_bwd_pair_dma = -1;
+void debug_set_bwd_pair_dma(int mode) { g_bwd_pair_dma = mode ? 1 : 0; }
 bool bwd_pair_supported(int ks, int cin, int cout) { return ks == 3 && ((cin == 64 && cout == 32) || (cin == 32 && cout == 16)); }
 size_t bwd_pair_workspace(int cin, int cout) { return (size_t)BP_MAXG * ((size_t)cout * cin * 9 + cout) * sizeof(float); }
 int bwd_pair(const TV& tx, const TV& tg, const TV& tgx, const void* wpk_dgrad, float* dw, float* db, int cin, int cout, int accumulate, float* ws,
@@ -2051,8 +2293,17 @@ int bwd_pair(const TV& tx, const TV& tg, const TV& tgx, const void* wpk_dgrad, f
     const int tpi = tiles_x * tiles_y, total = tpi * tx.n;
     const int cap = (cin == 64 ? 1 : 2) * num_cus_();
     const int G = total < cap ? total : (cap < BP_MAXG ? cap : BP_MAXG);
-    if (cin == 64)
+    // $MMIF_BWD_PAIR_DMA=0 / mmif_debug_set_bwd_pair_dma(0): the register-staged kernel (A/B; bit-identical results)
+    if (g_bwd_pair_dma < 0) { const char* e = getenv("MMIF_BWD_PAIR_DMA"); g_bwd_pair_dma = (e != nullptr && e[0] == '0') ? 0 : 1; }
+    const bool use_dma = g_bwd_pair_dma == 1 && tg.halo == 1 && tg.folded;
+    static int bp_abl = -1;   // $MMIF_BP_ABLATE (timing ablations, wrong results): 1 no tile requests after the first, 2 no gx stores, 4 no wgrad loops, 8 no dgrad k-loops
+    if (bp_abl < 0) { const char* e = getenv("MMIF_BP_ABLATE"); bp_abl = e != nullptr ? atoi(e) : 0; }   // (the loader reads the gradient's zero ring for rows / columns past the image)
+    if (cin == 64 && use_dma)
+        hipLaunchKernelGGL((bwd_pair_dma_kernel<4, 2>), dim3(G), dim3(512), 0, st, tx, tg, tgx, (const uint4*)wpk_dgrad, ws, tiles_x, tpi, total, G, bp_abl);
+    else if (cin == 64)
         hipLaunchKernelGGL((bwd_pair_kernel<4, 2>), dim3(G), dim3(512), 0, st, tx, tg, tgx, (const uint4*)wpk_dgrad, ws, tiles_x, tpi, total, G);
+    else if (use_dma)
+        hipLaunchKernelGGL((bwd_pair_dma_kernel<2, 1>), dim3(G), dim3(512), 0, st, tx, tg, tgx, (const uint4*)wpk_dgrad, ws, tiles_x, tpi, total, G, bp_abl);
     else
         hipLaunchKernelGGL((bwd_pair_kernel<2, 1>), dim3(G), dim3(512), 0, st, tx, tg, tgx, (const uint4*)wpk_dgrad, ws, tiles_x, tpi, total, G);
     if (int rc = check_launch("bwd_pair")) return rc;
@@ -2383,6 +2634,7 @@ using namespace mmif;
 extern "C" void mmif_debug_set_trace(void* device_buf) { mmif::g_trace = (long long*)device_buf; }
 // 1 (default; also $MMIF_CONV_DMA) = use the DMA-staged kernels where they apply, 0 = register-staged kernels only
 extern "C" void mmif_debug_set_conv_dma(int32_t mode) { mmif::g_dma_mode = mode ? 1 : 0; }
+extern "C" void mmif_debug_set_bwd_pair_dma(int32_t mode) { mmif::debug_set_bwd_pair_dma(mode); }
 
 extern "C" size_t mmif_packed_weight_bytes(int32_t cout, int32_t cin, int32_t ksize) {
     const size_t a = packed_bytes(cout, cin, ksize), b = packed_bytes(cin, cout, ksize);

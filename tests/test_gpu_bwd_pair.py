@@ -61,6 +61,38 @@ def test_bwd_pair_vs_separate_kernels(cin, cout, n, h, w):
         assert float((dw_a - 2 * dw_b).abs().max()) <= 2e-4 * max(1e-6, float(dw_b.abs().max()))
 
 
+@pytest.mark.parametrize("cin,cout", [(64, 32), (32, 16)])
+@pytest.mark.parametrize("n,h,w", SHAPES + [(3, 256, 256), (1, 17, 300)], ids=[f"{n}x{h}x{w}" for n, h, w in SHAPES + [(3, 256, 256), (1, 17, 300)]])
+def test_bwd_pair_dma_staging_is_bit_identical_to_register_staging(cin, cout, n, h, w):
+    """round 4: bwd_pair_dma_kernel (a loader wave's LDS-DMA into a double-buffered tile, one barrier per tile, bias sums in the tap-row-1
+    wave) against bwd_pair_kernel (register-staged): gx, dW AND db bit for bit -- same tiles per block, same MFMA sequences, same
+    fixed-order reduction.  Ragged tiles on both axes, one-tile and many-tiles-per-block walks, odd tile counts (the buffer parity)."""
+    from mmif import tensor as T
+    from mmif._lib import lib
+    with dtype_ctx("bf16"):
+        g = torch.Generator().manual_seed(h * 17 + w + cout)
+        x = T.BT.from_nchw(torch.relu(torch.randn(n, cin, h, w, generator=g)).to(DEV), torch.bfloat16)
+        gy = T.BT.from_nchw(torch.randn(n, cout, h, w, generator=g).to(DEV), torch.bfloat16, halo=1).as_folded()
+        wgt = (torch.randn(cout, cin, 3, 3, generator=g) * 0.05).to(DEV)
+        pk = T.PackedWeights(cout, cin, 3, DEV)
+        pk.pack(wgt)
+        ws = torch.empty(T.wgrad_workspace_bytes(cin, cout, 3) // 4 + 1, dtype=torch.float32, device=DEV)
+        res = {}
+        try:
+            for mode in (0, 1):
+                lib.mmif_debug_set_bwd_pair_dma(mode)
+                gx = T.BT.alloc(n, cin, h, w, torch.bfloat16, DEV, halo=1, zero=True)
+                dw, db = torch.zeros(cout, cin, 3, 3, device=DEV), torch.zeros(cout, device=DEV)
+                T.conv_bwd_pair(gy, x, gx, dw, db, cin, cout, 3, pk, ws)
+                torch.cuda.synchronize()
+                res[mode] = (gx.buf.view(torch.int16).clone(), dw.clone(), db.clone())
+        finally:
+            lib.mmif_debug_set_bwd_pair_dma(1)
+        assert float(res[0][1].abs().max()) > 0 and float(res[0][2].abs().max()) > 0
+        for a, b, what in zip(res[0], res[1], ("gx", "dW", "db")):
+            assert torch.equal(a, b), what
+
+
 def test_models_with_and_without_bwd_pair():
     import core.model as M
     with dtype_ctx("bf16"):
