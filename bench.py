@@ -235,7 +235,7 @@ def parity_leg(args, dev, img1, img2):
     per-kernel HIP events on --roofline-layer; its error is taken against the CPU oracle on two small closed-form samples (2 pairs of
     64 x 64 and one ragged 37 x 53 pair: fused image, total loss, every parameter gradient)."""
     import core.model as M
-    from core.loss import FusionLoss, GradLoss, PixelLoss, SSIMLoss
+    from core.loss import FusionLoss, GradLoss, PixelLoss, SSIMLoss, unit_gradient
     from mmif import engine as E
     from mmif import tensor as T
     from mmif._lib import lib
@@ -250,7 +250,7 @@ def parity_leg(args, dev, img1, img2):
             opt.zero_grad(set_to_none=True)
             f = model(a, b)
             tot = l_all(a, b, f) if l_all is not None else l_ssim(a, b, f) + l_pix(a, b, f, mode='max') + l_grad(a, b, f, mode='max')
-            tot.backward()
+            tot.backward(unit_gradient(tot))
             opt.step()
             return f, tot
         torch.manual_seed(0)
@@ -344,7 +344,7 @@ def main():
     torch.cuda.set_device(dev)
 
     import core.model as M
-    from core.loss import FusionLoss, GradLoss, PixelLoss, SSIMLoss
+    from core.loss import FusionLoss, GradLoss, PixelLoss, SSIMLoss, unit_gradient
     from mmif import engine as E
     from mmif import tensor as T
     from mmif.dist import broadcast_parameters
@@ -384,7 +384,7 @@ def main():
             tot = a + b + c
             vals = [tot, a, b, c]
         opt.stage_scalars(vals)      # (data parallel) the loss values ride in the early gradient all-reduce
-        tot.backward()
+        tot.backward(unit_gradient(tot))   # (= tot.backward(); core/loss.py: a cached ones tensor, as train.py does)
         opt.step(scalars=vals)
         return tot
 

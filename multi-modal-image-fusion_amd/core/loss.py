@@ -280,7 +280,25 @@ class _FusionLossFn(torch.autograd.Function):
     def backward(ctx, g, _gparts):
         if ctx.grad is None or g is None:
             return None, None, None, None
+        u = _UNIT.get((g.device, g.dtype))
+        if u is not None and g.data_ptr() == u.data_ptr():   # total.backward(unit_gradient(total)): d(total)/d(total) = 1, nothing to scale
+            return ctx.grad, None, None, None
         return ctx.grad * g, None, None, None
+
+
+_UNIT = {}
+
+
+def unit_gradient(total):
+    """The root gradient of `total.backward()` -- a tensor of ones of total's shape -- as ONE cached tensor per (device, dtype):
+    `total.backward(unit_gradient(total))` is `total.backward()` without the fill kernel autograd launches for its own ones_like, and
+    FusionLoss recognises the cached tensor by address and hands its stored d(total)/d(imgf) on without the multiply-by-one pass.  The
+    tensor must never be written to."""
+    key = (total.device, total.dtype)
+    u = _UNIT.get(key)
+    if u is None:
+        u = _UNIT[key] = torch.ones((), dtype=total.dtype, device=total.device)
+    return u if total.dim() == 0 else u.expand(total.shape)
 
 
 class FusionLoss(nn.Module):

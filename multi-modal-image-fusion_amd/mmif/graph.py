@@ -69,7 +69,8 @@ class GraphedStep:
         stream and adopt the engine's gradient views without a copy, and the views are handed to the parameters here.  (Layer-wise
         models, core/block.py, use their parameters directly: for those the old rule of torch's graph capture holds -- no autograd graph
         of an earlier default-stream step may be alive.)"""
-        total.backward()
+        from core.loss import unit_gradient
+        total.backward(unit_gradient(total))      # (= total.backward() without autograd's ones_like fill; core/loss.py)
         for p, q in self._leaves:
             p.grad = q.grad
         self._leaves.clear()

@@ -193,7 +193,9 @@ class FusedClipAdam(torch.optim.Optimizer):
         D.stage_tail(None)     # scalars parked for a backward whose early reduce never ran must not ride in a later one
         k = len(scalars) if scalars is not None else 0
         tail_done = early is not None and early[1] >= total + k and k > 0
-        if k and not tail_done:   # straight into the tail of the flat buffer (one small launch)
+        if k and not in_group:    # one rank: nothing to reduce, the caller's values ARE the result (no copy into the tail and back out)
+            self.reduced_scalars = _scalar_vector(scalars)
+        elif k and not tail_done:   # straight into the tail of the flat buffer (one small launch)
             if torch.is_tensor(scalars):
                 flat_g[total:total + k].copy_(scalars.detach())
             else:
@@ -210,7 +212,7 @@ class FusedClipAdam(torch.optim.Optimizer):
                 if k and not tail_done:
                     dist.all_reduce(flat_g[total:total + N_TAIL])
             D.arm_early_reduce(self._last_flat is not None)
-        if k:
+        if k and in_group:
             tail = flat_g[total:total + k]
             self.reduced_scalars = tail / world if world > 1 else tail.clone()
         g = self.param_groups[0]

@@ -24,7 +24,7 @@ from torch.optim.lr_scheduler import MultiStepLR
 from torch.utils.data import DataLoader, DistributedSampler, TensorDataset
 
 from common import *
-from core.loss import FusionLoss, GradLoss, PixelLoss, SSIMLoss
+from core.loss import FusionLoss, GradLoss, PixelLoss, SSIMLoss, unit_gradient
 from core.model import *
 from data._io import imwrite
 from mmif import engine as E
@@ -80,7 +80,7 @@ def train_model(model, data_loader, loss_fn1, loss_fn2, loss_fn3, epoch, mode='t
             total_loss, loss1, loss2, loss3 = _losses(loss_fn1, loss_fn2, loss_fn3, img1, img2, imgf)
             if hasattr(optimizer, "stage_scalars"):   # (data parallel) the loss values ride in the early gradient all-reduce
                 optimizer.stage_scalars([total_loss, loss1, loss2, loss3])
-            total_loss.backward()
+            total_loss.backward(unit_gradient(total_loss))   # (= .backward(): a cached ones tensor instead of a fill kernel per step)
             # clip_grad_norm_(5) + Adam + (distributed) gradient & loss all-reduce: one fused step
             optimizer.step(scalars=[total_loss, loss1, loss2, loss3])
             total_loss, loss1, loss2, loss3 = optimizer.reduced_scalars.unbind(0)

@@ -231,3 +231,29 @@ def test_fusion_loss_known_answers():
     v = fl.values.cpu().numpy()
     assert abs(v[1] - ref["ssim"]) < 5e-6 and abs(v[2] - ref["pixel_max"]) < 1e-7 and abs(v[3] - ref["grad_max"]) < 1e-6
     assert abs(tot - ref["total_max"]) < 6e-6
+
+
+def test_unit_gradient_backward_equals_plain_backward():
+    """core.loss.unit_gradient: total.backward(unit_gradient(total)) is total.backward() -- FusionLoss hands its stored gradient on
+    without the multiply-by-one pass when it recognises the cached ones tensor, autograd launches no fill kernel for the root -- and a
+    different upstream gradient still scales: bit-identical d(total)/d(imgf) in the first two cases, exactly 2.5 x in the third."""
+    from core.loss import FusionLoss, GradLoss, PixelLoss, SSIMLoss, unit_gradient
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(3)
+    a, b = torch.rand(2, 1, 40, 56, generator=g).to(dev), torch.rand(2, 1, 40, 56, generator=g).to(dev)
+    fl = FusionLoss(SSIMLoss('ssim', weight=1.0), PixelLoss('l1', weight=0.01), GradLoss('l1', weight=0.1).to(dev), 'max', 'max')
+    grads = []
+    for kind in ("plain", "unit", "scaled"):
+        f = torch.rand(2, 1, 40, 56, generator=torch.Generator().manual_seed(4)).to(dev).requires_grad_(True)
+        tot = fl(a, b, f)
+        if kind == "plain":
+            tot.backward()
+        elif kind == "unit":
+            tot.backward(unit_gradient(tot))
+        else:
+            tot.backward(torch.full_like(tot, 2.5))
+        grads.append(f.grad.clone())
+    assert float(grads[0].abs().max()) > 0
+    assert torch.equal(grads[0], grads[1])
+    assert torch.equal(grads[2], grads[0] * 2.5)
+    assert float(unit_gradient(tot)) == 1.0
