@@ -490,6 +490,9 @@ void mmif_debug_set_conv1x1_stream(int32_t mode);
 /* mmif_conv2d_reflect_bwd_pair: 1 (default, $MMIF_BWD_PAIR_DMA) = tiles staged by a loader wave's LDS-DMA into a double-buffered tile
  * (bwd_pair_dma_kernel, round 4), 0 = the register-staged kernel; bit-identical results (tests/test_gpu_bwd_pair.py). */
 void mmif_debug_set_bwd_pair_dma(int32_t mode);
+/* 3x3 forward with 49..64 input and 17..32 output channels (decode.2 of the PFNet / DenseFuse decoders): 1 (default, $MMIF_THIN_WIDE) = the
+ * asynchronous loader / consumer kernel in its two-group, three-slot geometry (round 4), 0 = the register-staged kernel; bit-identical. */
+void mmif_debug_set_thin_wide(int32_t mode);
 
 #ifdef __cplusplus
 }

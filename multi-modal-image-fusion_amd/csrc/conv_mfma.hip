@@ -1168,13 +1168,17 @@ __device__ inline void tn_wait_counter(volatile unsigned* ctr, unsigned target) 
     __asm__ volatile("" ::: "memory");
 }
 
-template <int MF, bool DGRAD>
-__global__ __launch_bounds__((4 * TN_GROUPS + TN_LOAD) * 64, 4) void thin_conv_async_kernel(
+// GROUPS / PL / MAXP / RING / TIGHT (round 4): the 64 -> 32 forward (decode.2 of every PFNet / DenseFuse decoder: 8 input channel blocks) does
+// not fit the default geometry -- three consumer groups need four 45 KiB slots next to the 36 KiB image.  Its variant runs TWO consumer
+// groups on a ring of THREE slots of exactly the tile's 41 pieces (324-granule planes; the loaders' padding pieces re-stage the last real
+// piece in place, so a slot needs no room for them): 123 KiB + 36 KiB, 768 threads.  Every other layer keeps the geometry it was tuned on.
+template <int MF, bool DGRAD, int GROUPS = TN_GROUPS, int PL = TN_PL, int MAXP = 8, int RING = tn_ring_bytes(MF), bool TIGHT = false>
+__global__ __launch_bounds__((4 * GROUPS + TN_LOAD) * 64, GROUPS == TN_GROUPS ? 4 : 3) void thin_conv_async_kernel(
     TV tin, TV tout, TV tmask, const uint4* __restrict__ wpk, const float* __restrict__ bias, int n_out, int relu,
     unsigned long long mask_bits, unsigned long long accum_bits, int tiles_x, int tiles_y, int ntiles, int org, TV told, int use_old) {
     constexpr int TP = MT + 2;   // org: as in conv_dma_kernel (dgrad over the interior of the padded domain, fold steps in the border tiles)
-    constexpr int NCONS = 4 * TN_GROUPS;
-    __shared__ __attribute__((aligned(16))) char s_in[tn_ring_bytes(MF)];
+    constexpr int NCONS = 4 * GROUPS;
+    __shared__ __attribute__((aligned(16))) char s_in[RING];
     __shared__ __attribute__((aligned(16))) uint4 s_w[TN_MAXKG * MF * 16];
     __shared__ int2 s_tab[2][36];
     __shared__ __attribute__((aligned(16))) float s_bias[MF * 16];
@@ -1201,11 +1205,11 @@ __global__ __launch_bounds__((4 * TN_GROUPS + TN_LOAD) * 64, 4) void thin_conv_a
         tile_x = trem - tile_y * tiles_x;
         if (org) tile_x = (tile_x + tile_y + in_) % tiles_x;   // (see conv_dma_kernel: spread the border tiles over the blocks)
     };
-    const int in_pieces = (ncb_tot * TN_PL + 63) / 64;        // <= 32
+    const int in_pieces = (ncb_tot * PL + 63) / 64;           // <= 4 MAXP
     const int P = (in_pieces + TN_LOAD - 1) / TN_LOAD;        // pieces per loader wave per tile (every loader issues exactly P)
-    const int slot_bytes = P * TN_LOAD * 1024;
-    const int NS = min(TN_MAXSLOTS, tn_ring_bytes(MF) / slot_bytes);   // >= TN_GROUPS + 1 (checked by the host)
-    const int D = min(2, NS - TN_GROUPS);                              // tiles a loader keeps in flight behind the one it publishes
+    const int slot_bytes = TIGHT ? in_pieces * 1024 : P * TN_LOAD * 1024;
+    const int NS = min(TN_MAXSLOTS, RING / slot_bytes);   // >= GROUPS + 1 (checked by the host)
+    const int D = min(2, NS - GROUPS);                              // tiles a loader keeps in flight behind the one it publishes
 
     // ---- one-time setup: k-group tables, bias, counters, resident weights; ONE block barrier, none afterwards
     if (tid < 72) {
@@ -1214,7 +1218,7 @@ __global__ __launch_bounds__((4 * TN_GROUPS + TN_LOAD) * 64, 4) void thin_conv_a
         if (ncb > 0) {
             int tap = 0, cb = 0, plane = kg;
             if (kg < 9 * ncb) { tap = visit_tap(kg / ncb, 3); cb = kg % ncb; plane = tap * ncb + cb; }
-            s_tab[c][kg] = make_int2(((c * CHUNK_CB + cb) * TN_PL + (tap / 3) * TP + (tap % 3)) * 16, (c * 36 + plane) * MF * 256);
+            s_tab[c][kg] = make_int2(((c * CHUNK_CB + cb) * PL + (tap / 3) * TP + (tap % 3)) * 16, (c * 36 + plane) * MF * 256);
         }
     }
     if (!DGRAD && tid < MF * 16) s_bias[tid] = (bias != nullptr && tid < n_out) ? bias[tid] : 0.f;
@@ -1235,12 +1239,12 @@ __global__ __launch_bounds__((4 * TN_GROUPS + TN_LOAD) * 64, 4) void thin_conv_a
     if (wave >= NCONS) {
         // =============================== loader waves ===============================
         const int lw = wave - NCONS;
-        unsigned geo[8];   // tile independent: plane << 16 | tile row << 8 | tile col of the granule this lane stages (piece lw + 4 i)
+        unsigned geo[MAXP];   // tile independent: plane << 16 | tile row << 8 | tile col of the granule this lane stages (piece lw + 4 i)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < MAXP; ++i) {
             // (pieces past in_pieces -- padding so that every loader issues exactly P -- re-stage the last real piece: same sources)
-            const int slot = min(min(lw + TN_LOAD * i, in_pieces - 1) * 64 + lane, ncb_tot * TN_PL - 1);
-            const int pl = slot / TN_PL, p = min(slot - pl * TN_PL, TP * TP - 1);
+            const int slot = min(min(lw + TN_LOAD * i, in_pieces - 1) * 64 + lane, ncb_tot * PL - 1);
+            const int pl = slot / PL, p = min(slot - pl * PL, TP * TP - 1);
             geo[i] = (unsigned)(pl << 16 | (p / TP) << 8 | (p % TP));
         }
         const unsigned plane_bytes = (unsigned)(tin.plane * 16);
@@ -1251,7 +1255,7 @@ __global__ __launch_bounds__((4 * TN_GROUPS + TN_LOAD) * 64, 4) void thin_conv_a
             const char* src = tin.base + ((long long)in_ * tin.img + (long long)tin.cb_off * tin.plane) * 16;
             char* dst = s_in + (k % NS) * slot_bytes;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < MAXP; ++i) {
                 if (i < P) {
                     const int piece = min(lw + TN_LOAD * i, in_pieces - 1);
                     const int pl = (int)(geo[i] >> 16);
@@ -1295,7 +1299,7 @@ __global__ __launch_bounds__((4 * TN_GROUPS + TN_LOAD) * 64, 4) void thin_conv_a
     // =============================== consumer groups: group q = tiles q, q+3, ...; wave r of a group owns tile rows 4r .. 4r+3
     const int q = wave >> 2, r = wave & 3;
     const char* w_lane = reinterpret_cast<const char*>(s_w) + j * 16;
-    for (int k = q; k < nmine; k += TN_GROUPS) {
+    for (int k = q; k < nmine; k += GROUPS) {
         int in_, ty0, tx0;
         tile_of(b + k * G, in_, ty0, tx0);
         tn_wait_counter(&s_ready[k % NS], (unsigned)TN_LOAD * (unsigned)(k / NS + 1));
@@ -1334,7 +1338,7 @@ __global__ __launch_bounds__((4 * TN_GROUPS + TN_LOAD) * 64, 4) void thin_conv_a
         if (DGRAD && org) {
             for (int c = 0; c < nch; ++c) {
                 const int ncb = min(CHUNK_CB, ncb_tot - c * CHUNK_CB), gc = min(g, ncb - 1);
-                dgrad_fold_steps<MF>(acc, in_lane + (c * CHUNK_CB + gc) * (TN_PL * 16), w_lane + (c * 36 + gc) * (MF * 256), ncb, TP, g, j,
+                dgrad_fold_steps<MF>(acc, in_lane + (c * CHUNK_CB + gc) * (PL * 16), w_lane + (c * 36 + gc) * (MF * 256), ncb, TP, g, j,
                                      ty0 * MT + r * 4, tx0 * MT, tout.hs, tout.ws);
             }
         }
@@ -2414,6 +2418,19 @@ static int launch_conv_dma(bool dgrad, const TV& tin, const TV& tout, const TV& 
 
 // fold (dgrad only): the caller wants fold_halo(gx) applied as well and guarantees that gx's halo ring is zero on entry; *folded
 // reports whether the kernel chosen did it (interior tiles + fold steps, ring left zero) -- otherwise the caller runs the fold kernel.
+// the 64 -> 32 forward's geometry (thin_conv_async_kernel: two consumer groups, three tight slots of 324-granule planes)
+constexpr int TNW_GROUPS = 2, TNW_PL = 324, TNW_MAXCB = 8, TNW_MAXP = (TNW_MAXCB * TNW_PL + 63) / 64 / TN_LOAD + 1;   // 41 pieces -> 11 per loader
+constexpr int TNW_RING = 3 * ((TNW_MAXCB * TNW_PL + 63) / 64) * 1024;                                                  // 125 952 B
+static int g_thin_wide = -1;   // $MMIF_THIN_WIDE=0: decode.2's forward stays on the register-staged kernel (A/B; bit-identical results)
+static bool thin_wide_ok(bool dgrad, int ks, int mf, const TV& tin, const TV& tout) {
+    if (g_thin_wide < 0) { const char* e = getenv("MMIF_THIN_WIDE"); g_thin_wide = (e != nullptr && e[0] == '0') ? 0 : 1; }
+    if (!(g_thin_wide == 1 && g_dma_mode == 1 && !dgrad && ks == 3 && mf == 2 && tin.cb > TN_MAXCB && tin.cb <= TNW_MAXCB && tin.plane * 16 * TNW_MAXCB < (1ll << 31)))
+        return false;
+    const long long ntiles = (long long)cdiv(tout.ws, MT) * cdiv(tout.hs, MT) * tout.n;
+    int G = num_cus_() / 8 * 8;
+    if (G < 8) G = 8;
+    return TNW_RING / (cdiv(tin.cb * TNW_PL, 64) * 1024) >= TNW_GROUPS + 1 && ntiles >= 2ll * G && ntiles < (1ll << 31);
+}
 static bool thin_async_ok(bool dgrad, int ks, int mf, const TV& tin, const TV& tout, int org) {
     if (!(g_dma_mode == 1 && ks == 3 && mf <= 3 && (dgrad || mf >= 2) && tin.cb <= TN_MAXCB && (!dgrad || (tin.halo == 1 && tin.folded)) &&
           tin.plane * 16 * TN_MAXCB < (1ll << 31)))
@@ -2466,6 +2483,16 @@ int conv_mfma(bool dgrad, int ks, const TV& tin, const TV& tout, const TV& tmask
     // channels, a ring of at least TN_GROUPS + 1 tile slots, at least two tiles per persistent block).  Measured (B=32 256x256,
     // vs conv_mfma_kernel<3,MF>): every dgrad -13 .. -21 %, forward with 32 / 48 outputs -14 % / -30 %; forward with 16 outputs
     // is +3 .. +16 % (the register-staged kernel runs 4 blocks per SIMD there), so that case stays on the old kernel.
+    if (thin_wide_ok(dgrad, ks, mf, tin, tout)) {
+        const int tiles_x = cdiv(tout.ws, MT), tiles_y = cdiv(tout.hs, MT);
+        const long long ntiles = (long long)tiles_x * tiles_y * tout.n;
+        int G = num_cus_() / 8 * 8;
+        if (G < 8) G = 8;
+        hipLaunchKernelGGL((thin_conv_async_kernel<2, false, TNW_GROUPS, TNW_PL, TNW_MAXP, TNW_RING, true>), dim3(G), dim3((4 * TNW_GROUPS + TN_LOAD) * 64), 0,
+                           st, tin, tout, tmask, (const uint4*)w_packed, bias, n_out, relu, (unsigned long long)mask_bits,
+                           (unsigned long long)accum_bits, tiles_x, tiles_y, (int)ntiles, 0, tout, 0);
+        return check_launch("thin_conv_async fwd (wide)");
+    }
     if (thin_async_ok(dgrad, ks, mf, tin, tout, org)) {
         const int tiles_x = cdiv(tout.ws - 2 * org, MT), tiles_y = cdiv(tout.hs - 2 * org, MT);
         const long long ntiles = (long long)tiles_x * tiles_y * tout.n;
@@ -2635,6 +2662,7 @@ extern "C" void mmif_debug_set_trace(void* device_buf) { mmif::g_trace = (long l
 // 1 (default; also $MMIF_CONV_DMA) = use the DMA-staged kernels where they apply, 0 = register-staged kernels only
 extern "C" void mmif_debug_set_conv_dma(int32_t mode) { mmif::g_dma_mode = mode ? 1 : 0; }
 extern "C" void mmif_debug_set_bwd_pair_dma(int32_t mode) { mmif::debug_set_bwd_pair_dma(mode); }
+extern "C" void mmif_debug_set_thin_wide(int32_t mode) { mmif::g_thin_wide = mode ? 1 : 0; }
 
 extern "C" size_t mmif_packed_weight_bytes(int32_t cout, int32_t cin, int32_t ksize) {
     const size_t a = packed_bytes(cout, cin, ksize), b = packed_bytes(cin, cout, ksize);

@@ -11,6 +11,7 @@ from gpu_util import G, bf16_round, close, dtype_ctx, load_closed_form, tg
 from test_oracle_golden import F3_CASES, f3_tensors
 
 pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
 
 import os
 
@@ -211,3 +212,40 @@ def test_dgrad_with_fused_fold_equals_dgrad_then_fold(cin, cout, n, h, w):
     err = (a - b).abs()
     tol = 2.0 ** -6 * torch.maximum(a.abs(), b.abs()) + 3e-2   # two bf16 roundings of O(1) halo values
     assert bool((err <= tol).all()), f"fold targets differ by up to {float(err.max())}"
+
+
+@pytest.mark.parametrize("cin,cout,n,h,w", [(64, 32, 2, 256, 256), (64, 32, 9, 128, 128), (56, 32, 3, 250, 180), (64, 24, 1, 512, 384), (64, 32, 5, 100, 333)],
+                         ids=lambda v: str(v))
+def test_thin_wide_forward_equals_register_staged_kernel(cin, cout, n, h, w):
+    """round 4: the 64 -> 32 forward (decode.2 of the PFNet / DenseFuse decoders, core/model.py:84) on thin_conv_async_kernel's two-group /
+    three-slot geometry against the register-staged conv_mfma_kernel<3, 2> it replaces: bit for bit (same operand image, k-group order,
+    bias / ReLU / rounding points), ragged tiles on both axes, 56 input channels (7 blocks: a ragged last chunk), output slot inside a wider
+    buffer with untouched neighbours -- and against the CPU oracle on the rounded operands."""
+    from mmif import tensor as T
+    from mmif._lib import IMPL_MFMA, lib
+    from gpu_util import bf16_round
+    torch.manual_seed(cin + h)
+    xn = torch.relu(torch.randn(n, cin, h, w))
+    wt = (torch.randn(cout, cin, 3, 3) * 0.05).to(DEV)
+    b = torch.randn(cout).to(DEV)
+    pk = T.PackedWeights(cout, cin, 3, DEV)
+    pk.pack(wt)
+    xb = T.BT.from_nchw(xn.to(DEV), torch.bfloat16)
+    res = {}
+    try:
+        for mode in (0, 1):
+            lib.mmif_debug_set_thin_wide(mode)
+            big = T.BT.alloc(n, 32 + 16, h, w, torch.bfloat16, DEV)
+            big.buf.fill_(3.0)
+            y = big.view(1, (cout + 7) // 8)
+            T.conv_fwd(xb, wt, b, y, cin, cout, 3, True, pk, IMPL_MFMA)
+            torch.cuda.synchronize()
+            res[mode] = (big.buf.view(torch.int16).clone(), y.to_nchw(cout).cpu().numpy())
+    finally:
+        lib.mmif_debug_set_thin_wide(1)
+    assert torch.equal(res[0][0], res[1][0])
+    bb = res[1][0].view(torch.bfloat16).float()
+    assert float((bb[:, 0] - 3).abs().max()) == 0 and float((bb[:, 1 + (cout + 7) // 8:] - 3).abs().max()) == 0, "neighbours of the output slot"
+    if n * h * w <= 2 * 256 * 256:
+        want = O.conv2d_reflect_fwd(bf16_round(xn.numpy()), bf16_round(wt.cpu().numpy()), b.cpu().numpy(), True)
+        close(res[1][1], bf16_round(want), 6e-3, "y vs oracle")
