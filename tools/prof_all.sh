@@ -11,6 +11,7 @@ tools/prof_bench.sh ${tag}df --model DenseFuse --no-parity-path > /dev/null 2>&1
 cp gpurun_out/kstats_${tag}df.txt gpurun_out/${tag}_kernel_stats_densefuse_b32_256_bf16.txt
 tools/sweep_configs.sh > gpurun_out/${tag}_config_sweep.txt 2>&1
 tools/sweep_bwd_pair.sh $tag > /dev/null 2>&1
+cp gpurun_out/${tag}_traffic.json profiles/${tag}_traffic.json   # (on the box's copy: the bench line below reads the counter pass of THIS build)
 python3 bench.py > gpurun_out/${tag}_bench_line.json 2> gpurun_out/${tag}_bench.err
 tail -c 1500 gpurun_out/${tag}_bench_line.json
 cat gpurun_out/${tag}_config_sweep.txt
