@@ -79,6 +79,9 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend for N > 1 (nccl = RCCL; gloo: debugging)")
     ap.add_argument("--one-device", action="store_true", help="debug: every rank on cuda:0 (gloo only) -- exercises the N > 1 plumbing on a 1-GPU box")
     ap.add_argument("--hbm-tag", default="auto", help="an HBM-bound engine op timed the same way for `roofline_hbm` ('' = none)")
+    ap.add_argument("--roofline-every", type=int, default=0, help="time the roofline launches on every N-th timed step (0 = auto: about five samples "
+                    "per kernel, every step when --steps <= 5).  Each HIP event pair around a launch idles the GPU for ~10 us (a marker packet "
+                    "before and after: 4 timed launches per step were ~45 us = 1.2 %% of the step the events are there to describe)")
     return ap.parse_args()
 
 
@@ -410,13 +413,16 @@ def main():
     enc_stream = args.dtype == "bf16" and os.environ.get("MMIF_ENC_STREAM", "1") != "0" and args.model in ("PFNetv1", "DenseFuse", "PFNetv2", "VIFNet")
     if hbm_tag == "auto":   # the encoder: ONE streaming launch for its 2 x 4 layers, or (layer-wise) its widest thin layer 48 -> 16
         hbm_tag = "encode:fwd" if enc_stream else ({"PFNetv1": "encode1.1.2:fwd", "DenseFuse": "encode.1.2:fwd", "PFNetv2": "encode.1.2:fwd", "VIFNet": "encode.1.2:fwd"}.get(args.model, "") if args.mode == "train" else "")
-    T.PROFILE_TAGS = {f"{args.roofline_layer}:{k}" for k in ("fwd", "dgrad", "wgrad")} | ({hbm_tag} if hbm_tag else set())
+    tags = {f"{args.roofline_layer}:{k}" for k in ("fwd", "dgrad", "wgrad")} | ({hbm_tag} if hbm_tag else set())
+    every = args.roofline_every if args.roofline_every > 0 else max(1, min(8, args.steps // 5))
+    T.PROFILE_TAGS = set()
     T.PROFILE_EVENTS.clear()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        T.PROFILE_TAGS = tags if i % every == 0 else set()   # (live, inside the timed region -- on a sample of its steps)
         tot = step()
     if use_dist:
         dist.barrier()
@@ -483,6 +489,8 @@ def main():
             "ideal_pairs_per_s_per_gpu": ideal,
             "roofline": roof,
             "roofline_kernels": roofs or None,
+            "roofline_sampling": {"every_nth_timed_step": every, "timed_steps": args.steps,
+                                  "note": "HIP events around the named launches, recorded inside the timed region on every n-th step"},
             "roofline_hbm": roof_hbm,
             "parity_path": None,
             "cpu_baseline": None,
