@@ -261,11 +261,13 @@ def parity_leg(args, dev, img1, img2):
         opt = FusedClipAdam(model.parameters(), lr=1e-4, betas=(0.9, 0.999), max_norm=5.0)
         for _ in range(6):     # (warm-up as the main leg's: packing, leases, the clock's ramp after the idle oracle / setup phase)
             one(model, opt, img1, img2)
-        T.PROFILE_TAGS = {f"{args.roofline_layer}:{k}" for k in ("fwd", "dgrad", "wgrad")}
+        tags = {f"{args.roofline_layer}:{k}" for k in ("fwd", "dgrad", "wgrad")}
+        every = args.roofline_every if args.roofline_every > 0 else max(1, min(8, args.parity_steps // 5))
         T.PROFILE_EVENTS.clear()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.parity_steps):
+        for i in range(args.parity_steps):
+            T.PROFILE_TAGS = tags if i % every == 0 else set()   # (as the main leg: events on a sample of the timed steps)
             one(model, opt, img1, img2)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
