@@ -17,6 +17,7 @@ from oracle import fusion_oracle as O
 from gpu_util import close, dtype_ctx, load_closed_form, load_live, tg
 
 pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
 
 RF = 8  # PFNetv1: 4 encoder + 4 decoder 3x3 convs -> receptive-field radius 8
 
@@ -410,3 +411,36 @@ def test_parity_path_step_vs_fp32_fma_family_256(name):
     for k, g in res["valu"][2].items():
         worst = max(worst, close(res["auto"][2][k], g, 1e-3, f"d loss / d {k}"))
     assert worst <= 2e-4, worst   # (measured ~2e-5: the backward's two-piece products; a ReLU-decision flip would show as ~1e-3)
+
+
+@pytest.mark.parametrize("name", ["PFNetv1", "DenseFuse"])
+def test_round4_kernel_variants_are_bit_identical_at_the_headline_size(name):
+    """BASELINE config 2 (batch 32, 256 x 256, bf16): one train step's fused image and EVERY parameter gradient with round 4's DMA-staged pair
+    backward (bwd_pair_dma_kernel) and wide thin forward (thin_conv_async_kernel, two groups / three slots) against the register-staged
+    kernels they replace -- bit for bit (same operand images, k-group orders, rounding points, fixed-order reductions)."""
+    import core.model as M
+    from mmif._lib import lib
+    from gpu_util import dtype_ctx
+    g = torch.Generator().manual_seed(21)
+    i1, i2 = torch.rand(32, 1, 256, 256, generator=g).to(DEV), torch.rand(32, 1, 256, 256, generator=g).to(DEV)
+    gy = torch.rand(32, 1, 256, 256, generator=g).to(DEV)
+    res = {}
+    try:
+        for mode in (0, 1):
+            lib.mmif_debug_set_bwd_pair_dma(mode)
+            lib.mmif_debug_set_thin_wide(mode)
+            with dtype_ctx("bf16"):
+                torch.manual_seed(5)
+                m = getattr(M, name)().to(DEV)
+                y = m(i1, i2)
+                y.backward(gy)
+                torch.cuda.synchronize()
+                res[mode] = (y.detach().clone(), [p.grad.detach().clone() for p in m.parameters()])
+    finally:
+        lib.mmif_debug_set_bwd_pair_dma(1)
+        lib.mmif_debug_set_thin_wide(1)
+    assert float(res[0][0].abs().max()) > 0
+    assert torch.equal(res[0][0], res[1][0]), "fused image"
+    for k, (a, b) in enumerate(zip(res[0][1], res[1][1])):
+        assert float(a.abs().max()) > 0
+        assert torch.equal(a, b), f"parameter gradient {k}"
