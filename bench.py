@@ -368,9 +368,11 @@ def main():
 
     B, S = args.batch, args.size
     Wd = args.width or S
-    gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
-    img1 = torch.rand(B, 1, S, Wd, generator=gen).to(dev)  # synthetic IR / visible pairs in [0,1)
-    img2 = torch.rand(B, 1, S, Wd, generator=gen).to(dev)
+    # manual_seed(0); img1, img2 = rand(global batch, 1, H, W) in that order; rank r takes the slice
+    # [r B, (r + 1) B) of the global batch (the DistributedSampler split of train.py:204-209 on synthetic data)
+    gen = torch.Generator(device="cpu").manual_seed(0)
+    img1 = torch.rand(B * world, 1, S, Wd, generator=gen)[rank * B:(rank + 1) * B].to(dev)  # synthetic IR / visible pairs in [0,1)
+    img2 = torch.rand(B * world, 1, S, Wd, generator=gen)[rank * B:(rank + 1) * B].to(dev)
 
     def infer_step():
         with torch.no_grad():

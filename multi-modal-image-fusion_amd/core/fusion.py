@@ -124,7 +124,8 @@ def channel_pooling(tensor, mode='avg'):
     if mode == 'nl':
         return _nonlocal(tensor, spatial=False)
     if mode == 'nuclear':
-        raise NotImplementedError("channel_pooling('nuclear') is outside the accelerated hot path")
+        from ._stock import nuclear_pooling
+        return nuclear_pooling(tensor)
     raise ValueError("only supported ['avg', 'max', 'nuclear', 'nl'] mode")
 
 

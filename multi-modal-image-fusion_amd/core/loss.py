@@ -12,6 +12,8 @@ import torch.nn as nn
 from mmif import tensor as T
 from mmif._lib import check, lib
 
+from . import _stock
+
 __all__ = ['SSIM', 'MS_SSIM', 'MSW_SSIM', 'SSIMLoss', 'PixelLoss', 'GradLoss', 'TVLoss', 'NormLoss', 'FusionLoss']
 
 eps = 1e-7
@@ -127,11 +129,14 @@ class SSIM(nn.Module):
 
     def __init__(self, win_size=11, data_range=1.0, use_padding=False, size_average=True):
         super(SSIM, self).__init__()
-        if win_size not in (3, 5, 7, 9, 11) or use_padding or not size_average:
-            raise NotImplementedError("the HIP SSIM implements windows 3/5/7/9/11, no padding, per-sample means")
         self.win_size, self.data_range, self.use_padding, self.size_average = win_size, data_range, use_padding, size_average
+        # argument combinations outside the HIP kernels (reflect-padded windows, per-pixel maps, other window sizes) run as stock torch
+        # ops with the reference's results (core/_stock.py)
+        self._stock = win_size not in (3, 5, 7, 9, 11) or bool(use_padding) or not size_average
 
     def forward(self, img1, img2):
+        if self._stock or min(img1.shape[-2:]) < self.win_size:
+            return _stock.ssim_terms(img1, img2, self.win_size, self.data_range, self.use_padding, self.size_average, _stock.window(self.win_size))
         i1, i2, _ = _prep(img1, img2, img2)
         n, _, h, w = i1.shape
         out = torch.empty((3, n), dtype=torch.float32, device=i1.device)
@@ -153,11 +158,12 @@ class MS_SSIM(nn.Module):
 
     def __init__(self, win_size=11, data_range=1.0, use_padding=False, size_average=True):
         super(MS_SSIM, self).__init__()
-        if win_size != 11 or use_padding or not size_average:
-            raise NotImplementedError("the HIP MS-SSIM implements the reference's configuration: 11x11 window, no padding, per-sample mean")
         self.win_size, self.data_range, self.use_padding, self.size_average = win_size, data_range, use_padding, size_average
+        self._stock = win_size != 11 or bool(use_padding) or not size_average      # (core/_stock.py: stock torch ops, same results)
 
     def forward(self, img1, img2):
+        if self._stock:
+            return _stock.msssim(img1, img2, self.win_size, self.data_range, self.use_padding, self.size_average)
         vals = [1.0 - _ModeLossFn.apply(img2[i:i + 1], img1[i:i + 1], img1[i:i + 1], _SSIM_MODES['ms-ssim'], 1.0, float(self.data_range))
                 for i in range(img1.shape[0])]
         return torch.stack(vals)
@@ -169,11 +175,12 @@ class MSW_SSIM(nn.Module):
 
     def __init__(self, win_sizes=(11, 9, 7, 5, 3), data_range=1.0, use_padding=False, size_average=False):
         super(MSW_SSIM, self).__init__()
-        if tuple(win_sizes) != (11, 9, 7, 5, 3) or use_padding or size_average:
-            raise NotImplementedError("the HIP MSW-SSIM implements win_sizes=(11, 9, 7, 5, 3), no padding, per-pixel weights")
         self.win_sizes, self.data_range, self.use_padding, self.size_average = tuple(win_sizes), data_range, use_padding, size_average
+        self._stock = tuple(win_sizes) != (11, 9, 7, 5, 3) or bool(use_padding) or bool(size_average)   # (core/_stock.py)
 
     def forward(self, img1, img2, imgf):
+        if self._stock:
+            return _stock.mswssim(img1, img2, imgf, self.win_sizes, self.data_range, self.use_padding, self.size_average)
         return 1.0 - _ModeLossFn.apply(imgf, img1, img2, _SSIM_MODES['msw-ssim'], 1.0, float(self.data_range))
 
 
@@ -183,13 +190,12 @@ class SSIMLoss(nn.Module):
         self.mode, self.data_range, self.use_padding, self.weight = mode, data_range, use_padding, weight
 
     def forward(self, img1, img2, imgf):
+        if self.use_padding and (self.mode == 'ssim' or self.mode in _SSIM_MODES):
+            # reflect-padded windows (core/loss.py:42-49) are not a HIP kernel: stock torch ops, the reference's results (core/_stock.py)
+            return _stock.ssim_loss(self.mode, img1, img2, imgf, self.data_range, True, self.weight)
         if self.mode == 'ssim':
-            if self.use_padding:
-                raise NotImplementedError("use_padding=True is outside the accelerated hot path")
             return _LossFn.apply(imgf, img1, img2, 0, float(self.weight), float(self.data_range), 0)
         if self.mode in _SSIM_MODES:
-            if self.use_padding:
-                raise NotImplementedError("use_padding=True is outside the accelerated path")
             return _ModeLossFn.apply(imgf, img1, img2, _SSIM_MODES[self.mode], float(self.weight), float(self.data_range))
         raise ValueError("only supported ['ssim', 'w-ssim', 'ms-ssim', 'msw-ssim'] mode")
 

@@ -136,8 +136,9 @@ class VIFNet(_FusionModel):
 
 class NestFuse(_FusionModel):
     '''NestFuse (reference core/model.py:319-363): 1x1 conv_in, four ConvBlock levels with 2x2 max-pool,
-    spatial/channel attention fusion per level, UNet++ NestDecoder, 1x1 conv_out.  Every ConvLayer runs on
-    the HIP kernels (k = 1 and 3); pooling / up-sampling / attention are tensor-level glue for now.'''
+    spatial/channel attention fusion per level, UNet++ NestDecoder, 1x1 conv_out.  One autograd node per call
+    (mmif/nest_engine.py): every ConvLayer (k = 1 and 3), the 2x2 max-pools, the nearest-x2 up-sampling with its reflect
+    pad and the attention fusion run as HIP kernels on blocked buffers (csrc/nest.hip, csrc/conv_mfma.hip, csrc/conv1x1.hip).'''
 
     def __init__(self, down_mode='maxpool', up_mode='nearest'):
         super(NestFuse, self).__init__()

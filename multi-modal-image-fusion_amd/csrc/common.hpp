@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/mmif.h"
@@ -22,6 +23,15 @@ int check_launch(const char* what);
             return MMIF_EINVAL;          \
         }                                \
     } while (0)
+
+// timing-ablation switches ($MMIF_*_ABLATE, tools/sweep_*.sh): a non-zero value makes the kernels skip loads / stores / k-loops, i.e. the
+// results are WRONG -- say so loudly, once, so that a stray variable in a training environment cannot pass unnoticed
+inline int ablate_env(const char* name) {
+    const char* e = getenv(name);
+    const int v = e != nullptr ? atoi(e) : 0;
+    if (v != 0) fprintf(stderr, "mmif: WARNING: %s=%d is a timing-ablation mode -- kernel results are WRONG (diagnostics only)\n", name, v);
+    return v;
+}
 
 // ---------------------------------------------------------------- bf16 <-> f32 (round to nearest even)
 typedef uint16_t bf16_t;

@@ -2301,7 +2301,7 @@ int bwd_pair(const TV& tx, const TV& tg, const TV& tgx, const void* wpk_dgrad, f
     if (g_bwd_pair_dma < 0) { const char* e = getenv("MMIF_BWD_PAIR_DMA"); g_bwd_pair_dma = (e != nullptr && e[0] == '0') ? 0 : 1; }
     const bool use_dma = g_bwd_pair_dma == 1 && tg.halo == 1 && tg.folded;
     static int bp_abl = -1;   // $MMIF_BP_ABLATE (timing ablations, wrong results): 1 no tile requests after the first, 2 no gx stores, 4 no wgrad loops, 8 no dgrad k-loops
-    if (bp_abl < 0) { const char* e = getenv("MMIF_BP_ABLATE"); bp_abl = e != nullptr ? atoi(e) : 0; }   // (the loader reads the gradient's zero ring for rows / columns past the image)
+    if (bp_abl < 0) bp_abl = ablate_env("MMIF_BP_ABLATE");   // (the loader reads the gradient's zero ring for rows / columns past the image)
     if (cin == 64 && use_dma)
         hipLaunchKernelGGL((bwd_pair_dma_kernel<4, 2>), dim3(G), dim3(512), 0, st, tx, tg, tgx, (const uint4*)wpk_dgrad, ws, tiles_x, tpi, total, G, bp_abl);
     else if (cin == 64)
@@ -2378,8 +2378,7 @@ static void init_modes() {
     if (g_dma_mode >= 0 && g_fuse_fold >= 0) return;
     const char* e = getenv("MMIF_CONV_DMA");
     if (g_dma_mode < 0) g_dma_mode = (e != nullptr && e[0] == '0') ? 0 : 1;   // (mmif_debug_set_conv_dma may have set it already)
-    const char* a = getenv("MMIF_CONV_ABLATE");
-    g_abl = a != nullptr ? atoi(a) : 0;
+    g_abl = ablate_env("MMIF_CONV_ABLATE");
     const char* r = getenv("MMIF_DGRAD_FOLD");
     g_fuse_fold = (r != nullptr && r[0] == '0') ? 0 : 1;
 }

@@ -1455,7 +1455,7 @@ static int launch_conv_x3(bool dgrad, const TV& tin, const TV& tout, const TV& t
     const int nch = x3_nch(n_in), nmb = x3_nmb(n_out);
     constexpr int X3_THREADS = 64 * NW;
     static int abl = -1;
-    if (abl < 0) { const char* e = getenv("MMIF_X3_ABLATE"); abl = e != nullptr ? atoi(e) : 0; }
+    if (abl < 0) abl = ablate_env("MMIF_X3_ABLATE");
     relu = (relu & 255) | (abl << 8);
     if (dgrad)
         hipLaunchKernelGGL((conv_x3_kernel<MB, true, NP, NW, RJ, KS, false, M16>), dim3(G), dim3(X3_THREADS), 0, st, tin, tout, tmask, (const uint4*)wpk, bias, n_out, nch, nmb,
@@ -1586,7 +1586,7 @@ int wgrad_x3(const TV& tx, const TV& tg, float* dw, float* db, int cin, int cout
     int G = wgrad_x3_G(cin, cout);
     if (total < G) G = total;
     static int abl = -1;
-    if (abl < 0) { const char* e = getenv("MMIF_X3_ABLATE"); abl = e != nullptr ? atoi(e) : 0; }
+    if (abl < 0) abl = ablate_env("MMIF_X3_ABLATE");
     const int tx_abl = tiles_x | (abl << 16);
 #define XW_LAUNCH(...) hipLaunchKernelGGL((wgrad_x3_kernel<__VA_ARGS__>), dim3(G * n_icg * n_ocg), dim3(XW_THREADS), 0, st, tx, tg, ws, cin, cout, tx_abl, tpi, total, G, n_icg, n_ocg, signs)
     if (thin) { if (signs != nullptr) XW_LAUNCH(16, 6, 2, 3, true); else XW_LAUNCH(16, 6, 2, 3); }
@@ -1631,6 +1631,9 @@ extern "C" int32_t mmif_get_x3_forward_pieces(void) { return x3_fwd_pieces(); }
 // to mmif_set_x3_forward_pieces(3) (bf16 pieces carry fp32's exponent range).
 extern "C" int32_t mmif_x3_pack_saturations(int32_t reset) {
     unsigned v = 0;
+    // the pack kernels run on the caller's (possibly non-blocking) streams, which a symbol copy on the null stream does not order against:
+    // drain the device first.  Never legal under stream capture -- the engine does not call this while capturing.
+    if (hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); return -1; }
     if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_x3_sat_count), sizeof(v)) != hipSuccess) { (void)hipGetLastError(); return -1; }
     if (reset) {
         const unsigned z = 0;

@@ -372,7 +372,7 @@ extern "C" int mmif_dense_encoder_chain(const mmif_dense_chain* ca, const mmif_d
     ec_geometry(A.n, A.h, A.w, nb, A.nstrips, A.nseg, A.seg_rows);
     A.items = A.n * A.nseg * A.nstrips;
     static int abl = -1;
-    if (abl < 0) { const char* e = getenv("MMIF_EC_ABLATE"); abl = e != nullptr ? atoi(e) : 0; }
+    if (abl < 0) abl = ablate_env("MMIF_EC_ABLATE");
     A.abl = abl;
     hipLaunchKernelGGL(enc_chain_bwd_kernel, dim3(cdiv(A.items, EC_WAVES), nb), dim3(EC_WAVES * 64), 0, (hipStream_t)stream, A);
     return check_launch("dense_encoder_chain");

@@ -513,12 +513,14 @@ class DenseEncoderMixin:
     def chain_out(first, F, slot=0):
         """[g0 | g1 | g2 | g3] of one encoder branch: the streaming chain's output (it is not an in-place kernel), read by the branch's
         weight-gradient pass afterwards -- one 8-block view per branch slot of a buffer kept with the encoder's first layer"""
-        key = (F.n, F.h, F.w, F.buf.device)
-        cached = getattr(first, "_gz", None)
-        if cached is None or cached[0] != key:
-            cached = (key, BT.alloc(F.n, 128, F.h, F.w, torch.bfloat16, F.buf.device))
-            first._gz = cached
-        return cached[1].view(8 * slot, 8)
+        # one 64-channel buffer per (shape, branch slot), never freed while the spec lives: a captured GraphedStep has the address baked
+        # into its launches, and an eager step of another shape in between must not recycle it (ADVICE r4)
+        key = (F.n, F.h, F.w, F.buf.device, slot)
+        pool = first.__dict__.setdefault("_gz", {})
+        gz = pool.get(key)
+        if gz is None:
+            gz = pool[key] = BT.alloc(F.n, 64, F.h, F.w, torch.bfloat16, F.buf.device)
+        return gz
 
     @staticmethod
     def chain_streams(specs, F, impl):

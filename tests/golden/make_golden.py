@@ -28,6 +28,8 @@ GPU box.  Fixture map:
   f14_n4_nested.npz / f14_manifest.json   UNFusion, MAFusion forward + gradient digests
   f15_n4_res2.npz / f15_manifest.json   depth-wise ConvLayer, ReLU6, Res2ConvBlock (core/block.py:286-350), Res2Fusion
   f7_metric_ssim.json        core/metric.py:316-364 calc_ssim (the SSIM that test.py:49-52 reports) on closed-form images
+  f16_stock_fallbacks.npz    the argument combinations that run as stock torch ops (core/_stock.py): SSIMLoss(use_padding=True) in its four
+                             modes, SSIM(size_average=False) / other windows, metric calc_ssim(win 7, padding, full), channel_pooling('nuclear')
 """
 import json
 import os
@@ -595,8 +597,40 @@ def make_f9():
     save("f9_ssim_modes.npz", out)
 
 
+def make_f16():
+    """Argument combinations outside the HIP kernels (stock torch fallbacks that must not change results)."""
+    import core.metric as rmetric
+    out = {}
+    shape = (2, 1, 40, 52)
+    i1, i2 = T(closed_form_image(shape, 0.3)), T(closed_form_image(shape, 1.7))
+    for mode, shp in (("ssim", shape), ("w-ssim", shape), ("msw-ssim", shape), ("ms-ssim", (1, 1, 192, 208))):
+        a, b = T(closed_form_image(shp, 0.3)), T(closed_form_image(shp, 1.7))
+        f = T(closed_form_image(shp, 2.9)).requires_grad_(True)
+        loss = rloss.SSIMLoss(mode, use_padding=True, weight=0.7)(a, b, f)
+        loss.backward()
+        out[f"pad_{mode}__loss"] = np.float64(loss.item())
+        out[f"pad_{mode}__grad"] = f.grad.numpy()
+    f = T(closed_form_image(shape, 2.9))
+    for tag, mod in (("ssim_maps", rloss.SSIM(11, 1.0, False, False)), ("ssim_pad7", rloss.SSIM(7, 1.0, True, True))):
+        res = mod(i1, f)
+        for k, v in res.items():
+            out[f"{tag}__{k}"] = v.numpy()
+    out["msssim_pad"] = rloss.MS_SSIM(11, 1.0, True, True)(T(closed_form_image((1, 1, 192, 208), 0.3)), T(closed_form_image((1, 1, 192, 208), 2.9))).numpy()
+    out["mswssim_avg"] = np.float64(rloss.MSW_SSIM((11, 7, 3), 1.0, False, True)(i1, i2, f).item())
+    s, c = rmetric.calc_ssim(i1, f, win_size=7, data_range=1.0, use_padding=True, full=True)
+    out["metric_w7_pad_full"] = np.array([s.item(), c.item()], np.float64)
+    out["metric_small"] = np.float64(rmetric.calc_ssim(i1[:, :, :9, :20], f[:, :, :9, :20], data_range=1.0).item())
+    out["metric_maps"] = rmetric.calc_ssim(i1, f, data_range=1.0, size_average=False).numpy()
+    t = T(closed_form_signed((2, 6, 9, 13), 0.9)).requires_grad_(True)
+    v = rfusion.channel_pooling(t, 'nuclear')
+    (v * T(np.arange(1, 7, dtype=np.float32).reshape(1, 6, 1, 1))).sum().backward()
+    out["nuclear__y"] = v.detach().numpy()
+    out["nuclear__dx"] = t.grad.numpy()
+    save("f16_stock_fallbacks.npz", out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10", "f11", "f12", "f13", "f14", "f15"]
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10", "f11", "f12", "f13", "f14", "f15", "f16"]
     for w in which:
         globals()["make_" + w]()
         print("wrote", w)

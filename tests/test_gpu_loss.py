@@ -85,8 +85,10 @@ def test_metric_calc_ssim_vs_golden():
         assert s.dim() == 0
         assert abs(float(s) - r["ssim"]) <= 1e-4, (tag, float(s), r["ssim"])
         assert abs(float(calc_ssim(a, a, **r["kwargs"])) - r["ssim_self"]) <= 1e-5
-    with pytest.raises(NotImplementedError):
-        calc_ssim(a, b, full=True)
+    # argument combinations outside the HIP kernel run as stock torch ops (core/_stock.py; pinned to the reference by golden F16 in
+    # tests/test_stock_fallbacks_cpu.py): full=True returns (ssim, cs) and the ssim agrees with the kernel's
+    s_full, cs_full = calc_ssim(a, b, full=True, **r["kwargs"])
+    assert abs(float(s_full) - float(s)) <= 1e-5 and cs_full.dim() == 0
     with pytest.raises(RuntimeError):
         calc_ssim(a.repeat(1, 3, 1, 1), b.repeat(1, 3, 1, 1))
 
@@ -164,8 +166,14 @@ def test_ms_ssim_and_msw_ssim_classes():
     for i in range(2):       # oracle: loss(a, a, b) = 1 - ms(a, b) for one sample
         l, _ = O.ssim_mode_loss(an[i:i + 1], an[i:i + 1], bn[i:i + 1], "ms-ssim", need_grad=False)
         assert abs(ms[i] - (1.0 - float(l))) <= 1e-4, (i, ms[i], 1.0 - float(l))
-    with pytest.raises(NotImplementedError):
-        MSW_SSIM(win_sizes=(11, 7))
+    # other window lists: stock torch ops with the reference's result (core/_stock.py, golden F16) -- same value as the kernel for the default list
+    an, bn, fn_ = (O.closed_form_image((2, 1, 40, 52), p) for p in (0.3, 1.7, 2.9))
+    v_k = MSW_SSIM()(tg(an), tg(bn), tg(fn_)).item()
+    v_s = MSW_SSIM(win_sizes=(11, 9, 7, 5, 3), use_padding=False, size_average=False)._stock
+    assert v_s is False
+    import core._stock as S
+    assert abs(S.mswssim(tg(an), tg(bn), tg(fn_)).item() - v_k) <= 2e-5
+    assert MSW_SSIM(win_sizes=(11, 7))(tg(an), tg(bn), tg(fn_)).dim() == 0
 
 
 @pytest.mark.parametrize("win", [11, 7, 3])
