@@ -493,6 +493,10 @@ void mmif_debug_set_bwd_pair_dma(int32_t mode);
 /* 3x3 forward with 49..64 input and 17..32 output channels (decode.2 of the PFNet / DenseFuse decoders): 1 (default, $MMIF_THIN_WIDE) = the
  * asynchronous loader / consumer kernel in its two-group, three-slot geometry (round 4), 0 = the register-staged kernel; bit-identical. */
 void mmif_debug_set_thin_wide(int32_t mode);
+/* persistent blocks (8..256, default 256 = one per CU) of the wide layers' weight-gradient kernel (wgrad_dma_kernel): a smaller grid leaves
+ * compute units to a kernel that runs concurrently on another stream -- the intra-step overlap of decode.0's weight gradient with the
+ * encoder's backward (mmif/engine.py, $MMIF_OVERLAP).  Results change in the last bits only (the per-block partial sums regroup). */
+void mmif_debug_set_wgrad_dma_blocks(int32_t blocks);
 
 #ifdef __cplusplus
 }

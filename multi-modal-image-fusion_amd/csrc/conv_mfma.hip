@@ -2553,9 +2553,11 @@ static bool wgrad_dma_shape(int ks, int cin, int cout) {
     const long long padded = (long long)cdiv(cin, 64) * 64 * cdiv(cout, 64) * 64;
     return ks == 3 && cin % 8 == 0 && cout % 8 == 0 && (long long)cin * cout * 10 >= padded * 6;
 }
-static int wgrad_dma_G(int cin, int cout) {   // tile groups per (icg, ocg) pair: about one persistent block per CU in total
+static int g_wgrad_dma_blocks = 256;   // mmif_debug_set_wgrad_dma_blocks: persistent blocks of wgrad_dma_kernel (one per CU); fewer leave CUs to
+                                       // a kernel running concurrently on another stream (the intra-step overlap experiment)
+static int wgrad_dma_G(int cin, int cout, int blocks = 256) {   // tile groups per (icg, ocg) pair: about one persistent block per CU in total
     const int npairs = cdiv(cin, 64) * cdiv(cout, 64);
-    int G = 256 / npairs;
+    int G = blocks / npairs;
     if (G >= 8) G = G / 8 * 8;   // multiples of 8 keep the blocks that share tiles on one XCD
     return G < 1 ? 1 : G;
 }
@@ -2591,7 +2593,7 @@ static int launch_wgrad_dma(const TV& tx, const TV& tg, float* dw, float* db, in
     const int tiles_x = cdiv(tx.w, MT), tiles_y = cdiv(tx.h, MT);
     const int tpi = tiles_x * tiles_y, total = tpi * tx.n;
     const int n_icg = cdiv(cin, 64), n_ocg = cdiv(cout, 64);
-    int G = wgrad_dma_G(cin, cout);
+    int G = wgrad_dma_G(cin, cout, g_wgrad_dma_blocks);   // (the workspace is sized for the full grid)
     if (G > total) G = total;   // every tile group owns at least one tile (the reduce sums all G partials)
     hipLaunchKernelGGL(wgrad_dma_kernel, dim3(G * n_icg * n_ocg), dim3((D_CONS + D_LOAD) * 64), 0, st, tx, tg, ws, tiles_x, tpi, total, G,
                        n_icg, n_ocg, sgn);
@@ -2662,6 +2664,7 @@ extern "C" void mmif_debug_set_trace(void* device_buf) { mmif::g_trace = (long l
 extern "C" void mmif_debug_set_conv_dma(int32_t mode) { mmif::g_dma_mode = mode ? 1 : 0; }
 extern "C" void mmif_debug_set_bwd_pair_dma(int32_t mode) { mmif::debug_set_bwd_pair_dma(mode); }
 extern "C" void mmif_debug_set_thin_wide(int32_t mode) { mmif::g_thin_wide = mode ? 1 : 0; }
+extern "C" void mmif_debug_set_wgrad_dma_blocks(int32_t blocks) { mmif::g_wgrad_dma_blocks = blocks < 8 ? 8 : (blocks > 256 ? 256 : blocks); }
 
 extern "C" size_t mmif_packed_weight_bytes(int32_t cout, int32_t cin, int32_t ksize) {
     const size_t a = packed_bytes(cout, cin, ksize), b = packed_bytes(cin, cout, ksize);

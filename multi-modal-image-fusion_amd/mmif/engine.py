@@ -64,6 +64,13 @@ def switch(name, default="1"):
     return v
 
 
+def switch_int(name, default):
+    v = _SW.get(name)
+    if v is None:
+        v = _SW[name] = int(os.environ.get(name, str(default)))
+    return v
+
+
 def reload_switches():
     _SW.clear()
 
@@ -439,6 +446,39 @@ class ModelEngine:
         else:
             T.conv_wgrad(x, gy, s.dw, s.db, s.cin, s.cout, s.k, ws, accumulate, impl, s.name + ":wgrad")
 
+    # ---- intra-step overlap ($MMIF_OVERLAP=1; round 5) ------------------------------------------------
+    # decode.0's weight gradient (matrix-pipe / power bound, off the critical path: nothing downstream reads dW) runs on a SECOND stream
+    # with a reduced persistent grid ($MMIF_OVERLAP_BLOCKS of the 256 CU slots) while the encoder's backward (LDS-issue / HBM bound)
+    # takes the rest of the chip on the main stream; the streams fork after decode.0's input gradient and join at the end of the backward.
+    # Inside a hipGraph capture the fork / join become parallel branches of the graph.  Measured in profiles/r05_overlap.txt.
+    def overlap_ok(self, s, dtype, impl, x, gx):
+        return (switch("MMIF_OVERLAP", "0") and dtype == torch.bfloat16 and impl != _lib.IMPL_VALU and not s.split and s.packed is not None
+                and x.halo == 0 and gx.halo == 1 and x.h >= 4 and x.w >= 4 and T.bwd_wide_supported(s.cin, s.cout, s.k))
+
+    def fork_wgrad(self, s, x, g, impl):
+        cur = torch.cuda.current_stream()
+        side = getattr(self, "_side", None)
+        if side is None or side.device != cur.device:
+            side = self._side = torch.cuda.Stream(device=cur.device)
+        need = T.wgrad_workspace_bytes(s.cin, s.cout, s.k)
+        ws2 = getattr(self, "_ws_side", None)
+        if ws2 is None or ws2.device != x.buf.device or ws2.numel() * 4 < need:
+            ws2 = self._ws_side = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.buf.device)
+        side.wait_stream(cur)
+        _lib.lib.mmif_debug_set_wgrad_dma_blocks(switch_int("MMIF_OVERLAP_BLOCKS", 192))
+        try:
+            with torch.cuda.stream(side):
+                self.c_wgrad(s, x, g, ws2, impl)
+        finally:
+            _lib.lib.mmif_debug_set_wgrad_dma_blocks(256)
+        self._forked = side
+
+    def join_side(self):
+        side = getattr(self, "_forked", None)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+            self._forked = None
+
     def forward(self, img1, img2):
         raise NotImplementedError
 
@@ -656,13 +696,24 @@ class PFNetv1Engine(ModelEngine, DenseEncoderMixin):
             # gradient w.r.t. the concatenated encoder features (i == 0): only each encoder's last DenseBlock output
             # (blocks 6,7 / 14,15) has no further contributor
             mb = all_bits(gx.cb) if i > 0 else bits(6, 7, 14, 15)
+            if i == 0 and self.overlap_ok(s, dtype, impl, x, gx):
+                # the input gradient first (its mask: the activations themselves, 32 of the 128 channels), the weight gradient on the side stream
+                gin = g
+                g = self.c_dgrad(s, gin, x, gx, mb, 0, impl)
+                self.fork_wgrad(s, x, gin, impl)
+                continue
             if self.wide_ok(s, dtype, impl, x, gx):
                 g = self.c_bwd_wide(s, g, x, gx, mb, ws)  # wide layer: the wgrad leaves the ReLU sign bytes the dgrad masks with
                 continue
             self.c_wgrad(s, x, g, ws, impl)
             g = self.c_dgrad(s, g, x, gx, mb, 0, impl)
-        self.early_reduce(flat, self.dec)      # (data parallel) the decoder's gradients leave while the encoder's backward runs
+        forked = getattr(self, "_forked", None) is not None
+        if not forked:
+            self.early_reduce(flat, self.dec)      # (data parallel) the decoder's gradients leave while the encoder's backward runs
         self.enc_bwd_all(img1, img2, F, g, ws, impl)
+        if forked:
+            self.join_side()
+            self.early_reduce(flat, self.dec)
         return grads
 
     def enc_bwd_all(self, img1, img2, F, g, ws, impl):
@@ -752,12 +803,26 @@ class DenseFuseEngine(ModelEngine, DenseEncoderMixin):
             # i == 0: the auto-encoder's input is the DenseBlock output (only its last conv, blocks 6,7, has no further contributor);
             # x = f1 + f2 is not a ReLU output
             mb = all_bits(gx.cb) if i > 0 else (bits(6, 7) if single else 0)
+            if i == 0 and not single and self.overlap_ok(s, dtype, impl, x, gx):
+                gin = g
+                g = self.c_dgrad(s, gin, x, gx, mb, 0, impl)
+                self.fork_wgrad(s, x, gin, impl)
+                continue
             if self.wide_ok(s, dtype, impl, x, gx):
                 g = self.c_bwd_wide(s, g, x, gx, mb, ws)
                 continue
             self.c_wgrad(s, x, g, ws, impl)
             g = self.c_dgrad(s, g, x, gx, mb, 0, impl)
+        if getattr(self, "_forked", None) is not None:
+            try:
+                return self._encoder_backward(L, F, g, ws, impl, dtype, dev, n, h, w, single, img1, img2, grads)
+            finally:
+                self.join_side()
+                self.early_reduce(flat, self.dec)
         self.early_reduce(flat, self.dec)
+        return self._encoder_backward(L, F, g, ws, impl, dtype, dev, n, h, w, single, img1, img2, grads)
+
+    def _encoder_backward(self, L, F, g, ws, impl, dtype, dev, n, h, w, single, img1, img2, grads):
         if single:
             self.enc_bwd(self.enc, img1, F, g, 0, 0, ws, impl)
             return grads

@@ -93,6 +93,25 @@ def test_bench_two_ranks_gloo_one_device():
     assert out["parity_path"] is None and out["cpu_baseline"] is None       # N = 1 only
 
 
+@pytest.mark.parametrize("model,batch", [("PFNetv1", 4), ("DenseFuse", 4)])
+def test_bench_eight_ranks_gloo_one_device_preflight(model, batch):
+    """Pre-flight for the driver's first real `--gpus 8` run (round-4 verdict item 9; reference train.py:203-222, 285-297): eight ranks
+    through the self-launch, one rendezvous port, the stdout discipline (ONE JSON line, last), global_batch = 8 x per-rank batch, `dp8`
+    -- configs 2 (PFNetv1) and 3 (DenseFuse, batch split over 8 ranks).  One GPU here, so the ranks share cuda:0 over gloo; nothing is
+    measured, everything must not break."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--one-device", "--model", model, "--batch", str(batch),
+                        "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-parity-path"], capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, f"bench.py --gpus 8 failed:\n{r.stdout[-3000:]}\n{r.stderr[-3000:]}"
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert sum(1 for l in lines if l.lstrip().startswith("{")) == 1, lines[-5:]      # exactly one JSON line on stdout
+    out = json.loads(lines[-1])
+    assert out["n_gpus"] == 8 and out["config"]["global_batch"] == 8 * batch and out["config"]["parallelism"] == "dp8"
+    assert out["scaling"] == "weak" and out["steps"] == 2 and out["value"] > 0 and model in out["config"]["workload"]
+    assert np.isfinite(out["final_loss"]) and 0.0 < out["final_loss"] < 10.0
+    assert out["parity_path"] is None and out["cpu_baseline"] is None
+
+
 def test_bench_single_gpu_line_has_the_contract_fields():
     import json
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--batch", "4", "--size", "64", "--cpu-sample", "2",

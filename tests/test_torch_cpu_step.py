@@ -37,6 +37,36 @@ def test_torch_cpu_models_vs_golden_f5(name, shape):
         close_digest(v.grad.numpy(), ref[f"{tag}__dp_{k}"], 1e-4, k)
 
 
+def load_live(model, name):
+    """oracle.LIVE_PARAMS: the closed-form set whose final ReLU passes 30-60 % of the pixels (what golden F5 holds for the nested nets)"""
+    P = model.init_params(0)
+    with torch.no_grad():
+        for i, (k, v) in enumerate(P.items()):
+            v.copy_(torch.from_numpy(O.live_param(name, i, k, tuple(v.shape))))
+    return P
+
+
+@pytest.mark.parametrize("name,shape", [("NestFuse", (1, 1, 32, 32)), ("RFNNest", (1, 1, 32, 32)), ("NestFuse", (2, 1, 36, 44)),
+                                        ("RFNNest", (2, 1, 36, 44))])
+def test_torch_cpu_nested_models_vs_live_golden_f5(name, shape):
+    """NestFuse / RFN-Nest (reference core/model.py:319-384) in the torch-CPU restatement: fused image + all 44 / 92 parameter
+    gradients against the LIVE golden cases, incl. the odd pyramid 36x44 -> 18x22 -> 9x11 -> 4x5 (Upsample._pad)."""
+    ref = np.load(os.path.join(G, "f5_models.npz"))
+    man = json.load(open(os.path.join(G, "f5_manifest.json")))
+    tag = f"{name}_{shape[0]}x{shape[2]}x{shape[3]}"
+    m = TC.TorchCpuModel(name)
+    assert [[k, list(s)] for k, s in m.shapes.items()] == man[name]
+    P = load_live(m, name)
+    i1, i2 = torch.from_numpy(O.closed_form_image(shape, 0.3)), torch.from_numpy(O.closed_form_image(shape, 1.7))
+    y = m.forward(P, i1, i2)
+    yr = ref[tag + "__y"]
+    assert 0.3 <= float((yr > 0).mean()) <= 0.7
+    close(y.detach().numpy(), yr, 5e-5, "y")
+    y.backward(torch.from_numpy(O.closed_form_image(shape, 0.9)))
+    for k, v in P.items():
+        close_digest(v.grad.numpy(), ref[f"{tag}__dp_{k}"], 2e-4, k)
+
+
 @pytest.mark.parametrize("name", ["PFNetv1", "DenseFuse"])
 def test_torch_cpu_train_trajectory_vs_golden_f6(name):
     ref = np.load(os.path.join(G, "f6_traj.npz"))
