@@ -17,7 +17,7 @@
 // The k-group order, the operand images (mmif_pack_weights) and the bias / ReLU / rounding points are those of the layer-wise
 // kernels (conv_image.hip, conv_mfma.hip), so the results are bit-identical to running the four layers one by one
 // (tests/test_gpu_enc_stream.py).
-#include "common.hpp"
+#include "enc_stream.hpp"
 #include <stdlib.h>
 
 namespace mmif {
@@ -36,25 +36,7 @@ constexpr int ES_WAVES = 4;
 #endif             // 2 no input-fragment reads, 4 no global stores, 8 no first-layer FMAs (tools/bench_enc.py)
 constexpr int ES_AHEAD = 4;                          // K steps of operand fetches in flight ahead of the MFMAs
 constexpr int ES_KEEP = ES_W - 6;                     // 26 output columns per interior strip
-// packed operand images (k-group planes of [16 oc][8] bf16 = 256 B): 16->16: 18 -> 20 planes, 32->16: 36, 48->16: 36 + 20
-constexpr int ES_P1 = 20, ES_P2 = 36, ES_P3 = 56;
 constexpr int ES_WPLANES = ES_P1 + ES_P2 + ES_P3;     // 112 planes = 28672 B
-
-struct EncBranch {
-    const float* img;          // [n][h][w] fp32
-    const float* w0;           // first layer, [16][1][3][3]
-    const float* b0;           // [16] or NULL
-    const uint4* wpk[3];       // forward operand images of the three DenseBlock convs
-    const float* bias[3];      // [16] each or NULL
-    TV out;                    // 8-block view: x0 | x1 | x2 | x3
-};
-struct EncArgs {
-    EncBranch br[2];
-    int n, h, w;
-    int nstrips, nseg, seg_rows;
-    int items;                 // per branch: n * nseg * nstrips
-    int relu0;                 // ReLU after the first layer (always 1 on the reference's path; the dense convs always have one)
-};
 
 template <int N> struct ESI { static constexpr int value = N; };
 __device__ inline int es_tap(int i) { return (i % 3) * 3 + i / 3; }   // visit order of the 3x3 taps (conv_mfma.hip visit_tap)
@@ -326,6 +308,8 @@ extern "C" int mmif_dense_encoder_fwd(const mmif_dense_encoder* enc_a, const mmi
     }
     A.n = out_a->n; A.h = out_a->h; A.w = out_a->w;
     A.relu0 = 1;
+    // round 5: the 64-column input-stationary kernel (csrc/enc_stream2.hip); $MMIF_ENC_STREAM2=0 / mmif_debug_set_enc_stream2(0): this file's
+    if (enc_stream2_ok(A.n, A.h, A.w)) return enc_stream2_launch(A, nb, (hipStream_t)stream);
     es_geometry(A.n, A.h, A.w, nb, A.nstrips, A.nseg, A.seg_rows);
     A.items = A.n * A.nseg * A.nstrips;
     hipLaunchKernelGGL(enc_stream_fwd_kernel, dim3(cdiv(A.items, ES_WAVES), nb), dim3(ES_WAVES * 64), 0, (hipStream_t)stream, A);

@@ -1,0 +1,347 @@
+// Streaming DenseBlock encoder, forward (bf16 MFMA), second generation (round 5): ConvLayer(1 -> 16) + DenseBlock(16, 16, 3 convs) of the
+// PFNet / DenseFuse family (reference core/model.py:73-80, core/block.py:137-151) as ONE kernel, like enc_stream.hip, rebuilt around what
+// that kernel's counters said (~760 instructions per wave and 32-pixel row step, 1.5 LDS operand
+// reads per MFMA, the four layers of a row step a serial chain):
+//
+//   * INPUT-STATIONARY accumulation.  With 16 output channels a layer has ONE M-tile, so in the output-stationary order every MFMA
+//     needs its own B fragment (16 pixels x 32 k).  Here a wave reads the B fragments of input row R once and multiplies them with the
+//     weights of all THREE tap rows:  out[R+1] = W(u=0) x[R] (a fresh accumulator that starts from the bias),  out[R] += W(u=1) x[R],
+//     out[R-1] += W(u=2) x[R] (which completes row R-1) -- three accumulator rows per layer rotate through the row loop (unrolled by
+//     three).  One B read + three A reads feed twelve MFMAs: 0.58 LDS reads per MFMA instead of 1.5.  K is ordered tap-row major, so
+//     the 16 -> 16 layer pads 48 to 64 (two k-steps) and the 48 -> 16 layer 144 to 160 (five): 30 MFMAs per 16-pixel tile and row
+//     instead of 28.
+//   * 64-column strips, one wave per SIMD (512 registers: 3 layers x 3 rows x 4 tiles of accumulators = 144).  A strip keeps 58 of
+//     its 64 columns (60 at an image edge) instead of 26 / 29 of 32, and the per-row bookkeeping is paid once per 64 pixels.
+//   * SKEWED pipeline: step s produces x0 row s (fp32 FMAs on the image), feeds x0 row s-1 to layer 1 (completing x1 row s-2), rows
+//     s-3 of [x0 | x1] to layer 2 (x2 row s-4) and rows s-5 of [x0 | x1 | x2] to layer 3 (x3 row s-6): everything a step READS from
+//     the wave's LDS ring was written in an earlier step, so the four stages of a step are independent instruction streams for the
+//     scheduler instead of a chain of LDS round trips.  Ring: 8 / 4 / 2 row slots of x0 / x1 / x2 (28 KB per wave).
+//   * Reflect padding.  Rows: input row 1 also feeds out row 0 through W(u=0), input row h-2 also out row h-1 through W(u=2) (extra
+//     MFMAs in the few steps that touch those rows; the row loop has a branch-free fast body for all others).  Columns: an edge strip
+//     carries the padded column (-1 or w) as a GHOST pixel of its ring rows -- x0 computes it from the reflected image columns, x1 / x2
+//     copy it from column 1 / w-2 after their epilogue -- so every operand read is base + immediate with no per-lane column tables.
+//   * Epilogue on packed pairs: v_cvt_pk_bf16_f32, ReLU as v_pk_max_i16 against 0, two v_permlane16_swap per 32 pixels (the
+//     conv_dma_kernel recipe), the bias rides in as the C operand of the fresh accumulator's first MFMA.
+//
+// Rounding points are the layer-wise kernels' (every x_k rounded to bf16 once, fp32 accumulation), the accumulation ORDER is not, so
+// the results are no longer bit-identical to them: tests/test_gpu_enc_stream.py holds this kernel to the fp64 definition of every stage
+// on the kernel's own bf16 inputs at one bf16 rounding (as tests/test_gpu_enc_chain.py does for the backward chain).  x0 (fp32 FMAs in
+// the old order) stays bit-identical.  $MMIF_ENC_STREAM2=0 selects the round-2 kernel.
+#include "enc_stream.hpp"
+#include <stdlib.h>
+
+namespace mmif {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 e2_bf16x8;
+typedef __attribute__((ext_vector_type(4))) float e2_f32x4;
+typedef float e2_f32x2 __attribute__((ext_vector_type(2)));
+typedef short e2_i16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned e2_u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int E2_W = 64;                       // strip width in pixels
+constexpr int E2_KEEP = 58;                    // columns an interior strip keeps (3 lost per side over the three 3x3 layers)
+constexpr int E2_ROW = 2048;                   // one ring slot: [cb 0: 64 px][cb 1: 64 px] x 16 B
+constexpr int E2_S0 = 8, E2_S1 = 4, E2_S2 = 2; // ring slots of x0 / x1 / x2 (powers of two: slot = row & (S - 1))
+constexpr int E2_X0 = 0, E2_X1 = E2_S0 * E2_ROW, E2_X2 = E2_X1 + E2_S1 * E2_ROW, E2_RING = E2_X2 + E2_S2 * E2_ROW;   // 28672
+constexpr int E2_WAVES = 4;
+constexpr int E2_NFRAG = 30;                   // A fragments: (2 + 3 + 5 k-steps) x 3 tap rows, 1 KB each
+constexpr int E2_WBYTES = E2_NFRAG * 1024;
+constexpr int E2_LDS = E2_WBYTES + E2_WAVES * E2_RING + 64;   // (+ 64: operand reads run up to two granules past a row)
+
+template <int N> struct E2I { static constexpr int value = N; };
+
+__global__ __launch_bounds__(E2_WAVES * 64, 1) void enc_stream2_fwd_kernel(EncArgs A) {
+    __shared__ __attribute__((aligned(16))) char smem[E2_LDS];
+    const EncBranch& B = A.br[blockIdx.y];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, g = lane >> 4;
+
+    // ---- A fragments of (layer, k-step, tap row u), gathered from the layer-wise operand images (planes of [16 oc][8 ch] bf16):
+    // fragment f = (kq * 3 + u), kq = 0,1: 16->16 | 2..4: 32->16 | 5..9: 48->16; lane (oc = j, k-group g) takes the plane of its (tap, cb).
+    // Four-block chunks [x0 | x1] (k-step = tap column v, k-group = channel block); two-block chunks (x0 for the first conv, x2 for
+    // the third): k-step 0 = tap columns 0 | 1 (k-groups 0,1 | 2,3), k-step 1 = tap column 2 | the image's zero planes.
+    for (int e = tid; e < E2_NFRAG * 64; e += E2_WAVES * 64) {
+        const int f = e >> 6, l = e & 63, oc = l & 15, kg = l >> 4;
+        const int u = f % 3, kq = f / 3;
+        const int L = kq < 2 ? 1 : (kq < 5 ? 2 : 3), q = kq < 2 ? kq : (kq < 5 ? kq - 2 : kq - 5);
+        int plane;
+        if (L >= 2 && q < 3) plane = (u * 3 + q) * 4 + kg;
+        else {
+            const int q2 = L == 1 ? q : q - 3, base = L == 3 ? ES_P2 : 0;
+            plane = base + ((q2 == 1 && kg >= 2) ? 18 + (kg & 1) : (u * 3 + (q2 == 0 ? (kg >> 1) : 2)) * 2 + (kg & 1));
+        }
+        reinterpret_cast<uint4*>(smem)[e] = B.wpk[L - 1][plane * 16 + oc];
+    }
+    // the wave's ring starts zeroed: pad k-groups, warm-up rows and the granules next to a row are read before they are ever written
+    // (their products are multiplied by zero weights or only reach discarded columns, but NaN bit patterns would not stay there)
+    const int ring = E2_WBYTES + wave * E2_RING;     // byte address in LDS
+    for (int e = lane; e < E2_RING / 16; e += 64) reinterpret_cast<uint4*>(smem + ring)[e] = make_uint4(0u, 0u, 0u, 0u);
+    if (wave == E2_WAVES - 1 && lane < 4) reinterpret_cast<uint4*>(smem + E2_WBYTES + E2_WAVES * E2_RING)[lane] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+
+    const int item = blockIdx.x * E2_WAVES + wave;
+    if (item >= A.items) return;
+    const int strip = item % A.nstrips;
+    const int seg = (item / A.nstrips) % A.nseg;
+    const int in_ = item / (A.nstrips * A.nseg);
+    const int H = A.h, W = A.w;
+    const int y_lo = seg * A.seg_rows, y_hi = min(H, y_lo + A.seg_rows);
+    if (y_lo >= y_hi) return;
+
+    // ---- strip geometry.  Ring pixel p of the strip is image column r0 + p.  The first strip starts at column -1 (its ghost), the last
+    // one ends at column w (its ghost); a single strip (w <= 62) has both.  Kept columns [o_lo, o_hi): 3 px from an interior strip edge.
+    int r0, o_lo, o_hi;
+    if (A.nstrips == 1) { r0 = -1; o_lo = 0; o_hi = W; }
+    else if (strip == 0) { r0 = -1; o_lo = 0; o_hi = 60; }
+    else {
+        o_lo = 60 + E2_KEEP * (strip - 1);
+        if (strip == A.nstrips - 1) { r0 = W - (E2_W - 1); o_hi = W; }
+        else { r0 = o_lo - 3; o_hi = o_lo + E2_KEEP; }
+    }
+    const bool ghost_l = r0 < 0, ghost_r = r0 + E2_W > W;
+    const int pg_r = W - r0;                          // ring pixel of the right ghost (column w) when ghost_r
+
+    // ---- lane constants
+    const int h2 = g >> 1, cbk = g & 1;
+    const int la = g * 256 + j * 16;                                   // A operand: k-group plane g of a fragment, row (output channel) j
+    const int lb4 = ring + cbk * 1024 + j * 16 - 16;                    // B operand, four-block chunk: tensor h2 (x0 | x1), block cbk, tap column 0
+    const int lb2 = ring + cbk * 1024 + (j + h2) * 16 - 16;             // two-block chunk: tap column h2 (k-step 0); + 32: tap column 2 (k-step 1)
+    // epilogue side (after the row swap): this lane holds the granule of pixel 32 p + 16 (g & 1) + j, channel block g >> 1
+    const int px_e = 16 * (g & 1) + j, cb_e = g >> 1;
+    const int lw_e = ring + cb_e * 1024 + px_e * 16;
+    // first layer (VALU): lane = (pixel lane & 31 (+ 32 hf), channel block lane >> 5); its 8 channels' weights live in registers
+    const int px_a = lane & 31, cb_a = lane >> 5;
+    const int lw_a = ring + E2_X0 + cb_a * 1024 + px_a * 16;
+    bool ok_e[2], ok_a[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int ce = r0 + px_e + 32 * p, ca = r0 + px_a + 32 * p;
+        ok_e[p] = ce >= o_lo && ce < o_hi;
+        ok_a[p] = ca >= o_lo && ca < o_hi;
+    }
+    int cimg[2][3];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        const int c = min(max(reflect_idx(r0 + px_a + 32 * hf, W), 0), W - 1);
+#pragma unroll
+        for (int v = 0; v < 3; ++v) cimg[hf][v] = 4 * min(max(reflect_idx(c + v - 1, W), 0), W - 1);   // byte offset inside an image row
+    }
+    e2_f32x2 wp[4][9], bp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c0 = cb_a * 8 + 2 * i;
+        bp[i] = B.b0 != nullptr ? (e2_f32x2){B.b0[c0], B.b0[c0 + 1]} : (e2_f32x2){0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wp[i][t] = (e2_f32x2){B.w0[c0 * 9 + t], B.w0[(c0 + 1) * 9 + t]};
+    }
+    e2_f32x4 biasC[3];    // C operand of a fresh accumulator: this lane's output channels 4 g .. 4 g + 3
+#pragma unroll
+    for (int L = 0; L < 3; ++L)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) biasC[L][r] = B.bias[L] != nullptr ? B.bias[L][4 * g + r] : 0.f;
+
+    // global traffic through buffer descriptors: a 32-bit lane offset (constant per lane) + a scalar row offset + an immediate, no 64-bit
+    // lane addresses (an image of the widest view is < 4 GiB; out-of-range offsets -- the left ghost's -16 -- are dropped by the hardware)
+    const unsigned plane_b = (unsigned)(B.out.plane * 16), row_b = (unsigned)B.out.ws * 16u;
+    char* out_img = B.out.base + ((long long)in_ * B.out.img + (long long)B.out.cb_off * B.out.plane) * 16;
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(out_img, 0, (int)((unsigned)(B.out.cb_total - B.out.cb_off) * plane_b), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_img = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B.img + (long long)in_ * H * W), 0, H * W * 4, 0x00020000);
+    const unsigned st_e = (unsigned)cb_e * plane_b + (unsigned)(r0 + px_e) * 16u;   // (wraps for the left ghost: never stored)
+    const unsigned st_a = (unsigned)cb_a * plane_b + (unsigned)(r0 + px_a) * 16u;
+
+    // rows each stage touches: x0 rows [a_lo, a_hi) feed layer 1, x1 rows [b_lo, b_hi) layer 2, x2 rows [c_lo, c_hi) layer 3
+    const int a_lo = max(0, y_lo - 3), a_hi = min(H, y_hi + 3);
+    const int b_lo = max(0, y_lo - 2), b_hi = min(H, y_hi + 2);
+    const int c_lo = max(0, y_lo - 1), c_hi = min(H, y_hi + 1);
+    const int f_lo = max(y_lo + 6, 7), f_hi = min(a_hi, H - 1);   // steps whose three layers are all active, emit, and touch no reflect row
+
+    e2_f32x4 acc[3][3][4];
+#pragma unroll
+    for (int L = 0; L < 3; ++L)
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[L][r][t] = (e2_f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto rrow = [&](int y) { return min(max(reflect_idx(y, H), 0), H - 1); };
+    float win[3][2][3];   // image rows s-1, s, s+1 in sets (P+2) % 3, P, (P+1) % 3
+    auto ld_img_row = [&](int y, float (&dst)[2][3]) {
+        const int ro = rrow(y) * W * 4;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int v = 0; v < 3; ++v) dst[hf][v] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_img, cimg[hf][v], ro, 0));
+    };
+    const e2_i16x2 zero2 = {0, 0};
+    auto relu2 = [&](uint32_t w) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(e2_i16x2, w), zero2)); };
+
+    // ---- one row step (P = (s - a_lo) % 3 at compile time; FAST: no stage is idle, no reflect row is touched)
+    auto step = [&](auto Pc, auto Fc, int s) __attribute__((always_inline)) {
+        constexpr int P = decltype(Pc)::value;
+        constexpr bool FAST = decltype(Fc)::value != 0;
+        // ======== x0 row s: fp32 FMAs on the image (order: bias, then the nine taps row-major -- the layer-wise kernel's)
+        if (FAST || (s >= a_lo && s < a_hi)) {
+            const bool row_st = s >= y_lo && s < y_hi;
+            const int wb = lw_a + ((s & (E2_S0 - 1)) << 11);
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                e2_f32x2 a2[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a2[i] = bp[i];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const float x = win[(P + 2 + t / 3) % 3][hf][t % 3];
+                    const e2_f32x2 xx = {x, x};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) a2[i] = __builtin_elementwise_fma(xx, wp[i][t], a2[i]);
+                }
+                uint32_t wv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    wv[i] = relu2(pack_bf16x2(a2[i].x, a2[i].y));      // (the first layer always has its ReLU: the launcher checks relu0)
+                }
+                const uint4 gr = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+                *reinterpret_cast<uint4*>(smem + wb + hf * 512) = gr;
+                if (row_st && ok_a[hf]) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(e2_u32x4, gr), rs_out, st_a + hf * 512, s * row_b, 0);
+            }
+            // the row that step s + 1 shifts in (image row s + 2) replaces row s - 1 in its register set: requested one step ahead
+            ld_img_row(s + 2, win[(P + 2) % 3]);
+        }
+
+        // ======== the three DenseBlock convs: layer L consumes input row R = s - (2 L - 1) and completes its output row R - 1
+        auto layer = [&](auto Lc) __attribute__((always_inline)) {
+            constexpr int L = decltype(Lc)::value;
+            constexpr int LAG = 2 * L - 1;
+            constexpr int i0 = (P + 9 - LAG + 1) % 3, i1 = (P + 9 - LAG) % 3, i2 = (P + 9 - LAG - 1) % 3;   // accumulator rows of out rows R+1, R, R-1
+            constexpr int FB = L == 1 ? 0 : (L == 2 ? 2 : 5);
+            constexpr int XO = L == 1 ? E2_X1 : E2_X2, SO = L == 1 ? E2_S1 : E2_S2;    // ring of this layer's OUTPUT (L < 3)
+            const int R = s - LAG;
+            const int in_lo = L == 1 ? a_lo : (L == 2 ? b_lo : c_lo), in_hi = L == 1 ? a_hi : (L == 2 ? b_hi : c_hi);
+            const int out_lo = L == 1 ? b_lo : (L == 2 ? c_lo : y_lo), out_hi = L == 1 ? b_hi : (L == 2 ? c_hi : y_hi);
+            if (FAST || (R >= in_lo && R < in_hi)) {
+                const bool top = !FAST && R == 1, bot = !FAST && R == H - 2;
+                if (!FAST && R == 0) {   // image row 0 has no row above it to open its accumulator: start it from the bias here
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[L - 1][i1][t] = biasC[L - 1];
+                }
+                auto kstep = [&](int fq, const char* pb, bool first) __attribute__((always_inline)) {
+                    const char* pa = smem + la + fq * 3 * 1024;
+                    const e2_bf16x8 a0 = *reinterpret_cast<const e2_bf16x8*>(pa);
+                    const e2_bf16x8 a1 = *reinterpret_cast<const e2_bf16x8*>(pa + 1024);
+                    const e2_bf16x8 a2 = *reinterpret_cast<const e2_bf16x8*>(pa + 2048);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const e2_bf16x8 b = *reinterpret_cast<const e2_bf16x8*>(pb + t * 256);
+                        acc[L - 1][i0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b, first ? biasC[L - 1] : acc[L - 1][i0][t], 0, 0, 0);
+                        acc[L - 1][i1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b, acc[L - 1][i1][t], 0, 0, 0);
+                        acc[L - 1][i2][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b, acc[L - 1][i2][t], 0, 0, 0);
+                        if (!FAST) {
+                            if (top) acc[L - 1][i2][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b, acc[L - 1][i2][t], 0, 0, 0);   // row -1 = row 1
+                            if (bot) acc[L - 1][i0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b, acc[L - 1][i0][t], 0, 0, 0);   // row h = row h-2
+                        }
+                    }
+                };
+                if (L >= 2) {   // [x0 | x1] rows R: lane groups 0,1 read the x0 ring, 2,3 the x1 ring
+                    const int b4 = lb4 + (h2 ? E2_X1 + ((R & (E2_S1 - 1)) << 11) : E2_X0 + ((R & (E2_S0 - 1)) << 11));
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) kstep(FB + q, smem + b4 + q * 16, q == 0);
+                }
+                if (L != 2) {   // x0 (first conv) / x2 (third conv) row R
+                    const int b2 = lb2 + (L == 1 ? E2_X0 + ((R & (E2_S0 - 1)) << 11) : E2_X2 + ((R & (E2_S2 - 1)) << 11));
+                    kstep(FB + (L == 1 ? 0 : 3), smem + b2, L == 1);
+                    kstep(FB + (L == 1 ? 1 : 4), smem + b2 + 32, false);
+                }
+            }
+            // ---- epilogue of out row R - 1: round, ReLU, pair the column tiles, ring + global stores
+            const int r = R - 1;
+            if (FAST || (r >= out_lo && r < out_hi)) {
+                const bool row_st = r >= y_lo && r < y_hi;
+                const int wb = lw_e + XO + ((r & (SO - 1)) << 11);
+                const unsigned orow = (unsigned)(2 * L) * plane_b + (unsigned)r * row_b;
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    uint32_t pk[2][2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const e2_f32x4 a = acc[L - 1][i2][2 * p + e];
+                        pk[e][0] = relu2(pack_bf16x2(a[0], a[1]));
+                        pk[e][1] = relu2(pack_bf16x2(a[2], a[3]));
+                    }
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+                    const uint4 o = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                    if (L < 3) {
+                        *reinterpret_cast<uint4*>(smem + wb + p * 512) = o;
+                        // ghost pixels of an edge strip: column -1 := column 1 (ring pixel 0 := 2), column w := column w - 2
+                        if (ghost_l && p == 0 && px_e == 2) *reinterpret_cast<uint4*>(smem + wb - 32) = o;
+                        if (ghost_r && px_e + 32 * p == pg_r - 2) *reinterpret_cast<uint4*>(smem + wb + p * 512 + 32) = o;
+                    }
+                    if (row_st && ok_e[p]) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(e2_u32x4, o), rs_out, st_e + p * 512, orow, 0);
+                }
+            }
+        };
+        layer(E2I<1>());
+        layer(E2I<2>());
+        layer(E2I<3>());
+    };
+
+    // ---- the pipeline: s = a_lo .. (last x3 row + 6); phase 0 at s = a_lo
+    ld_img_row(a_lo - 1, win[2]);
+    ld_img_row(a_lo, win[0]);
+    ld_img_row(a_lo + 1, win[1]);
+    const int s_end = y_hi + 6;      // x3 row y_hi - 1 is emitted at step y_hi + 5
+    for (int s = a_lo; s < s_end; s += 3) {
+        if (s >= f_lo && s + 2 < f_hi) {
+            step(E2I<0>(), E2I<1>(), s);
+            step(E2I<1>(), E2I<1>(), s + 1);
+            step(E2I<2>(), E2I<1>(), s + 2);
+        } else {
+            step(E2I<0>(), E2I<0>(), s);
+            step(E2I<1>(), E2I<0>(), s + 1);
+            step(E2I<2>(), E2I<0>(), s + 2);
+        }
+    }
+}
+
+// items-per-launch heuristic: every (strip, segment, image, branch) is one wave, four waves a block, one block per CU (LDS).  More
+// segments fill the chip but each pays 3 warm-up rows of x0 plus the 6-step pipeline skew: minimise rounds x steps per wave.
+static void e2_geometry(int n, int h, int w, int nb, int& nstrips, int& nseg, int& seg_rows) {
+    nstrips = w <= E2_W - 2 ? 1 : 2 + (w > 120 ? (w - 120 + E2_KEEP - 1) / E2_KEEP : 0);
+    int ncu = 256;
+    {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+    }
+    long long best = -1;
+    nseg = 1;
+    for (int k = 1; k <= (h + 7) / 8; ++k) {
+        const int rows = (h + k - 1) / k;
+        const long long blocks = (long long)nb * (((long long)n * nstrips * k + E2_WAVES - 1) / E2_WAVES);
+        const long long cost = ((blocks + ncu - 1) / ncu) * (rows + 12);
+        if (best < 0 || cost < best) { best = cost; nseg = k; }
+    }
+    seg_rows = (h + nseg - 1) / nseg;
+    nseg = (h + seg_rows - 1) / seg_rows;   // drop empty trailing segments
+}
+
+static int g_es2 = -1;
+bool enc_stream2_ok(int n, int h, int w) {
+    (void)n;
+    if (g_es2 < 0) { const char* e = getenv("MMIF_ENC_STREAM2"); g_es2 = (e != nullptr && e[0] == '0') ? 0 : 1; }
+    return g_es2 == 1 && h >= 2 && w >= 2;
+}
+
+int enc_stream2_launch(EncArgs& A, int nb, hipStream_t st) {
+    MMIF_REQUIRE(A.relu0 == 1, "dense_encoder_fwd (stream2): the first layer's ReLU is compiled in");
+    MMIF_REQUIRE((long long)A.h * A.w * 4 < (1ll << 31), "dense_encoder_fwd (stream2): one image must stay below 2 GiB");
+    e2_geometry(A.n, A.h, A.w, nb, A.nstrips, A.nseg, A.seg_rows);
+    A.items = A.n * A.nseg * A.nstrips;
+    hipLaunchKernelGGL(enc_stream2_fwd_kernel, dim3(cdiv(A.items, E2_WAVES), nb), dim3(E2_WAVES * 64), 0, st, A);
+    return check_launch("dense_encoder_fwd (stream2)");
+}
+
+}  // namespace mmif
+
+extern "C" void mmif_debug_set_enc_stream2(int32_t mode) { mmif::g_es2 = mode ? 1 : 0; }

@@ -166,6 +166,7 @@ SIGNATURES = {
     "mmif_debug_set_bwd_pair_dma": (None, [_i32]),
     "mmif_debug_set_thin_wide": (None, [_i32]),
     "mmif_debug_set_wgrad_dma_blocks": (None, [_i32]),
+    "mmif_debug_set_enc_stream2": (None, [_i32]),
     "mmif_probe_tr16": (_i32, [_vp, _vp, _vp]),
     "mmif_probe_mfma": (_i32, [_vp, _vp, _vp, _vp]),
     "mmif_probe_dma": (_i32, [_vp, _vp, _vp, _vp, _vp]),

