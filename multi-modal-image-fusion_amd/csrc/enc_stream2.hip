@@ -45,7 +45,8 @@ constexpr int E2_S0 = 8, E2_S1 = 4, E2_S2 = 2; // ring slots of x0 / x1 / x2 (po
 constexpr int E2_X0 = 0, E2_X1 = E2_S0 * E2_ROW, E2_X2 = E2_X1 + E2_S1 * E2_ROW, E2_RING = E2_X2 + E2_S2 * E2_ROW;   // 28672
 constexpr int E2_WAVES = 4;
 constexpr int E2_NFRAG = 30;                   // A fragments: (2 + 3 + 5 k-steps) x 3 tap rows, 1 KB each
-constexpr int E2_WBYTES = E2_NFRAG * 1024;
+constexpr int E2_W0 = E2_NFRAG * 1024;        // first layer's fp32 weights [cb 2][tap 9][8 ch] + bias [cb 2][8]: 640 B, read by broadcast
+constexpr int E2_WBYTES = E2_W0 + 640;
 constexpr int E2_LDS = E2_WBYTES + E2_WAVES * E2_RING + 64;   // (+ 64: operand reads run up to two granules past a row)
 
 template <int N> struct E2I { static constexpr int value = N; };
@@ -72,6 +73,13 @@ __global__ __launch_bounds__(E2_WAVES * 64, 1) void enc_stream2_fwd_kernel(EncAr
             plane = base + ((q2 == 1 && kg >= 2) ? 18 + (kg & 1) : (u * 3 + (q2 == 0 ? (kg >> 1) : 2)) * 2 + (kg & 1));
         }
         reinterpret_cast<uint4*>(smem)[e] = B.wpk[L - 1][plane * 16 + oc];
+    }
+    // first layer: [cb][tap][8 channels] fp32 (a lane's 8 channels of one tap = two 16-byte broadcast reads), then the biases [cb][8]
+    for (int e = tid; e < 160; e += E2_WAVES * 64) {
+        float v;
+        if (e < 144) { const int cb = e / 72, t = (e % 72) / 8, c = e % 8; v = B.w0[(cb * 8 + c) * 9 + t]; }
+        else v = B.b0 != nullptr ? B.b0[e - 144] : 0.f;
+        reinterpret_cast<float*>(smem + E2_W0)[e] = v;
     }
     // the wave's ring starts zeroed: pad k-groups, warm-up rows and the granules next to a row are read before they are ever written
     // (their products are multiplied by zero weights or only reach discarded columns, but NaN bit patterns would not stay there)
@@ -127,14 +135,7 @@ __global__ __launch_bounds__(E2_WAVES * 64, 1) void enc_stream2_fwd_kernel(EncAr
 #pragma unroll
         for (int v = 0; v < 3; ++v) cimg[hf][v] = 4 * min(max(reflect_idx(c + v - 1, W), 0), W - 1);   // byte offset inside an image row
     }
-    e2_f32x2 wp[4][9], bp[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c0 = cb_a * 8 + 2 * i;
-        bp[i] = B.b0 != nullptr ? (e2_f32x2){B.b0[c0], B.b0[c0 + 1]} : (e2_f32x2){0.f, 0.f};
-#pragma unroll
-        for (int t = 0; t < 9; ++t) wp[i][t] = (e2_f32x2){B.w0[c0 * 9 + t], B.w0[(c0 + 1) * 9 + t]};
-    }
+    const int lx0 = E2_W0 + cb_a * 288;               // this lane's first-layer weights: tap t at + 32 t (8 floats), bias at E2_W0 + 576 + 32 cb
     e2_f32x4 biasC[3];    // C operand of a fresh accumulator: this lane's output channels 4 g .. 4 g + 3
 #pragma unroll
     for (int L = 0; L < 3; ++L)
@@ -147,8 +148,13 @@ __global__ __launch_bounds__(E2_WAVES * 64, 1) void enc_stream2_fwd_kernel(EncAr
     char* out_img = B.out.base + ((long long)in_ * B.out.img + (long long)B.out.cb_off * B.out.plane) * 16;
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(out_img, 0, (int)((unsigned)(B.out.cb_total - B.out.cb_off) * plane_b), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_img = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B.img + (long long)in_ * H * W), 0, H * W * 4, 0x00020000);
-    const unsigned st_e = (unsigned)cb_e * plane_b + (unsigned)(r0 + px_e) * 16u;   // (wraps for the left ghost: never stored)
-    const unsigned st_a = (unsigned)cb_a * plane_b + (unsigned)(r0 + px_a) * 16u;
+    // per-lane store offsets; a lane outside the strip's kept columns carries bit 31 = beyond the descriptor's range = dropped
+    unsigned st_e[2], st_a[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        st_e[p] = ok_e[p] ? (unsigned)cb_e * plane_b + (unsigned)(r0 + px_e + 32 * p) * 16u : 0x80000000u;
+        st_a[p] = ok_a[p] ? (unsigned)cb_a * plane_b + (unsigned)(r0 + px_a + 32 * p) * 16u : 0x80000000u;
+    }
 
     // rows each stage touches: x0 rows [a_lo, a_hi) feed layer 1, x1 rows [b_lo, b_hi) layer 2, x2 rows [c_lo, c_hi) layer 3
     const int a_lo = max(0, y_lo - 3), a_hi = min(H, y_hi + 3);
@@ -176,130 +182,192 @@ __global__ __launch_bounds__(E2_WAVES * 64, 1) void enc_stream2_fwd_kernel(EncAr
     const e2_i16x2 zero2 = {0, 0};
     auto relu2 = [&](uint32_t w) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(e2_i16x2, w), zero2)); };
 
-    // ---- one row step (P = (s - a_lo) % 3 at compile time; FAST: no stage is idle, no reflect row is touched)
+    // ---- one row step (P = (s - a_lo) % 3 at compile time; FAST: no stage is idle, no reflect row is touched).
+    // The step is a FLAT software pipeline over its ten k-steps (16->16: 2, 32->16: 3, 48->16: 5): region n requests the operand
+    // fragments of k-step n + 1 and runs the 12 MFMAs of k-step n on the fragments requested one region earlier, plus one slice of the
+    // step's VALU work (the two halves of the x0 row, the epilogue of the layer that finished one region ago).  The regions are
+    // separated by scheduling fences: left alone, the scheduler hoists every LDS read of the step to its top (one wave per SIMD = a
+    // 512-register budget it is happy to fill) and the allocator spills -- scratch reloads wait on vmcnt(0), i.e. on the step's stores.
+#define E2_FENCE() __builtin_amdgcn_sched_barrier(0)
     auto step = [&](auto Pc, auto Fc, int s) __attribute__((always_inline)) {
         constexpr int P = decltype(Pc)::value;
         constexpr bool FAST = decltype(Fc)::value != 0;
-        // ======== x0 row s: fp32 FMAs on the image (order: bias, then the nine taps row-major -- the layer-wise kernel's)
-        if (FAST || (s >= a_lo && s < a_hi)) {
-            const bool row_st = s >= y_lo && s < y_hi;
-            const int wb = lw_a + ((s & (E2_S0 - 1)) << 11);
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                e2_f32x2 a2[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) a2[i] = bp[i];
-#pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const float x = win[(P + 2 + t / 3) % 3][hf][t % 3];
-                    const e2_f32x2 xx = {x, x};
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) a2[i] = __builtin_elementwise_fma(xx, wp[i][t], a2[i]);
-                }
-                uint32_t wv[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    wv[i] = relu2(pack_bf16x2(a2[i].x, a2[i].y));      // (the first layer always has its ReLU: the launcher checks relu0)
-                }
-                const uint4 gr = make_uint4(wv[0], wv[1], wv[2], wv[3]);
-                *reinterpret_cast<uint4*>(smem + wb + hf * 512) = gr;
-                if (row_st && ok_a[hf]) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(e2_u32x4, gr), rs_out, st_a + hf * 512, s * row_b, 0);
-            }
-            // the row that step s + 1 shifts in (image row s + 2) replaces row s - 1 in its register set: requested one step ahead
-            ld_img_row(s + 2, win[(P + 2) % 3]);
-        }
+        const int R1 = s - 1, R2 = s - 3, R3 = s - 5;      // input row of layer L = s - (2 L - 1); it completes out row R - 1
+        const bool x0_on = FAST || (s >= a_lo && s < a_hi);
+        const bool on1 = FAST || (R1 >= a_lo && R1 < a_hi), on2 = FAST || (R2 >= b_lo && R2 < b_hi), on3 = FAST || (R3 >= c_lo && R3 < c_hi);
+        const bool em1 = FAST || (R1 - 1 >= b_lo && R1 - 1 < b_hi), em2 = FAST || (R2 - 1 >= c_lo && R2 - 1 < c_hi),
+                   em3 = FAST || (R3 - 1 >= y_lo && R3 - 1 < y_hi);
+        // operand bases of this step (lane groups 0,1 of a four-block chunk read the x0 ring, 2,3 the x1 ring)
+        const int bL1 = lb2 + E2_X0 + ((R1 & (E2_S0 - 1)) << 11);
+        const int bL2 = lb4 + (h2 ? E2_X1 + ((R2 & (E2_S1 - 1)) << 11) : E2_X0 + ((R2 & (E2_S0 - 1)) << 11));
+        const int bL3 = lb4 + (h2 ? E2_X1 + ((R3 & (E2_S1 - 1)) << 11) : E2_X0 + ((R3 & (E2_S0 - 1)) << 11));
+        const int bL3x = lb2 + E2_X2 + ((R3 & (E2_S2 - 1)) << 11);
+        e2_bf16x8 fa[2][3], fb[2][4];       // double-buffered fragments: k-step n lives in set n & 1
 
-        // ======== the three DenseBlock convs: layer L consumes input row R = s - (2 L - 1) and completes its output row R - 1
-        auto layer = [&](auto Lc) __attribute__((always_inline)) {
-            constexpr int L = decltype(Lc)::value;
-            constexpr int LAG = 2 * L - 1;
+        // k-step n: 0,1 = 16->16 on x0 | 2..4 = 32->16 on [x0 | x1] | 5..7 = 48->16 on [x0 | x1], 8,9 = on x2
+        auto load_k = [&](auto Nc) __attribute__((always_inline)) {
+            constexpr int N = decltype(Nc)::value;
+            const char* pa = smem + la + N * 3 * 1024;
+#pragma unroll
+            for (int u = 0; u < 3; ++u) fa[N & 1][u] = *reinterpret_cast<const e2_bf16x8*>(pa + u * 1024);
+            const char* pb = smem + (N < 2 ? bL1 + 32 * N : (N < 5 ? bL2 + 16 * (N - 2) : (N < 8 ? bL3 + 16 * (N - 5) : bL3x + 32 * (N - 8))));
+#pragma unroll
+            for (int t = 0; t < 4; ++t) fb[N & 1][t] = *reinterpret_cast<const e2_bf16x8*>(pb + t * 256);
+        };
+        auto mma_k = [&](auto Nc) __attribute__((always_inline)) {
+            constexpr int N = decltype(Nc)::value;
+            constexpr int L = N < 2 ? 1 : (N < 5 ? 2 : 3), LAG = 2 * L - 1;
+            constexpr bool first = N == 0 || N == 2 || N == 5;
             constexpr int i0 = (P + 9 - LAG + 1) % 3, i1 = (P + 9 - LAG) % 3, i2 = (P + 9 - LAG - 1) % 3;   // accumulator rows of out rows R+1, R, R-1
-            constexpr int FB = L == 1 ? 0 : (L == 2 ? 2 : 5);
-            constexpr int XO = L == 1 ? E2_X1 : E2_X2, SO = L == 1 ? E2_S1 : E2_S2;    // ring of this layer's OUTPUT (L < 3)
             const int R = s - LAG;
-            const int in_lo = L == 1 ? a_lo : (L == 2 ? b_lo : c_lo), in_hi = L == 1 ? a_hi : (L == 2 ? b_hi : c_hi);
-            const int out_lo = L == 1 ? b_lo : (L == 2 ? c_lo : y_lo), out_hi = L == 1 ? b_hi : (L == 2 ? c_hi : y_hi);
-            if (FAST || (R >= in_lo && R < in_hi)) {
-                const bool top = !FAST && R == 1, bot = !FAST && R == H - 2;
-                if (!FAST && R == 0) {   // image row 0 has no row above it to open its accumulator: start it from the bias here
+            const bool top = !FAST && R == 1, bot = !FAST && R == H - 2;
+            if (!FAST && first && R == 0) {   // image row 0 has no row above it to open its accumulator: start it from the bias here
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) acc[L - 1][i1][t] = biasC[L - 1];
-                }
-                auto kstep = [&](int fq, const char* pb, bool first) __attribute__((always_inline)) {
-                    const char* pa = smem + la + fq * 3 * 1024;
-                    const e2_bf16x8 a0 = *reinterpret_cast<const e2_bf16x8*>(pa);
-                    const e2_bf16x8 a1 = *reinterpret_cast<const e2_bf16x8*>(pa + 1024);
-                    const e2_bf16x8 a2 = *reinterpret_cast<const e2_bf16x8*>(pa + 2048);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const e2_bf16x8 b = *reinterpret_cast<const e2_bf16x8*>(pb + t * 256);
-                        acc[L - 1][i0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b, first ? biasC[L - 1] : acc[L - 1][i0][t], 0, 0, 0);
-                        acc[L - 1][i1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b, acc[L - 1][i1][t], 0, 0, 0);
-                        acc[L - 1][i2][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b, acc[L - 1][i2][t], 0, 0, 0);
-                        if (!FAST) {
-                            if (top) acc[L - 1][i2][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b, acc[L - 1][i2][t], 0, 0, 0);   // row -1 = row 1
-                            if (bot) acc[L - 1][i0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b, acc[L - 1][i0][t], 0, 0, 0);   // row h = row h-2
-                        }
-                    }
-                };
-                if (L >= 2) {   // [x0 | x1] rows R: lane groups 0,1 read the x0 ring, 2,3 the x1 ring
-                    const int b4 = lb4 + (h2 ? E2_X1 + ((R & (E2_S1 - 1)) << 11) : E2_X0 + ((R & (E2_S0 - 1)) << 11));
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) kstep(FB + q, smem + b4 + q * 16, q == 0);
-                }
-                if (L != 2) {   // x0 (first conv) / x2 (third conv) row R
-                    const int b2 = lb2 + (L == 1 ? E2_X0 + ((R & (E2_S0 - 1)) << 11) : E2_X2 + ((R & (E2_S2 - 1)) << 11));
-                    kstep(FB + (L == 1 ? 0 : 3), smem + b2, L == 1);
-                    kstep(FB + (L == 1 ? 1 : 4), smem + b2 + 32, false);
-                }
+                for (int t = 0; t < 4; ++t) acc[L - 1][i1][t] = biasC[L - 1];
             }
-            // ---- epilogue of out row R - 1: round, ReLU, pair the column tiles, ring + global stores
-            const int r = R - 1;
-            if (FAST || (r >= out_lo && r < out_hi)) {
-                const bool row_st = r >= y_lo && r < y_hi;
-                const int wb = lw_e + XO + ((r & (SO - 1)) << 11);
-                const unsigned orow = (unsigned)(2 * L) * plane_b + (unsigned)r * row_b;
 #pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    uint32_t pk[2][2];
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const e2_f32x4 a = acc[L - 1][i2][2 * p + e];
-                        pk[e][0] = relu2(pack_bf16x2(a[0], a[1]));
-                        pk[e][1] = relu2(pack_bf16x2(a[2], a[3]));
-                    }
-                    const auto s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
-                    const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
-                    const uint4 o = make_uint4(s0[0], s1[0], s0[1], s1[1]);
-                    if (L < 3) {
-                        *reinterpret_cast<uint4*>(smem + wb + p * 512) = o;
-                        // ghost pixels of an edge strip: column -1 := column 1 (ring pixel 0 := 2), column w := column w - 2
-                        if (ghost_l && p == 0 && px_e == 2) *reinterpret_cast<uint4*>(smem + wb - 32) = o;
-                        if (ghost_r && px_e + 32 * p == pg_r - 2) *reinterpret_cast<uint4*>(smem + wb + p * 512 + 32) = o;
-                    }
-                    if (row_st && ok_e[p]) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(e2_u32x4, o), rs_out, st_e + p * 512, orow, 0);
+            for (int t = 0; t < 4; ++t) {
+                const e2_bf16x8 b = fb[N & 1][t];
+                acc[L - 1][i0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[N & 1][0], b, first ? biasC[L - 1] : acc[L - 1][i0][t], 0, 0, 0);
+                acc[L - 1][i1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[N & 1][1], b, acc[L - 1][i1][t], 0, 0, 0);
+                acc[L - 1][i2][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[N & 1][2], b, acc[L - 1][i2][t], 0, 0, 0);
+                if (!FAST) {
+                    if (top) acc[L - 1][i2][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[N & 1][0], b, acc[L - 1][i2][t], 0, 0, 0);   // row -1 = row 1
+                    if (bot) acc[L - 1][i0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[N & 1][2], b, acc[L - 1][i0][t], 0, 0, 0);   // row h = row h-2
                 }
             }
         };
-        layer(E2I<1>());
-        layer(E2I<2>());
-        layer(E2I<3>());
+        // x0 row s (both 32-pixel halves): fp32 FMAs on the image, order per channel = bias, then the nine taps row-major (the
+        // layer-wise kernel's).  The weights come from LDS by broadcast reads, tap by tap (held in registers they cost 80 VGPRs).
+        e2_f32x2 a2[2][4];
+        auto x0_taps = [&](int t0, int t1) __attribute__((always_inline)) {
+            if (t0 == 0) {
+                const float4 b0 = *reinterpret_cast<const float4*>(smem + E2_W0 + 576 + cb_a * 32), b1 = *reinterpret_cast<const float4*>(smem + E2_W0 + 592 + cb_a * 32);
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    a2[hf][0] = (e2_f32x2){b0.x, b0.y}; a2[hf][1] = (e2_f32x2){b0.z, b0.w};
+                    a2[hf][2] = (e2_f32x2){b1.x, b1.y}; a2[hf][3] = (e2_f32x2){b1.z, b1.w};
+                }
+            }
+#pragma unroll
+            for (int t = t0; t < t1; ++t) {
+                const float4 w0 = *reinterpret_cast<const float4*>(smem + lx0 + t * 32), w1 = *reinterpret_cast<const float4*>(smem + lx0 + t * 32 + 16);
+                const e2_f32x2 wq[4] = {{w0.x, w0.y}, {w0.z, w0.w}, {w1.x, w1.y}, {w1.z, w1.w}};
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const float x = win[(P + 2 + t / 3) % 3][hf][t % 3];
+                    const e2_f32x2 xx = {x, x};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) a2[hf][i] = __builtin_elementwise_fma(xx, wq[i], a2[hf][i]);
+                }
+            }
+        };
+        auto x0_finish = [&]() __attribute__((always_inline)) {
+            // unconditional stores: lanes outside the kept columns carry an out-of-range offset (st_a), rows of another segment get the bit here
+            const unsigned own = (s >= y_lo && s < y_hi) ? 0u : 0x80000000u;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                uint32_t wv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) wv[i] = relu2(pack_bf16x2(a2[hf][i].x, a2[hf][i].y));      // (the first layer always has its ReLU: the launcher checks relu0)
+                const uint4 gr = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+                *reinterpret_cast<uint4*>(smem + lw_a + ((s & (E2_S0 - 1)) << 11) + hf * 512) = gr;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(e2_u32x4, gr), rs_out, (int)(st_a[hf] | own), s * (int)row_b, 0);
+            }
+        };
+        // epilogue of out row R - 1 of layer L: round, ReLU, pair the column tiles, ring + global stores, ghost pixels
+        auto epilogue = [&](auto Lc) __attribute__((always_inline)) {
+            constexpr int L = decltype(Lc)::value;
+            constexpr int LAG = 2 * L - 1;
+            constexpr int i2 = (P + 9 - LAG - 1) % 3;
+            constexpr int XO = L == 1 ? E2_X1 : E2_X2, SO = L == 1 ? E2_S1 : E2_S2;    // ring of this layer's OUTPUT (L < 3)
+            const int r = s - LAG - 1;
+            const int wb = lw_e + XO + ((r & (SO - 1)) << 11);
+            const unsigned own = (r >= y_lo && r < y_hi) ? 0u : 0x80000000u;
+            const int orow = (int)((unsigned)(2 * L) * plane_b + (unsigned)r * row_b);
+            uint4 o[2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                uint32_t pk[2][2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const e2_f32x4 a = acc[L - 1][i2][2 * p + e];
+                    pk[e][0] = relu2(pack_bf16x2(a[0], a[1]));
+                    pk[e][1] = relu2(pack_bf16x2(a[2], a[3]));
+                }
+                const auto s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+                o[p] = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                if (L < 3) *reinterpret_cast<uint4*>(smem + wb + p * 512) = o[p];
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(e2_u32x4, o[p]), rs_out, (int)(st_e[p] | own), orow, 0);
+            }
+            if (L < 3) {
+                // ghost pixels of an edge strip, AFTER both halves of the row are in the ring (a narrow image's right ghost lies inside
+                // the computed range): column -1 := column 1 (ring pixel 0 := 2), column w := column w - 2
+                if (ghost_l && px_e == 2) *reinterpret_cast<uint4*>(smem + wb - 32) = o[0];
+                if (ghost_r) {
+#pragma unroll
+                    for (int p = 0; p < 2; ++p)
+                        if (px_e + 32 * p == pg_r - 2) *reinterpret_cast<uint4*>(smem + wb + p * 512 + 32) = o[p];
+                }
+            }
+        };
+
+        load_k(E2I<0>());
+        E2_FENCE();
+        load_k(E2I<1>()); if (on1) mma_k(E2I<0>()); if (x0_on) x0_taps(0, 5);
+        E2_FENCE();
+        load_k(E2I<2>()); if (on1) mma_k(E2I<1>()); if (x0_on) { x0_taps(5, 9); x0_finish(); }
+        E2_FENCE();
+        // (the image row that step s + 1 shifts in -- row s + 2 -- replaces row s - 1 in its register set: requested as soon as the x0
+        // row is done, a whole step ahead of its use)
+        load_k(E2I<3>()); if (on2) mma_k(E2I<2>()); if (x0_on) ld_img_row(s + 2, win[(P + 2) % 3]); if (em1) epilogue(E2I<1>());
+        E2_FENCE();
+        load_k(E2I<4>()); if (on2) mma_k(E2I<3>());
+        E2_FENCE();
+        load_k(E2I<5>()); if (on2) mma_k(E2I<4>());
+        E2_FENCE();
+        load_k(E2I<6>()); if (on3) mma_k(E2I<5>()); if (em2) epilogue(E2I<2>());
+        E2_FENCE();
+        load_k(E2I<7>()); if (on3) mma_k(E2I<6>());
+        E2_FENCE();
+        load_k(E2I<8>()); if (on3) mma_k(E2I<7>());
+        E2_FENCE();
+        load_k(E2I<9>()); if (on3) mma_k(E2I<8>());
+        E2_FENCE();
+        if (on3) mma_k(E2I<9>());
+        E2_FENCE();
+        if (em3) epilogue(E2I<3>());
+        E2_FENCE();
     };
+#undef E2_FENCE
 
     // ---- the pipeline: s = a_lo .. (last x3 row + 6); phase 0 at s = a_lo
     ld_img_row(a_lo - 1, win[2]);
     ld_img_row(a_lo, win[0]);
     ld_img_row(a_lo + 1, win[1]);
     const int s_end = y_hi + 6;      // x3 row y_hi - 1 is emitted at step y_hi + 5
-    for (int s = a_lo; s < s_end; s += 3) {
-        if (s >= f_lo && s + 2 < f_hi) {
-            step(E2I<0>(), E2I<1>(), s);
-            step(E2I<1>(), E2I<1>(), s + 1);
-            step(E2I<2>(), E2I<1>(), s + 2);
-        } else {
+    // Three stretches of steps, in groups of three (the accumulator rotation): general steps up to the first group that lies inside
+    // [f_lo, f_hi), the branch-free groups, general steps again to the end.  The general body and the fast body are SEPARATE loops of one
+    // outer loop -- as the two arms of an if inside a single row loop they made the register allocator shuffle the 144 accumulator
+    // registers between the arms in every iteration (512 registers + scratch; either body alone needs 172 + 144 / 194 + 240).
+    int s = a_lo;
+#pragma unroll 1
+    for (int part = 0; part < 2; ++part) {
+        const int stop = part == 0 ? min(s_end, f_lo) : s_end;
+#pragma unroll 1
+        for (; s < stop; s += 3) {
             step(E2I<0>(), E2I<0>(), s);
             step(E2I<1>(), E2I<0>(), s + 1);
             step(E2I<2>(), E2I<0>(), s + 2);
+        }
+        if (part == 0) {
+#pragma unroll 1
+            for (; s + 2 < f_hi; s += 3) {
+                step(E2I<0>(), E2I<1>(), s);
+                step(E2I<1>(), E2I<1>(), s + 1);
+                step(E2I<2>(), E2I<1>(), s + 2);
+            }
         }
     }
 }
@@ -336,6 +404,9 @@ bool enc_stream2_ok(int n, int h, int w) {
 int enc_stream2_launch(EncArgs& A, int nb, hipStream_t st) {
     MMIF_REQUIRE(A.relu0 == 1, "dense_encoder_fwd (stream2): the first layer's ReLU is compiled in");
     MMIF_REQUIRE((long long)A.h * A.w * 4 < (1ll << 31), "dense_encoder_fwd (stream2): one image must stay below 2 GiB");
+    for (int b = 0; b < nb; ++b)
+        MMIF_REQUIRE((long long)A.br[b].out.cb_total * A.br[b].out.plane * 16 < (1ll << 31),
+                     "dense_encoder_fwd (stream2): one image of the output allocation must stay below 2 GiB (bit 31 of a store offset = masked lane)");
     e2_geometry(A.n, A.h, A.w, nb, A.nstrips, A.nseg, A.seg_rows);
     A.items = A.n * A.nseg * A.nstrips;
     hipLaunchKernelGGL(enc_stream2_fwd_kernel, dim3(cdiv(A.items, E2_WAVES), nb), dim3(E2_WAVES * 64), 0, st, A);
