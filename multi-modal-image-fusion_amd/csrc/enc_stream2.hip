@@ -45,8 +45,7 @@ constexpr int E2_S0 = 8, E2_S1 = 4, E2_S2 = 2; // ring slots of x0 / x1 / x2 (po
 constexpr int E2_X0 = 0, E2_X1 = E2_S0 * E2_ROW, E2_X2 = E2_X1 + E2_S1 * E2_ROW, E2_RING = E2_X2 + E2_S2 * E2_ROW;   // 28672
 constexpr int E2_WAVES = 4;
 constexpr int E2_NFRAG = 30;                   // A fragments: (2 + 3 + 5 k-steps) x 3 tap rows, 1 KB each
-constexpr int E2_W0 = E2_NFRAG * 1024;        // first layer's fp32 weights [cb 2][tap 9][8 ch] + bias [cb 2][8]: 640 B, read by broadcast
-constexpr int E2_WBYTES = E2_W0 + 640;
+constexpr int E2_WBYTES = E2_NFRAG * 1024;
 constexpr int E2_LDS = E2_WBYTES + E2_WAVES * E2_RING + 64;   // (+ 64: operand reads run up to two granules past a row)
 
 template <int N> struct E2I { static constexpr int value = N; };
@@ -73,13 +72,6 @@ __global__ __launch_bounds__(E2_WAVES * 64, 1) void enc_stream2_fwd_kernel(EncAr
             plane = base + ((q2 == 1 && kg >= 2) ? 18 + (kg & 1) : (u * 3 + (q2 == 0 ? (kg >> 1) : 2)) * 2 + (kg & 1));
         }
         reinterpret_cast<uint4*>(smem)[e] = B.wpk[L - 1][plane * 16 + oc];
-    }
-    // first layer: [cb][tap][8 channels] fp32 (a lane's 8 channels of one tap = two 16-byte broadcast reads), then the biases [cb][8]
-    for (int e = tid; e < 160; e += E2_WAVES * 64) {
-        float v;
-        if (e < 144) { const int cb = e / 72, t = (e % 72) / 8, c = e % 8; v = B.w0[(cb * 8 + c) * 9 + t]; }
-        else v = B.b0 != nullptr ? B.b0[e - 144] : 0.f;
-        reinterpret_cast<float*>(smem + E2_W0)[e] = v;
     }
     // the wave's ring starts zeroed: pad k-groups, warm-up rows and the granules next to a row are read before they are ever written
     // (their products are multiplied by zero weights or only reach discarded columns, but NaN bit patterns would not stay there)
@@ -118,24 +110,28 @@ __global__ __launch_bounds__(E2_WAVES * 64, 1) void enc_stream2_fwd_kernel(EncAr
     // epilogue side (after the row swap): this lane holds the granule of pixel 32 p + 16 (g & 1) + j, channel block g >> 1
     const int px_e = 16 * (g & 1) + j, cb_e = g >> 1;
     const int lw_e = ring + cb_e * 1024 + px_e * 16;
-    // first layer (VALU): lane = (pixel lane & 31 (+ 32 hf), channel block lane >> 5); its 8 channels' weights live in registers
-    const int px_a = lane & 31, cb_a = lane >> 5;
-    const int lw_a = ring + E2_X0 + cb_a * 1024 + px_a * 16;
-    bool ok_e[2], ok_a[2];
+    bool ok_e[2];
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-        const int ce = r0 + px_e + 32 * p, ca = r0 + px_a + 32 * p;
+        const int ce = r0 + px_e + 32 * p;
         ok_e[p] = ce >= o_lo && ce < o_hi;
-        ok_a[p] = ca >= o_lo && ca < o_hi;
     }
-    int cimg[2][3];
+    // first layer on the fp32 matrix path (v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulate): one MFMA per tap ROW u, its
+    // K = 4 the three tap columns (k-group g = column g - 1; g = 3 is padding).  The B operand of lane (pixel j, group g) is the image
+    // value at (row s - 1 + u, column reflect(16 t + j) + g - 1) -- loaded straight into the operand register, no VALU work at all --,
+    // the A operand the weight w0[oc j][u][g].  Output layout = the bf16 layers', so x0 shares their epilogue.
+    int cimg[4];          // byte offset inside an image row per column tile; bit 31 (beyond the descriptor: loads return 0) for the pad group
+    float a0[3];
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
-        const int c = min(max(reflect_idx(r0 + px_a + 32 * hf, W), 0), W - 1);
-#pragma unroll
-        for (int v = 0; v < 3; ++v) cimg[hf][v] = 4 * min(max(reflect_idx(c + v - 1, W), 0), W - 1);   // byte offset inside an image row
+    for (int t = 0; t < 4; ++t) {
+        const int c = min(max(reflect_idx(r0 + 16 * t + j, W), 0), W - 1);
+        cimg[t] = g < 3 ? 4 * min(max(reflect_idx(c + g - 1, W), 0), W - 1) : (int)0x80000000u;
     }
-    const int lx0 = E2_W0 + cb_a * 288;               // this lane's first-layer weights: tap t at + 32 t (8 floats), bias at E2_W0 + 576 + 32 cb
+#pragma unroll
+    for (int u = 0; u < 3; ++u) a0[u] = g < 3 ? B.w0[j * 9 + u * 3 + g] : 0.f;
+    e2_f32x4 biasC0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) biasC0[r] = B.b0 != nullptr ? B.b0[4 * g + r] : 0.f;
     e2_f32x4 biasC[3];    // C operand of a fresh accumulator: this lane's output channels 4 g .. 4 g + 3
 #pragma unroll
     for (int L = 0; L < 3; ++L)
@@ -149,12 +145,9 @@ __global__ __launch_bounds__(E2_WAVES * 64, 1) void enc_stream2_fwd_kernel(EncAr
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(out_img, 0, (int)((unsigned)(B.out.cb_total - B.out.cb_off) * plane_b), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_img = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B.img + (long long)in_ * H * W), 0, H * W * 4, 0x00020000);
     // per-lane store offsets; a lane outside the strip's kept columns carries bit 31 = beyond the descriptor's range = dropped
-    unsigned st_e[2], st_a[2];
+    unsigned st_e[2];
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        st_e[p] = ok_e[p] ? (unsigned)cb_e * plane_b + (unsigned)(r0 + px_e + 32 * p) * 16u : 0x80000000u;
-        st_a[p] = ok_a[p] ? (unsigned)cb_a * plane_b + (unsigned)(r0 + px_a + 32 * p) * 16u : 0x80000000u;
-    }
+    for (int p = 0; p < 2; ++p) st_e[p] = ok_e[p] ? (unsigned)cb_e * plane_b + (unsigned)(r0 + px_e + 32 * p) * 16u : 0x80000000u;
 
     // rows each stage touches: x0 rows [a_lo, a_hi) feed layer 1, x1 rows [b_lo, b_hi) layer 2, x2 rows [c_lo, c_hi) layer 3
     const int a_lo = max(0, y_lo - 3), a_hi = min(H, y_hi + 3);
@@ -171,13 +164,11 @@ __global__ __launch_bounds__(E2_WAVES * 64, 1) void enc_stream2_fwd_kernel(EncAr
             for (int t = 0; t < 4; ++t) acc[L][r][t] = (e2_f32x4){0.f, 0.f, 0.f, 0.f};
 
     auto rrow = [&](int y) { return min(max(reflect_idx(y, H), 0), H - 1); };
-    float win[3][2][3];   // image rows s-1, s, s+1 in sets (P+2) % 3, P, (P+1) % 3
-    auto ld_img_row = [&](int y, float (&dst)[2][3]) {
+    float win[3][4];   // image rows s-1, s, s+1 (one operand value per column tile) in sets (P+2) % 3, P, (P+1) % 3
+    auto ld_img_row = [&](int y, float (&dst)[4]) {
         const int ro = rrow(y) * W * 4;
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-            for (int v = 0; v < 3; ++v) dst[hf][v] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_img, cimg[hf][v], ro, 0));
+        for (int t = 0; t < 4; ++t) dst[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_img, cimg[t], ro, 0));
     };
     const e2_i16x2 zero2 = {0, 0};
     auto relu2 = [&](uint32_t w) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(e2_i16x2, w), zero2)); };
@@ -237,51 +228,23 @@ __global__ __launch_bounds__(E2_WAVES * 64, 1) void enc_stream2_fwd_kernel(EncAr
                 }
             }
         };
-        // x0 row s (both 32-pixel halves): fp32 FMAs on the image, order per channel = bias, then the nine taps row-major (the
-        // layer-wise kernel's).  The weights come from LDS by broadcast reads, tap by tap (held in registers they cost 80 VGPRs).
-        e2_f32x2 a2[2][4];
-        auto x0_taps = [&](int t0, int t1) __attribute__((always_inline)) {
-            if (t0 == 0) {
-                const float4 b0 = *reinterpret_cast<const float4*>(smem + E2_W0 + 576 + cb_a * 32), b1 = *reinterpret_cast<const float4*>(smem + E2_W0 + 592 + cb_a * 32);
+        // x0 row s: three fp32 MFMAs per column tile (tap rows u = 0, 1, 2 on image rows s - 1, s, s + 1), the bias as the first C
+        e2_f32x4 acc0[4];
+        auto x0_mma = [&]() __attribute__((always_inline)) {
 #pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    a2[hf][0] = (e2_f32x2){b0.x, b0.y}; a2[hf][1] = (e2_f32x2){b0.z, b0.w};
-                    a2[hf][2] = (e2_f32x2){b1.x, b1.y}; a2[hf][3] = (e2_f32x2){b1.z, b1.w};
-                }
-            }
+            for (int u = 0; u < 3; ++u)
 #pragma unroll
-            for (int t = t0; t < t1; ++t) {
-                const float4 w0 = *reinterpret_cast<const float4*>(smem + lx0 + t * 32), w1 = *reinterpret_cast<const float4*>(smem + lx0 + t * 32 + 16);
-                const e2_f32x2 wq[4] = {{w0.x, w0.y}, {w0.z, w0.w}, {w1.x, w1.y}, {w1.z, w1.w}};
-#pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    const float x = win[(P + 2 + t / 3) % 3][hf][t % 3];
-                    const e2_f32x2 xx = {x, x};
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) a2[hf][i] = __builtin_elementwise_fma(xx, wq[i], a2[hf][i]);
-                }
-            }
+                for (int t = 0; t < 4; ++t)
+                    acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u], win[(P + 2 + u) % 3][t], u == 0 ? biasC0 : acc0[t], 0, 0, 0);
         };
-        auto x0_finish = [&]() __attribute__((always_inline)) {
-            // unconditional stores: lanes outside the kept columns carry an out-of-range offset (st_a), rows of another segment get the bit here
-            const unsigned own = (s >= y_lo && s < y_hi) ? 0u : 0x80000000u;
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                uint32_t wv[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) wv[i] = relu2(pack_bf16x2(a2[hf][i].x, a2[hf][i].y));      // (the first layer always has its ReLU: the launcher checks relu0)
-                const uint4 gr = make_uint4(wv[0], wv[1], wv[2], wv[3]);
-                *reinterpret_cast<uint4*>(smem + lw_a + ((s & (E2_S0 - 1)) << 11) + hf * 512) = gr;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(e2_u32x4, gr), rs_out, (int)(st_a[hf] | own), s * (int)row_b, 0);
-            }
-        };
-        // epilogue of out row R - 1 of layer L: round, ReLU, pair the column tiles, ring + global stores, ghost pixels
+        // epilogue of a finished row (x0: row s; layer L >= 1: out row R - 1 = s - 2 L): round, ReLU (as a signed 16-bit max on the rounded
+        // pair), pair the column tiles, ring + global stores, ghost pixels
         auto epilogue = [&](auto Lc) __attribute__((always_inline)) {
             constexpr int L = decltype(Lc)::value;
             constexpr int LAG = 2 * L - 1;
             constexpr int i2 = (P + 9 - LAG - 1) % 3;
-            constexpr int XO = L == 1 ? E2_X1 : E2_X2, SO = L == 1 ? E2_S1 : E2_S2;    // ring of this layer's OUTPUT (L < 3)
-            const int r = s - LAG - 1;
+            constexpr int XO = L == 0 ? E2_X0 : (L == 1 ? E2_X1 : E2_X2), SO = L == 0 ? E2_S0 : (L == 1 ? E2_S1 : E2_S2);    // ring of the OUTPUT (L < 3)
+            const int r = L == 0 ? s : s - LAG - 1;
             const int wb = lw_e + XO + ((r & (SO - 1)) << 11);
             const unsigned own = (r >= y_lo && r < y_hi) ? 0u : 0x80000000u;
             const int orow = (int)((unsigned)(2 * L) * plane_b + (unsigned)r * row_b);
@@ -291,7 +254,7 @@ __global__ __launch_bounds__(E2_WAVES * 64, 1) void enc_stream2_fwd_kernel(EncAr
                 uint32_t pk[2][2];
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
-                    const e2_f32x4 a = acc[L - 1][i2][2 * p + e];
+                    const e2_f32x4 a = L == 0 ? acc0[2 * p + e] : acc[L > 0 ? L - 1 : 0][i2][2 * p + e];
                     pk[e][0] = relu2(pack_bf16x2(a[0], a[1]));
                     pk[e][1] = relu2(pack_bf16x2(a[2], a[3]));
                 }
@@ -301,7 +264,7 @@ __global__ __launch_bounds__(E2_WAVES * 64, 1) void enc_stream2_fwd_kernel(EncAr
                 if (L < 3) *reinterpret_cast<uint4*>(smem + wb + p * 512) = o[p];
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(e2_u32x4, o[p]), rs_out, (int)(st_e[p] | own), orow, 0);
             }
-            if (L < 3) {
+            if (L >= 1 && L < 3) {     // (x0 computes its ghosts itself, from the reflected image columns)
                 // ghost pixels of an edge strip, AFTER both halves of the row are in the ring (a narrow image's right ghost lies inside
                 // the computed range): column -1 := column 1 (ring pixel 0 := 2), column w := column w - 2
                 if (ghost_l && px_e == 2) *reinterpret_cast<uint4*>(smem + wb - 32) = o[0];
@@ -315,9 +278,9 @@ __global__ __launch_bounds__(E2_WAVES * 64, 1) void enc_stream2_fwd_kernel(EncAr
 
         load_k(E2I<0>());
         E2_FENCE();
-        load_k(E2I<1>()); if (on1) mma_k(E2I<0>()); if (x0_on) x0_taps(0, 5);
+        load_k(E2I<1>()); if (on1) mma_k(E2I<0>()); if (x0_on) x0_mma();
         E2_FENCE();
-        load_k(E2I<2>()); if (on1) mma_k(E2I<1>()); if (x0_on) { x0_taps(5, 9); x0_finish(); }
+        load_k(E2I<2>()); if (on1) mma_k(E2I<1>()); if (x0_on) epilogue(E2I<0>());
         E2_FENCE();
         // (the image row that step s + 1 shifts in -- row s + 2 -- replaces row s - 1 in its register set: requested as soon as the x0
         // row is done, a whole step ahead of its use)
