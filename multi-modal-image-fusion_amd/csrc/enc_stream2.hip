@@ -37,6 +37,8 @@ typedef __attribute__((ext_vector_type(4))) float e2_f32x4;
 typedef float e2_f32x2 __attribute__((ext_vector_type(2)));
 typedef short e2_i16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned e2_u32x4 __attribute__((ext_vector_type(4)));
+#define E2_GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define E2_LPTR(p) ((__attribute__((address_space(3))) void*)(p))
 
 constexpr int E2_W = 64;                       // strip width in pixels
 constexpr int E2_KEEP = 58;                    // columns an interior strip keeps (3 lost per side over the three 3x3 layers)
@@ -46,9 +48,14 @@ constexpr int E2_X0 = 0, E2_X1 = E2_S0 * E2_ROW, E2_X2 = E2_X1 + E2_S1 * E2_ROW,
 constexpr int E2_WAVES = 4;
 constexpr int E2_NFRAG = 30;                   // A fragments: (2 + 3 + 5 k-steps) x 3 tap rows, 1 KB each
 constexpr int E2_WBYTES = E2_NFRAG * 1024;
-constexpr int E2_LDS = E2_WBYTES + E2_WAVES * E2_RING + 64;   // (+ 64: operand reads run up to two granules past a row)
+constexpr int E2_IMGS = 8, E2_IMGROW = 288;    // per wave: 8 slots of one strip-wide fp32 image row (66 used entries of 72), filled by LDS-DMA
+constexpr int E2_IMG0 = E2_WBYTES + E2_WAVES * E2_RING + 64;   // (+ 64: operand reads run up to two granules past a ring row)
+constexpr int E2_LDS = E2_IMG0 + E2_WAVES * E2_IMGS * E2_IMGROW;
 
 template <int N> struct E2I { static constexpr int value = N; };
+#ifndef E2_ABL
+#define E2_ABL 0   // timing ablations (diagnostic builds only, tools/build_ab_enc2.sh; results are WRONG when non-zero): 1 no global stores,
+#endif             // 2 no bf16 MFMAs, 4 no LDS operand reads after a step's first, 8 no epilogues at all, 16 no first-layer MFMAs / image loads
 
 __global__ __launch_bounds__(E2_WAVES * 64, 1) void enc_stream2_fwd_kernel(EncArgs A) {
     __shared__ __attribute__((aligned(16))) char smem[E2_LDS];
@@ -78,6 +85,8 @@ __global__ __launch_bounds__(E2_WAVES * 64, 1) void enc_stream2_fwd_kernel(EncAr
     const int ring = E2_WBYTES + wave * E2_RING;     // byte address in LDS
     for (int e = lane; e < E2_RING / 16; e += 64) reinterpret_cast<uint4*>(smem + ring)[e] = make_uint4(0u, 0u, 0u, 0u);
     if (wave == E2_WAVES - 1 && lane < 4) reinterpret_cast<uint4*>(smem + E2_WBYTES + E2_WAVES * E2_RING)[lane] = make_uint4(0u, 0u, 0u, 0u);
+    const int iring = E2_IMG0 + wave * (E2_IMGS * E2_IMGROW);
+    for (int e = lane; e < E2_IMGS * E2_IMGROW / 16; e += 64) reinterpret_cast<uint4*>(smem + iring)[e] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
 
     const int item = blockIdx.x * E2_WAVES + wave;
@@ -120,13 +129,13 @@ __global__ __launch_bounds__(E2_WAVES * 64, 1) void enc_stream2_fwd_kernel(EncAr
     // K = 4 the three tap columns (k-group g = column g - 1; g = 3 is padding).  The B operand of lane (pixel j, group g) is the image
     // value at (row s - 1 + u, column reflect(16 t + j) + g - 1) -- loaded straight into the operand register, no VALU work at all --,
     // the A operand the weight w0[oc j][u][g].  Output layout = the bf16 layers', so x0 shares their epilogue.
-    int cimg[4];          // byte offset inside an image row per column tile; bit 31 (beyond the descriptor: loads return 0) for the pad group
+    // Image rows reach the wave through its LDS image ring: entry e of a row = image column reflect(r0 - 1 + e), so the operand of ring
+    // pixel p, tap column g - 1, is entry p + g (the strip's ghost pixels come out wrong that way -- column -1 would see columns 2, 1, 0
+    // instead of 0, 1, 2 -- and are overwritten by the epilogue's ghost copy like those of x1 / x2).
     float a0[3];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int c = min(max(reflect_idx(r0 + 16 * t + j, W), 0), W - 1);
-        cimg[t] = g < 3 ? 4 * min(max(reflect_idx(c + g - 1, W), 0), W - 1) : (int)0x80000000u;
-    }
+    const int li = iring + (j + g) * 4;                                        // operand read: + 64 t + slot
+    const int cdma0 = 4 * min(max(reflect_idx(r0 - 1 + lane, W), 0), W - 1);  // DMA source column (bytes) of entries 0..63
+    const int cdma1 = 4 * min(max(reflect_idx(r0 + 63 + (lane & 1), W), 0), W - 1);   // entries 64, 65 (lanes 0, 1)
 #pragma unroll
     for (int u = 0; u < 3; ++u) a0[u] = g < 3 ? B.w0[j * 9 + u * 3 + g] : 0.f;
     e2_f32x4 biasC0;
@@ -143,7 +152,7 @@ __global__ __launch_bounds__(E2_WAVES * 64, 1) void enc_stream2_fwd_kernel(EncAr
     const unsigned plane_b = (unsigned)(B.out.plane * 16), row_b = (unsigned)B.out.ws * 16u;
     char* out_img = B.out.base + ((long long)in_ * B.out.img + (long long)B.out.cb_off * B.out.plane) * 16;
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(out_img, 0, (int)((unsigned)(B.out.cb_total - B.out.cb_off) * plane_b), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_img = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B.img + (long long)in_ * H * W), 0, H * W * 4, 0x00020000);
+    const char* img = reinterpret_cast<const char*>(B.img + (long long)in_ * H * W);
     // per-lane store offsets; a lane outside the strip's kept columns carries bit 31 = beyond the descriptor's range = dropped
     unsigned st_e[2];
 #pragma unroll
@@ -164,11 +173,25 @@ __global__ __launch_bounds__(E2_WAVES * 64, 1) void enc_stream2_fwd_kernel(EncAr
             for (int t = 0; t < 4; ++t) acc[L][r][t] = (e2_f32x4){0.f, 0.f, 0.f, 0.f};
 
     auto rrow = [&](int y) { return min(max(reflect_idx(y, H), 0), H - 1); };
-    float win[3][4];   // image rows s-1, s, s+1 (one operand value per column tile) in sets (P+2) % 3, P, (P+1) % 3
-    auto ld_img_row = [&](int y, float (&dst)[4]) {
-        const int ro = rrow(y) * W * 4;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) dst[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_img, cimg[t], ro, 0));
+    // image rows s-1, s, s+1 (one operand value per column tile) in register sets (P+2) % 3, P, (P+1) % 3 of `win`.  A row is REQUESTED
+    // (LDS-DMA into the image ring, no destination registers) four steps before the step that reads it out of LDS: loads and stores share
+    // one in-order counter, so waiting for a row also waits for every store issued before its request -- with a one-step distance that
+    // was the row step's own x0 stores, and the wave stalled on HBM write latency in every step (ablation: 312 -> 168 us without the
+    // image loads, profiles/r05_ubench_enc_stream2_ablation.txt); four steps back those stores have long been acknowledged.  The
+    // compiler knows nothing of the DMA: the waits are explicit (vmcnt counted by hand in the branch-free body, 0 elsewhere) and the
+    // reads inline asm (a C++ read of DMA-written LDS makes it wait for ALL outstanding vector-memory operations).
+    float win[3][4];
+    auto dma_img_row = [&](int y) __attribute__((always_inline)) {
+        const char* src = img + (long long)rrow(y) * W * 4;
+        char* dst = smem + iring + (y & (E2_IMGS - 1)) * E2_IMGROW;
+        __builtin_amdgcn_global_load_lds(E2_GPTR(src + cdma0), E2_LPTR(dst), 4, 0, 0);
+        if (lane < 2) __builtin_amdgcn_global_load_lds(E2_GPTR(src + cdma1), E2_LPTR(dst + 256), 4, 0, 0);
+    };
+    auto read_img_row = [&](int y, float (&dst)[4]) __attribute__((always_inline)) {
+        const int a = li + (y & (E2_IMGS - 1)) * E2_IMGROW;
+        __asm__ volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %4 offset:64\n\tds_read_b32 %2, %4 offset:128\n\tds_read_b32 %3, %4 offset:192\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(dst[0]), "=&v"(dst[1]), "=&v"(dst[2]), "=&v"(dst[3]) : "v"(a) : "memory");
     };
     const e2_i16x2 zero2 = {0, 0};
     auto relu2 = [&](uint32_t w) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(e2_i16x2, w), zero2)); };
@@ -198,6 +221,11 @@ __global__ __launch_bounds__(E2_WAVES * 64, 1) void enc_stream2_fwd_kernel(EncAr
         // k-step n: 0,1 = 16->16 on x0 | 2..4 = 32->16 on [x0 | x1] | 5..7 = 48->16 on [x0 | x1], 8,9 = on x2
         auto load_k = [&](auto Nc) __attribute__((always_inline)) {
             constexpr int N = decltype(Nc)::value;
+            if ((E2_ABL & 4) && N >= 2) {
+#pragma unroll
+                for (int u = 0; u < 3; ++u) fa[N & 1][u] = fa[N & 1][u];
+                return;
+            }
             const char* pa = smem + la + N * 3 * 1024;
 #pragma unroll
             for (int u = 0; u < 3; ++u) fa[N & 1][u] = *reinterpret_cast<const e2_bf16x8*>(pa + u * 1024);
@@ -207,6 +235,7 @@ __global__ __launch_bounds__(E2_WAVES * 64, 1) void enc_stream2_fwd_kernel(EncAr
         };
         auto mma_k = [&](auto Nc) __attribute__((always_inline)) {
             constexpr int N = decltype(Nc)::value;
+            if (E2_ABL & 2) return;
             constexpr int L = N < 2 ? 1 : (N < 5 ? 2 : 3), LAG = 2 * L - 1;
             constexpr bool first = N == 0 || N == 2 || N == 5;
             constexpr int i0 = (P + 9 - LAG + 1) % 3, i1 = (P + 9 - LAG) % 3, i2 = (P + 9 - LAG - 1) % 3;   // accumulator rows of out rows R+1, R, R-1
@@ -231,6 +260,11 @@ __global__ __launch_bounds__(E2_WAVES * 64, 1) void enc_stream2_fwd_kernel(EncAr
         // x0 row s: three fp32 MFMAs per column tile (tap rows u = 0, 1, 2 on image rows s - 1, s, s + 1), the bias as the first C
         e2_f32x4 acc0[4];
         auto x0_mma = [&]() __attribute__((always_inline)) {
+            if (E2_ABL & 16) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc0[t] = biasC0;
+                return;
+            }
 #pragma unroll
             for (int u = 0; u < 3; ++u)
 #pragma unroll
@@ -241,6 +275,7 @@ __global__ __launch_bounds__(E2_WAVES * 64, 1) void enc_stream2_fwd_kernel(EncAr
         // pair), pair the column tiles, ring + global stores, ghost pixels
         auto epilogue = [&](auto Lc) __attribute__((always_inline)) {
             constexpr int L = decltype(Lc)::value;
+            if (E2_ABL & 8) return;
             constexpr int LAG = 2 * L - 1;
             constexpr int i2 = (P + 9 - LAG - 1) % 3;
             constexpr int XO = L == 0 ? E2_X0 : (L == 1 ? E2_X1 : E2_X2), SO = L == 0 ? E2_S0 : (L == 1 ? E2_S1 : E2_S2);    // ring of the OUTPUT (L < 3)
@@ -262,9 +297,9 @@ __global__ __launch_bounds__(E2_WAVES * 64, 1) void enc_stream2_fwd_kernel(EncAr
                 const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
                 o[p] = make_uint4(s0[0], s1[0], s0[1], s1[1]);
                 if (L < 3) *reinterpret_cast<uint4*>(smem + wb + p * 512) = o[p];
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(e2_u32x4, o[p]), rs_out, (int)(st_e[p] | own), orow, 0);
+                if (!(E2_ABL & 1)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(e2_u32x4, o[p]), rs_out, (int)(st_e[p] | own), orow, 0);
             }
-            if (L >= 1 && L < 3) {     // (x0 computes its ghosts itself, from the reflected image columns)
+            if (L < 3) {
                 // ghost pixels of an edge strip, AFTER both halves of the row are in the ring (a narrow image's right ghost lies inside
                 // the computed range): column -1 := column 1 (ring pixel 0 := 2), column w := column w - 2
                 if (ghost_l && px_e == 2) *reinterpret_cast<uint4*>(smem + wb - 32) = o[0];
@@ -284,7 +319,9 @@ __global__ __launch_bounds__(E2_WAVES * 64, 1) void enc_stream2_fwd_kernel(EncAr
         E2_FENCE();
         // (the image row that step s + 1 shifts in -- row s + 2 -- replaces row s - 1 in its register set: requested as soon as the x0
         // row is done, a whole step ahead of its use)
-        load_k(E2I<3>()); if (on2) mma_k(E2I<2>()); if (x0_on) ld_img_row(s + 2, win[(P + 2) % 3]); if (em1) epilogue(E2I<1>());
+        load_k(E2I<3>()); if (on2) mma_k(E2I<2>());
+        if (x0_on && !(E2_ABL & 16)) dma_img_row(s + 5);       // (read out of the ring at the end of step s + 3)
+        if (em1) epilogue(E2I<1>());
         E2_FENCE();
         load_k(E2I<4>()); if (on2) mma_k(E2I<3>());
         E2_FENCE();
@@ -301,14 +338,24 @@ __global__ __launch_bounds__(E2_WAVES * 64, 1) void enc_stream2_fwd_kernel(EncAr
         if (on3) mma_k(E2I<9>());
         E2_FENCE();
         if (em3) epilogue(E2I<3>());
+        if (x0_on && !(E2_ABL & 16)) {
+            // image row s + 2 for the next step, into the set of row s - 1 (dead since this step's first-layer MFMAs).  Its DMA left at step
+            // s - 3; vector-memory operations issued since: 6 stores of that step + 10 (8 stores, 2 DMAs) of each of the steps s-2, s-1, s
+            if (FAST) __builtin_amdgcn_s_waitcnt(0x0f70 | (36 & 15) | ((36 >> 4) << 14));
+            else __builtin_amdgcn_s_waitcnt(0x0f70);
+            read_img_row(s + 2, win[(P + 2) % 3]);
+        }
         E2_FENCE();
     };
 #undef E2_FENCE
 
     // ---- the pipeline: s = a_lo .. (last x3 row + 6); phase 0 at s = a_lo
-    ld_img_row(a_lo - 1, win[2]);
-    ld_img_row(a_lo, win[0]);
-    ld_img_row(a_lo + 1, win[1]);
+#pragma unroll 1
+    for (int y = a_lo - 1; y < a_lo + 5; ++y) dma_img_row(y);
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    read_img_row(a_lo - 1, win[2]);
+    read_img_row(a_lo, win[0]);
+    read_img_row(a_lo + 1, win[1]);
     const int s_end = y_hi + 6;      // x3 row y_hi - 1 is emitted at step y_hi + 5
     // Three stretches of steps, in groups of three (the accumulator rotation): general steps up to the first group that lies inside
     // [f_lo, f_hi), the branch-free groups, general steps again to the end.  The general body and the fast body are SEPARATE loops of one

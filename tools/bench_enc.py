@@ -38,16 +38,16 @@ def one(B, H, W, modes):
         for name, fn in (("fwd (2 branches)", fwd), ("wgrad (1 branch)", wgrad)):
             if name.startswith("wgrad") and env.get("MMIF_ENC_STREAM") == "0":
                 continue
-            for _ in range(3):
+            for _ in range(150):     # (the first launches of a process run ~15 % slower than the sustained rate: clock ramp)
                 fn()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(20):
+            for _ in range(200):
                 fn()
             e1.record()
             torch.cuda.synchronize()
-            print(f"{label:28s} {name:18s} {e0.elapsed_time(e1) / 20 * 1e3:8.1f} us", flush=True)
+            print(f"{label:28s} {name:18s} {e0.elapsed_time(e1) / 200 * 1e3:8.1f} us", flush=True)
         for k in env:
             os.environ.pop(k)
 
