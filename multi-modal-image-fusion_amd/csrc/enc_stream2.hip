@@ -340,8 +340,10 @@ __global__ __launch_bounds__(E2_WAVES * 64, 1) void enc_stream2_fwd_kernel(EncAr
         if (em3) epilogue(E2I<3>());
         if (x0_on && !(E2_ABL & 16)) {
             // image row s + 2 for the next step, into the set of row s - 1 (dead since this step's first-layer MFMAs).  Its DMA left at step
-            // s - 3; vector-memory operations issued since: 6 stores of that step + 10 (8 stores, 2 DMAs) of each of the steps s-2, s-1, s
-            if (FAST) __builtin_amdgcn_s_waitcnt(0x0f70 | (36 & 15) | ((36 >> 4) << 14));
+            // s - 3; vector-memory operations issued since, at least: 2 stores of that step (the scheduler may have put its other two in
+            // front of the DMA, and the third layer does not emit yet in the three general steps before the first fast one), 8 each of the
+            // steps s - 2 and s - 1, 10 of this step = 28; steady state 34.  vmcnt(24) leaves more than two steps of stores in flight.
+            if (FAST) __builtin_amdgcn_s_waitcnt(0x0f70 | (24 & 15) | ((24 >> 4) << 14));
             else __builtin_amdgcn_s_waitcnt(0x0f70);
             read_img_row(s + 2, win[(P + 2) % 3]);
         }
