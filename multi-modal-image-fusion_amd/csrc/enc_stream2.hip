@@ -163,6 +163,7 @@ __global__ __launch_bounds__(E2_WAVES * 64, 1) void enc_stream2_fwd_kernel(EncAr
     const int b_lo = max(0, y_lo - 2), b_hi = min(H, y_hi + 2);
     const int c_lo = max(0, y_lo - 1), c_hi = min(H, y_hi + 1);
     const int f_lo = max(y_lo + 6, 7), f_hi = min(a_hi, H - 1);   // steps whose three layers are all active, emit, and touch no reflect row
+    const int warm = a_lo + 3 * ((f_lo - a_lo + 2) / 3) + 9;      // first branch-free step that has nine branch-free steps behind it
 
     e2_f32x4 acc[3][3][4];
 #pragma unroll
@@ -174,12 +175,10 @@ __global__ __launch_bounds__(E2_WAVES * 64, 1) void enc_stream2_fwd_kernel(EncAr
 
     auto rrow = [&](int y) { return min(max(reflect_idx(y, H), 0), H - 1); };
     // image rows s-1, s, s+1 (one operand value per column tile) in register sets (P+2) % 3, P, (P+1) % 3 of `win`.  A row is REQUESTED
-    // (LDS-DMA into the image ring, no destination registers) four steps before the step that reads it out of LDS: loads and stores share
-    // one in-order counter, so waiting for a row also waits for every store issued before its request -- with a one-step distance that
-    // was the row step's own x0 stores, and the wave stalled on HBM write latency in every step (ablation: 312 -> 168 us without the
-    // image loads, profiles/r05_ubench_enc_stream2_ablation.txt); four steps back those stores have long been acknowledged.  The
-    // compiler knows nothing of the DMA: the waits are explicit (vmcnt counted by hand in the branch-free body, 0 elsewhere) and the
-    // reads inline asm (a C++ read of DMA-written LDS makes it wait for ALL outstanding vector-memory operations).
+    // (LDS-DMA into the image ring: no destination registers, nothing the compiler tracks) SEVEN steps before the step that reads it out
+    // of LDS, i.e. more than 63 vector-memory operations earlier, so that in the steady state it needs no s_waitcnt at all (see the read
+    // at the end of a step).  The reads are inline asm: a C++ read of DMA-written LDS makes the compiler wait for ALL outstanding
+    // vector-memory operations.
     float win[3][4];
     auto dma_img_row = [&](int y) __attribute__((always_inline)) {
         const char* src = img + (long long)rrow(y) * W * 4;
@@ -320,7 +319,7 @@ __global__ __launch_bounds__(E2_WAVES * 64, 1) void enc_stream2_fwd_kernel(EncAr
         // (the image row that step s + 1 shifts in -- row s + 2 -- replaces row s - 1 in its register set: requested as soon as the x0
         // row is done, a whole step ahead of its use)
         load_k(E2I<3>()); if (on2) mma_k(E2I<2>());
-        if (x0_on && !(E2_ABL & 16)) dma_img_row(s + 5);       // (read out of the ring at the end of step s + 3)
+        if (x0_on && !(E2_ABL & 16)) dma_img_row(s + 9);       // (read out of the ring at the end of step s + 7)
         if (em1) epilogue(E2I<1>());
         E2_FENCE();
         load_k(E2I<4>()); if (on2) mma_k(E2I<3>());
@@ -339,12 +338,13 @@ __global__ __launch_bounds__(E2_WAVES * 64, 1) void enc_stream2_fwd_kernel(EncAr
         E2_FENCE();
         if (em3) epilogue(E2I<3>());
         if (x0_on && !(E2_ABL & 16)) {
-            // image row s + 2 for the next step, into the set of row s - 1 (dead since this step's first-layer MFMAs).  Its DMA left at step
-            // s - 3; vector-memory operations issued since, at least: 2 stores of that step (the scheduler may have put its other two in
-            // front of the DMA, and the third layer does not emit yet in the three general steps before the first fast one), 8 each of the
-            // steps s - 2 and s - 1, 10 of this step = 28; steady state 34.  vmcnt(24) leaves more than two steps of stores in flight.
-            if (FAST) __builtin_amdgcn_s_waitcnt(0x0f70 | (24 & 15) | ((24 >> 4) << 14));
-            else __builtin_amdgcn_s_waitcnt(0x0f70);
+            // image row s + 2 for the next step, into the set of row s - 1 (dead since this step's first-layer MFMAs).  Its DMA left at
+            // step s - 7, and at least 70 vector-memory operations (8 stores + 2 DMAs per branch-free step) have been issued since: a wave has
+            // at most 63 in flight and they complete in order, so the row HAS landed -- no wait at all, which is the point: any
+            // s_waitcnt vmcnt(n) here also waits for stores, and with the chip's HBM write queue full (this kernel's steady state) even
+            // stores from two steps back are still in flight (measured: distance 1 and distance 4 with counted waits both cost ~100 us).
+            // The general steps, and the first nine branch-free steps after them, have issued fewer operations: they wait for everything.
+            if (!FAST || s < warm) __builtin_amdgcn_s_waitcnt(0x0f70);
             read_img_row(s + 2, win[(P + 2) % 3]);
         }
         E2_FENCE();
@@ -353,11 +353,13 @@ __global__ __launch_bounds__(E2_WAVES * 64, 1) void enc_stream2_fwd_kernel(EncAr
 
     // ---- the pipeline: s = a_lo .. (last x3 row + 6); phase 0 at s = a_lo
 #pragma unroll 1
-    for (int y = a_lo - 1; y < a_lo + 5; ++y) dma_img_row(y);
+    for (int y = a_lo - 1; y < a_lo + 2; ++y) dma_img_row(y);
     __builtin_amdgcn_s_waitcnt(0x0f70);
     read_img_row(a_lo - 1, win[2]);
     read_img_row(a_lo, win[0]);
     read_img_row(a_lo + 1, win[1]);
+#pragma unroll 1
+    for (int y = a_lo + 2; y < a_lo + 9; ++y) dma_img_row(y);      // (row a_lo + 8 takes the slot of row a_lo, read above)
     const int s_end = y_hi + 6;      // x3 row y_hi - 1 is emitted at step y_hi + 5
     // Three stretches of steps, in groups of three (the accumulator rotation): general steps up to the first group that lies inside
     // [f_lo, f_hi), the branch-free groups, general steps again to the end.  The general body and the fast body are SEPARATE loops of one
