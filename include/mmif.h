@@ -497,9 +497,9 @@ void mmif_debug_set_thin_wide(int32_t mode);
  * compute units to a kernel that runs concurrently on another stream -- the intra-step overlap of decode.0's weight gradient with the
  * encoder's backward (mmif/engine.py, $MMIF_OVERLAP).  Results change in the last bits only (the per-block partial sums regroup). */
 void mmif_debug_set_wgrad_dma_blocks(int32_t blocks);
-/* mmif_dense_encoder_fwd: 1 (default, $MMIF_ENC_STREAM2) = the round-5 streaming kernel (64-column strips, input-stationary accumulation,
- * csrc/enc_stream2.hip; every stage within one bf16 rounding of its fp64 definition), 0 = the round-2 kernel (32-column strips,
- * bit-identical to the four layer-wise launches). */
+/* mmif_dense_encoder_fwd ($MMIF_ENC_STREAM2): 2 (default) = the round-5 streaming kernel with 32-column strips, eight waves per CU; 1 = the
+ * same with 64-column strips, four waves per CU (csrc/enc_stream2.hip: input-stationary accumulation; every stage within one bf16
+ * rounding of its fp64 definition); 0 = the round-2 kernel (csrc/enc_stream.hip, bit-identical to the four layer-wise launches). */
 void mmif_debug_set_enc_stream2(int32_t mode);
 
 #ifdef __cplusplus

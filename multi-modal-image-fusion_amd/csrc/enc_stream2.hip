@@ -40,25 +40,41 @@ typedef unsigned e2_u32x4 __attribute__((ext_vector_type(4)));
 #define E2_GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define E2_LPTR(p) ((__attribute__((address_space(3))) void*)(p))
 
-constexpr int E2_W = 64;                       // strip width in pixels
-constexpr int E2_KEEP = 58;                    // columns an interior strip keeps (3 lost per side over the three 3x3 layers)
-constexpr int E2_ROW = 2048;                   // one ring slot: [cb 0: 64 px][cb 1: 64 px] x 16 B
 constexpr int E2_S0 = 8, E2_S1 = 4, E2_S2 = 2; // ring slots of x0 / x1 / x2 (powers of two: slot = row & (S - 1))
-constexpr int E2_X0 = 0, E2_X1 = E2_S0 * E2_ROW, E2_X2 = E2_X1 + E2_S1 * E2_ROW, E2_RING = E2_X2 + E2_S2 * E2_ROW;   // 28672
-constexpr int E2_WAVES = 4;
-constexpr int E2_NFRAG = 30;                   // A fragments: (2 + 3 + 5 k-steps) x 3 tap rows, 1 KB each
-constexpr int E2_WBYTES = E2_NFRAG * 1024;
-constexpr int E2_IMGS = 8, E2_IMGROW = 288;    // per wave: 8 slots of one strip-wide fp32 image row (66 used entries of 72), filled by LDS-DMA
-constexpr int E2_IMG0 = E2_WBYTES + E2_WAVES * E2_RING + 64;   // (+ 64: operand reads run up to two granules past a ring row)
-constexpr int E2_LDS = E2_IMG0 + E2_WAVES * E2_IMGS * E2_IMGROW;
+constexpr int E2_NFRAG = 24;                   // A fragments in LDS: (3 + 5 k-steps of the 32->16 / 48->16 convs) x 3 tap rows, 1 KB each
+constexpr int E2_WBYTES = E2_NFRAG * 1024;     // (the 16->16 conv's six fragments live in registers)
+// Geometry of the two instantiations: NT = 4 column tiles (64-pixel strips, four waves per CU, one per SIMD) and NT = 2 (32-pixel strips,
+// eight waves per CU, two per SIMD).  Same work per SIMD either way; with two waves a SIMD keeps computing while one of them sits in a
+// store that HBM back-pressure holds at issue -- measured on the NT = 4 build: compute 133 us and stores 105 us did not overlap at all
+// (profiles/r05_ubench_enc_stream2_ablation.txt).
+template <int NT> struct E2G {
+    static constexpr int W = 16 * NT;              // strip width in pixels
+    static constexpr int KEEP = W - 6;             // columns an interior strip keeps (3 lost per side over the three 3x3 layers)
+    static constexpr int EDGE = W - 4;             // ... the first / last strip of an image (one ghost pixel + 3 lost on the inner side)
+    static constexpr int CBS = 256 * NT;           // bytes of one channel block of a ring row (W pixels x 16 B)
+    static constexpr int ROW = 2 * CBS;            // one ring slot: [cb 0][cb 1]
+    static constexpr int X0 = 0, X1 = E2_S0 * ROW, X2 = X1 + E2_S1 * ROW, RING = X2 + E2_S2 * ROW;
+    static constexpr int WAVES = NT == 4 ? 4 : 8;
+    static constexpr int NP = NT / 2;              // tile pairs of the epilogue
+    static constexpr int OPS = 2 * NT + (NT == 4 ? 2 : 1);     // vector-memory operations of a branch-free step (stores + image DMAs)
+    static constexpr int AHEAD = 2 + (64 + OPS - 1) / OPS;     // image rows are requested this many steps ahead (> 63 operations): 9 / 15
+    static constexpr int IMGS = NT == 4 ? 8 : 16;              // slots of the image ring (>= AHEAD - 1)
+    static constexpr int IMGROW = NT == 4 ? 288 : 160;         // bytes per slot (W + 2 used entries, + the pad group's)
+    static constexpr int IMG0 = E2_WBYTES + WAVES * RING + 64; // (+ 64: operand reads run up to two granules past a ring row)
+    static constexpr int LDS = IMG0 + WAVES * IMGS * IMGROW;
+};
 
 template <int N> struct E2I { static constexpr int value = N; };
 #ifndef E2_ABL
 #define E2_ABL 0   // timing ablations (diagnostic builds only, tools/build_ab_enc2.sh; results are WRONG when non-zero): 1 no global stores,
 #endif             // 2 no bf16 MFMAs, 4 no LDS operand reads after a step's first, 8 no epilogues at all, 16 no first-layer MFMAs / image loads
 
-__global__ __launch_bounds__(E2_WAVES * 64, 1) void enc_stream2_fwd_kernel(EncArgs A) {
-    __shared__ __attribute__((aligned(16))) char smem[E2_LDS];
+template <int NT>
+__global__ __launch_bounds__(E2G<NT>::WAVES * 64, 1) void enc_stream2_fwd_kernel(EncArgs A) {
+    using G = E2G<NT>;
+    constexpr int E2_X0 = G::X0, E2_X1 = G::X1, E2_X2 = G::X2, E2_RING = G::RING, E2_WAVES = G::WAVES, E2_W = G::W, E2_KEEP = G::KEEP;
+    constexpr int E2_IMGS = G::IMGS, E2_IMGROW = G::IMGROW, E2_IMG0 = G::IMG0, CBS = G::CBS, ROWB = G::ROW, NP = G::NP;
+    __shared__ __attribute__((aligned(16))) char smem[G::LDS];
     const EncBranch& B = A.br[blockIdx.y];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -68,16 +84,17 @@ __global__ __launch_bounds__(E2_WAVES * 64, 1) void enc_stream2_fwd_kernel(EncAr
     // fragment f = (kq * 3 + u), kq = 0,1: 16->16 | 2..4: 32->16 | 5..9: 48->16; lane (oc = j, k-group g) takes the plane of its (tap, cb).
     // Four-block chunks [x0 | x1] (k-step = tap column v, k-group = channel block); two-block chunks (x0 for the first conv, x2 for
     // the third): k-step 0 = tap columns 0 | 1 (k-groups 0,1 | 2,3), k-step 1 = tap column 2 | the image's zero planes.
+    auto a_plane = [&](int kq, int u, int kg) {
+        const int L = kq < 2 ? 1 : (kq < 5 ? 2 : 3), q = kq < 2 ? kq : (kq < 5 ? kq - 2 : kq - 5);
+        if (L >= 2 && q < 3) return (u * 3 + q) * 4 + kg;
+        const int q2 = L == 1 ? q : q - 3, base = L == 3 ? ES_P2 : 0;
+        return base + ((q2 == 1 && kg >= 2) ? 18 + (kg & 1) : (u * 3 + (q2 == 0 ? (kg >> 1) : 2)) * 2 + (kg & 1));
+    };
     for (int e = tid; e < E2_NFRAG * 64; e += E2_WAVES * 64) {
         const int f = e >> 6, l = e & 63, oc = l & 15, kg = l >> 4;
-        const int u = f % 3, kq = f / 3;
-        const int L = kq < 2 ? 1 : (kq < 5 ? 2 : 3), q = kq < 2 ? kq : (kq < 5 ? kq - 2 : kq - 5);
-        int plane;
-        if (L >= 2 && q < 3) plane = (u * 3 + q) * 4 + kg;
-        else {
-            const int q2 = L == 1 ? q : q - 3, base = L == 3 ? ES_P2 : 0;
-            plane = base + ((q2 == 1 && kg >= 2) ? 18 + (kg & 1) : (u * 3 + (q2 == 0 ? (kg >> 1) : 2)) * 2 + (kg & 1));
-        }
+        const int u = f % 3, kq = f / 3 + 2;
+        const int L = kq < 5 ? 2 : 3;
+        const int plane = a_plane(kq, u, kg);
         reinterpret_cast<uint4*>(smem)[e] = B.wpk[L - 1][plane * 16 + oc];
     }
     // the wave's ring starts zeroed: pad k-groups, warm-up rows and the granules next to a row are read before they are ever written
@@ -99,12 +116,12 @@ __global__ __launch_bounds__(E2_WAVES * 64, 1) void enc_stream2_fwd_kernel(EncAr
     if (y_lo >= y_hi) return;
 
     // ---- strip geometry.  Ring pixel p of the strip is image column r0 + p.  The first strip starts at column -1 (its ghost), the last
-    // one ends at column w (its ghost); a single strip (w <= 62) has both.  Kept columns [o_lo, o_hi): 3 px from an interior strip edge.
+    // one ends at column w (its ghost); a single strip (w <= W - 2) has both.  Kept columns [o_lo, o_hi): 3 px from an interior strip edge.
     int r0, o_lo, o_hi;
     if (A.nstrips == 1) { r0 = -1; o_lo = 0; o_hi = W; }
-    else if (strip == 0) { r0 = -1; o_lo = 0; o_hi = 60; }
+    else if (strip == 0) { r0 = -1; o_lo = 0; o_hi = G::EDGE; }
     else {
-        o_lo = 60 + E2_KEEP * (strip - 1);
+        o_lo = G::EDGE + E2_KEEP * (strip - 1);
         if (strip == A.nstrips - 1) { r0 = W - (E2_W - 1); o_hi = W; }
         else { r0 = o_lo - 3; o_hi = o_lo + E2_KEEP; }
     }
@@ -114,14 +131,19 @@ __global__ __launch_bounds__(E2_WAVES * 64, 1) void enc_stream2_fwd_kernel(EncAr
     // ---- lane constants
     const int h2 = g >> 1, cbk = g & 1;
     const int la = g * 256 + j * 16;                                   // A operand: k-group plane g of a fragment, row (output channel) j
-    const int lb4 = ring + cbk * 1024 + j * 16 - 16;                    // B operand, four-block chunk: tensor h2 (x0 | x1), block cbk, tap column 0
-    const int lb2 = ring + cbk * 1024 + (j + h2) * 16 - 16;             // two-block chunk: tap column h2 (k-step 0); + 32: tap column 2 (k-step 1)
+    const int lb4 = ring + cbk * CBS + j * 16 - 16;                     // B operand, four-block chunk: tensor h2 (x0 | x1), block cbk, tap column 0
+    const int lb2 = ring + cbk * CBS + (j + h2) * 16 - 16;              // two-block chunk: tap column h2 (k-step 0); + 32: tap column 2 (k-step 1)
+    e2_bf16x8 aL1[2][3];                                               // the 16->16 conv's A fragments (k-steps 0, 1 x tap rows), from its operand image
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int u = 0; u < 3; ++u) aL1[q][u] = __builtin_bit_cast(e2_bf16x8, B.wpk[0][a_plane(q, u, g) * 16 + j]);
     // epilogue side (after the row swap): this lane holds the granule of pixel 32 p + 16 (g & 1) + j, channel block g >> 1
     const int px_e = 16 * (g & 1) + j, cb_e = g >> 1;
-    const int lw_e = ring + cb_e * 1024 + px_e * 16;
-    bool ok_e[2];
+    const int lw_e = ring + cb_e * CBS + px_e * 16;
+    bool ok_e[NP];
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
+    for (int p = 0; p < NP; ++p) {
         const int ce = r0 + px_e + 32 * p;
         ok_e[p] = ce >= o_lo && ce < o_hi;
     }
@@ -135,7 +157,7 @@ __global__ __launch_bounds__(E2_WAVES * 64, 1) void enc_stream2_fwd_kernel(EncAr
     float a0[3];
     const int li = iring + (j + g) * 4;                                        // operand read: + 64 t + slot
     const int cdma0 = 4 * min(max(reflect_idx(r0 - 1 + lane, W), 0), W - 1);  // DMA source column (bytes) of entries 0..63
-    const int cdma1 = 4 * min(max(reflect_idx(r0 + 63 + (lane & 1), W), 0), W - 1);   // entries 64, 65 (lanes 0, 1)
+    const int cdma1 = 4 * min(max(reflect_idx(r0 + 63 + (lane & 1), W), 0), W - 1);   // entries 64, 65 (lanes 0, 1; 64-pixel strips only)
 #pragma unroll
     for (int u = 0; u < 3; ++u) a0[u] = g < 3 ? B.w0[j * 9 + u * 3 + g] : 0.f;
     e2_f32x4 biasC0;
@@ -154,24 +176,24 @@ __global__ __launch_bounds__(E2_WAVES * 64, 1) void enc_stream2_fwd_kernel(EncAr
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(out_img, 0, (int)((unsigned)(B.out.cb_total - B.out.cb_off) * plane_b), 0x00020000);
     const char* img = reinterpret_cast<const char*>(B.img + (long long)in_ * H * W);
     // per-lane store offsets; a lane outside the strip's kept columns carries bit 31 = beyond the descriptor's range = dropped
-    unsigned st_e[2];
+    unsigned st_e[NP];
 #pragma unroll
-    for (int p = 0; p < 2; ++p) st_e[p] = ok_e[p] ? (unsigned)cb_e * plane_b + (unsigned)(r0 + px_e + 32 * p) * 16u : 0x80000000u;
+    for (int p = 0; p < NP; ++p) st_e[p] = ok_e[p] ? (unsigned)cb_e * plane_b + (unsigned)(r0 + px_e + 32 * p) * 16u : 0x80000000u;
 
     // rows each stage touches: x0 rows [a_lo, a_hi) feed layer 1, x1 rows [b_lo, b_hi) layer 2, x2 rows [c_lo, c_hi) layer 3
     const int a_lo = max(0, y_lo - 3), a_hi = min(H, y_hi + 3);
     const int b_lo = max(0, y_lo - 2), b_hi = min(H, y_hi + 2);
     const int c_lo = max(0, y_lo - 1), c_hi = min(H, y_hi + 1);
     const int f_lo = max(y_lo + 6, 7), f_hi = min(a_hi, H - 1);   // steps whose three layers are all active, emit, and touch no reflect row
-    const int warm = a_lo + 3 * ((f_lo - a_lo + 2) / 3) + 9;      // first branch-free step that has nine branch-free steps behind it
+    const int warm = a_lo + 3 * ((f_lo - a_lo + 2) / 3) + G::AHEAD;   // first branch-free step whose image row was requested by a branch-free step
 
-    e2_f32x4 acc[3][3][4];
+    e2_f32x4 acc[3][3][NT];
 #pragma unroll
     for (int L = 0; L < 3; ++L)
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[L][r][t] = (e2_f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < NT; ++t) acc[L][r][t] = (e2_f32x4){0.f, 0.f, 0.f, 0.f};
 
     auto rrow = [&](int y) { return min(max(reflect_idx(y, H), 0), H - 1); };
     // image rows s-1, s, s+1 (one operand value per column tile) in register sets (P+2) % 3, P, (P+1) % 3 of `win`.  A row is REQUESTED
@@ -179,18 +201,23 @@ __global__ __launch_bounds__(E2_WAVES * 64, 1) void enc_stream2_fwd_kernel(EncAr
     // of LDS, i.e. more than 63 vector-memory operations earlier, so that in the steady state it needs no s_waitcnt at all (see the read
     // at the end of a step).  The reads are inline asm: a C++ read of DMA-written LDS makes the compiler wait for ALL outstanding
     // vector-memory operations.
-    float win[3][4];
+    float win[3][NT];
     auto dma_img_row = [&](int y) __attribute__((always_inline)) {
         const char* src = img + (long long)rrow(y) * W * 4;
         char* dst = smem + iring + (y & (E2_IMGS - 1)) * E2_IMGROW;
-        __builtin_amdgcn_global_load_lds(E2_GPTR(src + cdma0), E2_LPTR(dst), 4, 0, 0);
-        if (lane < 2) __builtin_amdgcn_global_load_lds(E2_GPTR(src + cdma1), E2_LPTR(dst + 256), 4, 0, 0);
+        if (NT == 4) {
+            __builtin_amdgcn_global_load_lds(E2_GPTR(src + cdma0), E2_LPTR(dst), 4, 0, 0);
+            if (lane < 2) __builtin_amdgcn_global_load_lds(E2_GPTR(src + cdma1), E2_LPTR(dst + 256), 4, 0, 0);
+        } else if (lane < E2_W + 2) __builtin_amdgcn_global_load_lds(E2_GPTR(src + cdma0), E2_LPTR(dst), 4, 0, 0);
     };
-    auto read_img_row = [&](int y, float (&dst)[4]) __attribute__((always_inline)) {
+    auto read_img_row = [&](int y, float (&dst)[NT]) __attribute__((always_inline)) {
         const int a = li + (y & (E2_IMGS - 1)) * E2_IMGROW;
-        __asm__ volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %4 offset:64\n\tds_read_b32 %2, %4 offset:128\n\tds_read_b32 %3, %4 offset:192\n\t"
-                         "s_waitcnt lgkmcnt(0)"
-                         : "=&v"(dst[0]), "=&v"(dst[1]), "=&v"(dst[2]), "=&v"(dst[3]) : "v"(a) : "memory");
+        if constexpr (NT == 4)
+            __asm__ volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %4 offset:64\n\tds_read_b32 %2, %4 offset:128\n\tds_read_b32 %3, %4 offset:192\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(dst[0]), "=&v"(dst[1]), "=&v"(dst[2]), "=&v"(dst[3]) : "v"(a) : "memory");
+        else
+            __asm__ volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:64\n\ts_waitcnt lgkmcnt(0)" : "=&v"(dst[0]), "=&v"(dst[1]) : "v"(a) : "memory");
     };
     const e2_i16x2 zero2 = {0, 0};
     auto relu2 = [&](uint32_t w) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(e2_i16x2, w), zero2)); };
@@ -211,11 +238,11 @@ __global__ __launch_bounds__(E2_WAVES * 64, 1) void enc_stream2_fwd_kernel(EncAr
         const bool em1 = FAST || (R1 - 1 >= b_lo && R1 - 1 < b_hi), em2 = FAST || (R2 - 1 >= c_lo && R2 - 1 < c_hi),
                    em3 = FAST || (R3 - 1 >= y_lo && R3 - 1 < y_hi);
         // operand bases of this step (lane groups 0,1 of a four-block chunk read the x0 ring, 2,3 the x1 ring)
-        const int bL1 = lb2 + E2_X0 + ((R1 & (E2_S0 - 1)) << 11);
-        const int bL2 = lb4 + (h2 ? E2_X1 + ((R2 & (E2_S1 - 1)) << 11) : E2_X0 + ((R2 & (E2_S0 - 1)) << 11));
-        const int bL3 = lb4 + (h2 ? E2_X1 + ((R3 & (E2_S1 - 1)) << 11) : E2_X0 + ((R3 & (E2_S0 - 1)) << 11));
-        const int bL3x = lb2 + E2_X2 + ((R3 & (E2_S2 - 1)) << 11);
-        e2_bf16x8 fa[2][3], fb[2][4];       // double-buffered fragments: k-step n lives in set n & 1
+        const int bL1 = lb2 + E2_X0 + (R1 & (E2_S0 - 1)) * ROWB;
+        const int bL2 = lb4 + (h2 ? E2_X1 + (R2 & (E2_S1 - 1)) * ROWB : E2_X0 + (R2 & (E2_S0 - 1)) * ROWB);
+        const int bL3 = lb4 + (h2 ? E2_X1 + (R3 & (E2_S1 - 1)) * ROWB : E2_X0 + (R3 & (E2_S0 - 1)) * ROWB);
+        const int bL3x = lb2 + E2_X2 + (R3 & (E2_S2 - 1)) * ROWB;
+        e2_bf16x8 fa[2][3], fb[2][NT];      // double-buffered fragments: k-step n lives in set n & 1
 
         // k-step n: 0,1 = 16->16 on x0 | 2..4 = 32->16 on [x0 | x1] | 5..7 = 48->16 on [x0 | x1], 8,9 = on x2
         auto load_k = [&](auto Nc) __attribute__((always_inline)) {
@@ -225,12 +252,12 @@ __global__ __launch_bounds__(E2_WAVES * 64, 1) void enc_stream2_fwd_kernel(EncAr
                 for (int u = 0; u < 3; ++u) fa[N & 1][u] = fa[N & 1][u];
                 return;
             }
-            const char* pa = smem + la + N * 3 * 1024;
+            const char* pa = smem + la + (N >= 2 ? N - 2 : 0) * 3 * 1024;
 #pragma unroll
-            for (int u = 0; u < 3; ++u) fa[N & 1][u] = *reinterpret_cast<const e2_bf16x8*>(pa + u * 1024);
+            for (int u = 0; u < 3; ++u) fa[N & 1][u] = N < 2 ? aL1[N < 2 ? N : 0][u] : *reinterpret_cast<const e2_bf16x8*>(pa + u * 1024);
             const char* pb = smem + (N < 2 ? bL1 + 32 * N : (N < 5 ? bL2 + 16 * (N - 2) : (N < 8 ? bL3 + 16 * (N - 5) : bL3x + 32 * (N - 8))));
 #pragma unroll
-            for (int t = 0; t < 4; ++t) fb[N & 1][t] = *reinterpret_cast<const e2_bf16x8*>(pb + t * 256);
+            for (int t = 0; t < NT; ++t) fb[N & 1][t] = *reinterpret_cast<const e2_bf16x8*>(pb + t * 256);
         };
         auto mma_k = [&](auto Nc) __attribute__((always_inline)) {
             constexpr int N = decltype(Nc)::value;
@@ -242,10 +269,10 @@ __global__ __launch_bounds__(E2_WAVES * 64, 1) void enc_stream2_fwd_kernel(EncAr
             const bool top = !FAST && R == 1, bot = !FAST && R == H - 2;
             if (!FAST && first && R == 0) {   // image row 0 has no row above it to open its accumulator: start it from the bias here
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc[L - 1][i1][t] = biasC[L - 1];
+                for (int t = 0; t < NT; ++t) acc[L - 1][i1][t] = biasC[L - 1];
             }
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
+            for (int t = 0; t < NT; ++t) {
                 const e2_bf16x8 b = fb[N & 1][t];
                 acc[L - 1][i0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[N & 1][0], b, first ? biasC[L - 1] : acc[L - 1][i0][t], 0, 0, 0);
                 acc[L - 1][i1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[N & 1][1], b, acc[L - 1][i1][t], 0, 0, 0);
@@ -257,17 +284,17 @@ __global__ __launch_bounds__(E2_WAVES * 64, 1) void enc_stream2_fwd_kernel(EncAr
             }
         };
         // x0 row s: three fp32 MFMAs per column tile (tap rows u = 0, 1, 2 on image rows s - 1, s, s + 1), the bias as the first C
-        e2_f32x4 acc0[4];
+        e2_f32x4 acc0[NT];
         auto x0_mma = [&]() __attribute__((always_inline)) {
             if (E2_ABL & 16) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc0[t] = biasC0;
+                for (int t = 0; t < NT; ++t) acc0[t] = biasC0;
                 return;
             }
 #pragma unroll
             for (int u = 0; u < 3; ++u)
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+                for (int t = 0; t < NT; ++t)
                     acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u], win[(P + 2 + u) % 3][t], u == 0 ? biasC0 : acc0[t], 0, 0, 0);
         };
         // epilogue of a finished row (x0: row s; layer L >= 1: out row R - 1 = s - 2 L): round, ReLU (as a signed 16-bit max on the rounded
@@ -279,12 +306,12 @@ __global__ __launch_bounds__(E2_WAVES * 64, 1) void enc_stream2_fwd_kernel(EncAr
             constexpr int i2 = (P + 9 - LAG - 1) % 3;
             constexpr int XO = L == 0 ? E2_X0 : (L == 1 ? E2_X1 : E2_X2), SO = L == 0 ? E2_S0 : (L == 1 ? E2_S1 : E2_S2);    // ring of the OUTPUT (L < 3)
             const int r = L == 0 ? s : s - LAG - 1;
-            const int wb = lw_e + XO + ((r & (SO - 1)) << 11);
+            const int wb = lw_e + XO + (r & (SO - 1)) * ROWB;
             const unsigned own = (r >= y_lo && r < y_hi) ? 0u : 0x80000000u;
             const int orow = (int)((unsigned)(2 * L) * plane_b + (unsigned)r * row_b);
-            uint4 o[2];
+            uint4 o[NP];
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
+            for (int p = 0; p < NP; ++p) {
                 uint32_t pk[2][2];
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
@@ -304,7 +331,7 @@ __global__ __launch_bounds__(E2_WAVES * 64, 1) void enc_stream2_fwd_kernel(EncAr
                 if (ghost_l && px_e == 2) *reinterpret_cast<uint4*>(smem + wb - 32) = o[0];
                 if (ghost_r) {
 #pragma unroll
-                    for (int p = 0; p < 2; ++p)
+                    for (int p = 0; p < NP; ++p)
                         if (px_e + 32 * p == pg_r - 2) *reinterpret_cast<uint4*>(smem + wb + p * 512 + 32) = o[p];
                 }
             }
@@ -319,7 +346,7 @@ __global__ __launch_bounds__(E2_WAVES * 64, 1) void enc_stream2_fwd_kernel(EncAr
         // (the image row that step s + 1 shifts in -- row s + 2 -- replaces row s - 1 in its register set: requested as soon as the x0
         // row is done, a whole step ahead of its use)
         load_k(E2I<3>()); if (on2) mma_k(E2I<2>());
-        if (x0_on && !(E2_ABL & 16)) dma_img_row(s + 9);       // (read out of the ring at the end of step s + 7)
+        if (x0_on && !(E2_ABL & 16)) dma_img_row(s + G::AHEAD);   // (read out of the ring at the end of step s + AHEAD - 2)
         if (em1) epilogue(E2I<1>());
         E2_FENCE();
         load_k(E2I<4>()); if (on2) mma_k(E2I<3>());
@@ -339,11 +366,11 @@ __global__ __launch_bounds__(E2_WAVES * 64, 1) void enc_stream2_fwd_kernel(EncAr
         if (em3) epilogue(E2I<3>());
         if (x0_on && !(E2_ABL & 16)) {
             // image row s + 2 for the next step, into the set of row s - 1 (dead since this step's first-layer MFMAs).  Its DMA left at
-            // step s - 7, and at least 70 vector-memory operations (8 stores + 2 DMAs per branch-free step) have been issued since: a wave has
-            // at most 63 in flight and they complete in order, so the row HAS landed -- no wait at all, which is the point: any
+            // step s - (AHEAD - 2), and at least 64 vector-memory operations (OPS stores + DMAs per branch-free step) have been issued since: a
+            // wave has at most 63 in flight and they complete in order, so the row HAS landed -- no wait at all, which is the point: any
             // s_waitcnt vmcnt(n) here also waits for stores, and with the chip's HBM write queue full (this kernel's steady state) even
             // stores from two steps back are still in flight (measured: distance 1 and distance 4 with counted waits both cost ~100 us).
-            // The general steps, and the first nine branch-free steps after them, have issued fewer operations: they wait for everything.
+            // The general steps, and the first AHEAD branch-free steps after them, have issued fewer operations: they wait for everything.
             if (!FAST || s < warm) __builtin_amdgcn_s_waitcnt(0x0f70);
             read_img_row(s + 2, win[(P + 2) % 3]);
         }
@@ -359,7 +386,7 @@ __global__ __launch_bounds__(E2_WAVES * 64, 1) void enc_stream2_fwd_kernel(EncAr
     read_img_row(a_lo, win[0]);
     read_img_row(a_lo + 1, win[1]);
 #pragma unroll 1
-    for (int y = a_lo + 2; y < a_lo + 9; ++y) dma_img_row(y);      // (row a_lo + 8 takes the slot of row a_lo, read above)
+    for (int y = a_lo + 2; y < a_lo + G::AHEAD; ++y) dma_img_row(y);      // (the last ones reuse the slots of the rows read above)
     const int s_end = y_hi + 6;      // x3 row y_hi - 1 is emitted at step y_hi + 5
     // Three stretches of steps, in groups of three (the accumulator rotation): general steps up to the first group that lies inside
     // [f_lo, f_hi), the branch-free groups, general steps again to the end.  The general body and the fast body are SEPARATE loops of one
@@ -386,10 +413,12 @@ __global__ __launch_bounds__(E2_WAVES * 64, 1) void enc_stream2_fwd_kernel(EncAr
     }
 }
 
-// items-per-launch heuristic: every (strip, segment, image, branch) is one wave, four waves a block, one block per CU (LDS).  More
+// items-per-launch heuristic: every (strip, segment, image, branch) is one wave, WAVES waves a block, one block per CU (LDS).  More
 // segments fill the chip but each pays 3 warm-up rows of x0 plus the 6-step pipeline skew: minimise rounds x steps per wave.
+template <int NT>
 static void e2_geometry(int n, int h, int w, int nb, int& nstrips, int& nseg, int& seg_rows) {
-    nstrips = w <= E2_W - 2 ? 1 : 2 + (w > 120 ? (w - 120 + E2_KEEP - 1) / E2_KEEP : 0);
+    using G = E2G<NT>;
+    nstrips = w <= G::W - 2 ? 1 : 2 + (w > 2 * G::EDGE ? (w - 2 * G::EDGE + G::KEEP - 1) / G::KEEP : 0);
     int ncu = 256;
     {
         int dev = 0;
@@ -400,7 +429,7 @@ static void e2_geometry(int n, int h, int w, int nb, int& nstrips, int& nseg, in
     nseg = 1;
     for (int k = 1; k <= (h + 7) / 8; ++k) {
         const int rows = (h + k - 1) / k;
-        const long long blocks = (long long)nb * (((long long)n * nstrips * k + E2_WAVES - 1) / E2_WAVES);
+        const long long blocks = (long long)nb * (((long long)n * nstrips * k + G::WAVES - 1) / G::WAVES);
         const long long cost = ((blocks + ncu - 1) / ncu) * (rows + 12);
         if (best < 0 || cost < best) { best = cost; nseg = k; }
     }
@@ -408,11 +437,22 @@ static void e2_geometry(int n, int h, int w, int nb, int& nstrips, int& nseg, in
     nseg = (h + seg_rows - 1) / seg_rows;   // drop empty trailing segments
 }
 
-static int g_es2 = -1;
+static int g_es2 = -1;      // $MMIF_ENC_STREAM2: 0 = the round-2 kernel, 1 = 64-pixel strips (four waves per CU), 2 (default) = 32-pixel strips (eight)
+static void e2_init() {
+    if (g_es2 < 0) { const char* e = getenv("MMIF_ENC_STREAM2"); g_es2 = e != nullptr ? atoi(e) : 2; if (g_es2 < 0 || g_es2 > 2) g_es2 = 2; }
+}
 bool enc_stream2_ok(int n, int h, int w) {
     (void)n;
-    if (g_es2 < 0) { const char* e = getenv("MMIF_ENC_STREAM2"); g_es2 = (e != nullptr && e[0] == '0') ? 0 : 1; }
-    return g_es2 == 1 && h >= 2 && w >= 2;
+    e2_init();
+    return g_es2 >= 1 && h >= 2 && w >= 2;
+}
+
+template <int NT>
+static int e2_launch(EncArgs& A, int nb, hipStream_t st) {
+    e2_geometry<NT>(A.n, A.h, A.w, nb, A.nstrips, A.nseg, A.seg_rows);
+    A.items = A.n * A.nseg * A.nstrips;
+    hipLaunchKernelGGL(enc_stream2_fwd_kernel<NT>, dim3(cdiv(A.items, E2G<NT>::WAVES), nb), dim3(E2G<NT>::WAVES * 64), 0, st, A);
+    return check_launch("dense_encoder_fwd (stream2)");
 }
 
 int enc_stream2_launch(EncArgs& A, int nb, hipStream_t st) {
@@ -421,12 +461,10 @@ int enc_stream2_launch(EncArgs& A, int nb, hipStream_t st) {
     for (int b = 0; b < nb; ++b)
         MMIF_REQUIRE((long long)A.br[b].out.cb_total * A.br[b].out.plane * 16 < (1ll << 31),
                      "dense_encoder_fwd (stream2): one image of the output allocation must stay below 2 GiB (bit 31 of a store offset = masked lane)");
-    e2_geometry(A.n, A.h, A.w, nb, A.nstrips, A.nseg, A.seg_rows);
-    A.items = A.n * A.nseg * A.nstrips;
-    hipLaunchKernelGGL(enc_stream2_fwd_kernel, dim3(cdiv(A.items, E2_WAVES), nb), dim3(E2_WAVES * 64), 0, st, A);
-    return check_launch("dense_encoder_fwd (stream2)");
+    e2_init();
+    return g_es2 == 1 ? e2_launch<4>(A, nb, st) : e2_launch<2>(A, nb, st);
 }
 
 }  // namespace mmif
 
-extern "C" void mmif_debug_set_enc_stream2(int32_t mode) { mmif::g_es2 = mode ? 1 : 0; }
+extern "C" void mmif_debug_set_enc_stream2(int32_t mode) { mmif::g_es2 = mode < 0 ? 0 : (mode > 2 ? 2 : mode); }

@@ -3,8 +3,9 @@ core/model.py:73-80, core/block.py:137-151), two kernel generations:
 
 * csrc/enc_stream2.hip (round 5, the default): 64-column strips, input-stationary accumulation.  Same rounding points as the layer-wise
   kernels but another fp32 accumulation ORDER, so it is held to the fp64 DEFINITION of every stage on the kernel's own bf16 inputs at
-  one bf16 rounding (as tests/test_gpu_enc_chain.py holds the backward chain), x0 (fp32 FMAs in the layer-wise order) bit for bit, and
-  to the layer-wise launches within one bf16 rounding per stage;
+  one bf16 rounding (as tests/test_gpu_enc_chain.py holds the backward chain) -- x0 included: it runs on the exact-fp32 matrix path --,
+  and to the layer-wise launches within one bf16 rounding per stage; both strip widths (32 pixels / eight waves per CU, the default, and
+  64 pixels / four waves);
 * csrc/enc_stream.hip (round 2; mmif_debug_set_enc_stream2(0) / $MMIF_ENC_STREAM2=0): BIT-IDENTICAL to the four layer-wise launches.
 
 Both within the bf16 bar of the fp32 oracle; shapes cover one strip, two strips (both ghosts' edge strips), interior strips, ragged
@@ -23,18 +24,19 @@ ULP = 2.0 ** -8
 
 
 class gen:
-    """with gen(2): ... -- select the streaming kernel generation (1 = round 2's, 2 = round 5's) for the block"""
+    """with gen(m): ... -- select the streaming kernel for the block: 0 = round 2's (csrc/enc_stream.hip), 1 = round 5's with 64-pixel strips
+    (four waves per CU), 2 = round 5's with 32-pixel strips (eight waves per CU; the default)"""
 
-    def __init__(self, g):
-        self.g = g
+    def __init__(self, mode):
+        self.mode = mode
 
     def __enter__(self):
         from mmif._lib import lib
-        lib.mmif_debug_set_enc_stream2(1 if self.g == 2 else 0)
+        lib.mmif_debug_set_enc_stream2(self.mode)
 
     def __exit__(self, *a):
         from mmif._lib import lib
-        lib.mmif_debug_set_enc_stream2(1)
+        lib.mmif_debug_set_enc_stream2(2)
 
 
 SHAPES = [(1, 2, 2), (2, 5, 7), (1, 3, 40), (2, 32, 32), (1, 37, 53), (3, 64, 64), (1, 70, 33), (2, 129, 200), (2, 256, 256), (1, 300, 331)]
@@ -60,7 +62,7 @@ def _engine_and_buffers(n, h, w, seed):
 @pytest.mark.parametrize("n,h,w", SHAPES, ids=[f"{n}x{h}x{w}" for n, h, w in SHAPES])
 def test_stream_equals_layerwise_bit_for_bit(n, h, w):
     """round-2 kernel"""
-    with dtype_ctx("bf16"), gen(1):
+    with dtype_ctx("bf16"), gen(0):
         eng, T, i1, i2, dtype, impl = _engine_and_buffers(n, h, w, 3 + h)
         Fa = T.BT.alloc(n, 128, h, w, dtype, DEV)
         Fb = T.BT.alloc(n, 128, h, w, dtype, DEV)
@@ -96,11 +98,12 @@ def _fp64_stage(inp, wgt, bias):
     return O.conv2d_reflect_fwd(inp.astype(np.float64), bf16_round(wgt).astype(np.float64), bias.astype(np.float64), relu=True)
 
 
+@pytest.mark.parametrize("mode", [2, 1], ids=["32px", "64px"])
 @pytest.mark.parametrize("n,h,w", SHAPES2, ids=[f"{n}x{h}x{w}" for n, h, w in SHAPES2])
-def test_stream2_vs_fp64_definition_and_layerwise(n, h, w):
+def test_stream2_vs_fp64_definition_and_layerwise(n, h, w, mode):
     """round-5 kernel: every stage = bf16(relu(b + conv(reflect_pad(its own stored inputs)))) in fp64 within one rounding; x0 bit-identical
     to the layer-wise first layer; x1..x3 within one bf16 rounding per stage of the layer-wise launches"""
-    with dtype_ctx("bf16"), gen(2):
+    with dtype_ctx("bf16"), gen(mode):
         eng, T, i1, i2, dtype, impl = _engine_and_buffers(n, h, w, 3 + h)
         Fa = T.BT.alloc(n, 128, h, w, dtype, DEV)
         Fb = T.BT.alloc(n, 128, h, w, dtype, DEV)
@@ -121,7 +124,10 @@ def test_stream2_vs_fp64_definition_and_layerwise(n, h, w):
         for e, img in ((0, i1), (1, i2)):
             x = img.cpu().numpy()
             mine = got[:, 64 * e:64 * e + 64]
-            assert np.array_equal(mine[:, :16], lay[:, 64 * e:64 * e + 16]), f"branch {e}: x0 must be bit-identical to the layer-wise first layer"
+            # x0 runs on the exact-fp32 matrix path (v_mfma_f32_16x16x4_f32): same products as the layer-wise FMAs, another summation order
+            # inside the instruction -- the rounded values agree except where the fp32 sums straddle a bf16 rounding boundary
+            d0 = mine[:, :16] != lay[:, 64 * e:64 * e + 16]
+            assert d0.mean() < 0.02, f"branch {e}: x0 differs from the layer-wise first layer in {d0.mean():.4f} of its elements"
             for k, sp in enumerate(eng.enc[e]):
                 wgt, b = sp.w.detach().cpu().numpy(), sp.b.detach().cpu().numpy()
                 if k == 0:
@@ -143,12 +149,13 @@ def test_stream2_vs_fp64_definition_and_layerwise(n, h, w):
         assert torch.equal(Fc.buf[:, 8:].view(torch.int16), Fb.buf[:, 8:].view(torch.int16)) and float(Fc.buf[:, :8].float().abs().max()) == 0.0
 
 
-def test_stream2_geometry_fuzz():
-    """seeded random shapes through the round-5 kernel's strip / segment / ghost geometry: x1..x3 against the fp64 definition"""
+@pytest.mark.parametrize("mode", [2, 1], ids=["32px", "64px"])
+def test_stream2_geometry_fuzz(mode):
+    """seeded random shapes through the round-5 kernel's strip / segment / ghost geometry: x0..x3 against the fp64 definition"""
     import random
     rnd = random.Random(4321)
     shapes = [(rnd.randint(1, 3), rnd.randint(2, 90), rnd.randint(2, 260)) for _ in range(20)] + [(1, 2, 2), (1, 3, 61), (1, 2, 65), (4, 31, 119)]
-    with dtype_ctx("bf16"), gen(2):
+    with dtype_ctx("bf16"), gen(mode):
         for n, h, w in shapes:
             eng, T, i1, i2, dtype, impl = _engine_and_buffers(n, h, w, 100 + h * w)
             F = T.BT.alloc(n, 128, h, w, dtype, DEV)
@@ -166,7 +173,7 @@ def test_stream2_geometry_fuzz():
                     assert err.max() <= 1.01 * ULP, f"{(n, h, w)} branch {e} x{k}: {err.max():.3e} at {np.unravel_index(err.argmax(), err.shape)}"
 
 
-@pytest.mark.parametrize("generation", [1, 2])
+@pytest.mark.parametrize("generation", [0, 1, 2])
 def test_stream_vs_fp32_oracle(generation):
     """against the numpy oracle of the four layers (fp32): the bf16 storage bar of the layer-wise path (3e-2 of max|.|)"""
     n, h, w = 2, 37, 53
@@ -186,7 +193,7 @@ def test_stream_vs_fp32_oracle(generation):
             assert rel_err(got[:, 64 * e:64 * e + 64], want) < 3e-2
 
 
-@pytest.mark.parametrize("generation", [1, 2])
+@pytest.mark.parametrize("generation", [0, 1, 2])
 def test_models_use_the_streaming_encoder_and_match_layerwise(generation):
     """whole models (PFNetv1, DenseFuse incl. auto-encoder mode, VIFNet, PFNetv2): forward output and every parameter gradient with the
     streaming encoder on and off -- bit-identical for the round-2 kernel, within the bf16 rounding noise of three stages for round 5's"""
@@ -194,7 +201,7 @@ def test_models_use_the_streaming_encoder_and_match_layerwise(generation):
     from mmif import tensor as T
 
     def same(a, b, what):
-        if generation == 1:
+        if generation == 0:
             assert torch.equal(a, b), what
         else:
             assert float((a - b).abs().max()) <= 2e-2 * float(b.abs().max()) + 1e-12, (what, float((a - b).abs().max()), float(b.abs().max()))
@@ -253,7 +260,7 @@ def test_stream_geometry_fuzz():
     import random
     rnd = random.Random(1234)
     shapes = [(rnd.randint(1, 3), rnd.randint(2, 90), rnd.randint(2, 140)) for _ in range(24)] + [(1, 2, 33), (1, 33, 2), (1, 3, 58), (5, 31, 59)]
-    with dtype_ctx("bf16"), gen(1):
+    with dtype_ctx("bf16"), gen(0):
         for n, h, w in shapes:
             eng, T, i1, i2, dtype, impl = _engine_and_buffers(n, h, w, 100 + h * w)
             Fa, Fb = T.BT.alloc(n, 128, h, w, dtype, DEV), T.BT.alloc(n, 128, h, w, dtype, DEV)

@@ -33,7 +33,10 @@ def one(B, H, W, modes):
     def wgrad():   # one branch
         T.dense_encoder_wgrad(i1, F.view(0, 6), GF.view(0, 8), grads, ws)
 
+    from mmif._lib import lib
     for label, env in modes:
+        lib.mmif_debug_set_enc_stream2(int(env.get("_ES2", "2")))
+        env = {k: v for k, v in env.items() if not k.startswith("_")}
         os.environ.update(env)
         for name, fn in (("fwd (2 branches)", fwd), ("wgrad (1 branch)", wgrad)):
             if name.startswith("wgrad") and env.get("MMIF_ENC_STREAM") == "0":
@@ -58,6 +61,6 @@ if __name__ == "__main__":
     if "--child" in sys.argv:
         one(B, H, W, [("stream " + os.path.basename(os.environ.get("MMIF_LIB", "?")), {})])
     else:
-        one(B, H, W, [("layer-wise", {"MMIF_ENC_STREAM": "0"}), ("stream", {})])
+        one(B, H, W, [("stream2 32 px (default)", {}), ("stream2 64 px", {"_ES2": "1"}), ("stream (round 2)", {"_ES2": "0"})])
         for lib in sorted(glob.glob(os.path.join(ROOT, "ab", "lib*.so"))):
             subprocess.run([sys.executable, __file__, str(B), str(H), str(W), "--child"], env=dict(os.environ, MMIF_LIB=lib))
