@@ -29,6 +29,7 @@
 // the old order) stays bit-identical.  $MMIF_ENC_STREAM2=0 selects the round-2 kernel.
 #include "enc_stream.hpp"
 #include <stdlib.h>
+#pragma clang diagnostic ignored "-Winline-asm"   // (the LDS-DMA asm names m0 in its clobber list: "reserved register")
 
 namespace mmif {
 
@@ -58,10 +59,10 @@ template <int NT> struct E2G {
     static constexpr int NP = NT / 2;              // tile pairs of the epilogue
     static constexpr int OPS = 2 * NT + (NT == 4 ? 2 : 1);     // vector-memory operations of a branch-free step (stores + image DMAs)
     static constexpr int AHEAD = 2 + (64 + OPS - 1) / OPS;     // image rows are requested this many steps ahead (> 63 operations): 9 / 15
-    static constexpr int IMGS = NT == 4 ? 8 : 16;              // slots of the image ring (>= AHEAD - 1)
+    static constexpr int IMGS = 16;                            // slots of the image ring (> AHEAD)
     static constexpr int IMGROW = NT == 4 ? 288 : 160;         // bytes per slot (W + 2 used entries, + the pad group's)
-    static constexpr int IMG0 = E2_WBYTES + WAVES * RING + 64; // (+ 64: operand reads run up to two granules past a ring row)
-    static constexpr int LDS = IMG0 + WAVES * IMGS * IMGROW;
+    static constexpr int LDS = E2_WBYTES + WAVES * RING + 64;  // (+ 64: operand reads run up to two granules past a ring row)
+    static constexpr int LDS_IMG = WAVES * IMGS * IMGROW;      // the image ring is an LDS variable of its own, see the kernel
 };
 
 template <int N> struct E2I { static constexpr int value = N; };
@@ -73,8 +74,12 @@ template <int NT>
 __global__ __launch_bounds__(E2G<NT>::WAVES * 64, 1) void enc_stream2_fwd_kernel(EncArgs A) {
     using G = E2G<NT>;
     constexpr int E2_X0 = G::X0, E2_X1 = G::X1, E2_X2 = G::X2, E2_RING = G::RING, E2_WAVES = G::WAVES, E2_W = G::W, E2_KEEP = G::KEEP;
-    constexpr int E2_IMGS = G::IMGS, E2_IMGROW = G::IMGROW, E2_IMG0 = G::IMG0, CBS = G::CBS, ROWB = G::ROW, NP = G::NP;
+    constexpr int E2_IMGS = G::IMGS, E2_IMGROW = G::IMGROW, CBS = G::CBS, ROWB = G::ROW, NP = G::NP;
     __shared__ __attribute__((aligned(16))) char smem[G::LDS];
+    // The image ring is written by LDS-DMA.  The compiler orders every C++ read of an LDS object a pending DMA may write behind ALL
+    // outstanding vector-memory operations (s_waitcnt vmcnt(0) -- with this kernel's stores in flight: microseconds, in every step), so
+    // the ring is a SEPARATE object that C++ code never reads (its reads are inline asm) -- nothing aliases the operand rings / fragments.
+    __shared__ __attribute__((aligned(16))) char smem_img[G::LDS_IMG];
     const EncBranch& B = A.br[blockIdx.y];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -102,8 +107,8 @@ __global__ __launch_bounds__(E2G<NT>::WAVES * 64, 1) void enc_stream2_fwd_kernel
     const int ring = E2_WBYTES + wave * E2_RING;     // byte address in LDS
     for (int e = lane; e < E2_RING / 16; e += 64) reinterpret_cast<uint4*>(smem + ring)[e] = make_uint4(0u, 0u, 0u, 0u);
     if (wave == E2_WAVES - 1 && lane < 4) reinterpret_cast<uint4*>(smem + E2_WBYTES + E2_WAVES * E2_RING)[lane] = make_uint4(0u, 0u, 0u, 0u);
-    const int iring = E2_IMG0 + wave * (E2_IMGS * E2_IMGROW);
-    for (int e = lane; e < E2_IMGS * E2_IMGROW / 16; e += 64) reinterpret_cast<uint4*>(smem + iring)[e] = make_uint4(0u, 0u, 0u, 0u);
+    const int iring = wave * (E2_IMGS * E2_IMGROW);      // byte offset inside smem_img
+    for (int e = lane; e < E2_IMGS * E2_IMGROW / 16; e += 64) reinterpret_cast<uint4*>(smem_img + iring)[e] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
 
     const int item = blockIdx.x * E2_WAVES + wave;
@@ -155,7 +160,7 @@ __global__ __launch_bounds__(E2G<NT>::WAVES * 64, 1) void enc_stream2_fwd_kernel
     // pixel p, tap column g - 1, is entry p + g (the strip's ghost pixels come out wrong that way -- column -1 would see columns 2, 1, 0
     // instead of 0, 1, 2 -- and are overwritten by the epilogue's ghost copy like those of x1 / x2).
     float a0[3];
-    const int li = iring + (j + g) * 4;                                        // operand read: + 64 t + slot
+    const int li = (int)(size_t)(__attribute__((address_space(3))) char*)smem_img + iring + (j + g) * 4;   // operand read (LDS byte address): + 64 t + slot
     const int cdma0 = 4 * min(max(reflect_idx(r0 - 1 + lane, W), 0), W - 1);  // DMA source column (bytes) of entries 0..63
     const int cdma1 = 4 * min(max(reflect_idx(r0 + 63 + (lane & 1), W), 0), W - 1);   // entries 64, 65 (lanes 0, 1; 64-pixel strips only)
 #pragma unroll
@@ -185,7 +190,6 @@ __global__ __launch_bounds__(E2G<NT>::WAVES * 64, 1) void enc_stream2_fwd_kernel
     const int b_lo = max(0, y_lo - 2), b_hi = min(H, y_hi + 2);
     const int c_lo = max(0, y_lo - 1), c_hi = min(H, y_hi + 1);
     const int f_lo = max(y_lo + 6, 7), f_hi = min(a_hi, H - 1);   // steps whose three layers are all active, emit, and touch no reflect row
-    const int warm = a_lo + 3 * ((f_lo - a_lo + 2) / 3) + G::AHEAD;   // first branch-free step whose image row was requested by a branch-free step
 
     e2_f32x4 acc[3][3][NT];
 #pragma unroll
@@ -202,13 +206,19 @@ __global__ __launch_bounds__(E2G<NT>::WAVES * 64, 1) void enc_stream2_fwd_kernel
     // at the end of a step).  The reads are inline asm: a C++ read of DMA-written LDS makes the compiler wait for ALL outstanding
     // vector-memory operations.
     float win[3][NT];
+    // (inline asm, not __builtin_amdgcn_global_load_lds: the compiler orders every later LDS access of the wave -- reads AND writes, of any
+    // LDS object -- behind a pending LDS-DMA it knows of with s_waitcnt vmcnt(0), i.e. behind all of the step's stores)
+    auto dma_issue = [&](const char* gsrc, unsigned lds_dst) __attribute__((always_inline)) {
+        __asm__ volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" : : "s"(lds_dst), "v"(gsrc) : "memory", "m0");
+    };
+    const unsigned iring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem_img + (unsigned)iring;
     auto dma_img_row = [&](int y) __attribute__((always_inline)) {
         const char* src = img + (long long)rrow(y) * W * 4;
-        char* dst = smem + iring + (y & (E2_IMGS - 1)) * E2_IMGROW;
+        const unsigned dst = iring_lds + (unsigned)((y & (E2_IMGS - 1)) * E2_IMGROW);
         if (NT == 4) {
-            __builtin_amdgcn_global_load_lds(E2_GPTR(src + cdma0), E2_LPTR(dst), 4, 0, 0);
-            if (lane < 2) __builtin_amdgcn_global_load_lds(E2_GPTR(src + cdma1), E2_LPTR(dst + 256), 4, 0, 0);
-        } else if (lane < E2_W + 2) __builtin_amdgcn_global_load_lds(E2_GPTR(src + cdma0), E2_LPTR(dst), 4, 0, 0);
+            dma_issue(src + cdma0, dst);
+            if (lane < 2) dma_issue(src + cdma1, dst + 256);
+        } else if (lane < E2_W + 2) dma_issue(src + cdma0, dst);
     };
     auto read_img_row = [&](int y, float (&dst)[NT]) __attribute__((always_inline)) {
         const int a = li + (y & (E2_IMGS - 1)) * E2_IMGROW;
@@ -299,6 +309,15 @@ __global__ __launch_bounds__(E2G<NT>::WAVES * 64, 1) void enc_stream2_fwd_kernel
         };
         // epilogue of a finished row (x0: row s; layer L >= 1: out row R - 1 = s - 2 L): round, ReLU (as a signed 16-bit max on the rounded
         // pair), pair the column tiles, ring + global stores, ghost pixels
+        // a general step whose layer does not emit still issues that layer's store instructions (offset beyond the descriptor: dropped by
+        // the hardware): EVERY step issues the same number of vector-memory operations, which is what lets the image rows do without
+        // an s_waitcnt (see the read at the end of the step)
+        auto dummy_stores = [&]() __attribute__((always_inline)) {
+            if (E2_ABL & 1) return;
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+                __builtin_amdgcn_raw_buffer_store_b128((e2_u32x4){0u, 0u, 0u, 0u}, rs_out, (int)0x80000000u, 0, 0);
+        };
         auto epilogue = [&](auto Lc) __attribute__((always_inline)) {
             constexpr int L = decltype(Lc)::value;
             if (E2_ABL & 8) return;
@@ -347,13 +366,13 @@ __global__ __launch_bounds__(E2G<NT>::WAVES * 64, 1) void enc_stream2_fwd_kernel
         // row is done, a whole step ahead of its use)
         load_k(E2I<3>()); if (on2) mma_k(E2I<2>());
         if (x0_on && !(E2_ABL & 16)) dma_img_row(s + G::AHEAD);   // (read out of the ring at the end of step s + AHEAD - 2)
-        if (em1) epilogue(E2I<1>());
+        if (em1) epilogue(E2I<1>()); else dummy_stores();
         E2_FENCE();
         load_k(E2I<4>()); if (on2) mma_k(E2I<3>());
         E2_FENCE();
         load_k(E2I<5>()); if (on2) mma_k(E2I<4>());
         E2_FENCE();
-        load_k(E2I<6>()); if (on3) mma_k(E2I<5>()); if (em2) epilogue(E2I<2>());
+        load_k(E2I<6>()); if (on3) mma_k(E2I<5>()); if (em2) epilogue(E2I<2>()); else dummy_stores();
         E2_FENCE();
         load_k(E2I<7>()); if (on3) mma_k(E2I<6>());
         E2_FENCE();
@@ -363,15 +382,15 @@ __global__ __launch_bounds__(E2G<NT>::WAVES * 64, 1) void enc_stream2_fwd_kernel
         E2_FENCE();
         if (on3) mma_k(E2I<9>());
         E2_FENCE();
-        if (em3) epilogue(E2I<3>());
+        if (em3) epilogue(E2I<3>()); else dummy_stores();
         if (x0_on && !(E2_ABL & 16)) {
-            // image row s + 2 for the next step, into the set of row s - 1 (dead since this step's first-layer MFMAs).  Its DMA left at
-            // step s - (AHEAD - 2), and at least 64 vector-memory operations (OPS stores + DMAs per branch-free step) have been issued since: a
-            // wave has at most 63 in flight and they complete in order, so the row HAS landed -- no wait at all, which is the point: any
-            // s_waitcnt vmcnt(n) here also waits for stores, and with the chip's HBM write queue full (this kernel's steady state) even
-            // stores from two steps back are still in flight (measured: distance 1 and distance 4 with counted waits both cost ~100 us).
-            // The general steps, and the first AHEAD branch-free steps after them, have issued fewer operations: they wait for everything.
-            if (!FAST || s < warm) __builtin_amdgcn_s_waitcnt(0x0f70);
+            // image row s + 2 for the next step, into the set of row s - 1 (dead since this step's first-layer MFMAs).  NO WAIT: the row
+            // was requested either before the first step (the prologue waits once, with no store in flight yet) or AHEAD - 2 steps ago,
+            // and every step issues exactly OPS vector-memory operations -- at least 64 since the request.  A wave has at most 63 in
+            // flight and they complete in order, so the row has landed.  That is the point of the whole arrangement: any
+            // s_waitcnt vmcnt(n) also waits for STORES, and with the HBM write queue full (this kernel's steady state) stores stay in
+            // flight for microseconds -- requested one step ahead, or four steps ahead with a counted wait, the image rows cost the
+            // kernel ~100 us (profiles/r05_ubench_enc_stream2_ablation.txt).
             read_img_row(s + 2, win[(P + 2) % 3]);
         }
         E2_FENCE();
@@ -379,14 +398,13 @@ __global__ __launch_bounds__(E2G<NT>::WAVES * 64, 1) void enc_stream2_fwd_kernel
 #undef E2_FENCE
 
     // ---- the pipeline: s = a_lo .. (last x3 row + 6); phase 0 at s = a_lo
+    static_assert(G::AHEAD + 1 <= E2_IMGS && 2 * NP + (G::AHEAD - 2) * G::OPS >= 64, "image ring / request distance");
 #pragma unroll 1
-    for (int y = a_lo - 1; y < a_lo + 2; ++y) dma_img_row(y);
-    __builtin_amdgcn_s_waitcnt(0x0f70);
+    for (int y = a_lo - 1; y < a_lo + G::AHEAD; ++y) dma_img_row(y);
+    __builtin_amdgcn_s_waitcnt(0x0f70);      // (the only vector-memory wait of the kernel: nothing but these requests is in flight)
     read_img_row(a_lo - 1, win[2]);
     read_img_row(a_lo, win[0]);
     read_img_row(a_lo + 1, win[1]);
-#pragma unroll 1
-    for (int y = a_lo + 2; y < a_lo + G::AHEAD; ++y) dma_img_row(y);      // (the last ones reuse the slots of the rows read above)
     const int s_end = y_hi + 6;      // x3 row y_hi - 1 is emitted at step y_hi + 5
     // Three stretches of steps, in groups of three (the accumulator rotation): general steps up to the first group that lies inside
     // [f_lo, f_hi), the branch-free groups, general steps again to the end.  The general body and the fast body are SEPARATE loops of one
