@@ -362,6 +362,48 @@ def test_graphed_step_equals_eager_step():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["PFNetv1", "DenseFuse"])
+def test_graph_replay_after_an_eager_step_of_another_shape(name):
+    """the streaming backward chain's output buffer used to be a single-entry cache keyed on the shape -- an eager step
+    with another batch size between two replays freed the buffer whose address the captured graph had baked in, and the next replay
+    wrote into memory the allocator may have handed to someone else.  The buffers are now kept per (shape, branch slot): capture at
+    B = 4, run an eager step at B = 2 (and allocate + fill a few large tensors, which is what would have landed in the freed block),
+    replay, and compare every parameter gradient bit for bit with an eager B = 4 backward on the same inputs."""
+    import core.model as M
+    from core.loss import GradLoss, PixelLoss, SSIMLoss
+    from mmif.graph import GraphedStep
+    from mmif.optim import FusedClipAdam
+    dev = torch.device("cuda", 0)
+    with dtype_ctx("bf16"):
+        l1, l2, l3 = SSIMLoss('ssim', weight=1.0), PixelLoss('l1', weight=0.01), GradLoss('l1', weight=0.1).to(dev)
+
+        def losses(a, b, f):
+            x, y, z = l1(a, b, f), l2(a, b, f, mode='max'), l3(a, b, f, mode='max')
+            return x + y + z, x, y, z
+        g = torch.Generator(device="cpu").manual_seed(17)
+        a4, b4 = torch.rand(4, 1, 72, 88, generator=g).to(dev), torch.rand(4, 1, 72, 88, generator=g).to(dev)
+        a2, b2 = torch.rand(2, 1, 72, 88, generator=g).to(dev), torch.rand(2, 1, 72, 88, generator=g).to(dev)
+        torch.manual_seed(3)
+        model = getattr(M, name)().to(dev)
+        opt = FusedClipAdam(model.parameters(), lr=1e-3, max_norm=5.0)
+        gs = GraphedStep(model, losses, opt, a4, b4)
+        gs(a4, b4, step_optimizer=False)
+        torch.cuda.synchronize()
+        ref = [p.grad.detach().clone() for p in model.parameters()]
+        # an eager backward of ANOTHER shape in between (no optimiser step: the weights must stay what the reference saw) ...
+        opt.zero_grad(set_to_none=True)
+        losses(a2, b2, model(a2, b2))[0].backward()
+        opt.zero_grad(set_to_none=True)
+        junk = [torch.full((4, 64, 72, 88), float(k + 1), device=dev, dtype=torch.bfloat16) for k in range(6)]   # ... and fresh allocations
+        gs(a4, b4, step_optimizer=False)
+        torch.cuda.synchronize()
+        for k, (p, r) in enumerate(zip(model.parameters(), ref)):
+            assert float(r.abs().max()) > 0
+            assert torch.equal(p.grad, r), f"parameter {k}: replay after an eager step of another shape differs"
+        assert all(float(t.float().mean()) == k + 1 for k, t in enumerate(junk))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", ["PFNetv1", "NestFuse", "RFNNest"])
 def test_graphed_step_after_eager_steps_with_live_loss_tensors(name):
     """Round 4: bench.py --model NestFuse --graph died with SIGSEGV inside hipStreamEndCapture.  Eager optimiser steps on the default
