@@ -459,6 +459,16 @@ typedef struct mmif_dense_chain {
     const mmif_tensor* out;
 } mmif_dense_chain;
 int mmif_dense_encoder_chain(const mmif_dense_chain* chain_a, const mmif_dense_chain* chain_b, void* stream);
+/* Round 5: the WHOLE backward of the DenseBlock encoder -- the gradient chain above AND dW, db of ConvLayer(1, 16) + the three DenseBlock
+ * convs (mmif_dense_encoder_wgrad) -- as ONE streaming launch per call (csrc/enc_bwd.hip): g0..g2 never leave the chip, the activations
+ * x0..x2 are read once.  chain_x->out is ignored.  dwdb_x = {dW0, db0, dW1, db1, dW2, db2, dW3, db3} (fp32, reference layouts; a db
+ * may be NULL); accumulate_x != 0: add onto what they hold (the second branch of a shared encoder).  img_x: the branch's input image
+ * [n][h][w] fp32.  workspace: mmif_dense_encoder_bwd_workspace() bytes.  Reference: autograd of core/model.py:73-80 + core/block.py:137-151
+ * (train.py:71).  h, w >= 4; bf16 tensors. */
+size_t mmif_dense_encoder_bwd_workspace(void);
+int mmif_dense_encoder_bwd(const mmif_dense_chain* chain_a, const float* img_a, float* const* dwdb_a, int32_t accumulate_a,
+                           const mmif_dense_chain* chain_b, const float* img_b, float* const* dwdb_b, int32_t accumulate_b,
+                           void* workspace, size_t workspace_bytes, void* stream);
 /* The same for fp32 tensors: x3-format images (mmif_packed_weight_bytes_x3(16 (3 - k), 16, 3)) for the split-operand dgrad kernels. */
 int mmif_pack_dense_chain_x3(const float* w1, const float* w2, const float* w3, void* packed_v0, void* packed_v1, void* packed_v2,
                              void* stream);

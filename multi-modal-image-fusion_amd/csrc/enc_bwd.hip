@@ -1,0 +1,582 @@
+// Backward of the DenseBlock encoder -- ConvLayer(1 -> 16) + DenseBlock(16, 16) of the PFNet / DenseFuse family (reference
+// core/model.py:73-80, core/block.py:137-151 under autograd, train.py:71) -- as ONE streaming kernel (round 5): the gradient chain
+//     g2 = [x2 > 0] (G2 + A32 g3)      g1 = [x1 > 0] (G1 + A21 g2 + A31 g3)      g0 = [x0 > 0] (G0 + A10 g1 + A20 g2 + A30 g3)
+// (A_lk = adjoint of reflect pad + 3x3 correlation; csrc/enc_chain.hip, round 4) AND the weight gradients dW, db of all four layers
+// (csrc/enc_wgrad.hip, round 2) from the same rows while they are in LDS.
+//
+// The two-kernel form moves 288 channel planes per branch through HBM: the chain reads G (64) + the masks x0..x2 (48) and WRITES
+// [g0 | g1 | g2 | g3] (64), the weight-gradient pass reads them back (64) with x0..x2 (48) again -- 0.65 ms of the 3.7 ms PFNetv1
+// step at ~4 TB/s, i.e. bandwidth bound.  The gradients g0..g2 have no other consumer.  Here a wave owns a strip of 32 columns of one
+// image segment and walks down its rows; per row step r it
+//   * takes g3 row r+3 (registers -> LDS ring) and runs the chain in INPUT-STATIONARY form (csrc/enc_stream2.hip): input row R feeds
+//     the three tap rows at once -- out[R+1] (fresh accumulator, its C operand = the incoming gradient G of that row), out[R],
+//     out[R-1] (complete) -- layer 1 on g3 row r+3 -> g2 row r+2, layer 2 on [g2 | g3] row r+2 -> g1 row r+1, layer 3 on
+//     [g1 | g2 | g3] row r+1 -> g0 row r; epilogue = the round-4 kernel's (column fold of the padded-domain halo by a cross-lane add,
+//     ReLU mask from x, one rounding), the rows stay in small LDS rings (4 / 4 / 2 / 1 slots);
+//   * forms the weight-gradient products of row r: dW_L[o][c][u][v] += sum_px gL[o](r, px) x_in[c](R(r+u-1), px+v-1), K = the strip's 32
+//     pixels = ONE k-step, both operands k-major through transposing LDS reads (ds_read_b64_tr_b16): 54 bf16 MFMAs into 54 accumulator
+//     tiles that live in the wave's registers for the whole strip (216 of its 512: one wave per SIMD), the first layer against the
+//     fp32 image on the exact fp32 matrix path, the bias sums as products with a ones operand.
+// The activations x0..x2 and the image rows come in by LDS-DMA (a ring of 6 rows, requested two steps ahead); the ReLU masks of the
+// chain are read from the same ring.  HBM traffic: G (64 planes) + x (48) + the image, NOTHING written but one partial sum per block.
+// Pixels are counted once: the weight-gradient operand of gL is zeroed outside the strip's kept columns, rows outside the segment are
+// skipped; strips / segments recompute their margins (3 columns / rows).
+#include "enc_wgrad.hpp"
+#include <stdlib.h>
+#pragma clang diagnostic ignored "-Winline-asm"   // (the LDS-DMA asm names m0 in its clobber list: "reserved register")
+
+namespace mmif {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 fb_bf16x8;
+typedef __attribute__((ext_vector_type(4))) float fb_f32x4;
+typedef __attribute__((ext_vector_type(4))) short fb_s16x4;
+typedef __attribute__((ext_vector_type(8))) short fb_s16x8;
+typedef unsigned fb_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned fb_u32x2 __attribute__((ext_vector_type(2)));
+#define FB_LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+
+constexpr int FB_W = 32, FB_KEEP = FB_W - 6;
+constexpr int FB_CBS = 512;                    // bytes of one channel block of a ring row (32 px x 16 B)
+constexpr int FB_ROW = 2 * FB_CBS;             // one gradient ring slot: [cb 0][cb 1]
+constexpr int FB_S3 = 4, FB_S2 = 4, FB_S1 = 2; // ring slots of g3 / g2 / g1 (powers of two); g0: one
+constexpr int FB_G3 = 0, FB_G2 = FB_S3 * FB_ROW, FB_G1 = FB_G2 + FB_S2 * FB_ROW, FB_G0 = FB_G1 + FB_S1 * FB_ROW, FB_GRING = FB_G0 + FB_ROW;   // 11264
+constexpr int FB_XS = 6;                       // slots of the activation / image rings (rows r-1 .. r+2 in use, r+3, r+4 in flight)
+constexpr int FB_XROW = 6 * FB_CBS;            // x0 | x1 | x2 row: [6 cb][32 px][16 B]
+constexpr int FB_IROW = 128;                   // image row: 32 fp32
+constexpr int FB_WAVES = 4;
+constexpr int FB_NFRAG = 30;                   // chain A fragments in LDS: (2 + 3 + 5 k-steps) x 3 tap rows, 1 KB each
+constexpr int FB_WBYTES = FB_NFRAG * 1024;
+constexpr int FB_LDS = FB_WBYTES + FB_WAVES * FB_GRING + 64;
+constexpr int FB_LDS_DMA = FB_WAVES * FB_XS * (FB_XROW + FB_IROW);
+constexpr int FB_OPS = 7 + 4;                  // vector-memory operations per step: g3 row + 6 G fragments (registers), 3 x-row DMAs + 1 image DMA
+static_assert(EW_PER * 4 <= FB_LDS, "the block partial is staged in the operand LDS");
+
+struct BwdBranch {
+    TV g3, glow, x;            // 2-block gradient view, 6-block view G0 | G1 | G2, 6-block view x0 | x1 | x2 (halo 0)
+    const uint4* wpk[3];       // dgrad operand images of the virtual layers: [0] dst x0 (48 in), [1] dst x1 (32 in), [2] dst x2 (16 in)
+    const float* img;          // [n][h][w] fp32
+    float* partial;            // gridDim.x block partials of EW_PER floats
+};
+struct BwdArgs {
+    BwdBranch br[2];
+    int n, h, w;
+    int nstrips, nseg, seg_rows;
+    int items;                 // per branch: n * nseg * nstrips
+};
+
+template <int N> struct FBI { static constexpr int value = N; };
+
+__global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs A) {
+    __shared__ __attribute__((aligned(16))) char smem[FB_LDS];
+    // written by LDS-DMA only (inline asm: the compiler must not know, it would order every LDS access of the wave behind the pending
+    // DMAs with s_waitcnt vmcnt(0), see csrc/enc_stream2.hip); read by plain loads (masks) and transposing reads (operands)
+    __shared__ __attribute__((aligned(16))) char smem_dma[FB_LDS_DMA];
+    const BwdBranch& B = A.br[blockIdx.y];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, g = lane >> 4;
+
+    // ---- chain A fragments (tap-row major K order, csrc/enc_stream2.hip): virtual layer 1 = dst x2 (input g3), 2 = dst x1 ([g2 | g3]),
+    // 3 = dst x0 ([g1 | g2] + g3)
+    auto a_plane = [&](int kq, int u, int kg) {
+        const int L = kq < 2 ? 1 : (kq < 5 ? 2 : 3), q = kq < 2 ? kq : (kq < 5 ? kq - 2 : kq - 5);
+        if (L >= 2 && q < 3) return (u * 3 + q) * 4 + kg;
+        const int q2 = L == 1 ? q : q - 3, base = L == 3 ? 36 : 0;
+        return base + ((q2 == 1 && kg >= 2) ? 18 + (kg & 1) : (u * 3 + (q2 == 0 ? (kg >> 1) : 2)) * 2 + (kg & 1));
+    };
+    for (int e = tid; e < FB_NFRAG * 64; e += FB_WAVES * 64) {
+        const int f = e >> 6, l = e & 63, oc = l & 15, kg = l >> 4;
+        const int u = f % 3, kq = f / 3;
+        reinterpret_cast<uint4*>(smem)[e] = B.wpk[kq < 2 ? 2 : (kq < 5 ? 1 : 0)][a_plane(kq, u, kg) * 16 + oc];
+    }
+    const int ring = FB_WBYTES + wave * FB_GRING;
+    for (int e = lane; e < FB_GRING / 16; e += 64) reinterpret_cast<uint4*>(smem + ring)[e] = make_uint4(0u, 0u, 0u, 0u);
+    if (wave == FB_WAVES - 1 && lane < 4) reinterpret_cast<uint4*>(smem + FB_WBYTES + FB_WAVES * FB_GRING)[lane] = make_uint4(0u, 0u, 0u, 0u);
+    const int xring = wave * (FB_XS * FB_XROW);                                     // byte offsets inside smem_dma
+    const int iring = FB_WAVES * FB_XS * FB_XROW + wave * (FB_XS * FB_IROW);
+    for (int e = lane; e < FB_XS * FB_XROW / 16; e += 64) reinterpret_cast<uint4*>(smem_dma + xring)[e] = make_uint4(0u, 0u, 0u, 0u);
+    for (int e = lane; e < FB_XS * FB_IROW / 16; e += 64) reinterpret_cast<uint4*>(smem_dma + iring)[e] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+
+    // ---- weight-gradient accumulators (per wave, over its whole strip): w3[u][v][b] = dW3 tile (16 oc x 16 ci of input block b) of tap (u, v)
+    fb_f32x4 w3[3][3][3], w2[3][3][2], w1[3][3], accb[3], acc0;
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            w1[u][v] = (fb_f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int b = 0; b < 3; ++b) w3[u][v][b] = (fb_f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int b = 0; b < 2; ++b) w2[u][v][b] = (fb_f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) accb[i] = (fb_f32x4){0.f, 0.f, 0.f, 0.f};
+    acc0 = (fb_f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int item = blockIdx.x * FB_WAVES + wave;
+    const int H = A.h, W = A.w;
+    const int strip = item % A.nstrips;
+    const int seg = (item / A.nstrips) % A.nseg;
+    const int in_ = min(item / (A.nstrips * A.nseg), A.n - 1);
+    const int y_lo = seg * A.seg_rows, y_hi = min(H, y_lo + A.seg_rows);
+    if (item < A.items && y_lo < y_hi) {
+        // ---- strip geometry (csrc/enc_chain.hip): region [r0, r0 + 32) of image columns, r0 = -1 for the first strip (column -1 and column w
+        // belong to the edge strips, which fold them onto columns 1 / w-2); kept columns [o_lo, o_hi)
+        auto strip_r0 = [&](int s) { return A.nstrips == 1 ? -1 : min(-1 + FB_KEEP * s, W - (FB_W - 1)); };
+        auto strip_hi = [&](int r) { return (r + FB_W >= W + 1) ? W : min(r + FB_W - 3, W - 4); };
+        const int r0 = strip_r0(strip);
+        const int o_hi = strip_hi(r0);
+        const int o_lo = strip == 0 ? 0 : max(r0 + 3, strip_hi(strip_r0(strip - 1)));
+        const bool edgeL = r0 < 0, edgeR = r0 + FB_W >= W + 1;
+
+        // ---- lane constants: chain operands
+        const int h2 = g >> 1, cbk = g & 1;
+        const int la = g * 256 + j * 16;
+        const int lb4 = ring + cbk * FB_CBS + j * 16 - 16;
+        const int lb2 = ring + cbk * FB_CBS + (j + h2) * 16 - 16;
+        // chain epilogue (after the row swap): this lane holds the granule of pixel 16 (g & 1) + j, channel block g >> 1
+        const int px_e = 16 * (g & 1) + j, cb_e = g >> 1;
+        const int x_e = r0 + px_e;
+        const bool in_e = x_e >= 0 && x_e < W;
+        const int lw_e = ring + cb_e * FB_CBS + px_e * 16;
+        const int srcL = (cb_e * 2 + (max(px_e - 2, 0) >> 4)) * 16 + (max(px_e - 2, 0) & 15);
+        const int srcR = (cb_e * 2 + (min(px_e + 2, FB_W - 1) >> 4)) * 16 + (min(px_e + 2, FB_W - 1) & 15);
+        const bool tgtL = edgeL && x_e == 1, tgtR = edgeR && x_e == W - 2;
+        // g3 rows: lane = (pixel lane & 31, channel block lane >> 5)
+        const int px_a = lane & 31, cb_a = lane >> 5;
+        const int x_a = r0 + px_a;
+        const bool in_a = x_a >= 0 && x_a < W;
+        const int lw_a = ring + FB_G3 + cb_a * FB_CBS + px_a * 16;
+
+        // ---- global operands through buffer descriptors (32-bit lane offsets; bit 31 = beyond the descriptor = reads as zero)
+        auto img_base = [&](const TV& t) { return t.base + ((long long)in_ * t.img + (long long)t.cb_off * t.plane) * 16; };
+        const unsigned g3_plane = (unsigned)(B.g3.plane * 16), g3_row = (unsigned)B.g3.ws * 16u, g3_org = (unsigned)(B.g3.halo * (B.g3.ws + 1)) * 16u;
+        const unsigned gl_plane = (unsigned)(B.glow.plane * 16), gl_row = (unsigned)B.glow.ws * 16u, gl_org = (unsigned)(B.glow.halo * (B.glow.ws + 1)) * 16u;
+        const unsigned x_plane = (unsigned)(B.x.plane * 16), x_rowb = (unsigned)B.x.ws * 16u;
+        const __amdgpu_buffer_rsrc_t rs_g3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(img_base(B.g3)), 0, (int)((unsigned)(B.g3.cb_total - B.g3.cb_off) * g3_plane), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_gl = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(img_base(B.glow)), 0, (int)((unsigned)(B.glow.cb_total - B.glow.cb_off) * gl_plane), 0x00020000);
+        const unsigned g3_off = in_a ? (unsigned)cb_a * g3_plane + (unsigned)x_a * 16u + g3_org : 0x80000000u;
+        unsigned gl_off[2];      // G fragments in accumulator layout: this lane's channels 4 g .. 4 g + 3 of pixel 16 t + j = 8 bytes of a granule
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int c = r0 + 16 * t + j;
+            gl_off[t] = (c >= 0 && c < W) ? (unsigned)(g >> 1) * gl_plane + (unsigned)c * 16u + (unsigned)(g & 1) * 8u + gl_org : 0x80000000u;
+        }
+        auto crow = [&](int y) { return (unsigned)min(max(y, 0), H - 1); };
+        auto rrow = [&](int y) { return min(max(reflect_idx(y, H), 0), H - 1); };
+        // activation / image rows by LDS-DMA: ring pixel p = image column reflect(r0 + p) (the edge strips' ghost pixels hold the reflected column)
+        const char* x_img = img_base(B.x);
+        const char* im_img = reinterpret_cast<const char*>(B.img + (long long)in_ * H * W);
+        const unsigned xring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem_dma + (unsigned)xring;
+        const unsigned iring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem_dma + (unsigned)iring;
+        const int cdma = min(max(reflect_idx(r0 + (lane & 31), W), 0), W - 1);
+        const unsigned xdma_off = (unsigned)(lane >> 5) * x_plane + (unsigned)cdma * 16u;
+        auto dma16 = [&](const char* gsrc, unsigned lds_dst) __attribute__((always_inline)) {
+            __asm__ volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(lds_dst), "v"(gsrc) : "memory", "m0");
+        };
+        auto dma4 = [&](const char* gsrc, unsigned lds_dst) __attribute__((always_inline)) {
+            __asm__ volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" : : "s"(lds_dst), "v"(gsrc) : "memory", "m0");
+        };
+        auto xslot = [&](int y) { return (int)((unsigned)y % (unsigned)FB_XS); };      // (y >= 0)
+        auto dma_rows = [&](int y) __attribute__((always_inline)) {   // x0 | x1 | x2 row (3 x 1 KiB) + image row of image row clamp(y)
+            const int yy = (int)crow(y), sl_ = xslot(yy);
+            const char* src = x_img + (unsigned long long)((unsigned)yy * x_rowb);
+            const unsigned dst = xring_lds + (unsigned)(sl_ * FB_XROW);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) dma16(src + (unsigned long long)(xdma_off + (unsigned)(2 * i) * x_plane), dst + (unsigned)i * 1024u);
+            if (lane < 32) dma4(im_img + ((long long)yy * W + cdma) * 4, iring_lds + (unsigned)(sl_ * FB_IROW));
+        };
+
+        // ---- lane constants: weight-gradient operands (transposing reads: in-group lane sl supplies pixel sl >> 2 (+ 4), 4-channel chunk sl & 3)
+        const int tr_row = j >> 2, tr_c = j & 3;
+        const int ltr = (tr_c >> 1) * FB_CBS + (8 * g + tr_row) * 16 + (tr_c & 1) * 8;
+        unsigned km[4];          // keep-mask of this lane's 8 pixels 8 g .. 8 g + 7 (two bf16 per dword)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int c0 = r0 + 8 * g + 2 * d, c1 = c0 + 1;
+            km[d] = ((c0 >= o_lo && c0 < o_hi) ? 0xffffu : 0u) | ((c1 >= o_lo && c1 < o_hi) ? 0xffff0000u : 0u);
+        }
+        unsigned kq8 = 0;        // first layer: keep bits of pixels 4 q + g, q = 0 .. 7
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int c = r0 + 4 * q + g;
+            kq8 |= (c >= o_lo && c < o_hi) ? (1u << q) : 0u;
+        }
+        const int un = min(j / 3, 2), vn = j - 3 * (j / 3);
+        const fb_bf16x8 ones = __builtin_bit_cast(fb_bf16x8, make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u));
+        auto tr_frag = [&](int addr) __attribute__((always_inline)) {
+            const fb_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(FB_LDS_PTR(fb_s16x4, smem + addr));
+            const fb_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(FB_LDS_PTR(fb_s16x4, smem + addr + 64));
+            return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        };
+        auto tr_frag_x = [&](int addr) __attribute__((always_inline)) {
+            const fb_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(FB_LDS_PTR(fb_s16x4, smem_dma + addr));
+            const fb_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(FB_LDS_PTR(fb_s16x4, smem_dma + addr + 64));
+            return __builtin_bit_cast(fb_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        };
+
+        // rows each stage touches (as csrc/enc_chain.hip): g3 rows [a_lo, a_hi), g2 rows [b_lo, b_hi), g1 rows [c_lo, c_hi), g0 rows [y_lo, y_hi)
+        const int a_lo = max(0, y_lo - 3), a_hi = min(H, y_hi + 3);
+        const int b_lo = max(0, y_lo - 2), b_hi = min(H, y_hi + 2);
+        const int c_lo = max(0, y_lo - 1), c_hi = min(H, y_hi + 1);
+        const int r_first = a_lo - 3;
+
+        fb_u32x4 pg3;            // (the g3 row travels one step ahead only: one register set)
+        fb_u32x2 pG[3][2];       // C operands of the fresh accumulators (G2 row r + 4, G1 row r + 3, G0 row r + 2 at step r): one set, each layer's
+                                 // pair re-requested for the NEXT step right after this step's first k-step of that layer consumed it
+        auto request_g3 = [&](int y) __attribute__((always_inline)) {
+            pg3 = __builtin_amdgcn_raw_buffer_load_b128(rs_g3, (int)g3_off, (int)(crow(y) * g3_row), 0);
+        };
+        auto request_G = [&](int Lc, int r) __attribute__((always_inline)) {      // for step r
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                pG[Lc - 1][t] = __builtin_amdgcn_raw_buffer_load_b64(rs_gl, (int)gl_off[t], (int)((unsigned)(2 * (3 - Lc)) * gl_plane + crow(r + 5 - Lc) * gl_row), 0);
+        };
+        auto g_c = [&](const fb_u32x2& v) {
+            return (fb_f32x4){__uint_as_float(v[0] << 16), __uint_as_float(v[0] & 0xffff0000u), __uint_as_float(v[1] << 16), __uint_as_float(v[1] & 0xffff0000u)};
+        };
+
+        fb_f32x4 acc[3][3][2];
+#pragma unroll
+        for (int L = 0; L < 3; ++L)
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[L][q][t] = (fb_f32x4){0.f, 0.f, 0.f, 0.f};
+
+#define FB_FENCE() __builtin_amdgcn_sched_barrier(0)
+        // ---- one row step (P = (r - r_first) % 3 at compile time; FAST: every stage active, no border row)
+        auto step = [&](auto Pc, auto Fc, int r) __attribute__((always_inline)) {
+            constexpr int P = decltype(Pc)::value;
+            constexpr bool FAST = decltype(Fc)::value != 0;
+            const int R1 = r + 3, R2 = r + 2, R3 = r + 1;      // input row of chain layer Lc = r + 4 - Lc; it completes out row R - 1
+            const bool on1 = FAST || (R1 >= a_lo && R1 < a_hi), on2 = FAST || (R2 >= b_lo && R2 < b_hi), on3 = FAST || (R3 >= c_lo && R3 < c_hi);
+            const bool em1 = FAST || (R1 - 1 >= b_lo && R1 - 1 < b_hi), em2 = FAST || (R2 - 1 >= c_lo && R2 - 1 < c_hi),
+                       em3 = FAST || (r >= y_lo && r < y_hi);
+            // everything requested before the previous step has landed (the previous step's FB_OPS operations may still be in flight)
+            __builtin_amdgcn_s_waitcnt(0x0f70 | (FB_OPS & 15) | ((FB_OPS >> 4) << 14));
+            const int bL1 = lb2 + FB_G3 + (R1 & (FB_S3 - 1)) * FB_ROW;
+            const int bL2 = lb4 + (h2 ? FB_G3 + (R2 & (FB_S3 - 1)) * FB_ROW : FB_G2 + (R2 & (FB_S2 - 1)) * FB_ROW);
+            const int bL3 = lb4 + (h2 ? FB_G2 + (R3 & (FB_S2 - 1)) * FB_ROW : FB_G1 + (R3 & (FB_S1 - 1)) * FB_ROW);
+            const int bL3x = lb2 + FB_G3 + (R3 & (FB_S3 - 1)) * FB_ROW;
+            fb_bf16x8 fa[2][3], fbr[2][2];
+
+            auto load_k = [&](auto Nc) __attribute__((always_inline)) {
+                constexpr int N = decltype(Nc)::value;
+                const char* pa = smem + la + N * 3 * 1024;
+#pragma unroll
+                for (int u = 0; u < 3; ++u) fa[N & 1][u] = *reinterpret_cast<const fb_bf16x8*>(pa + u * 1024);
+                const char* pb = smem + (N < 2 ? bL1 + 32 * N : (N < 5 ? bL2 + 16 * (N - 2) : (N < 8 ? bL3 + 16 * (N - 5) : bL3x + 32 * (N - 8))));
+#pragma unroll
+                for (int t = 0; t < 2; ++t) fbr[N & 1][t] = *reinterpret_cast<const fb_bf16x8*>(pb + t * 256);
+            };
+            auto mma_k = [&](auto Nc) __attribute__((always_inline)) {
+                constexpr int N = decltype(Nc)::value;
+                constexpr int Lc = N < 2 ? 1 : (N < 5 ? 2 : 3);
+                constexpr bool first = N == 0 || N == 2 || N == 5;
+                constexpr int i1 = (P + 4 - Lc) % 3, i0 = (i1 + 1) % 3, i2 = (i1 + 2) % 3;      // accumulator rows of out rows R, R+1, R-1
+                const int R = r + 4 - Lc;
+                // adjoint of reflect padding along y: padded row -1 (= tap row 2 of input row 0) folds onto row 1, padded row h onto row h-2
+                const bool top = !FAST && R == 0, bot = !FAST && R == H - 1;
+                if (!FAST && first && R == 0) {   // row 0 has no row above it to open its accumulator: start it from G row 0 here
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+                        acc[Lc - 1][i1][t] = g_c(__builtin_amdgcn_raw_buffer_load_b64(rs_gl, (int)gl_off[t], (int)((unsigned)(2 * (3 - Lc)) * gl_plane), 0));
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const fb_bf16x8 b = fbr[N & 1][t];
+                    acc[Lc - 1][i0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[N & 1][0], b, first ? g_c(pG[Lc - 1][t]) : acc[Lc - 1][i0][t], 0, 0, 0);
+                    acc[Lc - 1][i1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[N & 1][1], b, acc[Lc - 1][i1][t], 0, 0, 0);
+                    acc[Lc - 1][i2][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[N & 1][2], b, acc[Lc - 1][i2][t], 0, 0, 0);
+                    if (!FAST) {
+                        if (top) acc[Lc - 1][i0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[N & 1][2], b, acc[Lc - 1][i0][t], 0, 0, 0);
+                        if (bot) acc[Lc - 1][i2][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[N & 1][0], b, acc[Lc - 1][i2][t], 0, 0, 0);
+                    }
+                }
+                if (first) request_G(Lc, r + 1);
+            };
+            // epilogue of chain layer Lc: out row rho = R - 1 of g(3 - Lc): pair the column tiles, fold the edge columns, ReLU mask, round once
+            auto epilogue = [&](auto Lc_) __attribute__((always_inline)) {
+                constexpr int Lc = decltype(Lc_)::value;
+                constexpr int i2 = ((P + 4 - Lc) % 3 + 2) % 3;
+                constexpr int XO = Lc == 1 ? FB_G2 : (Lc == 2 ? FB_G1 : FB_G0), SO = Lc == 1 ? FB_S2 : (Lc == 2 ? FB_S1 : 1);
+                const int rho = r + 3 - Lc;
+                float c[8];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[Lc - 1][i2][0][q]), __float_as_uint(acc[Lc - 1][i2][1][q]), false, false);
+                    c[q] = __uint_as_float(sw[0]);
+                    c[4 + q] = __uint_as_float(sw[1]);
+                }
+                if (edgeL || edgeR) {   // wave-uniform: the adjoint of reflect padding along x
+                    float fl[8], fr[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        fl[i] = __shfl(c[i], srcL, 64);
+                        fr[i] = __shfl(c[i], srcR, 64);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) c[i] += (tgtL ? fl[i] : 0.f) + (tgtR ? fr[i] : 0.f);
+                }
+                // mask: x(3 - Lc) row rho from the activation ring (bf16 > 0  <=>  sign clear and magnitude non-zero; columns outside the image: zero)
+                const uint4 xq = *reinterpret_cast<const uint4*>(smem_dma + xring + xslot((int)crow(rho)) * FB_XROW + (2 * (3 - Lc) + cb_e) * FB_CBS + px_e * 16);
+                const uint32_t xw[4] = {xq.x, xq.y, xq.z, xq.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t lo = xw[i] & 0xffffu, hi = xw[i] >> 16;
+                    if (!in_e || !((lo & 0x8000u) == 0 && (lo & 0x7fffu) != 0)) c[2 * i] = 0.f;
+                    if (!in_e || !((hi & 0x8000u) == 0 && (hi & 0x7fffu) != 0)) c[2 * i + 1] = 0.f;
+                }
+                const uint4 gr = make_uint4(pack_bf16x2(c[0], c[1]), pack_bf16x2(c[2], c[3]), pack_bf16x2(c[4], c[5]), pack_bf16x2(c[6], c[7]));
+                *reinterpret_cast<uint4*>(smem + lw_e + XO + (rho & (SO - 1)) * FB_ROW) = gr;
+            };
+            // weight-gradient products of row r (g stationary: gL row r against the activation rows R(r-1), r, R(r+1))
+            auto wgrad = [&]() __attribute__((always_inline)) {
+                fb_bf16x8 ag[3];     // g1, g2, g3 row r, k-major, pixels outside the kept columns zeroed
+#pragma unroll
+                for (int L = 1; L <= 3; ++L) {
+                    const int base = ring + (L == 3 ? FB_G3 + (r & (FB_S3 - 1)) * FB_ROW : (L == 2 ? FB_G2 + (r & (FB_S2 - 1)) * FB_ROW : FB_G1 + (r & (FB_S1 - 1)) * FB_ROW));
+                    fb_u32x4 raw = __builtin_bit_cast(fb_u32x4, tr_frag(base + ltr));
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) raw[d] &= km[d];
+                    ag[L - 1] = __builtin_bit_cast(fb_bf16x8, raw);
+                }
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const int xs = xring + xslot(rrow(r + u - 1)) * FB_XROW + ltr;
+#pragma unroll
+                    for (int v = 0; v < 3; ++v) {
+                        fb_bf16x8 bx[3];
+#pragma unroll
+                        for (int b = 0; b < 3; ++b) bx[b] = tr_frag_x(xs + 2 * b * FB_CBS + (v - 1) * 16);
+#pragma unroll
+                        for (int b = 0; b < 3; ++b) w3[u][v][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ag[2], bx[b], w3[u][v][b], 0, 0, 0);
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) w2[u][v][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ag[1], bx[b], w2[u][v][b], 0, 0, 0);
+                        w1[u][v] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ag[0], bx[0], w1[u][v], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int L = 0; L < 3; ++L) accb[L] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ag[L], ones, accb[L], 0, 0, 0);   // every column = the sum
+                // first layer: D[o][n] += sum_p g0[o](p) B[p][n], B[p][n] = image(p + tap n) for n < 9, 1 for n = 9 (-> db0): exact fp32
+                const int g0b = ring + FB_G0 + (j >> 3) * FB_CBS + (j & 7) * 2;
+                const int ib = iring + xslot(rrow(r + un - 1)) * FB_IROW + (vn - 1) * 4;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int p = 4 * q + g;
+                    const unsigned short gb = *reinterpret_cast<const unsigned short*>(smem + g0b + p * 16);
+                    const float af = ((kq8 >> q) & 1u) ? __uint_as_float((unsigned)gb << 16) : 0.f;
+                    const float iv = *reinterpret_cast<const float*>(smem_dma + ib + p * 4);
+                    const float bf = j < 9 ? iv : (j == 9 ? 1.f : 0.f);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf, acc0, 0, 0, 0);
+                }
+            };
+
+            load_k(FBI<0>());
+            FB_FENCE();
+            load_k(FBI<1>()); if (on1) mma_k(FBI<0>());
+            FB_FENCE();
+            if (on1) mma_k(FBI<1>());
+            FB_FENCE();
+            if (em1) epilogue(FBI<1>());
+            FB_FENCE();
+            load_k(FBI<2>());      // (layer 2 reads the g2 row the epilogue above just wrote)
+            FB_FENCE();
+            load_k(FBI<3>()); if (on2) mma_k(FBI<2>());
+            FB_FENCE();
+            load_k(FBI<4>()); if (on2) mma_k(FBI<3>());
+            FB_FENCE();
+            if (on2) mma_k(FBI<4>());
+            FB_FENCE();
+            if (em2) epilogue(FBI<2>());
+            FB_FENCE();
+            load_k(FBI<5>());
+            FB_FENCE();
+            load_k(FBI<6>()); if (on3) mma_k(FBI<5>());
+            FB_FENCE();
+            load_k(FBI<7>()); if (on3) mma_k(FBI<6>());
+            FB_FENCE();
+            load_k(FBI<8>()); if (on3) mma_k(FBI<7>());
+            FB_FENCE();
+            load_k(FBI<9>()); if (on3) mma_k(FBI<8>());
+            FB_FENCE();
+            if (on3) mma_k(FBI<9>());
+            FB_FENCE();
+            if (em3) epilogue(FBI<3>());
+            FB_FENCE();
+            if (em3) wgrad();
+            FB_FENCE();
+            // ---- the step's global traffic, in one place: g3 row r + 4 (set of step r + 1) into its ring slot, this set reloaded for step
+            // r + 3, the activation / image rows r + 4 requested
+            {
+                const int ya = r + 4;
+                if (FAST || (ya >= a_lo && ya < a_hi)) *reinterpret_cast<fb_u32x4*>(smem + lw_a + (ya & (FB_S3 - 1)) * FB_ROW) = pg3;
+            }
+            request_g3(r + 5);
+            dma_rows(r + 4);
+            FB_FENCE();
+        };
+#undef FB_FENCE
+
+        // ---- the pipeline: steps r = r_first .. y_hi - 1, phase 0 at r_first.  Prologue: sets 0..2 (steps r_first .. r_first + 2), activation /
+        // image rows r_first - 1 .. r_first + 3, g3 row r_first + 3 into its slot.
+        request_g3(r_first + 3);
+#pragma unroll
+        for (int Lc = 1; Lc <= 3; ++Lc) request_G(Lc, r_first);
+#pragma unroll 1
+        for (int y = max(r_first - 1, 0); y < r_first + 4; ++y)
+            if (y >= 0) dma_rows(y);
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        if (r_first + 3 >= a_lo && r_first + 3 < a_hi) *reinterpret_cast<fb_u32x4*>(smem + lw_a + ((r_first + 3) & (FB_S3 - 1)) * FB_ROW) = pg3;
+        request_g3(r_first + 4);
+        // branch-free steps: every stage active and emitting, no stage at image row 0 / h-1, the g3 row written at the end inside [a_lo, a_hi)
+        const int f_lo = max(max(y_lo, c_lo - 1), 0), f_hi = min(min(y_hi, a_hi - 4), H - 4);
+        int r = r_first;
+#pragma unroll 1
+        for (int part = 0; part < 2; ++part) {
+            const int stop = part == 0 ? min(y_hi, f_lo) : y_hi;
+#pragma unroll 1
+            for (; r < stop; r += 3) {
+                step(FBI<0>(), FBI<0>(), r);
+                step(FBI<1>(), FBI<0>(), r + 1);
+                step(FBI<2>(), FBI<0>(), r + 2);
+            }
+            if (part == 0) {
+#pragma unroll 1
+                for (; r + 2 < f_hi; r += 3) {
+                    step(FBI<0>(), FBI<1>(), r);
+                    step(FBI<1>(), FBI<1>(), r + 1);
+                    step(FBI<2>(), FBI<1>(), r + 2);
+                }
+            }
+        }
+    }
+
+    // ---- block partial: the four waves' accumulators summed in LDS (natural [o][c][u][v] order, enc_wgrad.hpp) -> one coalesced copy
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+    for (int wv = 0; wv < FB_WAVES; ++wv) {
+        if (wave == wv) {
+            auto put = [&](int idx, float v) { red[idx] = wv == 0 ? v : red[idx] + v; };
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+#pragma unroll
+                for (int v = 0; v < 3; ++v) {
+                    const int t = 3 * u + v;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int oc = 4 * g + q;
+#pragma unroll
+                        for (int b = 0; b < 3; ++b) put(EW_OFF3 + (oc * 48 + 16 * b + j) * 9 + t, w3[u][v][b][q]);
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) put(EW_OFF2 + (oc * 32 + 16 * b + j) * 9 + t, w2[u][v][b][q]);
+                        put(EW_OFF1 + (oc * 16 + j) * 9 + t, w1[u][v][q]);
+                    }
+                }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                put(EW_OFF0 + (4 * g + q) * 16 + j, acc0[q]);
+                if (j == 0) {
+#pragma unroll
+                    for (int L = 0; L < 3; ++L) put(EW_OFFB + L * 16 + 4 * g + q, accb[L][q]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float* dst = B.partial + (long long)blockIdx.x * EW_PER;
+    for (int e = tid; e < EW_PER; e += FB_WAVES * 64) dst[e] = red[e];
+}
+
+static void fb_geometry(int n, int h, int w, int nb, int& nstrips, int& nseg, int& seg_rows) {
+    nstrips = w <= FB_W - 2 ? 1 : (w - (FB_W - 2) + FB_KEEP - 1) / FB_KEEP + 1;
+    int ncu = 256;
+    {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+    }
+    long long best = -1;
+    nseg = 1;
+    for (int k = 1; k <= (h + 7) / 8; ++k) {
+        const int rows = (h + k - 1) / k;
+        const long long blocks = (long long)nb * (((long long)n * nstrips * k + FB_WAVES - 1) / FB_WAVES);
+        if (blocks / nb > EW_MAXG / 2) break;        // (block partials of both branches share one workspace of EW_MAXG slots)
+        const long long cost = ((blocks + ncu - 1) / ncu) * (rows + 8);
+        if (best < 0 || cost < best) { best = cost; nseg = k; }
+    }
+    seg_rows = (h + nseg - 1) / nseg;
+    nseg = (h + seg_rows - 1) / seg_rows;
+}
+
+}  // namespace mmif
+
+using namespace mmif;
+
+static int fb_check_branch(const mmif_dense_chain* c, const float* img, float* const* dwdb, const char* which) {
+    MMIF_REQUIRE(c != nullptr && c->g3 != nullptr && c->glow != nullptr && c->x != nullptr && img != nullptr && dwdb != nullptr, "dense_encoder_bwd: %s: NULL argument", which);
+    for (int i = 0; i < 3; ++i) MMIF_REQUIRE(c->packed[i] != nullptr, "dense_encoder_bwd: %s: operand image %d is NULL", which, i);
+    for (int i = 0; i < 8; i += 2) MMIF_REQUIRE(dwdb[i] != nullptr, "dense_encoder_bwd: %s: dW%d is NULL", which, i / 2);
+    if (int rc = validate_tensor(c->g3, "g3")) return rc;
+    if (int rc = validate_tensor(c->glow, "glow")) return rc;
+    if (int rc = validate_tensor(c->x, "x")) return rc;
+    const mmif_tensor *a = c->g3, *b = c->glow, *x = c->x;
+    MMIF_REQUIRE(a->dtype == MMIF_BF16 && b->dtype == MMIF_BF16 && x->dtype == MMIF_BF16, "dense_encoder_bwd: %s: bf16 tensors expected", which);
+    MMIF_REQUIRE(a->cb == 2 && b->cb == 6 && x->cb == 6, "dense_encoder_bwd: %s: views of 2 / 6 / 6 channel blocks expected", which);
+    MMIF_REQUIRE(x->halo == 0 && (a->halo == 0 || (a->flags & MMIF_T_FOLDED)) && (b->halo == 0 || (b->flags & MMIF_T_FOLDED)),
+                 "dense_encoder_bwd: %s: x halo 0, gradients halo 0 or folded", which);
+    MMIF_REQUIRE(a->n == x->n && b->n == x->n && a->h == x->h && b->h == x->h && a->w == x->w && b->w == x->w, "dense_encoder_bwd: %s: shape mismatch", which);
+    MMIF_REQUIRE(x->h >= 4 && x->w >= 4, "dense_encoder_bwd: needs h, w >= 4 (rows / columns 1 and h-2 / w-2 are distinct fold targets)");
+    for (const mmif_tensor* t : {a, b, x})
+        MMIF_REQUIRE((long long)t->cb_total * (t->h + 2 * t->halo) * (t->w + 2 * t->halo) * 16 < (1ll << 31),
+                     "dense_encoder_bwd: %s: one image of every allocation must stay below 2 GiB (32-bit lane offsets, bit 31 = masked)", which);
+    return MMIF_OK;
+}
+
+extern "C" size_t mmif_dense_encoder_bwd_workspace(void) { return (size_t)EW_MAXG * EW_PER * sizeof(float); }
+
+// dwdb_x = {dW0, db0, dW1, db1, dW2, db2, dW3, db3} of the branch's encoder (db may be NULL); accumulate_x: onto what the pointers hold
+// (the second branch of a shared encoder accumulates onto the first's).  chain_x->out is not used (nothing is written but the gradients).
+extern "C" int mmif_dense_encoder_bwd(const mmif_dense_chain* chain_a, const float* img_a, float* const* dwdb_a, int32_t accumulate_a,
+                                      const mmif_dense_chain* chain_b, const float* img_b, float* const* dwdb_b, int32_t accumulate_b,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+    if (int rc = fb_check_branch(chain_a, img_a, dwdb_a, "branch a")) return rc;
+    const int nb = chain_b != nullptr ? 2 : 1;
+    if (nb == 2) {
+        if (int rc = fb_check_branch(chain_b, img_b, dwdb_b, "branch b")) return rc;
+        MMIF_REQUIRE(chain_a->x->n == chain_b->x->n && chain_a->x->h == chain_b->x->h && chain_a->x->w == chain_b->x->w, "dense_encoder_bwd: the two branches differ in shape");
+    }
+    if (workspace == nullptr || workspace_bytes < mmif_dense_encoder_bwd_workspace()) {
+        set_error("dense_encoder_bwd: workspace too small");
+        return MMIF_EWORKSPACE;
+    }
+    BwdArgs A;
+    memset(&A, 0, sizeof(A));
+    A.n = chain_a->x->n; A.h = chain_a->x->h; A.w = chain_a->x->w;
+    fb_geometry(A.n, A.h, A.w, nb, A.nstrips, A.nseg, A.seg_rows);
+    A.items = A.n * A.nseg * A.nstrips;
+    const int G = cdiv(A.items, FB_WAVES);
+    MMIF_REQUIRE(nb * G <= EW_MAXG, "dense_encoder_bwd: too many blocks for the partial-sum workspace");
+    for (int b = 0; b < nb; ++b) {
+        const mmif_dense_chain* c = b ? chain_b : chain_a;
+        BwdBranch& Bb = A.br[b];
+        Bb.g3 = make_tv(c->g3); Bb.glow = make_tv(c->glow); Bb.x = make_tv(c->x);
+        for (int i = 0; i < 3; ++i) Bb.wpk[i] = (const uint4*)c->packed[i];
+        Bb.img = b ? img_b : img_a;
+        Bb.partial = (float*)workspace + (size_t)b * G * EW_PER;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(enc_bwd_fused_kernel, dim3(G, nb), dim3(FB_WAVES * 64), 0, st, A);
+    if (int rc = check_launch("dense_encoder_bwd")) return rc;
+    for (int b = 0; b < nb; ++b) {
+        float* const* d = b ? dwdb_b : dwdb_a;
+        EwDst D;
+        D.dw0 = d[0]; D.db0 = d[1];
+        D.dw[0] = d[2]; D.db[0] = d[3]; D.dw[1] = d[4]; D.db[1] = d[5]; D.dw[2] = d[6]; D.db[2] = d[7];
+        if (int rc = enc_wgrad_reduce_launch(A.br[b].partial, D, G, b ? accumulate_b : accumulate_a, st)) return rc;
+    }
+    return MMIF_OK;
+}

@@ -13,7 +13,7 @@
 //           N = 9 taps + a column of ones = db0) and db1..db3 (bf16 MFMA against ones)
 // No K split between waves -> no cross-wave reduction; per-block partials are reduced in a fixed order by a second kernel
 // (deterministic, no atomics).  ~250 B staged per pixel => HBM-bound; 2 blocks per CU (65 KB LDS each).
-#include "common.hpp"
+#include "enc_wgrad.hpp"
 
 namespace mmif {
 
@@ -29,12 +29,8 @@ constexpr int EW_T = 16, EW_TP = 18;
 constexpr int EW_XPL = 324;     // granules per x plane (18 x 18); 5184 B = 64 mod 256 (as wgrad_mfma_kernel's tiles)
 constexpr int EW_GPL = 260;     // granules per g plane (256 used)
 constexpr int EW_NX = 6, EW_NG = 8;
-// per-block partial (floats): dW3 [16][48][9] | dW2 [16][32][9] | dW1 [16][16][9] | layer 0 [16 oc][16: taps 0..8, db0, 6 unused] | db1..3
-constexpr int EW_OFF3 = 0, EW_OFF2 = 16 * 48 * 9, EW_OFF1 = EW_OFF2 + 16 * 32 * 9, EW_OFF0 = EW_OFF1 + 16 * 16 * 9;
-constexpr int EW_OFFB = EW_OFF0 + 256, EW_PER = EW_OFFB + 48;
 constexpr int EW_TILE_BYTES = (EW_NX * EW_XPL + EW_NG * EW_GPL) * 16 + EW_TP * EW_TP * 4;
 constexpr int EW_SM_BYTES = EW_TILE_BYTES > EW_PER * 4 ? EW_TILE_BYTES : EW_PER * 4;
-constexpr int EW_MAXG = 512;
 #ifndef EW_ABL
 #define EW_ABL 0   // timing ablations (diagnostic builds, -DEW_ABL=n; results WRONG when non-zero): 1 no bf16 product waves, 2 no first-layer /
 #endif             // bias wave, 4 no global prefetch after the first tile (tools/bench_enc.py)
@@ -417,7 +413,6 @@ int wgrad_taprow(const TV& tx, const TV& tg, float* dw, float* db, int cin, int 
     return check_launch("wgrad_taprow_reduce");
 }
 
-struct EwDst { float* dw0; float* db0; float* dw[3]; float* db[3]; };
 
 // 64 outputs x 4 slices of the G partials per block; fixed summation order
 __global__ __launch_bounds__(64 * RED_SLICES) void enc_wgrad_reduce(const float* __restrict__ partial, EwDst D, int G, int accumulate) {
@@ -438,6 +433,11 @@ __global__ __launch_bounds__(64 * RED_SLICES) void enc_wgrad_reduce(const float*
         if (D.db[L] != nullptr) p = D.db[L] + oc;
     }
     if (p != nullptr) *p = accumulate ? *p + t : t;
+}
+
+int enc_wgrad_reduce_launch(const float* partial, const EwDst& D, int G, int accumulate, hipStream_t st) {
+    hipLaunchKernelGGL(enc_wgrad_reduce, dim3(cdiv(EW_PER, 64)), dim3(64 * RED_SLICES), 0, st, partial, D, G, accumulate);
+    return check_launch("enc_wgrad_reduce");
 }
 
 }  // namespace mmif

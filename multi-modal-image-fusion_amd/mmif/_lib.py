@@ -111,6 +111,9 @@ SIGNATURES = {
     "mmif_pack_dense_chain": (_i32, [_vp] * 7),
     "mmif_pack_dense_chain_x3": (_i32, [_vp] * 7),
     "mmif_dense_encoder_chain": (_i32, [C.POINTER(MmifDenseChain), C.POINTER(MmifDenseChain), _vp]),
+    "mmif_dense_encoder_bwd_workspace": (_sz, []),
+    "mmif_dense_encoder_bwd": (_i32, [C.POINTER(MmifDenseChain), _vp, C.POINTER(C.c_void_p), _i32, C.POINTER(MmifDenseChain), _vp, C.POINTER(C.c_void_p), _i32,
+                                      _vp, _sz, _vp]),
     "mmif_dense_encoder_wgrad_workspace": (_sz, []),
     "mmif_dense_encoder_wgrad": (_i32, [_vp, _TP, _TP] + [_vp] * 8 + [_i32, _vp, _sz, _vp]),
     "mmif_act_fwd": (_i32, [_vp, _vp, _i64, _i32, _f32, _vp]),

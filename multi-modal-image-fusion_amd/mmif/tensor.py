@@ -294,6 +294,34 @@ def dense_encoder_chain(branches, tag=None):
         check(lib.mmif_dense_encoder_chain(C.byref(structs[0]), C.byref(structs[1]) if len(structs) > 1 else None, stream_ptr()), "dense_encoder_chain")
 
 
+def dense_encoder_bwd_workspace_bytes():
+    return lib.mmif_dense_encoder_bwd_workspace()
+
+
+def dense_encoder_bwd(branches, ws, tag=None):
+    """The whole backward of ConvLayer(1,16) + DenseBlock(16,16) of one or two branches as ONE streaming launch (csrc/enc_bwd.hip): the
+    gradient chain and all four layers' weight gradients; nothing but dW / db is written.
+    branches: [(g3 2-block view, glow 6-block view, x 6-block view, chain images (pack_dense_chain), img fp32 [n,1,h,w],
+                [(dw0, db0), (dw1, db1), (dw2, db2), (dw3, db3)], accumulate), ...]"""
+    structs, ptrs, keep = [], [], []
+    for g3, glow, x, pk, img, grads, acc in branches:
+        e = _lib.MmifDenseChain()
+        e.g3, e.glow, e.x, e.out = C.pointer(g3._d), C.pointer(glow._d), C.pointer(x._d), None
+        for k in range(3):
+            assert pk[k].fmt == BF16 and (pk[k].cout, pk[k].cin, pk[k].k) == (16 * (3 - k), 16, 3), "pack_dense_chain images expected"
+            e.packed[k] = pk[k].dgrad.data_ptr()
+        arr = (C.c_void_p * 8)(*[t.data_ptr() if t is not None else None for pair in grads for t in pair])
+        structs.append(e)
+        ptrs.append(arr)
+        keep.append((g3, glow, x, img, grads))
+    a, b = 0, (1 if len(structs) > 1 else None)
+    with _timed(tag):
+        check(lib.mmif_dense_encoder_bwd(C.byref(structs[a]), _ptr(branches[a][4]), ptrs[a], int(branches[a][6]),
+                                         C.byref(structs[b]) if b is not None else None, _ptr(branches[b][4]) if b is not None else None,
+                                         ptrs[b] if b is not None else None, int(branches[b][6]) if b is not None else 0,
+                                         _ptr(ws), ws.numel() * ws.element_size(), stream_ptr()), "dense_encoder_bwd")
+
+
 def dense_encoder_wgrad_workspace_bytes():
     return lib.mmif_dense_encoder_wgrad_workspace()
 
