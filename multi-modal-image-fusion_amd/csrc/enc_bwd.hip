@@ -36,18 +36,26 @@ typedef unsigned fb_u32x2 __attribute__((ext_vector_type(2)));
 #define FB_LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
 
 constexpr int FB_W = 32, FB_KEEP = FB_W - 6;
-constexpr int FB_CBS = 512;                    // bytes of one channel block of a ring row (32 px x 16 B)
+constexpr int FB_XCBS = 512;                   // bytes of one channel block of an ACTIVATION ring row (32 px x 16 B)
+// gradient ring rows carry a zero guard granule on either side of their 32 pixels: the chain is a ZERO-padded correlation of the gradient
+// rows (the adjoint of reflect padding is applied to its padded-domain result), so the operand reads of pixel -1 / 32 -- one granule
+// before / after the row -- must be zero where the strip holds the image's padded column (enc_stream2.hip reads its neighbours' bytes
+// there: its border pixels are overwritten by the ghost copy; here they FOLD onto columns 1 / w-2)
+constexpr int FB_CBS = 544;                    // bytes of one channel block of a gradient ring row: [guard][32 px][guard] x 16 B
 constexpr int FB_ROW = 2 * FB_CBS;             // one gradient ring slot: [cb 0][cb 1]
 constexpr int FB_S3 = 4, FB_S2 = 4, FB_S1 = 2; // ring slots of g3 / g2 / g1 (powers of two); g0: one
 constexpr int FB_G3 = 0, FB_G2 = FB_S3 * FB_ROW, FB_G1 = FB_G2 + FB_S2 * FB_ROW, FB_G0 = FB_G1 + FB_S1 * FB_ROW, FB_GRING = FB_G0 + FB_ROW;   // 11264
 constexpr int FB_XS = 6;                       // slots of the activation / image rings (rows r-1 .. r+2 in use, r+3, r+4 in flight)
-constexpr int FB_XROW = 6 * FB_CBS;            // x0 | x1 | x2 row: [6 cb][32 px][16 B]
+constexpr int FB_XROW = 6 * FB_XCBS;           // x0 | x1 | x2 row: [6 cb][32 px][16 B]
 constexpr int FB_IROW = 128;                   // image row: 32 fp32
 constexpr int FB_WAVES = 4;
 constexpr int FB_NFRAG = 30;                   // chain A fragments in LDS: (2 + 3 + 5 k-steps) x 3 tap rows, 1 KB each
 constexpr int FB_WBYTES = FB_NFRAG * 1024;
 constexpr int FB_LDS = FB_WBYTES + FB_WAVES * FB_GRING + 64;
-constexpr int FB_LDS_DMA = FB_WAVES * FB_XS * (FB_XROW + FB_IROW);
+// (64 zero bytes after the activation rings and after the image rings: the operand reads of pixel 32 run one granule past a row, into the
+//  next row / slot / wave -- finite data, multiplied by a zeroed gradient -- and after the LAST row they must not find the fp32 image
+//  ring, whose low halves read as bf16 are arbitrary bit patterns, NaN included)
+constexpr int FB_LDS_DMA = FB_WAVES * FB_XS * (FB_XROW + FB_IROW) + 128;
 constexpr int FB_OPS = 7 + 4;                  // vector-memory operations per step: g3 row + 6 G fragments (registers), 3 x-row DMAs + 1 image DMA
 static_assert(EW_PER * 4 <= FB_LDS, "the block partial is staged in the operand LDS");
 
@@ -93,9 +101,13 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
     for (int e = lane; e < FB_GRING / 16; e += 64) reinterpret_cast<uint4*>(smem + ring)[e] = make_uint4(0u, 0u, 0u, 0u);
     if (wave == FB_WAVES - 1 && lane < 4) reinterpret_cast<uint4*>(smem + FB_WBYTES + FB_WAVES * FB_GRING)[lane] = make_uint4(0u, 0u, 0u, 0u);
     const int xring = wave * (FB_XS * FB_XROW);                                     // byte offsets inside smem_dma
-    const int iring = FB_WAVES * FB_XS * FB_XROW + wave * (FB_XS * FB_IROW);
+    const int iring = FB_WAVES * FB_XS * FB_XROW + 64 + wave * (FB_XS * FB_IROW);
     for (int e = lane; e < FB_XS * FB_XROW / 16; e += 64) reinterpret_cast<uint4*>(smem_dma + xring)[e] = make_uint4(0u, 0u, 0u, 0u);
     for (int e = lane; e < FB_XS * FB_IROW / 16; e += 64) reinterpret_cast<uint4*>(smem_dma + iring)[e] = make_uint4(0u, 0u, 0u, 0u);
+    if (tid < 4) {
+        reinterpret_cast<uint4*>(smem_dma + FB_WAVES * FB_XS * FB_XROW)[tid] = make_uint4(0u, 0u, 0u, 0u);
+        reinterpret_cast<uint4*>(smem_dma + FB_LDS_DMA - 64)[tid] = make_uint4(0u, 0u, 0u, 0u);
+    }
     __syncthreads();
 
     // ---- weight-gradient accumulators (per wave, over its whole strip): w3[u][v][b] = dW3 tile (16 oc x 16 ci of input block b) of tap (u, v)
@@ -133,13 +145,13 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
         // ---- lane constants: chain operands
         const int h2 = g >> 1, cbk = g & 1;
         const int la = g * 256 + j * 16;
-        const int lb4 = ring + cbk * FB_CBS + j * 16 - 16;
-        const int lb2 = ring + cbk * FB_CBS + (j + h2) * 16 - 16;
+        const int lb4 = ring + cbk * FB_CBS + j * 16;                 // (+ 16 guard - 16 for tap column 0)
+        const int lb2 = ring + cbk * FB_CBS + (j + h2) * 16;
         // chain epilogue (after the row swap): this lane holds the granule of pixel 16 (g & 1) + j, channel block g >> 1
         const int px_e = 16 * (g & 1) + j, cb_e = g >> 1;
         const int x_e = r0 + px_e;
         const bool in_e = x_e >= 0 && x_e < W;
-        const int lw_e = ring + cb_e * FB_CBS + px_e * 16;
+        const int lw_e = ring + 16 + cb_e * FB_CBS + px_e * 16;
         const int srcL = (cb_e * 2 + (max(px_e - 2, 0) >> 4)) * 16 + (max(px_e - 2, 0) & 15);
         const int srcR = (cb_e * 2 + (min(px_e + 2, FB_W - 1) >> 4)) * 16 + (min(px_e + 2, FB_W - 1) & 15);
         const bool tgtL = edgeL && x_e == 1, tgtR = edgeR && x_e == W - 2;
@@ -147,7 +159,7 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
         const int px_a = lane & 31, cb_a = lane >> 5;
         const int x_a = r0 + px_a;
         const bool in_a = x_a >= 0 && x_a < W;
-        const int lw_a = ring + FB_G3 + cb_a * FB_CBS + px_a * 16;
+        const int lw_a = ring + FB_G3 + 16 + cb_a * FB_CBS + px_a * 16;
 
         // ---- global operands through buffer descriptors (32-bit lane offsets; bit 31 = beyond the descriptor = reads as zero)
         auto img_base = [&](const TV& t) { return t.base + ((long long)in_ * t.img + (long long)t.cb_off * t.plane) * 16; };
@@ -190,7 +202,8 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
 
         // ---- lane constants: weight-gradient operands (transposing reads: in-group lane sl supplies pixel sl >> 2 (+ 4), 4-channel chunk sl & 3)
         const int tr_row = j >> 2, tr_c = j & 3;
-        const int ltr = (tr_c >> 1) * FB_CBS + (8 * g + tr_row) * 16 + (tr_c & 1) * 8;
+        const int ltr = (tr_c >> 1) * FB_CBS + 16 + (8 * g + tr_row) * 16 + (tr_c & 1) * 8;        // gradient rings
+        const int ltr_x = (tr_c >> 1) * FB_XCBS + (8 * g + tr_row) * 16 + (tr_c & 1) * 8;         // activation ring
         unsigned km[4];          // keep-mask of this lane's 8 pixels 8 g .. 8 g + 7 (two bf16 per dword)
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
@@ -295,7 +308,6 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
                         if (bot) acc[Lc - 1][i2][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[N & 1][0], b, acc[Lc - 1][i2][t], 0, 0, 0);
                     }
                 }
-                if (first) request_G(Lc, r + 1);
             };
             // epilogue of chain layer Lc: out row rho = R - 1 of g(3 - Lc): pair the column tiles, fold the edge columns, ReLU mask, round once
             auto epilogue = [&](auto Lc_) __attribute__((always_inline)) {
@@ -321,7 +333,7 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
                     for (int i = 0; i < 8; ++i) c[i] += (tgtL ? fl[i] : 0.f) + (tgtR ? fr[i] : 0.f);
                 }
                 // mask: x(3 - Lc) row rho from the activation ring (bf16 > 0  <=>  sign clear and magnitude non-zero; columns outside the image: zero)
-                const uint4 xq = *reinterpret_cast<const uint4*>(smem_dma + xring + xslot((int)crow(rho)) * FB_XROW + (2 * (3 - Lc) + cb_e) * FB_CBS + px_e * 16);
+                const uint4 xq = *reinterpret_cast<const uint4*>(smem_dma + xring + xslot((int)crow(rho)) * FB_XROW + (2 * (3 - Lc) + cb_e) * FB_XCBS + px_e * 16);
                 const uint32_t xw[4] = {xq.x, xq.y, xq.z, xq.w};
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -345,12 +357,12 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
                 }
 #pragma unroll
                 for (int u = 0; u < 3; ++u) {
-                    const int xs = xring + xslot(rrow(r + u - 1)) * FB_XROW + ltr;
+                    const int xs = xring + xslot(rrow(r + u - 1)) * FB_XROW + ltr_x;
 #pragma unroll
                     for (int v = 0; v < 3; ++v) {
                         fb_bf16x8 bx[3];
 #pragma unroll
-                        for (int b = 0; b < 3; ++b) bx[b] = tr_frag_x(xs + 2 * b * FB_CBS + (v - 1) * 16);
+                        for (int b = 0; b < 3; ++b) bx[b] = tr_frag_x(xs + 2 * b * FB_XCBS + (v - 1) * 16);
 #pragma unroll
                         for (int b = 0; b < 3; ++b) w3[u][v][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ag[2], bx[b], w3[u][v][b], 0, 0, 0);
 #pragma unroll
@@ -361,7 +373,7 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
 #pragma unroll
                 for (int L = 0; L < 3; ++L) accb[L] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ag[L], ones, accb[L], 0, 0, 0);   // every column = the sum
                 // first layer: D[o][n] += sum_p g0[o](p) B[p][n], B[p][n] = image(p + tap n) for n < 9, 1 for n = 9 (-> db0): exact fp32
-                const int g0b = ring + FB_G0 + (j >> 3) * FB_CBS + (j & 7) * 2;
+                const int g0b = ring + FB_G0 + 16 + (j >> 3) * FB_CBS + (j & 7) * 2;
                 const int ib = iring + xslot(rrow(r + un - 1)) * FB_IROW + (vn - 1) * 4;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
@@ -377,6 +389,7 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
             load_k(FBI<0>());
             FB_FENCE();
             load_k(FBI<1>()); if (on1) mma_k(FBI<0>());
+            request_G(1, r + 1);      // (every step, whether or not the layer ran: the set always holds the NEXT step's rows)
             FB_FENCE();
             if (on1) mma_k(FBI<1>());
             FB_FENCE();
@@ -385,6 +398,7 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
             load_k(FBI<2>());      // (layer 2 reads the g2 row the epilogue above just wrote)
             FB_FENCE();
             load_k(FBI<3>()); if (on2) mma_k(FBI<2>());
+            request_G(2, r + 1);
             FB_FENCE();
             load_k(FBI<4>()); if (on2) mma_k(FBI<3>());
             FB_FENCE();
@@ -395,6 +409,7 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
             load_k(FBI<5>());
             FB_FENCE();
             load_k(FBI<6>()); if (on3) mma_k(FBI<5>());
+            request_G(3, r + 1);
             FB_FENCE();
             load_k(FBI<7>()); if (on3) mma_k(FBI<6>());
             FB_FENCE();

@@ -298,7 +298,7 @@ class ModelEngine:
             else:
                 need = max(need, T.wgrad_workspace_bytes(s.cin, s.cout, s.k))
         if isinstance(self, DenseEncoderMixin):
-            need = max(need, T.dense_encoder_wgrad_workspace_bytes())
+            need = max(need, T.dense_encoder_wgrad_workspace_bytes(), T.dense_encoder_bwd_workspace_bytes())
         if self._ws is None or self._ws.device != device or self._ws.numel() * 4 < need:
             self._ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=device)
         return self._ws
@@ -570,6 +570,23 @@ class DenseEncoderMixin:
                 and F.h >= 4 and F.w >= 4 and switch("MMIF_ENC_CHAIN") and switch("MMIF_ENC_CHAIN_STREAM"))
 
     @staticmethod
+    def bwd_fused(branches, F, ws, impl):
+        """branches: [(specs, img, fbase, g3 2-block view, glow 6-block view, accumulate), (...)] -- the WHOLE backward of the encoder branches
+        (gradient chain + the four layers' weight gradients) as ONE streaming launch (csrc/enc_bwd.hip, round 5; $MMIF_ENC_BWD_FUSED=0: the
+        chain and weight-gradient launches of rounds 2 / 4).  Returns False when the kernel does not apply (the caller takes the other path)."""
+        if not (switch("MMIF_ENC_BWD_FUSED") and switch("MMIF_ENC_CHAIN") and switch("MMIF_ENC_CHAIN_STREAM") and switch("MMIF_ENC_WGRAD")
+                and F.dtype == torch.bfloat16 and impl != _lib.IMPL_VALU and F.h >= 4 and F.w >= 4 and F.halo == 0
+                and all(all(s.k == 3 for s in specs) and [(s.cin, s.cout) for s in specs] == [(1, 16), (16, 16), (32, 16), (48, 16)]
+                        for specs, *_ in branches)):
+            return False
+        args = []
+        for specs, img, fbase, g3, glow, acc in branches:
+            pk = DenseEncoderMixin.chain_images(specs, _lib.BF16)
+            args.append((g3, glow, F.view(fbase, 6), pk, img, [(s.dw, s.db) for s in specs], acc))
+        T.dense_encoder_bwd(args, ws, tag="encode:bwd")
+        return True
+
+    @staticmethod
     def chain_all(branches, F, GF, impl):
         """branches: [(specs, fbase, gbase, onto), (...)] -- the backward chains of BOTH encoder branches as ONE streaming launch; returns
         their [g0 | g1 | g2 | g3] views for enc_bwd(gz=...), or None per branch when the streaming kernel does not apply"""
@@ -717,6 +734,9 @@ class PFNetv1Engine(ModelEngine, DenseEncoderMixin):
         return grads
 
     def enc_bwd_all(self, img1, img2, F, g, ws, impl):
+        gf = g.as_folded()
+        if self.bwd_fused([(self.enc[0], img1, 0, gf.view(6, 2), gf.view(0, 6), False), (self.enc[1], img2, 8, gf.view(14, 2), gf.view(8, 6), False)], F, ws, impl):
+            return
         gz = self.chain_all([(self.enc[0], 0, 0, None), (self.enc[1], 8, 8, None)], F, g, impl)
         self.enc_bwd(self.enc[0], img1, F, g, 0, 0, ws, impl, gz=gz[0])
         self.enc_bwd(self.enc[1], img2, F, g, 8, 8, ws, impl, gz=gz[1])
@@ -736,6 +756,9 @@ class VIFNetEngine(PFNetv1Engine):
         ModelEngine.__init__(self, module, shared + self.dec)
 
     def enc_bwd_all(self, img1, img2, F, g, ws, impl):
+        gf = g.as_folded()
+        if self.bwd_fused([(self.enc[0], img1, 0, gf.view(6, 2), gf.view(0, 6), False), (self.enc[1], img2, 8, gf.view(14, 2), gf.view(8, 6), True)], F, ws, impl):
+            return
         gz = self.chain_all([(self.enc[0], 0, 0, None), (self.enc[1], 8, 8, None)], F, g, impl)
         self.enc_bwd(self.enc[0], img1, F, g, 0, 0, ws, impl, accumulate_w=False, gz=gz[0])
         self.enc_bwd(self.enc[1], img2, F, g, 8, 8, ws, impl, accumulate_w=True, gz=gz[1])
@@ -824,7 +847,9 @@ class DenseFuseEngine(ModelEngine, DenseEncoderMixin):
 
     def _encoder_backward(self, L, F, g, ws, impl, dtype, dev, n, h, w, single, img1, img2, grads):
         if single:
-            self.enc_bwd(self.enc, img1, F, g, 0, 0, ws, impl)
+            gf = g.as_folded()
+            if not self.bwd_fused([(self.enc, img1, 0, gf.view(6, 2), gf.view(0, 6), False)], F, ws, impl):
+                self.enc_bwd(self.enc, img1, F, g, 0, 0, ws, impl)
             return grads
         # fusion backward: d(f1+f2) -> each encoder's own gradient buffer (they diverge below);
         # ReLU mask only on the DenseBlock's last conv output (blocks 6,7), the rest are masked by
@@ -834,11 +859,17 @@ class DenseFuseEngine(ModelEngine, DenseEncoderMixin):
             # 'sum' fusion: d(f1 + f2) IS each branch's gradient.  Only the masked top blocks (6,7 / 14,15) are materialised per branch;
             # the chain reads the lower blocks' starting values straight from g ($MMIF_FUSE_SHARE=0: copy them per branch first)
             T.fuse_elem_bwd(F.view(6, 2), F.view(14, 2), g.view(6, 2), GF.view(6, 2), GF.view(14, 2), self.fusion_mode, True)
+            gff = GF.as_folded()
+            if self.bwd_fused([(self.enc, img1, 0, gff.view(6, 2), g.view(0, 6), False), (self.enc, img2, 8, gff.view(14, 2), g.view(0, 6), True)], F, ws, impl):
+                return grads
             gz = self.chain_all([(self.enc, 0, 0, g), (self.enc, 8, 8, g)], F, GF, impl)
             self.enc_bwd(self.enc, img1, F, GF, 0, 0, ws, impl, accumulate_w=False, onto=g, gz=gz[0])
             self.enc_bwd(self.enc, img2, F, GF, 8, 8, ws, impl, accumulate_w=True, onto=g, gz=gz[1])
             return grads
         self.fusion_bwd(L, F, g, GF, ws)
+        gff = GF.as_folded()
+        if self.bwd_fused([(self.enc, img1, 0, gff.view(6, 2), gff.view(0, 6), False), (self.enc, img2, 8, gff.view(14, 2), gff.view(8, 6), True)], F, ws, impl):
+            return grads
         gz = self.chain_all([(self.enc, 0, 0, None), (self.enc, 8, 8, None)], F, GF, impl)
         self.enc_bwd(self.enc, img1, F, GF, 0, 0, ws, impl, accumulate_w=False, gz=gz[0])
         self.enc_bwd(self.enc, img2, F, GF, 8, 8, ws, impl, accumulate_w=True, gz=gz[1])

@@ -121,6 +121,48 @@ def test_fused_backward_two_branches_accumulate_and_split_gradient_tensors():
         close(db.cpu().numpy(), rb_.cpu().numpy(), 2e-3, f"db{L}")
 
 
+@pytest.mark.parametrize("name,single", [("PFNetv1", False), ("VIFNet", False), ("DenseFuse", False), ("DenseFuse", True), ("PFNetv2", False)])
+def test_models_with_the_fused_encoder_backward_match_the_two_kernel_path(name, single):
+    """every engine that owns a DenseBlock encoder, one backward with the fused kernel ($MMIF_ENC_BWD_FUSED, the default) and with the
+    chain + weight-gradient launches it replaces: identical fused image (the forward is the same), every parameter gradient within the
+    summation-order noise of the encoder's weight gradients (the decoder's are bit-identical: nothing upstream of them changed)"""
+    import os
+    import core.model as M
+    from mmif import engine as E
+    from mmif import tensor as T
+    from gpu_util import dtype_ctx
+    with dtype_ctx("bf16"):
+        torch.manual_seed(7)
+        m = getattr(M, name)().to(DEV)
+        g = torch.Generator().manual_seed(3)
+        i1, i2 = torch.rand(2, 1, 40, 56, generator=g).to(DEV), torch.rand(2, 1, 40, 56, generator=g).to(DEV)
+        res = []
+        for on in ("0", "1"):
+            os.environ["MMIF_ENC_BWD_FUSED"] = on
+            E.reload_switches()
+            try:
+                T.PROFILE_TAGS.add("encode:bwd")
+                T.PROFILE_EVENTS.pop("encode:bwd", None)
+                m.zero_grad(set_to_none=True)
+                y = m(i1) if single else m(i1, i2)
+                (y * y).mean().backward()
+                torch.cuda.synchronize()
+                res.append((y.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters()}, len(T.PROFILE_EVENTS.get("encode:bwd", []))))
+            finally:
+                os.environ.pop("MMIF_ENC_BWD_FUSED")
+                E.reload_switches()
+                T.PROFILE_TAGS.discard("encode:bwd")
+        assert res[0][2] == 0 and res[1][2] == 1, "the fused launch must run exactly when enabled"
+        assert torch.equal(res[0][0], res[1][0])
+        for k in res[0][1]:
+            a, b = res[0][1][k].double(), res[1][1][k].double()
+            assert float(a.abs().max()) > 0, k
+            if "encode" in k:
+                assert float((a - b).abs().max()) <= 2e-3 * float(a.abs().max()), (name, single, k, float((a - b).abs().max()) / float(a.abs().max()))
+            else:
+                assert torch.equal(a, b), (name, single, k)
+
+
 def test_fused_backward_argument_validation():
     import ctypes as C
     from mmif import _lib
