@@ -30,6 +30,8 @@ namespace mmif {
 typedef __attribute__((ext_vector_type(8))) __bf16 fb_bf16x8;
 typedef __attribute__((ext_vector_type(4))) float fb_f32x4;
 typedef __attribute__((ext_vector_type(4))) short fb_s16x4;
+typedef __attribute__((ext_vector_type(2))) short fb_s16x2;
+typedef __attribute__((ext_vector_type(2))) unsigned short fb_u16x2;
 typedef __attribute__((ext_vector_type(8))) short fb_s16x8;
 typedef unsigned fb_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned fb_u32x2 __attribute__((ext_vector_type(2)));
@@ -43,21 +45,24 @@ constexpr int FB_XCBS = 512;                   // bytes of one channel block of 
 // there: its border pixels are overwritten by the ghost copy; here they FOLD onto columns 1 / w-2)
 constexpr int FB_CBS = 544;                    // bytes of one channel block of a gradient ring row: [guard][32 px][guard] x 16 B
 constexpr int FB_ROW = 2 * FB_CBS;             // one gradient ring slot: [cb 0][cb 1]
-constexpr int FB_S3 = 4, FB_S2 = 4, FB_S1 = 2; // ring slots of g3 / g2 / g1 (powers of two); g0: one
-constexpr int FB_G3 = 0, FB_G2 = FB_S3 * FB_ROW, FB_G1 = FB_G2 + FB_S2 * FB_ROW, FB_G0 = FB_G1 + FB_S1 * FB_ROW, FB_GRING = FB_G0 + FB_ROW;   // 11264
-constexpr int FB_XS = 6;                       // slots of the activation / image rings (rows r-1 .. r+2 in use, r+3, r+4 in flight)
+constexpr int FB_S3 = 4, FB_S2 = 4, FB_S1 = 2, FB_S0 = 2;   // ring slots of g3 / g2 / g1 / g0 (powers of two)
+constexpr int FB_G3 = 0, FB_G2 = FB_S3 * FB_ROW, FB_G1 = FB_G2 + FB_S2 * FB_ROW, FB_G0 = FB_G1 + FB_S1 * FB_ROW, FB_GRING = FB_G0 + FB_S0 * FB_ROW;   // 13056
+constexpr int FB_XS = 6;                       // slots of the activation ring (rows r-1 .. r+3 in use, r+4 in flight)
+constexpr int FB_IS = 8;                       // slots of the image ring (rows r-3 .. r+3 in use: the first layer's products trail by two rows)
 constexpr int FB_XROW = 6 * FB_XCBS;           // x0 | x1 | x2 row: [6 cb][32 px][16 B]
 constexpr int FB_IROW = 128;                   // image row: 32 fp32
-constexpr int FB_WAVES = 4;
+constexpr int FB_PAIRS = 4;                    // wave pairs per block: waves 0..3 run the chain (role A), waves 4..7 the weight gradients (B);
+constexpr int FB_WAVES = 2 * FB_PAIRS;         // wave p and wave p + 4 share SIMD p and one strip
 constexpr int FB_NFRAG = 30;                   // chain A fragments in LDS: (2 + 3 + 5 k-steps) x 3 tap rows, 1 KB each
 constexpr int FB_WBYTES = FB_NFRAG * 1024;
-constexpr int FB_LDS = FB_WBYTES + FB_WAVES * FB_GRING + 64;
+constexpr int FB_LDS = FB_WBYTES + FB_PAIRS * FB_GRING + 64;
 // (64 zero bytes after the activation rings and after the image rings: the operand reads of pixel 32 run one granule past a row, into the
 //  next row / slot / wave -- finite data, multiplied by a zeroed gradient -- and after the LAST row they must not find the fp32 image
 //  ring, whose low halves read as bf16 are arbitrary bit patterns, NaN included)
-constexpr int FB_LDS_DMA = FB_WAVES * FB_XS * (FB_XROW + FB_IROW) + 128;
+constexpr int FB_LDS_DMA = FB_PAIRS * (FB_XS * FB_XROW + FB_IS * FB_IROW) + 128;
 constexpr int FB_OPS = 7 + 4;                  // vector-memory operations per step: g3 row + 6 G fragments (registers), 3 x-row DMAs + 1 image DMA
 static_assert(EW_PER * 4 <= FB_LDS, "the block partial is staged in the operand LDS");
+static_assert(FB_LDS + FB_LDS_DMA <= 160 * 1024, "LDS budget of one CU");
 
 struct BwdBranch {
     TV g3, glow, x;            // 2-block gradient view, 6-block view G0 | G1 | G2, 6-block view x0 | x1 | x2 (halo 0)
@@ -74,6 +79,17 @@ struct BwdArgs {
 
 template <int N> struct FBI { static constexpr int value = N; };
 
+#define FB_FENCE() __builtin_amdgcn_sched_barrier(0)
+// the pair's (and the block's) step barrier: LDS traffic of this wave retired, then s_barrier.  Inline asm with a memory clobber: the
+// compiler keeps memory accesses on their side of it, and -- unlike __syncthreads() -- does not drain the vector-memory counter (the
+// chain waves always have two steps of requests in flight)
+#define FB_STEP_BARRIER() __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+// compile-time ablations (tools/build_ab_encbwd.sh; TIMING ONLY, results are wrong): 1 no weight-gradient products (role B idle, no w1),
+// 2 no chain MFMAs, 4 no epilogues, 8 no global requests / LDS-DMA in the steps, 16 no first-layer products, 32 no chain operand reads
+#ifndef FB_ABL
+#define FB_ABL 0
+#endif
+
 __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs A) {
     __shared__ __attribute__((aligned(16))) char smem[FB_LDS];
     // written by LDS-DMA only (inline asm: the compiler must not know, it would order every LDS access of the wave behind the pending
@@ -82,6 +98,7 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
     const BwdBranch& B = A.br[blockIdx.y];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pair = wave & (FB_PAIRS - 1), role = wave / FB_PAIRS;
     const int j = lane & 15, g = lane >> 4;
 
     // ---- chain A fragments (tap-row major K order, csrc/enc_stream2.hip): virtual layer 1 = dst x2 (input g3), 2 = dst x1 ([g2 | g3]),
@@ -97,51 +114,187 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
         const int u = f % 3, kq = f / 3;
         reinterpret_cast<uint4*>(smem)[e] = B.wpk[kq < 2 ? 2 : (kq < 5 ? 1 : 0)][a_plane(kq, u, kg) * 16 + oc];
     }
-    const int ring = FB_WBYTES + wave * FB_GRING;
-    for (int e = lane; e < FB_GRING / 16; e += 64) reinterpret_cast<uint4*>(smem + ring)[e] = make_uint4(0u, 0u, 0u, 0u);
-    if (wave == FB_WAVES - 1 && lane < 4) reinterpret_cast<uint4*>(smem + FB_WBYTES + FB_WAVES * FB_GRING)[lane] = make_uint4(0u, 0u, 0u, 0u);
-    const int xring = wave * (FB_XS * FB_XROW);                                     // byte offsets inside smem_dma
-    const int iring = FB_WAVES * FB_XS * FB_XROW + 64 + wave * (FB_XS * FB_IROW);
-    for (int e = lane; e < FB_XS * FB_XROW / 16; e += 64) reinterpret_cast<uint4*>(smem_dma + xring)[e] = make_uint4(0u, 0u, 0u, 0u);
-    for (int e = lane; e < FB_XS * FB_IROW / 16; e += 64) reinterpret_cast<uint4*>(smem_dma + iring)[e] = make_uint4(0u, 0u, 0u, 0u);
+    const int ring = FB_WBYTES + pair * FB_GRING;
+    const int xring = pair * (FB_XS * FB_XROW);                                     // byte offsets inside smem_dma
+    const int iring = FB_PAIRS * FB_XS * FB_XROW + 64 + pair * (FB_IS * FB_IROW);
+    if (role == 0) {
+        for (int e = lane; e < FB_GRING / 16; e += 64) reinterpret_cast<uint4*>(smem + ring)[e] = make_uint4(0u, 0u, 0u, 0u);
+    } else {
+        for (int e = lane; e < FB_XS * FB_XROW / 16; e += 64) reinterpret_cast<uint4*>(smem_dma + xring)[e] = make_uint4(0u, 0u, 0u, 0u);
+        for (int e = lane; e < FB_IS * FB_IROW / 16; e += 64) reinterpret_cast<uint4*>(smem_dma + iring)[e] = make_uint4(0u, 0u, 0u, 0u);
+    }
     if (tid < 4) {
-        reinterpret_cast<uint4*>(smem_dma + FB_WAVES * FB_XS * FB_XROW)[tid] = make_uint4(0u, 0u, 0u, 0u);
+        reinterpret_cast<uint4*>(smem + FB_WBYTES + FB_PAIRS * FB_GRING)[tid] = make_uint4(0u, 0u, 0u, 0u);
+        reinterpret_cast<uint4*>(smem_dma + FB_PAIRS * FB_XS * FB_XROW)[tid] = make_uint4(0u, 0u, 0u, 0u);
         reinterpret_cast<uint4*>(smem_dma + FB_LDS_DMA - 64)[tid] = make_uint4(0u, 0u, 0u, 0u);
     }
     __syncthreads();
 
-    // ---- weight-gradient accumulators (per wave, over its whole strip): w3[u][v][b] = dW3 tile (16 oc x 16 ci of input block b) of tap (u, v)
-    fb_f32x4 w3[3][3][3], w2[3][3][2], w1[3][3], accb[3], acc0;
-#pragma unroll
-    for (int u = 0; u < 3; ++u)
-#pragma unroll
-        for (int v = 0; v < 3; ++v) {
-            w1[u][v] = (fb_f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int b = 0; b < 3; ++b) w3[u][v][b] = (fb_f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int b = 0; b < 2; ++b) w2[u][v][b] = (fb_f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) accb[i] = (fb_f32x4){0.f, 0.f, 0.f, 0.f};
-    acc0 = (fb_f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int item = blockIdx.x * FB_WAVES + wave;
+    const int item = blockIdx.x * FB_PAIRS + pair;
     const int H = A.h, W = A.w;
     const int strip = item % A.nstrips;
     const int seg = (item / A.nstrips) % A.nseg;
     const int in_ = min(item / (A.nstrips * A.nseg), A.n - 1);
     const int y_lo = seg * A.seg_rows, y_hi = min(H, y_lo + A.seg_rows);
-    if (item < A.items && y_lo < y_hi) {
-        // ---- strip geometry (csrc/enc_chain.hip): region [r0, r0 + 32) of image columns, r0 = -1 for the first strip (column -1 and column w
-        // belong to the edge strips, which fold them onto columns 1 / w-2); kept columns [o_lo, o_hi)
-        auto strip_r0 = [&](int s) { return A.nstrips == 1 ? -1 : min(-1 + FB_KEEP * s, W - (FB_W - 1)); };
-        auto strip_hi = [&](int r) { return (r + FB_W >= W + 1) ? W : min(r + FB_W - 3, W - 4); };
-        const int r0 = strip_r0(strip);
-        const int o_hi = strip_hi(r0);
-        const int o_lo = strip == 0 ? 0 : max(r0 + 3, strip_hi(strip_r0(strip - 1)));
-        const bool edgeL = r0 < 0, edgeR = r0 + FB_W >= W + 1;
+    const bool valid = item < A.items && y_lo < y_hi;
+    // every wave of the block runs the same number of steps (one barrier each): rows r_first .. y_hi + 1 of the longest segment
+    const int NSTEP = 3 * ((A.seg_rows + 8 + 2) / 3);
 
+    // ---- strip geometry (csrc/enc_chain.hip): region [r0, r0 + 32) of image columns, r0 = -1 for the first strip (column -1 and column w
+    // belong to the edge strips, which fold them onto columns 1 / w-2); kept columns [o_lo, o_hi)
+    auto strip_r0 = [&](int s) { return A.nstrips == 1 ? -1 : min(-1 + FB_KEEP * s, W - (FB_W - 1)); };
+    auto strip_hi = [&](int r) { return (r + FB_W >= W + 1) ? W : min(r + FB_W - 3, W - 4); };
+    const int r0 = strip_r0(strip);
+    const int o_hi = strip_hi(r0);
+    const int o_lo = strip == 0 ? 0 : max(r0 + 3, strip_hi(strip_r0(strip - 1)));
+    // rows each stage touches (as csrc/enc_chain.hip): g3 rows [a_lo, a_hi), g2 rows [b_lo, b_hi), g1 rows [c_lo, c_hi), g0 rows [y_lo, y_hi)
+    const int a_lo = max(0, y_lo - 3), a_hi = min(H, y_hi + 3);
+    const int b_lo = max(0, y_lo - 2), b_hi = min(H, y_hi + 2);
+    const int c_lo = max(0, y_lo - 1), c_hi = min(H, y_hi + 1);
+    const int r_first = a_lo - 3;
+
+    // ---- lane constants of the transposing reads (weight-gradient operands: in-group lane sl supplies pixel sl >> 2 (+ 4), 4-channel chunk sl & 3)
+    const int tr_row = j >> 2, tr_c = j & 3;
+    const int ltr = (tr_c >> 1) * FB_CBS + 16 + (8 * g + tr_row) * 16 + (tr_c & 1) * 8;        // gradient rings
+    const int ltr_x = (tr_c >> 1) * FB_XCBS + (8 * g + tr_row) * 16 + (tr_c & 1) * 8;         // activation ring
+    unsigned km[4];          // keep-mask of this lane's 8 pixels 8 g .. 8 g + 7 (two bf16 per dword)
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const int c0 = r0 + 8 * g + 2 * d, c1 = c0 + 1;
+        km[d] = ((c0 >= o_lo && c0 < o_hi) ? 0xffffu : 0u) | ((c1 >= o_lo && c1 < o_hi) ? 0xffff0000u : 0u);
+    }
+    auto tr_frag = [&](int addr) __attribute__((always_inline)) {
+        const fb_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(FB_LDS_PTR(fb_s16x4, smem + addr));
+        const fb_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(FB_LDS_PTR(fb_s16x4, smem + addr + 64));
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    auto tr_frag_x = [&](int addr) __attribute__((always_inline)) {
+        const fb_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(FB_LDS_PTR(fb_s16x4, smem_dma + addr));
+        const fb_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(FB_LDS_PTR(fb_s16x4, smem_dma + addr + 64));
+        return __builtin_bit_cast(fb_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    auto masked_g = [&](int addr) __attribute__((always_inline)) {      // one gradient row, k-major, pixels outside the kept columns zeroed
+        fb_u32x4 raw = __builtin_bit_cast(fb_u32x4, tr_frag(addr + ltr));
+#pragma unroll
+        for (int d = 0; d < 4; ++d) raw[d] &= km[d];
+        return __builtin_bit_cast(fb_bf16x8, raw);
+    };
+    auto crow = [&](int y) { return (unsigned)min(max(y, 0), H - 1); };
+    auto rrow = [&](int y) { return min(max(reflect_idx(y, H), 0), H - 1); };
+    auto xslot = [&](int y) { return (int)((unsigned)y % (unsigned)FB_XS); };      // (y >= 0)
+    const fb_bf16x8 ones = __builtin_bit_cast(fb_bf16x8, make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u));
+
+    // ---- block partial (after the steps): the pairs' accumulators summed in LDS (natural [o][c][u][v] order, enc_wgrad.hpp) -> one
+    // coalesced copy.  Both roles call it with their own accumulators (same number of barriers)
+    auto block_partial = [&](auto&& puts) __attribute__((always_inline)) {
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);
+        for (int wv = 0; wv < FB_PAIRS; ++wv) {
+            if (pair == wv) puts([&](int idx, float v) { red[idx] = wv == 0 ? v : red[idx] + v; });
+            __syncthreads();
+        }
+        float* dst = B.partial + (long long)blockIdx.x * EW_PER;
+        for (int e = tid; e < EW_PER; e += FB_WAVES * 64) dst[e] = red[e];
+    };
+    const fb_f32x4 zero4 = (fb_f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (role == 1) {
+        // ================= role B: dW3, dW2, db3, db2 of row r = g3 / g2 row r (final since step r - 2) against the activation rows
+        // R(r-1), r, R(r+1): nine chunks of one tap (u, v), operands double-buffered
+        fb_f32x4 w3[3][3][3], w2[3][3][2], accb[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+#pragma unroll
+            for (int v = 0; v < 3; ++v) {
+#pragma unroll
+                for (int b = 0; b < 3; ++b) w3[u][v][b] = zero4;
+#pragma unroll
+                for (int b = 0; b < 2; ++b) w2[u][v][b] = zero4;
+            }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) accb[i] = zero4;
+#pragma unroll 1
+        for (int s = 0; s < NSTEP; ++s) {
+            const int r = r_first + s;
+            if (!(FB_ABL & 1) && valid && r >= y_lo && r < y_hi) {
+                fb_bf16x8 ag2 = masked_g(ring + FB_G2 + (r & (FB_S2 - 1)) * FB_ROW), ag3 = masked_g(ring + FB_G3 + (r & (FB_S3 - 1)) * FB_ROW);
+                int xs3[3];
+#pragma unroll
+                for (int u = 0; u < 3; ++u) xs3[u] = xring + xslot(rrow(r + u - 1)) * FB_XROW + ltr_x;
+                fb_bf16x8 bx[2][3];
+                auto wg_load = [&](auto Cc) __attribute__((always_inline)) {
+                    constexpr int C = decltype(Cc)::value, u = C / 3, v = C % 3;
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) bx[C & 1][b] = tr_frag_x(xs3[u] + 2 * b * FB_XCBS + (v - 1) * 16);
+                };
+                auto wg_mma = [&](auto Cc) __attribute__((always_inline)) {
+                    constexpr int C = decltype(Cc)::value, u = C / 3, v = C % 3;
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) w3[u][v][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ag3, bx[C & 1][b], w3[u][v][b], 0, 0, 0);
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) w2[u][v][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ag2, bx[C & 1][b], w2[u][v][b], 0, 0, 0);
+                };
+                wg_load(FBI<0>());
+                FB_FENCE();
+                wg_load(FBI<1>()); wg_mma(FBI<0>());
+                FB_FENCE();
+                wg_load(FBI<2>()); wg_mma(FBI<1>());
+                FB_FENCE();
+                wg_load(FBI<3>()); wg_mma(FBI<2>());
+                FB_FENCE();
+                wg_load(FBI<4>()); wg_mma(FBI<3>());
+                FB_FENCE();
+                wg_load(FBI<5>()); wg_mma(FBI<4>());
+                FB_FENCE();
+                wg_load(FBI<6>()); wg_mma(FBI<5>());
+                FB_FENCE();
+                wg_load(FBI<7>()); wg_mma(FBI<6>());
+                FB_FENCE();
+                wg_load(FBI<8>()); wg_mma(FBI<7>());
+                FB_FENCE();
+                wg_mma(FBI<8>());
+                accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ag2, ones, accb[1], 0, 0, 0);   // every column = the sum
+                accb[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ag3, ones, accb[2], 0, 0, 0);
+                FB_FENCE();
+            }
+            FB_STEP_BARRIER();
+        }
+        block_partial([&](auto put) {
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+#pragma unroll
+                for (int v = 0; v < 3; ++v) {
+                    const int t = 3 * u + v;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int oc = 4 * g + q;
+#pragma unroll
+                        for (int b = 0; b < 3; ++b) put(EW_OFF3 + (oc * 48 + 16 * b + j) * 9 + t, w3[u][v][b][q]);
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) put(EW_OFF2 + (oc * 32 + 16 * b + j) * 9 + t, w2[u][v][b][q]);
+                    }
+                }
+            if (j == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int L = 1; L < 3; ++L) put(EW_OFFB + L * 16 + 4 * g + q, accb[L][q]);
+            }
+        });
+    } else {
+        // ================= role A: the gradient chain, dW1 / db1 and the first layer's gradients
+        fb_f32x4 w1[3][3], accb[1], acc0 = zero4;
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+#pragma unroll
+            for (int v = 0; v < 3; ++v) w1[u][v] = zero4;
+        accb[0] = zero4;
+        if (!valid) {
+#pragma unroll 1
+            for (int s = 0; s < NSTEP; ++s) FB_STEP_BARRIER();
+        } else {
+        const bool edgeL = r0 < 0, edgeR = r0 + FB_W >= W + 1;
         // ---- lane constants: chain operands
         const int h2 = g >> 1, cbk = g & 1;
         const int la = g * 256 + j * 16;
@@ -152,6 +305,7 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
         const int x_e = r0 + px_e;
         const bool in_e = x_e >= 0 && x_e < W;
         const int lw_e = ring + 16 + cb_e * FB_CBS + px_e * 16;
+        const uint32_t inm_e = in_e ? 0xffffffffu : 0u;
         const int srcL = (cb_e * 2 + (max(px_e - 2, 0) >> 4)) * 16 + (max(px_e - 2, 0) & 15);
         const int srcR = (cb_e * 2 + (min(px_e + 2, FB_W - 1) >> 4)) * 16 + (min(px_e + 2, FB_W - 1) & 15);
         const bool tgtL = edgeL && x_e == 1, tgtR = edgeR && x_e == W - 2;
@@ -175,8 +329,6 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
             const int c = r0 + 16 * t + j;
             gl_off[t] = (c >= 0 && c < W) ? (unsigned)(g >> 1) * gl_plane + (unsigned)c * 16u + (unsigned)(g & 1) * 8u + gl_org : 0x80000000u;
         }
-        auto crow = [&](int y) { return (unsigned)min(max(y, 0), H - 1); };
-        auto rrow = [&](int y) { return min(max(reflect_idx(y, H), 0), H - 1); };
         // activation / image rows by LDS-DMA: ring pixel p = image column reflect(r0 + p) (the edge strips' ghost pixels hold the reflected column)
         const char* x_img = img_base(B.x);
         const char* im_img = reinterpret_cast<const char*>(B.img + (long long)in_ * H * W);
@@ -190,61 +342,30 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
         auto dma4 = [&](const char* gsrc, unsigned lds_dst) __attribute__((always_inline)) {
             __asm__ volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" : : "s"(lds_dst), "v"(gsrc) : "memory", "m0");
         };
-        auto xslot = [&](int y) { return (int)((unsigned)y % (unsigned)FB_XS); };      // (y >= 0)
         auto dma_rows = [&](int y) __attribute__((always_inline)) {   // x0 | x1 | x2 row (3 x 1 KiB) + image row of image row clamp(y)
-            const int yy = (int)crow(y), sl_ = xslot(yy);
+            const int yy = (int)crow(y);
             const char* src = x_img + (unsigned long long)((unsigned)yy * x_rowb);
-            const unsigned dst = xring_lds + (unsigned)(sl_ * FB_XROW);
+            const unsigned dst = xring_lds + (unsigned)(xslot(yy) * FB_XROW);
 #pragma unroll
             for (int i = 0; i < 3; ++i) dma16(src + (unsigned long long)(xdma_off + (unsigned)(2 * i) * x_plane), dst + (unsigned)i * 1024u);
-            if (lane < 32) dma4(im_img + ((long long)yy * W + cdma) * 4, iring_lds + (unsigned)(sl_ * FB_IROW));
+            if (lane < 32) dma4(im_img + ((long long)yy * W + cdma) * 4, iring_lds + (unsigned)((yy & (FB_IS - 1)) * FB_IROW));
         };
-
-        // ---- lane constants: weight-gradient operands (transposing reads: in-group lane sl supplies pixel sl >> 2 (+ 4), 4-channel chunk sl & 3)
-        const int tr_row = j >> 2, tr_c = j & 3;
-        const int ltr = (tr_c >> 1) * FB_CBS + 16 + (8 * g + tr_row) * 16 + (tr_c & 1) * 8;        // gradient rings
-        const int ltr_x = (tr_c >> 1) * FB_XCBS + (8 * g + tr_row) * 16 + (tr_c & 1) * 8;         // activation ring
-        unsigned km[4];          // keep-mask of this lane's 8 pixels 8 g .. 8 g + 7 (two bf16 per dword)
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            const int c0 = r0 + 8 * g + 2 * d, c1 = c0 + 1;
-            km[d] = ((c0 >= o_lo && c0 < o_hi) ? 0xffffu : 0u) | ((c1 >= o_lo && c1 < o_hi) ? 0xffff0000u : 0u);
-        }
-        unsigned kq8 = 0;        // first layer: keep bits of pixels 4 q + g, q = 0 .. 7
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int c = r0 + 4 * q + g;
-            kq8 |= (c >= o_lo && c < o_hi) ? (1u << q) : 0u;
-        }
         const int un = min(j / 3, 2), vn = j - 3 * (j / 3);
-        const fb_bf16x8 ones = __builtin_bit_cast(fb_bf16x8, make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u));
-        auto tr_frag = [&](int addr) __attribute__((always_inline)) {
-            const fb_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(FB_LDS_PTR(fb_s16x4, smem + addr));
-            const fb_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(FB_LDS_PTR(fb_s16x4, smem + addr + 64));
-            return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-        };
-        auto tr_frag_x = [&](int addr) __attribute__((always_inline)) {
-            const fb_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(FB_LDS_PTR(fb_s16x4, smem_dma + addr));
-            const fb_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(FB_LDS_PTR(fb_s16x4, smem_dma + addr + 64));
-            return __builtin_bit_cast(fb_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-        };
-
-        // rows each stage touches (as csrc/enc_chain.hip): g3 rows [a_lo, a_hi), g2 rows [b_lo, b_hi), g1 rows [c_lo, c_hi), g0 rows [y_lo, y_hi)
-        const int a_lo = max(0, y_lo - 3), a_hi = min(H, y_hi + 3);
-        const int b_lo = max(0, y_lo - 2), b_hi = min(H, y_hi + 2);
-        const int c_lo = max(0, y_lo - 1), c_hi = min(H, y_hi + 1);
-        const int r_first = a_lo - 3;
 
         fb_u32x4 pg3;            // (the g3 row travels one step ahead only: one register set)
-        fb_u32x2 pG[3][2];       // C operands of the fresh accumulators (G2 row r + 4, G1 row r + 3, G0 row r + 2 at step r): one set, each layer's
-                                 // pair re-requested for the NEXT step right after this step's first k-step of that layer consumed it
+        fb_u32x2 pG[3][2];       // C operands of the fresh accumulators of the NEXT step: each layer's pair is re-requested right after this
+                                 // step's first k-step of that layer consumed it
         auto request_g3 = [&](int y) __attribute__((always_inline)) {
             pg3 = __builtin_amdgcn_raw_buffer_load_b128(rs_g3, (int)g3_off, (int)(crow(y) * g3_row), 0);
         };
+        // input row of chain layer Lc at step r: R = r + RO(Lc) -- layer 1 on g3 row r + 3 -> g2 row r + 2, layer 2 on [g2 | g3] row r + 2 ->
+        // g1 row r + 1 (the one dependent pair of a step), layer 3 one step BEHIND on [g1 | g2 | g3] row r -> g0 row r - 1 (its operands are a
+        // step old: it fills the waits of the dependent pair); each opens out row R + 1 from G(3 - Lc) row R + 1
+#define FB_RO(Lc) ((Lc) == 1 ? 3 : ((Lc) == 2 ? 2 : 0))
         auto request_G = [&](int Lc, int r) __attribute__((always_inline)) {      // for step r
 #pragma unroll
             for (int t = 0; t < 2; ++t)
-                pG[Lc - 1][t] = __builtin_amdgcn_raw_buffer_load_b64(rs_gl, (int)gl_off[t], (int)((unsigned)(2 * (3 - Lc)) * gl_plane + crow(r + 5 - Lc) * gl_row), 0);
+                pG[Lc - 1][t] = __builtin_amdgcn_raw_buffer_load_b64(rs_gl, (int)gl_off[t], (int)((unsigned)(2 * (3 - Lc)) * gl_plane + crow(r + FB_RO(Lc) + 1) * gl_row), 0);
         };
         auto g_c = [&](const fb_u32x2& v) {
             return (fb_f32x4){__uint_as_float(v[0] << 16), __uint_as_float(v[0] & 0xffff0000u), __uint_as_float(v[1] << 16), __uint_as_float(v[1] & 0xffff0000u)};
@@ -258,15 +379,16 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
 #pragma unroll
                 for (int t = 0; t < 2; ++t) acc[L][q][t] = (fb_f32x4){0.f, 0.f, 0.f, 0.f};
 
-#define FB_FENCE() __builtin_amdgcn_sched_barrier(0)
         // ---- one row step (P = (r - r_first) % 3 at compile time; FAST: every stage active, no border row)
         auto step = [&](auto Pc, auto Fc, int r) __attribute__((always_inline)) {
             constexpr int P = decltype(Pc)::value;
             constexpr bool FAST = decltype(Fc)::value != 0;
-            const int R1 = r + 3, R2 = r + 2, R3 = r + 1;      // input row of chain layer Lc = r + 4 - Lc; it completes out row R - 1
+            const int R1 = r + 3, R2 = r + 2, R3 = r;
             const bool on1 = FAST || (R1 >= a_lo && R1 < a_hi), on2 = FAST || (R2 >= b_lo && R2 < b_hi), on3 = FAST || (R3 >= c_lo && R3 < c_hi);
             const bool em1 = FAST || (R1 - 1 >= b_lo && R1 - 1 < b_hi), em2 = FAST || (R2 - 1 >= c_lo && R2 - 1 < c_hi),
-                       em3 = FAST || (r >= y_lo && r < y_hi);
+                       em3 = FAST || (R3 - 1 >= y_lo && R3 - 1 < y_hi);
+            const bool wg = !(FB_ABL & 1) && (FAST || (r >= y_lo && r < y_hi));              // dW1, db1 of row r
+            const bool l0 = !(FB_ABL & 16) && (FAST || (r - 2 >= y_lo && r - 2 < y_hi));     // first layer of row r - 2
             // everything requested before the previous step has landed (the previous step's FB_OPS operations may still be in flight)
             __builtin_amdgcn_s_waitcnt(0x0f70 | (FB_OPS & 15) | ((FB_OPS >> 4) << 14));
             const int bL1 = lb2 + FB_G3 + (R1 & (FB_S3 - 1)) * FB_ROW;
@@ -275,21 +397,24 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
             const int bL3x = lb2 + FB_G3 + (R3 & (FB_S3 - 1)) * FB_ROW;
             fb_bf16x8 fa[2][3], fbr[2][2];
 
-            auto load_k = [&](auto Nc) __attribute__((always_inline)) {
-                constexpr int N = decltype(Nc)::value;
+            auto load_k = [&](auto Nc, auto Bc) __attribute__((always_inline)) {
+                constexpr int N = decltype(Nc)::value, S = decltype(Bc)::value;
+                if (FB_ABL & 32) return;
                 const char* pa = smem + la + N * 3 * 1024;
 #pragma unroll
-                for (int u = 0; u < 3; ++u) fa[N & 1][u] = *reinterpret_cast<const fb_bf16x8*>(pa + u * 1024);
+                for (int u = 0; u < 3; ++u) fa[S][u] = *reinterpret_cast<const fb_bf16x8*>(pa + u * 1024);
                 const char* pb = smem + (N < 2 ? bL1 + 32 * N : (N < 5 ? bL2 + 16 * (N - 2) : (N < 8 ? bL3 + 16 * (N - 5) : bL3x + 32 * (N - 8))));
 #pragma unroll
-                for (int t = 0; t < 2; ++t) fbr[N & 1][t] = *reinterpret_cast<const fb_bf16x8*>(pb + t * 256);
+                for (int t = 0; t < 2; ++t) fbr[S][t] = *reinterpret_cast<const fb_bf16x8*>(pb + t * 256);
             };
-            auto mma_k = [&](auto Nc) __attribute__((always_inline)) {
-                constexpr int N = decltype(Nc)::value;
+            auto mma_k = [&](auto Nc, auto Bc) __attribute__((always_inline)) {
+                constexpr int N = decltype(Nc)::value, S = decltype(Bc)::value;
                 constexpr int Lc = N < 2 ? 1 : (N < 5 ? 2 : 3);
                 constexpr bool first = N == 0 || N == 2 || N == 5;
-                constexpr int i1 = (P + 4 - Lc) % 3, i0 = (i1 + 1) % 3, i2 = (i1 + 2) % 3;      // accumulator rows of out rows R, R+1, R-1
-                const int R = r + 4 - Lc;
+                constexpr int i1 = (P + FB_RO(Lc)) % 3, i0 = (i1 + 1) % 3, i2 = (i1 + 2) % 3;      // accumulator rows of out rows R, R+1, R-1
+                if (FB_ABL & 2) return;
+                if (!(Lc == 1 ? on1 : (Lc == 2 ? on2 : on3))) return;
+                const int R = r + FB_RO(Lc);
                 // adjoint of reflect padding along y: padded row -1 (= tap row 2 of input row 0) folds onto row 1, padded row h onto row h-2
                 const bool top = !FAST && R == 0, bot = !FAST && R == H - 1;
                 if (!FAST && first && R == 0) {   // row 0 has no row above it to open its accumulator: start it from G row 0 here
@@ -299,22 +424,26 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
                 }
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    const fb_bf16x8 b = fbr[N & 1][t];
-                    acc[Lc - 1][i0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[N & 1][0], b, first ? g_c(pG[Lc - 1][t]) : acc[Lc - 1][i0][t], 0, 0, 0);
-                    acc[Lc - 1][i1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[N & 1][1], b, acc[Lc - 1][i1][t], 0, 0, 0);
-                    acc[Lc - 1][i2][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[N & 1][2], b, acc[Lc - 1][i2][t], 0, 0, 0);
+                    const fb_bf16x8 b = fbr[S][t];
+                    acc[Lc - 1][i0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[S][0], b, first ? g_c(pG[Lc - 1][t]) : acc[Lc - 1][i0][t], 0, 0, 0);
+                    acc[Lc - 1][i1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[S][1], b, acc[Lc - 1][i1][t], 0, 0, 0);
+                    acc[Lc - 1][i2][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[S][2], b, acc[Lc - 1][i2][t], 0, 0, 0);
                     if (!FAST) {
-                        if (top) acc[Lc - 1][i0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[N & 1][2], b, acc[Lc - 1][i0][t], 0, 0, 0);
-                        if (bot) acc[Lc - 1][i2][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[N & 1][0], b, acc[Lc - 1][i2][t], 0, 0, 0);
+                        if (top) acc[Lc - 1][i0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[S][2], b, acc[Lc - 1][i0][t], 0, 0, 0);
+                        if (bot) acc[Lc - 1][i2][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[S][0], b, acc[Lc - 1][i2][t], 0, 0, 0);
                     }
                 }
             };
-            // epilogue of chain layer Lc: out row rho = R - 1 of g(3 - Lc): pair the column tiles, fold the edge columns, ReLU mask, round once
+            // epilogue of chain layer Lc: out row rho = R - 1 of g(3 - Lc): pair the column tiles, fold the edge columns, round once, ReLU mask
             auto epilogue = [&](auto Lc_) __attribute__((always_inline)) {
                 constexpr int Lc = decltype(Lc_)::value;
-                constexpr int i2 = ((P + 4 - Lc) % 3 + 2) % 3;
-                constexpr int XO = Lc == 1 ? FB_G2 : (Lc == 2 ? FB_G1 : FB_G0), SO = Lc == 1 ? FB_S2 : (Lc == 2 ? FB_S1 : 1);
-                const int rho = r + 3 - Lc;
+                constexpr int i2 = ((P + FB_RO(Lc)) % 3 + 2) % 3;
+                constexpr int XO = Lc == 1 ? FB_G2 : (Lc == 2 ? FB_G1 : FB_G0), SO = Lc == 1 ? FB_S2 : (Lc == 2 ? FB_S1 : FB_S0);
+                if (FB_ABL & 4) return;
+                if (!(Lc == 1 ? em1 : (Lc == 2 ? em2 : em3))) return;
+                const int rho = r + FB_RO(Lc) - 1;
+                // mask: x(3 - Lc) row rho from the activation ring
+                const uint4 xq = *reinterpret_cast<const uint4*>(smem_dma + xring + xslot((int)crow(rho)) * FB_XROW + (2 * (3 - Lc) + cb_e) * FB_XCBS + px_e * 16);
                 float c[8];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -332,111 +461,111 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
 #pragma unroll
                     for (int i = 0; i < 8; ++i) c[i] += (tgtL ? fl[i] : 0.f) + (tgtR ? fr[i] : 0.f);
                 }
-                // mask: x(3 - Lc) row rho from the activation ring (bf16 > 0  <=>  sign clear and magnitude non-zero; columns outside the image: zero)
-                const uint4 xq = *reinterpret_cast<const uint4*>(smem_dma + xring + xslot((int)crow(rho)) * FB_XROW + (2 * (3 - Lc) + cb_e) * FB_XCBS + px_e * 16);
+                // bf16 > 0  <=>  as int16 > 0 (negative zero and negatives are <= 0): max(x, 0) -> min(., 1) -> 0 - . = 0xffff per kept half;
+                // columns outside the image: zero
                 const uint32_t xw[4] = {xq.x, xq.y, xq.z, xq.w};
+                uint32_t gr[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const uint32_t lo = xw[i] & 0xffffu, hi = xw[i] >> 16;
-                    if (!in_e || !((lo & 0x8000u) == 0 && (lo & 0x7fffu) != 0)) c[2 * i] = 0.f;
-                    if (!in_e || !((hi & 0x8000u) == 0 && (hi & 0x7fffu) != 0)) c[2 * i + 1] = 0.f;
+                    fb_s16x2 sv = __builtin_bit_cast(fb_s16x2, xw[i]);
+                    sv = __builtin_elementwise_max(sv, (fb_s16x2){0, 0});
+                    fb_u16x2 uv = __builtin_bit_cast(fb_u16x2, sv);
+                    uv = __builtin_elementwise_min(uv, (fb_u16x2){1, 1});
+                    uv = (fb_u16x2){0, 0} - uv;
+                    gr[i] = pack_bf16x2(c[2 * i], c[2 * i + 1]) & __builtin_bit_cast(uint32_t, uv) & inm_e;
                 }
-                const uint4 gr = make_uint4(pack_bf16x2(c[0], c[1]), pack_bf16x2(c[2], c[3]), pack_bf16x2(c[4], c[5]), pack_bf16x2(c[6], c[7]));
-                *reinterpret_cast<uint4*>(smem + lw_e + XO + (rho & (SO - 1)) * FB_ROW) = gr;
+                *reinterpret_cast<uint4*>(smem + lw_e + XO + (rho & (SO - 1)) * FB_ROW) = make_uint4(gr[0], gr[1], gr[2], gr[3]);
             };
-            // weight-gradient products of row r (g stationary: gL row r against the activation rows R(r-1), r, R(r+1))
-            auto wgrad = [&]() __attribute__((always_inline)) {
-                fb_bf16x8 ag[3];     // g1, g2, g3 row r, k-major, pixels outside the kept columns zeroed
+            // ---- dW1 / db1 of row r: g1 row r (written by the previous step) against x0 rows R(r-1), r, R(r+1), one tap row per chunk
+            fb_bf16x8 ag1, bx[3];
+            auto w1_load = [&](auto Uc) __attribute__((always_inline)) {
+                constexpr int u = decltype(Uc)::value;
+                if (!wg) return;
+                if (u == 0) ag1 = masked_g(ring + FB_G1 + (r & (FB_S1 - 1)) * FB_ROW);
+                const int xs = xring + xslot(rrow(r + u - 1)) * FB_XROW + ltr_x;
 #pragma unroll
-                for (int L = 1; L <= 3; ++L) {
-                    const int base = ring + (L == 3 ? FB_G3 + (r & (FB_S3 - 1)) * FB_ROW : (L == 2 ? FB_G2 + (r & (FB_S2 - 1)) * FB_ROW : FB_G1 + (r & (FB_S1 - 1)) * FB_ROW));
-                    fb_u32x4 raw = __builtin_bit_cast(fb_u32x4, tr_frag(base + ltr));
+                for (int v = 0; v < 3; ++v) bx[v] = tr_frag_x(xs + (v - 1) * 16);
+            };
+            auto w1_mma = [&](auto Uc) __attribute__((always_inline)) {
+                constexpr int u = decltype(Uc)::value;
+                if (!wg) return;
 #pragma unroll
-                    for (int d = 0; d < 4; ++d) raw[d] &= km[d];
-                    ag[L - 1] = __builtin_bit_cast(fb_bf16x8, raw);
-                }
+                for (int v = 0; v < 3; ++v) w1[u][v] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ag1, bx[v], w1[u][v], 0, 0, 0);
+                if (u == 2) accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ag1, ones, accb[0], 0, 0, 0);   // every column = the sum
+            };
+            // ---- first layer, row r - 2: D[o][n] += sum_p g0[o](p) B[p][n], B[p][n] = image(p + tap n) for n < 9, 1 for n = 9 (-> db0): exact
+            // fp32.  MFMA e takes pixels 8 g + e: its A operand is element e of the transposed fragment a bf16 product would use
+            fb_u32x4 l0g;
+            float l0i[8];
+            auto l0_load = [&]() __attribute__((always_inline)) {
+                if (!l0) return;
+                l0g = __builtin_bit_cast(fb_u32x4, tr_frag(ring + FB_G0 + ((r - 2) & (FB_S0 - 1)) * FB_ROW + ltr));
+                const int ib = iring + (rrow(r - 2 + un - 1) & (FB_IS - 1)) * FB_IROW + (vn - 1) * 4 + 32 * g;
 #pragma unroll
-                for (int u = 0; u < 3; ++u) {
-                    const int xs = xring + xslot(rrow(r + u - 1)) * FB_XROW + ltr_x;
+                for (int e = 0; e < 8; ++e) l0i[e] = *reinterpret_cast<const float*>(smem_dma + ib + e * 4);
+            };
+            auto l0_mma = [&]() __attribute__((always_inline)) {
+                if (!l0) return;
 #pragma unroll
-                    for (int v = 0; v < 3; ++v) {
-                        fb_bf16x8 bx[3];
-#pragma unroll
-                        for (int b = 0; b < 3; ++b) bx[b] = tr_frag_x(xs + 2 * b * FB_XCBS + (v - 1) * 16);
-#pragma unroll
-                        for (int b = 0; b < 3; ++b) w3[u][v][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ag[2], bx[b], w3[u][v][b], 0, 0, 0);
-#pragma unroll
-                        for (int b = 0; b < 2; ++b) w2[u][v][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ag[1], bx[b], w2[u][v][b], 0, 0, 0);
-                        w1[u][v] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ag[0], bx[0], w1[u][v], 0, 0, 0);
-                    }
-                }
-#pragma unroll
-                for (int L = 0; L < 3; ++L) accb[L] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ag[L], ones, accb[L], 0, 0, 0);   // every column = the sum
-                // first layer: D[o][n] += sum_p g0[o](p) B[p][n], B[p][n] = image(p + tap n) for n < 9, 1 for n = 9 (-> db0): exact fp32
-                const int g0b = ring + FB_G0 + 16 + (j >> 3) * FB_CBS + (j & 7) * 2;
-                const int ib = iring + xslot(rrow(r + un - 1)) * FB_IROW + (vn - 1) * 4;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int p = 4 * q + g;
-                    const unsigned short gb = *reinterpret_cast<const unsigned short*>(smem + g0b + p * 16);
-                    const float af = ((kq8 >> q) & 1u) ? __uint_as_float((unsigned)gb << 16) : 0.f;
-                    const float iv = *reinterpret_cast<const float*>(smem_dma + ib + p * 4);
-                    const float bf = j < 9 ? iv : (j == 9 ? 1.f : 0.f);
+                for (int e = 0; e < 8; ++e) {
+                    const uint32_t w = l0g[e >> 1] & km[e >> 1];
+                    const float af = __uint_as_float((e & 1) ? (w & 0xffff0000u) : (w << 16));
+                    const float bf = j < 9 ? l0i[e] : (j == 9 ? 1.f : 0.f);
                     acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf, acc0, 0, 0, 0);
                 }
             };
+            constexpr FBI<0> b0;
+            constexpr FBI<1> b1;
 
-            load_k(FBI<0>());
+            load_k(FBI<0>(), b0); w1_load(FBI<0>());
             FB_FENCE();
-            load_k(FBI<1>()); if (on1) mma_k(FBI<0>());
-            request_G(1, r + 1);      // (every step, whether or not the layer ran: the set always holds the NEXT step's rows)
+            load_k(FBI<5>(), b1); mma_k(FBI<0>(), b0);
+            if (!(FB_ABL & 8)) request_G(1, r + 1);      // (every step, whether or not the layer ran: the set always holds the NEXT step's rows)
             FB_FENCE();
-            if (on1) mma_k(FBI<1>());
+            load_k(FBI<1>(), b0); mma_k(FBI<5>(), b1);
+            if (!(FB_ABL & 8)) request_G(3, r + 1);
             FB_FENCE();
-            if (em1) epilogue(FBI<1>());
+            load_k(FBI<6>(), b1); mma_k(FBI<1>(), b0); w1_mma(FBI<0>());
             FB_FENCE();
-            load_k(FBI<2>());      // (layer 2 reads the g2 row the epilogue above just wrote)
+            load_k(FBI<7>(), b0); mma_k(FBI<6>(), b1); w1_load(FBI<1>());
             FB_FENCE();
-            load_k(FBI<3>()); if (on2) mma_k(FBI<2>());
-            request_G(2, r + 1);
+            mma_k(FBI<7>(), b0); epilogue(FBI<1>());
             FB_FENCE();
-            load_k(FBI<4>()); if (on2) mma_k(FBI<3>());
+            load_k(FBI<2>(), b1);      // (layer 2 reads the g2 row the epilogue above just wrote)
+            w1_mma(FBI<1>());
             FB_FENCE();
-            if (on2) mma_k(FBI<4>());
+            w1_load(FBI<2>());
+            load_k(FBI<8>(), b0); mma_k(FBI<2>(), b1);
+            if (!(FB_ABL & 8)) request_G(2, r + 1);
             FB_FENCE();
-            if (em2) epilogue(FBI<2>());
+            load_k(FBI<3>(), b1); mma_k(FBI<8>(), b0); w1_mma(FBI<2>());
             FB_FENCE();
-            load_k(FBI<5>());
+            load_k(FBI<9>(), b0); mma_k(FBI<3>(), b1); l0_load();
             FB_FENCE();
-            load_k(FBI<6>()); if (on3) mma_k(FBI<5>());
-            request_G(3, r + 1);
+            load_k(FBI<4>(), b1); mma_k(FBI<9>(), b0);
             FB_FENCE();
-            load_k(FBI<7>()); if (on3) mma_k(FBI<6>());
+            mma_k(FBI<4>(), b1); epilogue(FBI<3>());
             FB_FENCE();
-            load_k(FBI<8>()); if (on3) mma_k(FBI<7>());
+            l0_mma();
             FB_FENCE();
-            load_k(FBI<9>()); if (on3) mma_k(FBI<8>());
+            epilogue(FBI<2>());
             FB_FENCE();
-            if (on3) mma_k(FBI<9>());
-            FB_FENCE();
-            if (em3) epilogue(FBI<3>());
-            FB_FENCE();
-            if (em3) wgrad();
-            FB_FENCE();
-            // ---- the step's global traffic, in one place: g3 row r + 4 (set of step r + 1) into its ring slot, this set reloaded for step
-            // r + 3, the activation / image rows r + 4 requested
+            FB_STEP_BARRIER();
+            // ---- the step's global traffic, in one place, after the barrier (role B has finished with the slots overwritten here): g3 row
+            // r + 4 (set of step r + 1) into its ring slot, this set reloaded for step r + 3, the activation / image rows r + 4 requested
             {
                 const int ya = r + 4;
                 if (FAST || (ya >= a_lo && ya < a_hi)) *reinterpret_cast<fb_u32x4*>(smem + lw_a + (ya & (FB_S3 - 1)) * FB_ROW) = pg3;
             }
-            request_g3(r + 5);
-            dma_rows(r + 4);
+            if (!(FB_ABL & 8)) {
+                request_g3(r + 5);
+                dma_rows(r + 4);
+            }
             FB_FENCE();
         };
-#undef FB_FENCE
 
-        // ---- the pipeline: steps r = r_first .. y_hi - 1, phase 0 at r_first.  Prologue: sets 0..2 (steps r_first .. r_first + 2), activation /
-        // image rows r_first - 1 .. r_first + 3, g3 row r_first + 3 into its slot.
+        // ---- the pipeline: steps r = r_first .. r_first + NSTEP - 1, phase 0 at r_first.  Prologue: sets 0..2 (steps r_first .. r_first + 2),
+        // activation / image rows r_first - 1 .. r_first + 3, g3 row r_first + 3 into its slot.
         request_g3(r_first + 3);
 #pragma unroll
         for (int Lc = 1; Lc <= 3; ++Lc) request_G(Lc, r_first);
@@ -447,11 +576,12 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
         if (r_first + 3 >= a_lo && r_first + 3 < a_hi) *reinterpret_cast<fb_u32x4*>(smem + lw_a + ((r_first + 3) & (FB_S3 - 1)) * FB_ROW) = pg3;
         request_g3(r_first + 4);
         // branch-free steps: every stage active and emitting, no stage at image row 0 / h-1, the g3 row written at the end inside [a_lo, a_hi)
-        const int f_lo = max(max(y_lo, c_lo - 1), 0), f_hi = min(min(y_hi, a_hi - 4), H - 4);
+        const int r_end = r_first + NSTEP;
+        const int f_lo = max(y_lo + 2, 1), f_hi = min(min(y_hi, a_hi - 4), H - 4);
         int r = r_first;
 #pragma unroll 1
         for (int part = 0; part < 2; ++part) {
-            const int stop = part == 0 ? min(y_hi, f_lo) : y_hi;
+            const int stop = part == 0 ? min(r_end, f_lo) : r_end;
 #pragma unroll 1
             for (; r < stop; r += 3) {
                 step(FBI<0>(), FBI<0>(), r);
@@ -467,44 +597,24 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
                 }
             }
         }
-    }
-
-    // ---- block partial: the four waves' accumulators summed in LDS (natural [o][c][u][v] order, enc_wgrad.hpp) -> one coalesced copy
-    __builtin_amdgcn_s_waitcnt(0x0f70);
-    __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);
-    for (int wv = 0; wv < FB_WAVES; ++wv) {
-        if (wave == wv) {
-            auto put = [&](int idx, float v) { red[idx] = wv == 0 ? v : red[idx] + v; };
+        }
+        block_partial([&](auto put) {
 #pragma unroll
             for (int u = 0; u < 3; ++u)
 #pragma unroll
-                for (int v = 0; v < 3; ++v) {
-                    const int t = 3 * u + v;
+                for (int v = 0; v < 3; ++v)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int oc = 4 * g + q;
-#pragma unroll
-                        for (int b = 0; b < 3; ++b) put(EW_OFF3 + (oc * 48 + 16 * b + j) * 9 + t, w3[u][v][b][q]);
-#pragma unroll
-                        for (int b = 0; b < 2; ++b) put(EW_OFF2 + (oc * 32 + 16 * b + j) * 9 + t, w2[u][v][b][q]);
-                        put(EW_OFF1 + (oc * 16 + j) * 9 + t, w1[u][v][q]);
-                    }
-                }
+                    for (int q = 0; q < 4; ++q) put(EW_OFF1 + ((4 * g + q) * 16 + j) * 9 + 3 * u + v, w1[u][v][q]);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 put(EW_OFF0 + (4 * g + q) * 16 + j, acc0[q]);
-                if (j == 0) {
-#pragma unroll
-                    for (int L = 0; L < 3; ++L) put(EW_OFFB + L * 16 + 4 * g + q, accb[L][q]);
-                }
+                if (j == 0) put(EW_OFFB + 4 * g + q, accb[0][q]);
             }
-        }
-        __syncthreads();
+        });
     }
-    float* dst = B.partial + (long long)blockIdx.x * EW_PER;
-    for (int e = tid; e < EW_PER; e += FB_WAVES * 64) dst[e] = red[e];
 }
+#undef FB_FENCE
+#undef FB_RO
 
 static void fb_geometry(int n, int h, int w, int nb, int& nstrips, int& nseg, int& seg_rows) {
     nstrips = w <= FB_W - 2 ? 1 : (w - (FB_W - 2) + FB_KEEP - 1) / FB_KEEP + 1;
@@ -518,7 +628,7 @@ static void fb_geometry(int n, int h, int w, int nb, int& nstrips, int& nseg, in
     nseg = 1;
     for (int k = 1; k <= (h + 7) / 8; ++k) {
         const int rows = (h + k - 1) / k;
-        const long long blocks = (long long)nb * (((long long)n * nstrips * k + FB_WAVES - 1) / FB_WAVES);
+        const long long blocks = (long long)nb * (((long long)n * nstrips * k + FB_PAIRS - 1) / FB_PAIRS);
         if (blocks / nb > EW_MAXG / 2) break;        // (block partials of both branches share one workspace of EW_MAXG slots)
         const long long cost = ((blocks + ncu - 1) / ncu) * (rows + 8);
         if (best < 0 || cost < best) { best = cost; nseg = k; }
@@ -573,7 +683,7 @@ extern "C" int mmif_dense_encoder_bwd(const mmif_dense_chain* chain_a, const flo
     A.n = chain_a->x->n; A.h = chain_a->x->h; A.w = chain_a->x->w;
     fb_geometry(A.n, A.h, A.w, nb, A.nstrips, A.nseg, A.seg_rows);
     A.items = A.n * A.nseg * A.nstrips;
-    const int G = cdiv(A.items, FB_WAVES);
+    const int G = cdiv(A.items, FB_PAIRS);
     MMIF_REQUIRE(nb * G <= EW_MAXG, "dense_encoder_bwd: too many blocks for the partial-sum workspace");
     for (int b = 0; b < nb; ++b) {
         const mmif_dense_chain* c = b ? chain_b : chain_a;
