@@ -202,7 +202,8 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
     if (role == 1) {
         // ================= role B: dW3, dW2, db3, db2 of row r = g3 / g2 row r (final since step r - 2) against the activation rows
         // R(r-1), r, R(r+1): nine chunks of one tap (u, v), operands double-buffered
-        fb_f32x4 w3[3][3][3], w2[3][3][2], accb[3];
+        fb_f32x4 w3[3][3][3], w2[3][3][2], accb[3], acc0 = zero4;
+        const int un = min(j / 3, 2), vn = j - 3 * (j / 3);
 #pragma unroll
         for (int u = 0; u < 3; ++u)
 #pragma unroll
@@ -217,6 +218,10 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
 #pragma unroll 1
         for (int s = 0; s < NSTEP; ++s) {
             const int r = r_first + s;
+            // first layer, row r - 2 (g0 row r - 2 left the chain in step r - 1): D[o][n] += sum_p g0[o](p) B[p][n], B[p][n] = image(p + tap n)
+            // for n < 9, 1 for n = 9 (-> db0): exact fp32.  MFMA e takes pixels 8 g + e: its A operand is element e of the transposed
+            // fragment a bf16 product would use
+            const bool l0 = !(FB_ABL & 16) && valid && r - 2 >= y_lo && r - 2 < y_hi;
             if (!(FB_ABL & 1) && valid && r >= y_lo && r < y_hi) {
                 fb_bf16x8 ag2 = masked_g(ring + FB_G2 + (r & (FB_S2 - 1)) * FB_ROW), ag3 = masked_g(ring + FB_G3 + (r & (FB_S3 - 1)) * FB_ROW);
                 int xs3[3];
@@ -256,11 +261,29 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
                 wg_mma(FBI<8>());
                 accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ag2, ones, accb[1], 0, 0, 0);   // every column = the sum
                 accb[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ag3, ones, accb[2], 0, 0, 0);
+                accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(masked_g(ring + FB_G1 + (r & (FB_S1 - 1)) * FB_ROW), ones, accb[0], 0, 0, 0);
                 FB_FENCE();
             }
+            if (l0) {     // (operands read here, not ahead: this role has the slack, not the registers)
+                const fb_u32x4 l0g = __builtin_bit_cast(fb_u32x4, tr_frag(ring + FB_G0 + ((r - 2) & (FB_S0 - 1)) * FB_ROW + ltr));
+                const int ib = iring + (rrow(r - 2 + un - 1) & (FB_IS - 1)) * FB_IROW + (vn - 1) * 4 + 32 * g;
+                float l0i[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) l0i[e] = *reinterpret_cast<const float*>(smem_dma + ib + e * 4);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const uint32_t w = l0g[e >> 1] & km[e >> 1];
+                    const float af = __uint_as_float((e & 1) ? (w & 0xffff0000u) : (w << 16));
+                    const float bf = j < 9 ? l0i[e] : (j == 9 ? 1.f : 0.f);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf, acc0, 0, 0, 0);
+                }
+            }
+            FB_FENCE();
             FB_STEP_BARRIER();
         }
         block_partial([&](auto put) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) put(EW_OFF0 + (4 * g + q) * 16 + j, acc0[q]);
 #pragma unroll
             for (int u = 0; u < 3; ++u)
 #pragma unroll
@@ -279,17 +302,16 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
-                    for (int L = 1; L < 3; ++L) put(EW_OFFB + L * 16 + 4 * g + q, accb[L][q]);
+                    for (int L = 0; L < 3; ++L) put(EW_OFFB + L * 16 + 4 * g + q, accb[L][q]);
             }
         });
     } else {
         // ================= role A: the gradient chain, dW1 / db1 and the first layer's gradients
-        fb_f32x4 w1[3][3], accb[1], acc0 = zero4;
+        fb_f32x4 w1[3][3];
 #pragma unroll
         for (int u = 0; u < 3; ++u)
 #pragma unroll
             for (int v = 0; v < 3; ++v) w1[u][v] = zero4;
-        accb[0] = zero4;
         if (!valid) {
 #pragma unroll 1
             for (int s = 0; s < NSTEP; ++s) FB_STEP_BARRIER();
@@ -309,6 +331,8 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
         const int srcL = (cb_e * 2 + (max(px_e - 2, 0) >> 4)) * 16 + (max(px_e - 2, 0) & 15);
         const int srcR = (cb_e * 2 + (min(px_e + 2, FB_W - 1) >> 4)) * 16 + (min(px_e + 2, FB_W - 1) & 15);
         const bool tgtL = edgeL && x_e == 1, tgtR = edgeR && x_e == W - 2;
+        const bool tgt_f = tgtL || tgtR;
+        const int src_f = tgtL ? srcL : srcR;
         // g3 rows: lane = (pixel lane & 31, channel block lane >> 5)
         const int px_a = lane & 31, cb_a = lane >> 5;
         const int x_a = r0 + px_a;
@@ -336,22 +360,22 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
         const unsigned iring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem_dma + (unsigned)iring;
         const int cdma = min(max(reflect_idx(r0 + (lane & 31), W), 0), W - 1);
         const unsigned xdma_off = (unsigned)(lane >> 5) * x_plane + (unsigned)cdma * 16u;
-        auto dma16 = [&](const char* gsrc, unsigned lds_dst) __attribute__((always_inline)) {
-            __asm__ volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(lds_dst), "v"(gsrc) : "memory", "m0");
+        // (scalar row base + one 32-bit lane offset: no 64-bit lane pointers to keep in -- or spill from -- the vector registers)
+        auto dma16 = [&](const char* sbase, unsigned voff, unsigned lds_dst) __attribute__((always_inline)) {
+            __asm__ volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(lds_dst), "v"(voff), "s"(sbase) : "memory", "m0");
         };
-        auto dma4 = [&](const char* gsrc, unsigned lds_dst) __attribute__((always_inline)) {
-            __asm__ volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" : : "s"(lds_dst), "v"(gsrc) : "memory", "m0");
+        auto dma4 = [&](const char* sbase, unsigned voff, unsigned lds_dst) __attribute__((always_inline)) {
+            __asm__ volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" : : "s"(lds_dst), "v"(voff), "s"(sbase) : "memory", "m0");
         };
+        const unsigned idma_off = (unsigned)cdma * 4u;
         auto dma_rows = [&](int y) __attribute__((always_inline)) {   // x0 | x1 | x2 row (3 x 1 KiB) + image row of image row clamp(y)
             const int yy = (int)crow(y);
             const char* src = x_img + (unsigned long long)((unsigned)yy * x_rowb);
             const unsigned dst = xring_lds + (unsigned)(xslot(yy) * FB_XROW);
 #pragma unroll
-            for (int i = 0; i < 3; ++i) dma16(src + (unsigned long long)(xdma_off + (unsigned)(2 * i) * x_plane), dst + (unsigned)i * 1024u);
-            if (lane < 32) dma4(im_img + ((long long)yy * W + cdma) * 4, iring_lds + (unsigned)((yy & (FB_IS - 1)) * FB_IROW));
+            for (int i = 0; i < 3; ++i) dma16(src + (unsigned long long)((unsigned)(2 * i) * x_plane), xdma_off, dst + (unsigned)i * 1024u);
+            if (lane < 32) dma4(im_img + (long long)yy * W * 4, idma_off, iring_lds + (unsigned)((yy & (FB_IS - 1)) * FB_IROW));
         };
-        const int un = min(j / 3, 2), vn = j - 3 * (j / 3);
-
         fb_u32x4 pg3;            // (the g3 row travels one step ahead only: one register set)
         fb_u32x2 pG[3][2];       // C operands of the fresh accumulators of the NEXT step: each layer's pair is re-requested right after this
                                  // step's first k-step of that layer consumed it
@@ -388,14 +412,13 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
             const bool em1 = FAST || (R1 - 1 >= b_lo && R1 - 1 < b_hi), em2 = FAST || (R2 - 1 >= c_lo && R2 - 1 < c_hi),
                        em3 = FAST || (R3 - 1 >= y_lo && R3 - 1 < y_hi);
             const bool wg = !(FB_ABL & 1) && (FAST || (r >= y_lo && r < y_hi));              // dW1, db1 of row r
-            const bool l0 = !(FB_ABL & 16) && (FAST || (r - 2 >= y_lo && r - 2 < y_hi));     // first layer of row r - 2
             // everything requested before the previous step has landed (the previous step's FB_OPS operations may still be in flight)
             __builtin_amdgcn_s_waitcnt(0x0f70 | (FB_OPS & 15) | ((FB_OPS >> 4) << 14));
             const int bL1 = lb2 + FB_G3 + (R1 & (FB_S3 - 1)) * FB_ROW;
             const int bL2 = lb4 + (h2 ? FB_G3 + (R2 & (FB_S3 - 1)) * FB_ROW : FB_G2 + (R2 & (FB_S2 - 1)) * FB_ROW);
             const int bL3 = lb4 + (h2 ? FB_G2 + (R3 & (FB_S2 - 1)) * FB_ROW : FB_G1 + (R3 & (FB_S1 - 1)) * FB_ROW);
             const int bL3x = lb2 + FB_G3 + (R3 & (FB_S3 - 1)) * FB_ROW;
-            fb_bf16x8 fa[2][3], fbr[2][2];
+            fb_bf16x8 fa[3][3], fbr[3][2];     // three operand sets: a k-step's reads are issued two regions before its products
 
             auto load_k = [&](auto Nc, auto Bc) __attribute__((always_inline)) {
                 constexpr int N = decltype(Nc)::value, S = decltype(Bc)::value;
@@ -451,15 +474,12 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
                     c[q] = __uint_as_float(sw[0]);
                     c[4 + q] = __uint_as_float(sw[1]);
                 }
-                if (edgeL || edgeR) {   // wave-uniform: the adjoint of reflect padding along x
-                    float fl[8], fr[8];
+                if (edgeL || edgeR) {   // wave-uniform: the adjoint of reflect padding along x (a lane is the target of at most one fold: w >= 4)
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
-                        fl[i] = __shfl(c[i], srcL, 64);
-                        fr[i] = __shfl(c[i], srcR, 64);
+                        const float f = __shfl(c[i], src_f, 64);
+                        c[i] += tgt_f ? f : 0.f;
                     }
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) c[i] += (tgtL ? fl[i] : 0.f) + (tgtR ? fr[i] : 0.f);
                 }
                 // bf16 > 0  <=>  as int16 > 0 (negative zero and negatives are <= 0): max(x, 0) -> min(., 1) -> 0 - . = 0xffff per kept half;
                 // columns outside the image: zero
@@ -477,78 +497,59 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
                 *reinterpret_cast<uint4*>(smem + lw_e + XO + (rho & (SO - 1)) * FB_ROW) = make_uint4(gr[0], gr[1], gr[2], gr[3]);
             };
             // ---- dW1 / db1 of row r: g1 row r (written by the previous step) against x0 rows R(r-1), r, R(r+1), one tap row per chunk
-            fb_bf16x8 ag1, bx[3];
-            auto w1_load = [&](auto Uc) __attribute__((always_inline)) {
-                constexpr int u = decltype(Uc)::value;
+            fb_bf16x8 ag1, bx;
+            auto w1_load = [&](auto Cc) __attribute__((always_inline)) {
+                constexpr int C = decltype(Cc)::value, u = C / 3, v = C % 3;
                 if (!wg) return;
-                if (u == 0) ag1 = masked_g(ring + FB_G1 + (r & (FB_S1 - 1)) * FB_ROW);
-                const int xs = xring + xslot(rrow(r + u - 1)) * FB_XROW + ltr_x;
-#pragma unroll
-                for (int v = 0; v < 3; ++v) bx[v] = tr_frag_x(xs + (v - 1) * 16);
+                if (C == 0) ag1 = masked_g(ring + FB_G1 + (r & (FB_S1 - 1)) * FB_ROW);
+                bx = tr_frag_x(xring + xslot(rrow(r + u - 1)) * FB_XROW + ltr_x + (v - 1) * 16);
             };
-            auto w1_mma = [&](auto Uc) __attribute__((always_inline)) {
-                constexpr int u = decltype(Uc)::value;
+            auto w1_mma = [&](auto Cc) __attribute__((always_inline)) {
+                constexpr int C = decltype(Cc)::value, u = C / 3, v = C % 3;
                 if (!wg) return;
-#pragma unroll
-                for (int v = 0; v < 3; ++v) w1[u][v] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ag1, bx[v], w1[u][v], 0, 0, 0);
-                if (u == 2) accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ag1, ones, accb[0], 0, 0, 0);   // every column = the sum
-            };
-            // ---- first layer, row r - 2: D[o][n] += sum_p g0[o](p) B[p][n], B[p][n] = image(p + tap n) for n < 9, 1 for n = 9 (-> db0): exact
-            // fp32.  MFMA e takes pixels 8 g + e: its A operand is element e of the transposed fragment a bf16 product would use
-            fb_u32x4 l0g;
-            float l0i[8];
-            auto l0_load = [&]() __attribute__((always_inline)) {
-                if (!l0) return;
-                l0g = __builtin_bit_cast(fb_u32x4, tr_frag(ring + FB_G0 + ((r - 2) & (FB_S0 - 1)) * FB_ROW + ltr));
-                const int ib = iring + (rrow(r - 2 + un - 1) & (FB_IS - 1)) * FB_IROW + (vn - 1) * 4 + 32 * g;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) l0i[e] = *reinterpret_cast<const float*>(smem_dma + ib + e * 4);
-            };
-            auto l0_mma = [&]() __attribute__((always_inline)) {
-                if (!l0) return;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const uint32_t w = l0g[e >> 1] & km[e >> 1];
-                    const float af = __uint_as_float((e & 1) ? (w & 0xffff0000u) : (w << 16));
-                    const float bf = j < 9 ? l0i[e] : (j == 9 ? 1.f : 0.f);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf, acc0, 0, 0, 0);
-                }
+                w1[u][v] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ag1, bx, w1[u][v], 0, 0, 0);
             };
             constexpr FBI<0> b0;
             constexpr FBI<1> b1;
-
-            load_k(FBI<0>(), b0); w1_load(FBI<0>());
+            constexpr FBI<2> b2;
+            // order of the k-steps: 0 5 1 6 7 | E1 | 2 8 3 9 4 | E3 E2  (layers 1 -> 2 are the dependent pair, layer 3's k-steps 5..9 and
+            // the dW1 chunks fill between them)
+            load_k(FBI<0>(), b0); load_k(FBI<5>(), b1); w1_load(FBI<0>());
             FB_FENCE();
-            load_k(FBI<5>(), b1); mma_k(FBI<0>(), b0);
+            load_k(FBI<1>(), b2); mma_k(FBI<0>(), b0); w1_mma(FBI<0>());
             if (!(FB_ABL & 8)) request_G(1, r + 1);      // (every step, whether or not the layer ran: the set always holds the NEXT step's rows)
             FB_FENCE();
-            load_k(FBI<1>(), b0); mma_k(FBI<5>(), b1);
+            load_k(FBI<6>(), b0); w1_load(FBI<1>()); mma_k(FBI<5>(), b1);
             if (!(FB_ABL & 8)) request_G(3, r + 1);
             FB_FENCE();
-            load_k(FBI<6>(), b1); mma_k(FBI<1>(), b0); w1_mma(FBI<0>());
+            load_k(FBI<7>(), b1); mma_k(FBI<1>(), b2); w1_mma(FBI<1>());
             FB_FENCE();
-            load_k(FBI<7>(), b0); mma_k(FBI<6>(), b1); w1_load(FBI<1>());
+            w1_load(FBI<2>()); mma_k(FBI<6>(), b0);
             FB_FENCE();
-            mma_k(FBI<7>(), b0); epilogue(FBI<1>());
+            epilogue(FBI<1>());
+            load_k(FBI<2>(), b2);      // (layer 2 reads the g2 row the epilogue above just wrote)
+            w1_mma(FBI<2>());
             FB_FENCE();
-            load_k(FBI<2>(), b1);      // (layer 2 reads the g2 row the epilogue above just wrote)
-            w1_mma(FBI<1>());
+            load_k(FBI<8>(), b0); w1_load(FBI<3>()); mma_k(FBI<7>(), b1);
             FB_FENCE();
-            w1_load(FBI<2>());
-            load_k(FBI<8>(), b0); mma_k(FBI<2>(), b1);
+            load_k(FBI<3>(), b1); mma_k(FBI<2>(), b2); w1_mma(FBI<3>());
             if (!(FB_ABL & 8)) request_G(2, r + 1);
             FB_FENCE();
-            load_k(FBI<3>(), b1); mma_k(FBI<8>(), b0); w1_mma(FBI<2>());
+            load_k(FBI<9>(), b2); w1_load(FBI<4>()); mma_k(FBI<8>(), b0);
             FB_FENCE();
-            load_k(FBI<9>(), b0); mma_k(FBI<3>(), b1); l0_load();
+            load_k(FBI<4>(), b0); mma_k(FBI<3>(), b1); w1_mma(FBI<4>());
             FB_FENCE();
-            load_k(FBI<4>(), b1); mma_k(FBI<9>(), b0);
+            w1_load(FBI<5>()); mma_k(FBI<9>(), b2);
             FB_FENCE();
-            mma_k(FBI<4>(), b1); epilogue(FBI<3>());
+            mma_k(FBI<4>(), b0); w1_mma(FBI<5>()); 
             FB_FENCE();
-            l0_mma();
+            w1_load(FBI<6>()); epilogue(FBI<3>());
             FB_FENCE();
-            epilogue(FBI<2>());
+            w1_mma(FBI<6>()); w1_load(FBI<7>());
+            FB_FENCE();
+            epilogue(FBI<2>()); w1_mma(FBI<7>()); w1_load(FBI<8>());
+            FB_FENCE();
+            w1_mma(FBI<8>());
             FB_FENCE();
             FB_STEP_BARRIER();
             // ---- the step's global traffic, in one place, after the barrier (role B has finished with the slots overwritten here): g3 row
@@ -605,11 +606,6 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
                 for (int v = 0; v < 3; ++v)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) put(EW_OFF1 + ((4 * g + q) * 16 + j) * 9 + 3 * u + v, w1[u][v][q]);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                put(EW_OFF0 + (4 * g + q) * 16 + j, acc0[q]);
-                if (j == 0) put(EW_OFFB + 4 * g + q, accb[0][q]);
-            }
         });
     }
 }
