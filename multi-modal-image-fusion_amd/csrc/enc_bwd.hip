@@ -38,7 +38,8 @@ typedef unsigned fb_u32x2 __attribute__((ext_vector_type(2)));
 #define FB_LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
 
 constexpr int FB_W = 32, FB_KEEP = FB_W - 6;
-constexpr int FB_XCBS = 512;                   // bytes of one channel block of an ACTIVATION ring row (32 px x 16 B)
+// activation ring rows are PIXEL-major inside a layer's 16 channels: [x0 | x1 | x2][32 px][2 channel blocks][16 B] -- the 16 lanes of a
+// transposing read (4 pixels x 16 channels) touch 128 contiguous bytes (no bank conflict); the DMA lane 2 px + cb fetches that granule
 // gradient ring rows carry a zero guard granule on either side of their 32 pixels: the chain is a ZERO-padded correlation of the gradient
 // rows (the adjoint of reflect padding is applied to its padded-domain result), so the operand reads of pixel -1 / 32 -- one granule
 // before / after the row -- must be zero where the strip holds the image's padded column (enc_stream2.hip reads its neighbours' bytes
@@ -49,7 +50,7 @@ constexpr int FB_S3 = 4, FB_S2 = 4, FB_S1 = 2, FB_S0 = 2;   // ring slots of g3 
 constexpr int FB_G3 = 0, FB_G2 = FB_S3 * FB_ROW, FB_G1 = FB_G2 + FB_S2 * FB_ROW, FB_G0 = FB_G1 + FB_S1 * FB_ROW, FB_GRING = FB_G0 + FB_S0 * FB_ROW;   // 13056
 constexpr int FB_XS = 6;                       // slots of the activation ring (rows r-1 .. r+3 in use, r+4 in flight)
 constexpr int FB_IS = 8;                       // slots of the image ring (rows r-3 .. r+3 in use: the first layer's products trail by two rows)
-constexpr int FB_XROW = 6 * FB_XCBS;           // x0 | x1 | x2 row: [6 cb][32 px][16 B]
+constexpr int FB_XROW = 3 * 1024;              // x0 | x1 | x2 row
 constexpr int FB_IROW = 128;                   // image row: 32 fp32
 constexpr int FB_PAIRS = 4;                    // wave pairs per block: waves 0..3 run the chain (role A), waves 4..7 the weight gradients (B);
 constexpr int FB_WAVES = 2 * FB_PAIRS;         // wave p and wave p + 4 share SIMD p and one strip
@@ -59,8 +60,7 @@ constexpr int FB_LDS = FB_WBYTES + FB_PAIRS * FB_GRING + 64;
 // (64 zero bytes after the activation rings and after the image rings: the operand reads of pixel 32 run one granule past a row, into the
 //  next row / slot / wave -- finite data, multiplied by a zeroed gradient -- and after the LAST row they must not find the fp32 image
 //  ring, whose low halves read as bf16 are arbitrary bit patterns, NaN included)
-constexpr int FB_LDS_DMA = FB_PAIRS * (FB_XS * FB_XROW + FB_IS * FB_IROW) + 128;
-constexpr int FB_OPS = 7 + 4;                  // vector-memory operations per step: g3 row + 6 G fragments (registers), 3 x-row DMAs + 1 image DMA
+constexpr int FB_LDS_DMA = FB_PAIRS * (FB_XS * FB_XROW + FB_IS * FB_IROW) + 192;
 static_assert(EW_PER * 4 <= FB_LDS, "the block partial is staged in the operand LDS");
 static_assert(FB_LDS + FB_LDS_DMA <= 160 * 1024, "LDS budget of one CU");
 
@@ -115,8 +115,8 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
         reinterpret_cast<uint4*>(smem)[e] = B.wpk[kq < 2 ? 2 : (kq < 5 ? 1 : 0)][a_plane(kq, u, kg) * 16 + oc];
     }
     const int ring = FB_WBYTES + pair * FB_GRING;
-    const int xring = pair * (FB_XS * FB_XROW);                                     // byte offsets inside smem_dma
-    const int iring = FB_PAIRS * FB_XS * FB_XROW + 64 + pair * (FB_IS * FB_IROW);
+    const int xring = 64 + pair * (FB_XS * FB_XROW);                                // byte offsets inside smem_dma (64 zero bytes in front)
+    const int iring = 64 + FB_PAIRS * FB_XS * FB_XROW + 64 + pair * (FB_IS * FB_IROW);
     if (role == 0) {
         for (int e = lane; e < FB_GRING / 16; e += 64) reinterpret_cast<uint4*>(smem + ring)[e] = make_uint4(0u, 0u, 0u, 0u);
     } else {
@@ -125,7 +125,8 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
     }
     if (tid < 4) {
         reinterpret_cast<uint4*>(smem + FB_WBYTES + FB_PAIRS * FB_GRING)[tid] = make_uint4(0u, 0u, 0u, 0u);
-        reinterpret_cast<uint4*>(smem_dma + FB_PAIRS * FB_XS * FB_XROW)[tid] = make_uint4(0u, 0u, 0u, 0u);
+        reinterpret_cast<uint4*>(smem_dma)[tid] = make_uint4(0u, 0u, 0u, 0u);
+        reinterpret_cast<uint4*>(smem_dma + 64 + FB_PAIRS * FB_XS * FB_XROW)[tid] = make_uint4(0u, 0u, 0u, 0u);
         reinterpret_cast<uint4*>(smem_dma + FB_LDS_DMA - 64)[tid] = make_uint4(0u, 0u, 0u, 0u);
     }
     __syncthreads();
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
     // ---- lane constants of the transposing reads (weight-gradient operands: in-group lane sl supplies pixel sl >> 2 (+ 4), 4-channel chunk sl & 3)
     const int tr_row = j >> 2, tr_c = j & 3;
     const int ltr = (tr_c >> 1) * FB_CBS + 16 + (8 * g + tr_row) * 16 + (tr_c & 1) * 8;        // gradient rings
-    const int ltr_x = (tr_c >> 1) * FB_XCBS + (8 * g + tr_row) * 16 + (tr_c & 1) * 8;         // activation ring
+    const int ltr_x = (8 * g + tr_row) * 32 + tr_c * 8;                                       // activation ring (pixel-major: 32 B = 16 channels)
     unsigned km[4];          // keep-mask of this lane's 8 pixels 8 g .. 8 g + 7 (two bf16 per dword)
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
     };
     auto tr_frag_x = [&](int addr) __attribute__((always_inline)) {
         const fb_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(FB_LDS_PTR(fb_s16x4, smem_dma + addr));
-        const fb_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(FB_LDS_PTR(fb_s16x4, smem_dma + addr + 64));
+        const fb_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(FB_LDS_PTR(fb_s16x4, smem_dma + addr + 128));
         return __builtin_bit_cast(fb_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     };
     auto masked_g = [&](int addr) __attribute__((always_inline)) {      // one gradient row, k-major, pixels outside the kept columns zeroed
@@ -198,6 +199,7 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
         for (int e = tid; e < EW_PER; e += FB_WAVES * 64) dst[e] = red[e];
     };
     const fb_f32x4 zero4 = (fb_f32x4){0.f, 0.f, 0.f, 0.f};
+    auto img_base = [&](const TV& t) { return t.base + ((long long)in_ * t.img + (long long)t.cb_off * t.plane) * 16; };
 
     if (role == 1) {
         // ================= role B: dW3, dW2, db3, db2 of row r = g3 / g2 row r (final since step r - 2) against the activation rows
@@ -215,9 +217,44 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
             }
 #pragma unroll
         for (int i = 0; i < 3; ++i) accb[i] = zero4;
+        const unsigned x_plane = (unsigned)(B.x.plane * 16), x_rowb = (unsigned)B.x.ws * 16u;
+        // activation / image rows by LDS-DMA (this role has the slack to issue them and to wait for them): ring pixel p = image column reflect(r0 + p) (the edge strips' ghost pixels hold the reflected column)
+        const char* x_img = img_base(B.x);
+        const char* im_img = reinterpret_cast<const char*>(B.img + (long long)in_ * H * W);
+        const unsigned xring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem_dma + (unsigned)xring;
+        const unsigned iring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem_dma + (unsigned)iring;
+        const int cdma = min(max(reflect_idx(r0 + (lane & 31), W), 0), W - 1);          // image row: lane = pixel
+        const int cdmx = min(max(reflect_idx(r0 + (lane >> 1), W), 0), W - 1);          // activation rows: lane = 2 pixel + channel block
+        const unsigned xdma_off = (unsigned)(lane & 1) * x_plane + (unsigned)cdmx * 16u;
+        // (scalar row base + one 32-bit lane offset: no 64-bit lane pointers to keep in -- or spill from -- the vector registers)
+        auto dma16 = [&](const char* sbase, unsigned voff, unsigned lds_dst) __attribute__((always_inline)) {
+            __asm__ volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(lds_dst), "v"(voff), "s"(sbase) : "memory", "m0");
+        };
+        auto dma4 = [&](const char* sbase, unsigned voff, unsigned lds_dst) __attribute__((always_inline)) {
+            __asm__ volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" : : "s"(lds_dst), "v"(voff), "s"(sbase) : "memory", "m0");
+        };
+        const unsigned idma_off = (unsigned)cdma * 4u;
+        auto dma_rows = [&](int y) __attribute__((always_inline)) {   // x0 | x1 | x2 row (3 x 1 KiB) + image row of image row clamp(y)
+            const int yy = (int)crow(y);
+            const char* src = x_img + (unsigned long long)((unsigned)yy * x_rowb);
+            const unsigned dst = xring_lds + (unsigned)(xslot(yy) * FB_XROW);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) dma16(src + (unsigned long long)((unsigned)(2 * i) * x_plane), xdma_off, dst + (unsigned)i * 1024u);
+            if (lane < 32) dma4(im_img + (long long)yy * W * 4, idma_off, iring_lds + (unsigned)((yy & (FB_IS - 1)) * FB_IROW));
+        };
+        // prologue: rows r_first - 1 .. r_first + 3 (step r requests row r + 4 at its start and has it landed at its barrier: the chain waves
+        // first touch row r + 4 in step r + 2)
+        if (valid && !(FB_ABL & 8)) {
+#pragma unroll 1
+            for (int y = max(r_first - 1, 0); y < r_first + 4; ++y)
+                if (y >= 0) dma_rows(y);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        FB_STEP_BARRIER();
 #pragma unroll 1
         for (int s = 0; s < NSTEP; ++s) {
             const int r = r_first + s;
+            if (valid && !(FB_ABL & 8)) dma_rows(r + 4);
             // first layer, row r - 2 (g0 row r - 2 left the chain in step r - 1): D[o][n] += sum_p g0[o](p) B[p][n], B[p][n] = image(p + tap n)
             // for n < 9, 1 for n = 9 (-> db0): exact fp32.  MFMA e takes pixels 8 g + e: its A operand is element e of the transposed
             // fragment a bf16 product would use
@@ -231,7 +268,7 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
                 auto wg_load = [&](auto Cc) __attribute__((always_inline)) {
                     constexpr int C = decltype(Cc)::value, u = C / 3, v = C % 3;
 #pragma unroll
-                    for (int b = 0; b < 3; ++b) bx[C & 1][b] = tr_frag_x(xs3[u] + 2 * b * FB_XCBS + (v - 1) * 16);
+                    for (int b = 0; b < 3; ++b) bx[C & 1][b] = tr_frag_x(xs3[u] + b * 1024 + (v - 1) * 32);
                 };
                 auto wg_mma = [&](auto Cc) __attribute__((always_inline)) {
                     constexpr int C = decltype(Cc)::value, u = C / 3, v = C % 3;
@@ -279,6 +316,7 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
                 }
             }
             FB_FENCE();
+            __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): this role's only vector-memory operations are the DMAs
             FB_STEP_BARRIER();
         }
         block_partial([&](auto put) {
@@ -314,7 +352,7 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
             for (int v = 0; v < 3; ++v) w1[u][v] = zero4;
         if (!valid) {
 #pragma unroll 1
-            for (int s = 0; s < NSTEP; ++s) FB_STEP_BARRIER();
+            for (int s = 0; s <= NSTEP; ++s) FB_STEP_BARRIER();
         } else {
         const bool edgeL = r0 < 0, edgeR = r0 + FB_W >= W + 1;
         // ---- lane constants: chain operands
@@ -340,10 +378,8 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
         const int lw_a = ring + FB_G3 + 16 + cb_a * FB_CBS + px_a * 16;
 
         // ---- global operands through buffer descriptors (32-bit lane offsets; bit 31 = beyond the descriptor = reads as zero)
-        auto img_base = [&](const TV& t) { return t.base + ((long long)in_ * t.img + (long long)t.cb_off * t.plane) * 16; };
         const unsigned g3_plane = (unsigned)(B.g3.plane * 16), g3_row = (unsigned)B.g3.ws * 16u, g3_org = (unsigned)(B.g3.halo * (B.g3.ws + 1)) * 16u;
         const unsigned gl_plane = (unsigned)(B.glow.plane * 16), gl_row = (unsigned)B.glow.ws * 16u, gl_org = (unsigned)(B.glow.halo * (B.glow.ws + 1)) * 16u;
-        const unsigned x_plane = (unsigned)(B.x.plane * 16), x_rowb = (unsigned)B.x.ws * 16u;
         const __amdgpu_buffer_rsrc_t rs_g3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(img_base(B.g3)), 0, (int)((unsigned)(B.g3.cb_total - B.g3.cb_off) * g3_plane), 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_gl = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(img_base(B.glow)), 0, (int)((unsigned)(B.glow.cb_total - B.glow.cb_off) * gl_plane), 0x00020000);
         const unsigned g3_off = in_a ? (unsigned)cb_a * g3_plane + (unsigned)x_a * 16u + g3_org : 0x80000000u;
@@ -353,29 +389,6 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
             const int c = r0 + 16 * t + j;
             gl_off[t] = (c >= 0 && c < W) ? (unsigned)(g >> 1) * gl_plane + (unsigned)c * 16u + (unsigned)(g & 1) * 8u + gl_org : 0x80000000u;
         }
-        // activation / image rows by LDS-DMA: ring pixel p = image column reflect(r0 + p) (the edge strips' ghost pixels hold the reflected column)
-        const char* x_img = img_base(B.x);
-        const char* im_img = reinterpret_cast<const char*>(B.img + (long long)in_ * H * W);
-        const unsigned xring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem_dma + (unsigned)xring;
-        const unsigned iring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem_dma + (unsigned)iring;
-        const int cdma = min(max(reflect_idx(r0 + (lane & 31), W), 0), W - 1);
-        const unsigned xdma_off = (unsigned)(lane >> 5) * x_plane + (unsigned)cdma * 16u;
-        // (scalar row base + one 32-bit lane offset: no 64-bit lane pointers to keep in -- or spill from -- the vector registers)
-        auto dma16 = [&](const char* sbase, unsigned voff, unsigned lds_dst) __attribute__((always_inline)) {
-            __asm__ volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(lds_dst), "v"(voff), "s"(sbase) : "memory", "m0");
-        };
-        auto dma4 = [&](const char* sbase, unsigned voff, unsigned lds_dst) __attribute__((always_inline)) {
-            __asm__ volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" : : "s"(lds_dst), "v"(voff), "s"(sbase) : "memory", "m0");
-        };
-        const unsigned idma_off = (unsigned)cdma * 4u;
-        auto dma_rows = [&](int y) __attribute__((always_inline)) {   // x0 | x1 | x2 row (3 x 1 KiB) + image row of image row clamp(y)
-            const int yy = (int)crow(y);
-            const char* src = x_img + (unsigned long long)((unsigned)yy * x_rowb);
-            const unsigned dst = xring_lds + (unsigned)(xslot(yy) * FB_XROW);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) dma16(src + (unsigned long long)((unsigned)(2 * i) * x_plane), xdma_off, dst + (unsigned)i * 1024u);
-            if (lane < 32) dma4(im_img + (long long)yy * W * 4, idma_off, iring_lds + (unsigned)((yy & (FB_IS - 1)) * FB_IROW));
-        };
         fb_u32x4 pg3;            // (the g3 row travels one step ahead only: one register set)
         fb_u32x2 pG[3][2];       // C operands of the fresh accumulators of the NEXT step: each layer's pair is re-requested right after this
                                  // step's first k-step of that layer consumed it
@@ -412,8 +425,6 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
             const bool em1 = FAST || (R1 - 1 >= b_lo && R1 - 1 < b_hi), em2 = FAST || (R2 - 1 >= c_lo && R2 - 1 < c_hi),
                        em3 = FAST || (R3 - 1 >= y_lo && R3 - 1 < y_hi);
             const bool wg = !(FB_ABL & 1) && (FAST || (r >= y_lo && r < y_hi));              // dW1, db1 of row r
-            // everything requested before the previous step has landed (the previous step's FB_OPS operations may still be in flight)
-            __builtin_amdgcn_s_waitcnt(0x0f70 | (FB_OPS & 15) | ((FB_OPS >> 4) << 14));
             const int bL1 = lb2 + FB_G3 + (R1 & (FB_S3 - 1)) * FB_ROW;
             const int bL2 = lb4 + (h2 ? FB_G3 + (R2 & (FB_S3 - 1)) * FB_ROW : FB_G2 + (R2 & (FB_S2 - 1)) * FB_ROW);
             const int bL3 = lb4 + (h2 ? FB_G2 + (R3 & (FB_S2 - 1)) * FB_ROW : FB_G1 + (R3 & (FB_S1 - 1)) * FB_ROW);
@@ -457,6 +468,14 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
                     }
                 }
             };
+            // ReLU mask of an epilogue: x(3 - Lc) row rho from the activation ring, read one region ahead of its use
+            uint4 xq;
+            auto mask_load = [&](auto Lc_) __attribute__((always_inline)) {
+                constexpr int Lc = decltype(Lc_)::value;
+                if ((FB_ABL & 4) || !(Lc == 1 ? em1 : (Lc == 2 ? em2 : em3))) return;
+                const int rho = r + FB_RO(Lc) - 1;
+                xq = *reinterpret_cast<const uint4*>(smem_dma + xring + xslot((int)crow(rho)) * FB_XROW + (3 - Lc) * 1024 + px_e * 32 + cb_e * 16);
+            };
             // epilogue of chain layer Lc: out row rho = R - 1 of g(3 - Lc): pair the column tiles, fold the edge columns, round once, ReLU mask
             auto epilogue = [&](auto Lc_) __attribute__((always_inline)) {
                 constexpr int Lc = decltype(Lc_)::value;
@@ -465,8 +484,6 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
                 if (FB_ABL & 4) return;
                 if (!(Lc == 1 ? em1 : (Lc == 2 ? em2 : em3))) return;
                 const int rho = r + FB_RO(Lc) - 1;
-                // mask: x(3 - Lc) row rho from the activation ring
-                const uint4 xq = *reinterpret_cast<const uint4*>(smem_dma + xring + xslot((int)crow(rho)) * FB_XROW + (2 * (3 - Lc) + cb_e) * FB_XCBS + px_e * 16);
                 float c[8];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -474,7 +491,25 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
                     c[q] = __uint_as_float(sw[0]);
                     c[4 + q] = __uint_as_float(sw[1]);
                 }
-                if (edgeL || edgeR) {   // wave-uniform: the adjoint of reflect padding along x (a lane is the target of at most one fold: w >= 4)
+                // the adjoint of reflect padding along x (edge strips; a lane is the target of at most one fold: w >= 4).  Branch-free steps: by
+                // DPP row shifts -- a wave-uniform branch with LDS traffic inside (ds_bpermute) makes the compiler drain the whole LDS queue,
+                // prefetched operands included, at its join; source and target share a 16-lane row there (fold_cross: no branch-free steps)
+                if (FAST) {
+                    if (edgeL) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {      // row_shr:2: lane j <- lane j - 2
+                            const int f = __builtin_amdgcn_update_dpp(0, (int)__float_as_uint(c[i]), 0x112, 0xf, 0xf, false);
+                            c[i] += tgtL ? __uint_as_float((unsigned)f) : 0.f;
+                        }
+                    }
+                    if (edgeR) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {      // row_shl:2: lane j <- lane j + 2
+                            const int f = __builtin_amdgcn_update_dpp(0, (int)__float_as_uint(c[i]), 0x102, 0xf, 0xf, false);
+                            c[i] += tgtR ? __uint_as_float((unsigned)f) : 0.f;
+                        }
+                    }
+                } else if (edgeL || edgeR) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const float f = __shfl(c[i], src_f, 64);
@@ -502,7 +537,7 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
                 constexpr int C = decltype(Cc)::value, u = C / 3, v = C % 3;
                 if (!wg) return;
                 if (C == 0) ag1 = masked_g(ring + FB_G1 + (r & (FB_S1 - 1)) * FB_ROW);
-                bx = tr_frag_x(xring + xslot(rrow(r + u - 1)) * FB_XROW + ltr_x + (v - 1) * 16);
+                bx = tr_frag_x(xring + xslot(rrow(r + u - 1)) * FB_XROW + ltr_x + (v - 1) * 32);
             };
             auto w1_mma = [&](auto Cc) __attribute__((always_inline)) {
                 constexpr int C = decltype(Cc)::value, u = C / 3, v = C % 3;
@@ -524,7 +559,7 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
             FB_FENCE();
             load_k(FBI<7>(), b1); mma_k(FBI<1>(), b2); w1_mma(FBI<1>());
             FB_FENCE();
-            w1_load(FBI<2>()); mma_k(FBI<6>(), b0);
+            w1_load(FBI<2>()); mask_load(FBI<1>()); mma_k(FBI<6>(), b0);
             FB_FENCE();
             epilogue(FBI<1>());
             load_k(FBI<2>(), b2);      // (layer 2 reads the g2 row the epilogue above just wrote)
@@ -541,9 +576,9 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
             FB_FENCE();
             w1_load(FBI<5>()); mma_k(FBI<9>(), b2);
             FB_FENCE();
-            mma_k(FBI<4>(), b0); w1_mma(FBI<5>()); 
+            mask_load(FBI<3>()); mma_k(FBI<4>(), b0); w1_mma(FBI<5>());
             FB_FENCE();
-            w1_load(FBI<6>()); epilogue(FBI<3>());
+            epilogue(FBI<3>()); w1_load(FBI<6>()); mask_load(FBI<2>());
             FB_FENCE();
             w1_mma(FBI<6>()); w1_load(FBI<7>());
             FB_FENCE();
@@ -558,10 +593,7 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
                 const int ya = r + 4;
                 if (FAST || (ya >= a_lo && ya < a_hi)) *reinterpret_cast<fb_u32x4*>(smem + lw_a + (ya & (FB_S3 - 1)) * FB_ROW) = pg3;
             }
-            if (!(FB_ABL & 8)) {
-                request_g3(r + 5);
-                dma_rows(r + 4);
-            }
+            if (!(FB_ABL & 8)) request_g3(r + 5);
             FB_FENCE();
         };
 
@@ -570,15 +602,14 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
         request_g3(r_first + 3);
 #pragma unroll
         for (int Lc = 1; Lc <= 3; ++Lc) request_G(Lc, r_first);
-#pragma unroll 1
-        for (int y = max(r_first - 1, 0); y < r_first + 4; ++y)
-            if (y >= 0) dma_rows(y);
-        __builtin_amdgcn_s_waitcnt(0x0f70);
         if (r_first + 3 >= a_lo && r_first + 3 < a_hi) *reinterpret_cast<fb_u32x4*>(smem + lw_a + ((r_first + 3) & (FB_S3 - 1)) * FB_ROW) = pg3;
+        FB_STEP_BARRIER();      // (the weight-gradient role's prologue rows have landed)
         request_g3(r_first + 4);
         // branch-free steps: every stage active and emitting, no stage at image row 0 / h-1, the g3 row written at the end inside [a_lo, a_hi)
         const int r_end = r_first + NSTEP;
-        const int f_lo = max(y_lo + 2, 1), f_hi = min(min(y_hi, a_hi - 4), H - 4);
+        // (fold_cross: one strip of width 15 / 16 -- the right fold's source and target pixels sit in different 16-lane rows)
+        const bool fold_cross = A.nstrips == 1 && (W == 15 || W == 16);
+        const int f_lo = max(y_lo + 2, 1), f_hi = fold_cross ? f_lo : min(min(y_hi, a_hi - 4), H - 4);
         int r = r_first;
 #pragma unroll 1
         for (int part = 0; part < 2; ++part) {
