@@ -370,6 +370,7 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
         const int srcR = (cb_e * 2 + (min(px_e + 2, FB_W - 1) >> 4)) * 16 + (min(px_e + 2, FB_W - 1) & 15);
         const bool tgtL = edgeL && x_e == 1, tgtR = edgeR && x_e == W - 2;
         const bool tgt_f = tgtL || tgtR;
+        const float mulL = tgtL ? 1.f : 0.f, mulR = tgtR ? 1.f : 0.f;
         const int src_f = tgtL ? srcL : srcR;
         // g3 rows: lane = (pixel lane & 31, channel block lane >> 5)
         const int px_a = lane & 31, cb_a = lane >> 5;
@@ -495,19 +496,16 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
                 // DPP row shifts -- a wave-uniform branch with LDS traffic inside (ds_bpermute) makes the compiler drain the whole LDS queue,
                 // prefetched operands included, at its join; source and target share a 16-lane row there (fold_cross: no branch-free steps)
                 if (FAST) {
+                    // (one fused multiply-add per value and side, its source operand through DPP; the multiplier is the target lanes' 1.0 / 0.0)
                     if (edgeL) {
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) {      // row_shr:2: lane j <- lane j - 2
-                            const int f = __builtin_amdgcn_update_dpp(0, (int)__float_as_uint(c[i]), 0x112, 0xf, 0xf, false);
-                            c[i] += tgtL ? __uint_as_float((unsigned)f) : 0.f;
-                        }
+                        for (int i = 0; i < 8; ++i)      // row_shr:2: lane j <- lane j - 2 (0 where the row has no such lane)
+                            c[i] = fmaf(__uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(c[i]), 0x112, 0xf, 0xf, true)), mulL, c[i]);
                     }
                     if (edgeR) {
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) {      // row_shl:2: lane j <- lane j + 2
-                            const int f = __builtin_amdgcn_update_dpp(0, (int)__float_as_uint(c[i]), 0x102, 0xf, 0xf, false);
-                            c[i] += tgtR ? __uint_as_float((unsigned)f) : 0.f;
-                        }
+                        for (int i = 0; i < 8; ++i)      // row_shl:2: lane j <- lane j + 2
+                            c[i] = fmaf(__uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(c[i]), 0x102, 0xf, 0xf, true)), mulR, c[i]);
                     }
                 } else if (edgeL || edgeR) {
 #pragma unroll
@@ -516,18 +514,20 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
                         c[i] += tgt_f ? f : 0.f;
                     }
                 }
-                // bf16 > 0  <=>  as int16 > 0 (negative zero and negatives are <= 0): max(x, 0) -> min(., 1) -> 0 - . = 0xffff per kept half;
-                // columns outside the image: zero
+                // bf16 > 0  <=>  as int16 > 0 (negative zero and negatives are <= 0): packed max(x, 0) -> min(., 1) -> 0 - . = 0xffff per kept half
+                // (inline asm: the compiler turns the same three vector operations into two compares and two selects per dword); columns
+                // outside the image (edge strips only): zero
                 const uint32_t xw[4] = {xq.x, xq.y, xq.z, xq.w};
                 uint32_t gr[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    fb_s16x2 sv = __builtin_bit_cast(fb_s16x2, xw[i]);
-                    sv = __builtin_elementwise_max(sv, (fb_s16x2){0, 0});
-                    fb_u16x2 uv = __builtin_bit_cast(fb_u16x2, sv);
-                    uv = __builtin_elementwise_min(uv, (fb_u16x2){1, 1});
-                    uv = (fb_u16x2){0, 0} - uv;
-                    gr[i] = pack_bf16x2(c[2 * i], c[2 * i + 1]) & __builtin_bit_cast(uint32_t, uv) & inm_e;
+                    uint32_t m;
+                    __asm__("v_pk_max_i16 %0, %1, 0\n\tv_pk_min_u16 %0, %0, %2\n\tv_pk_sub_u16 %0, 0, %0" : "=&v"(m) : "v"(xw[i]), "s"(0x00010001u));
+                    gr[i] = pack_bf16x2(c[2 * i], c[2 * i + 1]) & m;
+                }
+                if (edgeL || edgeR) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) gr[i] &= inm_e;
                 }
                 *reinterpret_cast<uint4*>(smem + lw_e + XO + (rho & (SO - 1)) * FB_ROW) = make_uint4(gr[0], gr[1], gr[2], gr[3]);
             };
