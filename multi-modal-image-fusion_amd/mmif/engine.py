@@ -572,9 +572,9 @@ class DenseEncoderMixin:
     @staticmethod
     def bwd_fused(branches, F, ws, impl):
         """branches: [(specs, img, fbase, g3 2-block view, glow 6-block view, accumulate), (...)] -- the WHOLE backward of the encoder branches
-        (gradient chain + the four layers' weight gradients) as ONE streaming launch (csrc/enc_bwd.hip, round 5; opt-in with $MMIF_ENC_BWD_FUSED=1 until it beats the
-        chain and weight-gradient launches of rounds 2 / 4 it replaces -- profiles/r05_*).  Returns False when the kernel does not apply (the caller takes the other path)."""
-        if not (switch("MMIF_ENC_BWD_FUSED", "0") and switch("MMIF_ENC_CHAIN") and switch("MMIF_ENC_CHAIN_STREAM") and switch("MMIF_ENC_WGRAD")
+        (gradient chain + the four layers' weight gradients) as ONE streaming launch (csrc/enc_bwd.hip, round 5; $MMIF_ENC_BWD_FUSED=0: the chain and
+        weight-gradient launches of rounds 2 / 4 it replaces -- 0.40 ms against 0.64 ms at the headline size, profiles/r05_*).  Returns False when the kernel does not apply (the caller takes the other path)."""
+        if not (switch("MMIF_ENC_BWD_FUSED") and switch("MMIF_ENC_CHAIN") and switch("MMIF_ENC_CHAIN_STREAM") and switch("MMIF_ENC_WGRAD")
                 and F.dtype == torch.bfloat16 and impl != _lib.IMPL_VALU and F.h >= 4 and F.w >= 4 and F.halo == 0
                 and all(all(s.k == 3 for s in specs) and [(s.cin, s.cout) for s in specs] == [(1, 16), (16, 16), (32, 16), (48, 16)]
                         for specs, *_ in branches)):

@@ -123,7 +123,7 @@ def test_fused_backward_two_branches_accumulate_and_split_gradient_tensors():
 
 @pytest.mark.parametrize("name,single", [("PFNetv1", False), ("VIFNet", False), ("DenseFuse", False), ("DenseFuse", True), ("PFNetv2", False)])
 def test_models_with_the_fused_encoder_backward_match_the_two_kernel_path(name, single):
-    """every engine that owns a DenseBlock encoder, one backward with the fused kernel ($MMIF_ENC_BWD_FUSED=1) and with the
+    """every engine that owns a DenseBlock encoder, one backward with the fused kernel ($MMIF_ENC_BWD_FUSED, the default) and with the
     chain + weight-gradient launches it replaces: identical fused image (the forward is the same), every parameter gradient within the
     summation-order noise of the encoder's weight gradients (the decoder's are bit-identical: nothing upstream of them changed)"""
     import os
