@@ -73,8 +73,9 @@ struct BwdBranch {
 struct BwdArgs {
     BwdBranch br[2];
     int n, h, w;
-    int nstrips, nseg, seg_rows;
-    int items;                 // per branch: n * nseg * nstrips
+    int nstrips;
+    int rows_per_slot;         // rows of the branch's line of n * nstrips * h rows that one wave pair walks
+    int nbarriers;             // barriers every wave executes: an upper bound of (pieces + steps) of a pair
 };
 
 template <int N> struct FBI { static constexpr int value = N; };
@@ -131,39 +132,49 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
     }
     __syncthreads();
 
-    const int item = blockIdx.x * FB_PAIRS + pair;
+    // ---- work split: the branch's (image, strip) columns of h rows form one line of n * nstrips * h rows; wave pair `slot` owns rows
+    // [slot * rows_per_slot, + rows_per_slot) of it -- one or more PIECES (column, [y_lo, y_hi)), walked one after the other with the weight
+    // gradients accumulating in registers across them (one block per CU, one partial sum per block).  Every wave of the block executes the
+    // same number of barriers: its pieces' (1 + steps), then idle ones up to A.nbarriers.
     const int H = A.h, W = A.w;
-    const int strip = item % A.nstrips;
-    const int seg = (item / A.nstrips) % A.nseg;
-    const int in_ = min(item / (A.nstrips * A.nseg), A.n - 1);
-    const int y_lo = seg * A.seg_rows, y_hi = min(H, y_lo + A.seg_rows);
-    const bool valid = item < A.items && y_lo < y_hi;
-    // every wave of the block runs the same number of steps (one barrier each): rows r_first .. y_hi + 1 of the longest segment
-    const int NSTEP = 3 * ((A.seg_rows + 8 + 2) / 3);
-
-    // ---- strip geometry (csrc/enc_chain.hip): region [r0, r0 + 32) of image columns, r0 = -1 for the first strip (column -1 and column w
+    const long long line_rows = (long long)A.n * A.nstrips * H;
+    const long long pos_begin = min(line_rows, (long long)(blockIdx.x * FB_PAIRS + pair) * A.rows_per_slot);
+    const long long pos_end = min(line_rows, pos_begin + A.rows_per_slot);
+    int strip = 0, in_ = 0, y_lo = 0, y_hi = 0, NSTEP = 0;
+    int r0 = 0, o_lo = 0, o_hi = 0, a_lo = 0, a_hi = 0, b_lo = 0, b_hi = 0, c_lo = 0, c_hi = 0, r_first = 0;
+    unsigned km[4] = {0u, 0u, 0u, 0u};          // keep-mask of this lane's 8 pixels 8 g .. 8 g + 7 (two bf16 per dword)
+    // strip geometry (csrc/enc_chain.hip): region [r0, r0 + 32) of image columns, r0 = -1 for the first strip (column -1 and column w
     // belong to the edge strips, which fold them onto columns 1 / w-2); kept columns [o_lo, o_hi)
     auto strip_r0 = [&](int s) { return A.nstrips == 1 ? -1 : min(-1 + FB_KEEP * s, W - (FB_W - 1)); };
     auto strip_hi = [&](int r) { return (r + FB_W >= W + 1) ? W : min(r + FB_W - 3, W - 4); };
-    const int r0 = strip_r0(strip);
-    const int o_hi = strip_hi(r0);
-    const int o_lo = strip == 0 ? 0 : max(r0 + 3, strip_hi(strip_r0(strip - 1)));
-    // rows each stage touches (as csrc/enc_chain.hip): g3 rows [a_lo, a_hi), g2 rows [b_lo, b_hi), g1 rows [c_lo, c_hi), g0 rows [y_lo, y_hi)
-    const int a_lo = max(0, y_lo - 3), a_hi = min(H, y_hi + 3);
-    const int b_lo = max(0, y_lo - 2), b_hi = min(H, y_hi + 2);
-    const int c_lo = max(0, y_lo - 1), c_hi = min(H, y_hi + 1);
-    const int r_first = a_lo - 3;
+    auto set_piece = [&](long long pos) {          // the piece that starts at line position pos; returns the position after it
+        const int col = (int)(pos / H);
+        y_lo = (int)(pos - (long long)col * H);
+        y_hi = (int)min((long long)H, y_lo + (pos_end - pos));
+        strip = col % A.nstrips;
+        in_ = col / A.nstrips;
+        r0 = strip_r0(strip);
+        o_hi = strip_hi(r0);
+        o_lo = strip == 0 ? 0 : max(r0 + 3, strip_hi(strip_r0(strip - 1)));
+        // rows each stage touches (as csrc/enc_chain.hip): g3 rows [a_lo, a_hi), g2 rows [b_lo, b_hi), g1 rows [c_lo, c_hi), g0 rows [y_lo, y_hi)
+        a_lo = max(0, y_lo - 3); a_hi = min(H, y_hi + 3);
+        b_lo = max(0, y_lo - 2); b_hi = min(H, y_hi + 2);
+        c_lo = max(0, y_lo - 1); c_hi = min(H, y_hi + 1);
+        r_first = a_lo - 3;
+        NSTEP = 3 * ((y_hi + 2 - r_first + 2) / 3);      // steps r_first .. y_hi + 1 (the first layer's products trail by two rows), in threes
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int c0 = r0 + 8 * g + 2 * d, c1 = c0 + 1;
+            km[d] = ((c0 >= o_lo && c0 < o_hi) ? 0xffffu : 0u) | ((c1 >= o_lo && c1 < o_hi) ? 0xffff0000u : 0u);
+        }
+        return pos + (y_hi - y_lo);
+    };
+    int nbar = 0;          // barriers executed so far
 
     // ---- lane constants of the transposing reads (weight-gradient operands: in-group lane sl supplies pixel sl >> 2 (+ 4), 4-channel chunk sl & 3)
     const int tr_row = j >> 2, tr_c = j & 3;
     const int ltr = (tr_c >> 1) * FB_CBS + 16 + (8 * g + tr_row) * 16 + (tr_c & 1) * 8;        // gradient rings
     const int ltr_x = (8 * g + tr_row) * 32 + tr_c * 8;                                       // activation ring (pixel-major: 32 B = 16 channels)
-    unsigned km[4];          // keep-mask of this lane's 8 pixels 8 g .. 8 g + 7 (two bf16 per dword)
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-        const int c0 = r0 + 8 * g + 2 * d, c1 = c0 + 1;
-        km[d] = ((c0 >= o_lo && c0 < o_hi) ? 0xffffu : 0u) | ((c1 >= o_lo && c1 < o_hi) ? 0xffff0000u : 0u);
-    }
     auto tr_frag = [&](int addr) __attribute__((always_inline)) {
         const fb_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(FB_LDS_PTR(fb_s16x4, smem + addr));
         const fb_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(FB_LDS_PTR(fb_s16x4, smem + addr + 64));
@@ -218,6 +229,9 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
 #pragma unroll
         for (int i = 0; i < 3; ++i) accb[i] = zero4;
         const unsigned x_plane = (unsigned)(B.x.plane * 16), x_rowb = (unsigned)B.x.ws * 16u;
+#pragma unroll 1
+        for (long long pos = pos_begin; pos < pos_end;) {
+        pos = set_piece(pos);
         // activation / image rows by LDS-DMA (this role has the slack to issue them and to wait for them): ring pixel p = image column reflect(r0 + p) (the edge strips' ghost pixels hold the reflected column)
         const char* x_img = img_base(B.x);
         const char* im_img = reinterpret_cast<const char*>(B.img + (long long)in_ * H * W);
@@ -244,7 +258,7 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
         };
         // prologue: rows r_first - 1 .. r_first + 3 (step r requests row r + 4 at its start and has it landed at its barrier: the chain waves
         // first touch row r + 4 in step r + 2)
-        if (valid && !(FB_ABL & 8)) {
+        if (!(FB_ABL & 8)) {
 #pragma unroll 1
             for (int y = max(r_first - 1, 0); y < r_first + 4; ++y)
                 if (y >= 0) dma_rows(y);
@@ -254,12 +268,12 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
 #pragma unroll 1
         for (int s = 0; s < NSTEP; ++s) {
             const int r = r_first + s;
-            if (valid && !(FB_ABL & 8)) dma_rows(r + 4);
+            if (!(FB_ABL & 8)) dma_rows(r + 4);
             // first layer, row r - 2 (g0 row r - 2 left the chain in step r - 1): D[o][n] += sum_p g0[o](p) B[p][n], B[p][n] = image(p + tap n)
             // for n < 9, 1 for n = 9 (-> db0): exact fp32.  MFMA e takes pixels 8 g + e: its A operand is element e of the transposed
             // fragment a bf16 product would use
-            const bool l0 = !(FB_ABL & 16) && valid && r - 2 >= y_lo && r - 2 < y_hi;
-            if (!(FB_ABL & 1) && valid && r >= y_lo && r < y_hi) {
+            const bool l0 = !(FB_ABL & 16) && r - 2 >= y_lo && r - 2 < y_hi;
+            if (!(FB_ABL & 1) && r >= y_lo && r < y_hi) {
                 fb_bf16x8 ag2 = masked_g(ring + FB_G2 + (r & (FB_S2 - 1)) * FB_ROW), ag3 = masked_g(ring + FB_G3 + (r & (FB_S3 - 1)) * FB_ROW);
                 int xs3[3];
 #pragma unroll
@@ -316,9 +330,15 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
                 }
             }
             FB_FENCE();
-            __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): this role's only vector-memory operations are the DMAs
+            // the rows requested in the PREVIOUS step have landed (this role's only vector-memory operations are the DMAs, four per step:
+            // row r + 4 is requested at the start of step r, published by the barrier of step r + 1, first touched by the chain in step r + 2)
+            __builtin_amdgcn_s_waitcnt(0x0f70 | 4);
             FB_STEP_BARRIER();
         }
+        nbar += 1 + NSTEP;
+        }
+#pragma unroll 1
+        for (; nbar < A.nbarriers; ++nbar) FB_STEP_BARRIER();
         block_partial([&](auto put) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) put(EW_OFF0 + (4 * g + q) * 16 + j, acc0[q]);
@@ -350,10 +370,9 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
         for (int u = 0; u < 3; ++u)
 #pragma unroll
             for (int v = 0; v < 3; ++v) w1[u][v] = zero4;
-        if (!valid) {
 #pragma unroll 1
-            for (int s = 0; s <= NSTEP; ++s) FB_STEP_BARRIER();
-        } else {
+        for (long long pos = pos_begin; pos < pos_end;) {
+        pos = set_piece(pos);
         const bool edgeL = r0 < 0, edgeR = r0 + FB_W >= W + 1;
         // ---- lane constants: chain operands
         const int h2 = g >> 1, cbk = g & 1;
@@ -629,7 +648,10 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
                 }
             }
         }
+        nbar += 1 + NSTEP;
         }
+#pragma unroll 1
+        for (; nbar < A.nbarriers; ++nbar) FB_STEP_BARRIER();
         block_partial([&](auto put) {
 #pragma unroll
             for (int u = 0; u < 3; ++u)
@@ -643,7 +665,8 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
 #undef FB_FENCE
 #undef FB_RO
 
-static void fb_geometry(int n, int h, int w, int nb, int& nstrips, int& nseg, int& seg_rows) {
+// one block per CU (and branch): the line of n * nstrips * h rows in equal slices of at least 8 rows
+static void fb_geometry(int n, int h, int w, int nb, int& nstrips, int& rows_per_slot, int& nbarriers, int& nblocks) {
     nstrips = w <= FB_W - 2 ? 1 : (w - (FB_W - 2) + FB_KEEP - 1) / FB_KEEP + 1;
     int ncu = 256;
     {
@@ -651,17 +674,13 @@ static void fb_geometry(int n, int h, int w, int nb, int& nstrips, int& nseg, in
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
     }
-    long long best = -1;
-    nseg = 1;
-    for (int k = 1; k <= (h + 7) / 8; ++k) {
-        const int rows = (h + k - 1) / k;
-        const long long blocks = (long long)nb * (((long long)n * nstrips * k + FB_PAIRS - 1) / FB_PAIRS);
-        if (blocks / nb > EW_MAXG / 2) break;        // (block partials of both branches share one workspace of EW_MAXG slots)
-        const long long cost = ((blocks + ncu - 1) / ncu) * (rows + 8);
-        if (best < 0 || cost < best) { best = cost; nseg = k; }
-    }
-    seg_rows = (h + nseg - 1) / nseg;
-    nseg = (h + seg_rows - 1) / seg_rows;
+    const long long rows = (long long)n * nstrips * h;
+    const int gmax = std::max(1, std::min(ncu / nb, EW_MAXG / 2));          // (block partials of both branches share one workspace of EW_MAXG slots)
+    rows_per_slot = (int)std::max<long long>(8, (rows + (long long)gmax * FB_PAIRS - 1) / ((long long)gmax * FB_PAIRS));
+    nblocks = (int)((rows + (long long)rows_per_slot * FB_PAIRS - 1) / ((long long)rows_per_slot * FB_PAIRS));
+    // a pair's pieces: at most one per started column of its slice, + 1 for the split one; a piece of k rows takes 1 + (k + 8 rounded up to 3) barriers
+    const int pieces = (rows_per_slot + h - 1) / h + 1;
+    nbarriers = rows_per_slot + pieces * 11;
 }
 
 }  // namespace mmif
@@ -708,9 +727,8 @@ extern "C" int mmif_dense_encoder_bwd(const mmif_dense_chain* chain_a, const flo
     BwdArgs A;
     memset(&A, 0, sizeof(A));
     A.n = chain_a->x->n; A.h = chain_a->x->h; A.w = chain_a->x->w;
-    fb_geometry(A.n, A.h, A.w, nb, A.nstrips, A.nseg, A.seg_rows);
-    A.items = A.n * A.nseg * A.nstrips;
-    const int G = cdiv(A.items, FB_PAIRS);
+    int G = 0;
+    fb_geometry(A.n, A.h, A.w, nb, A.nstrips, A.rows_per_slot, A.nbarriers, G);
     MMIF_REQUIRE(nb * G <= EW_MAXG, "dense_encoder_bwd: too many blocks for the partial-sum workspace");
     for (int b = 0; b < nb; ++b) {
         const mmif_dense_chain* c = b ? chain_b : chain_a;
