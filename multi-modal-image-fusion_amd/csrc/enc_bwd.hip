@@ -142,7 +142,7 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
     const long long pos_end = min(line_rows, pos_begin + A.rows_per_slot);
     int strip = 0, in_ = 0, y_lo = 0, y_hi = 0, NSTEP = 0;
     int r0 = 0, o_lo = 0, o_hi = 0, a_lo = 0, a_hi = 0, b_lo = 0, b_hi = 0, c_lo = 0, c_hi = 0, r_first = 0;
-    unsigned km[4] = {0u, 0u, 0u, 0u};          // keep-mask of this lane's 8 pixels 8 g .. 8 g + 7 (two bf16 per dword)
+    unsigned km[4] = {0u, 0u, 0u, 0u};          // keep-mask of this lane's 8 pixels (the K order below; two bf16 per dword)
     // strip geometry (csrc/enc_chain.hip): region [r0, r0 + 32) of image columns, r0 = -1 for the first strip (column -1 and column w
     // belong to the edge strips, which fold them onto columns 1 / w-2); kept columns [o_lo, o_hi)
     auto strip_r0 = [&](int s) { return A.nstrips == 1 ? -1 : min(-1 + FB_KEEP * s, W - (FB_W - 1)); };
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
         NSTEP = 3 * ((y_hi + 2 - r_first + 2) / 3);      // steps r_first .. y_hi + 1 (the first layer's products trail by two rows), in threes
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
-            const int c0 = r0 + 8 * g + 2 * d, c1 = c0 + 1;
+            const int c0 = r0 + (d < 2 ? 4 * g + 2 * d : 16 + 4 * g + 2 * (d - 2)), c1 = c0 + 1;
             km[d] = ((c0 >= o_lo && c0 < o_hi) ? 0xffffu : 0u) | ((c1 >= o_lo && c1 < o_hi) ? 0xffff0000u : 0u);
         }
         return pos + (y_hi - y_lo);
@@ -173,16 +173,20 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
 
     // ---- lane constants of the transposing reads (weight-gradient operands: in-group lane sl supplies pixel sl >> 2 (+ 4), 4-channel chunk sl & 3)
     const int tr_row = j >> 2, tr_c = j & 3;
-    const int ltr = (tr_c >> 1) * FB_CBS + 16 + (8 * g + tr_row) * 16 + (tr_c & 1) * 8;        // gradient rings
-    const int ltr_x = (8 * g + tr_row) * 32 + tr_c * 8;                                       // activation ring (pixel-major: 32 B = 16 channels)
+    // K order of the weight-gradient products (any bijection pixel <-> k works as long as both operands use it): k = 8 g + e is pixel
+    // 4 g + e for e < 4 and 16 + 4 g + (e - 4) for e >= 4 -- the 64 lanes of one transposing read then cover 16 CONSECUTIVE pixels (512
+    // contiguous bytes of the pixel-major activation ring; lane groups 256 B apart shared their banks: a third of the LDS cycles of the
+    // first version were bank conflicts), the second read of a fragment the other 16
+    const int ltr = (tr_c >> 1) * FB_CBS + 16 + (4 * g + tr_row) * 16 + (tr_c & 1) * 8;        // gradient rings
+    const int ltr_x = (4 * g + tr_row) * 32 + tr_c * 8;                                       // activation ring (pixel-major: 32 B = 16 channels)
     auto tr_frag = [&](int addr) __attribute__((always_inline)) {
         const fb_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(FB_LDS_PTR(fb_s16x4, smem + addr));
-        const fb_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(FB_LDS_PTR(fb_s16x4, smem + addr + 64));
+        const fb_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(FB_LDS_PTR(fb_s16x4, smem + addr + 256));
         return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     };
     auto tr_frag_x = [&](int addr) __attribute__((always_inline)) {
         const fb_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(FB_LDS_PTR(fb_s16x4, smem_dma + addr));
-        const fb_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(FB_LDS_PTR(fb_s16x4, smem_dma + addr + 128));
+        const fb_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(FB_LDS_PTR(fb_s16x4, smem_dma + addr + 512));
         return __builtin_bit_cast(fb_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     };
     auto masked_g = [&](int addr) __attribute__((always_inline)) {      // one gradient row, k-major, pixels outside the kept columns zeroed
@@ -270,7 +274,7 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
             const int r = r_first + s;
             if (!(FB_ABL & 8)) dma_rows(r + 4);
             // first layer, row r - 2 (g0 row r - 2 left the chain in step r - 1): D[o][n] += sum_p g0[o](p) B[p][n], B[p][n] = image(p + tap n)
-            // for n < 9, 1 for n = 9 (-> db0): exact fp32.  MFMA e takes pixels 8 g + e: its A operand is element e of the transposed
+            // for n < 9, 1 for n = 9 (-> db0): exact fp32.  MFMA e takes the pixels of k = 8 g + e (K order above): its A operand is element e of the transposed
             // fragment a bf16 product would use
             const bool l0 = !(FB_ABL & 16) && r - 2 >= y_lo && r - 2 < y_hi;
             if (!(FB_ABL & 1) && r >= y_lo && r < y_hi) {
@@ -317,10 +321,10 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
             }
             if (l0) {     // (operands read here, not ahead: this role has the slack, not the registers)
                 const fb_u32x4 l0g = __builtin_bit_cast(fb_u32x4, tr_frag(ring + FB_G0 + ((r - 2) & (FB_S0 - 1)) * FB_ROW + ltr));
-                const int ib = iring + (rrow(r - 2 + un - 1) & (FB_IS - 1)) * FB_IROW + (vn - 1) * 4 + 32 * g;
+                const int ib = iring + (rrow(r - 2 + un - 1) & (FB_IS - 1)) * FB_IROW + (vn - 1) * 4 + 16 * g;      // (pixel 4 g + e | 16 + 4 g + e - 4)
                 float l0i[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) l0i[e] = *reinterpret_cast<const float*>(smem_dma + ib + e * 4);
+                for (int e = 0; e < 8; ++e) l0i[e] = *reinterpret_cast<const float*>(smem_dma + ib + (e < 4 ? e * 4 : 64 + (e - 4) * 4));
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const uint32_t w = l0g[e >> 1] & km[e >> 1];
