@@ -193,7 +193,10 @@ __global__ __launch_bounds__(256) void image_out_fwd_tiled_kernel(TV tx, const f
                                                                   float* __restrict__ img, int relu, int tiles_x) {
     constexpr int TP = ITILE + 2;
     constexpr int GU = Elem<T>::gran_bytes / 16;   // uint4 per granule
-    __shared__ __attribute__((aligned(16))) uint4 s_x[2][TP * TP * GU];
+    // rows of 32 granules (512 B): ds_read_b128 serves the wave's four 16-pixel rows in lane groups that mix two rows; a row stride that
+    // is a multiple of 256 B keeps each group on 64 distinct banks (the natural 18-granule stride made half of them 2-way conflicts)
+    constexpr int TS = 32;
+    __shared__ __attribute__((aligned(16))) uint4 s_x[2][TP * TS * GU];
     const int tid = threadIdx.x;
     const int x0 = (blockIdx.x % tiles_x) * ITILE, y0 = (blockIdx.x / tiles_x) * ITILE;
     const int in_ = blockIdx.y;
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(256) void image_out_fwd_tiled_kernel(TV tx, const f
         const int x = min(max(reflect_idx(x0 + p % TP - 1, tx.w), 0), tx.w - 1);
         const uint4* src = reinterpret_cast<const uint4*>(tx.base + tx.gidx(in_, b, y, x) * Elem<T>::gran_bytes);
 #pragma unroll
-        for (int q = 0; q < GU; ++q) s_x[b][p * GU + q] = src[q];
+        for (int q = 0; q < GU; ++q) s_x[b][((p / TP) * TS + p % TP) * GU + q] = src[q];
     }
     float wr[16][9];
 #pragma unroll
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(256) void image_out_fwd_tiled_kernel(TV tx, const f
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             float v[8];
-            Elem<T>::load(&s_x[b][((tyy + t / 3) * TP + txx + t % 3) * GU], v);
+            Elem<T>::load(&s_x[b][((tyy + t / 3) * TS + txx + t % 3) * GU], v);
 #pragma unroll
             for (int i = 0; i < 8; ++i) r = fmaf(v[i], wr[b * 8 + i][t], r);
         }

@@ -328,8 +328,11 @@ __global__ __launch_bounds__(256) void grad_loss_kernel(const float* __restrict_
                                                         const float* __restrict__ f, int H, int W, float gscale,
                                                         int mode_max, int l2, float* __restrict__ grad,
                                                         float* __restrict__ partial, int tiles_x, int accum) {
-    __shared__ float in[3][GIN][GIN + 1];
-    __shared__ float dx[GD][GD + 1], dy[GD][GD + 1];
+    // row strides by the LDS banking of ds_read_b32 (two 32-lane groups, bank = dword index mod 32): the Sobel pass walks 20-wide rows with
+    // consecutive lanes -- a stride = 20 (mod 32) keeps the 32 lanes of a group on 32 distinct banks across the row change (52 floats);
+    // the adjoint pass reads 16-wide rows, two per group -- stride = 16 (mod 32) (48 floats).  (23 / 21 made every read a 2-way conflict.)
+    __shared__ float in[3][GIN][52];
+    __shared__ float dx[GD][48], dy[GD][48];
     __shared__ float red[16];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const int x0 = (blockIdx.x % tiles_x) * LT, y0 = (blockIdx.x / tiles_x) * LT;
