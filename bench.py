@@ -158,7 +158,7 @@ def measured_traffic(tag, match):
     return ent, f"profiles/{TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, lib {tj['lib_sha256'][:12]})"
 
 
-TRAFFIC_FILE = "r04_traffic.json"
+TRAFFIC_FILE = "r05_traffic.json"
 KIND_KERNEL_BF16 = {"fwd": "conv_dma_kernel<false>", "dgrad": "conv_dma_kernel<true> (ReLU sign bytes, in-tile reflect fold)",
                     "wgrad": "wgrad_dma_kernel + wgrad_dma_reduce"}
 KIND_KERNEL_FP32 = {"fwd": "conv_x3_kernel<fwd>", "dgrad": "conv_x3_kernel<dgrad> + fold", "wgrad": "wgrad_x3_kernel + wgrad_x3_reduce"}
@@ -418,6 +418,8 @@ def main():
     if hbm_tag == "auto":   # the encoder: ONE streaming launch for its 2 x 4 layers, or (layer-wise) its widest thin layer 48 -> 16
         hbm_tag = "encode:fwd" if enc_stream else ({"PFNetv1": "encode1.1.2:fwd", "DenseFuse": "encode.1.2:fwd", "PFNetv2": "encode.1.2:fwd", "VIFNet": "encode.1.2:fwd"}.get(args.model, "") if args.mode == "train" else "")
     tags = {f"{args.roofline_layer}:{k}" for k in ("fwd", "dgrad", "wgrad")} | ({hbm_tag} if hbm_tag else set())
+    if hbm_tag == "encode:fwd" and args.mode == "train":
+        tags |= {"encode:bwd"}      # the fused encoder backward (csrc/enc_bwd.hip), when the engine takes it
     every = args.roofline_every if args.roofline_every > 0 else max(1, min(8, args.steps // 5))
     T.PROFILE_TAGS = set()
     T.PROFILE_EVENTS.clear()
@@ -463,7 +465,7 @@ def main():
                 fused = float(B) * S * Wd * nbr * (4 + 64 * 2)
                 ent, src = measured_traffic(hbm_tag, workload_id)
                 moved = ent["hbm_bytes_per_launch"] if ent else fused
-                roof_hbm = {"bound": "hbm", "kernel": f"enc_stream_fwd_kernel {nbr} x (1->16, 16->16, 32->16, 48->16) k3 (encode:fwd)",
+                roof_hbm = {"bound": "hbm", "kernel": f"enc_stream2_fwd_kernel {nbr} x (1->16, 16->16, 32->16, 48->16) k3 (encode:fwd)",
                             "achieved": moved / (ms * 1e-3) / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": moved / (ms * 1e-3) / PEAK_HBM,
                             "avg_launch_ms": ms, "launches": len(evh), "traffic": ent["hbm_bytes_per_launch"] if ent else None, "traffic_source": src,
                             "fused_bytes": fused, "algorithmic_bytes_layerwise": nbytes, "equivalent_layerwise_GBps": nbytes / (ms * 1e-3) / 1e9}
@@ -476,6 +478,21 @@ def main():
                             "achieved": nbytes / (ms * 1e-3) / 1e9,
                             "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": nbytes / (ms * 1e-3) / PEAK_HBM, "avg_launch_ms": ms,
                             "launches": len(evh), "traffic": ent["hbm_bytes_per_launch"] if ent else None, "traffic_source": src, "algorithmic_bytes": nbytes}
+        roof_hbm_bwd = None
+        evb = T.PROFILE_EVENTS.get("encode:bwd", [])
+        if evb:
+            # bytes the launch moves: per branch the incoming gradient G (64 planes) and x0..x2 (48 planes) in bf16, the fp32 image; nothing
+            # written but one partial sum per block.  The two launches it replaces moved 2.4 GB
+            ms = sum(a.elapsed_time(b) for a, b in evb) / len(evb)
+            nbr = 2
+            moved_alg = float(B) * S * Wd * nbr * (4 + (64 + 48) * 2)
+            ent, src = measured_traffic("encode:bwd", workload_id)
+            moved = ent["hbm_bytes_per_launch"] if ent else moved_alg
+            roof_hbm_bwd = {"bound": "hbm", "kernel": "enc_bwd_fused_kernel 2 x (gradient chain + dW, db of 1->16, 16->16, 32->16, 48->16) (encode:bwd)",
+                            "achieved": moved / (ms * 1e-3) / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": moved / (ms * 1e-3) / PEAK_HBM,
+                            "avg_launch_ms": ms, "launches": len(evb), "traffic": ent["hbm_bytes_per_launch"] if ent else None, "traffic_source": src,
+                            "algorithmic_bytes": moved_alg,
+                            "note": "LDS / issue bound, not bandwidth bound: 133 MFMA per 32-pixel row step and wave pair (DESIGN section 4)"}
         ideal = ideal_pairs_per_s(args.model, S, Wd, args.dtype, 3 if args.dtype == "fp32" else 1) if args.mode == "train" else None
         out = {
             "metric": "image-pairs/sec at 256x256, PFNet train step" if args.mode == "train" else f"image-pairs/sec at {Wd}x{S}, {args.model} inference", "value": value, "unit": "image-pairs/s",
@@ -496,6 +513,7 @@ def main():
             "roofline_sampling": {"every_nth_timed_step": every, "timed_steps": args.steps,
                                   "note": "HIP events around the named launches, recorded inside the timed region on every n-th step"},
             "roofline_hbm": roof_hbm,
+            "roofline_hbm_bwd": roof_hbm_bwd,
             "parity_path": None,
             "cpu_baseline": None,
         }

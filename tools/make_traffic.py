@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/r04_traffic.json from the two TCC counter passes of tools/prof_pmc.sh (run on the GPU box, repo root):
+"""profiles/<tag>_traffic.json from the two TCC counter passes of tools/prof_pmc.sh (run on the GPU box, repo root):
     tools/make_traffic.py <tag> > gpurun_out/traffic_<tag>.json
 HBM bytes per launch of the roofline kernels of the default bench (PFNetv1 train B=32 256x256 bf16): decode.0's forward
 (conv_dma_kernel<false, 0>: decode.0 and decode.1 alternate per step; decode.0 is the launch with the larger WRITE_SIZE), its dgrad and
@@ -46,15 +46,20 @@ def pick_larger_fetch(sub):
 
 
 dg, wg = pick_larger_fetch("conv_dma_kernel<true"), pick_larger_fetch("wgrad_dma_kernel")
-fe, we = per_dispatch("FETCH_SIZE", "enc_stream_fwd_kernel"), per_dispatch("WRITE_SIZE", "enc_stream_fwd_kernel")
+fe, we = per_dispatch("FETCH_SIZE", "enc_stream2_fwd_kernel"), per_dispatch("WRITE_SIZE", "enc_stream2_fwd_kernel")
+fb, wb = per_dispatch("FETCH_SIZE", "enc_bwd_fused_kernel"), per_dispatch("WRITE_SIZE", "enc_bwd_fused_kernel")
 B, S = 32, 256
 out = {"workload": "PFNetv1 train B=32 256x256 bf16", "lib_sha256": h,
        "command": f"tools/prof_pmc.sh {tag}: rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separately, WRITE_SIZE) --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity-path",
        "kernels": {
            "decode.0:fwd": entry("conv_dma_kernel<false, 0> 128->128 k3 (decode.0 forward)", f0, w0, float(B) * S * S * 256 * 2),
-           "encode:fwd": entry("enc_stream_fwd_kernel, both encoder branches", fe, we, float(B) * S * S * 2 * (4 + 64 * 2),
+           "encode:fwd": entry("enc_stream2_fwd_kernel<2>, both encoder branches", fe, we, float(B) * S * S * 2 * (4 + 64 * 2),
                                "; the image loads are 4 B/lane (uncalibrated width): counted like the 16-B reads, an upper bound"),
        }}
+if fb and wb:
+    # the fused encoder backward reads G (64 planes) + x0..x2 (48) per branch as bf16 and the fp32 image, writes one partial per block
+    out["kernels"]["encode:bwd"] = entry("enc_bwd_fused_kernel, both encoder branches (gradient chain + dW, db of the four layers)", fb, wb,
+                                         float(B) * S * S * 2 * (4 + (64 + 48) * 2))
 if dg:
     out["kernels"]["decode.0:dgrad"] = entry("conv_dma_kernel<true, 2> 128->128 k3 (decode.0 input gradient, sign bytes)", dg[0], dg[1], float(B) * S * S * 256 * 2)
 if wg:

@@ -11,7 +11,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   csv=$(find gpurun_out/pmc_${tag}_$c -name "*counter_collection.csv" | head -1)
   python3 tools/pmc_stats.py $csv > gpurun_out/pmc_${tag}_$c.txt
   python3 tools/pmc_per_dispatch.py $csv "conv_dma_kernel<false" > gpurun_out/pmc_${tag}_${c}_decode_fwd.txt
-  python3 tools/pmc_per_dispatch.py $csv "enc_stream_fwd_kernel" > gpurun_out/pmc_${tag}_${c}_enc_stream.txt
+  python3 tools/pmc_per_dispatch.py $csv "enc_stream2_fwd_kernel" > gpurun_out/pmc_${tag}_${c}_enc_stream.txt
   head -12 gpurun_out/pmc_${tag}_$c.txt
   python3 tools/make_traffic.py ${tag} > gpurun_out/${tag}_traffic.json 2>/dev/null || true
 done
