@@ -5,22 +5,27 @@
 // (csrc/enc_wgrad.hip, round 2) from the same rows while they are in LDS.
 //
 // The two-kernel form moves 288 channel planes per branch through HBM: the chain reads G (64) + the masks x0..x2 (48) and WRITES
-// [g0 | g1 | g2 | g3] (64), the weight-gradient pass reads them back (64) with x0..x2 (48) again -- 0.65 ms of the 3.7 ms PFNetv1
-// step at ~4 TB/s, i.e. bandwidth bound.  The gradients g0..g2 have no other consumer.  Here a wave owns a strip of 32 columns of one
-// image segment and walks down its rows; per row step r it
-//   * takes g3 row r+3 (registers -> LDS ring) and runs the chain in INPUT-STATIONARY form (csrc/enc_stream2.hip): input row R feeds
-//     the three tap rows at once -- out[R+1] (fresh accumulator, its C operand = the incoming gradient G of that row), out[R],
-//     out[R-1] (complete) -- layer 1 on g3 row r+3 -> g2 row r+2, layer 2 on [g2 | g3] row r+2 -> g1 row r+1, layer 3 on
-//     [g1 | g2 | g3] row r+1 -> g0 row r; epilogue = the round-4 kernel's (column fold of the padded-domain halo by a cross-lane add,
-//     ReLU mask from x, one rounding), the rows stay in small LDS rings (4 / 4 / 2 / 1 slots);
-//   * forms the weight-gradient products of row r: dW_L[o][c][u][v] += sum_px gL[o](r, px) x_in[c](R(r+u-1), px+v-1), K = the strip's 32
-//     pixels = ONE k-step, both operands k-major through transposing LDS reads (ds_read_b64_tr_b16): 54 bf16 MFMAs into 54 accumulator
-//     tiles that live in the wave's registers for the whole strip (216 of its 512: one wave per SIMD), the first layer against the
-//     fp32 image on the exact fp32 matrix path, the bias sums as products with a ones operand.
-// The activations x0..x2 and the image rows come in by LDS-DMA (a ring of 6 rows, requested two steps ahead); the ReLU masks of the
-// chain are read from the same ring.  HBM traffic: G (64 planes) + x (48) + the image, NOTHING written but one partial sum per block.
-// Pixels are counted once: the weight-gradient operand of gL is zeroed outside the strip's kept columns, rows outside the segment are
-// skipped; strips / segments recompute their margins (3 columns / rows).
+// [g0 | g1 | g2 | g3] (64), the weight-gradient pass reads them back (64) with x0..x2 (48) again.  The gradients g0..g2 have no other
+// consumer.  Here they never leave the chip.  A wave needs 216 weight-gradient accumulator registers next to the chain's 72 + operands:
+// too much for one wave -- so the work of a 32-column strip is split over a PAIR of waves on the same SIMD (warp specialisation; a block is
+// four pairs: wave p = role A, wave p + 4 = role B, 256 registers each):
+//   role A  walks down the strip's rows; per row step r it takes g3 row r+4 (registers -> LDS ring) and runs the chain in INPUT-STATIONARY
+//           form (csrc/enc_stream2.hip): input row R of a layer feeds the three tap rows at once -- out[R+1] (fresh accumulator, its C operand
+//           = the incoming gradient G of that row), out[R], out[R-1] (complete) -- layer 1 on g3 row r+3 -> g2 row r+2, layer 2 on [g2 | g3]
+//           row r+2 -> g1 row r+1, layer 3 ONE STEP BEHIND on [g1 | g2 | g3] row r -> g0 row r-1 (its operands are a step old: its k-steps
+//           fill the latencies of the dependent pair); epilogue = tile pairing by v_permlane16_swap, column fold of the padded-domain halo
+//           (DPP row shift + FMA in edge strips), ReLU mask from x, one rounding; the rows stay in LDS rings (4 / 4 / 2 / 2 slots).  It also
+//           forms dW1 (g1 row r against x0 rows r-1 .. r+1: nine MFMAs per step).
+//   role B  forms dW3, dW2, the bias sums and the first layer's gradients: dW_L[o][c][u][v] += sum_px gL[o](r, px) x_in[c](R(r+u-1), px+v-1),
+//           K = the strip's 32 pixels = ONE k-step, both operands k-major through transposing LDS reads (ds_read_b64_tr_b16); the first layer
+//           against the fp32 image on the exact fp32 matrix path, two rows behind (g0 row r-2 left the chain in step r-1).  It also issues
+//           the LDS-DMA of the activation / image rows (ring of 6 / 8 rows) and waits for them: it has the slack.
+// One s_barrier per row step couples the roles: everything a role reads was written at least one barrier earlier (table in DESIGN.md 4.1).
+// One block per CU: the branch's (image, strip) columns form one line of rows cut into equal slices; a pair walks its slice in pieces, the
+// weight gradients accumulate in registers across pieces; one partial sum per block, finished by enc_wgrad_reduce in fixed order.
+// HBM traffic: G (64 planes) + x (48) + the image, NOTHING written but the block partials.  Pixels are counted once: the weight-gradient
+// operand of gL is zeroed outside the strip's kept columns, rows outside the piece are skipped; strips / pieces recompute their margins
+// (3 columns / rows).
 #include "enc_wgrad.hpp"
 #include <stdlib.h>
 #pragma clang diagnostic ignored "-Winline-asm"   // (the LDS-DMA asm names m0 in its clobber list: "reserved register")
