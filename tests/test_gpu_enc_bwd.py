@@ -20,7 +20,10 @@ from gpu_util import bf16_round, close
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
-SHAPES = [(2, 37, 53), (1, 16, 16), (1, 4, 4), (2, 5, 31), (1, 9, 30), (3, 64, 29), (1, 33, 32), (1, 20, 57), (2, 40, 256), (1, 300, 64), (1, 7, 4), (2, 128, 130)]
+SHAPES = [(2, 37, 53), (1, 16, 16), (1, 4, 4), (2, 5, 31), (1, 9, 30), (3, 64, 29), (1, 33, 32), (1, 20, 57), (2, 40, 256), (1, 300, 64), (1, 7, 4), (2, 128, 130),
+          # one block per CU walks a slice of the (image, strip) rows in pieces: many short columns per slice (h small, n large), a slice that
+          # starts and ends inside a column, the reference's test frame (1024 x 1224: 47 strips), widths whose right fold crosses a 16-lane row
+          (32, 8, 40), (5, 64, 64), (1, 515, 1224), (3, 100, 15), (2, 61, 16), (7, 19, 83)]
 
 
 def _setup(n, h, w, seed):
