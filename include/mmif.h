@@ -442,6 +442,8 @@ int mmif_dense_encoder_wgrad(const float* img, const mmif_tensor* x, const mmif_
  * (sizes mmif_packed_weight_bytes(16 (3 - k), 16, 3)) from the fp32 weights w1 [16][16][3][3], w2 [16][32][3][3], w3 [16][48][3][3]. */
 int mmif_pack_dense_chain(const float* w1, const float* w2, const float* w3, void* packed_v0, void* packed_v1, void* packed_v2,
                           void* stream);
+/* Both encoder branches of a two-encoder model (PFNetv1: `core/model.py:73-80` twice) in ONE launch: w_x = {w1, w2, w3}, packed_x = {v0, v1, v2}. */
+int mmif_pack_dense_chain_pair(const float* const* w_a, void* const* packed_a, const float* const* w_b, void* const* packed_b, void* stream);
 /* The whole chain as ONE streaming launch (csrc/enc_chain.hip, bf16): a line-buffer pipeline like mmif_dense_encoder_fwd's, walking down the
  * image -- g2 = [x2 > 0](G2 + A32 g3), g1 = [x1 > 0](G1 + A21 g2 + A31 g3), g0 = [x0 > 0](G0 + A10 g1 + A20 g2 + A30 g3) with the adjoint of
  * reflect padding applied in place (rows 1 / h-2: a second k-loop pass; columns: the edge strips carry columns -1 / w and fold them with one

@@ -2715,8 +2715,10 @@ extern "C" int mmif_pack_weights_multi(const mmif_pack_job* jobs, int32_t n_jobs
 // per destination (accumulate onto G_k + ReLU mask in the epilogue, fp32 sum of all contributions, ONE bf16 rounding) instead of
 // read-modify-write passes over the lower blocks.  This kernel writes the three virtual layers' dgrad operand images.
 struct ChainSrc { const float* w[3]; bf16_t* dst[3]; long long total[3]; };
-__global__ void pack_dense_chain_kernel(ChainSrc S) {
-    const int k = blockIdx.y;                       // destination x_k; virtual cout = 16 (3 - k), cin = 16
+struct ChainSrc2 { ChainSrc s[2]; };          // two encoder branches in one launch (blockIdx.y = 3 * branch + k)
+__global__ void pack_dense_chain_kernel(ChainSrc2 S2) {
+    const ChainSrc& S = S2.s[blockIdx.y / 3];
+    const int k = blockIdx.y % 3;                   // destination x_k; virtual cout = 16 (3 - k), cin = 16
     const int n_in = 16 * (3 - k), ncb = 2 * (3 - k);
     const long long total = S.total[k];
     (void)n_in;
@@ -2752,8 +2754,27 @@ extern "C" int mmif_pack_dense_chain(const float* w1, const float* w2, const flo
     S.w[0] = w1; S.w[1] = w2; S.w[2] = w3;
     S.dst[0] = (bf16_t*)packed_v0; S.dst[1] = (bf16_t*)packed_v1; S.dst[2] = (bf16_t*)packed_v2;
     for (int k = 0; k < 3; ++k) S.total[k] = (long long)(packed_bytes(16, 16 * (3 - k), 3) / 2);
-    hipLaunchKernelGGL(pack_dense_chain_kernel, dim3(8, 3), dim3(256), 0, (hipStream_t)stream, S);
+    ChainSrc2 S2;
+    S2.s[0] = S; S2.s[1] = S;
+    hipLaunchKernelGGL(pack_dense_chain_kernel, dim3(8, 3), dim3(256), 0, (hipStream_t)stream, S2);
     return check_launch("pack_dense_chain");
+}
+
+// the same for the two encoder branches of a PFNet-style model in ONE launch (w_a / packed_a: {w1, w2, w3} / {v0, v1, v2} of branch a)
+extern "C" int mmif_pack_dense_chain_pair(const float* const* w_a, void* const* packed_a, const float* const* w_b, void* const* packed_b, void* stream) {
+    MMIF_REQUIRE(w_a != nullptr && packed_a != nullptr && w_b != nullptr && packed_b != nullptr, "pack_dense_chain_pair: NULL argument");
+    ChainSrc2 S2;
+    for (int b = 0; b < 2; ++b)
+        for (int k = 0; k < 3; ++k) {
+            const float* w = (b ? w_b : w_a)[k];
+            void* d = (b ? packed_b : packed_a)[k];
+            MMIF_REQUIRE(w != nullptr && d != nullptr, "pack_dense_chain_pair: NULL weight / image");
+            S2.s[b].w[k] = w;
+            S2.s[b].dst[k] = (bf16_t*)d;
+            S2.s[b].total[k] = (long long)(packed_bytes(16, 16 * (3 - k), 3) / 2);
+        }
+    hipLaunchKernelGGL(pack_dense_chain_kernel, dim3(8, 6), dim3(256), 0, (hipStream_t)stream, S2);
+    return check_launch("pack_dense_chain_pair");
 }
 
 extern "C" int mmif_pack_weights(const float* w, int32_t cout, int32_t cin, int32_t ksize, void* packed_fwd, void* packed_dgrad,

@@ -750,12 +750,13 @@ extern "C" int mmif_dense_encoder_bwd(const mmif_dense_chain* chain_a, const flo
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(enc_bwd_fused_kernel, dim3(G, nb), dim3(FB_WAVES * 64), 0, st, A);
     if (int rc = check_launch("dense_encoder_bwd")) return rc;
+    EwDst D[2];
     for (int b = 0; b < nb; ++b) {
         float* const* d = b ? dwdb_b : dwdb_a;
-        EwDst D;
-        D.dw0 = d[0]; D.db0 = d[1];
-        D.dw[0] = d[2]; D.db[0] = d[3]; D.dw[1] = d[4]; D.db[1] = d[5]; D.dw[2] = d[6]; D.db[2] = d[7];
-        if (int rc = enc_wgrad_reduce_launch(A.br[b].partial, D, G, b ? accumulate_b : accumulate_a, st)) return rc;
+        D[b].dw0 = d[0]; D[b].db0 = d[1];
+        D[b].dw[0] = d[2]; D[b].db[0] = d[3]; D[b].dw[1] = d[4]; D[b].db[1] = d[5]; D[b].dw[2] = d[6]; D[b].db[2] = d[7];
     }
+    if (nb == 2) return enc_wgrad_reduce_pair_launch(A.br[0].partial, D[0], accumulate_a, A.br[1].partial, D[1], accumulate_b, G, st);
+    if (int rc = enc_wgrad_reduce_launch(A.br[0].partial, D[0], G, accumulate_a, st)) return rc;
     return MMIF_OK;
 }

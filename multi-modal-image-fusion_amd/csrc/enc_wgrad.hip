@@ -435,6 +435,48 @@ __global__ __launch_bounds__(64 * RED_SLICES) void enc_wgrad_reduce(const float*
     if (p != nullptr) *p = accumulate ? *p + t : t;
 }
 
+// both branches of a fused encoder backward in ONE launch: blockIdx.y = branch when the destinations differ; a SHARED encoder (the second
+// branch accumulates onto the first's gradients) runs its two sums one after the other in the same blocks -- the order of the two launches
+// this replaces, bit for bit
+struct EwPair { const float* partial[2]; EwDst D[2]; int accumulate[2]; int serial; };
+__global__ __launch_bounds__(64 * RED_SLICES) void enc_wgrad_reduce_pair(EwPair P, int G) {
+    __shared__ float red[RED_SLICES][64];
+    const int idx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int b0 = P.serial ? 0 : blockIdx.y, b1 = P.serial ? 2 : b0 + 1;
+    for (int b = b0; b < b1; ++b) {
+        const float t = partial_sum(P.partial[b], idx, EW_PER, G, idx < EW_PER, red);
+        __syncthreads();      // (red is reused by the second sum)
+        if ((threadIdx.x >> 6) != 0 || idx >= EW_PER) continue;
+        const EwDst& D = P.D[b];
+        float* p = nullptr;
+        if (idx < EW_OFF2) p = D.dw[2] + idx;
+        else if (idx < EW_OFF1) p = D.dw[1] + (idx - EW_OFF2);
+        else if (idx < EW_OFF0) p = D.dw[0] + (idx - EW_OFF1);
+        else if (idx < EW_OFFB) {
+            const int oc = (idx - EW_OFF0) >> 4, n = (idx - EW_OFF0) & 15;
+            if (n < 9) p = D.dw0 + oc * 9 + n;
+            else if (n == 9 && D.db0 != nullptr) p = D.db0 + oc;
+        } else {
+            const int L = (idx - EW_OFFB) >> 4, oc = (idx - EW_OFFB) & 15;
+            if (D.db[L] != nullptr) p = D.db[L] + oc;
+        }
+        if (p != nullptr) *p = P.accumulate[b] ? *p + t : t;
+    }
+}
+
+int enc_wgrad_reduce_pair_launch(const float* pa, const EwDst& Da, int acc_a, const float* pb, const EwDst& Db, int acc_b, int G, hipStream_t st) {
+    EwPair P;
+    P.partial[0] = pa; P.partial[1] = pb;
+    P.D[0] = Da; P.D[1] = Db;
+    P.accumulate[0] = acc_a; P.accumulate[1] = acc_b;
+    // any destination in common => the second branch must see the first's result: serial inside the blocks
+    bool shared = Da.dw0 == Db.dw0 || (Da.db0 != nullptr && Da.db0 == Db.db0);
+    for (int i = 0; i < 3; ++i) shared = shared || Da.dw[i] == Db.dw[i] || (Da.db[i] != nullptr && Da.db[i] == Db.db[i]);
+    P.serial = shared ? 1 : 0;
+    hipLaunchKernelGGL(enc_wgrad_reduce_pair, dim3(cdiv(EW_PER, 64), shared ? 1 : 2), dim3(64 * RED_SLICES), 0, st, P, G);
+    return check_launch("enc_wgrad_reduce_pair");
+}
+
 int enc_wgrad_reduce_launch(const float* partial, const EwDst& D, int G, int accumulate, hipStream_t st) {
     hipLaunchKernelGGL(enc_wgrad_reduce, dim3(cdiv(EW_PER, 64)), dim3(64 * RED_SLICES), 0, st, partial, D, G, accumulate);
     return check_launch("enc_wgrad_reduce");

@@ -13,5 +13,7 @@ constexpr int EW_MAXG = 512;
 struct EwDst { float* dw0; float* db0; float* dw[3]; float* db[3]; };
 // fixed-order sum of G partials (EW_PER floats each) into the four layers' dW / db (accumulate: onto what is there)
 int enc_wgrad_reduce_launch(const float* partial, const EwDst& D, int G, int accumulate, hipStream_t st);
+// the same for two branches in one launch (same summation order as two launches; shared destinations are summed one after the other)
+int enc_wgrad_reduce_pair_launch(const float* pa, const EwDst& Da, int acc_a, const float* pb, const EwDst& Db, int acc_b, int G, hipStream_t st);
 
 }  // namespace mmif

@@ -580,11 +580,32 @@ class DenseEncoderMixin:
                         for specs, *_ in branches)):
             return False
         args = []
+        if len(branches) == 2:
+            DenseEncoderMixin.chain_images_pair(branches[0][0], branches[1][0])
         for specs, img, fbase, g3, glow, acc in branches:
             pk = DenseEncoderMixin.chain_images(specs, _lib.BF16)
             args.append((g3, glow, F.view(fbase, 6), pk, img, [(s.dw, s.db) for s in specs], acc))
         T.dense_encoder_bwd(args, ws, tag="encode:bwd")
         return True
+
+    @staticmethod
+    def chain_images_pair(specs_a, specs_b):
+        """two encoder branches with their own weights (PFNetv1): when both sets of bf16 chain images exist and are stale, re-pack them in ONE
+        launch; chain_images() then finds them current.  Anything else (first use, shared weights, one side current) is left to chain_images()."""
+        ca, cb = getattr(specs_a[0], "_chain", None), getattr(specs_b[0], "_chain", None)
+        if ca is None or cb is None or specs_a[0] is specs_b[0]:
+            return
+        keys, wss = [], []
+        for specs in (specs_a, specs_b):
+            c = specs[1:]
+            keys.append((WEIGHTS_EPOCH[0], _lib.BF16) + tuple((s.conv.weight._version, s.conv.weight.data_ptr()) for s in c))
+            wss.append([s.conv.weight.detach() for s in c])
+        if ca[0] == keys[0] or cb[0] == keys[1] or ca[1][0].fmt != _lib.BF16 or cb[1][0].fmt != _lib.BF16 \
+                or ca[1][0].dgrad.device != wss[0][0].device or cb[1][0].dgrad.device != wss[1][0].device:
+            return
+        T.repack_dense_chain_pair(ca[1], wss[0], cb[1], wss[1])
+        specs_a[0]._chain = (keys[0], ca[1])
+        specs_b[0]._chain = (keys[1], cb[1])
 
     @staticmethod
     def chain_all(branches, F, GF, impl):

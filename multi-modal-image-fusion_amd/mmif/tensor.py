@@ -278,6 +278,14 @@ def repack_dense_chain(pk, w1, w2, w3):
     check(fn(_ptr(w1), _ptr(w2), _ptr(w3), _ptr(pk[0].dgrad), _ptr(pk[1].dgrad), _ptr(pk[2].dgrad), stream_ptr()), "pack_dense_chain")
 
 
+def repack_dense_chain_pair(pk_a, ws_a, pk_b, ws_b):
+    """bf16 chain images of two encoder branches in ONE launch (mmif_pack_dense_chain_pair)"""
+    assert pk_a[0].fmt == BF16 and pk_b[0].fmt == BF16
+    arr = lambda ptrs: (C.c_void_p * 3)(*ptrs)
+    keep = [arr([_ptr(w) for w in ws_a]), arr([_ptr(p.dgrad) for p in pk_a]), arr([_ptr(w) for w in ws_b]), arr([_ptr(p.dgrad) for p in pk_b])]
+    check(lib.mmif_pack_dense_chain_pair(*[C.cast(a, C.c_void_p) for a in keep], stream_ptr()), "pack_dense_chain_pair")
+
+
 def dense_encoder_chain(branches, tag=None):
     """The DenseBlock's backward gradient chain of one or two branches as ONE streaming launch (csrc/enc_chain.hip).
     branches: [(g3 2-block view, glow 6-block view, x 6-block view, chain images (pack_dense_chain), out 8-block view), ...]"""
