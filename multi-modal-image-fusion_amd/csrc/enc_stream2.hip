@@ -66,6 +66,10 @@ template <int NT> struct E2G {
 };
 
 template <int N> struct E2I { static constexpr int value = N; };
+#ifndef E2_STORE_AUX
+#define E2_STORE_AUX 1      // cache-policy bits of the output stores: sc0 (1) measured 196 us against 205 (0), nt (2) 231, sc1 (16) 225, 3 / 17 / 18 / 19 223-233
+                             // (scope bits only ever strengthen coherence; the kernel boundary publishes the rows either way)
+#endif
 #ifndef E2_ABL
 #define E2_ABL 0   // timing ablations (diagnostic builds only, tools/build_ab_enc2.sh; results are WRONG when non-zero): 1 no global stores (32: the stores go to one cache-resident 16 KiB per block instead),
 #endif             // 2 no bf16 MFMAs, 4 no LDS operand reads after a step's first, 8 no epilogues at all, 16 no first-layer MFMAs / image loads
@@ -344,7 +348,7 @@ __global__ __launch_bounds__(E2G<NT>::WAVES * 64, 1) void enc_stream2_fwd_kernel
                 if (L < 3) *reinterpret_cast<uint4*>(smem + wb + p * 512) = o[p];
                 if (E2_ABL & 32)      // every store of a block into the same 16 KiB (cache resident): the store INSTRUCTIONS without the HBM write stream
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(e2_u32x4, o[p]), rs_out, (int)((st_e[p] & 0x3ff0u) | own), (int)(blockIdx.x * 16384u), 0);
-                else if (!(E2_ABL & 1)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(e2_u32x4, o[p]), rs_out, (int)(st_e[p] | own), orow, 0);
+                else if (!(E2_ABL & 1)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(e2_u32x4, o[p]), rs_out, (int)(st_e[p] | own), orow, E2_STORE_AUX);
             }
             if (L < 3) {
                 // ghost pixels of an edge strip, AFTER both halves of the row are in the ring (a narrow image's right ghost lies inside
