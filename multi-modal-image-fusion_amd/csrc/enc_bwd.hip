@@ -118,7 +118,10 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
     for (int e = tid; e < FB_NFRAG * 64; e += FB_WAVES * 64) {
         const int f = e >> 6, l = e & 63, oc = l & 15, kg = l >> 4;
         const int u = f % 3, kq = f / 3;
-        reinterpret_cast<uint4*>(smem)[e] = B.wpk[kq < 2 ? 2 : (kq < 5 ? 1 : 0)][a_plane(kq, u, kg) * 16 + oc];
+        // (lane group g of a fragment holds the k-group ((g & 1) << 1) | (g >> 1) of the packed image: the chain's B reads put the ring / tap
+        //  selector in bit 0 of the lane group and the channel block in bit 1 -- with the channel block in bit 0, the 544-byte stride of the
+        //  guarded rows put two of the four 16-lane groups of every ds_read_b128 on shared banks: 29 % of the chain's LDS cycles)
+        reinterpret_cast<uint4*>(smem)[e] = B.wpk[kq < 2 ? 2 : (kq < 5 ? 1 : 0)][a_plane(kq, u, ((kg & 1) << 1) | (kg >> 1)) * 16 + oc];
     }
     const int ring = FB_WBYTES + pair * FB_GRING;
     const int xring = 64 + pair * (FB_XS * FB_XROW);                                // byte offsets inside smem_dma (64 zero bytes in front)
@@ -384,7 +387,7 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
         pos = set_piece(pos);
         const bool edgeL = r0 < 0, edgeR = r0 + FB_W >= W + 1;
         // ---- lane constants: chain operands
-        const int h2 = g >> 1, cbk = g & 1;
+        const int h2 = g & 1, cbk = g >> 1;      // (bit 0: second ring / next tap column, bit 1: channel block -- see the fragment staging)
         const int la = g * 256 + j * 16;
         const int lb4 = ring + cbk * FB_CBS + j * 16;                 // (+ 16 guard - 16 for tap column 0)
         const int lb2 = ring + cbk * FB_CBS + (j + h2) * 16;

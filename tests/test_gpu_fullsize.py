@@ -460,3 +460,60 @@ def test_round4_kernel_variants_are_bit_identical_at_the_headline_size(name):
     for k, (a, b) in enumerate(zip(res[0][1], res[1][1])):
         assert float(a.abs().max()) > 0
         assert torch.equal(a, b), f"parameter gradient {k}"
+
+
+@pytest.mark.parametrize("name", ["PFNetv1", "DenseFuse"])
+def test_round5_encoder_kernels_at_the_headline_size(name):
+    """BASELINE config 2 (batch 32, 256 x 256, bf16): one train step with round 5's encoder kernels against the kernels they replace.
+    (a) the fused encoder backward (csrc/enc_bwd.hip: gradient chain + weight gradients of all four layers in one launch, a block per CU walking
+    slices of rows) against enc_chain_bwd_kernel + enc_wgrad_kernel: identical fused image and decoder gradients (nothing upstream of them
+    changed), encoder gradients within the summation-order noise (2e-3 of their maximum; same rounding points);
+    (b) the streaming encoder forward's three forms (csrc/enc_stream2.hip 32- / 64-pixel strips, csrc/enc_stream.hip): another accumulation
+    order inside a layer, same rounding points -- fused image within two bf16 steps of its range, every gradient within 2e-2 of its maximum."""
+    import os
+    import core.model as M
+    from mmif import engine as E
+    from mmif._lib import lib
+    from gpu_util import dtype_ctx
+    g = torch.Generator().manual_seed(23)
+    i1, i2 = torch.rand(32, 1, 256, 256, generator=g).to(DEV), torch.rand(32, 1, 256, 256, generator=g).to(DEV)
+    gy = torch.rand(32, 1, 256, 256, generator=g).to(DEV)
+
+    def step():
+        with dtype_ctx("bf16"):
+            torch.manual_seed(5)
+            m = getattr(M, name)().to(DEV)
+            y = m(i1, i2)
+            y.backward(gy)
+            torch.cuda.synchronize()
+            return y.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+
+    ref = step()
+    assert float(ref[0].abs().max()) > 0
+    # (a)
+    os.environ["MMIF_ENC_BWD_FUSED"] = "0"
+    E.reload_switches()
+    try:
+        two = step()
+    finally:
+        os.environ.pop("MMIF_ENC_BWD_FUSED")
+        E.reload_switches()
+    assert torch.equal(ref[0], two[0]), "fused image"
+    for k in ref[1]:
+        a, b = ref[1][k].double(), two[1][k].double()
+        assert float(b.abs().max()) > 0, k
+        if "encode" in k:
+            assert float((a - b).abs().max()) <= 2e-3 * float(b.abs().max()), (k, float((a - b).abs().max()), float(b.abs().max()))
+        else:
+            assert torch.equal(ref[1][k], two[1][k]), k
+    # (b)
+    try:
+        for mode in (1, 0):
+            lib.mmif_debug_set_enc_stream2(mode)
+            alt = step()
+            assert float((ref[0].double() - alt[0].double()).abs().max()) <= 2 * 2.0 ** -8 * float(ref[0].abs().max()), mode
+            for k in ref[1]:
+                a, b = ref[1][k].double(), alt[1][k].double()
+                assert float((a - b).abs().max()) <= 2e-2 * float(b.abs().max()), (mode, k, float((a - b).abs().max()), float(b.abs().max()))
+    finally:
+        lib.mmif_debug_set_enc_stream2(2)
