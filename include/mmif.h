@@ -509,6 +509,17 @@ void mmif_debug_set_thin_wide(int32_t mode);
  * compute units to a kernel that runs concurrently on another stream -- the intra-step overlap of decode.0's weight gradient with the
  * encoder's backward (mmif/engine.py, $MMIF_OVERLAP).  Results change in the last bits only (the per-block partial sums regroup). */
 void mmif_debug_set_wgrad_dma_blocks(int32_t blocks);
+/* Deferred weight-gradient reductions (round 5, csrc/reduce_defer.hip).  Every weight-gradient entry point above ends in a small fixed-order
+ * reduce launch over its per-block partial sums -- autograd's accumulation of `convolution_backward`'s weight / bias gradients into `.grad`
+ * (`train.py:71`).  Between begin() and flush() the reduces of mmif_conv2d_reflect_bwd_wide, mmif_conv2d_reflect_bwd_pair and
+ * mmif_conv2d_image_out_wgrad are queued -- their partial sums go to slots of `arena` (device memory, sized by the caller as the sum of the
+ * layers' weight-gradient workspaces; a layer that does not fit, or a ninth job, reduces at once as without deferral) -- and flush() runs
+ * all of them as ONE launch: the same sums in the same order, bit-identical dW / db, one launch latency instead of five in a PFNetv1 step.
+ * dW / db of a queued layer are NOT valid before the flush.  One stream for producers, flush and consumers. */
+int mmif_reduce_defer_begin(void* arena, size_t bytes);
+int mmif_reduce_defer_flush(int32_t keep_deferring, void* stream);
+int32_t mmif_reduce_defer_pending(void);
+
 /* mmif_dense_encoder_fwd ($MMIF_ENC_STREAM2): 2 (default) = the round-5 streaming kernel with 32-column strips, eight waves per CU; 1 = the
  * same with 64-column strips, four waves per CU (csrc/enc_stream2.hip: input-stationary accumulation; every stage within one bf16
  * rounding of its fp64 definition); 0 = the round-2 kernel (csrc/enc_stream.hip, bit-identical to the four layer-wise launches). */

@@ -4,6 +4,7 @@
 // These layers are HBM-bound (K = 9 or M = 1): plain VALU kernels, fp32 math, T only on the
 // feature-map side.
 #include "common.hpp"
+#include "reduce_defer.hpp"
 
 namespace mmif {
 
@@ -520,12 +521,18 @@ extern "C" int mmif_conv2d_image_out_wgrad(const mmif_tensor* x, const float* gi
     const int G = (int)(cdiv(npix, 256) < IMG_G ? cdiv(npix, 256) : IMG_G);
     const int n_cg = cdiv(cin, 16);
     hipStream_t st = (hipStream_t)stream;
-    float* ws = (float*)workspace;
+    float* ws = defer_ws((float*)workspace, (size_t)G * n_cg * (16 * ksize * ksize + 1) * sizeof(float));
 #define CALL(T, KS) hipLaunchKernelGGL((image_out_wgrad_kernel<T, KS>), dim3(G, tx.cb), dim3(256), 0, st, tx, gimg, y_img, ws, npix)
     DISPATCH_T_KS(x->dtype, ksize, CALL);
 #undef CALL
     if (int rc = check_launch("image_out_wgrad")) return rc;
     const int n = cin * ksize * ksize + 1;
+    {
+        RedJob J;
+        J.partial = ws; J.dw = dw; J.db = db; J.type = RED_IMAGE_OUT; J.sl = RED_SLICES; J.G = G; J.accumulate = accumulate;
+        J.p0 = cin; J.p1 = ksize; J.p2 = n_cg; J.p3 = 0; J.nvb = cdiv(n, 64);
+        if (defer_push(J)) return MMIF_OK;
+    }
     if (ksize == 3) hipLaunchKernelGGL((image_out_wgrad_reduce<3>), dim3(cdiv(n, 64)), dim3(64 * RED_SLICES), 0, st, ws, dw, db, cin, G, n_cg, accumulate);
     else hipLaunchKernelGGL((image_out_wgrad_reduce<1>), dim3(cdiv(n, 64)), dim3(64 * RED_SLICES), 0, st, ws, dw, db, cin, G, n_cg, accumulate);
     return check_launch("image_out_wgrad_reduce");

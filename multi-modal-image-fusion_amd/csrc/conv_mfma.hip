@@ -20,6 +20,7 @@
 // layout, so fragments are fetched with the gfx950 LDS transpose read ds_read_b64_tr_b16
 // (4 pixels x 16 channels per 16-lane group -> per lane 4 consecutive pixels of one channel).
 #include "common.hpp"
+#include "reduce_defer.hpp"
 #include <stdlib.h>
 
 namespace mmif {
@@ -2297,6 +2298,7 @@ int bwd_pair(const TV& tx, const TV& tg, const TV& tgx, const void* wpk_dgrad, f
     const int tpi = tiles_x * tiles_y, total = tpi * tx.n;
     const int cap = (cin == 64 ? 1 : 2) * num_cus_();
     const int G = total < cap ? total : (cap < BP_MAXG ? cap : BP_MAXG);
+    ws = defer_ws(ws, (size_t)G * ((size_t)cout * cin * 9 + cout) * sizeof(float));
     // $MMIF_BWD_PAIR_DMA=0 / mmif_debug_set_bwd_pair_dma(0): the register-staged kernel (A/B; bit-identical results)
     if (g_bwd_pair_dma < 0) { const char* e = getenv("MMIF_BWD_PAIR_DMA"); g_bwd_pair_dma = (e != nullptr && e[0] == '0') ? 0 : 1; }
     const bool use_dma = g_bwd_pair_dma == 1 && tg.halo == 1 && tg.folded;
@@ -2595,11 +2597,18 @@ static int launch_wgrad_dma(const TV& tx, const TV& tg, float* dw, float* db, in
     const int n_icg = cdiv(cin, 64), n_ocg = cdiv(cout, 64);
     int G = wgrad_dma_G(cin, cout, g_wgrad_dma_blocks);   // (the workspace is sized for the full grid)
     if (G > total) G = total;   // every tile group owns at least one tile (the reduce sums all G partials)
+    ws = defer_ws(ws, (size_t)G * n_icg * n_ocg * WD_PER * sizeof(float));      // (csrc/reduce_defer.hpp: an arena slot while reductions are deferred)
     hipLaunchKernelGGL(wgrad_dma_kernel, dim3(G * n_icg * n_ocg), dim3((D_CONS + D_LOAD) * 64), 0, st, tx, tg, ws, tiles_x, tpi, total, G,
                        n_icg, n_ocg, sgn);
     if (int rc = check_launch("wgrad_dma")) return rc;
     const int n = cout * cin * 9 + cout;
     const int RG = G;
+    {
+        RedJob J;
+        J.partial = ws; J.dw = dw; J.db = db; J.type = RED_WGRAD_DMA; J.sl = RG > 64 ? 16 : 4; J.G = G; J.accumulate = accumulate;
+        J.p0 = cin; J.p1 = cout; J.p2 = n_icg; J.p3 = n_ocg; J.nvb = cdiv(n, 64);
+        if (defer_push(J)) return MMIF_OK;
+    }
     if (RG > 64) hipLaunchKernelGGL(wgrad_dma_reduce<16>, dim3(cdiv(n, 64)), dim3(1024), 0, st, ws, dw, db, cin, cout, G, n_icg, n_ocg, accumulate);
     else hipLaunchKernelGGL(wgrad_dma_reduce<4>, dim3(cdiv(n, 64)), dim3(256), 0, st, ws, dw, db, cin, cout, G, n_icg, n_ocg, accumulate);
     return check_launch("wgrad_dma_reduce");

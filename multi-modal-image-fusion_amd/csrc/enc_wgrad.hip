@@ -14,6 +14,7 @@
 // No K split between waves -> no cross-wave reduction; per-block partials are reduced in a fixed order by a second kernel
 // (deterministic, no atomics).  ~250 B staged per pixel => HBM-bound; 2 blocks per CU (65 KB LDS each).
 #include "enc_wgrad.hpp"
+#include "reduce_defer.hpp"
 
 namespace mmif {
 
@@ -394,6 +395,12 @@ size_t wgrad_taprow_workspace(int cin, int cout) { return (size_t)EW_MAXG * ((si
 // fixed-order reduction of G natural-layout partials ([cout][cin][3][3] then [cout]) -- shared with the fused backward kernel of conv_mfma.hip
 int taprow_reduce_launch(const float* ws, float* dw, float* db, int cin, int cout, int G, int accumulate, hipStream_t st) {
     const int n_w = cout * cin * 9, per = n_w + cout;
+    {
+        RedJob J;
+        J.partial = ws; J.dw = dw; J.db = db; J.type = RED_TAPROW; J.sl = RED_SLICES; J.G = G; J.accumulate = accumulate;
+        J.p0 = n_w; J.p1 = per; J.p2 = 0; J.p3 = 0; J.nvb = cdiv(per, 64);
+        if (defer_push(J)) return MMIF_OK;
+    }
     hipLaunchKernelGGL(taprow_wgrad_reduce, dim3(cdiv(per, 64)), dim3(64 * RED_SLICES), 0, st, ws, dw, db, n_w, per, G, accumulate);
     return check_launch("wgrad_taprow_reduce");
 }

@@ -110,6 +110,9 @@ SIGNATURES = {
     "mmif_conv2d_reflect_bwd_wide": (_i32, [_TP, _vp, _TP, _TP, _vp, _vp, _i32, _i32, _i32, _u64, _i32, _vp, _sz, _vp, _sz, _vp]),
     "mmif_pack_dense_chain": (_i32, [_vp] * 7),
     "mmif_pack_dense_chain_pair": (_i32, [_vp] * 5),
+    "mmif_reduce_defer_begin": (_i32, [_vp, _sz]),
+    "mmif_reduce_defer_flush": (_i32, [_i32, _vp]),
+    "mmif_reduce_defer_pending": (_i32, []),
     "mmif_pack_dense_chain_x3": (_i32, [_vp] * 7),
     "mmif_dense_encoder_chain": (_i32, [C.POINTER(MmifDenseChain), C.POINTER(MmifDenseChain), _vp]),
     "mmif_dense_encoder_bwd_workspace": (_sz, []),

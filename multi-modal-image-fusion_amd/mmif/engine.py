@@ -303,6 +303,30 @@ class ModelEngine:
             self._ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=device)
         return self._ws
 
+    def defer_reduces(self, device, layers):
+        """queue the fixed-order reduce launches of `layers`' weight gradients (csrc/reduce_defer.hip) until flush_reduces(): their partial sums
+        go to an arena of the layers' summed workspaces.  OFF by default ($MMIF_DEFER_REDUCE=1 switches it on; bit-identical either way):
+        measured at the headline size, the one launch takes 29 us against 32 us for the five it replaces -- a reduce right after its producer
+        reads the partial sums (113 MB for decode.0) out of the last-level cache, the deferred one reads 220 MB from HBM after the other
+        backward kernels have evicted them."""
+        if not switch("MMIF_DEFER_REDUCE", "0"):
+            return False
+        need = 0
+        for s in layers:
+            if s.pair:
+                return False
+            b = T.image_wgrad_workspace_bytes(max(s.cin, s.cout), s.k) if (s.cin == 1 or s.cout == 1) else T.wgrad_workspace_bytes(s.cin, s.cout, s.k)
+            need += (b + 255) // 256 * 256
+        arena = getattr(self, "_arena", None)
+        if arena is None or arena.device != device or arena.numel() * 4 < need:
+            arena = self._arena = torch.empty((need + 3) // 4, dtype=torch.float32, device=device)
+        T.check(_lib.lib.mmif_reduce_defer_begin(arena.data_ptr(), arena.numel() * 4), "reduce_defer_begin")
+        return True
+
+    @staticmethod
+    def flush_reduces(keep=False):
+        T.check(_lib.lib.mmif_reduce_defer_flush(1 if keep else 0, T.stream_ptr()), "reduce_defer_flush")
+
     # ---- buffers ----------------------------------------------------------------------------
     def lease(self, key, device):
         lst = self.pool.setdefault(key, [])
@@ -721,6 +745,9 @@ class PFNetv1Engine(ModelEngine, DenseEncoderMixin):
         acts = [F] + [L.bufs[f"D{i}"] for i in range(len(self.dec) - 1)]
         last = self.dec[-1]
         x = acts[-1]
+        # the decoder's weight-gradient reduces as ONE launch at the end of the decoder's backward (not with the side-stream experiment: its
+        # producer runs on another stream)
+        deferred = dtype == torch.bfloat16 and not switch("MMIF_OVERLAP", "0") and self.defer_reduces(dev, self.dec)
         T.image_out_wgrad(x, gout, L.out, last.dw, last.db, last.cin, last.k, ws)
         g = self.buf(L, f"G{len(acts) - 1}", n, last.cin, h, w, dtype, dev, halo=1)
         T.image_out_dgrad(gout, L.out, last.w.detach(), x, g, last.cin, last.k, all_bits(g.cb), 0)
@@ -745,6 +772,8 @@ class PFNetv1Engine(ModelEngine, DenseEncoderMixin):
                 continue
             self.c_wgrad(s, x, g, ws, impl)
             g = self.c_dgrad(s, g, x, gx, mb, 0, impl)
+        if deferred:
+            self.flush_reduces()
         forked = getattr(self, "_forked", None) is not None
         if not forked:
             self.early_reduce(flat, self.dec)      # (data parallel) the decoder's gradients leave while the encoder's backward runs
@@ -834,6 +863,9 @@ class DenseFuseEngine(ModelEngine, DenseEncoderMixin):
         acts = [first_in] + [L.bufs[f"D{i}"] for i in range(len(self.dec) - 1)]
         last = self.dec[-1]
         x = acts[-1]
+        # the decoder's weight-gradient reduces as ONE launch at the end of the decoder's backward (not with the side-stream experiment: its
+        # producer runs on another stream)
+        deferred = dtype == torch.bfloat16 and not switch("MMIF_OVERLAP", "0") and self.defer_reduces(dev, self.dec)
         T.image_out_wgrad(x, gout, L.out, last.dw, last.db, last.cin, last.k, ws)
         g = self.buf(L, f"G{len(acts) - 1}", n, last.cin, h, w, dtype, dev, halo=1)
         T.image_out_dgrad(gout, L.out, last.w.detach(), x, g, last.cin, last.k, all_bits(g.cb), 0)
@@ -857,6 +889,8 @@ class DenseFuseEngine(ModelEngine, DenseEncoderMixin):
                 continue
             self.c_wgrad(s, x, g, ws, impl)
             g = self.c_dgrad(s, g, x, gx, mb, 0, impl)
+        if deferred:
+            self.flush_reduces()
         if getattr(self, "_forked", None) is not None:
             try:
                 return self._encoder_backward(L, F, g, ws, impl, dtype, dev, n, h, w, single, img1, img2, grads)

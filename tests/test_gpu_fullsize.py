@@ -517,3 +517,40 @@ def test_round5_encoder_kernels_at_the_headline_size(name):
                 assert float((a - b).abs().max()) <= 2e-2 * float(b.abs().max()), (mode, k, float((a - b).abs().max()), float(b.abs().max()))
     finally:
         lib.mmif_debug_set_enc_stream2(2)
+
+
+@pytest.mark.parametrize("name", ["PFNetv1", "DenseFuse", "VIFNet"])
+def test_deferred_weight_gradient_reduces_are_bit_identical_at_the_headline_size(name):
+    """csrc/reduce_defer.hip: the decoder's five weight-gradient reduce launches queued and run as ONE launch ($MMIF_DEFER_REDUCE=1; off by default: no faster)
+    against a reduce right after every producer: the same sums in the same order -- every parameter gradient bit for bit (batch 32, 256 x 256,
+    bf16), nothing left queued after the backward."""
+    import os
+    import core.model as M
+    from mmif import engine as E
+    from mmif._lib import lib
+    from gpu_util import dtype_ctx
+    g = torch.Generator().manual_seed(29)
+    i1, i2 = torch.rand(32, 1, 256, 256, generator=g).to(DEV), torch.rand(32, 1, 256, 256, generator=g).to(DEV)
+    gy = torch.rand(32, 1, 256, 256, generator=g).to(DEV)
+    res = {}
+    try:
+        for mode in ("1", "0"):
+            os.environ["MMIF_DEFER_REDUCE"] = mode
+            E.reload_switches()
+            with dtype_ctx("bf16"):
+                torch.manual_seed(5)
+                m = getattr(M, name)().to(DEV)
+                for _ in range(2):      # (twice: the second backward re-uses the arena)
+                    m.zero_grad(set_to_none=True)
+                    y = m(i1, i2)
+                    y.backward(gy)
+                torch.cuda.synchronize()
+                assert lib.mmif_reduce_defer_pending() == 0
+                res[mode] = (y.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters()})
+    finally:
+        os.environ.pop("MMIF_DEFER_REDUCE", None)
+        E.reload_switches()
+    assert torch.equal(res["0"][0], res["1"][0])
+    for k in res["0"][1]:
+        assert float(res["0"][1][k].abs().max()) > 0, k
+        assert torch.equal(res["0"][1][k], res["1"][1][k]), k
