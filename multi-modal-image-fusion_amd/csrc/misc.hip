@@ -201,10 +201,16 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
     if (threadIdx.x == 0) partial[blockIdx.x] = t;
 }
 
-// partial[np] holds sums of squares; writes stats[0] = scaled norm, stats[1] = clip coefficient * grad_scale
-__global__ void norm_finish_kernel(const float* __restrict__ partial, int np, float grad_scale, float max_norm,
-                                   float* __restrict__ stats, float* __restrict__ norm_out) {
+// partial[np] holds sums of squares; stats[0] = scaled norm, stats[1] = clip coefficient * grad_scale come out of the Adam launch below
+// clip coefficient + Adam in one launch: every block forms the total of the sums of squares itself -- the arithmetic of the former one-block
+// finish launch with its 256 threads, so the norm, the coefficient and the update are bit-identical to the two-launch form -- block 0 also publishes them
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long long n, float step_size, float beta1,
+                                                   float beta2, float inv_bc2_sqrt, float eps,
+                                                   const float* __restrict__ partial, int np, float grad_scale, float max_norm,
+                                                   float* __restrict__ stats, float* __restrict__ norm_out) {
     __shared__ float red[16];
+    __shared__ float s_gs;
     float s = 0.f;
     for (int i = threadIdx.x; i < np; i += blockDim.x) s += partial[i];
     const float t = block_sum(s, red);
@@ -212,17 +218,15 @@ __global__ void norm_finish_kernel(const float* __restrict__ partial, int np, fl
         const float norm = sqrtf(t) * grad_scale;
         float coef = 1.f;
         if (max_norm > 0.f) coef = fminf(1.f, max_norm / (norm + 1e-6f));
-        stats[0] = norm;
-        stats[1] = coef * grad_scale;
-        if (norm_out) norm_out[0] = norm;
+        s_gs = coef * grad_scale;
+        if (blockIdx.x == 0) {
+            stats[0] = norm;
+            stats[1] = coef * grad_scale;
+            if (norm_out) norm_out[0] = norm;
+        }
     }
-}
-
-__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                   float* __restrict__ v, long long n, float step_size, float beta1,
-                                                   float beta2, float inv_bc2_sqrt, float eps,
-                                                   const float* __restrict__ stats) {
-    const float gs = stats[1];
+    __syncthreads();
+    const float gs = s_gs;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const float gi = g[i] * gs;
         const float mi = m[i] + (gi - m[i]) * (1.f - beta1);             // exp_avg.lerp_(grad, 1-beta1)
@@ -367,13 +371,11 @@ extern "C" int mmif_clip_adam_step(float* params, const float* grads, float* exp
     if (nb > ADAM_PARTIALS) nb = ADAM_PARTIALS;
     hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(256), 0, st, grads, (long long)numel, partial);
     if (int rc = check_launch("sumsq")) return rc;
-    hipLaunchKernelGGL(norm_finish_kernel, dim3(1), dim3(256), 0, st, partial, nb, grad_scale, max_norm, stats, norm_out);
-    if (int rc = check_launch("norm_finish")) return rc;
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     const float step_size = (float)((double)lr / bc1);
     const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
     hipLaunchKernelGGL(adam_kernel, dim3(nb), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq, (long long)numel, step_size,
-                       beta1, beta2, inv_bc2_sqrt, eps, stats);
+                       beta1, beta2, inv_bc2_sqrt, eps, partial, nb, grad_scale, max_norm, stats, norm_out);
     return check_launch("adam");
 }
