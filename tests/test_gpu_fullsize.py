@@ -554,3 +554,38 @@ def test_deferred_weight_gradient_reduces_are_bit_identical_at_the_headline_size
     for k in res["0"][1]:
         assert float(res["0"][1][k].abs().max()) > 0, k
         assert torch.equal(res["0"][1][k], res["1"][1][k]), k
+
+
+def test_deferred_reduces_fall_back_when_the_arena_is_too_small():
+    """mmif_reduce_defer_begin with an arena that holds no layer's partial sums: every reduce runs right behind its producer as without
+    deferral (nothing queued), gradients bit-identical; an arena that holds only the small layers queues those and reduces the rest at once."""
+    import os
+    import core.model as M
+    from mmif import engine as E
+    from mmif import tensor as T
+    from mmif._lib import lib, check
+    from gpu_util import dtype_ctx
+    g = torch.Generator().manual_seed(31)
+    i1, i2 = torch.rand(2, 1, 64, 80, generator=g).to(DEV), torch.rand(2, 1, 64, 80, generator=g).to(DEV)
+    gy = torch.rand(2, 1, 64, 80, generator=g).to(DEV)
+    with dtype_ctx("bf16"):
+        torch.manual_seed(5)
+        m = M.PFNetv1().to(DEV)
+        y = m(i1, i2)
+        y.backward(gy)
+        torch.cuda.synchronize()
+        ref = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+        for arena_bytes in (256, 4 << 20):
+            arena = torch.empty(arena_bytes // 4, dtype=torch.float32, device=DEV)
+            # (the engine itself only defers with $MMIF_DEFER_REDUCE=1: drive the queue from outside around a plain backward)
+            m.zero_grad(set_to_none=True)
+            y = m(i1, i2)
+            check(lib.mmif_reduce_defer_begin(arena.data_ptr(), arena.numel() * 4), "begin")
+            y.backward(gy)
+            queued = lib.mmif_reduce_defer_pending()
+            check(lib.mmif_reduce_defer_flush(0, T.stream_ptr()), "flush")
+            torch.cuda.synchronize()
+            assert lib.mmif_reduce_defer_pending() == 0
+            assert (queued == 0) if arena_bytes == 256 else (queued > 0), (arena_bytes, queued)
+            for k, p in m.named_parameters():
+                assert torch.equal(p.grad, ref[k]), (arena_bytes, k)
