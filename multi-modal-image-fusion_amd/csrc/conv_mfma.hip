@@ -21,6 +21,20 @@
 // (4 pixels x 16 channels per 16-lane group -> per lane 4 consecutive pixels of one channel).
 #include "common.hpp"
 #include "reduce_defer.hpp"
+// the epilogues' 16-byte output stores carry the sc0 scope bit (-DMMIF_STORE_SC0=0: plain stores, A/B builds).  Round 5, measured: the
+// WHOLE PFNetv1 step is 11-12 % faster with it (8.78 k -> 9.81 k pairs/s, five alternating runs on one box) -- every kernel of the step, also
+// the ones that contain no such store (the fused encoder backward 419 -> 367 us, the weight gradients 367 -> 341 us): what the plain
+// write-back stores leave dirty in the cache hierarchy is paid for by whatever runs next.  Scope bits only ever strengthen coherence; the
+// kernel boundary publishes the data either way (profiles/r05_store_scope.txt).
+#ifndef MMIF_STORE_SC0
+#define MMIF_STORE_SC0 1
+#endif
+#if MMIF_STORE_SC0
+typedef unsigned mmif_st_u32x4 __attribute__((ext_vector_type(4)));
+#define MMIF_STORE_GRAN(p, v) do { const uint4 v__ = (v); const mmif_st_u32x4 w__ = {v__.x, v__.y, v__.z, v__.w}; __asm__ volatile("global_store_dwordx4 %0, %1, off sc0" : : "v"((const void*)(p)), "v"(w__) : "memory"); } while (0)
+#else
+#define MMIF_STORE_GRAN(p, v) (*reinterpret_cast<uint4*>(p) = (v))
+#endif
 #include <stdlib.h>
 
 namespace mmif {
@@ -279,7 +293,7 @@ __device__ inline void conv_epilogue(const f32x4 (&acc)[MF][4], const TV& tout, 
         }
 #pragma unroll
         for (int p2 = 0; p2 < 2; ++p2)
-            if (outok[p2]) *reinterpret_cast<uint4*>(oplane + (2 * p2) * row_bytes) = outv[p2];
+            if (outok[p2]) MMIF_STORE_GRAN(oplane + (2 * p2) * row_bytes, outv[p2]);
     }
 }
 
@@ -366,7 +380,7 @@ __device__ inline void conv_epilogue_packed(const f32x4 (&acc)[MF][4], const TV&
                 };
                 o.x &= dmask(0); o.y &= dmask(1); o.z &= dmask(2); o.w &= dmask(3);
             }
-            if (blk_ok && row_ok[p2]) *reinterpret_cast<uint4*>(oplane + (2 * p2) * row_bytes) = o;
+            if (blk_ok && row_ok[p2]) MMIF_STORE_GRAN(oplane + (2 * p2) * row_bytes, o);
         }
     }
     ESTAMP();
