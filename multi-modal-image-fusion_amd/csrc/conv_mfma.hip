@@ -21,20 +21,11 @@
 // (4 pixels x 16 channels per 16-lane group -> per lane 4 consecutive pixels of one channel).
 #include "common.hpp"
 #include "reduce_defer.hpp"
-// the epilogues' 16-byte output stores carry the sc0 scope bit (-DMMIF_STORE_SC0=0: plain stores, A/B builds).  Round 5, measured: the
-// WHOLE PFNetv1 step is 11-12 % faster with it (8.78 k -> 9.81 k pairs/s, five alternating runs on one box) -- every kernel of the step, also
-// the ones that contain no such store (the fused encoder backward 419 -> 367 us, the weight gradients 367 -> 341 us): what the plain
-// write-back stores leave dirty in the cache hierarchy is paid for by whatever runs next.  Scope bits only ever strengthen coherence; the
-// kernel boundary publishes the data either way (profiles/r05_store_scope.txt).
-#ifndef MMIF_STORE_SC0
-#define MMIF_STORE_SC0 1
-#endif
-#if MMIF_STORE_SC0
-typedef unsigned mmif_st_u32x4 __attribute__((ext_vector_type(4)));
-#define MMIF_STORE_GRAN(p, v) do { const uint4 v__ = (v); const mmif_st_u32x4 w__ = {v__.x, v__.y, v__.z, v__.w}; __asm__ volatile("global_store_dwordx4 %0, %1, off sc0" : : "v"((const void*)(p)), "v"(w__) : "memory"); } while (0)
-#else
+// the epilogues' 16-byte output stores.  (Round 5 tried them as inline-asm `global_store_dwordx4 ... sc0`, after the sc0 bit had made the
+// streaming encoder's buffer stores 5 % faster: no change in the step once the asm was correct -- a first version without the two wait
+// states a > 8-byte store needs before its data registers are rewritten stored garbage, and the step ran 12 % "faster" on the garbage
+// (less switching in the matrix pipes, higher clocks): tests/test_gpu_bwd_pair.py caught it.  Plain stores: the compiler pads its own.)
 #define MMIF_STORE_GRAN(p, v) (*reinterpret_cast<uint4*>(p) = (v))
-#endif
 #include <stdlib.h>
 
 namespace mmif {
