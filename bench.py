@@ -18,6 +18,8 @@ Rank 0 prints ONE JSON line (contract in the task description) including
   roofline     -- the dominant kernel timed live with HIP events inside the timed region
   parity_path  -- the same step on the parity-grade path (fp32 tensors, 3x3 / 1x1 layers on the matrix pipe as split-operand products,
                   csrc/conv_x3.hip) timed the same way, with its error against the CPU oracle on a small sample (N = 1 only)
+  other_configs -- BASELINE.json's configs 3, 4, 5 on this GPU (DenseFuse B=32 256^2, NestFuse / RFN-Nest B=4 512^2 train steps, PFNetv1
+                  inference on one 1224x1024 pair): 10 timed steps each after 3 warm-up steps, value / ms_per_step / fraction of ideal (N = 1 only)
   cpu_baseline -- the torch-CPU restatement of the step (oracle/torch_cpu_step.py, "port") timed on this box's host cores
 """
 import argparse
@@ -38,18 +40,21 @@ import torch.distributed as dist
 MODEL_WORK_TRAIN = {"PFNetv1": (107.04e9, 366.1e6, 256), "PFNetv2": (36.82e9, 517.1e6, 256), "DenseFuse": (34.56e9, 240.3e6, 256),
                     "NestFuse": (1828.4e9, 4006.9e6, 512), "RFNNest": (2665.9e9, 6324.5e6, 512)}
 MODEL_FLOPS_TRAIN = {k: v[0] for k, v in MODEL_WORK_TRAIN.items() if v[2] == 256}
+# forward only: (GFLOP, MB bf16) per image pair at the model's side; scaled by the pixel count for other frames
+MODEL_WORK_INFER = {"PFNetv1": (35.69e9, 122.0e6, 256), "DenseFuse": (11.53e9, 80.1e6, 256), "NestFuse": (609.5e9, 1335.6e6, 512), "RFNNest": (888.6e9, 2108.2e6, 512)}
 PEAK_MFMA_BF16 = 2.5e15   # dense, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_MATRIX_FP32 = 157e12
 PEAK_HBM = 8.0e12
 
 
-def ideal_pairs_per_s(model, h, w, dtype, products=1):
+def ideal_pairs_per_s(model, h, w, dtype, products=1, mode="train"):
     """SURVEY 8(d)'s "ideal pairs/s/GPU": 1 / max(t_MFMA, t_HBM) of the step's algorithmic flops and bytes at the peaks above.  fp32
     storage doubles the bytes; `products` = half-precision MFMA products the path issues per algorithmic product (3 on the split-operand
     fp32 path), priced at the bf16 matrix peak"""
-    if model not in MODEL_WORK_TRAIN:
+    table = MODEL_WORK_TRAIN if mode == "train" else MODEL_WORK_INFER
+    if model not in table:
         return None
-    fl, by, side = MODEL_WORK_TRAIN[model]
+    fl, by, side = table[model]
     scale = (h * w) / float(side * side)
     return 1.0 / max(products * fl * scale / PEAK_MFMA_BF16, by * scale * (2 if dtype == "fp32" else 1) / PEAK_HBM)
 
@@ -75,6 +80,9 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=8, help="image pairs per step of the CPU sample")
     ap.add_argument("--no-parity-path", action="store_true", help="skip the second timed leg on the parity-grade fp32 / split-bf16 path")
     ap.add_argument("--parity-steps", type=int, default=16)
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the `other_configs` block (BASELINE configs 3, 4, 5 on this GPU)")
+    ap.add_argument("--other-steps", type=int, default=10)
+    ap.add_argument("--other-warmup", type=int, default=3)
     ap.add_argument("--roofline-layer", default="decode.0", help="engine layer whose forward / dgrad / wgrad launches are timed with HIP events; "
                     "`roofline` reports the one with the largest share of the step, `roofline_kernels` all three")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend for N > 1 (nccl = RCCL; gloo: debugging)")
@@ -168,9 +176,8 @@ KIND_KERNEL_FP32 = {"fwd": "conv_x3_kernel<fwd>", "dgrad": "conv_x3_kernel<dgrad
 def conv_rooflines(T, engine, layer, B, S, Wd, dtype, step_ms, workload_id=None):
     """`roofline` objects of the forward / dgrad / wgrad launches of one conv layer from the HIP events bench recorded inside the timed
     region (T.PROFILE_EVENTS): ALGORITHMIC flops (2 B H W Cin Cout k^2 per pass) over the average launch duration.  bf16:
-    against the dense bf16 MFMA peak.  fp32 tensors (split-operand kernels): the algorithmic rate against the fp32 matrix peak (157
-    TFLOP/s -- the kernels beat it because they issue half-precision products) AND the executed MFMA rate (products_per_tap x the
-    algorithmic flops) against the bf16 peak, as separate fields."""
+    against the dense bf16 MFMA peak.  fp32 tensors (split-operand kernels): the EXECUTED MFMA rate (products_per_tap x the algorithmic
+    flops) against the same bf16 peak, the algorithmic fp32 rate as a separate field."""
     spec = [s for s in engine.specs if s.name == layer]
     if not spec:
         return {}
@@ -184,17 +191,21 @@ def conv_rooflines(T, engine, layer, B, S, Wd, dtype, step_ms, workload_id=None)
         ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
         ach = flops / (ms * 1e-3)
         r = {"bound": "mfma", "kernel": f"{(KIND_KERNEL_FP32 if dtype == 'fp32' else KIND_KERNEL_BF16)[kind]} {sp.cin}->{sp.cout} k{sp.k} ({layer}:{kind})",
-             "achieved": ach / 1e12, "peak": (PEAK_MATRIX_FP32 if dtype == "fp32" else PEAK_MFMA_BF16) / 1e12, "unit": "TFLOP/s",
-             "frac": ach / (PEAK_MATRIX_FP32 if dtype == "fp32" else PEAK_MFMA_BF16), "avg_launch_ms": ms, "launches": len(evs),
+             "achieved": ach / 1e12, "peak": PEAK_MFMA_BF16 / 1e12, "unit": "TFLOP/s",
+             "frac": ach / PEAK_MFMA_BF16, "avg_launch_ms": ms, "launches": len(evs),
              "step_share": ms / step_ms if step_ms else None, "traffic": None,
              "algorithmic_bytes": float(B) * S * Wd * (sp.cin + sp.cout) * (2 if dtype == "bf16" else 4)}
         if dtype == "fp32":
+            # the split-operand kernels issue products_per_tap half-precision MFMA products per algorithmic fp32 product: `achieved` / `frac`
+            # are the EXECUTED matrix work against the dense bf16 MFMA peak (the pipe these kernels run on); the algorithmic fp32 rate is
+            # beside it (gfx950's own fp32 matrix rate is 157 TFLOP/s -- these kernels beat it, which is their point, not a roofline)
             from mmif._lib import lib as _l
             prods = {16: 3, 3: 6, 2: 3}[_l.mmif_get_x3_forward_pieces()] if kind == "fwd" else 3
             r["products_per_tap"] = prods
-            r["executed_mfma_tflops"] = ach * prods / 1e12
-            r["executed_frac_of_bf16_mfma_peak"] = ach * prods / PEAK_MFMA_BF16
-            r["peak_note"] = "peak = fp32 matrix (157 TFLOP/s); the split-operand kernels issue products_per_tap half-precision MFMA products per algorithmic product"
+            r["algorithmic_fp32_tflops"] = ach / 1e12
+            r["achieved"] = r["executed_mfma_tflops"] = ach * prods / 1e12
+            r["frac"] = r["executed_frac_of_bf16_mfma_peak"] = ach * prods / PEAK_MFMA_BF16
+            r["peak_note"] = "achieved = executed half-precision MFMA work (products_per_tap x the algorithmic fp32 flops); peak = dense bf16 MFMA"
         if workload_id is not None:
             # HBM bytes per launch from the TCC PMC passes of the same command (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs,
             # gfx950 correction applied, tools/prof_pmc.sh + tools/make_traffic.py) -- only when taken on THIS library build
@@ -294,6 +305,67 @@ def parity_leg(args, dev, img1, img2):
                 "tolerance": "BASELINE north star: 1e-3 relative"}
     finally:
         E.set_compute_dtype(prev)
+
+
+# the other BASELINE.json configs, timed by the same process after the headline leg (verdict r5 item 1d): (key, model, mode, batch, H, W, config)
+OTHER_CONFIGS = (("DenseFuse_b32_256", "DenseFuse", "train", 32, 256, 256, "configs[2] per-GPU share: DenseFuse 256x256 bf16, batch 32 per GPU"),
+                 ("NestFuse_b4_512", "NestFuse", "train", 4, 512, 512, "configs[3]: NestFuse 512x512 bf16, batch 4 per GPU"),
+                 ("RFNNest_b4_512", "RFNNest", "train", 4, 512, 512, "configs[3]: RFN-Nest 512x512 bf16, batch 4 per GPU"),
+                 ("infer_1224x1024", "PFNetv1", "infer", 1, 1024, 1224, "configs[4]: PFNetv1 forward (no_grad, test.py path) on one 1224x1024 pair, bf16"))
+
+
+def other_configs_leg(args, dev):
+    """BASELINE.json's configs 3, 4 and 5 on this GPU, each `--other-steps` timed steps after `--other-warmup` untimed ones (device
+    synchronised on both sides), bf16 feature maps, through the same drop-in API and the same step function as the headline leg: value
+    (image-pairs/s), ms_per_step and the fraction of SURVEY 8(d)'s ideal.  About 2 s of GPU time in total."""
+    import core.model as M
+    from core.loss import FusionLoss, GradLoss, PixelLoss, SSIMLoss, unit_gradient
+    from mmif import engine as E
+    from mmif.optim import FusedClipAdam
+    prev = E.compute_dtype()
+    E.set_compute_dtype("bf16")
+    res = {}
+    try:
+        for key, name, mode, B, H, Wd, what in OTHER_CONFIGS:
+            torch.manual_seed(0)
+            model = getattr(M, name)().to(dev)
+            gen = torch.Generator(device="cpu").manual_seed(0)
+            a = torch.rand(B, 1, H, Wd, generator=gen).to(dev)
+            b = torch.rand(B, 1, H, Wd, generator=gen).to(dev)
+            if mode == "train":
+                opt = FusedClipAdam(model.parameters(), lr=1e-4, betas=(0.9, 0.999), max_norm=5.0)
+                l_all = FusionLoss(SSIMLoss('ssim', weight=1.0), PixelLoss('l1', weight=0.01), GradLoss('l1', weight=0.1).to(dev), 'max', 'max')
+
+                def one():
+                    opt.zero_grad(set_to_none=True)
+                    f = model(a, b)
+                    tot = l_all(a, b, f)
+                    tot.backward(unit_gradient(tot))
+                    opt.step(scalars=l_all.values)
+                    return tot
+            else:
+                def one():
+                    with torch.no_grad():
+                        return model(a, b).mean()
+            for _ in range(args.other_warmup):
+                one()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.other_steps):
+                tot = one()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            value = B * args.other_steps / dt
+            ideal = ideal_pairs_per_s(name, H, Wd, "bf16", 1, mode)
+            res[key] = {"config": what, "model": name, "mode": mode, "batch": B, "height": H, "width": Wd, "dtype": "bf16", "value": value,
+                        "unit": "image-pairs/s", "ms_per_step": dt / args.other_steps * 1e3, "steps": args.other_steps, "warmup": args.other_warmup,
+                        "step_frac_of_ideal": value / ideal if ideal else None, "ideal_pairs_per_s_per_gpu": ideal, "final_value": float(tot.item())}
+            del model, a, b
+            if mode == "train":
+                del opt, l_all
+    finally:
+        E.set_compute_dtype(prev)
+    return res
 
 
 def free_port():
@@ -516,11 +588,16 @@ def main():
             "roofline_hbm": roof_hbm,
             "roofline_hbm_bwd": roof_hbm_bwd,
             "parity_path": None,
+            "other_configs": None,
             "cpu_baseline": None,
         }
         assert out["n_gpus"] == args.gpus
         if world == 1 and not args.no_parity_path and args.mode == "train" and args.dtype == "bf16" and args.model in ("PFNetv1", "DenseFuse", "PFNetv2", "VIFNet"):
             out["parity_path"] = parity_leg(args, dev, img1, img2)
+        headline = (args.model, args.mode, args.dtype, B, S, Wd) == ("PFNetv1", "train", "bf16", 32, 256, 256)
+        if world == 1 and not args.no_other_configs and headline and not args.graph:
+            del tot
+            out["other_configs"] = other_configs_leg(args, dev)
         if world == 1 and not args.no_cpu_baseline and args.mode == "train" and Wd == S:
             out["cpu_baseline"] = cpu_baseline(args.model, S, args.cpu_sample)
     else:

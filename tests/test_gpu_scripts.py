@@ -93,23 +93,45 @@ def test_bench_two_ranks_gloo_one_device():
     assert out["parity_path"] is None and out["cpu_baseline"] is None       # N = 1 only
 
 
-@pytest.mark.parametrize("model,batch", [("PFNetv1", 4), ("DenseFuse", 4)])
-def test_bench_eight_ranks_gloo_one_device_preflight(model, batch):
-    """Pre-flight for the driver's first real `--gpus 8` run (round-4 verdict item 9; reference train.py:203-222, 285-297): eight ranks
-    through the self-launch, one rendezvous port, the stdout discipline (ONE JSON line, last), global_batch = 8 x per-rank batch, `dp8`
-    -- configs 2 (PFNetv1) and 3 (DenseFuse, batch split over 8 ranks).  One GPU here, so the ranks share cuda:0 over gloo; nothing is
-    measured, everything must not break."""
+@pytest.mark.parametrize("model,batch,gpus,size", [("PFNetv1", 4, 8, 256), ("DenseFuse", 4, 8, 256), ("NestFuse", 1, 4, 64)])
+def test_bench_eight_ranks_gloo_one_device_preflight(model, batch, gpus, size):
+    """Pre-flight for the driver's first real `--gpus 8` run (round-4 verdict item 9, round-5 item 10; reference train.py:203-222, 285-297):
+    N ranks through the self-launch, one rendezvous port, the stdout discipline (ONE JSON line, last), n_gpus = N, global_batch = N x
+    per-rank batch, `dpN` -- configs 2 (PFNetv1) and 3 (DenseFuse, batch split over 8 ranks) on 8 ranks, config 4 (NestFuse) on its 4.
+    One GPU here, so the ranks share cuda:0 over gloo; nothing is measured, everything must not break."""
     import json
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--one-device", "--model", model, "--batch", str(batch),
-                        "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-parity-path"], capture_output=True, text=True, timeout=1500, cwd=ROOT)
-    assert r.returncode == 0, f"bench.py --gpus 8 failed:\n{r.stdout[-3000:]}\n{r.stderr[-3000:]}"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--backend", "gloo", "--one-device", "--model", model, "--batch", str(batch),
+                        "--size", str(size), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-parity-path"], capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, f"bench.py --gpus {gpus} failed:\n{r.stdout[-3000:]}\n{r.stderr[-3000:]}"
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert sum(1 for l in lines if l.lstrip().startswith("{")) == 1, lines[-5:]      # exactly one JSON line on stdout
     out = json.loads(lines[-1])
-    assert out["n_gpus"] == 8 and out["config"]["global_batch"] == 8 * batch and out["config"]["parallelism"] == "dp8"
+    assert out["n_gpus"] == gpus and out["config"]["global_batch"] == gpus * batch and out["config"]["parallelism"] == f"dp{gpus}"
+    assert out["config"]["backend"] == "gloo"
     assert out["scaling"] == "weak" and out["steps"] == 2 and out["value"] > 0 and model in out["config"]["workload"]
     assert np.isfinite(out["final_loss"]) and 0.0 < out["final_loss"] < 10.0
-    assert out["parity_path"] is None and out["cpu_baseline"] is None
+    assert out["parity_path"] is None and out["cpu_baseline"] is None and out["other_configs"] is None     # N = 1 only
+
+
+def test_bench_other_configs_block_small_shapes(monkeypatch):
+    """`other_configs` of bench.py's line (verdict r5 item 1d): the leg that times BASELINE configs 3, 4, 5 after the headline, run here on
+    small stand-ins of the four configs (same models / modes / step function): every entry carries value, ms_per_step and -- where SURVEY
+    8(d) has a row -- the fraction of ideal; losses finite; the compute dtype is restored."""
+    import argparse
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from mmif import engine as E
+    monkeypatch.setattr(bench, "OTHER_CONFIGS", (("DenseFuse_small", "DenseFuse", "train", 2, 64, 64, "t"), ("NestFuse_small", "NestFuse", "train", 1, 64, 64, "t"),
+                                                 ("RFNNest_small", "RFNNest", "train", 1, 64, 64, "t"), ("infer_small", "PFNetv1", "infer", 1, 72, 104, "t")))
+    prev = E.compute_dtype()
+    res = bench.other_configs_leg(argparse.Namespace(other_steps=2, other_warmup=1), torch.device("cuda", 0))
+    assert E.compute_dtype() == prev
+    assert set(res) == {"DenseFuse_small", "NestFuse_small", "RFNNest_small", "infer_small"}
+    for k, v in res.items():
+        assert v["value"] > 0 and v["ms_per_step"] > 0 and v["steps"] == 2 and np.isfinite(v["final_value"]), (k, v)
+        assert v["step_frac_of_ideal"] is not None and 0 < v["step_frac_of_ideal"] < 1, (k, v)
+    assert [c[0] for c in bench.OTHER_CONFIGS] and {c[1] for c in bench.OTHER_CONFIGS} == {"DenseFuse", "NestFuse", "RFNNest", "PFNetv1"}
 
 
 def test_bench_single_gpu_line_has_the_contract_fields():
@@ -128,4 +150,5 @@ def test_bench_single_gpu_line_has_the_contract_fields():
     assert cb["kind"] == "port" and cb["steps"] >= 3 and cb["cores"] <= 32 and cb["value"] >= cb["median_value"] > 0
     pp = out["parity_path"]
     assert pp["rel_err_vs_oracle"] < 1e-3 and pp["grad_rel_err_vs_oracle"] < 1e-3 and len(pp["oracle_samples"]) == 2
-    assert pp["roofline"]["peak"] == 157.0 and pp["roofline"]["products_per_tap"] == 3 and pp["roofline"]["executed_mfma_tflops"] > pp["roofline"]["achieved"]
+    assert pp["roofline"]["peak"] == 2500.0 and pp["roofline"]["products_per_tap"] == 3 and pp["roofline"]["frac"] < 1.0
+    assert abs(pp["roofline"]["executed_mfma_tflops"] - 3 * pp["roofline"]["algorithmic_fp32_tflops"]) < 1e-6 * pp["roofline"]["executed_mfma_tflops"]
