@@ -269,6 +269,22 @@ int mmif_conv2d_image_out_dgrad(const float* gimg, const float* y_img, const flo
 int mmif_conv2d_image_out_wgrad(const mmif_tensor* x, const float* gimg, const float* y_img, float* dw, float* db,
                                 int32_t cin, int32_t ksize, int32_t accumulate, void* workspace,
                                 size_t workspace_bytes, void* stream);
+
+/* The whole backward of the decoders' last layer -- ConvLayer(16, 1, 3x3) of PFNetv1 / DenseFuse / PFNetv2 / VIFNet, reference
+ * core/model.py:86,178 -- as ONE launch (round 6, csrc/image_bwd.hip): dL/dx with the reflect-padding adjoint applied and the ReLU mask of
+ * the layer's input (x > 0), dW and db.  Replaces mmif_conv2d_image_out_wgrad + mmif_conv2d_image_out_dgrad + mmif_fold_halo on that layer.
+ *   x      the layer's input activations, 16 channels (2 channel blocks), halo 0, bf16
+ *   gimg   dL/dy, [n][h][w] fp32;  y_img: the layer's output when it has a ReLU (the gradient is masked by y > 0), else NULL
+ *   w      fp32 [1][16][3][3]
+ *   gx     dL/dx, 2 channel blocks, halo 1: the interior is written (every channel block masked by x > 0, one rounding); the halo ring is
+ *          NOT touched and must be zero on entry -- the result is a FOLDED gradient (MMIF_T_FOLDED semantics)
+ *   dw, db as mmif_conv2d_image_out_wgrad (workspace: mmif_conv2d_image_wgrad_workspace(16, 3))
+ * mmif_conv2d_image_out_bwd_supported says whether (dtype, cin, ksize, h, w) is taken: bf16, 16 channels, 3x3, h, w >= 4; otherwise the
+ * call returns MMIF_EINVAL and the caller uses the three separate entry points. */
+int32_t mmif_conv2d_image_out_bwd_supported(int32_t dtype, int32_t cin, int32_t ksize, int32_t h, int32_t w);
+int mmif_conv2d_image_out_bwd(const mmif_tensor* x, const float* gimg, const float* y_img, const float* w, const mmif_tensor* gx,
+                              float* dw, float* db, int32_t cin, int32_t ksize, int32_t accumulate, void* workspace,
+                              size_t workspace_bytes, void* stream);
 size_t mmif_conv2d_image_wgrad_workspace(int32_t c, int32_t ksize);
 
 /* ---- fusion functions (core/fusion.py) ---- */
@@ -509,6 +525,10 @@ void mmif_debug_set_thin_wide(int32_t mode);
  * compute units to a kernel that runs concurrently on another stream -- the intra-step overlap of decode.0's weight gradient with the
  * encoder's backward (mmif/engine.py, $MMIF_OVERLAP).  Results change in the last bits only (the per-block partial sums regroup). */
 void mmif_debug_set_wgrad_dma_blocks(int32_t blocks);
+/* Weight gradients of 3x3 layers whose channel counts are not multiples of 64 (round 6; NestFuse's 88 / 120 / 136 / 152 / 184 / 304-channel
+ * layers): 1 (default, $MMIF_WGRAD_RAGGED) = wgrad_dma_kernel does not stage the channel-block planes of a ragged last group that lie past the
+ * tensor (their products are never reduced), 0 = it re-reads the last real plane for them as before.  Identical dW / db either way. */
+void mmif_debug_set_ragged(int32_t mode);
 /* Deferred weight-gradient reductions (round 5, csrc/reduce_defer.hip).  Every weight-gradient entry point above ends in a small fixed-order
  * reduce launch over its per-block partial sums -- autograd's accumulation of `convolution_backward`'s weight / bias gradients into `.grad`
  * (`train.py:71`).  Between begin() and flush() the reduces of mmif_conv2d_reflect_bwd_wide, mmif_conv2d_reflect_bwd_pair and

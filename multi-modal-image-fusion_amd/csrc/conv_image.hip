@@ -400,6 +400,13 @@ __global__ __launch_bounds__(64 * RED_SLICES) void image_out_wgrad_reduce(const 
 
 constexpr int IMG_G = 512;
 
+// (csrc/image_bwd.hip: the fused backward of the 16 -> 1 layer leaves its block partials in image_out_wgrad_kernel's layout)
+int image_out_wgrad_reduce3_launch(const float* ws, float* dw, float* db, int cin, int G, int n_cg, int accumulate, hipStream_t st) {
+    const int n = cin * 9 + 1;
+    hipLaunchKernelGGL((image_out_wgrad_reduce<3>), dim3(cdiv(n, 64)), dim3(64 * RED_SLICES), 0, st, ws, dw, db, cin, G, n_cg, accumulate);
+    return check_launch("image_out_wgrad_reduce");
+}
+
 }  // namespace mmif
 
 using namespace mmif;

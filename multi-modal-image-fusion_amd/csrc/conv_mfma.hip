@@ -1597,7 +1597,8 @@ constexpr int WDL_ITERS = (WD_PIECES + D_LOAD - 1) / D_LOAD;   // 19 pieces per 
 constexpr int WD_PER = 64 * 64 * 9 + 64;                   // floats per block partial: dW[64 oc][64 ic][9], db[64]
 
 __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void wgrad_dma_kernel(TV tx, TV tg, float* __restrict__ partial, int tiles_x,
-                                                                               int tpi, int total, int G, int n_icg, int n_ocg, SignMap sgn) {
+                                                                               int tpi, int total, int G, int n_icg, int n_ocg, SignMap sgn,
+                                                                               int ragged_skip) {
     constexpr int TP = MT + 2;
     __shared__ __attribute__((aligned(16))) char s_buf[2 * WD_BUF_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1640,6 +1641,12 @@ __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void wgrad_dma_kernel(TV
                 pl_off[i] = P < WD_XPIECES ? (unsigned)min(pl, xpl_max0) * xplane : (unsigned)min(pl, gpl_max0) * gplane;
             }
         }
+        // Ragged last channel group (round 6; NestFuse: 152 = 64 + 64 + 24 output, 304 = 4 x 64 + 48 input channels): the pieces that hold
+        // only planes past the tensor are not requested at all -- the kernel runs at the rate its tiles are staged (74 KB per tile and block,
+        // ~4.4 TB/s over the chip, measured round 6), and those pieces used to re-read the last real plane.  The consumers multiply whatever
+        // the slots hold: those dW rows / columns and db entries are never reduced.  ($MMIF_WGRAD_RAGGED=0 stages them as before)
+        const int px_end = ragged_skip ? (min(8, tx.cb - icg * 8) * WG_XPL + 63) / 64 : WD_XPIECES;
+        const int pg_end = WD_XPIECES + (ragged_skip ? (min(8, tg.cb - ocg * 8) * WG_GPL + 63) / 64 : WD_GPIECES);
         auto issue = [&](int tile, int buf) {
             const int in_ = tile / tpi, tt = tile - in_ * tpi;
             const int y0 = (tt / tiles_x) * MT, x0 = (tt % tiles_x) * MT;
@@ -1650,6 +1657,7 @@ __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void wgrad_dma_kernel(TV
             for (int i = 0; i < WDL_ITERS; ++i) {
                 const int P = lw + D_LOAD * i;   // wave uniform
                 const int py = (int)((geo[i] >> 8) & 255u), px = (int)(geo[i] & 255u);
+                if (P >= px_end && (P < WD_XPIECES || P >= pg_end)) continue;
                 if (P < WD_XPIECES) {
                     const int y = min(max(reflect_idx(y0 + py - 1, tx.h), 0), tx.h - 1);
                     const int x = min(max(reflect_idx(x0 + px - 1, tx.w), 0), tx.w - 1);
@@ -2379,6 +2387,7 @@ static int g_fuse_fold = -1;   // $MMIF_DGRAD_FOLD: 1 (default) = the DMA-staged
 static int g_abl = 0;            // $MMIF_CONV_ABLATE (diagnostics): bit 0 = no staging DMAs after the first chunk
 
 static int g_lmask = -1;
+static int g_wgrad_ragged = 1;    // mmif_debug_set_ragged / $MMIF_WGRAD_RAGGED=0: wgrad_dma_kernel stages the padded planes of a ragged channel group too (A/B)
 // the environment switches, read once -- by whichever entry point runs first (a process whose first MFMA call was a weight gradient used
 // to leave g_fuse_fold unset, i.e. the stand-alone fold kernel for the rest of its life)
 static void init_modes() {
@@ -2388,6 +2397,8 @@ static void init_modes() {
     g_abl = ablate_env("MMIF_CONV_ABLATE");
     const char* r = getenv("MMIF_DGRAD_FOLD");
     g_fuse_fold = (r != nullptr && r[0] == '0') ? 0 : 1;
+    const char* q = getenv("MMIF_WGRAD_RAGGED");
+    if (q != nullptr && q[0] == '0') g_wgrad_ragged = 0;
 }
 static int launch_conv_dma(bool dgrad, const TV& tin, const TV& tout, const TV& tmask, const void* wpk, const float* bias, int n_out,
                            int relu, uint64_t mask_bits, uint64_t accum_bits, int org, hipStream_t st, SignMap sgn = SignMap{nullptr, 0, 0, 0}) {
@@ -2604,7 +2615,7 @@ static int launch_wgrad_dma(const TV& tx, const TV& tg, float* dw, float* db, in
     if (G > total) G = total;   // every tile group owns at least one tile (the reduce sums all G partials)
     ws = defer_ws(ws, (size_t)G * n_icg * n_ocg * WD_PER * sizeof(float));      // (csrc/reduce_defer.hpp: an arena slot while reductions are deferred)
     hipLaunchKernelGGL(wgrad_dma_kernel, dim3(G * n_icg * n_ocg), dim3((D_CONS + D_LOAD) * 64), 0, st, tx, tg, ws, tiles_x, tpi, total, G,
-                       n_icg, n_ocg, sgn);
+                       n_icg, n_ocg, sgn, g_wgrad_ragged);
     if (int rc = check_launch("wgrad_dma")) return rc;
     const int n = cout * cin * 9 + cout;
     const int RG = G;
@@ -2678,6 +2689,7 @@ extern "C" void mmif_debug_set_trace(void* device_buf) { mmif::g_trace = (long l
 extern "C" void mmif_debug_set_conv_dma(int32_t mode) { mmif::g_dma_mode = mode ? 1 : 0; }
 extern "C" void mmif_debug_set_bwd_pair_dma(int32_t mode) { mmif::debug_set_bwd_pair_dma(mode); }
 extern "C" void mmif_debug_set_thin_wide(int32_t mode) { mmif::g_thin_wide = mode ? 1 : 0; }
+extern "C" void mmif_debug_set_ragged(int32_t mode) { mmif::g_wgrad_ragged = mode ? 1 : 0; }
 extern "C" void mmif_debug_set_wgrad_dma_blocks(int32_t blocks) { mmif::g_wgrad_dma_blocks = blocks < 8 ? 8 : (blocks > 256 ? 256 : blocks); }
 
 extern "C" size_t mmif_packed_weight_bytes(int32_t cout, int32_t cin, int32_t ksize) {

@@ -135,6 +135,8 @@ SIGNATURES = {
     "mmif_conv2d_image_out_dgrad": (_i32, [_vp, _vp, _vp, _TP, _TP, _i32, _i32, _u64, _u64, _vp]),
     "mmif_conv2d_image_out_wgrad": (_i32, [_TP, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),
     "mmif_conv2d_image_wgrad_workspace": (_sz, [_i32, _i32]),
+    "mmif_conv2d_image_out_bwd_supported": (_i32, [_i32, _i32, _i32, _i32, _i32]),
+    "mmif_conv2d_image_out_bwd": (_i32, [_TP, _vp, _vp, _vp, _TP, _vp, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),
     "mmif_fuse_elem_fwd": (_i32, [_TP, _TP, _TP, _i32, _vp]),
     "mmif_fuse_elem_bwd": (_i32, [_TP, _TP, _TP, _TP, _TP, _i32, _i32, _vp]),
     "mmif_fuse_attn_workspace": (_sz, [_i32, _i32]),
@@ -173,6 +175,7 @@ SIGNATURES = {
     "mmif_debug_set_bwd_pair_dma": (None, [_i32]),
     "mmif_debug_set_thin_wide": (None, [_i32]),
     "mmif_debug_set_wgrad_dma_blocks": (None, [_i32]),
+    "mmif_debug_set_ragged": (None, [_i32]),
     "mmif_debug_set_enc_stream2": (None, [_i32]),
     "mmif_probe_tr16": (_i32, [_vp, _vp, _vp]),
     "mmif_probe_mfma": (_i32, [_vp, _vp, _vp, _vp]),

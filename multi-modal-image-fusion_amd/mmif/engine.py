@@ -470,6 +470,16 @@ class ModelEngine:
         else:
             T.conv_wgrad(x, gy, s.dw, s.db, s.cin, s.cout, s.k, ws, accumulate, impl, s.name + ":wgrad")
 
+    @staticmethod
+    def image_layer_bwd(last, x, gout, yout, g, ws):
+        """backward of the decoder's last layer (Cout = 1): dW, db and the folded, masked input gradient in g.  bf16, 16 channels, 3x3: ONE
+        launch (csrc/image_bwd.hip, round 6; $MMIF_IMAGE_BWD=0: weight gradient, input gradient and fold as three)"""
+        if switch("MMIF_IMAGE_BWD") and T.image_out_bwd_supported(x, last.cin, last.k) and g.cb == 2:
+            return T.image_out_bwd(x, gout, yout, last.w.detach(), g, last.dw, last.db, last.cin, last.k, ws)
+        T.image_out_wgrad(x, gout, yout, last.dw, last.db, last.cin, last.k, ws)
+        T.image_out_dgrad(gout, yout, last.w.detach(), x, g, last.cin, last.k, all_bits(g.cb), 0)
+        return g.fold_halo_() if last.k > 1 else g.as_folded()
+
     # ---- intra-step overlap ($MMIF_OVERLAP=1; round 5) ------------------------------------------------
     # decode.0's weight gradient (matrix-pipe / power bound, off the critical path: nothing downstream reads dW) runs on a SECOND stream
     # with a reduced persistent grid ($MMIF_OVERLAP_BLOCKS of the 256 CU slots) while the encoder's backward (LDS-issue / HBM bound)
@@ -748,10 +758,8 @@ class PFNetv1Engine(ModelEngine, DenseEncoderMixin):
         # the decoder's weight-gradient reduces as ONE launch at the end of the decoder's backward (not with the side-stream experiment: its
         # producer runs on another stream)
         deferred = dtype == torch.bfloat16 and not switch("MMIF_OVERLAP", "0") and self.defer_reduces(dev, self.dec)
-        T.image_out_wgrad(x, gout, L.out, last.dw, last.db, last.cin, last.k, ws)
         g = self.buf(L, f"G{len(acts) - 1}", n, last.cin, h, w, dtype, dev, halo=1)
-        T.image_out_dgrad(gout, L.out, last.w.detach(), x, g, last.cin, last.k, all_bits(g.cb), 0)
-        g = g.fold_halo_() if last.k > 1 else g.as_folded()
+        g = self.image_layer_bwd(last, x, gout, L.out, g, ws)
         for i in range(len(self.dec) - 2, -1, -1):
             s, x = self.dec[i], acts[i]
             gx = self.buf(L, f"G{i}", n, s.cin, h, w, dtype, dev, halo=1)
@@ -866,10 +874,8 @@ class DenseFuseEngine(ModelEngine, DenseEncoderMixin):
         # the decoder's weight-gradient reduces as ONE launch at the end of the decoder's backward (not with the side-stream experiment: its
         # producer runs on another stream)
         deferred = dtype == torch.bfloat16 and not switch("MMIF_OVERLAP", "0") and self.defer_reduces(dev, self.dec)
-        T.image_out_wgrad(x, gout, L.out, last.dw, last.db, last.cin, last.k, ws)
         g = self.buf(L, f"G{len(acts) - 1}", n, last.cin, h, w, dtype, dev, halo=1)
-        T.image_out_dgrad(gout, L.out, last.w.detach(), x, g, last.cin, last.k, all_bits(g.cb), 0)
-        g = g.fold_halo_() if last.k > 1 else g.as_folded()
+        g = self.image_layer_bwd(last, x, gout, L.out, g, ws)
         for i in range(len(self.dec) - 2, -1, -1):
             s, x = self.dec[i], acts[i]
             gx = self.buf(L, f"G{i}", n, s.cin, h, w, dtype, dev, halo=1)

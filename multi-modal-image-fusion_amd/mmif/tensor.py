@@ -361,6 +361,19 @@ def image_out_wgrad(x, gimg, yimg, dw, db, cin, k, ws, accumulate=False):
                                           ws.numel() * ws.element_size(), stream_ptr()), "image_out_wgrad")
 
 
+def image_out_bwd_supported(x, cin, k):
+    """the fused backward of the 16 -> 1 layer (csrc/image_bwd.hip) takes this activation tensor"""
+    return bool(lib.mmif_conv2d_image_out_bwd_supported(x.code, cin, k, x.h, x.w)) and x.halo == 0 and x.cb == 2
+
+
+def image_out_bwd(x, gimg, yimg, w, gx, dw, db, cin, k, ws, accumulate=False):
+    """dL/dx (reflect adjoint applied, masked by x > 0, into the interior of the zero-ringed halo-1 tensor gx), dW, db of the Cout = 1 layer in
+    ONE launch; returns gx as a folded view"""
+    check(lib.mmif_conv2d_image_out_bwd(x.d, _ptr(gimg), _ptr(yimg), _ptr(w), gx.d, _ptr(dw), _ptr(db), cin, k, int(accumulate), _ptr(ws),
+                                        ws.numel() * ws.element_size(), stream_ptr()), "image_out_bwd")
+    return gx.as_folded()
+
+
 def fuse_elem_fwd(a, b, out, mode):
     check(lib.mmif_fuse_elem_fwd(a.d, b.d, out.d, mode, stream_ptr()), "fuse_elem_fwd")
 

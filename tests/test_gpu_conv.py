@@ -72,6 +72,10 @@ DMA_SHAPES = [(128, 128, 2, 37, 53), (176, 112, 1, 64, 48), (72, 64, 2, 33, 40),
 # two tiles: >= 512 tiles of 16x16
 DMA_SHAPES += [(16, 16, 3, 180, 200), (48, 16, 2, 250, 270), (16, 48, 3, 178, 190), (32, 16, 2, 256, 256), (24, 40, 2, 257, 300),
                (48, 48, 2, 241, 275), (8, 16, 2, 256, 300)]
+# NestFuse's decoder / encoder 3x3 layers (reference core/block.py:836-867: channel counts that are not multiples of 64 -- ragged last
+# M-block in forward (Cout) and dgrad (Cin), ragged 64-channel groups in the weight gradient, which skips the staging of their padded planes)
+DMA_SHAPES += [(304, 152, 1, 48, 40), (176, 88, 2, 33, 48), (272, 136, 1, 40, 56), (240, 120, 1, 64, 32), (384, 192, 1, 32, 48), (368, 184, 1, 36, 44),
+               (112, 56, 2, 40, 40), (160, 80, 1, 64, 64), (64, 72, 1, 70, 50), (80, 200, 1, 34, 34)]
 _rng = np.random.default_rng(20240)
 DMA_SHAPES += [(int(_rng.integers(7, 40)) * 8, int(_rng.integers(7, 32)) * 8, int(_rng.integers(1, 4)), int(_rng.integers(8, 90)),
                 int(_rng.integers(8, 90))) for _ in range(10)]   # seeded random shapes: ragged everything
@@ -114,6 +118,57 @@ def test_dma_staged_kernels_equal_register_staged(cin, cout, n, h, w):
     assert torch.equal(res[0][1], res[1][1]), "dgrad differs"
     close(res[1][2].cpu().numpy(), res[0][2].cpu().numpy(), 2e-5, "dw")
     close(res[1][3].cpu().numpy(), res[0][3].cpu().numpy(), 2e-5, "db")
+
+
+RAGGED_SHAPES = [(304, 152, 2, 96, 80), (176, 88, 1, 128, 128), (272, 136, 2, 64, 72), (384, 192, 1, 96, 96), (120, 72, 1, 130, 70), (64, 136, 2, 50, 66)]
+
+
+@pytest.mark.parametrize("cin,cout,n,h,w", RAGGED_SHAPES, ids=[f"{a}-{b}-{n}x{h}x{w}" for a, b, n, h, w in RAGGED_SHAPES])
+def test_ragged_channel_groups_on_equals_off(cin, cout, n, h, w):
+    """Round 6: wgrad_dma_kernel skips the staging of channel-block planes past the tensor in a ragged last 64-channel group
+    (mmif_debug_set_ragged): the consumers then multiply stale LDS contents for the padded fragments, which must not reach any real output --
+    dW / db identical to the run that stages them, forward and input gradient untouched (with ReLU masks / accumulation in the ragged block as
+    well) -- and the weight gradient against its fp64 definition on the bf16 operands."""
+    from mmif import tensor as T
+    from mmif._lib import IMPL_MFMA, lib
+    dev = "cuda:0"
+    torch.manual_seed(cin * 3 + cout)
+    x = T.BT.alloc(n, cin, h, w, torch.bfloat16, dev); x.buf.normal_()
+    gy = T.BT.alloc(n, cout, h, w, torch.bfloat16, dev, halo=1, zero=True); gy.buf[:, :, 1:-1, 1:-1].normal_()
+    gy = gy.as_folded()
+    wt = torch.randn(cout, cin, 3, 3, device=dev) * 0.05
+    b = torch.randn(cout, device=dev)
+    pk = T.PackedWeights(cout, cin, 3, dev); pk.pack(wt)
+    ws = torch.empty(T.wgrad_workspace_bytes(cin, cout, 3) // 4 + 1, dtype=torch.float32, device=dev)
+    mask = 0xa5a5a5a5a5a5a5 & ((1 << x.cb) - 1) | (1 << (x.cb - 1))      # (the ragged last block's channel blocks masked AND accumulated)
+    acc_bits = 0xcccccccccccccc & ((1 << x.cb) - 1) | (1 << (x.cb - 1))
+    res = {}
+    try:
+        for mode in (0, 1):
+            lib.mmif_debug_set_ragged(mode)
+            y = T.BT.alloc(n, cout, h, w, torch.bfloat16, dev)
+            y.buf.fill_(7.0)          # (a fragment past the tensor must not be stored anywhere)
+            gx = T.BT.alloc(n, cin, h, w, torch.bfloat16, dev, halo=1, zero=True)
+            gx.buf[:, :, 1:-1, 1:-1].fill_(0.25)
+            dw, db = torch.zeros_like(wt), torch.zeros_like(b)
+            T.conv_fwd(x, wt, b, y, cin, cout, 3, True, pk, IMPL_MFMA)
+            T.conv_dgrad(gy, wt, x, gx, cin, cout, 3, mask, acc_bits, pk, IMPL_MFMA, fold=True)
+            T.conv_wgrad(x, gy, dw, db, cin, cout, 3, ws, False, IMPL_MFMA)
+            torch.cuda.synchronize()
+            res[mode] = (y.buf.clone(), gx.buf.clone(), dw, db)
+    finally:
+        lib.mmif_debug_set_ragged(1)
+    assert torch.equal(res[0][0], res[1][0]), "fwd differs"
+    assert torch.equal(res[0][1], res[1][1]), "dgrad differs"
+    close(res[1][2].cpu().numpy(), res[0][2].cpu().numpy(), 2e-5, "dw")
+    close(res[1][3].cpu().numpy(), res[0][3].cpu().numpy(), 2e-5, "db")
+    # the weight gradient against its fp64 definition on the same bf16 operands (reflect-padded x, interior of gy)
+    xs = x.to_nchw().double()
+    gs = gy.to_nchw().double()
+    xp = torch.nn.functional.pad(xs, (1, 1, 1, 1), mode="reflect")
+    ref = torch.nn.grad.conv2d_weight(xp, wt.shape, gs)
+    close(res[1][2].cpu().numpy(), ref.cpu().numpy(), 1e-4, "dw vs fp64")
+    close(res[1][3].cpu().numpy(), gs.sum(dim=(0, 2, 3)).cpu().numpy(), 1e-4, "db vs fp64")
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

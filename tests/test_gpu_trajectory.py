@@ -43,6 +43,16 @@ def _batches():
 
 
 def _cpu_run(batches):
+    # (8 intra-op threads: on the 256-CPU GPU box torch's default pool made this 64 x 64 run take 275 s instead of ~35)
+    prev = torch.get_num_threads()
+    torch.set_num_threads(min(8, prev))
+    try:
+        return _cpu_run_(batches)
+    finally:
+        torch.set_num_threads(prev)
+
+
+def _cpu_run_(batches):
     m = TC.TorchCpuModel("PFNetv1")
     P = m.init_params(0)
     opt = TC.make_optimizer(P)

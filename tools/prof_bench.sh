@@ -4,7 +4,7 @@
 tag=$1; shift
 R=$PWD; cd /tmp && export TMPDIR=/tmp; cd $R
 rm -rf gpurun_out/prof_$tag
-rocprofv3 --kernel-trace -d gpurun_out/prof_$tag -o b -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline "$@" > gpurun_out/prof_$tag.log 2>&1
+rocprofv3 --kernel-trace -d gpurun_out/prof_$tag -o b -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-other-configs "$@" > gpurun_out/prof_$tag.log 2>&1
 db=$(find gpurun_out/prof_$tag -name "*.db" | head -1)
 python3 tools/rocpd_stats.py $db 13 > gpurun_out/kstats_$tag.txt
 head -40 gpurun_out/kstats_$tag.txt

@@ -7,7 +7,7 @@ tag=$1
 R=$PWD; cd /tmp && export TMPDIR=/tmp; cd $R
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmc_${tag}_$c
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmc_${tag}_$c -o p -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity-path > gpurun_out/pmc_${tag}_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmc_${tag}_$c -o p -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity-path --no-other-configs > gpurun_out/pmc_${tag}_$c.log 2>&1
   csv=$(find gpurun_out/pmc_${tag}_$c -name "*counter_collection.csv" | head -1)
   python3 tools/pmc_stats.py $csv > gpurun_out/pmc_${tag}_$c.txt
   python3 tools/pmc_per_dispatch.py $csv "conv_dma_kernel<false" > gpurun_out/pmc_${tag}_${c}_decode_fwd.txt

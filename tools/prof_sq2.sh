@@ -6,7 +6,7 @@
 tag=$1; pmc=$2; shift; shift
 R=$PWD; cd /tmp && export TMPDIR=/tmp; cd $R
 rm -rf gpurun_out/sq_$tag
-timeout 300 rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d gpurun_out/sq_$tag -o p -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity-path "$@" > gpurun_out/sq_$tag.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d gpurun_out/sq_$tag -o p -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity-path --no-other-configs "$@" > gpurun_out/sq_$tag.log 2>&1
 csv=$(find gpurun_out/sq_$tag -name "*counter_collection.csv" | head -1)
 python3 tools/pmc_stats.py $csv > gpurun_out/sq_$tag.txt
 grep -i "kernel\|pairconv" gpurun_out/sq_$tag.txt | head -12

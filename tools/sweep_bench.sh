@@ -1,4 +1,4 @@
-run() { python bench.py --steps 10 --warmup 3 --no-cpu-baseline "$@" 2>&1 | tail -1 | python -c "import sys,json
+run() { python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-other-configs "$@" 2>&1 | tail -1 | python -c "import sys,json
 l=sys.stdin.read().strip()
 try:
     d=json.loads(l); print('$*', '->', round(d['value'],1), d['unit'], round(d['ms_per_step'],3),'ms')
