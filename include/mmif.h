@@ -438,6 +438,15 @@ typedef struct mmif_dense_encoder {
 } mmif_dense_encoder;
 int mmif_dense_encoder_fwd(const mmif_dense_encoder* enc_a, const mmif_tensor* out_a, const mmif_dense_encoder* enc_b,
                            const mmif_tensor* out_b, void* stream);
+/* DenseFuse's forward up to the fused features (`core/model.py:165-186`, `core/fusion.py:21-29` element_fusion 'sum'), round 6: both images of
+ * a pair through ONE shared encoder AND `sum` = out_a + out_b (bf16 values added in fp32, one rounding: bit-identical to mmif_fuse_elem_fwd
+ * on the two outputs) in one launch -- a wave carries the same 32-column strip of both images and holds both results of a pixel when it
+ * stores them, so the separate pass over 192 channel planes disappears.  enc_a / enc_b must name the SAME weights (pointers equal) and
+ * differ only in `img`; out_a, out_b as for mmif_dense_encoder_fwd; sum: bf16 halo-0 view of 8 channel blocks.  _supported: 1 when the call
+ * is taken (shared weights, the round-5 streaming kernel enabled), else the caller runs mmif_dense_encoder_fwd + mmif_fuse_elem_fwd. */
+int32_t mmif_dense_encoder_fwd_sum_supported(const mmif_dense_encoder* enc_a, const mmif_dense_encoder* enc_b, int32_t n, int32_t h, int32_t w);
+int mmif_dense_encoder_fwd_sum(const mmif_dense_encoder* enc_a, const mmif_tensor* out_a, const mmif_dense_encoder* enc_b,
+                               const mmif_tensor* out_b, const mmif_tensor* sum, void* stream);
 
 /* Weight gradients of the same encoder, all four layers in ONE pass (csrc/enc_wgrad.hip; replaces three mmif_conv2d_reflect_wgrad
  * calls + mmif_conv2d_image_in_wgrad): x = the forward's [x0 | x1 | x2 | ..] (bf16, halo 0, >= 6 channel blocks), gz = the four
@@ -483,6 +492,9 @@ int mmif_dense_encoder_chain(const mmif_dense_chain* chain_a, const mmif_dense_c
  * may be NULL); accumulate_x != 0: add onto what they hold (the second branch of a shared encoder).  img_x: the branch's input image
  * [n][h][w] fp32.  workspace: mmif_dense_encoder_bwd_workspace() bytes.  Reference: autograd of core/model.py:73-80 + core/block.py:137-151
  * (train.py:71).  h, w >= 4; bf16 tensors. */
+/* 1 when an allocation of cb_total channel blocks of h x w (+ 2 halo) pixels stays within mmif_dense_encoder_bwd's 32-bit lane offsets (one image
+ * below 2 GiB) and h, w >= 4: callers ask for every tensor involved and take mmif_dense_encoder_chain + mmif_dense_encoder_wgrad otherwise. */
+int32_t mmif_dense_encoder_bwd_fits(int32_t cb_total, int32_t h, int32_t w, int32_t halo);
 size_t mmif_dense_encoder_bwd_workspace(void);
 int mmif_dense_encoder_bwd(const mmif_dense_chain* chain_a, const float* img_a, float* const* dwdb_a, int32_t accumulate_a,
                            const mmif_dense_chain* chain_b, const float* img_b, float* const* dwdb_b, int32_t accumulate_b,

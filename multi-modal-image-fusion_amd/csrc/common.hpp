@@ -124,6 +124,9 @@ inline TV make_tv(const mmif_tensor* t) {
 }
 
 int validate_tensor(const mmif_tensor* t, const char* name);
+// compute units of the current device, cached per device (hipGetDeviceProperties fills a multi-KB struct and can reach the driver: not on the
+// per-launch path -- ADVICE r5); $MMIF_NUM_CUS overrides (experiments: persistent grids on part of the chip)
+int cached_num_cus();
 
 // reflect index R(t, L) of F.pad(mode='reflect') (edge pixel not repeated); L >= 2 for |offset| 1
 __host__ __device__ inline int reflect_idx(int t, int L) {

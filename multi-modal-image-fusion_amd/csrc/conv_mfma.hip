@@ -2369,17 +2369,7 @@ static int launch_conv_mfma(bool dgrad, const TV& tin, const TV& tout, const TV&
     return check_launch(dgrad ? "conv_mfma dgrad" : "conv_mfma fwd");
 }
 
-static int num_cus_() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-        if (n <= 0) n = 256;
-        if (const char* e = getenv("MMIF_NUM_CUS")) n = atoi(e) > 0 ? atoi(e) : n;   // (experiments: persistent grids on part of the chip)
-    }
-    return n;
-}
+static int num_cus_() { return cached_num_cus(); }
 
 static int g_dma_mode = -1;   // $MMIF_CONV_DMA: 1 (default) = DMA-staged kernel where it applies, 0 = never
 static int g_num_cus = 0;
@@ -2406,13 +2396,7 @@ static int launch_conv_dma(bool dgrad, const TV& tin, const TV& tout, const TV& 
     const int nmb = n_mblocks(n_out);
     const int m16p = nmb * 4 * 16;
     const long long nitems = (long long)tiles_x * tiles_y * tout.n * nmb;
-    if (g_num_cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_num_cus = prop.multiProcessorCount;
-        if (g_num_cus <= 0) g_num_cus = 256;
-        if (const char* e = getenv("MMIF_NUM_CUS")) g_num_cus = atoi(e) > 0 ? atoi(e) : g_num_cus;
-    }
+    g_num_cus = cached_num_cus();
     int G = g_num_cus / 8 * 8;   // one persistent block per CU (150 KB of LDS each)
     if (G < 8) G = 8;
     if (nitems < G) G = (int)nitems;

@@ -680,12 +680,7 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
 // one block per CU (and branch): the line of n * nstrips * h rows in equal slices of at least 8 rows
 static void fb_geometry(int n, int h, int w, int nb, int& nstrips, int& rows_per_slot, int& nbarriers, int& nblocks) {
     nstrips = w <= FB_W - 2 ? 1 : (w - (FB_W - 2) + FB_KEEP - 1) / FB_KEEP + 1;
-    int ncu = 256;
-    {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
-    }
+    const int ncu = cached_num_cus();
     const long long rows = (long long)n * nstrips * h;
     const int gmax = std::max(1, std::min(ncu / nb, EW_MAXG / 2));          // (block partials of both branches share one workspace of EW_MAXG slots)
     rows_per_slot = (int)std::max<long long>(8, (rows + (long long)gmax * FB_PAIRS - 1) / ((long long)gmax * FB_PAIRS));
@@ -717,6 +712,12 @@ static int fb_check_branch(const mmif_dense_chain* c, const float* img, float* c
         MMIF_REQUIRE((long long)t->cb_total * (t->h + 2 * t->halo) * (t->w + 2 * t->halo) * 16 < (1ll << 31),
                      "dense_encoder_bwd: %s: one image of every allocation must stay below 2 GiB (32-bit lane offsets, bit 31 = masked)", which);
     return MMIF_OK;
+}
+
+// does every allocation the call would touch stay within the kernel's 32-bit lane offsets?  (cb_total channel blocks, halo: of the LARGEST of
+// g3 / glow / x) -- the engine asks before it takes the fused path and falls back to the chain + weight-gradient launches otherwise
+extern "C" int32_t mmif_dense_encoder_bwd_fits(int32_t cb_total, int32_t h, int32_t w, int32_t halo) {
+    return h >= 4 && w >= 4 && (long long)cb_total * (h + 2 * halo) * (w + 2 * halo) * 16 < (1ll << 31) ? 1 : 0;
 }
 
 extern "C" size_t mmif_dense_encoder_bwd_workspace(void) { return (size_t)EW_MAXG * EW_PER * sizeof(float); }

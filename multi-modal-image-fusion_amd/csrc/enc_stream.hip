@@ -289,6 +289,43 @@ static int es_check_branch(const mmif_dense_encoder* e, const mmif_tensor* out, 
     return MMIF_OK;
 }
 
+// DenseFuse's encoder pass (round 6): both images through ONE shared encoder and their element-wise sum, one launch (csrc/enc_stream2.hip, dual form)
+extern "C" int32_t mmif_dense_encoder_fwd_sum_supported(const mmif_dense_encoder* enc_a, const mmif_dense_encoder* enc_b, int32_t n, int32_t h, int32_t w) {
+    EncArgs P;
+    memset(&P, 0, sizeof(P));
+    P.n = n; P.h = h; P.w = w;
+    if (enc_a == nullptr || enc_b == nullptr || !enc_stream2_ok(P, 0)) return 0;
+    if ((long long)16 * h * w * 16 >= (1ll << 31)) return 0;      // (a 128-channel feature buffer's image must stay below 2 GiB)
+    if (enc_a->w0 != enc_b->w0 || enc_a->b0 != enc_b->b0) return 0;
+    for (int i = 0; i < 3; ++i)
+        if (enc_a->packed[i] != enc_b->packed[i] || enc_a->bias[i] != enc_b->bias[i]) return 0;
+    return 1;
+}
+extern "C" int mmif_dense_encoder_fwd_sum(const mmif_dense_encoder* enc_a, const mmif_tensor* out_a, const mmif_dense_encoder* enc_b,
+                                          const mmif_tensor* out_b, const mmif_tensor* sum, void* stream) {
+    if (int rc = es_check_branch(enc_a, out_a, "branch a")) return rc;
+    if (int rc = es_check_branch(enc_b, out_b, "branch b")) return rc;
+    if (int rc = validate_tensor(sum, "sum")) return rc;
+    MMIF_REQUIRE(out_a->n == out_b->n && out_a->h == out_b->h && out_a->w == out_b->w, "dense_encoder_fwd_sum: the two branches differ in shape");
+    MMIF_REQUIRE(sum->dtype == MMIF_BF16 && sum->halo == 0 && sum->cb == 8 && sum->n == out_a->n && sum->h == out_a->h && sum->w == out_a->w,
+                 "dense_encoder_fwd_sum: sum must be a bf16 halo-0 view of 8 channel blocks of the branches' shape");
+    MMIF_REQUIRE(mmif_dense_encoder_fwd_sum_supported(enc_a, enc_b, out_a->n, out_a->h, out_a->w),
+                 "dense_encoder_fwd_sum: the two branches must share ONE set of weights (and $MMIF_ENC_STREAM2 must not be 0)");
+    EncArgs A;
+    memset(&A, 0, sizeof(A));
+    for (int b = 0; b < 2; ++b) {
+        const mmif_dense_encoder* e = b ? enc_b : enc_a;
+        EncBranch& B = A.br[b];
+        B.img = e->img; B.w0 = e->w0; B.b0 = e->b0;
+        for (int i = 0; i < 3; ++i) { B.wpk[i] = (const uint4*)e->packed[i]; B.bias[i] = e->bias[i]; }
+        B.out = make_tv(b ? out_b : out_a);
+    }
+    A.sum = make_tv(sum);
+    A.n = out_a->n; A.h = out_a->h; A.w = out_a->w;
+    A.relu0 = 1;
+    return enc_stream2_launch_dual(A, (hipStream_t)stream);
+}
+
 extern "C" int mmif_dense_encoder_fwd(const mmif_dense_encoder* enc_a, const mmif_tensor* out_a, const mmif_dense_encoder* enc_b,
                                       const mmif_tensor* out_b, void* stream) {
     if (int rc = es_check_branch(enc_a, out_a, "branch a")) return rc;
@@ -309,7 +346,7 @@ extern "C" int mmif_dense_encoder_fwd(const mmif_dense_encoder* enc_a, const mmi
     A.n = out_a->n; A.h = out_a->h; A.w = out_a->w;
     A.relu0 = 1;
     // round 5: the 64-column input-stationary kernel (csrc/enc_stream2.hip); $MMIF_ENC_STREAM2=0 / mmif_debug_set_enc_stream2(0): this file's
-    if (enc_stream2_ok(A.n, A.h, A.w)) return enc_stream2_launch(A, nb, (hipStream_t)stream);
+    if (enc_stream2_ok(A, nb)) return enc_stream2_launch(A, nb, (hipStream_t)stream);
     es_geometry(A.n, A.h, A.w, nb, A.nstrips, A.nseg, A.seg_rows);
     A.items = A.n * A.nseg * A.nstrips;
     hipLaunchKernelGGL(enc_stream_fwd_kernel, dim3(cdiv(A.items, ES_WAVES), nb), dim3(ES_WAVES * 64), 0, (hipStream_t)stream, A);

@@ -22,10 +22,12 @@ struct EncArgs {
     int nstrips, nseg, seg_rows;
     int items;                 // per branch: n * nseg * nstrips
     int relu0;                 // ReLU after the first layer (always 1 on the reference's path; the dense convs always have one)
+    TV sum;                    // enc_stream2's dual form only: 8-block view that receives out(br[0]) + out(br[1])
 };
 
 // enc_stream2.hip
-bool enc_stream2_ok(int n, int h, int w);
+bool enc_stream2_ok(const EncArgs& A, int nb);
 int enc_stream2_launch(EncArgs& A, int nb, hipStream_t st);
+int enc_stream2_launch_dual(EncArgs& A, hipStream_t st);
 
 }  // namespace mmif

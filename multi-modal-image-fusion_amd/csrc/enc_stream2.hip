@@ -48,19 +48,27 @@ constexpr int E2_WBYTES = E2_NFRAG * 1024;     // (the 16->16 conv's six fragmen
 // eight waves per CU, two per SIMD).  Same work per SIMD either way; with two waves a SIMD keeps computing while one of them sits in a
 // store that HBM back-pressure holds at issue -- measured on the NT = 4 build: compute 133 us and stores 105 us did not overlap at all
 // (profiles/r05_ubench_enc_stream2_ablation.txt).
-template <int NT> struct E2G {
-    static constexpr int W = 16 * NT;              // strip width in pixels
+// DUAL (round 6, NT = 4 only): the wave's 64 ring pixels are TWO 32-pixel strips -- the same columns of the two images of a pair, column
+// tiles 0, 1 = image a, tiles 2, 3 = image b -- run through ONE shared set of weights (DenseFuse: `core/model.py:165-186`, one encoder for
+// both images).  Every tile is its own MFMA stream, the two halves only meet in the operand reads next to pixel 31 | 32, which land in columns
+// a 32-pixel strip discards anyway; the epilogue then holds the granules of BOTH images of a pixel in one lane and emits their sum
+// f1 + f2 (`core/fusion.py:21-29`, element_fusion 'sum') next to the two branches' own rows: mmif_fuse_elem_fwd's pass over 192 channel
+// planes disappears.
+template <int NT, bool DUAL = false> struct E2G {
+    static_assert(!DUAL || NT == 4, "the dual form is the four-tile instantiation");
+    static constexpr int W = DUAL ? 32 : 16 * NT;  // strip width in pixels (of one image)
     static constexpr int KEEP = W - 6;             // columns an interior strip keeps (3 lost per side over the three 3x3 layers)
     static constexpr int EDGE = W - 4;             // ... the first / last strip of an image (one ghost pixel + 3 lost on the inner side)
-    static constexpr int CBS = 256 * NT;           // bytes of one channel block of a ring row (W pixels x 16 B)
+    static constexpr int CBS = 256 * NT;           // bytes of one channel block of a ring row (16 NT pixels x 16 B)
     static constexpr int ROW = 2 * CBS;            // one ring slot: [cb 0][cb 1]
     static constexpr int X0 = 0, X1 = E2_S0 * ROW, X2 = X1 + E2_S1 * ROW, RING = X2 + E2_S2 * ROW;
     static constexpr int WAVES = NT == 4 ? 4 : 8;
     static constexpr int NP = NT / 2;              // tile pairs of the epilogue
-    static constexpr int OPS = 2 * NT + (NT == 4 ? 2 : 1);     // vector-memory operations of a branch-free step (stores + image DMAs)
-    static constexpr int AHEAD = 2 + (64 + OPS - 1) / OPS;     // image rows are requested this many steps ahead (> 63 operations): 9 / 15
+    static constexpr int NST = NP + (DUAL ? 1 : 0);   // stores of one layer's epilogue (DUAL: + the sum's)
+    static constexpr int OPS = 4 * NST + (NT == 4 ? 2 : 1);    // vector-memory operations of a branch-free step (stores + image DMAs)
+    static constexpr int AHEAD = 2 + (64 + OPS - 1) / OPS;     // image rows are requested this many steps ahead (> 63 operations): 9 / 15 (dual: 7)
     static constexpr int IMGS = 16;                            // slots of the image ring (> AHEAD)
-    static constexpr int IMGROW = NT == 4 ? 288 : 160;         // bytes per slot (W + 2 used entries, + the pad group's)
+    static constexpr int IMGROW = NT == 4 ? 288 : 160;         // bytes per slot (W + 2 used entries per image, + the pad group's)
     static constexpr int LDS = E2_WBYTES + WAVES * RING + 64;  // (+ 64: operand reads run up to two granules past a ring row)
     static constexpr int LDS_IMG = WAVES * IMGS * IMGROW;      // the image ring is an LDS variable of its own, see the kernel
 };
@@ -74,9 +82,9 @@ template <int N> struct E2I { static constexpr int value = N; };
 #define E2_ABL 0   // timing ablations (diagnostic builds only, tools/build_ab_enc2.sh; results are WRONG when non-zero): 1 no global stores (32: the stores go to one cache-resident 16 KiB per block instead),
 #endif             // 2 no bf16 MFMAs, 4 no LDS operand reads after a step's first, 8 no epilogues at all, 16 no first-layer MFMAs / image loads
 
-template <int NT>
-__global__ __launch_bounds__(E2G<NT>::WAVES * 64, 1) void enc_stream2_fwd_kernel(EncArgs A) {
-    using G = E2G<NT>;
+template <int NT, bool DUAL = false>
+__global__ __launch_bounds__((E2G<NT, DUAL>::WAVES * 64), 1) void enc_stream2_fwd_kernel(EncArgs A) {
+    using G = E2G<NT, DUAL>;
     constexpr int E2_X0 = G::X0, E2_X1 = G::X1, E2_X2 = G::X2, E2_RING = G::RING, E2_WAVES = G::WAVES, E2_W = G::W, E2_KEEP = G::KEEP;
     constexpr int E2_IMGS = G::IMGS, E2_IMGROW = G::IMGROW, CBS = G::CBS, ROWB = G::ROW, NP = G::NP;
     __shared__ __attribute__((aligned(16))) char smem[G::LDS];
@@ -84,7 +92,7 @@ __global__ __launch_bounds__(E2G<NT>::WAVES * 64, 1) void enc_stream2_fwd_kernel
     // outstanding vector-memory operations (s_waitcnt vmcnt(0) -- with this kernel's stores in flight: microseconds, in every step), so
     // the ring is a SEPARATE object that C++ code never reads (its reads are inline asm) -- nothing aliases the operand rings / fragments.
     __shared__ __attribute__((aligned(16))) char smem_img[G::LDS_IMG];
-    const EncBranch& B = A.br[blockIdx.y];
+    const EncBranch& B = A.br[DUAL ? 0 : blockIdx.y];       // (DUAL: the shared weights come from branch 0, blockIdx.y = 0)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, g = lane >> 4;
@@ -153,7 +161,7 @@ __global__ __launch_bounds__(E2G<NT>::WAVES * 64, 1) void enc_stream2_fwd_kernel
     bool ok_e[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-        const int ce = r0 + px_e + 32 * p;
+        const int ce = r0 + px_e + (DUAL ? 0 : 32 * p);     // (DUAL: pair p = image p, the same columns)
         ok_e[p] = ce >= o_lo && ce < o_hi;
     }
     // first layer on the fp32 matrix path (v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulate): one MFMA per tap ROW u, its
@@ -165,8 +173,9 @@ __global__ __launch_bounds__(E2G<NT>::WAVES * 64, 1) void enc_stream2_fwd_kernel
     // instead of 0, 1, 2 -- and are overwritten by the epilogue's ghost copy like those of x1 / x2).
     float a0[3];
     const int li = (int)(size_t)(__attribute__((address_space(3))) char*)smem_img + iring + (j + g) * 4;   // operand read (LDS byte address): + 64 t + slot
-    const int cdma0 = 4 * min(max(reflect_idx(r0 - 1 + lane, W), 0), W - 1);  // DMA source column (bytes) of entries 0..63
-    const int cdma1 = 4 * min(max(reflect_idx(r0 + 63 + (lane & 1), W), 0), W - 1);   // entries 64, 65 (lanes 0, 1; 64-pixel strips only)
+    // DUAL: entries 0..33 = image a's columns r0 - 1 .. r0 + 32, entries 34..67 = image b's (tiles 2, 3 read 8 bytes further: read_img_row)
+    const int cdma0 = 4 * min(max(reflect_idx(r0 - 1 + (DUAL && lane >= 34 ? lane - 34 : lane), W), 0), W - 1);  // DMA source column (bytes) of entries 0..63
+    const int cdma1 = 4 * min(max(reflect_idx(DUAL ? r0 + 29 + (lane & 3) : r0 + 63 + (lane & 1), W), 0), W - 1);   // entries 64, 65 (lanes 0, 1; 64-pixel strips only) | DUAL: 64..67
 #pragma unroll
     for (int u = 0; u < 3; ++u) a0[u] = g < 3 ? B.w0[j * 9 + u * 3 + g] : 0.f;
     e2_f32x4 biasC0;
@@ -184,10 +193,18 @@ __global__ __launch_bounds__(E2G<NT>::WAVES * 64, 1) void enc_stream2_fwd_kernel
     char* out_img = B.out.base + ((long long)in_ * B.out.img + (long long)B.out.cb_off * B.out.plane) * 16;
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(out_img, 0, (int)((unsigned)(B.out.cb_total - B.out.cb_off) * plane_b), 0x00020000);
     const char* img = reinterpret_cast<const char*>(B.img + (long long)in_ * H * W);
+    // DUAL: image b and its output view, the sum's view (same h, w, halo 0 => the same plane / row pitch: checked by the host)
+    const EncBranch& Bb = A.br[DUAL ? 1 : 0];
+    const char* img_b = reinterpret_cast<const char*>(Bb.img + (long long)in_ * H * W);
+    const char* img_l = (DUAL && lane >= 34) ? img_b : img;      // per-lane source image of the first DMA of a row
+    char* out_img_b = Bb.out.base + ((long long)in_ * Bb.out.img + (long long)Bb.out.cb_off * Bb.out.plane) * 16;
+    const __amdgpu_buffer_rsrc_t rs_out_b = __builtin_amdgcn_make_buffer_rsrc(out_img_b, 0, (int)((unsigned)(Bb.out.cb_total - Bb.out.cb_off) * plane_b), 0x00020000);
+    char* sum_img = DUAL ? A.sum.base + ((long long)in_ * A.sum.img + (long long)A.sum.cb_off * A.sum.plane) * 16 : out_img;
+    const __amdgpu_buffer_rsrc_t rs_sum = __builtin_amdgcn_make_buffer_rsrc(sum_img, 0, (int)((unsigned)((DUAL ? A.sum.cb_total - A.sum.cb_off : 1)) * plane_b), 0x00020000);
     // per-lane store offsets; a lane outside the strip's kept columns carries bit 31 = beyond the descriptor's range = dropped
     unsigned st_e[NP];
 #pragma unroll
-    for (int p = 0; p < NP; ++p) st_e[p] = ok_e[p] ? (unsigned)cb_e * plane_b + (unsigned)(r0 + px_e + 32 * p) * 16u : 0x80000000u;
+    for (int p = 0; p < NP; ++p) st_e[p] = ok_e[p] ? (unsigned)cb_e * plane_b + (unsigned)(r0 + px_e + (DUAL ? 0 : 32 * p)) * 16u : 0x80000000u;
 
     // rows each stage touches: x0 rows [a_lo, a_hi) feed layer 1, x1 rows [b_lo, b_hi) layer 2, x2 rows [c_lo, c_hi) layer 3
     const int a_lo = max(0, y_lo - 3), a_hi = min(H, y_hi + 3);
@@ -219,14 +236,22 @@ __global__ __launch_bounds__(E2G<NT>::WAVES * 64, 1) void enc_stream2_fwd_kernel
     auto dma_img_row = [&](int y) __attribute__((always_inline)) {
         const char* src = img + (long long)rrow(y) * W * 4;
         const unsigned dst = iring_lds + (unsigned)((y & (E2_IMGS - 1)) * E2_IMGROW);
-        if (NT == 4) {
+        if (DUAL) {
+            const long long ro = (long long)rrow(y) * W * 4;
+            dma_issue(img_l + ro + cdma0, dst);
+            if (lane < 4) dma_issue(img_b + ro + cdma1, dst + 256);
+        } else if (NT == 4) {
             dma_issue(src + cdma0, dst);
             if (lane < 2) dma_issue(src + cdma1, dst + 256);
         } else if (lane < E2_W + 2) dma_issue(src + cdma0, dst);
     };
     auto read_img_row = [&](int y, float (&dst)[NT]) __attribute__((always_inline)) {
         const int a = li + (y & (E2_IMGS - 1)) * E2_IMGROW;
-        if constexpr (NT == 4)
+        if constexpr (DUAL)      // (image b's entries start at 34: its tiles read two entries further)
+            __asm__ volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %4 offset:64\n\tds_read_b32 %2, %4 offset:136\n\tds_read_b32 %3, %4 offset:200\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(dst[0]), "=&v"(dst[1]), "=&v"(dst[2]), "=&v"(dst[3]) : "v"(a) : "memory");
+        else if constexpr (NT == 4)
             __asm__ volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %4 offset:64\n\tds_read_b32 %2, %4 offset:128\n\tds_read_b32 %3, %4 offset:192\n\t"
                              "s_waitcnt lgkmcnt(0)"
                              : "=&v"(dst[0]), "=&v"(dst[1]), "=&v"(dst[2]), "=&v"(dst[3]) : "v"(a) : "memory");
@@ -319,7 +344,7 @@ __global__ __launch_bounds__(E2G<NT>::WAVES * 64, 1) void enc_stream2_fwd_kernel
         auto dummy_stores = [&]() __attribute__((always_inline)) {
             if (E2_ABL & 1) return;
 #pragma unroll
-            for (int p = 0; p < NP; ++p)
+            for (int p = 0; p < G::NST; ++p)
                 __builtin_amdgcn_raw_buffer_store_b128((e2_u32x4){0u, 0u, 0u, 0u}, rs_out, (int)0x80000000u, 0, 0);
         };
         auto epilogue = [&](auto Lc) __attribute__((always_inline)) {
@@ -348,16 +373,29 @@ __global__ __launch_bounds__(E2G<NT>::WAVES * 64, 1) void enc_stream2_fwd_kernel
                 if (L < 3) *reinterpret_cast<uint4*>(smem + wb + p * 512) = o[p];
                 if (E2_ABL & 32)      // every store of a block into the same 16 KiB (cache resident): the store INSTRUCTIONS without the HBM write stream
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(e2_u32x4, o[p]), rs_out, (int)((st_e[p] & 0x3ff0u) | own), (int)(blockIdx.x * 16384u), 0);
-                else if (!(E2_ABL & 1)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(e2_u32x4, o[p]), rs_out, (int)(st_e[p] | own), orow, E2_STORE_AUX);
+                else if (!(E2_ABL & 1)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(e2_u32x4, o[p]), (DUAL && p == 1) ? rs_out_b : rs_out, (int)(st_e[p] | own), orow, E2_STORE_AUX);
+            }
+            if constexpr (DUAL) {
+                // f1 + f2 of this lane's pixel and channel block: the two images' bf16 values added in fp32, rounded once (mmif_fuse_elem_fwd's
+                // arithmetic: bit-identical to the separate pass)
+                auto add2 = [](uint32_t a, uint32_t b) {
+                    return pack_bf16x2(__uint_as_float(a << 16) + __uint_as_float(b << 16), __uint_as_float(a & 0xffff0000u) + __uint_as_float(b & 0xffff0000u));
+                };
+                const uint4 ob = o[NP - 1];
+                const e2_u32x4 sm = {add2(o[0].x, ob.x), add2(o[0].y, ob.y), add2(o[0].z, ob.z), add2(o[0].w, ob.w)};
+                if (!(E2_ABL & 1)) __builtin_amdgcn_raw_buffer_store_b128(sm, rs_sum, (int)(st_e[0] | own), orow, E2_STORE_AUX);
             }
             if (L < 3) {
                 // ghost pixels of an edge strip, AFTER both halves of the row are in the ring (a narrow image's right ghost lies inside
                 // the computed range): column -1 := column 1 (ring pixel 0 := 2), column w := column w - 2
-                if (ghost_l && px_e == 2) *reinterpret_cast<uint4*>(smem + wb - 32) = o[0];
+                if (ghost_l && px_e == 2) {
+                    *reinterpret_cast<uint4*>(smem + wb - 32) = o[0];
+                    if constexpr (DUAL) *reinterpret_cast<uint4*>(smem + wb + 512 - 32) = o[NP - 1];      // image b's strip starts at ring pixel 32
+                }
                 if (ghost_r) {
 #pragma unroll
                     for (int p = 0; p < NP; ++p)
-                        if (px_e + 32 * p == pg_r - 2) *reinterpret_cast<uint4*>(smem + wb + p * 512 + 32) = o[p];
+                        if (px_e + (DUAL ? 0 : 32 * p) == pg_r - 2) *reinterpret_cast<uint4*>(smem + wb + p * 512 + 32) = o[p];
                 }
             }
         };
@@ -439,16 +477,11 @@ __global__ __launch_bounds__(E2G<NT>::WAVES * 64, 1) void enc_stream2_fwd_kernel
 
 // items-per-launch heuristic: every (strip, segment, image, branch) is one wave, WAVES waves a block, one block per CU (LDS).  More
 // segments fill the chip but each pays 3 warm-up rows of x0 plus the 6-step pipeline skew: minimise rounds x steps per wave.
-template <int NT>
+template <int NT, bool DUAL = false>
 static void e2_geometry(int n, int h, int w, int nb, int& nstrips, int& nseg, int& seg_rows) {
-    using G = E2G<NT>;
+    using G = E2G<NT, DUAL>;
     nstrips = w <= G::W - 2 ? 1 : 2 + (w > 2 * G::EDGE ? (w - 2 * G::EDGE + G::KEEP - 1) / G::KEEP : 0);
-    int ncu = 256;
-    {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
-    }
+    const int ncu = cached_num_cus();
     long long best = -1;
     nseg = 1;
     for (int k = 1; k <= (h + 7) / 8; ++k) {
@@ -465,10 +498,14 @@ static int g_es2 = -1;      // $MMIF_ENC_STREAM2: 0 = the round-2 kernel, 1 = 64
 static void e2_init() {
     if (g_es2 < 0) { const char* e = getenv("MMIF_ENC_STREAM2"); g_es2 = e != nullptr ? atoi(e) : 2; if (g_es2 < 0 || g_es2 > 2) g_es2 = 2; }
 }
-bool enc_stream2_ok(int n, int h, int w) {
-    (void)n;
+// (the size limits of this kernel -- 32-bit lane offsets with bit 31 = masked lane -- are part of the predicate: a frame beyond them takes the
+// round-2 kernel, which allows 4 GiB per image, instead of failing: ADVICE r5)
+bool enc_stream2_ok(const EncArgs& A, int nb) {
     e2_init();
-    return g_es2 >= 1 && h >= 2 && w >= 2;
+    if (!(g_es2 >= 1 && A.h >= 2 && A.w >= 2 && (long long)A.h * A.w * 4 < (1ll << 31))) return false;
+    for (int b = 0; b < nb; ++b)
+        if ((long long)A.br[b].out.cb_total * A.br[b].out.plane * 16 >= (1ll << 31)) return false;
+    return true;
 }
 
 template <int NT>
@@ -477,6 +514,20 @@ static int e2_launch(EncArgs& A, int nb, hipStream_t st) {
     A.items = A.n * A.nseg * A.nstrips;
     hipLaunchKernelGGL(enc_stream2_fwd_kernel<NT>, dim3(cdiv(A.items, E2G<NT>::WAVES), nb), dim3(E2G<NT>::WAVES * 64), 0, st, A);
     return check_launch("dense_encoder_fwd (stream2)");
+}
+
+// both images of a pair through one shared encoder + their sum (A.sum), one wave per (strip, segment, pair)
+int enc_stream2_launch_dual(EncArgs& A, hipStream_t st) {
+    MMIF_REQUIRE(A.relu0 == 1, "dense_encoder_fwd_sum: the first layer's ReLU is compiled in");
+    MMIF_REQUIRE((long long)A.h * A.w * 4 < (1ll << 31), "dense_encoder_fwd_sum: one image must stay below 2 GiB");
+    for (int b = 0; b < 2; ++b)
+        MMIF_REQUIRE((long long)A.br[b].out.cb_total * A.br[b].out.plane * 16 < (1ll << 31),
+                     "dense_encoder_fwd_sum: one image of an output allocation must stay below 2 GiB");
+    MMIF_REQUIRE((long long)A.sum.cb_total * A.sum.plane * 16 < (1ll << 31), "dense_encoder_fwd_sum: one image of the sum's allocation must stay below 2 GiB");
+    e2_geometry<4, true>(A.n, A.h, A.w, 1, A.nstrips, A.nseg, A.seg_rows);
+    A.items = A.n * A.nseg * A.nstrips;
+    hipLaunchKernelGGL((enc_stream2_fwd_kernel<4, true>), dim3(cdiv(A.items, E2G<4, true>::WAVES), 1), dim3(E2G<4, true>::WAVES * 64), 0, st, A);
+    return check_launch("dense_encoder_fwd_sum (stream2 dual)");
 }
 
 int enc_stream2_launch(EncArgs& A, int nb, hipStream_t st) {

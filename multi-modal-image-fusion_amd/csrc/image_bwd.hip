@@ -176,11 +176,101 @@ __global__ __launch_bounds__(512, 2) void image_out_bwd16_kernel(TV tx, TV tgx, 
     }
 }
 
+// ---------------------------------------------------------------- forward of the same layer (round 6)
+// image_out_fwd_tiled_kernel kept the 144 weights in vector registers (3 waves per SIMD) and ran load -> LDS -> barrier -> arithmetic -> store
+// once per 16 x 16-tile block: 40 us for 75 MB at B = 32 256 x 256, latency bound.  Here: the recipe of the backward kernel above -- a thread
+// owns (pixel, channel block), the channel block's 72 weights sit in scalar registers, persistent blocks walk 8 x 32-pixel tiles with the next
+// tile's reflect-padded 10 x 34 x 2 granules requested one tile ahead (double-buffered LDS, one barrier for the tile + one for the exchange
+// of the two channel blocks' partial sums).  y = (bias + sum over channel block 0) + (sum over channel block 1), each sum an FMA chain in
+// (tap, channel) order -- the tiled kernel's single chain regrouped (fp32, ~1e-7).
+constexpr int IF_GW = IB_TW + 2, IF_GH = IB_TH + 2;     // 34 x 10 granules per channel block
+constexpr int IF_GP = 36;                               // row pitch in granules
+constexpr int IF_N = IF_GW * IF_GH;                     // 340
+
+__global__ __launch_bounds__(512, 2) void image_out_fwd16_kernel(TV tx, const float* __restrict__ w, const float* __restrict__ bias,
+                                                                 float* __restrict__ img, int relu, int tiles_x, int tiles_y, int total) {
+    __shared__ __attribute__((aligned(16))) uint4 s_x[2][2][IF_GH * IF_GP];
+    __shared__ float s_p[2][256];
+    const int tid = threadIdx.x;
+    const int cb = __builtin_amdgcn_readfirstlane(tid >> 8);
+    const int pix = tid & 255, ty = pix >> 5, txx = pix & 31;
+    const int H = tx.h, W = tx.w;
+    const TileWalk tw = xcd_walk(total, gridDim.x, blockIdx.x);
+    const float* wq = w + cb * 72;
+    float wr[8][9];
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wr[c][t] = wq[c * 9 + t];
+    const float b0 = bias != nullptr ? bias[0] : 0.f;
+    auto tile_origin = [&](int tile, int& in_, int& y0, int& x0) {
+        const int tpi = tiles_x * tiles_y;
+        in_ = tile / tpi;
+        const int r = tile - in_ * tpi;
+        y0 = (r / tiles_x) * IB_TH;
+        x0 = (r % tiles_x) * IB_TW;
+    };
+    // staged granules of this thread: e = pix and pix + 256 (< 340) of its channel block
+    const int e1 = min(pix + 256, IF_N - 1);
+    const int py0 = pix / IF_GW, px0 = pix % IF_GW, py1 = e1 / IF_GW, px1 = e1 % IF_GW;
+    auto load_x = [&](int tile, int py, int px) {
+        int in_, y0, x0;
+        tile_origin(tile, in_, y0, x0);
+        const int y = min(max(reflect_idx(y0 - 1 + py, H), 0), H - 1), x = min(max(reflect_idx(x0 - 1 + px, W), 0), W - 1);
+        return *reinterpret_cast<const uint4*>(tx.base + tx.gidx(in_, cb, y, x) * 16);
+    };
+    uint4 xa = make_uint4(0, 0, 0, 0), xb = xa;
+    if (tw.count > 0) { xa = load_x(tw.first, py0, px0); xb = load_x(tw.first, py1, px1); }
+    for (int k = 0; k < tw.count; ++k) {
+        const int tile = tw.first + k * tw.stride;
+        uint4* sx = s_x[k & 1][cb];
+        sx[py0 * IF_GP + px0] = xa;
+        if (pix + 256 < IF_N) sx[py1 * IF_GP + px1] = xb;
+        __syncthreads();
+        if (k + 1 < tw.count) { xa = load_x(tile + tw.stride, py0, px0); xb = load_x(tile + tw.stride, py1, px1); }
+        float r = cb == 0 ? b0 : 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const uint4 q = sx[(ty + t / 3) * IF_GP + txx + t % 3];
+            const uint32_t qw[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                r = fmaf(__uint_as_float(qw[i] << 16), wr[2 * i][t], r);
+                r = fmaf(__uint_as_float(qw[i] & 0xffff0000u), wr[2 * i + 1][t], r);
+            }
+        }
+        if (cb == 1) s_p[k & 1][pix] = r;
+        __syncthreads();
+        if (cb == 0) {
+            int in_, y0, x0;
+            tile_origin(tile, in_, y0, x0);
+            const int y = y0 + ty, x = x0 + txx;
+            if (y < H && x < W) {
+                float v = r + s_p[k & 1][pix];
+                if (relu) v = fmaxf(v, 0.f);
+                img[((long long)in_ * H + y) * W + x] = v;
+            }
+        }
+    }
+}
+
 int image_out_wgrad_reduce3_launch(const float* ws, float* dw, float* db, int cin, int G, int n_cg, int accumulate, hipStream_t st);   // conv_image.hip
 
 }  // namespace mmif
 
 using namespace mmif;
+
+// (conv_image.hip's mmif_conv2d_image_out_fwd takes this kernel for bf16, 16 channels, 3x3)
+int image_out_fwd16_launch(const TV& tx, const float* w, const float* bias, float* img, int relu, hipStream_t st) {
+    const int tiles_x = cdiv(tx.w, IB_TW), tiles_y = cdiv(tx.h, IB_TH);
+    const long long total = (long long)tiles_x * tiles_y * tx.n;
+    if (total >= (1ll << 31)) { set_error("image_out_fwd: too many tiles"); return MMIF_EINVAL; }
+    int G = 1024;      // four persistent blocks per CU (39 registers, 25 KB of LDS each)
+    if (total < G) G = (int)total;
+    if (G >= 8) G = G / 8 * 8;
+    hipLaunchKernelGGL(image_out_fwd16_kernel, dim3(G), dim3(512), 0, st, tx, w, bias, img, relu, tiles_x, tiles_y, (int)total);
+    return check_launch("image_out_fwd");
+}
 
 extern "C" int32_t mmif_conv2d_image_out_bwd_supported(int32_t dtype, int32_t cin, int32_t ksize, int32_t h, int32_t w) {
     return dtype == MMIF_BF16 && cin == 16 && ksize == 3 && h >= 4 && w >= 4 ? 1 : 0;

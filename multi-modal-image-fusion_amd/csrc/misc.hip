@@ -15,6 +15,21 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+int cached_num_cus() {
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (cus[dev] == 0) {
+        int n = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+        if (const char* e = getenv("MMIF_NUM_CUS")) n = atoi(e) > 0 ? atoi(e) : n;
+        cus[dev] = n;
+    }
+    return cus[dev];
+}
+
 int check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

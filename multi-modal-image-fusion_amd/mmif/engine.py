@@ -32,6 +32,8 @@ FLAT_BUFFERS = {}
 FRESH_LEAVES = [None]
 # bumped by every fused optimiser step: the packed bf16 weight images must be rebuilt
 WEIGHTS_EPOCH = [0]
+# id()s of pooled scratch buffers whose addresses are baked into a captured hipGraph (never evicted from their pools)
+GRAPH_PINNED = set()
 GRAD_TAIL = 8  # scalar slots after the gradients (loss values ride along in the gradient all-reduce)
 
 
@@ -591,9 +593,19 @@ class DenseEncoderMixin:
         # into its launches, and an eager step of another shape in between must not recycle it
         key = (F.n, F.h, F.w, F.buf.device, slot)
         pool = first.__dict__.setdefault("_gz", {})
-        gz = pool.get(key)
+        gz = pool.pop(key, None)
         if gz is None:
-            gz = pool[key] = BT.alloc(F.n, 64, F.h, F.w, torch.bfloat16, F.buf.device)
+            gz = BT.alloc(F.n, 64, F.h, F.w, torch.bfloat16, F.buf.device)
+            # bounded (variable-size crops grew this without limit): the least recently used shapes go once more than 8 are held --
+            # except those a live GraphedStep captured (mmif/graph.py pins the buffers of its capture in GRAPH_PINNED)
+            while len(pool) >= 8:
+                victim = next((k for k in pool if id(pool[k].buf) not in GRAPH_PINNED), None)
+                if victim is None:
+                    break
+                del pool[victim]
+        pool[key] = gz          # (re-inserted last = most recently used)
+        if torch.cuda.is_current_stream_capturing():
+            GRAPH_PINNED.add(id(gz.buf))
         return gz
 
     @staticmethod
@@ -610,6 +622,7 @@ class DenseEncoderMixin:
         weight-gradient launches of rounds 2 / 4 it replaces -- 0.40 ms against 0.64 ms at the headline size, profiles/r05_*).  Returns False when the kernel does not apply (the caller takes the other path)."""
         if not (switch("MMIF_ENC_BWD_FUSED") and switch("MMIF_ENC_CHAIN") and switch("MMIF_ENC_CHAIN_STREAM") and switch("MMIF_ENC_WGRAD")
                 and F.dtype == torch.bfloat16 and impl != _lib.IMPL_VALU and F.h >= 4 and F.w >= 4 and F.halo == 0
+                and all(_lib.lib.mmif_dense_encoder_bwd_fits(t.cb_total, t.h, t.w, t.halo) for br in branches for t in (F, br[3], br[4]))
                 and all(all(s.k == 3 for s in specs) and [(s.cin, s.cout) for s in specs] == [(1, 16), (16, 16), (32, 16), (48, 16)]
                         for specs, *_ in branches)):
             return False
@@ -758,30 +771,32 @@ class PFNetv1Engine(ModelEngine, DenseEncoderMixin):
         # the decoder's weight-gradient reduces as ONE launch at the end of the decoder's backward (not with the side-stream experiment: its
         # producer runs on another stream)
         deferred = dtype == torch.bfloat16 and not switch("MMIF_OVERLAP", "0") and self.defer_reduces(dev, self.dec)
-        g = self.buf(L, f"G{len(acts) - 1}", n, last.cin, h, w, dtype, dev, halo=1)
-        g = self.image_layer_bwd(last, x, gout, L.out, g, ws)
-        for i in range(len(self.dec) - 2, -1, -1):
-            s, x = self.dec[i], acts[i]
-            gx = self.buf(L, f"G{i}", n, s.cin, h, w, dtype, dev, halo=1)
-            if i > 0 and self.pair_ok(s, dtype, impl, h, w):
-                g = self.c_bwd_pair(s, g, x, gx, ws)      # thin layer: dgrad (every block masked) + wgrad in one launch
-                continue
-            # gradient w.r.t. the concatenated encoder features (i == 0): only each encoder's last DenseBlock output
-            # (blocks 6,7 / 14,15) has no further contributor
-            mb = all_bits(gx.cb) if i > 0 else bits(6, 7, 14, 15)
-            if i == 0 and self.overlap_ok(s, dtype, impl, x, gx):
-                # the input gradient first (its mask: the activations themselves, 32 of the 128 channels), the weight gradient on the side stream
-                gin = g
-                g = self.c_dgrad(s, gin, x, gx, mb, 0, impl)
-                self.fork_wgrad(s, x, gin, impl)
-                continue
-            if self.wide_ok(s, dtype, impl, x, gx):
-                g = self.c_bwd_wide(s, g, x, gx, mb, ws)  # wide layer: the wgrad leaves the ReLU sign bytes the dgrad masks with
-                continue
-            self.c_wgrad(s, x, g, ws, impl)
-            g = self.c_dgrad(s, g, x, gx, mb, 0, impl)
-        if deferred:
-            self.flush_reduces()
+        try:      # (a failing launch must not leave the library's deferred-reduce queue open: ADVICE r5)
+            g = self.buf(L, f"G{len(acts) - 1}", n, last.cin, h, w, dtype, dev, halo=1)
+            g = self.image_layer_bwd(last, x, gout, L.out, g, ws)
+            for i in range(len(self.dec) - 2, -1, -1):
+                s, x = self.dec[i], acts[i]
+                gx = self.buf(L, f"G{i}", n, s.cin, h, w, dtype, dev, halo=1)
+                if i > 0 and self.pair_ok(s, dtype, impl, h, w):
+                    g = self.c_bwd_pair(s, g, x, gx, ws)      # thin layer: dgrad (every block masked) + wgrad in one launch
+                    continue
+                # gradient w.r.t. the concatenated encoder features (i == 0): only each encoder's last DenseBlock output
+                # (blocks 6,7 / 14,15) has no further contributor
+                mb = all_bits(gx.cb) if i > 0 else bits(6, 7, 14, 15)
+                if i == 0 and self.overlap_ok(s, dtype, impl, x, gx):
+                    # the input gradient first (its mask: the activations themselves, 32 of the 128 channels), the weight gradient on the side stream
+                    gin = g
+                    g = self.c_dgrad(s, gin, x, gx, mb, 0, impl)
+                    self.fork_wgrad(s, x, gin, impl)
+                    continue
+                if self.wide_ok(s, dtype, impl, x, gx):
+                    g = self.c_bwd_wide(s, g, x, gx, mb, ws)  # wide layer: the wgrad leaves the ReLU sign bytes the dgrad masks with
+                    continue
+                self.c_wgrad(s, x, g, ws, impl)
+                g = self.c_dgrad(s, g, x, gx, mb, 0, impl)
+        finally:
+            if deferred:
+                self.flush_reduces()
         forked = getattr(self, "_forked", None) is not None
         if not forked:
             self.early_reduce(flat, self.dec)      # (data parallel) the decoder's gradients leave while the encoder's backward runs
@@ -843,12 +858,14 @@ class DenseFuseEngine(ModelEngine, DenseEncoderMixin):
         L = self.lease((n, h, w, dtype, single), dev)
         L.imgs = (img1, img2)
         F = self.buf(L, "F", n, 64 if single else 128, h, w, dtype, dev)
-        self.enc_fwd_all([(self.enc, img1, 0)] + ([] if single else [(self.enc, img2, 8)]), F, dtype, impl)
         if single:
+            self.enc_fwd_all([(self.enc, img1, 0)], F, dtype, impl)
             x = F
         else:
             x = self.buf(L, "S", n, 64, h, w, dtype, dev)
-            self.fusion_fwd(L, F, x)
+            if not self.enc_fwd_sum(img1, img2, F, x, dtype, impl):
+                self.enc_fwd_all([(self.enc, img1, 0), (self.enc, img2, 8)], F, dtype, impl)
+                self.fusion_fwd(L, F, x)
         for i, s in enumerate(self.dec[:-1]):
             y = self.buf(L, f"D{i}", n, s.cout, h, w, dtype, dev)
             self.c_fwd(s, x, y, impl)
@@ -874,29 +891,31 @@ class DenseFuseEngine(ModelEngine, DenseEncoderMixin):
         # the decoder's weight-gradient reduces as ONE launch at the end of the decoder's backward (not with the side-stream experiment: its
         # producer runs on another stream)
         deferred = dtype == torch.bfloat16 and not switch("MMIF_OVERLAP", "0") and self.defer_reduces(dev, self.dec)
-        g = self.buf(L, f"G{len(acts) - 1}", n, last.cin, h, w, dtype, dev, halo=1)
-        g = self.image_layer_bwd(last, x, gout, L.out, g, ws)
-        for i in range(len(self.dec) - 2, -1, -1):
-            s, x = self.dec[i], acts[i]
-            gx = self.buf(L, f"G{i}", n, s.cin, h, w, dtype, dev, halo=1)
-            if i > 0 and self.pair_ok(s, dtype, impl, h, w):
-                g = self.c_bwd_pair(s, g, x, gx, ws)
-                continue
-            # i == 0: the auto-encoder's input is the DenseBlock output (only its last conv, blocks 6,7, has no further contributor);
-            # x = f1 + f2 is not a ReLU output
-            mb = all_bits(gx.cb) if i > 0 else (bits(6, 7) if single else 0)
-            if i == 0 and not single and self.overlap_ok(s, dtype, impl, x, gx):
-                gin = g
-                g = self.c_dgrad(s, gin, x, gx, mb, 0, impl)
-                self.fork_wgrad(s, x, gin, impl)
-                continue
-            if self.wide_ok(s, dtype, impl, x, gx):
-                g = self.c_bwd_wide(s, g, x, gx, mb, ws)
-                continue
-            self.c_wgrad(s, x, g, ws, impl)
-            g = self.c_dgrad(s, g, x, gx, mb, 0, impl)
-        if deferred:
-            self.flush_reduces()
+        try:
+            g = self.buf(L, f"G{len(acts) - 1}", n, last.cin, h, w, dtype, dev, halo=1)
+            g = self.image_layer_bwd(last, x, gout, L.out, g, ws)
+            for i in range(len(self.dec) - 2, -1, -1):
+                s, x = self.dec[i], acts[i]
+                gx = self.buf(L, f"G{i}", n, s.cin, h, w, dtype, dev, halo=1)
+                if i > 0 and self.pair_ok(s, dtype, impl, h, w):
+                    g = self.c_bwd_pair(s, g, x, gx, ws)
+                    continue
+                # i == 0: the auto-encoder's input is the DenseBlock output (only its last conv, blocks 6,7, has no further contributor);
+                # x = f1 + f2 is not a ReLU output
+                mb = all_bits(gx.cb) if i > 0 else (bits(6, 7) if single else 0)
+                if i == 0 and not single and self.overlap_ok(s, dtype, impl, x, gx):
+                    gin = g
+                    g = self.c_dgrad(s, gin, x, gx, mb, 0, impl)
+                    self.fork_wgrad(s, x, gin, impl)
+                    continue
+                if self.wide_ok(s, dtype, impl, x, gx):
+                    g = self.c_bwd_wide(s, g, x, gx, mb, ws)
+                    continue
+                self.c_wgrad(s, x, g, ws, impl)
+                g = self.c_dgrad(s, g, x, gx, mb, 0, impl)
+        finally:
+            if deferred:
+                self.flush_reduces()
         if getattr(self, "_forked", None) is not None:
             try:
                 return self._encoder_backward(L, F, g, ws, impl, dtype, dev, n, h, w, single, img1, img2, grads)
@@ -935,6 +954,18 @@ class DenseFuseEngine(ModelEngine, DenseEncoderMixin):
         self.enc_bwd(self.enc, img1, F, GF, 0, 0, ws, impl, accumulate_w=False, gz=gz[0])
         self.enc_bwd(self.enc, img2, F, GF, 8, 8, ws, impl, accumulate_w=True, gz=gz[1])
         return grads
+
+    def enc_fwd_sum(self, img1, img2, F, S, dtype, impl):
+        """bf16, 'sum' fusion: the shared encoder on both images AND f1 + f2 as ONE launch (csrc/enc_stream2.hip's dual form, round 6;
+        $MMIF_ENC_SUM=0: the two-branch encoder launch + mmif_fuse_elem_fwd).  False = not taken."""
+        specs = self.enc
+        if not (dtype == torch.bfloat16 and impl != _lib.IMPL_VALU and switch("MMIF_ENC_STREAM") and switch("MMIF_ENC_SUM")
+                and type(self).fusion_fwd is DenseFuseEngine.fusion_fwd and self.fusion_mode == _lib.FUSE_SUM
+                and all(s.relu and s.k == 3 for s in specs) and [(s.cin, s.cout) for s in specs] == [(1, 16), (16, 16), (32, 16), (48, 16)]):
+            return False
+        br = [(img, specs[0].w.detach(), specs[0].b.detach(), [s.packed for s in specs[1:]], [s.b.detach() for s in specs[1:]], F.view(base, 8))
+              for img, base in ((img1, 0), (img2, 8))]
+        return T.dense_encoder_fwd_sum(br, S, tag="encode:fwd")
 
     def share_fused_grad(self, g, GF, dtype, impl):
         specs = self.enc

@@ -247,9 +247,7 @@ def image_in_fwd(img, w, bias, y, cout, k, relu):
     check(lib.mmif_conv2d_image_in_fwd(_ptr(img), _ptr(w), _ptr(bias), y.d, cout, k, int(relu), stream_ptr()), "image_in_fwd")
 
 
-def dense_encoder_fwd(branches, tag=None):
-    """ConvLayer(1,16) + DenseBlock(16,16) of one or two branches as ONE streaming launch (csrc/enc_stream.hip).
-    branches: [(img fp32 [n,1,h,w], w0, b0, (PackedWeights x 3), (bias x 3), out 8-block bf16 view), ...]"""
+def _encoder_structs(branches):
     structs = []
     for img, w0, b0, packed, biases, out in branches:
         e = _lib.MmifDenseEncoder()
@@ -259,10 +257,28 @@ def dense_encoder_fwd(branches, tag=None):
             e.packed[i] = packed[i].fwd.data_ptr()
             e.bias[i] = biases[i].data_ptr() if biases[i] is not None else None
         structs.append((e, out))
+    return structs
+
+
+def dense_encoder_fwd(branches, tag=None):
+    """ConvLayer(1,16) + DenseBlock(16,16) of one or two branches as ONE streaming launch (csrc/enc_stream.hip).
+    branches: [(img fp32 [n,1,h,w], w0, b0, (PackedWeights x 3), (bias x 3), out 8-block bf16 view), ...]"""
+    structs = _encoder_structs(branches)
     a, b = structs[0], (structs[1] if len(structs) > 1 else (None, None))
     with _timed(tag):
         check(lib.mmif_dense_encoder_fwd(C.byref(a[0]), a[1].d, C.byref(b[0]) if b[0] is not None else None,
                                          b[1].d if b[1] is not None else None, stream_ptr()), "dense_encoder_fwd")
+
+
+def dense_encoder_fwd_sum(branches, out_sum, tag=None):
+    """two branches that share ONE encoder (DenseFuse) + out_sum = out_a + out_b in one launch (csrc/enc_stream2.hip, dual form); returns False
+    (nothing launched) when the library does not take the case -- the caller then runs dense_encoder_fwd + fuse_elem_fwd"""
+    (ea, oa), (eb, ob) = _encoder_structs(branches)
+    if not lib.mmif_dense_encoder_fwd_sum_supported(C.byref(ea), C.byref(eb), oa.n, oa.h, oa.w):
+        return False
+    with _timed(tag):
+        check(lib.mmif_dense_encoder_fwd_sum(C.byref(ea), oa.d, C.byref(eb), ob.d, out_sum.d, stream_ptr()), "dense_encoder_fwd_sum")
+    return True
 
 
 def pack_dense_chain(w1, w2, w3, device, fmt=BF16):

@@ -275,3 +275,75 @@ def test_stream_geometry_fuzz():
             eng.enc_fwd_all(br, Fb, dtype, impl)
             torch.cuda.synchronize()
             assert torch.equal(Fa.buf.view(torch.int16), Fb.buf.view(torch.int16)), (n, h, w)
+
+
+SHAPES_SUM = [(1, 2, 2), (2, 5, 7), (1, 3, 30), (2, 32, 32), (1, 37, 53), (3, 64, 64), (1, 70, 33), (2, 129, 200), (2, 256, 256), (1, 300, 331), (1, 6, 58),
+              (1, 9, 31), (1, 4, 29), (2, 7, 84), (1, 12, 512)]
+
+
+@pytest.mark.parametrize("n,h,w", SHAPES_SUM, ids=[f"{n}x{h}x{w}" for n, h, w in SHAPES_SUM])
+def test_shared_encoder_plus_sum_in_one_launch(n, h, w):
+    """Round 6, DenseFuse (reference core/model.py:165-186, core/fusion.py:21-29): mmif_dense_encoder_fwd_sum -- both images of a pair through
+    ONE shared encoder and f1 + f2, one launch (csrc/enc_stream2.hip's dual form: a wave carries the same 32-column strip of both images).
+    Against the two-branch encoder launch (32-pixel strips: the same strips, the same MFMA sequence per tile) + mmif_fuse_elem_fwd: the two
+    branches' 64 channels and the sum bit for bit; nothing outside the three views is written."""
+    import core.model as M
+    from mmif import engine as E
+    from mmif import tensor as T
+    from mmif._lib import FUSE_SUM
+    with dtype_ctx("bf16"), gen(2):
+        torch.manual_seed(11 + h)
+        m = M.DenseFuse().to(DEV)
+        with torch.no_grad():
+            for p in m.parameters():
+                if p.dim() == 1:
+                    p.copy_(torch.randn_like(p) * 0.1)
+        eng = E.DenseFuseEngine(m)
+        g = torch.Generator().manual_seed(h * 7 + w)
+        i1, i2 = torch.rand(n, 1, h, w, generator=g).to(DEV), torch.rand(n, 1, h, w, generator=g).to(DEV)
+        (i1, i2), _, _, _, dtype, impl = eng.prepare((i1, i2))
+        Fa, Fb = T.BT.alloc(n, 128, h, w, dtype, DEV), T.BT.alloc(n, 128 + 16, h, w, dtype, DEV)
+        Sa, Sb = T.BT.alloc(n, 64, h, w, dtype, DEV), T.BT.alloc(n, 64 + 16, h, w, dtype, DEV)
+        for t in (Fa, Fb, Sa, Sb):
+            t.buf.fill_(7.0)
+        eng.enc_fwd_all([(eng.enc, i1, 0), (eng.enc, i2, 8)], Fa, dtype, impl)
+        T.fuse_elem_fwd(Fa.view(0, 8), Fa.view(8, 8), Sa, FUSE_SUM)
+        # the fused launch into views with a guard block on either side
+        assert eng.enc_fwd_sum(i1, i2, Fb.view(1, 16), Sb.view(1, 8), dtype, impl)
+        torch.cuda.synchronize()
+        a, b = Fa.buf.view(torch.int16), Fb.buf.view(torch.int16)
+        for name, x, y in (("branch a", a[:, :8], b[:, 1:9]), ("branch b", a[:, 8:], b[:, 9:17]), ("sum", Sa.buf.view(torch.int16), Sb.buf.view(torch.int16)[:, 1:9])):
+            if not torch.equal(x, y):
+                d = (x != y).nonzero()
+                raise AssertionError(f"{name}: {d.shape[0]} of {x.numel()} elements differ; first at [n, cb, y, x, e] = {d[0].tolist()}, "
+                                     f"per channel block: {[(x[:, c] != y[:, c]).sum().item() for c in range(x.shape[1])]}")
+        assert float(Sa.buf.float().abs().max()) > 0
+        for guard in (Fb.buf[:, 0], Fb.buf[:, 17], Sb.buf[:, 0], Sb.buf[:, 9]):
+            assert bool((guard.float() == 7.0).all()), "a guard block was written"
+
+
+def test_densefuse_step_with_and_without_the_fused_sum(monkeypatch):
+    """DenseFuse train step (bf16), $MMIF_ENC_SUM = 1 / 0: bit-identical fused image, losses and gradients (the same values reach the decoder)"""
+    import core.model as M
+    from core.loss import FusionLoss, GradLoss, PixelLoss, SSIMLoss, unit_gradient
+    from gpu_util import reload_switches
+    g = torch.Generator().manual_seed(4)
+    a, b = torch.rand(3, 1, 72, 104, generator=g).to(DEV), torch.rand(3, 1, 72, 104, generator=g).to(DEV)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MMIF_ENC_SUM", mode)
+        reload_switches()
+        with dtype_ctx("bf16"):
+            torch.manual_seed(0)
+            m = M.DenseFuse().to(DEV)
+            l_all = FusionLoss(SSIMLoss('ssim', weight=1.0), PixelLoss('l1', weight=0.01), GradLoss('l1', weight=0.1).to(DEV), 'max', 'max')
+            f = m(a, b)
+            tot = l_all(a, b, f)
+            tot.backward(unit_gradient(tot))
+            torch.cuda.synchronize()
+            res[mode] = (f.detach().cpu().clone(), tot.detach().item(), {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters()})
+    monkeypatch.delenv("MMIF_ENC_SUM")
+    reload_switches()
+    assert torch.equal(res["1"][0], res["0"][0]) and res["1"][1] == res["0"][1]
+    for k, g1 in res["1"][2].items():
+        assert float(g1.abs().max()) > 0 and torch.equal(g1, res["0"][2][k]), k
