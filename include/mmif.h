@@ -242,6 +242,16 @@ int mmif_conv2d_reflect_dgrad_folded(const mmif_tensor* gy, const float* w, cons
  * gx_old: gx's shape / halo / channel blocks, folded.  bf16 thin layers only (the asynchronous kernel): ask
  * mmif_conv2d_dgrad_onto_supported first.  Use: DenseFuse / VIFNet, where both encoder branches start from the ONE gradient of
  * f1 + f2 (core/fusion.py:21-29 'sum') -- no per-branch copy of it. */
+/* Folded dgrad of a wide 3x3 layer (its own output neither masked nor accumulated) that ALSO leaves two masked copies of fragment `frag`
+ * (16 channels = channel blocks 2 frag, 2 frag + 1 of gx) in dup_out (round 6, DenseFuse `core/model.py:165-186`: the gradient of f1 + f2 is
+ * the gradient of either encoder's output, but each encoder's last DenseBlock conv still owes it the ReLU mask of its own x3):
+ *   dup_out blocks [2 frag, + 1]     = gx blocks [2 frag, + 1] * [dup_mask blocks [2 frag, + 1]     > 0]
+ *   dup_out blocks [2 frag + 8, + 1] = gx blocks [2 frag, + 1] * [dup_mask blocks [2 frag + 8, + 1] > 0]
+ * dup_out: bf16 halo-1 tensor of gx's shape (interior written, ring untouched: folded), dup_mask: the bf16 halo-0 activations.  Bit-identical
+ * to mmif_conv2d_reflect_dgrad_folded + mmif_fuse_elem_bwd(MMIF_FUSE_SUM, relu_mask) on those blocks. */
+int mmif_conv2d_dgrad_dup_supported(const mmif_tensor* gy, const mmif_tensor* gx, int32_t cin, int32_t cout, int32_t ksize);
+int mmif_conv2d_reflect_dgrad_folded_dup(const mmif_tensor* gy, const void* w_packed_t, const mmif_tensor* gx, int32_t cin, int32_t cout,
+                                         int32_t ksize, const mmif_tensor* dup_out, const mmif_tensor* dup_mask, int32_t frag, void* stream);
 int mmif_conv2d_dgrad_onto_supported(const mmif_tensor* gy, const mmif_tensor* gx, int32_t cin, int32_t cout, int32_t ksize);
 int mmif_conv2d_reflect_dgrad_folded_onto(const mmif_tensor* gy, const void* w_packed_t, const mmif_tensor* x, const mmif_tensor* gx_old,
                                           const mmif_tensor* gx, int32_t cin, int32_t cout, int32_t ksize, uint64_t mask_bits,

@@ -24,12 +24,21 @@ int check_launch(const char* what);
         }                                \
     } while (0)
 
-// timing-ablation switches ($MMIF_*_ABLATE, tools/sweep_*.sh): a non-zero value makes the kernels skip loads / stores / k-loops, i.e. the
+// timing-ablation switches ($MMIF_ABLATE, tools/sweep_*.sh): a non-zero value makes the kernels skip loads / stores / k-loops, i.e. the
 // results are WRONG -- say so loudly, once, so that a stray variable in a training environment cannot pass unnoticed
-inline int ablate_env(const char* name) {
-    const char* e = getenv(name);
-    const int v = e != nullptr ? atoi(e) : 0;
-    if (v != 0) fprintf(stderr, "mmif: WARNING: %s=%d is a timing-ablation mode -- kernel results are WRONG (diagnostics only)\n", name, v);
+// ONE variable for all of them: MMIF_ABLATE="conv=5,x3=8" (keys: conv = conv_dma_kernel, x3 = the split-operand kernels, bp = bwd_pair_dma_kernel,
+// ec = enc_chain_bwd_kernel; the bit meanings are documented at the kernels)
+inline int ablate_env(const char* key) {
+    const char* e = getenv("MMIF_ABLATE");
+    if (e == nullptr) return 0;
+    const size_t kl = strlen(key);
+    int v = 0;
+    for (const char* p = e; *p != 0;) {
+        if (strncmp(p, key, kl) == 0 && p[kl] == '=') v = atoi(p + kl + 1);
+        while (*p != 0 && *p != ',') ++p;
+        if (*p == ',') ++p;
+    }
+    if (v != 0) fprintf(stderr, "mmif: WARNING: MMIF_ABLATE %s=%d is a timing-ablation mode -- kernel results are WRONG (diagnostics only)\n", key, v);
     return v;
 }
 

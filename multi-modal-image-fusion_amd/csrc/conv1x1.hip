@@ -180,17 +180,14 @@ static int c1_num_cus() {
     return n;
 }
 
-static int g_c1_mode = -1;   // $MMIF_CONV1X1_STREAM=0: keep the register-staged kernel (A/B timing)
+static int g_c1_mode = -1;   // mmif_debug_set_conv1x1_stream(0): keep the register-staged kernel (the tests' cross-check)
 constexpr size_t C1_MAX_LDS = 128 * 1024;
 
 static size_t c1_lds_bytes(int nch, int m16p) { return (size_t)nch * 4 * m16p * 16 + (size_t)m16p * 4; }
 
 // shapes the streaming kernel takes; everything else stays on conv_mfma_kernel<1, ...>
 bool conv1x1_stream_ok(bool dgrad, const TV& tin, const TV& tout, const TV& tmask, int n_out, int m16p, uint64_t mask_bits, uint64_t accum_bits) {
-    if (g_c1_mode < 0) {
-        const char* e = getenv("MMIF_CONV1X1_STREAM");
-        g_c1_mode = (e != nullptr && atoi(e) == 0) ? 0 : 1;
-    }
+    if (g_c1_mode < 0) g_c1_mode = 1;
     if (g_c1_mode == 0 || accum_bits != 0) return false;
     if (tin.hs != tout.hs || tin.ws != tout.ws || tin.n != tout.n) return false;          // same stored geometry: one linear walk
     if (tin.halo != 0 && !tin.folded) return false;                                       // an unfolded halo-1 gradient needs the fold-on-load path

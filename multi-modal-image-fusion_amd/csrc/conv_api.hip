@@ -11,6 +11,8 @@ int wgrad_valu(int dtype, int ks, const TV& tx, const TV& tg, float* dw, float* 
                float* ws, hipStream_t st);
 // conv_mfma.hip
 bool conv_mfma_supported(bool dgrad, int ks, int cin, int cout);
+bool conv_dgrad_dup_supported(int ks, int cin, const TV& tin, const TV& tout);
+int conv_dgrad_dup(const TV& tin, const TV& tout, const void* wpk, int cin, int cout, const TV& tdup, const TV& tmask, int frag, hipStream_t st);
 int conv_mfma(bool dgrad, int ks, const TV& tin, const TV& tout, const TV& tmask, const void* w_packed, const float* bias,
               int cin, int cout, int relu, uint64_t mask_bits, uint64_t accum_bits, hipStream_t st, bool fold = false,
               bool* folded = nullptr, const TV* told = nullptr);
@@ -155,6 +157,34 @@ extern "C" int mmif_conv2d_reflect_dgrad_folded_onto(const mmif_tensor* gy, cons
     MMIF_REQUIRE(gx_old != nullptr && w_packed_t != nullptr, "conv2d_reflect_dgrad_folded_onto: NULL gx_old / operand image");
     return dgrad_impl("conv2d_reflect_dgrad_folded_onto", gy, nullptr, w_packed_t, x, gx, cin, cout, ksize, mask_bits, accum_bits, MMIF_IMPL_MFMA,
                       stream, true, gx_old);
+}
+
+// dgrad (folded; its own output neither masked nor accumulated) that also leaves the two masked copies DenseFuse's encoder branches need of
+// 16 of its channels (struct DupOut, csrc/conv_mfma.hip) -- replaces mmif_fuse_elem_bwd on those blocks
+extern "C" int mmif_conv2d_dgrad_dup_supported(const mmif_tensor* gy, const mmif_tensor* gx, int32_t cin, int32_t cout, int32_t ksize) {
+    (void)cout;
+    if (validate_tensor(gy, "gy") != MMIF_OK || validate_tensor(gx, "gx") != MMIF_OK) return 0;
+    if (gy->dtype != MMIF_BF16 || gx->dtype != MMIF_BF16 || gy->halo != 1 || !(gy->flags & MMIF_T_FOLDED) || gx->halo != 1) return 0;
+    return conv_dgrad_dup_supported(ksize, cin, make_tv(gy), make_tv(gx)) ? 1 : 0;
+}
+extern "C" int mmif_conv2d_reflect_dgrad_folded_dup(const mmif_tensor* gy, const void* w_packed_t, const mmif_tensor* gx, int32_t cin, int32_t cout,
+                                                    int32_t ksize, const mmif_tensor* dup_out, const mmif_tensor* dup_mask, int32_t frag, void* stream) {
+    if (int rc = validate_tensor(gy, "gy")) return rc;
+    if (int rc = validate_tensor(gx, "gx")) return rc;
+    if (int rc = validate_tensor(dup_out, "dup_out")) return rc;
+    if (int rc = validate_tensor(dup_mask, "dup_mask")) return rc;
+    MMIF_REQUIRE(w_packed_t != nullptr, "conv2d_reflect_dgrad_folded_dup: NULL operand image");
+    MMIF_REQUIRE(gy->n == gx->n && gy->h == gx->h && gy->w == gx->w, "conv2d_reflect_dgrad_folded_dup: gy / gx mismatch");
+    MMIF_REQUIRE(cin > 0 && (cin + 7) / 8 == gx->cb && cout > 0 && (cout + 7) / 8 == gy->cb, "conv2d_reflect_dgrad_folded_dup: channel blocks do not match");
+    MMIF_REQUIRE(mmif_conv2d_dgrad_dup_supported(gy, gx, cin, cout, ksize), "conv2d_reflect_dgrad_folded_dup: layer / tensors not taken by the DMA-staged dgrad");
+    MMIF_REQUIRE(frag >= 0 && 2 * frag + 1 < gx->cb, "conv2d_reflect_dgrad_folded_dup: fragment %d outside the gradient's %d channel blocks", frag, gx->cb);
+    MMIF_REQUIRE(dup_out->dtype == MMIF_BF16 && dup_out->halo == 1 && dup_out->n == gx->n && dup_out->h == gx->h && dup_out->w == gx->w &&
+                     dup_out->cb >= 2 * frag + 10,
+                 "conv2d_reflect_dgrad_folded_dup: dup_out must be a bf16 halo-1 tensor of gx's shape with >= %d channel blocks", 2 * frag + 10);
+    MMIF_REQUIRE(dup_mask->dtype == MMIF_BF16 && dup_mask->halo == 0 && dup_mask->n == gx->n && dup_mask->h == gx->h && dup_mask->w == gx->w &&
+                     dup_mask->cb >= 2 * frag + 10,
+                 "conv2d_reflect_dgrad_folded_dup: dup_mask must be the bf16 halo-0 activations of gx's shape with >= %d channel blocks", 2 * frag + 10);
+    return conv_dgrad_dup(make_tv(gy), make_tv(gx), w_packed_t, cin, cout, make_tv(dup_out), make_tv(dup_mask), frag, (hipStream_t)stream);
 }
 
 extern "C" size_t mmif_conv2d_wgrad_workspace(int32_t cin, int32_t cout, int32_t ksize) {

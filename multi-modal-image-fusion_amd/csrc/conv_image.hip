@@ -477,13 +477,9 @@ extern "C" int mmif_conv2d_image_out_fwd(const mmif_tensor* x, const float* w, c
     const size_t shm = (size_t)cin * ksize * ksize * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     if (ksize == 3 && cin == 16 && x->cb == 2) {
-        // bf16: the persistent kernel of csrc/image_bwd.hip (round 6; $MMIF_IMAGE_FWD16=0: the tiled kernel below)
-        static const int fwd16 = [] { const char* e = getenv("MMIF_IMAGE_FWD16"); return (e != nullptr && e[0] == '0') ? 0 : 1; }();
-        if (x->dtype == MMIF_BF16 && fwd16) return image_out_fwd16_launch(tx, w, bias, img, relu, st);
-        if (x->dtype == MMIF_BF16)
-            hipLaunchKernelGGL(image_out_fwd_tiled_kernel<bf16_t>, dim3(tiles_x * tiles_y, tx.n), dim3(256), 0, st, tx, w, bias, img, relu, tiles_x);
-        else
-            hipLaunchKernelGGL(image_out_fwd_tiled_kernel<float>, dim3(tiles_x * tiles_y, tx.n), dim3(256), 0, st, tx, w, bias, img, relu, tiles_x);
+        // bf16: the persistent kernel of csrc/image_bwd.hip (round 6; 36 us against the tiled kernel's 40 at B = 32 256 x 256); fp32: the tiled kernel
+        if (x->dtype == MMIF_BF16) return image_out_fwd16_launch(tx, w, bias, img, relu, st);
+        hipLaunchKernelGGL(image_out_fwd_tiled_kernel<float>, dim3(tiles_x * tiles_y, tx.n), dim3(256), 0, st, tx, w, bias, img, relu, tiles_x);
         return check_launch("image_out_fwd");
     }
 #define CALL(T, KS) hipLaunchKernelGGL((image_out_fwd_kernel<T, KS>), dim3(tiles_x * tiles_y, tx.n), dim3(256), shm, st, tx, w, bias, img, cin, relu, tiles_x)

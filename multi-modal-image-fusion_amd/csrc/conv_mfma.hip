@@ -162,17 +162,29 @@ __device__ inline uint4 load_in_gradfold(const TV& t, int in_, int c, int y, int
     return make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
 }
 
+// Round 6 (DenseFuse, `core/model.py:165-186`): the gradient of f1 + f2 IS the gradient of either encoder's output, but each encoder's last
+// DenseBlock conv (channel blocks 6, 7 of its 8) still owes it the ReLU mask of its own x3.  A dgrad can leave those two masked COPIES itself:
+// fragment `frag` (16 channels = blocks 2 frag, 2 frag + 1 of the gradient it computes) is also written to out's blocks [2 frag, + 1] masked
+// by mask's blocks [2 frag, + 1], and to out's blocks [2 frag + 8, + 1] masked by mask's [2 frag + 8, + 1] (out: halo-1 tensor of gx's
+// geometry, mask: the halo-0 activations [x(img1) | x(img2)]) -- mmif_fuse_elem_bwd's pass disappears.  frag < 0: off.
+struct DupOut {
+    TV out, mask;
+    int frag;
+};
+
 // ------------------------------------------------------------------ shared epilogue
 // After the MFMAs lane (g, j) holds oc = 16*m + 4*g + r (r = 0..3) of pixels (row 4*wave + n, col j).
 // v_permlane16_swap pairs rows n, n+1: lanes with even g end up with all 8 channels of row n, odd g with all
 // 8 channels of row n+1, so every lane issues ONE 16-byte store per row pair (the 8-byte version was store-issue
 // bound: 16 stores ~ 10k cycles per block).  oxs / oys0: stored column / first stored row (of the lane's row pair 0).
-template <int MF, bool DGRAD, bool LM = false>
+// DUP (dgrad, no LM): the instantiation that writes struct DupOut's masked copies; its own output is neither masked nor accumulated
+template <int MF, bool DGRAD, bool LM = false, bool DUP = false>
 __device__ inline void conv_epilogue(const f32x4 (&acc)[MF][4], const TV& tout, const TV& tmask, const float* s_bias, int mb, int in_,
                                      int oxs, int oys0, int g, int relu, unsigned long long mask_bits, unsigned long long accum_bits,
                                      int xlim, int ylim,   // stored columns / rows >= xlim / ylim are not written
                                      const unsigned char* lmask = nullptr, int lrow0 = 0, int lcol = 0,
-                                     const TV* told = nullptr /* dgrad: accumulate ONTO this tensor's values instead of tout's (same n, h, w, halo) */) {
+                                     const TV* told = nullptr /* dgrad: accumulate ONTO this tensor's values instead of tout's (same n, h, w, halo) */,
+                                     const DupOut* dup = nullptr /* dgrad without LM: masked copies of one fragment, see struct DupOut */) {
     // lmask (conv_dma_kernel dgrad): the ReLU-mask SIGN BITS of this tile, one byte per (channel block, tile row, tile column),
     // staged into LDS by the loader waves ahead of time; lrow0 / lcol = this lane's first tile row / its column
     if (oxs >= xlim) return;
@@ -181,7 +193,7 @@ __device__ inline void conv_epilogue(const f32x4 (&acc)[MF][4], const TV& tout, 
     // dgrad: fetch the old gradient / the ReLU-mask activations of ALL the lane's outputs first -- one memory round trip for
     // the whole epilogue instead of one per 16-channel fragment (and the stores below may alias them as far as the compiler
     // can tell, which would serialise load -> store -> load)
-    uint4 oldv[DGRAD ? MF : 1][2], xmv[(DGRAD && !LM) ? MF : 1][2];
+    uint4 oldv[(DGRAD && !DUP) ? MF : 1][2], xmv[(DGRAD && !LM && !DUP) ? MF : 1][2];
     unsigned lbits[(DGRAD && LM) ? MF : 1][2];
     if (DGRAD && LM) {
 #pragma unroll
@@ -189,7 +201,7 @@ __device__ inline void conv_epilogue(const f32x4 (&acc)[MF][4], const TV& tout, 
 #pragma unroll
             for (int p2 = 0; p2 < 2; ++p2) lbits[LM ? m : 0][p2] = lmask[((2 * m + (g >> 1)) * DT_ROWS_C + lrow0 + 2 * p2) * MT + lcol];
     }
-    if (DGRAD) {
+    if (DGRAD && !DUP) {
         const unsigned mpix_off = (unsigned)min(max(reflect_idx(oxs - tout.halo, tmask.w), 0), tmask.w - 1) * 16u;
 #pragma unroll
         for (int m = 0; m < MF; ++m) {
@@ -221,6 +233,22 @@ __device__ inline void conv_epilogue(const f32x4 (&acc)[MF][4], const TV& tout, 
                     }
                 }
             }
+        }
+    }
+    // masked copies of one fragment (struct DupOut): the two mask granules of both row pairs are requested with the epilogue's other operands
+    uint4 dxa[2], dxb[2];
+    int dm = -1;
+    if (DUP && dup->frag >= mb * MF && dup->frag < mb * MF + MF) {
+        dm = dup->frag - mb * MF;
+        const int ocb_d = dup->frag * 2 + (g >> 1);
+        const TV& tk = dup->mask;
+        const unsigned kx = (unsigned)min(max(reflect_idx(oxs - tout.halo, tk.w), 0), tk.w - 1) * 16u;
+        const char* pa = tk.base + ((long long)in_ * tk.img + (long long)(tk.cb_off + ocb_d) * tk.plane) * 16 + kx;
+#pragma unroll
+        for (int p2 = 0; p2 < 2; ++p2) {
+            const int y = min(max(reflect_idx(oys0 + 2 * p2 - tout.halo, tk.h), 0), tk.h - 1);
+            dxa[p2] = *reinterpret_cast<const uint4*>(pa + (unsigned)(y * tk.ws) * 16u);
+            dxb[p2] = *reinterpret_cast<const uint4*>(pa + (unsigned)(y * tk.ws) * 16u + 8ll * tk.plane * 16);
         }
     }
 #pragma unroll
@@ -255,7 +283,7 @@ __device__ inline void conv_epilogue(const f32x4 (&acc)[MF][4], const TV& tout, 
                     const float t = c[i] + bv[i];
                     c[i] = relu ? fmaxf(t, 0.f) : t;
                 }
-            } else {
+            } else if constexpr (!DUP) {
                 const uint32_t ow[4] = {oldv[m][p2].x, oldv[m][p2].y, oldv[m][p2].z, oldv[m][p2].w};
                 const uint32_t xw[4] = {xmv[LM ? 0 : m][p2].x, xmv[LM ? 0 : m][p2].y, xmv[LM ? 0 : m][p2].z, xmv[LM ? 0 : m][p2].w};
                 if (LM) {
@@ -285,6 +313,23 @@ __device__ inline void conv_epilogue(const f32x4 (&acc)[MF][4], const TV& tout, 
 #pragma unroll
         for (int p2 = 0; p2 < 2; ++p2)
             if (outok[p2]) MMIF_STORE_GRAN(oplane + (2 * p2) * row_bytes, outv[p2]);
+        if (DUP && m == dm) {
+            // bf16 > 0 per 16-bit half: min(x, 1) then max(.., 0) as signed 16-bit values gives 1 / 0, times 0xffff the half's mask
+            auto keep = [](uint32_t v, uint32_t x) {
+                uint32_t q;
+                __asm__("v_pk_min_i16 %0, %1, %2\n\tv_pk_max_i16 %0, %0, 0" : "=&v"(q) : "v"(x), "v"(0x00010001u));
+                return v & (q * 0xffffu);
+            };
+            const TV& tdo = dup->out;
+            char* da = tdo.base + ((long long)in_ * tdo.img + (long long)(tdo.cb_off + ocb) * tdo.plane) * 16 + pix_off;
+#pragma unroll
+            for (int p2 = 0; p2 < 2; ++p2) {
+                if (!outok[p2]) continue;
+                const uint4 v = outv[p2], xa = dxa[p2], xb = dxb[p2];
+                MMIF_STORE_GRAN(da + (2 * p2) * row_bytes, make_uint4(keep(v.x, xa.x), keep(v.y, xa.y), keep(v.z, xa.z), keep(v.w, xa.w)));
+                MMIF_STORE_GRAN(da + (2 * p2) * row_bytes + 8ll * tdo.plane * 16, make_uint4(keep(v.x, xb.x), keep(v.y, xb.y), keep(v.z, xb.z), keep(v.w, xb.w)));
+            }
+        }
     }
 }
 
@@ -717,12 +762,14 @@ struct SignMap {
 static inline int sign_pitch(int w) { return (cdiv(w, MT) + 2) * MT; }
 
 // (LMASK: 0 = none, 1 = the loaders reduce the mask ACTIVATIONS to sign bytes, 2 = they fetch ready sign bytes -- struct SignMap)
-template <bool DGRAD, int LMASK>
+// (DUP: the dgrad that also leaves struct DupOut's masked copies -- its own instantiation: as a run-time option of <true, 0> the extra
+// operands spilled 28 registers at the 168-register budget)
+template <bool DGRAD, int LMASK, bool DUP = false>
 __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void conv_dma_kernel(TV tin, TV tout, TV tmask, const uint4* __restrict__ wpk,
                                                                               const float* __restrict__ bias, int n_out, int m16p, int relu,
                                                                               unsigned long long mask_bits, unsigned long long accum_bits,
                                                                               int tiles_x, int tiles_y, int nmb, long long* __restrict__ trace,
-                                                                              int abl, int org, SignMap sgn) {
+                                                                              int abl, int org, SignMap sgn, DupOut dup) {
     constexpr int MF = 4;
     __shared__ __attribute__((aligned(16))) char s_buf[2 * DBUF_BYTES];
     __shared__ int2 s_tab[2][DW_PIECES];
@@ -740,7 +787,7 @@ __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void conv_dma_kernel(TV 
     int tr_n = 0;
     long long* tr = (trace != nullptr && blockIdx.x < 128 && lane == 0 && wave < D_CONS) ? trace + ((long long)blockIdx.x * 8 + wave) * 64 : nullptr;
 #define DTRACE() do { if (tr != nullptr && tr_n < 62 && !(abl & 256)) tr[tr_n++] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
-    // $MMIF_CONV_ABLATE bit 8: stamp only the top of every third chunk (the period over the whole launch instead of the phases of
+    // $MMIF_ABLATE conv= bit 8: stamp only the top of every third chunk (the period over the whole launch instead of the phases of
     // its first 12 chunks)
 #define DTRACE_TOP(q) do { if (tr != nullptr && tr_n < 62 && (!(abl & 256) || (q) % 3 == 0)) tr[tr_n++] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
     if (tr != nullptr && tr_n < 62) tr[tr_n++] = (long long)__builtin_amdgcn_s_memtime();
@@ -830,7 +877,7 @@ __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void conv_dma_kernel(TV 
             }
         };
         auto issue_dma = [&](const DItem& itm, int c, int buf, int item_no = 0) {
-            // timing ablations (results are garbage): $MMIF_CONV_ABLATE bit 1 = no WEIGHT pieces on every second item (what a weight chunk
+            // timing ablations (results are garbage): $MMIF_ABLATE conv= bit 1 = no WEIGHT pieces on every second item (what a weight chunk
             // shared by two pixel tiles could save at most), bit 3 = no INPUT pieces on every second item (an input tile shared by two M-blocks)
             const bool skip_w = (abl & 2) && (item_no & 1), skip_in = (abl & 8) && (item_no & 1);
             const int ncb = min(CHUNK_CB, ncb_tot - c * CHUNK_CB);
@@ -967,8 +1014,8 @@ __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void conv_dma_kernel(TV 
                 conv_epilogue<MF, true, true>(acc, tout, tmask, s_bias[slot], (itm).mb, (itm).in_, oxs_, oys0_, g, relu, mask_bits,           \
                                               accum_bits, tout.ws - org, tout.hs - org, s_mask[LMASK ? (par) : 0], wave * 4 + (g & 1), j);    \
         } else {                                                                                                                              \
-            conv_epilogue<MF, true, false>(acc, tout, tmask, s_bias[slot], (itm).mb, (itm).in_, oxs_, oys0_, g, relu, mask_bits, accum_bits,  \
-                                           tout.ws - org, tout.hs - org, nullptr, wave * 4 + (g & 1), j);                                     \
+            conv_epilogue<MF, true, false, DUP>(acc, tout, tmask, s_bias[slot], (itm).mb, (itm).in_, oxs_, oys0_, g, relu, mask_bits,        \
+                                                accum_bits, tout.ws - org, tout.hs - org, nullptr, wave * 4 + (g & 1), j, nullptr, &dup);     \
         }                                                                                                                                     \
     } while (0)
     DItem cur = decode(first), pend = cur;
@@ -2312,11 +2359,11 @@ int bwd_pair(const TV& tx, const TV& tg, const TV& tgx, const void* wpk_dgrad, f
     const int cap = (cin == 64 ? 1 : 2) * num_cus_();
     const int G = total < cap ? total : (cap < BP_MAXG ? cap : BP_MAXG);
     ws = defer_ws(ws, (size_t)G * ((size_t)cout * cin * 9 + cout) * sizeof(float));
-    // $MMIF_BWD_PAIR_DMA=0 / mmif_debug_set_bwd_pair_dma(0): the register-staged kernel (A/B; bit-identical results)
-    if (g_bwd_pair_dma < 0) { const char* e = getenv("MMIF_BWD_PAIR_DMA"); g_bwd_pair_dma = (e != nullptr && e[0] == '0') ? 0 : 1; }
+    // mmif_debug_set_bwd_pair_dma(0): the register-staged kernel (the tests' cross-check; bit-identical results)
+    if (g_bwd_pair_dma < 0) g_bwd_pair_dma = 1;
     const bool use_dma = g_bwd_pair_dma == 1 && tg.halo == 1 && tg.folded;
-    static int bp_abl = -1;   // $MMIF_BP_ABLATE (timing ablations, wrong results): 1 no tile requests after the first, 2 no gx stores, 4 no wgrad loops, 8 no dgrad k-loops
-    if (bp_abl < 0) bp_abl = ablate_env("MMIF_BP_ABLATE");   // (the loader reads the gradient's zero ring for rows / columns past the image)
+    static int bp_abl = -1;   // $MMIF_ABLATE bp= (timing ablations, wrong results): 1 no tile requests after the first, 2 no gx stores, 4 no wgrad loops, 8 no dgrad k-loops
+    if (bp_abl < 0) bp_abl = ablate_env("bp");   // (the loader reads the gradient's zero ring for rows / columns past the image)
     if (cin == 64 && use_dma)
         hipLaunchKernelGGL((bwd_pair_dma_kernel<4, 2>), dim3(G), dim3(512), 0, st, tx, tg, tgx, (const uint4*)wpk_dgrad, ws, tiles_x, tpi, total, G, bp_abl);
     else if (cin == 64)
@@ -2334,7 +2381,8 @@ int bwd_pair(const TV& tx, const TV& tg, const TV& tgx, const void* wpk_dgrad, f
 // activations themselves -- for decode.1 (128 -> 64, every input block masked) that is 0.54 of the dgrad's 1.34 GB.
 static int launch_wgrad_dma(const TV& tx, const TV& tg, float* dw, float* db, int cin, int cout, int accumulate, float* ws, hipStream_t st, SignMap sgn);
 static int launch_conv_dma(bool dgrad, const TV& tin, const TV& tout, const TV& tmask, const void* wpk, const float* bias, int n_out, int relu,
-                           uint64_t mask_bits, uint64_t accum_bits, int org, hipStream_t st, SignMap sgn);
+                           uint64_t mask_bits, uint64_t accum_bits, int org, hipStream_t st, SignMap sgn = SignMap{nullptr, 0, 0, 0},
+                           const DupOut* dup = nullptr);
 static void init_modes();
 bool bwd_wide_supported(int ks, int cin, int cout) { return ks == 3 && cin >= 64 && cout >= 64 && cin % 64 == 0 && cout % 64 == 0 && cin <= 512; }
 size_t bwd_wide_signs_bytes(int n, int cin, int h, int w) { return (size_t)n * (cin / 8) * (h + 2) * sign_pitch(w); }
@@ -2371,27 +2419,23 @@ static int launch_conv_mfma(bool dgrad, const TV& tin, const TV& tout, const TV&
 
 static int num_cus_() { return cached_num_cus(); }
 
-static int g_dma_mode = -1;   // $MMIF_CONV_DMA: 1 (default) = DMA-staged kernel where it applies, 0 = never
+static int g_dma_mode = 1;    // mmif_debug_set_conv_dma: 1 (default) = DMA-staged kernel where it applies, 0 = never (the tests' cross-check)
 static int g_num_cus = 0;
-static int g_fuse_fold = -1;   // $MMIF_DGRAD_FOLD: 1 (default) = the DMA-staged dgrads fold the reflect halo themselves
-static int g_abl = 0;            // $MMIF_CONV_ABLATE (diagnostics): bit 0 = no staging DMAs after the first chunk
+constexpr int g_fuse_fold = 1;   // the DMA-staged dgrads fold the reflect halo themselves (round 2's A/B switch is gone: +5 % on the step)
+static int g_abl = 0;            // $MMIF_ABLATE conv= (diagnostics): bit 0 = no staging DMAs after the first chunk
 
-static int g_lmask = -1;
-static int g_wgrad_ragged = 1;    // mmif_debug_set_ragged / $MMIF_WGRAD_RAGGED=0: wgrad_dma_kernel stages the padded planes of a ragged channel group too (A/B)
-// the environment switches, read once -- by whichever entry point runs first (a process whose first MFMA call was a weight gradient used
-// to leave g_fuse_fold unset, i.e. the stand-alone fold kernel for the rest of its life)
+static int g_wgrad_ragged = 1;    // mmif_debug_set_ragged(0): wgrad_dma_kernel stages the padded planes of a ragged channel group too (the tests' cross-check)
 static void init_modes() {
-    if (g_dma_mode >= 0 && g_fuse_fold >= 0) return;
-    const char* e = getenv("MMIF_CONV_DMA");
-    if (g_dma_mode < 0) g_dma_mode = (e != nullptr && e[0] == '0') ? 0 : 1;   // (mmif_debug_set_conv_dma may have set it already)
-    g_abl = ablate_env("MMIF_CONV_ABLATE");
-    const char* r = getenv("MMIF_DGRAD_FOLD");
-    g_fuse_fold = (r != nullptr && r[0] == '0') ? 0 : 1;
-    const char* q = getenv("MMIF_WGRAD_RAGGED");
-    if (q != nullptr && q[0] == '0') g_wgrad_ragged = 0;
+    static bool done = false;
+    if (done) return;
+    done = true;
+    g_abl = ablate_env("conv");      // (timing ablations, diagnostics only: tools/sweep_staging.sh)
 }
 static int launch_conv_dma(bool dgrad, const TV& tin, const TV& tout, const TV& tmask, const void* wpk, const float* bias, int n_out,
-                           int relu, uint64_t mask_bits, uint64_t accum_bits, int org, hipStream_t st, SignMap sgn = SignMap{nullptr, 0, 0, 0}) {
+                           int relu, uint64_t mask_bits, uint64_t accum_bits, int org, hipStream_t st, SignMap sgn, const DupOut* dup) {
+    DupOut dupv;
+    if (dup != nullptr) dupv = *dup;
+    else { dupv.out = tout; dupv.mask = tout; dupv.frag = -1; }
     const int tiles_x = cdiv(tout.ws - 2 * org, MT), tiles_y = cdiv(tout.hs - 2 * org, DT_ROWS);
     const int nmb = n_mblocks(n_out);
     const int m16p = nmb * 4 * 16;
@@ -2400,16 +2444,15 @@ static int launch_conv_dma(bool dgrad, const TV& tin, const TV& tout, const TV& 
     int G = g_num_cus / 8 * 8;   // one persistent block per CU (150 KB of LDS each)
     if (G < 8) G = 8;
     if (nitems < G) G = (int)nitems;
-    // dgrad with ReLU masks and >= 2 chunks per tile: the loader waves stage the mask bits ($MMIF_DGRAD_LMASK=0: consumers fetch them)
-    if (g_lmask < 0) {
-        const char* e = getenv("MMIF_DGRAD_LMASK");
-        g_lmask = (e != nullptr && e[0] == '0') ? 0 : 1;
-    }
-    const bool lmask = dgrad && g_lmask == 1 && mask_bits != 0 && cdiv(tin.cb, CHUNK_CB) >= 2;
+    // dgrad with ReLU masks and >= 2 chunks per tile: the loader waves stage the mask bits (-15 % on the dgrads against consumers fetching them)
+    const bool lmask = dgrad && mask_bits != 0 && cdiv(tin.cb, CHUNK_CB) >= 2;
 #define DMA_GO(D_, L_, ORG_)                                                                                                                  \
     hipLaunchKernelGGL((conv_dma_kernel<D_, L_>), dim3(G), dim3((D_CONS + D_LOAD) * 64), 0, st, tin, tout, tmask, (const uint4*)wpk, bias, n_out, \
-                       m16p, relu, (unsigned long long)mask_bits, (unsigned long long)accum_bits, tiles_x, tiles_y, nmb, g_trace, g_abl, ORG_, sgn)
-    if (dgrad && lmask && sgn.p != nullptr) DMA_GO(true, 2, org);
+                       m16p, relu, (unsigned long long)mask_bits, (unsigned long long)accum_bits, tiles_x, tiles_y, nmb, g_trace, g_abl, ORG_, sgn, dupv)
+    if (dgrad && dupv.frag >= 0) {
+        hipLaunchKernelGGL((conv_dma_kernel<true, 0, true>), dim3(G), dim3((D_CONS + D_LOAD) * 64), 0, st, tin, tout, tmask, (const uint4*)wpk, bias, n_out,
+                           m16p, relu, 0ull, 0ull, tiles_x, tiles_y, nmb, g_trace, g_abl, org, sgn, dupv);
+    } else if (dgrad && lmask && sgn.p != nullptr) DMA_GO(true, 2, org);
     else if (dgrad && lmask) DMA_GO(true, 1, org);
     else if (dgrad) DMA_GO(true, 0, org);
     else DMA_GO(false, 0, 0);
@@ -2422,9 +2465,9 @@ static int launch_conv_dma(bool dgrad, const TV& tin, const TV& tout, const TV& 
 // the 64 -> 32 forward's geometry (thin_conv_async_kernel: two consumer groups, three tight slots of 324-granule planes)
 constexpr int TNW_GROUPS = 2, TNW_PL = 324, TNW_MAXCB = 8, TNW_MAXP = (TNW_MAXCB * TNW_PL + 63) / 64 / TN_LOAD + 1;   // 41 pieces -> 11 per loader
 constexpr int TNW_RING = 3 * ((TNW_MAXCB * TNW_PL + 63) / 64) * 1024;                                                  // 125 952 B
-static int g_thin_wide = -1;   // $MMIF_THIN_WIDE=0: decode.2's forward stays on the register-staged kernel (A/B; bit-identical results)
+static int g_thin_wide = -1;   // mmif_debug_set_thin_wide(0): decode.2's forward stays on the register-staged kernel (the tests' cross-check; bit-identical results)
 static bool thin_wide_ok(bool dgrad, int ks, int mf, const TV& tin, const TV& tout) {
-    if (g_thin_wide < 0) { const char* e = getenv("MMIF_THIN_WIDE"); g_thin_wide = (e != nullptr && e[0] == '0') ? 0 : 1; }
+    if (g_thin_wide < 0) g_thin_wide = 1;
     if (!(g_thin_wide == 1 && g_dma_mode == 1 && !dgrad && ks == 3 && mf == 2 && tin.cb > TN_MAXCB && tin.cb <= TNW_MAXCB && tin.plane * 16 * TNW_MAXCB < (1ll << 31)))
         return false;
     const long long ntiles = (long long)cdiv(tout.ws, MT) * cdiv(tout.hs, MT) * tout.n;
@@ -2532,6 +2575,20 @@ int conv_mfma(bool dgrad, int ks, const TV& tin, const TV& tout, const TV& tmask
 #undef GO
 }
 
+// dgrad (folded, nothing masked or accumulated on its own output) + the two masked copies of fragment `frag` (struct DupOut): the DMA-staged
+// kernel only -- wide layers (>= 49 input channels), 3x3, the in-tile reflect fold, gy a folded halo-1 gradient
+bool conv_dgrad_dup_supported(int ks, int cin, const TV& tin, const TV& tout) {
+    init_modes();
+    return g_dma_mode == 1 && g_fuse_fold == 1 && ks == 3 && pick_mf(cin) == 4 && tin.halo == 1 && tin.folded && tout.halo == 1 && tout.h >= 4 &&
+           tout.w >= 4 && tin.plane * 16 * CHUNK_CB < (1ll << 31);
+}
+int conv_dgrad_dup(const TV& tin, const TV& tout, const void* wpk, int cin, int cout, const TV& tdup, const TV& tmask, int frag, hipStream_t st) {
+    (void)cout;
+    DupOut d;
+    d.out = tdup; d.mask = tmask; d.frag = frag;
+    return launch_conv_dma(true, tin, tout, tout, wpk, nullptr, cin, 0, 0, 0, 1, st, SignMap{nullptr, 0, 0, 0}, &d);
+}
+
 static inline int pick_mfw(int cout) { return cout <= 16 ? 1 : (cout <= 32 ? 2 : 4); }
 
 // tile groups per (icg, ocg) pair of the register-staged wgrad.  The grid is G * nb persistent blocks; it must fit the resident
@@ -2569,7 +2626,6 @@ bool wgrad_taprow_supported(int ks, int cin, int cout);
 size_t wgrad_taprow_workspace(int cin, int cout);
 int wgrad_taprow(const TV& tx, const TV& tg, float* dw, float* db, int cin, int cout, int accumulate, float* ws, hipStream_t st);
 static int g_taprow_mode = -1;   // $MMIF_WGRAD_TAPROW=0: keep the per-input-group kernel (A/B timing)
-static int g_wg1_wide = 1;       // $MMIF_WGRAD1X1_WIDE=0: 1x1 weight gradients on 16-input-channel blocks as before (A/B timing)
 
 size_t wgrad_mfma_workspace(int cin, int cout, int ks) {
     const int mfw = pick_mfw(cout), icf = pick_icf(ks, cin, cout);
@@ -2641,8 +2697,6 @@ int wgrad_mfma(int ks, const TV& tx, const TV& tg, float* dw, float* db, int cin
     if (g_taprow_mode < 0) {
         const char* e = getenv("MMIF_WGRAD_TAPROW");
         g_taprow_mode = (e != nullptr && e[0] == '0') ? 0 : 1;
-        const char* e2 = getenv("MMIF_WGRAD1X1_WIDE");
-        g_wg1_wide = (e2 != nullptr && e2[0] == '0') ? 0 : 1;
     }
     if (g_taprow_mode == 1 && wgrad_taprow_supported(ks, cin, cout) && (tg.halo == 0 || tg.folded) && tx.halo == 0)
         return wgrad_taprow(tx, tg, dw, db, cin, cout, accumulate, ws, st);
@@ -2654,7 +2708,7 @@ int wgrad_mfma(int ks, const TV& tx, const TV& tg, float* dw, float* db, int cin
             case 1: GO(1, 1, 4);
             case 2: GO(1, 2, 2);
             default:
-                switch (g_wg1_wide ? pick_icf(1, cin, cout) : 1) {
+                switch (pick_icf(1, cin, cout)) {
                     case 4: return launch_wgrad_mfma<1, 4, 2, 4>(tx, tg, dw, db, cin, cout, accumulate, ws, st);
                     case 2: return launch_wgrad_mfma<1, 4, 2, 2>(tx, tg, dw, db, cin, cout, accumulate, ws, st);
                     default: GO(1, 4, 2);
@@ -2669,7 +2723,7 @@ int wgrad_mfma(int ks, const TV& tx, const TV& tg, float* dw, float* db, int cin
 using namespace mmif;
 
 extern "C" void mmif_debug_set_trace(void* device_buf) { mmif::g_trace = (long long*)device_buf; }
-// 1 (default; also $MMIF_CONV_DMA) = use the DMA-staged kernels where they apply, 0 = register-staged kernels only
+// 1 (default) = use the DMA-staged kernels where they apply, 0 = register-staged kernels only
 extern "C" void mmif_debug_set_conv_dma(int32_t mode) { mmif::g_dma_mode = mode ? 1 : 0; }
 extern "C" void mmif_debug_set_bwd_pair_dma(int32_t mode) { mmif::debug_set_bwd_pair_dma(mode); }
 extern "C" void mmif_debug_set_thin_wide(int32_t mode) { mmif::g_thin_wide = mode ? 1 : 0; }

@@ -228,7 +228,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_x3_kernel(TV tin, TV tout, TV
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const TileWalk tw = xcd_walk(total_tiles, gridDim.x, blockIdx.x);
-    // timing ablations ($MMIF_X3_ABLATE, results are garbage), each after the first step: 1 no input loads (the first step's data is
+    // timing ablations ($MMIF_ABLATE x3=, results are garbage), each after the first step: 1 no input loads (the first step's data is
     // kept: an all-zero tile clocks ~25 % higher and measures DVFS, not the loads), 2 no weight loads, 4 no split + LDS writes, 8 no
     // MFMAs.  decode.0, 128 -> 128, B = 32: forward (6 products) 2.75 ms, 1: 2.57, 4: 2.62, 5: 2.45, 8: 0.88; dgrad 1.95 / 1.78 / 1.84 /
     // 1.69 / 0.97; wgrad 1.62 / 1.29 / 1.54 / 1.18 / 0.82 -- the weight gradient waits for its tile loads (two half-tile round trips per
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_x3_kernel(TV tin, TV tout, TV
 
     // the next chunk's address arithmetic + loads (~300 instructions) leave the matrix pipe idle for the wave that issues them, and the two
     // waves of a SIMD run in step between the barriers: waves 0 .. NW/2-1 issue BEFORE the chunk's MFMAs, their SIMD partners (wave + NW/2)
-    // between the chunk's two 16-channel k-steps, so that one of the two feeds the pipe meanwhile ($MMIF_X3_ABLATE bit 4: all up front)
+    // between the chunk's two 16-channel k-steps, so that one of the two feeds the pipe meanwhile ($MMIF_ABLATE x3= bit 4: all up front)
     const bool issue_late = KK >= 2 && wave >= NW / 2 && !(abl & 16);
     for (int s = 0; s < nsteps; ++s) {
         if (s + 1 < nsteps && !issue_late) issue(s + 1);
@@ -1448,14 +1448,13 @@ static int launch_conv_x3(bool dgrad, const TV& tin, const TV& tout, const TV& t
                           int relu, uint64_t mask_bits, uint64_t accum_bits, hipStream_t st, const unsigned* signs) {
     const int tiles_x = cdiv(tout.ws, X3_TW), tiles_y = cdiv(tout.hs, RJ * NW);
     const int tpi = tiles_x * tiles_y, total = tpi * tout.n;
-    static int nw4_blocks = -1;   // four-wave blocks per CU (persistent grid): $MMIF_X3_NW4_BLOCKS, default 3 (42 KB of LDS, < 168 VGPRs each)
-    if (nw4_blocks < 0) { const char* e = getenv("MMIF_X3_NW4_BLOCKS"); nw4_blocks = e != nullptr && atoi(e) > 0 ? atoi(e) : 3; }
+    constexpr int nw4_blocks = 3;   // four-wave blocks per CU (persistent grid): 42 KB of LDS, < 168 VGPRs each (two: half the gain; four: over-subscribed)
     int G = x3_num_cus() * (NW == 4 ? nw4_blocks : 1);
     if (total < G) G = total;
     const int nch = x3_nch(n_in), nmb = x3_nmb(n_out);
     constexpr int X3_THREADS = 64 * NW;
     static int abl = -1;
-    if (abl < 0) abl = ablate_env("MMIF_X3_ABLATE");
+    if (abl < 0) abl = ablate_env("x3");
     relu = (relu & 255) | (abl << 8);
     if (dgrad)
         hipLaunchKernelGGL((conv_x3_kernel<MB, true, NP, NW, RJ, KS, false, M16>), dim3(G), dim3(X3_THREADS), 0, st, tin, tout, tmask, (const uint4*)wpk, bias, n_out, nch, nmb,
@@ -1486,20 +1485,15 @@ int conv_x3(bool dgrad, const TV& tin, const TV& tout, const TV& tmask, const vo
         return six ? launch_conv_x3<2, 3, 8, 2>(false, X3_ARGS) : launch_conv_x3<2, 2, 8, 2>(dgrad, X3_ARGS);
     }
     // <= 32 output channels: one 32-channel accumulator tile per pixel row, so a wave takes FOUR rows (32 x 32 pixel tiles) in the
-    // 3-piece forward: the same 216 MFMAs per wave and barrier as the 64-channel kernels for half the weight staging ($MMIF_X3_RJ4=0: two)
-    static int rj4 = -1;
-    if (rj4 < 0) { const char* e = getenv("MMIF_X3_RJ4"); rj4 = (e != nullptr && e[0] == '0') ? 0 : 1; }
+    // 3-piece forward: the same 216 MFMAs per wave and barrier as the 64-channel kernels for half the weight staging
+    constexpr int rj4 = 1;
     // thin layers (<= 32 out, <= 64 in: the DenseBlock convs and the decoder's tail) have almost no MFMA work per tile and run at the
     // latency of ONE tile's loads per block: four-wave blocks (8-row tiles, 16-channel chunks, 42 KB of LDS, 146 VGPRs) put THREE
     // independent blocks on a CU: forward 16->16 102 -> 77 us, 32->16 161 -> 144, 48->16 258 -> 212, 64->32 348 -> 324; dgrad 16->16
     // 160 -> 123, 32->16 204 -> 175 (two blocks: half of that; four: over-subscribed, slower; the 64-out-channel kernels on four-wave
-    // blocks: +-0).  $MMIF_X3_THIN_NW4=0: the eight-wave kernel
-    static int thin4 = -1;
-    if (thin4 < 0) { const char* e = getenv("MMIF_X3_THIN_NW4"); thin4 = (e != nullptr && e[0] == '0') ? 0 : 1; }
-    if (thin4 && n_in <= 64 && !six) {
-        static int m16 = -1;   // $MMIF_X3_M16=0: <= 16 output channels on the 32-wide tiles too
-        if (m16 < 0) { const char* e = getenv("MMIF_X3_M16"); m16 = (e != nullptr && e[0] == '0') ? 0 : 1; }
-        if (m16 && n_out <= 16) {
+    // blocks: +-0)
+    if (n_in <= 64 && !six) {
+        if (n_out <= 16) {      // <= 16 output channels: 16 x 16 x 32 MFMAs, K = two taps x 16 channels (no padded half tile)
             if (h16) return launch_conv_x3<1, 2, 4, 2, 3, true, true>(false, X3_ARGS);
             return launch_conv_x3<1, 2, 4, 2, 3, false, true>(dgrad, X3_ARGS);
         }
@@ -1560,9 +1554,7 @@ int wgrad_x3(const TV& tx, const TV& tg, float* dw, float* db, int cin, int cout
         return check_launch("wgrad_x3_reduce");
     }
     const bool thin = cin <= 48 && cout <= 16;
-    static int thin4 = -1;   // $MMIF_X3_THIN_WGRAD=0: thin layers on wgrad_x3_kernel<16, 6, 2>
-    if (thin4 < 0) { const char* e = getenv("MMIF_X3_THIN_WGRAD"); thin4 = (e != nullptr && e[0] == '0') ? 0 : 1; }
-    if (thin && thin4) {
+    if (thin) {
         const int tiles_x = cdiv(tx.w, XT_TW), tiles_y = cdiv(tx.h, XT_TH);
         const int tpi = tiles_x * tiles_y, total = tpi * tx.n;
         int G = x3_num_cus() * (cin <= 16 ? 5 : (cin <= 32 ? 4 : 3));   // blocks per CU: what the registers (92 / 128 / 168) and the LDS (20 / 32 / 44 KB) allow
@@ -1586,7 +1578,7 @@ int wgrad_x3(const TV& tx, const TV& tg, float* dw, float* db, int cin, int cout
     int G = wgrad_x3_G(cin, cout);
     if (total < G) G = total;
     static int abl = -1;
-    if (abl < 0) abl = ablate_env("MMIF_X3_ABLATE");
+    if (abl < 0) abl = ablate_env("x3");
     const int tx_abl = tiles_x | (abl << 16);
 #define XW_LAUNCH(...) hipLaunchKernelGGL((wgrad_x3_kernel<__VA_ARGS__>), dim3(G * n_icg * n_ocg), dim3(XW_THREADS), 0, st, tx, tg, ws, cin, cout, tx_abl, tpi, total, G, n_icg, n_ocg, signs)
     if (thin) { if (signs != nullptr) XW_LAUNCH(16, 6, 2, 3, true); else XW_LAUNCH(16, 6, 2, 3); }

@@ -51,7 +51,7 @@ struct ChainArgs {
     int n, h, w;
     int nstrips, nseg, seg_rows;
     int items;                 // per branch: n * nseg * nstrips
-    int abl;                   // timing ablations ($MMIF_EC_ABLATE, results are garbage): 1 no operand requests after the first two, 2 no
+    int abl;                   // timing ablations ($MMIF_ABLATE ec=, results are garbage): 1 no operand requests after the first two, 2 no
 };                             // output stores, 4 no k-loops
 
 template <int N> struct ECI { static constexpr int value = N; };
@@ -372,7 +372,7 @@ extern "C" int mmif_dense_encoder_chain(const mmif_dense_chain* ca, const mmif_d
     ec_geometry(A.n, A.h, A.w, nb, A.nstrips, A.nseg, A.seg_rows);
     A.items = A.n * A.nseg * A.nstrips;
     static int abl = -1;
-    if (abl < 0) abl = ablate_env("MMIF_EC_ABLATE");
+    if (abl < 0) abl = ablate_env("ec");
     A.abl = abl;
     hipLaunchKernelGGL(enc_chain_bwd_kernel, dim3(cdiv(A.items, EC_WAVES), nb), dim3(EC_WAVES * 64), 0, (hipStream_t)stream, A);
     return check_launch("dense_encoder_chain");

@@ -494,10 +494,8 @@ static void e2_geometry(int n, int h, int w, int nb, int& nstrips, int& nseg, in
     nseg = (h + seg_rows - 1) / seg_rows;   // drop empty trailing segments
 }
 
-static int g_es2 = -1;      // $MMIF_ENC_STREAM2: 0 = the round-2 kernel, 1 = 64-pixel strips (four waves per CU), 2 (default) = 32-pixel strips (eight)
-static void e2_init() {
-    if (g_es2 < 0) { const char* e = getenv("MMIF_ENC_STREAM2"); g_es2 = e != nullptr ? atoi(e) : 2; if (g_es2 < 0 || g_es2 > 2) g_es2 = 2; }
-}
+static int g_es2 = 2;       // mmif_debug_set_enc_stream2: 0 = the round-2 kernel, 1 = 64-pixel strips (four waves per CU), 2 (default) = 32-pixel strips (eight)
+static void e2_init() {}
 // (the size limits of this kernel -- 32-bit lane offsets with bit 31 = masked lane -- are part of the predicate: a frame beyond them takes the
 // round-2 kernel, which allows 4 GiB per image, instead of failing: ADVICE r5)
 bool enc_stream2_ok(const EncArgs& A, int nb) {

@@ -102,6 +102,8 @@ SIGNATURES = {
     "mmif_bn_bwd_sums": (_i32, [_vp] * 7 + [_i32, _i32, _i64, _i32, _f32, _vp, _sz, _vp]),
     "mmif_bn_apply_bwd": (_i32, [_vp] * 8 + [_i32, _i32, _i64, _i32, _f32, _vp]),
     "mmif_dense_encoder_fwd": (_i32, [C.POINTER(MmifDenseEncoder), _TP, C.POINTER(MmifDenseEncoder), _TP, _vp]),
+    "mmif_conv2d_dgrad_dup_supported": (_i32, [_TP, _TP, _i32, _i32, _i32]),
+    "mmif_conv2d_reflect_dgrad_folded_dup": (_i32, [_TP, _vp, _TP, _i32, _i32, _i32, _TP, _TP, _i32, _vp]),
     "mmif_dense_encoder_bwd_fits": (_i32, [_i32, _i32, _i32, _i32]),
     "mmif_dense_encoder_fwd_sum_supported": (_i32, [C.POINTER(MmifDenseEncoder), C.POINTER(MmifDenseEncoder), _i32, _i32, _i32]),
     "mmif_dense_encoder_fwd_sum": (_i32, [C.POINTER(MmifDenseEncoder), _TP, C.POINTER(MmifDenseEncoder), _TP, _TP, _vp]),

@@ -482,39 +482,6 @@ class ModelEngine:
         T.image_out_dgrad(gout, yout, last.w.detach(), x, g, last.cin, last.k, all_bits(g.cb), 0)
         return g.fold_halo_() if last.k > 1 else g.as_folded()
 
-    # ---- intra-step overlap ($MMIF_OVERLAP=1; round 5) ------------------------------------------------
-    # decode.0's weight gradient (matrix-pipe / power bound, off the critical path: nothing downstream reads dW) runs on a SECOND stream
-    # with a reduced persistent grid ($MMIF_OVERLAP_BLOCKS of the 256 CU slots) while the encoder's backward (LDS-issue / HBM bound)
-    # takes the rest of the chip on the main stream; the streams fork after decode.0's input gradient and join at the end of the backward.
-    # Inside a hipGraph capture the fork / join become parallel branches of the graph.  Measured in profiles/r05_overlap.txt.
-    def overlap_ok(self, s, dtype, impl, x, gx):
-        return (switch("MMIF_OVERLAP", "0") and dtype == torch.bfloat16 and impl != _lib.IMPL_VALU and not s.split and s.packed is not None
-                and x.halo == 0 and gx.halo == 1 and x.h >= 4 and x.w >= 4 and T.bwd_wide_supported(s.cin, s.cout, s.k))
-
-    def fork_wgrad(self, s, x, g, impl):
-        cur = torch.cuda.current_stream()
-        side = getattr(self, "_side", None)
-        if side is None or side.device != cur.device:
-            side = self._side = torch.cuda.Stream(device=cur.device)
-        need = T.wgrad_workspace_bytes(s.cin, s.cout, s.k)
-        ws2 = getattr(self, "_ws_side", None)
-        if ws2 is None or ws2.device != x.buf.device or ws2.numel() * 4 < need:
-            ws2 = self._ws_side = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.buf.device)
-        side.wait_stream(cur)
-        _lib.lib.mmif_debug_set_wgrad_dma_blocks(switch_int("MMIF_OVERLAP_BLOCKS", 192))
-        try:
-            with torch.cuda.stream(side):
-                self.c_wgrad(s, x, g, ws2, impl)
-        finally:
-            _lib.lib.mmif_debug_set_wgrad_dma_blocks(256)
-        self._forked = side
-
-    def join_side(self):
-        side = getattr(self, "_forked", None)
-        if side is not None:
-            torch.cuda.current_stream().wait_stream(side)
-            self._forked = None
-
     def forward(self, img1, img2):
         raise NotImplementedError
 
@@ -770,7 +737,7 @@ class PFNetv1Engine(ModelEngine, DenseEncoderMixin):
         x = acts[-1]
         # the decoder's weight-gradient reduces as ONE launch at the end of the decoder's backward (not with the side-stream experiment: its
         # producer runs on another stream)
-        deferred = dtype == torch.bfloat16 and not switch("MMIF_OVERLAP", "0") and self.defer_reduces(dev, self.dec)
+        deferred = dtype == torch.bfloat16 and self.defer_reduces(dev, self.dec)
         try:      # (a failing launch must not leave the library's deferred-reduce queue open: ADVICE r5)
             g = self.buf(L, f"G{len(acts) - 1}", n, last.cin, h, w, dtype, dev, halo=1)
             g = self.image_layer_bwd(last, x, gout, L.out, g, ws)
@@ -783,12 +750,6 @@ class PFNetv1Engine(ModelEngine, DenseEncoderMixin):
                 # gradient w.r.t. the concatenated encoder features (i == 0): only each encoder's last DenseBlock output
                 # (blocks 6,7 / 14,15) has no further contributor
                 mb = all_bits(gx.cb) if i > 0 else bits(6, 7, 14, 15)
-                if i == 0 and self.overlap_ok(s, dtype, impl, x, gx):
-                    # the input gradient first (its mask: the activations themselves, 32 of the 128 channels), the weight gradient on the side stream
-                    gin = g
-                    g = self.c_dgrad(s, gin, x, gx, mb, 0, impl)
-                    self.fork_wgrad(s, x, gin, impl)
-                    continue
                 if self.wide_ok(s, dtype, impl, x, gx):
                     g = self.c_bwd_wide(s, g, x, gx, mb, ws)  # wide layer: the wgrad leaves the ReLU sign bytes the dgrad masks with
                     continue
@@ -797,13 +758,8 @@ class PFNetv1Engine(ModelEngine, DenseEncoderMixin):
         finally:
             if deferred:
                 self.flush_reduces()
-        forked = getattr(self, "_forked", None) is not None
-        if not forked:
-            self.early_reduce(flat, self.dec)      # (data parallel) the decoder's gradients leave while the encoder's backward runs
+        self.early_reduce(flat, self.dec)      # (data parallel) the decoder's gradients leave while the encoder's backward runs
         self.enc_bwd_all(img1, img2, F, g, ws, impl)
-        if forked:
-            self.join_side()
-            self.early_reduce(flat, self.dec)
         return grads
 
     def enc_bwd_all(self, img1, img2, F, g, ws, impl):
@@ -890,7 +846,7 @@ class DenseFuseEngine(ModelEngine, DenseEncoderMixin):
         x = acts[-1]
         # the decoder's weight-gradient reduces as ONE launch at the end of the decoder's backward (not with the side-stream experiment: its
         # producer runs on another stream)
-        deferred = dtype == torch.bfloat16 and not switch("MMIF_OVERLAP", "0") and self.defer_reduces(dev, self.dec)
+        deferred = dtype == torch.bfloat16 and self.defer_reduces(dev, self.dec)
         try:
             g = self.buf(L, f"G{len(acts) - 1}", n, last.cin, h, w, dtype, dev, halo=1)
             g = self.image_layer_bwd(last, x, gout, L.out, g, ws)
@@ -903,10 +859,13 @@ class DenseFuseEngine(ModelEngine, DenseEncoderMixin):
                 # i == 0: the auto-encoder's input is the DenseBlock output (only its last conv, blocks 6,7, has no further contributor);
                 # x = f1 + f2 is not a ReLU output
                 mb = all_bits(gx.cb) if i > 0 else (bits(6, 7) if single else 0)
-                if i == 0 and not single and self.overlap_ok(s, dtype, impl, x, gx):
-                    gin = g
-                    g = self.c_dgrad(s, gin, x, gx, mb, 0, impl)
-                    self.fork_wgrad(s, x, gin, impl)
+                if i == 0 and not single and self.dup_ok(s, g, gx, L, dtype, impl):
+                    # 'sum' fusion: decode.0's dgrad also leaves the copies of its blocks 6, 7 that each encoder branch masks with its own x3
+                    # (csrc/conv_mfma.hip struct DupOut, round 6: mmif_fuse_elem_bwd's launch disappears); the weight gradient apart
+                    GF = self.buf(L, "GF", n, 128, h, w, dtype, dev, halo=1)
+                    self.c_wgrad(s, x, g, ws, impl)
+                    g = T.conv_dgrad_dup(g, gx, s.cin, s.cout, s.k, s.packed, GF, F, 3, s.name + ":dgrad")
+                    L.dup_done = True
                     continue
                 if self.wide_ok(s, dtype, impl, x, gx):
                     g = self.c_bwd_wide(s, g, x, gx, mb, ws)
@@ -916,12 +875,6 @@ class DenseFuseEngine(ModelEngine, DenseEncoderMixin):
         finally:
             if deferred:
                 self.flush_reduces()
-        if getattr(self, "_forked", None) is not None:
-            try:
-                return self._encoder_backward(L, F, g, ws, impl, dtype, dev, n, h, w, single, img1, img2, grads)
-            finally:
-                self.join_side()
-                self.early_reduce(flat, self.dec)
         self.early_reduce(flat, self.dec)
         return self._encoder_backward(L, F, g, ws, impl, dtype, dev, n, h, w, single, img1, img2, grads)
 
@@ -938,7 +891,9 @@ class DenseFuseEngine(ModelEngine, DenseEncoderMixin):
         if self.share_fused_grad(g, GF, dtype, impl):
             # 'sum' fusion: d(f1 + f2) IS each branch's gradient.  Only the masked top blocks (6,7 / 14,15) are materialised per branch;
             # the chain reads the lower blocks' starting values straight from g ($MMIF_FUSE_SHARE=0: copy them per branch first)
-            T.fuse_elem_bwd(F.view(6, 2), F.view(14, 2), g.view(6, 2), GF.view(6, 2), GF.view(14, 2), self.fusion_mode, True)
+            if not getattr(L, "dup_done", False):     # (decode.0's dgrad left them already: dup_ok)
+                T.fuse_elem_bwd(F.view(6, 2), F.view(14, 2), g.view(6, 2), GF.view(6, 2), GF.view(14, 2), self.fusion_mode, True)
+            L.dup_done = False
             gff = GF.as_folded()
             if self.bwd_fused([(self.enc, img1, 0, gff.view(6, 2), g.view(0, 6), False), (self.enc, img2, 8, gff.view(14, 2), g.view(0, 6), True)], F, ws, impl):
                 return grads
@@ -966,6 +921,15 @@ class DenseFuseEngine(ModelEngine, DenseEncoderMixin):
         br = [(img, specs[0].w.detach(), specs[0].b.detach(), [s.packed for s in specs[1:]], [s.b.detach() for s in specs[1:]], F.view(base, 8))
               for img, base in ((img1, 0), (img2, 8))]
         return T.dense_encoder_fwd_sum(br, S, tag="encode:fwd")
+
+    def dup_ok(self, s, gy, gx, L, dtype, impl):
+        """decode.0's input gradient also writes the two masked copies of its top blocks ($MMIF_DGRAD_DUP=0: mmif_fuse_elem_bwd does)"""
+        if not (switch("MMIF_DGRAD_DUP") and dtype == torch.bfloat16 and impl != _lib.IMPL_VALU and s.packed is not None and not s.split
+                and (s.cin, s.k) == (64, 3) and T.conv_dgrad_dup_supported(gy, gx, s.cin, s.cout, s.k)):
+            return False
+        n, h, w = gx.n, gx.h, gx.w
+        GF = self.buf(L, "GF", n, 128, h, w, dtype, gx.buf.device, halo=1)
+        return self.share_fused_grad(gx, GF, dtype, impl)
 
     def share_fused_grad(self, g, GF, dtype, impl):
         specs = self.enc

@@ -184,6 +184,19 @@ def dgrad_onto_supported(gy, gx, cin, cout, k):
     return bool(lib.mmif_conv2d_dgrad_onto_supported(gy.d, gx.d, cin, cout, k))
 
 
+def conv_dgrad_dup_supported(gy, gx, cin, cout, k):
+    return bool(lib.mmif_conv2d_dgrad_dup_supported(gy.d, gx.d, cin, cout, k))
+
+
+def conv_dgrad_dup(gy, gx, cin, cout, k, packed, dup_out, dup_mask, frag, tag=None):
+    """folded dgrad (nothing masked / accumulated) + the two masked copies of fragment `frag` in dup_out (csrc/conv_mfma.hip struct DupOut);
+    returns gx as a folded view"""
+    with _timed(tag):
+        check(lib.mmif_conv2d_reflect_dgrad_folded_dup(gy.d, _image(packed, "dgrad", gy.code), gx.d, cin, cout, k, dup_out.d, dup_mask.d, frag,
+                                                       stream_ptr()), "conv_dgrad_dup")
+    return gx.as_folded()
+
+
 def conv_dgrad_onto(gy, x, gx_old, gx, cin, cout, k, mask_bits, accum_bits, packed, tag=None):
     """gx = [mask](fold(dgrad(gy)) + gx_old) on the blocks in accum_bits: the accumulate operand comes from another tensor; returns the
     folded gx view (gx's halo ring must be zero on entry)"""

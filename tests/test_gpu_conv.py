@@ -304,3 +304,35 @@ def test_thin_wide_forward_equals_register_staged_kernel(cin, cout, n, h, w):
     if n * h * w <= 2 * 256 * 256:
         want = O.conv2d_reflect_fwd(bf16_round(xn.numpy()), bf16_round(wt.cpu().numpy()), b.cpu().numpy(), True)
         close(res[1][1], bf16_round(want), 6e-3, "y vs oracle")
+
+
+@pytest.mark.parametrize("n,h,w", [(1, 40, 56), (2, 37, 53), (1, 4, 4), (2, 128, 96), (1, 33, 250)], ids=lambda v: str(v))
+def test_dgrad_with_masked_copies_equals_dgrad_plus_fuse_elem_bwd(n, h, w):
+    """Round 6 (DenseFuse, reference core/model.py:165-186): mmif_conv2d_reflect_dgrad_folded_dup -- decode.0's input gradient (64 -> 64, nothing
+    masked on its own output) also leaves blocks 6, 7 masked by x3 of encoder branch a (blocks 6, 7 of F) and by x3 of branch b (blocks 14, 15)
+    in GF.  Against mmif_conv2d_reflect_dgrad_folded + mmif_fuse_elem_bwd(sum, relu mask): bit for bit; the other blocks of GF and its ring
+    untouched."""
+    from mmif import tensor as T
+    from mmif._lib import FUSE_SUM, IMPL_MFMA
+    dev = "cuda:0"
+    torch.manual_seed(h * 3 + w)
+    cin = cout = 64
+    gy = T.BT.alloc(n, cout, h, w, torch.bfloat16, dev, halo=1, zero=True); gy.buf[:, :, 1:-1, 1:-1].normal_()
+    gy = gy.as_folded()
+    F = T.BT.alloc(n, 128, h, w, torch.bfloat16, dev); F.buf.normal_()       # [x(img1) | x(img2)]: about half of the values > 0
+    wt = torch.randn(cout, cin, 3, 3, device=dev) * 0.05
+    pk = T.PackedWeights(cout, cin, 3, dev); pk.pack(wt)
+    gx_a = T.BT.alloc(n, cin, h, w, torch.bfloat16, dev, halo=1, zero=True)
+    gx_b = T.BT.alloc(n, cin, h, w, torch.bfloat16, dev, halo=1, zero=True)
+    GF_a = T.BT.alloc(n, 128, h, w, torch.bfloat16, dev, halo=1, zero=True)
+    GF_b = T.BT.alloc(n, 128, h, w, torch.bfloat16, dev, halo=1, zero=True)
+    assert T.conv_dgrad_dup_supported(gy, gx_b, cin, cout, 3) == (h >= 4 and w >= 4)
+    ga = T.conv_dgrad(gy, wt, None, gx_a, cin, cout, 3, 0, 0, pk, IMPL_MFMA, fold=True)
+    T.fuse_elem_bwd(F.view(6, 2), F.view(14, 2), ga.view(6, 2), GF_a.view(6, 2), GF_a.view(14, 2), FUSE_SUM, True)
+    gb = T.conv_dgrad_dup(gy, gx_b, cin, cout, 3, pk, GF_b, F, 3)
+    torch.cuda.synchronize()
+    assert torch.equal(gx_a.buf, gx_b.buf), "the dgrad's own output differs"
+    assert torch.equal(GF_a.buf, GF_b.buf), "the masked copies differ"
+    assert float(GF_b.buf[:, 6:8].float().abs().max()) > 0 and float(GF_b.buf[:, 14:16].float().abs().max()) > 0
+    assert float(GF_b.buf[:, :6].float().abs().max()) == 0 and float(GF_b.buf[:, 8:14].float().abs().max()) == 0
+    assert gb.flags == ga.flags

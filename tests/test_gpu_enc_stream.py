@@ -322,8 +322,10 @@ def test_shared_encoder_plus_sum_in_one_launch(n, h, w):
             assert bool((guard.float() == 7.0).all()), "a guard block was written"
 
 
-def test_densefuse_step_with_and_without_the_fused_sum(monkeypatch):
-    """DenseFuse train step (bf16), $MMIF_ENC_SUM = 1 / 0: bit-identical fused image, losses and gradients (the same values reach the decoder)"""
+@pytest.mark.parametrize("var", ["MMIF_ENC_SUM", "MMIF_DGRAD_DUP"])
+def test_densefuse_step_with_and_without_the_fused_sum(monkeypatch, var):
+    """DenseFuse train step (bf16), $MMIF_ENC_SUM = 1 / 0 (the sum inside the encoder launch) and $MMIF_DGRAD_DUP = 1 / 0 (the masked copies of
+    decode.0's input gradient inside its dgrad): bit-identical fused image, losses and gradients"""
     import core.model as M
     from core.loss import FusionLoss, GradLoss, PixelLoss, SSIMLoss, unit_gradient
     from gpu_util import reload_switches
@@ -331,7 +333,7 @@ def test_densefuse_step_with_and_without_the_fused_sum(monkeypatch):
     a, b = torch.rand(3, 1, 72, 104, generator=g).to(DEV), torch.rand(3, 1, 72, 104, generator=g).to(DEV)
     res = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("MMIF_ENC_SUM", mode)
+        monkeypatch.setenv(var, mode)
         reload_switches()
         with dtype_ctx("bf16"):
             torch.manual_seed(0)
@@ -342,7 +344,7 @@ def test_densefuse_step_with_and_without_the_fused_sum(monkeypatch):
             tot.backward(unit_gradient(tot))
             torch.cuda.synchronize()
             res[mode] = (f.detach().cpu().clone(), tot.detach().item(), {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters()})
-    monkeypatch.delenv("MMIF_ENC_SUM")
+    monkeypatch.delenv(var)
     reload_switches()
     assert torch.equal(res["1"][0], res["0"][0]) and res["1"][1] == res["0"][1]
     for k, g1 in res["1"][2].items():

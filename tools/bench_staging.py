@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """What does the L2 -> LDS staging of conv_dma_kernel cost, and what could sharing it buy?  decode.0 (128 -> 128) and decode.1 (128 -> 64)
-forward / folded dgrad at B = 32, 256 x 256 under $MMIF_CONV_ABLATE (read once per process: run one process per value, tools/sweep_staging.sh):
+forward / folded dgrad at B = 32, 256 x 256 under $MMIF_ABLATE conv= (read once per process: run one process per value, tools/sweep_staging.sh):
   0  the kernel as it ships            2  no WEIGHT pieces on every second item (upper bound of "one weight chunk serves two pixel tiles")
   8  no INPUT pieces on every second item (upper bound of "one input tile serves both M-blocks")   10  both      1  no staging at all
 Results of the ablated runs are garbage; the data stays Gaussian (zeros would measure the clock)."""
@@ -13,7 +13,7 @@ from mmif._lib import IMPL_MFMA
 B, S = 32, 256
 dev = "cuda:0"
 torch.manual_seed(0)
-abl = os.environ.get("MMIF_CONV_ABLATE", "0")
+abl = os.environ.get("MMIF_ABLATE", "0")
 for cin, cout in ((128, 128), (128, 64)):
     x = T.BT.alloc(B, cin, S, S, torch.bfloat16, dev); x.buf.normal_()
     y = T.BT.alloc(B, cout, S, S, torch.bfloat16, dev)

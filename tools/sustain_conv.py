@@ -51,7 +51,7 @@ n = int(t[0, 0, 63]) if t[0, 0, 63] > 0 else 62
 span = t[:, 0, n - 1] - t[:, 0, 0]
 nq = (n - 1) // 5
 tops = t[:, :, [1 + 5 * q for q in range(1, nq)]]
-if int(os.environ.get("MMIF_CONV_ABLATE", "0")) & 256:
+if "conv=256" in os.environ.get("MMIF_ABLATE", ""):
     tp = t[:, :, 1:n]                       # tops of chunks 0, 3, 6, ...
     per = np.median(np.diff(tp, axis=2), axis=0) / 3.0
     print("  chunk period over the launch (ticks, wave 0 / wave 4):")
@@ -59,6 +59,6 @@ if int(os.environ.get("MMIF_CONV_ABLATE", "0")) & 256:
     print("   w4", per[4].round(0))
 whole = np.median(t[:, 0, 62] - t[:, 0, 0])
 print(f"  whole block: {whole:.0f} ticks in {ms:.3f} ms -> shader clock ~{whole / (ms * 1e3):.0f} MHz (only the first {nq} chunks carry stamps)")
-print(f"conv_dma {kind} {cin}->{cout} B={B} {S}^2 data={data} abl={os.environ.get('MMIF_CONV_ABLATE', '0')}: first {first:.3f} ms ({flops / first / 1e9:.0f} TFLOP/s)  "
+print(f"conv_dma {kind} {cin}->{cout} B={B} {S}^2 data={data} abl={os.environ.get("MMIF_ABLATE", "0")}: first {first:.3f} ms ({flops / first / 1e9:.0f} TFLOP/s)  "
       f"after {secs:.0f} s {last:.3f} ms ({flops / last / 1e9:.0f})  traced {ms:.3f} ms, chunk period {np.median(np.diff(tops, axis=2)):.0f} ticks, "
       f"{np.median(span) / (ms * 1e3) * (1.0):.0f} ticks/us x (stamped fraction of the launch)")
