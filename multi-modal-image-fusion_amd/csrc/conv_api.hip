@@ -32,7 +32,7 @@ int bwd_wide(const TV& tx, const TV& tg, const TV& tgx, const void* wpk_dgrad, f
 // conv_x3.hip
 bool conv_x3_supported(bool dgrad, int ks, int cin, int cout, const TV& tin, const TV& tout);
 int conv_x3(bool dgrad, const TV& tin, const TV& tout, const TV& tmask, const void* wpk, const float* bias, int cin, int cout, int relu,
-            uint64_t mask_bits, uint64_t accum_bits, hipStream_t st, int ks, const unsigned* signs = nullptr);
+            uint64_t mask_bits, uint64_t accum_bits, hipStream_t st, int ks, const unsigned* signs = nullptr, bool* folded = nullptr);
 bool wgrad_x3_supported(int ks, int cin, int cout, const TV& tx, const TV& tg);
 size_t wgrad_x3_workspace(int cin, int cout, int ks);
 int wgrad_x3(const TV& tx, const TV& tg, float* dw, float* db, int cin, int cout, int accumulate, float* ws, hipStream_t st, int ks, unsigned* signs = nullptr);
@@ -120,7 +120,7 @@ static int dgrad_impl(const char* what, const mmif_tensor* gy, const float* w, c
         told = make_tv(gx_old);
     }
     if (im == MMIF_IMPL_X3) {
-        rc = conv_x3(true, tg, tgx, tm, w_packed_t, nullptr, cin, cout, 0, mask_bits, accum_bits, (hipStream_t)stream, ksize);
+        rc = conv_x3(true, tg, tgx, tm, w_packed_t, nullptr, cin, cout, 0, mask_bits, accum_bits, (hipStream_t)stream, ksize, nullptr, fold ? &folded : nullptr);
     } else if (im == MMIF_IMPL_MFMA) {
         rc = conv_mfma(true, ksize, tg, tgx, tm, w_packed_t, nullptr, cin, cout, 0, mask_bits, accum_bits, (hipStream_t)stream, fold, &folded,
                        gx_old != nullptr ? &told : nullptr);
@@ -290,8 +290,9 @@ extern "C" int mmif_conv2d_reflect_bwd_wide(const mmif_tensor* gy, const void* w
         if (phase != 2)
             if (int rc = wgrad_x3(tx, tg, dw, db, cin, cout, accumulate, (float*)workspace, (hipStream_t)stream, ksize, (unsigned*)signs)) return rc;
         if (phase == 1) return MMIF_OK;
-        if (int rc = conv_x3(true, tg, tgx, tx, w_packed_t, nullptr, cin, cout, 0, mask_bits, 0, (hipStream_t)stream, ksize, (const unsigned*)signs)) return rc;
-        return ksize == 1 ? MMIF_OK : mmif_fold_halo(gx, stream);
+        bool folded = false;
+        if (int rc = conv_x3(true, tg, tgx, tx, w_packed_t, nullptr, cin, cout, 0, mask_bits, 0, (hipStream_t)stream, ksize, (const unsigned*)signs, &folded)) return rc;
+        return (ksize == 1 || folded) ? MMIF_OK : mmif_fold_halo(gx, stream);
     }
     MMIF_REQUIRE(bwd_wide_supported(ksize, cin, cout), "conv2d_reflect_bwd_wide: unsupported layer %d -> %d k%d", cin, cout, ksize);
     MMIF_REQUIRE(w_packed_t != nullptr && dw != nullptr, "conv2d_reflect_bwd_wide: NULL operand image / dw");

@@ -206,7 +206,12 @@ template <int MB, bool DGRAD, int NP, int NW, int RJ, int KS, bool F16 = false, 
 __global__ __launch_bounds__(64 * NW, 2) void conv_x3_kernel(TV tin, TV tout, TV tmask, const uint4* __restrict__ wpk,
                                                               const float* __restrict__ bias, int n_out, int nch16, int nmb, int relu,
                                                               unsigned long long mask_bits, unsigned long long accum_bits, int tiles_x,
-                                                              int tiles_per_img, int total_tiles, const unsigned* __restrict__ signs) {
+                                                              int tiles_per_img, int total_tiles, const unsigned* __restrict__ signs, int org) {
+    // org = 1 (round 6; 3x3 dgrads of the 32-wide-tile kernels): the tiles cover the INTERIOR of the halo-1 output only and the reflect-padding
+    // adjoint is applied inside the tiles that own its targets, as conv_dma_kernel does (dgrad_fold_steps in conv_mfma.hip): in stored
+    // coordinates the ring row 0 is  sum_v A(2, v) G[1][X - 1 + v]  = the fragments output row 2 reads for its taps (0, v) times the weights
+    // of taps (2, v), and so on -- extra MFMAs for one row of one wave (rows) or with every lane but the target's zeroed (columns, corners).
+    // The padded 258 x 258 domain of a 256 x 256 image cost 9 x 17 tiles of 32 x 16 for the interior's 8 x 16, and a fold launch per tensor.
     constexpr int MBW = 32 * MB;
     constexpr int TAPS = KS * KS, PD = KS / 2;    // KS = 1: the same kernel without halo and with one tap (HBM-bound: NestFuse's 1x1 layers)
     constexpr int WG = TAPS * 2 * MBW;            // weight granules of one piece of a 16-channel sub-chunk
@@ -265,7 +270,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_x3_kernel(TV tin, TV tout, TV
         const int tile = tw.first + ti * tw.stride;
         const int in_ = tile / tiles_per_img, tt = tile - in_ * tiles_per_img;
         const int ys0 = (tt / tiles_x) * X3_TH, xs0 = (tt % tiles_x) * X3_TW;
-        const int iy0 = ys0 - tout.halo - PD, ix0 = xs0 - tout.halo - PD;   // logical origin of the input tile
+        const int iy0 = ys0 + org - tout.halo - PD, ix0 = xs0 + org - tout.halo - PD;   // logical origin of the input tile
         const char* base = tin.base + ((long long)in_ * tin.img + (long long)(tin.cb_off + c * CKB) * tin.plane) * 32;
         const int ncb = tin.cb - c * CKB;                                   // channel blocks this chunk really has
 #pragma unroll
@@ -494,6 +499,91 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_x3_kernel(TV tin, TV tout, TV
                     }
                     for (int i = nld; i < NPROD * RJ * MB; ++i) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 }
+                if constexpr (DGRAD && KS == 3 && RJ <= 2) {
+                    if (org) {
+                        // ---- reflect-padding adjoint of this sub-chunk (see the kernel's head): the tile of this step
+                        const int ti_f = s / per_tile, tile_f = tw.first + ti_f * tw.stride;
+                        const int tt_f = tile_f % tiles_per_img;
+                        const int yw = (tt_f / tiles_x) * X3_TH + 1 + RJ * wave, xl0 = (tt_f % tiles_x) * X3_TW + 1;   // stored row of j = 0 / column of lane 0
+                        const int jt = 2 - yw, jb = tout.hs - 3 - yw;                // the wave's row that is stored row 2 / hs - 3 (if in 0 .. RJ-1)
+                        const int lt = 2 - xl0, lr = tout.ws - 3 - xl0;              // the lane that is stored column 2 / ws - 3 (if in 0 .. 31)
+                        const bool has_t = jt >= 0 && jt < RJ, has_b = jb >= 0 && jb < RJ, has_l = lt >= 0 && lt < X3_TW, has_r = lr >= 0 && lr < X3_TW;
+                        if (has_t || has_b || has_l || has_r) {
+                            const x3_u4 z4 = {0u, 0u, 0u, 0u};
+                            auto fa = [&](int tap, int m, int p) { return x3_frag(s_w[p * WG + abase + tap * 2 * MBW + m * 32]); };
+                            auto fb = [&](int row, int v, int p, int lsel) {      // window row, column shift; lsel >= 0: that lane's column only
+                                x3_u4 q = s_in[p * ING + bbase + row * X3_IW + v];
+                                if (lsel >= 0 && nl != lsel) q = z4;
+                                return x3_frag(q);
+                            };
+                            auto row_fold = [&](int j, int tap_row, int brow_u) {   // ring row -> output row j: taps (tap_row, v) on the fragments of taps (brow_u, v)
+#pragma unroll
+                                for (int v = 0; v < 3; ++v) {
+                                    x3_bf16x8 b[NP];
+#pragma unroll
+                                    for (int p = 0; p < NP; ++p) b[p] = fb(brow_u + j, v, p, -1);
+#pragma unroll
+                                    for (int m = 0; m < MB; ++m) {
+                                        x3_bf16x8 a[NP];
+#pragma unroll
+                                        for (int p = 0; p < NP; ++p) a[p] = fa(tap_row * 3 + v, m, p);
+#pragma unroll
+                                        for (int q = 0; q < NPROD; ++q) {
+                                            if (j == 0) acc[m][0] = x3_mfma<F16>(a[X3Prod<NP>::A[q]], b[X3Prod<NP>::B[q]], acc[m][0]);
+                                            else acc[m][RJ > 1 ? 1 : 0] = x3_mfma<F16>(a[X3Prod<NP>::A[q]], b[X3Prod<NP>::B[q]], acc[m][RJ > 1 ? 1 : 0]);
+                                        }
+                                    }
+                                }
+                            };
+                            auto col_fold = [&](int tap_col, int b_v, int lsel) {   // ring column -> the lane lsel of every row: taps (u, tap_col) on the fragments of taps (u, b_v)
+#pragma unroll
+                                for (int u = 0; u < 3; ++u)
+#pragma unroll
+                                    for (int j = 0; j < RJ; ++j) {
+                                        x3_bf16x8 b[NP];
+#pragma unroll
+                                        for (int p = 0; p < NP; ++p) b[p] = fb(u + j, b_v, p, lsel);
+#pragma unroll
+                                        for (int m = 0; m < MB; ++m) {
+                                            x3_bf16x8 a[NP];
+#pragma unroll
+                                            for (int p = 0; p < NP; ++p) a[p] = fa(u * 3 + tap_col, m, p);
+#pragma unroll
+                                            for (int q = 0; q < NPROD; ++q) acc[m][j] = x3_mfma<F16>(a[X3Prod<NP>::A[q]], b[X3Prod<NP>::B[q]], acc[m][j]);
+                                        }
+                                    }
+                            };
+                            auto corner = [&](int j, int tap, int brow, int b_v, int lsel) {
+                                x3_bf16x8 b[NP];
+#pragma unroll
+                                for (int p = 0; p < NP; ++p) b[p] = fb(brow, b_v, p, lsel);
+#pragma unroll
+                                for (int m = 0; m < MB; ++m) {
+                                    x3_bf16x8 a[NP];
+#pragma unroll
+                                    for (int p = 0; p < NP; ++p) a[p] = fa(tap, m, p);
+#pragma unroll
+                                    for (int q = 0; q < NPROD; ++q) {
+                                        if (j == 0) acc[m][0] = x3_mfma<F16>(a[X3Prod<NP>::A[q]], b[X3Prod<NP>::B[q]], acc[m][0]);
+                                        else acc[m][RJ > 1 ? 1 : 0] = x3_mfma<F16>(a[X3Prod<NP>::A[q]], b[X3Prod<NP>::B[q]], acc[m][RJ > 1 ? 1 : 0]);
+                                    }
+                                }
+                            };
+                            if (has_t) {   // ring row 0 -> stored row 2: taps (2, v) on G row 1 = the fragments of this row's taps (0, v)
+                                row_fold(jt, 2, 0);
+                                if (has_l) corner(jt, 8, jt + 0, 0, lt);
+                                if (has_r) corner(jt, 6, jt + 0, 2, lr);
+                            }
+                            if (has_b) {   // ring row hs-1 -> stored row hs-3: taps (0, v) on G row hs-2 = the fragments of this row's taps (2, v)
+                                row_fold(jb, 0, 2);
+                                if (has_l) corner(jb, 2, jb + 2, 0, lt);
+                                if (has_r) corner(jb, 0, jb + 2, 2, lr);
+                            }
+                            if (has_l) col_fold(2, 0, lt);   // ring column 0 -> stored column 2: taps (u, 2) on G column 1 = the fragments of taps (u, 0)
+                            if (has_r) col_fold(0, 2, lr);   // ring column ws-1 -> stored column ws-3: taps (u, 0) on the fragments of taps (u, 2)
+                        }
+                    }
+                }
             }
         }
         // ---------------- epilogue after the item's last chunk ----------------
@@ -551,12 +641,12 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_x3_kernel(TV tin, TV tout, TV
             const int mb = (s / nch) % nmb, ti = s / per_tile;
             const int tile = tw.first + ti * tw.stride;
             const int in_ = tile / tiles_per_img, tt = tile - in_ * tiles_per_img;
-            const int ys0 = (tt / tiles_x) * X3_TH, xs0 = (tt % tiles_x) * X3_TW;
+            const int ys0 = (tt / tiles_x) * X3_TH + org, xs0 = (tt % tiles_x) * X3_TW + org;
             const int xs = xs0 + nl, half = lane >> 5;
 #pragma unroll
             for (int j = 0; j < RJ; ++j) {
                 const int ys = ys0 + RJ * wave + j;
-                const bool inside = ys < tout.hs && xs < tout.ws;
+                const bool inside = ys < tout.hs - org && xs < tout.ws - org;
                 const int oy = DGRAD ? min(max(reflect_idx(ys - tout.halo, tmask.h), 0), tmask.h - 1) : 0;
                 const int ox = DGRAD ? min(max(reflect_idx(xs - tout.halo, tmask.w), 0), tmask.w - 1) : 0;
                 const int ysc = min(ys, tout.hs - 1), xsc = min(xs, tout.ws - 1);   // in-range twin of the lane's position: every load below is
@@ -1445,8 +1535,12 @@ int conv_x3_pack_multi(const mmif_pack_job* jobs, int n_jobs, hipStream_t st) {
 
 template <int MB, int NP, int NW, int RJ, int KS = 3, bool F16 = false, bool M16 = false>
 static int launch_conv_x3(bool dgrad, const TV& tin, const TV& tout, const TV& tmask, const void* wpk, const float* bias, int n_out, int n_in,
-                          int relu, uint64_t mask_bits, uint64_t accum_bits, hipStream_t st, const unsigned* signs) {
-    const int tiles_x = cdiv(tout.ws, X3_TW), tiles_y = cdiv(tout.hs, RJ * NW);
+                          int relu, uint64_t mask_bits, uint64_t accum_bits, hipStream_t st, const unsigned* signs, bool* folded = nullptr) {
+    // dgrad, 3x3, the 32 x 32 x 16 tiles, a caller that wants the fold (folded != nullptr) and an output whose fold targets are distinct:
+    // interior tiles + in-tile fold steps (org = 1), the halo ring stays untouched (zero: the caller's contract for a fold-me call)
+    const int org = (dgrad && KS == 3 && !M16 && RJ <= 2 && folded != nullptr && tout.halo == 1 && tout.h >= 4 && tout.w >= 4) ? 1 : 0;
+    if (org) *folded = true;
+    const int tiles_x = cdiv(tout.ws - 2 * org, X3_TW), tiles_y = cdiv(tout.hs - 2 * org, RJ * NW);
     const int tpi = tiles_x * tiles_y, total = tpi * tout.n;
     constexpr int nw4_blocks = 3;   // four-wave blocks per CU (persistent grid): 42 KB of LDS, < 168 VGPRs each (two: half the gain; four: over-subscribed)
     int G = x3_num_cus() * (NW == 4 ? nw4_blocks : 1);
@@ -1458,20 +1552,23 @@ static int launch_conv_x3(bool dgrad, const TV& tin, const TV& tout, const TV& t
     relu = (relu & 255) | (abl << 8);
     if (dgrad)
         hipLaunchKernelGGL((conv_x3_kernel<MB, true, NP, NW, RJ, KS, false, M16>), dim3(G), dim3(X3_THREADS), 0, st, tin, tout, tmask, (const uint4*)wpk, bias, n_out, nch, nmb,
-                           relu, (unsigned long long)mask_bits, (unsigned long long)accum_bits, tiles_x, tpi, total, signs);
+                           relu, (unsigned long long)mask_bits, (unsigned long long)accum_bits, tiles_x, tpi, total, signs, org);
     else
         hipLaunchKernelGGL((conv_x3_kernel<MB, false, NP, NW, RJ, KS, F16, M16>), dim3(G), dim3(X3_THREADS), 0, st, tin, tout, tmask, (const uint4*)wpk, bias, n_out, nch, nmb,
-                           relu, (unsigned long long)mask_bits, (unsigned long long)accum_bits, tiles_x, tpi, total, (const unsigned*)nullptr);
+                           relu, (unsigned long long)mask_bits, (unsigned long long)accum_bits, tiles_x, tpi, total, (const unsigned*)nullptr, 0);
     return check_launch(dgrad ? "conv_x3 dgrad" : "conv_x3 fwd");
 }
 
 // forward: tin = x, tout = y;  dgrad: tin = gy (halo 0 or folded halo 1), tout = gx (the padded domain is written; the caller folds)
+// folded (dgrad): non-NULL = the caller wants fold_halo(gx) applied and guarantees a zero halo ring on entry; *folded says whether the kernel
+// chosen did it (interior tiles + fold steps) -- otherwise the caller runs the fold kernel
 int conv_x3(bool dgrad, const TV& tin, const TV& tout, const TV& tmask, const void* wpk, const float* bias, int cin, int cout, int relu,
-            uint64_t mask_bits, uint64_t accum_bits, hipStream_t st, int ks, const unsigned* signs) {
+            uint64_t mask_bits, uint64_t accum_bits, hipStream_t st, int ks, const unsigned* signs, bool* folded) {
+    if (folded != nullptr) *folded = false;
     const int n_out = dgrad ? cin : cout, n_in = dgrad ? cout : cin;
     const int fmt = dgrad ? 2 : x3_image_format(wpk);
     const bool six = !dgrad && fmt == 3, h16 = !dgrad && fmt == 16;
-#define X3_ARGS tin, tout, tmask, wpk, bias, n_out, n_in, relu, mask_bits, accum_bits, st, signs
+#define X3_ARGS tin, tout, tmask, wpk, bias, n_out, n_in, relu, mask_bits, accum_bits, st, signs, folded
     if (ks == 1) {
         if (x3_mb(n_out) == 2) {
             if (h16) return launch_conv_x3<2, 2, 8, 2, 1, true>(false, X3_ARGS);
