@@ -232,9 +232,9 @@ int mmif_conv2d_reflect_dgrad(const mmif_tensor* gy, const float* w, const void*
                               uint64_t accum_bits, int32_t impl, void* stream);
 /* The same followed by mmif_fold_halo(gx): on return gx's interior is the gradient w.r.t. the unpadded tensor and its halo ring
  * is zero (treat it as MMIF_T_FOLDED).  gx's halo ring must be zero on entry (a fresh zeroed buffer, or the result of an
- * earlier fold), also when accumulating.  The bf16 DMA-staged kernels do the fold inside the border tiles of the dgrad (interior
- * tiles only, no second pass, the halo values are never rounded to bf16); every other case runs dgrad + the fold kernel.
- * ($MMIF_DGRAD_FOLD=0 forces the two-kernel form.) */
+ * earlier fold), also when accumulating.  The bf16 DMA-staged kernels and (round 6) the 32-wide-tile split-operand kernels of fp32 tensors
+ * do the fold inside the border tiles of the dgrad (interior tiles only, no second pass, the halo values are never rounded); every other
+ * case runs dgrad + the fold kernel. */
 int mmif_conv2d_reflect_dgrad_folded(const mmif_tensor* gy, const float* w, const void* w_packed_t, const mmif_tensor* x,
                                      const mmif_tensor* gx, int32_t cin, int32_t cout, int32_t ksize,
                                      uint64_t mask_bits, uint64_t accum_bits, int32_t impl, void* stream);
@@ -531,21 +531,21 @@ int mmif_clip_adam_step(float* params, const float* grads, float* exp_avg, float
 /* ---- diagnostics: device buffer long long[1024][64]; when non-NULL the MFMA conv kernel stamps s_memtime per
  * phase for its first 1024 blocks (tools/trace_conv.py).  NULL (default) disables it. */
 void mmif_debug_set_trace(void* device_buf);
-/* kernel-generation switch for cross-checks: 1 (default, also $MMIF_CONV_DMA) = DMA-staged conv / wgrad kernels where they apply,
+/* kernel-generation switch for cross-checks: 1 (default) = DMA-staged conv / wgrad kernels where they apply,
  * 0 = the register-staged kernels everywhere. */
 void mmif_debug_set_conv_dma(int32_t mode);
-/* 1 (default, also $MMIF_CONV1X1_STREAM) = bf16 1x1 layers (forward, dgrad without an accumulate operand) on the streaming kernel of
+/* 1 (default) = bf16 1x1 layers (forward, dgrad without an accumulate operand) on the streaming kernel of
  * csrc/conv1x1.hip; 0 = the register-staged conv_mfma_kernel<1, ...>.  Bit-identical results either way. */
 void mmif_debug_set_conv1x1_stream(int32_t mode);
-/* mmif_conv2d_reflect_bwd_pair: 1 (default, $MMIF_BWD_PAIR_DMA) = tiles staged by a loader wave's LDS-DMA into a double-buffered tile
+/* mmif_conv2d_reflect_bwd_pair: 1 (default) = tiles staged by a loader wave's LDS-DMA into a double-buffered tile
  * (bwd_pair_dma_kernel, round 4), 0 = the register-staged kernel; bit-identical results (tests/test_gpu_bwd_pair.py). */
 void mmif_debug_set_bwd_pair_dma(int32_t mode);
-/* 3x3 forward with 49..64 input and 17..32 output channels (decode.2 of the PFNet / DenseFuse decoders): 1 (default, $MMIF_THIN_WIDE) = the
+/* 3x3 forward with 49..64 input and 17..32 output channels (decode.2 of the PFNet / DenseFuse decoders): 1 (default) = the
  * asynchronous loader / consumer kernel in its two-group, three-slot geometry (round 4), 0 = the register-staged kernel; bit-identical. */
 void mmif_debug_set_thin_wide(int32_t mode);
 /* persistent blocks (8..256, default 256 = one per CU) of the wide layers' weight-gradient kernel (wgrad_dma_kernel): a smaller grid leaves
  * compute units to a kernel that runs concurrently on another stream -- the intra-step overlap of decode.0's weight gradient with the
- * encoder's backward (mmif/engine.py, $MMIF_OVERLAP).  Results change in the last bits only (the per-block partial sums regroup). */
+ * encoder's backward (round 5's side-stream experiment, measured and closed: DESIGN.md section 4.1).  Results change in the last bits only (the per-block partial sums regroup). */
 void mmif_debug_set_wgrad_dma_blocks(int32_t blocks);
 /* Weight gradients of 3x3 layers whose channel counts are not multiples of 64 (round 6; NestFuse's 88 / 120 / 136 / 152 / 184 / 304-channel
  * layers): 1 (default, $MMIF_WGRAD_RAGGED) = wgrad_dma_kernel does not stage the channel-block planes of a ragged last group that lie past the
@@ -562,7 +562,7 @@ int mmif_reduce_defer_begin(void* arena, size_t bytes);
 int mmif_reduce_defer_flush(int32_t keep_deferring, void* stream);
 int32_t mmif_reduce_defer_pending(void);
 
-/* mmif_dense_encoder_fwd ($MMIF_ENC_STREAM2): 2 (default) = the round-5 streaming kernel with 32-column strips, eight waves per CU; 1 = the
+/* mmif_dense_encoder_fwd: 2 (default) = the round-5 streaming kernel with 32-column strips, eight waves per CU; 1 = the
  * same with 64-column strips, four waves per CU (csrc/enc_stream2.hip: input-stationary accumulation; every stage within one bf16
  * rounding of its fp64 definition); 0 = the round-2 kernel (csrc/enc_stream.hip, bit-identical to the four layer-wise launches). */
 void mmif_debug_set_enc_stream2(int32_t mode);
