@@ -131,6 +131,8 @@ def cpu_baseline(model_name, size, n_pairs, budget_s=24.0):
         ts = sorted(times)
         med = ts[len(ts) // 2]
         return {"value": n_pairs / ts[0], "unit": "image-pairs/s", "cores": threads, "kind": "port", "median_value": n_pairs / med,
+                "threads_note": "min(32, os.cpu_count()) intra-op threads: on an 8-pair 256x256 step torch's CPU convolutions stop scaling there -- with the box's "
+                                "full 128 / 256 threads round 3's sample measured the thread pool (+-70 % run to run), not the cores",
                 "steps": len(times), "step_seconds": [round(t, 3) for t in times],
                 "sample": f"best of {len(times)} train steps of {model_name} on {n_pairs} pairs {size}x{size} fp32 (one untimed warm-up step first), "
                           f"torch {torch.__version__} CPU ops (oracle/torch_cpu_step.py), {sum(times):.1f} s; torch.set_num_threads({threads}), "
@@ -150,7 +152,7 @@ def lib_sha256():
 
 
 def measured_traffic(tag, match):
-    """HBM bytes per launch of the kernel behind `tag` from the TCC counter passes on file (profiles/r04_traffic.json, written by
+    """HBM bytes per launch of the kernel behind `tag` from the TCC counter passes on file (profiles/r06_traffic.json, written by
     tools/make_traffic.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this command) -- only when those passes ran on
     THIS library build (sha256 of the .so) and this workload; otherwise (None, reason)."""
     tpath = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
@@ -167,7 +169,7 @@ def measured_traffic(tag, match):
     return ent, f"profiles/{TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, lib {tj['lib_sha256'][:12]})"
 
 
-TRAFFIC_FILE = "r05_traffic.json"
+TRAFFIC_FILE = "r06_traffic.json"
 KIND_KERNEL_BF16 = {"fwd": "conv_dma_kernel<false>", "dgrad": "conv_dma_kernel<true> (ReLU sign bytes, in-tile reflect fold)",
                     "wgrad": "wgrad_dma_kernel + wgrad_dma_reduce"}
 KIND_KERNEL_FP32 = {"fwd": "conv_x3_kernel<fwd>", "dgrad": "conv_x3_kernel<dgrad> + fold", "wgrad": "wgrad_x3_kernel + wgrad_x3_reduce"}

@@ -109,12 +109,12 @@ constexpr int PACK_MAX_IMAGES = 64;
 struct PackImage { const float* w; bf16_t* dst; long long total; int cout, cin, ks, dgrad, m16p; };
 struct PackTable { PackImage im[PACK_MAX_IMAGES]; };
 
-__device__ inline void pack_one(const PackImage& J, long long idx) {
+// one GRANULE (8 input channels of one (k-group plane, output row)) per thread: the chunk / tap decode is done once per granule (round 6:
+// with one element per thread NestFuse's 5.4 M elements took 71 us per step, index arithmetic bound)
+__device__ inline void pack_gran(const PackImage& J, long long row) {
     const int ks = J.ks, kk = ks * ks, cin = J.cin, m16p = J.m16p;
     const int n_out = J.dgrad ? cin : J.cout, n_in = J.dgrad ? J.cout : cin;
     const int ncb = (n_in + 7) / 8;
-    const int e = idx & 7;
-    const long long row = idx >> 3;
     const int oc = (int)(row % m16p);
     long long kgp = row / m16p;
     int c0 = 0, n = 0, kg = 0;
@@ -124,23 +124,30 @@ __device__ inline void pack_one(const PackImage& J, long long idx) {
         if (kgp < pad) { kg = (int)kgp; break; }
         kgp -= pad;
     }
-    float val = 0.f;
-    if (kg < kk * n) {
+    float val[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) val[e] = 0.f;
+    if (kg < kk * n && oc < n_out) {
         const int tap = kg / n, cb = kg % n;
         const int u = tap / ks, v = tap % ks;
-        const int ic = (c0 + cb) * 8 + e;
-        if (oc < n_out && ic < n_in) {
-            if (J.dgrad) val = J.w[(((long long)ic * cin + oc) * ks + (ks - 1 - u)) * ks + (ks - 1 - v)];
-            else val = J.w[(((long long)oc * cin + ic) * ks + u) * ks + v];
+        const int ic0 = (c0 + cb) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int ic = ic0 + e;
+            if (ic < n_in) {
+                if (J.dgrad) val[e] = J.w[(((long long)ic * cin + oc) * ks + (ks - 1 - u)) * ks + (ks - 1 - v)];
+                else val[e] = J.w[(((long long)oc * cin + ic) * ks + u) * ks + v];
+            }
         }
     }
-    J.dst[idx] = f32_to_bf16(val);
+    *reinterpret_cast<uint4*>(J.dst + row * 8) = make_uint4(pack_bf16x2(val[0], val[1]), pack_bf16x2(val[2], val[3]), pack_bf16x2(val[4], val[5]), pack_bf16x2(val[6], val[7]));
 }
 
 __global__ void pack_weights_multi_kernel(PackTable tab) {
     const PackImage& J = tab.im[blockIdx.y];
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < J.total; idx += (long long)gridDim.x * blockDim.x)
-        pack_one(J, idx);
+    const long long rows = J.total >> 3;
+    for (long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x; row < rows; row += (long long)gridDim.x * blockDim.x)
+        pack_gran(J, row);
 }
 
 // ------------------------------------------------------------------ granule loaders (bf16, raw uint4)
@@ -876,10 +883,16 @@ __global__ __launch_bounds__((D_CONS + D_LOAD) * 64, 3) void conv_dma_kernel(TV 
                 d_off[i] = (__umul24((unsigned)y, (unsigned)tin.ws) + (unsigned)x) * 16u + ((d_cb >> (2 * i)) & 3u) * plane_bytes;
             }
         };
+        // weight chunk (M-block, chunk) each buffer's weight region holds: a layer with at most two chunks per item (K <= 64: decode.1's
+        // dgrad, DenseFuse's decode.0) whose block keeps one M-block finds its weights where the last item left them and does not request
+        // them again (36 of a chunk's 75 pieces)
+        int wres[2] = {-1, -1};
         auto issue_dma = [&](const DItem& itm, int c, int buf, int item_no = 0) {
             // timing ablations (results are garbage): $MMIF_ABLATE conv= bit 1 = no WEIGHT pieces on every second item (what a weight chunk
             // shared by two pixel tiles could save at most), bit 3 = no INPUT pieces on every second item (an input tile shared by two M-blocks)
-            const bool skip_w = (abl & 2) && (item_no & 1), skip_in = (abl & 8) && (item_no & 1);
+            const int wkey = itm.mb * 256 + c;
+            const bool skip_w = ((abl & 2) && (item_no & 1)) || (wres[buf] == wkey && !(abl & 64)), skip_in = (abl & 8) && (item_no & 1);
+            wres[buf] = wkey;
             const int ncb = min(CHUNK_CB, ncb_tot - c * CHUNK_CB);
             const int nkgp = (9 * ncb + 3) / 4 * 4;
             char* dst_in = s_buf + buf * DBUF_BYTES;

@@ -1,6 +1,6 @@
 #!/bin/bash
-# Everything profiles/<tag>_* holds, regenerated on the library as built (run on the GPU box from the repo root):  tools/prof_all.sh r04
-# then, back in the container:  tools/collect_profiles.sh r04
+# Everything profiles/<tag>_* holds, regenerated on the library as built (run on the GPU box from the repo root):  tools/prof_all.sh r06
+# then, back in the container:  tools/collect_profiles.sh r06
 tag=$1
 tools/prof_round.sh $tag > gpurun_out/${tag}_prof_round.log 2>&1
 tools/prof_bench.sh ${tag}nf --model NestFuse --batch 4 --size 512 --no-parity-path > /dev/null 2>&1
@@ -9,8 +9,9 @@ tools/prof_bench.sh ${tag}rf --model RFNNest --batch 4 --size 512 --no-parity-pa
 cp gpurun_out/kstats_${tag}rf.txt gpurun_out/${tag}_kernel_stats_rfnnest_b4_512_bf16.txt
 tools/prof_bench.sh ${tag}df --model DenseFuse --no-parity-path > /dev/null 2>&1
 cp gpurun_out/kstats_${tag}df.txt gpurun_out/${tag}_kernel_stats_densefuse_b32_256_bf16.txt
+tools/prof_bench.sh ${tag}inf --mode infer --batch 1 --size 1024 --width 1224 > /dev/null 2>&1
+cp gpurun_out/kstats_${tag}inf.txt gpurun_out/${tag}_kernel_stats_infer_1224x1024_bf16.txt
 tools/sweep_configs.sh > gpurun_out/${tag}_config_sweep.txt 2>&1
-tools/sweep_bwd_pair.sh $tag > /dev/null 2>&1
 cp gpurun_out/${tag}_traffic.json profiles/${tag}_traffic.json   # (on the box's copy: the bench line below reads the counter pass of THIS build)
 python3 bench.py > gpurun_out/${tag}_bench_line.json 2> gpurun_out/${tag}_bench.err
 tail -c 1500 gpurun_out/${tag}_bench_line.json
