@@ -19,10 +19,11 @@ Rank 0 prints ONE JSON line (contract in the task description) including
   parity_path  -- the same step on the parity-grade path (fp32 tensors, 3x3 / 1x1 layers on the matrix pipe as split-operand products,
                   csrc/conv_x3.hip) timed the same way, with its error against the CPU oracle on a small sample (N = 1 only)
   other_configs -- BASELINE.json's configs 3, 4, 5 on this GPU (DenseFuse B=32 256^2, NestFuse / RFN-Nest B=4 512^2 train steps, PFNetv1
-                  inference on one 1224x1024 pair): 10 timed steps each after 3 warm-up steps, value / ms_per_step / fraction of ideal (N = 1 only)
+                  inference on one 1224x1024 pair): 20 timed steps each after 6 warm-up steps, value / ms_per_step / fraction of ideal (N = 1 only)
   cpu_baseline -- the torch-CPU restatement of the step (oracle/torch_cpu_step.py, "port") timed on this box's host cores
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -59,6 +60,16 @@ def ideal_pairs_per_s(model, h, w, dtype, products=1, mode="train"):
     return 1.0 / max(products * fl * scale / PEAK_MFMA_BF16, by * scale * (2 if dtype == "fp32" else 1) / PEAK_HBM)
 
 
+def settle_gc():
+    """Before a timed region: collect, then move everything alive into the permanent generation (gc.freeze).  Round 6 found a ~75-150 ms pause of
+    the host inside one default run in three: CPython's full (generation-2) collection walking the ~million container objects torch's import
+    leaves behind, triggered by allocation count -- at a fixed step of the loop (step 14 of the headline leg), i.e. while the host is only
+    ~35 ms ahead of the GPU, which then idles: 7.0-7.6 k instead of 8.6-9.0 k pairs/s with identical kernel times (tools/diag_stall*.py;
+    DESIGN.md section 4.2).  The collector stays ON; it just no longer re-walks start-up objects.  train.py does the same after its set-up."""
+    gc.collect()
+    gc.freeze()
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -81,14 +92,14 @@ def parse():
     ap.add_argument("--no-parity-path", action="store_true", help="skip the second timed leg on the parity-grade fp32 / split-bf16 path")
     ap.add_argument("--parity-steps", type=int, default=16)
     ap.add_argument("--no-other-configs", action="store_true", help="skip the `other_configs` block (BASELINE configs 3, 4, 5 on this GPU)")
-    ap.add_argument("--other-steps", type=int, default=10)
-    ap.add_argument("--other-warmup", type=int, default=3)
+    ap.add_argument("--other-steps", type=int, default=20)
+    ap.add_argument("--other-warmup", type=int, default=6)
     ap.add_argument("--roofline-layer", default="decode.0", help="engine layer whose forward / dgrad / wgrad launches are timed with HIP events; "
                     "`roofline` reports the one with the largest share of the step, `roofline_kernels` all three")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend for N > 1 (nccl = RCCL; gloo: debugging)")
     ap.add_argument("--one-device", action="store_true", help="debug: every rank on cuda:0 (gloo only) -- exercises the N > 1 plumbing on a 1-GPU box")
     ap.add_argument("--hbm-tag", default="auto", help="an HBM-bound engine op timed the same way for `roofline_hbm` ('' = none)")
-    ap.add_argument("--roofline-every", type=int, default=0, help="time the roofline launches on every N-th timed step (0 = auto: about five samples "
+    ap.add_argument("--roofline-every", type=int, default=0, help="time the roofline launches on every N-th timed step (0 = auto: five samples "
                     "per kernel, every step when --steps <= 5).  Each HIP event pair around a launch idles the GPU for ~10 us (a marker packet "
                     "before and after: 4 timed launches per step were ~45 us = 1.2 %% of the step the events are there to describe)")
     return ap.parse_args()
@@ -276,8 +287,10 @@ def parity_leg(args, dev, img1, img2):
         for _ in range(6):     # (warm-up as the main leg's: packing, leases, the clock's ramp after the idle oracle / setup phase)
             one(model, opt, img1, img2)
         tags = {f"{args.roofline_layer}:{k}" for k in ("fwd", "dgrad", "wgrad")}
-        every = args.roofline_every if args.roofline_every > 0 else max(1, min(8, args.parity_steps // 5))
+        every = args.roofline_every if args.roofline_every > 0 else max(1, args.parity_steps // 5)
+        T.prealloc_events(tags, (args.parity_steps + every - 1) // every + 2)
         T.PROFILE_EVENTS.clear()
+        settle_gc()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(args.parity_steps):
@@ -351,6 +364,7 @@ def other_configs_leg(args, dev):
                         return model(a, b).mean()
             for _ in range(args.other_warmup):
                 one()
+            settle_gc()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(args.other_steps):
@@ -495,20 +509,45 @@ def main():
     tags = {f"{args.roofline_layer}:{k}" for k in ("fwd", "dgrad", "wgrad")} | ({hbm_tag} if hbm_tag else set())
     if hbm_tag == "encode:fwd" and args.mode == "train":
         tags |= {"encode:bwd"}      # the fused encoder backward (csrc/enc_bwd.hip), when the engine takes it
-    every = args.roofline_every if args.roofline_every > 0 else max(1, min(8, args.steps // 5))
+    every = args.roofline_every if args.roofline_every > 0 else max(1, args.steps // 5)
+    # the sampled steps' events exist before the clock starts (created and recorded once), and one untimed step runs the sampled form of the
+    # backward (wgrad and dgrad of the wide layers as two calls): nothing is created or first-used inside the timed region
+    T.prealloc_events(tags, (args.steps + every - 1) // every + 2)
+    T.PROFILE_TAGS = tags
+    step()
     T.PROFILE_TAGS = set()
+    for evs in T.PROFILE_EVENTS.values():     # (the untimed sampled step's events go back to the pool)
+        for pair in evs:
+            T.PROFILE_EVENT_POOL.setdefault("_spare", []).append(pair)
     T.PROFILE_EVENTS.clear()
+    settle_gc()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    diag = os.environ.get("BENCH_DIAG", "0") == "1"       # (diagnostics: host stamps per step + a GPU event every tenth step)
+    if diag:
+        dev_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps // 10 + 1)]
+        for e in dev_ev:
+            e.record()
+        torch.cuda.synchronize()
+        hts = [time.perf_counter()]
+        t0 = hts[0]
     for i in range(args.steps):
+        if diag and i % 10 == 0:
+            dev_ev[i // 10].record()
         T.PROFILE_TAGS = tags if i % every == 0 else set()   # (live, inside the timed region -- on a sample of its steps)
         tot = step()
+        if diag:
+            hts.append(time.perf_counter())
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if diag:
+        hd = [(hts[k + 1] - hts[k]) * 1e3 for k in range(args.steps)]
+        gd = [dev_ev[k].elapsed_time(dev_ev[k + 1]) for k in range(len(dev_ev) - 1)]
+        print(f"DIAG ms/step {dt / args.steps * 1e3:.3f}; GPU ms per 10 steps {[round(v, 1) for v in gd]}; host worst {sorted([(round(h, 1), k) for k, h in enumerate(hd)])[-4:]}", file=sys.stderr)
     T.PROFILE_TAGS = set()
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if use_dist:

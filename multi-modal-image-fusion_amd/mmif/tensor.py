@@ -143,8 +143,24 @@ PROFILE_EVENTS = {}      # tag -> [(start_event, end_event), ...] recorded on th
 PROFILE_SHAPES = {}      # tag -> (n, h, w, cin, cout, k) of the last timed conv call with that tag
 
 
+PROFILE_EVENT_POOL = {}   # tag -> [(start_event, end_event), ...] created (and recorded once) ahead of time: prealloc_events()
+
+
+def prealloc_events(tags, n):
+    """n event pairs per tag, created and recorded once NOW (outside any timed region): a torch.cuda.Event only creates its HIP event at its first
+    record(), and that creation inside bench.py's timed loop stalled the host for tens of milliseconds once in a while (round 6: one default
+    run in five lost 10-20 %; the kernels' own durations never moved)"""
+    for tag in tags:
+        pool = PROFILE_EVENT_POOL.setdefault(tag, [])
+        while len(pool) < n:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            b.record()
+            pool.append((a, b))
+
+
 class _timed:
-    __slots__ = ("tag", "e0")
+    __slots__ = ("tag", "e0", "e1")
 
     def __init__(self, tag, shape=None):
         if shape is not None and tag is not None and PROFILE_TAGS:
@@ -153,14 +169,14 @@ class _timed:
 
     def __enter__(self):
         if self.tag is not None:
-            self.e0 = torch.cuda.Event(enable_timing=True)
+            pool = PROFILE_EVENT_POOL.get(self.tag)
+            self.e0, self.e1 = pool.pop() if pool else (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             self.e0.record()
 
     def __exit__(self, *a):
         if self.tag is not None:
-            e1 = torch.cuda.Event(enable_timing=True)
-            e1.record()
-            PROFILE_EVENTS.setdefault(self.tag, []).append((self.e0, e1))
+            self.e1.record()
+            PROFILE_EVENTS.setdefault(self.tag, []).append((self.e0, self.e1))
 
 
 # ------------------------------------------------------------------ op wrappers

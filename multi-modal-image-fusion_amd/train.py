@@ -190,6 +190,12 @@ if __name__ == '__main__':
         warmup_scheduler = WarmupLR(optimizer, 0.001, len(train_loader))   # reference train.py:323
 
     best_loss, best_epoch = 0.0, 0
+    # everything alive after set-up goes to the permanent generation: CPython's full collections then no longer walk the ~million objects
+    # torch's import left behind (a 75-150 ms pause of the launch thread every few hundred steps, during which the GPU runs dry; found with
+    # bench.py in round 6).  The collector itself stays on.
+    import gc
+    gc.collect()
+    gc.freeze()
     for epoch in range(num_epochs):
         if train_sampler is not None:
             train_sampler.set_epoch(epoch)
