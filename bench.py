@@ -298,6 +298,7 @@ def parity_leg(args, dev, img1, img2):
             one(model, opt, img1, img2)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        gc.unfreeze()
         T.PROFILE_TAGS = set()
         B, S, Wd = img1.shape[0], img1.shape[2], img1.shape[3]
         value = B * args.parity_steps / dt
@@ -326,6 +327,10 @@ def parity_leg(args, dev, img1, img2):
 OTHER_CONFIGS = (("DenseFuse_b32_256", "DenseFuse", "train", 32, 256, 256, "configs[2] per-GPU share: DenseFuse 256x256 bf16, batch 32 per GPU"),
                  ("NestFuse_b4_512", "NestFuse", "train", 4, 512, 512, "configs[3]: NestFuse 512x512 bf16, batch 4 per GPU"),
                  ("RFNNest_b4_512", "RFNNest", "train", 4, 512, 512, "configs[3]: RFN-Nest 512x512 bf16, batch 4 per GPU"),
+                 # (batch scaling of the same build: BASELINE's config 4 names no batch; at 4 pairs the 128 x 128 and 64 x 64 levels give a launch fewer
+                 # tiles than the chip has CUs)
+                 ("NestFuse_b8_512", "NestFuse", "train", 8, 512, 512, "configs[3] at batch 8 per GPU (batch scaling): NestFuse 512x512 bf16"),
+                 ("RFNNest_b8_512", "RFNNest", "train", 8, 512, 512, "configs[3] at batch 8 per GPU (batch scaling): RFN-Nest 512x512 bf16"),
                  ("infer_1224x1024", "PFNetv1", "infer", 1, 1024, 1224, "configs[4]: PFNetv1 forward (no_grad, test.py path) on one 1224x1024 pair, bf16"))
 
 
@@ -371,6 +376,7 @@ def other_configs_leg(args, dev):
                 tot = one()
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
+            gc.unfreeze()
             value = B * args.other_steps / dt
             ideal = ideal_pairs_per_s(name, H, Wd, "bf16", 1, mode)
             res[key] = {"config": what, "model": name, "mode": mode, "batch": B, "height": H, "width": Wd, "dtype": "bf16", "value": value,
@@ -544,6 +550,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    gc.unfreeze()
     if diag:
         hd = [(hts[k + 1] - hts[k]) * 1e3 for k in range(args.steps)]
         gd = [dev_ev[k].elapsed_time(dev_ev[k + 1]) for k in range(len(dev_ev) - 1)]
