@@ -324,10 +324,14 @@ constexpr int GD = LT + 2 * DH;       // 20
 
 __device__ inline float sgnf(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
 
+// px_mode (round 6, mmif_fusion_loss only): >= 0 = this kernel also forms the PIXEL term of the same pixels (bit 0: max mode, bit 1: l2) -- its
+// value as a second block partial (part_px), its gradient added between the gradient already there and the Sobel term, exactly where
+// pixel_loss_kernel(accum = 1) added it: the images are in LDS here anyway, and a 9 us launch over 25 MB disappears.  -1: Sobel term only.
 __global__ __launch_bounds__(256) void grad_loss_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
                                                         const float* __restrict__ f, int H, int W, float gscale,
                                                         int mode_max, int l2, float* __restrict__ grad,
-                                                        float* __restrict__ partial, int tiles_x, int accum) {
+                                                        float* __restrict__ partial, int tiles_x, int accum,
+                                                        int px_mode = -1, float gscale_px = 0.f, float* __restrict__ part_px = nullptr) {
     // row strides by the LDS banking of ds_read_b32 (two 32-lane groups, bank = dword index mod 32): the Sobel pass walks 20-wide rows with
     // consecutive lanes -- a stride = 20 (mod 32) keeps the 32 lanes of a group on 32 distinct banks across the row change (52 floats);
     // the adjoint pass reads 16-wide rows, two per group -- stride = 16 (mod 32) (48 floats).  (23 / 21 made every read a 2-way conflict.)
@@ -417,10 +421,39 @@ __global__ __launch_bounds__(256) void grad_loss_kernel(const float* __restrict_
         for (int a = 0; a < ny; ++a)
             for (int b = 0; b < nx; ++b) g += Tq(ys[a], xs[b]);
         float* gp = grad + ibase + (long long)y * W + x;
-        *gp = accum ? *gp + gscale * g : gscale * g;
+        float base = accum ? *gp : 0.f;
+        if (px_mode >= 0) {      // pixel_loss_kernel's gradient term (its arithmetic, its place in the sum)
+            const float a = in[0][ty + GH][tx + GH], b = in[1][ty + GH][tx + GH], c = in[2][ty + GH][tx + GH];
+            float pg;
+            if (px_mode & 1) {
+                const float d = c - fmaxf(a, b);
+                pg = (px_mode & 2) ? 2.f * d : sgnf(d);
+            } else {
+                const float d1 = c - a, d2 = c - b;
+                pg = 0.5f * ((px_mode & 2) ? 2.f * (d1 + d2) : sgnf(d1) + sgnf(d2));
+            }
+            base = base + gscale_px * pg;
+        }
+        *gp = (accum || px_mode >= 0) ? base + gscale * g : gscale * g;
+    }
+    float psum = 0.f;
+    if (px_mode >= 0 && y < H && x < W) {
+        const float a = in[0][ty + GH][tx + GH], b = in[1][ty + GH][tx + GH], c = in[2][ty + GH][tx + GH];
+        if (px_mode & 1) {
+            const float d = c - fmaxf(a, b);
+            psum = (px_mode & 2) ? d * d : fabsf(d);
+        } else {
+            const float d1 = c - a, d2 = c - b;
+            psum = 0.5f * ((px_mode & 2) ? d1 * d1 + d2 * d2 : fabsf(d1) + fabsf(d2));
+        }
     }
     const float t = block_sum(lsum, red);
     if (tid == 0) partial[(long long)in_ * gridDim.x + blockIdx.x] = t;
+    if (px_mode >= 0) {
+        __syncthreads();
+        const float tp = block_sum(psum, red);
+        if (tid == 0) part_px[(long long)in_ * gridDim.x + blockIdx.x] = tp;
+    }
 }
 
 void gaussian_window(Win11& w) {
@@ -525,7 +558,7 @@ static size_t fusion_parts(int32_t n, int32_t h, int32_t w, size_t* o_px, size_t
     const size_t ns = (size_t)cdiv(Wm, ST) * cdiv(Hm, ST) * n, ngr = (size_t)cdiv(w, LT) * cdiv(h, LT) * n;
     auto up = [](size_t v) { return (v + 63) / 64 * 64; };
     *o_px = up(ns);
-    *o_gr = *o_px + 2048;
+    *o_gr = *o_px + up(ngr);      // (the pixel term's partials: one per Sobel tile since round 6)
     *o_maps = *o_gr + up(ngr);
     return *o_maps + (size_t)4 * n * (h > 10 ? h - 10 : 0) * (w > 10 ? w - 10 : 0);
 }
@@ -560,16 +593,13 @@ extern "C" int mmif_fusion_loss(const float* img1, const float* img2, const floa
         if (int rc = check_launch("fusion_loss ssim_grad")) return rc;
     }
     const long long total = (long long)n * h * w;
-    int nb = cdiv(total, 256);
-    if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(pixel_loss_kernel, dim3(nb), dim3(256), 0, st, img1, img2, imgf, total, w_pixel / (float)total, pixel_max, pixel_l2,
-                       grad_out, pp, 1);
-    if (int rc = check_launch("fusion_loss pixel")) return rc;
+    // the pixel term rides in the Sobel kernel (round 6): same arithmetic, its gradient added at the same place of the sum, its value from
+    // 16 x 16-tile partials (mmif_pixel_loss sums grid-stride partials: equal to ~1e-7); the same kernel with and without a gradient
     const int tx = cdiv(w, LT), ty = cdiv(h, LT);
     hipLaunchKernelGGL(grad_loss_kernel, dim3(tx * ty, n), dim3(256), 0, st, img1, img2, imgf, h, w, w_grad / (float)total, grad_max, grad_l2,
-                       grad_out, pg, tx, 1);
-    if (int rc = check_launch("fusion_loss grad")) return rc;
-    hipLaunchKernelGGL(fusion_finish_kernel, dim3(1), dim3(1024), 0, st, ps, ns, w_ssim, 1.f / ((float)n * Hm * Wm), pp, nb,
+                       grad_out, pg, tx, 1, (pixel_max ? 1 : 0) | (pixel_l2 ? 2 : 0), w_pixel / (float)total, pp);
+    if (int rc = check_launch("fusion_loss pixel + grad")) return rc;
+    hipLaunchKernelGGL(fusion_finish_kernel, dim3(1), dim3(1024), 0, st, ps, ns, w_ssim, 1.f / ((float)n * Hm * Wm), pp, tx * ty * n,
                        w_pixel / (float)total, pg, tx * ty * n, w_grad / (float)total, loss_out);
     return check_launch("fusion_loss finish");
 }
