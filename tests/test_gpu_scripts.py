@@ -129,7 +129,7 @@ def test_bench_other_configs_block_small_shapes(monkeypatch):
     assert E.compute_dtype() == prev
     assert set(res) == {"DenseFuse_small", "NestFuse_small", "RFNNest_small", "infer_small"}
     for k, v in res.items():
-        assert v["value"] > 0 and v["ms_per_step"] > 0 and v["steps"] == 2 and np.isfinite(v["final_value"]), (k, v)
+        assert v["value"] > 0 and v["ms_per_step"] > 0 and 2 <= v["steps"] <= bench.OTHER_MAX_STEPS and v["warmup"] >= 1 and np.isfinite(v["final_value"]), (k, v)
         assert v["step_frac_of_ideal"] is not None and 0 < v["step_frac_of_ideal"] < 1, (k, v)
     assert [c[0] for c in bench.OTHER_CONFIGS] and {c[1] for c in bench.OTHER_CONFIGS} == {"DenseFuse", "NestFuse", "RFNNest", "PFNetv1"}
 
