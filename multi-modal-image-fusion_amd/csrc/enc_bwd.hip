@@ -18,16 +18,18 @@
 //           forms dW1 (g1 row r against x0 rows r-1 .. r+1: nine MFMAs per step).
 //   role B  forms dW3, dW2, the bias sums and the first layer's gradients: dW_L[o][c][u][v] += sum_px gL[o](r, px) x_in[c](R(r+u-1), px+v-1),
 //           K = the strip's 32 pixels = ONE k-step, both operands k-major through transposing LDS reads (ds_read_b64_tr_b16); the first layer
-//           against the fp32 image on the exact fp32 matrix path, two rows behind (g0 row r-2 left the chain in step r-1).  It also issues
+//           against the fp32 image as three exact bf16 pieces (round 6; the fp32 matrix path before), two rows behind (g0 row r-2 left the
+//           chain in step r-1).  It also issues
 //           the LDS-DMA of the activation / image rows (ring of 6 / 8 rows) and waits for them: it has the slack.
 // One s_barrier per row step couples the roles: everything a role reads was written at least one barrier earlier (table in DESIGN.md 4.1).
-// One block per CU: the branch's (image, strip) columns form one line of rows cut into equal slices; a pair walks its slice in pieces, the
+// One block per CU: the branch's (image, strip) columns form one line of rows cut into slices of equal weighted length (fb_geometry); a pair walks its slice in pieces, the
 // weight gradients accumulate in registers across pieces; one partial sum per block, finished by enc_wgrad_reduce in fixed order.
 // HBM traffic: G (64 planes) + x (48) + the image, NOTHING written but the block partials.  Pixels are counted once: the weight-gradient
 // operand of gL is zeroed outside the strip's kept columns, rows outside the piece are skipped; strips / pieces recompute their margins
 // (3 columns / rows).
 #include "enc_wgrad.hpp"
 #include <stdlib.h>
+#include <mutex>
 #pragma clang diagnostic ignored "-Winline-asm"   // (the LDS-DMA asm names m0 in its clobber list: "reserved register")
 
 namespace mmif {
@@ -65,7 +67,9 @@ constexpr int FB_LDS = FB_WBYTES + FB_PAIRS * FB_GRING + 64;
 // (64 zero bytes after the activation rings and after the image rings: the operand reads of pixel 32 run one granule past a row, into the
 //  next row / slot / wave -- finite data, multiplied by a zeroed gradient -- and after the LAST row they must not find the fp32 image
 //  ring, whose low halves read as bf16 are arbitrary bit patterns, NaN included)
-constexpr int FB_LDS_DMA = FB_PAIRS * (FB_XS * FB_XROW + FB_IS * FB_IROW) + 192;
+constexpr int FB_L0C = FB_PAIRS * (FB_XS * FB_XROW + FB_IS * FB_IROW) + 192;
+// (+ the constant columns of the first layer's B operand, read like an image row: 128 B of 1.0f -- column 9, the bias sum -- and 128 B of 0)
+constexpr int FB_LDS_DMA = FB_L0C + 256;
 static_assert(EW_PER * 4 <= FB_LDS, "the block partial is staged in the operand LDS");
 static_assert(FB_LDS + FB_LDS_DMA <= 160 * 1024, "LDS budget of one CU");
 
@@ -79,22 +83,49 @@ struct BwdArgs {
     BwdBranch br[2];
     int n, h, w;
     int nstrips;
-    int rows_per_slot;         // rows of the branch's line of n * nstrips * h rows that one wave pair walks
-    int nbarriers;             // barriers every wave executes: an upper bound of (pieces + steps) of a pair
+    int rows_per_slot;         // what one wave pair walks of the branch's line of n * nstrips columns, in WEIGHTED rows: a column counts
+                               // h + piece_cost (a piece -- the part of a column inside a slice -- pays about that many margin steps, so
+                               // slices that straddle a column boundary get fewer rows and every pair about the same number of steps)
+    int piece_cost;
+    int nbarriers;             // barriers every wave executes: the largest (pieces + steps) of a pair
 };
 
 template <int N> struct FBI { static constexpr int value = N; };
+
+// position on the line of rows (column c = rows [c h, (c + 1) h)) of the weighted position v: the piece_cost weighted rows at the end of a
+// column map to the start of the next one
+__host__ __device__ inline long long fb_line_pos(long long v, int h, int piece_cost, long long line_rows) {
+    const long long hv = h + piece_cost, c = v / hv, y = v - c * hv;
+    const long long pos = c * h + (y < h ? y : (long long)h);
+    return pos < line_rows ? pos : line_rows;
+}
+// steps of the piece [y_lo, y_hi) of a column (set_piece below)
+__host__ __device__ inline int fb_piece_steps(int y_lo, int y_hi) {
+    const int a_lo = y_lo - 3 > 0 ? y_lo - 3 : 0;
+    return 3 * ((y_hi + 2 - (a_lo - 3) + 2) / 3);
+}
 
 #define FB_FENCE() __builtin_amdgcn_sched_barrier(0)
 // the pair's (and the block's) step barrier: LDS traffic of this wave retired, then s_barrier.  Inline asm with a memory clobber: the
 // compiler keeps memory accesses on their side of it, and -- unlike __syncthreads() -- does not drain the vector-memory counter (the
 // chain waves always have two steps of requests in flight)
-#define FB_STEP_BARRIER() __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-// compile-time ablations (tools/build_ab_encbwd.sh; TIMING ONLY, results are wrong): 1 no weight-gradient products (role B idle, no w1),
-// 2 no chain MFMAs, 4 no epilogues, 8 no global requests / LDS-DMA in the steps, 16 no first-layer products, 32 no chain operand reads
 #ifndef FB_ABL
 #define FB_ABL 0
 #endif
+#ifndef FB_FRESH
+#define FB_FRESH 3
+#endif
+#ifndef FB_PRIO
+#define FB_PRIO 0
+#endif
+#if FB_ABL & 64
+#define FB_STEP_BARRIER() __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
+#define FB_STEP_BARRIER() __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
+// compile-time ablations (tools/build_ab_encbwd.sh; TIMING ONLY, results are wrong): 1 no weight-gradient products (role B idle, no w1),
+// 2 no chain MFMAs, 4 no epilogues, 8 no global requests / LDS-DMA in the steps, 16 no first-layer products, 32 no chain operand reads,
+// 64 no step barriers (the roles and the pairs run free)
 
 __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs A) {
     __shared__ __attribute__((aligned(16))) char smem[FB_LDS];
@@ -105,7 +136,7 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pair = wave & (FB_PAIRS - 1), role = wave / FB_PAIRS;
-    const int j = lane & 15, g = lane >> 4;
+    int j = lane & 15, g = lane >> 4;      // (each role re-derives them -- and what hangs off them -- from its own lane id read: see fresh_lane)
 
     // ---- chain A fragments (tap-row major K order, csrc/enc_stream2.hip): virtual layer 1 = dst x2 (input g3), 2 = dst x1 ([g2 | g3]),
     // 3 = dst x0 ([g1 | g2] + g3)
@@ -136,7 +167,11 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
         reinterpret_cast<uint4*>(smem + FB_WBYTES + FB_PAIRS * FB_GRING)[tid] = make_uint4(0u, 0u, 0u, 0u);
         reinterpret_cast<uint4*>(smem_dma)[tid] = make_uint4(0u, 0u, 0u, 0u);
         reinterpret_cast<uint4*>(smem_dma + 64 + FB_PAIRS * FB_XS * FB_XROW)[tid] = make_uint4(0u, 0u, 0u, 0u);
-        reinterpret_cast<uint4*>(smem_dma + FB_LDS_DMA - 64)[tid] = make_uint4(0u, 0u, 0u, 0u);
+        reinterpret_cast<uint4*>(smem_dma + FB_L0C - 64)[tid] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    if (tid < 16) {
+        const unsigned one = tid < 8 ? 0x3f800000u : 0u;
+        reinterpret_cast<uint4*>(smem_dma + FB_L0C)[tid] = make_uint4(one, one, one, one);
     }
     __syncthreads();
 
@@ -146,8 +181,8 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
     // same number of barriers: its pieces' (1 + steps), then idle ones up to A.nbarriers.
     const int H = A.h, W = A.w;
     const long long line_rows = (long long)A.n * A.nstrips * H;
-    const long long pos_begin = min(line_rows, (long long)(blockIdx.x * FB_PAIRS + pair) * A.rows_per_slot);
-    const long long pos_end = min(line_rows, pos_begin + A.rows_per_slot);
+    const long long pos_begin = fb_line_pos((long long)(blockIdx.x * FB_PAIRS + pair) * A.rows_per_slot, H, A.piece_cost, line_rows);
+    const long long pos_end = fb_line_pos((long long)(blockIdx.x * FB_PAIRS + pair + 1) * A.rows_per_slot, H, A.piece_cost, line_rows);
     int strip = 0, in_ = 0, y_lo = 0, y_hi = 0, NSTEP = 0;
     int r0 = 0, o_lo = 0, o_hi = 0, a_lo = 0, a_hi = 0, b_lo = 0, b_hi = 0, c_lo = 0, c_hi = 0, r_first = 0;
     unsigned km[4] = {0u, 0u, 0u, 0u};          // keep-mask of this lane's 8 pixels (the K order below; two bf16 per dword)
@@ -169,7 +204,7 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
         b_lo = max(0, y_lo - 2); b_hi = min(H, y_hi + 2);
         c_lo = max(0, y_lo - 1); c_hi = min(H, y_hi + 1);
         r_first = a_lo - 3;
-        NSTEP = 3 * ((y_hi + 2 - r_first + 2) / 3);      // steps r_first .. y_hi + 1 (the first layer's products trail by two rows), in threes
+        NSTEP = fb_piece_steps(y_lo, y_hi);              // steps r_first .. y_hi + 1 (the first layer's products trail by two rows), in threes
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             const int c0 = r0 + (d < 2 ? 4 * g + 2 * d : 16 + 4 * g + 2 * (d - 2)), c1 = c0 + 1;
@@ -179,14 +214,22 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
     };
     int nbar = 0;          // barriers executed so far
 
+    // (the lane coordinates of the tail are re-derived from a lane id the compiler cannot tie to the one above: it would otherwise carry --
+    //  spill -- j and g across the step loops for the tail's sake)
+    auto fresh_lane = [&](int level = 1) __attribute__((always_inline)) {
+        if (level > FB_FRESH) return lane;
+        int l;
+        __asm__ volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        return l;
+    };
     // ---- lane constants of the transposing reads (weight-gradient operands: in-group lane sl supplies pixel sl >> 2 (+ 4), 4-channel chunk sl & 3)
-    const int tr_row = j >> 2, tr_c = j & 3;
+    int tr_row = j >> 2, tr_c = j & 3;
     // K order of the weight-gradient products (any bijection pixel <-> k works as long as both operands use it): k = 8 g + e is pixel
     // 4 g + e for e < 4 and 16 + 4 g + (e - 4) for e >= 4 -- the 64 lanes of one transposing read then cover 16 CONSECUTIVE pixels (512
     // contiguous bytes of the pixel-major activation ring; lane groups 256 B apart shared their banks: a third of the LDS cycles of the
     // first version were bank conflicts), the second read of a fragment the other 16
-    const int ltr = (tr_c >> 1) * FB_CBS + 16 + (4 * g + tr_row) * 16 + (tr_c & 1) * 8;        // gradient rings
-    const int ltr_x = (4 * g + tr_row) * 32 + tr_c * 8;                                       // activation ring (pixel-major: 32 B = 16 channels)
+    int ltr = (tr_c >> 1) * FB_CBS + 16 + (4 * g + tr_row) * 16 + (tr_c & 1) * 8;        // gradient rings
+    int ltr_x = (4 * g + tr_row) * 32 + tr_c * 8;                                       // activation ring (pixel-major: 32 B = 16 channels)
     auto tr_frag = [&](int addr) __attribute__((always_inline)) {
         const fb_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(FB_LDS_PTR(fb_s16x4, smem + addr));
         const fb_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(FB_LDS_PTR(fb_s16x4, smem + addr + 256));
@@ -219,7 +262,7 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
             __syncthreads();
         }
         float* dst = B.partial + (long long)blockIdx.x * EW_PER;
-        for (int e = tid; e < EW_PER; e += FB_WAVES * 64) dst[e] = red[e];
+        for (int e = wave * 64 + fresh_lane(); e < EW_PER; e += FB_WAVES * 64) dst[e] = red[e];
     };
     const fb_f32x4 zero4 = (fb_f32x4){0.f, 0.f, 0.f, 0.f};
     auto img_base = [&](const TV& t) { return t.base + ((long long)in_ * t.img + (long long)t.cb_off * t.plane) * 16; };
@@ -227,8 +270,18 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
     if (role == 1) {
         // ================= role B: dW3, dW2, db3, db2 of row r = g3 / g2 row r (final since step r - 2) against the activation rows
         // R(r-1), r, R(r+1): nine chunks of one tap (u, v), operands double-buffered
+        {   // this role's own lane coordinates (nothing lane-derived is shared -- kept live, spilled -- across the role split)
+            const int l2 = fresh_lane(2);
+            j = l2 & 15; g = l2 >> 4; tr_row = j >> 2; tr_c = j & 3;
+            ltr = (tr_c >> 1) * FB_CBS + 16 + (4 * g + tr_row) * 16 + (tr_c & 1) * 8;
+            ltr_x = (4 * g + tr_row) * 32 + tr_c * 8;
+        }
+#ifdef FB_PRIOB
+        __builtin_amdgcn_s_setprio(FB_PRIOB);
+#endif
         fb_f32x4 w3[3][3][3], w2[3][3][2], accb[3], acc0 = zero4;
         const int un = min(j / 3, 2), vn = j - 3 * (j / 3);
+        const int l0_const = FB_L0C + (j == 9 ? 0 : 128);
 #pragma unroll
         for (int u = 0; u < 3; ++u)
 #pragma unroll
@@ -328,18 +381,29 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
                 FB_FENCE();
             }
             if (l0) {     // (operands read here, not ahead: this role has the slack, not the registers)
-                const fb_u32x4 l0g = __builtin_bit_cast(fb_u32x4, tr_frag(ring + FB_G0 + ((r - 2) & (FB_S0 - 1)) * FB_ROW + ltr));
-                const int ib = iring + (rrow(r - 2 + un - 1) & (FB_IS - 1)) * FB_IROW + (vn - 1) * 4 + 16 * g;      // (pixel 4 g + e | 16 + 4 g + e - 4)
-                float l0i[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) l0i[e] = *reinterpret_cast<const float*>(smem_dma + ib + (e < 4 ? e * 4 : 64 + (e - 4) * 4));
+                // the fp32 image as THREE bf16 pieces (hi = the top 16 bits, mid = the top 16 bits of the exact remainder, lo = what is left:
+                // 8 + 8 + 8 significand bits, every piece exact) against the bf16 gradient on the 16-cycle bf16 MFMA: bf16 x bf16 products are
+                // exact in fp32, so the three products sum to the fp32 product -- 48 MFMA cycles instead of the 256 of eight 16x16x4 fp32 ones
+                const fb_bf16x8 l0g = masked_g(ring + FB_G0 + ((r - 2) & (FB_S0 - 1)) * FB_ROW);
+                const int ib = j < 9 ? iring + (rrow(r - 2 + un - 1) & (FB_IS - 1)) * FB_IROW + (vn - 1) * 4 + 16 * g : l0_const;   // (pixel 4 g + e | 16 + 4 g + e - 4)
+                uint32_t hi[8], mid[8], lo[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const uint32_t w = l0g[e >> 1] & km[e >> 1];
-                    const float af = __uint_as_float((e & 1) ? (w & 0xffff0000u) : (w << 16));
-                    const float bf = j < 9 ? l0i[e] : (j == 9 ? 1.f : 0.f);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf, acc0, 0, 0, 0);
+                    const float x = *reinterpret_cast<const float*>(smem_dma + ib + (e < 4 ? e * 4 : 64 + (e - 4) * 4));
+                    hi[e] = __float_as_uint(x) & 0xffff0000u;
+                    const float r1 = x - __uint_as_float(hi[e]);
+                    mid[e] = __float_as_uint(r1) & 0xffff0000u;
+                    lo[e] = __float_as_uint(r1 - __uint_as_float(mid[e]));
                 }
+                auto pk8 = [&](const uint32_t* v) __attribute__((always_inline)) {      // the top halves of eight dwords -> bf16 x 8
+                    fb_u32x4 o;
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) o[d] = __builtin_amdgcn_perm(v[2 * d + 1], v[2 * d], 0x07060302u);
+                    return __builtin_bit_cast(fb_bf16x8, o);
+                };
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(l0g, pk8(lo), acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(l0g, pk8(mid), acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(l0g, pk8(hi), acc0, 0, 0, 0);
             }
             FB_FENCE();
             // the rows requested in the PREVIOUS step have landed (this role's only vector-memory operations are the DMAs, four per step:
@@ -352,6 +416,7 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
 #pragma unroll 1
         for (; nbar < A.nbarriers; ++nbar) FB_STEP_BARRIER();
         block_partial([&](auto put) {
+            const int l2 = fresh_lane(), j = l2 & 15, g = l2 >> 4;
 #pragma unroll
             for (int q = 0; q < 4; ++q) put(EW_OFF0 + (4 * g + q) * 16 + j, acc0[q]);
 #pragma unroll
@@ -377,6 +442,15 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
         });
     } else {
         // ================= role A: the gradient chain, dW1 / db1 and the first layer's gradients
+        {   // this role's own lane coordinates (nothing lane-derived is shared -- kept live, spilled -- across the role split)
+            const int l2 = fresh_lane(2);
+            j = l2 & 15; g = l2 >> 4; tr_row = j >> 2; tr_c = j & 3;
+            ltr = (tr_c >> 1) * FB_CBS + 16 + (4 * g + tr_row) * 16 + (tr_c & 1) * 8;
+            ltr_x = (4 * g + tr_row) * 32 + tr_c * 8;
+        }
+#if FB_PRIO
+        __builtin_amdgcn_s_setprio(FB_PRIO);
+#endif
         fb_f32x4 w1[3][3];
 #pragma unroll
         for (int u = 0; u < 3; ++u)
@@ -397,14 +471,12 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
         const bool in_e = x_e >= 0 && x_e < W;
         const int lw_e = ring + 16 + cb_e * FB_CBS + px_e * 16;
         const uint32_t inm_e = in_e ? 0xffffffffu : 0u;
-        const int srcL = (cb_e * 2 + (max(px_e - 2, 0) >> 4)) * 16 + (max(px_e - 2, 0) & 15);
-        const int srcR = (cb_e * 2 + (min(px_e + 2, FB_W - 1) >> 4)) * 16 + (min(px_e + 2, FB_W - 1) & 15);
         const bool tgtL = edgeL && x_e == 1, tgtR = edgeR && x_e == W - 2;
-        const bool tgt_f = tgtL || tgtR;
         const float mulL = tgtL ? 1.f : 0.f, mulR = tgtR ? 1.f : 0.f;
-        const int src_f = tgtL ? srcL : srcR;
         // g3 rows: lane = (pixel lane & 31, channel block lane >> 5)
-        const int px_a = lane & 31, cb_a = lane >> 5;
+        // (from a lane id read inside the piece loop: the plane products below are loop-invariant otherwise, hoisted and spilled)
+        const int lane_p = fresh_lane(3), jp = lane_p & 15, gp = lane_p >> 4;
+        const int px_a = lane_p & 31, cb_a = lane_p >> 5;
         const int x_a = r0 + px_a;
         const bool in_a = x_a >= 0 && x_a < W;
         const int lw_a = ring + FB_G3 + 16 + cb_a * FB_CBS + px_a * 16;
@@ -418,8 +490,8 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
         unsigned gl_off[2];      // G fragments in accumulator layout: this lane's channels 4 g .. 4 g + 3 of pixel 16 t + j = 8 bytes of a granule
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const int c = r0 + 16 * t + j;
-            gl_off[t] = (c >= 0 && c < W) ? (unsigned)(g >> 1) * gl_plane + (unsigned)c * 16u + (unsigned)(g & 1) * 8u + gl_org : 0x80000000u;
+            const int c = r0 + 16 * t + jp;
+            gl_off[t] = (c >= 0 && c < W) ? (unsigned)(gp >> 1) * gl_plane + (unsigned)c * 16u + (unsigned)(gp & 1) * 8u + gl_org : 0x80000000u;
         }
         fb_u32x4 pg3;            // (the g3 row travels one step ahead only: one register set)
         fb_u32x2 pG[3][2];       // C operands of the fresh accumulators of the NEXT step: each layer's pair is re-requested right after this
@@ -539,10 +611,16 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
                             c[i] = fmaf(__uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(c[i]), 0x102, 0xf, 0xf, true)), mulR, c[i]);
                     }
                 } else if (edgeL || edgeR) {
+                    // (border rows only: the source lane is worked out here, from a fresh lane id, not carried through the fast steps)
+                    const int l2 = fresh_lane(), px2 = 16 * ((l2 >> 4) & 1) + (l2 & 15), cb2 = l2 >> 5;
+                    const int x2 = r0 + px2;
+                    const bool tL = edgeL && x2 == 1, tR = edgeR && x2 == W - 2;
+                    const int ps = tL ? max(px2 - 2, 0) : min(px2 + 2, FB_W - 1);
+                    const int src4 = ((cb2 * 2 + (ps >> 4)) * 16 + (ps & 15)) * 4;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
-                        const float f = __shfl(c[i], src_f, 64);
-                        c[i] += tgt_f ? f : 0.f;
+                        const float f = __uint_as_float((unsigned)__builtin_amdgcn_ds_bpermute(src4, (int)__float_as_uint(c[i])));
+                        c[i] += (tL || tR) ? f : 0.f;
                     }
                 }
                 // bf16 > 0  <=>  as int16 > 0 (negative zero and negatives are <= 0): packed max(x, 0) -> min(., 1) -> 0 - . = 0xffff per kept half
@@ -665,6 +743,7 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
 #pragma unroll 1
         for (; nbar < A.nbarriers; ++nbar) FB_STEP_BARRIER();
         block_partial([&](auto put) {
+            const int l2 = fresh_lane(), j = l2 & 15, g = l2 >> 4;
 #pragma unroll
             for (int u = 0; u < 3; ++u)
 #pragma unroll
@@ -677,17 +756,40 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
 #undef FB_FENCE
 #undef FB_RO
 
-// one block per CU (and branch): the line of n * nstrips * h rows in equal slices of at least 8 rows
-static void fb_geometry(int n, int h, int w, int nb, int& nstrips, int& rows_per_slot, int& nbarriers, int& nblocks) {
-    nstrips = w <= FB_W - 2 ? 1 : (w - (FB_W - 2) + FB_KEEP - 1) / FB_KEEP + 1;
+// one block per CU (and branch): the line of n * nstrips columns in slices of equal WEIGHTED length (at least 8 rows + one piece's cost);
+// nbarriers = the most barriers any pair executes (a piece of k rows: 1 + its steps), counted here slice by slice; the weight of a piece is
+// the candidate with the smallest such maximum.  (The last geometry is kept: a training loop asks for the same one every step.)
+struct FbGeo { int n, h, w, nb, ncu, nstrips, rows_per_slot, piece_cost, nbarriers, nblocks; };
+static void fb_geometry(int n, int h, int w, int nb, FbGeo& G) {
+    static std::mutex mu;
+    static FbGeo last = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const int ncu = cached_num_cus();
-    const long long rows = (long long)n * nstrips * h;
+    std::lock_guard<std::mutex> lk(mu);
+    if (last.n == n && last.h == h && last.w == w && last.nb == nb && last.ncu == ncu) { G = last; return; }
+    G.n = n; G.h = h; G.w = w; G.nb = nb; G.ncu = ncu;
+    G.nstrips = w <= FB_W - 2 ? 1 : (w - (FB_W - 2) + FB_KEEP - 1) / FB_KEEP + 1;
+    const long long cols = (long long)n * G.nstrips, line_rows = cols * h;
     const int gmax = std::max(1, std::min(ncu / nb, EW_MAXG / 2));          // (block partials of both branches share one workspace of EW_MAXG slots)
-    rows_per_slot = (int)std::max<long long>(8, (rows + (long long)gmax * FB_PAIRS - 1) / ((long long)gmax * FB_PAIRS));
-    nblocks = (int)((rows + (long long)rows_per_slot * FB_PAIRS - 1) / ((long long)rows_per_slot * FB_PAIRS));
-    // a pair's pieces: at most one per started column of its slice, + 1 for the split one; a piece of k rows takes 1 + (k + 8 rounded up to 3) barriers
-    const int pieces = (rows_per_slot + h - 1) / h + 1;
-    nbarriers = rows_per_slot + pieces * 11;
+    G.nbarriers = 0;
+    for (int cost = 0; cost <= 12; cost += 2) {
+        const long long weighted = cols * (h + cost);
+        const int rps = (int)std::max<long long>(8 + cost, (weighted + (long long)gmax * FB_PAIRS - 1) / ((long long)gmax * FB_PAIRS));
+        const int nblocks = (int)((weighted + (long long)rps * FB_PAIRS - 1) / ((long long)rps * FB_PAIRS));
+        int worst = 0;
+        for (long long slot = 0; slot < (long long)nblocks * FB_PAIRS; ++slot) {
+            long long pos = fb_line_pos(slot * rps, h, cost, line_rows);
+            const long long end = fb_line_pos((slot + 1) * rps, h, cost, line_rows);
+            int bars = 0;
+            while (pos < end) {
+                const int y_lo = (int)(pos % h), y_hi = (int)std::min<long long>(h, y_lo + (end - pos));
+                bars += 1 + fb_piece_steps(y_lo, y_hi);
+                pos += y_hi - y_lo;
+            }
+            worst = std::max(worst, bars);
+        }
+        if (G.nbarriers == 0 || worst < G.nbarriers) { G.nbarriers = worst; G.rows_per_slot = rps; G.piece_cost = cost; G.nblocks = nblocks; }
+    }
+    last = G;
 }
 
 }  // namespace mmif
@@ -740,8 +842,10 @@ extern "C" int mmif_dense_encoder_bwd(const mmif_dense_chain* chain_a, const flo
     BwdArgs A;
     memset(&A, 0, sizeof(A));
     A.n = chain_a->x->n; A.h = chain_a->x->h; A.w = chain_a->x->w;
-    int G = 0;
-    fb_geometry(A.n, A.h, A.w, nb, A.nstrips, A.rows_per_slot, A.nbarriers, G);
+    FbGeo geo;
+    fb_geometry(A.n, A.h, A.w, nb, geo);
+    A.nstrips = geo.nstrips; A.rows_per_slot = geo.rows_per_slot; A.piece_cost = geo.piece_cost; A.nbarriers = geo.nbarriers;
+    const int G = geo.nblocks;
     MMIF_REQUIRE(nb * G <= EW_MAXG, "dense_encoder_bwd: too many blocks for the partial-sum workspace");
     for (int b = 0; b < nb; ++b) {
         const mmif_dense_chain* c = b ? chain_b : chain_a;
