@@ -112,11 +112,10 @@ __host__ __device__ inline int fb_piece_steps(int y_lo, int y_hi) {
 #ifndef FB_ABL
 #define FB_ABL 0
 #endif
+// FB_FRESH: how far lane coordinates are re-derived where they are used (fresh_lane below) instead of carried across the step loops: 0 nowhere
+// (12 spilled registers, all outside the loops), 1 the tails and border rows, 2 + each role's own, 3 + each piece's (0 spills)
 #ifndef FB_FRESH
 #define FB_FRESH 3
-#endif
-#ifndef FB_PRIO
-#define FB_PRIO 0
 #endif
 #if FB_ABL & 64
 #define FB_STEP_BARRIER() __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
@@ -276,9 +275,6 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
             ltr = (tr_c >> 1) * FB_CBS + 16 + (4 * g + tr_row) * 16 + (tr_c & 1) * 8;
             ltr_x = (4 * g + tr_row) * 32 + tr_c * 8;
         }
-#ifdef FB_PRIOB
-        __builtin_amdgcn_s_setprio(FB_PRIOB);
-#endif
         fb_f32x4 w3[3][3][3], w2[3][3][2], accb[3], acc0 = zero4;
         const int un = min(j / 3, 2), vn = j - 3 * (j / 3);
         const int l0_const = FB_L0C + (j == 9 ? 0 : 128);
@@ -448,9 +444,6 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void enc_bwd_fused_kernel(BwdArgs
             ltr = (tr_c >> 1) * FB_CBS + 16 + (4 * g + tr_row) * 16 + (tr_c & 1) * 8;
             ltr_x = (4 * g + tr_row) * 32 + tr_c * 8;
         }
-#if FB_PRIO
-        __builtin_amdgcn_s_setprio(FB_PRIO);
-#endif
         fb_f32x4 w1[3][3];
 #pragma unroll
         for (int u = 0; u < 3; ++u)
