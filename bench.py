@@ -207,7 +207,9 @@ def conv_rooflines(T, engine, layer, B, S, Wd, dtype, step_ms, workload_id=None)
              "achieved": ach / 1e12, "peak": PEAK_MFMA_BF16 / 1e12, "unit": "TFLOP/s",
              "frac": ach / PEAK_MFMA_BF16, "avg_launch_ms": ms, "launches": len(evs),
              "step_share": ms / step_ms if step_ms else None, "traffic": None,
-             "algorithmic_bytes": float(B) * S * Wd * (sp.cin + sp.cout) * (2 if dtype == "bf16" else 4)}
+             "algorithmic_bytes": float(B) * S * Wd * (sp.cin + sp.cout) * (2 if dtype == "bf16" else 4),
+             "clock_note": "peak is at the nominal 2.4 GHz; s_memtime cycles against wall time put this kernel family at ~1.65 GHz on Gaussian data "
+                           "(power budget) with the matrix pipe busy ~0.65 of the cycles: profiles/r06_ubench_conv_clock.txt, DESIGN.md 4.2"}
         if dtype == "fp32":
             # the split-operand kernels issue products_per_tap half-precision MFMA products per algorithmic fp32 product: `achieved` / `frac`
             # are the EXECUTED matrix work against the dense bf16 MFMA peak (the pipe these kernels run on); the algorithmic fp32 rate is
